@@ -1,0 +1,88 @@
+"""ctypes binding of libhdrsky.so (the C ABI declared in include/hdrsky.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol cannot be
+resolved, importing a kernel raises immediately (the GPU tests must never pass on a silent
+eager/PyTorch path).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhdrsky.so")
+
+c_int, c_float, c_void_p, c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+HDRSKY_BF16, HDRSKY_BF16X3 = 0, 1
+IN_NONE, IN_AFFINE, IN_PARTIALS = 0, 1, 2
+
+
+class ConvDesc(ctypes.Structure):
+    """Mirror of ``hdrsky_conv_desc`` (include/hdrsky.h)."""
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ("B", "H", "W", "Cin", "Ho", "Wo", "Cout", "KH", "KW", "stride", "pad_t", "pad_l",
+                 "upsample", "dilate", "Hc", "Wc", "compute", "in_mode", "ss_bstride", "in_nparts")] + \
+               [("in_eps", c_float), ("in_slope", c_float), ("out_slope", c_float),
+                ("final_relu", ctypes.c_int32), ("want_stats", ctypes.c_int32)]
+
+
+P = c_void_p
+# name -> (restype, argtypes); every symbol include/hdrsky.h declares
+SIGNATURES = {
+    "hdrsky_version": (ctypes.c_char_p, []),
+    "hdrsky_conv_desc_init": (c_int, [ctypes.POINTER(ConvDesc)] + [c_int] * 10),
+    "hdrsky_conv_packed_elems": (c_size_t, [c_int] * 4),
+    "hdrsky_conv_pack_weights": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
+    "hdrsky_conv_stats_nparts": (c_int, [ctypes.POINTER(ConvDesc)]),
+    "hdrsky_conv2d_fwd": (c_int, [ctypes.POINTER(ConvDesc)] + [P] * 13),
+    "hdrsky_norm_apply": (c_int, [P, P, c_int, P, P, c_float, c_float, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "hdrsky_in_finalize": (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_float, P, P, P, P, P]),
+    "hdrsky_bn_eval_affine": (c_int, [P, P, P, P, c_float, c_int, P, P, P]),
+    "hdrsky_norm_act_bwd": (c_int, [P, P, c_int, P, P, c_float, c_float, P, c_int, P, P, c_int, c_int, c_int, c_int, P]),
+    "hdrsky_fc_pack_weights": (c_int, [P, c_int, c_int, P, P, P, P, P]),
+    "hdrsky_fc_nsplit": (c_int, [c_int]),
+    "hdrsky_fc_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "hdrsky_fc_dgrad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "hdrsky_fc_finalize": (c_int, [P, c_int, c_int, c_int, P, c_int, P, P, P]),
+    "hdrsky_softmax_head": (c_int, [P, c_int, c_int, c_int, P, P, P, P, P]),
+    "hdrsky_softmax_pick_bwd": (c_int, [P, P, P, c_int, c_int, P, P, P]),
+    "hdrsky_spatial_sum": (c_int, [P, c_int, c_int, c_int, c_float, P, P]),
+    "hdrsky_grad_cam": (c_int, [P, P, c_int, c_int, c_int, P, P]),
+    "hdrsky_plz_build": (c_int, [P, P, P, P, c_int, c_int, c_int, P, P]),
+    "hdrsky_dense_heads": (c_int, [P, P, P, c_float, c_int, c_int, c_int, P, P, P, P, P, P, P]),
+    "hdrsky_sun_rad": (c_int, [P, P, P, P, c_int, c_int, P, P, P]),
+    "hdrsky_blend": (c_int, [P, P, c_int, c_float, P, P, P, P, P, P]),
+    "hdrsky_tonemap": (c_int, [P, P, c_size_t, c_int, P]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads libhdrsky.so once and types every entry point.  Raises RuntimeError when absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libhdrsky.so not found at %s - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950); there is no CPU/PyTorch fallback for the hot path" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError -> symbol missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class HdrSkyError(RuntimeError):
+    pass
+
+
+_ERR = {-1: "HDRSKY_EINVAL (bad argument / shape)", -2: "HDRSKY_EUNSUPPORTED (configuration not built)",
+        -3: "HDRSKY_ELAUNCH (HIP launch error)"}
+
+
+def check(rc, what):
+    if rc != 0:
+        raise HdrSkyError("%s failed: %s" % (what, _ERR.get(rc, rc)))

@@ -1,0 +1,67 @@
+// Shared device/host helpers for libhdrsky (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hdrsky.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+#define HDRSKY_CHECK_LAUNCH()                                  \
+  do {                                                         \
+    if (hipGetLastError() != hipSuccess) return HDRSKY_ELAUNCH; \
+  } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int roundup(int a, int b) { return cdiv(a, b) * b; }
+
+// fp32 -> bf16 round-to-nearest-even (v_cvt_pk_bf16_f32) and its fp32 residual.
+__device__ __forceinline__ unsigned short f2bf(float x) {
+  __bf16 h = (__bf16)x;
+  return __builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ float bf2f(unsigned short u) {
+  unsigned int v = ((unsigned int)u) << 16;
+  return __builtin_bit_cast(float, v);
+}
+
+// Packs 8 floats into 8 bf16 (hi) and optionally the bf16 of the residuals (lo).
+template <bool PRECISE>
+__device__ __forceinline__ void pack8(const float (&v)[8], uint4& hi, uint4& lo) {
+  unsigned short h[8], l[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    h[j] = f2bf(v[j]);
+    if (PRECISE) l[j] = f2bf(v[j] - bf2f(h[j]));
+  }
+  hi.x = h[0] | ((unsigned)h[1] << 16);
+  hi.y = h[2] | ((unsigned)h[3] << 16);
+  hi.z = h[4] | ((unsigned)h[5] << 16);
+  hi.w = h[6] | ((unsigned)h[7] << 16);
+  if (PRECISE) {
+    lo.x = l[0] | ((unsigned)l[1] << 16);
+    lo.y = l[2] | ((unsigned)l[3] << 16);
+    lo.z = l[4] | ((unsigned)l[5] << 16);
+    lo.w = l[6] | ((unsigned)l[7] << 16);
+  }
+}
+
+__device__ __forceinline__ float leaky(float v, float slope) { return v >= 0.f ? v : v * slope; }
+
+__device__ __forceinline__ f32x4_t mfma16(const uint4& a, const uint4& b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b),
+                                                 c, 0, 0, 0);
+}
+
+// Wave-level sum over the 64 lanes (result in every lane).
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}

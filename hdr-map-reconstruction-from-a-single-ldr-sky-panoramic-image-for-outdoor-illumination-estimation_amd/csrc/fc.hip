@@ -1,0 +1,181 @@
+// Small-M (batch-sized) dense layers of the sun-pose net on the matrix cores: HBM-bound
+// weight streaming.  out[s][m][o] = sum_{r in slice s} x[m][r] * Wop[r][o]
+//   forward  (Keras Dense, sunpose_net.py:48-51,65-68):  r = input feature k, o = unit n,
+//            weights read from the packed image [K/8][N][8] bf16 (8 consecutive k per 16 B)
+//   dgrad    (tf.gradients through Dense, grad_cam.py:31): r = unit n, o = input feature k,
+//            weights read from the natural image [K][N] bf16 (8 consecutive n per 16 B)
+// Both are one kernel with two B-operand address strides.  Each workgroup owns 64 output
+// columns x one reduction slice (split-R for occupancy: 64 column blocks x 4 slices = 256
+// workgroups at N = 4096); weights go HBM -> VGPR directly (streamed once, not shared between
+// waves), activations are staged as bf16 through a double-buffered LDS image shared by the 4 waves.
+#include "common.h"
+
+namespace {
+
+constexpr int RCH = 256;  // reduction elements per chunk (8 k-steps of 32)
+
+template <int MF, bool PRECISE>
+__global__ void __launch_bounds__(256) fc_mfma_kernel(const float* __restrict__ x, const uint4* __restrict__ whi,
+                                                      const uint4* __restrict__ wlo, float* __restrict__ out, int M,
+                                                      int R, int O, int nsplit, long stride_col, long stride_kg) {
+  constexpr int MP = MF * 16;
+  __shared__ uint4 sX[2][PRECISE ? 2 : 1][32 * MP];  // [buf][hi/lo][kgroup(32)][m]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kq = lane >> 4, lr = lane & 15;
+  const int ob = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
+  const int rslice = R / nsplit;
+  const int r0 = sp * rslice;
+  const int nchunks = rslice / RCH;
+  const int col = ob * 64 + wave * 16 + lr;
+  const bool col_ok = col < O;
+  const long wbase = (long)(col_ok ? col : 0) * stride_col;
+
+  f32x4_t acc[MF];
+#pragma unroll
+  for (int i = 0; i < MF; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  auto stage_x = [&](int chunk, int buf) {
+    // items: MP rows x 32 k-groups of 8
+    for (int i = tid; i < MP * 32; i += 256) {
+      const int m = i >> 5, kg = i & 31;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = 0.f;
+      if (m < M) {
+        const float* p = x + (size_t)m * R + r0 + chunk * RCH + kg * 8;
+        const float4 a = *reinterpret_cast<const float4*>(p);
+        const float4 b = *reinterpret_cast<const float4*>(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+      }
+      uint4 hi, lo;
+      pack8<PRECISE>(v, hi, lo);
+      sX[buf][0][kg * MP + m] = hi;
+      if (PRECISE) sX[buf][PRECISE ? 1 : 0][kg * MP + m] = lo;
+    }
+  };
+
+  uint4 bh[8], bl[8];
+  auto load_w = [&](int chunk) {
+    const long kg0 = (long)(r0 + chunk * RCH) / 8;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const long idx = wbase + (kg0 + s * 4 + kq) * stride_kg;
+      bh[s] = whi[idx];
+      if (PRECISE) bl[s] = wlo[idx];
+    }
+  };
+
+  stage_x(0, 0);
+  load_w(0);
+  __syncthreads();
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int buf = ch & 1;
+    uint4 ch_bh[8], ch_bl[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { ch_bh[s] = bh[s]; if (PRECISE) ch_bl[s] = bl[s]; }
+    if (ch + 1 < nchunks) load_w(ch + 1);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        const uint4 ah = sX[buf][0][(s * 4 + kq) * MP + mf * 16 + lr];
+        if (PRECISE) {
+          const uint4 al = sX[buf][PRECISE ? 1 : 0][(s * 4 + kq) * MP + mf * 16 + lr];
+          acc[mf] = mfma16(al, ch_bh[s], acc[mf]);
+          acc[mf] = mfma16(ah, ch_bl[s], acc[mf]);
+        }
+        acc[mf] = mfma16(ah, ch_bh[s], acc[mf]);
+      }
+    }
+    if (ch + 1 < nchunks) stage_x(ch + 1, buf ^ 1);
+    __syncthreads();
+  }
+  if (col_ok) {
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int m = mf * 16 + kq * 4 + j;
+        if (m < M) out[((size_t)sp * M + m) * O + col] = acc[mf][j];
+      }
+  }
+}
+
+// fp32 [K][N] -> packed [K/8][N][8] bf16 (hi/lo) and natural [K][N] bf16 (hi/lo)
+__global__ void fc_pack_kernel(const float* __restrict__ w, int K, int N, unsigned short* __restrict__ pk_hi,
+                               unsigned short* __restrict__ pk_lo, unsigned short* __restrict__ nat_hi,
+                               unsigned short* __restrict__ nat_lo) {
+  const size_t total = (size_t)K * N;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n = i % N;
+    const size_t k = i / N;
+    const float v = w[i];
+    const unsigned short h = f2bf(v);
+    const unsigned short l = f2bf(v - bf2f(h));
+    const size_t pidx = ((k >> 3) * N + n) * 8 + (k & 7);
+    if (pk_hi) pk_hi[pidx] = h;
+    if (pk_lo) pk_lo[pidx] = l;
+    if (nat_hi) nat_hi[i] = h;
+    if (nat_lo) nat_lo[i] = l;
+  }
+}
+
+template <bool PRECISE>
+int launch_fc(const float* x, const void* whi, const void* wlo, float* out, int M, int R, int O, int nsplit,
+              long stride_col, long stride_kg, hipStream_t s) {
+  const int grid = cdiv(O, 64) * nsplit;
+  if (M <= 16)
+    hipLaunchKernelGGL((fc_mfma_kernel<1, PRECISE>), dim3(grid), dim3(256), 0, s, x, (const uint4*)whi,
+                       (const uint4*)wlo, out, M, R, O, nsplit, stride_col, stride_kg);
+  else
+    hipLaunchKernelGGL((fc_mfma_kernel<2, PRECISE>), dim3(grid), dim3(256), 0, s, x, (const uint4*)whi,
+                       (const uint4*)wlo, out, M, R, O, nsplit, stride_col, stride_kg);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hdrsky_fc_pack_weights(const float* w, int K, int N, void* packed_hi, void* packed_lo, void* natural_hi,
+                           void* natural_lo, void* stream) {
+  if (!w || (K & 7) || (N & 7)) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(fc_pack_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, w, K, N,
+                     (unsigned short*)packed_hi, (unsigned short*)packed_lo, (unsigned short*)natural_hi,
+                     (unsigned short*)natural_lo);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_fc_nsplit(int R) {
+  int ns = 4;
+  while (ns > 1 && (R % (ns * RCH)) != 0) ns >>= 1;
+  return ns;
+}
+
+// forward: out_part[nsplit][M][N] = x[M][K] @ W[K][N]   (bias / activation: hdrsky_fc_finalize or hdrsky_softmax_head)
+int hdrsky_fc_fwd(const float* x, const void* packed_hi, const void* packed_lo, int M, int K, int N, int nsplit,
+                  int compute, float* out_part, void* stream) {
+  if (!x || !packed_hi || !out_part || M <= 0 || M > 32 || nsplit <= 0 || (K % (nsplit * RCH)) != 0 || (N & 7))
+    return HDRSKY_EINVAL;
+  if (compute == HDRSKY_BF16X3) {
+    if (!packed_lo) return HDRSKY_EINVAL;
+    return launch_fc<true>(x, packed_hi, packed_lo, out_part, M, K, N, nsplit, 1, N, (hipStream_t)stream);
+  }
+  return launch_fc<false>(x, packed_hi, nullptr, out_part, M, K, N, nsplit, 1, N, (hipStream_t)stream);
+}
+
+// data gradient: dx_part[nsplit][M][K] = dy[M][N] @ W[K][N]^T   (weights in the natural bf16 image)
+int hdrsky_fc_dgrad(const float* dy, const void* natural_hi, const void* natural_lo, int M, int K, int N, int nsplit,
+                    int compute, float* dx_part, void* stream) {
+  if (!dy || !natural_hi || !dx_part || M <= 0 || M > 32 || nsplit <= 0 || (N % (nsplit * RCH)) != 0 || (K & 7))
+    return HDRSKY_EINVAL;
+  if (compute == HDRSKY_BF16X3) {
+    if (!natural_lo) return HDRSKY_EINVAL;
+    return launch_fc<true>(dy, natural_hi, natural_lo, dx_part, M, N, K, nsplit, N / 8, 1, (hipStream_t)stream);
+  }
+  return launch_fc<false>(dy, natural_hi, nullptr, dx_part, M, N, K, nsplit, N / 8, 1, (hipStream_t)stream);
+}
+
+}  // extern "C"

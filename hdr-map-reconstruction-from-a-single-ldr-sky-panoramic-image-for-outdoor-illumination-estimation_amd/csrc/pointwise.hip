@@ -1,0 +1,652 @@
+// HBM/L2-bound kernels around the convolutions: InstanceNorm finalise / apply (+activation,
+// residual, 2x2 max-pool), their backward (Grad-CAM sweep and training), soft-max and its
+// picked-probability backward, Grad-CAM maps, the sun-radiance Dirac-delta head, tone mapping
+// and alpha blending.  All fp32; float4 (16 B / lane) accesses; wave64 shuffles for reductions.
+#include "common.h"
+
+namespace {
+
+// InstanceNorm scale/shift for sample b from the producer conv's per-tile (sum, sumsq)
+// partials [B][nparts][2][C] - identical summation order to conv_igemm's prologue.
+__device__ __forceinline__ void in_tables_from_partials(const float* __restrict__ part, int b, int nparts, int C,
+                                                        float inv_count, const float* gamma, const float* beta,
+                                                        float eps, float* sScale, float* sShift, float* sMean,
+                                                        float* sInv) {
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f, ss = 0.f;
+    const float* pp = part + (size_t)b * nparts * 2 * C + c;
+    for (int p = 0; p < nparts; ++p) {
+      s += pp[(2 * p) * C];
+      ss += pp[(2 * p + 1) * C];
+    }
+    const float mean = s * inv_count;
+    const float var = fmaxf(ss * inv_count - mean * mean, 0.f);
+    const float rstd = 1.f / sqrtf(var + eps);
+    const float inv = gamma[c] * rstd;
+    sScale[c] = inv;
+    sShift[c] = beta[c] - mean * inv;
+    if (sMean) { sMean[c] = mean; sInv[c] = rstd; }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// y = leaky(IN(x)) [+ residual]; optional 2x2/2 max-pool of y.   generator.py:26-35,98-106 ;
+// sunpose_net.py:20-30,55-62 (ops.maxpool2d ops.py:299-300)
+// grid = B * S blocks; block handles a contiguous range of 2x2 windows (pool) or pixels.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) norm_apply_kernel(const float* __restrict__ x, const float* __restrict__ part,
+                                                         int nparts, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps, float slope,
+                                                         const float* __restrict__ residual, float* __restrict__ y,
+                                                         float* __restrict__ ypool, int B, int H, int W, int C, int S) {
+  extern __shared__ float sm[];
+  float* sScale = sm;
+  float* sShift = sm + C;
+  const int b = blockIdx.x / S, s = blockIdx.x % S;
+  in_tables_from_partials(part, b, nparts, C, 1.f / (float)(H * W), gamma, beta, eps, sScale, sShift, nullptr, nullptr);
+  __syncthreads();
+  const int c4 = C >> 2;
+  const float* xb = x + (size_t)b * H * W * C;
+  float* yb = y + (size_t)b * H * W * C;
+  const float* rb = residual ? residual + (size_t)b * H * W * C : nullptr;
+  if (ypool == nullptr) {
+    const int total = H * W * c4;
+    const int per = (total + S - 1) / S;
+    const int end = min(total, (s + 1) * per);
+    for (int i = s * per + threadIdx.x; i < end; i += 256) {
+      const int c = (i % c4) * 4;
+      float4 v = reinterpret_cast<const float4*>(xb)[i];
+      v.x = leaky(v.x * sScale[c] + sShift[c], slope);
+      v.y = leaky(v.y * sScale[c + 1] + sShift[c + 1], slope);
+      v.z = leaky(v.z * sScale[c + 2] + sShift[c + 2], slope);
+      v.w = leaky(v.w * sScale[c + 3] + sShift[c + 3], slope);
+      if (rb) {
+        const float4 r = reinterpret_cast<const float4*>(rb)[i];
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+      }
+      reinterpret_cast<float4*>(yb)[i] = v;
+    }
+  } else {
+    const int Hp = H >> 1, Wp = W >> 1;
+    float* pb = ypool + (size_t)b * Hp * Wp * C;
+    const int total = Hp * Wp * c4;
+    const int per = (total + S - 1) / S;
+    const int end = min(total, (s + 1) * per);
+    for (int i = s * per + threadIdx.x; i < end; i += 256) {
+      const int cq = i % c4, pw = (i / c4) % Wp, ph = i / (c4 * Wp);
+      const int c = cq * 4;
+      float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          const size_t idx = ((size_t)(2 * ph + dy) * W + (2 * pw + dx)) * c4 + cq;
+          float4 v = reinterpret_cast<const float4*>(xb)[idx];
+          v.x = leaky(v.x * sScale[c] + sShift[c], slope);
+          v.y = leaky(v.y * sScale[c + 1] + sShift[c + 1], slope);
+          v.z = leaky(v.z * sScale[c + 2] + sShift[c + 2], slope);
+          v.w = leaky(v.w * sScale[c + 3] + sShift[c + 3], slope);
+          if (rb) {
+            const float4 r = reinterpret_cast<const float4*>(rb)[idx];
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+          }
+          reinterpret_cast<float4*>(yb)[idx] = v;
+          m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        }
+      reinterpret_cast<float4*>(pb)[i] = m;
+    }
+  }
+}
+
+// mean / rstd / scale / shift tables [B][C] (needed by backward kernels and host-side checks)
+__global__ void in_finalize_kernel(const float* __restrict__ part, int nparts, int B, int C, float inv_count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                   float* mean, float* rstd, float* scale, float* shift) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i % C;
+  float s = 0.f, ss = 0.f;
+  const float* pp = part + (size_t)b * nparts * 2 * C + c;
+  for (int p = 0; p < nparts; ++p) { s += pp[(2 * p) * C]; ss += pp[(2 * p + 1) * C]; }
+  const float m = s * inv_count;
+  const float var = fmaxf(ss * inv_count - m * m, 0.f);
+  const float r = 1.f / sqrtf(var + eps);
+  if (mean) mean[i] = m;
+  if (rstd) rstd[i] = r;
+  const float inv = gamma[c] * r;
+  if (scale) scale[i] = inv;
+  if (shift) shift[i] = beta[c] - m * inv;
+}
+
+// Keras BatchNormalization inference-mode affine: scale = gamma*rsqrt(mv+eps), shift = beta - mm*scale
+__global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* mm, const float* mv,
+                                      float eps, int C, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float inv = gamma[c] / sqrtf(mv[c] + eps);
+  scale[c] = inv;
+  shift[c] = beta[c] - mm[c] * inv;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward of y = leaky(IN(x)) (optionally followed by the 2x2 max-pool), data gradient only:
+//   g  = upstream routed through pool-argmax (first max in scan order) and the activation mask
+//   dx = gamma*rstd * (g - mean_hw(g) - xhat*mean_hw(g*xhat))
+// One block per (sample, 16-channel group); two passes over the group's H*W*16 values (L2-resident).
+// Also returns per-(b,c) sums (sum g, sum g*xhat) = (dbeta, dgamma) contributions when requested.
+// Used by the Grad-CAM sweep (grad_cam.py:31 tf.gradients through sunpose_net.py:20-30,55-62).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) norm_act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ part,
+                                                           int nparts, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, float slope,
+                                                           const float* __restrict__ dy, int pooled,
+                                                           float* __restrict__ dx, float* __restrict__ sums, int B,
+                                                           int H, int W, int C) {
+  __shared__ float sRed[64][2][16];
+  __shared__ float sM[2][16];
+  const int groups = C >> 4;
+  const int b = blockIdx.x / groups, cg = blockIdx.x % groups;
+  const int cl = (threadIdx.x & 3) * 4;      // channel offset inside the group (float4)
+  const int slot = threadIdx.x >> 2;         // 64 pixel slots
+  const int c = cg * 16 + cl;
+  // per-channel constants (4 channels per thread)
+  float mean[4], rstd[4], gm[4], bt[4];
+  {
+    const float inv_count = 1.f / (float)(H * W);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float s = 0.f, ss = 0.f;
+      const float* pp = part + (size_t)b * nparts * 2 * C + c + j;
+      for (int p = 0; p < nparts; ++p) { s += pp[(2 * p) * C]; ss += pp[(2 * p + 1) * C]; }
+      mean[j] = s * inv_count;
+      const float var = fmaxf(ss * inv_count - mean[j] * mean[j], 0.f);
+      rstd[j] = 1.f / sqrtf(var + eps);
+      gm[j] = gamma[c + j];
+      bt[j] = beta[c + j];
+    }
+  }
+  const float* xb = x + (size_t)b * H * W * C + c;
+  float* dxb = dx + (size_t)b * H * W * C + c;
+  const int Hp = H >> 1, Wp = W >> 1;
+  const float* dyb = dy + (size_t)b * (pooled ? Hp * Wp : H * W) * C + c;
+
+  auto grad_at = [&](int pix, const float4& xv, float (&xh)[4], float (&g)[4], const float4& up) {
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+    const float us[4] = {up.x, up.y, up.z, up.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      xh[j] = (xs[j] - mean[j]) * rstd[j];
+      const float pre = xh[j] * gm[j] + bt[j];
+      g[j] = us[j] * (pre > 0.f ? 1.f : slope);
+    }
+    (void)pix;
+  };
+
+  float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  for (int pass = 0; pass < 2; ++pass) {
+    if (!pooled) {
+      for (int p = slot; p < H * W; p += 64) {
+        const float4 xv = *reinterpret_cast<const float4*>(xb + (size_t)p * C);
+        const float4 up = *reinterpret_cast<const float4*>(dyb + (size_t)p * C);
+        float xh[4], g[4];
+        grad_at(p, xv, xh, g, up);
+        if (pass == 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { s1[j] += g[j]; s2[j] += g[j] * xh[j]; }
+        } else {
+          float4 o;
+          o.x = gm[0] * rstd[0] * (g[0] - s1[0] - xh[0] * s2[0]);
+          o.y = gm[1] * rstd[1] * (g[1] - s1[1] - xh[1] * s2[1]);
+          o.z = gm[2] * rstd[2] * (g[2] - s1[2] - xh[2] * s2[2]);
+          o.w = gm[3] * rstd[3] * (g[3] - s1[3] - xh[3] * s2[3]);
+          *reinterpret_cast<float4*>(dxb + (size_t)p * C) = o;
+        }
+      }
+    } else {
+      for (int pw = slot; pw < Hp * Wp; pw += 64) {
+        const int ph = pw / Wp, px = pw % Wp;
+        const float4 up = *reinterpret_cast<const float4*>(dyb + (size_t)pw * C);
+        const float us[4] = {up.x, up.y, up.z, up.w};
+        float4 xv[4];
+        float act[4][4], xh[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int p = (2 * ph + (k >> 1)) * W + 2 * px + (k & 1);
+          xv[k] = *reinterpret_cast<const float4*>(xb + (size_t)p * C);
+          const float xs[4] = {xv[k].x, xv[k].y, xv[k].z, xv[k].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            xh[k][j] = (xs[j] - mean[j]) * rstd[j];
+            act[k][j] = leaky(xh[k][j] * gm[j] + bt[j], slope);
+          }
+        }
+        float g[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int am = 0;
+          float best = act[0][j];
+#pragma unroll
+          for (int k = 1; k < 4; ++k)
+            if (act[k][j] > best) { best = act[k][j]; am = k; }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float pre = xh[k][j] * gm[j] + bt[j];
+            g[k][j] = (k == am) ? us[j] * (pre > 0.f ? 1.f : slope) : 0.f;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (pass == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s1[j] += g[k][j]; s2[j] += g[k][j] * xh[k][j]; }
+          } else {
+            const int p = (2 * ph + (k >> 1)) * W + 2 * px + (k & 1);
+            float4 o;
+            o.x = gm[0] * rstd[0] * (g[k][0] - s1[0] - xh[k][0] * s2[0]);
+            o.y = gm[1] * rstd[1] * (g[k][1] - s1[1] - xh[k][1] * s2[1]);
+            o.z = gm[2] * rstd[2] * (g[k][2] - s1[2] - xh[k][2] * s2[2]);
+            o.w = gm[3] * rstd[3] * (g[k][3] - s1[3] - xh[k][3] * s2[3]);
+            *reinterpret_cast<float4*>(dxb + (size_t)p * C) = o;
+          }
+        }
+      }
+    }
+    if (pass == 0) {
+      // block reduction over the 64 pixel slots (fixed order -> deterministic)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { sRed[slot][0][cl + j] = s1[j]; sRed[slot][1][cl + j] = s2[j]; }
+      __syncthreads();
+      if (threadIdx.x < 32) {
+        const int which = threadIdx.x >> 4, ch = threadIdx.x & 15;
+        float t = 0.f;
+        for (int k = 0; k < 64; ++k) t += sRed[k][which][ch];
+        sM[which][ch] = t;
+        if (sums) sums[((size_t)b * C + cg * 16 + ch) * 2 + which] = t;
+      }
+      __syncthreads();
+      const float inv_count = 1.f / (float)(H * W);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s1[j] = sM[0][cl + j] * inv_count; s2[j] = sM[1][cl + j] * inv_count; }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// soft-max head of the sun-pose net (sunpose_net.py:64-70): z = relu(sum_s part[s] + bias),
+// cmf = softmax(z); also the running global max of cmf (generator.py:160 reduce_max over the
+// whole batch tensor) via an order-independent integer atomicMax on the (positive) float bits.
+// One block per row.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) softmax_head_kernel(const float* __restrict__ part, int nsplit, int M, int N,
+                                                           const float* __restrict__ bias, float* __restrict__ z,
+                                                           float* __restrict__ cmf, unsigned int* gmax_bits) {
+  __shared__ float sred[4];
+  const int m = blockIdx.x;
+  extern __shared__ float srow[];  // N floats
+  float lmax = -INFINITY;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    float v = bias ? bias[n] : 0.f;
+    for (int s = 0; s < nsplit; ++s) v += part[((size_t)s * M + m) * N + n];
+    v = fmaxf(v, 0.f);
+    srow[n] = v;
+    if (z) z[(size_t)m * N + n] = v;
+    lmax = fmaxf(lmax, v);
+  }
+  lmax = wave_max(lmax);
+  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = lmax;
+  __syncthreads();
+  const float rmax = fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3]));
+  __syncthreads();
+  float lsum = 0.f;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    const float e = expf(srow[n] - rmax);
+    srow[n] = e;
+    lsum += e;
+  }
+  lsum = wave_sum(lsum);
+  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = lsum;
+  __syncthreads();
+  const float rsum = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+  float pmax = 0.f;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    const float p = srow[n] / rsum;
+    cmf[(size_t)m * N + n] = p;
+    pmax = fmaxf(pmax, p);
+  }
+  if (gmax_bits) {
+    pmax = wave_max(pmax);
+    if ((threadIdx.x & 63) == 0) atomicMax(gmax_bits, __float_as_uint(pmax));
+  }
+}
+
+// d y_c / d z for y_c = cmf[m, idx_m] through softmax and the relu in front of it:
+//   dz_j = y_c * ((j == idx) - cmf_j) * [z_j > 0]
+// idx_m = first argmax of pick_src[m, :] (cmf itself at inference, inference.py:98;
+// sunpose_gt in training, train.py:265-267).
+__global__ void __launch_bounds__(256) softmax_pick_bwd_kernel(const float* __restrict__ cmf,
+                                                               const float* __restrict__ z,
+                                                               const float* __restrict__ pick_src, int N,
+                                                               float* __restrict__ dz, int* __restrict__ idx_out) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  const int m = blockIdx.x;
+  const float* pr = pick_src + (size_t)m * N;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    const float v = pr[n];
+    if (v > best) { best = v; bi = n; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o);
+    const int oi = __shfl_xor(bi, o);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
+  __syncthreads();
+  best = sv[0]; bi = si[0];
+  for (int w = 1; w < 4; ++w)
+    if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+  const float yc = cmf[(size_t)m * N + bi];
+  if (threadIdx.x == 0 && idx_out) idx_out[m] = bi;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    const float p = cmf[(size_t)m * N + n];
+    const float g = yc * ((n == bi ? 1.f : 0.f) - p);
+    dz[(size_t)m * N + n] = z[(size_t)m * N + n] > 0.f ? g : 0.f;
+  }
+}
+
+// y[m][n] = (sum_s part[s][m][n] + bias[n]) with optional relu and optional mask [mask_src > 0]
+__global__ void fc_finalize_kernel(const float* __restrict__ part, int nsplit, int M, int N,
+                                   const float* __restrict__ bias, int relu, const float* __restrict__ mask_src,
+                                   float* __restrict__ y) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * N) return;
+  float v = bias ? bias[i % N] : 0.f;
+  for (int s = 0; s < nsplit; ++s) v += part[(size_t)s * M * N + i];
+  if (relu) v = fmaxf(v, 0.f);
+  if (mask_src) v = mask_src[i] > 0.f ? v : 0.f;
+  y[i] = v;
+}
+
+// out[b][c] = scale * sum_p x[b][p][c]     (GAP of the Grad-CAM gradient, grad_cam.py:34)
+__global__ void __launch_bounds__(256) spatial_sum_kernel(const float* __restrict__ x, int P, int C, float scale,
+                                                          float* __restrict__ out) {
+  __shared__ float sred[256];
+  const int b = blockIdx.x;
+  const int c = threadIdx.x % C;           // C in {32,64,128} divides 256
+  const int lanes_p = 256 / C;
+  const int p0 = threadIdx.x / C;
+  float s = 0.f;
+  for (int p = p0; p < P; p += lanes_p) s += x[((size_t)b * P + p) * C + c];
+  sred[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    float t = 0.f;
+    for (int k = 0; k < lanes_p; ++k) t += sred[k * C + threadIdx.x];
+    out[(size_t)b * C + threadIdx.x] = t * scale;
+  }
+}
+
+// cam[b][p] = relu(sum_c w[b][c] * A[b][p][c])   (grad_cam.py:35-38); one wave per pixel group
+__global__ void __launch_bounds__(256) cam_kernel(const float* __restrict__ A, const float* __restrict__ w, int P,
+                                                  int C, float* __restrict__ cam) {
+  extern __shared__ float sw[];
+  const int b = blockIdx.y;
+  for (int c = threadIdx.x; c < C; c += 256) sw[c] = w[(size_t)b * C + c];
+  __syncthreads();
+  const int c4 = C >> 2;                    // threads per pixel
+  const int ppb = 256 / c4;                 // pixels per block iteration
+  const int sub = threadIdx.x % c4, pl = threadIdx.x / c4;
+  for (int p = blockIdx.x * ppb + pl; p < P; p += gridDim.x * ppb) {
+    const float4 v = *reinterpret_cast<const float4*>(A + ((size_t)b * P + p) * C + sub * 4);
+    float s = v.x * sw[sub * 4] + v.y * sw[sub * 4 + 1] + v.z * sw[sub * 4 + 2] + v.w * sw[sub * 4 + 3];
+    for (int o = c4 >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (sub == 0) cam[(size_t)b * P + p] = fmaxf(s, 0.f);
+  }
+}
+
+__device__ __forceinline__ float bilinear_1ch(const float* __restrict__ src, int h, int w, int oy, int ox, int OH,
+                                              int OW) {
+  const float sy = (oy + 0.5f) * ((float)h / (float)OH) - 0.5f, sx = (ox + 0.5f) * ((float)w / (float)OW) - 0.5f;
+  const float fy = floorf(sy), fx = floorf(sx);
+  const int ylo = max((int)fy, 0), yhi = min((int)ceilf(sy), h - 1);
+  const int xlo = max((int)fx, 0), xhi = min((int)ceilf(sx), w - 1);
+  const float ly = sy - fy, lx = sx - fx;
+  const float tl = src[ylo * w + xlo], tr = src[ylo * w + xhi], bl = src[yhi * w + xlo], br = src[yhi * w + xhi];
+  const float top = tl + (tr - tl) * lx, bot = bl + (br - bl) * lx;
+  return top + (bot - top) * ly;
+}
+
+// plz = concat(ldr, cam1, resize(cam2), resize(cam3))  (generator.py:161-164)
+__global__ void plz_kernel(const float* __restrict__ ldr, const float* __restrict__ cam1,
+                           const float* __restrict__ cam2, const float* __restrict__ cam3, int B, int H, int W,
+                           float* __restrict__ plz) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * H * W) return;
+  const int b = i / (H * W), p = i % (H * W), oy = p / W, ox = p % W;
+  float* o = plz + (size_t)i * 6;
+  o[0] = ldr[(size_t)i * 3]; o[1] = ldr[(size_t)i * 3 + 1]; o[2] = ldr[(size_t)i * 3 + 2];
+  o[3] = cam1[i];
+  o[4] = bilinear_1ch(cam2 + (size_t)b * (H / 2) * (W / 2), H / 2, W / 2, oy, ox, H, W);
+  o[5] = bilinear_1ch(cam3 + (size_t)b * (H / 4) * (W / 4), H / 4, W / 4, oy, ox, H, W);
+}
+
+// gamma/beta heads of sunRadNet (sunrad_net.py:52-59): flat = leaky(x*scale[c]+shift[c], slope),
+// out = sigmoid(flat . k + bias) for the two Dense(1) layers.  One block per sample.
+__global__ void __launch_bounds__(256) dense_heads_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, float slope, int F, int C,
+                                                          const float* __restrict__ kg, const float* __restrict__ bg,
+                                                          const float* __restrict__ kb, const float* __restrict__ bb,
+                                                          float* __restrict__ gamma_out, float* __restrict__ beta_out) {
+  __shared__ float sred[2][4];
+  const int b = blockIdx.x;
+  float sg = 0.f, sb = 0.f;
+  for (int i = threadIdx.x; i < F; i += 256) {
+    const int c = i % C;
+    float v = x[(size_t)b * F + i];
+    if (scale) v = v * scale[c] + shift[c];
+    v = leaky(v, slope);
+    sg += v * kg[i];
+    sb += v * kb[i];
+  }
+  sg = wave_sum(sg); sb = wave_sum(sb);
+  if ((threadIdx.x & 63) == 0) { sred[0][threadIdx.x >> 6] = sg; sred[1][threadIdx.x >> 6] = sb; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float g = (sred[0][0] + sred[0][1]) + (sred[0][2] + sred[0][3]) + bg[0];
+    const float t = (sred[1][0] + sred[1][1]) + (sred[1][2] + sred[1][3]) + bb[0];
+    gamma_out[b] = 1.f / (1.f + expf(-g));
+    beta_out[b] = 1.f / (1.f + expf(-t));
+  }
+}
+
+// Dirac-delta sun radiance (sunrad_net.py:61-69 + generator.py:160,167 + tf_utils.py:263-271):
+//   x = cmf / max(cmf); rad = min(gamma*exp(-(1-x)^2/(beta+1e-5)) / (beta*sqrt(pi)+1e-5), 30000)
+// writes rad tiled to 3 channels and its log-compressed (gamma-domain) image.
+__global__ void sun_rad_kernel(const float* __restrict__ cmf, const unsigned int* __restrict__ gmax_bits,
+                               const float* __restrict__ gamma, const float* __restrict__ beta, int B, int P,
+                               float* __restrict__ rad_lin3, float* __restrict__ rad_gamma3) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * P) return;
+  const int b = i / P;
+  const float gmax = __uint_as_float(*gmax_bits);
+  const float x = cmf[i] / gmax;
+  const float g = gamma[b], bt = beta[b];
+  const float d = 1.f - x;
+  float r = expf(-(d * d) / (bt + 1e-5f)) * g;
+  r = r / (bt * 1.7724539f + 1e-5f);  // float32(sqrt(float32(pi)))
+  r = r > 30000.f ? 30000.f : r;
+  const float rg = logf(1.f + 10.f * r) / 2.3978953f;  // log(11)
+  rad_lin3[(size_t)i * 3] = r; rad_lin3[(size_t)i * 3 + 1] = r; rad_lin3[(size_t)i * 3 + 2] = r;
+  rad_gamma3[(size_t)i * 3] = rg; rad_gamma3[(size_t)i * 3 + 1] = rg; rad_gamma3[(size_t)i * 3 + 2] = rg;
+}
+
+__device__ __forceinline__ float log_decomp(float x) { return (expf(x * 2.3978953f) - 1.f) / 10.f; }
+
+// alpha mask + blending (inference.py:91-94,109-113 ; train.py:258-261,293-299 ; generator.py:171-175)
+__global__ void blend_kernel(const float* __restrict__ sky_gamma, const float* __restrict__ sun_gamma, int npix,
+                             float thr, float* __restrict__ y_gamma, float* __restrict__ y_lin,
+                             float* __restrict__ alpha, float* __restrict__ sky_lin, float* __restrict__ sun_lin) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix) return;
+  float sk[3], su[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { sk[c] = sky_gamma[(size_t)i * 3 + c]; su[c] = sun_gamma[(size_t)i * 3 + c]; }
+  const float m = fmaxf(fmaxf(log_decomp(sk[0]), log_decomp(sk[1])), log_decomp(sk[2]));
+  const float a = fminf(1.f, fmaxf(0.f, m - 1.f + thr) / thr);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float s = (1.f - a) * sk[c], u = a * su[c];
+    const float yg = s + u;
+    y_gamma[(size_t)i * 3 + c] = yg;
+    y_lin[(size_t)i * 3 + c] = log_decomp(yg);
+    if (alpha) alpha[(size_t)i * 3 + c] = a;
+    if (sky_lin) sky_lin[(size_t)i * 3 + c] = log_decomp(s);
+    if (sun_lin) sun_lin[(size_t)i * 3 + c] = log_decomp(u);
+  }
+}
+
+// tf_utils.hdr_logCompression / hdr_logDecompression (tf_utils.py:263-280), validDR = 10
+__global__ void tonemap_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, int decompress) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    y[i] = decompress ? log_decomp(v) : logf(1.f + 10.f * v) / 2.3978953f;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int hdrsky_norm_apply(const float* x, const float* part, int nparts, const float* gamma, const float* beta, float eps,
+                      float slope, const float* residual, float* y, float* ypool, int B, int H, int W, int C,
+                      void* stream) {
+  if (!x || !part || !gamma || !beta || !y || (C & 3) || C > 1024) return HDRSKY_EINVAL;
+  if (ypool && ((H | W) & 1)) return HDRSKY_EINVAL;
+  int S = 256 / B; if (S < 1) S = 1; if (S > 64) S = 64;
+  hipLaunchKernelGGL(norm_apply_kernel, dim3(B * S), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream, x, part,
+                     nparts, gamma, beta, eps, slope, residual, y, ypool, B, H, W, C, S);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_in_finalize(const float* part, int nparts, int B, int C, int count, const float* gamma, const float* beta,
+                       float eps, float* mean, float* rstd, float* scale, float* shift, void* stream) {
+  if (!part || !gamma || !beta) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(in_finalize_kernel, dim3(cdiv(B * C, 256)), dim3(256), 0, (hipStream_t)stream, part, nparts, B, C,
+                     1.f / (float)count, gamma, beta, eps, mean, rstd, scale, shift);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_bn_eval_affine(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var,
+                          float eps, int C, float* scale, float* shift, void* stream) {
+  if (!gamma || !beta || !moving_mean || !moving_var || !scale || !shift) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta,
+                     moving_mean, moving_var, eps, C, scale, shift);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_norm_act_bwd(const float* x, const float* part, int nparts, const float* gamma, const float* beta,
+                        float eps, float slope, const float* dy, int pooled, float* dx, float* sums, int B, int H,
+                        int W, int C, void* stream) {
+  if (!x || !part || !gamma || !beta || !dy || !dx || (C & 15)) return HDRSKY_EINVAL;
+  if (pooled && ((H | W) & 1)) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(norm_act_bwd_kernel, dim3(B * (C / 16)), dim3(256), 0, (hipStream_t)stream, x, part, nparts,
+                     gamma, beta, eps, slope, dy, pooled, dx, sums, B, H, W, C);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_softmax_head(const float* part, int nsplit, int M, int N, const float* bias, float* z, float* cmf,
+                        void* gmax_bits, void* stream) {
+  if (!part || !cmf || N * (int)sizeof(float) > 60 * 1024) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(softmax_head_kernel, dim3(M), dim3(256), N * sizeof(float), (hipStream_t)stream, part, nsplit, M,
+                     N, bias, z, cmf, (unsigned int*)gmax_bits);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_softmax_pick_bwd(const float* cmf, const float* z, const float* pick_src, int M, int N, float* dz,
+                            int* idx_out, void* stream) {
+  if (!cmf || !z || !pick_src || !dz) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(softmax_pick_bwd_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, cmf, z, pick_src, N, dz,
+                     idx_out);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_fc_finalize(const float* part, int nsplit, int M, int N, const float* bias, int relu, const float* mask_src,
+                       float* y, void* stream) {
+  if (!part || !y) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(fc_finalize_kernel, dim3(cdiv(M * N, 256)), dim3(256), 0, (hipStream_t)stream, part, nsplit, M, N,
+                     bias, relu, mask_src, y);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_spatial_sum(const float* x, int B, int P, int C, float scale, float* out, void* stream) {
+  if (!x || !out || C > 256 || (256 % C) != 0) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(spatial_sum_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, P, C, scale, out);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_grad_cam(const float* A, const float* w, int B, int P, int C, float* cam, void* stream) {
+  if (!A || !w || !cam || (C & 3) || C > 256 || (256 % (C / 4)) != 0) return HDRSKY_EINVAL;
+  const int ppb = 256 / (C / 4);
+  int gx = cdiv(P, ppb); if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(cam_kernel, dim3(gx, B), dim3(256), C * sizeof(float), (hipStream_t)stream, A, w, P, C, cam);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_plz_build(const float* ldr, const float* cam1, const float* cam2, const float* cam3, int B, int H, int W,
+                     float* plz, void* stream) {
+  if (!ldr || !cam1 || !cam2 || !cam3 || !plz || (H & 3) || (W & 3)) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(plz_kernel, dim3(cdiv(B * H * W, 256)), dim3(256), 0, (hipStream_t)stream, ldr, cam1, cam2, cam3,
+                     B, H, W, plz);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_dense_heads(const float* x, const float* scale, const float* shift, float slope, int B, int F, int C,
+                       const float* kg, const float* bg, const float* kb, const float* bb, float* gamma_out,
+                       float* beta_out, void* stream) {
+  if (!x || !kg || !bg || !kb || !bb || !gamma_out || !beta_out) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(dense_heads_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, scale, shift, slope, F, C, kg,
+                     bg, kb, bb, gamma_out, beta_out);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_sun_rad(const float* cmf, const void* gmax_bits, const float* gamma, const float* beta, int B, int P,
+                   float* rad_lin3, float* rad_gamma3, void* stream) {
+  if (!cmf || !gmax_bits || !gamma || !beta || !rad_lin3 || !rad_gamma3) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(sun_rad_kernel, dim3(cdiv(B * P, 256)), dim3(256), 0, (hipStream_t)stream, cmf,
+                     (const unsigned int*)gmax_bits, gamma, beta, B, P, rad_lin3, rad_gamma3);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_blend(const float* sky_gamma, const float* sun_gamma, int npix, float thr, float* y_gamma, float* y_lin,
+                 float* alpha, float* sky_lin, float* sun_lin, void* stream) {
+  if (!sky_gamma || !sun_gamma || !y_gamma || !y_lin) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(blend_kernel, dim3(cdiv(npix, 256)), dim3(256), 0, (hipStream_t)stream, sky_gamma, sun_gamma, npix,
+                     thr, y_gamma, y_lin, alpha, sky_lin, sun_lin);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_tonemap(const float* x, float* y, size_t n, int decompress, void* stream) {
+  if (!x || !y) return HDRSKY_EINVAL;
+  size_t g = (n + 255) / 256; if (g > 2048) g = 2048; if (g < 1) g = 1;
+  hipLaunchKernelGGL(tonemap_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, y, n, decompress);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+}  // extern "C"

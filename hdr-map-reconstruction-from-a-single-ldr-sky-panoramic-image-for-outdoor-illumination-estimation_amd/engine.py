@@ -1,0 +1,181 @@
+"""Fused execution plan of the generator graph on libhdrsky (inference.py:81-115, train.py:239-299).
+
+The reference runs ~250 TF ops per forward (conv, bias, moments, normalise, activation, resize,
+gather ... each its own kernel).  Here the same arithmetic is ~70 launches:
+  * every InstanceNorm is split into (a) the producing conv's epilogue, which writes per-tile
+    (sum, sumsq) partials, and (b) the consuming conv's operand load, which finalises the
+    statistics and applies normalise + activation while staging its halo tile into LDS;
+  * the resize-deconv's bilinear 2x resize happens in that same operand load;
+  * the three `tf.gradients` sweeps of Grad-CAM are one shared backward sweep that stops at
+    pool1's input (only the spatial MEANS of the activation gradients are needed, and the mean of a
+    max-pool's input gradient equals the sum of its output gradient / (H*W)).
+The whole sequence is enqueued on one HIP stream and is capturable into a hipGraph (no host
+synchronisation, no allocation outside torch's caching allocator).
+"""
+from collections import OrderedDict
+
+import torch
+
+from . import _lib as L
+from . import kernels as K
+from .kernels import BF16, BF16X3, InXf, PackedConv, PackedFC
+
+THRESHOLD = 0.12  # inference.py:36 / train.py:247
+
+
+def _dev(params, device):
+    return OrderedDict((k, torch.as_tensor(v).to(device=device, dtype=torch.float32).contiguous())
+                       for k, v in params.items())
+
+
+class Nets:
+    """Device-resident parameters + packed MFMA weight images of the generator (incl. sunRadNet)
+    and the sun-pose net."""
+
+    def __init__(self, gen_params, sun_params, device="cuda", precise=True, im_height=32, im_width=128):
+        self.device = torch.device(device)
+        self.h, self.w = im_height, im_width
+        self.precise = precise
+        self.gen = _dev(gen_params, self.device)
+        self.sun = _dev(sun_params, self.device)
+        self.pk = {}
+        self.repack_all()
+
+    def repack_all(self):
+        g, s = self.gen, self.sun
+        pk = self.pk
+        for name in ["conv1_d", "conv2_d", "conv3_d", "conv1_f", "conv1_u"] + \
+                    ["res.%d.conv%d" % (i, j) for i in range(6) for j in (1, 2)]:
+            pk["gen." + name] = PackedConv(g[name + ".w"], self.precise)
+        for name in ("conv3_f", "conv2_f", "conv3_u", "conv2_u"):
+            pk["gen." + name] = PackedConv(g[name + ".kernel_deconv2d"], self.precise)
+        for d in ("d1", "d2", "d3", "d4"):
+            pk["gen.sun." + d] = PackedConv(g["sun.%s.conv.kernel" % d], self.precise)
+        for l in (1, 2, 3):
+            for c in (1, 2):
+                name = "sunlayer%d.conv%d" % (l, c)
+                pk["sun." + name] = PackedConv(s[name + ".w"], self.precise)
+                if not (l == 1):  # Grad-CAM sweep needs dgrad of layers 2..3 (all four convs)
+                    pk["sun." + name + ".T"] = PackedConv(s[name + ".w"], self.precise, transpose_flip=True)
+        pk["sun.fc1"] = PackedFC(s["fc1.kernel"], self.precise)
+        pk["sun.fc2"] = PackedFC(s["fc2.kernel"], self.precise)
+
+
+def _in_xf(stats, p, name, slope):
+    return InXf(mode=L.IN_PARTIALS, slope=slope, stats=stats, gamma=p[name + ".gamma"], beta=p[name + ".beta"])
+
+
+def sunpose_forward(nets, ldr, compute):
+    """sunpose_net.model.sunposeEstimation (sunpose_net.py:54-72) -> dict with cmf, z, A1..3 (+ what the
+    Grad-CAM sweep re-reads: raw conv outputs and their IN partials)."""
+    s, pk = nets.sun, nets.pk
+    t = {}
+    x = ldr
+    for l in (1, 2, 3):
+        n1, n2 = "sunlayer%d.conv1" % l, "sunlayer%d.conv2" % l
+        r1, st1 = K.conv2d(x, pk["sun." + n1], s[n1 + ".b"], want_stats=True, compute=compute)
+        r2, st2 = K.conv2d(r1, pk["sun." + n2], s[n2 + ".b"], want_stats=True, compute=compute,
+                           xf=_in_xf(st1, s, "sunlayer%d.norm1" % l, 0.0))
+        a, pooled = K.norm_apply(r2, st2, s["sunlayer%d.norm2.gamma" % l], s["sunlayer%d.norm2.beta" % l], slope=0.0,
+                                 pool=True)
+        t["r%da" % l], t["st%da" % l], t["r%db" % l], t["st%db" % l], t["A%d" % l], t["P%d" % l] = r1, st1, r2, st2, a, pooled
+        x = pooled
+    B = ldr.shape[0]
+    flat = x.reshape(B, -1)
+    t["flat"] = flat
+    t["f1"] = K.fc_finalize(K.fc_fwd(flat, pk["sun.fc1"], compute), s["fc1.bias"], relu=True)
+    part2 = K.fc_fwd(t["f1"], pk["sun.fc2"], compute)
+    t["gmax"] = torch.zeros(1, dtype=torch.int32, device=ldr.device)
+    t["z"], t["cmf"] = K.softmax_head(part2, s["fc2.bias"], t["gmax"])
+    return t
+
+
+def gradcam_sweep(nets, t, pick_src, compute):
+    """grad_cam.layer x3 (grad_cam.py:29-44) as ONE backward sweep from y_c = cmf[b, argmax pick_src[b]]
+    down to the input of pool1.  Returns (cam1, cam2, cam3)."""
+    s, pk = nets.sun, nets.pk
+    B = t["cmf"].shape[0]
+    h, w = nets.h, nets.w
+    dz, _ = K.softmax_pick_bwd(t["cmf"], t["z"], pick_src)
+    df1 = K.fc_finalize(K.fc_dgrad(dz, pk["sun.fc2"], compute), None, relu=False, mask_src=t["f1"])
+    dflat = K.fc_finalize(K.fc_dgrad(df1, pk["sun.fc1"], compute))
+    dP3 = dflat.reshape(B, h // 8, w // 8, 128)
+    w3 = K.spatial_sum(dP3, 1.0 / ((h // 4) * (w // 4)))
+    # layer 3 backward: pool3 + relu + IN2 -> dgrad conv2 -> relu + IN1 -> dgrad conv1
+    g = K.norm_act_bwd(t["r3b"], t["st3b"], s["sunlayer3.norm2.gamma"], s["sunlayer3.norm2.beta"], 0.0, dP3, True)
+    g, _ = K.conv2d(g, pk["sun.sunlayer3.conv2.T"], None, compute=compute)
+    g = K.norm_act_bwd(t["r3a"], t["st3a"], s["sunlayer3.norm1.gamma"], s["sunlayer3.norm1.beta"], 0.0, g, False)
+    dP2, _ = K.conv2d(g, pk["sun.sunlayer3.conv1.T"], None, compute=compute)
+    w2 = K.spatial_sum(dP2, 1.0 / ((h // 2) * (w // 2)))
+    g = K.norm_act_bwd(t["r2b"], t["st2b"], s["sunlayer2.norm2.gamma"], s["sunlayer2.norm2.beta"], 0.0, dP2, True)
+    g, _ = K.conv2d(g, pk["sun.sunlayer2.conv2.T"], None, compute=compute)
+    g = K.norm_act_bwd(t["r2a"], t["st2a"], s["sunlayer2.norm1.gamma"], s["sunlayer2.norm1.beta"], 0.0, g, False)
+    dP1, _ = K.conv2d(g, pk["sun.sunlayer2.conv1.T"], None, compute=compute)
+    w1 = K.spatial_sum(dP1, 1.0 / (h * w))
+    return K.grad_cam_map(t["A1"], w1), K.grad_cam_map(t["A2"], w2), K.grad_cam_map(t["A3"], w3)
+
+
+def encode(nets, ldr, compute):
+    """generator.model.encode (generator.py:92-108) -> res_out [B,H/4,W/4,128]."""
+    g, pk = nets.gen, nets.pk
+    r1, s1 = K.conv2d(ldr, pk["gen.conv1_d"], g["conv1_d.b"], want_stats=True, compute=compute)
+    r2, s2 = K.conv2d(r1, pk["gen.conv2_d"], g["conv2_d.b"], stride=2, want_stats=True, compute=compute,
+                      xf=_in_xf(s1, g, "norm1_d", 0.1))
+    r3, s3 = K.conv2d(r2, pk["gen.conv3_d"], g["conv3_d.b"], stride=2, want_stats=True, compute=compute,
+                      xf=_in_xf(s2, g, "norm2_d", 0.1))
+    x = K.norm_apply(r3, s3, g["norm3_d.gamma"], g["norm3_d.beta"], slope=0.1)
+    for i in range(6):
+        p = "res.%d." % i
+        c1, t1 = K.conv2d(x, pk["gen." + p + "conv1"], g[p + "conv1.b"], want_stats=True, compute=compute)
+        c2, t2 = K.conv2d(c1, pk["gen." + p + "conv2"], g[p + "conv2.b"], want_stats=True, compute=compute,
+                          xf=_in_xf(t1, g, p + "norm1", 0.1))
+        x = K.norm_apply(c2, t2, g[p + "norm2.gamma"], g[p + "norm2.beta"], slope=1.0, residual=x)
+    return x
+
+
+def decode(nets, res_out, sfx, residual, compute):
+    """generator.model.sky_decode / sun_decode (generator.py:110-156): `residual` is the LDR input (sky)
+    or the log-compressed sun radiance (sun)."""
+    g, pk = nets.gen, nets.pk
+    r3, s3 = K.conv2d(res_out, pk["gen.conv3_" + sfx], g["conv3_%s.bias_deconv2d" % sfx], upsample=2, want_stats=True,
+                      compute=compute)
+    r2, s2 = K.conv2d(r3, pk["gen.conv2_" + sfx], g["conv2_%s.bias_deconv2d" % sfx], upsample=2, want_stats=True,
+                      compute=compute, xf=_in_xf(s3, g, "norm3_" + sfx, 0.1))
+    y, _ = K.conv2d(r2, pk["gen.conv1_" + sfx], g["conv1_%s.b" % sfx], compute=compute,
+                    xf=_in_xf(s2, g, "norm2_" + sfx, 0.1), out_slope=0.1, residual=residual, final_relu=True)
+    return y
+
+
+def sun_rad_estimation(nets, ldr, cams, t, compute):
+    """generator.model.sun_rad_estimation + sunRadNet in inference mode (generator.py:158-169,
+    sunrad_net.py:46-70): BN layers use their moving statistics."""
+    g, pk = nets.gen, nets.pk
+    plz = K.plz_build(ldr, *cams)
+    d1, _ = K.conv2d(plz, pk["gen.sun.d1"], None, stride=2, out_slope=0.3, compute=compute)
+    x, xf = d1, None
+    for d in ("d2", "d3", "d4"):
+        x, _ = K.conv2d(x, pk["gen.sun." + d], None, stride=(1 if d == "d4" else 2), xf=xf, compute=compute)
+        n = "sun.%s.norm." % d
+        sc, sh = K.bn_eval_affine(g[n + "gamma"], g[n + "beta"], g[n + "moving_mean"], g[n + "moving_variance"])
+        xf = InXf(mode=L.IN_AFFINE, slope=0.3, scale=sc, shift=sh)
+    gamma, beta = K.dense_heads(x, xf.scale, xf.shift, 0.3, g["sun.gamma.kernel"], g["sun.gamma.bias"],
+                                g["sun.beta.kernel"], g["sun.beta.bias"])
+    rad_lin, rad_gamma = K.sun_rad(t["cmf"], t["gmax"], gamma, beta, nets.h, nets.w)
+    return rad_lin, rad_gamma, gamma, beta
+
+
+def generator_forward(nets, ldr, pick_src=None, compute=BF16):
+    """inference.py:81-115 (pick_src=None: y_c = max cmf) / train.py:239-299 in test mode
+    (pick_src = sunpose_gt).  ldr [B,H,W,3] BGR in [0,1].  Returns the reference's outputs as a dict."""
+    B, H, W, _ = ldr.shape
+    res_out = encode(nets, ldr, compute)
+    sky_gamma = decode(nets, res_out, "f", ldr, compute)
+    t = sunpose_forward(nets, ldr, compute)
+    cams = gradcam_sweep(nets, t, t["cmf"] if pick_src is None else pick_src, compute)
+    rad_lin, rad_gamma, gamma, beta = sun_rad_estimation(nets, ldr, cams, t, compute)
+    sun_gamma = decode(nets, res_out, "u", rad_gamma, compute)
+    y_gamma, y_lin, alpha, sky_lin, sun_lin = K.blend(sky_gamma, sun_gamma, THRESHOLD)
+    return dict(y_final_lin=y_lin, y_final_gamma=y_gamma, sky_pred_lin=sky_lin, sun_pred_lin=sun_lin, gamma=gamma,
+                beta=beta, alpha_c3=alpha, sunpose_cmf=t["cmf"], sunpose_pred=t["cmf"].reshape(B, H, W, 1),
+                sun_cam1=cams[0], sun_cam2=cams[1], sun_cam3=cams[2], sun_rad_lin=rad_lin, res_out=res_out,
+                actv_maps=(t["A1"], t["A2"], t["A3"]))

@@ -1,0 +1,326 @@
+"""Typed torch-tensor front end of the C ABI (one thin function per libhdrsky entry point).
+
+PyTorch is plumbing here: device allocations (``torch.empty``), the current HIP stream and
+``data_ptr()``; every FLOP happens inside libhdrsky.so.  All functions validate shapes / dtypes /
+contiguity on the host before a kernel is enqueued (a mis-shaped operand must never reach the GPU).
+"""
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+BF16, BF16X3 = L.HDRSKY_BF16, L.HDRSKY_BF16X3
+IN_EPS = 1e-3  # tfa InstanceNormalization / Keras BatchNormalization default epsilon
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _f32(t, *shape):
+    if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise ValueError("expected a contiguous CUDA float32 tensor")
+    if shape and tuple(t.shape) != tuple(shape):
+        raise ValueError("shape %s != expected %s" % (tuple(t.shape), tuple(shape)))
+    return t
+
+
+@dataclass
+class Stats:
+    """Per-tile (sum, sumsq) partials [B][nparts][2][C] a conv emitted for the next normalisation."""
+    part: torch.Tensor
+    nparts: int
+    count: int  # H*W the sums run over
+
+
+@dataclass
+class InXf:
+    """Fused operand transform of a conv: act(norm(x)).  mode: IN_NONE / IN_AFFINE / IN_PARTIALS."""
+    mode: int = L.IN_NONE
+    slope: float = 1.0
+    scale: Optional[torch.Tensor] = None   # AFFINE [B,C] or [C]
+    shift: Optional[torch.Tensor] = None
+    stats: Optional[Stats] = None          # PARTIALS
+    gamma: Optional[torch.Tensor] = None
+    beta: Optional[torch.Tensor] = None
+    eps: float = IN_EPS
+
+
+class PackedConv:
+    """MFMA B-operand image of a [KH,KW,Cin,Cout] filter (bf16 hi plane + optional lo residual plane).
+    transpose_flip=True packs the data-gradient filter w'[ky,kx,co,ci] = w[KH-1-ky,KW-1-kx,ci,co]."""
+
+    def __init__(self, w, precise=True, transpose_flip=False):
+        _f32(w)
+        kh, kw, ci, co = w.shape
+        self.KH, self.KW = kh, kw
+        self.Cin, self.Cout = (co, ci) if transpose_flip else (ci, co)
+        self.flip = transpose_flip
+        lib = L.load()
+        n = lib.hdrsky_conv_packed_elems(kh, kw, self.Cin, self.Cout)
+        self.hi = torch.empty(n, dtype=torch.bfloat16, device=w.device)
+        self.lo = torch.empty(n, dtype=torch.bfloat16, device=w.device) if precise else None
+        self.repack(w)
+
+    def repack(self, w):
+        lib = L.load()
+        L.check(lib.hdrsky_conv_pack_weights(_p(w), self.KH, self.KW, self.Cin, self.Cout, int(self.flip),
+                                             _p(self.hi), _p(self.lo), _stream()), "conv_pack_weights")
+
+
+def conv_desc(B, H, W, Cin, Cout, KH, KW, stride=1, same=True, upsample=1):
+    d = L.ConvDesc()
+    L.check(L.load().hdrsky_conv_desc_init(d, B, H, W, Cin, Cout, KH, KW, stride, int(same), upsample), "conv_desc_init")
+    return d
+
+
+def conv2d(x, pw: PackedConv, bias=None, stride=1, same=True, upsample=1, xf: Optional[InXf] = None,
+           out_slope=1.0, residual=None, final_relu=False, want_stats=False, compute=BF16, desc=None, out=None):
+    """y = final_relu(act(conv(xf(x)) + bias) + residual); returns (y, Stats|None)."""
+    lib = L.load()
+    _f32(x)
+    B, H, W, C = x.shape
+    if C != pw.Cin:
+        raise ValueError("Cin mismatch: x has %d, filter %d" % (C, pw.Cin))
+    d = desc if desc is not None else conv_desc(B, H, W, C, pw.Cout, pw.KH, pw.KW, stride, same, upsample)
+    if (d.B, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW) != (B, H, W, C, pw.Cout, pw.KH, pw.KW):
+        raise ValueError("descriptor does not match operands")
+    d.compute = compute
+    if compute == BF16X3 and pw.lo is None:
+        raise ValueError("BF16X3 needs the lo weight plane (PackedConv(precise=True))")
+    xf = xf or InXf()
+    d.in_mode, d.in_slope = xf.mode, float(xf.slope)
+    in_scale = in_shift = in_part = in_gamma = in_beta = None
+    if xf.mode == L.IN_AFFINE:
+        in_scale, in_shift = _f32(xf.scale), _f32(xf.shift)
+        if in_scale.numel() == B * C:
+            d.ss_bstride = C
+        elif in_scale.numel() == C:
+            d.ss_bstride = 0
+        else:
+            raise ValueError("affine table must have C or B*C entries")
+        if in_shift.numel() != in_scale.numel():
+            raise ValueError("scale/shift size mismatch")
+    elif xf.mode == L.IN_PARTIALS:
+        st = xf.stats
+        in_part = _f32(st.part, B, st.nparts, 2, C)
+        if st.count != H * W:
+            raise ValueError("partials were not accumulated over this tensor's H*W")
+        in_gamma, in_beta = _f32(xf.gamma, C), _f32(xf.beta, C)
+        d.in_nparts, d.in_eps = st.nparts, float(xf.eps)
+    d.out_slope, d.final_relu, d.want_stats = float(out_slope), int(bool(final_relu)), int(bool(want_stats))
+    if bias is not None:
+        _f32(bias, pw.Cout)
+    y = out if out is not None else torch.empty((B, d.Ho, d.Wo, pw.Cout), dtype=torch.float32, device=x.device)
+    _f32(y, B, d.Ho, d.Wo, pw.Cout)
+    if residual is not None:
+        _f32(residual, B, d.Ho, d.Wo, pw.Cout)
+    stats = None
+    if want_stats:
+        nparts = lib.hdrsky_conv_stats_nparts(d)
+        stats = Stats(torch.empty((B, nparts, 2, pw.Cout), dtype=torch.float32, device=x.device), nparts, d.Ho * d.Wo)
+    L.check(lib.hdrsky_conv2d_fwd(d, _p(x), _p(pw.hi), _p(pw.lo), _p(bias), _p(in_scale), _p(in_shift), _p(in_part),
+                                  _p(in_gamma), _p(in_beta), _p(residual), _p(y),
+                                  _p(stats.part) if stats else None, _stream()), "conv2d_fwd")
+    return y, stats
+
+
+def norm_apply(x, stats: Stats, gamma, beta, slope=1.0, residual=None, pool=False, eps=IN_EPS):
+    """y = leaky(IN(x)) [+ residual]; optionally also the 2x2 max-pool of y.  Returns y or (y, ypool)."""
+    _f32(x)
+    B, H, W, C = x.shape
+    _f32(stats.part, B, stats.nparts, 2, C)
+    if stats.count != H * W:
+        raise ValueError("partials/count mismatch")
+    _f32(gamma, C); _f32(beta, C)
+    if residual is not None:
+        _f32(residual, B, H, W, C)
+    y = torch.empty_like(x)
+    yp = torch.empty((B, H // 2, W // 2, C), dtype=torch.float32, device=x.device) if pool else None
+    L.check(L.load().hdrsky_norm_apply(_p(x), _p(stats.part), stats.nparts, _p(gamma), _p(beta), eps, slope,
+                                       _p(residual), _p(y), _p(yp), B, H, W, C, _stream()), "norm_apply")
+    return (y, yp) if pool else y
+
+
+def in_finalize(stats: Stats, gamma, beta, B, C, eps=IN_EPS):
+    """(mean, rstd, scale, shift) tables [B,C]."""
+    _f32(stats.part, B, stats.nparts, 2, C)
+    outs = [torch.empty((B, C), dtype=torch.float32, device=gamma.device) for _ in range(4)]
+    L.check(L.load().hdrsky_in_finalize(_p(stats.part), stats.nparts, B, C, stats.count, _p(_f32(gamma, C)),
+                                        _p(_f32(beta, C)), eps, *[_p(o) for o in outs], _stream()), "in_finalize")
+    return outs
+
+
+def bn_eval_affine(gamma, beta, mm, mv, eps=IN_EPS):
+    C = gamma.numel()
+    for t in (gamma, beta, mm, mv):
+        _f32(t, C)
+    scale, shift = torch.empty_like(gamma), torch.empty_like(gamma)
+    L.check(L.load().hdrsky_bn_eval_affine(_p(gamma), _p(beta), _p(mm), _p(mv), eps, C, _p(scale), _p(shift), _stream()),
+            "bn_eval_affine")
+    return scale, shift
+
+
+def norm_act_bwd(x, stats: Stats, gamma, beta, slope, dy, pooled, eps=IN_EPS, want_sums=False):
+    """dx of y = leaky(IN(x)) [-> maxpool2x2]; dy is the gradient wrt y (or wrt the pooled y)."""
+    _f32(x)
+    B, H, W, C = x.shape
+    _f32(stats.part, B, stats.nparts, 2, C)
+    _f32(dy, B, H // 2 if pooled else H, W // 2 if pooled else W, C)
+    dx = torch.empty_like(x)
+    sums = torch.empty((B, C, 2), dtype=torch.float32, device=x.device) if want_sums else None
+    L.check(L.load().hdrsky_norm_act_bwd(_p(x), _p(stats.part), stats.nparts, _p(_f32(gamma, C)), _p(_f32(beta, C)),
+                                         eps, slope, _p(dy), int(pooled), _p(dx), _p(sums), B, H, W, C, _stream()),
+            "norm_act_bwd")
+    return (dx, sums) if want_sums else dx
+
+
+class PackedFC:
+    """bf16 images of a Dense kernel [K,N]: packed [K/8][N][8] (forward) and natural [K][N] (dgrad)."""
+
+    def __init__(self, w, precise=True, need_dgrad=True):
+        _f32(w)
+        self.K, self.N = w.shape
+        dev = w.device
+        mk = lambda: torch.empty(self.K * self.N, dtype=torch.bfloat16, device=dev)
+        self.pk_hi = mk()
+        self.pk_lo = mk() if precise else None
+        self.nat_hi = mk() if need_dgrad else None
+        self.nat_lo = mk() if (need_dgrad and precise) else None
+        self.repack(w)
+
+    def repack(self, w):
+        L.check(L.load().hdrsky_fc_pack_weights(_p(w), self.K, self.N, _p(self.pk_hi), _p(self.pk_lo), _p(self.nat_hi),
+                                                _p(self.nat_lo), _stream()), "fc_pack_weights")
+
+
+def fc_fwd(x, pf: PackedFC, compute=BF16):
+    """Split-R partial products [nsplit, M, N] of x[M,K] @ W[K,N]."""
+    M, K = x.shape
+    _f32(x, M, pf.K)
+    lib = L.load()
+    ns = lib.hdrsky_fc_nsplit(K)
+    out = torch.empty((ns, M, pf.N), dtype=torch.float32, device=x.device)
+    L.check(lib.hdrsky_fc_fwd(_p(x), _p(pf.pk_hi), _p(pf.pk_lo), M, K, pf.N, ns, compute, _p(out), _stream()), "fc_fwd")
+    return out
+
+
+def fc_dgrad(dy, pf: PackedFC, compute=BF16):
+    """Split-R partial products [nsplit, M, K] of dy[M,N] @ W[K,N]^T."""
+    M, N = dy.shape
+    _f32(dy, M, pf.N)
+    lib = L.load()
+    ns = lib.hdrsky_fc_nsplit(N)
+    out = torch.empty((ns, M, pf.K), dtype=torch.float32, device=dy.device)
+    L.check(lib.hdrsky_fc_dgrad(_p(dy), _p(pf.nat_hi), _p(pf.nat_lo), M, pf.K, N, ns, compute, _p(out), _stream()),
+            "fc_dgrad")
+    return out
+
+
+def fc_finalize(part, bias=None, relu=False, mask_src=None):
+    ns, M, N = part.shape
+    _f32(part)
+    y = torch.empty((M, N), dtype=torch.float32, device=part.device)
+    if bias is not None:
+        _f32(bias, N)
+    if mask_src is not None:
+        _f32(mask_src, M, N)
+    L.check(L.load().hdrsky_fc_finalize(_p(part), ns, M, N, _p(bias), int(relu), _p(mask_src), _p(y), _stream()),
+            "fc_finalize")
+    return y
+
+
+def softmax_head(part, bias, gmax_bits=None):
+    """z = relu(sum part + bias), cmf = softmax(z); gmax_bits (int32[1], zeroed by the caller) tracks max(cmf)."""
+    ns, M, N = part.shape
+    _f32(part); _f32(bias, N)
+    z = torch.empty((M, N), dtype=torch.float32, device=part.device)
+    cmf = torch.empty_like(z)
+    L.check(L.load().hdrsky_softmax_head(_p(part), ns, M, N, _p(bias), _p(z), _p(cmf), _p(gmax_bits), _stream()),
+            "softmax_head")
+    return z, cmf
+
+
+def softmax_pick_bwd(cmf, z, pick_src):
+    M, N = cmf.shape
+    _f32(cmf); _f32(z, M, N); _f32(pick_src, M, N)
+    dz = torch.empty_like(cmf)
+    idx = torch.empty((M,), dtype=torch.int32, device=cmf.device)
+    L.check(L.load().hdrsky_softmax_pick_bwd(_p(cmf), _p(z), _p(pick_src), M, N, _p(dz), _p(idx), _stream()),
+            "softmax_pick_bwd")
+    return dz, idx
+
+
+def spatial_sum(x, scale=1.0):
+    B, H, W, C = x.shape
+    _f32(x)
+    out = torch.empty((B, C), dtype=torch.float32, device=x.device)
+    L.check(L.load().hdrsky_spatial_sum(_p(x), B, H * W, C, scale, _p(out), _stream()), "spatial_sum")
+    return out
+
+
+def grad_cam_map(A, w):
+    B, H, W, C = A.shape
+    _f32(A); _f32(w, B, C)
+    cam = torch.empty((B, H, W, 1), dtype=torch.float32, device=A.device)
+    L.check(L.load().hdrsky_grad_cam(_p(A), _p(w), B, H * W, C, _p(cam), _stream()), "grad_cam")
+    return cam
+
+
+def plz_build(ldr, cam1, cam2, cam3):
+    B, H, W, _ = ldr.shape
+    _f32(ldr, B, H, W, 3); _f32(cam1, B, H, W, 1); _f32(cam2, B, H // 2, W // 2, 1); _f32(cam3, B, H // 4, W // 4, 1)
+    plz = torch.empty((B, H, W, 6), dtype=torch.float32, device=ldr.device)
+    L.check(L.load().hdrsky_plz_build(_p(ldr), _p(cam1), _p(cam2), _p(cam3), B, H, W, _p(plz), _stream()), "plz_build")
+    return plz
+
+
+def dense_heads(x, scale, shift, slope, kg, bg, kb, bb):
+    B = x.shape[0]
+    C = x.shape[-1]
+    F = x[0].numel()
+    _f32(x); _f32(kg, F, 1); _f32(kb, F, 1); _f32(bg, 1); _f32(bb, 1)
+    if scale is not None:
+        _f32(scale, C); _f32(shift, C)
+    g = torch.empty((B, 1, 1, 1), dtype=torch.float32, device=x.device)
+    b = torch.empty_like(g)
+    L.check(L.load().hdrsky_dense_heads(_p(x), _p(scale), _p(shift), slope, B, F, C, _p(kg), _p(bg), _p(kb), _p(bb),
+                                        _p(g), _p(b), _stream()), "dense_heads")
+    return g, b
+
+
+def sun_rad(cmf, gmax_bits, gamma, beta, H, W):
+    B, P = cmf.shape
+    _f32(cmf, B, H * W); _f32(gamma, B, 1, 1, 1); _f32(beta, B, 1, 1, 1)
+    lin = torch.empty((B, H, W, 3), dtype=torch.float32, device=cmf.device)
+    gam = torch.empty_like(lin)
+    L.check(L.load().hdrsky_sun_rad(_p(cmf), _p(gmax_bits), _p(gamma), _p(beta), B, P, _p(lin), _p(gam), _stream()),
+            "sun_rad")
+    return lin, gam
+
+
+def blend(sky_gamma, sun_gamma, thr=0.12, extras=True):
+    _f32(sky_gamma); _f32(sun_gamma, *sky_gamma.shape)
+    if sky_gamma.shape[-1] != 3:
+        raise ValueError("blend expects 3 channels")
+    npix = sky_gamma.numel() // 3
+    yg, yl = torch.empty_like(sky_gamma), torch.empty_like(sky_gamma)
+    al = sl = ul = None
+    if extras:
+        al, sl, ul = torch.empty_like(sky_gamma), torch.empty_like(sky_gamma), torch.empty_like(sky_gamma)
+    L.check(L.load().hdrsky_blend(_p(sky_gamma), _p(sun_gamma), npix, thr, _p(yg), _p(yl), _p(al), _p(sl), _p(ul),
+                                  _stream()), "blend")
+    return yg, yl, al, sl, ul
+
+
+def tonemap(x, decompress):
+    _f32(x)
+    y = torch.empty_like(x)
+    L.check(L.load().hdrsky_tonemap(_p(x), _p(y), x.numel(), int(decompress), _stream()), "tonemap")
+    return y

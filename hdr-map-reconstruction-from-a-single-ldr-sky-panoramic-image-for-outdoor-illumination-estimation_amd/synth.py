@@ -1,0 +1,67 @@
+"""Seeded synthetic inputs shaped like the reference's training batches (host-side numpy).
+
+There is no dataset, no ``dorfCurves.txt`` and no ``vgg16.npy`` in this environment, so the
+bench / tests use an analytic sky-dome + sun lobe that mimics what train.py feeds the step:
+  hdr_t            [B,H,W,3] fp32 BGR, mean normalised to 0.5 then exposure-scaled
+                   (train.py:109-110 ``0.5*hdr/(mean+1e-6)``, utils.py:86-91 ``2**U(-3,3)``)
+  jpeg_img_float   [B,H,W,3] fp32 on the k/255 lattice (train.py:79-92: clip, CRF, 8-bit quantise;
+                   the CRF LUT + JPEG round trip are replaced by a 1/2.2 gamma)
+  sunpose_gt       [B,H*W] von-Mises-Fisher pmf over the sky bins (train.py:42-52 with the bin
+                   directions of tf_utils.sunpose_init, tf_utils.py:112-129, and
+                   tf_utils.sphere2world, tf_utils.py:95-110)
+"""
+import numpy as np
+
+KAPPA = 80.0  # train.py:42
+
+
+def sunpose_bins(h, w):
+    """Unit vectors of the h*w sky bins: tf_utils.sunpose_init (tf_utils.py:112-129) for i in range(h*w)."""
+    i = np.arange(h * w, dtype=np.float64)
+    row = np.floor(i / w)
+    x = ((i + 1.0) - row * w - 1.0) * (360.0 / w) + (360.0 / (w * 2.0))
+    y = row * (90.0 / h) + (90.0 / (2.0 * h))
+    phi = y * (np.pi / 180.0)
+    theta = (x - 180.0) * (np.pi / 180.0)
+    return np.stack([np.cos(phi) * np.cos(theta), np.sin(phi), np.cos(phi) * np.sin(theta)], axis=1)
+
+
+def sphere2world(x, y, h, w):
+    """tf_utils.sphere2world (tf_utils.py:95-110), skydome=True."""
+    unit_w = 2.0 * np.pi / w
+    unit_h = np.pi / (h * 2)
+    theta = (x - 0.5 * w) * unit_w
+    phi = (h - y) * unit_h
+    return np.array([np.cos(phi) * np.cos(theta), np.sin(phi), np.cos(phi) * np.sin(theta)])
+
+
+def vmf_target(azimuth, elevation, h, w, kappa=KAPPA):
+    """train.py:42-52 ``vMF``: exp(kappa * <bin, sun>) normalised to sum 1."""
+    v = sphere2world(azimuth, elevation, h, w)
+    pdf = np.exp(kappa * (sunpose_bins(h, w) @ v))
+    return (pdf / pdf.sum()).astype(np.float32)
+
+
+def make_batch(batch, h=32, w=128, seed=1234):
+    """Returns dict(hdr_t, ldr, sunpose_gt) of np.float32 arrays (BGR channel order)."""
+    rng = np.random.default_rng(seed)
+    ys = np.arange(h, dtype=np.float64).reshape(h, 1)
+    bins = sunpose_bins(h, w).reshape(h, w, 3)
+    azimuth = w * 0.5 - 1.0  # AZIMUTH_gt, train.py:32
+    hdr = np.empty((batch, h, w, 3), np.float64)
+    gt = np.empty((batch, h * w), np.float32)
+    for b in range(batch):
+        tint = rng.uniform(0.8, 1.2, size=3)
+        sky = (0.2 + 0.6 * (ys / h)) * np.ones((1, w))
+        elev_row = float(rng.integers(0, h))
+        amp = 10.0 ** rng.uniform(1.0, 3.4)
+        sun_dir = sphere2world(azimuth, elev_row, h, w)
+        lobe = amp * np.exp(KAPPA * (bins @ sun_dir - 1.0))
+        img = sky[:, :, None] * tint[None, None, :] + lobe[:, :, None]
+        img = 0.5 * img / (img.mean() + 1e-6)
+        img = img * 2.0 ** rng.uniform(-3.0, 3.0)
+        hdr[b] = img
+        gt[b] = vmf_target(azimuth, elev_row, h, w)
+    hdr = hdr.astype(np.float32)
+    ldr = np.round(255.0 * np.clip(hdr, 0.0, 1.0) ** (1.0 / 2.2)) / 255.0
+    return dict(hdr_t=hdr, ldr=ldr.astype(np.float32), sunpose_gt=gt)

@@ -1,0 +1,180 @@
+/*
+ * hdrsky.h - C ABI of libhdrsky.so, the MI355X (gfx950) compute library behind the
+ * LDR->HDR sky-panorama hot path.
+ *
+ * The reference has no FFI: its boundary is the Keras Layer / Model Python API
+ * (SURVEY.md section 8b).  Every entry point below names the reference interface whose
+ * arithmetic it replaces (file:line under the reference root).  The Python host layer
+ * (the *_amd package) mirrors the reference's class / method names and binds these
+ * functions with ctypes; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - extern "C", plain pointers + sizes; no C++ / torch types cross the boundary.
+ *   - every pointer is DEVICE memory owned by the caller unless marked [host];
+ *     the library never allocates, frees or synchronises; all work is enqueued on
+ *     the `stream` argument (a hipStream_t passed as void*), so calls are capturable
+ *     into a hipGraph.
+ *   - tensors are NHWC fp32 at the boundary; `compute` selects how the contractions
+ *     run on the matrix cores: HDRSKY_BF16 (one bf16 MFMA product, fp32 accumulate)
+ *     or HDRSKY_BF16X3 (hi/lo split operands, three MFMA products: fp32-class accuracy).
+ *   - return value: 0 on success, a negative HDRSKY_E* code otherwise; nothing throws,
+ *     nothing calls exit().  Functions are re-entrant and thread-safe across streams.
+ */
+#ifndef HDRSKY_H
+#define HDRSKY_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HDRSKY_OK 0
+#define HDRSKY_EINVAL (-1)      /* bad argument / shape */
+#define HDRSKY_EUNSUPPORTED (-2) /* configuration not built */
+#define HDRSKY_ELAUNCH (-3)     /* HIP launch error */
+
+#define HDRSKY_BF16 0
+#define HDRSKY_BF16X3 1
+
+/* input-side fused transform of the conv / fc operand */
+#define HDRSKY_IN_NONE 0     /* x as is */
+#define HDRSKY_IN_AFFINE 1   /* act(x*scale[b*ss_bstride + c] + shift[...]) */
+#define HDRSKY_IN_PARTIALS 2 /* InstanceNorm finalised from the producer's per-tile (sum, sumsq) partials */
+
+const char* hdrsky_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution family.  Replaces:
+ *   ops.conv2d.call            ops.py:41-42     tf.nn.conv2d(x, w, [1,s,s,1], 'SAME') + bias_add
+ *   ops.deconv2d.call 'resize' ops.py:121-124   tf.image.resize(BILINEAR) -> stride-1 SAME conv + bias
+ *   Keras Conv2D               discriminator.py:11-13, :39-40 ; sunrad_net.py:12-14
+ *   vgg16.conv2d.call          vgg16.py:32-36   conv + bias + relu
+ * and the fused neighbours tfa InstanceNormalization (generator.py:15,19,61-85,
+ * sunpose_net.py:12,17) / Keras BatchNormalization + LeakyReLU (discriminator.py:16-17) that
+ * the reference applies between two convolutions: the normalise+activate of the PREVIOUS layer
+ * is folded into this conv's operand load, and this conv emits the (sum, sumsq) partials the
+ * NEXT normalisation needs.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct hdrsky_conv_desc {
+  int32_t B, H, W, Cin;   /* input tensor x [B,H,W,Cin] */
+  int32_t Ho, Wo, Cout;   /* output tensor y [B,Ho,Wo,Cout] */
+  int32_t KH, KW, stride; /* filter, stride (1 or 2) */
+  int32_t pad_t, pad_l;   /* zero padding before (TF SAME: total//2; VALID: 0) */
+  int32_t upsample;       /* 1, or 2: x is bilinearly resized (half-pixel) to [2H,2W] first */
+  int32_t dilate;         /* 1, or 2: x is zero-stuffed to [2H-1+dil_extra.., ..] (dgrad of stride 2) */
+  int32_t Hc, Wc;         /* conv-input domain after upsample/dilate (host fills: see hdrsky_conv_desc_init) */
+  int32_t compute;        /* HDRSKY_BF16 | HDRSKY_BF16X3 */
+  /* input transform */
+  int32_t in_mode;        /* HDRSKY_IN_* */
+  int32_t ss_bstride;     /* AFFINE: Cin for per-(b,c) tables, 0 for per-channel tables */
+  int32_t in_nparts;      /* PARTIALS: tiles per sample in in_part */
+  float in_eps;           /* PARTIALS: variance epsilon (1e-3 for tfa InstanceNormalization) */
+  float in_slope;         /* leaky slope applied after the affine: 1 = none, 0 = relu, 0.1, 0.3 */
+  /* epilogue: y = final_relu( act(conv + bias) + residual ) */
+  float out_slope;        /* 1 = none, 0 = relu, else leaky slope */
+  int32_t final_relu;     /* apply relu after the residual add */
+  int32_t want_stats;     /* write per-tile (sum, sumsq) of conv+bias into stats_part */
+} hdrsky_conv_desc;
+
+/* Fills Ho/Wo/pad/Hc/Wc for TF padding ("SAME": same=1, "VALID": same=0); returns 0 or HDRSKY_EINVAL. [host] */
+int hdrsky_conv_desc_init(hdrsky_conv_desc* d, int B, int H, int W, int Cin, int Cout, int KH, int KW,
+                          int stride, int same, int upsample);
+
+/* Number of bf16 elements of the packed weight image for a [KH,KW,Cin,Cout] filter. [host] */
+size_t hdrsky_conv_packed_elems(int KH, int KW, int Cin, int Cout);
+
+/* Packs fp32 HWIO weights w[KH,KW,Cin,Cout] into the MFMA B-operand image (hi plane, and the
+ * bf16 residual plane `lo` when non-null).  transpose_flip=1 packs the dgrad filter
+ * w'[ky,kx,co,ci] = w[KH-1-ky,KW-1-kx,ci,co] (then Cin/Cout below are those of w'). */
+int hdrsky_conv_pack_weights(const float* w, int KH, int KW, int Cin, int Cout, int transpose_flip,
+                             void* packed_hi, void* packed_lo, void* stream);
+
+/* Number of (sum,sumsq) tiles per sample this descriptor's launch writes to stats_part
+ * ([B][nparts][2][Cout] fp32). [host] */
+int hdrsky_conv_stats_nparts(const hdrsky_conv_desc* d);
+
+/* y = epilogue(conv(transform(x)))   (see the struct).  Pointers not used by the selected
+ * modes may be NULL.  in_scale/in_shift: AFFINE tables; in_part/in_gamma/in_beta: PARTIALS. */
+int hdrsky_conv2d_fwd(const hdrsky_conv_desc* d, const float* x, const void* w_hi, const void* w_lo,
+                      const float* bias, const float* in_scale, const float* in_shift,
+                      const float* in_part, const float* in_gamma, const float* in_beta,
+                      const float* residual, float* y, float* stats_part, void* stream);
+
+
+/* ------------------------------------------------------------------------------------------
+ * Normalisation / activation / pooling around the convolutions
+ * ---------------------------------------------------------------------------------------- */
+
+/* y = leaky(InstanceNorm(x), slope) [+ residual]; ypool (nullable) = 2x2/2 max-pool of y.
+ * IN statistics come from the producer conv's partials part[B][nparts][2][C].
+ * Replaces tfa InstanceNormalization + tf.nn.leaky_relu / ops.relu + tf.add + ops.maxpool2d:
+ * generator.py:26-35 (resBlock tail), :104-106 ; sunpose_net.py:20-30,55-62 ; ops.py:299-300,328-329. */
+int hdrsky_norm_apply(const float* x, const float* part, int nparts, const float* gamma, const float* beta, float eps,
+                      float slope, const float* residual, float* y, float* ypool, int B, int H, int W, int C,
+                      void* stream);
+
+/* mean / rstd / (gamma*rstd) / (beta - mean*gamma*rstd) tables [B][C] from the partials; outputs nullable. */
+int hdrsky_in_finalize(const float* part, int nparts, int B, int C, int count, const float* gamma, const float* beta,
+                       float eps, float* mean, float* rstd, float* scale, float* shift, void* stream);
+
+/* Keras BatchNormalization in inference mode as a per-channel affine (discriminator.py:25, sunrad_net.py:26
+ * with training=False): scale = gamma*rsqrt(moving_var+eps), shift = beta - moving_mean*scale. */
+int hdrsky_bn_eval_affine(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var,
+                          float eps, int C, float* scale, float* shift, void* stream);
+
+/* Data gradient of y = leaky(IN(x)) [-> 2x2 max-pool when pooled=1]; dy is [B,H,W,C] or [B,H/2,W/2,C].
+ * sums (nullable) receives [B][C][2] = (sum g, sum g*xhat).  tf.gradients path of grad_cam.py:31. */
+int hdrsky_norm_act_bwd(const float* x, const float* part, int nparts, const float* gamma, const float* beta,
+                        float eps, float slope, const float* dy, int pooled, float* dx, float* sums, int B, int H,
+                        int W, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Sun-pose dense head (sunpose_net.py:48-52,64-70) and its Grad-CAM backward (grad_cam.py:29-44)
+ * ---------------------------------------------------------------------------------------- */
+int hdrsky_fc_pack_weights(const float* w, int K, int N, void* packed_hi, void* packed_lo, void* natural_hi,
+                           void* natural_lo, void* stream);
+int hdrsky_fc_nsplit(int R); /* [host] reduction split the fc kernels use for a reduction length R */
+int hdrsky_fc_fwd(const float* x, const void* packed_hi, const void* packed_lo, int M, int K, int N, int nsplit,
+                  int compute, float* out_part, void* stream);
+int hdrsky_fc_dgrad(const float* dy, const void* natural_hi, const void* natural_lo, int M, int K, int N, int nsplit,
+                    int compute, float* dx_part, void* stream);
+/* y = [relu](sum_s part[s] + bias) [* (mask_src > 0)] */
+int hdrsky_fc_finalize(const float* part, int nsplit, int M, int N, const float* bias, int relu, const float* mask_src,
+                       float* y, void* stream);
+/* z = relu(sum_s part[s] + bias); cmf = softmax(z); *gmax_bits = max(*gmax_bits, bits(max cmf)) (zero it first). */
+int hdrsky_softmax_head(const float* part, int nsplit, int M, int N, const float* bias, float* z, float* cmf,
+                        void* gmax_bits, void* stream);
+/* dz = d cmf[m, argmax(pick_src[m])] / d z  (inference.py:98 ; train.py:265-267) */
+int hdrsky_softmax_pick_bwd(const float* cmf, const float* z, const float* pick_src, int M, int N, float* dz,
+                            int* idx_out, void* stream);
+/* out[b][c] = scale * sum_p x[b][p][c] */
+int hdrsky_spatial_sum(const float* x, int B, int P, int C, float scale, float* out, void* stream);
+/* cam[b][p] = relu(sum_c w[b][c]*A[b][p][c])  (grad_cam.py:34-38) */
+int hdrsky_grad_cam(const float* A, const float* w, int B, int P, int C, float* cam, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Sun-radiance head, tone mapping, blending
+ * ---------------------------------------------------------------------------------------- */
+/* plz = concat(ldr, cam1, resize(cam2), resize(cam3))  (generator.py:161-164) -> [B,H,W,6] */
+int hdrsky_plz_build(const float* ldr, const float* cam1, const float* cam2, const float* cam3, int B, int H, int W,
+                     float* plz, void* stream);
+/* gamma/beta = sigmoid(Dense(1)(flatten(leaky(x*scale[c]+shift[c]))))  (sunrad_net.py:52-59); F = flatten length */
+int hdrsky_dense_heads(const float* x, const float* scale, const float* shift, float slope, int B, int F, int C,
+                       const float* kg, const float* bg, const float* kb, const float* bb, float* gamma_out,
+                       float* beta_out, void* stream);
+/* Dirac-delta radiance (sunrad_net.py:61-69, generator.py:160,167) + hdr_logCompression (tf_utils.py:263-271) */
+int hdrsky_sun_rad(const float* cmf, const void* gmax_bits, const float* gamma, const float* beta, int B, int P,
+                   float* rad_lin3, float* rad_gamma3, void* stream);
+/* alpha mask + blend + log decompression (inference.py:91-94,109-113; train.py:258-261,293-299); outputs after
+ * y_lin are nullable */
+int hdrsky_blend(const float* sky_gamma, const float* sun_gamma, int npix, float thr, float* y_gamma, float* y_lin,
+                 float* alpha, float* sky_lin, float* sun_lin, void* stream);
+/* tf_utils.hdr_logCompression (decompress=0) / hdr_logDecompression (1)  (tf_utils.py:263-280) */
+int hdrsky_tonemap(const float* x, float* y, size_t n, int decompress, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HDRSKY_H */

@@ -1,0 +1,102 @@
+"""GPU parity: hdrsky_conv2d_fwd (through the C ABI) vs the CPU oracle, every layer shape of the
+generator / sun-pose / sun-radiance / discriminator / VGG stacks at small batch, both compute modes."""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+from oracle import tfsem as T
+from util import TOL_X3, assert_close, assert_close_bf16
+
+pytestmark = pytest.mark.gpu
+
+# (name, H, W, Cin, Cout, k, stride, same, upsample)
+LAYERS = [
+    ("g.conv1_d 7x7 3->32", 32, 128, 3, 32, 7, 1, True, 1),
+    ("g.conv2_d 3x3 s2 32->64", 32, 128, 32, 64, 3, 2, True, 1),
+    ("g.conv3_d 3x3 s2 64->128", 16, 64, 64, 128, 3, 2, True, 1),
+    ("g.res 3x3 128->128", 8, 32, 128, 128, 3, 1, True, 1),
+    ("g.conv3_f up+3x3 128->64", 8, 32, 128, 64, 3, 1, True, 2),
+    ("g.conv2_f up+3x3 64->32", 16, 64, 64, 32, 3, 1, True, 2),
+    ("g.conv1_f 7x7 32->3", 32, 128, 32, 3, 7, 1, True, 1),
+    ("s.l1.conv2 7x7 32->32", 32, 128, 32, 32, 7, 1, True, 1),
+    ("s.l2.conv2 3x3 64->64", 16, 64, 64, 64, 3, 1, True, 1),
+    ("d1 4x4 s2 6->64", 32, 128, 6, 64, 4, 2, True, 1),
+    ("d2 4x4 s2 64->128", 16, 64, 64, 128, 4, 2, True, 1),
+    ("d3 4x4 s2 128->256", 8, 32, 128, 256, 4, 2, True, 1),
+    ("d4 4x4 s1 256->512", 4, 16, 256, 512, 4, 1, True, 1),
+    ("dis.out 4x4 VALID 512->1", 4, 16, 512, 1, 4, 1, False, 1),
+    ("vgg.conv1_1 3x3 3->64", 32, 128, 3, 64, 3, 1, True, 1),
+    ("vgg.conv3_2 3x3 256->256", 8, 32, 256, 256, 3, 1, True, 1),
+    ("odd 3x3 s1 32->32 on 10x20", 10, 20, 32, 32, 3, 1, True, 1),
+    ("odd 3x3 s2 32->64 on 9x37", 9, 37, 32, 64, 3, 2, True, 1),
+]
+
+
+def _ref(x, w, b, stride, same, upsample):
+    xt = torch.from_numpy(x)
+    if upsample == 2:
+        xt = T.resize_bilinear(xt, 2 * x.shape[1], 2 * x.shape[2])
+    return T.conv2d(xt, torch.from_numpy(w), torch.from_numpy(b), stride, "SAME" if same else "VALID").numpy()
+
+
+@pytest.mark.parametrize("case", LAYERS, ids=[c[0] for c in LAYERS])
+@pytest.mark.parametrize("B", [2, 5])
+def test_conv_layers(dev, case, B):
+    K = pkg("kernels")
+    name, H, W, Cin, Cout, k, stride, same, up = case
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    ref = _ref(x, w, b, stride, same, up)
+    xd, wd, bd = (torch.from_numpy(a).to(dev) for a in (x, w, b))
+    pw = K.PackedConv(wd, precise=True)
+    y, _ = K.conv2d(xd, pw, bd, stride=stride, same=same, upsample=up, compute=K.BF16X3)
+    assert_close(y, ref, TOL_X3, name + " x3")
+    y, _ = K.conv2d(xd, pw, bd, stride=stride, same=same, upsample=up, compute=K.BF16)
+    assert_close_bf16(y, ref, name + " bf16")
+
+
+def test_conv_fused_in_stats_residual(dev):
+    """producer partials -> consumer IN + lrelu fused into the operand load; epilogue act + residual + relu."""
+    K = pkg("kernels"); L = pkg("_lib")
+    rng = np.random.default_rng(7)
+    B, H, W = 3, 16, 64
+    x = rng.standard_normal((B, H, W, 32)).astype(np.float32) * 2 + 0.5
+    w1 = (rng.standard_normal((3, 3, 32, 64)) / 17).astype(np.float32); b1 = rng.standard_normal(64).astype(np.float32)
+    w2 = (rng.standard_normal((3, 3, 64, 32)) / 24).astype(np.float32); b2 = rng.standard_normal(32).astype(np.float32)
+    gam = rng.uniform(0.5, 1.5, 64).astype(np.float32); bet = rng.standard_normal(64).astype(np.float32)
+    res = rng.standard_normal((B, H, W, 32)).astype(np.float32)
+    xt = torch.from_numpy(x)
+    c1 = T.conv2d(xt, torch.from_numpy(w1), torch.from_numpy(b1))
+    a1 = T.leaky_relu(T.instance_norm(c1, torch.from_numpy(gam), torch.from_numpy(bet)), 0.1)
+    c2 = T.conv2d(a1, torch.from_numpy(w2), torch.from_numpy(b2))
+    ref = torch.relu(T.leaky_relu(c2, 0.1) + torch.from_numpy(res))
+    d = lambda a: torch.from_numpy(a).to(dev)
+    p1, p2 = K.PackedConv(d(w1)), K.PackedConv(d(w2))
+    r1, st = K.conv2d(d(x), p1, d(b1), want_stats=True, compute=K.BF16X3)
+    assert_close(r1, c1, TOL_X3, "producer")
+    # statistics partials reproduce the moments
+    mean, rstd, _, _ = K.in_finalize(st, d(gam), d(bet), B, 64)
+    assert_close(mean, c1.mean(dim=(1, 2)), 1e-4, "IN mean")
+    var = ((c1 - c1.mean(dim=(1, 2), keepdim=True)) ** 2).mean(dim=(1, 2))
+    assert_close(rstd, torch.rsqrt(var + 1e-3), 1e-4, "IN rstd")
+    xf = K.InXf(mode=L.IN_PARTIALS, slope=0.1, stats=st, gamma=d(gam), beta=d(bet))
+    y, _ = K.conv2d(r1, p2, d(b2), xf=xf, out_slope=0.1, residual=d(res), final_relu=True, compute=K.BF16X3)
+    assert_close(y, ref, 3e-4, "fused consumer")
+
+
+def test_conv_dgrad_via_flipped_filter(dev):
+    """data gradient of a stride-1 SAME conv == conv with the transposed/flipped packed filter."""
+    K = pkg("kernels")
+    rng = np.random.default_rng(11)
+    x = torch.from_numpy(rng.standard_normal((2, 8, 32, 64)).astype(np.float32)).requires_grad_(True)
+    w = torch.from_numpy((rng.standard_normal((3, 3, 64, 128)) / 24).astype(np.float32))
+    dy = torch.from_numpy(rng.standard_normal((2, 8, 32, 128)).astype(np.float32))
+    (gx,) = torch.autograd.grad(T.conv2d(x, w, None), x, dy)
+    pT = K.PackedConv(w.to(dev), transpose_flip=True)
+    got, _ = K.conv2d(dy.to(dev), pT, None, compute=K.BF16X3)
+    assert_close(got, gx, TOL_X3, "dgrad")

@@ -1,0 +1,63 @@
+"""GPU parity of the whole generator graph (inference.py:81-115 / train.py:239-299 test mode) vs the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+from oracle import step as ostep
+from util import assert_close, rel_max, to_np
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(dev, B):
+    params, synth, engine = pkg("params"), pkg("synth"), pkg("engine")
+    gen = params.init_params(params.generator_spec(), 0)
+    sun = params.init_params(params.sunpose_spec(), 1)
+    batch = synth.make_batch(B, seed=1234)
+    nets = engine.Nets(gen, sun, device=dev)
+    tt = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}
+    return engine, nets, tt(gen), tt(sun), batch
+
+
+def psnr(a, b):
+    a, b = to_np(a).astype(np.float64), to_np(b).astype(np.float64)
+    peak = np.abs(b).max()
+    return 10 * np.log10(peak * peak / ((a - b) ** 2).mean())
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_generator_graph_inference_mode(dev, B):
+    K = pkg("kernels")
+    engine, nets, gen, sun, batch = _setup(dev, B)
+    ref = ostep.inference(gen, sun, torch.from_numpy(batch["ldr"]))
+    ldr = torch.from_numpy(batch["ldr"]).to(dev)
+    out = engine.generator_forward(nets, ldr, compute=K.BF16X3)
+    # Stage-wise checks (fp32-class BF16X3 contractions; tolerance relative to each tensor's max)
+    assert_close(out["res_out"], ref["res_out"], 1e-3, "res_out")
+    assert_close(out["sunpose_cmf"], ref["sunpose_cmf"], 2e-3, "cmf")
+    for k in ("sun_cam1", "sun_cam2", "sun_cam3"):
+        assert_close(out[k], ref[k], 5e-3, k)
+    assert_close(out["gamma"], ref["gamma"], 1e-4, "gamma"); assert_close(out["beta"], ref["beta"], 1e-4, "beta")
+    assert_close(out["sun_rad_lin"], ref["sun_rad_lin"], 2e-3, "sun_rad_lin")
+    assert_close(out["alpha_c3"], ref["alpha_c3"], 2e-3, "alpha")
+    assert_close(out["y_final_gamma"], ref["y_final_gamma"], 1e-3, "y_final_gamma")
+    assert_close(out["y_final_lin"], ref["y_final_lin"], 5e-3, "y_final_lin")
+    # fast path: single bf16 product.  PSNR of the gamma-domain output vs the fp32 oracle
+    out16 = engine.generator_forward(nets, ldr, compute=K.BF16)
+    p = psnr(out16["y_final_gamma"], ref["y_final_gamma"])
+    print("bf16 y_final_gamma PSNR vs oracle: %.1f dB, rel max %.3e" % (p, rel_max(out16["y_final_gamma"], ref["y_final_gamma"])))
+    assert p > 40.0
+
+
+def test_generator_graph_picks_gt_bin(dev):
+    """train.py:265-267: y_c = cmf[b, argmax(sunpose_gt[b])]."""
+    K = pkg("kernels")
+    engine, nets, gen, sun, batch = _setup(dev, 2)
+    gt = torch.from_numpy(batch["sunpose_gt"])
+    req = {k: v.clone().requires_grad_(True) for k, v in sun.items()}
+    ref = ostep.generator_graph(gen, req, torch.from_numpy(batch["ldr"]), y_index=gt.argmax(dim=1), training=False)
+    out = engine.generator_forward(nets, torch.from_numpy(batch["ldr"]).to(dev), pick_src=gt.to(dev), compute=K.BF16X3)
+    for k in ("sun_cam1", "sun_cam2", "sun_cam3"):
+        assert_close(out[k], ref[k].detach(), 5e-3, k)
+    assert_close(out["y_final_gamma"], ref["y_final_gamma"].detach(), 1e-3, "y_final_gamma")

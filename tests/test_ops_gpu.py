@@ -1,0 +1,143 @@
+"""GPU parity of the non-conv kernels (through the C ABI) vs the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+from oracle import networks as N
+from oracle import tfsem as T
+from util import TOL_F32, TOL_X3, assert_close, assert_close_bf16
+
+pytestmark = pytest.mark.gpu
+
+
+def _stats_for(K, x_dev, C):
+    """(sum,sumsq) partials of x itself, produced by a 1x1 identity conv through the real conv kernel."""
+    eye = torch.eye(C, device=x_dev.device).reshape(1, 1, C, C).contiguous()
+    pw = K.PackedConv(eye)
+    y, st = K.conv2d(x_dev, pw, None, want_stats=True, compute=K.BF16X3)
+    return y, st
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 128, 32), (3, 16, 64, 64), (2, 8, 32, 128)])
+@pytest.mark.parametrize("pool", [False, True])
+def test_norm_apply(dev, shape, pool):
+    K = pkg("kernels")
+    rng = np.random.default_rng(3)
+    B, H, W, C = shape
+    x = (rng.standard_normal(shape) * 1.7 + 0.3).astype(np.float32)
+    gam = rng.uniform(0.5, 1.5, C).astype(np.float32); bet = rng.standard_normal(C).astype(np.float32)
+    res = rng.standard_normal(shape).astype(np.float32)
+    d = lambda a: torch.from_numpy(a).to(dev)
+    xr, st = _stats_for(K, d(x), C)   # xr == x up to the split-bf16 rounding of the identity conv
+    ref = T.leaky_relu(T.instance_norm(xr.cpu(), torch.from_numpy(gam), torch.from_numpy(bet)), 0.1) + torch.from_numpy(res)
+    out = K.norm_apply(xr, st, d(gam), d(bet), slope=0.1, residual=d(res), pool=pool)
+    if pool:
+        y, yp = out
+        assert_close(yp, T.maxpool2x2(ref), 1e-4, "pooled")
+    else:
+        y = out
+    assert_close(y, ref, 1e-4, "norm_apply")
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 64, 64), (2, 8, 32, 128)])
+@pytest.mark.parametrize("pooled", [False, True])
+def test_norm_act_bwd(dev, shape, pooled):
+    K = pkg("kernels")
+    rng = np.random.default_rng(5)
+    B, H, W, C = shape
+    x = (rng.standard_normal(shape) * 1.3 + 0.2).astype(np.float32)
+    gam = rng.uniform(0.5, 1.5, C).astype(np.float32); bet = (rng.standard_normal(C) * 0.5).astype(np.float32)
+    d = lambda a: torch.from_numpy(a).to(dev)
+    xr, st = _stats_for(K, d(x), C)
+    xt = xr.cpu().clone().requires_grad_(True)
+    y = torch.relu(T.instance_norm(xt, torch.from_numpy(gam), torch.from_numpy(bet)))
+    if pooled:
+        y = T.maxpool2x2(y)
+    dy = rng.standard_normal(tuple(y.shape)).astype(np.float32)
+    (gx,) = torch.autograd.grad(y, xt, torch.from_numpy(dy))
+    got = K.norm_act_bwd(xr, st, d(gam), d(bet), 0.0, d(dy), pooled)
+    assert_close(got, gx, 2e-4, "norm_act_bwd")
+
+
+@pytest.mark.parametrize("M", [1, 4, 32])
+def test_fc_fwd_dgrad_softmax(dev, M):
+    K = pkg("kernels")
+    rng = np.random.default_rng(9)
+    Kd, Nd = 1024, 512
+    x = rng.standard_normal((M, Kd)).astype(np.float32)
+    w = (rng.standard_normal((Kd, Nd)) / 32).astype(np.float32)
+    b = rng.standard_normal(Nd).astype(np.float32)
+    d = lambda a: torch.from_numpy(a).to(dev)
+    pf = K.PackedFC(d(w))
+    ref = torch.from_numpy(x) @ torch.from_numpy(w) + torch.from_numpy(b)
+    y = K.fc_finalize(K.fc_fwd(d(x), pf, K.BF16X3), d(b))
+    assert_close(y, ref, TOL_X3, "fc x3")
+    y16 = K.fc_finalize(K.fc_fwd(d(x), pf, K.BF16), d(b))
+    assert_close_bf16(y16, ref, "fc bf16")
+    dy = rng.standard_normal((M, Nd)).astype(np.float32)
+    gref = torch.from_numpy(dy) @ torch.from_numpy(w).T
+    g = K.fc_finalize(K.fc_dgrad(d(dy), pf, K.BF16X3))
+    assert_close(g, gref, TOL_X3, "fc dgrad x3")
+    # soft-max head + picked-probability backward
+    gmax = torch.zeros(1, dtype=torch.int32, device=dev)
+    z, cmf = K.softmax_head(K.fc_fwd(d(x), pf, K.BF16X3), d(b), gmax)
+    zr = torch.relu(ref).requires_grad_(True)
+    cr = torch.softmax(zr, dim=-1)
+    assert_close(cmf, cr, 5e-4, "softmax")
+    assert abs(float(gmax.view(torch.float32).item()) - float(cr.max())) <= 5e-4 * float(cr.max())
+    yc = cr.max(dim=1).values.sum()
+    (gz,) = torch.autograd.grad(yc, zr)
+    dz, idx = K.softmax_pick_bwd(cmf, z, cmf)
+    assert (idx.cpu().numpy() == cr.argmax(dim=1).numpy()).all()
+    assert_close(dz, gz * (zr > 0), 1e-3, "softmax pick bwd")
+
+
+def test_cam_plz_heads_rad_blend(dev):
+    K = pkg("kernels")
+    rng = np.random.default_rng(13)
+    B, H, W = 3, 32, 128
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    A = rng.standard_normal((B, 16, 64, 64)).astype(np.float32)
+    g = rng.standard_normal((B, 8, 32, 64)).astype(np.float32)
+    w = K.spatial_sum(d(g), 1.0 / (16 * 64))
+    assert_close(w, g.sum(axis=(1, 2)) / (16 * 64), TOL_F32 * 10, "spatial_sum")
+    cam = K.grad_cam_map(d(A), w)
+    ref = np.maximum(np.einsum("bc,bhwc->bhw", w.cpu().numpy(), A), 0)[..., None]
+    assert_close(cam, ref, 1e-5, "cam")
+    ldr = rng.uniform(0, 1, (B, H, W, 3)); c1 = rng.uniform(0, 1, (B, H, W, 1))
+    c2 = rng.uniform(0, 1, (B, H // 2, W // 2, 1)); c3 = rng.uniform(0, 1, (B, H // 4, W // 4, 1))
+    plz = K.plz_build(d(ldr), d(c1), d(c2), d(c3))
+    t = lambda a: torch.from_numpy(a.astype(np.float32))
+    ref = torch.cat([t(ldr), t(c1), T.resize_bilinear(t(c2), H, W), T.resize_bilinear(t(c3), H, W)], dim=-1)
+    assert_close(plz, ref, 1e-6, "plz")
+    # dense heads + delta function
+    x = rng.standard_normal((B, 4, 16, 512)).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, 512).astype(np.float32); sh = rng.standard_normal(512).astype(np.float32)
+    kg = (rng.standard_normal((32768, 1)) / 180).astype(np.float32); kb = (rng.standard_normal((32768, 1)) / 180).astype(np.float32)
+    bg = np.array([0.1], np.float32); bb = np.array([-0.2], np.float32)
+    gam, bet = K.dense_heads(d(x), d(sc), d(sh), 0.3, d(kg), d(bg), d(kb), d(bb))
+    flat = T.leaky_relu(t(x) * t(sc) + t(sh), 0.3).reshape(B, -1)
+    gr = torch.sigmoid(flat @ t(kg) + t(bg)); br = torch.sigmoid(flat @ t(kb) + t(bb))
+    assert_close(gam.reshape(B, 1), gr, 1e-4, "gamma head"); assert_close(bet.reshape(B, 1), br, 1e-4, "beta head")
+    cmf = torch.softmax(t(rng.standard_normal((B, H * W)) * 3), dim=-1)
+    gmax = torch.tensor([float(cmf.max())], dtype=torch.float32).view(torch.int32).to(dev)
+    lin, gm = K.sun_rad(cmf.to(dev), gmax, gam, bet, H, W)
+    p = {"x": None}
+    xn = (cmf / cmf.max()).reshape(B, H, W, 1)
+    y = torch.exp(-torch.pow(1.0 - xn, 2.0) / (gam.cpu() + 1e-5)) * gam.cpu() / (bet.cpu() * 1.7724539 + 1e-5)
+    y = torch.where(y > 30000.0, torch.full_like(y, 30000.0), y).repeat(1, 1, 1, 3)
+    assert_close(lin, y, 1e-5, "sun_rad lin"); assert_close(gm, T.hdr_log_compression(y), 1e-5, "sun_rad gamma")
+    # blend
+    sky = rng.uniform(0, 1.4, (B, H, W, 3)).astype(np.float32); sun = rng.uniform(0, 3.0, (B, H, W, 3)).astype(np.float32)
+    yg, yl, al, sl, ul = K.blend(d(sky), d(sun))
+    a = T.hdr_log_decompression(t(sky)).max(dim=3).values
+    a = torch.minimum(torch.ones_like(a), torch.clamp(a - 1.0 + 0.12, min=0.0) / 0.12).unsqueeze(-1).repeat(1, 1, 1, 3)
+    s, u = (1 - a) * t(sky), a * t(sun)
+    assert_close(al, a, 2e-5, "alpha"); assert_close(yg, s + u, 1e-6, "y_gamma")
+    assert_close(yl, T.hdr_log_decompression(s + u), 1e-5, "y_lin")
+    assert_close(sl, T.hdr_log_decompression(s), 1e-5, "sky_lin"); assert_close(ul, T.hdr_log_decompression(u), 1e-5, "sun_lin")
+    # tone map round trip
+    v = d(rng.uniform(0, 50, (1000,)))
+    assert_close(K.tonemap(K.tonemap(v, False), True), v, 1e-5, "tonemap round trip")
+    assert_close(K.tonemap(v, False), T.hdr_log_compression(v.cpu()), 1e-6, "log compression")
