@@ -2,8 +2,9 @@
 
 There is no dataset, no ``dorfCurves.txt`` and no ``vgg16.npy`` in this environment, so the
 bench / tests use an analytic sky-dome + sun lobe that mimics what train.py feeds the step:
-  hdr_t            [B,H,W,3] fp32 BGR, mean normalised to 0.5 then exposure-scaled
-                   (train.py:109-110 ``0.5*hdr/(mean+1e-6)``, utils.py:86-91 ``2**U(-3,3)``)
+  hdr_t            [B,H,W,3] fp32 BGR, mean normalised to 0.5 then exposure-scaled, plus the
+                   signal-dependent + constant Gaussian noise of the augmentation
+                   (train.py:109-110 ``0.5*hdr/(mean+1e-6)``, utils.py:86-91 ``2**U(-3,3)``, train.py:66-74)
   jpeg_img_float   [B,H,W,3] fp32 on the k/255 lattice (train.py:79-92: clip, CRF, 8-bit quantise;
                    the CRF LUT + JPEG round trip are replaced by a 1/2.2 gamma)
   sunpose_gt       [B,H*W] von-Mises-Fisher pmf over the sky bins (train.py:42-52 with the bin
@@ -60,6 +61,11 @@ def make_batch(batch, h=32, w=128, seed=1234):
         img = sky[:, :, None] * tint[None, None, :] + lobe[:, :, None]
         img = 0.5 * img / (img.mean() + 1e-6)
         img = img * 2.0 ** rng.uniform(-3.0, 3.0)
+        # Poisson-like + Gaussian sensor noise of the reference's augmentation (train.py:66-74)
+        sigma_s = 0.08 / 6.0 * rng.uniform(0.0, 1.0, size=(1, 1, 3))
+        sigma_c = 0.005 * rng.uniform(0.0, 1.0, size=(1, 1, 3))
+        img = img + rng.standard_normal(img.shape) * sigma_s * img + sigma_c * rng.standard_normal(img.shape)
+        img = np.maximum(img, 0.0)
         hdr[b] = img
         gt[b] = vmf_target(azimuth, elev_row, h, w)
     hdr = hdr.astype(np.float32)
