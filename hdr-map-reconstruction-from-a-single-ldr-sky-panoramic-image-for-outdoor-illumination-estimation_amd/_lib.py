@@ -46,10 +46,10 @@ SIGNATURES = {
     "hdrsky_softmax_head": (c_int, [P, c_int, c_int, c_int, P, P, P, P, P]),
     "hdrsky_softmax_pick_bwd": (c_int, [P, P, P, c_int, c_int, P, P, P]),
     "hdrsky_spatial_sum": (c_int, [P, c_int, c_int, c_int, c_float, P, P]),
-    "hdrsky_grad_cam": (c_int, [P, P, c_int, c_int, c_int, P, P]),
+    "hdrsky_grad_cam": (c_int, [P, P, c_int, c_float, c_int, c_int, c_int, P, P]),
     "hdrsky_plz_build": (c_int, [P, P, P, P, c_int, c_int, c_int, P, P]),
-    "hdrsky_dense_heads": (c_int, [P, P, P, c_float, c_int, c_int, c_int, P, P, P, P, P, P, P]),
-    "hdrsky_sun_rad": (c_int, [P, P, P, P, c_int, c_int, P, P, P]),
+    "hdrsky_dense_heads": (c_int, [P, P, P, c_float, c_int, c_int, c_int, P, P, c_int, P, P]),
+    "hdrsky_sun_rad": (c_int, [P, P, P, c_int, P, P, c_int, c_int, P, P, P, P, P]),
     "hdrsky_blend": (c_int, [P, P, c_int, c_float, P, P, P, P, P, P]),
     "hdrsky_tonemap": (c_int, [P, P, c_size_t, c_int, P]),
 }

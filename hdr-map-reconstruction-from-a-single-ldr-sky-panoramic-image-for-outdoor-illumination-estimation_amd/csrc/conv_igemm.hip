@@ -12,11 +12,14 @@
 // Replaces tf.nn.conv2d + bias_add (ops.py:41-42), resize+conv (ops.py:121-124), Keras Conv2D
 // (discriminator.py:11-13, sunrad_net.py:12-14), vgg16.conv2d (vgg16.py:32-36) and, through
 // transposed/flipped packed filters, their data gradients.
+#include <cstdio>
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
 
-constexpr int KC = 4;  // k-steps (of 32) per B chunk / barrier
+constexpr int kc_for(int bn) { return bn <= 32 ? 8 : 4; }  // k-steps (of 32) per B chunk / barrier
 
 struct ConvKArgs {
   const float* x;
@@ -37,9 +40,10 @@ struct ConvKArgs {
   float in_eps, in_inv_count, in_slope, out_slope;
   int final_relu, want_stats;
   int tiles_x, tiles_y, nblocks;
-  int cgs, log2nq, ngroups, ksg, log2cbg, ntaps;
-  int HT, WT, NPIX, NPIXP, wt_magic;
+  int cgs, log2nq, ngroups, ksg, log2cbg, ntaps, kzero;
+  int HT, WT, NPIX, NPIXP, wt_magic, kw_magic;
   int off_alo, off_b, off_ss, off_tap, off_stat;
+  unsigned long long* stamps;  // debug: per-workgroup phase time stamps (null in production)
 };
 
 // load 8 consecutive channels and apply the producer's affine + leaky activation
@@ -58,16 +62,94 @@ __device__ __forceinline__ void load8_xf(const float* __restrict__ p, const floa
   }
 }
 
-template <int WM, int WN, int MI, int NI, int TW, bool NARROW, bool PRECISE>
-__global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvKArgs a) {
+#define HDRSKY_STAMP(k)                                                               \
+  if (a.stamps != nullptr && threadIdx.x == 0) {                                      \
+    a.stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime();            \
+    if ((k) == 0 || (k) == 5) a.stamps[(size_t)blockIdx.x * 8 + 6 + ((k) ? 1 : 0)] = __builtin_amdgcn_s_memrealtime(); \
+  }
+
+// KC k-steps of MFMA on one LDS-resident B chunk; TAIL=true guards each k-step against the end of the
+// reduction (only the last chunk can be partial)
+template <int MI, int NI, int BN, int KC, int BPLANES, int BITEMS, bool NARROW, bool PRECISE, bool TAIL>
+__device__ __forceinline__ void compute_chunk(const ConvKArgs& a, const unsigned char* smem, const uint4* sB,
+                                              const int* sTap, int ch, int kq, const int (&abase)[MI],
+                                              const int (&bbase)[NI], f32x4_t (&acc)[MI][NI]) {
+  const int buf = ch & 1;
+  const unsigned char* bh = reinterpret_cast<const unsigned char*>(sB + (buf * BPLANES) * BITEMS);
+  const unsigned char* bl = reinterpret_cast<const unsigned char*>(sB + (buf * BPLANES + (PRECISE ? 1 : 0)) * BITEMS);
+#pragma unroll
+  for (int ksl = 0; ksl < KC; ++ksl) {
+    const int ks = ch * KC + ksl;
+    if (TAIL && ks >= a.ksg) break;
+    // operand-plane offset of this k-step: (ky*WT + kx) pixels [+ channel block]; division by KW is a
+    // multiply-shift (exact for tap < 64), scalar in the WIDE case
+    int aoff;
+    if (NARROW) {
+      const int tap = min(ks * 4 + kq, a.ntaps - 1);
+      const int ky = (tap * a.kw_magic) >> 16;
+      aoff = (ky * a.WT + (tap - ky * a.KW)) * 16;
+    } else {
+      const int tap = min(ks >> a.log2cbg, a.ntaps - 1), cb = ks & ((1 << a.log2cbg) - 1);
+      const int ky = (tap * a.kw_magic) >> 16;
+      aoff = (ky * a.WT + (tap - ky * a.KW) + cb * 4 * a.NPIXP) * 16;
+    }
+    uint4 ah[MI], al[MI], wh[NI], wl[NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      ah[mi] = *reinterpret_cast<const uint4*>(smem + abase[mi] + aoff);
+      if (PRECISE) al[mi] = *reinterpret_cast<const uint4*>(smem + a.off_alo + abase[mi] + aoff);
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      wh[ni] = *reinterpret_cast<const uint4*>(bh + bbase[ni] + ksl * (4 * BN * 16));
+      if (PRECISE) wl[ni] = *reinterpret_cast<const uint4*>(bl + bbase[ni] + ksl * (4 * BN * 16));
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        if (PRECISE) {
+          acc[mi][ni] = mfma16(al[mi], wh[ni], acc[mi][ni]);
+          acc[mi][ni] = mfma16(ah[mi], wl[ni], acc[mi][ni]);
+        }
+        acc[mi][ni] = mfma16(ah[mi], wh[ni], acc[mi][ni]);
+      }
+  }
+}
+
+// B chunk `chunk_` -> registers R##h / R##l (k-step index is wave-uniform; clamped at the end of the reduction:
+// surplus k-steps are fetched but never multiplied)
+#define HDRSKY_LOAD_B(R, chunk_)                                                                          \
+  _Pragma("unroll") for (int j = 0; j < BPT; ++j) {                                                      \
+    const int ks_ = min((chunk_) * KC + j * RPP + bsub, a.ksg - 1);                                       \
+    int kp_;                                                                                              \
+    if (NARROW) kp_ = ks_;                                                                                \
+    else kp_ = (ks_ >> a.log2cbg) * cin32 + (g << a.log2cbg) + (ks_ & ((1 << a.log2cbg) - 1));           \
+    const size_t src_ = (size_t)(kp_ * 4) * a.Npad + boff;                                                \
+    R##h[j] = a.whi[src_];                                                                                \
+    if (PRECISE) R##l[j] = a.wlo[src_];                                                                   \
+  }
+#define HDRSKY_STORE_B(R, buf_)                                                                           \
+  _Pragma("unroll") for (int j = 0; j < BPT; ++j) {                                                      \
+    sB[((buf_) * BPLANES + 0) * BITEMS + tid + j * NT] = R##h[j];                                        \
+    if (PRECISE) sB[((buf_) * BPLANES + 1) * BITEMS + tid + j * NT] = R##l[j];                           \
+  }
+
+template <int WM, int WN, int MI, int NI, int TW, bool NARROW, bool PRECISE, bool DB>
+__global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const ConvKArgs a) {
+  constexpr int NW = WM * WN;                // waves per workgroup (4 or 8)
+  constexpr int NT = NW * 64;
   constexpr int BM = WM * MI * 16;
   constexpr int BN = WN * NI * 16;
   constexpr int TH = BM / TW;
   constexpr int FPR = TW / 16;               // M fragments per tile row
+  constexpr int KC = kc_for(BN);
   constexpr int BITEMS = KC * 4 * BN;        // uint4 per B chunk plane
-  constexpr int BPT = BITEMS / 256;          // per thread
-  static_assert(WM * WN == 4, "4 waves");
-  static_assert(BITEMS % 256 == 0, "B chunk must tile the block");
+  constexpr int BPT = BITEMS / NT;           // per thread
+  constexpr int BPLANES = PRECISE ? 2 : 1;
+  constexpr int BNP = BN + 4;                // padded row of the epilogue tile
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+  static_assert(BITEMS % NT == 0 && BPT >= 1, "B chunk must tile the block");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint4* sAhi = reinterpret_cast<uint4*>(smem);
@@ -77,7 +159,6 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvKArgs a) {
   float* sShift = sScale + a.Cin;
   int* sTap = reinterpret_cast<int*>(smem + a.off_tap);
   float* sStat = reinterpret_cast<float*>(smem + a.off_stat);
-  constexpr int BPLANES = PRECISE ? 2 : 1;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -85,7 +166,15 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvKArgs a) {
   const int wm = wave / WN, wn = wave % WN;
   const int kq = lane >> 4, lr = lane & 15;
 
-  int bid = blockIdx.x;
+  // XCD-aware order: hardware deals consecutive workgroup ids round-robin over the 8 XCDs (each with its
+  // own L2); remap so that each XCD owns a CONTIGUOUS range of logical tiles (= a few whole samples) and
+  // the activations are pulled through the fabric once, not once per XCD.  Bijective for any grid size.
+  int bid;
+  {
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int qd = nwg >> 3, rm = nwg & 7;
+    bid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+  }
   const int nb = bid % a.nblocks; bid /= a.nblocks;
   const int tx = bid % a.tiles_x; bid /= a.tiles_x;
   const int ty = bid % a.tiles_y;
@@ -93,16 +182,16 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvKArgs a) {
   const int oy0 = ty * TH, ox0 = tx * TW, n0 = nb * BN;
   const int iy0 = oy0 * a.stride - a.pad_t, ix0 = ox0 * a.stride - a.pad_l;
 
-  // ---- prologue: tap offset table + input transform tables ---------------------------------
-  for (int t = tid; t < a.ntaps; t += 256) sTap[t] = (t / a.KW) * a.WT + (t % a.KW);
-  const bool xf = a.in_mode != HDRSKY_IN_NONE;
+  HDRSKY_STAMP(0)
+  // ---- prologue: tap offset table + input transform tables (identity when in_mode == NONE) ----
+  for (int t = tid; t < a.ntaps; t += NT) sTap[t] = (t / a.KW) * a.WT + (t % a.KW);
   if (a.in_mode == HDRSKY_IN_AFFINE) {
-    for (int c = tid; c < a.Cin; c += 256) {
+    for (int c = tid; c < a.Cin; c += NT) {
       sScale[c] = a.in_scale[b * a.ss_bstride + c];
       sShift[c] = a.in_shift[b * a.ss_bstride + c];
     }
   } else if (a.in_mode == HDRSKY_IN_PARTIALS) {
-    for (int c = tid; c < a.Cin; c += 256) {
+    for (int c = tid; c < a.Cin; c += NT) {
       float s = 0.f, ss = 0.f;
       const float* pp = a.in_part + (size_t)b * a.in_nparts * 2 * a.Cin + c;
       for (int p = 0; p < a.in_nparts; ++p) {
@@ -115,8 +204,11 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvKArgs a) {
       sScale[c] = inv;
       sShift[c] = a.in_beta[c] - mean * inv;
     }
+  } else {
+    for (int c = tid; c < a.Cin; c += NT) { sScale[c] = 1.f; sShift[c] = 0.f; }
   }
   __syncthreads();
+  HDRSKY_STAMP(1)
 
   // ---- per-lane fragment bases ---------------------------------------------------------------
   int abase[MI];  // byte offset of this lane's A row (pixel) inside a plane (+ its k-quarter plane)
@@ -138,29 +230,33 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvKArgs a) {
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const int nchunks = (a.ksg + KC - 1) / KC;
+  constexpr int RPP = NT / (4 * BN);  // k-steps covered by one pass of the block over a B chunk
+  const int bsub = __builtin_amdgcn_readfirstlane(tid / (4 * BN));
+  const int boff = ((tid % (4 * BN)) / BN) * a.Npad + n0 + (tid % BN);  // (q, n) part of the packed index
   const int cin32 = a.Cin >> 5;
+  const float slope = a.in_slope;
 
   for (int g = 0; g < a.ngroups; ++g) {
-    if (g > 0) __syncthreads();  // everyone finished reading the previous group's planes
+    if (g > 0 && !DB) __syncthreads();  // everyone finished reading the previous group's planes
 
-    // ---- stage the halo patch of this channel group into LDS --------------------------------
+    // LDS-ring variant: first B chunk goes in flight before the (long) A staging
+    uint4 brh[BPT], brl[BPT];
+    if (!DB) { HDRSKY_LOAD_B(br, 0) }
+
+    // ---- stage the halo patch of this channel group into LDS (branch-free per item) ----------
     if (NARROW) {
-      for (int p = tid; p < a.NPIX; p += 256) {
+      for (int p = tid; p < a.NPIX; p += NT) {
         const int hy = (int)(((unsigned)p * (unsigned)a.wt_magic) >> 24);
         const int hx = p - hy * a.WT;
         const int cy = iy0 + hy, cx = ix0 + hx;
+        const bool ok = cy >= 0 && cy < a.Hc && cx >= 0 && cx < a.Wc;
+        const float* src = a.x + ((size_t)(b * a.H + (ok ? cy : 0)) * a.W + (ok ? cx : 0)) * a.Cin;
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = 0.f;
-        if (cy >= 0 && cy < a.Hc && cx >= 0 && cx < a.Wc) {
-          const float* src = a.x + ((size_t)(b * a.H + cy) * a.W + cx) * a.Cin;
-#pragma unroll
-          for (int j = 0; j < 8; ++j)
-            if (j < a.Cin) {
-              float t = src[j];
-              if (xf) t = t * sScale[j] + sShift[j];
-              v[j] = leaky(t, a.in_slope);
-            }
+        for (int j = 0; j < 8; ++j) {
+          const float t = src[j < a.Cin ? j : 0];
+          const float u = leaky(t * sScale[j < a.Cin ? j : 0] + sShift[j < a.Cin ? j : 0], slope);
+          v[j] = (ok && j < a.Cin) ? u : 0.f;
         }
         uint4 hi, lo;
         pack8<PRECISE>(v, hi, lo);
@@ -170,177 +266,267 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvKArgs a) {
     } else {
       const int nq = 1 << a.log2nq;
       const int nitems = a.NPIX << a.log2nq;
-      for (int i = tid; i < nitems; i += 256) {
-        const int p = i >> a.log2nq, q = i & (nq - 1);
-        const int hy = (int)(((unsigned)p * (unsigned)a.wt_magic) >> 24);
-        const int hx = p - hy * a.WT;
-        const int cy = iy0 + hy, cx = ix0 + hx;
-        const int c0 = g * a.cgs + q * 8;
-        float v[8];
+      const float* xb = a.x + (size_t)b * a.H * a.W * a.Cin + g * a.cgs;
+      // NT % nq == 0, so a thread always stages the same 8-channel chunk: its affine lives in registers
+      const int qt = tid & (nq - 1);
+      float sc8[8], sh8[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = 0.f;
-        if (cy >= 0 && cy < a.Hc && cx >= 0 && cx < a.Wc) {
-          const float* sc = sScale + c0;
-          const float* sh = sShift + c0;
-          const float* xb = a.x + (size_t)b * a.H * a.W * a.Cin + c0;
-          if (a.upsample == 2) {
-            // tf.image.resize BILINEAR, half-pixel centres: src = (dst+0.5)*0.5-0.5
-            const float sy = (cy + 0.5f) * 0.5f - 0.5f, sx = (cx + 0.5f) * 0.5f - 0.5f;
-            const float fy = floorf(sy), fx = floorf(sx);
-            const int ylo = max((int)fy, 0), yhi = min((int)ceilf(sy), a.H - 1);
-            const int xlo = max((int)fx, 0), xhi = min((int)ceilf(sx), a.W - 1);
-            const float ly = sy - fy, lx = sx - fx;
-            float tl[8], tr[8], bl[8], br[8];
-            load8_xf(xb + ((size_t)ylo * a.W + xlo) * a.Cin, sc, sh, xf, a.in_slope, tl);
-            load8_xf(xb + ((size_t)ylo * a.W + xhi) * a.Cin, sc, sh, xf, a.in_slope, tr);
-            load8_xf(xb + ((size_t)yhi * a.W + xlo) * a.Cin, sc, sh, xf, a.in_slope, bl);
-            load8_xf(xb + ((size_t)yhi * a.W + xhi) * a.Cin, sc, sh, xf, a.in_slope, br);
+      for (int j = 0; j < 8; ++j) { sc8[j] = sScale[g * a.cgs + qt * 8 + j]; sh8[j] = sShift[g * a.cgs + qt * 8 + j]; }
+      if (a.upsample == 2) {
+        for (int i = tid; i < nitems; i += NT) {
+          const int p = i >> a.log2nq, q = i & (nq - 1);
+          const int hy = (int)(((unsigned)p * (unsigned)a.wt_magic) >> 24);
+          const int hx = p - hy * a.WT;
+          const int cy = iy0 + hy, cx = ix0 + hx;
+          const bool ok = cy >= 0 && cy < a.Hc && cx >= 0 && cx < a.Wc;
+          // tf.image.resize BILINEAR, half-pixel centres: src = (dst+0.5)*0.5-0.5
+          const float sy = (cy + 0.5f) * 0.5f - 0.5f, sx = (cx + 0.5f) * 0.5f - 0.5f;
+          const float fy = floorf(sy), fx = floorf(sx);
+          const int ylo = min(max((int)fy, 0), a.H - 1), yhi = max(min((int)ceilf(sy), a.H - 1), 0);
+          const int xlo = min(max((int)fx, 0), a.W - 1), xhi = max(min((int)ceilf(sx), a.W - 1), 0);
+          const float ly = sy - fy, lx = sx - fx;
+          const float* s00 = xb + ((size_t)ylo * a.W + xlo) * a.Cin + q * 8;
+          const float* s01 = xb + ((size_t)ylo * a.W + xhi) * a.Cin + q * 8;
+          const float* s10 = xb + ((size_t)yhi * a.W + xlo) * a.Cin + q * 8;
+          const float* s11 = xb + ((size_t)yhi * a.W + xhi) * a.Cin + q * 8;
+          float4 t[8];
+          t[0] = *reinterpret_cast<const float4*>(s00); t[1] = *reinterpret_cast<const float4*>(s00 + 4);
+          t[2] = *reinterpret_cast<const float4*>(s01); t[3] = *reinterpret_cast<const float4*>(s01 + 4);
+          t[4] = *reinterpret_cast<const float4*>(s10); t[5] = *reinterpret_cast<const float4*>(s10 + 4);
+          t[6] = *reinterpret_cast<const float4*>(s11); t[7] = *reinterpret_cast<const float4*>(s11 + 4);
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float sc = sc8[j], sh = sh8[j];
+            const int w = j >> 2, e = j & 3;
+            const float tl = leaky(((const float*)&t[0 + w])[e] * sc + sh, slope);
+            const float tr = leaky(((const float*)&t[2 + w])[e] * sc + sh, slope);
+            const float bl = leaky(((const float*)&t[4 + w])[e] * sc + sh, slope);
+            const float br = leaky(((const float*)&t[6 + w])[e] * sc + sh, slope);
+            const float top = tl + (tr - tl) * lx;
+            const float bot = bl + (br - bl) * lx;
+            v[j] = ok ? top + (bot - top) * ly : 0.f;
+          }
+          uint4 hi, lo;
+          pack8<PRECISE>(v, hi, lo);
+          sAhi[q * a.NPIXP + p] = hi;
+          if (PRECISE) sAlo[q * a.NPIXP + p] = lo;
+        }
+      } else {
+        // plain / zero-stuffed operand: UNR items per thread, all loads issued before any use
+        constexpr int UNR = 4;
+        const int dummy = a.NPIXP - 1;  // pad slot of plane 0: never read
+        const int dsh = a.dilate == 2 ? 1 : 0;
+        for (int i0 = tid; i0 < nitems; i0 += NT * UNR) {
+          float4 va[UNR], vb[UNR];
+          bool ok[UNR];
+          int dst[UNR];
+#pragma unroll
+          for (int u = 0; u < UNR; ++u) {
+            const int i = i0 + u * NT;
+            const int ic = min(i, nitems - 1);
+            const int p = ic >> a.log2nq, q = ic & (nq - 1);
+            const int hy = (int)(((unsigned)p * (unsigned)a.wt_magic) >> 24);
+            const int hx = p - hy * a.WT;
+            int cy = iy0 + hy, cx = ix0 + hx;
+            bool v = cy >= 0 && cy < a.Hc && cx >= 0 && cx < a.Wc;
+            v = v && (((cy | cx) & dsh) == 0);  // zero-stuffed operand: odd positions are zeros
+            cy >>= dsh; cx >>= dsh;
+            ok[u] = v;
+            dst[u] = (i < nitems) ? q * a.NPIXP + p : dummy;
+            const float* src = xb + ((size_t)(v ? cy : 0) * a.W + (v ? cx : 0)) * a.Cin + q * 8;
+            va[u] = *reinterpret_cast<const float4*>(src);
+            vb[u] = *reinterpret_cast<const float4*>(src + 4);
+          }
+#pragma unroll
+          for (int u = 0; u < UNR; ++u) {
+            const float in[8] = {va[u].x, va[u].y, va[u].z, va[u].w, vb[u].x, vb[u].y, vb[u].z, vb[u].w};
+            float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-              const float top = tl[j] + (tr[j] - tl[j]) * lx;
-              const float bot = bl[j] + (br[j] - bl[j]) * lx;
-              v[j] = top + (bot - top) * ly;
+              const float t = leaky(in[j] * sc8[j] + sh8[j], slope);
+              v[j] = ok[u] ? t : 0.f;
             }
-          } else if (a.dilate == 2) {
-            if (((cy | cx) & 1) == 0)
-              load8_xf(xb + ((size_t)(cy >> 1) * a.W + (cx >> 1)) * a.Cin, sc, sh, xf, a.in_slope, v);
-          } else {
-            load8_xf(xb + ((size_t)cy * a.W + cx) * a.Cin, sc, sh, xf, a.in_slope, v);
+            uint4 hi, lo;
+            pack8<PRECISE>(v, hi, lo);
+            sAhi[dst[u]] = hi;
+            if (PRECISE) sAlo[dst[u]] = lo;
           }
         }
-        uint4 hi, lo;
-        pack8<PRECISE>(v, hi, lo);
-        sAhi[q * a.NPIXP + p] = hi;
-        if (PRECISE) sAlo[q * a.NPIXP + p] = lo;
       }
     }
+    if (g == 0) { HDRSKY_STAMP(2) }
 
-    // ---- B ring: chunk 0 ------------------------------------------------------------------------
-    uint4 breg[BPLANES][BPT];
-    auto load_b = [&](int chunk) {
+    if (DB) {
+      // ---- direct-B main loop: no LDS for weights, no barriers.  Each wave streams ITS B fragments
+      // (16-byte rows of the packed image, L2/L1-resident) into a rotating window of DPF k-steps of
+      // registers; a fragment's register is refilled right after the MFMAs that consumed it issue.
+      __syncthreads();  // operand planes staged
+      constexpr int DPF = (NI == 1) ? 8 : 4;
+      const uint4* wlh = a.whi + (size_t)kq * a.Npad + n0 + (wn * NI) * 16 + lr;
+      const uint4* wll = PRECISE ? a.wlo + (size_t)kq * a.Npad + n0 + (wn * NI) * 16 + lr : nullptr;
+      const size_t kstride = (size_t)4 * a.Npad;
+      uint4 bqh[DPF][NI], bql[DPF][NI];
+      auto kp_of = [&](int ks) {
+        const int kc = min(ks, a.ksg - 1);
+        return NARROW ? kc : (kc >> a.log2cbg) * cin32 + (g << a.log2cbg) + (kc & ((1 << a.log2cbg) - 1));
+      };
 #pragma unroll
-      for (int j = 0; j < BPT; ++j) {
-        const int i = tid + j * 256;
-        const int ksl = i / (4 * BN);
-        const int rem = i - ksl * (4 * BN);
-        const int q = rem / BN, n = rem - q * BN;
-        const int ks = chunk * KC + ksl;
-        uint4 vh = uint4{0, 0, 0, 0}, vl = uint4{0, 0, 0, 0};
-        if (ks < a.ksg) {
-          int kp;
-          if (NARROW) kp = ks;
-          else kp = (ks >> a.log2cbg) * cin32 + (g << a.log2cbg) + (ks & ((1 << a.log2cbg) - 1));
-          const size_t src = ((size_t)(kp * 4 + q) * a.Npad + n0 + n);
-          vh = a.whi[src];
-          if (PRECISE) vl = a.wlo[src];
+      for (int j = 0; j < DPF; ++j) {
+        const size_t o = (size_t)kp_of(j) * kstride;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          bqh[j][ni] = wlh[o + ni * 16];
+          if (PRECISE) bql[j][ni] = wll[o + ni * 16];
         }
-        breg[0][j] = vh;
-        if (PRECISE) breg[BPLANES - 1][j] = vl;
       }
-    };
-    auto store_b = [&](int buf) {
+      for (int ks0 = 0; ks0 < a.ksg; ks0 += DPF) {
+        const bool full = ks0 + DPF <= a.ksg;
 #pragma unroll
-      for (int j = 0; j < BPT; ++j) {
-        sB[(buf * BPLANES + 0) * BITEMS + tid + j * 256] = breg[0][j];
-        if (PRECISE) sB[(buf * BPLANES + 1) * BITEMS + tid + j * 256] = breg[BPLANES - 1][j];
-      }
-    };
-    load_b(0);
-    store_b(0);
-    __syncthreads();
-
-    for (int ch = 0; ch < nchunks; ++ch) {
-      const int buf = ch & 1;
-      if (ch + 1 < nchunks) load_b(ch + 1);
-      const unsigned char* bh = reinterpret_cast<const unsigned char*>(sB + (buf * BPLANES) * BITEMS);
-      const unsigned char* bl = reinterpret_cast<const unsigned char*>(sB + (buf * BPLANES + 1) * BITEMS);
+        for (int j = 0; j < DPF; ++j) {
+          const int ks = ks0 + j;
+          if (full || ks < a.ksg) {
+            int aoff;
+            if (NARROW) {
+              const int tap = min(ks * 4 + kq, a.ntaps - 1);
+              const int ky = (tap * a.kw_magic) >> 16;
+              aoff = (ky * a.WT + (tap - ky * a.KW)) * 16;
+            } else {
+              const int tap = ks >> a.log2cbg, cb = ks & ((1 << a.log2cbg) - 1);
+              const int ky = (tap * a.kw_magic) >> 16;
+              aoff = (ky * a.WT + (tap - ky * a.KW) + cb * 4 * a.NPIXP) * 16;
+            }
+            uint4 ah[MI], al[MI];
 #pragma unroll
-      for (int ksl = 0; ksl < KC; ++ksl) {
-        const int ks = ch * KC + ksl;
-        if (ks < a.ksg) {
-          int aoff;
-          if (NARROW) {
-            const int tap = min(ks * 4 + kq, a.ntaps - 1);
-            aoff = sTap[tap] * 16;
-          } else {
-            const int tap = ks >> a.log2cbg, cb = ks & ((1 << a.log2cbg) - 1);
-            aoff = (sTap[tap] + cb * 4 * a.NPIXP) * 16;
-          }
-          uint4 ah[MI], al[MI], wh[NI], wl[NI];
+            for (int mi = 0; mi < MI; ++mi) {
+              ah[mi] = *reinterpret_cast<const uint4*>(smem + abase[mi] + aoff);
+              if (PRECISE) al[mi] = *reinterpret_cast<const uint4*>(smem + a.off_alo + abase[mi] + aoff);
+            }
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi) {
-            ah[mi] = *reinterpret_cast<const uint4*>(smem + abase[mi] + aoff);
-            if (PRECISE) al[mi] = *reinterpret_cast<const uint4*>(smem + a.off_alo + abase[mi] + aoff);
-          }
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni) {
-            wh[ni] = *reinterpret_cast<const uint4*>(bh + bbase[ni] + ksl * (4 * BN * 16));
-            if (PRECISE) wl[ni] = *reinterpret_cast<const uint4*>(bl + bbase[ni] + ksl * (4 * BN * 16));
-          }
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi)
+              for (int ni = 0; ni < NI; ++ni) {
+                if (PRECISE) {
+                  acc[mi][ni] = mfma16(al[mi], bqh[j][ni], acc[mi][ni]);
+                  acc[mi][ni] = mfma16(ah[mi], bql[j][ni], acc[mi][ni]);
+                }
+                acc[mi][ni] = mfma16(ah[mi], bqh[j][ni], acc[mi][ni]);
+              }
+            const size_t o = (size_t)kp_of(ks + DPF) * kstride;  // clamped at the end: surplus loads are unused
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
-              if (PRECISE) {
-                acc[mi][ni] = mfma16(al[mi], wh[ni], acc[mi][ni]);
-                acc[mi][ni] = mfma16(ah[mi], wl[ni], acc[mi][ni]);
-              }
-              acc[mi][ni] = mfma16(ah[mi], wh[ni], acc[mi][ni]);
+              bqh[j][ni] = wlh[o + ni * 16];
+              if (PRECISE) bql[j][ni] = wll[o + ni * 16];
             }
+          }
         }
       }
-      if (ch + 1 < nchunks) store_b(buf ^ 1);
+      __syncthreads();  // all waves done with the operand planes (next group restages / epilogue reuses them)
+    } else {
+      // ---- B ring: LDS double buffer; chunk ch+1 is fetched into registers at the top of iteration ch
+      // and written to the other buffer after the MFMAs of chunk ch (registers are not loop-carried).
+      HDRSKY_STORE_B(br, 0)
       __syncthreads();
+      unsigned long long tl = 0, tc = 0, ts = 0, tb = 0;  // debug: cycles in load-issue / MFMA / LDS-store(+load wait) / barrier
+      for (int ch = 0; ch < nchunks; ++ch) {
+        uint4 nxh[BPT], nxl[BPT];
+        const bool dbg = a.stamps != nullptr;
+        unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+        if (dbg) t0 = __builtin_amdgcn_s_memtime();
+        HDRSKY_LOAD_B(nx, ch + 1)
+        if (dbg) t1 = __builtin_amdgcn_s_memtime();
+        if (ch + 1 < nchunks)
+          compute_chunk<MI, NI, BN, KC, BPLANES, BITEMS, NARROW, PRECISE, false>(a, smem, sB, sTap, ch, kq, abase, bbase, acc);
+        else
+          compute_chunk<MI, NI, BN, KC, BPLANES, BITEMS, NARROW, PRECISE, true>(a, smem, sB, sTap, ch, kq, abase, bbase, acc);
+        if (dbg) { asm volatile("" ::"v"(acc[0][0][0])); t2 = __builtin_amdgcn_s_memtime(); }
+        HDRSKY_STORE_B(nx, (ch + 1) & 1)
+        if (dbg) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); t3 = __builtin_amdgcn_s_memtime(); }
+        __syncthreads();
+        if (dbg) { t4 = __builtin_amdgcn_s_memtime(); tl += t1 - t0; tc += t2 - t1; ts += t3 - t2; tb += t4 - t3; }
+      }
+      if (a.stamps != nullptr && tid == 0 && g == 0) {
+        unsigned long long* d = a.stamps + (size_t)gridDim.x * 8 + (size_t)blockIdx.x * 4;
+        d[0] = tl; d[1] = tc; d[2] = ts; d[3] = tb;
+      }
     }
   }
 
-  // ---- epilogue -----------------------------------------------------------------------------------
-  float csum[NI], csq[NI];
+  HDRSKY_STAMP(3)
+  // ---- epilogue: accumulators -> LDS tile [BM][BN] -> coalesced 16-byte rows ------------------------
+  // (the last __syncthreads of the ring guarantees every wave is done reading the operand planes)
+  float* sOut = reinterpret_cast<float*>(smem);
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni) { csum[ni] = 0.f; csq[ni] = 0.f; }
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const int n = n0 + (wn * NI + ni) * 16 + lr;
-    const bool nok = n < a.Cout;
-    const float bv = (a.bias != nullptr && nok) ? a.bias[n] : 0.f;
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const int f = wm * MI + mi;
-      const int oy = oy0 + f / FPR;
-      const int oxb = ox0 + (f % FPR) * 16 + kq * 4;
+      for (int j = 0; j < 4; ++j)
+        sOut[((wm * MI + mi) * 16 + kq * 4 + j) * BNP + (wn * NI + ni) * 16 + lr] = acc[mi][ni][j];
+  __syncthreads();
+  constexpr int C4 = BN / 4;          // float4 columns
+  constexpr int PPI = NT / C4;        // pixels per pass
+  const int c4 = tid % C4;
+  const int n = n0 + c4 * 4;
+  float bias4[4], cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int ox = oxb + j;
-        if (nok && oy < a.Ho && ox < a.Wo) {
-          float v = acc[mi][ni][j] + bv;
-          csum[ni] += v;
-          csq[ni] += v * v;
-          const size_t idx = ((size_t)(b * a.Ho + oy) * a.Wo + ox) * a.Cout + n;
-          if (a.out_slope != 1.f) v = leaky(v, a.out_slope);
-          if (a.residual != nullptr) v += a.residual[idx];
-          if (a.final_relu) v = fmaxf(v, 0.f);
-          a.y[idx] = v;
+  for (int e = 0; e < 4; ++e) bias4[e] = (a.bias != nullptr && n + e < a.Cout) ? a.bias[n + e] : 0.f;
+  const bool vec = ((a.Cout & 3) == 0) && (n + 3 < a.Cout);
+#pragma unroll
+  for (int it = 0; it * PPI < BM; ++it) {
+    const int m = it * PPI + tid / C4;           // tile-local pixel (fragment-major order)
+    const int f = m >> 4;
+    const int oy = oy0 + f / FPR, ox = ox0 + (f % FPR) * 16 + (m & 15);
+    if (m < BM && oy < a.Ho && ox < a.Wo) {
+      const float4 t = *reinterpret_cast<const float4*>(sOut + m * BNP + c4 * 4);
+      float v[4] = {t.x + bias4[0], t.y + bias4[1], t.z + bias4[2], t.w + bias4[3]};
+      const size_t idx = ((size_t)(b * a.Ho + oy) * a.Wo + ox) * a.Cout + n;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (n + e < a.Cout) { cs[e] += v[e]; cq[e] += v[e] * v[e]; }
+        v[e] = leaky(v[e], a.out_slope);
+      }
+      if (vec) {
+        if (a.residual != nullptr) {
+          const float4 r = *reinterpret_cast<const float4*>(a.residual + idx);
+          v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
         }
+        if (a.final_relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        *reinterpret_cast<float4*>(a.y + idx) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n + e < a.Cout) {
+            float o = v[e];
+            if (a.residual != nullptr) o += a.residual[idx + e];
+            if (a.final_relu) o = fmaxf(o, 0.f);
+            a.y[idx + e] = o;
+          }
       }
     }
   }
   if (a.want_stats) {
+    // lanes holding the same float4 column are C4 apart inside a wave
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      float s = csum[ni], q = csq[ni];
-      s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
-      q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
-      if (kq == 0) {
-        const int col = (wn * NI + ni) * 16 + lr;
-        sStat[(wm * BN + col) * 2 + 0] = s;
-        sStat[(wm * BN + col) * 2 + 1] = q;
+    for (int o = C4; o < 64; o <<= 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { cs[e] += __shfl_xor(cs[e], o); cq[e] += __shfl_xor(cq[e], o); }
+    }
+    if (lane < C4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sStat[(wave * BN + c4 * 4 + e) * 2 + 0] = cs[e];
+        sStat[(wave * BN + c4 * 4 + e) * 2 + 1] = cq[e];
       }
     }
     __syncthreads();
     if (tid < BN && n0 + tid < a.Cout) {
       float s = 0.f, q = 0.f;
 #pragma unroll
-      for (int w = 0; w < WM; ++w) {
+      for (int w = 0; w < NW; ++w) {
         s += sStat[(w * BN + tid) * 2 + 0];
         q += sStat[(w * BN + tid) * 2 + 1];
       }
@@ -350,6 +536,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvKArgs a) {
       dst[a.Cout] = q;
     }
   }
+  HDRSKY_STAMP(5)
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -358,7 +545,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvKArgs a) {
 __global__ void pack_weights_kernel(const float* __restrict__ w, int KH, int KW, int Cin, int Cout, int Npad,
                                     int narrow, int flip, int ksteps, unsigned short* __restrict__ hi,
                                     unsigned short* __restrict__ lo) {
-  const size_t total = (size_t)ksteps * 4 * Npad * 8;
+  const size_t total = (size_t)(ksteps + 1) * 4 * Npad * 8;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int j = i & 7;
     size_t r = i >> 3;
@@ -369,7 +556,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int KH, int KW,
     if (narrow) { tap = kp * 4 + q; c = j; }
     else { const int cin32 = Cin >> 5; tap = kp / cin32; c = (kp % cin32) * 32 + q * 8 + j; }
     float v = 0.f;
-    if (tap < KH * KW && c < Cin && n < Cout) {
+    if (kp < ksteps && tap < KH * KW && c < Cin && n < Cout) {
       int ky = tap / KW, kx = tap % KW;
       if (flip) {
         // packed filter w'[ky,kx,c(=co of w),n(=ci of w)] = w[KH-1-ky, KW-1-kx, n, c]; w is [KH,KW,Cout',Cin'] = [.., n-range, c-range]
@@ -396,9 +583,9 @@ int ilog2(int v) {
   return l;
 }
 
-struct TileCfg { int wm, wn, mi, ni, tw; };
+struct TileCfg { int wm, wn, mi, ni, tw, db; };
 
-template <int WM, int WN, int MI, int NI, int TW, bool NARROW, bool PRECISE>
+template <int WM, int WN, int MI, int NI, int TW, bool NARROW, bool PRECISE, bool DB>
 int launch_conv(ConvKArgs& a, hipStream_t stream) {
   constexpr int BM = WM * MI * 16, BN = WN * NI * 16, TH = BM / TW;
   a.tiles_x = cdiv(a.Wo, TW);
@@ -407,12 +594,15 @@ int launch_conv(ConvKArgs& a, hipStream_t stream) {
   a.HT = (TH - 1) * a.stride + a.KH;
   a.WT = (TW - 1) * a.stride + a.KW;
   a.NPIX = a.HT * a.WT;
-  a.NPIXP = roundup(a.NPIX, 16) + (a.stride == 2 ? 1 : 0);
+  a.NPIXP = roundup(a.NPIX, 16) + 1;  // = 1 (mod 16): conflict-free ds_write_b128 of the staging, <=1 two-way slot on reads
   a.wt_magic = ((1 << 24) + a.WT - 1) / a.WT;
+  a.kw_magic = (65536 + a.KW - 1) / a.KW;
   a.ntaps = a.KH * a.KW;
   const int bplanes = PRECISE ? 2 : 1;
-  const int b_bytes = 2 * bplanes * KC * 4 * BN * 16;
-  const int misc = 2 * a.Cin * 4 + roundup(a.ntaps, 4) * 4 + WM * BN * 2 * 4;
+  constexpr int KC = kc_for(BN);
+  const int b_bytes = DB ? 0 : 2 * bplanes * KC * 4 * BN * 16;
+  constexpr int NW = WM * WN;
+  const int misc = 2 * a.Cin * 4 + roundup(a.ntaps, 4) * 4 + NW * BN * 2 * 4;
   const int budget = 160 * 1024 - b_bytes - roundup(misc, 16) - 64;
   if (NARROW) {
     a.cgs = 8; a.ngroups = 1; a.log2nq = 0; a.log2cbg = 0;
@@ -431,9 +621,13 @@ int launch_conv(ConvKArgs& a, hipStream_t stream) {
   a.off_ss = a.off_b + b_bytes;
   a.off_tap = a.off_ss + 2 * a.Cin * 4;
   a.off_stat = roundup(a.off_tap + a.ntaps * 4, 16);
-  const int lds = a.off_stat + WM * BN * 2 * 4;
+  int lds = a.off_stat + NW * BN * 2 * 4;
+  // the epilogue re-uses the operand planes (from offset 0) as a [BM][BN+4] fp32 tile; it must not reach
+  // the stat scratch
+  const int out_bytes = BM * (BN + 4) * 4;
+  if (out_bytes > a.off_stat) { a.off_stat = roundup(out_bytes, 16); lds = a.off_stat + NW * BN * 2 * 4; }
   if (lds > 160 * 1024) return HDRSKY_EUNSUPPORTED;
-  auto kern = conv_igemm_kernel<WM, WN, MI, NI, TW, NARROW, PRECISE>;
+  auto kern = conv_igemm_kernel<WM, WN, MI, NI, TW, NARROW, PRECISE, DB>;
   static int max_lds_set = 0;
   if (lds > max_lds_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -442,7 +636,7 @@ int launch_conv(ConvKArgs& a, hipStream_t stream) {
     max_lds_set = 160 * 1024;
   }
   const int grid = a.B * a.tiles_y * a.tiles_x * a.nblocks;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, stream, a);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }
@@ -450,14 +644,22 @@ int launch_conv(ConvKArgs& a, hipStream_t stream) {
 template <bool NARROW, bool PRECISE>
 int dispatch_tile(ConvKArgs& a, const TileCfg& t, hipStream_t s) {
 #define HDRSKY_CASE(WM_, WN_, MI_, NI_, TW_)                                              \
-  if (t.wm == WM_ && t.wn == WN_ && t.mi == MI_ && t.ni == NI_ && t.tw == TW_)           \
-    return launch_conv<WM_, WN_, MI_, NI_, TW_, NARROW, PRECISE>(a, s);
-  // BN = 64
+  if (!t.db && t.wm == WM_ && t.wn == WN_ && t.mi == MI_ && t.ni == NI_ && t.tw == TW_) \
+    return launch_conv<WM_, WN_, MI_, NI_, TW_, NARROW, PRECISE, false>(a, s);
+#define HDRSKY_CASE_DB(WM_, WN_, MI_, NI_, TW_)                                           \
+  if (t.db && t.wm == WM_ && t.wn == WN_ && t.mi == MI_ && t.ni == NI_ && t.tw == TW_)  \
+    return launch_conv<WM_, WN_, MI_, NI_, TW_, NARROW, PRECISE, true>(a, s);
+  // LDS-ring variant
   HDRSKY_CASE(2, 2, 4, 2, 32) HDRSKY_CASE(2, 2, 2, 2, 32) HDRSKY_CASE(2, 2, 2, 2, 16)
-  // BN = 32
   HDRSKY_CASE(4, 1, 4, 2, 32) HDRSKY_CASE(4, 1, 2, 2, 32) HDRSKY_CASE(2, 2, 2, 1, 32) HDRSKY_CASE(2, 2, 2, 1, 16)
-  // BN = 16
   HDRSKY_CASE(4, 1, 4, 1, 32) HDRSKY_CASE(4, 1, 2, 1, 32) HDRSKY_CASE(4, 1, 1, 1, 16)
+  HDRSKY_CASE(2, 4, 2, 1, 32) HDRSKY_CASE(4, 2, 2, 2, 32) HDRSKY_CASE(4, 2, 2, 1, 32) HDRSKY_CASE(8, 1, 2, 2, 32)
+  HDRSKY_CASE(8, 1, 4, 2, 32) HDRSKY_CASE(2, 4, 2, 1, 16) HDRSKY_CASE(8, 1, 2, 1, 32)
+  // direct-B variant (weights streamed per wave, barrier-free main loop)
+  HDRSKY_CASE_DB(1, 4, 4, 1, 32) HDRSKY_CASE_DB(2, 4, 4, 1, 32) HDRSKY_CASE_DB(1, 8, 4, 1, 32) HDRSKY_CASE_DB(2, 2, 4, 1, 32)
+  HDRSKY_CASE_DB(4, 2, 4, 1, 32) HDRSKY_CASE_DB(2, 4, 2, 1, 32) HDRSKY_CASE_DB(4, 1, 4, 1, 32) HDRSKY_CASE_DB(8, 1, 4, 1, 32)
+  HDRSKY_CASE_DB(1, 4, 4, 1, 16) HDRSKY_CASE_DB(1, 4, 2, 1, 16) HDRSKY_CASE_DB(2, 2, 4, 2, 32) HDRSKY_CASE_DB(2, 4, 4, 2, 32)
+#undef HDRSKY_CASE_DB
 #undef HDRSKY_CASE
   return HDRSKY_EUNSUPPORTED;
 }
@@ -465,30 +667,46 @@ int dispatch_tile(ConvKArgs& a, const TileCfg& t, hipStream_t s) {
 // Tile heuristic: widest N block the layer fills, then the largest pixel tile that still
 // yields >= ~1 workgroup per CU (256 CUs), preferring more workgroups for small problems.
 TileCfg choose_tile(const hdrsky_conv_desc* d) {
-  const int bn = d->Cout >= 64 ? 64 : (d->Cout >= 32 ? 32 : 16);
+  if (const char* e = getenv("HDRSKY_TILE")) {  // tuning hook: "wm,wn,mi,ni,tw"
+    TileCfg o;
+    o.db = 0;
+    if (sscanf(e, "%d,%d,%d,%d,%d,%d", &o.wm, &o.wn, &o.mi, &o.ni, &o.tw, &o.db) >= 5) return o;
+  }
+  // Measured on MI355X (profiles/microbench_conv.py, B=32, 32x128 network): these layers are bound by
+  // per-CU operand traffic and instruction issue, not MFMA, so the table prefers 8-wave workgroups
+  // (two waves per SIMD) and, for Cout >= 64, the barrier-free direct-B main loop.
   const int tw = (d->Wo >= 32) ? 32 : 16;
-  const int nblk = cdiv(d->Cout, bn);
-  auto wgs = [&](int bm) { return d->B * cdiv(d->Ho, bm / tw) * cdiv(d->Wo, tw) * nblk; };
-  TileCfg t;
-  t.tw = tw;
-  if (bn == 64) {
-    if (tw == 32 && wgs(128) >= 256) t = TileCfg{2, 2, 4, 2, 32};
-    else t = TileCfg{2, 2, 2, 2, tw};
-  } else if (bn == 32) {
-    if (tw == 32 && wgs(256) >= 256) t = TileCfg{4, 1, 4, 2, 32};
-    else if (tw == 32 && wgs(128) >= 256) t = TileCfg{4, 1, 2, 2, 32};
-    else t = TileCfg{2, 2, 2, 1, tw};
+  const long M = (long)d->B * d->Ho * d->Wo;
+  const bool narrow = d->Cin <= 8;
+  TileCfg t{2, 2, 2, 2, tw, 0};
+  if (tw == 16) {
+    if (d->Cout >= 64) t = (d->Ho >= 4) ? TileCfg{1, 4, 4, 1, 16, 1} : TileCfg{1, 4, 2, 1, 16, 1};
+    else if (d->Cout > 16) t = TileCfg{2, 2, 2, 1, 16, 0};
+    else t = TileCfg{4, 1, 1, 1, 16, 0};
+  } else if (d->Cout >= 64) {
+    if (d->Cout >= 256 && M <= 16384) t = TileCfg{1, 8, 4, 1, 32, 1};   // 64 px x 128 ch
+    else if (M <= 16384) t = TileCfg{2, 4, 2, 1, 32, 1};               // 64 px x 64 ch, 8 waves
+    else t = TileCfg{2, 4, 4, 1, 32, 1};                               // 128 px x 64 ch, 8 waves
+  } else if (d->Cout > 16) {
+    if (M >= 65536) t = narrow ? TileCfg{4, 2, 4, 1, 32, 1} : TileCfg{8, 1, 4, 2, 32, 0};  // 256 px x 32 ch
+    else t = TileCfg{2, 2, 4, 1, 32, 1};                               // 128 px x 32 ch
   } else {
-    if (tw == 32 && wgs(256) >= 256) t = TileCfg{4, 1, 4, 1, 32};
-    else if (tw == 32) t = TileCfg{4, 1, 2, 1, 32};
-    else t = TileCfg{4, 1, 1, 1, 16};
+    // Cout <= 16 (the 3-channel output convs): the 32-wide column block (zero-padded weights) measured
+    // faster than the 16-wide one
+    if (M >= 65536) t = TileCfg{8, 1, 4, 2, 32, 0};
+    else t = TileCfg{4, 1, 2, 1, 32, 0};
   }
   return t;
 }
 
 }  // namespace
 
+static unsigned long long* g_stamps = nullptr;
+
 extern "C" {
+
+/* debug only: per-workgroup s_memtime stamps of subsequent conv launches (8 x u64 per workgroup); null disables */
+void hdrsky_debug_conv_stamps(void* buf) { g_stamps = (unsigned long long*)buf; }
 
 const char* hdrsky_version(void) { return "hdrsky 0.1 (gfx950)"; }
 
@@ -516,7 +734,7 @@ int hdrsky_conv_desc_init(hdrsky_conv_desc* d, int B, int H, int W, int Cin, int
 }
 
 size_t hdrsky_conv_packed_elems(int KH, int KW, int Cin, int Cout) {
-  return (size_t)conv_ksteps(KH, KW, Cin) * 4 * roundup(Cout, 64) * 8;
+  return (size_t)(conv_ksteps(KH, KW, Cin) + 1) * 4 * roundup(Cout, 64) * 8;  // + one all-zero k-step
 }
 
 int hdrsky_conv_pack_weights(const float* w, int KH, int KW, int Cin, int Cout, int transpose_flip, void* packed_hi,
@@ -525,7 +743,7 @@ int hdrsky_conv_pack_weights(const float* w, int KH, int KW, int Cin, int Cout, 
   if (Cin > 8 && (Cin % 32) != 0) return HDRSKY_EUNSUPPORTED;
   const int ks = conv_ksteps(KH, KW, Cin);
   const int Npad = roundup(Cout, 64);
-  const size_t total = (size_t)ks * 4 * Npad * 8;
+  const size_t total = (size_t)(ks + 1) * 4 * Npad * 8;
   const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   hipLaunchKernelGGL(pack_weights_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, KH, KW, Cin, Cout, Npad,
                      Cin <= 8 ? 1 : 0, transpose_flip, ks, (unsigned short*)packed_hi, (unsigned short*)packed_lo);
@@ -560,11 +778,13 @@ int hdrsky_conv2d_fwd(const hdrsky_conv_desc* d, const float* x, const void* w_h
   a.residual = residual; a.y = y; a.stats = stats_part;
   a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
   a.Npad = roundup(d->Cout, 64);
+  a.kzero = conv_ksteps(d->KH, d->KW, d->Cin);
   a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad_t = d->pad_t; a.pad_l = d->pad_l;
   a.upsample = d->upsample; a.dilate = d->dilate; a.Hc = d->Hc; a.Wc = d->Wc;
   a.in_mode = d->in_mode; a.ss_bstride = d->ss_bstride; a.in_nparts = d->in_nparts;
   a.in_eps = d->in_eps; a.in_inv_count = 1.f / (float)(d->H * d->W); a.in_slope = d->in_slope;
   a.out_slope = d->out_slope; a.final_relu = d->final_relu; a.want_stats = d->want_stats;
+  a.stamps = g_stamps;
   const TileCfg t = choose_tile(d);
   hipStream_t s = (hipStream_t)stream;
   if (narrow) return precise ? dispatch_tile<true, true>(a, t, s) : dispatch_tile<true, false>(a, t, s);

@@ -390,11 +390,22 @@ __global__ void __launch_bounds__(256) spatial_sum_kernel(const float* __restric
 }
 
 // cam[b][p] = relu(sum_c w[b][c] * A[b][p][c])   (grad_cam.py:35-38); one wave per pixel group
-__global__ void __launch_bounds__(256) cam_kernel(const float* __restrict__ A, const float* __restrict__ w, int P,
-                                                  int C, float* __restrict__ cam) {
+__global__ void __launch_bounds__(256) cam_kernel(const float* __restrict__ A, const float* __restrict__ w,
+                                                  int w_nparts, float w_scale, int P, int C,
+                                                  float* __restrict__ cam) {
   extern __shared__ float sw[];
   const int b = blockIdx.y;
-  for (int c = threadIdx.x; c < C; c += 256) sw[c] = w[(size_t)b * C + c];
+  // w_nparts == 0: w is a [B][C] table; else w is a conv statistics tensor [B][nparts][2][C] whose sum plane is
+  // reduced here (the GAP of the activation gradient, grad_cam.py:34)
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float t;
+    if (w_nparts == 0) t = w[(size_t)b * C + c];
+    else {
+      t = 0.f;
+      for (int p = 0; p < w_nparts; ++p) t += w[((size_t)(b * w_nparts + p) * 2) * C + c];
+    }
+    sw[c] = t * w_scale;
+  }
   __syncthreads();
   const int c4 = C >> 2;                    // threads per pixel
   const int ppb = 256 / c4;                 // pixels per block iteration
@@ -433,47 +444,59 @@ __global__ void plz_kernel(const float* __restrict__ ldr, const float* __restric
   o[5] = bilinear_1ch(cam3 + (size_t)b * (H / 4) * (W / 4), H / 4, W / 4, oy, ox, H, W);
 }
 
-// gamma/beta heads of sunRadNet (sunrad_net.py:52-59): flat = leaky(x*scale[c]+shift[c], slope),
-// out = sigmoid(flat . k + bias) for the two Dense(1) layers.  One block per sample.
+// gamma/beta heads of sunRadNet (sunrad_net.py:52-59), stage 1: flat = leaky(x*scale[c]+shift[c], slope);
+// each block reduces one slice of the two Dense(1) dot products -> part[b][slice][2] (fixed order: deterministic).
 __global__ void __launch_bounds__(256) dense_heads_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, float slope, int F, int C,
-                                                          const float* __restrict__ kg, const float* __restrict__ bg,
-                                                          const float* __restrict__ kb, const float* __restrict__ bb,
-                                                          float* __restrict__ gamma_out, float* __restrict__ beta_out) {
+                                                          const float* __restrict__ kg, const float* __restrict__ kb,
+                                                          int S, float* __restrict__ part) {
   __shared__ float sred[2][4];
-  const int b = blockIdx.x;
+  const int b = blockIdx.x / S, sl = blockIdx.x % S;
+  const int per = (F / 4 + S - 1) / S;  // float4 items per slice
+  const int beg = sl * per, end = min(F / 4, beg + per);
   float sg = 0.f, sb = 0.f;
-  for (int i = threadIdx.x; i < F; i += 256) {
-    const int c = i % C;
-    float v = x[(size_t)b * F + i];
-    if (scale) v = v * scale[c] + shift[c];
-    v = leaky(v, slope);
-    sg += v * kg[i];
-    sb += v * kb[i];
+  const float4* x4 = reinterpret_cast<const float4*>(x + (size_t)b * F);
+  const float4* g4 = reinterpret_cast<const float4*>(kg);
+  const float4* b4 = reinterpret_cast<const float4*>(kb);
+  for (int i = beg + threadIdx.x; i < end; i += 256) {
+    const int c = (i * 4) % C;
+    float4 v = x4[i];
+    if (scale) {
+      v.x = v.x * scale[c] + shift[c]; v.y = v.y * scale[c + 1] + shift[c + 1];
+      v.z = v.z * scale[c + 2] + shift[c + 2]; v.w = v.w * scale[c + 3] + shift[c + 3];
+    }
+    v.x = leaky(v.x, slope); v.y = leaky(v.y, slope); v.z = leaky(v.z, slope); v.w = leaky(v.w, slope);
+    const float4 wg = g4[i], wb = b4[i];
+    sg += v.x * wg.x + v.y * wg.y + v.z * wg.z + v.w * wg.w;
+    sb += v.x * wb.x + v.y * wb.y + v.z * wb.z + v.w * wb.w;
   }
   sg = wave_sum(sg); sb = wave_sum(sb);
   if ((threadIdx.x & 63) == 0) { sred[0][threadIdx.x >> 6] = sg; sred[1][threadIdx.x >> 6] = sb; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const float g = (sred[0][0] + sred[0][1]) + (sred[0][2] + sred[0][3]) + bg[0];
-    const float t = (sred[1][0] + sred[1][1]) + (sred[1][2] + sred[1][3]) + bb[0];
-    gamma_out[b] = 1.f / (1.f + expf(-g));
-    beta_out[b] = 1.f / (1.f + expf(-t));
+    part[((size_t)b * S + sl) * 2 + 0] = (sred[0][0] + sred[0][1]) + (sred[0][2] + sred[0][3]);
+    part[((size_t)b * S + sl) * 2 + 1] = (sred[1][0] + sred[1][1]) + (sred[1][2] + sred[1][3]);
   }
 }
 
-// Dirac-delta sun radiance (sunrad_net.py:61-69 + generator.py:160,167 + tf_utils.py:263-271):
+// stage 2 + Dirac-delta sun radiance (sunrad_net.py:54-69 + generator.py:160,167 + tf_utils.py:263-271):
+//   gamma/beta = sigmoid(sum_slices part + bias)
 //   x = cmf / max(cmf); rad = min(gamma*exp(-(1-x)^2/(beta+1e-5)) / (beta*sqrt(pi)+1e-5), 30000)
 // writes rad tiled to 3 channels and its log-compressed (gamma-domain) image.
 __global__ void sun_rad_kernel(const float* __restrict__ cmf, const unsigned int* __restrict__ gmax_bits,
-                               const float* __restrict__ gamma, const float* __restrict__ beta, int B, int P,
-                               float* __restrict__ rad_lin3, float* __restrict__ rad_gamma3) {
+                               const float* __restrict__ part, int S, const float* __restrict__ bg,
+                               const float* __restrict__ bb, int B, int P, float* __restrict__ gamma_out,
+                               float* __restrict__ beta_out, float* __restrict__ rad_lin3,
+                               float* __restrict__ rad_gamma3) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * P) return;
   const int b = i / P;
+  float ag = bg[0], ab = bb[0];
+  for (int s = 0; s < S; ++s) { ag += part[((size_t)b * S + s) * 2]; ab += part[((size_t)b * S + s) * 2 + 1]; }
+  const float g = 1.f / (1.f + expf(-ag)), bt = 1.f / (1.f + expf(-ab));
+  if (i % P == 0) { gamma_out[b] = g; beta_out[b] = bt; }
   const float gmax = __uint_as_float(*gmax_bits);
   const float x = cmf[i] / gmax;
-  const float g = gamma[b], bt = beta[b];
   const float d = 1.f - x;
   float r = expf(-(d * d) / (bt + 1e-5f)) * g;
   r = r / (bt * 1.7724539f + 1e-5f);  // float32(sqrt(float32(pi)))
@@ -595,11 +618,13 @@ int hdrsky_spatial_sum(const float* x, int B, int P, int C, float scale, float* 
   return HDRSKY_OK;
 }
 
-int hdrsky_grad_cam(const float* A, const float* w, int B, int P, int C, float* cam, void* stream) {
-  if (!A || !w || !cam || (C & 3) || C > 256 || (256 % (C / 4)) != 0) return HDRSKY_EINVAL;
+int hdrsky_grad_cam(const float* A, const float* w, int w_nparts, float w_scale, int B, int P, int C, float* cam,
+                    void* stream) {
+  if (!A || !w || !cam || (C & 3) || C > 256 || (256 % (C / 4)) != 0 || w_nparts < 0) return HDRSKY_EINVAL;
   const int ppb = 256 / (C / 4);
   int gx = cdiv(P, ppb); if (gx > 64) gx = 64;
-  hipLaunchKernelGGL(cam_kernel, dim3(gx, B), dim3(256), C * sizeof(float), (hipStream_t)stream, A, w, P, C, cam);
+  hipLaunchKernelGGL(cam_kernel, dim3(gx, B), dim3(256), C * sizeof(float), (hipStream_t)stream, A, w, w_nparts, w_scale,
+                     P, C, cam);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }
@@ -614,20 +639,19 @@ int hdrsky_plz_build(const float* ldr, const float* cam1, const float* cam2, con
 }
 
 int hdrsky_dense_heads(const float* x, const float* scale, const float* shift, float slope, int B, int F, int C,
-                       const float* kg, const float* bg, const float* kb, const float* bb, float* gamma_out,
-                       float* beta_out, void* stream) {
-  if (!x || !kg || !bg || !kb || !bb || !gamma_out || !beta_out) return HDRSKY_EINVAL;
-  hipLaunchKernelGGL(dense_heads_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, scale, shift, slope, F, C, kg,
-                     bg, kb, bb, gamma_out, beta_out);
+                       const float* kg, const float* kb, int S, float* part, void* stream) {
+  if (!x || !kg || !kb || !part || S <= 0 || (F & 3) || (C & 3)) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(dense_heads_kernel, dim3(B * S), dim3(256), 0, (hipStream_t)stream, x, scale, shift, slope, F, C, kg,
+                     kb, S, part);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }
 
-int hdrsky_sun_rad(const float* cmf, const void* gmax_bits, const float* gamma, const float* beta, int B, int P,
-                   float* rad_lin3, float* rad_gamma3, void* stream) {
-  if (!cmf || !gmax_bits || !gamma || !beta || !rad_lin3 || !rad_gamma3) return HDRSKY_EINVAL;
+int hdrsky_sun_rad(const float* cmf, const void* gmax_bits, const float* part, int S, const float* bg, const float* bb,
+                   int B, int P, float* gamma_out, float* beta_out, float* rad_lin3, float* rad_gamma3, void* stream) {
+  if (!cmf || !gmax_bits || !part || !bg || !bb || !gamma_out || !beta_out || !rad_lin3 || !rad_gamma3) return HDRSKY_EINVAL;
   hipLaunchKernelGGL(sun_rad_kernel, dim3(cdiv(B * P, 256)), dim3(256), 0, (hipStream_t)stream, cmf,
-                     (const unsigned int*)gmax_bits, gamma, beta, B, P, rad_lin3, rad_gamma3);
+                     (const unsigned int*)gmax_bits, part, S, bg, bb, B, P, gamma_out, beta_out, rad_lin3, rad_gamma3);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }

@@ -39,6 +39,7 @@ class Nets:
         self.gen = _dev(gen_params, self.device)
         self.sun = _dev(sun_params, self.device)
         self.pk = {}
+        self.side_stream = torch.cuda.Stream(device=self.device)
         self.repack_all()
 
     def repack_all(self):
@@ -59,6 +60,15 @@ class Nets:
                     pk["sun." + name + ".T"] = PackedConv(s[name + ".w"], self.precise, transpose_flip=True)
         pk["sun.fc1"] = PackedFC(s["fc1.kernel"], self.precise)
         pk["sun.fc2"] = PackedFC(s["fc2.kernel"], self.precise)
+        self.refresh_eval_tables()
+
+    def refresh_eval_tables(self):
+        """Inference-mode BatchNorm of sunRadNet as per-channel affines (recompute after the moving stats change)."""
+        g = self.gen
+        self.bn_eval = {}
+        for d in ("d2", "d3", "d4"):
+            n = "sun.%s.norm." % d
+            self.bn_eval[d] = K.bn_eval_affine(g[n + "gamma"], g[n + "beta"], g[n + "moving_mean"], g[n + "moving_variance"])
 
 
 def _in_xf(stats, p, name, slope):
@@ -105,14 +115,14 @@ def gradcam_sweep(nets, t, pick_src, compute):
     g = K.norm_act_bwd(t["r3b"], t["st3b"], s["sunlayer3.norm2.gamma"], s["sunlayer3.norm2.beta"], 0.0, dP3, True)
     g, _ = K.conv2d(g, pk["sun.sunlayer3.conv2.T"], None, compute=compute)
     g = K.norm_act_bwd(t["r3a"], t["st3a"], s["sunlayer3.norm1.gamma"], s["sunlayer3.norm1.beta"], 0.0, g, False)
-    dP2, _ = K.conv2d(g, pk["sun.sunlayer3.conv1.T"], None, compute=compute)
-    w2 = K.spatial_sum(dP2, 1.0 / ((h // 2) * (w // 2)))
+    dP2, sP2 = K.conv2d(g, pk["sun.sunlayer3.conv1.T"], None, compute=compute, want_stats=True)
     g = K.norm_act_bwd(t["r2b"], t["st2b"], s["sunlayer2.norm2.gamma"], s["sunlayer2.norm2.beta"], 0.0, dP2, True)
     g, _ = K.conv2d(g, pk["sun.sunlayer2.conv2.T"], None, compute=compute)
     g = K.norm_act_bwd(t["r2a"], t["st2a"], s["sunlayer2.norm1.gamma"], s["sunlayer2.norm1.beta"], 0.0, g, False)
-    dP1, _ = K.conv2d(g, pk["sun.sunlayer2.conv1.T"], None, compute=compute)
-    w1 = K.spatial_sum(dP1, 1.0 / (h * w))
-    return K.grad_cam_map(t["A1"], w1), K.grad_cam_map(t["A2"], w2), K.grad_cam_map(t["A3"], w3)
+    _, sP1 = K.conv2d(g, pk["sun.sunlayer2.conv1.T"], None, compute=compute, want_stats=True)
+    # GAP of d y_c / d A_k == sum of the pooled-map gradient / (H_k*W_k): the dgrad conv's per-tile sums
+    return (K.grad_cam_map(t["A1"], sP1, 1.0 / (h * w)), K.grad_cam_map(t["A2"], sP2, 1.0 / ((h // 2) * (w // 2))),
+            K.grad_cam_map(t["A3"], w3))
 
 
 def encode(nets, ldr, compute):
@@ -155,12 +165,11 @@ def sun_rad_estimation(nets, ldr, cams, t, compute):
     x, xf = d1, None
     for d in ("d2", "d3", "d4"):
         x, _ = K.conv2d(x, pk["gen.sun." + d], None, stride=(1 if d == "d4" else 2), xf=xf, compute=compute)
-        n = "sun.%s.norm." % d
-        sc, sh = K.bn_eval_affine(g[n + "gamma"], g[n + "beta"], g[n + "moving_mean"], g[n + "moving_variance"])
+        sc, sh = nets.bn_eval[d]
         xf = InXf(mode=L.IN_AFFINE, slope=0.3, scale=sc, shift=sh)
-    gamma, beta = K.dense_heads(x, xf.scale, xf.shift, 0.3, g["sun.gamma.kernel"], g["sun.gamma.bias"],
-                                g["sun.beta.kernel"], g["sun.beta.bias"])
-    rad_lin, rad_gamma = K.sun_rad(t["cmf"], t["gmax"], gamma, beta, nets.h, nets.w)
+    part = K.dense_heads(x, xf.scale, xf.shift, 0.3, g["sun.gamma.kernel"], g["sun.beta.kernel"])
+    rad_lin, rad_gamma, gamma, beta = K.sun_rad(t["cmf"], t["gmax"], part, g["sun.gamma.bias"], g["sun.beta.bias"],
+                                                nets.h, nets.w)
     return rad_lin, rad_gamma, gamma, beta
 
 
@@ -168,11 +177,18 @@ def generator_forward(nets, ldr, pick_src=None, compute=BF16):
     """inference.py:81-115 (pick_src=None: y_c = max cmf) / train.py:239-299 in test mode
     (pick_src = sunpose_gt).  ldr [B,H,W,3] BGR in [0,1].  Returns the reference's outputs as a dict."""
     B, H, W, _ = ldr.shape
+    # two independent branches (generator encoder + sky decoder | sun-pose net + Grad-CAM + sun radiance) run on
+    # two HIP streams; under hipGraph capture this becomes a fork/join in the graph.
+    main = torch.cuda.current_stream()
+    side = nets.side_stream
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        t = sunpose_forward(nets, ldr, compute)
+        cams = gradcam_sweep(nets, t, t["cmf"] if pick_src is None else pick_src, compute)
+        rad_lin, rad_gamma, gamma, beta = sun_rad_estimation(nets, ldr, cams, t, compute)
     res_out = encode(nets, ldr, compute)
     sky_gamma = decode(nets, res_out, "f", ldr, compute)
-    t = sunpose_forward(nets, ldr, compute)
-    cams = gradcam_sweep(nets, t, t["cmf"] if pick_src is None else pick_src, compute)
-    rad_lin, rad_gamma, gamma, beta = sun_rad_estimation(nets, ldr, cams, t, compute)
+    main.wait_stream(side)
     sun_gamma = decode(nets, res_out, "u", rad_gamma, compute)
     y_gamma, y_lin, alpha, sky_lin, sun_lin = K.blend(sky_gamma, sun_gamma, THRESHOLD)
     return dict(y_final_lin=y_lin, y_final_gamma=y_gamma, sky_pred_lin=sky_lin, sun_pred_lin=sun_lin, gamma=gamma,

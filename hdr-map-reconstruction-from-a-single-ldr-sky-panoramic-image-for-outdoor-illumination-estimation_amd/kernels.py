@@ -265,11 +265,18 @@ def spatial_sum(x, scale=1.0):
     return out
 
 
-def grad_cam_map(A, w):
+def grad_cam_map(A, w, scale=1.0):
+    """cam = relu(sum_c w_c * A[..., c]).  w: [B,C] table, or the Stats of the conv that produced the activation
+    gradient (its per-tile sums are the GAP numerator)."""
     B, H, W, C = A.shape
-    _f32(A); _f32(w, B, C)
+    _f32(A)
     cam = torch.empty((B, H, W, 1), dtype=torch.float32, device=A.device)
-    L.check(L.load().hdrsky_grad_cam(_p(A), _p(w), B, H * W, C, _p(cam), _stream()), "grad_cam")
+    if isinstance(w, Stats):
+        _f32(w.part, B, w.nparts, 2, C)
+        wp, nparts = w.part, w.nparts
+    else:
+        wp, nparts = _f32(w, B, C), 0
+    L.check(L.load().hdrsky_grad_cam(_p(A), _p(wp), nparts, scale, B, H * W, C, _p(cam), _stream()), "grad_cam")
     return cam
 
 
@@ -281,28 +288,34 @@ def plz_build(ldr, cam1, cam2, cam3):
     return plz
 
 
-def dense_heads(x, scale, shift, slope, kg, bg, kb, bb):
+HEAD_SLICES = 16
+
+
+def dense_heads(x, scale, shift, slope, kg, kb):
+    """Stage 1 of the sunRadNet gamma/beta heads: per-slice partial dot products [B, HEAD_SLICES, 2]."""
     B = x.shape[0]
     C = x.shape[-1]
     F = x[0].numel()
-    _f32(x); _f32(kg, F, 1); _f32(kb, F, 1); _f32(bg, 1); _f32(bb, 1)
+    _f32(x); _f32(kg, F, 1); _f32(kb, F, 1)
     if scale is not None:
         _f32(scale, C); _f32(shift, C)
-    g = torch.empty((B, 1, 1, 1), dtype=torch.float32, device=x.device)
-    b = torch.empty_like(g)
-    L.check(L.load().hdrsky_dense_heads(_p(x), _p(scale), _p(shift), slope, B, F, C, _p(kg), _p(bg), _p(kb), _p(bb),
-                                        _p(g), _p(b), _stream()), "dense_heads")
-    return g, b
+    part = torch.empty((B, HEAD_SLICES, 2), dtype=torch.float32, device=x.device)
+    L.check(L.load().hdrsky_dense_heads(_p(x), _p(scale), _p(shift), slope, B, F, C, _p(kg), _p(kb), HEAD_SLICES,
+                                        _p(part), _stream()), "dense_heads")
+    return part
 
 
-def sun_rad(cmf, gmax_bits, gamma, beta, H, W):
+def sun_rad(cmf, gmax_bits, head_part, bg, bb, H, W):
+    """gamma/beta = sigmoid(sum head_part + bias); Dirac-delta radiance (linear, x3) and its log-compressed image."""
     B, P = cmf.shape
-    _f32(cmf, B, H * W); _f32(gamma, B, 1, 1, 1); _f32(beta, B, 1, 1, 1)
+    _f32(cmf, B, H * W); _f32(head_part, B, head_part.shape[1], 2); _f32(bg, 1); _f32(bb, 1)
     lin = torch.empty((B, H, W, 3), dtype=torch.float32, device=cmf.device)
     gam = torch.empty_like(lin)
-    L.check(L.load().hdrsky_sun_rad(_p(cmf), _p(gmax_bits), _p(gamma), _p(beta), B, P, _p(lin), _p(gam), _stream()),
-            "sun_rad")
-    return lin, gam
+    g = torch.empty((B, 1, 1, 1), dtype=torch.float32, device=cmf.device)
+    b = torch.empty_like(g)
+    L.check(L.load().hdrsky_sun_rad(_p(cmf), _p(gmax_bits), _p(head_part), head_part.shape[1], _p(bg), _p(bb), B, P,
+                                    _p(g), _p(b), _p(lin), _p(gam), _stream()), "sun_rad")
+    return lin, gam, g, b
 
 
 def blend(sky_gamma, sun_gamma, thr=0.12, extras=True):

@@ -151,8 +151,11 @@ int hdrsky_softmax_pick_bwd(const float* cmf, const float* z, const float* pick_
                             int* idx_out, void* stream);
 /* out[b][c] = scale * sum_p x[b][p][c] */
 int hdrsky_spatial_sum(const float* x, int B, int P, int C, float scale, float* out, void* stream);
-/* cam[b][p] = relu(sum_c w[b][c]*A[b][p][c])  (grad_cam.py:34-38) */
-int hdrsky_grad_cam(const float* A, const float* w, int B, int P, int C, float* cam, void* stream);
+/* cam[b][p] = relu(sum_c w[b][c]*A[b][p][c])  (grad_cam.py:34-38).  w_nparts == 0: w is a [B][C] table;
+ * w_nparts > 0: w is the statistics tensor [B][w_nparts][2][C] of the conv that produced the activation
+ * gradient and its per-tile sums are reduced here; either way the weights are multiplied by w_scale. */
+int hdrsky_grad_cam(const float* A, const float* w, int w_nparts, float w_scale, int B, int P, int C, float* cam,
+                    void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Sun-radiance head, tone mapping, blending
@@ -160,13 +163,14 @@ int hdrsky_grad_cam(const float* A, const float* w, int B, int P, int C, float* 
 /* plz = concat(ldr, cam1, resize(cam2), resize(cam3))  (generator.py:161-164) -> [B,H,W,6] */
 int hdrsky_plz_build(const float* ldr, const float* cam1, const float* cam2, const float* cam3, int B, int H, int W,
                      float* plz, void* stream);
-/* gamma/beta = sigmoid(Dense(1)(flatten(leaky(x*scale[c]+shift[c]))))  (sunrad_net.py:52-59); F = flatten length */
+/* sunRadNet heads, stage 1 (sunrad_net.py:52-53): part[b][s][2] = slice s of flatten(leaky(x*scale[c]+shift[c])) . {kg, kb};
+ * F = flatten length, S slices per sample. */
 int hdrsky_dense_heads(const float* x, const float* scale, const float* shift, float slope, int B, int F, int C,
-                       const float* kg, const float* bg, const float* kb, const float* bb, float* gamma_out,
-                       float* beta_out, void* stream);
-/* Dirac-delta radiance (sunrad_net.py:61-69, generator.py:160,167) + hdr_logCompression (tf_utils.py:263-271) */
-int hdrsky_sun_rad(const float* cmf, const void* gmax_bits, const float* gamma, const float* beta, int B, int P,
-                   float* rad_lin3, float* rad_gamma3, void* stream);
+                       const float* kg, const float* kb, int S, float* part, void* stream);
+/* stage 2 + Dirac-delta radiance: gamma/beta = sigmoid(sum_s part + bias) (sunrad_net.py:54-59), then the radiance map
+ * (sunrad_net.py:61-69, generator.py:160,167) and its hdr_logCompression (tf_utils.py:263-271), tiled to 3 channels. */
+int hdrsky_sun_rad(const float* cmf, const void* gmax_bits, const float* part, int S, const float* bg, const float* bb,
+                   int B, int P, float* gamma_out, float* beta_out, float* rad_lin3, float* rad_gamma3, void* stream);
 /* alpha mask + blend + log decompression (inference.py:91-94,109-113; train.py:258-261,293-299); outputs after
  * y_lin are nullable */
 int hdrsky_blend(const float* sky_gamma, const float* sun_gamma, int npix, float thr, float* y_gamma, float* y_lin,

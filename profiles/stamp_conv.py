@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Phase breakdown of one conv launch from in-kernel s_memtime stamps (diagnostic path only).
+Shares (cycles per workgroup): prologue | A staging | main loop (B ring + MFMA) | epilogue.
+usage: python profiles/stamp_conv.py <layer-substring> ["tile;tile;..."]"""
+import ctypes
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "profiles"))
+PKG = "hdr-map-reconstruction-from-a-single-ldr-sky-panoramic-image-for-outdoor-illumination-estimation_amd"
+K = importlib.import_module(PKG + ".kernels")
+L = importlib.import_module(PKG + "._lib")
+from microbench_conv import LAYERS  # noqa: E402
+
+
+def main():
+    lib = L.load()
+    lib.hdrsky_debug_conv_stamps.argtypes = [ctypes.c_void_p]
+    lib.hdrsky_debug_conv_stamps.restype = None
+    dev = torch.device("cuda:0")
+    B = 32
+    only = sys.argv[1] if len(sys.argv) > 1 else "g.res"
+    tiles = sys.argv[2].split(";") if len(sys.argv) > 2 else [""]
+    for (name, H, W, Cin, Cout, k, stride, up, xfm, stats) in LAYERS:
+        if only not in name:
+            continue
+        x = torch.randn(B, H, W, Cin, device=dev)
+        w = torch.randn(k, k, Cin, Cout, device=dev) / (k * k * Cin) ** 0.5
+        pw = K.PackedConv(w, precise=False)
+        bias = torch.zeros(Cout, device=dev)
+        for t in tiles:
+            if t:
+                os.environ["HDRSKY_TILE"] = t
+            else:
+                os.environ.pop("HDRSKY_TILE", None)
+            buf = torch.zeros(65536 * 8, dtype=torch.int64, device=dev)
+            for _ in range(20):
+                K.conv2d(x, pw, bias, stride=stride, upsample=up, want_stats=stats)
+            torch.cuda.synchronize()
+            lib.hdrsky_debug_conv_stamps(buf.data_ptr())
+            K.conv2d(x, pw, bias, stride=stride, upsample=up, want_stats=stats)
+            torch.cuda.synchronize()
+            lib.hdrsky_debug_conv_stamps(None)
+            raw = buf.cpu().numpy()
+            s = raw.reshape(-1, 8)
+            nwg = int((s[:, 0] != 0).sum()) * 2 // 3  # rows: nwg stamp rows + nwg/2 rows of inner-loop counters
+            inner = raw[nwg * 8: nwg * 8 + nwg * 4].reshape(-1, 4).astype(np.float64)
+            s = s[:nwg]
+            d = np.stack([s[:, 1] - s[:, 0], s[:, 2] - s[:, 1], s[:, 3] - s[:, 2], s[:, 5] - s[:, 3]], 1).astype(np.float64)
+            tot = (s[:, 5] - s[:, 0]).astype(np.float64)
+            rt = (s[:, 7] - s[:, 6]).astype(np.float64)
+            mhz = np.median(tot / np.maximum(rt, 1)) * 100.0
+            span = (s[:, 7].max() - s[:, 6].min()) / 100.0
+            print("%-24s tile %-12s WGs %5d | cycles/WG: prologue %6.0f  stageA %6.0f  mainloop %6.0f  epilogue %6.0f | "
+                  "total %6.0f cyc = %.2f us @ %.0f MHz | kernel span %.2f us"
+                  % ((name, t or "auto", len(s)) + tuple(np.median(d, 0)) + (np.median(tot), np.median(tot) / mhz, mhz, span)),
+                  flush=True)
+            print("      main loop split (cycles/WG, wave 0): B-load issue %6.0f | MFMA chunk %6.0f | LDS store + load wait %6.0f | barrier %6.0f"
+                  % tuple(np.median(inner, 0)), flush=True)
+
+
+if __name__ == "__main__":
+    main()

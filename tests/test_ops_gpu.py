@@ -105,6 +105,10 @@ def test_cam_plz_heads_rad_blend(dev):
     cam = K.grad_cam_map(d(A), w)
     ref = np.maximum(np.einsum("bc,bhwc->bhw", w.cpu().numpy(), A), 0)[..., None]
     assert_close(cam, ref, 1e-5, "cam")
+    # same weights taken from the statistics partials of the conv that produced the gradient
+    _, st = _stats_for(K, d(g), 64)
+    cam2 = K.grad_cam_map(d(A), st, 1.0 / (16 * 64))
+    assert_close(cam2, ref, 1e-4, "cam from partials")
     ldr = rng.uniform(0, 1, (B, H, W, 3)); c1 = rng.uniform(0, 1, (B, H, W, 1))
     c2 = rng.uniform(0, 1, (B, H // 2, W // 2, 1)); c3 = rng.uniform(0, 1, (B, H // 4, W // 4, 1))
     plz = K.plz_build(d(ldr), d(c1), d(c2), d(c3))
@@ -116,13 +120,13 @@ def test_cam_plz_heads_rad_blend(dev):
     sc = rng.uniform(0.5, 1.5, 512).astype(np.float32); sh = rng.standard_normal(512).astype(np.float32)
     kg = (rng.standard_normal((32768, 1)) / 180).astype(np.float32); kb = (rng.standard_normal((32768, 1)) / 180).astype(np.float32)
     bg = np.array([0.1], np.float32); bb = np.array([-0.2], np.float32)
-    gam, bet = K.dense_heads(d(x), d(sc), d(sh), 0.3, d(kg), d(bg), d(kb), d(bb))
+    part = K.dense_heads(d(x), d(sc), d(sh), 0.3, d(kg), d(kb))
     flat = T.leaky_relu(t(x) * t(sc) + t(sh), 0.3).reshape(B, -1)
     gr = torch.sigmoid(flat @ t(kg) + t(bg)); br = torch.sigmoid(flat @ t(kb) + t(bb))
-    assert_close(gam.reshape(B, 1), gr, 1e-4, "gamma head"); assert_close(bet.reshape(B, 1), br, 1e-4, "beta head")
     cmf = torch.softmax(t(rng.standard_normal((B, H * W)) * 3), dim=-1)
     gmax = torch.tensor([float(cmf.max())], dtype=torch.float32).view(torch.int32).to(dev)
-    lin, gm = K.sun_rad(cmf.to(dev), gmax, gam, bet, H, W)
+    lin, gm, gam, bet = K.sun_rad(cmf.to(dev), gmax, part, d(bg), d(bb), H, W)
+    assert_close(gam.reshape(B, 1), gr, 1e-4, "gamma head"); assert_close(bet.reshape(B, 1), br, 1e-4, "beta head")
     p = {"x": None}
     xn = (cmf / cmf.max()).reshape(B, H, W, 1)
     y = torch.exp(-torch.pow(1.0 - xn, 2.0) / (gam.cpu() + 1e-5)) * gam.cpu() / (bet.cpu() * 1.7724539 + 1e-5)
