@@ -136,6 +136,6 @@ def train_step_grads(gen, sun, dis, vgg, ldr, hdr_t, sunpose_gt):
         else:
             grads_gen[k] = g
     grads_dis = {k: (torch.zeros_like(v) if g is None else g) for (k, v), g in zip(dvars, dgrads)}
-    losses = {k: float(v) for k, v in {**gl, **dl}.items()}
+    losses = {k: float(v.detach()) for k, v in {**gl, **dl}.items()}
     outs = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}
     return losses, grads_gen, grads_sun, grads_dis, stats_gen, stats_dis, outs
