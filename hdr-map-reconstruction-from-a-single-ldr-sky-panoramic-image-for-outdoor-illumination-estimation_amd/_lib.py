@@ -34,6 +34,7 @@ SIGNATURES = {
     "hdrsky_conv_pack_weights": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "hdrsky_conv_stats_nparts": (c_int, [ctypes.POINTER(ConvDesc)]),
     "hdrsky_conv2d_fwd": (c_int, [ctypes.POINTER(ConvDesc)] + [P] * 13),
+    "hdrsky_conv2d_wgrad": (c_int, [ctypes.POINTER(ConvDesc)] + [P] * 10),
     "hdrsky_norm_apply": (c_int, [P, P, c_int, P, P, c_float, c_float, P, P, P, c_int, c_int, c_int, c_int, P]),
     "hdrsky_in_finalize": (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_float, P, P, P, P, P]),
     "hdrsky_bn_eval_affine": (c_int, [P, P, P, P, c_float, c_int, P, P, P]),

@@ -131,6 +131,48 @@ def conv2d(x, pw: PackedConv, bias=None, stride=1, same=True, upsample=1, xf: Op
     return y, stats
 
 
+def _xf_args(d, xf, B, H, W, C):
+    """Fills the operand-transform fields of a descriptor; returns the five table pointers."""
+    xf = xf or InXf()
+    d.in_mode, d.in_slope = xf.mode, float(xf.slope)
+    in_scale = in_shift = in_part = in_gamma = in_beta = None
+    if xf.mode == L.IN_AFFINE:
+        in_scale, in_shift = _f32(xf.scale), _f32(xf.shift)
+        d.ss_bstride = C if in_scale.numel() == B * C else 0
+        if in_scale.numel() not in (C, B * C) or in_shift.numel() != in_scale.numel():
+            raise ValueError("affine table must have C or B*C entries")
+    elif xf.mode == L.IN_PARTIALS:
+        st = xf.stats
+        in_part = _f32(st.part, B, st.nparts, 2, C)
+        if st.count != H * W:
+            raise ValueError("partials were not accumulated over this tensor's H*W")
+        in_gamma, in_beta = _f32(xf.gamma, C), _f32(xf.beta, C)
+        d.in_nparts, d.in_eps = st.nparts, float(xf.eps)
+    return in_scale, in_shift, in_part, in_gamma, in_beta
+
+
+def conv2d_wgrad(x, dy, KH, KW, stride=1, same=True, upsample=1, xf: Optional[InXf] = None, compute=BF16,
+                 want_db=True, dw=None, db=None):
+    """(dw [KH,KW,Cin,Cout], db [Cout]) of the conv whose forward consumed xf(x) and produced dy's shape.
+    Accumulates into dw/db when given (they must then already hold valid values), else allocates zeros."""
+    _f32(x); _f32(dy)
+    B, H, W, C = x.shape
+    Cout = dy.shape[-1]
+    d = conv_desc(B, H, W, C, Cout, KH, KW, stride, same, upsample)
+    if tuple(dy.shape) != (B, d.Ho, d.Wo, Cout):
+        raise ValueError("dy shape %s does not match the conv output %s" % (tuple(dy.shape), (B, d.Ho, d.Wo, Cout)))
+    d.compute = compute
+    tabs = _xf_args(d, xf, B, H, W, C)
+    if dw is None:
+        dw = torch.zeros((KH, KW, C, Cout), dtype=torch.float32, device=x.device)
+    if db is None and want_db:
+        db = torch.zeros((Cout,), dtype=torch.float32, device=x.device)
+    _f32(dw, KH, KW, C, Cout)
+    L.check(L.load().hdrsky_conv2d_wgrad(d, _p(x), _p(dy), *[_p(t) for t in tabs], _p(dw), _p(db), _stream()),
+            "conv2d_wgrad")
+    return dw, db
+
+
 def norm_apply(x, stats: Stats, gamma, beta, slope=1.0, residual=None, pool=False, eps=IN_EPS):
     """y = leaky(IN(x)) [+ residual]; optionally also the 2x2 max-pool of y.  Returns y or (y, ypool)."""
     _f32(x)

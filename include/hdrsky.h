@@ -178,6 +178,17 @@ int hdrsky_blend(const float* sky_gamma, const float* sun_gamma, int npix, float
 /* tf_utils.hdr_logCompression (decompress=0) / hdr_logDecompression (1)  (tf_utils.py:263-280) */
 int hdrsky_tonemap(const float* x, float* y, size_t n, int decompress, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Training-step kernels (train.py:382-415)
+ * ---------------------------------------------------------------------------------------- */
+
+/* Weight / bias gradient of the convolution described by `d` (same descriptor, same fused operand transform as the
+ * forward call): dw[KH,KW,Cin,Cout] += sum_pixels X' (x) dY, db[Cout] += sum_pixels dY (db nullable).
+ * fp32 atomics: ZERO dw / db first.  tf.GradientTape through tf.nn.conv2d (train.py:402-406). */
+int hdrsky_conv2d_wgrad(const hdrsky_conv_desc* d, const float* x, const float* dy, const float* in_scale,
+                        const float* in_shift, const float* in_part, const float* in_gamma, const float* in_beta,
+                        float* dw, float* db, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
