@@ -30,6 +30,7 @@ P = c_void_p
 SIGNATURES = {
     "hdrsky_version": (ctypes.c_char_p, []),
     "hdrsky_conv_desc_init": (c_int, [ctypes.POINTER(ConvDesc)] + [c_int] * 10),
+    "hdrsky_conv_desc_init_dgrad": (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvDesc)]),
     "hdrsky_conv_packed_elems": (c_size_t, [c_int] * 4),
     "hdrsky_conv_pack_weights": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "hdrsky_conv_stats_nparts": (c_int, [ctypes.POINTER(ConvDesc)]),
@@ -38,7 +39,7 @@ SIGNATURES = {
     "hdrsky_norm_apply": (c_int, [P, P, c_int, P, P, c_float, c_float, P, P, P, c_int, c_int, c_int, c_int, P]),
     "hdrsky_in_finalize": (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_float, P, P, P, P, P]),
     "hdrsky_bn_eval_affine": (c_int, [P, P, P, P, c_float, c_int, P, P, P]),
-    "hdrsky_norm_act_bwd": (c_int, [P, P, c_int, P, P, c_float, c_float, P, c_int, P, P, c_int, c_int, c_int, c_int, P]),
+    "hdrsky_norm_act_bwd": (c_int, [P, P, c_int, P, P, c_float, c_float, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "hdrsky_fc_pack_weights": (c_int, [P, c_int, c_int, P, P, P, P, P]),
     "hdrsky_fc_nsplit": (c_int, [c_int]),
     "hdrsky_fc_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
@@ -53,6 +54,31 @@ SIGNATURES = {
     "hdrsky_sun_rad": (c_int, [P, P, P, c_int, P, P, c_int, c_int, P, P, P, P, P]),
     "hdrsky_blend": (c_int, [P, P, c_int, c_float, P, P, P, P, P, P]),
     "hdrsky_tonemap": (c_int, [P, P, c_size_t, c_int, P]),
+    "hdrsky_bn_train_finalize": (c_int, [P, c_int, c_int, c_int, P, P, c_float, c_float, P, P, P, P, P, P, P]),
+    "hdrsky_bn_bwd_nblocks": (c_int, []),
+    "hdrsky_bn_act_bwd": (c_int, [P, P, P, P, P, P, c_float, c_int, c_int, P, P, P, P, P]),
+    "hdrsky_affine_act_bwd": (c_int, [P, P, P, P, c_float, c_size_t, c_int, P, P]),
+    "hdrsky_maxpool_fwd": (c_int, [P, c_int, c_int, c_int, c_int, P, P]),
+    "hdrsky_maxpool_relu_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P]),
+    "hdrsky_up2x_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P]),
+    "hdrsky_up2x_bwd": (c_int, [P, c_int, c_int, c_int, c_int, c_float, c_int, P, P]),
+    "hdrsky_blur3": (c_int, [P, c_int, c_int, c_int, c_int, c_float, c_int, P, P]),
+    "hdrsky_dog_mid": (c_int, [P, c_int, c_int, c_int, c_int, c_float, P, P, P]),
+    "hdrsky_dog_mid_bwd": (c_int, [P, c_int, c_int, c_int, c_int, P, P]),
+    "hdrsky_l1": (c_int, [P, P, c_size_t, c_float, c_float, P, P, c_int, P]),
+    "hdrsky_mse": (c_int, [P, c_float, c_size_t, c_float, c_float, P, P, P]),
+    "hdrsky_kl": (c_int, [P, P, c_int, c_int, P, P, P]),
+    "hdrsky_softmax_bwd": (c_int, [P, P, P, c_int, c_int, P, P]),
+    "hdrsky_blend_bwd": (c_int, [P, P, P, P, c_size_t, P, P, P]),
+    "hdrsky_decoder_tail_bwd": (c_int, [P, P, P, c_size_t, P, P, P]),
+    "hdrsky_sun_rad_bwd": (c_int, [P, P, P, P, P, c_int, c_int, P, P, P, P]),
+    "hdrsky_dense_heads_bwd": (c_int, [P, P, P, c_float, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P]),
+    "hdrsky_slice_channels": (c_int, [P, c_size_t, c_int, c_int, c_int, c_float, c_int, P, P]),
+    "hdrsky_concat2": (c_int, [P, c_int, P, c_int, c_size_t, P, P]),
+    "hdrsky_vgg_pre": (c_int, [P, c_size_t, P, P]),
+    "hdrsky_axpby": (c_int, [P, c_float, P, c_float, c_size_t, P, P]),
+    "hdrsky_fc_wgrad": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, P]),
+    "hdrsky_rmsprop": (c_int, [P, P, P, c_size_t, c_float, c_float, c_float, c_float, P]),
 }
 
 _lib = None

@@ -733,6 +733,22 @@ int hdrsky_conv_desc_init(hdrsky_conv_desc* d, int B, int H, int W, int Cin, int
   return HDRSKY_OK;
 }
 
+int hdrsky_conv_desc_init_dgrad(hdrsky_conv_desc* d, const hdrsky_conv_desc* f) {
+  // data gradient of the conv `f` as a stride-1 conv of the (zero-stuffed, for stride 2) output gradient with
+  // the flipped/transposed filter: pad' = K-1-pad, output = f's conv-input domain (the 2x-resized image when
+  // f.upsample == 2; follow with hdrsky_up2x_bwd).
+  if (!d || !f || f->dilate != 1) return HDRSKY_EINVAL;
+  *d = hdrsky_conv_desc{};
+  d->B = f->B; d->H = f->Ho; d->W = f->Wo; d->Cin = f->Cout; d->Cout = f->Cin;
+  d->KH = f->KH; d->KW = f->KW; d->stride = 1; d->upsample = 1; d->dilate = f->stride;
+  d->Hc = (f->Ho - 1) * f->stride + 1; d->Wc = (f->Wo - 1) * f->stride + 1;
+  d->pad_t = f->KH - 1 - f->pad_t; d->pad_l = f->KW - 1 - f->pad_l;
+  d->Ho = f->Hc; d->Wo = f->Wc;
+  d->compute = f->compute;
+  d->in_mode = HDRSKY_IN_NONE; d->in_slope = 1.f; d->out_slope = 1.f; d->in_eps = 1e-3f;
+  return HDRSKY_OK;
+}
+
 size_t hdrsky_conv_packed_elems(int KH, int KW, int Cin, int Cout) {
   return (size_t)(conv_ksteps(KH, KW, Cin) + 1) * 4 * roundup(Cout, 64) * 8;  // + one all-zero k-step
 }

@@ -140,8 +140,8 @@ __global__ void __launch_bounds__(256) norm_act_bwd_kernel(const float* __restri
                                                            int nparts, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps, float slope,
                                                            const float* __restrict__ dy, int pooled,
-                                                           float* __restrict__ dx, float* __restrict__ sums, int B,
-                                                           int H, int W, int C) {
+                                                           float* __restrict__ dx, float* __restrict__ sums,
+                                                           float* dgamma, float* dbeta, int B, int H, int W, int C) {
   __shared__ float sRed[64][2][16];
   __shared__ float sM[2][16];
   const int groups = C >> 4;
@@ -261,7 +261,9 @@ __global__ void __launch_bounds__(256) norm_act_bwd_kernel(const float* __restri
         float t = 0.f;
         for (int k = 0; k < 64; ++k) t += sRed[k][which][ch];
         sM[which][ch] = t;
-        if (sums) sums[((size_t)b * C + cg * 16 + ch) * 2 + which] = t;
+        if (sums) sums[((size_t)b * 2 + which) * C + cg * 16 + ch] = t;
+        if (which == 0 && dbeta) atomicAdd(dbeta + cg * 16 + ch, t);
+        if (which == 1 && dgamma) atomicAdd(dgamma + cg * 16 + ch, t);
       }
       __syncthreads();
       const float inv_count = 1.f / (float)(H * W);
@@ -574,12 +576,12 @@ int hdrsky_bn_eval_affine(const float* gamma, const float* beta, const float* mo
 }
 
 int hdrsky_norm_act_bwd(const float* x, const float* part, int nparts, const float* gamma, const float* beta,
-                        float eps, float slope, const float* dy, int pooled, float* dx, float* sums, int B, int H,
-                        int W, int C, void* stream) {
+                        float eps, float slope, const float* dy, int pooled, float* dx, float* sums, float* dgamma,
+                        float* dbeta, int B, int H, int W, int C, void* stream) {
   if (!x || !part || !gamma || !beta || !dy || !dx || (C & 15)) return HDRSKY_EINVAL;
   if (pooled && ((H | W) & 1)) return HDRSKY_EINVAL;
   hipLaunchKernelGGL(norm_act_bwd_kernel, dim3(B * (C / 16)), dim3(256), 0, (hipStream_t)stream, x, part, nparts,
-                     gamma, beta, eps, slope, dy, pooled, dx, sums, B, H, W, C);
+                     gamma, beta, eps, slope, dy, pooled, dx, sums, dgamma, dbeta, B, H, W, C);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }

@@ -1,0 +1,881 @@
+// Training-step kernels that are not convolutions (train.py:301-415): BatchNorm train-mode statistics and
+// backward, activation / pooling backward, bilinear-resize adjoint, Dense weight gradient, soft-max backward,
+// the losses with their gradients (KL, L1 means, LSGAN, DoG), blend / decoder-tail / sun-radiance backward and
+// the fused multi-tensor RMSprop.  fp32 throughout; scalar loss values are accumulated with atomics (they are
+// logging only - no gradient depends on them); every gradient is deterministic.
+#include "common.h"
+
+namespace {
+
+constexpr float LN11 = 2.3978953f;
+
+// ------------------------------------------------------------------------------------------------------------
+// Keras BatchNormalization, training mode (discriminator.py:25, sunrad_net.py:26): batch mean / biased variance
+// from the producing conv's per-tile partials; moving stats <- 0.99*moving + 0.01*batch (variance Bessel-corrected).
+// ------------------------------------------------------------------------------------------------------------
+__global__ void bn_train_finalize_kernel(const float* __restrict__ part, int nparts_total, int C, float count,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                         float momentum, float* moving_mean, float* moving_var, float* mean,
+                                         float* rstd, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f, ss = 0.f;
+  for (int p = 0; p < nparts_total; ++p) { s += part[(size_t)(2 * p) * C + c]; ss += part[(size_t)(2 * p + 1) * C + c]; }
+  const float m = s / count;
+  const float var = fmaxf(ss / count - m * m, 0.f);
+  const float r = 1.f / sqrtf(var + eps);
+  mean[c] = m; rstd[c] = r;
+  const float inv = gamma[c] * r;
+  scale[c] = inv; shift[c] = beta[c] - m * inv;
+  if (moving_mean) {
+    moving_mean[c] = moving_mean[c] * momentum + m * (1.f - momentum);
+    moving_var[c] = moving_var[c] * momentum + var * (count / fmaxf(count - 1.f, 1.f)) * (1.f - momentum);
+  }
+}
+
+// g = dy * act'(pre), pre = xhat*gamma+beta, xhat = (x-mean[c])*rstd[c]; per-block partial (sum g, sum g*xhat)
+__global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float slope, size_t npix, int C, float* __restrict__ part) {
+  extern __shared__ float sm[];  // [256][8] partials
+  const int c4 = C >> 2;
+  const int lanes_c = c4 < 256 ? c4 : 256;            // threads along channels (C/4 <= 256)
+  const int rows = 256 / lanes_c;
+  const int tc = threadIdx.x % lanes_c, tr = threadIdx.x / lanes_c;
+  float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  if (tr < rows) {
+    const int c = tc * 4;
+    float mu[4], rs[4], gm[4], bt[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { mu[j] = mean[c + j]; rs[j] = rstd[c + j]; gm[j] = gamma[c + j]; bt[j] = beta[c + j]; }
+    for (size_t p = (size_t)blockIdx.x * rows + tr; p < npix; p += (size_t)gridDim.x * rows) {
+      const float4 xv = *reinterpret_cast<const float4*>(x + p * C + c);
+      const float4 dv = *reinterpret_cast<const float4*>(dy + p * C + c);
+      const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float xh = (xs[j] - mu[j]) * rs[j];
+        const float g = ds[j] * ((xh * gm[j] + bt[j]) > 0.f ? 1.f : slope);
+        s1[j] += g; s2[j] += g * xh;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { sm[threadIdx.x * 8 + j] = s1[j]; sm[threadIdx.x * 8 + 4 + j] = s2[j]; }
+  __syncthreads();
+  if (threadIdx.x < lanes_c) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float t = 0.f;
+      for (int r = 0; r < rows; ++r) t += sm[(r * lanes_c + threadIdx.x) * 8 + j];
+      part[((size_t)blockIdx.x * 2 + (j >> 2)) * C + threadIdx.x * 4 + (j & 3)] = t;
+    }
+  }
+}
+
+// sums over blocks -> dbeta, dgamma (accumulated into the gradient buffers) and the two means for the apply pass
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblocks, int C, float count, float* m1m2,
+                                       float* dgamma, float* dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int b = 0; b < nblocks; ++b) { s1 += part[((size_t)b * 2) * C + c]; s2 += part[((size_t)b * 2 + 1) * C + c]; }
+  m1m2[c] = s1 / count; m1m2[C + c] = s2 / count;
+  if (dbeta) dbeta[c] += s1;
+  if (dgamma) dgamma[c] += s2;
+}
+
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
+                                    const float* __restrict__ m1m2, size_t n4, int C, float* __restrict__ dx) {
+  const int c4 = C >> 2;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4) * 4;
+    const float4 xv = reinterpret_cast<const float4*>(x)[i];
+    const float4 dv = reinterpret_cast<const float4*>(dy)[i];
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float xh = (xs[j] - mean[c + j]) * rstd[c + j];
+      const float g = ds[j] * ((xh * gamma[c + j] + beta[c + j]) > 0.f ? 1.f : slope);
+      o[j] = gamma[c + j] * rstd[c + j] * (g - m1m2[c + j] - xh * m1m2[C + c + j]);
+    }
+    reinterpret_cast<float4*>(dx)[i] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// dx = dy * act'(x*scale[c]+shift[c]) * scale[c]   (BatchNorm in inference mode = constant per-channel affine;
+// scale == nullptr: plain activation backward on the ACTIVATED tensor y passed as x: dx = dy * (y > 0 ? 1 : slope))
+__global__ void affine_act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                      const float* __restrict__ scale, const float* __restrict__ shift, float slope,
+                                      size_t n, int C, float* __restrict__ dx) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const float v = x[i];
+    if (scale) dx[i] = dy[i] * ((v * scale[c] + shift[c]) > 0.f ? 1.f : slope) * scale[c];
+    else dx[i] = dy[i] * (v > 0.f ? 1.f : slope);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// 2x2/2 max-pool (vgg16.py:85-86) and its backward fused with the ReLU in front of it: y is the post-ReLU conv
+// output; the gradient goes to the first arg-max of each window and only where y > 0.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void maxpool_fwd_kernel(const float* __restrict__ y, int B, int H, int W, int C, float* __restrict__ p) {
+  const int c4 = C >> 2, Hp = H >> 1, Wp = W >> 1;
+  const size_t total = (size_t)B * Hp * Wp * c4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int cq = (int)(i % c4);
+    const size_t pix = i / c4;
+    const int pw = (int)(pix % Wp), ph = (int)((pix / Wp) % Hp), b = (int)(pix / ((size_t)Wp * Hp));
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float4 v = reinterpret_cast<const float4*>(y)[((size_t)(b * H + 2 * ph + (k >> 1)) * W + 2 * pw + (k & 1)) * c4 + cq];
+      m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+    }
+    reinterpret_cast<float4*>(p)[i] = m;
+  }
+}
+
+__global__ void maxpool_relu_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dp, int B, int H, int W,
+                                        int C, float* __restrict__ dy) {
+  const int c4 = C >> 2, Hp = H >> 1, Wp = W >> 1;
+  const size_t total = (size_t)B * Hp * Wp * c4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int cq = (int)(i % c4);
+    const size_t pix = i / c4;
+    const int pw = (int)(pix % Wp), ph = (int)((pix / Wp) % Hp), b = (int)(pix / ((size_t)Wp * Hp));
+    const float4 up = reinterpret_cast<const float4*>(dp)[i];
+    const float us[4] = {up.x, up.y, up.z, up.w};
+    float v[4][4];
+    size_t idx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      idx[k] = ((size_t)(b * H + 2 * ph + (k >> 1)) * W + 2 * pw + (k & 1)) * c4 + cq;
+      const float4 t = reinterpret_cast<const float4*>(y)[idx[k]];
+      v[k][0] = t.x; v[k][1] = t.y; v[k][2] = t.z; v[k][3] = t.w;
+    }
+    float o[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int am = 0;
+      float best = v[0][j];
+#pragma unroll
+      for (int k = 1; k < 4; ++k)
+        if (v[k][j] > best) { best = v[k][j]; am = k; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k][j] = (k == am && v[k][j] > 0.f) ? us[j] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) reinterpret_cast<float4*>(dy)[idx[k]] = make_float4(o[k][0], o[k][1], o[k][2], o[k][3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// bilinear 2x resize (half-pixel centres) forward on an optional difference a-b, and its adjoint
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void axis2x(int o, int n, int& lo, int& hi, float& t) {
+  const float s = (o + 0.5f) * 0.5f - 0.5f;
+  const float f = floorf(s);
+  lo = max((int)f, 0); hi = min((int)ceilf(s), n - 1); t = s - f;
+}
+
+__global__ void up2x_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, int B, int H, int W, int C,
+                                float* __restrict__ y) {
+  const size_t total = (size_t)B * 4 * H * W * C;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const size_t pix = i / C;
+    const int ox = (int)(pix % (2 * W)), oy = (int)((pix / (2 * W)) % (2 * H)), bb = (int)(pix / ((size_t)4 * W * H));
+    int ylo, yhi, xlo, xhi; float ty, tx;
+    axis2x(oy, H, ylo, yhi, ty); axis2x(ox, W, xlo, xhi, tx);
+    auto at = [&](int yy, int xx) {
+      const size_t k = ((size_t)(bb * H + yy) * W + xx) * C + c;
+      return b ? a[k] - b[k] : a[k];
+    };
+    const float tl = at(ylo, xlo), tr = at(ylo, xhi), bl = at(yhi, xlo), br = at(yhi, xhi);
+    const float top = tl + (tr - tl) * tx, bot = bl + (br - bl) * tx;
+    y[i] = top + (bot - top) * ty;
+  }
+}
+
+// dx[b,iy,ix,c] = sum over the <= 4x4 outputs that sample (iy,ix) of their bilinear weight * dy   (exact adjoint)
+__global__ void up2x_bwd_kernel(const float* __restrict__ dy, int B, int H, int W, int C, float scale, int accumulate,
+                                float* __restrict__ dx) {
+  const size_t total = (size_t)B * H * W * C;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const size_t pix = i / C;
+    const int ix = (int)(pix % W), iy = (int)((pix / W) % H), bb = (int)(pix / ((size_t)W * H));
+    float wy[4], wx[4];
+    int oys[4], oxs[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int oy = 2 * iy - 1 + k, ox = 2 * ix - 1 + k;
+      oys[k] = oy; oxs[k] = ox;
+      wy[k] = 0.f; wx[k] = 0.f;
+      if (oy >= 0 && oy < 2 * H) {
+        int lo, hi; float t; axis2x(oy, H, lo, hi, t);
+        wy[k] = (lo == iy ? 1.f - t : 0.f) + (hi == iy ? t : 0.f);
+      }
+      if (ox >= 0 && ox < 2 * W) {
+        int lo, hi; float t; axis2x(ox, W, lo, hi, t);
+        wx[k] = (lo == ix ? 1.f - t : 0.f) + (hi == ix ? t : 0.f);
+      }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 4; ++kx) {
+        const float w = wy[ky] * wx[kx];
+        if (w != 0.f) s += w * dy[((size_t)(bb * 2 * H + oys[ky]) * 2 * W + oxs[kx]) * C + c];
+      }
+    dx[i] = accumulate ? dx[i] + s * scale : s * scale;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// DoG loss (tf_utils.py:61-73, train.py:316-322).  All operators are linear, so DoG(y) - DoG(t) = DoG(y - t):
+//   e_up = resize2x(y - t)                      (up2x_fwd_kernel)
+//   base = G(1.2489996) e_up                     (blur3_kernel)
+//   d_i  = G(s_{i+1}) base - G(s_i) base,  i = 0..3, s = {1.2262735, 1.5450078, 1.9465878, 2.452547, 3.0900156}
+//   loss = sum_i mean|d_i|;  h_j = g_{j-1} - g_j with g_i = sign(d_i)/N     (dog_mid_kernel)
+//   d base = sum_j G(s_j)^T h_j                  (dog_mid_bwd_kernel),  then G^T (blur3 transpose) and resize adjoint.
+// 3x3 Gaussian, TFA kernel softmax(-x^2/(2 sigma^2)), REFLECT padding (no edge repeat).
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void gauss3(float sigma, float& a, float& c) {
+  const float e = expf(-1.f / (2.f * sigma * sigma));
+  c = 1.f / (1.f + 2.f * e);
+  a = e * c;
+}
+__device__ __forceinline__ int refl(int p, int n) { return p < 0 ? -p : (p >= n ? 2 * n - 2 - p : p); }
+
+// forward blur (transpose = 0) or its adjoint (transpose = 1) on [B,H,W,C]
+__global__ void blur3_kernel(const float* __restrict__ x, int B, int H, int W, int C, float sigma, int transpose,
+                             float* __restrict__ y) {
+  float a, c0;
+  gauss3(sigma, a, c0);
+  const size_t total = (size_t)B * H * W * C;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const size_t pix = i / C;
+    const int px = (int)(pix % W), py = (int)((pix / W) % H), bb = (int)(pix / ((size_t)W * H));
+    const float* xb = x + (size_t)bb * H * W * C + c;
+    float s = 0.f;
+    if (!transpose) {
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx)
+          s += (dy ? a : c0) * (dx ? a : c0) * xb[((size_t)refl(py + dy, H) * W + refl(px + dx, W)) * C];
+    } else {
+      // adjoint: contributions of every output p whose (reflected) tap lands on this input position
+      float wy[4], wx[4]; int ys[4], xs[4];
+      ys[0] = py - 1; wy[0] = py - 1 >= 0 ? a : 0.f;
+      ys[1] = py; wy[1] = c0;
+      ys[2] = py + 1; wy[2] = py + 1 < H ? a : 0.f;
+      ys[3] = py == 1 ? 0 : H - 1; wy[3] = (py == 1 ? a : 0.f) + ((py == H - 2 && py != 1) ? a : 0.f);
+      if (py == 1 && py == H - 2) { /* H == 3: both mirrors hit row 1 from rows 0 and 2 */ }
+      xs[0] = px - 1; wx[0] = px - 1 >= 0 ? a : 0.f;
+      xs[1] = px; wx[1] = c0;
+      xs[2] = px + 1; wx[2] = px + 1 < W ? a : 0.f;
+      xs[3] = px == 1 ? 0 : W - 1; wx[3] = (px == 1 ? a : 0.f) + ((px == W - 2 && px != 1) ? a : 0.f);
+#pragma unroll
+      for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+          const float w = wy[ky] * wx[kx];
+          if (w != 0.f) s += w * xb[((size_t)ys[ky] * W + xs[kx]) * C];
+        }
+    }
+    y[i] = s;
+  }
+}
+
+__constant__ float DOG_S[5] = {1.2262735f, 1.5450078f, 1.9465878f, 2.452547f, 3.0900156f};
+
+// loss += weight * sum_i mean|d_i|;  h[j] (5 planes, each [n]) = g_{j-1} - g_j with g_i = weight*sign(d_i)/n
+__global__ void __launch_bounds__(256) dog_mid_kernel(const float* __restrict__ base, int B, int H, int W, int C,
+                                                      float weight, float* __restrict__ h, float* loss) {
+  float a[5], c0[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) gauss3(DOG_S[j], a[j], c0[j]);
+  const size_t total = (size_t)B * H * W * C;
+  const float inv_n = 1.f / (float)total;
+  float lacc = 0.f;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const size_t pix = i / C;
+    const int px = (int)(pix % W), py = (int)((pix / W) % H), bb = (int)(pix / ((size_t)W * H));
+    const float* xb = base + (size_t)bb * H * W * C + c;
+    float centre = 0.f, edge = 0.f, corner = 0.f;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const float v = xb[((size_t)refl(py + dy, H) * W + refl(px + dx, W)) * C];
+        if (dy == 0 && dx == 0) centre = v; else if (dy == 0 || dx == 0) edge += v; else corner += v;
+      }
+    float bl[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) bl[j] = c0[j] * c0[j] * centre + a[j] * c0[j] * edge + a[j] * a[j] * corner;
+    float g[6];
+    g[0] = 0.f; g[5] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float d = bl[k + 1] - bl[k];
+      lacc += fabsf(d);
+      g[k + 1] = d > 0.f ? weight * inv_n : (d < 0.f ? -weight * inv_n : 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) h[(size_t)j * total + i] = g[j] - g[j + 1];
+  }
+  lacc = wave_sum(lacc);
+  if ((threadIdx.x & 63) == 0 && loss) atomicAdd(loss, lacc * inv_n);
+}
+
+// d base = sum_j G(s_j)^T h_j
+__global__ void dog_mid_bwd_kernel(const float* __restrict__ h, int B, int H, int W, int C, float* __restrict__ dbase) {
+  float a[5], c0[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) gauss3(DOG_S[j], a[j], c0[j]);
+  const size_t total = (size_t)B * H * W * C;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const size_t pix = i / C;
+    const int px = (int)(pix % W), py = (int)((pix / W) % H), bb = (int)(pix / ((size_t)W * H));
+    // adjoint tap multiplicities along each axis: m[k] = how many times neighbour k contributes with weight `a`
+    int ys[4], xs[4]; float my[4], mx[4];
+    ys[0] = py - 1; my[0] = py - 1 >= 0 ? 1.f : 0.f;
+    ys[1] = py; my[1] = -1.f;  // marker: centre weight
+    ys[2] = py + 1; my[2] = py + 1 < H ? 1.f : 0.f;
+    ys[3] = py == 1 ? 0 : H - 1; my[3] = (py == 1 ? 1.f : 0.f) + ((py == H - 2 && py != 1) ? 1.f : 0.f);
+    xs[0] = px - 1; mx[0] = px - 1 >= 0 ? 1.f : 0.f;
+    xs[1] = px; mx[1] = -1.f;
+    xs[2] = px + 1; mx[2] = px + 1 < W ? 1.f : 0.f;
+    xs[3] = px == 1 ? 0 : W - 1; mx[3] = (px == 1 ? 1.f : 0.f) + ((px == W - 2 && px != 1) ? 1.f : 0.f);
+    float s = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 4; ++kx) {
+        if (my[ky] == 0.f || mx[kx] == 0.f) continue;
+        const size_t src = ((size_t)(bb * H + ys[ky]) * W + xs[kx]) * C + c;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          const float wy = my[ky] < 0.f ? c0[j] : a[j] * my[ky];
+          const float wx = mx[kx] < 0.f ? c0[j] : a[j] * mx[kx];
+          s += wy * wx * h[(size_t)j * total + src];
+        }
+      }
+    dbase[i] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// scalar losses with gradients
+// ------------------------------------------------------------------------------------------------------------
+// loss += wl * mean|a - b|;  da (+)= wg * sign(a-b)/n      (train.py:311-313, :325; b may be null)
+__global__ void __launch_bounds__(256) l1_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n,
+                                                 float wl, float wg, float* loss, float* __restrict__ da,
+                                                 int accumulate) {
+  const float inv_n = 1.f / (float)n;
+  float acc = 0.f;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float d = a[i] - (b ? b[i] : 0.f);
+    acc += fabsf(d);
+    if (da) {
+      const float g = d > 0.f ? wg * inv_n : (d < 0.f ? -wg * inv_n : 0.f);
+      da[i] = accumulate ? da[i] + g : g;
+    }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0 && loss) atomicAdd(loss, acc * inv_n * wl);
+}
+
+// LSGAN: loss += wl * mean((x - target)^2); dx = wg * 2 (x - target)/n     (train.py:234-237)
+__global__ void __launch_bounds__(256) mse_kernel(const float* __restrict__ x, float target, size_t n, float wl, float wg,
+                                                  float* loss, float* __restrict__ dx) {
+  const float inv_n = 1.f / (float)n;
+  float acc = 0.f;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float d = x[i] - target;
+    acc += d * d;
+    if (dx) dx[i] = wg * 2.f * d * inv_n;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0 && loss) atomicAdd(loss, acc * inv_n * wl);
+}
+
+// Keras KLDivergence (train.py:232,305): loss += mean_b sum_j yt log(yt/yp), both clipped to [1e-7,1];
+// dcmf = -yt/yp / B inside the clip range of yp, else 0
+__global__ void __launch_bounds__(256) kl_kernel(const float* __restrict__ gt, const float* __restrict__ cmf, int B, int N,
+                                                 float* loss, float* __restrict__ dcmf) {
+  const size_t n = (size_t)B * N;
+  float acc = 0.f;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float yt = fminf(fmaxf(gt[i], 1e-7f), 1.f);
+    const float p = cmf[i];
+    const float yp = fminf(fmaxf(p, 1e-7f), 1.f);
+    acc += yt * logf(yt / yp);
+    if (dcmf) dcmf[i] = (p > 1e-7f && p < 1.f) ? -yt / yp / (float)B : 0.f;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0 && loss) atomicAdd(loss, acc / (float)B);
+}
+
+// dz = cmf * (dcmf - sum_j dcmf_j cmf_j) * [z > 0]      (softmax + the ReLU in front of it; one block per row)
+__global__ void __launch_bounds__(256) softmax_bwd_kernel(const float* __restrict__ cmf, const float* __restrict__ dcmf,
+                                                          const float* __restrict__ z, int N, float* __restrict__ dz) {
+  __shared__ float sred[4];
+  const size_t row = (size_t)blockIdx.x * N;
+  float s = 0.f;
+  for (int n = threadIdx.x; n < N; n += 256) s += dcmf[row + n] * cmf[row + n];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const float dot = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+  for (int n = threadIdx.x; n < N; n += 256)
+    dz[row + n] = z[row + n] > 0.f ? cmf[row + n] * (dcmf[row + n] - dot) : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// blend / decoder tail / sun radiance backward
+// ------------------------------------------------------------------------------------------------------------
+// y_g = (1-a) sky + a sun,  y_lin = decomp(y_g).  Given dL/dy_g (dyg, nullable) and dL/dy_lin (dyl, nullable):
+//   t = dyg + dyl * decomp'(y_g);  dsky = (1-a) t;  dsun = a t          (alpha is a constant: train.py:257)
+__global__ void blend_bwd_kernel(const float* __restrict__ y_gamma, const float* __restrict__ alpha,
+                                 const float* __restrict__ dyg, const float* __restrict__ dyl, size_t n,
+                                 float* __restrict__ dsky, float* __restrict__ dsun) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float t = dyg ? dyg[i] : 0.f;
+    if (dyl) t += dyl[i] * expf(y_gamma[i] * LN11) * (LN11 / 10.f);
+    const float a = alpha[i];
+    dsky[i] = (1.f - a) * t;
+    dsun[i] = a * t;
+  }
+}
+
+// y = relu(res + lrelu(c, 0.1)):  g = dy*[y>0];  dres = g;  dc = g * (y - res > 0 ? 1 : 0.1)   (generator.py:119-124)
+__global__ void decoder_tail_bwd_kernel(const float* __restrict__ y, const float* __restrict__ res,
+                                        const float* __restrict__ dy, size_t n, float* __restrict__ dc,
+                                        float* __restrict__ dres) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float yv = y[i];
+    const float g = yv > 0.f ? dy[i] : 0.f;
+    if (dres) dres[i] = g;
+    dc[i] = g * ((yv - res[i]) > 0.f ? 1.f : 0.1f);
+  }
+}
+
+// Backward of hdrsky_sun_rad.  One block per sample: d rad_gamma3 [B,P,3] ->
+//   dpre[b][0..1] = d(pre-sigmoid gamma, beta),  dx[b][p] = dL/d(cmf/gmax),  dotx[b] = sum_p dx*cmf  (for the max term)
+__global__ void __launch_bounds__(256) sun_rad_bwd_kernel(const float* __restrict__ cmf, const unsigned int* gmax_bits,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ drg3, int P, float* __restrict__ dx,
+                                                          float* __restrict__ dpre, float* __restrict__ dotx) {
+  __shared__ float sred[3][4];
+  const int b = blockIdx.x;
+  const float gmax = __uint_as_float(*gmax_bits);
+  const float g = gamma[b], bt = beta[b];
+  const float D = bt * 1.7724539f + 1e-5f, be = bt + 1e-5f;
+  float sg = 0.f, sb = 0.f, sd = 0.f;
+  for (int p = threadIdx.x; p < P; p += 256) {
+    const size_t i = (size_t)b * P + p;
+    const float x = cmf[i] / gmax;
+    const float d1 = 1.f - x;
+    const float E = expf(-(d1 * d1) / be);
+    const float r = g * E / D;
+    float dr = 0.f;
+    if (!(r > 30000.f)) {
+      const float drg = drg3[i * 3] + drg3[i * 3 + 1] + drg3[i * 3 + 2];
+      dr = drg * 10.f / ((1.f + 10.f * r) * LN11);
+    }
+    sg += dr * E / D;
+    sb += dr * (g * E * (d1 * d1) / (be * be) / D - g * E * 1.7724539f / (D * D));
+    const float dxi = dr * g * E * 2.f * d1 / be / D;
+    dx[i] = dxi;
+    sd += dxi * cmf[i];
+  }
+  sg = wave_sum(sg); sb = wave_sum(sb); sd = wave_sum(sd);
+  if ((threadIdx.x & 63) == 0) { sred[0][threadIdx.x >> 6] = sg; sred[1][threadIdx.x >> 6] = sb; sred[2][threadIdx.x >> 6] = sd; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float tg = (sred[0][0] + sred[0][1]) + (sred[0][2] + sred[0][3]);
+    const float tb = (sred[1][0] + sred[1][1]) + (sred[1][2] + sred[1][3]);
+    dpre[b * 2 + 0] = tg * g * (1.f - g);
+    dpre[b * 2 + 1] = tb * bt * (1.f - bt);
+    dotx[b] = (sred[2][0] + sred[2][1]) + (sred[2][2] + sred[2][3]);
+  }
+}
+
+// dcmf (+)= dx/gmax, and at the (first) arg-max element of the whole batch: -= sum_b dotx[b] / gmax^2
+// (tf.reduce_max over the batch tensor, generator.py:160)
+__global__ void sun_rad_bwd_cmf_kernel(const float* __restrict__ cmf, const unsigned int* gmax_bits,
+                                       const float* __restrict__ dx, const float* __restrict__ dotx, int B, int P,
+                                       int* claimed, float* __restrict__ dcmf) {
+  const float gmax = __uint_as_float(*gmax_bits);
+  float tot = 0.f;
+  for (int b = 0; b < B; ++b) tot += dotx[b];
+  const size_t n = (size_t)B * P;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float g = dx[i] / gmax;
+    if (cmf[i] == gmax && atomicCAS(claimed, 0, 1) == 0) g -= tot / (gmax * gmax);
+    dcmf[i] += g;
+  }
+}
+
+// d flat[b][i] = dpre[b][0]*kg[i] + dpre[b][1]*kb[i];  dkg[i] += sum_b dpre[b][0]*flat[b][i] (flat recomputed from x);
+// dbias handled by the caller (sum_b dpre).   (sunrad_net.py:52-53)
+__global__ void dense_heads_bwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                       const float* __restrict__ shift, float slope, int B, int F, int C,
+                                       const float* __restrict__ kg, const float* __restrict__ kb,
+                                       const float* __restrict__ dpre, float* __restrict__ dact, float* __restrict__ dkg,
+                                       float* __restrict__ dkb, float* dbg, float* dbb) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < F; i += gridDim.x * blockDim.x) {
+    const int c = i % C;
+    const float wg = kg[i], wb = kb[i];
+    float ag = 0.f, ab = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const float v = x[(size_t)b * F + i];
+      const float f = leaky(scale ? v * scale[c] + shift[c] : v, slope);
+      ag += dpre[b * 2] * f; ab += dpre[b * 2 + 1] * f;
+      dact[(size_t)b * F + i] = dpre[b * 2] * wg + dpre[b * 2 + 1] * wb;
+    }
+    dkg[i] += ag; dkb[i] += ab;
+    if (i == 0) {
+      float sg = 0.f, sb = 0.f;
+      for (int b = 0; b < B; ++b) { sg += dpre[b * 2]; sb += dpre[b * 2 + 1]; }
+      dbg[0] += sg; dbb[0] += sb;
+    }
+  }
+}
+
+// out[b,p,0..c_take) = x[b,p,c_off..c_off+c_take) * scale      (d y_lin = channels 3..5 of the disc input gradient)
+__global__ void slice_channels_kernel(const float* __restrict__ x, size_t npix, int C, int c_off, int c_take, float scale,
+                                      int accumulate, float* __restrict__ out) {
+  const size_t n = npix * c_take;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = x[(i / c_take) * C + c_off + (i % c_take)] * scale;
+    out[i] = accumulate ? out[i] + v : v;
+  }
+}
+
+// concat along channels: out[b,p,:] = [a (Ca), b (Cb)]      (discriminator.py:43)
+__global__ void concat2_kernel(const float* __restrict__ a, int Ca, const float* __restrict__ b, int Cb, size_t npix,
+                               float* __restrict__ out) {
+  const int C = Ca + Cb;
+  const size_t n = npix * C;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const size_t p = i / C;
+    out[i] = c < Ca ? a[p * Ca + c] : b[p * Cb + (c - Ca)];
+  }
+}
+
+// VGG input: x*255 - mean[c]  (vgg16.py:133-141); backward is a multiply by 255 (folded into the caller's scale)
+__global__ void vgg_pre_kernel(const float* __restrict__ x, size_t n, float* __restrict__ y) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % 3);
+    y[i] = x[i] * 255.f - (c == 0 ? 103.939f : (c == 1 ? 116.779f : 123.68f));
+  }
+}
+
+// y = a*sa + b*sb  (b nullable)
+__global__ void axpby_kernel(const float* __restrict__ a, float sa, const float* __restrict__ b, float sb, size_t n,
+                             float* __restrict__ y) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    y[i] = a[i] * sa + (b ? b[i] * sb : 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Dense weight / bias gradient: dW[K][N] += x[M][K]^T dy[M][N], db[N] += sum_m dy   (M <= 32: HBM-write bound)
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) fc_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int M,
+                                                       int K, int N, int accumulate, float* __restrict__ dw,
+                                                       float* __restrict__ db) {
+  __shared__ float sx[32][8];  // [m][k-local]
+  const int n4 = N >> 2;
+  const int k0 = blockIdx.y * 8;
+  const int nq = blockIdx.x * 256 + threadIdx.x;
+  for (int i = threadIdx.x; i < M * 8; i += 256) sx[i / 8][i % 8] = x[(size_t)(i / 8) * K + k0 + (i % 8)];
+  __syncthreads();
+  if (nq >= n4) return;
+  float4 acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int m = 0; m < M; ++m) {
+    const float4 d = reinterpret_cast<const float4*>(dy + (size_t)m * N)[nq];
+    bs.x += d.x; bs.y += d.y; bs.z += d.z; bs.w += d.w;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float xv = sx[m][k];
+      acc[k].x += xv * d.x; acc[k].y += xv * d.y; acc[k].z += xv * d.z; acc[k].w += xv * d.w;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    float4* dst = reinterpret_cast<float4*>(dw + (size_t)(k0 + k) * N) + nq;
+    float4 o = accumulate ? *dst : make_float4(0.f, 0.f, 0.f, 0.f);
+    o.x += acc[k].x; o.y += acc[k].y; o.z += acc[k].z; o.w += acc[k].w;
+    *dst = o;
+  }
+  if (db && blockIdx.y == 0) {
+    float4* dst = reinterpret_cast<float4*>(db) + nq;
+    float4 o = accumulate ? *dst : make_float4(0.f, 0.f, 0.f, 0.f);
+    o.x += bs.x; o.y += bs.y; o.z += bs.z; o.w += bs.w;
+    *dst = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Keras-2 OptimizerV2 RMSprop (train.py:201-202; rho 0.9, momentum 0, eps 1e-7 OUTSIDE the sqrt) over one flat
+// parameter buffer:  ms <- rho*ms + (1-rho)*g^2 ;  w <- w - lr*g/(sqrt(ms)+eps).  gscale averages replica sums.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) rmsprop_kernel(float* __restrict__ w, const float* __restrict__ g,
+                                                      float* __restrict__ ms, size_t n4, float lr, float rho, float eps,
+                                                      float gscale) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 wv = reinterpret_cast<float4*>(w)[i];
+    const float4 gv = reinterpret_cast<const float4*>(g)[i];
+    float4 mv = reinterpret_cast<float4*>(ms)[i];
+    const float gs[4] = {gv.x * gscale, gv.y * gscale, gv.z * gscale, gv.w * gscale};
+    float ws[4] = {wv.x, wv.y, wv.z, wv.w}, m[4] = {mv.x, mv.y, mv.z, mv.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      m[j] = rho * m[j] + (1.f - rho) * gs[j] * gs[j];
+      ws[j] -= lr * gs[j] / (sqrtf(m[j]) + eps);
+    }
+    reinterpret_cast<float4*>(w)[i] = make_float4(ws[0], ws[1], ws[2], ws[3]);
+    reinterpret_cast<float4*>(ms)[i] = make_float4(m[0], m[1], m[2], m[3]);
+  }
+}
+
+inline unsigned grid_for(size_t n, int per = 256) {
+  size_t g = (n + per - 1) / per;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+}  // namespace
+
+#define S_(x) ((hipStream_t)(x))
+
+extern "C" {
+
+int hdrsky_bn_train_finalize(const float* part, int nparts_total, int C, int count, const float* gamma, const float* beta,
+                             float eps, float momentum, float* moving_mean, float* moving_var, float* mean, float* rstd,
+                             float* scale, float* shift, void* stream) {
+  if (!part || !gamma || !beta || !mean || !rstd || !scale || !shift) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(bn_train_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S_(stream), part, nparts_total, C,
+                     (float)count, gamma, beta, eps, momentum, moving_mean, moving_var, mean, rstd, scale, shift);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+/* workspace: (2*nblocks*C + 2*C) floats, nblocks = hdrsky_bn_bwd_nblocks() */
+int hdrsky_bn_bwd_nblocks(void) { return 128; }
+
+int hdrsky_bn_act_bwd(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
+                      const float* beta, float slope, int npix, int C, float* workspace, float* dgamma, float* dbeta,
+                      float* dx, void* stream) {
+  if (!x || !dy || !mean || !rstd || !gamma || !beta || !workspace || !dx || (C & 3) || C > 1024) return HDRSKY_EINVAL;
+  const int nb = 128;
+  float* part = workspace;
+  float* m1m2 = workspace + (size_t)2 * nb * C;
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(256), 256 * 8 * sizeof(float), S_(stream), x, dy, mean, rstd,
+                     gamma, beta, slope, (size_t)npix, C, part);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S_(stream), part, nb, C, (float)npix, m1m2,
+                     dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for((size_t)npix * C / 4)), dim3(256), 0, S_(stream), x, dy, mean,
+                     rstd, gamma, beta, slope, m1m2, (size_t)npix * C / 4, C, dx);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_affine_act_bwd(const float* x, const float* dy, const float* scale, const float* shift, float slope, size_t n,
+                          int C, float* dx, void* stream) {
+  if (!x || !dy || !dx) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(affine_act_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, S_(stream), x, dy, scale, shift, slope, n, C, dx);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_maxpool_fwd(const float* y, int B, int H, int W, int C, float* p, void* stream) {
+  if (!y || !p || (C & 3) || ((H | W) & 1)) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((size_t)B * H * W * C / 16)), dim3(256), 0, S_(stream), y, B, H, W, C, p);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_maxpool_relu_bwd(const float* y, const float* dp, int B, int H, int W, int C, float* dy, void* stream) {
+  if (!y || !dp || !dy || (C & 3) || ((H | W) & 1)) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(maxpool_relu_bwd_kernel, dim3(grid_for((size_t)B * H * W * C / 16)), dim3(256), 0, S_(stream), y, dp, B,
+                     H, W, C, dy);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_up2x_fwd(const float* a, const float* b, int B, int H, int W, int C, float* y, void* stream) {
+  if (!a || !y) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(up2x_fwd_kernel, dim3(grid_for((size_t)B * 4 * H * W * C)), dim3(256), 0, S_(stream), a, b, B, H, W, C, y);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_up2x_bwd(const float* dy, int B, int H, int W, int C, float scale, int accumulate, float* dx, void* stream) {
+  if (!dy || !dx) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(up2x_bwd_kernel, dim3(grid_for((size_t)B * H * W * C)), dim3(256), 0, S_(stream), dy, B, H, W, C, scale,
+                     accumulate, dx);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_blur3(const float* x, int B, int H, int W, int C, float sigma, int transpose, float* y, void* stream) {
+  if (!x || !y || H < 4 || W < 4) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(blur3_kernel, dim3(grid_for((size_t)B * H * W * C)), dim3(256), 0, S_(stream), x, B, H, W, C, sigma,
+                     transpose, y);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_dog_mid(const float* base, int B, int H, int W, int C, float weight, float* h, float* loss, void* stream) {
+  if (!base || !h) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(dog_mid_kernel, dim3(grid_for((size_t)B * H * W * C)), dim3(256), 0, S_(stream), base, B, H, W, C,
+                     weight, h, loss);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_dog_mid_bwd(const float* h, int B, int H, int W, int C, float* dbase, void* stream) {
+  if (!h || !dbase || H < 4 || W < 4) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(dog_mid_bwd_kernel, dim3(grid_for((size_t)B * H * W * C)), dim3(256), 0, S_(stream), h, B, H, W, C, dbase);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_l1(const float* a, const float* b, size_t n, float wl, float wg, float* loss, float* da, int accumulate,
+              void* stream) {
+  if (!a) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(l1_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, S_(stream), a, b, n, wl, wg, loss, da, accumulate);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_mse(const float* x, float target, size_t n, float wl, float wg, float* loss, float* dx, void* stream) {
+  if (!x) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(mse_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, S_(stream), x, target, n, wl, wg, loss, dx);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_kl(const float* gt, const float* cmf, int B, int N, float* loss, float* dcmf, void* stream) {
+  if (!gt || !cmf) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(kl_kernel, dim3(grid_for((size_t)B * N, 1024)), dim3(256), 0, S_(stream), gt, cmf, B, N, loss, dcmf);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_softmax_bwd(const float* cmf, const float* dcmf, const float* z, int M, int N, float* dz, void* stream) {
+  if (!cmf || !dcmf || !z || !dz) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3(M), dim3(256), 0, S_(stream), cmf, dcmf, z, N, dz);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_blend_bwd(const float* y_gamma, const float* alpha, const float* dyg, const float* dyl, size_t n, float* dsky,
+                     float* dsun, void* stream) {
+  if (!y_gamma || !alpha || !dsky || !dsun) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(blend_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, S_(stream), y_gamma, alpha, dyg, dyl, n, dsky, dsun);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_decoder_tail_bwd(const float* y, const float* res, const float* dy, size_t n, float* dc, float* dres,
+                            void* stream) {
+  if (!y || !res || !dy || !dc) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(decoder_tail_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, S_(stream), y, res, dy, n, dc, dres);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+/* scratch: B*P + B floats + 1 int (claimed flag, zeroed here); dcmf is accumulated into */
+int hdrsky_sun_rad_bwd(const float* cmf, const void* gmax_bits, const float* gamma, const float* beta, const float* drg3,
+                       int B, int P, float* scratch, float* dpre, float* dcmf, void* stream) {
+  if (!cmf || !gmax_bits || !gamma || !beta || !drg3 || !scratch || !dpre || !dcmf) return HDRSKY_EINVAL;
+  float* dx = scratch;
+  float* dotx = scratch + (size_t)B * P;
+  int* claimed = reinterpret_cast<int*>(dotx + B);
+  if (hipMemsetAsync(claimed, 0, sizeof(int), S_(stream)) != hipSuccess) return HDRSKY_ELAUNCH;
+  hipLaunchKernelGGL(sun_rad_bwd_kernel, dim3(B), dim3(256), 0, S_(stream), cmf, (const unsigned int*)gmax_bits, gamma, beta,
+                     drg3, P, dx, dpre, dotx);
+  hipLaunchKernelGGL(sun_rad_bwd_cmf_kernel, dim3(grid_for((size_t)B * P)), dim3(256), 0, S_(stream), cmf,
+                     (const unsigned int*)gmax_bits, dx, dotx, B, P, claimed, dcmf);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_dense_heads_bwd(const float* x, const float* scale, const float* shift, float slope, int B, int F, int C,
+                           const float* kg, const float* kb, const float* dpre, float* dact, float* dkg, float* dkb,
+                           float* dbg, float* dbb, void* stream) {
+  if (!x || !kg || !kb || !dpre || !dact || !dkg || !dkb || !dbg || !dbb) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(dense_heads_bwd_kernel, dim3(cdiv(F, 256)), dim3(256), 0, S_(stream), x, scale, shift, slope, B, F, C,
+                     kg, kb, dpre, dact, dkg, dkb, dbg, dbb);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_slice_channels(const float* x, size_t npix, int C, int c_off, int c_take, float scale, int accumulate,
+                          float* out, void* stream) {
+  if (!x || !out || c_off + c_take > C) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(slice_channels_kernel, dim3(grid_for(npix * c_take)), dim3(256), 0, S_(stream), x, npix, C, c_off,
+                     c_take, scale, accumulate, out);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_concat2(const float* a, int Ca, const float* b, int Cb, size_t npix, float* out, void* stream) {
+  if (!a || !b || !out) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(concat2_kernel, dim3(grid_for(npix * (Ca + Cb))), dim3(256), 0, S_(stream), a, Ca, b, Cb, npix, out);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_vgg_pre(const float* x, size_t n, float* y, void* stream) {
+  if (!x || !y || (n % 3) != 0) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(vgg_pre_kernel, dim3(grid_for(n)), dim3(256), 0, S_(stream), x, n, y);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_axpby(const float* a, float sa, const float* b, float sb, size_t n, float* y, void* stream) {
+  if (!a || !y) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(256), 0, S_(stream), a, sa, b, sb, n, y);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_fc_wgrad(const float* x, const float* dy, int M, int K, int N, int accumulate, float* dw, float* db,
+                    void* stream) {
+  if (!x || !dy || !dw || M <= 0 || M > 32 || (K & 7) || (N & 3)) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(fc_wgrad_kernel, dim3(cdiv(N / 4, 256), K / 8), dim3(256), 0, S_(stream), x, dy, M, K, N, accumulate, dw, db);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_rmsprop(float* w, const float* g, float* ms, size_t n, float lr, float rho, float eps, float gscale,
+                   void* stream) {
+  if (!w || !g || !ms || (n & 3)) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(rmsprop_kernel, dim3(grid_for(n / 4, 1024)), dim3(256), 0, S_(stream), w, g, ms, n / 4, lr, rho, eps, gscale);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+}  // extern "C"

@@ -209,16 +209,17 @@ def bn_eval_affine(gamma, beta, mm, mv, eps=IN_EPS):
     return scale, shift
 
 
-def norm_act_bwd(x, stats: Stats, gamma, beta, slope, dy, pooled, eps=IN_EPS, want_sums=False):
+def norm_act_bwd(x, stats: Stats, gamma, beta, slope, dy, pooled, eps=IN_EPS, want_sums=False, dgamma=None, dbeta=None):
     """dx of y = leaky(IN(x)) [-> maxpool2x2]; dy is the gradient wrt y (or wrt the pooled y)."""
     _f32(x)
     B, H, W, C = x.shape
     _f32(stats.part, B, stats.nparts, 2, C)
     _f32(dy, B, H // 2 if pooled else H, W // 2 if pooled else W, C)
     dx = torch.empty_like(x)
-    sums = torch.empty((B, C, 2), dtype=torch.float32, device=x.device) if want_sums else None
+    sums = torch.empty((B, 2, C), dtype=torch.float32, device=x.device) if want_sums else None
     L.check(L.load().hdrsky_norm_act_bwd(_p(x), _p(stats.part), stats.nparts, _p(_f32(gamma, C)), _p(_f32(beta, C)),
-                                         eps, slope, _p(dy), int(pooled), _p(dx), _p(sums), B, H, W, C, _stream()),
+                                         eps, slope, _p(dy), int(pooled), _p(dx), _p(sums), _p(dgamma), _p(dbeta),
+                                         B, H, W, C, _stream()),
             "norm_act_bwd")
     return (dx, sums) if want_sums else dx
 
@@ -379,3 +380,216 @@ def tonemap(x, decompress):
     y = torch.empty_like(x)
     L.check(L.load().hdrsky_tonemap(_p(x), _p(y), x.numel(), int(decompress), _stream()), "tonemap")
     return y
+
+
+# ------------------------------------------------------------------------------------------------
+# training-step front ends (csrc/train_ops.hip, csrc/conv_wgrad.hip)
+# ------------------------------------------------------------------------------------------------
+def conv_dgrad_desc(fwd):
+    d = L.ConvDesc()
+    L.check(L.load().hdrsky_conv_desc_init_dgrad(d, fwd), "conv_desc_init_dgrad")
+    return d
+
+
+def conv2d_dgrad(dy, pwT: PackedConv, fwd_desc, residual=None, compute=BF16, want_stats=False):
+    """Gradient wrt the conv-input domain of the forward conv `fwd_desc` (pwT = PackedConv(w, transpose_flip=True))."""
+    return conv2d(dy, pwT, None, desc=conv_dgrad_desc(fwd_desc), residual=residual, compute=compute, want_stats=want_stats)
+
+
+def _empty_like_shape(t, shape):
+    return torch.empty(shape, dtype=torch.float32, device=t.device)
+
+
+def bn_train_finalize(stats: Stats, gamma, beta, B, C, moving_mean=None, moving_var=None, eps=IN_EPS, momentum=0.99):
+    """Batch statistics over (N,H,W) from conv partials -> (mean, rstd, scale, shift) [C]; updates moving stats in place."""
+    _f32(stats.part, B, stats.nparts, 2, C)
+    outs = [torch.empty((C,), dtype=torch.float32, device=gamma.device) for _ in range(4)]
+    L.check(L.load().hdrsky_bn_train_finalize(_p(stats.part), B * stats.nparts, C, B * stats.count, _p(_f32(gamma, C)),
+                                              _p(_f32(beta, C)), eps, momentum, _p(moving_mean), _p(moving_var),
+                                              *[_p(o) for o in outs], _stream()), "bn_train_finalize")
+    return outs
+
+
+def bn_act_bwd(x, dy, mean, rstd, gamma, beta, slope, dgamma=None, dbeta=None):
+    _f32(x); _f32(dy, *x.shape)
+    C = x.shape[-1]
+    npix = x.numel() // C
+    lib = L.load()
+    ws = torch.empty((2 * lib.hdrsky_bn_bwd_nblocks() * C + 2 * C,), dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    L.check(lib.hdrsky_bn_act_bwd(_p(x), _p(dy), _p(_f32(mean, C)), _p(_f32(rstd, C)), _p(_f32(gamma, C)), _p(_f32(beta, C)),
+                                  slope, npix, C, _p(ws), _p(dgamma), _p(dbeta), _p(dx), _stream()), "bn_act_bwd")
+    return dx
+
+
+def affine_act_bwd(x, dy, scale, shift, slope):
+    _f32(x); _f32(dy, *x.shape)
+    C = x.shape[-1]
+    dx = torch.empty_like(x)
+    L.check(L.load().hdrsky_affine_act_bwd(_p(x), _p(dy), _p(scale), _p(shift), slope, x.numel(), C, _p(dx), _stream()),
+            "affine_act_bwd")
+    return dx
+
+
+def maxpool(y):
+    B, H, W, C = y.shape
+    _f32(y)
+    p = torch.empty((B, H // 2, W // 2, C), dtype=torch.float32, device=y.device)
+    L.check(L.load().hdrsky_maxpool_fwd(_p(y), B, H, W, C, _p(p), _stream()), "maxpool_fwd")
+    return p
+
+
+def maxpool_relu_bwd(y, dp):
+    B, H, W, C = y.shape
+    _f32(y); _f32(dp, B, H // 2, W // 2, C)
+    dy = torch.empty_like(y)
+    L.check(L.load().hdrsky_maxpool_relu_bwd(_p(y), _p(dp), B, H, W, C, _p(dy), _stream()), "maxpool_relu_bwd")
+    return dy
+
+
+def up2x(a, b=None):
+    B, H, W, C = a.shape
+    _f32(a)
+    if b is not None:
+        _f32(b, *a.shape)
+    y = torch.empty((B, 2 * H, 2 * W, C), dtype=torch.float32, device=a.device)
+    L.check(L.load().hdrsky_up2x_fwd(_p(a), _p(b), B, H, W, C, _p(y), _stream()), "up2x_fwd")
+    return y
+
+
+def up2x_bwd(dy, scale=1.0, out=None):
+    B, H2, W2, C = dy.shape
+    _f32(dy)
+    acc = out is not None
+    dx = out if acc else torch.empty((B, H2 // 2, W2 // 2, C), dtype=torch.float32, device=dy.device)
+    _f32(dx, B, H2 // 2, W2 // 2, C)
+    L.check(L.load().hdrsky_up2x_bwd(_p(dy), B, H2 // 2, W2 // 2, C, scale, int(acc), _p(dx), _stream()), "up2x_bwd")
+    return dx
+
+
+def blur3(x, sigma, transpose=False):
+    B, H, W, C = x.shape
+    _f32(x)
+    y = torch.empty_like(x)
+    L.check(L.load().hdrsky_blur3(_p(x), B, H, W, C, sigma, int(transpose), _p(y), _stream()), "blur3")
+    return y
+
+
+DOG_SIGMA_BASE = 1.2489996
+
+
+def dog_loss(y_lin, hdr_t, weight, loss_slot, dy_out):
+    """loss_slot += weight * DoG-L1(y_lin, hdr_t) (tf_utils.py:61-73, train.py:316-322); dy_out += its gradient wrt y_lin."""
+    lib = L.load()
+    B, H, W, C = y_lin.shape
+    up = up2x(y_lin, hdr_t)
+    base = blur3(up, DOG_SIGMA_BASE)
+    h = torch.empty((5,) + tuple(base.shape), dtype=torch.float32, device=base.device)
+    L.check(lib.hdrsky_dog_mid(_p(base), B, 2 * H, 2 * W, C, weight, _p(h), _p(loss_slot), _stream()), "dog_mid")
+    dbase = torch.empty_like(base)
+    L.check(lib.hdrsky_dog_mid_bwd(_p(h), B, 2 * H, 2 * W, C, _p(dbase), _stream()), "dog_mid_bwd")
+    dup = blur3(dbase, DOG_SIGMA_BASE, transpose=True)
+    up2x_bwd(dup, 1.0, out=dy_out)
+
+
+def l1(a, b, wl, wg, loss_slot, da=None, accumulate=False):
+    _f32(a)
+    if b is not None:
+        _f32(b, *a.shape)
+    L.check(L.load().hdrsky_l1(_p(a), _p(b), a.numel(), wl, wg, _p(loss_slot), _p(da), int(accumulate), _stream()), "l1")
+
+
+def mse(x, target, wl, wg, loss_slot, want_grad=True):
+    _f32(x)
+    dx = torch.empty_like(x) if want_grad else None
+    L.check(L.load().hdrsky_mse(_p(x), target, x.numel(), wl, wg, _p(loss_slot), _p(dx), _stream()), "mse")
+    return dx
+
+
+def kl(gt, cmf, loss_slot):
+    B, N = cmf.shape
+    _f32(gt, B, N); _f32(cmf)
+    d = torch.empty_like(cmf)
+    L.check(L.load().hdrsky_kl(_p(gt), _p(cmf), B, N, _p(loss_slot), _p(d), _stream()), "kl")
+    return d
+
+
+def softmax_bwd(cmf, dcmf, z):
+    M, N = cmf.shape
+    dz = torch.empty_like(cmf)
+    L.check(L.load().hdrsky_softmax_bwd(_p(_f32(cmf)), _p(_f32(dcmf, M, N)), _p(_f32(z, M, N)), M, N, _p(dz), _stream()),
+            "softmax_bwd")
+    return dz
+
+
+def blend_bwd(y_gamma, alpha, dyg, dyl):
+    ds, du = torch.empty_like(y_gamma), torch.empty_like(y_gamma)
+    L.check(L.load().hdrsky_blend_bwd(_p(_f32(y_gamma)), _p(_f32(alpha, *y_gamma.shape)), _p(dyg), _p(dyl), y_gamma.numel(),
+                                      _p(ds), _p(du), _stream()), "blend_bwd")
+    return ds, du
+
+
+def decoder_tail_bwd(y, res, dy, want_dres):
+    dc = torch.empty_like(y)
+    dres = torch.empty_like(y) if want_dres else None
+    L.check(L.load().hdrsky_decoder_tail_bwd(_p(_f32(y)), _p(_f32(res, *y.shape)), _p(_f32(dy, *y.shape)), y.numel(), _p(dc),
+                                             _p(dres), _stream()), "decoder_tail_bwd")
+    return dc, dres
+
+
+def sun_rad_bwd(cmf, gmax_bits, gamma, beta, drg3, dcmf):
+    B, P = cmf.shape
+    scratch = torch.empty((B * P + B + 4,), dtype=torch.float32, device=cmf.device)
+    dpre = torch.empty((B, 2), dtype=torch.float32, device=cmf.device)
+    L.check(L.load().hdrsky_sun_rad_bwd(_p(cmf), _p(gmax_bits), _p(gamma), _p(beta), _p(_f32(drg3)), B, P, _p(scratch), _p(dpre),
+                                        _p(_f32(dcmf, B, P)), _stream()), "sun_rad_bwd")
+    return dpre
+
+
+def dense_heads_bwd(x, scale, shift, slope, kg, kb, dpre, dkg, dkb, dbg, dbb):
+    B = x.shape[0]; C = x.shape[-1]; F = x[0].numel()
+    dact = torch.empty_like(x)
+    L.check(L.load().hdrsky_dense_heads_bwd(_p(_f32(x)), _p(scale), _p(shift), slope, B, F, C, _p(kg), _p(kb), _p(dpre), _p(dact),
+                                            _p(dkg), _p(dkb), _p(dbg), _p(dbb), _stream()), "dense_heads_bwd")
+    return dact
+
+
+def slice_channels(x, c_off, c_take, scale=1.0, out=None):
+    C = x.shape[-1]
+    npix = x.numel() // C
+    acc = out is not None
+    o = out if acc else torch.empty(tuple(x.shape[:-1]) + (c_take,), dtype=torch.float32, device=x.device)
+    L.check(L.load().hdrsky_slice_channels(_p(_f32(x)), npix, C, c_off, c_take, scale, int(acc), _p(o), _stream()), "slice_channels")
+    return o
+
+
+def concat2(a, b):
+    Ca, Cb = a.shape[-1], b.shape[-1]
+    out = torch.empty(tuple(a.shape[:-1]) + (Ca + Cb,), dtype=torch.float32, device=a.device)
+    L.check(L.load().hdrsky_concat2(_p(_f32(a)), Ca, _p(_f32(b)), Cb, a.numel() // Ca, _p(out), _stream()), "concat2")
+    return out
+
+
+def vgg_pre(x):
+    y = torch.empty_like(x)
+    L.check(L.load().hdrsky_vgg_pre(_p(_f32(x)), x.numel(), _p(y), _stream()), "vgg_pre")
+    return y
+
+
+def axpby(a, sa, b=None, sb=0.0, out=None):
+    y = out if out is not None else torch.empty_like(a)
+    L.check(L.load().hdrsky_axpby(_p(_f32(a)), sa, _p(b), sb, a.numel(), _p(y), _stream()), "axpby")
+    return y
+
+
+def fc_wgrad(x, dy, dw, db, accumulate=False):
+    M, Kd = x.shape
+    N = dy.shape[1]
+    _f32(x); _f32(dy, M, N); _f32(dw, Kd, N)
+    L.check(L.load().hdrsky_fc_wgrad(_p(x), _p(dy), M, Kd, N, int(accumulate), _p(dw), _p(db), _stream()), "fc_wgrad")
+
+
+def rmsprop(w, g, ms, lr, rho=0.9, eps=1e-7, gscale=1.0):
+    n = w.numel()
+    _f32(w); _f32(g, n); _f32(ms, n)
+    L.check(L.load().hdrsky_rmsprop(_p(w), _p(g), _p(ms), n, lr, rho, eps, gscale, _stream()), "rmsprop")

@@ -82,6 +82,10 @@ typedef struct hdrsky_conv_desc {
 int hdrsky_conv_desc_init(hdrsky_conv_desc* d, int B, int H, int W, int Cin, int Cout, int KH, int KW,
                           int stride, int same, int upsample);
 
+/* Descriptor of the DATA GRADIENT of conv `fwd` (stride-1 conv of the zero-stuffed output gradient with the
+ * transpose_flip=1 packed filter; output = fwd's conv-input domain). [host] */
+int hdrsky_conv_desc_init_dgrad(hdrsky_conv_desc* d, const hdrsky_conv_desc* fwd);
+
 /* Number of bf16 elements of the packed weight image for a [KH,KW,Cin,Cout] filter. [host] */
 size_t hdrsky_conv_packed_elems(int KH, int KW, int Cin, int Cout);
 
@@ -125,10 +129,11 @@ int hdrsky_bn_eval_affine(const float* gamma, const float* beta, const float* mo
                           float eps, int C, float* scale, float* shift, void* stream);
 
 /* Data gradient of y = leaky(IN(x)) [-> 2x2 max-pool when pooled=1]; dy is [B,H,W,C] or [B,H/2,W/2,C].
- * sums (nullable) receives [B][C][2] = (sum g, sum g*xhat).  tf.gradients path of grad_cam.py:31. */
+ * sums (nullable) receives [B][2][C] = (sum g, sum g*xhat) planes; dgamma/dbeta (nullable) are ACCUMULATED with
+ * fp32 atomics.  tf.gradients path of grad_cam.py:31 and the IN backward of train.py:402. */
 int hdrsky_norm_act_bwd(const float* x, const float* part, int nparts, const float* gamma, const float* beta,
-                        float eps, float slope, const float* dy, int pooled, float* dx, float* sums, int B, int H,
-                        int W, int C, void* stream);
+                        float eps, float slope, const float* dy, int pooled, float* dx, float* sums, float* dgamma,
+                        float* dbeta, int B, int H, int W, int C, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Sun-pose dense head (sunpose_net.py:48-52,64-70) and its Grad-CAM backward (grad_cam.py:29-44)
@@ -188,6 +193,62 @@ int hdrsky_tonemap(const float* x, float* y, size_t n, int decompress, void* str
 int hdrsky_conv2d_wgrad(const hdrsky_conv_desc* d, const float* x, const float* dy, const float* in_scale,
                         const float* in_shift, const float* in_part, const float* in_gamma, const float* in_beta,
                         float* dw, float* db, void* stream);
+
+/* Keras BatchNormalization(training=True) statistics from the producing conv's partials [nparts_total][2][C]
+ * (discriminator.py:25, sunrad_net.py:26): mean/rstd/scale/shift tables + moving-stat update (momentum 0.99,
+ * Bessel-corrected variance).  moving_* nullable. */
+int hdrsky_bn_train_finalize(const float* part, int nparts_total, int C, int count, const float* gamma, const float* beta, float eps, float momentum, float* moving_mean, float* moving_var, float* mean, float* rstd, float* scale, float* shift, void* stream);
+/* [host] number of reduction blocks hdrsky_bn_act_bwd uses; its workspace is (2*nblocks*C + 2*C) floats. */
+int hdrsky_bn_bwd_nblocks(void);
+/* Backward of y = leaky(BN_train(x)): dx, and dgamma/dbeta ACCUMULATED into the given buffers (nullable). */
+int hdrsky_bn_act_bwd(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma, const float* beta, float slope, int npix, int C, float* workspace, float* dgamma, float* dbeta, float* dx, void* stream);
+/* dx = dy*act'(x*scale[c]+shift[c])*scale[c] (BN in inference mode); scale==NULL: x is the ACTIVATED tensor and
+ * dx = dy*(x>0 ? 1 : slope)  (Keras LeakyReLU / ReLU backward). */
+int hdrsky_affine_act_bwd(const float* x, const float* dy, const float* scale, const float* shift, float slope, size_t n, int C, float* dx, void* stream);
+/* 2x2/2 max-pool (vgg16.py:85-86). */
+int hdrsky_maxpool_fwd(const float* y, int B, int H, int W, int C, float* p, void* stream);
+/* Backward of maxpool(relu(.)) given the post-ReLU tensor y: gradient to the first arg-max where y > 0. */
+int hdrsky_maxpool_relu_bwd(const float* y, const float* dp, int B, int H, int W, int C, float* dy, void* stream);
+/* y = resize2x_bilinear(a - b) (b nullable), half-pixel centres (tf_utils.py:64). */
+int hdrsky_up2x_fwd(const float* a, const float* b, int B, int H, int W, int C, float* y, void* stream);
+/* Exact adjoint of the 2x bilinear resize: dx (+)= scale * R^T dy   (backward of ops.py:122 / tf_utils.py:64). */
+int hdrsky_up2x_bwd(const float* dy, int B, int H, int W, int C, float scale, int accumulate, float* dx, void* stream);
+/* TFA gaussian_filter2d 3x3, REFLECT padding (tf_utils.py:65,69-70); transpose=1 applies the adjoint. */
+int hdrsky_blur3(const float* x, int B, int H, int W, int C, float sigma, int transpose, float* y, void* stream);
+/* DoG differences + L1 (tf_utils.py:66-71, train.py:319-322) on the blurred base image: loss += weight*sum_i mean|d_i|,
+ * h[5][n] = gradient wrt the five Gaussian images. */
+int hdrsky_dog_mid(const float* base, int B, int H, int W, int C, float weight, float* h, float* loss, void* stream);
+/* dbase = sum_j G(s_j)^T h_j. */
+int hdrsky_dog_mid_bwd(const float* h, int B, int H, int W, int C, float* dbase, void* stream);
+/* loss += wl*mean|a-b| (b nullable); da (+)= wg*sign(a-b)/n  (train.py:311-313,325). */
+int hdrsky_l1(const float* a, const float* b, size_t n, float wl, float wg, float* loss, float* da, int accumulate, void* stream);
+/* LSGAN terms (train.py:234-237): loss += wl*mean((x-target)^2); dx = wg*2(x-target)/n. */
+int hdrsky_mse(const float* x, float target, size_t n, float wl, float wg, float* loss, float* dx, void* stream);
+/* Keras KLDivergence (train.py:232,305) and its gradient wrt cmf. */
+int hdrsky_kl(const float* gt, const float* cmf, int B, int N, float* loss, float* dcmf, void* stream);
+/* dz = cmf*(dcmf - <dcmf,cmf>)*[z>0]  (softmax + ReLU, sunpose_net.py:68-70). */
+int hdrsky_softmax_bwd(const float* cmf, const float* dcmf, const float* z, int M, int N, float* dz, void* stream);
+/* Backward of hdrsky_blend (alpha is a constant, train.py:257): dyg / dyl nullable. */
+int hdrsky_blend_bwd(const float* y_gamma, const float* alpha, const float* dyg, const float* dyl, size_t n, float* dsky, float* dsun, void* stream);
+/* Backward of y = relu(res + lrelu(c,0.1)) (generator.py:119-124,151-155): dc and (nullable) dres. */
+int hdrsky_decoder_tail_bwd(const float* y, const float* res, const float* dy, size_t n, float* dc, float* dres, void* stream);
+/* Backward of hdrsky_sun_rad: dpre[B][2] (pre-sigmoid gamma/beta), dcmf += (incl. the batch reduce_max term,
+ * generator.py:160).  scratch: B*P + B floats + 1 int. */
+int hdrsky_sun_rad_bwd(const float* cmf, const void* gmax_bits, const float* gamma, const float* beta, const float* drg3, int B, int P, float* scratch, float* dpre, float* dcmf, void* stream);
+/* Backward of the two Dense(1) heads: dact (wrt the activated flatten), dkg/dkb/dbg/dbb accumulated. */
+int hdrsky_dense_heads_bwd(const float* x, const float* scale, const float* shift, float slope, int B, int F, int C, const float* kg, const float* kb, const float* dpre, float* dact, float* dkg, float* dkb, float* dbg, float* dbb, void* stream);
+/* out (+)= scale * x[..., c_off:c_off+c_take]  (gradient of tf.concat, discriminator.py:43). */
+int hdrsky_slice_channels(const float* x, size_t npix, int C, int c_off, int c_take, float scale, int accumulate, float* out, void* stream);
+/* tf.concat([a, b], axis=-1) (discriminator.py:43). */
+int hdrsky_concat2(const float* a, int Ca, const float* b, int Cb, size_t npix, float* out, void* stream);
+/* x*255 - VGG_MEAN (vgg16.py:133-141). */
+int hdrsky_vgg_pre(const float* x, size_t n, float* y, void* stream);
+/* y = sa*a + sb*b (b nullable). */
+int hdrsky_axpby(const float* a, float sa, const float* b, float sb, size_t n, float* y, void* stream);
+/* Dense weight / bias gradient dW[K][N] (+)= x^T dy, db (+)= sum_m dy (M <= 32). */
+int hdrsky_fc_wgrad(const float* x, const float* dy, int M, int K, int N, int accumulate, float* dw, float* db, void* stream);
+/* Keras-2 OptimizerV2 RMSprop step over one flat buffer (train.py:201-202,403,406): g is first multiplied by gscale. */
+int hdrsky_rmsprop(float* w, const float* g, float* ms, size_t n, float lr, float rho, float eps, float gscale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,180 @@
+"""GPU parity of the training step (train.py:382-415) vs the oracle's autograd restatement, plus its building blocks."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+from oracle import step as ostep
+from oracle import tfsem as T
+from util import assert_close, rel_max, rel_rms
+
+pytestmark = pytest.mark.gpu
+
+
+def test_resize_adjoint_blur_adjoint_dog(dev):
+    K = pkg("kernels")
+    rng = np.random.default_rng(0)
+    x = torch.from_numpy(rng.standard_normal((2, 6, 10, 3)).astype(np.float32)).requires_grad_(True)
+    up = T.resize_bilinear(x, 12, 20)
+    dy = torch.from_numpy(rng.standard_normal((2, 12, 20, 3)).astype(np.float32))
+    (gx,) = torch.autograd.grad(up, x, dy)
+    assert_close(K.up2x(x.detach().to(dev)), up.detach(), 1e-6, "up2x")
+    assert_close(K.up2x_bwd(dy.to(dev)), gx, 1e-5, "up2x adjoint")
+    y = torch.from_numpy(rng.standard_normal((2, 8, 12, 3)).astype(np.float32)).requires_grad_(True)
+    bl = T.gaussian_filter2d_3x3(y, 1.5450078)
+    dz = torch.from_numpy(rng.standard_normal((2, 8, 12, 3)).astype(np.float32))
+    (gy,) = torch.autograd.grad(bl, y, dz)
+    assert_close(K.blur3(y.detach().to(dev), 1.5450078), bl.detach(), 1e-5, "blur")
+    assert_close(K.blur3(dz.to(dev), 1.5450078, transpose=True), gy, 1e-5, "blur adjoint")
+    # full DoG loss + gradient
+    a = torch.from_numpy(rng.uniform(0, 3, (2, 8, 16, 3)).astype(np.float32)).requires_grad_(True)
+    b = torch.from_numpy(rng.uniform(0, 3, (2, 8, 16, 3)).astype(np.float32))
+    loss = sum((p - q).abs().mean() for p, q in zip(T.dog(a), T.dog(b)))
+    (ga,) = torch.autograd.grad(1000.0 * loss, a)
+    slot = torch.zeros(1, device=dev); dyo = torch.zeros((2, 8, 16, 3), device=dev)
+    K.dog_loss(a.detach().to(dev), b.to(dev), 1000.0, slot, dyo)
+    assert abs(float(slot) - float(loss)) <= 1e-4 * float(loss)
+    assert rel_rms(dyo, ga) < 2e-2   # sign() flips at |d| ~ 0 make a few entries differ
+    assert_close(dyo, ga, 0.5, "dog grad (max)")
+
+
+def test_losses_softmax_bn_pool(dev):
+    K = pkg("kernels")
+    rng = np.random.default_rng(1)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    # KL + softmax backward
+    z = torch.relu(torch.from_numpy(rng.standard_normal((3, 512)).astype(np.float32))).requires_grad_(True)
+    gt = torch.softmax(torch.from_numpy(rng.standard_normal((3, 512)).astype(np.float32) * 3), -1)
+    cmf = torch.softmax(z, -1)
+    kl = T.kl_divergence(gt, cmf)
+    (gz,) = torch.autograd.grad(kl, z)
+    slot = torch.zeros(1, device=dev)
+    dcmf = K.kl(gt.to(dev), cmf.detach().to(dev), slot)
+    assert abs(float(slot) - float(kl)) < 1e-5 * abs(float(kl))
+    dz = K.softmax_bwd(cmf.detach().to(dev), dcmf, z.detach().to(dev))
+    assert_close(dz, gz * (z > 0), 1e-4, "kl->softmax->relu backward")
+    # LSGAN
+    x = torch.from_numpy(rng.standard_normal((3, 1, 13, 1)).astype(np.float32)).requires_grad_(True)
+    l = ((x - 1.0) ** 2).mean()
+    (gx,) = torch.autograd.grad(0.5 * l, x)
+    slot.zero_()
+    dx = K.mse(x.detach().to(dev), 1.0, 1.0, 0.5, slot)
+    assert abs(float(slot) - float(l)) < 1e-5 and rel_max(dx, gx) < 1e-5
+    # BatchNorm train: stats from conv partials, backward with dgamma/dbeta
+    B, H, W, C = 3, 8, 32, 128
+    xr = (rng.standard_normal((B, H, W, C)) * 1.5 + 0.4).astype(np.float32)
+    eye = torch.eye(C, device=dev).reshape(1, 1, C, C).contiguous()
+    xd, st = K.conv2d(d(xr), K.PackedConv(eye), None, want_stats=True, compute=K.BF16X3)
+    gam = rng.uniform(0.5, 1.5, C).astype(np.float32); bet = rng.standard_normal(C).astype(np.float32)
+    mm = torch.zeros(C, device=dev); mv = torch.ones(C, device=dev)
+    mean, rstd, sc, sh = K.bn_train_finalize(st, d(gam), d(bet), B, C, mm, mv)
+    xt = xd.cpu().clone().requires_grad_(True)
+    gt_, bt_ = torch.from_numpy(gam).requires_grad_(True), torch.from_numpy(bet).requires_grad_(True)
+    yb, nmm, nmv = T.batch_norm(xt, gt_, bt_, torch.zeros(C), torch.ones(C), True)
+    ya = T.leaky_relu(yb, 0.3)
+    dy = rng.standard_normal((B, H, W, C)).astype(np.float32)
+    gx, gg, gb = torch.autograd.grad(ya, (xt, gt_, bt_), torch.from_numpy(dy))
+    assert_close(mm, nmm, 1e-4, "moving mean"); assert_close(mv, nmv, 1e-4, "moving var")
+    dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    dx = K.bn_act_bwd(xd, d(dy), mean, rstd, d(gam), d(bet), 0.3, dg, db)
+    assert_close(dx, gx, 2e-4, "bn dx"); assert_close(dg, gg, 2e-4, "bn dgamma"); assert_close(db, gb, 2e-4, "bn dbeta")
+    # maxpool + relu backward
+    yv = torch.relu(torch.from_numpy(rng.standard_normal((2, 8, 16, 64)).astype(np.float32)))
+    pre = yv.clone().requires_grad_(True)
+    pl = T.maxpool2x2(torch.relu(pre))
+    dp = rng.standard_normal(tuple(pl.shape)).astype(np.float32)
+    (gp,) = torch.autograd.grad(pl, pre, torch.from_numpy(dp))
+    assert_close(K.maxpool(yv.to(dev)), pl.detach(), 1e-6, "maxpool")
+    got = K.maxpool_relu_bwd(yv.to(dev), d(dp))
+    mism = ((got.cpu() != 0) != (gp != 0)).float().mean()   # ties among zeros route differently but carry no gradient
+    assert float(mism) == 0.0 and rel_max(got, gp) < 1e-6
+    # Dense wgrad + RMSprop
+    xm = rng.standard_normal((32, 256)).astype(np.float32); dym = rng.standard_normal((32, 128)).astype(np.float32)
+    dw = torch.zeros((256, 128), device=dev); dbv = torch.zeros(128, device=dev)
+    K.fc_wgrad(d(xm), d(dym), dw, dbv)
+    assert_close(dw, xm.T @ dym, 1e-5, "fc wgrad"); assert_close(dbv, dym.sum(0), 1e-5, "fc bias grad")
+    w0 = rng.standard_normal(1024).astype(np.float32); g0 = rng.standard_normal(1024).astype(np.float32)
+    ms0 = rng.uniform(0, 1, 1024).astype(np.float32)
+    wd, msd = d(w0), d(ms0)
+    K.rmsprop(wd, d(g0), msd, 1e-4)
+    wr, mr = T.rmsprop_update(torch.from_numpy(w0), torch.from_numpy(g0), torch.from_numpy(ms0), 1e-4)
+    assert_close(wd, wr, 1e-6, "rmsprop w"); assert_close(msd, mr, 1e-6, "rmsprop ms")
+
+
+def _mk(dev, B, compute_name="BF16X3"):
+    params, synth, trainer, K = pkg("params"), pkg("synth"), pkg("trainer"), pkg("kernels")
+    gen = params.init_params(params.generator_spec(), 0); sun = params.init_params(params.sunpose_spec(), 1)
+    dis = params.init_params(params.discriminator_spec(), 2); vgg = params.init_params(params.vgg_spec(), 3)
+    batch = synth.make_batch(B, seed=1234)
+    tr = trainer.Trainer(gen, sun, dis, vgg, device=dev, precise=True, compute=getattr(K, compute_name))
+    return tr, (gen, sun, dis, vgg), batch
+
+
+def test_train_step_gradients_match_oracle(dev):
+    tr, (gen, sun, dis, vgg), batch = _mk(dev, 2)
+    tt = lambda dd: {k: torch.from_numpy(v) for k, v in dd.items()}
+    ldr, hdr, gt = (torch.from_numpy(batch[k]) for k in ("ldr", "hdr_t", "sunpose_gt"))
+    losses, gg, gs, gd, sg, sd, outs = ostep.train_step_grads(tt(gen), tt(sun), tt(dis), tt(vgg), ldr, hdr, gt)
+    out = tr.step(ldr.to(dev), hdr.to(dev), gt.to(dev), update=False)
+    got = tr.loss_dict()
+    print({k: (got[k], losses.get(k)) for k in got})
+    ref_names = {"kl": "kl", "perceptual": "perceptual", "dog": "dog", "l1": "l1", "adv": "adv",
+                 "disc_generated": "generated", "disc_real": "real", "total_gen_loss": "total_gen_loss",
+                 "total_disc_loss": "total_disc_loss"}
+    for k, rk in ref_names.items():
+        assert abs(got[k] - losses[rk]) <= 2e-3 * abs(losses[rk]) + 1e-6, (k, got[k], losses[rk])
+    assert_close(out["y_final_gamma"], outs["y_final_gamma"], 1e-3, "y_final_gamma (training mode)")
+    # ---- generator-step gradients (gen + sun variables) vs the oracle's autograd --------------------------------
+    # Tolerance relative to each tensor's max |gradient|.  The contraction error is fp32-class (BF16X3); what is left
+    # are discrete effects (sign() of the L1/DoG terms, ReLU / max-pool masks, the 1%-level Grad-CAM map differences
+    # explained in test_forward_gpu) - hence 5e-2 on the worst tensor and 3e-3 on the median tensor.
+    worst = []
+    for prefix, ref, flat in (("gen.", gg, tr.gs), ("sun.", gs, tr.gs)):
+        for k, v in ref.items():
+            g = flat.g[prefix + k]
+            is_bias = k.endswith(".b") or k.endswith("bias_deconv2d")
+            if is_bias and not k.startswith("conv1_f") and not k.startswith("conv1_u"):
+                # a conv bias in front of InstanceNorm has an exactly-zero gradient (IN removes the mean): both sides
+                # hold rounding noise only - require it to be negligible against the layer's weight gradient
+                wk = k[:-2] + ".w" if k.endswith(".b") else k.replace("bias_deconv2d", "kernel_deconv2d")
+                scale = float(ref[wk].abs().max()) * float(np.prod(ref[wk].shape[:3]))
+                assert float(g.abs().max()) <= 1e-4 * scale, (prefix + k, float(g.abs().max()), scale)
+                continue
+            worst.append((rel_max(g, v), prefix + k))
+    worst.sort(reverse=True)
+    print("worst generator-step gradient errors:", worst[:8])
+    assert worst[0][0] < 5e-2, worst[:5]
+    assert np.median([e for e, _ in worst]) < 3e-3
+    for k, v in sg.items():   # sunRadNet BN moving statistics after one train-mode call
+        assert_close(tr.gs.w["gen." + k], v, 1e-4, "gen " + k)
+
+    # ---- discriminator-step gradients --------------------------------------------------------------------------
+    # The generated-image pass is chaotic w.r.t. its input: with random weights and B=2 a 1e-4 relative perturbation
+    # of y_final_gamma (HDR peaks ~2e4 through lrelu + batch-stat BN) moves these gradients by 2-8 %% in the ORACLE
+    # itself (measured).  So the discriminator step is checked on identical inputs: the oracle's discriminator step is
+    # evaluated at the y_final_lin this implementation produced.
+    dr = {k: torch.from_numpy(v).clone().requires_grad_("moving" not in k) for k, v in dis.items()}
+    stats = {}
+    dl = ostep.discriminator_losses(dr, ldr, hdr, out["y_final_lin"].cpu(), training=True, new_stats=stats)
+    names = [k for k in dr if "moving" not in k]
+    refs = torch.autograd.grad(dl["total_disc_loss"], [dr[k] for k in names])
+    for k, v in zip(names, refs):
+        assert_close(tr.ds.g["dis." + k], v, 3e-4, "dis grad " + k)
+    for k, v in stats.items():
+        assert_close(tr.ds.w["dis." + k], v, 1e-4, "dis " + k)
+
+
+def test_train_step_updates_weights_like_rmsprop(dev):
+    tr, _, batch = _mk(dev, 2)
+    ldr, hdr, gt = (torch.from_numpy(batch[k]).to(dev) for k in ("ldr", "hdr_t", "sunpose_gt"))
+    w0 = tr.gs.flat[:tr.gs.ntrain].clone()
+    tr.step(ldr, hdr, gt, update=True)
+    g = tr.gs.grad
+    ms = 0.1 * g * g
+    ref = w0 - 1e-4 * g / (ms.sqrt() + 1e-7)
+    assert_close(tr.gs.flat[:tr.gs.ntrain], ref, 1e-6, "first RMSprop step")
+    # second step runs on the repacked weights and stays finite
+    tr.step(ldr, hdr, gt, update=True)
+    assert torch.isfinite(tr.gs.flat).all() and torch.isfinite(tr.ds.flat).all()
+    v = tr.loss_dict()
+    assert all(np.isfinite(x) for x in v.values())
