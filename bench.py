@@ -5,11 +5,14 @@
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the workload over one batch of 32 synthetic 32x128 sky panoramas per GPU
-(inputs resident in HBM before the timed region; the whole pass is replayed as one hipGraph).
+(inputs resident in HBM before the timed region; the pass is replayed as hipGraphs).
 Rank 0 prints ONE JSON line (metric/value/... + "roofline" + "cpu_baseline").
 
-Workloads (BASELINE.json configs): "fwd" = configs[1] generator + sun-pose net (+ the Grad-CAM sweep
-the reference runs inside its generator graph) forward, batch 32.
+Workloads (BASELINE.json configs):
+  train (default) = configs[2]/[3]: the full train.py step - generator + sun-pose + Grad-CAM + sun-radiance forward,
+                    discriminator x3, VGG16 perceptual, DoG/L1/KL/LSGAN losses, both backward passes, RMSprop x2,
+                    weight re-packing - batch 32 per GPU; N > 1: data parallel, gradients all-reduced (RCCL).
+  fwd             = configs[1]: generator + sun-pose net (+ Grad-CAM sweep) forward only, batch 32 (replicas).
 """
 import argparse
 import importlib
@@ -22,30 +25,28 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 PKG = "hdr-map-reconstruction-from-a-single-ldr-sky-panoramic-image-for-outdoor-illumination-estimation_amd"
 
-MFMA_PEAK_TFLOPS = 2500.0   # dense bf16, MI355X_MICROARCH.md "Chip-level parameters"
-FWD_MFLOP_PER_IMG = 3220.3  # G + S + C (algorithmic 2*MAC of conv/dense contractions)
+MFMA_PEAK_TFLOPS = 2500.0    # dense bf16, MI355X_MICROARCH.md "Chip-level parameters"
+FWD_MFLOP_PER_IMG = 3220.3   # G + S + C (algorithmic 2*MAC of conv/dense contractions)
+TRAIN_MFLOP_PER_IMG = 16900.0  # 3(G+S) + C + 8D + 3V
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE configs[1]: 32)")
-    ap.add_argument("--workload", default="fwd", choices=["fwd"])
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE configs[1..3]: 32)")
+    ap.add_argument("--workload", default="train", choices=["train", "fwd"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     return ap.parse_args()
 
 
-def dominant_kernel_roofline(torch, K, nets, batch, iters=200):
-    """The res-block convolution (3x3, 128->128 on [B,8,32,128]: 12 of the generator's launches, 43% of its
-    FLOPs) timed live with HIP events on the launch stream.  Algorithmic FLOPs per launch =
-    2 * (B*8*32) * (3*3*128) * 128."""
-    dev = nets.device
-    x = torch.randn(batch, nets.h // 4, nets.w // 4, 128, device=dev)
-    pw = nets.pk["gen.res.0.conv1"]
-    bias = nets.gen["res.0.conv1.b"]
+def dominant_kernel_roofline(torch, K, pw, bias, batch, h, w, iters=200):
+    """The res-block convolution (3x3, 128->128 on [B,8,32,128]: 12 forward launches + their data-gradient twins per
+    step) timed live with HIP events on the launch stream.  Algorithmic FLOPs per launch = 2*(B*8*32)*(3*3*128)*128."""
+    dev = bias.device
+    x = torch.randn(batch, h // 4, w // 4, 128, device=dev)
     y = torch.empty_like(x)
     for _ in range(10):
         K.conv2d(x, pw, bias, want_stats=True, compute=K.BF16, out=y)
@@ -62,7 +63,7 @@ def dominant_kernel_roofline(torch, K, nets, batch, iters=200):
     e1.record(stream)
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / iters
-    flop = 2.0 * (batch * (nets.h // 4) * (nets.w // 4)) * (9 * 128) * 128
+    flop = 2.0 * (batch * (h // 4) * (w // 4)) * (9 * 128) * 128
     achieved = flop / (us * 1e-6) / 1e12
     return {"bound": "mfma", "kernel": "conv_igemm_kernel (res-block 3x3 128->128, B=%d)" % batch,
             "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -70,22 +71,28 @@ def dominant_kernel_roofline(torch, K, nets, batch, iters=200):
             "avg_launch_us": round(us, 3), "flop_per_launch": flop}
 
 
-def cpu_baseline(torch, gen, sun, batch_np):
-    """CPU restatement (oracle/, NOT TensorFlow) of the same forward on this host's cores: bounded sample."""
+def cpu_baseline(torch, workload, nets_np, batch_np):
+    """CPU restatement (oracle/, NOT TensorFlow) of the same workload on this host's cores: bounded sample."""
     from oracle import step as ostep
     tt = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}
-    g, s = tt(gen), tt(sun)
-    ldr = torch.from_numpy(batch_np["ldr"])
-    ostep.inference(g, s, ldr[:2])  # warm-up
+    gen, sun, dis, vgg = (tt(d) for d in nets_np)
+    ldr, hdr, gt = (torch.from_numpy(batch_np[k]) for k in ("ldr", "hdr_t", "sunpose_gt"))
+    if workload == "fwd":
+        fn = lambda n: ostep.inference(gen, sun, ldr[:n])
+        what = "oracle/step.inference"
+    else:
+        fn = lambda n: ostep.train_step_grads(gen, sun, dis, vgg, ldr[:n], hdr[:n], gt[:n])
+        what = "oracle/step.train_step_grads (forward + both backward passes; optimizer excluded)"
+    fn(2)  # warm-up
     t0 = time.perf_counter()
     n = 0
     while time.perf_counter() - t0 < 12.0:
-        ostep.inference(g, s, ldr)
+        fn(ldr.shape[0])
         n += ldr.shape[0]
     dt = time.perf_counter() - t0
     return {"value": round(n / dt, 2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d images (batches of %d) of the same synthetic workload through oracle/step.inference "
-                      "(torch-CPU fp32 restatement, not TF2), %.1f s" % (n, ldr.shape[0], dt)}
+            "sample": "%d images (batches of %d) of the same synthetic workload through %s "
+                      "(torch-CPU fp32 restatement, not TF2), %.1f s" % (n, ldr.shape[0], what, dt)}
 
 
 def main():
@@ -107,40 +114,79 @@ def main():
     params = importlib.import_module(PKG + ".params")
     synth = importlib.import_module(PKG + ".synth")
     engine = importlib.import_module(PKG + ".engine")
+    trainer = importlib.import_module(PKG + ".trainer")
     K = importlib.import_module(PKG + ".kernels")
 
     gen = params.init_params(params.generator_spec(), 0)
     sun = params.init_params(params.sunpose_spec(), 1)
+    dis = params.init_params(params.discriminator_spec(), 2)
+    vgg = params.init_params(params.vgg_spec(), 3)
     batch_np = synth.make_batch(args.batch, seed=1234 + rank)
-    nets = engine.Nets(gen, sun, device=dev, precise=False)
     ldr = torch.from_numpy(batch_np["ldr"]).to(dev)
+    hdr = torch.from_numpy(batch_np["hdr_t"]).to(dev)
+    gt = torch.from_numpy(batch_np["sunpose_gt"]).to(dev)
 
-    def step():
-        return engine.generator_forward(nets, ldr, compute=K.BF16)
+    if args.workload == "fwd":
+        nets = engine.Nets(gen, sun, device=dev, precise=False)
+        phases = [lambda: engine.generator_forward(nets, ldr, compute=K.BF16)]
+        between = None
+        roof_pw, roof_b = nets.pk["gen.res.0.conv1"], nets.gen["res.0.conv1.b"]
+        probe = lambda out: out["y_final_lin"]
+    else:
+        tr = trainer.Trainer(gen, sun, dis, vgg, device=dev, precise=False, compute=K.BF16, world_size=world)
+        # phase A: forward + both backward passes (gradients of this replica's batch-32 step);
+        # between: sum the gradients over replicas (RCCL all-reduce; every loss is a batch mean, so the data-parallel
+        #          gradient is the replica average: SURVEY.md section 8e); phase B: RMSprop x2 + weight re-packing.
+        phases = [lambda: tr.step(ldr, hdr, gt, update=False), lambda: tr.apply_gradients(gscale=1.0 / world)]
 
-    # warm-up (eager) then capture one step into a hipGraph
+        def between():
+            dist.all_reduce(tr.gs.grad)
+            dist.all_reduce(tr.ds.grad)
+        if world == 1:
+            between = None
+        roof_pw, roof_b = tr.conv["gen.res.0.conv1"].pk, tr.gs.w["gen.res.0.conv1.b"]
+        probe = lambda out: out["y_final_lin"]
+
+    # warm-up (eager) then capture each phase into a hipGraph
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
-        for _ in range(3):
-            out = step()
+        for _ in range(2):
+            out = phases[0]()
+            if between:
+                between()
+            for ph in phases[1:]:
+                ph()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
-    graph = None
-    if not args.no_graph:
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            out = step()
-    run = graph.replay if graph is not None else step
+    runs = []
+    if args.no_graph:
+        runs = list(phases)
+    else:
+        for i, ph in enumerate(phases):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                o = ph()
+            if i == 0:
+                out = o
+            runs.append(g.replay)
+
+    def one_step():
+        runs[0]()
+        if between:
+            between()
+        for r in runs[1:]:
+            r()
+
     for _ in range(args.warmup):
-        run()
+        one_step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        run()
+        one_step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -150,26 +196,32 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    assert torch.isfinite(out["y_final_lin"]).all()
+    assert torch.isfinite(probe(out)).all()
 
     if rank == 0:
         imgs = args.batch * world * args.steps
         value = imgs / dt
+        train = args.workload == "train"
         res = {
-            "metric": "images/sec (32x128 sky panoramas)", "value": round(value, 1), "unit": "images/s",
+            "metric": "training images/sec (32x128 sky panoramas)" if train else "generator fwd images/sec (32x128 sky panoramas)",
+            "value": round(value, 1), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "ms_per_img": round(dt / imgs * world * 1e3, 6),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
-            "data": "synthetic (seeded sky-dome + sun lobe, random-init weights)",
-            "config": {"workload": "BASELINE configs[1]: generator + sunpose_net forward (incl. the Grad-CAM sweep "
-                                   "and sun-radiance head of the generator graph), batch=%d per GPU, 32x128x3" % args.batch,
+            "data": "synthetic (seeded sky-dome + sun lobe + sensor noise, random-init weights, synthetic VGG16 weights)",
+            "config": {"workload": ("BASELINE configs[2]: full train.py step (gen + sunpose + disc + VGG16 perceptual + "
+                                    "tone-map/DoG/L1/KL/LSGAN losses, RMSprop x2), batch=%d per GPU, 32x128x3" % args.batch)
+                       if train else
+                       ("BASELINE configs[1]: generator + sunpose_net forward (incl. the Grad-CAM sweep and sun-radiance "
+                        "head of the generator graph), batch=%d per GPU, 32x128x3" % args.batch),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
-                       "parallelism": "replicas" if world > 1 else "single", "hipgraph": graph is not None},
-            "algorithmic_tflops": round(value * FWD_MFLOP_PER_IMG * 1e6 / 1e12, 2),
+                       "parallelism": ("dp%d (RCCL all-reduce of fp32 gradients)" % world if train else "replicas") if world > 1 else "single",
+                       "hipgraph": not args.no_graph},
+            "algorithmic_tflops": round(value * (TRAIN_MFLOP_PER_IMG if train else FWD_MFLOP_PER_IMG) * 1e6 / 1e12, 2),
         }
-        res["roofline"] = dominant_kernel_roofline(torch, K, nets, args.batch)
+        res["roofline"] = dominant_kernel_roofline(torch, K, roof_pw, roof_b, args.batch, 32, 128)
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(torch, gen, sun, batch_np)
+            res["cpu_baseline"] = cpu_baseline(torch, args.workload, (gen, sun, dis, vgg), batch_np)
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

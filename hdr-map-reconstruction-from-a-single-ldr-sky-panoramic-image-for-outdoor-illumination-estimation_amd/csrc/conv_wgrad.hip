@@ -292,7 +292,7 @@ int launch_wgrad(WgradArgs& a, hipStream_t stream) {
   if (lds > 160 * 1024) return HDRSKY_EUNSUPPORTED;
   // enough workgroups to fill the chip, few enough that the atomic traffic (one dW block per workgroup) stays small
   const int nblk = a.cblocks * a.oblocks;
-  int chunks = cdiv(512, nblk);
+  int chunks = cdiv(128, nblk);
   if (chunks > a.ntiles) chunks = a.ntiles;
   a.tiles_per_wg = cdiv(a.ntiles, chunks);
   chunks = cdiv(a.ntiles, a.tiles_per_wg);

@@ -9,18 +9,30 @@ namespace {
 
 constexpr float LN11 = 2.3978953f;
 
+// block-wide sum (256 threads) -> one atomicAdd per block
+__device__ __forceinline__ void block_atomic_add(float v, float scale, float* dst) {
+  __shared__ float sblk[4];
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) sblk[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0 && dst) atomicAdd(dst, ((sblk[0] + sblk[1]) + (sblk[2] + sblk[3])) * scale);
+}
+
+
 // ------------------------------------------------------------------------------------------------------------
 // Keras BatchNormalization, training mode (discriminator.py:25, sunrad_net.py:26): batch mean / biased variance
 // from the producing conv's per-tile partials; moving stats <- 0.99*moving + 0.01*batch (variance Bessel-corrected).
 // ------------------------------------------------------------------------------------------------------------
-__global__ void bn_train_finalize_kernel(const float* __restrict__ part, int nparts_total, int C, float count,
-                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                         float momentum, float* moving_mean, float* moving_var, float* mean,
-                                         float* rstd, float* scale, float* shift) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ void __launch_bounds__(64) bn_train_finalize_kernel(const float* __restrict__ part, int nparts_total, int C,
+                                                               float count, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float eps, float momentum,
+                                                               float* moving_mean, float* moving_var, float* mean,
+                                                               float* rstd, float* scale, float* shift) {
+  const int c = blockIdx.x;  // one wave per channel; lanes stride over the partials (fixed shuffle tree: deterministic)
   float s = 0.f, ss = 0.f;
-  for (int p = 0; p < nparts_total; ++p) { s += part[(size_t)(2 * p) * C + c]; ss += part[(size_t)(2 * p + 1) * C + c]; }
+  for (int p = threadIdx.x; p < nparts_total; p += 64) { s += part[(size_t)(2 * p) * C + c]; ss += part[(size_t)(2 * p + 1) * C + c]; }
+  s = wave_sum(s); ss = wave_sum(ss);
+  if (threadIdx.x != 0) return;
   const float m = s / count;
   const float var = fmaxf(ss / count - m * m, 0.f);
   const float r = 1.f / sqrtf(var + eps);
@@ -75,12 +87,13 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* __restr
 }
 
 // sums over blocks -> dbeta, dgamma (accumulated into the gradient buffers) and the two means for the apply pass
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblocks, int C, float count, float* m1m2,
-                                       float* dgamma, float* dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ void __launch_bounds__(64) bn_bwd_finalize_kernel(const float* __restrict__ part, int nblocks, int C,
+                                                             float count, float* m1m2, float* dgamma, float* dbeta) {
+  const int c = blockIdx.x;  // one wave per channel
   float s1 = 0.f, s2 = 0.f;
-  for (int b = 0; b < nblocks; ++b) { s1 += part[((size_t)b * 2) * C + c]; s2 += part[((size_t)b * 2 + 1) * C + c]; }
+  for (int b = threadIdx.x; b < nblocks; b += 64) { s1 += part[((size_t)b * 2) * C + c]; s2 += part[((size_t)b * 2 + 1) * C + c]; }
+  s1 = wave_sum(s1); s2 = wave_sum(s2);
+  if (threadIdx.x != 0) return;
   m1m2[c] = s1 / count; m1m2[C + c] = s2 / count;
   if (dbeta) dbeta[c] += s1;
   if (dgamma) dgamma[c] += s2;
@@ -335,8 +348,7 @@ __global__ void __launch_bounds__(256) dog_mid_kernel(const float* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 5; ++j) h[(size_t)j * total + i] = g[j] - g[j + 1];
   }
-  lacc = wave_sum(lacc);
-  if ((threadIdx.x & 63) == 0 && loss) atomicAdd(loss, lacc * inv_n);
+  block_atomic_add(lacc, inv_n, loss);
 }
 
 // d base = sum_j G(s_j)^T h_j
@@ -394,8 +406,7 @@ __global__ void __launch_bounds__(256) l1_kernel(const float* __restrict__ a, co
       da[i] = accumulate ? da[i] + g : g;
     }
   }
-  acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0 && loss) atomicAdd(loss, acc * inv_n * wl);
+  block_atomic_add(acc, inv_n * wl, loss);
 }
 
 // LSGAN: loss += wl * mean((x - target)^2); dx = wg * 2 (x - target)/n     (train.py:234-237)
@@ -408,8 +419,7 @@ __global__ void __launch_bounds__(256) mse_kernel(const float* __restrict__ x, f
     acc += d * d;
     if (dx) dx[i] = wg * 2.f * d * inv_n;
   }
-  acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0 && loss) atomicAdd(loss, acc * inv_n * wl);
+  block_atomic_add(acc, inv_n * wl, loss);
 }
 
 // Keras KLDivergence (train.py:232,305): loss += mean_b sum_j yt log(yt/yp), both clipped to [1e-7,1];
@@ -425,8 +435,7 @@ __global__ void __launch_bounds__(256) kl_kernel(const float* __restrict__ gt, c
     acc += yt * logf(yt / yp);
     if (dcmf) dcmf[i] = (p > 1e-7f && p < 1.f) ? -yt / yp / (float)B : 0.f;
   }
-  acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0 && loss) atomicAdd(loss, acc / (float)B);
+  block_atomic_add(acc, 1.f / (float)B, loss);
 }
 
 // dz = cmf * (dcmf - sum_j dcmf_j cmf_j) * [z > 0]      (softmax + the ReLU in front of it; one block per row)
@@ -674,7 +683,7 @@ int hdrsky_bn_train_finalize(const float* part, int nparts_total, int C, int cou
                              float eps, float momentum, float* moving_mean, float* moving_var, float* mean, float* rstd,
                              float* scale, float* shift, void* stream) {
   if (!part || !gamma || !beta || !mean || !rstd || !scale || !shift) return HDRSKY_EINVAL;
-  hipLaunchKernelGGL(bn_train_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S_(stream), part, nparts_total, C,
+  hipLaunchKernelGGL(bn_train_finalize_kernel, dim3(C), dim3(64), 0, S_(stream), part, nparts_total, C,
                      (float)count, gamma, beta, eps, momentum, moving_mean, moving_var, mean, rstd, scale, shift);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
@@ -692,7 +701,7 @@ int hdrsky_bn_act_bwd(const float* x, const float* dy, const float* mean, const 
   float* m1m2 = workspace + (size_t)2 * nb * C;
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(256), 256 * 8 * sizeof(float), S_(stream), x, dy, mean, rstd,
                      gamma, beta, slope, (size_t)npix, C, part);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S_(stream), part, nb, C, (float)npix, m1m2,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, S_(stream), part, nb, C, (float)npix, m1m2,
                      dgamma, dbeta);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for((size_t)npix * C / 4)), dim3(256), 0, S_(stream), x, dy, mean,
                      rstd, gamma, beta, slope, m1m2, (size_t)npix * C / 4, C, dx);
@@ -748,7 +757,7 @@ int hdrsky_blur3(const float* x, int B, int H, int W, int C, float sigma, int tr
 
 int hdrsky_dog_mid(const float* base, int B, int H, int W, int C, float weight, float* h, float* loss, void* stream) {
   if (!base || !h) return HDRSKY_EINVAL;
-  hipLaunchKernelGGL(dog_mid_kernel, dim3(grid_for((size_t)B * H * W * C)), dim3(256), 0, S_(stream), base, B, H, W, C,
+  hipLaunchKernelGGL(dog_mid_kernel, dim3(grid_for((size_t)B * H * W * C) > 1024 ? 1024 : grid_for((size_t)B * H * W * C)), dim3(256), 0, S_(stream), base, B, H, W, C,
                      weight, h, loss);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
@@ -764,21 +773,21 @@ int hdrsky_dog_mid_bwd(const float* h, int B, int H, int W, int C, float* dbase,
 int hdrsky_l1(const float* a, const float* b, size_t n, float wl, float wg, float* loss, float* da, int accumulate,
               void* stream) {
   if (!a) return HDRSKY_EINVAL;
-  hipLaunchKernelGGL(l1_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, S_(stream), a, b, n, wl, wg, loss, da, accumulate);
+  hipLaunchKernelGGL(l1_kernel, dim3(grid_for(n, 2048) > 512 ? 512 : grid_for(n, 2048)), dim3(256), 0, S_(stream), a, b, n, wl, wg, loss, da, accumulate);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }
 
 int hdrsky_mse(const float* x, float target, size_t n, float wl, float wg, float* loss, float* dx, void* stream) {
   if (!x) return HDRSKY_EINVAL;
-  hipLaunchKernelGGL(mse_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, S_(stream), x, target, n, wl, wg, loss, dx);
+  hipLaunchKernelGGL(mse_kernel, dim3(grid_for(n, 2048) > 512 ? 512 : grid_for(n, 2048)), dim3(256), 0, S_(stream), x, target, n, wl, wg, loss, dx);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }
 
 int hdrsky_kl(const float* gt, const float* cmf, int B, int N, float* loss, float* dcmf, void* stream) {
   if (!gt || !cmf) return HDRSKY_EINVAL;
-  hipLaunchKernelGGL(kl_kernel, dim3(grid_for((size_t)B * N, 1024)), dim3(256), 0, S_(stream), gt, cmf, B, N, loss, dcmf);
+  hipLaunchKernelGGL(kl_kernel, dim3(grid_for((size_t)B * N, 1024) > 512 ? 512 : grid_for((size_t)B * N, 1024)), dim3(256), 0, S_(stream), gt, cmf, B, N, loss, dcmf);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }

@@ -103,6 +103,7 @@ class Trainer:
         self.ds = FlatParams(OrderedDict(("dis." + k, v) for k, v in dis_params.items()), self.device)
         self.vgg = E._dev(vgg_params, self.device)
         self.side_stream = torch.cuda.Stream(device=self.device)
+        self.side_stream2 = torch.cuda.Stream(device=self.device)
         self.losses = torch.zeros(len(LOSS_SLOTS), dtype=torch.float32, device=self.device)
         self._build_layers()
 
@@ -353,31 +354,44 @@ class Trainer:
         t = S["t"]
         y_lin, y_gamma = S["y_lin"], S["y_gamma"]
 
+        # Three independent chains run on three HIP streams (fork/join; captured as such in the hipGraph):
+        #   main : L1 + DoG + KL, then the generator backward
+        #   sA   : VGG16 perceptual forward/backward, later the sun-pose net backward
+        #   sB   : adversarial term (discriminator, inference-mode BN), then the whole discriminator step
+        main, sA, sB = torch.cuda.current_stream(), self.side_stream, self.side_stream2
+        sA.wait_stream(main); sB.wait_stream(main)
+
         # ---- generator losses + gradients wrt y_final_lin / y_final_gamma (train.py:301-331) ----------------
         dyl = torch.empty_like(y_lin)
         K.l1(y_lin, hdr_t, 1.0, 10.0, self.losses[3:4], da=dyl)                       # 10 * L1
         K.dog_loss(y_lin, hdr_t, 1000.0, self.losses[2:3], dyl)                       # 1000 * DoG
-        # adversarial term: discriminator in inference mode (train.py:302)
-        Rg = self._down_stack("dis.", self.ds.w, K.concat2(ldr, y_lin), training=False)
-        cvo = c["dis.out"]
-        logits, _ = cvo.fwd(Rg["d4"]["raw"], Rg["xf_out"], cp)
-        dlog = K.mse(logits, 1.0, 1.0, 1.0, self.losses[4:5])
-        dact4 = cvo.dgrad(Rg["d4"]["raw"], dlog, cp)
-        din = self._down_stack_bwd("dis.", self.ds.w, None, Rg, dact4, training=False, want_input_grad=True, do_wgrad=False)
-        K.slice_channels(din, 3, 3, 1.0, out=dyl)
-        dyg = self._vgg_loss_and_grad(y_gamma, hdr_t)                                  # 0.01 * perceptual
         dcmf = K.kl(sunpose_gt, t["cmf"], self.losses[0:1])                            # KL
+        with torch.cuda.stream(sA):
+            dyg = self._vgg_loss_and_grad(y_gamma, hdr_t)                              # 0.01 * perceptual
+        cvo = c["dis.out"]
+        with torch.cuda.stream(sB):
+            # adversarial term: discriminator in inference mode (train.py:302)
+            Rg = self._down_stack("dis.", self.ds.w, K.concat2(ldr, y_lin), training=False)
+            logits, _ = cvo.fwd(Rg["d4"]["raw"], Rg["xf_out"], cp)
+            dlog = K.mse(logits, 1.0, 1.0, 1.0, self.losses[4:5])
+            dact4 = cvo.dgrad(Rg["d4"]["raw"], dlog, cp)
+            din = self._down_stack_bwd("dis.", self.ds.w, None, Rg, dact4, training=False, want_input_grad=True, do_wgrad=False)
+            d_adv = K.slice_channels(din, 3, 3, 1.0)
+        main.wait_stream(sB)   # d_adv ready; sB carries on with the discriminator step
+        main.wait_stream(sA)   # dyg ready
+        K.axpby(dyl, 1.0, d_adv, 1.0, out=dyl)
 
         # ---- discriminator step (train.py:351-380): real then generated, BN batch statistics -------------------
         # (its forward passes read the PRE-update generator output; its moving stats update after the generator
         #  step's inference-mode call above, as in the reference's program order)
-        for which, img, target, slot in (("real", hdr_t, 1.0, 6), ("fake", y_lin, 0.0, 5)):
-            Rd = self._down_stack("dis.", self.ds.w, K.concat2(ldr, img), training=True)
-            lg, _ = cvo.fwd(Rd["d4"]["raw"], Rd["xf_out"], cp)
-            dl = K.mse(lg, target, 1.0, 0.5, self.losses[slot:slot + 1])
-            self._wg("dis.out", Rd["d4"]["raw"], Rd["xf_out"], dl)
-            da4 = cvo.dgrad(Rd["d4"]["raw"], dl, cp)
-            self._down_stack_bwd("dis.", self.ds.w, self.ds.g, Rd, da4, training=True, want_input_grad=False)
+        with torch.cuda.stream(sB):
+            for which, img, target, slot in (("real", hdr_t, 1.0, 6), ("fake", y_lin, 0.0, 5)):
+                Rd = self._down_stack("dis.", self.ds.w, K.concat2(ldr, img), training=True)
+                lg, _ = cvo.fwd(Rd["d4"]["raw"], Rd["xf_out"], cp)
+                dl = K.mse(lg, target, 1.0, 0.5, self.losses[slot:slot + 1])
+                self._wg("dis.out", Rd["d4"]["raw"], Rd["xf_out"], dl)
+                da4 = cvo.dgrad(Rd["d4"]["raw"], dl, cp)
+                self._down_stack_bwd("dis.", self.ds.w, self.ds.g, Rd, da4, training=True, want_input_grad=False)
 
         # ---- generator backward ---------------------------------------------------------------------------------
         dsky, dsun = K.blend_bwd(y_gamma, S["alpha"], dyg, dyl)
@@ -403,6 +417,23 @@ class Trainer:
         dact4 = K.dense_heads_bwd(R["d4"]["raw"], xf.scale, xf.shift, 0.3, w["gen.sun.gamma.kernel"], w["gen.sun.beta.kernel"],
                                   dpre, g["gen.sun.gamma.kernel"], g["gen.sun.beta.kernel"], g["gen.sun.gamma.bias"],
                                   g["gen.sun.beta.bias"])
+        sA.wait_stream(main)   # dcmf now holds KL + sun-radiance contributions
+        with torch.cuda.stream(sA):
+            # sun-pose net: KL + the sun-radiance path meet in dcmf (sunpose_net.py:54-72)
+            dz = K.softmax_bwd(t["cmf"], dcmf, t["z"])
+            K.fc_wgrad(t["f1"], dz, g["sun.fc2.kernel"], g["sun.fc2.bias"])
+            df1 = K.fc_finalize(K.fc_dgrad(dz, self.fc2, cp), None, relu=False, mask_src=t["f1"])
+            K.fc_wgrad(t["flat"], df1, g["sun.fc1.kernel"], g["sun.fc1.bias"])
+            dP = K.fc_finalize(K.fc_dgrad(df1, self.fc1, cp)).reshape(B, self.h // 8, self.w // 8, 128)
+            for l in (3, 2, 1):
+                n = "sun.sunlayer%d" % l
+                dr2 = self._in_bwd(t["r%db" % l], t["st%db" % l], n + ".norm2", 0.0, dP, pooled=True)
+                self._wg(n + ".conv2", t["r%da" % l], t["xf%d" % l], dr2)
+                da = c[n + ".conv2"].dgrad(t["r%da" % l], dr2, cp)
+                dr1 = self._in_bwd(t["r%da" % l], t["st%da" % l], n + ".norm1", 0.0, da)
+                self._wg(n + ".conv1", t["in%d" % l], None, dr1)
+                if l > 1:
+                    dP = c[n + ".conv1"].dgrad(t["in%d" % l], dr1, cp)
         self._down_stack_bwd("gen.sun.", w, g, R, dact4, training=True, want_input_grad=False)
         # encoder (generator.py:92-108, resBlock :26-35)
         dx = dres
@@ -424,21 +455,7 @@ class Trainer:
         dc1 = self._in_bwd(S["c1"], S["s1"], "gen.norm1_d", 0.1, da1)
         self._wg("gen.conv1_d", ldr, None, dc1)
 
-        # sun-pose net: KL + the sun-radiance path meet in dcmf (sunpose_net.py:54-72)
-        dz = K.softmax_bwd(t["cmf"], dcmf, t["z"])
-        K.fc_wgrad(t["f1"], dz, g["sun.fc2.kernel"], g["sun.fc2.bias"])
-        df1 = K.fc_finalize(K.fc_dgrad(dz, self.fc2, cp), None, relu=False, mask_src=t["f1"])
-        K.fc_wgrad(t["flat"], df1, g["sun.fc1.kernel"], g["sun.fc1.bias"])
-        dP = K.fc_finalize(K.fc_dgrad(df1, self.fc1, cp)).reshape(B, self.h // 8, self.w // 8, 128)
-        for l in (3, 2, 1):
-            n = "sun.sunlayer%d" % l
-            dr2 = self._in_bwd(t["r%db" % l], t["st%db" % l], n + ".norm2", 0.0, dP, pooled=True)
-            self._wg(n + ".conv2", t["r%da" % l], t["xf%d" % l], dr2)
-            da = c[n + ".conv2"].dgrad(t["r%da" % l], dr2, cp)
-            dr1 = self._in_bwd(t["r%da" % l], t["st%da" % l], n + ".norm1", 0.0, da)
-            self._wg(n + ".conv1", t["in%d" % l], None, dr1)
-            if l > 1:
-                dP = c[n + ".conv1"].dgrad(t["in%d" % l], dr1, cp)
+        main.wait_stream(sA); main.wait_stream(sB)
 
         if update:
             self.apply_gradients()
