@@ -1,0 +1,222 @@
+// Distortion-aware panoramic convolution (distortion_aware_ops.py:5-270; deconv2d :272-542 = bilinear resize + this).
+//
+// Reference data flow: per-row spherical sampling offsets -> four tf.gather_nd materialisations of [B,h,w,k*k,C]
+// -> weighted sum -> [B, h*w, k*k*C] x [k*k*C, F] matmul + bias.  Here the im2col tensor never exists: for each
+// filter tap a workgroup gathers its 64 output pixels' bilinear samples straight from the (L2-resident) NHWC input
+// into a double-buffered bf16 LDS tile (exact reference arithmetic: float32 coordinates, clamp in y, 360-degree wrap
+// in x applied once to the coordinate and once to the corner indices, weights from the UNWRAPPED corner indices),
+// and feeds it to v_mfma_f32_16x16x32_bf16 against the packed filter (row = tap*C + c, the HWIO order).
+#include <cmath>
+
+#include "common.h"
+
+namespace {
+
+struct DaArgs {
+  const float* x;
+  const uint4* whi;
+  const uint4* wlo;
+  const float* bias;
+  const float* offs;  // [h][k*k][2] (y, x), identical for every column
+  float* y;
+  int B, H, W, Cin, Cout, Npad, ksize, k2, pad, in_h, in_w, cin32, nblocks, tiles_x;
+};
+
+// one bilinear sample position of the reference (distortion_aware_ops.py:62-106), all in float32
+struct Tap4 {
+  int y0, y1, x0, x1;      // corner indices in PADDED coordinates (x wrapped, y clamped)
+  float w0, w1, w2, w3;
+};
+
+__device__ __forceinline__ Tap4 da_tap(float base_y, float base_x, float off_y, float off_x, int in_h, int in_w) {
+  float y = base_y + off_y;
+  float x = base_x + off_x;
+  y = fminf(fmaxf(y, 0.f), (float)(in_h - 1));
+  x = x < 0.f ? x + (float)in_w : x;
+  x = x > (float)(in_w - 1) ? x - (float)in_w : x;
+  int y0 = (int)floorf(y), x0 = (int)floorf(x);
+  int y1 = y0 + 1, x1 = x0 + 1;
+  y0 = min(max(y0, 0), in_h - 1);
+  y1 = min(max(y1, 0), in_h - 1);
+  const int x0w = x0, x1w = x1;  // unwrapped: used for the weights (:89, :100-106)
+  x0 = x0 < 0 ? x0 + in_w : x0; x1 = x1 < 0 ? x1 + in_w : x1;
+  x0 = x0 > in_w - 1 ? x0 - in_w : x0; x1 = x1 > in_w - 1 ? x1 - in_w : x1;
+  Tap4 t;
+  t.y0 = y0; t.y1 = y1; t.x0 = x0; t.x1 = x1;
+  const float fy0 = (float)y0, fy1 = (float)y1, fx0 = (float)x0w, fx1 = (float)x1w;
+  t.w0 = (fy1 - y) * (fx1 - x);
+  t.w1 = (fy1 - y) * (x - fx0);
+  t.w2 = (y - fy0) * (fx1 - x);
+  t.w3 = (y - fy0) * (x - fx0);
+  return t;
+}
+
+template <bool PRECISE>
+__global__ void __launch_bounds__(256) da_conv_kernel(const DaArgs a) {
+  constexpr int TM = 64, BN = 64;   // 64 output pixels of one row x 64 filters; wave w owns filters [16w, 16w+16)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, lr = lane & 15;
+  const int nq = a.Cin >> 3;
+  const int plane = TM + 1;                                   // 16-byte units per channel-chunk plane
+  const int buf_units = nq * plane * (PRECISE ? 2 : 1);
+  uint4* sA = reinterpret_cast<uint4*>(smem);
+
+  int bid = blockIdx.x;
+  const int nb = bid % a.nblocks; bid /= a.nblocks;
+  const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+  const int oy = bid % a.H, b = bid / a.H;
+  const int ox0 = tx * TM, n0 = nb * BN;
+
+  f32x4_t acc[4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) acc[mi] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const uint4* wlh = a.whi + (size_t)kq * a.Npad + n0 + wave * 16 + lr;
+  const uint4* wll = PRECISE ? a.wlo + (size_t)kq * a.Npad + n0 + wave * 16 + lr : nullptr;
+  const float* xb = a.x + (size_t)b * a.H * a.W * a.Cin;
+
+  for (int t = 0; t < a.k2; ++t) {
+    uint4* buf = sA + (t & 1) * buf_units;
+    const float off_y = a.offs[(oy * a.k2 + t) * 2], off_x = a.offs[(oy * a.k2 + t) * 2 + 1];
+    const int ty = t / a.ksize, tx_ = t % a.ksize;
+    // ---- gather + bilinear blend of this tap's 64 samples x Cin channels ---------------------------------
+    for (int i = tid; i < TM * nq; i += 256) {
+      const int m = i / nq, q = i % nq;
+      const int ox = ox0 + m;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = 0.f;
+      if (ox < a.W) {
+        // base grid = VALID patches of the padded meshgrid (:152-168): padded coordinate of tap (ty,tx) at (oy,ox)
+        const Tap4 s = da_tap((float)(oy + ty), (float)(ox + tx_), off_y, off_x, a.in_h, a.in_w);
+        const int ys[4] = {s.y0, s.y0, s.y1, s.y1}, xs[4] = {s.x0, s.x1, s.x0, s.x1};
+        const float ws[4] = {s.w0, s.w1, s.w2, s.w3};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int yy = ys[k] - a.pad, xx = xs[k] - a.pad;      // back to un-padded coordinates; border = zeros
+          if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
+            const float* p = xb + ((size_t)yy * a.W + xx) * a.Cin + q * 8;
+            const float4 lo = *reinterpret_cast<const float4*>(p), hi = *reinterpret_cast<const float4*>(p + 4);
+            v[0] += ws[k] * lo.x; v[1] += ws[k] * lo.y; v[2] += ws[k] * lo.z; v[3] += ws[k] * lo.w;
+            v[4] += ws[k] * hi.x; v[5] += ws[k] * hi.y; v[6] += ws[k] * hi.z; v[7] += ws[k] * hi.w;
+          }
+        }
+      }
+      uint4 h8, l8;
+      pack8<PRECISE>(v, h8, l8);
+      buf[q * plane + m] = h8;
+      if (PRECISE) buf[nq * plane + q * plane + m] = l8;
+    }
+    __syncthreads();   // tile t staged; also: every wave is past the MFMAs of tile t-1, so buffer (t+1)&1 is free
+    // ---- MFMA: Cin/32 k-steps, 4 pixel fragments x this wave's 16 filters -----------------------------------
+    for (int cb = 0; cb < a.cin32; ++cb) {
+      const size_t o = (size_t)((t * a.cin32 + cb) * 4) * a.Npad;
+      const uint4 bh = wlh[o];
+      uint4 bl = uint4{0, 0, 0, 0};
+      if (PRECISE) bl = wll[o];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const uint4 ah = buf[(cb * 4 + kq) * plane + mi * 16 + lr];
+        if (PRECISE) {
+          const uint4 al = buf[nq * plane + (cb * 4 + kq) * plane + mi * 16 + lr];
+          acc[mi] = mfma16(al, bh, acc[mi]);
+          acc[mi] = mfma16(ah, bl, acc[mi]);
+        }
+        acc[mi] = mfma16(ah, bh, acc[mi]);
+      }
+    }
+  }
+  // ---- epilogue: + bias, store -------------------------------------------------------------------------------
+  const int n = n0 + wave * 16 + lr;
+  if (n < a.Cout) {
+    const float bv = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ox = ox0 + mi * 16 + kq * 4 + j;
+        if (ox < a.W) a.y[((size_t)(b * a.H + oy) * a.W + ox) * a.Cout + n] = acc[mi][j] + bv;
+      }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// distortion_aware_ops.conv2d.distortion (:198-270) evaluated in float32 in the reference's operation order.
+// out: [h][k*k][2] floats (y, x).  [host]
+int hdrsky_da_offsets(int h, int w, int ksize, int dilation_rate, int skydome, float* out) {
+  if (!out || h <= 0 || w <= 0 || ksize <= 0 || (ksize & 1) == 0) return HDRSKY_EINVAL;
+  const float pi = (float)M_PI;
+  const int n = ksize / 2, middle = n * (ksize + 1), k2 = ksize * ksize;
+  const float unit_w = (float)(2.0 * M_PI) / (float)w;
+  const float unit_h = pi / (float)(skydome ? h * 2 : h);
+  const float rho = tanf(unit_w) * (float)dilation_rate;
+  const int xc = (int)(w * 0.5);
+  for (int y = 0; y < h; ++y) {
+    const float theta = (float)((double)xc - 0.5 * (double)w) * unit_w;
+    const float phi = skydome ? (float)(h - y) * unit_h : (float)((double)h * 0.5 - (double)y) * unit_h;
+    const float pu[3] = {cosf(phi) * cosf(theta), sinf(phi), cosf(phi) * sinf(theta)};
+    // t_x = cross((0,1,0), p_u), t_y = cross(p_u, t_x)   (not normalised)
+    const float tx[3] = {1.f * pu[2] - 0.f * pu[1], 0.f * pu[0] - 0.f * pu[2], 0.f * pu[1] - 1.f * pu[0]};
+    const float ty[3] = {pu[1] * tx[2] - pu[2] * tx[1], pu[2] * tx[0] - pu[0] * tx[2], pu[0] * tx[1] - pu[1] * tx[0]};
+    float ky[64 * 2], kx[64 * 2];
+    if (k2 > 128) return HDRSKY_EUNSUPPORTED;
+    int i = 0;
+    for (int gy = n; gy >= -n; --gy)
+      for (int gx = n; gx >= -n; --gx, ++i) {
+        float ur[3];
+        for (int d = 0; d < 3; ++d) ur[d] = pu[d] + rho * ((float)gx * tx[d] + (float)gy * ty[d]);
+        float theta_r;
+        if (ur[0] > 0.f) theta_r = atan2f(ur[2], ur[0]);
+        else if (ur[0] < 0.f) theta_r = ur[2] >= 0.f ? atan2f(ur[2], ur[0]) + pi : atan2f(ur[2], ur[0]) - pi;
+        else if (ur[2] > 0.f) theta_r = pi * 0.5f;
+        else if (ur[2] < 0.f) theta_r = -pi * 0.5f;
+        else return HDRSKY_EINVAL;  // "undefined coordinates"
+        const float phi_r = asinf(ur[1]);
+        kx[i] = (theta_r / pi + 1.f) * 0.5f * (float)w;
+        ky[i] = skydome ? (1.f - (2.f * phi_r) / pi) * (float)h : (0.5f - phi_r / pi) * (float)h;
+      }
+    for (i = 0; i < k2; ++i) {
+      out[(y * k2 + i) * 2 + 0] = ky[i] - ky[middle];
+      out[(y * k2 + i) * 2 + 1] = kx[i] - kx[middle];
+    }
+  }
+  return HDRSKY_OK;
+}
+
+// y[B,H,W,Cout] = DA-conv(x[B,H,W,Cin]) + bias; weights packed with hdrsky_conv_pack_weights(w, k, k, Cin, Cout, 0, ..)
+// from the reference's [k*k*Cin, Cout] kernel (same memory order as HWIO); offs = device copy of hdrsky_da_offsets.
+int hdrsky_da_conv2d_fwd(const float* x, const void* w_hi, const void* w_lo, const float* bias, const float* offs, int B,
+                         int H, int W, int Cin, int Cout, int ksize, int compute, float* y, void* stream) {
+  if (!x || !w_hi || !offs || !y || (ksize & 1) == 0) return HDRSKY_EINVAL;
+  if ((Cin % 32) != 0) return HDRSKY_EUNSUPPORTED;
+  const bool precise = compute == HDRSKY_BF16X3;
+  if (precise && !w_lo) return HDRSKY_EINVAL;
+  DaArgs a{};
+  a.x = x; a.whi = (const uint4*)w_hi; a.wlo = (const uint4*)w_lo; a.bias = bias; a.offs = offs; a.y = y;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.Npad = roundup(Cout, 64);
+  a.ksize = ksize; a.k2 = ksize * ksize;
+  // conv2d._pad_input (:125-150) for stride 1: pad (k-1)//2 before, rest after, when k > 1
+  a.pad = ksize > 1 ? (ksize - 1) / 2 : 0;
+  a.in_h = H + (ksize > 1 ? ksize - 1 : 0); a.in_w = W + (ksize > 1 ? ksize - 1 : 0);
+  a.cin32 = Cin / 32; a.nblocks = cdiv(Cout, 64); a.tiles_x = cdiv(W, 64);
+  const int lds = 2 * (Cin / 8) * 65 * 16 * (precise ? 2 : 1);
+  if (lds > 160 * 1024) return HDRSKY_EUNSUPPORTED;
+  const int grid = B * H * a.tiles_x * a.nblocks;
+  if (precise) {
+    auto k = da_conv_kernel<true>;
+    static bool set = false;
+    if (!set) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return HDRSKY_ELAUNCH; set = true; }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+  } else {
+    auto k = da_conv_kernel<false>;
+    static bool set = false;
+    if (!set) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return HDRSKY_ELAUNCH; set = true; }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+  }
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+}  // extern "C"

@@ -593,3 +593,33 @@ def rmsprop(w, g, ms, lr, rho=0.9, eps=1e-7, gscale=1.0):
     n = w.numel()
     _f32(w); _f32(g, n); _f32(ms, n)
     L.check(L.load().hdrsky_rmsprop(_p(w), _p(g), _p(ms), n, lr, rho, eps, gscale, _stream()), "rmsprop")
+
+
+# ------------------------------------------------------------------------------------------------
+# distortion-aware convolution (csrc/da_conv.hip)
+# ------------------------------------------------------------------------------------------------
+def da_offsets(h, w, ksize=3, dilation_rate=1, skydome=True):
+    """Host float32 offset table [h, k*k, 2] (distortion_aware_ops.py:198-270)."""
+    import ctypes
+    import numpy as np
+    out = np.zeros((h, ksize * ksize, 2), np.float32)
+    L.check(L.load().hdrsky_da_offsets(h, w, ksize, dilation_rate, int(skydome), out.ctypes.data_as(ctypes.c_void_p)),
+            "da_offsets")
+    return out
+
+
+def da_conv2d(x, pw: PackedConv, bias, offs, compute=BF16):
+    """distortion_aware_ops.conv2d.call: offs = device tensor [H, k*k, 2] from da_offsets(H, W, k, ...)."""
+    _f32(x)
+    B, H, W, C = x.shape
+    if C != pw.Cin or pw.KH != pw.KW:
+        raise ValueError("filter / input mismatch")
+    _f32(offs, H, pw.KH * pw.KW, 2)
+    if bias is not None:
+        _f32(bias, pw.Cout)
+    if compute == BF16X3 and pw.lo is None:
+        raise ValueError("BF16X3 needs the lo weight plane")
+    y = torch.empty((B, H, W, pw.Cout), dtype=torch.float32, device=x.device)
+    L.check(L.load().hdrsky_da_conv2d_fwd(_p(x), _p(pw.hi), _p(pw.lo), _p(bias), _p(offs), B, H, W, C, pw.Cout, pw.KH,
+                                          compute, _p(y), _stream()), "da_conv2d_fwd")
+    return y

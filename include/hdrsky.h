@@ -250,6 +250,18 @@ int hdrsky_fc_wgrad(const float* x, const float* dy, int M, int K, int N, int ac
 /* Keras-2 OptimizerV2 RMSprop step over one flat buffer (train.py:201-202,403,406): g is first multiplied by gscale. */
 int hdrsky_rmsprop(float* w, const float* g, float* ms, size_t n, float lr, float rho, float eps, float gscale, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Distortion-aware panoramic convolution (distortion_aware_ops.py)
+ * ---------------------------------------------------------------------------------------- */
+/* conv2d.distortion (distortion_aware_ops.py:198-270), float32 in the reference's operation order:
+ * out[h][k*k][2] = (y, x) sampling offsets per row (identical for every column). [host] */
+int hdrsky_da_offsets(int h, int w, int ksize, int dilation_rate, int skydome, float* out);
+/* conv2d.call (distortion_aware_ops.py:50-123): bilinear gather with y clamp / 360-degree x wrap fused into an MFMA
+ * GEMM; w_* = hdrsky_conv_pack_weights image of the [k*k*Cin, Cout] kernel viewed as [k,k,Cin,Cout]; offs = device
+ * copy of hdrsky_da_offsets(H, W, k, ..).  stride 1, Cin % 32 == 0.  deconv2d.call (:321-395) = hdrsky_up2x_fwd + this. */
+int hdrsky_da_conv2d_fwd(const float* x, const void* w_hi, const void* w_lo, const float* bias, const float* offs, int B,
+                         int H, int W, int Cin, int Cout, int ksize, int compute, float* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
