@@ -115,6 +115,7 @@ def main():
     synth = importlib.import_module(PKG + ".synth")
     engine = importlib.import_module(PKG + ".engine")
     trainer = importlib.import_module(PKG + ".trainer")
+    par = importlib.import_module(PKG + ".parallel")
     K = importlib.import_module(PKG + ".kernels")
 
     gen = params.init_params(params.generator_spec(), 0)
@@ -139,9 +140,11 @@ def main():
         #          gradient is the replica average: SURVEY.md section 8e); phase B: RMSprop x2 + weight re-packing.
         phases = [lambda: tr.step(ldr, hdr, gt, update=False), lambda: tr.apply_gradients(gscale=1.0 / world)]
 
+        par.broadcast_params_([tr.gs.flat, tr.ds.flat])   # replicas start from rank 0's weights
+        tr.repack()
+
         def between():
-            dist.all_reduce(tr.gs.grad)
-            dist.all_reduce(tr.ds.grad)
+            par.allreduce_sum_([tr.gs.grad, tr.ds.grad])
         if world == 1:
             between = None
         roof_pw, roof_b = tr.conv["gen.res.0.conv1"].pk, tr.gs.w["gen.res.0.conv1.b"]

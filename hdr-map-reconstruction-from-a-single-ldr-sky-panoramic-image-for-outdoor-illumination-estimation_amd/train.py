@@ -1,0 +1,86 @@
+"""`python -m <pkg>.train` - the reference's train.py CLI surface (train.py:527-545) on the MI355X step.
+
+Flags keep the reference's names and defaults: --dir --lr(1e-4) --batchsize(32) --epochs(1000) --imheight(32)
+--imwidth(128) --sky --sun --dorf --vgg.  There is no Laval dataset / dorfCurves.txt / vgg16.npy in this environment:
+without --dir the loop trains on seeded synthetic batches (synth.make_batch); --vgg loads a real vgg16.npy when given.
+Per epoch it prints the reference's scalar names (train.py:480-489) and every 10th epoch saves SKY / SUN checkpoints
+with max_to_keep=5 (train.py:516-522).  Launch with torchrun for data parallelism (one process per GPU).
+"""
+import argparse
+import os
+import time
+
+import torch
+
+from . import checkpoint as ckpt
+from . import kernels as K
+from . import parallel as par
+from . import params as P
+from . import synth
+from .trainer import Trainer
+
+
+def main(argv=None):
+    cwd = os.getcwd()
+    ap = argparse.ArgumentParser(description="training the LDR->HDR sky model")
+    ap.add_argument("--dir", type=str, default=None, help="dataset directory (TFRecords; not supported here -> synthetic)")
+    ap.add_argument("--lr", type=float, default=1e-4)
+    ap.add_argument("--batchsize", type=int, default=32)
+    ap.add_argument("--epochs", type=int, default=1000)
+    ap.add_argument("--imheight", type=int, default=32)
+    ap.add_argument("--imwidth", type=int, default=128)
+    ap.add_argument("--sky", type=str, default=os.path.join(cwd, "checkpoints/SKY"))
+    ap.add_argument("--sun", type=str, default=os.path.join(cwd, "checkpoints/SUN"))
+    ap.add_argument("--dorf", type=str, default=None)
+    ap.add_argument("--vgg", type=str, default=None)
+    ap.add_argument("--steps-per-epoch", type=int, default=8, help="synthetic mode: steps per epoch")
+    args = ap.parse_args(argv)
+
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    rank, world, _ = par.init_from_env(device=dev)
+    h, w = args.imheight, args.imwidth
+    gen = P.init_params(P.generator_spec(h, w), 0)
+    sun = P.init_params(P.sunpose_spec(h, w), 1)
+    dis = P.init_params(P.discriminator_spec(), 2)
+    vgg = P.load_vgg_npy(args.vgg) if args.vgg else P.init_params(P.vgg_spec(), 3)
+    sky_mgr, sun_mgr = ckpt.CheckpointManager(args.sky), ckpt.CheckpointManager(args.sun)
+    tensors, epoch0 = sky_mgr.restore()
+    if tensors:
+        ckpt.load_into(gen, tensors, "gen_model"); ckpt.load_into(dis, tensors, "dis_model")
+        print("Latest SKY checkpoint has restored!!")
+    sun_t, _ = sun_mgr.restore()
+    if sun_t:
+        ckpt.load_into(sun, sun_t, "lin")
+        print("Latest SUN checkpoint has restored!!")
+    tr = Trainer(gen, sun, dis, vgg, device=dev, lr=args.lr, im_height=h, im_width=w, compute=K.BF16, world_size=world)
+    if tensors and "gen_optimizer/rms" in tensors:
+        tr.gs.ms.copy_(torch.from_numpy(tensors["gen_optimizer/rms"])); tr.ds.ms.copy_(torch.from_numpy(tensors["disc_optimizer/rms"]))
+    par.broadcast_params_([tr.gs.flat, tr.ds.flat]); tr.repack()
+
+    for epoch in range(epoch0 + 1, args.epochs + 1):
+        t0 = time.perf_counter()
+        acc = {}
+        for it in range(args.steps_per_epoch):
+            b = synth.make_batch(args.batchsize, h, w, seed=(epoch * 100003 + it) * world + rank)
+            ldr, hdr, gt = (torch.from_numpy(b[k]).to(dev) for k in ("ldr", "hdr_t", "sunpose_gt"))
+            out = tr.step(ldr, hdr, gt, update=False)
+            par.allreduce_sum_([tr.gs.grad, tr.ds.grad])
+            tr.apply_gradients(gscale=1.0 / world)
+            for k, v in tr.loss_dict().items():
+                acc[k] = acc.get(k, 0.0) + v / args.steps_per_epoch
+        if rank == 0:
+            names = (("gen_total_loss", "total_gen_loss"), ("gen_l1_loss", "l1"), ("gen_perceptual_loss", "perceptual"),
+                     ("gen_DoG_loss", "dog"), ("gen_adv_loss", "adv"), ("gen_kl_div", "kl"),
+                     ("disc_total_loss", "total_disc_loss"), ("disc_generated_loss", "disc_generated"), ("disc_real_loss", "disc_real"))
+            print("[epoch %d] %s  g_out=%.4f b_out=%.4f  Spends : %.2f(s)" %
+                  (epoch, "  ".join("%s=%.5g" % (n, acc[k]) for n, k in names), float(out["gamma"].max()),
+                   float(out["beta"].max()), time.perf_counter() - t0))
+            if epoch % 10 == 0:
+                print("Saved SKY checkpoint for epoch {}: {}".format(epoch, sky_mgr.save(ckpt.sky_tensors(tr), epoch)))
+                print("Saved SUN checkpoint for epoch {}: {}".format(epoch, sun_mgr.save(ckpt.sun_tensors(tr), epoch)))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,38 @@
+"""CPU tests of the host-side surface: Radiance .hdr codec and the checkpoint manager (retention, latest, restore)."""
+import os
+
+import numpy as np
+
+from conftest import pkg
+
+
+def test_hdr_roundtrip(tmp_path):
+    io = pkg("hdr_io")
+    rng = np.random.default_rng(0)
+    img = (10.0 ** rng.uniform(-3, 4, (32, 128, 3))).astype(np.float32)
+    img[0, 0] = 0.0
+    p = os.path.join(str(tmp_path), "a.hdr")
+    io.write_hdr(p, img)
+    back = io.read_hdr(p)
+    assert back.shape == img.shape
+    # RGBE: 8-bit mantissa shared exponent -> relative error <= 1/128 of the pixel's max channel
+    tol = img.max(axis=-1, keepdims=True) / 128.0 + 1e-30
+    assert (np.abs(back - img) <= tol).all()
+    assert (back[0, 0] == 0).all()
+    data = open(p, "rb").read()
+    assert data.startswith(b"#?RADIANCE") and b"-Y 32 +X 128" in data
+
+
+def test_checkpoint_manager_retention_and_restore(tmp_path):
+    ck = pkg("checkpoint")
+    m = ck.CheckpointManager(os.path.join(str(tmp_path), "SKY"), max_to_keep=5)
+    assert m.latest_checkpoint is None and m.restore() == (None, 0)
+    for e in range(1, 8):
+        m.save({"gen_model/conv1_d/w": np.full((2, 2), e, np.float32), "gen_optimizer/rms": np.zeros(4, np.float32)}, epoch=e * 10)
+    files = sorted(os.listdir(m.directory))
+    assert len([f for f in files if f.endswith(".npz")]) == 5 and "checkpoint" in files
+    assert m.latest_checkpoint.endswith("ckpt-7.npz")
+    t, epoch = m.restore()
+    assert epoch == 70 and float(t["gen_model/conv1_d/w"][0, 0]) == 7.0
+    params = {"conv1_d.w": np.zeros((2, 2), np.float32), "conv1_d.b": np.zeros(2, np.float32)}
+    assert ck.load_into(params, t, "gen_model") == 1 and params["conv1_d.w"][1, 1] == 7.0

@@ -178,3 +178,20 @@ def test_train_step_updates_weights_like_rmsprop(dev):
     assert torch.isfinite(tr.gs.flat).all() and torch.isfinite(tr.ds.flat).all()
     v = tr.loss_dict()
     assert all(np.isfinite(x) for x in v.values())
+
+
+def test_cli_train_and_inference_smoke(dev, tmp_path, capsys):
+    """train CLI (2 synthetic epochs at batch 2) writes nothing before epoch 10; inference CLI turns a jpg into a .hdr."""
+    train = pkg("train"); inference = pkg("inference"); hdr_io = pkg("hdr_io")
+    sky, sun = str(tmp_path / "SKY"), str(tmp_path / "SUN")
+    train.main(["--batchsize", "2", "--epochs", "2", "--steps-per-epoch", "1", "--sky", sky, "--sun", sun])
+    out = capsys.readouterr().out
+    assert "gen_total_loss=" in out and "disc_real_loss=" in out
+    from PIL import Image
+    indir, outdir = tmp_path / "in", tmp_path / "out"
+    indir.mkdir()
+    img = (np.random.default_rng(0).uniform(0, 255, (32, 128, 3))).astype(np.uint8)
+    Image.fromarray(img).save(str(indir / "sky1.jpg"), quality=95)
+    inference.main(["--indir", str(indir), "--outdir", str(outdir), "--sky", sky, "--sun", sun])
+    back = hdr_io.read_hdr(str(outdir / "sky1.hdr"))
+    assert back.shape == (32, 128, 3) and np.isfinite(back).all() and back.max() > 0
