@@ -33,6 +33,7 @@ SIGNATURES = {
     "hdrsky_conv_desc_init_dgrad": (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvDesc)]),
     "hdrsky_conv_packed_elems": (c_size_t, [c_int] * 4),
     "hdrsky_conv_pack_weights": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
+    "hdrsky_conv_pack_weights_multi": (c_int, [P, c_int, c_int, P]),
     "hdrsky_conv_stats_nparts": (c_int, [ctypes.POINTER(ConvDesc)]),
     "hdrsky_conv2d_fwd": (c_int, [ctypes.POINTER(ConvDesc)] + [P] * 13),
     "hdrsky_conv2d_wgrad": (c_int, [ctypes.POINTER(ConvDesc)] + [P] * 10),

@@ -542,33 +542,64 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const ConvKArg
 // ---------------------------------------------------------------------------------------------------
 // weight packing: fp32 HWIO -> [kstep][4][Npad][8] bf16 (hi / lo planes)
 // ---------------------------------------------------------------------------------------------------
+// one element of the packed image (index i) from the fp32 HWIO filter
+__device__ __forceinline__ void pack_one(const float* __restrict__ w, int KH, int KW, int Cin, int Cout, int Npad,
+                                         int narrow, int flip, int ksteps, size_t i, unsigned short* __restrict__ hi,
+                                         unsigned short* __restrict__ lo) {
+  const int j = i & 7;
+  size_t r = i >> 3;
+  const int n = r % Npad; r /= Npad;
+  const int q = r & 3;
+  const int kp = (int)(r >> 2);
+  int tap, c;
+  if (narrow) { tap = kp * 4 + q; c = j; }
+  else { const int cin32 = Cin >> 5; tap = kp / cin32; c = (kp % cin32) * 32 + q * 8 + j; }
+  float v = 0.f;
+  if (kp < ksteps && tap < KH * KW && c < Cin && n < Cout) {
+    int ky = tap / KW, kx = tap % KW;
+    if (flip) {
+      // packed filter w'[ky,kx,c(=co of w),n(=ci of w)] = w[KH-1-ky, KW-1-kx, n, c]; w is [KH,KW,Cout',Cin']
+      ky = KH - 1 - ky; kx = KW - 1 - kx;
+      v = w[((size_t)(ky * KW + kx) * Cout + n) * Cin + c];
+    } else {
+      v = w[((size_t)(ky * KW + kx) * Cin + c) * Cout + n];
+    }
+  }
+  const unsigned short h = f2bf(v);
+  hi[i] = h;
+  if (lo != nullptr) lo[i] = f2bf(v - bf2f(h));
+}
+
 __global__ void pack_weights_kernel(const float* __restrict__ w, int KH, int KW, int Cin, int Cout, int Npad,
                                     int narrow, int flip, int ksteps, unsigned short* __restrict__ hi,
                                     unsigned short* __restrict__ lo) {
   const size_t total = (size_t)(ksteps + 1) * 4 * Npad * 8;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int j = i & 7;
-    size_t r = i >> 3;
-    const int n = r % Npad; r /= Npad;
-    const int q = r & 3;
-    const int kp = (int)(r >> 2);
-    int tap, c;
-    if (narrow) { tap = kp * 4 + q; c = j; }
-    else { const int cin32 = Cin >> 5; tap = kp / cin32; c = (kp % cin32) * 32 + q * 8 + j; }
-    float v = 0.f;
-    if (kp < ksteps && tap < KH * KW && c < Cin && n < Cout) {
-      int ky = tap / KW, kx = tap % KW;
-      if (flip) {
-        // packed filter w'[ky,kx,c(=co of w),n(=ci of w)] = w[KH-1-ky, KW-1-kx, n, c]; w is [KH,KW,Cout',Cin'] = [.., n-range, c-range]
-        ky = KH - 1 - ky; kx = KW - 1 - kx;
-        v = w[((size_t)(ky * KW + kx) * Cout + n) * Cin + c];
-      } else {
-        v = w[((size_t)(ky * KW + kx) * Cin + c) * Cout + n];
-      }
-    }
-    const unsigned short h = f2bf(v);
-    hi[i] = h;
-    if (lo != nullptr) lo[i] = f2bf(v - bf2f(h));
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+    pack_one(w, KH, KW, Cin, Cout, Npad, narrow, flip, ksteps, i, hi, lo);
+}
+
+// Multi-tensor re-pack after an optimizer step: one launch for every conv filter of a network.
+// jobs[j] = {w, hi, lo, KH, KW, Cin, Cout, flip, first_block} (9 x int64); a block packs 2048 elements.
+__global__ void __launch_bounds__(256) pack_multi_kernel(const long long* __restrict__ jobs, int njobs) {
+  int lo_j = 0, hi_j = njobs - 1;
+  while (lo_j < hi_j) {  // last job whose first_block <= blockIdx.x
+    const int mid = (lo_j + hi_j + 1) >> 1;
+    if (jobs[mid * 9 + 8] <= (long long)blockIdx.x) lo_j = mid; else hi_j = mid - 1;
+  }
+  const long long* jb = jobs + lo_j * 9;
+  const float* w = reinterpret_cast<const float*>(jb[0]);
+  unsigned short* hi = reinterpret_cast<unsigned short*>(jb[1]);
+  unsigned short* lo = reinterpret_cast<unsigned short*>(jb[2]);
+  const int KH = (int)jb[3], KW = (int)jb[4], Cin = (int)jb[5], Cout = (int)jb[6], flip = (int)jb[7];
+  const int narrow = Cin <= 8 ? 1 : 0;
+  const int ksteps = narrow ? (KH * KW + 3) / 4 : KH * KW * (Cin / 32);
+  const int Npad = (Cout + 63) / 64 * 64;
+  const size_t total = (size_t)(ksteps + 1) * 4 * Npad * 8;
+  const size_t base = (size_t)(blockIdx.x - (int)jb[8]) * 2048;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const size_t i = base + k * 256 + threadIdx.x;
+    if (i < total) pack_one(w, KH, KW, Cin, Cout, Npad, narrow, flip, ksteps, i, hi, lo);
   }
 }
 
@@ -763,6 +794,13 @@ int hdrsky_conv_pack_weights(const float* w, int KH, int KW, int Cin, int Cout, 
   const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   hipLaunchKernelGGL(pack_weights_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, KH, KW, Cin, Cout, Npad,
                      Cin <= 8 ? 1 : 0, transpose_flip, ks, (unsigned short*)packed_hi, (unsigned short*)packed_lo);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_conv_pack_weights_multi(const void* jobs, int njobs, int total_blocks, void* stream) {
+  if (!jobs || njobs <= 0 || total_blocks <= 0) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(pack_multi_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const long long*)jobs, njobs);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }

@@ -42,9 +42,12 @@ __device__ __forceinline__ uint2 lds_tr(const unsigned char* p) {
   return __builtin_bit_cast(uint2, v);
 }
 
-template <int TPW, int CBF, int OBF, int TW, bool NARROW, bool PRECISE>
-__global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
+template <int TPW, int CBF, int OBF, int TW, bool NARROW, bool PRECISE, int NW>
+__global__ void __launch_bounds__(NW * 64) conv_wgrad_kernel(const WgradArgs a) {
   constexpr int CB = CBF * 16, OB = OBF * 16;
+  constexpr int NT = NW * 64;
+  constexpr int CBH = (NW == 8) ? CBF / 2 : CBF;   // 8 waves: 4 tap groups x 2 halves of the ci fragments
+  static_assert(NW == 4 || (NW == 8 && (CBF % 2) == 0), "8-wave variant needs an even number of ci fragments");
   constexpr int BM = 128, TH = BM / TW;      // output pixels per tile (4 k-steps of 32)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sX = smem;
@@ -62,11 +65,13 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
   const int cb0 = (blk / a.oblocks) * CB, ob0 = (blk % a.oblocks) * OB;
   const float slope = a.in_slope;
 
-  f32x4_t acc[TPW][CBF][OBF];
+  const int tgrp = wave & 3;                        // tap group of this wave
+  const int cih = (NW == 8) ? (wave >> 2) * CBH : 0;  // first ci fragment of this wave
+  f32x4_t acc[TPW][CBH][OBF];
 #pragma unroll
   for (int t = 0; t < TPW; ++t)
 #pragma unroll
-    for (int i = 0; i < CBF; ++i)
+    for (int i = 0; i < CBH; ++i)
 #pragma unroll
       for (int j = 0; j < OBF; ++j) acc[t][i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   float bsum[8];
@@ -83,7 +88,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
     __syncthreads();  // previous tile fully consumed
     if (b != prev_b) {  // per-sample operand transform tables for this block's CB channels
       prev_b = b;
-      for (int c = tid; c < CB; c += 256) {
+      for (int c = tid; c < CB; c += NT) {
         const int cc = cb0 + c;
         float sc = 1.f, sh = 0.f;
         if (cc < a.Cin) {
@@ -108,7 +113,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
     {
       constexpr int NQ = CB / 8;
       const int nitems = a.NPIX * NQ;
-      for (int i = tid; i < nitems; i += 256) {
+      for (int i = tid; i < nitems; i += NT) {
         const int px = i / NQ, qc = i % NQ;
         const int hy = (int)(((unsigned)px * (unsigned)a.wt_magic) >> 24);
         const int hx = px - hy * a.WT;
@@ -162,10 +167,10 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
     }
     // ---- stage dY tile: [pixel][OB] bf16 rows (+ per-thread bias-gradient partial sums) -----------------
     {
-      constexpr int NQ = OB / 8;  // 256 % NQ == 0: a thread always handles the same 8 output channels
+      constexpr int NQ = OB / 8;  // NT % NQ == 0: a thread always handles the same 8 output channels
       const int qc = tid % NQ;
       const int n0 = ob0 + qc * 8;
-      for (int i = tid; i < BM * NQ; i += 256) {
+      for (int i = tid; i < BM * NQ; i += NT) {
         const int m = i / NQ;
         const int oy = oy0 + m / TW, ox = ox0 + m % TW;
         const bool ok = oy < a.Ho && ox < a.Wo;
@@ -203,19 +208,19 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
       }
 #pragma unroll
       for (int t = 0; t < TPW; ++t) {
-        const int tap = wave + 4 * t;   // wave-uniform
+        const int tap = tgrp + 4 * t;   // wave-uniform
         if (tap < a.ntaps) {
           const int ky = (tap * a.kw_magic) >> 16, kx = tap - ky * a.KW;
           const int xpix = (mty * a.stride + ky) * a.WT + mtx * a.stride + kx;
           const int step4 = 4 * a.stride * a.RX;
 #pragma unroll
-          for (int i = 0; i < CBF; ++i) {
-            const unsigned char* ad = sX + (size_t)xpix * a.RX + (i * 16 + p * 4) * 2;
+          for (int i = 0; i < CBH; ++i) {
+            const unsigned char* ad = sX + (size_t)xpix * a.RX + ((cih + i) * 16 + p * 4) * 2;
             const uint2 v0 = lds_tr(ad), v1 = lds_tr(ad + step4);
             const uint4 ah = uint4{v0.x, v0.y, v1.x, v1.y};
             uint4 al = uint4{0, 0, 0, 0};
             if (PRECISE) {
-              const unsigned char* adl = sXl + (size_t)xpix * a.RX + (i * 16 + p * 4) * 2;
+              const unsigned char* adl = sXl + (size_t)xpix * a.RX + ((cih + i) * 16 + p * 4) * 2;
               const uint2 w0 = lds_tr(adl), w1 = lds_tr(adl + step4);
               al = uint4{w0.x, w0.y, w1.x, w1.y};
             }
@@ -236,15 +241,15 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
   // ---- epilogue: add this block's partial dW (and db) to global memory --------------------------------------
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
-    const int tap = wave + 4 * t;
+    const int tap = tgrp + 4 * t;
     if (tap < a.ntaps) {
 #pragma unroll
-      for (int i = 0; i < CBF; ++i)
+      for (int i = 0; i < CBH; ++i)
 #pragma unroll
         for (int j = 0; j < OBF; ++j)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const int ci = cb0 + i * 16 + kq * 4 + e, co = ob0 + j * 16 + lr;
+            const int ci = cb0 + (cih + i) * 16 + kq * 4 + e, co = ob0 + j * 16 + lr;
             if (ci < a.Cin && co < a.Cout) atomicAdd(a.dw + ((size_t)tap * a.Cin + ci) * a.Cout + co, acc[t][i][j][e]);
           }
     }
@@ -258,7 +263,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
     if (tid < OB) {
       const int qc = tid / 8, j = tid % 8;
       float s = 0.f;
-      for (int k = qc; k < 256; k += NQ) s += sRed[k * 8 + j];
+      for (int k = qc; k < NT; k += NQ) s += sRed[k * 8 + j];
       if (ob0 + tid < a.Cout) atomicAdd(a.db + ob0 + tid, s);
     }
   }
@@ -266,6 +271,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
 
 template <int TPW, int CBF, int OBF, int TW, bool NARROW, bool PRECISE>
 int launch_wgrad(WgradArgs& a, hipStream_t stream) {
+  constexpr int NW = (!NARROW && (CBF % 2) == 0) ? 8 : 4;
   constexpr int CB = CBF * 16, OB = OBF * 16, BM = 128, TH = BM / TW;
   a.tiles_x = cdiv(a.Wo, TW);
   a.tiles_y = cdiv(a.Ho, TH);
@@ -288,7 +294,7 @@ int launch_wgrad(WgradArgs& a, hipStream_t stream) {
   a.off_ylo = a.off_y + ybytes;
   a.off_ss = a.off_y + ybytes * planes;
   a.off_red = a.off_ss + 2 * CB * 4;
-  const int lds = a.off_red + 256 * 8 * 4;
+  const int lds = a.off_red + NW * 64 * 8 * 4;
   if (lds > 160 * 1024) return HDRSKY_EUNSUPPORTED;
   // enough workgroups to fill the chip, few enough that the atomic traffic (one dW block per workgroup) stays small
   const int nblk = a.cblocks * a.oblocks;
@@ -296,7 +302,7 @@ int launch_wgrad(WgradArgs& a, hipStream_t stream) {
   if (chunks > a.ntiles) chunks = a.ntiles;
   a.tiles_per_wg = cdiv(a.ntiles, chunks);
   chunks = cdiv(a.ntiles, a.tiles_per_wg);
-  auto kern = conv_wgrad_kernel<TPW, CBF, OBF, TW, NARROW, PRECISE>;
+  auto kern = conv_wgrad_kernel<TPW, CBF, OBF, TW, NARROW, PRECISE, NW>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
@@ -304,7 +310,7 @@ int launch_wgrad(WgradArgs& a, hipStream_t stream) {
       return HDRSKY_ELAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(nblk * chunks), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL(kern, dim3(nblk * chunks), dim3(NW * 64), lds, stream, a);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }

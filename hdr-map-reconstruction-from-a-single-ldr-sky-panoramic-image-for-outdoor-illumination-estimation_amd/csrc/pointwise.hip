@@ -149,20 +149,32 @@ __global__ void __launch_bounds__(256) norm_act_bwd_kernel(const float* __restri
   const int cl = (threadIdx.x & 3) * 4;      // channel offset inside the group (float4)
   const int slot = threadIdx.x >> 2;         // 64 pixel slots
   const int c = cg * 16 + cl;
-  // per-channel constants (4 channels per thread)
+  // per-channel constants (4 channels per thread).  The 16 channels' statistics are reduced cooperatively: thread
+  // (slice, ch) sums every 16th partial, then 16 threads add the 16 slices in a fixed order (one memory round trip
+  // instead of nparts dependent ones).
   float mean[4], rstd[4], gm[4], bt[4];
   {
-    const float inv_count = 1.f / (float)(H * W);
+    __shared__ float sPart[16][16][2];
+    __shared__ float sMR[16][2];
+    const int ch = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    float s = 0.f, ss = 0.f;
+    const float* pp = part + (size_t)b * nparts * 2 * C + cg * 16 + ch;
+    for (int p = sl; p < nparts; p += 16) { s += pp[(2 * p) * C]; ss += pp[(2 * p + 1) * C]; }
+    sPart[sl][ch][0] = s; sPart[sl][ch][1] = ss;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+      float ts = 0.f, tss = 0.f;
+      for (int k = 0; k < 16; ++k) { ts += sPart[k][threadIdx.x][0]; tss += sPart[k][threadIdx.x][1]; }
+      const float inv_count = 1.f / (float)(H * W);
+      const float m = ts * inv_count;
+      const float var = fmaxf(tss * inv_count - m * m, 0.f);
+      sMR[threadIdx.x][0] = m; sMR[threadIdx.x][1] = 1.f / sqrtf(var + eps);
+    }
+    __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float s = 0.f, ss = 0.f;
-      const float* pp = part + (size_t)b * nparts * 2 * C + c + j;
-      for (int p = 0; p < nparts; ++p) { s += pp[(2 * p) * C]; ss += pp[(2 * p + 1) * C]; }
-      mean[j] = s * inv_count;
-      const float var = fmaxf(ss * inv_count - mean[j] * mean[j], 0.f);
-      rstd[j] = 1.f / sqrtf(var + eps);
-      gm[j] = gamma[c + j];
-      bt[j] = beta[c + j];
+      mean[j] = sMR[cl + j][0]; rstd[j] = sMR[cl + j][1];
+      gm[j] = gamma[c + j]; bt[j] = beta[c + j];
     }
   }
   const float* xb = x + (size_t)b * H * W * C + c;

@@ -74,6 +74,25 @@ class PackedConv:
                                              _p(self.hi), _p(self.lo), _stream()), "conv_pack_weights")
 
 
+class MultiPacker:
+    """One-launch re-pack of a list of (fp32 HWIO weight view, PackedConv) pairs (hdrsky_conv_pack_weights_multi)."""
+
+    def __init__(self, pairs):
+        rows, blk = [], 0
+        for w, pw in pairs:
+            n = pw.hi.numel()
+            rows.append([w.data_ptr(), pw.hi.data_ptr(), pw.lo.data_ptr() if pw.lo is not None else 0, pw.KH, pw.KW,
+                         pw.Cin, pw.Cout, int(pw.flip), blk])
+            blk += (n + 2047) // 2048
+        self.njobs, self.blocks = len(rows), blk
+        self.table = torch.tensor(rows, dtype=torch.int64, device=pairs[0][0].device)
+        self._keep = pairs   # the pointers in the table must stay valid
+
+    def run(self):
+        L.check(L.load().hdrsky_conv_pack_weights_multi(_p(self.table), self.njobs, self.blocks, _stream()),
+                "conv_pack_weights_multi")
+
+
 def conv_desc(B, H, W, Cin, Cout, KH, KW, stride=1, same=True, upsample=1):
     d = L.ConvDesc()
     L.check(L.load().hdrsky_conv_desc_init(d, B, H, W, Cin, Cout, KH, KW, stride, int(same), upsample), "conv_desc_init")

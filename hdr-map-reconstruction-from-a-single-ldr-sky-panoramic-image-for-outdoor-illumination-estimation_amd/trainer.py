@@ -146,8 +146,14 @@ class Trainer:
             self.vgg_pkT[name] = PackedConv(self.vgg[name + ".w"], pr, transpose_flip=True)
 
     def repack(self):
-        for cv in self.conv.values():
-            cv.repack()
+        if getattr(self, "_packer", None) is None:
+            pairs = []
+            for cv in self.conv.values():
+                pairs.append((cv.w, cv.pk))
+                if cv.pkT is not None:
+                    pairs.append((cv.w, cv.pkT))
+            self._packer = K.MultiPacker(pairs)
+        self._packer.run()
         self.fc1.repack(self.gs.w["sun.fc1.kernel"])
         self.fc2.repack(self.gs.w["sun.fc2.kernel"])
 

@@ -95,6 +95,11 @@ size_t hdrsky_conv_packed_elems(int KH, int KW, int Cin, int Cout);
 int hdrsky_conv_pack_weights(const float* w, int KH, int KW, int Cin, int Cout, int transpose_flip,
                              void* packed_hi, void* packed_lo, void* stream);
 
+/* Re-packs MANY filters in one launch (after an optimizer step).  jobs: device array [njobs][9] of int64
+ * {w ptr, packed_hi ptr, packed_lo ptr (0 = none), KH, KW, Cin, Cout, transpose_flip, first_block}; job j owns blocks
+ * [first_block_j, first_block_{j+1}) with ceil(packed_elems/2048) blocks each; total_blocks = their sum. */
+int hdrsky_conv_pack_weights_multi(const void* jobs, int njobs, int total_blocks, void* stream);
+
 /* Number of (sum,sumsq) tiles per sample this descriptor's launch writes to stats_part
  * ([B][nparts][2][Cout] fp32). [host] */
 int hdrsky_conv_stats_nparts(const hdrsky_conv_desc* d);

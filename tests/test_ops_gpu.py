@@ -129,7 +129,7 @@ def test_cam_plz_heads_rad_blend(dev):
     assert_close(gam.reshape(B, 1), gr, 1e-4, "gamma head"); assert_close(bet.reshape(B, 1), br, 1e-4, "beta head")
     p = {"x": None}
     xn = (cmf / cmf.max()).reshape(B, H, W, 1)
-    y = torch.exp(-torch.pow(1.0 - xn, 2.0) / (gam.cpu() + 1e-5)) * gam.cpu() / (bet.cpu() * 1.7724539 + 1e-5)
+    y = torch.exp(-torch.pow(1.0 - xn, 2.0) / (bet.cpu() + 1e-5)) * gam.cpu() / (bet.cpu() * 1.7724539 + 1e-5)
     y = torch.where(y > 30000.0, torch.full_like(y, 30000.0), y).repeat(1, 1, 1, 3)
     assert_close(lin, y, 1e-5, "sun_rad lin"); assert_close(gm, T.hdr_log_compression(y), 1e-5, "sun_rad gamma")
     # blend
