@@ -138,15 +138,25 @@ def main():
         # phase A: forward + both backward passes (gradients of this replica's batch-32 step);
         # between: sum the gradients over replicas (RCCL all-reduce; every loss is a batch mean, so the data-parallel
         #          gradient is the replica average: SURVEY.md section 8e); phase B: RMSprop x2 + weight re-packing.
-        phases = [lambda: tr.step(ldr, hdr, gt, update=False), lambda: tr.apply_gradients(gscale=1.0 / world)]
-
+        # A1: forward, losses, backward down to the sun-pose Dense gradients; A2: the rest of both backward passes;
+        # B: RMSprop x2 + weight re-packing.  N > 1: the all-reduce of the Dense-gradient slice (201 of the 233 MB)
+        # is started after A1 and runs on RCCL's stream while A2 computes; the remaining 32 MB follow A2.
+        phases = [lambda: tr.step_a1(ldr, hdr, gt), lambda: tr.step_a2(), lambda: tr.apply_gradients(gscale=1.0 / world)]
         par.broadcast_params_([tr.gs.flat, tr.ds.flat])   # replicas start from rank 0's weights
         tr.repack()
+        fc0, fc1 = tr.fc_grad_range()
+        pending = []
 
-        def between():
-            par.allreduce_sum_([tr.gs.grad, tr.ds.grad])
-        if world == 1:
-            between = None
+        def after_a1():
+            pending.append(dist.all_reduce(tr.gs.grad[fc0:fc1], async_op=True))
+
+        def after_a2():
+            pending.pop().wait()
+            dist.all_reduce(tr.gs.grad[:fc0])
+            dist.all_reduce(tr.ds.grad)
+        between = [after_a1, after_a2] if world > 1 else None
+        if world == 1:   # single GPU: the two parts are captured as one graph
+            phases = [lambda: tr.step(ldr, hdr, gt, update=False), lambda: tr.apply_gradients(gscale=1.0)]
         roof_pw, roof_b = tr.conv["gen.res.0.conv1"].pk, tr.gs.w["gen.res.0.conv1.b"]
         probe = lambda out: out["y_final_lin"]
 
@@ -155,11 +165,12 @@ def main():
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         for _ in range(2):
-            out = phases[0]()
-            if between:
-                between()
-            for ph in phases[1:]:
-                ph()
+            for i, ph in enumerate(phases):
+                o = ph()
+                if i == 0:
+                    out = o
+                if between and i < len(between):
+                    between[i]()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     runs = []
@@ -175,11 +186,10 @@ def main():
             runs.append(g.replay)
 
     def one_step():
-        runs[0]()
-        if between:
-            between()
-        for r in runs[1:]:
+        for i, r in enumerate(runs):
             r()
+            if between and i < len(between):
+                between[i]()
 
     for _ in range(args.warmup):
         one_step()

@@ -352,6 +352,21 @@ class Trainer:
     def step(self, ldr, hdr_t, sunpose_gt, update=True):
         """ldr / hdr_t [B,H,W,3] BGR (train.py:386-387 rgb2bgr already applied), sunpose_gt [B,H*W].
         Returns the dict generator_in_step returns (train.py:349) - losses are in self.losses (device)."""
+        out = self.step_a1(ldr, hdr_t, sunpose_gt)
+        self.step_a2()
+        if update:
+            self.apply_gradients()
+        return out
+
+    def fc_grad_range(self):
+        """[start, end) of the two Dense layers' gradients inside gs.grad - contiguous, the last trainables of the
+        sun-pose net (50.3 M of the 58.3 M parameters): the slice whose all-reduce overlaps step_a2."""
+        o = self.gs.offsets["sun.fc1.kernel"][0]
+        return o, self.gs.ntrain
+
+    def step_a1(self, ldr, hdr_t, sunpose_gt):
+        """Part 1: forward, losses, and the backward pass down to the gradients of the sun-pose Dense layers
+        (which are 86 % of the gradient bytes: the data-parallel driver starts their all-reduce right after this)."""
         w, g, c, cp = self.gs.w, self.gs.g, self.conv, self.compute
         B = ldr.shape[0]
         self.gs.grad.zero_(); self.ds.grad.zero_(); self.losses.zero_()
@@ -361,13 +376,10 @@ class Trainer:
         y_lin, y_gamma = S["y_lin"], S["y_gamma"]
 
         # Three independent chains run on three HIP streams (fork/join; captured as such in the hipGraph):
-        #   main : L1 + DoG + KL, then the generator backward
-        #   sA   : VGG16 perceptual forward/backward, later the sun-pose net backward
-        #   sB   : adversarial term (discriminator, inference-mode BN), then the whole discriminator step
+        #   main : L1 + DoG + KL            sA : VGG16 perceptual forward/backward
+        #   sB   : adversarial term (discriminator with inference-mode BN, train.py:302)
         main, sA, sB = torch.cuda.current_stream(), self.side_stream, self.side_stream2
         sA.wait_stream(main); sB.wait_stream(main)
-
-        # ---- generator losses + gradients wrt y_final_lin / y_final_gamma (train.py:301-331) ----------------
         dyl = torch.empty_like(y_lin)
         K.l1(y_lin, hdr_t, 1.0, 10.0, self.losses[3:4], da=dyl)                       # 10 * L1
         K.dog_loss(y_lin, hdr_t, 1000.0, self.losses[2:3], dyl)                       # 1000 * DoG
@@ -376,20 +388,44 @@ class Trainer:
             dyg = self._vgg_loss_and_grad(y_gamma, hdr_t)                              # 0.01 * perceptual
         cvo = c["dis.out"]
         with torch.cuda.stream(sB):
-            # adversarial term: discriminator in inference mode (train.py:302)
             Rg = self._down_stack("dis.", self.ds.w, K.concat2(ldr, y_lin), training=False)
             logits, _ = cvo.fwd(Rg["d4"]["raw"], Rg["xf_out"], cp)
             dlog = K.mse(logits, 1.0, 1.0, 1.0, self.losses[4:5])
             dact4 = cvo.dgrad(Rg["d4"]["raw"], dlog, cp)
             din = self._down_stack_bwd("dis.", self.ds.w, None, Rg, dact4, training=False, want_input_grad=True, do_wgrad=False)
             d_adv = K.slice_channels(din, 3, 3, 1.0)
-        main.wait_stream(sB)   # d_adv ready; sB carries on with the discriminator step
-        main.wait_stream(sA)   # dyg ready
+        main.wait_stream(sB); main.wait_stream(sA)
         K.axpby(dyl, 1.0, d_adv, 1.0, out=dyl)
 
-        # ---- discriminator step (train.py:351-380): real then generated, BN batch statistics -------------------
-        # (its forward passes read the PRE-update generator output; its moving stats update after the generator
-        #  step's inference-mode call above, as in the reference's program order)
+        # generator backward, first stretch: blend -> decoder tails -> sun radiance head -> dcmf complete
+        dsky, dsun = K.blend_bwd(y_gamma, S["alpha"], dyg, dyl)
+        tails = {}
+        for sfx, dy in (("f", dsky), ("u", dsun)):
+            y, residual = S["dec_" + sfx][6], S["dec_" + sfx][7]
+            tails[sfx] = K.decoder_tail_bwd(y, residual, dy, want_dres=(sfx == "u"))
+        dpre = K.sun_rad_bwd(t["cmf"], t["gmax"], S["gamma"], S["beta"], tails["u"][1], dcmf)
+        # sun-pose Dense layers (sunpose_net.py:64-70): KL + the sun-radiance path meet in dcmf
+        dz = K.softmax_bwd(t["cmf"], dcmf, t["z"])
+        K.fc_wgrad(t["f1"], dz, g["sun.fc2.kernel"], g["sun.fc2.bias"])
+        df1 = K.fc_finalize(K.fc_dgrad(dz, self.fc2, cp), None, relu=False, mask_src=t["f1"])
+        K.fc_wgrad(t["flat"], df1, g["sun.fc1.kernel"], g["sun.fc1.bias"])
+        dP3 = K.fc_finalize(K.fc_dgrad(df1, self.fc1, cp)).reshape(B, self.h // 8, self.w // 8, 128)
+        self._S = dict(S=S, tails=tails, dpre=dpre, dP3=dP3, ldr=ldr, hdr_t=hdr_t)
+        return dict(y_final_lin=y_lin, y_final_gamma=y_gamma, sky_pred_lin=S["sky_lin"], sun_pred_lin=S["sun_lin"],
+                    gamma=S["gamma"], beta=S["beta"], alpha_c3=S["alpha"], sunpose_cmf=t["cmf"], sun_cam1=S["cams"][0],
+                    sun_cam2=S["cams"][1], sun_cam3=S["cams"][2], sun_rad_lin=S["rad_lin"])
+
+    def step_a2(self):
+        """Part 2: everything else - discriminator step (sB), sun-pose conv layers backward (sA), generator backward
+        (main).  The three chains write disjoint gradient ranges."""
+        w, g, c, cp = self.gs.w, self.gs.g, self.conv, self.compute
+        S, tails, dpre, dP, ldr, hdr_t = (self._S[k] for k in ("S", "tails", "dpre", "dP3", "ldr", "hdr_t"))
+        t, y_lin = S["t"], S["y_lin"]
+        main, sA, sB = torch.cuda.current_stream(), self.side_stream, self.side_stream2
+        sA.wait_stream(main); sB.wait_stream(main)
+        cvo = c["dis.out"]
+        # ---- discriminator step (train.py:351-380): real then generated, BN batch statistics (their moving-stat
+        # updates come after the generator step's inference-mode call of part 1, as in the reference's program order)
         with torch.cuda.stream(sB):
             for which, img, target, slot in (("real", hdr_t, 1.0, 6), ("fake", y_lin, 0.0, 5)):
                 Rd = self._down_stack("dis.", self.ds.w, K.concat2(ldr, img), training=True)
@@ -398,39 +434,8 @@ class Trainer:
                 self._wg("dis.out", Rd["d4"]["raw"], Rd["xf_out"], dl)
                 da4 = cvo.dgrad(Rd["d4"]["raw"], dl, cp)
                 self._down_stack_bwd("dis.", self.ds.w, self.ds.g, Rd, da4, training=True, want_input_grad=False)
-
-        # ---- generator backward ---------------------------------------------------------------------------------
-        dsky, dsun = K.blend_bwd(y_gamma, S["alpha"], dyg, dyl)
-        dres = torch.zeros_like(S["x"][-1])
-        drg = None
-        for sfx, dy in (("f", dsky), ("u", dsun)):
-            d3, s3, xf2, d2, s2, xf1, y, residual = S["dec_" + sfx]
-            dc, dr = K.decoder_tail_bwd(y, residual, dy, want_dres=(sfx == "u"))
-            if sfx == "u":
-                drg = dr
-            self._wg("gen.conv1_" + sfx, d2, xf1, dc)
-            da2 = c["gen.conv1_" + sfx].dgrad(d2, dc, cp)
-            dd2 = self._in_bwd(d2, s2, "gen.norm2_" + sfx, 0.1, da2)
-            self._wg("gen.conv2_" + sfx, d3, xf2, dd2)
-            da3 = c["gen.conv2_" + sfx].dgrad(d3, dd2, cp)
-            dd3 = self._in_bwd(d3, s3, "gen.norm3_" + sfx, 0.1, da3)
-            self._wg("gen.conv3_" + sfx, S["x"][-1], None, dd3)
-            c["gen.conv3_" + sfx].dgrad(S["x"][-1], dd3, cp, out=dres)
-        # sun radiance head (generator.py:158-169, sunrad_net.py:46-70)
-        R = S["sunrad"]
-        dpre = K.sun_rad_bwd(t["cmf"], t["gmax"], S["gamma"], S["beta"], drg, dcmf)
-        xf = R["xf_out"]
-        dact4 = K.dense_heads_bwd(R["d4"]["raw"], xf.scale, xf.shift, 0.3, w["gen.sun.gamma.kernel"], w["gen.sun.beta.kernel"],
-                                  dpre, g["gen.sun.gamma.kernel"], g["gen.sun.beta.kernel"], g["gen.sun.gamma.bias"],
-                                  g["gen.sun.beta.bias"])
-        sA.wait_stream(main)   # dcmf now holds KL + sun-radiance contributions
+        # ---- sun-pose conv layers (sunpose_net.py:54-62) --------------------------------------------------------
         with torch.cuda.stream(sA):
-            # sun-pose net: KL + the sun-radiance path meet in dcmf (sunpose_net.py:54-72)
-            dz = K.softmax_bwd(t["cmf"], dcmf, t["z"])
-            K.fc_wgrad(t["f1"], dz, g["sun.fc2.kernel"], g["sun.fc2.bias"])
-            df1 = K.fc_finalize(K.fc_dgrad(dz, self.fc2, cp), None, relu=False, mask_src=t["f1"])
-            K.fc_wgrad(t["flat"], df1, g["sun.fc1.kernel"], g["sun.fc1.bias"])
-            dP = K.fc_finalize(K.fc_dgrad(df1, self.fc1, cp)).reshape(B, self.h // 8, self.w // 8, 128)
             for l in (3, 2, 1):
                 n = "sun.sunlayer%d" % l
                 dr2 = self._in_bwd(t["r%db" % l], t["st%db" % l], n + ".norm2", 0.0, dP, pooled=True)
@@ -440,9 +445,26 @@ class Trainer:
                 self._wg(n + ".conv1", t["in%d" % l], None, dr1)
                 if l > 1:
                     dP = c[n + ".conv1"].dgrad(t["in%d" % l], dr1, cp)
+        # ---- generator: decoders, sun radiance stack, encoder -----------------------------------------------------
+        dres = torch.zeros_like(S["x"][-1])
+        for sfx in ("f", "u"):
+            d3, s3, xf2, d2, s2, xf1, y, residual = S["dec_" + sfx]
+            dc = tails[sfx][0]
+            self._wg("gen.conv1_" + sfx, d2, xf1, dc)
+            da2 = c["gen.conv1_" + sfx].dgrad(d2, dc, cp)
+            dd2 = self._in_bwd(d2, s2, "gen.norm2_" + sfx, 0.1, da2)
+            self._wg("gen.conv2_" + sfx, d3, xf2, dd2)
+            da3 = c["gen.conv2_" + sfx].dgrad(d3, dd2, cp)
+            dd3 = self._in_bwd(d3, s3, "gen.norm3_" + sfx, 0.1, da3)
+            self._wg("gen.conv3_" + sfx, S["x"][-1], None, dd3)
+            c["gen.conv3_" + sfx].dgrad(S["x"][-1], dd3, cp, out=dres)
+        R = S["sunrad"]    # sun radiance head (generator.py:158-169, sunrad_net.py:46-70)
+        xf = R["xf_out"]
+        dact4 = K.dense_heads_bwd(R["d4"]["raw"], xf.scale, xf.shift, 0.3, w["gen.sun.gamma.kernel"], w["gen.sun.beta.kernel"],
+                                  dpre, g["gen.sun.gamma.kernel"], g["gen.sun.beta.kernel"], g["gen.sun.gamma.bias"],
+                                  g["gen.sun.beta.bias"])
         self._down_stack_bwd("gen.sun.", w, g, R, dact4, training=True, want_input_grad=False)
-        # encoder (generator.py:92-108, resBlock :26-35)
-        dx = dres
+        dx = dres          # encoder (generator.py:92-108, resBlock :26-35)
         for i in range(5, -1, -1):
             p = "gen.res.%d." % i
             r1, t1, xf, r2, t2 = S["res%d" % i]
@@ -460,14 +482,7 @@ class Trainer:
         da1 = c["gen.conv2_d"].dgrad(S["c1"], dc2, cp)
         dc1 = self._in_bwd(S["c1"], S["s1"], "gen.norm1_d", 0.1, da1)
         self._wg("gen.conv1_d", ldr, None, dc1)
-
         main.wait_stream(sA); main.wait_stream(sB)
-
-        if update:
-            self.apply_gradients()
-        return dict(y_final_lin=y_lin, y_final_gamma=y_gamma, sky_pred_lin=S["sky_lin"], sun_pred_lin=S["sun_lin"],
-                    gamma=S["gamma"], beta=S["beta"], alpha_c3=S["alpha"], sunpose_cmf=t["cmf"], sun_cam1=S["cams"][0],
-                    sun_cam2=S["cams"][1], sun_cam3=S["cams"][2], sun_rad_lin=S["rad_lin"])
 
     def apply_gradients(self, gscale=1.0):
         """optimizer_gen / optimizer_disc .apply_gradients (train.py:403,406): RMSprop(lr), then refresh the packed
