@@ -65,9 +65,14 @@ def dominant_kernel_roofline(torch, K, pw, bias, batch, h, w, iters=200):
     us = e0.elapsed_time(e1) * 1e3 / iters
     flop = 2.0 * (batch * (h // 4) * (w // 4)) * (9 * 128) * 128
     achieved = flop / (us * 1e-6) / 1e12
+    traffic = None   # HBM-side bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE)
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_resconv.json")
+    if batch == 32 and os.path.exists(pmc):
+        with open(pmc) as f:
+            traffic = json.load(f).get("hbm_bytes_per_launch")
     return {"bound": "mfma", "kernel": "conv_igemm_kernel (res-block 3x3 128->128, B=%d)" % batch,
             "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / MFMA_PEAK_TFLOPS, 5), "traffic": None,
+            "frac": round(achieved / MFMA_PEAK_TFLOPS, 5), "traffic": traffic,
             "avg_launch_us": round(us, 3), "flop_per_launch": flop}
 
 
