@@ -108,13 +108,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # HDRSKY_BENCH_FORCE_DP=1 runs the N>1 code path (process group, phase split, overlapped all-reduces) with a
+    # single rank, so that path can be rehearsed on a one-GPU box.
+    dp = world > 1 or os.environ.get("HDRSKY_BENCH_FORCE_DP", "0") == "1"
+    if dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     else:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local if world > 1 else 0)
+    dev = torch.device("cuda", local if dp else 0)
 
     params = importlib.import_module(PKG + ".params")
     synth = importlib.import_module(PKG + ".synth")
@@ -159,8 +163,8 @@ def main():
             pending.pop().wait()
             dist.all_reduce(tr.gs.grad[:fc0])
             dist.all_reduce(tr.ds.grad)
-        between = [after_a1, after_a2] if world > 1 else None
-        if world == 1:   # single GPU: the two parts are captured as one graph
+        between = [after_a1, after_a2] if dp else None
+        if not dp:   # single GPU: the two parts are captured as one graph
             phases = [lambda: tr.step(ldr, hdr, gt, update=False), lambda: tr.apply_gradients(gscale=1.0)]
         roof_pw, roof_b = tr.conv["gen.res.0.conv1"].pk, tr.gs.w["gen.res.0.conv1.b"]
         probe = lambda out: out["y_final_lin"]
@@ -184,7 +188,8 @@ def main():
     else:
         for i, ph in enumerate(phases):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread_local: RCCL's watchdog thread may query events while this thread captures
+            with torch.cuda.graph(g, capture_error_mode="thread_local" if dp else "global"):
                 o = ph()
             if i == 0:
                 out = o
@@ -199,18 +204,18 @@ def main():
     for _ in range(args.warmup):
         one_step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dp:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dp:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dp:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -241,7 +246,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(torch, args.workload, (gen, sun, dis, vgg), batch_np)
         print(json.dumps(res))
-    if world > 1:
+    if dp:
         dist.barrier()
         dist.destroy_process_group()
 
