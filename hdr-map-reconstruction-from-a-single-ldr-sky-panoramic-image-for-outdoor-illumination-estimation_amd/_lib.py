@@ -55,6 +55,7 @@ SIGNATURES = {
     "hdrsky_sun_rad": (c_int, [P, P, P, c_int, P, P, c_int, c_int, P, P, P, P, P]),
     "hdrsky_blend": (c_int, [P, P, c_int, c_float, P, P, P, P, P, P]),
     "hdrsky_tonemap": (c_int, [P, P, c_size_t, c_int, P]),
+    "hdrsky_leaky_relu": (c_int, [P, P, c_size_t, c_float, P]),
     "hdrsky_da_offsets": (c_int, [c_int, c_int, c_int, c_int, c_int, P]),
     "hdrsky_da_conv2d_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     "hdrsky_bn_train_finalize": (c_int, [P, c_int, c_int, c_int, P, P, c_float, c_float, P, P, P, P, P, P, P]),

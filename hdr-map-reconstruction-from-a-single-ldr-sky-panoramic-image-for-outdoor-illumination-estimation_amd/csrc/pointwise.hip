@@ -553,6 +553,14 @@ __global__ void tonemap_kernel(const float* __restrict__ x, float* __restrict__ 
   }
 }
 
+// ops.relu (ops.py:324-329) / LeakyReLU as a standalone layer: y = x > 0 ? x : slope * x
+__global__ void leaky_relu_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, float slope) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    y[i] = v > 0.f ? v : slope * v;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -683,6 +691,14 @@ int hdrsky_tonemap(const float* x, float* y, size_t n, int decompress, void* str
   if (!x || !y) return HDRSKY_EINVAL;
   size_t g = (n + 255) / 256; if (g > 2048) g = 2048; if (g < 1) g = 1;
   hipLaunchKernelGGL(tonemap_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, y, n, decompress);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_leaky_relu(const float* x, float* y, size_t n, float slope, void* stream) {
+  if (!x || !y) return HDRSKY_EINVAL;
+  size_t g = (n + 255) / 256; if (g > 2048) g = 2048; if (g < 1) g = 1;
+  hipLaunchKernelGGL(leaky_relu_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, y, n, slope);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }

@@ -36,8 +36,9 @@ class Nets:
         self.device = torch.device(device)
         self.h, self.w = im_height, im_width
         self.precise = precise
-        self.gen = _dev(gen_params, self.device)
-        self.sun = _dev(sun_params, self.device)
+        # either network may be absent (the layer-API mirrors own one network each)
+        self.gen = _dev(gen_params, self.device) if gen_params is not None else None
+        self.sun = _dev(sun_params, self.device) if sun_params is not None else None
         self.pk = {}
         self.side_stream = torch.cuda.Stream(device=self.device)
         self.repack_all()
@@ -45,22 +46,24 @@ class Nets:
     def repack_all(self):
         g, s = self.gen, self.sun
         pk = self.pk
-        for name in ["conv1_d", "conv2_d", "conv3_d", "conv1_f", "conv1_u"] + \
-                    ["res.%d.conv%d" % (i, j) for i in range(6) for j in (1, 2)]:
+        for name in (["conv1_d", "conv2_d", "conv3_d", "conv1_f", "conv1_u"] +
+                     ["res.%d.conv%d" % (i, j) for i in range(6) for j in (1, 2)]) if g is not None else ():
             pk["gen." + name] = PackedConv(g[name + ".w"], self.precise)
-        for name in ("conv3_f", "conv2_f", "conv3_u", "conv2_u"):
+        for name in ("conv3_f", "conv2_f", "conv3_u", "conv2_u") if g is not None else ():
             pk["gen." + name] = PackedConv(g[name + ".kernel_deconv2d"], self.precise)
-        for d in ("d1", "d2", "d3", "d4"):
+        for d in ("d1", "d2", "d3", "d4") if g is not None else ():
             pk["gen.sun." + d] = PackedConv(g["sun.%s.conv.kernel" % d], self.precise)
-        for l in (1, 2, 3):
+        for l in (1, 2, 3) if s is not None else ():
             for c in (1, 2):
                 name = "sunlayer%d.conv%d" % (l, c)
                 pk["sun." + name] = PackedConv(s[name + ".w"], self.precise)
                 if not (l == 1):  # Grad-CAM sweep needs dgrad of layers 2..3 (all four convs)
                     pk["sun." + name + ".T"] = PackedConv(s[name + ".w"], self.precise, transpose_flip=True)
-        pk["sun.fc1"] = PackedFC(s["fc1.kernel"], self.precise)
-        pk["sun.fc2"] = PackedFC(s["fc2.kernel"], self.precise)
-        self.refresh_eval_tables()
+        if s is not None:
+            pk["sun.fc1"] = PackedFC(s["fc1.kernel"], self.precise)
+            pk["sun.fc2"] = PackedFC(s["fc2.kernel"], self.precise)
+        if g is not None:
+            self.refresh_eval_tables()
 
     def refresh_eval_tables(self):
         """Inference-mode BatchNorm of sunRadNet as per-channel affines (recompute after the moving stats change)."""
@@ -156,17 +159,36 @@ def decode(nets, res_out, sfx, residual, compute):
     return y
 
 
-def sun_rad_estimation(nets, ldr, cams, t, compute):
-    """generator.model.sun_rad_estimation + sunRadNet in inference mode (generator.py:158-169,
-    sunrad_net.py:46-70): BN layers use their moving statistics."""
+def down_stack(x, pk, p, prefix, compute, training=False, bn_eval=None):
+    """downsampling x4 (sunrad_net.py:21-28 == discriminator.py:20-27): 4x4 convs without bias, d1 without norm,
+    LeakyReLU(0.3).  Returns the RAW d4 output and the (scale, shift) affine of its BatchNorm; the caller's kernel
+    applies affine + LeakyReLU while loading.  training=True: batch statistics and the moving-average update
+    (momentum 0.99); training=False: moving statistics."""
+    B = x.shape[0]
+    x, _ = K.conv2d(x, pk[prefix + "d1"], None, stride=2, out_slope=0.3, compute=compute)
+    xf = None
+    for d in ("d2", "d3", "d4"):
+        x, st = K.conv2d(x, pk[prefix + d], None, stride=(1 if d == "d4" else 2), xf=xf, compute=compute,
+                         want_stats=training)
+        n = "%s.norm." % d
+        if training:
+            _, _, sc, sh = K.bn_train_finalize(st, p[n + "gamma"], p[n + "beta"], B, x.shape[-1], p[n + "moving_mean"],
+                                               p[n + "moving_variance"])
+        elif bn_eval is not None:
+            sc, sh = bn_eval[d]
+        else:
+            sc, sh = K.bn_eval_affine(p[n + "gamma"], p[n + "beta"], p[n + "moving_mean"], p[n + "moving_variance"])
+        xf = InXf(mode=L.IN_AFFINE, slope=0.3, scale=sc, shift=sh)
+    return x, xf
+
+
+def sun_rad_estimation(nets, ldr, cams, t, compute, training=False):
+    """generator.model.sun_rad_estimation + sunRadNet (generator.py:158-169, sunrad_net.py:46-70); inference mode
+    (BN moving statistics) unless training=True."""
     g, pk = nets.gen, nets.pk
     plz = K.plz_build(ldr, *cams)
-    d1, _ = K.conv2d(plz, pk["gen.sun.d1"], None, stride=2, out_slope=0.3, compute=compute)
-    x, xf = d1, None
-    for d in ("d2", "d3", "d4"):
-        x, _ = K.conv2d(x, pk["gen.sun." + d], None, stride=(1 if d == "d4" else 2), xf=xf, compute=compute)
-        sc, sh = nets.bn_eval[d]
-        xf = InXf(mode=L.IN_AFFINE, slope=0.3, scale=sc, shift=sh)
+    sunp = OrderedDict((k[4:], v) for k, v in g.items() if k.startswith("sun."))
+    x, xf = down_stack(plz, pk, sunp, "gen.sun.", compute, training, None if training else nets.bn_eval)
     part = K.dense_heads(x, xf.scale, xf.shift, 0.3, g["sun.gamma.kernel"], g["sun.beta.kernel"])
     rad_lin, rad_gamma, gamma, beta = K.sun_rad(t["cmf"], t["gmax"], part, g["sun.gamma.bias"], g["sun.beta.bias"],
                                                 nets.h, nets.w)

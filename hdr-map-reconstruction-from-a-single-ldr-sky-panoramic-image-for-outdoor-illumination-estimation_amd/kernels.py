@@ -404,6 +404,14 @@ def tonemap(x, decompress):
 # ------------------------------------------------------------------------------------------------
 # training-step front ends (csrc/train_ops.hip, csrc/conv_wgrad.hip)
 # ------------------------------------------------------------------------------------------------
+def leaky_relu(x, slope=0.0):
+    """ops.relu (ops.py:324-329) for slope 0; LeakyReLU otherwise."""
+    x = _f32(x)
+    y = torch.empty_like(x)
+    L.check(L.load().hdrsky_leaky_relu(_p(x), _p(y), x.numel(), float(slope), _stream()), "leaky_relu")
+    return y
+
+
 def conv_dgrad_desc(fwd):
     d = L.ConvDesc()
     L.check(L.load().hdrsky_conv_desc_init_dgrad(d, fwd), "conv_desc_init_dgrad")

@@ -187,6 +187,8 @@ int hdrsky_blend(const float* sky_gamma, const float* sun_gamma, int npix, float
                  float* alpha, float* sky_lin, float* sun_lin, void* stream);
 /* tf_utils.hdr_logCompression (decompress=0) / hdr_logDecompression (1)  (tf_utils.py:263-280) */
 int hdrsky_tonemap(const float* x, float* y, size_t n, int decompress, void* stream);
+/* ops.relu (ops.py:324-329; slope 0) and stand-alone LeakyReLU layers: y = x > 0 ? x : slope * x. */
+int hdrsky_leaky_relu(const float* x, float* y, size_t n, float slope, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Training-step kernels (train.py:382-415)
