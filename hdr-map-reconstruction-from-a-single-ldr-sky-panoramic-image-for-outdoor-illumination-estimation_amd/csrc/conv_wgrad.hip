@@ -11,6 +11,9 @@
 // then just a ROW offset of the X tile, always 8-byte aligned.
 // One workgroup owns a [taps x CB x OB] block of dW, walks `tiles_per_wg` output-pixel tiles accumulating in
 // registers (each wave a subset of the taps), and adds its block to dW with fp32 atomics (dW zeroed by the caller).
+#include <cstdio>
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -35,6 +38,7 @@ struct WgradArgs {
   int HT, WT, NPIX, wt_magic, kw_magic, ntaps;
   int RX, RY;                    // LDS row strides (bytes) of the X / dY tiles
   int off_xlo, off_y, off_ylo, off_ss, off_red;
+  int wg_target;                 // tuning hook (HDRSKY_WGRAD): workgroups to aim for, 0 = default
 };
 
 __device__ __forceinline__ uint2 lds_tr(const unsigned char* p) {
@@ -285,6 +289,7 @@ int launch_wgrad(WgradArgs& a, hipStream_t stream) {
   a.kw_magic = (65536 + a.KW - 1) / a.KW;
   a.ntaps = a.KH * a.KW;
   if (cdiv(a.ntaps, 4) > TPW) return HDRSKY_EUNSUPPORTED;
+  if (!NARROW && (a.Cin % CB) != 0) return HDRSKY_EUNSUPPORTED;   // the X staging reads whole CB-channel blocks
   a.RX = CB * 2 + 16;
   a.RY = OB * 2 + 16;
   const int planes = PRECISE ? 2 : 1;
@@ -298,7 +303,7 @@ int launch_wgrad(WgradArgs& a, hipStream_t stream) {
   if (lds > 160 * 1024) return HDRSKY_EUNSUPPORTED;
   // enough workgroups to fill the chip, few enough that the atomic traffic (one dW block per workgroup) stays small
   const int nblk = a.cblocks * a.oblocks;
-  int chunks = cdiv(128, nblk);
+  int chunks = cdiv(a.wg_target > 0 ? a.wg_target : 128, nblk);
   if (chunks > a.ntiles) chunks = a.ntiles;
   a.tiles_per_wg = cdiv(a.ntiles, chunks);
   chunks = cdiv(a.ntiles, a.tiles_per_wg);
@@ -355,25 +360,31 @@ extern "C" int hdrsky_conv2d_wgrad(const hdrsky_conv_desc* d, const float* x, co
   a.in_eps = d->in_eps; a.in_inv_count = 1.f / (float)(d->H * d->W); a.in_slope = d->in_slope;
   const int ntaps = d->KH * d->KW;
   const int tpw = ntaps <= 12 ? (ntaps <= 9 ? 3 : 4) : (ntaps <= 16 ? 4 : 13);
+  // dW block per workgroup, measured per layer shape (profiles/microbench_wgrad.py): 32x32-channel blocks and
+  // ~256 workgroups beat larger blocks - the kernel is bound by staging latency and atomic traffic, not by MFMA
   int cbf, obf;
-  if (narrow) cbf = 1;
-  else cbf = d->Cin >= 64 ? 4 : 2;
-  obf = d->Cout >= 64 ? 4 : (d->Cout >= 32 ? 2 : 1);
-  // register budget: TPW*CBF*OBF accumulator fragments per wave
-  if (tpw == 13) { if (cbf > 2) cbf = 2; if (obf > 2) obf = 2; }
-  if (tpw == 4 && !narrow) { if (obf > 2) obf = 2; if (cbf == 2 && obf == 1) obf = 2; }
-  if (tpw == 3 && !narrow && obf == 1) obf = 2;
-  const int tw = d->Wo >= 32 ? 32 : 16;
+  if (narrow) { cbf = 1; obf = d->Cout >= 64 ? 4 : (d->Cout >= 32 ? 2 : 1); }
+  else { cbf = 2; obf = (tpw == 13 || d->Cout < 32) ? 1 : 2; }
+  if (tpw == 13 && obf > 2) obf = 2;               // register budget: TPW*CBF*OBF accumulator fragments per wave
+  if (tpw != 13 && !narrow && obf == 1) obf = 2;
+  a.wg_target = 256;
+  int tw = d->Wo >= 32 ? 32 : 16;
+  if (const char* e = getenv("HDRSKY_WGRAD")) {   // tuning hook: "cbf,obf,tw,workgroups"
+    int c = 0, o = 0, t = 0, g = 0;
+    if (sscanf(e, "%d,%d,%d,%d", &c, &o, &t, &g) >= 3) {
+      if (c > 0 && !narrow) cbf = c;
+      if (o > 0) obf = o;
+      if (t > 0) tw = t;
+      a.wg_target = g;
+    }
+  }
   hipStream_t s = (hipStream_t)stream;
   const bool precise = d->compute == HDRSKY_BF16X3;
   {  // LDS budget: a strided halo tile with 64 channels (x2 planes in BF16X3) can exceed 160 KB -> 32-channel blocks
-    const int th = 128 / tw;
+    const int th = 128 / tw;   // (hook-forced shapes that do not fit return EUNSUPPORTED from the launcher)
     const int npix = ((th - 1) * d->stride + d->KH) * ((tw - 1) * d->stride + d->KW);
     const int planes = precise ? 2 : 1;
-    if (!narrow && cbf == 4 && planes * (npix * (64 * 2 + 16) + 128 * (obf * 32 + 16)) > 150 * 1024) {
-      cbf = 2;
-      if (tpw == 4 && obf == 1) obf = 2;
-    }
+    if (!narrow && cbf == 4 && planes * (npix * (64 * 2 + 16) + 128 * (obf * 32 + 16)) > 150 * 1024) cbf = 2;
   }
   if (narrow) return precise ? dispatch_wgrad<true, true>(a, tpw, cbf, obf, tw, s) : dispatch_wgrad<true, false>(a, tpw, cbf, obf, tw, s);
   return precise ? dispatch_wgrad<false, true>(a, tpw, cbf, obf, tw, s) : dispatch_wgrad<false, false>(a, tpw, cbf, obf, tw, s);
