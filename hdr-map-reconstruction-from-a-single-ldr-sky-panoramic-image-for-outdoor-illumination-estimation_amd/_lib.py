@@ -26,6 +26,14 @@ class ConvDesc(ctypes.Structure):
 
 
 P = c_void_p
+
+
+class WgradJob(ctypes.Structure):
+    """Mirror of ``hdrsky_wgrad_job`` (include/hdrsky.h)."""
+    _fields_ = [("desc", ConvDesc)] + [(n, c_void_p) for n in
+                                       ("x", "dy", "in_scale", "in_shift", "in_part", "in_gamma", "in_beta", "dw", "db")]
+
+
 # name -> (restype, argtypes); every symbol include/hdrsky.h declares
 SIGNATURES = {
     "hdrsky_version": (ctypes.c_char_p, []),
@@ -37,10 +45,12 @@ SIGNATURES = {
     "hdrsky_conv_stats_nparts": (c_int, [ctypes.POINTER(ConvDesc)]),
     "hdrsky_conv2d_fwd": (c_int, [ctypes.POINTER(ConvDesc)] + [P] * 13),
     "hdrsky_conv2d_wgrad": (c_int, [ctypes.POINTER(ConvDesc)] + [P] * 10),
+    "hdrsky_conv2d_wgrad_multi": (c_int, [ctypes.POINTER(WgradJob), c_int, P]),
     "hdrsky_norm_apply": (c_int, [P, P, c_int, P, P, c_float, c_float, P, P, P, c_int, c_int, c_int, c_int, P]),
     "hdrsky_in_finalize": (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_float, P, P, P, P, P]),
     "hdrsky_bn_eval_affine": (c_int, [P, P, P, P, c_float, c_int, P, P, P]),
-    "hdrsky_norm_act_bwd": (c_int, [P, P, c_int, P, P, c_float, c_float, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "hdrsky_norm_act_bwd": (c_int, [P, P, c_int, P, P, c_float, c_float, P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "hdrsky_norm_act_bwd_nslices": (c_int, [c_int] * 5),
     "hdrsky_fc_pack_weights": (c_int, [P, c_int, c_int, P, P, P, P, P]),
     "hdrsky_fc_nsplit": (c_int, [c_int]),
     "hdrsky_fc_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),

@@ -38,181 +38,300 @@ struct WgradArgs {
   int HT, WT, NPIX, wt_magic, kw_magic, ntaps;
   int RX, RY;                    // LDS row strides (bytes) of the X / dY tiles
   int off_xlo, off_y, off_ylo, off_ss, off_red;
-  int wg_target;                 // tuning hook (HDRSKY_WGRAD): workgroups to aim for, 0 = default
+  int nchunks;                   // pixel split of this job
+  int dbg;
 };
+
+constexpr int WG_MAXJ = 12;      // jobs per launch (the argument block must stay below 4 KB)
+struct MultiArgs {
+  int njobs;
+  int first[WG_MAXJ + 1];        // first block of each job (prefix sums), first[njobs] = grid size
+  WgradArgs job[WG_MAXJ];
+};
+static_assert(sizeof(MultiArgs) <= 4096, "kernel argument block");
 
 __device__ __forceinline__ uint2 lds_tr(const unsigned char* p) {
   const s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
   return __builtin_bit_cast(uint2, v);
 }
 
-template <int TPW, int CBF, int OBF, int TW, bool NARROW, bool PRECISE, int NW>
-__global__ void __launch_bounds__(NW * 64) conv_wgrad_kernel(const WgradArgs a) {
-  constexpr int CB = CBF * 16, OB = OBF * 16;
+// One launch serves up to WG_MAXJ independent layers ("jobs", passed by value in the kernel argument block): a
+// training step has ~40 conv layers whose weight gradients are mutually independent and individually far too small
+// for 256 CUs - launched one by one each needs a deep pixel split (fp32 atomic traffic = split x |dW|, ~1 TB/s
+// chip-wide) to fill the chip; launched together they fill it with a shallow split and large dW blocks.
+// Geometry (template): NW waves = NTG tap groups x CS splits of the ci fragments x OS splits of the co fragments;
+// the staging phase (global -> registers -> transform -> bf16 -> LDS) is issue-bound VALU work shared by all
+// NW*64 threads.  XR: rows of the X' register prefetch array (items per thread; UP: 4 source pixels per item).
+// UP: the forward conv resized its input 2x (resize-deconv): an X' item is interpolated from four source pixels.
+template <int TPW, int CBF, int OBF, int TW, bool NARROW, bool PRECISE, bool UP, int NW, int CS, int OS, int XR>
+__global__ void __launch_bounds__(NW * 64) conv_wgrad_kernel(const MultiArgs m) {
   constexpr int NT = NW * 64;
-  constexpr int CBH = (NW == 8) ? CBF / 2 : CBF;   // 8 waves: 4 tap groups x 2 halves of the ci fragments
-  static_assert(NW == 4 || (NW == 8 && (CBF % 2) == 0), "8-wave variant needs an even number of ci fragments");
-  constexpr int BM = 128, TH = BM / TW;      // output pixels per tile (4 k-steps of 32)
+  constexpr int CB = CBF * 16, OB = OBF * 16;
+  static_assert(CBF % CS == 0 && OBF % OS == 0 && NW % (CS * OS) == 0, "wave roles");
+  constexpr int CBH = CBF / CS, OBH = OBF / OS;    // fragments per wave
+  constexpr int NTG = NW / (CS * OS);              // tap groups
+  constexpr int BM = 128, TH = BM / TW;            // output pixels per tile (4 k-steps of 32)
+  constexpr int NQX = CB / 8, NQY = OB / 8;        // 8-channel groups per staged pixel
+  constexpr int XI = UP ? XR / 4 : XR;             // X' items per thread and tile
+  int job = 0;
+  while (job + 1 < m.njobs && (int)blockIdx.x >= m.first[job + 1]) ++job;
+  const WgradArgs& a = m.job[job];
+  const int bid = blockIdx.x - m.first[job];
+  constexpr int YMAX = (BM * NQY + NT - 1) / NT;   // dY items per thread and tile
+  static_assert(NT % NQY == 0, "a thread must always stage the same 8 output channels (bias partial sums)");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sX = smem;
   unsigned char* sXl = smem + a.off_xlo;
   unsigned char* sY = smem + a.off_y;
   unsigned char* sYl = smem + a.off_ylo;
-  float* sScale = reinterpret_cast<float*>(smem + a.off_ss);
-  float* sShift = sScale + CB;
+  float* sTab = reinterpret_cast<float*>(smem + a.off_ss);   // [sample of this workgroup][scale CB | shift CB]
   float* sRed = reinterpret_cast<float*>(smem + a.off_red);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3, kq = g, lr = lane & 15;
   const int nblk = a.cblocks * a.oblocks;
-  const int blk = blockIdx.x % nblk, chunk = blockIdx.x / nblk;
+  const int blk = bid % nblk, chunk = bid / nblk;
   const int cb0 = (blk / a.oblocks) * CB, ob0 = (blk % a.oblocks) * OB;
   const float slope = a.in_slope;
+  const bool xform = a.in_mode != HDRSKY_IN_NONE || slope != 1.f;
 
-  const int tgrp = wave & 3;                        // tap group of this wave
-  const int cih = (NW == 8) ? (wave >> 2) * CBH : 0;  // first ci fragment of this wave
-  f32x4_t acc[TPW][CBH][OBF];
+  const int tgrp = wave % NTG;                           // tap group of this wave
+  const int cih = ((wave / NTG) % CS) * CBH;             // first ci fragment of this wave
+  const int ojh = ((wave / NTG) / CS) * OBH;             // first co fragment of this wave
+  f32x4_t acc[TPW][CBH][OBH];
 #pragma unroll
   for (int t = 0; t < TPW; ++t)
 #pragma unroll
     for (int i = 0; i < CBH; ++i)
 #pragma unroll
-      for (int j = 0; j < OBF; ++j) acc[t][i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < OBH; ++j) acc[t][i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   float bsum[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
 
   const int tile0 = chunk * a.tiles_per_wg;
   const int tile1 = min(a.ntiles, tile0 + a.tiles_per_wg);
-  int prev_b = -1;
-  for (int tile = tile0; tile < tile1; ++tile) {
-    const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, b = tile / (a.tiles_x * a.tiles_y);
-    const int oy0 = ty * TH, ox0 = tx * TW;
-    const int iy0 = oy0 * a.stride - a.pad_t, ix0 = ox0 * a.stride - a.pad_l;
-    __syncthreads();  // previous tile fully consumed
-    if (b != prev_b) {  // per-sample operand transform tables for this block's CB channels
-      prev_b = b;
-      for (int c = tid; c < CB; c += NT) {
-        const int cc = cb0 + c;
-        float sc = 1.f, sh = 0.f;
-        if (cc < a.Cin) {
-          if (a.in_mode == HDRSKY_IN_AFFINE) {
-            sc = a.in_scale[b * a.ss_bstride + cc];
-            sh = a.in_shift[b * a.ss_bstride + cc];
-          } else if (a.in_mode == HDRSKY_IN_PARTIALS) {
-            float s = 0.f, ss = 0.f;
-            const float* pp = a.in_part + (size_t)b * a.in_nparts * 2 * a.Cin + cc;
-            for (int k = 0; k < a.in_nparts; ++k) { s += pp[(2 * k) * a.Cin]; ss += pp[(2 * k + 1) * a.Cin]; }
-            const float mean = s * a.in_inv_count;
-            const float var = fmaxf(ss * a.in_inv_count - mean * mean, 0.f);
-            sc = a.in_gamma[cc] / sqrtf(var + a.in_eps);
-            sh = a.in_beta[cc] - mean * sc;
-          }
+  const int tps = a.tiles_x * a.tiles_y;            // tiles per sample
+  const int bfirst = tile0 / tps;
+  const int nitems = a.NPIX * NQX;
+
+  // Software pipeline: the global loads of tile t+1 are issued into registers (xr / yr) before the MFMA phase of
+  // tile t and are transformed + written to LDS at the top of the next iteration.
+  float xr[XR][8];   // X' items of this thread; UP: the four source pixels of its one item
+  float yr[YMAX][8];
+
+  // ---- per-sample operand transform tables for every sample this workgroup touches ----------------------------
+  {
+    const int blast = (tile1 - 1) / tps;
+    const int ntab = (blast - bfirst + 1) * CB;
+    for (int idx = tid; idx < ntab; idx += NT) {
+      const int sb = idx / CB, c = idx % CB, b = bfirst + sb, cc = cb0 + c;
+      float sc = 1.f, sh = 0.f;
+      if (cc < a.Cin) {
+        if (a.in_mode == HDRSKY_IN_AFFINE) {
+          sc = a.in_scale[b * a.ss_bstride + cc];
+          sh = a.in_shift[b * a.ss_bstride + cc];
+        } else if (a.in_mode == HDRSKY_IN_PARTIALS) {
+          float s0 = 0.f, ss = 0.f;
+          const float* pp = a.in_part + (size_t)b * a.in_nparts * 2 * a.Cin + cc;
+#pragma unroll 4
+          for (int k = 0; k < a.in_nparts; ++k) { s0 += pp[(2 * k) * a.Cin]; ss += pp[(2 * k + 1) * a.Cin]; }
+          const float mean = s0 * a.in_inv_count;
+          const float var = fmaxf(ss * a.in_inv_count - mean * mean, 0.f);
+          sc = a.in_gamma[cc] / sqrtf(var + a.in_eps);
+          sh = a.in_beta[cc] - mean * sc;
         }
-        sScale[c] = sc; sShift[c] = sh;
       }
-      __syncthreads();
+      sTab[sb * 2 * CB + c] = sc;
+      sTab[sb * 2 * CB + CB + c] = sh;
     }
-    // ---- stage X' halo tile: [pixel][CB] bf16 rows (transform + optional 2x bilinear resize) ----------
-    {
-      constexpr int NQ = CB / 8;
-      const int nitems = a.NPIX * NQ;
-      for (int i = tid; i < nitems; i += NT) {
-        const int px = i / NQ, qc = i % NQ;
-        const int hy = (int)(((unsigned)px * (unsigned)a.wt_magic) >> 24);
-        const int hx = px - hy * a.WT;
-        const int cy = iy0 + hy, cx = ix0 + hx;
-        const bool ok = cy >= 0 && cy < a.Hc && cx >= 0 && cx < a.Wc;
-        float v[8];
-        if (NARROW) {
-          const float* src = a.x + ((size_t)(b * a.H + (ok ? cy : 0)) * a.W + (ok ? cx : 0)) * a.Cin;
+  }
+
+  for (int tile = tile0 - 1; tile < tile1; ++tile) {
+    // ================= stage tile `tile` from the registers filled one iteration ago =============================
+    if (tile >= tile0 && !(a.dbg & 4)) {
+      const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, b = tile / tps;
+      const int oy0 = ty * TH, ox0 = tx * TW;
+      const int iy0 = oy0 * a.stride - a.pad_t, ix0 = ox0 * a.stride - a.pad_l;
+      const float* tsc = sTab + (b - bfirst) * 2 * CB;
+      const float* tsh = tsc + CB;
+      __syncthreads();  // previous tile fully consumed (first pass: transform tables visible)
+      if (UP) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int c = qc * 8 + j;
-            const bool cok = ok && c < a.Cin;
-            const float t = src[cok ? c : 0];
-            v[j] = cok ? leaky(t * sScale[c] + sShift[c], slope) : 0.f;
-          }
-        } else {
-          const int c0 = cb0 + qc * 8;
-          const float* xb = a.x + (size_t)b * a.H * a.W * a.Cin + c0;
-          if (a.upsample == 2) {
+        for (int it = 0; it < XI; ++it) {
+          const int i = it * NT + tid;
+          if (i < nitems) {
+            const int px = i / NQX, qc = i % NQX;
+            const int hy = (int)(((unsigned)px * (unsigned)a.wt_magic) >> 24);
+            const int hx = px - hy * a.WT;
+            const int cy = iy0 + hy, cx = ix0 + hx;
+            const bool ok = cy >= 0 && cy < a.Hc && cx >= 0 && cx < a.Wc;
             const float sy = (cy + 0.5f) * 0.5f - 0.5f, sx = (cx + 0.5f) * 0.5f - 0.5f;
-            const float fy = floorf(sy), fx = floorf(sx);
-            const int ylo = min(max((int)fy, 0), a.H - 1), yhi = max(min((int)ceilf(sy), a.H - 1), 0);
-            const int xlo = min(max((int)fx, 0), a.W - 1), xhi = max(min((int)ceilf(sx), a.W - 1), 0);
-            const float ly = sy - fy, lx = sx - fx;
-            const float* s00 = xb + ((size_t)ylo * a.W + xlo) * a.Cin;
-            const float* s01 = xb + ((size_t)ylo * a.W + xhi) * a.Cin;
-            const float* s10 = xb + ((size_t)yhi * a.W + xlo) * a.Cin;
-            const float* s11 = xb + ((size_t)yhi * a.W + xhi) * a.Cin;
+            const float ly = sy - floorf(sy), lx = sx - floorf(sx);
+            float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-              const float sc = sScale[qc * 8 + j], sh = sShift[qc * 8 + j];
-              const float tl = leaky(s00[j] * sc + sh, slope), tr = leaky(s01[j] * sc + sh, slope);
-              const float bl = leaky(s10[j] * sc + sh, slope), br = leaky(s11[j] * sc + sh, slope);
+              const float sc = tsc[qc * 8 + j], sh = tsh[qc * 8 + j];
+              const float tl = leaky(xr[(it * 4 + 0) % XR][j] * sc + sh, slope), tr = leaky(xr[(it * 4 + 1) % XR][j] * sc + sh, slope);
+              const float bl = leaky(xr[(it * 4 + 2) % XR][j] * sc + sh, slope), br = leaky(xr[(it * 4 + 3) % XR][j] * sc + sh, slope);
               const float top = tl + (tr - tl) * lx, bot = bl + (br - bl) * lx;
               v[j] = ok ? top + (bot - top) * ly : 0.f;
             }
-          } else {
-            const float* src = xb + ((size_t)(ok ? cy : 0) * a.W + (ok ? cx : 0)) * a.Cin;
-            const float4 va = *reinterpret_cast<const float4*>(src);
-            const float4 vb = *reinterpret_cast<const float4*>(src + 4);
-            const float in[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = ok ? leaky(in[j] * sScale[qc * 8 + j] + sShift[qc * 8 + j], slope) : 0.f;
+            uint4 hi, lo;
+            pack8<PRECISE>(v, hi, lo);
+            *reinterpret_cast<uint4*>(sX + (size_t)px * a.RX + qc * 16) = hi;
+            if (PRECISE) *reinterpret_cast<uint4*>(sXl + (size_t)px * a.RX + qc * 16) = lo;
           }
         }
-        uint4 hi, lo;
-        pack8<PRECISE>(v, hi, lo);
-        *reinterpret_cast<uint4*>(sX + (size_t)px * a.RX + qc * 16) = hi;
-        if (PRECISE) *reinterpret_cast<uint4*>(sXl + (size_t)px * a.RX + qc * 16) = lo;
-      }
-    }
-    // ---- stage dY tile: [pixel][OB] bf16 rows (+ per-thread bias-gradient partial sums) -----------------
-    {
-      constexpr int NQ = OB / 8;  // NT % NQ == 0: a thread always handles the same 8 output channels
-      const int qc = tid % NQ;
-      const int n0 = ob0 + qc * 8;
-      for (int i = tid; i < BM * NQ; i += NT) {
-        const int m = i / NQ;
-        const int oy = oy0 + m / TW, ox = ox0 + m % TW;
-        const bool ok = oy < a.Ho && ox < a.Wo;
-        float v[8];
-        const float* src = a.dy + ((size_t)(b * a.Ho + (ok ? oy : 0)) * a.Wo + (ok ? ox : 0)) * a.Cout;
+      } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const bool cok = ok && (n0 + j) < a.Cout;
-          v[j] = cok ? src[n0 + j] : 0.f;
-          bsum[j] += v[j];
+        for (int it = 0; it < XI; ++it) {
+          const int i = it * NT + tid;
+          if (i < nitems) {
+            const int px = i / NQX, qc = i % NQX;
+            const int hy = (int)(((unsigned)px * (unsigned)a.wt_magic) >> 24);
+            const int hx = px - hy * a.WT;
+            const int cy = iy0 + hy, cx = ix0 + hx;
+            const bool ok = cy >= 0 && cy < a.Hc && cx >= 0 && cx < a.Wc;
+            float v[8];
+            if (xform) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                const bool cok = NARROW ? (ok && qc * 8 + j < a.Cin) : ok;
+                v[j] = cok ? leaky(xr[it][j] * tsc[qc * 8 + j] + tsh[qc * 8 + j], slope) : 0.f;
+              }
+            } else {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                const bool cok = NARROW ? (ok && qc * 8 + j < a.Cin) : ok;
+                v[j] = cok ? xr[it][j] : 0.f;
+              }
+            }
+            uint4 hi, lo;
+            pack8<PRECISE>(v, hi, lo);
+            *reinterpret_cast<uint4*>(sX + (size_t)px * a.RX + qc * 16) = hi;
+            if (PRECISE) *reinterpret_cast<uint4*>(sXl + (size_t)px * a.RX + qc * 16) = lo;
+          }
         }
-        uint4 hi, lo;
-        pack8<PRECISE>(v, hi, lo);
-        *reinterpret_cast<uint4*>(sY + (size_t)m * a.RY + qc * 16) = hi;
-        if (PRECISE) *reinterpret_cast<uint4*>(sYl + (size_t)m * a.RY + qc * 16) = lo;
+      }
+#pragma unroll
+      for (int it = 0; it < YMAX; ++it) {   // dY tile: [pixel][OB] bf16 rows (+ per-thread bias-gradient partial sums)
+        const int i = it * NT + tid;
+        if (i < BM * NQY) {
+          const int m = i / NQY, qc = i % NQY;   // NT % NQY == 0: a thread always handles the same 8 output channels
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bsum[j] += yr[it][j];
+          uint4 hi, lo;
+          pack8<PRECISE>(yr[it], hi, lo);
+          *reinterpret_cast<uint4*>(sY + (size_t)m * a.RY + qc * 16) = hi;
+          if (PRECISE) *reinterpret_cast<uint4*>(sYl + (size_t)m * a.RY + qc * 16) = lo;
+        }
+      }
+      __syncthreads();
+    }
+    // ================= issue the global loads of tile + 1 =========================================================
+    if (tile + 1 < tile1 && !(a.dbg & 8)) {
+      const int nt = tile + 1;
+      const int tx = nt % a.tiles_x, ty = (nt / a.tiles_x) % a.tiles_y, b = nt / tps;
+      const int oy0 = ty * TH, ox0 = tx * TW;
+      const int iy0 = oy0 * a.stride - a.pad_t, ix0 = ox0 * a.stride - a.pad_l;
+      if (UP) {
+#pragma unroll
+        for (int it = 0; it < XI; ++it) {
+          const int i = it * NT + tid;
+          if (i < nitems) {
+            const int px = i / NQX, qc = i % NQX;
+            const int hy = (int)(((unsigned)px * (unsigned)a.wt_magic) >> 24);
+            const int hx = px - hy * a.WT;
+            const int cy = iy0 + hy, cx = ix0 + hx;
+            const float sy = (cy + 0.5f) * 0.5f - 0.5f, sx = (cx + 0.5f) * 0.5f - 0.5f;
+            const int ylo = min(max((int)floorf(sy), 0), a.H - 1), yhi = max(min((int)ceilf(sy), a.H - 1), 0);
+            const int xlo = min(max((int)floorf(sx), 0), a.W - 1), xhi = max(min((int)ceilf(sx), a.W - 1), 0);
+            const float* xb = a.x + (size_t)b * a.H * a.W * a.Cin + cb0 + qc * 8;
+            const float* sp[4] = {xb + ((size_t)ylo * a.W + xlo) * a.Cin, xb + ((size_t)ylo * a.W + xhi) * a.Cin,
+                                  xb + ((size_t)yhi * a.W + xlo) * a.Cin, xb + ((size_t)yhi * a.W + xhi) * a.Cin};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float4 va = *reinterpret_cast<const float4*>(sp[k]);
+              const float4 vb = *reinterpret_cast<const float4*>(sp[k] + 4);
+              float* d = xr[(it * 4 + k) % XR];
+              d[0] = va.x; d[1] = va.y; d[2] = va.z; d[3] = va.w; d[4] = vb.x; d[5] = vb.y; d[6] = vb.z; d[7] = vb.w;
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int it = 0; it < XI; ++it) {
+          const int i = it * NT + tid;
+          if (i < nitems) {
+            const int px = i / NQX, qc = i % NQX;
+            const int hy = (int)(((unsigned)px * (unsigned)a.wt_magic) >> 24);
+            const int hx = px - hy * a.WT;
+            const int cy = iy0 + hy, cx = ix0 + hx;
+            const bool ok = cy >= 0 && cy < a.Hc && cx >= 0 && cx < a.Wc;
+            if (NARROW) {
+              const float* src = a.x + ((size_t)(b * a.H + (ok ? cy : 0)) * a.W + (ok ? cx : 0)) * a.Cin;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                const int c = qc * 8 + j;
+                xr[it][j] = src[c < a.Cin ? c : 0];
+              }
+            } else {
+              const float* src = a.x + ((size_t)(b * a.H + (ok ? cy : 0)) * a.W + (ok ? cx : 0)) * a.Cin + cb0 + qc * 8;
+              const float4 va = *reinterpret_cast<const float4*>(src);
+              const float4 vb = *reinterpret_cast<const float4*>(src + 4);
+              xr[it][0] = va.x; xr[it][1] = va.y; xr[it][2] = va.z; xr[it][3] = va.w;
+              xr[it][4] = vb.x; xr[it][5] = vb.y; xr[it][6] = vb.z; xr[it][7] = vb.w;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < YMAX; ++it) {
+        const int i = it * NT + tid;
+        if (i < BM * NQY) {
+          const int m = i / NQY, qc = i % NQY;
+          const int oy = oy0 + m / TW, ox = ox0 + m % TW;
+          const bool ok = oy < a.Ho && ox < a.Wo;
+          const int n0 = ob0 + qc * 8;
+          const float* src = a.dy + ((size_t)(b * a.Ho + (ok ? oy : 0)) * a.Wo + (ok ? ox : 0)) * a.Cout;
+          if ((a.Cout & 7) == 0 && n0 + 8 <= a.Cout) {
+            const float4 va = *reinterpret_cast<const float4*>(src + n0);
+            const float4 vb = *reinterpret_cast<const float4*>(src + n0 + 4);
+            yr[it][0] = ok ? va.x : 0.f; yr[it][1] = ok ? va.y : 0.f; yr[it][2] = ok ? va.z : 0.f; yr[it][3] = ok ? va.w : 0.f;
+            yr[it][4] = ok ? vb.x : 0.f; yr[it][5] = ok ? vb.y : 0.f; yr[it][6] = ok ? vb.z : 0.f; yr[it][7] = ok ? vb.w : 0.f;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const bool cok = ok && (n0 + j) < a.Cout;
+              const float t = src[cok ? n0 + j : 0];
+              yr[it][j] = cok ? t : 0.f;
+            }
+          }
+        }
       }
     }
-    __syncthreads();
-    // ---- MFMA: 4 k-steps of 32 output pixels ------------------------------------------------------------
+    if (tile < tile0 || (a.dbg & 1)) continue;
+    // ================= MFMA: 4 k-steps of 32 output pixels =========================================================
 #pragma unroll 1
     for (int r = 0; r < BM / 32; ++r) {
       const int m = r * 32 + g * 8 + q;        // this lane's row of the first 4-pixel block (second: m+4)
       const int mty = m / TW, mtx = m % TW;
-      uint4 bh[OBF], bl[OBF];
+      uint4 bh[OBH], bl[OBH];
 #pragma unroll
-      for (int j = 0; j < OBF; ++j) {
-        const unsigned char* ad = sY + (size_t)m * a.RY + (j * 16 + p * 4) * 2;
+      for (int j = 0; j < OBH; ++j) {
+        const unsigned char* ad = sY + (size_t)m * a.RY + ((ojh + j) * 16 + p * 4) * 2;
         const uint2 v0 = lds_tr(ad), v1 = lds_tr(ad + 4 * a.RY);
         bh[j] = uint4{v0.x, v0.y, v1.x, v1.y};
         if (PRECISE) {
-          const unsigned char* al = sYl + (size_t)m * a.RY + (j * 16 + p * 4) * 2;
+          const unsigned char* al = sYl + (size_t)m * a.RY + ((ojh + j) * 16 + p * 4) * 2;
           const uint2 w0 = lds_tr(al), w1 = lds_tr(al + 4 * a.RY);
           bl[j] = uint4{w0.x, w0.y, w1.x, w1.y};
         }
       }
 #pragma unroll
       for (int t = 0; t < TPW; ++t) {
-        const int tap = tgrp + 4 * t;   // wave-uniform
+        const int tap = tgrp + NTG * t;   // wave-uniform
         if (tap < a.ntaps) {
           const int ky = (tap * a.kw_magic) >> 16, kx = tap - ky * a.KW;
           const int xpix = (mty * a.stride + ky) * a.WT + mtx * a.stride + kx;
@@ -229,7 +348,7 @@ __global__ void __launch_bounds__(NW * 64) conv_wgrad_kernel(const WgradArgs a) 
               al = uint4{w0.x, w0.y, w1.x, w1.y};
             }
 #pragma unroll
-            for (int j = 0; j < OBF; ++j) {
+            for (int j = 0; j < OBH; ++j) {
               if (PRECISE) {
                 acc[t][i][j] = mfma16(al, bh[j], acc[t][i][j]);
                 acc[t][i][j] = mfma16(ah, bl[j], acc[t][i][j]);
@@ -242,24 +361,24 @@ __global__ void __launch_bounds__(NW * 64) conv_wgrad_kernel(const WgradArgs a) 
     }
   }
 
+  if (a.dbg & 2) return;
   // ---- epilogue: add this block's partial dW (and db) to global memory --------------------------------------
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
-    const int tap = tgrp + 4 * t;
+    const int tap = tgrp + NTG * t;
     if (tap < a.ntaps) {
 #pragma unroll
       for (int i = 0; i < CBH; ++i)
 #pragma unroll
-        for (int j = 0; j < OBF; ++j)
+        for (int j = 0; j < OBH; ++j)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const int ci = cb0 + (cih + i) * 16 + kq * 4 + e, co = ob0 + j * 16 + lr;
+            const int ci = cb0 + (cih + i) * 16 + kq * 4 + e, co = ob0 + (ojh + j) * 16 + lr;
             if (ci < a.Cin && co < a.Cout) atomicAdd(a.dw + ((size_t)tap * a.Cin + ci) * a.Cout + co, acc[t][i][j][e]);
           }
     }
   }
   if (a.db != nullptr && cb0 == 0) {
-    constexpr int NQ = OB / 8;
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 8; ++j) sRed[tid * 8 + j] = bsum[j];
@@ -267,125 +386,205 @@ __global__ void __launch_bounds__(NW * 64) conv_wgrad_kernel(const WgradArgs a) 
     if (tid < OB) {
       const int qc = tid / 8, j = tid % 8;
       float s = 0.f;
-      for (int k = qc; k < NT; k += NQ) s += sRed[k * 8 + j];
+      for (int k = qc; k < NT; k += NQY) s += sRed[k * 8 + j];
       if (ob0 + tid < a.Cout) atomicAdd(a.db + ob0 + tid, s);
     }
   }
 }
 
-template <int TPW, int CBF, int OBF, int TW, bool NARROW, bool PRECISE>
-int launch_wgrad(WgradArgs& a, hipStream_t stream) {
-  constexpr int NW = (!NARROW && (CBF % 2) == 0) ? 8 : 4;
-  constexpr int CB = CBF * 16, OB = OBF * 16, BM = 128, TH = BM / TW;
-  a.tiles_x = cdiv(a.Wo, TW);
-  a.tiles_y = cdiv(a.Ho, TH);
-  a.ntiles = a.B * a.tiles_x * a.tiles_y;
-  a.cblocks = cdiv(NARROW ? 16 : a.Cin, CB);
-  a.oblocks = cdiv(a.Cout, OB);
-  a.HT = (TH - 1) * a.stride + a.KH;
-  a.WT = (TW - 1) * a.stride + a.KW;
-  a.NPIX = a.HT * a.WT;
-  a.wt_magic = ((1 << 24) + a.WT - 1) / a.WT;
-  a.kw_magic = (65536 + a.KW - 1) / a.KW;
-  a.ntaps = a.KH * a.KW;
-  if (cdiv(a.ntaps, 4) > TPW) return HDRSKY_EUNSUPPORTED;
-  if (!NARROW && (a.Cin % CB) != 0) return HDRSKY_EUNSUPPORTED;   // the X staging reads whole CB-channel blocks
-  a.RX = CB * 2 + 16;
-  a.RY = OB * 2 + 16;
-  const int planes = PRECISE ? 2 : 1;
-  const int xbytes = roundup(a.NPIX * a.RX, 16), ybytes = roundup(BM * a.RY, 16);
-  a.off_xlo = xbytes;
-  a.off_y = xbytes * planes;
-  a.off_ylo = a.off_y + ybytes;
-  a.off_ss = a.off_y + ybytes * planes;
-  a.off_red = a.off_ss + 2 * CB * 4;
-  const int lds = a.off_red + NW * 64 * 8 * 4;
-  if (lds > 160 * 1024) return HDRSKY_EUNSUPPORTED;
-  // enough workgroups to fill the chip, few enough that the atomic traffic (one dW block per workgroup) stays small
-  const int nblk = a.cblocks * a.oblocks;
-  int chunks = cdiv(a.wg_target > 0 ? a.wg_target : 128, nblk);
-  if (chunks > a.ntiles) chunks = a.ntiles;
-  a.tiles_per_wg = cdiv(a.ntiles, chunks);
-  chunks = cdiv(a.ntiles, a.tiles_per_wg);
-  auto kern = conv_wgrad_kernel<TPW, CBF, OBF, TW, NARROW, PRECISE, NW>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
-        hipSuccess)
-      return HDRSKY_ELAUNCH;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(nblk * chunks), dim3(NW * 64), lds, stream, a);
-  HDRSKY_CHECK_LAUNCH();
-  return HDRSKY_OK;
-}
+// ---- host side -------------------------------------------------------------------------------------------------
+struct Geo { int tpw, cbf, obf, tw, nw, cs, os, xr; bool narrow, precise, up; };
 
-template <bool NARROW, bool PRECISE>
-int dispatch_wgrad(WgradArgs& a, int tpw, int cbf, int obf, int tw, hipStream_t s) {
-#define HDRSKY_WG(TPW_, CBF_, OBF_)                                                                   \
-  if (tpw == TPW_ && cbf == CBF_ && obf == OBF_) {                                                   \
-    return tw == 32 ? launch_wgrad<TPW_, CBF_, OBF_, 32, NARROW, PRECISE>(a, s)                      \
-                    : launch_wgrad<TPW_, CBF_, OBF_, 16, NARROW, PRECISE>(a, s);                      \
+template <int TPW, int CBF, int OBF, int TW, bool NARROW, bool PRECISE, bool UP, int NW, int CS, int OS, int XR>
+struct WgradVariant {
+  static constexpr int NT = NW * 64, CB = CBF * 16, OB = OBF * 16, BM = 128, TH = BM / TW, NTG = NW / (CS * OS);
+  // fills the geometry-dependent fields of one job; returns the LDS bytes it needs, or a negative error
+  static int prepare(WgradArgs& a, int wg_target) {
+    if (UP != (a.upsample == 2)) return HDRSKY_EUNSUPPORTED;
+    a.tiles_x = cdiv(a.Wo, TW);
+    a.tiles_y = cdiv(a.Ho, TH);
+    a.ntiles = a.B * a.tiles_x * a.tiles_y;
+    a.cblocks = cdiv(NARROW ? 16 : a.Cin, CB);
+    a.oblocks = cdiv(a.Cout, OB);
+    a.HT = (TH - 1) * a.stride + a.KH;
+    a.WT = (TW - 1) * a.stride + a.KW;
+    a.NPIX = a.HT * a.WT;
+    a.wt_magic = ((1 << 24) + a.WT - 1) / a.WT;
+    a.kw_magic = (65536 + a.KW - 1) / a.KW;
+    a.ntaps = a.KH * a.KW;
+    if (cdiv(a.ntaps, NTG) > TPW) return HDRSKY_EUNSUPPORTED;
+    if (!NARROW && (a.Cin % CB) != 0) return HDRSKY_EUNSUPPORTED;   // the X staging reads whole CB-channel blocks
+    if (cdiv(a.NPIX * (CB / 8), NT) > (UP ? XR / 4 : XR)) return HDRSKY_EUNSUPPORTED;   // register prefetch budget
+    a.RX = CB * 2 + 16;
+    a.RY = OB * 2 + 16;
+    const int planes = PRECISE ? 2 : 1;
+    const int xbytes = roundup(a.NPIX * a.RX, 16), ybytes = roundup(BM * a.RY, 16);
+    a.off_xlo = xbytes;
+    a.off_y = xbytes * planes;
+    a.off_ylo = a.off_y + ybytes;
+    a.off_ss = a.off_y + ybytes * planes;
+    // pixel split: enough workgroups to fill the chip, few enough that the atomic traffic (one dW block per
+    // workgroup) stays small
+    const int nblk = a.cblocks * a.oblocks;
+    int chunks = cdiv(wg_target, nblk);
+    if (chunks < 1) chunks = 1;
+    if (chunks > a.ntiles) chunks = a.ntiles;
+    a.tiles_per_wg = cdiv(a.ntiles, chunks);
+    a.nchunks = cdiv(a.ntiles, a.tiles_per_wg);
+    const int tps = a.tiles_x * a.tiles_y;
+    const int nsamp = (a.tiles_per_wg + tps - 2) / tps + 1;          // samples a run of tiles_per_wg tiles can touch
+    a.off_red = a.off_ss + nsamp * 2 * CB * 4;
+    const int lds = a.off_red + NT * 8 * 4;
+    if (lds > 160 * 1024) return HDRSKY_EUNSUPPORTED;
+    return lds;
   }
-  if (NARROW) {
-    HDRSKY_WG(13, 1, 2) HDRSKY_WG(4, 1, 4) HDRSKY_WG(3, 1, 4)
-  } else {
-    HDRSKY_WG(3, 2, 4) HDRSKY_WG(3, 4, 4) HDRSKY_WG(3, 4, 2) HDRSKY_WG(3, 2, 2)
-    HDRSKY_WG(4, 4, 2) HDRSKY_WG(4, 4, 1) HDRSKY_WG(4, 2, 2)
-    HDRSKY_WG(13, 2, 2) HDRSKY_WG(13, 2, 1)
+  static int launch(MultiArgs& m, int lds, hipStream_t stream) {
+    auto kern = conv_wgrad_kernel<TPW, CBF, OBF, TW, NARROW, PRECISE, UP, NW, CS, OS, XR>;
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024) != hipSuccess)
+        return HDRSKY_ELAUNCH;
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(m.first[m.njobs]), dim3(NT), lds, stream, m);
+    HDRSKY_CHECK_LAUNCH();
+    return HDRSKY_OK;
   }
+};
+
+// Runs `fn` on the kernel variant that implements geometry `g` (the instantiated set).
+template <typename F>
+int with_variant(const Geo& g, F&& fn) {
+#define HDRSKY_WG(TPW_, CBF_, OBF_, NARROW_, UP_, NW_, CS_, OS_, XR_)                                                \
+  if (g.tpw == TPW_ && g.cbf == CBF_ && g.obf == OBF_ && g.narrow == NARROW_ && g.up == UP_ && g.nw == NW_) {        \
+    if (g.precise) return g.tw == 32 ? fn(WgradVariant<TPW_, CBF_, OBF_, 32, NARROW_, true, UP_, NW_, CS_, OS_, XR_>()) \
+                                     : fn(WgradVariant<TPW_, CBF_, OBF_, 16, NARROW_, true, UP_, NW_, CS_, OS_, XR_>()); \
+    return g.tw == 32 ? fn(WgradVariant<TPW_, CBF_, OBF_, 32, NARROW_, false, UP_, NW_, CS_, OS_, XR_>())            \
+                      : fn(WgradVariant<TPW_, CBF_, OBF_, 16, NARROW_, false, UP_, NW_, CS_, OS_, XR_>());            \
+  }
+  // 16 waves, 32x32-channel dW blocks (a layer on its own)
+  HDRSKY_WG(3, 2, 2, false, false, 16, 2, 2, 3) HDRSKY_WG(3, 2, 2, false, true, 16, 2, 2, 4)
+  HDRSKY_WG(4, 2, 2, false, false, 16, 2, 2, 3) HDRSKY_WG(7, 2, 1, false, false, 16, 2, 1, 3)
+  HDRSKY_WG(2, 1, 4, true, false, 16, 1, 2, 3) HDRSKY_WG(2, 1, 2, true, false, 16, 1, 2, 3)
+  HDRSKY_WG(7, 1, 2, true, false, 16, 1, 2, 3)
+  // 8 waves, 64x64-channel dW blocks (several wide layers in one launch)
+  HDRSKY_WG(3, 4, 4, false, false, 8, 2, 1, 4)
 #undef HDRSKY_WG
   return HDRSKY_EUNSUPPORTED;
 }
 
-}  // namespace
+// Geometry for one layer: `big` = 64x64-channel blocks (grouped launches of wide stride-1 layers).
+static Geo choose_geo(const hdrsky_conv_desc* d, bool big) {
+  Geo g{};
+  const int ntaps = d->KH * d->KW;
+  g.narrow = d->Cin <= 8;
+  g.precise = d->compute == HDRSKY_BF16X3;
+  g.up = d->upsample == 2;
+  g.tw = d->Wo >= 32 ? 32 : 16;
+  if (big) {
+    g.nw = 8; g.cs = 2; g.os = 1; g.cbf = 4; g.obf = 4; g.tpw = ntaps <= 12 ? 3 : 4;
+    return g;
+  }
+  g.nw = 16;
+  if (g.narrow) { g.cbf = 1; g.obf = (d->Cout >= 64 && ntaps <= 16) ? 4 : 2; g.tpw = ntaps <= 16 ? 2 : 7; }
+  else if (ntaps > 16) { g.cbf = 2; g.obf = 1; g.tpw = 7; }
+  else { g.cbf = 2; g.obf = 2; g.tpw = ntaps <= 12 ? 3 : 4; }
+  return g;
+}
 
-extern "C" int hdrsky_conv2d_wgrad(const hdrsky_conv_desc* d, const float* x, const float* dy, const float* in_scale,
-                                   const float* in_shift, const float* in_part, const float* in_gamma,
-                                   const float* in_beta, float* dw, float* db, void* stream) {
-  if (!d || !x || !dy || !dw) return HDRSKY_EINVAL;
+static bool can_go_big(const hdrsky_conv_desc* d) {
+  return d->Cin >= 64 && d->Cout >= 64 && (d->Cin % 64) == 0 && d->stride == 1 && d->upsample == 1 && d->KH * d->KW <= 9;
+}
+
+static int fill_job(WgradArgs& a, const hdrsky_wgrad_job& j) {
+  const hdrsky_conv_desc* d = &j.desc;
+  if (!j.x || !j.dy || !j.dw) return HDRSKY_EINVAL;
   if (d->dilate != 1) return HDRSKY_EUNSUPPORTED;
   const bool narrow = d->Cin <= 8;
   if (!narrow && (d->Cin % 32) != 0) return HDRSKY_EUNSUPPORTED;
   if (narrow && d->upsample != 1) return HDRSKY_EUNSUPPORTED;
-  if (d->in_mode == HDRSKY_IN_AFFINE && (!in_scale || !in_shift)) return HDRSKY_EINVAL;
-  if (d->in_mode == HDRSKY_IN_PARTIALS && (!in_part || !in_gamma || !in_beta || d->in_nparts <= 0)) return HDRSKY_EINVAL;
-  WgradArgs a{};
-  a.x = x; a.dy = dy; a.dw = dw; a.db = db;
-  a.in_scale = in_scale; a.in_shift = in_shift; a.in_part = in_part; a.in_gamma = in_gamma; a.in_beta = in_beta;
+  if (d->in_mode == HDRSKY_IN_AFFINE && (!j.in_scale || !j.in_shift)) return HDRSKY_EINVAL;
+  if (d->in_mode == HDRSKY_IN_PARTIALS && (!j.in_part || !j.in_gamma || !j.in_beta || d->in_nparts <= 0)) return HDRSKY_EINVAL;
+  a = WgradArgs{};
+  a.x = j.x; a.dy = j.dy; a.dw = j.dw; a.db = j.db;
+  a.in_scale = j.in_scale; a.in_shift = j.in_shift; a.in_part = j.in_part; a.in_gamma = j.in_gamma; a.in_beta = j.in_beta;
   a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
   a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad_t = d->pad_t; a.pad_l = d->pad_l;
   a.upsample = d->upsample; a.Hc = d->Hc; a.Wc = d->Wc;
   a.in_mode = d->in_mode; a.ss_bstride = d->ss_bstride; a.in_nparts = d->in_nparts;
   a.in_eps = d->in_eps; a.in_inv_count = 1.f / (float)(d->H * d->W); a.in_slope = d->in_slope;
-  const int ntaps = d->KH * d->KW;
-  const int tpw = ntaps <= 12 ? (ntaps <= 9 ? 3 : 4) : (ntaps <= 16 ? 4 : 13);
-  // dW block per workgroup, measured per layer shape (profiles/microbench_wgrad.py): 32x32-channel blocks and
-  // ~256 workgroups beat larger blocks - the kernel is bound by staging latency and atomic traffic, not by MFMA
-  int cbf, obf;
-  if (narrow) { cbf = 1; obf = d->Cout >= 64 ? 4 : (d->Cout >= 32 ? 2 : 1); }
-  else { cbf = 2; obf = (tpw == 13 || d->Cout < 32) ? 1 : 2; }
-  if (tpw == 13 && obf > 2) obf = 2;               // register budget: TPW*CBF*OBF accumulator fragments per wave
-  if (tpw != 13 && !narrow && obf == 1) obf = 2;
-  a.wg_target = 256;
-  int tw = d->Wo >= 32 ? 32 : 16;
-  if (const char* e = getenv("HDRSKY_WGRAD")) {   // tuning hook: "cbf,obf,tw,workgroups"
-    int c = 0, o = 0, t = 0, g = 0;
-    if (sscanf(e, "%d,%d,%d,%d", &c, &o, &t, &g) >= 3) {
-      if (c > 0 && !narrow) cbf = c;
-      if (o > 0) obf = o;
-      if (t > 0) tw = t;
-      a.wg_target = g;
+  if (const char* e = getenv("HDRSKY_WGRAD_DBG")) a.dbg = atoi(e);
+  return HDRSKY_OK;
+}
+
+static bool same_geo(const Geo& p, const Geo& q) {
+  return p.tpw == q.tpw && p.cbf == q.cbf && p.obf == q.obf && p.tw == q.tw && p.nw == q.nw && p.narrow == q.narrow &&
+         p.precise == q.precise && p.up == q.up;
+}
+
+}  // namespace
+
+extern "C" int hdrsky_conv2d_wgrad_multi(const hdrsky_wgrad_job* jobs, int njobs, void* stream) {
+  if (njobs < 0 || (njobs > 0 && !jobs)) return HDRSKY_EINVAL;
+  if (njobs > 256) return HDRSKY_EUNSUPPORTED;
+  // workgroups per launch (measured, profiles/microbench_wgrad.py): 256 for a layer on its own, 192 for a group
+  int wg_hook = 0, force_small = 0;
+  if (const char* e = getenv("HDRSKY_WGRAD")) sscanf(e, "%d,%d", &wg_hook, &force_small);   // tuning hook
+  // wide stride-1 layers use 64x64-channel blocks when at least three of them share a launch
+  int nwide = 0;
+  for (int i = 0; i < njobs; ++i) nwide += can_go_big(&jobs[i].desc) ? 1 : 0;
+  const bool use_big = nwide >= 3 && !force_small;
+  Geo geo[256];
+  bool done[256];
+  for (int i = 0; i < njobs; ++i) { geo[i] = choose_geo(&jobs[i].desc, use_big && can_go_big(&jobs[i].desc)); done[i] = false; }
+  for (int i = 0; i < njobs; ++i) {
+    if (done[i]) continue;
+    int members[256], nm = 0;
+    double work[256], wsum = 0.0;
+    for (int k = i; k < njobs; ++k)
+      if (!done[k] && same_geo(geo[i], geo[k])) {
+        const hdrsky_conv_desc& d = jobs[k].desc;
+        work[nm] = (double)d.B * d.Ho * d.Wo * d.KH * d.KW * d.Cin * d.Cout;
+        wsum += work[nm];
+        members[nm++] = k;
+        done[k] = true;
+      }
+    const int wg_total = wg_hook > 0 ? wg_hook : (nm == 1 ? 256 : 192);
+    for (int base = 0; base < nm; base += WG_MAXJ) {   // kernel argument block holds WG_MAXJ jobs
+      const int cnt = nm - base < WG_MAXJ ? nm - base : WG_MAXJ;
+      MultiArgs m{};
+      m.njobs = cnt;
+      int lds = 0, rc = HDRSKY_OK;
+      rc = with_variant(geo[i], [&](auto v) {
+        int blocks = 0;
+        for (int q = 0; q < cnt; ++q) {
+          WgradArgs& a = m.job[q];
+          int r = fill_job(a, jobs[members[base + q]]);
+          if (r != HDRSKY_OK) return r;
+          int target = (int)(wg_total * work[base + q] / wsum + 0.5);
+          r = decltype(v)::prepare(a, target);
+          if (r < 0) return r;
+          if (r > lds) lds = r;
+          m.first[q] = blocks;
+          blocks += a.cblocks * a.oblocks * a.nchunks;
+        }
+        m.first[cnt] = blocks;
+        return decltype(v)::launch(m, lds, (hipStream_t)stream);
+      });
+      if (rc != HDRSKY_OK) return rc;
     }
   }
-  hipStream_t s = (hipStream_t)stream;
-  const bool precise = d->compute == HDRSKY_BF16X3;
-  {  // LDS budget: a strided halo tile with 64 channels (x2 planes in BF16X3) can exceed 160 KB -> 32-channel blocks
-    const int th = 128 / tw;   // (hook-forced shapes that do not fit return EUNSUPPORTED from the launcher)
-    const int npix = ((th - 1) * d->stride + d->KH) * ((tw - 1) * d->stride + d->KW);
-    const int planes = precise ? 2 : 1;
-    if (!narrow && cbf == 4 && planes * (npix * (64 * 2 + 16) + 128 * (obf * 32 + 16)) > 150 * 1024) cbf = 2;
-  }
-  if (narrow) return precise ? dispatch_wgrad<true, true>(a, tpw, cbf, obf, tw, s) : dispatch_wgrad<true, false>(a, tpw, cbf, obf, tw, s);
-  return precise ? dispatch_wgrad<false, true>(a, tpw, cbf, obf, tw, s) : dispatch_wgrad<false, false>(a, tpw, cbf, obf, tw, s);
+  return HDRSKY_OK;
+}
+
+extern "C" int hdrsky_conv2d_wgrad(const hdrsky_conv_desc* d, const float* x, const float* dy, const float* in_scale,
+                                   const float* in_shift, const float* in_part, const float* in_gamma,
+                                   const float* in_beta, float* dw, float* db, void* stream) {
+  if (!d) return HDRSKY_EINVAL;
+  hdrsky_wgrad_job j{};
+  j.desc = *d;
+  j.x = x; j.dy = dy; j.in_scale = in_scale; j.in_shift = in_shift; j.in_part = in_part; j.in_gamma = in_gamma;
+  j.in_beta = in_beta; j.dw = dw; j.db = db;
+  return hdrsky_conv2d_wgrad_multi(&j, 1, stream);
 }

@@ -132,20 +132,25 @@ __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, con
 // Backward of y = leaky(IN(x)) (optionally followed by the 2x2 max-pool), data gradient only:
 //   g  = upstream routed through pool-argmax (first max in scan order) and the activation mask
 //   dx = gamma*rstd * (g - mean_hw(g) - xhat*mean_hw(g*xhat))
-// One block per (sample, 16-channel group); two passes over the group's H*W*16 values (L2-resident).
-// Also returns per-(b,c) sums (sum g, sum g*xhat) = (dbeta, dgamma) contributions when requested.
-// Used by the Grad-CAM sweep (grad_cam.py:31 tf.gradients through sunpose_net.py:20-30,55-62).
+// A block owns (sample, 16-channel group, spatial slice).  MODE 0 writes the slice's (sum g, sum g*xhat) to the
+// workspace, MODE 1 adds the slices of its sample in a fixed order and applies the formula to its slice, MODE 2
+// (one slice) does both in one launch.  The per-(b,c) sums are also the (dbeta, dgamma) contributions.
+// Used by the Grad-CAM sweep (grad_cam.py:31 tf.gradients through sunpose_net.py:20-30,55-62) and the IN backward
+// of the training step (train.py:402).
 // ---------------------------------------------------------------------------------------------
+template <int MODE>
 __global__ void __launch_bounds__(256) norm_act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ part,
                                                            int nparts, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps, float slope,
                                                            const float* __restrict__ dy, int pooled,
                                                            float* __restrict__ dx, float* __restrict__ sums,
-                                                           float* dgamma, float* dbeta, int B, int H, int W, int C) {
+                                                           float* dgamma, float* dbeta, float* __restrict__ ws, int S,
+                                                           int B, int H, int W, int C) {
   __shared__ float sRed[64][2][16];
   __shared__ float sM[2][16];
   const int groups = C >> 4;
-  const int b = blockIdx.x / groups, cg = blockIdx.x % groups;
+  const int sl_id = blockIdx.x % S;
+  const int b = (blockIdx.x / S) / groups, cg = (blockIdx.x / S) % groups;
   const int cl = (threadIdx.x & 3) * 4;      // channel offset inside the group (float4)
   const int slot = threadIdx.x >> 2;         // 64 pixel slots
   const int c = cg * 16 + cl;
@@ -180,28 +185,46 @@ __global__ void __launch_bounds__(256) norm_act_bwd_kernel(const float* __restri
   const float* xb = x + (size_t)b * H * W * C + c;
   float* dxb = dx + (size_t)b * H * W * C + c;
   const int Hp = H >> 1, Wp = W >> 1;
-  const float* dyb = dy + (size_t)b * (pooled ? Hp * Wp : H * W) * C + c;
-
-  auto grad_at = [&](int pix, const float4& xv, float (&xh)[4], float (&g)[4], const float4& up) {
-    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-    const float us[4] = {up.x, up.y, up.z, up.w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      xh[j] = (xs[j] - mean[j]) * rstd[j];
-      const float pre = xh[j] * gm[j] + bt[j];
-      g[j] = us[j] * (pre > 0.f ? 1.f : slope);
-    }
-    (void)pix;
-  };
+  const int nunits = pooled ? Hp * Wp : H * W;            // pixels, or 2x2 windows
+  const int per = (nunits + S - 1) / S;
+  const int u0 = sl_id * per, u1 = min(nunits, u0 + per);
+  const float* dyb = dy + (size_t)b * nunits * C + c;
 
   float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
-  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+  for (int pass = (MODE == 1 ? 1 : 0); pass < (MODE == 0 ? 1 : 2); ++pass) {
+    if (pass == 1 && MODE == 1) {
+      // totals of this (sample, channel group) over the S slices, fixed order
+      if (threadIdx.x < 32) {
+        const int which = threadIdx.x >> 4, ch = threadIdx.x & 15;
+        float t = 0.f;
+        for (int k = 0; k < S; ++k) t += ws[(((size_t)b * S + k) * 2 + which) * C + cg * 16 + ch];
+        sM[which][ch] = t;
+        if (sl_id == 0) {
+          if (sums) sums[((size_t)b * 2 + which) * C + cg * 16 + ch] = t;
+          if (which == 0 && dbeta) atomicAdd(dbeta + cg * 16 + ch, t);
+          if (which == 1 && dgamma) atomicAdd(dgamma + cg * 16 + ch, t);
+        }
+      }
+      __syncthreads();
+      const float inv_count = 1.f / (float)(H * W);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s1[j] = sM[0][cl + j] * inv_count; s2[j] = sM[1][cl + j] * inv_count; }
+    }
     if (!pooled) {
-      for (int p = slot; p < H * W; p += 64) {
+#pragma unroll 4
+      for (int p = u0 + slot; p < u1; p += 64) {
         const float4 xv = *reinterpret_cast<const float4*>(xb + (size_t)p * C);
         const float4 up = *reinterpret_cast<const float4*>(dyb + (size_t)p * C);
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+        const float us[4] = {up.x, up.y, up.z, up.w};
         float xh[4], g[4];
-        grad_at(p, xv, xh, g, up);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          xh[j] = (xs[j] - mean[j]) * rstd[j];
+          const float pre = xh[j] * gm[j] + bt[j];
+          g[j] = us[j] * (pre > 0.f ? 1.f : slope);
+        }
         if (pass == 0) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) { s1[j] += g[j]; s2[j] += g[j] * xh[j]; }
@@ -215,7 +238,8 @@ __global__ void __launch_bounds__(256) norm_act_bwd_kernel(const float* __restri
         }
       }
     } else {
-      for (int pw = slot; pw < Hp * Wp; pw += 64) {
+#pragma unroll 2
+      for (int pw = u0 + slot; pw < u1; pw += 64) {
         const int ph = pw / Wp, px = pw % Wp;
         const float4 up = *reinterpret_cast<const float4*>(dyb + (size_t)pw * C);
         const float us[4] = {up.x, up.y, up.z, up.w};
@@ -225,6 +249,9 @@ __global__ void __launch_bounds__(256) norm_act_bwd_kernel(const float* __restri
         for (int k = 0; k < 4; ++k) {
           const int p = (2 * ph + (k >> 1)) * W + 2 * px + (k & 1);
           xv[k] = *reinterpret_cast<const float4*>(xb + (size_t)p * C);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
           const float xs[4] = {xv[k].x, xv[k].y, xv[k].z, xv[k].w};
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -272,15 +299,21 @@ __global__ void __launch_bounds__(256) norm_act_bwd_kernel(const float* __restri
         const int which = threadIdx.x >> 4, ch = threadIdx.x & 15;
         float t = 0.f;
         for (int k = 0; k < 64; ++k) t += sRed[k][which][ch];
-        sM[which][ch] = t;
-        if (sums) sums[((size_t)b * 2 + which) * C + cg * 16 + ch] = t;
-        if (which == 0 && dbeta) atomicAdd(dbeta + cg * 16 + ch, t);
-        if (which == 1 && dgamma) atomicAdd(dgamma + cg * 16 + ch, t);
+        if (MODE == 0) {
+          ws[(((size_t)b * S + sl_id) * 2 + which) * C + cg * 16 + ch] = t;
+        } else {
+          sM[which][ch] = t;
+          if (sums) sums[((size_t)b * 2 + which) * C + cg * 16 + ch] = t;
+          if (which == 0 && dbeta) atomicAdd(dbeta + cg * 16 + ch, t);
+          if (which == 1 && dgamma) atomicAdd(dgamma + cg * 16 + ch, t);
+        }
       }
-      __syncthreads();
-      const float inv_count = 1.f / (float)(H * W);
+      if (MODE == 2) {
+        __syncthreads();
+        const float inv_count = 1.f / (float)(H * W);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { s1[j] = sM[0][cl + j] * inv_count; s2[j] = sM[1][cl + j] * inv_count; }
+        for (int j = 0; j < 4; ++j) { s1[j] = sM[0][cl + j] * inv_count; s2[j] = sM[1][cl + j] * inv_count; }
+      }
     }
   }
 }
@@ -595,13 +628,36 @@ int hdrsky_bn_eval_affine(const float* gamma, const float* beta, const float* mo
   return HDRSKY_OK;
 }
 
+// spatial slices per (sample, 16-channel group): aim for >= 512 workgroups, at least 64 pixels (windows) each
+int hdrsky_norm_act_bwd_nslices(int B, int H, int W, int C, int pooled) {
+  const int units = pooled ? (H / 2) * (W / 2) : H * W;
+  const int groups = B * (C / 16);
+  int S = groups > 0 ? (512 + groups - 1) / groups : 1;
+  const int smax = units / 64 > 0 ? units / 64 : 1;
+  if (S > smax) S = smax;
+  if (S > 64) S = 64;
+  return S < 1 ? 1 : S;
+}
+
 int hdrsky_norm_act_bwd(const float* x, const float* part, int nparts, const float* gamma, const float* beta,
                         float eps, float slope, const float* dy, int pooled, float* dx, float* sums, float* dgamma,
-                        float* dbeta, int B, int H, int W, int C, void* stream) {
+                        float* dbeta, float* ws, int B, int H, int W, int C, void* stream) {
   if (!x || !part || !gamma || !beta || !dy || !dx || (C & 15)) return HDRSKY_EINVAL;
   if (pooled && ((H | W) & 1)) return HDRSKY_EINVAL;
-  hipLaunchKernelGGL(norm_act_bwd_kernel, dim3(B * (C / 16)), dim3(256), 0, (hipStream_t)stream, x, part, nparts,
-                     gamma, beta, eps, slope, dy, pooled, dx, sums, dgamma, dbeta, B, H, W, C);
+  const int S = hdrsky_norm_act_bwd_nslices(B, H, W, C, pooled);
+  const int groups = B * (C / 16);
+  if (S == 1) {
+    hipLaunchKernelGGL(norm_act_bwd_kernel<2>, dim3(groups), dim3(256), 0, (hipStream_t)stream, x, part, nparts, gamma,
+                       beta, eps, slope, dy, pooled, dx, sums, dgamma, dbeta, ws, 1, B, H, W, C);
+    HDRSKY_CHECK_LAUNCH();
+    return HDRSKY_OK;
+  }
+  if (!ws) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(norm_act_bwd_kernel<0>, dim3(groups * S), dim3(256), 0, (hipStream_t)stream, x, part, nparts, gamma,
+                     beta, eps, slope, dy, pooled, dx, sums, dgamma, dbeta, ws, S, B, H, W, C);
+  HDRSKY_CHECK_LAUNCH();
+  hipLaunchKernelGGL(norm_act_bwd_kernel<1>, dim3(groups * S), dim3(256), 0, (hipStream_t)stream, x, part, nparts, gamma,
+                     beta, eps, slope, dy, pooled, dx, sums, dgamma, dbeta, ws, S, B, H, W, C);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }

@@ -192,6 +192,36 @@ def conv2d_wgrad(x, dy, KH, KW, stride=1, same=True, upsample=1, xf: Optional[In
     return dw, db
 
 
+def wgrad_job(x, dy, KH, KW, dw, db=None, stride=1, same=True, upsample=1, xf: Optional[InXf] = None, compute=BF16):
+    """One entry for conv2d_wgrad_multi: dw [KH,KW,Cin,Cout] (+= ; must hold valid values, e.g. zeros), db [Cout] or None.
+    The returned job references its tensors, which keeps them alive until the launch."""
+    _f32(x); _f32(dy)
+    B, H, W, C = x.shape
+    Cout = dy.shape[-1]
+    d = conv_desc(B, H, W, C, Cout, KH, KW, stride, same, upsample)
+    if tuple(dy.shape) != (B, d.Ho, d.Wo, Cout):
+        raise ValueError("dy shape %s does not match the conv output %s" % (tuple(dy.shape), (B, d.Ho, d.Wo, Cout)))
+    d.compute = compute
+    tabs = _xf_args(d, xf, B, H, W, C)
+    _f32(dw, KH, KW, C, Cout)
+    if db is not None:
+        _f32(db, Cout)
+    return (d, x, dy, tabs, dw, db)
+
+
+def conv2d_wgrad_multi(jobs):
+    """Weight gradients of several independent conv layers in as few launches as the library can manage."""
+    if not jobs:
+        return
+    arr = (L.WgradJob * len(jobs))()
+    for i, (d, x, dy, tabs, dw, db) in enumerate(jobs):
+        j = arr[i]
+        j.desc = d
+        j.x, j.dy, j.dw, j.db = _p(x), _p(dy), _p(dw), _p(db)
+        j.in_scale, j.in_shift, j.in_part, j.in_gamma, j.in_beta = [_p(t) for t in tabs]
+    L.check(L.load().hdrsky_conv2d_wgrad_multi(arr, len(jobs), _stream()), "conv2d_wgrad_multi")
+
+
 def norm_apply(x, stats: Stats, gamma, beta, slope=1.0, residual=None, pool=False, eps=IN_EPS):
     """y = leaky(IN(x)) [+ residual]; optionally also the 2x2 max-pool of y.  Returns y or (y, ypool)."""
     _f32(x)
@@ -236,9 +266,11 @@ def norm_act_bwd(x, stats: Stats, gamma, beta, slope, dy, pooled, eps=IN_EPS, wa
     _f32(dy, B, H // 2 if pooled else H, W // 2 if pooled else W, C)
     dx = torch.empty_like(x)
     sums = torch.empty((B, 2, C), dtype=torch.float32, device=x.device) if want_sums else None
+    S = L.load().hdrsky_norm_act_bwd_nslices(B, H, W, C, int(pooled))
+    ws = torch.empty((B, S, 2, C), dtype=torch.float32, device=x.device) if S > 1 else None
     L.check(L.load().hdrsky_norm_act_bwd(_p(x), _p(stats.part), stats.nparts, _p(_f32(gamma, C)), _p(_f32(beta, C)),
                                          eps, slope, _p(dy), int(pooled), _p(dx), _p(sums), _p(dgamma), _p(dbeta),
-                                         B, H, W, C, _stream()),
+                                         _p(ws), B, H, W, C, _stream()),
             "norm_act_bwd")
     return (dx, sums) if want_sums else dx
 

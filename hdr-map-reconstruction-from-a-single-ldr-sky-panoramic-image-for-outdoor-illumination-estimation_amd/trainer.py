@@ -78,9 +78,9 @@ class _Conv:
         return K.conv2d(x, self.pk, self.b, stride=self.stride, same=self.same, upsample=self.upsample, xf=xf,
                         compute=compute, **kw)
 
-    def wgrad(self, x, xf, dy, gw, gb, compute):
-        K.conv2d_wgrad(x, dy, self.kh, self.kw, stride=self.stride, same=self.same, upsample=self.upsample, xf=xf,
-                       compute=compute, dw=gw, db=gb, want_db=gb is not None)
+    def wgrad_job(self, x, xf, dy, gw, gb, compute):
+        return K.wgrad_job(x, dy, self.kh, self.kw, gw, gb, stride=self.stride, same=self.same, upsample=self.upsample,
+                           xf=xf, compute=compute)
 
     def dgrad(self, x, dy, compute, residual=None, want_stats=False, out=None):
         """Gradient wrt the (transformed, pre-resize) conv operand."""
@@ -105,6 +105,8 @@ class Trainer:
         self.side_stream = torch.cuda.Stream(device=self.device)
         self.side_stream2 = torch.cuda.Stream(device=self.device)
         self.losses = torch.zeros(len(LOSS_SLOTS), dtype=torch.float32, device=self.device)
+        self._wjobs, self._wkeep = {}, []
+        self.wgrad_stream = torch.cuda.Stream(device=self.device)
         self._build_layers()
 
     # -------------------------------------------------------------------------------------------------
@@ -168,9 +170,34 @@ class Trainer:
                               dgamma=g[name + ".gamma"], dbeta=g[name + ".beta"])
 
     def _wg(self, name, x, xf, dy):
+        """Queues the weight gradient of one conv layer.  Nothing in the backward chain consumes it, and ~40 of them
+        one by one would each need the whole chip: they are launched together (per stream, `_flush_wgrads`) so that
+        layers of similar geometry share a launch.  The queued job keeps its operands referenced until then."""
         cv = self.conv[name]
         grads = self.ds.g if name.startswith("dis.") else self.gs.g
-        cv.wgrad(x, xf, dy, grads[cv.wkey], grads[cv.bkey] if cv.bkey else None, self.compute)
+        q = self._wjobs.setdefault(torch.cuda.current_stream().cuda_stream, [])
+        q.append(cv.wgrad_job(x, xf, dy, grads[cv.wkey], grads[cv.bkey] if cv.bkey else None, self.compute))
+
+    def _flush_wgrads(self, handoff=False):
+        """Launches the weight gradients queued on the current stream - on this stream, or (handoff) on the wgrad
+        stream behind an event, so that they run beside the rest of this stream's backward chain instead of at its
+        tail.  Handed-off jobs stay referenced until `_join_wgrads`."""
+        cur = torch.cuda.current_stream()
+        q = self._wjobs.pop(cur.cuda_stream, None)
+        if not q:
+            return
+        if not handoff:
+            K.conv2d_wgrad_multi(q)
+            return
+        self.wgrad_stream.wait_stream(cur)
+        with torch.cuda.stream(self.wgrad_stream):
+            K.conv2d_wgrad_multi(q)
+        self._wkeep.extend(q)
+
+    def _join_wgrads(self):
+        if self._wkeep:
+            torch.cuda.current_stream().wait_stream(self.wgrad_stream)
+            self._wkeep.clear()
 
     # ---- generator forward (training mode) --------------------------------------------------------------
     def _gen_forward(self, ldr, pick_src):
@@ -434,6 +461,7 @@ class Trainer:
                 self._wg("dis.out", Rd["d4"]["raw"], Rd["xf_out"], dl)
                 da4 = cvo.dgrad(Rd["d4"]["raw"], dl, cp)
                 self._down_stack_bwd("dis.", self.ds.w, self.ds.g, Rd, da4, training=True, want_input_grad=False)
+            self._flush_wgrads()
         # ---- sun-pose conv layers (sunpose_net.py:54-62) --------------------------------------------------------
         with torch.cuda.stream(sA):
             for l in (3, 2, 1):
@@ -445,6 +473,7 @@ class Trainer:
                 self._wg(n + ".conv1", t["in%d" % l], None, dr1)
                 if l > 1:
                     dP = c[n + ".conv1"].dgrad(t["in%d" % l], dr1, cp)
+            self._flush_wgrads()
         # ---- generator: decoders, sun radiance stack, encoder -----------------------------------------------------
         dres = torch.zeros_like(S["x"][-1])
         for sfx in ("f", "u"):
@@ -458,12 +487,14 @@ class Trainer:
             dd3 = self._in_bwd(d3, s3, "gen.norm3_" + sfx, 0.1, da3)
             self._wg("gen.conv3_" + sfx, S["x"][-1], None, dd3)
             c["gen.conv3_" + sfx].dgrad(S["x"][-1], dd3, cp, out=dres)
+        self._flush_wgrads(handoff=True)
         R = S["sunrad"]    # sun radiance head (generator.py:158-169, sunrad_net.py:46-70)
         xf = R["xf_out"]
         dact4 = K.dense_heads_bwd(R["d4"]["raw"], xf.scale, xf.shift, 0.3, w["gen.sun.gamma.kernel"], w["gen.sun.beta.kernel"],
                                   dpre, g["gen.sun.gamma.kernel"], g["gen.sun.beta.kernel"], g["gen.sun.gamma.bias"],
                                   g["gen.sun.beta.bias"])
         self._down_stack_bwd("gen.sun.", w, g, R, dact4, training=True, want_input_grad=False)
+        self._flush_wgrads(handoff=True)
         dx = dres          # encoder (generator.py:92-108, resBlock :26-35)
         for i in range(5, -1, -1):
             p = "gen.res.%d." % i
@@ -474,6 +505,7 @@ class Trainer:
             dr1 = self._in_bwd(r1, t1, p + "norm1", 0.1, da1)
             self._wg(p + "conv1", S["x"][i], None, dr1)
             dx = c[p + "conv1"].dgrad(S["x"][i], dr1, cp, residual=dx)      # + identity branch
+        self._flush_wgrads(handoff=True)
         dc3 = self._in_bwd(S["c3"], S["s3"], "gen.norm3_d", 0.1, dx)
         self._wg("gen.conv3_d", S["c2"], S["xf3"], dc3)
         da2 = c["gen.conv3_d"].dgrad(S["c2"], dc3, cp)
@@ -482,7 +514,9 @@ class Trainer:
         da1 = c["gen.conv2_d"].dgrad(S["c1"], dc2, cp)
         dc1 = self._in_bwd(S["c1"], S["s1"], "gen.norm1_d", 0.1, da1)
         self._wg("gen.conv1_d", ldr, None, dc1)
+        self._flush_wgrads()
         main.wait_stream(sA); main.wait_stream(sB)
+        self._join_wgrads()
 
     def apply_gradients(self, gscale=1.0):
         """optimizer_gen / optimizer_disc .apply_gradients (train.py:403,406): RMSprop(lr), then refresh the packed

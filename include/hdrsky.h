@@ -138,7 +138,9 @@ int hdrsky_bn_eval_affine(const float* gamma, const float* beta, const float* mo
  * fp32 atomics.  tf.gradients path of grad_cam.py:31 and the IN backward of train.py:402. */
 int hdrsky_norm_act_bwd(const float* x, const float* part, int nparts, const float* gamma, const float* beta,
                         float eps, float slope, const float* dy, int pooled, float* dx, float* sums, float* dgamma,
-                        float* dbeta, int B, int H, int W, int C, void* stream);
+                        float* dbeta, float* ws, int B, int H, int W, int C, void* stream);
+/* Spatial slices S the call above splits each sample into; when S > 1 it needs the workspace ws [B][S][2][C]. [host] */
+int hdrsky_norm_act_bwd_nslices(int B, int H, int W, int C, int pooled);
 
 /* ------------------------------------------------------------------------------------------
  * Sun-pose dense head (sunpose_net.py:48-52,64-70) and its Grad-CAM backward (grad_cam.py:29-44)
@@ -200,6 +202,23 @@ int hdrsky_leaky_relu(const float* x, float* y, size_t n, float slope, void* str
 int hdrsky_conv2d_wgrad(const hdrsky_conv_desc* d, const float* x, const float* dy, const float* in_scale,
                         const float* in_shift, const float* in_part, const float* in_gamma, const float* in_beta,
                         float* dw, float* db, void* stream);
+
+/* Several independent weight gradients in as few launches as possible (layers of similar geometry share a launch;
+ * a training step has ~40 of them and each is far too small for 256 CUs on its own).  `jobs` is a HOST array; the
+ * device pointers in it follow hdrsky_conv2d_wgrad.  Same semantics as njobs single calls on `stream`. */
+typedef struct hdrsky_wgrad_job {
+  hdrsky_conv_desc desc;
+  const float* x;
+  const float* dy;
+  const float* in_scale;
+  const float* in_shift;
+  const float* in_part;
+  const float* in_gamma;
+  const float* in_beta;
+  float* dw;
+  float* db;
+} hdrsky_wgrad_job;
+int hdrsky_conv2d_wgrad_multi(const hdrsky_wgrad_job* jobs, int njobs, void* stream);
 
 /* Keras BatchNormalization(training=True) statistics from the producing conv's partials [nparts_total][2][C]
  * (discriminator.py:25, sunrad_net.py:26): mean/rstd/scale/shift tables + moving-stat update (momentum 0.99,

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--cfg", default="")
     ap.add_argument("--only", default="")
+    ap.add_argument("--group", type=int, default=0, help="N copies of each layer in ONE multi launch (per-layer time)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     B = args.batch
@@ -50,16 +51,25 @@ def main():
             else: os.environ.pop("HDRSKY_WGRAD", None)
             try:
                 dw, db = K.conv2d_wgrad(x, dy, k, k, stride, True, up)
+                if args.group:
+                    xs = [torch.randn_like(x) for _ in range(args.group)]
+                    dys = [torch.randn_like(dy) for _ in range(args.group)]
+                    jobs = [K.wgrad_job(xs[i], dys[i], k, k, torch.zeros_like(dw), torch.zeros_like(db), stride=stride,
+                                        upsample=up) for i in range(args.group)]
+                    K.conv2d_wgrad_multi(jobs)
             except Exception as e:
                 res.append("%s: n/a" % t); continue
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 for _ in range(args.iters):
-                    K.conv2d_wgrad(x, dy, k, k, stride, True, up, dw=dw, db=db)
+                    if args.group:
+                        K.conv2d_wgrad_multi(jobs)
+                    else:
+                        K.conv2d_wgrad(x, dy, k, k, stride, True, up, dw=dw, db=db)
             g.replay(); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) * 1e3 / args.iters
+            us = e0.elapsed_time(e1) * 1e3 / args.iters / max(1, args.group)
             total[ci] += us * cnt
             res.append("%s: %6.2f us %5.1f TF" % (t or "auto", us, flop / us / 1e6))
         print("%-24s %5.2f GF x%-2d | %s" % (name, flop / 1e9, cnt, " | ".join(res)), flush=True)

@@ -67,3 +67,34 @@ def test_wgrad_with_fused_in_transform(dev):
     xf = K.InXf(mode=L.IN_PARTIALS, slope=0.1, stats=st, gamma=d(gam), beta=d(bet))
     dw, _ = K.conv2d_wgrad(r1, dy.to(dev), 3, 3, xf=xf, compute=K.BF16X3)
     assert_close(dw, gw, 4e-4, "fused-operand wgrad")
+
+
+def test_wgrad_multi_matches_autograd(dev):
+    """hdrsky_conv2d_wgrad_multi: a mixed list of layers (>= 3 wide stride-1 layers -> the large-block grouped geometry,
+    plus narrow / 7x7 / strided / resize-deconv layers in the same call) against torch autograd of the oracle conv."""
+    K = pkg("kernels")
+    B = 3
+    shapes = [("res a", 8, 32, 128, 128, 3, 1, 1), ("res b", 8, 32, 128, 128, 3, 1, 1), ("l3a", 8, 32, 64, 128, 3, 1, 1),
+              ("l2b", 16, 64, 64, 64, 3, 1, 1), ("d4", 4, 16, 256, 512, 4, 1, 1), ("up", 8, 32, 128, 64, 3, 1, 2),
+              ("conv1", 32, 128, 3, 32, 7, 1, 1), ("l1b", 16, 64, 32, 32, 7, 1, 1), ("d2", 16, 64, 64, 128, 4, 2, 1)]
+    for compute, tol in ((K.BF16X3, 3e-4), (K.BF16, None)):
+        jobs, refs = [], []
+        for name, H, W, Cin, Cout, k, stride, up in shapes:
+            rng = np.random.default_rng(zlib.crc32(name.encode()))
+            x = torch.from_numpy(rng.standard_normal((B, H, W, Cin)).astype(np.float32))
+            w = torch.zeros(k, k, Cin, Cout, requires_grad=True)
+            b = torch.zeros(Cout, requires_grad=True)
+            xin = T.resize_bilinear(x, 2 * H, 2 * W) if up == 2 else x
+            y = T.conv2d(xin, w, b, stride, "SAME")
+            dy = torch.from_numpy(rng.standard_normal(tuple(y.shape)).astype(np.float32))
+            refs.append(torch.autograd.grad(y, (w, b), dy))
+            dw = torch.zeros(k, k, Cin, Cout, device=dev)
+            db = torch.zeros(Cout, device=dev)
+            jobs.append(K.wgrad_job(x.to(dev), dy.to(dev), k, k, dw, db, stride=stride, upsample=up, compute=compute))
+        K.conv2d_wgrad_multi(jobs)
+        for (name, *_), job, (gw, gb) in zip(shapes, jobs, refs):
+            if tol is None:
+                assert_close_bf16(job[4], gw, name + " dw bf16 (multi)")
+            else:
+                assert_close(job[4], gw, tol, name + " dw (multi)")
+            assert_close(job[5], gb, 1e-4, name + " db (multi)")
