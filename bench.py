@@ -139,67 +139,56 @@ def main():
     if args.workload == "fwd":
         nets = engine.Nets(gen, sun, device=dev, precise=False)
         phases = [lambda: engine.generator_forward(nets, ldr, compute=K.BF16)]
-        between = None
         roof_pw, roof_b = nets.pk["gen.res.0.conv1"], nets.gen["res.0.conv1.b"]
         probe = lambda out: out["y_final_lin"]
     else:
         tr = trainer.Trainer(gen, sun, dis, vgg, device=dev, precise=False, compute=K.BF16, world_size=world)
-        # phase A: forward + both backward passes (gradients of this replica's batch-32 step);
-        # between: sum the gradients over replicas (RCCL all-reduce; every loss is a batch mean, so the data-parallel
-        #          gradient is the replica average: SURVEY.md section 8e); phase B: RMSprop x2 + weight re-packing.
-        # A1: forward, losses, backward down to the sun-pose Dense gradients; A2: the rest of both backward passes;
-        # B: RMSprop x2 + weight re-packing.  N > 1: the all-reduce of the Dense-gradient slice (201 of the 233 MB)
-        # is started after A1 and runs on RCCL's stream while A2 computes; the remaining 32 MB follow A2.
-        phases = [lambda: tr.step_a1(ldr, hdr, gt), lambda: tr.step_a2(), lambda: tr.apply_gradients(gscale=1.0 / world)]
+        # One step = the Trainer's segment plan (forward, losses, both backward passes, RMSprop x2 + weight re-packing),
+        # every segment captured into its own hipGraph and replayed on its stream.  N > 1: each replica runs the
+        # reference's batch-32 step on its shard; gradients are summed over replicas (RCCL all-reduce; every loss is a
+        # batch mean, so the data-parallel gradient is the replica average: SURVEY.md section 8e) and scaled by 1/world
+        # inside the RMSprop kernel.  The all-reduce of the sun-pose Dense gradients (201 of the 233 MB) is started as
+        # soon as they are complete and runs on RCCL's stream beside the rest of the backward pass; the remaining
+        # 32 MB follow when every gradient is ready.
         par.broadcast_params_([tr.gs.flat, tr.ds.flat])   # replicas start from rank 0's weights
         tr.repack()
         fc0, fc1 = tr.fc_grad_range()
         pending = []
 
-        def after_a1():
+        def fc_grads_ready():
             pending.append(dist.all_reduce(tr.gs.grad[fc0:fc1], async_op=True))
 
-        def after_a2():
+        def grads_ready():
             pending.pop().wait()
             dist.all_reduce(tr.gs.grad[:fc0])
             dist.all_reduce(tr.ds.grad)
-        between = [after_a1, after_a2] if dp else None
-        if not dp:   # single GPU: the two parts are captured as one graph
-            phases = [lambda: tr.step(ldr, hdr, gt, update=False), lambda: tr.apply_gradients(gscale=1.0)]
+        hooks = {tr.FC_GRADS_READY: fc_grads_ready, tr.GRADS_READY: grads_ready} if dp else None
         roof_pw, roof_b = tr.conv["gen.res.0.conv1"].pk, tr.gs.w["gen.res.0.conv1.b"]
         probe = lambda out: out["y_final_lin"]
+        if args.no_graph:
+            out = tr.step(ldr, hdr, gt, update=False)
+            one_step = lambda: (tr.step(ldr, hdr, gt, update=False), hooks and [h() for h in hooks.values()], tr.apply_gradients())
+        else:
+            out = tr.capture(ldr, hdr, gt)
+            one_step = lambda: tr.replay(hooks=hooks)
+        phases = None
 
-    # warm-up (eager) then capture each phase into a hipGraph
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(2):
-            for i, ph in enumerate(phases):
-                o = ph()
-                if i == 0:
-                    out = o
-                if between and i < len(between):
-                    between[i]()
-    torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
-    runs = []
-    if args.no_graph:
-        runs = list(phases)
-    else:
-        for i, ph in enumerate(phases):
+    if phases is not None:   # forward workload: warm-up (eager), then the whole forward captured as one hipGraph
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                out = phases[0]()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        if args.no_graph:
+            one_step = phases[0]
+        else:
             g = torch.cuda.CUDAGraph()
             # thread_local: RCCL's watchdog thread may query events while this thread captures
             with torch.cuda.graph(g, capture_error_mode="thread_local" if dp else "global"):
-                o = ph()
-            if i == 0:
-                out = o
-            runs.append(g.replay)
-
-    def one_step():
-        for i, r in enumerate(runs):
-            r()
-            if between and i < len(between):
-                between[i]()
+                out = phases[0]()
+            one_step = g.replay
 
     for _ in range(args.warmup):
         one_step()

@@ -2,6 +2,8 @@
 // residual, 2x2 max-pool), their backward (Grad-CAM sweep and training), soft-max and its
 // picked-probability backward, Grad-CAM maps, the sun-radiance Dirac-delta head, tone mapping
 // and alpha blending.  All fp32; float4 (16 B / lane) accesses; wave64 shuffles for reductions.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -594,9 +596,34 @@ __global__ void leaky_relu_kernel(const float* __restrict__ x, float* __restrict
   }
 }
 
+// Debug aid: workgroups that sit on the CUs with a known LDS pattern and report words that change under them
+// (= some co-resident workgroup of another kernel wrote outside its own LDS allocation).  Bounded loop.
+__global__ void __launch_bounds__(64) lds_canary_kernel(int iters, unsigned int* report) {
+  __shared__ unsigned int pat[1024];
+  for (int i = threadIdx.x; i < 1024; i += 64) pat[i] = 0xC0FFEE00u ^ (unsigned)i;
+  __syncthreads();
+  for (int it = 0; it < iters; ++it) {
+    __builtin_amdgcn_s_sleep(64);
+    for (int i = threadIdx.x; i < 1024; i += 64) {
+      const unsigned int v = pat[i];
+      if (v != (0xC0FFEE00u ^ (unsigned)i)) {
+        const unsigned int n = atomicAdd(report, 1u);
+        if (n < 15) { report[1 + 2 * n] = (unsigned)i; report[2 + 2 * n] = v; }
+        pat[i] = 0xC0FFEE00u ^ (unsigned)i;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int hdrsky_debug_lds_canary(int nblocks, int iters, void* report, void* stream) {
+  hipLaunchKernelGGL(lds_canary_kernel, dim3(nblocks), dim3(64), 0, (hipStream_t)stream, iters, (unsigned int*)report);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
 
 int hdrsky_norm_apply(const float* x, const float* part, int nparts, const float* gamma, const float* beta, float eps,
                       float slope, const float* residual, float* y, float* ypool, int B, int H, int W, int C,
@@ -628,12 +655,13 @@ int hdrsky_bn_eval_affine(const float* gamma, const float* beta, const float* mo
   return HDRSKY_OK;
 }
 
-// spatial slices per (sample, 16-channel group): aim for >= 512 workgroups, at least 64 pixels (windows) each
+// spatial slices per (sample, 16-channel group): aim for >= 512 workgroups, at least 256 pixels (windows) each
 int hdrsky_norm_act_bwd_nslices(int B, int H, int W, int C, int pooled) {
   const int units = pooled ? (H / 2) * (W / 2) : H * W;
   const int groups = B * (C / 16);
-  int S = groups > 0 ? (512 + groups - 1) / groups : 1;
-  const int smax = units / 64 > 0 ? units / 64 : 1;
+  static const int target = getenv("HDRSKY_NAB_TARGET") ? atoi(getenv("HDRSKY_NAB_TARGET")) : 512;   // tuning hook
+  int S = groups > 0 ? (target + groups - 1) / groups : 1;
+  const int smax = units / 256 > 0 ? units / 256 : 1;   // below ~256 pixels per slice the second launch costs more
   if (S > smax) S = smax;
   if (S > 64) S = 64;
   return S < 1 ? 1 : S;

@@ -608,12 +608,9 @@ __global__ void axpby_kernel(const float* __restrict__ a, float sa, const float*
 __global__ void __launch_bounds__(256) fc_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int M,
                                                        int K, int N, int accumulate, float* __restrict__ dw,
                                                        float* __restrict__ db) {
-  __shared__ float sx[32][8];  // [m][k-local]
   const int n4 = N >> 2;
   const int k0 = blockIdx.y * 8;
   const int nq = blockIdx.x * 256 + threadIdx.x;
-  for (int i = threadIdx.x; i < M * 8; i += 256) sx[i / 8][i % 8] = x[(size_t)(i / 8) * K + k0 + (i % 8)];
-  __syncthreads();
   if (nq >= n4) return;
   float4 acc[8];
 #pragma unroll
@@ -624,7 +621,7 @@ __global__ void __launch_bounds__(256) fc_wgrad_kernel(const float* __restrict__
     bs.x += d.x; bs.y += d.y; bs.z += d.z; bs.w += d.w;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const float xv = sx[m][k];
+      const float xv = x[(size_t)m * K + k0 + k];   // block-uniform address: a scalar load
       acc[k].x += xv * d.x; acc[k].y += xv * d.y; acc[k].z += xv * d.z; acc[k].w += xv * d.w;
     }
   }

@@ -102,11 +102,10 @@ class Trainer:
         self.gs = FlatParams(named, self.device)          # optimizer_gen: _gen + _sun variables (train.py:402-403)
         self.ds = FlatParams(OrderedDict(("dis." + k, v) for k, v in dis_params.items()), self.device)
         self.vgg = E._dev(vgg_params, self.device)
-        self.side_stream = torch.cuda.Stream(device=self.device)
-        self.side_stream2 = torch.cuda.Stream(device=self.device)
+        self._streams = [torch.cuda.Stream(device=self.device) for _ in range(4)]
+        self._graphs, self._gscale = None, 1.0 / world_size
         self.losses = torch.zeros(len(LOSS_SLOTS), dtype=torch.float32, device=self.device)
-        self._wjobs, self._wkeep = {}, []
-        self.wgrad_stream = torch.cuda.Stream(device=self.device)
+        self._wjobs = {}
         self._build_layers()
 
     # -------------------------------------------------------------------------------------------------
@@ -172,79 +171,18 @@ class Trainer:
     def _wg(self, name, x, xf, dy):
         """Queues the weight gradient of one conv layer.  Nothing in the backward chain consumes it, and ~40 of them
         one by one would each need the whole chip: they are launched together (per stream, `_flush_wgrads`) so that
-        layers of similar geometry share a launch.  The queued job keeps its operands referenced until then."""
+        layers of similar geometry share a launch - at the end of the segment that queued them, or in a segment of
+        their own on the wgrad stream.  The queued job keeps its operands referenced until then."""
         cv = self.conv[name]
         grads = self.ds.g if name.startswith("dis.") else self.gs.g
         q = self._wjobs.setdefault(torch.cuda.current_stream().cuda_stream, [])
         q.append(cv.wgrad_job(x, xf, dy, grads[cv.wkey], grads[cv.bkey] if cv.bkey else None, self.compute))
 
-    def _flush_wgrads(self, handoff=False):
-        """Launches the weight gradients queued on the current stream - on this stream, or (handoff) on the wgrad
-        stream behind an event, so that they run beside the rest of this stream's backward chain instead of at its
-        tail.  Handed-off jobs stay referenced until `_join_wgrads`."""
-        cur = torch.cuda.current_stream()
-        q = self._wjobs.pop(cur.cuda_stream, None)
-        if not q:
-            return
-        if not handoff:
+    def _flush_wgrads(self):
+        """Launches the weight gradients queued on the current stream."""
+        q = self._take_wgrads()
+        if q:
             K.conv2d_wgrad_multi(q)
-            return
-        self.wgrad_stream.wait_stream(cur)
-        with torch.cuda.stream(self.wgrad_stream):
-            K.conv2d_wgrad_multi(q)
-        self._wkeep.extend(q)
-
-    def _join_wgrads(self):
-        if self._wkeep:
-            torch.cuda.current_stream().wait_stream(self.wgrad_stream)
-            self._wkeep.clear()
-
-    # ---- generator forward (training mode) --------------------------------------------------------------
-    def _gen_forward(self, ldr, pick_src):
-        S, w, c, cp = {}, self.gs.w, self.conv, self.compute
-        # encoder (generator.py:92-108)
-        S["c1"], S["s1"] = c["gen.conv1_d"].fwd(ldr, compute=cp, want_stats=True)
-        S["xf2"] = self._inxf(S["s1"], "gen.norm1_d", 0.1)
-        S["c2"], S["s2"] = c["gen.conv2_d"].fwd(S["c1"], S["xf2"], cp, want_stats=True)
-        S["xf3"] = self._inxf(S["s2"], "gen.norm2_d", 0.1)
-        S["c3"], S["s3"] = c["gen.conv3_d"].fwd(S["c2"], S["xf3"], cp, want_stats=True)
-        x = K.norm_apply(S["c3"], S["s3"], w["gen.norm3_d.gamma"], w["gen.norm3_d.beta"], slope=0.1)
-        S["x"] = [x]
-        for i in range(6):
-            p = "gen.res.%d." % i
-            r1, t1 = c[p + "conv1"].fwd(x, compute=cp, want_stats=True)
-            xf = self._inxf(t1, p + "norm1", 0.1)
-            r2, t2 = c[p + "conv2"].fwd(r1, xf, cp, want_stats=True)
-            x = K.norm_apply(r2, t2, w[p + "norm2.gamma"], w[p + "norm2.beta"], slope=1.0, residual=x)
-            S["res%d" % i] = (r1, t1, xf, r2, t2)
-            S["x"].append(x)
-        res_out = x
-
-        def decode(sfx, residual):
-            d3, s3 = c["gen.conv3_" + sfx].fwd(res_out, compute=cp, want_stats=True)
-            xf2 = self._inxf(s3, "gen.norm3_" + sfx, 0.1)
-            d2, s2 = c["gen.conv2_" + sfx].fwd(d3, xf2, cp, want_stats=True)
-            xf1 = self._inxf(s2, "gen.norm2_" + sfx, 0.1)
-            y, _ = c["gen.conv1_" + sfx].fwd(d2, xf1, cp, out_slope=0.1, residual=residual, final_relu=True)
-            S["dec_" + sfx] = (d3, s3, xf2, d2, s2, xf1, y, residual)
-            return y
-
-        # the sun-pose branch runs beside the encoder / sky decoder on a second stream
-        main, side = torch.cuda.current_stream(), self.side_stream
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            t = self._sunpose_forward(ldr)
-            cams = self._gradcam(t, pick_src)
-            rad = self._sunrad_forward(ldr, cams, t, S)
-        sky_gamma = decode("f", ldr)
-        main.wait_stream(side)
-        S["t"], S["cams"] = t, cams
-        rad_lin, rad_gamma, gamma, beta = rad
-        sun_gamma = decode("u", rad_gamma)
-        y_gamma, y_lin, alpha, sky_lin, sun_lin = K.blend(sky_gamma, sun_gamma, E.THRESHOLD)
-        S.update(y_gamma=y_gamma, y_lin=y_lin, alpha=alpha, sky_gamma=sky_gamma, sun_gamma=sun_gamma, gamma=gamma, beta=beta,
-                 rad_gamma=rad_gamma, rad_lin=rad_lin, sky_lin=sky_lin, sun_lin=sun_lin, ldr=ldr)
-        return S
 
     def _sunpose_forward(self, ldr):
         w, c, cp = self.gs.w, self.conv, self.compute
@@ -376,94 +314,125 @@ class Trainer:
         return K.axpby(g, 255.0)   # d/d y_gamma of the 0.01-weighted perceptual term
 
     # ---- one training step -----------------------------------------------------------------------------------
-    def step(self, ldr, hdr_t, sunpose_gt, update=True):
-        """ldr / hdr_t [B,H,W,3] BGR (train.py:386-387 rgb2bgr already applied), sunpose_gt [B,H*W].
-        Returns the dict generator_in_step returns (train.py:349) - losses are in self.losses (device)."""
-        out = self.step_a1(ldr, hdr_t, sunpose_gt)
-        self.step_a2()
-        if update:
-            self.apply_gradients()
-        return out
-
-    def fc_grad_range(self):
-        """[start, end) of the two Dense layers' gradients inside gs.grad - contiguous, the last trainables of the
-        sun-pose net (50.3 M of the 58.3 M parameters): the slice whose all-reduce overlaps step_a2."""
-        o = self.gs.offsets["sun.fc1.kernel"][0]
-        return o, self.gs.ntrain
-
-    def step_a1(self, ldr, hdr_t, sunpose_gt):
-        """Part 1: forward, losses, and the backward pass down to the gradients of the sun-pose Dense layers
-        (which are 86 % of the gradient bytes: the data-parallel driver starts their all-reduce right after this)."""
+    # The step is a DAG of linear SEGMENTS, each bound to one of four HIP streams.  Eagerly they are enqueued in plan
+    # order with event waits; for replay every segment is captured into its own hipGraph and the graphs are launched
+    # on their streams with the same event waits.  (One hipGraph of the whole multi-stream step executes its
+    # branches almost serially on this runtime - measured: one kernel in flight 75 % of the time - whereas separate
+    # single-stream graphs on separate streams do run side by side.)
+    def _plan(self):
         w, g, c, cp = self.gs.w, self.gs.g, self.conv, self.compute
-        B = ldr.shape[0]
-        self.gs.grad.zero_(); self.ds.grad.zero_(); self.losses.zero_()
+        T = self._T                                   # tensors that cross segment boundaries
+        B, h, wd = T["ldr"].shape[0], self.h, self.w
+        segs = []
 
-        S = self._gen_forward(ldr, sunpose_gt)
-        t = S["t"]
-        y_lin, y_gamma = S["y_lin"], S["y_gamma"]
+        def seg(name, stream, deps=()):
+            def deco(fn):
+                segs.append((name, stream, tuple(deps), fn))
+                return fn
+            return deco
 
-        # Three independent chains run on three HIP streams (fork/join; captured as such in the hipGraph):
-        #   main : L1 + DoG + KL            sA : VGG16 perceptual forward/backward
-        #   sB   : adversarial term (discriminator with inference-mode BN, train.py:302)
-        main, sA, sB = torch.cuda.current_stream(), self.side_stream, self.side_stream2
-        sA.wait_stream(main); sB.wait_stream(main)
-        dyl = torch.empty_like(y_lin)
-        K.l1(y_lin, hdr_t, 1.0, 10.0, self.losses[3:4], da=dyl)                       # 10 * L1
-        K.dog_loss(y_lin, hdr_t, 1000.0, self.losses[2:3], dyl)                       # 1000 * DoG
-        dcmf = K.kl(sunpose_gt, t["cmf"], self.losses[0:1])                            # KL
-        with torch.cuda.stream(sA):
-            dyg = self._vgg_loss_and_grad(y_gamma, hdr_t)                              # 0.01 * perceptual
-        cvo = c["dis.out"]
-        with torch.cuda.stream(sB):
-            Rg = self._down_stack("dis.", self.ds.w, K.concat2(ldr, y_lin), training=False)
+        def decode(sfx, residual):
+            res_out = T["x"][-1]
+            d3, s3 = c["gen.conv3_" + sfx].fwd(res_out, compute=cp, want_stats=True)
+            xf2 = self._inxf(s3, "gen.norm3_" + sfx, 0.1)
+            d2, s2 = c["gen.conv2_" + sfx].fwd(d3, xf2, cp, want_stats=True)
+            xf1 = self._inxf(s2, "gen.norm2_" + sfx, 0.1)
+            y, _ = c["gen.conv1_" + sfx].fwd(d2, xf1, cp, out_slope=0.1, residual=residual, final_relu=True)
+            T["dec_" + sfx] = (d3, s3, xf2, d2, s2, xf1, y, residual)
+            return y
+
+        # ------------------------------------------------------------------ forward (train.py:239-299)
+        @seg("fwd_enc", 0)
+        def _():
+            self.gs.grad.zero_(); self.ds.grad.zero_(); self.losses.zero_()
+            ldr = T["ldr"]
+            T["c1"], T["s1"] = c["gen.conv1_d"].fwd(ldr, compute=cp, want_stats=True)        # generator.py:92-108
+            T["xf2"] = self._inxf(T["s1"], "gen.norm1_d", 0.1)
+            T["c2"], T["s2"] = c["gen.conv2_d"].fwd(T["c1"], T["xf2"], cp, want_stats=True)
+            T["xf3"] = self._inxf(T["s2"], "gen.norm2_d", 0.1)
+            T["c3"], T["s3"] = c["gen.conv3_d"].fwd(T["c2"], T["xf3"], cp, want_stats=True)
+            x = K.norm_apply(T["c3"], T["s3"], w["gen.norm3_d.gamma"], w["gen.norm3_d.beta"], slope=0.1)
+            T["x"] = [x]
+            for i in range(6):
+                p = "gen.res.%d." % i
+                r1, t1 = c[p + "conv1"].fwd(x, compute=cp, want_stats=True)
+                xf = self._inxf(t1, p + "norm1", 0.1)
+                r2, t2 = c[p + "conv2"].fwd(r1, xf, cp, want_stats=True)
+                x = K.norm_apply(r2, t2, w[p + "norm2.gamma"], w[p + "norm2.beta"], slope=1.0, residual=x)
+                T["res%d" % i] = (r1, t1, xf, r2, t2)
+                T["x"].append(x)
+            T["sky_gamma"] = decode("f", ldr)
+
+        @seg("fwd_sun", 1)
+        def _():       # sun-pose net, Grad-CAM (constants for the gradient: train.py:257-271), sun radiance head
+            t = T["t"] = self._sunpose_forward(T["ldr"])
+            T["cams"] = self._gradcam(t, T["gt"])
+            T["rad"] = self._sunrad_forward(T["ldr"], T["cams"], t, T)
+
+        @seg("fwd_blend", 0, ["fwd_sun"])
+        def _():
+            rad_lin, rad_gamma, gamma, beta = T["rad"]
+            sun_gamma = decode("u", rad_gamma)
+            y_gamma, y_lin, alpha, sky_lin, sun_lin = K.blend(T["sky_gamma"], sun_gamma, E.THRESHOLD)
+            T.update(y_gamma=y_gamma, y_lin=y_lin, alpha=alpha, sun_gamma=sun_gamma, gamma=gamma, beta=beta,
+                     rad_gamma=rad_gamma, rad_lin=rad_lin, sky_lin=sky_lin, sun_lin=sun_lin)
+
+        # ------------------------------------------------------------------ losses (train.py:301-331)
+        @seg("loss_main", 0)
+        def _():
+            dyl = T["dyl"] = torch.empty_like(T["y_lin"])
+            K.l1(T["y_lin"], T["hdr_t"], 1.0, 10.0, self.losses[3:4], da=dyl)                       # 10 * L1
+            K.dog_loss(T["y_lin"], T["hdr_t"], 1000.0, self.losses[2:3], dyl)                       # 1000 * DoG
+            T["dcmf"] = K.kl(T["gt"], T["t"]["cmf"], self.losses[0:1])                              # KL
+
+        @seg("loss_vgg", 1, ["fwd_blend"])
+        def _():
+            T["dyg"] = self._vgg_loss_and_grad(T["y_gamma"], T["hdr_t"])                            # 0.01 * perceptual
+
+        @seg("loss_adv", 2, ["fwd_blend"])
+        def _():       # adversarial term: discriminator with inference-mode BN (train.py:302)
+            cvo = c["dis.out"]
+            Rg = self._down_stack("dis.", self.ds.w, K.concat2(T["ldr"], T["y_lin"]), training=False)
             logits, _ = cvo.fwd(Rg["d4"]["raw"], Rg["xf_out"], cp)
             dlog = K.mse(logits, 1.0, 1.0, 1.0, self.losses[4:5])
             dact4 = cvo.dgrad(Rg["d4"]["raw"], dlog, cp)
             din = self._down_stack_bwd("dis.", self.ds.w, None, Rg, dact4, training=False, want_input_grad=True, do_wgrad=False)
-            d_adv = K.slice_channels(din, 3, 3, 1.0)
-        main.wait_stream(sB); main.wait_stream(sA)
-        K.axpby(dyl, 1.0, d_adv, 1.0, out=dyl)
+            T["d_adv"] = K.slice_channels(din, 3, 3, 1.0)
 
-        # generator backward, first stretch: blend -> decoder tails -> sun radiance head -> dcmf complete
-        dsky, dsun = K.blend_bwd(y_gamma, S["alpha"], dyg, dyl)
-        tails = {}
-        for sfx, dy in (("f", dsky), ("u", dsun)):
-            y, residual = S["dec_" + sfx][6], S["dec_" + sfx][7]
-            tails[sfx] = K.decoder_tail_bwd(y, residual, dy, want_dres=(sfx == "u"))
-        dpre = K.sun_rad_bwd(t["cmf"], t["gmax"], S["gamma"], S["beta"], tails["u"][1], dcmf)
-        # sun-pose Dense layers (sunpose_net.py:64-70): KL + the sun-radiance path meet in dcmf
-        dz = K.softmax_bwd(t["cmf"], dcmf, t["z"])
-        K.fc_wgrad(t["f1"], dz, g["sun.fc2.kernel"], g["sun.fc2.bias"])
-        df1 = K.fc_finalize(K.fc_dgrad(dz, self.fc2, cp), None, relu=False, mask_src=t["f1"])
-        K.fc_wgrad(t["flat"], df1, g["sun.fc1.kernel"], g["sun.fc1.bias"])
-        dP3 = K.fc_finalize(K.fc_dgrad(df1, self.fc1, cp)).reshape(B, self.h // 8, self.w // 8, 128)
-        self._S = dict(S=S, tails=tails, dpre=dpre, dP3=dP3, ldr=ldr, hdr_t=hdr_t)
-        return dict(y_final_lin=y_lin, y_final_gamma=y_gamma, sky_pred_lin=S["sky_lin"], sun_pred_lin=S["sun_lin"],
-                    gamma=S["gamma"], beta=S["beta"], alpha_c3=S["alpha"], sunpose_cmf=t["cmf"], sun_cam1=S["cams"][0],
-                    sun_cam2=S["cams"][1], sun_cam3=S["cams"][2], sun_rad_lin=S["rad_lin"])
+        # ------------------------------------------------------------------ backward, first stretch
+        @seg("bwd_head", 0, ["loss_vgg", "loss_adv"])
+        def _():       # blend -> decoder tails -> sun radiance head -> dcmf complete -> sun-pose Dense layers
+            t, dyl = T["t"], T["dyl"]
+            K.axpby(dyl, 1.0, T["d_adv"], 1.0, out=dyl)
+            dsky, dsun = K.blend_bwd(T["y_gamma"], T["alpha"], T["dyg"], dyl)
+            tails = T["tails"] = {}
+            for sfx, dy in (("f", dsky), ("u", dsun)):
+                y, residual = T["dec_" + sfx][6], T["dec_" + sfx][7]
+                tails[sfx] = K.decoder_tail_bwd(y, residual, dy, want_dres=(sfx == "u"))
+            T["dpre"] = K.sun_rad_bwd(t["cmf"], t["gmax"], T["gamma"], T["beta"], tails["u"][1], T["dcmf"])
+            dz = K.softmax_bwd(t["cmf"], T["dcmf"], t["z"])       # KL + the sun-radiance path meet in dcmf
+            K.fc_wgrad(t["f1"], dz, g["sun.fc2.kernel"], g["sun.fc2.bias"])
+            df1 = T["df1"] = K.fc_finalize(K.fc_dgrad(dz, self.fc2, cp), None, relu=False, mask_src=t["f1"])
+            K.fc_wgrad(t["flat"], df1, g["sun.fc1.kernel"], g["sun.fc1.bias"])
+            T["dP3"] = K.fc_finalize(K.fc_dgrad(df1, self.fc1, cp)).reshape(B, h // 8, wd // 8, 128)
 
-    def step_a2(self):
-        """Part 2: everything else - discriminator step (sB), sun-pose conv layers backward (sA), generator backward
-        (main).  The three chains write disjoint gradient ranges."""
-        w, g, c, cp = self.gs.w, self.gs.g, self.conv, self.compute
-        S, tails, dpre, dP, ldr, hdr_t = (self._S[k] for k in ("S", "tails", "dpre", "dP3", "ldr", "hdr_t"))
-        t, y_lin = S["t"], S["y_lin"]
-        main, sA, sB = torch.cuda.current_stream(), self.side_stream, self.side_stream2
-        sA.wait_stream(main); sB.wait_stream(main)
-        cvo = c["dis.out"]
-        # ---- discriminator step (train.py:351-380): real then generated, BN batch statistics (their moving-stat
-        # updates come after the generator step's inference-mode call of part 1, as in the reference's program order)
-        with torch.cuda.stream(sB):
-            for which, img, target, slot in (("real", hdr_t, 1.0, 6), ("fake", y_lin, 0.0, 5)):
-                Rd = self._down_stack("dis.", self.ds.w, K.concat2(ldr, img), training=True)
+        # ------------------------------------------------------------------ discriminator step (train.py:351-380)
+        @seg("disc_step", 2)
+        def _():       # real then generated, BN batch statistics (after the inference-mode call of loss_adv: same stream)
+            cvo = c["dis.out"]
+            for which, img, target, slot in (("real", T["hdr_t"], 1.0, 6), ("fake", T["y_lin"], 0.0, 5)):
+                Rd = self._down_stack("dis.", self.ds.w, K.concat2(T["ldr"], img), training=True)
                 lg, _ = cvo.fwd(Rd["d4"]["raw"], Rd["xf_out"], cp)
                 dl = K.mse(lg, target, 1.0, 0.5, self.losses[slot:slot + 1])
                 self._wg("dis.out", Rd["d4"]["raw"], Rd["xf_out"], dl)
                 da4 = cvo.dgrad(Rd["d4"]["raw"], dl, cp)
                 self._down_stack_bwd("dis.", self.ds.w, self.ds.g, Rd, da4, training=True, want_input_grad=False)
             self._flush_wgrads()
-        # ---- sun-pose conv layers (sunpose_net.py:54-62) --------------------------------------------------------
-        with torch.cuda.stream(sA):
+
+        # ------------------------------------------------------------------ sun-pose conv layers (sunpose_net.py:54-62)
+        @seg("bwd_sunpose", 1, ["bwd_head"])
+        def _():
+            t, dP = T["t"], T["dP3"]
             for l in (3, 2, 1):
                 n = "sun.sunlayer%d" % l
                 dr2 = self._in_bwd(t["r%db" % l], t["st%db" % l], n + ".norm2", 0.0, dP, pooled=True)
@@ -474,56 +443,176 @@ class Trainer:
                 if l > 1:
                     dP = c[n + ".conv1"].dgrad(t["in%d" % l], dr1, cp)
             self._flush_wgrads()
-        # ---- generator: decoders, sun radiance stack, encoder -----------------------------------------------------
-        dres = torch.zeros_like(S["x"][-1])
-        for sfx in ("f", "u"):
-            d3, s3, xf2, d2, s2, xf1, y, residual = S["dec_" + sfx]
-            dc = tails[sfx][0]
-            self._wg("gen.conv1_" + sfx, d2, xf1, dc)
-            da2 = c["gen.conv1_" + sfx].dgrad(d2, dc, cp)
-            dd2 = self._in_bwd(d2, s2, "gen.norm2_" + sfx, 0.1, da2)
-            self._wg("gen.conv2_" + sfx, d3, xf2, dd2)
-            da3 = c["gen.conv2_" + sfx].dgrad(d3, dd2, cp)
-            dd3 = self._in_bwd(d3, s3, "gen.norm3_" + sfx, 0.1, da3)
-            self._wg("gen.conv3_" + sfx, S["x"][-1], None, dd3)
-            c["gen.conv3_" + sfx].dgrad(S["x"][-1], dd3, cp, out=dres)
-        self._flush_wgrads(handoff=True)
-        R = S["sunrad"]    # sun radiance head (generator.py:158-169, sunrad_net.py:46-70)
-        xf = R["xf_out"]
-        dact4 = K.dense_heads_bwd(R["d4"]["raw"], xf.scale, xf.shift, 0.3, w["gen.sun.gamma.kernel"], w["gen.sun.beta.kernel"],
-                                  dpre, g["gen.sun.gamma.kernel"], g["gen.sun.beta.kernel"], g["gen.sun.gamma.bias"],
-                                  g["gen.sun.beta.bias"])
-        self._down_stack_bwd("gen.sun.", w, g, R, dact4, training=True, want_input_grad=False)
-        self._flush_wgrads(handoff=True)
-        dx = dres          # encoder (generator.py:92-108, resBlock :26-35)
-        for i in range(5, -1, -1):
-            p = "gen.res.%d." % i
-            r1, t1, xf, r2, t2 = S["res%d" % i]
-            dr2 = self._in_bwd(r2, t2, p + "norm2", 1.0, dx)
-            self._wg(p + "conv2", r1, xf, dr2)
-            da1 = c[p + "conv2"].dgrad(r1, dr2, cp)
-            dr1 = self._in_bwd(r1, t1, p + "norm1", 0.1, da1)
-            self._wg(p + "conv1", S["x"][i], None, dr1)
-            dx = c[p + "conv1"].dgrad(S["x"][i], dr1, cp, residual=dx)      # + identity branch
-        self._flush_wgrads(handoff=True)
-        dc3 = self._in_bwd(S["c3"], S["s3"], "gen.norm3_d", 0.1, dx)
-        self._wg("gen.conv3_d", S["c2"], S["xf3"], dc3)
-        da2 = c["gen.conv3_d"].dgrad(S["c2"], dc3, cp)
-        dc2 = self._in_bwd(S["c2"], S["s2"], "gen.norm2_d", 0.1, da2)
-        self._wg("gen.conv2_d", S["c1"], S["xf2"], dc2)
-        da1 = c["gen.conv2_d"].dgrad(S["c1"], dc2, cp)
-        dc1 = self._in_bwd(S["c1"], S["s1"], "gen.norm1_d", 0.1, da1)
-        self._wg("gen.conv1_d", ldr, None, dc1)
-        self._flush_wgrads()
-        main.wait_stream(sA); main.wait_stream(sB)
-        self._join_wgrads()
 
-    def apply_gradients(self, gscale=1.0):
-        """optimizer_gen / optimizer_disc .apply_gradients (train.py:403,406): RMSprop(lr), then refresh the packed
-        bf16 weight images."""
-        K.rmsprop(self.gs.flat[:self.gs.ntrain], self.gs.grad, self.gs.ms, self.lr, gscale=gscale)
-        K.rmsprop(self.ds.flat[:self.ds.ntrain], self.ds.grad, self.ds.ms, self.lr, gscale=gscale)
-        self.repack()
+        # ------------------------------------------------------------------ generator backward; its weight gradients
+        # are launched in groups on stream 3 as soon as each stretch of the chain has produced their operands
+        @seg("bwd_dec", 0)
+        def _():
+            dres = T["dres"] = torch.zeros_like(T["x"][-1])
+            for sfx in ("f", "u"):
+                d3, s3, xf2, d2, s2, xf1, y, residual = T["dec_" + sfx]
+                dc = T["tails"][sfx][0]
+                self._wg("gen.conv1_" + sfx, d2, xf1, dc)
+                da2 = c["gen.conv1_" + sfx].dgrad(d2, dc, cp)
+                dd2 = self._in_bwd(d2, s2, "gen.norm2_" + sfx, 0.1, da2)
+                self._wg("gen.conv2_" + sfx, d3, xf2, dd2)
+                da3 = c["gen.conv2_" + sfx].dgrad(d3, dd2, cp)
+                dd3 = self._in_bwd(d3, s3, "gen.norm3_" + sfx, 0.1, da3)
+                self._wg("gen.conv3_" + sfx, T["x"][-1], None, dd3)
+                c["gen.conv3_" + sfx].dgrad(T["x"][-1], dd3, cp, out=dres)
+            T["wq_dec"] = self._take_wgrads()
+
+        @seg("wg_dec", 3, ["bwd_dec"])
+        def _():
+            K.conv2d_wgrad_multi(T["wq_dec"])
+
+        @seg("bwd_sunrad", 0)
+        def _():       # sun radiance head (generator.py:158-169, sunrad_net.py:46-70)
+            R = T["sunrad"]
+            xf = R["xf_out"]
+            dact4 = K.dense_heads_bwd(R["d4"]["raw"], xf.scale, xf.shift, 0.3, w["gen.sun.gamma.kernel"],
+                                      w["gen.sun.beta.kernel"], T["dpre"], g["gen.sun.gamma.kernel"],
+                                      g["gen.sun.beta.kernel"], g["gen.sun.gamma.bias"], g["gen.sun.beta.bias"])
+            self._down_stack_bwd("gen.sun.", w, g, R, dact4, training=True, want_input_grad=False)
+            T["wq_sunrad"] = self._take_wgrads()
+
+        @seg("wg_sunrad", 3, ["bwd_sunrad"])
+        def _():
+            K.conv2d_wgrad_multi(T["wq_sunrad"])
+
+        @seg("bwd_res", 0)
+        def _():       # encoder res blocks (generator.py:26-35)
+            dx = T["dres"]
+            for i in range(5, -1, -1):
+                p = "gen.res.%d." % i
+                r1, t1, xf, r2, t2 = T["res%d" % i]
+                dr2 = self._in_bwd(r2, t2, p + "norm2", 1.0, dx)
+                self._wg(p + "conv2", r1, xf, dr2)
+                da1 = c[p + "conv2"].dgrad(r1, dr2, cp)
+                dr1 = self._in_bwd(r1, t1, p + "norm1", 0.1, da1)
+                self._wg(p + "conv1", T["x"][i], None, dr1)
+                dx = c[p + "conv1"].dgrad(T["x"][i], dr1, cp, residual=dx)      # + identity branch
+            T["dx_enc"] = dx
+            T["wq_res"] = self._take_wgrads()
+
+        @seg("wg_res", 3, ["bwd_res"])
+        def _():
+            K.conv2d_wgrad_multi(T["wq_res"])
+
+        @seg("bwd_enc", 0)
+        def _():       # encoder head (generator.py:92-108)
+            dc3 = self._in_bwd(T["c3"], T["s3"], "gen.norm3_d", 0.1, T["dx_enc"])
+            self._wg("gen.conv3_d", T["c2"], T["xf3"], dc3)
+            da2 = c["gen.conv3_d"].dgrad(T["c2"], dc3, cp)
+            dc2 = self._in_bwd(T["c2"], T["s2"], "gen.norm2_d", 0.1, da2)
+            self._wg("gen.conv2_d", T["c1"], T["xf2"], dc2)
+            da1 = c["gen.conv2_d"].dgrad(T["c1"], dc2, cp)
+            dc1 = self._in_bwd(T["c1"], T["s1"], "gen.norm1_d", 0.1, da1)
+            self._wg("gen.conv1_d", T["ldr"], None, dc1)
+            self._flush_wgrads()
+
+        # every gradient is complete here: a data-parallel driver hooks its all-reduce onto this (empty) segment
+        segs.append(("grads_ready", 0, ("disc_step", "bwd_sunpose", "wg_res"), None))
+
+        # ------------------------------------------------------------------ optimizers (train.py:403,406)
+        @seg("apply", 0)
+        def _():
+            gscale = self._gscale
+            K.rmsprop(self.gs.flat[:self.gs.ntrain], self.gs.grad, self.gs.ms, self.lr, gscale=gscale)
+            K.rmsprop(self.ds.flat[:self.ds.ntrain], self.ds.grad, self.ds.ms, self.lr, gscale=gscale)
+            self.repack()
+
+        return segs
+
+    FC_GRADS_READY, GRADS_READY = "bwd_head", "grads_ready"      # hook points of a data-parallel driver
+
+    def _take_wgrads(self):
+        return self._wjobs.pop(torch.cuda.current_stream().cuda_stream, [])
+
+    def _execute(self, names=None, graphs=None, hooks=None):
+        """Enqueues the plan's segments (all, or those in `names`) on the four streams; `graphs` replays captured
+        segments instead of re-issuing their launches.  hooks[name]() runs on the segment's stream right after it."""
+        caller = torch.cuda.current_stream()
+        st = self._streams
+        for s in st:
+            s.wait_stream(caller)
+        for name, si, deps, fn in self._segs:
+            if names is not None and name not in names:
+                continue
+            s = st[si]
+            for d_ in deps:
+                if d_ in self._events:
+                    s.wait_event(self._events[d_])
+            with torch.cuda.stream(s):
+                if fn is None:
+                    pass
+                elif graphs is not None:
+                    graphs[name].replay()
+                else:
+                    fn()
+                if hooks and name in hooks:
+                    hooks[name]()
+                ev = self._events.get(name)
+                if ev is None:
+                    ev = self._events[name] = torch.cuda.Event()
+                ev.record(s)
+        for s in st:
+            caller.wait_stream(s)
+
+    def _bind(self, ldr, hdr_t, sunpose_gt):
+        self._T = dict(ldr=ldr, hdr_t=hdr_t, gt=sunpose_gt)
+        self._segs = self._plan()
+        self._events = {}
+
+    def _outputs(self):
+        T = self._T
+        return dict(y_final_lin=T["y_lin"], y_final_gamma=T["y_gamma"], sky_pred_lin=T["sky_lin"], sun_pred_lin=T["sun_lin"],
+                    gamma=T["gamma"], beta=T["beta"], alpha_c3=T["alpha"], sunpose_cmf=T["t"]["cmf"],
+                    sun_cam1=T["cams"][0], sun_cam2=T["cams"][1], sun_cam3=T["cams"][2], sun_rad_lin=T["rad_lin"])
+
+    def step(self, ldr, hdr_t, sunpose_gt, update=True):
+        """ldr / hdr_t [B,H,W,3] BGR (train.py:386-387 rgb2bgr already applied), sunpose_gt [B,H*W].
+        Returns the dict generator_in_step returns (train.py:349) - losses are in self.losses (device)."""
+        self._bind(ldr, hdr_t, sunpose_gt)
+        self._execute([n for n, *_ in self._segs if update or n != "apply"])
+        return self._outputs()
+
+    def apply_gradients(self, gscale=None):
+        """optimizer_gen / optimizer_disc .apply_gradients (train.py:403,406): RMSprop(lr) on gradients scaled by
+        gscale (default 1/world: data-parallel sum -> mean), then refresh the packed bf16 weight images."""
+        if gscale is not None:
+            self._gscale = float(gscale)
+        self._execute(["apply"])
+
+    def fc_grad_range(self):
+        """[start, end) of the two Dense layers' gradients inside gs.grad - contiguous, the last trainables of the
+        sun-pose net (50.3 M of the 58.3 M parameters); complete once segment FC_GRADS_READY has run, so a data-parallel
+        driver starts their all-reduce there (hook) and it overlaps the rest of the backward pass."""
+        o = self.gs.offsets["sun.fc1.kernel"][0]
+        return o, self.gs.ntrain
+
+    def capture(self, ldr, hdr_t, sunpose_gt, warmup=2):
+        """Captures every segment of the step on (ldr, hdr_t, sunpose_gt) - static input buffers the caller refills -
+        into its own hipGraph.  `replay()` then runs one step."""
+        self._bind(ldr, hdr_t, sunpose_gt)
+        for _ in range(warmup):
+            self._execute()
+        torch.cuda.synchronize()
+        self._graphs = {}
+        for name, si, deps, fn in self._segs:
+            if fn is None:
+                continue
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=self._streams[si], capture_error_mode="thread_local"):
+                fn()
+            self._graphs[name] = gr
+        torch.cuda.synchronize()
+        return self._outputs()
+
+    def replay(self, update=True, hooks=None):
+        """One step from the captured graphs; hooks: {segment name: callable run on that segment's stream after it}."""
+        names = None if update else [n for n, *_ in self._segs if n != "apply"]
+        self._execute(names, graphs=self._graphs, hooks=hooks)
 
     def loss_dict(self):
         """Host copy of the loss terms with the reference's names (train.py:480-489) - synchronises."""

@@ -195,3 +195,29 @@ def test_cli_train_and_inference_smoke(dev, tmp_path, capsys):
     inference.main(["--indir", str(indir), "--outdir", str(outdir), "--sky", sky, "--sun", sun])
     back = hdr_io.read_hdr(str(outdir / "sky1.hdr"))
     assert back.shape == (32, 128, 3) and np.isfinite(back).all() and back.max() > 0
+
+
+def test_step_is_repeatable_under_stream_concurrency(dev):
+    """The step runs as segments on four streams.  Repeating it from the same state must reproduce the Dense-layer
+    gradients bit for bit (they involve no atomics) and they must equal flat^T @ df1 of the step's own tensors - this
+    caught a kernel whose operands were disturbed by a concurrently running segment."""
+    tr, _, batch = _mk(dev, 2)
+    ldr, hdr, gt = (torch.from_numpy(batch[k]).to(dev) for k in ("ldr", "hdr_t", "sunpose_gt"))
+    w0g, w0d = tr.gs.flat.clone(), tr.ds.flat.clone()
+    first = None
+    for it in range(6):
+        tr.gs.flat.copy_(w0g); tr.ds.flat.copy_(w0d)
+        tr.step(ldr, hdr, gt, update=False)
+        torch.cuda.synchronize()
+        T = tr._T
+        ref = T["t"]["flat"].double().t() @ T["df1"].double()
+        got = tr.gs.g["sun.fc1.kernel"]
+        assert float((got.double() - ref).abs().max()) <= 1e-6 * float(ref.abs().max()), it
+        snap = {k: tr.gs.g[k].clone() for k in ("sun.fc1.kernel", "sun.fc2.kernel", "sun.fc1.bias", "sun.fc2.bias")}
+        snap["y"] = T["y_lin"].clone(); snap["losses"] = tr.losses.clone()
+        if first is None:
+            first = snap
+        else:
+            for k in ("sun.fc1.kernel", "sun.fc2.kernel", "sun.fc1.bias", "sun.fc2.bias", "y"):
+                assert torch.equal(first[k], snap[k]), (it, k)
+            assert float((first["losses"] - snap["losses"]).abs().max()) <= 1e-5 * float(first["losses"].abs().max())
