@@ -102,6 +102,7 @@ def cpu_baseline(torch, workload, nets_np, batch_np):
 
 def main():
     args = parse()
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # the step uses 4 streams + RCCL's: see the package __init__
     import torch
     import torch.distributed as dist
 
@@ -158,19 +159,23 @@ def main():
         def fc_grads_ready():
             pending.append(dist.all_reduce(tr.gs.grad[fc0:fc1], async_op=True))
 
-        def grads_ready():
+        def fc_grads_reduced():          # runs on the stream of the Dense-layer optimizer segment, right before it
             pending.pop().wait()
+
+        def grads_ready():
             dist.all_reduce(tr.gs.grad[:fc0])
             dist.all_reduce(tr.ds.grad)
         hooks = {tr.FC_GRADS_READY: fc_grads_ready, tr.GRADS_READY: grads_ready} if dp else None
+        pre_hooks = {tr.APPLY[0]: fc_grads_reduced} if dp else None
         roof_pw, roof_b = tr.conv["gen.res.0.conv1"].pk, tr.gs.w["gen.res.0.conv1.b"]
         probe = lambda out: out["y_final_lin"]
         if args.no_graph:
             out = tr.step(ldr, hdr, gt, update=False)
-            one_step = lambda: (tr.step(ldr, hdr, gt, update=False), hooks and [h() for h in hooks.values()], tr.apply_gradients())
+            one_step = lambda: (tr.step(ldr, hdr, gt, update=False), hooks and [fc_grads_ready(), fc_grads_reduced(), grads_ready()],
+                                tr.apply_gradients())
         else:
             out = tr.capture(ldr, hdr, gt)
-            one_step = lambda: tr.replay(hooks=hooks)
+            one_step = lambda: tr.replay(hooks=hooks, pre_hooks=pre_hooks)
         phases = None
 
     if phases is not None:   # forward workload: warm-up (eager), then the whole forward captured as one hipGraph

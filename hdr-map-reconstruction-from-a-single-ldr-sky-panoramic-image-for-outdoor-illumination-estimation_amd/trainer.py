@@ -146,7 +146,7 @@ class Trainer:
             self.vgg_pk[name] = PackedConv(self.vgg[name + ".w"], pr)
             self.vgg_pkT[name] = PackedConv(self.vgg[name + ".w"], pr, transpose_flip=True)
 
-    def repack(self):
+    def repack(self, fc=True):
         if getattr(self, "_packer", None) is None:
             pairs = []
             for cv in self.conv.values():
@@ -155,8 +155,9 @@ class Trainer:
                     pairs.append((cv.w, cv.pkT))
             self._packer = K.MultiPacker(pairs)
         self._packer.run()
-        self.fc1.repack(self.gs.w["sun.fc1.kernel"])
-        self.fc2.repack(self.gs.w["sun.fc2.kernel"])
+        if fc:
+            self.fc1.repack(self.gs.w["sun.fc1.kernel"])
+            self.fc2.repack(self.gs.w["sun.fc2.kernel"])
 
     # ---- small helpers ------------------------------------------------------------------------------
     def _inxf(self, stats, name, slope):
@@ -280,37 +281,48 @@ class Trainer:
         return rad_lin, rad_gamma, gamma, beta
 
     # ---- VGG16 perceptual term (vgg16.py:127-165, train.py:308-313) ---------------------------------------
-    def _vgg_loss_and_grad(self, y_gamma, hdr_t):
-        cp, B = self.compute, y_gamma.shape[0]
-        both = torch.empty((2 * B,) + tuple(y_gamma.shape[1:]), dtype=torch.float32, device=y_gamma.device)
-        K.axpby(y_gamma, 1.0, out=both[:B])
-        K.axpby(K.tonemap(hdr_t, False), 1.0, out=both[B:])
-        x = K.vgg_pre(both)
-        acts, pools = {}, []
-        for blk in (("conv1_1", "conv1_2"), ("conv2_1", "conv2_2"), ("conv3_1", "conv3_2", "conv3_3")):
+    VGG_BLOCKS = (("conv1_1", "conv1_2"), ("conv2_1", "conv2_2"), ("conv3_1", "conv3_2", "conv3_3"))
+
+    def _vgg_forward(self, x_gamma, keep):
+        """pool1..3 of a gamma-domain BGR batch; `keep` collects what the backward pass re-reads."""
+        cp = self.compute
+        x = K.vgg_pre(x_gamma)
+        pools = []
+        for blk in self.VGG_BLOCKS:
             for name in blk:
-                acts[name + ".in"] = x
+                if keep is not None:
+                    keep[name + ".in"] = x
                 x, _ = K.conv2d(x, self.vgg_pk[name], self.vgg[name + ".b"], out_slope=0.0, compute=cp)
-                acts[name] = x
+                if keep is not None:
+                    keep[name] = x
             x = K.maxpool(x)
             pools.append(x)
+        return pools
+
+    def _vgg_target(self, hdr_t):
+        """vgg2(hdr_t_gamma) (train.py:309): does not depend on the generator, so it runs beside the forward pass."""
+        return self._vgg_forward(K.tonemap(hdr_t, False), None)
+
+    def _vgg_loss_and_grad(self, y_gamma, target_pools):
+        cp, B = self.compute, y_gamma.shape[0]
+        acts = {}
+        pools = self._vgg_forward(y_gamma, acts)
         dps = []
-        for p in pools:   # L1 between the prediction half and the target half; gradient wrt the prediction half
-            dp = torch.empty_like(p[:B])
-            K.l1(p[:B], p[B:], 1.0, 0.01, self.losses[1:2], da=dp)
+        for p, q in zip(pools, target_pools):   # 0.01 * sum_i mean|pool_i(pred) - pool_i(target)|, gradient wrt the prediction
+            dp = torch.empty_like(p)
+            K.l1(p, q, 1.0, 0.01, self.losses[1:2], da=dp)
             dps.append(dp)
-        # backward through the prediction half only
         g = None
-        for bi, blk in reversed(list(enumerate((("conv1_1", "conv1_2"), ("conv2_1", "conv2_2"), ("conv3_1", "conv3_2", "conv3_3"))))):
+        for bi, blk in reversed(list(enumerate(self.VGG_BLOCKS))):
             dp = dps[bi] if g is None else K.axpby(dps[bi], 1.0, g, 1.0)
-            g = K.maxpool_relu_bwd(acts[blk[-1]][:B], dp)          # wrt the pre-ReLU output of the block's last conv
+            g = K.maxpool_relu_bwd(acts[blk[-1]], dp)          # wrt the pre-ReLU output of the block's last conv
             for k in range(len(blk) - 1, -1, -1):
                 name = blk[k]
-                xin = acts[name + ".in"][:B]
+                xin = acts[name + ".in"]
                 d = K.conv_desc(B, xin.shape[1], xin.shape[2], xin.shape[3], self.vgg_pk[name].Cout, 3, 3, 1, True, 1)
                 g, _ = K.conv2d_dgrad(g, self.vgg_pkT[name], d, compute=cp)   # wrt this conv's (post-ReLU) input
                 if k > 0:
-                    g = K.affine_act_bwd(acts[blk[k - 1]][:B], g, None, None, 0.0)
+                    g = K.affine_act_bwd(acts[blk[k - 1]], g, None, None, 0.0)
         return K.axpby(g, 255.0)   # d/d y_gamma of the 0.01-weighted perceptual term
 
     # ---- one training step -----------------------------------------------------------------------------------
@@ -342,6 +354,13 @@ class Trainer:
             return y
 
         # ------------------------------------------------------------------ forward (train.py:239-299)
+        # (the longest independent chain is enqueued first; segment order = host launch order)
+        @seg("fwd_sun", 1)
+        def _():       # sun-pose net, Grad-CAM (constants for the gradient: train.py:257-271), sun radiance head
+            t = T["t"] = self._sunpose_forward(T["ldr"])
+            T["cams"] = self._gradcam(t, T["gt"])
+            T["rad"] = self._sunrad_forward(T["ldr"], T["cams"], t, T)
+
         @seg("fwd_enc", 0)
         def _():
             self.gs.grad.zero_(); self.ds.grad.zero_(); self.losses.zero_()
@@ -363,11 +382,9 @@ class Trainer:
                 T["x"].append(x)
             T["sky_gamma"] = decode("f", ldr)
 
-        @seg("fwd_sun", 1)
-        def _():       # sun-pose net, Grad-CAM (constants for the gradient: train.py:257-271), sun radiance head
-            t = T["t"] = self._sunpose_forward(T["ldr"])
-            T["cams"] = self._gradcam(t, T["gt"])
-            T["rad"] = self._sunrad_forward(T["ldr"], T["cams"], t, T)
+        @seg("vgg_target", 2)
+        def _():
+            T["vgg_tgt"] = self._vgg_target(T["hdr_t"])
 
         @seg("fwd_blend", 0, ["fwd_sun"])
         def _():
@@ -385,9 +402,9 @@ class Trainer:
             K.dog_loss(T["y_lin"], T["hdr_t"], 1000.0, self.losses[2:3], dyl)                       # 1000 * DoG
             T["dcmf"] = K.kl(T["gt"], T["t"]["cmf"], self.losses[0:1])                              # KL
 
-        @seg("loss_vgg", 1, ["fwd_blend"])
+        @seg("loss_vgg", 1, ["fwd_blend", "vgg_target"])
         def _():
-            T["dyg"] = self._vgg_loss_and_grad(T["y_gamma"], T["hdr_t"])                            # 0.01 * perceptual
+            T["dyg"] = self._vgg_loss_and_grad(T["y_gamma"], T["vgg_tgt"])                          # 0.01 * perceptual
 
         @seg("loss_adv", 2, ["fwd_blend"])
         def _():       # adversarial term: discriminator with inference-mode BN (train.py:302)
@@ -428,6 +445,16 @@ class Trainer:
                 da4 = cvo.dgrad(Rd["d4"]["raw"], dl, cp)
                 self._down_stack_bwd("dis.", self.ds.w, self.ds.g, Rd, da4, training=True, want_input_grad=False)
             self._flush_wgrads()
+
+        # The two Dense layers hold 50.3 M of the 58.3 M parameters and nothing reads their weights or gradients after
+        # bwd_head: their RMSprop update and bf16 re-packing (~1 GB of HBM traffic) run here, beside the rest of the
+        # backward pass, instead of at the end of the step.  (Data-parallel: after the all-reduce of that slice.)
+        @seg("apply_fc", 2, ["bwd_head"])
+        def _():
+            fc0, fc1 = self.fc_grad_range()
+            K.rmsprop(self.gs.flat[fc0:fc1], self.gs.grad[fc0:fc1], self.gs.ms[fc0:fc1], self.lr, gscale=self._gscale)
+            self.fc1.repack(w["sun.fc1.kernel"])
+            self.fc2.repack(w["sun.fc2.kernel"])
 
         # ------------------------------------------------------------------ sun-pose conv layers (sunpose_net.py:54-62)
         @seg("bwd_sunpose", 1, ["bwd_head"])
@@ -515,23 +542,25 @@ class Trainer:
         segs.append(("grads_ready", 0, ("disc_step", "bwd_sunpose", "wg_res"), None))
 
         # ------------------------------------------------------------------ optimizers (train.py:403,406)
-        @seg("apply", 0)
+        @seg("apply", 0, ["apply_fc"])
         def _():
-            gscale = self._gscale
-            K.rmsprop(self.gs.flat[:self.gs.ntrain], self.gs.grad, self.gs.ms, self.lr, gscale=gscale)
+            gscale, fc0 = self._gscale, self.fc_grad_range()[0]
+            K.rmsprop(self.gs.flat[:fc0], self.gs.grad[:fc0], self.gs.ms[:fc0], self.lr, gscale=gscale)
             K.rmsprop(self.ds.flat[:self.ds.ntrain], self.ds.grad, self.ds.ms, self.lr, gscale=gscale)
-            self.repack()
+            self.repack(fc=False)
 
         return segs
 
     FC_GRADS_READY, GRADS_READY = "bwd_head", "grads_ready"      # hook points of a data-parallel driver
+    APPLY = ("apply_fc", "apply")                                # the optimizer segments
 
     def _take_wgrads(self):
         return self._wjobs.pop(torch.cuda.current_stream().cuda_stream, [])
 
-    def _execute(self, names=None, graphs=None, hooks=None):
+    def _execute(self, names=None, graphs=None, hooks=None, pre_hooks=None):
         """Enqueues the plan's segments (all, or those in `names`) on the four streams; `graphs` replays captured
-        segments instead of re-issuing their launches.  hooks[name]() runs on the segment's stream right after it."""
+        segments instead of re-issuing their launches.  pre_hooks[name]() / hooks[name]() run on the segment's stream
+        right before / after it."""
         caller = torch.cuda.current_stream()
         st = self._streams
         for s in st:
@@ -544,6 +573,8 @@ class Trainer:
                 if d_ in self._events:
                     s.wait_event(self._events[d_])
             with torch.cuda.stream(s):
+                if pre_hooks and name in pre_hooks:
+                    pre_hooks[name]()
                 if fn is None:
                     pass
                 elif graphs is not None:
@@ -574,7 +605,7 @@ class Trainer:
         """ldr / hdr_t [B,H,W,3] BGR (train.py:386-387 rgb2bgr already applied), sunpose_gt [B,H*W].
         Returns the dict generator_in_step returns (train.py:349) - losses are in self.losses (device)."""
         self._bind(ldr, hdr_t, sunpose_gt)
-        self._execute([n for n, *_ in self._segs if update or n != "apply"])
+        self._execute([n for n, *_ in self._segs if update or n not in self.APPLY])
         return self._outputs()
 
     def apply_gradients(self, gscale=None):
@@ -582,7 +613,7 @@ class Trainer:
         gscale (default 1/world: data-parallel sum -> mean), then refresh the packed bf16 weight images."""
         if gscale is not None:
             self._gscale = float(gscale)
-        self._execute(["apply"])
+        self._execute(self.APPLY)
 
     def fc_grad_range(self):
         """[start, end) of the two Dense layers' gradients inside gs.grad - contiguous, the last trainables of the
@@ -609,10 +640,11 @@ class Trainer:
         torch.cuda.synchronize()
         return self._outputs()
 
-    def replay(self, update=True, hooks=None):
-        """One step from the captured graphs; hooks: {segment name: callable run on that segment's stream after it}."""
-        names = None if update else [n for n, *_ in self._segs if n != "apply"]
-        self._execute(names, graphs=self._graphs, hooks=hooks)
+    def replay(self, update=True, hooks=None, pre_hooks=None):
+        """One step from the captured graphs; hooks / pre_hooks: {segment name: callable run on that segment's stream
+        after / before it}."""
+        names = None if update else [n for n, *_ in self._segs if n not in self.APPLY]
+        self._execute(names, graphs=self._graphs, hooks=hooks, pre_hooks=pre_hooks)
 
     def loss_dict(self):
         """Host copy of the loss terms with the reference's names (train.py:480-489) - synchronises."""
