@@ -39,6 +39,10 @@ def parse():
     ap.add_argument("--workload", default="train", choices=["train", "fwd"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="run only the timed loop of the roofline kernel and print its object (the command behind "
+                         "profiles/r01_roofline_kernel_stats.csv: in the full run the same kernel template also "
+                         "serves other layers, beside other streams, so its rocprof average there is not this launch)")
     return ap.parse_args()
 
 
@@ -137,6 +141,11 @@ def main():
     hdr = torch.from_numpy(batch_np["hdr_t"]).to(dev)
     gt = torch.from_numpy(batch_np["sunpose_gt"]).to(dev)
 
+    if args.roofline_only:
+        w = torch.from_numpy(gen["res.0.conv1.w"]).to(dev)
+        print(json.dumps(dominant_kernel_roofline(torch, K, K.PackedConv(w, False), torch.zeros(128, device=dev),
+                                                  args.batch, 32, 128)))
+        return
     if args.workload == "fwd":
         nets = engine.Nets(gen, sun, device=dev, precise=False)
         phases = [lambda: engine.generator_forward(nets, ldr, compute=K.BF16)]
