@@ -641,6 +641,29 @@ __global__ void __launch_bounds__(256) fc_wgrad_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Keras-2 OptimizerV2 Adam (train_sun.py:191 via tf_utils.py:324; beta1 0.9, beta2 0.999, eps 1e-7) over one flat
+// parameter buffer:  m <- b1*m + (1-b1)*g ; v <- b2*v + (1-b2)*g^2 ; w <- w - lr_t * m / (sqrt(v) + eps)
+// with lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t) computed by the caller (t = step count).
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, size_t n4, float lr_t, float b1, float b2,
+                                                   float eps, float gscale) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 wv = reinterpret_cast<float4*>(w)[i], mv = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+    const float4 gv = reinterpret_cast<const float4*>(g)[i];
+    float* wp = &wv.x; float* mp = &mv.x; float* vp = &vv.x; const float* gp = &gv.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gg = gp[k] * gscale;
+      mp[k] = b1 * mp[k] + (1.f - b1) * gg;
+      vp[k] = b2 * vp[k] + (1.f - b2) * gg * gg;
+      wp[k] -= lr_t * mp[k] / (sqrtf(vp[k]) + eps);
+    }
+    reinterpret_cast<float4*>(w)[i] = wv; reinterpret_cast<float4*>(m)[i] = mv; reinterpret_cast<float4*>(v)[i] = vv;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Keras-2 OptimizerV2 RMSprop (train.py:201-202; rho 0.9, momentum 0, eps 1e-7 OUTSIDE the sqrt) over one flat
 // parameter buffer:  ms <- rho*ms + (1-rho)*g^2 ;  w <- w - lr*g/(sqrt(ms)+eps).  gscale averages replica sums.
 // ------------------------------------------------------------------------------------------------------------
@@ -872,6 +895,14 @@ int hdrsky_fc_wgrad(const float* x, const float* dy, int M, int K, int N, int ac
                     void* stream) {
   if (!x || !dy || !dw || M <= 0 || M > 32 || (K & 7) || (N & 3)) return HDRSKY_EINVAL;
   hipLaunchKernelGGL(fc_wgrad_kernel, dim3(cdiv(N / 4, 256), K / 8), dim3(256), 0, S_(stream), x, dy, M, K, N, accumulate, dw, db);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_adam(float* w, const float* g, float* m, float* v, size_t n, float lr_t, float beta1, float beta2, float eps,
+                float gscale, void* stream) {
+  if (!w || !g || !m || !v || (n & 3)) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4, 1024)), dim3(256), 0, S_(stream), w, g, m, v, n / 4, lr_t, beta1, beta2, eps, gscale);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }

@@ -657,6 +657,16 @@ def rmsprop(w, g, ms, lr, rho=0.9, eps=1e-7, gscale=1.0):
 # ------------------------------------------------------------------------------------------------
 # distortion-aware convolution (csrc/da_conv.hip)
 # ------------------------------------------------------------------------------------------------
+def adam(w, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-7, gscale=1.0):
+    """One tf.keras Adam step (OptimizerV2 form) on flat buffers; `step` is the 1-based update count."""
+    n = w.numel()
+    _f32(w); _f32(g); _f32(m); _f32(v)
+    import numpy as np                      # lr_t in float32, as OptimizerV2 forms it
+    f = np.float32
+    lr_t = float(f(lr) * np.sqrt(f(1) - np.power(f(beta2), f(step))) / (f(1) - np.power(f(beta1), f(step))))
+    L.check(L.load().hdrsky_adam(_p(w), _p(g), _p(m), _p(v), n, lr_t, beta1, beta2, eps, gscale, _stream()), "adam")
+
+
 def da_offsets(h, w, ksize=3, dilation_rate=1, skydome=True):
     """Host float32 offset table [h, k*k, 2] (distortion_aware_ops.py:198-270)."""
     import ctypes

@@ -652,3 +652,74 @@ class Trainer:
         v["total_gen_loss"] = v["kl"] + 1000.0 * v["dog"] + v["adv"] + 10.0 * v["l1"] + 0.01 * v["perceptual"]
         v["total_disc_loss"] = 0.5 * (v["disc_generated"] + v["disc_real"])
         return v
+
+
+class SunPoseTrainer(Trainer):
+    """Sun-pose pre-training step (train_sun.py:220-264): loss = KLDivergence(gt, cmf) + DoG-L1 between the cmf image
+    and the target image; tf.keras Adam(lr).  Re-uses the sun-pose forward / Grad-CAM / backward chains of `Trainer`;
+    only the parameter set (sun-pose net alone), the loss head and the optimizer differ.  (The reference script
+    reads `utils.utils.str2bool` and `args.dorfpath`, neither of which exists - train_sun.py:155,167; the step itself
+    is what is mirrored here.)"""
+
+    LOSSES = ("kl", "dog")
+
+    def __init__(self, sun_params, device="cuda", lr=1e-4, im_height=32, im_width=128, precise=False, compute=BF16,
+                 world_size=1):
+        self.device = torch.device(device)
+        self.h, self.w = im_height, im_width
+        self.lr, self.compute, self.precise, self.world = lr, compute, precise, world_size
+        self.gs = FlatParams(OrderedDict(("sun." + k, v) for k, v in sun_params.items()), self.device)
+        self.adam_m, self.adam_v = torch.zeros_like(self.gs.grad), torch.zeros_like(self.gs.grad)
+        self.steps_done = 0
+        self.losses = torch.zeros(len(self.LOSSES), dtype=torch.float32, device=self.device)
+        self._wjobs, self._packer = {}, None
+        w, c = self.gs.w, {}
+        for l in (1, 2, 3):
+            for j in (1, 2):
+                n = "sun.sunlayer%d.conv%d" % (l, j)
+                c[n] = _Conv(w[n + ".w"], w[n + ".b"], n + ".w", n + ".b", precise=precise, need_dgrad=not (l == 1 and j == 1))
+        self.conv = c
+        self.fc1, self.fc2 = PackedFC(w["sun.fc1.kernel"], precise), PackedFC(w["sun.fc2.kernel"], precise)
+
+    def step(self, ldr, sunpose_gt, update=True, want_cams=True, dog_weight=1.0):
+        """ldr [B,H,W,3] BGR in [0,1], sunpose_gt [B,H*W].  Returns (pred [B,H,W,1], target image, [cam1,cam2,cam3]).
+        dog_weight is 1 in the reference (train_sun.py:255)."""
+        w, g, c, cp = self.gs.w, self.gs.g, self.conv, self.compute
+        B = ldr.shape[0]
+        self.gs.grad.zero_(); self.losses.zero_()
+        t = self._sunpose_forward(ldr)
+        cams = self._gradcam(t, sunpose_gt) if want_cams else None              # under stop_recording: constants
+        dcmf = K.kl(sunpose_gt, t["cmf"], self.losses[0:1])                     # d KL / d cmf
+        pred, gt_img = t["cmf"].view(B, self.h, self.w, 1), sunpose_gt.view(B, self.h, self.w, 1)
+        if dog_weight != 0.0:
+            K.dog_loss(pred, gt_img, float(dog_weight), self.losses[1:2], dcmf.view(B, self.h, self.w, 1))
+        dz = K.softmax_bwd(t["cmf"], dcmf, t["z"])
+        K.fc_wgrad(t["f1"], dz, g["sun.fc2.kernel"], g["sun.fc2.bias"])
+        df1 = K.fc_finalize(K.fc_dgrad(dz, self.fc2, cp), None, relu=False, mask_src=t["f1"])
+        K.fc_wgrad(t["flat"], df1, g["sun.fc1.kernel"], g["sun.fc1.bias"])
+        dP = K.fc_finalize(K.fc_dgrad(df1, self.fc1, cp)).reshape(B, self.h // 8, self.w // 8, 128)
+        for l in (3, 2, 1):
+            n = "sun.sunlayer%d" % l
+            dr2 = self._in_bwd(t["r%db" % l], t["st%db" % l], n + ".norm2", 0.0, dP, pooled=True)
+            self._wg(n + ".conv2", t["r%da" % l], t["xf%d" % l], dr2)
+            da = c[n + ".conv2"].dgrad(t["r%da" % l], dr2, cp)
+            dr1 = self._in_bwd(t["r%da" % l], t["st%da" % l], n + ".norm1", 0.0, da)
+            self._wg(n + ".conv1", t["in%d" % l], None, dr1)
+            if l > 1:
+                dP = c[n + ".conv1"].dgrad(t["in%d" % l], dr1, cp)
+        self._flush_wgrads()
+        if update:
+            self.apply_gradients()
+        return pred, gt_img, cams
+
+    def apply_gradients(self, gscale=None):
+        """optimizer_sun.apply_gradients (train_sun.py:259): Adam(lr) on gradients scaled by gscale (default 1/world)."""
+        self.steps_done += 1
+        K.adam(self.gs.flat[:self.gs.ntrain], self.gs.grad, self.adam_m, self.adam_v, self.lr, self.steps_done,
+               gscale=(1.0 / self.world) if gscale is None else gscale)
+        self.repack()
+
+    def loss_dict(self):
+        v = dict(zip(self.LOSSES, self.losses.tolist()))
+        v["sun_loss"] = v["kl"] + v["dog"]
+        return v

@@ -139,3 +139,25 @@ def train_step_grads(gen, sun, dis, vgg, ldr, hdr_t, sunpose_gt):
     losses = {k: float(v.detach()) for k, v in {**gl, **dl}.items()}
     outs = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}
     return losses, grads_gen, grads_sun, grads_dis, stats_gen, stats_dis, outs
+
+
+def sun_train_step_grads(sun, ldr, sunpose_gt, dog_weight=1.0):
+    """train_sun.py:220-264 up to (not including) apply_gradients: sun-pose pre-training.
+    loss = KLDivergence(gt, cmf) + sum_4 mean|DoG_i(cmf image) - DoG_i(gt image)|; the Grad-CAM maps are returned
+    but do not enter the loss (computed under stop_recording).  `ldr` is already BGR.
+    Returns (losses, grads, outputs)."""
+    sun_r = {k: v.detach().clone().requires_grad_(True) for k, v in sun.items()}
+    b, h, w, _ = ldr.shape
+    cmf, maps = N.sunpose_estimation(sun_r, ldr)
+    y_index = sunpose_gt.argmax(dim=1)
+    y_c = cmf.gather(1, y_index.view(-1, 1)).squeeze(1)
+    cams = [N.grad_cam_layer(y_c, a, create_graph=False).detach() for a in maps]
+    kl = T.kl_divergence(sunpose_gt, cmf)
+    pred, gt_img = cmf.view(b, h, w, 1), sunpose_gt.view(b, h, w, 1)
+    dog = sum((a - c).abs().mean() for a, c in zip(T.dog(pred), T.dog(gt_img)))
+    loss = kl + dog_weight * dog          # the reference uses weight 1 (train_sun.py:255); 0 isolates the KL path in tests
+    names = list(sun_r.keys())
+    grads = torch.autograd.grad(loss, [sun_r[k] for k in names], allow_unused=True)
+    grads = {k: (torch.zeros_like(sun_r[k]) if g is None else g) for k, g in zip(names, grads)}
+    return dict(kl=float(kl.detach()), dog=float(dog.detach()), sun_loss=float(loss.detach())), grads, \
+        dict(sunpose_cmf=cmf.detach(), sun_cam1=cams[0], sun_cam2=cams[1], sun_cam3=cams[2])

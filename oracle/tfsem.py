@@ -183,6 +183,21 @@ def kl_divergence(y_true, y_pred, eps=1e-7):
 def rmsprop_update(w, g, ms, lr, rho=0.9, eps=1e-7):
     """Keras-2 OptimizerV2 RMSprop, momentum=0, centered=False (train.py:201-202):
     ms <- rho*ms + (1-rho)*g^2 ; w <- w - lr*g/(sqrt(ms)+eps).  Returns (w, ms)."""
-    ms = rho * ms + (1.0 - rho) * g * g
+    r = torch.tensor(rho, dtype=torch.float32)       # OptimizerV2 forms 1-rho in float32
+    ms = r * ms + (1.0 - r) * g * g
     w = w - lr * g / (torch.sqrt(ms) + eps)
     return w, ms
+
+
+def adam_update(w, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-7):
+    """Keras-2 OptimizerV2 Adam (train_sun.py:191 via tf_utils.py:324), non-amsgrad:
+    m <- b1*m + (1-b1)*g ; v <- b2*v + (1-b2)*g^2 ; lr_t = lr*sqrt(1-b2^t)/(1-b1^t) ;
+    w <- w - lr_t*m/(sqrt(v)+eps).  `step` is the 1-based update count.  Returns (w, m, v)."""
+    # OptimizerV2 keeps the hyper-parameters as float32 tensors and forms 1-beta, beta^t and lr_t in float32
+    f = lambda x: torch.tensor(x, dtype=torch.float32)
+    b1, b2 = f(beta1), f(beta2)
+    lr_t = f(lr) * torch.sqrt(1.0 - torch.pow(b2, f(float(step)))) / (1.0 - torch.pow(b1, f(float(step))))
+    m = b1 * m + (1.0 - b1) * g
+    v = b2 * v + (1.0 - b2) * g * g
+    w = w - lr_t * m / (torch.sqrt(v) + eps)
+    return w, m, v

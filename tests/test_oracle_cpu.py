@@ -172,3 +172,18 @@ def test_gradcam_matches_finite_difference():
         e = torch.zeros_like(a3); e[i] = 1e-6
         fd = (tail(a3.detach() + e) - tail(a3.detach() - e)) / 2e-6
         assert abs(float(fd) - float(gr[i])) <= 1e-5 * max(1e-12, float(gr.abs().max()))
+
+
+def test_adam_update_closed_form():
+    """Keras OptimizerV2 Adam, first step from zero slots: w1 = w0 - lr*sqrt(1-b2)/(1-b1) * (1-b1) g / (sqrt((1-b2) g^2) + eps)."""
+    import torch
+    from oracle import tfsem as T
+    w0, g = torch.tensor([1.0, -2.0, 0.5]), torch.tensor([0.3, -4.0, 1e-3])
+    w1, m1, v1 = T.adam_update(w0, g, torch.zeros(3), torch.zeros(3), 1e-3, 1)
+    b1, b2, eps = 0.9, 0.999, 1e-7
+    expect = w0 - 1e-3 * (1 - b2) ** 0.5 / (1 - b1) * ((1 - b1) * g) / (((1 - b2) * g * g).sqrt() + eps)
+    # OptimizerV2 forms 1-beta in float32: float32(1) - float32(0.999) differs from 0.001 by 1.3e-5 relative
+    assert torch.allclose(w1, expect, rtol=3e-5, atol=0)
+    assert torch.allclose(m1, (1 - b1) * g, rtol=1e-6) and torch.allclose(v1, (1 - b2) * g * g, rtol=3e-5)
+    # for |g| >> eps the first step has magnitude ~lr regardless of the gradient scale
+    assert abs(float((w0 - w1)[1]) - (-1e-3)) < 1e-6

@@ -197,6 +197,24 @@ def test_cli_train_and_inference_smoke(dev, tmp_path, capsys):
     assert back.shape == (32, 128, 3) and np.isfinite(back).all() and back.max() > 0
 
 
+def test_cli_train_sun_smoke(dev, tmp_path, capsys):
+    """sun-pose pre-training CLI: 10 tiny synthetic epochs -> one SUN checkpoint (every 10th epoch, max_to_keep=5) that
+    the next invocation restores (weights, Adam slots and step count) and that train.py / inference.py can read."""
+    train_sun, ckpt = pkg("train_sun"), pkg("checkpoint")
+    sun = str(tmp_path / "SUN")
+    train_sun.main(["--batchsize", "2", "--epochs", "10", "--steps-per-epoch", "1", "--sun", sun])
+    out = capsys.readouterr().out
+    assert "train_loss_SUN" in out and "Saved checkpoint for epoch 10" in out
+    tensors, epoch = ckpt.CheckpointManager(sun).restore()
+    assert epoch == 10 and int(tensors["optimizer/iter"]) == 10
+    assert tensors["lin/fc1/kernel"].shape == (8192, 4096) and np.isfinite(tensors["lin/fc1/kernel"]).all()
+    train_sun.main(["--batchsize", "2", "--epochs", "11", "--steps-per-epoch", "1", "--sun", sun])
+    out = capsys.readouterr().out
+    assert "Latest checkpoint has restored!!" in out and "[epoch 11]" in out and "[epoch 10]" not in out
+    train_sun.main(["--train", "false", "--batchsize", "2", "--sun", sun])
+    assert "inference: cmf max" in capsys.readouterr().out
+
+
 def test_step_is_repeatable_under_stream_concurrency(dev):
     """The step runs as segments on four streams.  Repeating it from the same state must reproduce the Dense-layer
     gradients bit for bit (they involve no atomics) and they must equal flat^T @ df1 of the step's own tensors - this
@@ -221,3 +239,77 @@ def test_step_is_repeatable_under_stream_concurrency(dev):
             for k in ("sun.fc1.kernel", "sun.fc2.kernel", "sun.fc1.bias", "sun.fc2.bias", "y"):
                 assert torch.equal(first[k], snap[k]), (it, k)
             assert float((first["losses"] - snap["losses"]).abs().max()) <= 1e-5 * float(first["losses"].abs().max())
+
+
+def test_adam_kernel(dev):
+    """hdrsky_adam vs the oracle's Keras-OptimizerV2 Adam over three consecutive steps."""
+    K = pkg("kernels")
+    rng = np.random.default_rng(21)
+    n = 4096 + 8
+    w0 = rng.standard_normal(n).astype(np.float32)
+    w, m, v = torch.from_numpy(w0).to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    wr, mr, vr = torch.from_numpy(w0), torch.zeros(n), torch.zeros(n)
+    for step in (1, 2, 3):
+        g = torch.from_numpy((rng.standard_normal(n) * 10.0 ** rng.uniform(-4, 1, n)).astype(np.float32))
+        K.adam(w, g.to(dev), m, v, 1e-4, step)
+        wr, mr, vr = T.adam_update(wr, g, mr, vr, 1e-4, step)
+    assert_close(w, wr, 1e-6, "adam w"); assert_close(m, mr, 1e-6, "adam m"); assert_close(v, vr, 1e-6, "adam v")
+
+
+def test_sunpose_pretraining_step_matches_oracle(dev):
+    """train_sun.py:220-264: KL + DoG loss on the cmf image, gradients of every sun-pose variable, one Adam update.
+    The DoG term is an L1 of differences that are ~1e-9 wherever both 1-channel images are flat (a random-init net's
+    cmf is nearly uniform), so the sign() in its gradient is decided by rounding noise there - in the oracle as much as
+    here.  The backward chain is therefore checked tightly with the DoG term switched off, and with the reference's
+    weight 1 the losses are checked tightly and the gradients by direction (cosine)."""
+    params, synth, trainer, K = pkg("params"), pkg("synth"), pkg("trainer"), pkg("kernels")
+    from oracle import networks as onet
+    sun = params.init_params(params.sunpose_spec(), 1)
+    sun_t = {k: torch.from_numpy(v) for k, v in sun.items()}
+    # A Dense unit whose pre-activation is within rounding of the ReLU kink (|o| ~ 1e-5 of the layer's maximum) is on in
+    # one implementation and off in the other, and one such unit moves the fc1 gradients by >10 %: pick a batch whose
+    # Dense pre-activations keep a margin from zero (with 2 x 4096 units per layer about every second batch has none).
+    for seed in range(1234, 1264):
+        batch = synth.make_batch(2, seed=seed)
+        ldr, gt = torch.from_numpy(batch["ldr"]), torch.from_numpy(batch["sunpose_gt"])
+        with torch.no_grad():
+            a = ldr
+            for l in (1, 2, 3):
+                a = T.maxpool2x2(onet._sunpose_layer(sun_t, "sunlayer%d" % l, a))
+            o1 = T.dense(T.flatten_nhwc(a), sun_t["fc1.kernel"], sun_t["fc1.bias"])
+            o2 = T.dense(torch.relu(o1), sun_t["fc2.kernel"], sun_t["fc2.bias"])
+        if min(float(o1.abs().min() / o1.abs().max()), float(o2.abs().min() / o2.abs().max())) > 3e-5:
+            break
+    else:
+        pytest.skip("no batch with a ReLU margin found")
+    print("batch seed", seed)
+    tr = trainer.SunPoseTrainer(sun, device=dev, precise=True, compute=K.BF16X3)
+    for dog_weight in (0.0, 1.0):
+        losses, grads, outs = ostep.sun_train_step_grads(sun_t, ldr, gt, dog_weight)
+        pred, gt_img, cams = tr.step(ldr.to(dev), gt.to(dev), update=False, dog_weight=dog_weight)
+        got = tr.loss_dict()
+        for k in (("kl",) if dog_weight == 0.0 else ("kl", "dog", "sun_loss")):
+            assert abs(got[k] - losses[k]) <= 1e-3 * abs(losses[k]) + 1e-7, (k, got[k], losses[k])
+        assert_close(pred.reshape(2, -1), outs["sunpose_cmf"], 2e-3, "cmf")
+        worst, dots = [], [0.0, 0.0, 0.0]
+        for k, ref in grads.items():
+            g = tr.gs.g["sun." + k].cpu()
+            scale = float(ref.abs().max())
+            if (k.endswith(".b") and "conv" in k) or scale == 0.0:   # conv bias before an InstanceNorm: exactly zero gradient
+                wk = "sun." + k[:-2] + ".w"
+                assert float(g.abs().max()) <= 1e-4 * float(tr.gs.g[wk].abs().max()), k
+                continue
+            worst.append((float((g - ref).abs().max()) / scale, k))
+            dots[0] += float((g.double() * ref.double()).sum()); dots[1] += float((g.double() ** 2).sum()); dots[2] += float((ref.double() ** 2).sum())
+        worst.sort(reverse=True)
+        cos = dots[0] / (dots[1] * dots[2]) ** 0.5
+        print("dog_weight", dog_weight, "cosine", cos, worst[:4])
+        if dog_weight == 0.0:   # same bounds as the full training step: ReLU / max-pool mask flips at the 1e-2 level
+            assert worst[0][0] < 5e-2, worst[:5]
+            assert np.median([e for e, _ in worst]) < 3e-3
+        assert cos > (0.9999 if dog_weight == 0.0 else 0.98), cos
+    # one Adam update of the flat buffer
+    w0 = tr.gs.flat[:tr.gs.ntrain].clone(); g0 = tr.gs.grad.clone()
+    tr.apply_gradients()
+    wr, _, _ = T.adam_update(w0.cpu(), g0.cpu(), torch.zeros_like(w0.cpu()), torch.zeros_like(w0.cpu()), tr.lr, 1)
+    assert_close(tr.gs.flat[:tr.gs.ntrain], wr, 1e-6, "adam step of the sun-pose net")
