@@ -201,3 +201,14 @@ def adam_update(w, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-7):
     v = b2 * v + (1.0 - b2) * g * g
     w = w - lr_t * m / (torch.sqrt(v) + eps)
     return w, m, v
+
+
+def conv2d_transpose(x, w, b, out_h, out_w, stride, padding="SAME"):
+    """tf.nn.conv2d_transpose(x, w[kh,kw,Cout,Cin], output_shape=[B,out_h,out_w,Cout], strides, padding) + bias
+    (ops.py:116-119).  By definition the gradient of conv2d(z[B,out_h,out_w,Cout], w, strides, padding) wrt z,
+    evaluated with x as the upstream gradient."""
+    z = torch.zeros(x.shape[0], out_h, out_w, w.shape[2], dtype=x.dtype, requires_grad=True)
+    y = conv2d(z, w, None, stride, padding)
+    assert tuple(y.shape) == tuple(x.shape), (tuple(y.shape), tuple(x.shape))
+    (g,) = torch.autograd.grad(y, z, x)
+    return g + b if b is not None else g

@@ -34,8 +34,17 @@ def test_ops_layers(dev):
     y = de(x.to(dev))
     assert sorted(de.variables) == ["bias_deconv2d", "kernel_deconv2d"]
     assert_close(y, T.deconv2d_resize(x, de.kernel_deconv2d.cpu(), de.bias_deconv2d.cpu(), 32, 64), TOL_X3, "ops.deconv2d")
-    with pytest.raises(NotImplementedError):
-        ops.deconv2d(16, [32, 64], 3, 3, method="upsample")
+    for k, pad, oshape in ((3, "SAME", [32, 64]), (4, "SAME", [32, 64]), (3, "SAME", [16, 32])):   # stride 2, 2, 1
+        tp = ops.deconv2d(output_channels=48, output_imshape=oshape, k_h=k, k_w=k, padding=pad, method="upsample", seed=6,
+                          compute=K.BF16X3)
+        y = tp(x.to(dev))
+        assert tuple(tp.kernel_deconv2d.shape) == (k, k, 48, 32)                      # [kh, kw, Cout, Cin] (ops.py:77-82)
+        tp.assign(tp.kernel_deconv2d, torch.from_numpy(rng.standard_normal(48).astype(np.float32)))
+        y = tp(x.to(dev))
+        ref = T.conv2d_transpose(x, tp.kernel_deconv2d.cpu(), tp.bias_deconv2d.cpu(), oshape[0], oshape[1], oshape[0] // 16, pad)
+        assert_close(y, ref, TOL_X3, "ops.deconv2d upsample k=%d -> %s" % (k, oshape))
+    with pytest.raises(ValueError):
+        ops.deconv2d(16, [32, 64], 3, 3, method="transpose")
     with pytest.raises(ValueError):
         ops.deconv2d(16, [48, 96], 3, 3)(x.to(dev))
     assert_close(ops.maxpool2d(kernel_size=2)(x.to(dev)), T.maxpool2x2(x), 0.0, "ops.maxpool2d")

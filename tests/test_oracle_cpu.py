@@ -187,3 +187,22 @@ def test_adam_update_closed_form():
     assert torch.allclose(m1, (1 - b1) * g, rtol=1e-6) and torch.allclose(v1, (1 - b2) * g * g, rtol=3e-5)
     # for |g| >> eps the first step has magnitude ~lr regardless of the gradient scale
     assert abs(float((w0 - w1)[1]) - (-1e-3)) < 1e-6
+
+
+def test_conv2d_transpose_oracle_against_explicit_construction():
+    """tf.nn.conv2d_transpose, SAME, stride 2, k=3: TF pads the FORWARD conv (0,1) => the transpose is a full
+    conv_transpose2d cropped at [0 : 2*in]; stride 1 is a SAME conv with the flipped, channel-transposed filter."""
+    import torch
+    import torch.nn.functional as F
+    from oracle import tfsem as T
+    rng = np.random.default_rng(4)
+    x = torch.from_numpy(rng.standard_normal((2, 5, 7, 6)).astype(np.float32))
+    w = torch.from_numpy(rng.standard_normal((3, 3, 4, 6)).astype(np.float32))       # [kh,kw,Cout,Cin]
+    b = torch.from_numpy(rng.standard_normal(4).astype(np.float32))
+    got = T.conv2d_transpose(x, w, b, 10, 14, 2)
+    full = F.conv_transpose2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), stride=2)   # weight [Cin, Cout, kh, kw]
+    ref = full[:, :, 0:10, 0:14].permute(0, 2, 3, 1) + b
+    assert torch.allclose(got, ref, atol=1e-5)
+    got1 = T.conv2d_transpose(x, w, None, 5, 7, 1)
+    ref1 = T.conv2d(x, w.flip(0, 1).permute(0, 1, 3, 2).contiguous(), None, 1, "SAME")
+    assert torch.allclose(got1, ref1, atol=1e-5)
