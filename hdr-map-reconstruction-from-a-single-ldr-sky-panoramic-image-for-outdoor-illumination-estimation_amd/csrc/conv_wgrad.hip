@@ -39,7 +39,6 @@ struct WgradArgs {
   int RX, RY;                    // LDS row strides (bytes) of the X / dY tiles
   int off_xlo, off_y, off_ylo, off_ss, off_red;
   int nchunks;                   // pixel split of this job
-  int dbg;
 };
 
 constexpr int WG_MAXJ = 12;      // jobs per launch (the argument block must stay below 4 KB)
@@ -149,7 +148,7 @@ __global__ void __launch_bounds__(NW * 64) conv_wgrad_kernel(const MultiArgs m) 
 
   for (int tile = tile0 - 1; tile < tile1; ++tile) {
     // ================= stage tile `tile` from the registers filled one iteration ago =============================
-    if (tile >= tile0 && !(a.dbg & 4)) {
+    if (tile >= tile0) {
       const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, b = tile / tps;
       const int oy0 = ty * TH, ox0 = tx * TW;
       const int iy0 = oy0 * a.stride - a.pad_t, ix0 = ox0 * a.stride - a.pad_l;
@@ -230,7 +229,7 @@ __global__ void __launch_bounds__(NW * 64) conv_wgrad_kernel(const MultiArgs m) 
       __syncthreads();
     }
     // ================= issue the global loads of tile + 1 =========================================================
-    if (tile + 1 < tile1 && !(a.dbg & 8)) {
+    if (tile + 1 < tile1) {
       const int nt = tile + 1;
       const int tx = nt % a.tiles_x, ty = (nt / a.tiles_x) % a.tiles_y, b = nt / tps;
       const int oy0 = ty * TH, ox0 = tx * TW;
@@ -311,7 +310,7 @@ __global__ void __launch_bounds__(NW * 64) conv_wgrad_kernel(const MultiArgs m) 
         }
       }
     }
-    if (tile < tile0 || (a.dbg & 1)) continue;
+    if (tile < tile0) continue;
     // ================= MFMA: 4 k-steps of 32 output pixels =========================================================
 #pragma unroll 1
     for (int r = 0; r < BM / 32; ++r) {
@@ -361,7 +360,6 @@ __global__ void __launch_bounds__(NW * 64) conv_wgrad_kernel(const MultiArgs m) 
     }
   }
 
-  if (a.dbg & 2) return;
   // ---- epilogue: add this block's partial dW (and db) to global memory --------------------------------------
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
@@ -514,7 +512,6 @@ static int fill_job(WgradArgs& a, const hdrsky_wgrad_job& j) {
   a.upsample = d->upsample; a.Hc = d->Hc; a.Wc = d->Wc;
   a.in_mode = d->in_mode; a.ss_bstride = d->ss_bstride; a.in_nparts = d->in_nparts;
   a.in_eps = d->in_eps; a.in_inv_count = 1.f / (float)(d->H * d->W); a.in_slope = d->in_slope;
-  if (const char* e = getenv("HDRSKY_WGRAD_DBG")) a.dbg = atoi(e);
   return HDRSKY_OK;
 }
 
