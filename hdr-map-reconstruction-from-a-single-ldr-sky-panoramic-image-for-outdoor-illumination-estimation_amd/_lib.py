@@ -68,6 +68,8 @@ SIGNATURES = {
     "hdrsky_leaky_relu": (c_int, [P, P, c_size_t, c_float, P]),
     "hdrsky_da_offsets": (c_int, [c_int, c_int, c_int, c_int, c_int, P]),
     "hdrsky_da_conv2d_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "hdrsky_da_gather": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "hdrsky_da_scatter": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
     "hdrsky_bn_train_finalize": (c_int, [P, c_int, c_int, c_int, P, P, c_float, c_float, P, P, P, P, P, P, P]),
     "hdrsky_bn_bwd_nblocks": (c_int, []),
     "hdrsky_bn_act_bwd": (c_int, [P, P, P, P, P, P, c_float, c_int, c_int, P, P, P, P, P]),

@@ -139,6 +139,79 @@ __global__ void __launch_bounds__(256) da_conv_kernel(const DaArgs a) {
   }
 }
 
+// ---- backward building blocks ----------------------------------------------------------------------------------
+// The layer is y = G(x) W + b with G the (linear) bilinear gather [B,h,w,k*k*C].  Its gradients are
+//   dW = G(x)^T dY   (a 1x1-conv weight gradient on the gathered tensor),   db = sum dY,
+//   dX = G^T (dY W^T) (a 1x1 conv producing dG, then the transpose of the gather = a bilinear SCATTER with the same
+//                      corner indices and weights; fp32 atomics because several samples share a corner).
+struct DaGsArgs {
+  const float* src;   // gather: x [B,H,W,C]            scatter: dG [B,H,W,k2*C]
+  float* dst;         // gather: G [B,H,W,k2*C]         scatter: dx [B,H,W,C] (zeroed by the caller)
+  const float* offs;
+  int B, H, W, C, ksize, k2, pad, in_h, in_w;
+};
+
+template <bool SCATTER>
+__global__ void __launch_bounds__(256) da_gather_scatter_kernel(const DaGsArgs a) {
+  const int nq = a.C >> 3;
+  const size_t total = (size_t)a.B * a.H * a.W * a.k2 * nq;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int q = (int)(i % nq);
+    size_t r = i / nq;
+    const int t = (int)(r % a.k2); r /= a.k2;
+    const int ox = (int)(r % a.W); r /= a.W;
+    const int oy = (int)(r % a.H);
+    const int b = (int)(r / a.H);
+    const float off_y = a.offs[(oy * a.k2 + t) * 2], off_x = a.offs[(oy * a.k2 + t) * 2 + 1];
+    const Tap4 s = da_tap((float)(oy + t / a.ksize), (float)(ox + t % a.ksize), off_y, off_x, a.in_h, a.in_w);
+    const int ys[4] = {s.y0, s.y0, s.y1, s.y1}, xs[4] = {s.x0, s.x1, s.x0, s.x1};
+    const float ws[4] = {s.w0, s.w1, s.w2, s.w3};
+    const size_t gidx = ((((size_t)b * a.H + oy) * a.W + ox) * a.k2 + t) * a.C + q * 8;
+    float v[8];
+    if (SCATTER) {
+      const float4 lo = *reinterpret_cast<const float4*>(a.src + gidx), hi = *reinterpret_cast<const float4*>(a.src + gidx + 4);
+      v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int yy = ys[k] - a.pad, xx = xs[k] - a.pad;      // un-padded coordinates; the zero border carries no gradient
+      if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
+        const size_t xi = (((size_t)b * a.H + yy) * a.W + xx) * a.C + q * 8;
+        if (SCATTER) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) atomicAdd(a.dst + xi + j, ws[k] * v[j]);
+        } else {
+          const float4 lo = *reinterpret_cast<const float4*>(a.src + xi), hi = *reinterpret_cast<const float4*>(a.src + xi + 4);
+          v[0] += ws[k] * lo.x; v[1] += ws[k] * lo.y; v[2] += ws[k] * lo.z; v[3] += ws[k] * lo.w;
+          v[4] += ws[k] * hi.x; v[5] += ws[k] * hi.y; v[6] += ws[k] * hi.z; v[7] += ws[k] * hi.w;
+        }
+      }
+    }
+    if (!SCATTER) {
+      *reinterpret_cast<float4*>(a.dst + gidx) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(a.dst + gidx + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+  }
+}
+
+static int da_gs_launch(bool scatter, const float* src, const float* offs, int B, int H, int W, int C, int ksize, float* dst,
+                        void* stream) {
+  if (!src || !offs || !dst || (ksize & 1) == 0 || (C & 7)) return HDRSKY_EINVAL;
+  DaGsArgs a{};
+  a.src = src; a.dst = dst; a.offs = offs; a.B = B; a.H = H; a.W = W; a.C = C; a.ksize = ksize; a.k2 = ksize * ksize;
+  a.pad = ksize > 1 ? (ksize - 1) / 2 : 0;
+  a.in_h = H + (ksize > 1 ? ksize - 1 : 0); a.in_w = W + (ksize > 1 ? ksize - 1 : 0);
+  const size_t total = (size_t)B * H * W * a.k2 * (C / 8);
+  size_t grid = (total + 255) / 256; if (grid > 65535) grid = 65535; if (grid < 1) grid = 1;
+  if (scatter) hipLaunchKernelGGL(da_gather_scatter_kernel<true>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(da_gather_scatter_kernel<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -217,6 +290,16 @@ int hdrsky_da_conv2d_fwd(const float* x, const void* w_hi, const void* w_lo, con
   }
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
+}
+
+// G[B,H,W,k*k*C] = bilinear gather of x[B,H,W,C] (the operand of the layer's matmul, distortion_aware_ops.py:62-113)
+int hdrsky_da_gather(const float* x, const float* offs, int B, int H, int W, int C, int ksize, float* G, void* stream) {
+  return da_gs_launch(false, x, offs, B, H, W, C, ksize, G, stream);
+}
+
+// dx[B,H,W,C] += transpose of the gather applied to dG[B,H,W,k*k*C] (fp32 atomics: zero dx first)
+int hdrsky_da_scatter(const float* dG, const float* offs, int B, int H, int W, int C, int ksize, float* dx, void* stream) {
+  return da_gs_launch(true, dG, offs, B, H, W, C, ksize, dx, stream);
 }
 
 }  // extern "C"

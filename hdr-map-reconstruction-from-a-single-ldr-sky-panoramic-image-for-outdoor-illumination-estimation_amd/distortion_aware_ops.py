@@ -45,6 +45,10 @@ class conv2d:
             self.build(tuple(inputs.shape), inputs.device)
         return K.da_conv2d(inputs, self._pw, self.bias, self._offs, self.compute)
 
+    def backward(self, inputs, dy, want_dx=True):
+        """What a tape returns for this layer: (d inputs, d kernel [k*k*Cin, filters], d bias)."""
+        return K.da_conv2d_bwd(inputs, dy, self.kernel, self._offs, self.kernel_size, self.compute, want_dx)
+
 
 class deconv2d(conv2d):
     """Resize-deconv: tf.image.resize(BILINEAR) to output_imshape (2x), then the distortion-aware conv (:321-395)."""
@@ -62,3 +66,7 @@ class deconv2d(conv2d):
         if not self.built:
             self.build(tuple(up.shape), inputs.device)
         return K.da_conv2d(up, self._pw, self.bias, self._offs, self.compute)
+
+    def backward(self, inputs, dy, want_dx=True):
+        dup, dk, db = super().backward(K.up2x(inputs), dy, want_dx)
+        return (K.up2x_bwd(dup) if want_dx else None), dk, db

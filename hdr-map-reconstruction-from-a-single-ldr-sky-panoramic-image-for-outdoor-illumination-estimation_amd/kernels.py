@@ -692,3 +692,29 @@ def da_conv2d(x, pw: PackedConv, bias, offs, compute=BF16):
     L.check(L.load().hdrsky_da_conv2d_fwd(_p(x), _p(pw.hi), _p(pw.lo), _p(bias), _p(offs), B, H, W, C, pw.Cout, pw.KH,
                                           compute, _p(y), _stream()), "da_conv2d_fwd")
     return y
+
+
+def da_gather(x, offs, ksize):
+    """G [B,H,W,k*k*C]: the bilinear-gathered operand of the distortion-aware conv's matmul."""
+    B, H, W, C = x.shape
+    _f32(x); _f32(offs, H, ksize * ksize, 2)
+    G = torch.empty((B, H, W, ksize * ksize * C), dtype=torch.float32, device=x.device)
+    L.check(L.load().hdrsky_da_gather(_p(x), _p(offs), B, H, W, C, ksize, _p(G), _stream()), "da_gather")
+    return G
+
+
+def da_conv2d_bwd(x, dy, kernel, offs, ksize, compute=BF16, want_dx=True):
+    """Gradients of y = da_conv2d(x; kernel [k*k*C, F], bias): returns (dx or None, dkernel [k*k*C, F], dbias [F])."""
+    B, H, W, C = x.shape
+    F = dy.shape[-1]
+    k2 = ksize * ksize
+    _f32(dy, B, H, W, F); _f32(kernel, k2 * C, F)
+    G = da_gather(x, offs, ksize)
+    dw, db = conv2d_wgrad(G, dy, 1, 1, compute=compute)                       # [1,1,k2*C,F]
+    dx = None
+    if want_dx:
+        wT = kernel.t().contiguous().view(1, 1, F, k2 * C)                   # dG = dY W^T as a 1x1 conv
+        dG, _ = conv2d(dy, PackedConv(wT, precise=(compute == BF16X3)), None, compute=compute)
+        dx = torch.zeros_like(x)
+        L.check(L.load().hdrsky_da_scatter(_p(dG), _p(offs), B, H, W, C, ksize, _p(dx), _stream()), "da_scatter")
+    return dx, dw.view(k2 * C, F), db

@@ -291,6 +291,11 @@ int hdrsky_da_offsets(int h, int w, int ksize, int dilation_rate, int skydome, f
  * copy of hdrsky_da_offsets(H, W, k, ..).  stride 1, Cin % 32 == 0.  deconv2d.call (:321-395) = hdrsky_up2x_fwd + this. */
 int hdrsky_da_conv2d_fwd(const float* x, const void* w_hi, const void* w_lo, const float* bias, const float* offs, int B,
                          int H, int W, int Cin, int Cout, int ksize, int compute, float* y, void* stream);
+/* Backward building blocks of the distortion-aware conv (tf.GradientTape through distortion_aware_ops.py:62-121):
+ * with G = hdrsky_da_gather(x) [B,H,W,k*k*C] the layer is a 1x1 conv of G, so dW = hdrsky_conv2d_wgrad(1x1; G, dY),
+ * dG = hdrsky_conv2d_fwd(1x1 with the transposed kernel; dY) and dx = hdrsky_da_scatter(dG) (dx zeroed; fp32 atomics). */
+int hdrsky_da_gather(const float* x, const float* offs, int B, int H, int W, int C, int ksize, float* G, void* stream);
+int hdrsky_da_scatter(const float* dG, const float* offs, int B, int H, int W, int C, int ksize, float* dx, void* stream);
 
 #ifdef __cplusplus
 }

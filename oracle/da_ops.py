@@ -146,3 +146,44 @@ def da_deconv2d(x, kernel, bias, offsets, out_h, out_w, k=3):
     """distortion_aware_ops.deconv2d.call (:321-395): bilinear resize to output_imshape, then the
     conv2d call with strides forced to 1 (:323); offsets are built for (out_h, out_w) (:315)."""
     return da_conv2d(resize_bilinear(x, out_h, out_w), kernel, bias, offsets, k=k, stride=1)
+
+
+def da_conv2d_grads(x, kernel, offsets, dy, k=3):
+    """Gradients of y = da_conv2d(x, kernel, bias, offsets) for an upstream dy (what tf.GradientTape returns for
+    distortion_aware_ops.conv2d.call :50-123): the layer is linear in x and in the kernel, y = G(x) W + b with G the
+    bilinear gather, so dW = G(x)^T dy, db = sum dy and dx = G^T (dy W^T) - the transpose of the gather is a scatter-add
+    with the same corner indices and weights (the zero padding receives, and drops, its share).
+    Returns (dx [B,h,w,C], dkernel [k*k*C, F], dbias [F])."""
+    x = np.asarray(x, F32); dy = np.asarray(dy, F32); kernel = np.asarray(kernel, F32)
+    b, h, w, c = x.shape
+    pt, pb = _pad_amounts(h, k, 1)
+    pl, pr = _pad_amounts(w, k, 1)
+    in_h, in_w = h + pt + pb, w + pl + pr
+    oy = np.arange(h).reshape(h, 1, 1); ox = np.arange(w).reshape(1, w, 1)
+    ty = (np.arange(k * k) // k).reshape(1, 1, k * k); tx = (np.arange(k * k) % k).reshape(1, 1, k * k)
+    y = (oy + ty + 0 * ox).astype(F32) + offsets[:, None, :, 0]
+    xx = (ox + tx + 0 * oy).astype(F32) + offsets[:, None, :, 1]
+    y = np.clip(y, F32(0), F32(in_h - 1))
+    xx = np.where(xx < 0, xx + F32(in_w), xx)
+    xx = np.where(xx > in_w - 1, xx - F32(in_w), xx)
+    y0 = np.floor(y).astype(np.int32); x0 = np.floor(xx).astype(np.int32)
+    y1, x1 = y0 + 1, x0 + 1
+    y0 = np.clip(y0, 0, in_h - 1); y1 = np.clip(y1, 0, in_h - 1)
+    x0_w, x1_w = x0, x1
+    x0 = np.where(x0 < 0, x0 + in_w, x0); x1 = np.where(x1 < 0, x1 + in_w, x1)
+    x0 = np.where(x0 > in_w - 1, x0 - in_w, x0); x1 = np.where(x1 > in_w - 1, x1 - in_w, x1)
+    y0f, y1f, x0f, x1f = y0.astype(F32), y1.astype(F32), x0_w.astype(F32), x1_w.astype(F32)
+    ws = [(y1f - y) * (x1f - xx), (y1f - y) * (xx - x0f), (y - y0f) * (x1f - xx), (y - y0f) * (xx - x0f)]
+    corners = [(y0, x0), (y0, x1), (y1, x0), (y1, x1)]
+    xp = np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0))).astype(np.float64)
+    G = sum(wk[None, ..., None].astype(np.float64) * xp[:, yk, xk] for wk, (yk, xk) in zip(ws, corners))   # [B,h,w,k2,C]
+    dyf = dy.reshape(b * h * w, -1).astype(np.float64)
+    dkernel = G.reshape(b * h * w, k * k * c).T @ dyf
+    dbias = dyf.sum(axis=0)
+    dG = (dyf @ kernel.astype(np.float64).T).reshape(b, h, w, k * k, c)
+    dxp = np.zeros_like(xp)
+    for wk, (yk, xk) in zip(ws, corners):
+        for bi in range(b):
+            np.add.at(dxp[bi], (yk, xk), wk[..., None].astype(np.float64) * dG[bi])
+    dx = dxp[:, pt:pt + h, pl:pl + w]
+    return dx.astype(F32), dkernel.astype(F32), dbias.astype(F32)

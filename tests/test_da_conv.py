@@ -23,6 +23,48 @@ def test_offset_table_matches_oracle(h, w, k, dil):
     assert np.abs(got_flat - da_ops.distortion(h, w, k, dil, False)).max() <= 2e-4
 
 
+def test_da_conv_gradient_oracle_is_the_adjoint():
+    """The gradient restatement against the definition of an adjoint: <dy, DA(x') - DA(0)> = <dx, x'> for any x' (the
+    layer is affine in x), <dy, DA(x; W') - DA(x; 0)> = <dW, W'>, and db = sum dy."""
+    rng = np.random.default_rng(12)
+    B, H, W, C, F = 2, 8, 32, 8, 5
+    x, xq = rng.standard_normal((2, B, H, W, C)).astype(np.float32)
+    kern, kq = (rng.standard_normal((2, 9 * C, F)) / 8).astype(np.float32)
+    bias = rng.standard_normal(F).astype(np.float32)
+    dy = rng.standard_normal((B, H, W, F)).astype(np.float32)
+    offs = da_ops.distortion(H, W)
+    dx, dk, db = da_ops.da_conv2d_grads(x, kern, offs, dy)
+    zero_b = np.zeros(F, np.float32)
+    lhs = float((dy.astype(np.float64) * da_ops.da_conv2d(xq, kern, zero_b, offs)).sum())
+    assert abs(lhs - float((dx.astype(np.float64) * xq).sum())) <= 1e-4 * abs(lhs)
+    lhs = float((dy.astype(np.float64) * da_ops.da_conv2d(x, kq, zero_b, offs)).sum())
+    assert abs(lhs - float((dk.astype(np.float64) * kq).sum())) <= 1e-4 * abs(lhs)
+    assert np.allclose(db, dy.reshape(-1, F).sum(0), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 8, 32, 128, 128), (2, 16, 64, 64, 64), (1, 8, 32, 32, 64)])
+def test_da_conv_backward_matches_oracle(dev, shape):
+    """hdrsky_da_gather / 1x1 wgrad / 1x1 conv / hdrsky_da_scatter composed as the layer's backward pass."""
+    K = pkg("kernels")
+    B, H, W, C, F = shape
+    rng = np.random.default_rng(B * 17 + C + F)
+    x = rng.standard_normal((B, H, W, C)).astype(np.float32)
+    kern = (rng.standard_normal((9 * C, F)) / np.sqrt(9 * C)).astype(np.float32)
+    dy = rng.standard_normal((B, H, W, F)).astype(np.float32)
+    offs = K.da_offsets(H, W, 3, 1, True)
+    rdx, rdk, rdb = da_ops.da_conv2d_grads(x, kern, da_ops.distortion(H, W), dy)
+    d = lambda a: torch.from_numpy(a).to(dev)
+    dx, dk, db = K.da_conv2d_bwd(d(x), d(dy), d(kern), d(offs), 3, compute=K.BF16X3)
+    assert_close(dx, rdx, 3e-4, "da conv dx"); assert_close(dk, rdk, 3e-4, "da conv dkernel"); assert_close(db, rdb, 1e-4, "da conv dbias")
+    dx16, dk16, _ = K.da_conv2d_bwd(d(x), d(dy), d(kern), d(offs), 3, compute=K.BF16)
+    assert_close_bf16(dx16, rdx, "da conv dx bf16"); assert_close_bf16(dk16, rdk, "da conv dkernel bf16")
+    # gathered operand against the forward pass: G(x) W + b == da_conv2d(x)
+    G = K.da_gather(d(x), d(offs), 3)
+    y = K.da_conv2d(d(x), K.PackedConv(d(kern).view(3, 3, C, F)), torch.zeros(F, device=dev), d(offs), K.BF16X3)
+    assert_close(G.reshape(-1, 9 * C).double() @ d(kern).double(), y.reshape(-1, F), 3e-4, "gather consistent with forward")
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(2, 8, 32, 128, 128), (2, 16, 64, 64, 64), (1, 32, 128, 32, 32), (3, 8, 32, 32, 96)])
 def test_da_conv_matches_oracle(dev, shape):
@@ -61,3 +103,29 @@ def test_da_layer_api(dev):
     z = dl(x)
     refz = da_ops.da_deconv2d(x.cpu().numpy(), dl.kernel.cpu().numpy(), dl.bias.cpu().numpy(), da_ops.distortion(16, 64), 16, 64)
     assert_close(z, refz, 3e-4, "layer deconv2d")
+
+
+@pytest.mark.gpu
+def test_da_layer_backward(dev):
+    """Layer objects' backward(): conv2d against the numpy adjoint; deconv2d = resize adjoint of the conv's input gradient."""
+    da = pkg("distortion_aware_ops"); K = pkg("kernels")
+    rng = np.random.default_rng(8)
+    x = torch.from_numpy(rng.standard_normal((2, 8, 32, 64)).astype(np.float32)).to(dev)
+    layer = da.conv2d(64, kernel_size=3, compute=K.BF16X3)
+    y = layer(x)
+    dy = torch.from_numpy(rng.standard_normal(tuple(y.shape)).astype(np.float32)).to(dev)
+    dx, dk, db = layer.backward(x, dy)
+    rdx, rdk, rdb = da_ops.da_conv2d_grads(x.cpu().numpy(), layer.kernel.cpu().numpy(), da_ops.distortion(8, 32), dy.cpu().numpy())
+    assert_close(dx, rdx, 3e-4, "layer dx"); assert_close(dk, rdk, 3e-4, "layer dkernel"); assert_close(db, rdb, 1e-4, "layer dbias")
+    dl = da.deconv2d(32, kernel_size=3, output_imshape=[16, 64], compute=K.BF16X3)
+    y2 = dl(x)
+    dy2 = torch.from_numpy(rng.standard_normal(tuple(y2.shape)).astype(np.float32)).to(dev)
+    dx2, dk2, _ = dl.backward(x, dy2)
+    up = da_ops.resize_bilinear(x.cpu().numpy(), 16, 64)
+    rdup, rdk2, _ = da_ops.da_conv2d_grads(up, dl.kernel.cpu().numpy(), da_ops.distortion(16, 64), dy2.cpu().numpy())
+    assert_close(dk2, rdk2, 3e-4, "deconv dkernel")
+    # adjoint of the 2x bilinear resize, via its definition: <resize(e), rdup> for the gradient of each input element
+    xt = x.cpu().double().requires_grad_(True)
+    from oracle import tfsem as T
+    (ref_dx2,) = torch.autograd.grad(T.resize_bilinear(xt, 16, 64), xt, torch.from_numpy(rdup).double())
+    assert_close(dx2, ref_dx2.float(), 3e-4, "deconv dx")
