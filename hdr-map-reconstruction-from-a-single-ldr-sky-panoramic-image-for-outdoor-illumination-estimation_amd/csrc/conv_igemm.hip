@@ -690,6 +690,7 @@ int dispatch_tile(ConvKArgs& a, const TileCfg& t, hipStream_t s) {
   HDRSKY_CASE_DB(1, 4, 4, 1, 32) HDRSKY_CASE_DB(2, 4, 4, 1, 32) HDRSKY_CASE_DB(1, 8, 4, 1, 32) HDRSKY_CASE_DB(2, 2, 4, 1, 32)
   HDRSKY_CASE_DB(4, 2, 4, 1, 32) HDRSKY_CASE_DB(2, 4, 2, 1, 32) HDRSKY_CASE_DB(4, 1, 4, 1, 32) HDRSKY_CASE_DB(8, 1, 4, 1, 32)
   HDRSKY_CASE_DB(1, 4, 4, 1, 16) HDRSKY_CASE_DB(1, 4, 2, 1, 16) HDRSKY_CASE_DB(2, 2, 4, 2, 32) HDRSKY_CASE_DB(2, 4, 4, 2, 32)
+  HDRSKY_CASE_DB(1, 8, 2, 1, 16)
 #undef HDRSKY_CASE_DB
 #undef HDRSKY_CASE
   return HDRSKY_EUNSUPPORTED;
@@ -711,7 +712,8 @@ TileCfg choose_tile(const hdrsky_conv_desc* d) {
   const bool narrow = d->Cin <= 8;
   TileCfg t{2, 2, 2, 2, tw, 0};
   if (tw == 16) {
-    if (d->Cout >= 64) t = (d->Ho >= 4) ? TileCfg{1, 4, 4, 1, 16, 1} : TileCfg{1, 4, 2, 1, 16, 1};
+    if (d->Cout >= 128) t = TileCfg{1, 8, 2, 1, 16, 1};               // 32 px x 128 ch, 8 waves (the 4x16-pixel layers)
+    else if (d->Cout >= 64) t = (d->Ho >= 4) ? TileCfg{1, 4, 4, 1, 16, 1} : TileCfg{1, 4, 2, 1, 16, 1};
     else if (d->Cout > 16) t = TileCfg{2, 2, 2, 1, 16, 0};
     else t = TileCfg{4, 1, 1, 1, 16, 0};
   } else if (d->Cout >= 64) {
