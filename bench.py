@@ -106,7 +106,6 @@ def cpu_baseline(torch, workload, nets_np, batch_np):
 
 def main():
     args = parse()
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # the step uses 4 streams + RCCL's: see the package __init__
     import torch
     import torch.distributed as dist
 

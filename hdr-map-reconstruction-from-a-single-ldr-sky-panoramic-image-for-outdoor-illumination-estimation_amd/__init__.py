@@ -9,10 +9,4 @@ kernels for gfx950 behind the C ABI in include/hdrsky.h.  Sub-modules:
   kernels  torch-tensor front end of each C entry point
   engine   fused execution plan of the generator graph
 """
-import os as _os
-
-# The training step runs on four HIP streams (+ the caller's and RCCL's); the runtime's default of four hardware queues
-# would make some of them share a queue and serialise.  Must be set before the first HIP call of the process.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
 PACKAGE = __name__
