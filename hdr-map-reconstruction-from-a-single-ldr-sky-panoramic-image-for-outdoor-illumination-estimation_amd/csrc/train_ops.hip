@@ -217,19 +217,20 @@ __global__ void up2x_fwd_kernel(const float* __restrict__ a, const float* __rest
 }
 
 // dx[b,iy,ix,c] = sum over the <= 4x4 outputs that sample (iy,ix) of their bilinear weight * dy   (exact adjoint)
-__global__ void up2x_bwd_kernel(const float* __restrict__ dy, int B, int H, int W, int C, float scale, int accumulate,
-                                float* __restrict__ dx) {
-  const size_t total = (size_t)B * H * W * C;
+// V = channels per thread (4: float4 loads when C % 4 == 0; 1: the 3-channel DoG images)
+template <int V>
+__global__ void __launch_bounds__(256) up2x_bwd_kernel(const float* __restrict__ dy, int B, int H, int W, int C, float scale,
+                                                       int accumulate, float* __restrict__ dx) {
+  const int CV = C / V;
+  const size_t total = (size_t)B * H * W * CV;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    const size_t pix = i / C;
+    const int c = (int)(i % CV) * V;
+    const size_t pix = i / CV;
     const int ix = (int)(pix % W), iy = (int)((pix / W) % H), bb = (int)(pix / ((size_t)W * H));
     float wy[4], wx[4];
-    int oys[4], oxs[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int oy = 2 * iy - 1 + k, ox = 2 * ix - 1 + k;
-      oys[k] = oy; oxs[k] = ox;
       wy[k] = 0.f; wx[k] = 0.f;
       if (oy >= 0 && oy < 2 * H) {
         int lo, hi; float t; axis2x(oy, H, lo, hi, t);
@@ -240,15 +241,32 @@ __global__ void up2x_bwd_kernel(const float* __restrict__ dy, int B, int H, int 
         wx[k] = (lo == ix ? 1.f - t : 0.f) + (hi == ix ? t : 0.f);
       }
     }
-    float s = 0.f;
+    float s[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) s[v] = 0.f;
 #pragma unroll
     for (int ky = 0; ky < 4; ++ky)
 #pragma unroll
       for (int kx = 0; kx < 4; ++kx) {
         const float w = wy[ky] * wx[kx];
-        if (w != 0.f) s += w * dy[((size_t)(bb * 2 * H + oys[ky]) * 2 * W + oxs[kx]) * C + c];
+        if (w != 0.f) {   // zero weight <=> output pixel outside the image: never dereferenced
+          const float* p = dy + ((size_t)(bb * 2 * H + 2 * iy - 1 + ky) * 2 * W + 2 * ix - 1 + kx) * C + c;
+          if (V == 4) {
+            const float4 d = *reinterpret_cast<const float4*>(p);
+            s[0] += w * d.x; s[1 % V] += w * d.y; s[2 % V] += w * d.z; s[3 % V] += w * d.w;
+          } else {
+            s[0] += w * p[0];
+          }
+        }
       }
-    dx[i] = accumulate ? dx[i] + s * scale : s * scale;
+    float* o = dx + pix * C + c;
+    if (V == 4) {
+      float4 r = make_float4(s[0] * scale, s[1 % V] * scale, s[2 % V] * scale, s[3 % V] * scale);
+      if (accumulate) { const float4 q = *reinterpret_cast<const float4*>(o); r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w; }
+      *reinterpret_cast<float4*>(o) = r;
+    } else {
+      o[0] = accumulate ? o[0] + s[0] * scale : s[0] * scale;
+    }
   }
 }
 
@@ -761,8 +779,12 @@ int hdrsky_up2x_fwd(const float* a, const float* b, int B, int H, int W, int C, 
 
 int hdrsky_up2x_bwd(const float* dy, int B, int H, int W, int C, float scale, int accumulate, float* dx, void* stream) {
   if (!dy || !dx) return HDRSKY_EINVAL;
-  hipLaunchKernelGGL(up2x_bwd_kernel, dim3(grid_for((size_t)B * H * W * C)), dim3(256), 0, S_(stream), dy, B, H, W, C, scale,
-                     accumulate, dx);
+  if ((C & 3) == 0)
+    hipLaunchKernelGGL(up2x_bwd_kernel<4>, dim3(grid_for((size_t)B * H * W * C / 4)), dim3(256), 0, S_(stream), dy, B, H, W, C,
+                       scale, accumulate, dx);
+  else
+    hipLaunchKernelGGL(up2x_bwd_kernel<1>, dim3(grid_for((size_t)B * H * W * C)), dim3(256), 0, S_(stream), dy, B, H, W, C, scale,
+                       accumulate, dx);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }
