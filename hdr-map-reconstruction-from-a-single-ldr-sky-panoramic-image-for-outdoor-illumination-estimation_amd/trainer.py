@@ -102,7 +102,10 @@ class Trainer:
         self.gs = FlatParams(named, self.device)          # optimizer_gen: _gen + _sun variables (train.py:402-403)
         self.ds = FlatParams(OrderedDict(("dis." + k, v) for k, v in dis_params.items()), self.device)
         self.vgg = E._dev(vgg_params, self.device)
-        self._streams = [torch.cuda.Stream(device=self.device) for _ in range(4)]
+        # streams 0-2 carry the critical chain (forward, losses, generator backward) at high priority; 3-4 carry what
+        # only has to finish by the end of the step (discriminator step, Dense-layer optimizer, sun-pose backward,
+        # weight gradients) at low priority, so they fill the gaps instead of delaying the chain
+        self._streams = [torch.cuda.Stream(device=self.device) for _ in range(5)]
         self._graphs, self._gscale = None, 1.0 / world_size
         self.losses = torch.zeros(len(LOSS_SLOTS), dtype=torch.float32, device=self.device)
         self._wjobs = {}
@@ -303,14 +306,16 @@ class Trainer:
         """vgg2(hdr_t_gamma) (train.py:309): does not depend on the generator, so it runs beside the forward pass."""
         return self._vgg_forward(K.tonemap(hdr_t, False), None)
 
-    def _vgg_loss_and_grad(self, y_gamma, target_pools):
+    def _vgg_loss_and_grad(self, y_gamma, target_pools, share=1.0, out=None):
+        """Perceptual term of the samples in y_gamma; `share` = their fraction of the batch (the L1 terms are batch
+        means, so a part of the batch contributes share x its own mean)."""
         cp, B = self.compute, y_gamma.shape[0]
         acts = {}
         pools = self._vgg_forward(y_gamma, acts)
         dps = []
         for p, q in zip(pools, target_pools):   # 0.01 * sum_i mean|pool_i(pred) - pool_i(target)|, gradient wrt the prediction
             dp = torch.empty_like(p)
-            K.l1(p, q, 1.0, 0.01, self.losses[1:2], da=dp)
+            K.l1(p, q, share, 0.01 * share, self.losses[1:2], da=dp)
             dps.append(dp)
         g = None
         for bi, blk in reversed(list(enumerate(self.VGG_BLOCKS))):
@@ -323,7 +328,7 @@ class Trainer:
                 g, _ = K.conv2d_dgrad(g, self.vgg_pkT[name], d, compute=cp)   # wrt this conv's (post-ReLU) input
                 if k > 0:
                     g = K.affine_act_bwd(acts[blk[k - 1]], g, None, None, 0.0)
-        return K.axpby(g, 255.0)   # d/d y_gamma of the 0.01-weighted perceptual term
+        return K.axpby(g, 255.0, out=out)   # d/d y_gamma of the 0.01-weighted perceptual term
 
     # ---- one training step -----------------------------------------------------------------------------------
     # The step is a DAG of linear SEGMENTS, each bound to one of four HIP streams.  Eagerly they are enqueued in plan
@@ -392,7 +397,8 @@ class Trainer:
             sun_gamma = decode("u", rad_gamma)
             y_gamma, y_lin, alpha, sky_lin, sun_lin = K.blend(T["sky_gamma"], sun_gamma, E.THRESHOLD)
             T.update(y_gamma=y_gamma, y_lin=y_lin, alpha=alpha, sun_gamma=sun_gamma, gamma=gamma, beta=beta,
-                     rad_gamma=rad_gamma, rad_lin=rad_lin, sky_lin=sky_lin, sun_lin=sun_lin)
+                     rad_gamma=rad_gamma, rad_lin=rad_lin, sky_lin=sky_lin, sun_lin=sun_lin,
+                     dyg=torch.empty_like(y_gamma))
 
         # ------------------------------------------------------------------ losses (train.py:301-331)
         @seg("loss_main", 0)
@@ -402,11 +408,22 @@ class Trainer:
             K.dog_loss(T["y_lin"], T["hdr_t"], 1000.0, self.losses[2:3], dyl)                       # 1000 * DoG
             T["dcmf"] = K.kl(T["gt"], T["t"]["cmf"], self.losses[0:1])                              # KL
 
+        # 0.01 * perceptual: the longest pole between the forward pass and the backward pass, and the main chain idles
+        # meanwhile - the batch is split in two halves that run on two streams (the L1 terms are batch means)
+        half = B // 2
+
         @seg("loss_vgg", 1, ["fwd_blend", "vgg_target"])
         def _():
-            T["dyg"] = self._vgg_loss_and_grad(T["y_gamma"], T["vgg_tgt"])                          # 0.01 * perceptual
+            n = half if half > 0 else B
+            self._vgg_loss_and_grad(T["y_gamma"][:n], [p[:n] for p in T["vgg_tgt"]], n / B, out=T["dyg"][:n])
 
-        @seg("loss_adv", 2, ["fwd_blend"])
+        if half > 0:
+            @seg("loss_vgg_b", 2, ["fwd_blend"])
+            def _():
+                self._vgg_loss_and_grad(T["y_gamma"][half:], [p[half:] for p in T["vgg_tgt"]], (B - half) / B,
+                                        out=T["dyg"][half:])
+
+        @seg("loss_adv", 0)
         def _():       # adversarial term: discriminator with inference-mode BN (train.py:302)
             cvo = c["dis.out"]
             Rg = self._down_stack("dis.", self.ds.w, K.concat2(T["ldr"], T["y_lin"]), training=False)
@@ -417,7 +434,7 @@ class Trainer:
             T["d_adv"] = K.slice_channels(din, 3, 3, 1.0)
 
         # ------------------------------------------------------------------ backward, first stretch
-        @seg("bwd_head", 0, ["loss_vgg", "loss_adv"])
+        @seg("bwd_head", 0, ["loss_vgg", "loss_vgg_b"])
         def _():       # blend -> decoder tails -> sun radiance head -> dcmf complete -> sun-pose Dense layers
             t, dyl = T["t"], T["dyl"]
             K.axpby(dyl, 1.0, T["d_adv"], 1.0, out=dyl)
@@ -434,8 +451,8 @@ class Trainer:
             T["dP3"] = K.fc_finalize(K.fc_dgrad(df1, self.fc1, cp)).reshape(B, h // 8, wd // 8, 128)
 
         # ------------------------------------------------------------------ discriminator step (train.py:351-380)
-        @seg("disc_step", 2)
-        def _():       # real then generated, BN batch statistics (after the inference-mode call of loss_adv: same stream)
+        @seg("disc_step", 3, ["loss_adv"])
+        def _():       # real then generated, BN batch statistics (after the inference-mode call of loss_adv)
             cvo = c["dis.out"]
             for which, img, target, slot in (("real", T["hdr_t"], 1.0, 6), ("fake", T["y_lin"], 0.0, 5)):
                 Rd = self._down_stack("dis.", self.ds.w, K.concat2(T["ldr"], img), training=True)
@@ -449,7 +466,7 @@ class Trainer:
         # The two Dense layers hold 50.3 M of the 58.3 M parameters and nothing reads their weights or gradients after
         # bwd_head: their RMSprop update and bf16 re-packing (~1 GB of HBM traffic) run here, beside the rest of the
         # backward pass, instead of at the end of the step.  (Data-parallel: after the all-reduce of that slice.)
-        @seg("apply_fc", 2, ["bwd_head"])
+        @seg("apply_fc", 3, ["bwd_head"])
         def _():
             fc0, fc1 = self.fc_grad_range()
             K.rmsprop(self.gs.flat[fc0:fc1], self.gs.grad[fc0:fc1], self.gs.ms[fc0:fc1], self.lr, gscale=self._gscale)
@@ -457,7 +474,7 @@ class Trainer:
             self.fc2.repack(w["sun.fc2.kernel"])
 
         # ------------------------------------------------------------------ sun-pose conv layers (sunpose_net.py:54-62)
-        @seg("bwd_sunpose", 1, ["bwd_head"])
+        @seg("bwd_sunpose", 4, ["bwd_head"])
         def _():
             t, dP = T["t"], T["dP3"]
             for l in (3, 2, 1):
@@ -489,7 +506,7 @@ class Trainer:
                 c["gen.conv3_" + sfx].dgrad(T["x"][-1], dd3, cp, out=dres)
             T["wq_dec"] = self._take_wgrads()
 
-        @seg("wg_dec", 3, ["bwd_dec"])
+        @seg("wg_dec", 4, ["bwd_dec"])
         def _():
             K.conv2d_wgrad_multi(T["wq_dec"])
 
@@ -503,7 +520,7 @@ class Trainer:
             self._down_stack_bwd("gen.sun.", w, g, R, dact4, training=True, want_input_grad=False)
             T["wq_sunrad"] = self._take_wgrads()
 
-        @seg("wg_sunrad", 3, ["bwd_sunrad"])
+        @seg("wg_sunrad", 4, ["bwd_sunrad"])
         def _():
             K.conv2d_wgrad_multi(T["wq_sunrad"])
 
@@ -522,7 +539,7 @@ class Trainer:
             T["dx_enc"] = dx
             T["wq_res"] = self._take_wgrads()
 
-        @seg("wg_res", 3, ["bwd_res"])
+        @seg("wg_res", 4, ["bwd_res"])
         def _():
             K.conv2d_wgrad_multi(T["wq_res"])
 
@@ -558,7 +575,7 @@ class Trainer:
         return self._wjobs.pop(torch.cuda.current_stream().cuda_stream, [])
 
     def _execute(self, names=None, graphs=None, hooks=None, pre_hooks=None):
-        """Enqueues the plan's segments (all, or those in `names`) on the four streams; `graphs` replays captured
+        """Enqueues the plan's segments (all, or those in `names`) on the five streams; `graphs` replays captured
         segments instead of re-issuing their launches.  pre_hooks[name]() / hooks[name]() run on the segment's stream
         right before / after it."""
         caller = torch.cuda.current_stream()
