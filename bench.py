@@ -57,7 +57,8 @@ def dominant_kernel_roofline(torch, K, pw, bias, batch, h, w, iters=200):
     stream = torch.cuda.current_stream()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    # thread_local: with a process group alive RCCL's watchdog thread queries events while this thread captures
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
         for _ in range(iters):
             K.conv2d(x, pw, bias, want_stats=True, compute=K.BF16, out=y)
     g.replay()
@@ -162,24 +163,29 @@ def main():
         par.broadcast_params_([tr.gs.flat, tr.ds.flat])   # replicas start from rank 0's weights
         tr.repack()
         fc0, fc1 = tr.fc_grad_range()
-        pending = []
 
-        def fc_grads_ready():
-            pending.append(dist.all_reduce(tr.gs.grad[fc0:fc1], async_op=True))
+        comm = torch.cuda.Stream(device=dev)
 
-        def fc_grads_reduced():          # runs on the stream of the Dense-layer optimizer segment, right before it
-            pending.pop().wait()
+        def fc_grads_reduce():
+            # Runs on the stream of the Dense-layer optimizer segment right before it - late in the HOST's launch order,
+            # so the RCCL enqueue cost does not delay the launches of the critical chain - but the collective itself
+            # only waits for the event behind the segment that completes these gradients: it starts on the GPU as
+            # soon as they exist and runs beside the rest of the backward pass.
+            comm.wait_event(tr.event(tr.FC_GRADS_READY))
+            with torch.cuda.stream(comm):
+                work = dist.all_reduce(tr.gs.grad[fc0:fc1], async_op=True)
+            work.wait()
 
         def grads_ready():
             dist.all_reduce(tr.gs.grad[:fc0])
             dist.all_reduce(tr.ds.grad)
-        hooks = {tr.FC_GRADS_READY: fc_grads_ready, tr.GRADS_READY: grads_ready} if dp else None
-        pre_hooks = {tr.APPLY[0]: fc_grads_reduced} if dp else None
+        hooks = {tr.GRADS_READY: grads_ready} if dp else None
+        pre_hooks = {tr.APPLY[0]: fc_grads_reduce} if dp else None
         roof_pw, roof_b = tr.conv["gen.res.0.conv1"].pk, tr.gs.w["gen.res.0.conv1.b"]
         probe = lambda out: out["y_final_lin"]
         if args.no_graph:
             out = tr.step(ldr, hdr, gt, update=False)
-            one_step = lambda: (tr.step(ldr, hdr, gt, update=False), hooks and [fc_grads_ready(), fc_grads_reduced(), grads_ready()],
+            one_step = lambda: (tr.step(ldr, hdr, gt, update=False), hooks and [fc_grads_reduce(), grads_ready()],
                                 tr.apply_gradients())
         else:
             out = tr.capture(ldr, hdr, gt)

@@ -12,6 +12,8 @@ RMS slots) so zeroing the gradients and the optimizer update are a single memset
 """
 from collections import OrderedDict
 
+import os
+
 import numpy as np
 import torch
 
@@ -102,10 +104,11 @@ class Trainer:
         self.gs = FlatParams(named, self.device)          # optimizer_gen: _gen + _sun variables (train.py:402-403)
         self.ds = FlatParams(OrderedDict(("dis." + k, v) for k, v in dis_params.items()), self.device)
         self.vgg = E._dev(vgg_params, self.device)
-        # streams 0-2 carry the critical chain (forward, losses, generator backward) at high priority; 3-4 carry what
-        # only has to finish by the end of the step (discriminator step, Dense-layer optimizer, sun-pose backward,
-        # weight gradients) at low priority, so they fill the gaps instead of delaying the chain
-        self._streams = [torch.cuda.Stream(device=self.device) for _ in range(5)]
+        # Three streams: 0 = the critical chain; 1 and 2 = the sun-pose branch / the two perceptual half-batches and,
+        # once those are done, the work that only has to finish by the end of the step (discriminator step, Dense-layer
+        # optimizer | sun-pose backward, weight gradients).  More streams than that end up sharing one of the runtime's
+        # four hardware queues with each other or with RCCL's stream (measured: 4.6 instead of 4.1 ms per step).
+        self._streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
         self._graphs, self._gscale = None, 1.0 / world_size
         self.losses = torch.zeros(len(LOSS_SLOTS), dtype=torch.float32, device=self.device)
         self._wjobs = {}
@@ -331,7 +334,7 @@ class Trainer:
         return K.axpby(g, 255.0, out=out)   # d/d y_gamma of the 0.01-weighted perceptual term
 
     # ---- one training step -----------------------------------------------------------------------------------
-    # The step is a DAG of linear SEGMENTS, each bound to one of four HIP streams.  Eagerly they are enqueued in plan
+    # The step is a DAG of linear SEGMENTS, each bound to one of three HIP streams.  Eagerly they are enqueued in plan
     # order with event waits; for replay every segment is captured into its own hipGraph and the graphs are launched
     # on their streams with the same event waits.  (One hipGraph of the whole multi-stream step executes its
     # branches almost serially on this runtime - measured: one kernel in flight 75 % of the time - whereas separate
@@ -451,7 +454,7 @@ class Trainer:
             T["dP3"] = K.fc_finalize(K.fc_dgrad(df1, self.fc1, cp)).reshape(B, h // 8, wd // 8, 128)
 
         # ------------------------------------------------------------------ discriminator step (train.py:351-380)
-        @seg("disc_step", 3, ["loss_adv"])
+        @seg("disc_step", 1, ["loss_adv"])
         def _():       # real then generated, BN batch statistics (after the inference-mode call of loss_adv)
             cvo = c["dis.out"]
             for which, img, target, slot in (("real", T["hdr_t"], 1.0, 6), ("fake", T["y_lin"], 0.0, 5)):
@@ -463,18 +466,8 @@ class Trainer:
                 self._down_stack_bwd("dis.", self.ds.w, self.ds.g, Rd, da4, training=True, want_input_grad=False)
             self._flush_wgrads()
 
-        # The two Dense layers hold 50.3 M of the 58.3 M parameters and nothing reads their weights or gradients after
-        # bwd_head: their RMSprop update and bf16 re-packing (~1 GB of HBM traffic) run here, beside the rest of the
-        # backward pass, instead of at the end of the step.  (Data-parallel: after the all-reduce of that slice.)
-        @seg("apply_fc", 3, ["bwd_head"])
-        def _():
-            fc0, fc1 = self.fc_grad_range()
-            K.rmsprop(self.gs.flat[fc0:fc1], self.gs.grad[fc0:fc1], self.gs.ms[fc0:fc1], self.lr, gscale=self._gscale)
-            self.fc1.repack(w["sun.fc1.kernel"])
-            self.fc2.repack(w["sun.fc2.kernel"])
-
         # ------------------------------------------------------------------ sun-pose conv layers (sunpose_net.py:54-62)
-        @seg("bwd_sunpose", 4, ["bwd_head"])
+        @seg("bwd_sunpose", 2, ["bwd_head"])
         def _():
             t, dP = T["t"], T["dP3"]
             for l in (3, 2, 1):
@@ -506,7 +499,7 @@ class Trainer:
                 c["gen.conv3_" + sfx].dgrad(T["x"][-1], dd3, cp, out=dres)
             T["wq_dec"] = self._take_wgrads()
 
-        @seg("wg_dec", 4, ["bwd_dec"])
+        @seg("wg_dec", 2, ["bwd_dec"])
         def _():
             K.conv2d_wgrad_multi(T["wq_dec"])
 
@@ -520,7 +513,7 @@ class Trainer:
             self._down_stack_bwd("gen.sun.", w, g, R, dact4, training=True, want_input_grad=False)
             T["wq_sunrad"] = self._take_wgrads()
 
-        @seg("wg_sunrad", 4, ["bwd_sunrad"])
+        @seg("wg_sunrad", 2, ["bwd_sunrad"])
         def _():
             K.conv2d_wgrad_multi(T["wq_sunrad"])
 
@@ -539,7 +532,7 @@ class Trainer:
             T["dx_enc"] = dx
             T["wq_res"] = self._take_wgrads()
 
-        @seg("wg_res", 4, ["bwd_res"])
+        @seg("wg_res", 2, ["bwd_res"])
         def _():
             K.conv2d_wgrad_multi(T["wq_res"])
 
@@ -554,6 +547,16 @@ class Trainer:
             dc1 = self._in_bwd(T["c1"], T["s1"], "gen.norm1_d", 0.1, da1)
             self._wg("gen.conv1_d", T["ldr"], None, dc1)
             self._flush_wgrads()
+
+        # The two Dense layers hold 50.3 M of the 58.3 M parameters and nothing reads their weights or gradients after
+        # bwd_head: their RMSprop update and bf16 re-packing (~1 GB of HBM traffic) run here, beside the rest of the
+        # backward pass, instead of at the end of the step.  (Data-parallel: after the all-reduce of that slice.)
+        @seg("apply_fc", 1, ["bwd_head"])
+        def _():
+            fc0, fc1 = self.fc_grad_range()
+            K.rmsprop(self.gs.flat[fc0:fc1], self.gs.grad[fc0:fc1], self.gs.ms[fc0:fc1], self.lr, gscale=self._gscale)
+            self.fc1.repack(w["sun.fc1.kernel"])
+            self.fc2.repack(w["sun.fc2.kernel"])
 
         # every gradient is complete here: a data-parallel driver hooks its all-reduce onto this (empty) segment
         segs.append(("grads_ready", 0, ("disc_step", "bwd_sunpose", "wg_res"), None))
@@ -575,7 +578,7 @@ class Trainer:
         return self._wjobs.pop(torch.cuda.current_stream().cuda_stream, [])
 
     def _execute(self, names=None, graphs=None, hooks=None, pre_hooks=None):
-        """Enqueues the plan's segments (all, or those in `names`) on the five streams; `graphs` replays captured
+        """Enqueues the plan's segments (all, or those in `names`) on the three streams; `graphs` replays captured
         segments instead of re-issuing their launches.  pre_hooks[name]() / hooks[name]() run on the segment's stream
         right before / after it."""
         caller = torch.cuda.current_stream()
@@ -606,6 +609,10 @@ class Trainer:
                 ev.record(s)
         for s in st:
             caller.wait_stream(s)
+
+    def event(self, name):
+        """The HIP event recorded after segment `name` in the current step (for drivers that order their own work)."""
+        return self._events[name]
 
     def _bind(self, ldr, hdr_t, sunpose_gt):
         self._T = dict(ldr=ldr, hdr_t=hdr_t, gt=sunpose_gt)
