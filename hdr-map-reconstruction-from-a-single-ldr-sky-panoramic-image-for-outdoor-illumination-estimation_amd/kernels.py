@@ -654,6 +654,16 @@ def rmsprop(w, g, ms, lr, rho=0.9, eps=1e-7, gscale=1.0):
     L.check(L.load().hdrsky_rmsprop(_p(w), _p(g), _p(ms), n, lr, rho, eps, gscale, _stream()), "rmsprop")
 
 
+def rmsprop_fc(w, g, ms, pf, lr, rho=0.9, eps=1e-7, gscale=1.0):
+    """RMSprop step of a Dense kernel w [K,N] (views of the flat buffers) fused with the refresh of its PackedFC images."""
+    Kd, N = w.shape
+    _f32(w); _f32(g, Kd, N); _f32(ms, Kd, N)
+    if pf.pk_lo is not None or (pf.K, pf.N) != (Kd, N):
+        raise ValueError("rmsprop_fc: BF16 images of the same kernel only")
+    L.check(L.load().hdrsky_rmsprop_fc(_p(w), _p(g), _p(ms), Kd, N, lr, rho, eps, gscale, _p(pf.pk_hi), _p(pf.nat_hi),
+                                       _stream()), "rmsprop_fc")
+
+
 # ------------------------------------------------------------------------------------------------
 # distortion-aware convolution (csrc/da_conv.hip)
 # ------------------------------------------------------------------------------------------------

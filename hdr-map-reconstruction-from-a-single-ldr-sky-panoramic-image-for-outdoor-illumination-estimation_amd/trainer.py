@@ -554,9 +554,17 @@ class Trainer:
         @seg("apply_fc", 1, ["bwd_head"])
         def _():
             fc0, fc1 = self.fc_grad_range()
-            K.rmsprop(self.gs.flat[fc0:fc1], self.gs.grad[fc0:fc1], self.gs.ms[fc0:fc1], self.lr, gscale=self._gscale)
-            self.fc1.repack(w["sun.fc1.kernel"])
-            self.fc2.repack(w["sun.fc2.kernel"])
+            if self.precise:      # BF16X3 keeps residual planes: plain update, then re-pack
+                K.rmsprop(self.gs.flat[fc0:fc1], self.gs.grad[fc0:fc1], self.gs.ms[fc0:fc1], self.lr, gscale=self._gscale)
+                self.fc1.repack(w["sun.fc1.kernel"])
+                self.fc2.repack(w["sun.fc2.kernel"])
+                return
+            for name, pf in (("sun.fc1", self.fc1), ("sun.fc2", self.fc2)):
+                o, n, shape = self.gs.offsets[name + ".kernel"]
+                K.rmsprop_fc(w[name + ".kernel"], g[name + ".kernel"], self.gs.ms[o:o + n].view(shape), pf, self.lr,
+                             gscale=self._gscale)
+                o, n, _ = self.gs.offsets[name + ".bias"]
+                K.rmsprop(self.gs.flat[o:o + n], self.gs.grad[o:o + n], self.gs.ms[o:o + n], self.lr, gscale=self._gscale)
 
         # every gradient is complete here: a data-parallel driver hooks its all-reduce onto this (empty) segment
         segs.append(("grads_ready", 0, ("disc_step", "bwd_sunpose", "wg_res"), None))

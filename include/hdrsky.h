@@ -275,6 +275,10 @@ int hdrsky_axpby(const float* a, float sa, const float* b, float sb, size_t n, f
 int hdrsky_fc_wgrad(const float* x, const float* dy, int M, int K, int N, int accumulate, float* dw, float* db, void* stream);
 /* Keras-2 OptimizerV2 RMSprop step over one flat buffer (train.py:201-202,403,406): g is first multiplied by gscale. */
 int hdrsky_rmsprop(float* w, const float* g, float* ms, size_t n, float lr, float rho, float eps, float gscale, void* stream);
+/* The same update for a Dense kernel w[K][N], fused with the refresh of its bf16 images (hdrsky_fc_pack_weights layouts:
+ * packed_hi [K/8][N][8], natural_hi [K][N] or NULL) - HDRSKY_BF16 mode only (no residual planes). */
+int hdrsky_rmsprop_fc(float* w, const float* g, float* ms, int K, int N, float lr, float rho, float eps, float gscale,
+                      void* packed_hi, void* natural_hi, void* stream);
 /* tf.keras.optimizers.Adam (train_sun.py:191 / tf_utils.py:324; defaults beta 0.9 / 0.999, eps 1e-7) over a flat buffer:
  * m, v are the slots; lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t) is computed by the caller for step t; g is scaled by gscale. */
 int hdrsky_adam(float* w, const float* g, float* m, float* v, size_t n, float lr_t, float beta1, float beta2, float eps,

@@ -180,6 +180,26 @@ def test_train_step_updates_weights_like_rmsprop(dev):
     assert all(np.isfinite(x) for x in v.values())
 
 
+def test_bf16_step_fused_dense_optimizer(dev):
+    """BF16 trainer: the Dense kernels are updated by hdrsky_rmsprop_fc, which also refreshes their bf16 MFMA images -
+    same weights as the closed form and bit-identical images to a fresh hdrsky_fc_pack_weights of the result."""
+    params, synth, trainer, K = pkg("params"), pkg("synth"), pkg("trainer"), pkg("kernels")
+    gen = params.init_params(params.generator_spec(), 0); sun = params.init_params(params.sunpose_spec(), 1)
+    dis = params.init_params(params.discriminator_spec(), 2); vgg = params.init_params(params.vgg_spec(), 3)
+    batch = synth.make_batch(2, seed=1234)
+    tr = trainer.Trainer(gen, sun, dis, vgg, device=dev, precise=False, compute=K.BF16)
+    ldr, hdr, gt = (torch.from_numpy(batch[k]).to(dev) for k in ("ldr", "hdr_t", "sunpose_gt"))
+    w0 = tr.gs.flat[:tr.gs.ntrain].clone()
+    tr.step(ldr, hdr, gt, update=True)
+    g = tr.gs.grad
+    ref = w0 - 1e-4 * g / ((0.1 * g * g).sqrt() + 1e-7)
+    assert_close(tr.gs.flat[:tr.gs.ntrain], ref, 1e-6, "first RMSprop step (fused Dense path)")
+    for name, pf in (("sun.fc1.kernel", tr.fc1), ("sun.fc2.kernel", tr.fc2)):
+        fresh = K.PackedFC(tr.gs.w[name], precise=False)
+        assert torch.equal(fresh.pk_hi.view(torch.int16), pf.pk_hi.view(torch.int16)), name
+        assert torch.equal(fresh.nat_hi.view(torch.int16), pf.nat_hi.view(torch.int16)), name
+
+
 def test_cli_train_and_inference_smoke(dev, tmp_path, capsys):
     """train CLI (2 synthetic epochs at batch 2) writes nothing before epoch 10; inference CLI turns a jpg into a .hdr."""
     train = pkg("train"); inference = pkg("inference"); hdr_io = pkg("hdr_io")
