@@ -62,14 +62,14 @@ __device__ __forceinline__ uint2 lds_tr(const unsigned char* p) {
 // the staging phase (global -> registers -> transform -> bf16 -> LDS) is issue-bound VALU work shared by all
 // NW*64 threads.  XR: rows of the X' register prefetch array (items per thread; UP: 4 source pixels per item).
 // UP: the forward conv resized its input 2x (resize-deconv): an X' item is interpolated from four source pixels.
-template <int TPW, int CBF, int OBF, int TW, bool NARROW, bool PRECISE, bool UP, int NW, int CS, int OS, int XR>
+template <int TPW, int CBF, int OBF, int TW, bool NARROW, bool PRECISE, bool UP, int NW, int CS, int OS, int XR, int BM>
 __global__ void __launch_bounds__(NW * 64) conv_wgrad_kernel(const MultiArgs m) {
   constexpr int NT = NW * 64;
   constexpr int CB = CBF * 16, OB = OBF * 16;
   static_assert(CBF % CS == 0 && OBF % OS == 0 && NW % (CS * OS) == 0, "wave roles");
   constexpr int CBH = CBF / CS, OBH = OBF / OS;    // fragments per wave
   constexpr int NTG = NW / (CS * OS);              // tap groups
-  constexpr int BM = 128, TH = BM / TW;            // output pixels per tile (4 k-steps of 32)
+  constexpr int TH = BM / TW;                      // BM output pixels per tile (BM/32 k-steps): 128, or 64 for 4-row images
   constexpr int NQX = CB / 8, NQY = OB / 8;        // 8-channel groups per staged pixel
   constexpr int XI = UP ? XR / 4 : XR;             // X' items per thread and tile
   int job = 0;
@@ -391,11 +391,11 @@ __global__ void __launch_bounds__(NW * 64) conv_wgrad_kernel(const MultiArgs m) 
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------
-struct Geo { int tpw, cbf, obf, tw, nw, cs, os, xr; bool narrow, precise, up; };
+struct Geo { int tpw, cbf, obf, tw, nw, cs, os, xr, bm; bool narrow, precise, up; };
 
-template <int TPW, int CBF, int OBF, int TW, bool NARROW, bool PRECISE, bool UP, int NW, int CS, int OS, int XR>
+template <int TPW, int CBF, int OBF, int TW, bool NARROW, bool PRECISE, bool UP, int NW, int CS, int OS, int XR, int BM>
 struct WgradVariant {
-  static constexpr int NT = NW * 64, CB = CBF * 16, OB = OBF * 16, BM = 128, TH = BM / TW, NTG = NW / (CS * OS);
+  static constexpr int NT = NW * 64, CB = CBF * 16, OB = OBF * 16, TH = BM / TW, NTG = NW / (CS * OS);
   // fills the geometry-dependent fields of one job; returns the LDS bytes it needs, or a negative error
   static int prepare(WgradArgs& a, int wg_target) {
     if (UP != (a.upsample == 2)) return HDRSKY_EUNSUPPORTED;
@@ -437,7 +437,7 @@ struct WgradVariant {
     return lds;
   }
   static int launch(MultiArgs& m, int lds, hipStream_t stream) {
-    auto kern = conv_wgrad_kernel<TPW, CBF, OBF, TW, NARROW, PRECISE, UP, NW, CS, OS, XR>;
+    auto kern = conv_wgrad_kernel<TPW, CBF, OBF, TW, NARROW, PRECISE, UP, NW, CS, OS, XR, BM>;
     static bool attr_set = false;
     if (!attr_set) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -454,21 +454,26 @@ struct WgradVariant {
 // Runs `fn` on the kernel variant that implements geometry `g` (the instantiated set).
 template <typename F>
 int with_variant(const Geo& g, F&& fn) {
-#define HDRSKY_WG(TPW_, CBF_, OBF_, NARROW_, UP_, NW_, CS_, OS_, XR_)                                                \
-  if (g.tpw == TPW_ && g.cbf == CBF_ && g.obf == OBF_ && g.narrow == NARROW_ && g.up == UP_ && g.nw == NW_) {        \
-    if (g.precise) return g.tw == 32 ? fn(WgradVariant<TPW_, CBF_, OBF_, 32, NARROW_, true, UP_, NW_, CS_, OS_, XR_>()) \
-                                     : fn(WgradVariant<TPW_, CBF_, OBF_, 16, NARROW_, true, UP_, NW_, CS_, OS_, XR_>()); \
-    return g.tw == 32 ? fn(WgradVariant<TPW_, CBF_, OBF_, 32, NARROW_, false, UP_, NW_, CS_, OS_, XR_>())            \
-                      : fn(WgradVariant<TPW_, CBF_, OBF_, 16, NARROW_, false, UP_, NW_, CS_, OS_, XR_>());            \
+#define HDRSKY_WG_(TPW_, CBF_, OBF_, NARROW_, UP_, NW_, CS_, OS_, XR_, BM_, TW_)                                     \
+  if (g.tpw == TPW_ && g.cbf == CBF_ && g.obf == OBF_ && g.narrow == NARROW_ && g.up == UP_ && g.nw == NW_ &&        \
+      g.bm == BM_ && g.tw == TW_) {                                                                                   \
+    if (g.precise) return fn(WgradVariant<TPW_, CBF_, OBF_, TW_, NARROW_, true, UP_, NW_, CS_, OS_, XR_, BM_>());     \
+    return fn(WgradVariant<TPW_, CBF_, OBF_, TW_, NARROW_, false, UP_, NW_, CS_, OS_, XR_, BM_>());                   \
   }
+#define HDRSKY_WG(TPW_, CBF_, OBF_, NARROW_, UP_, NW_, CS_, OS_, XR_)                                                \
+  HDRSKY_WG_(TPW_, CBF_, OBF_, NARROW_, UP_, NW_, CS_, OS_, XR_, 128, 32)                                            \
+  HDRSKY_WG_(TPW_, CBF_, OBF_, NARROW_, UP_, NW_, CS_, OS_, XR_, 128, 16)
   // 16 waves, 32x32-channel dW blocks (a layer on its own)
   HDRSKY_WG(3, 2, 2, false, false, 16, 2, 2, 3) HDRSKY_WG(3, 2, 2, false, true, 16, 2, 2, 4)
   HDRSKY_WG(4, 2, 2, false, false, 16, 2, 2, 3) HDRSKY_WG(7, 2, 1, false, false, 16, 2, 1, 3)
   HDRSKY_WG(2, 1, 4, true, false, 16, 1, 2, 3) HDRSKY_WG(2, 1, 2, true, false, 16, 1, 2, 3)
   HDRSKY_WG(7, 1, 2, true, false, 16, 1, 2, 3)
+  // 64-pixel tiles for outputs of at most four 16-pixel rows (the 4x16 maps of the discriminator / sun-radiance stacks)
+  HDRSKY_WG_(4, 2, 2, false, false, 16, 2, 2, 3, 64, 16) HDRSKY_WG_(3, 2, 2, false, false, 16, 2, 2, 3, 64, 16)
   // 8 waves, 64x64-channel dW blocks (several wide layers in one launch)
   HDRSKY_WG(3, 4, 4, false, false, 8, 2, 1, 4)
 #undef HDRSKY_WG
+#undef HDRSKY_WG_
   return HDRSKY_EUNSUPPORTED;
 }
 
@@ -480,6 +485,7 @@ static Geo choose_geo(const hdrsky_conv_desc* d, bool big) {
   g.precise = d->compute == HDRSKY_BF16X3;
   g.up = d->upsample == 2;
   g.tw = d->Wo >= 32 ? 32 : 16;
+  g.bm = 128;
   if (big) {
     g.nw = 8; g.cs = 2; g.os = 1; g.cbf = 4; g.obf = 4; g.tpw = ntaps <= 12 ? 3 : 4;
     return g;
@@ -487,7 +493,10 @@ static Geo choose_geo(const hdrsky_conv_desc* d, bool big) {
   g.nw = 16;
   if (g.narrow) { g.cbf = 1; g.obf = (d->Cout >= 64 && ntaps <= 16) ? 4 : 2; g.tpw = ntaps <= 16 ? 2 : 7; }
   else if (ntaps > 16) { g.cbf = 2; g.obf = 1; g.tpw = 7; }
-  else { g.cbf = 2; g.obf = 2; g.tpw = ntaps <= 12 ? 3 : 4; }
+  else {
+    g.cbf = 2; g.obf = 2; g.tpw = ntaps <= 12 ? 3 : 4;
+    if (g.tw == 16 && d->Ho <= 4 && !g.up) g.bm = 64;   // a 128-pixel tile would be half padding
+  }
   return g;
 }
 
@@ -516,7 +525,7 @@ static int fill_job(WgradArgs& a, const hdrsky_wgrad_job& j) {
 }
 
 static bool same_geo(const Geo& p, const Geo& q) {
-  return p.tpw == q.tpw && p.cbf == q.cbf && p.obf == q.obf && p.tw == q.tw && p.nw == q.nw && p.narrow == q.narrow &&
+  return p.tpw == q.tpw && p.cbf == q.cbf && p.obf == q.obf && p.tw == q.tw && p.nw == q.nw && p.bm == q.bm && p.narrow == q.narrow &&
          p.precise == q.precise && p.up == q.up;
 }
 
