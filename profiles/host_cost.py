@@ -44,3 +44,19 @@ print("segment timeline (us from step start): name stream start end dur")
 for n, si, d, f in tr._segs:
     a, b_ = base.elapsed_time(st[n]) * 1e3, base.elapsed_time(en[n]) * 1e3
     print("  %-12s s%d %7.0f %7.0f %6.0f   deps %s" % (n, si, a, b_, b_ - a, list(d)))
+# ---- each segment's graph alone (nothing else on the GPU) ---------------------------------------------------------
+print("segment alone (us):")
+tot = {}
+for n, si, d, f in tr._segs:
+    if f is None: continue
+    gr = tr._graphs[n]
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(tr._streams[si]):
+        gr.replay(); torch.cuda.synchronize()
+        e0.record(); gr.replay(); e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3
+    tot[si] = tot.get(si, 0) + us
+    print("  %-12s s%d %7.0f" % (n, si, us))
+print("sum per stream:", {k: round(v) for k, v in tot.items()}, "all:", round(sum(tot.values())))
