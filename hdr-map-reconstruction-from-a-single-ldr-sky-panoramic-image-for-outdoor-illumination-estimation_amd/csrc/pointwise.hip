@@ -596,6 +596,59 @@ __global__ void leaky_relu_kernel(const float* __restrict__ x, float* __restrict
   }
 }
 
+// train.py:54-94 `_preprocessing` without the JPEG round trip: exposure, signal-dependent + constant Gaussian noise,
+// relu, clip to [0,1], camera response function by linear interpolation of a K-sample LUT (tf_utils.apply_rf /
+// interp_1d / sample_1d, tf_utils.py:191-255: index clipped to [0, K-1]), 8-bit quantisation with round-half-to-even.
+__global__ void ldr_synth_kernel(const float* __restrict__ hdr, const float* __restrict__ t, const float* __restrict__ sigma_s,
+                                 const float* __restrict__ sigma_c, const float* __restrict__ noise_s,
+                                 const float* __restrict__ noise_c, const float* __restrict__ crf, int K, size_t per_sample,
+                                 size_t total, float* __restrict__ hdr_t, float* __restrict__ ldr) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / per_sample), c = (int)(i % 3);
+    const float x0 = hdr[i] * t[b];
+    const float ns = noise_s[i] * (sigma_s[b * 3 + c] * x0);
+    float x = x0 + ns;
+    x = x + sigma_c[b * 3 + c] * noise_c[i];
+    x = fmaxf(x, 0.f);
+    hdr_t[i] = x;
+    const float cl = fminf(fmaxf(x, 0.f), 1.f);
+    const float pos = (float)(K - 1) * cl;
+    const float y0 = floorf(pos), y1 = y0 + 1.f;
+    const int i0 = min(max((int)y0, 0), K - 1), i1 = min(max((int)y1, 0), K - 1);
+    const float* lut = crf + (size_t)b * K;
+    const float v = (y1 - pos) * lut[i0] + (pos - y0) * lut[i1];
+    ldr[i] = rintf(v * 255.f) / 255.f;
+  }
+}
+
+// train.py:42-52 `vMF`: pmf[b][j] = exp(kappa * <bin_j, sun_b>) / sum_j, bins = tf_utils.sunpose_init (tf_utils.py:112-129),
+// sun_b = tf_utils.sphere2world((azimuth, elevation_b), h, w, skydome=True) (tf_utils.py:95-110).  One block per sample.
+__global__ void __launch_bounds__(256) vmf_target_kernel(const float* __restrict__ elevation, float azimuth, int h, int w,
+                                                         float kappa, float* __restrict__ out) {
+  __shared__ float sred[4];
+  const int b = blockIdx.x, n = h * w;
+  const float pi = 3.14159265358979323846f;
+  const float th_s = (azimuth - 0.5f * (float)w) * (2.f * pi / (float)w);
+  const float ph_s = ((float)h - elevation[b]) * (pi / (float)(h * 2));
+  const float sx = cosf(ph_s) * cosf(th_s), sy = sinf(ph_s), sz = cosf(ph_s) * sinf(th_s);
+  float part = 0.f;
+  for (int j = threadIdx.x; j < n; j += 256) {
+    const float row = floorf((float)j / (float)w);
+    const float xd = (((float)j + 1.f) - row * (float)w - 1.f) * (360.f / (float)w) + (360.f / ((float)w * 2.f));
+    const float yd = row * (90.f / (float)h) + (90.f / (2.f * (float)h));
+    const float phi = yd * (pi / 180.f), theta = (xd - 180.f) * (pi / 180.f);
+    const float d = cosf(phi) * cosf(theta) * sx + sinf(phi) * sy + cosf(phi) * sinf(theta) * sz;
+    const float e = expf(kappa * d);
+    out[(size_t)b * n + j] = e;
+    part += e;
+  }
+  part = wave_sum(part);
+  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = part;
+  __syncthreads();
+  const float tot = sred[0] + sred[1] + sred[2] + sred[3];
+  for (int j = threadIdx.x; j < n; j += 256) out[(size_t)b * n + j] /= tot;
+}
+
 // Debug aid: workgroups that sit on the CUs with a known LDS pattern and report words that change under them
 // (= some co-resident workgroup of another kernel wrote outside its own LDS allocation).  Bounded loop.
 __global__ void __launch_bounds__(64) lds_canary_kernel(int iters, unsigned int* report) {
@@ -618,6 +671,25 @@ __global__ void __launch_bounds__(64) lds_canary_kernel(int iters, unsigned int*
 }  // namespace
 
 extern "C" {
+
+int hdrsky_ldr_synth(const float* hdr, const float* t, const float* sigma_s, const float* sigma_c, const float* noise_s,
+                     const float* noise_c, const float* crf, int crf_len, int B, int H, int W, float* hdr_t, float* ldr,
+                     void* stream) {
+  if (!hdr || !t || !sigma_s || !sigma_c || !noise_s || !noise_c || !crf || !hdr_t || !ldr || crf_len < 2) return HDRSKY_EINVAL;
+  const size_t per = (size_t)H * W * 3, total = per * B;
+  size_t g = (total + 255) / 256; if (g > 4096) g = 4096; if (g < 1) g = 1;
+  hipLaunchKernelGGL(ldr_synth_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, hdr, t, sigma_s, sigma_c, noise_s,
+                     noise_c, crf, crf_len, per, total, hdr_t, ldr);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_vmf_target(const float* elevation, float azimuth, int B, int H, int W, float kappa, float* out, void* stream) {
+  if (!elevation || !out || B <= 0) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(vmf_target_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, elevation, azimuth, H, W, kappa, out);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
 
 int hdrsky_debug_lds_canary(int nblocks, int iters, void* report, void* stream) {
   hipLaunchKernelGGL(lds_canary_kernel, dim3(nblocks), dim3(64), 0, (hipStream_t)stream, iters, (unsigned int*)report);

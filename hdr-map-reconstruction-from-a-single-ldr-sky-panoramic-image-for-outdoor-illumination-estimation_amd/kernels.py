@@ -728,3 +728,30 @@ def da_conv2d_bwd(x, dy, kernel, offs, ksize, compute=BF16, want_dx=True):
         dx = torch.zeros_like(x)
         L.check(L.load().hdrsky_da_scatter(_p(dG), _p(offs), B, H, W, C, ksize, _p(dx), _stream()), "da_scatter")
     return dx, dw.view(k2 * C, F), db
+
+
+# ------------------------------------------------------------------------------------------------
+# device-side input synthesis (train.py:42-94)
+# ------------------------------------------------------------------------------------------------
+def ldr_synth(hdr, t, sigma_s, sigma_c, noise_s, noise_c, crf):
+    """train.py:54-94 without the JPEG round trip -> (hdr_t, jpeg_img_float stand-in), both [B,H,W,3]."""
+    B, H, W, C = hdr.shape
+    if C != 3:
+        raise ValueError("3-channel images expected")
+    _f32(hdr); _f32(t, B); _f32(sigma_s, B, 3); _f32(sigma_c, B, 3); _f32(noise_s, B, H, W, 3); _f32(noise_c, B, H, W, 3)
+    _f32(crf); 
+    if crf.shape[0] != B:
+        raise ValueError("one response curve per sample")
+    hdr_t, ldr = torch.empty_like(hdr), torch.empty_like(hdr)
+    L.check(L.load().hdrsky_ldr_synth(_p(hdr), _p(t), _p(sigma_s), _p(sigma_c), _p(noise_s), _p(noise_c), _p(crf),
+                                      crf.shape[1], B, H, W, _p(hdr_t), _p(ldr), _stream()), "ldr_synth")
+    return hdr_t, ldr
+
+
+def vmf_target(elevation, azimuth, H, W, kappa=80.0):
+    """train.py:42-52: von-Mises-Fisher pmf over the H*W sky bins for each sample's sun elevation (row units)."""
+    B = elevation.numel()
+    _f32(elevation, B)
+    out = torch.empty((B, H * W), dtype=torch.float32, device=elevation.device)
+    L.check(L.load().hdrsky_vmf_target(_p(elevation), float(azimuth), B, H, W, float(kappa), _p(out), _stream()), "vmf_target")
+    return out

@@ -71,3 +71,41 @@ def make_batch(batch, h=32, w=128, seed=1234):
     hdr = hdr.astype(np.float32)
     ldr = np.round(255.0 * np.clip(hdr, 0.0, 1.0) ** (1.0 / 2.2)) / 255.0
     return dict(hdr_t=hdr, ldr=ldr.astype(np.float32), sunpose_gt=gt)
+
+
+def gamma_crf(n_curves=1, k=1024, gamma=2.2):
+    """Stand-in for the DoRF response curves (dorfCurves.txt is not available): k samples of x^(1/gamma) on [0,1]."""
+    x = np.linspace(0.0, 1.0, k)
+    return np.tile((x ** (1.0 / gamma)).astype(np.float32)[None], (n_curves, 1))
+
+
+def make_batch_device(batch, h=32, w=128, seed=1234, device="cuda", crf=None):
+    """The same synthetic distribution as make_batch, produced on the GPU: analytic sky-dome + sun lobe (torch ops on
+    the device - test/bench plumbing), then the reference's augmentation and target construction in libhdrsky
+    (kernels.ldr_synth = train.py:54-94 without JPEG, kernels.vmf_target = train.py:42-52).  Returns dict of CUDA
+    tensors (hdr_t, ldr, sunpose_gt).  Different random stream than make_batch (torch generator instead of numpy)."""
+    import torch
+    from . import kernels as K
+    dev = torch.device(device)
+    g = torch.Generator(device=dev); g.manual_seed(int(seed))
+    u = lambda *shape: torch.rand(*shape, device=dev, generator=g)
+    ys = torch.arange(h, device=dev, dtype=torch.float32).view(1, h, 1, 1)
+    tint = 0.8 + 0.4 * u(batch, 1, 1, 3)
+    elev = torch.floor(u(batch) * h)
+    amp = 10.0 ** (1.0 + 2.4 * u(batch))
+    bins = torch.from_numpy(sunpose_bins(h, w).astype(np.float32)).to(dev).view(1, h, w, 3)
+    azimuth = w * 0.5 - 1.0
+    theta = (azimuth - 0.5 * w) * (2.0 * np.pi / w)
+    phi = (h - elev) * (np.pi / (h * 2))
+    sun = torch.stack([torch.cos(phi) * np.cos(theta), torch.sin(phi), torch.cos(phi) * np.sin(theta)], dim=1).view(batch, 1, 1, 3)
+    lobe = amp.view(batch, 1, 1, 1) * torch.exp(KAPPA * ((bins * sun).sum(-1, keepdim=True) - 1.0))
+    img = (0.2 + 0.6 * ys / h) * tint + lobe
+    img = (0.5 * img / (img.mean(dim=(1, 2, 3), keepdim=True) + 1e-6)).contiguous()          # train.py:109-110
+    t = 2.0 ** (-3.0 + 6.0 * u(batch))                                                          # utils.py:86-91
+    sigma_s, sigma_c = 0.08 / 6.0 * u(batch, 3), 0.005 * u(batch, 3)                            # train.py:66-68
+    n_s = torch.randn(batch, h, w, 3, device=dev, generator=g)
+    n_c = torch.randn(batch, h, w, 3, device=dev, generator=g)
+    if crf is None:
+        crf = torch.from_numpy(gamma_crf(batch)).to(dev)
+    hdr_t, ldr = K.ldr_synth(img, t, sigma_s.contiguous(), sigma_c.contiguous(), n_s, n_c, crf)
+    return dict(hdr_t=hdr_t, ldr=ldr, sunpose_gt=K.vmf_target(elev.contiguous(), azimuth, h, w, KAPPA))

@@ -34,6 +34,8 @@ def main(argv=None):
     ap.add_argument("--dorf", type=str, default=None)
     ap.add_argument("--vgg", type=str, default=None)
     ap.add_argument("--steps-per-epoch", type=int, default=8, help="synthetic mode: steps per epoch")
+    ap.add_argument("--host-synth", action="store_true",
+                    help="build the synthetic batches with numpy on the host (40 ms per batch of 32) instead of on the GPU")
     args = ap.parse_args(argv)
 
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -63,8 +65,13 @@ def main(argv=None):
         t0 = time.perf_counter()
         acc = {}
         for it in range(args.steps_per_epoch):
-            b = synth.make_batch(args.batchsize, h, w, seed=(epoch * 100003 + it) * world + rank)
-            ldr, hdr, gt = (torch.from_numpy(b[k]).to(dev) for k in ("ldr", "hdr_t", "sunpose_gt"))
+            seed = (epoch * 100003 + it) * world + rank
+            if args.host_synth:
+                b = synth.make_batch(args.batchsize, h, w, seed=seed)
+                ldr, hdr, gt = (torch.from_numpy(b[k]).to(dev) for k in ("ldr", "hdr_t", "sunpose_gt"))
+            else:   # augmentation + target construction of train.py:42-94 on the GPU
+                b = synth.make_batch_device(args.batchsize, h, w, seed=seed, device=dev)
+                ldr, hdr, gt = b["ldr"], b["hdr_t"], b["sunpose_gt"]
             out = tr.step(ldr, hdr, gt, update=False)
             par.allreduce_sum_([tr.gs.grad, tr.ds.grad])
             tr.apply_gradients(gscale=1.0 / world)

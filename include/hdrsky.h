@@ -285,6 +285,18 @@ int hdrsky_adam(float* w, const float* g, float* m, float* v, size_t n, float lr
                 float gscale, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Device-side input synthesis (train.py:42-94: the host augmentation, minus the JPEG round trip)
+ * ---------------------------------------------------------------------------------------- */
+/* `_preprocessing` (train.py:54-94): hdr_t = relu(hdr*t + n_s*(sigma_s*hdr*t) + sigma_c*n_c) per sample b / channel c;
+ * ldr = round_half_even(255 * CRF_b(clip(hdr_t, 0, 1))) / 255 with CRF_b a crf_len-sample LUT interpolated linearly
+ * (tf_utils.apply_rf, tf_utils.py:245-255).  t [B], sigma_* [B,3], noise_* [B,H,W,3] standard normals, crf [B,crf_len]. */
+int hdrsky_ldr_synth(const float* hdr, const float* t, const float* sigma_s, const float* sigma_c, const float* noise_s,
+                     const float* noise_c, const float* crf, int crf_len, int B, int H, int W, float* hdr_t, float* ldr,
+                     void* stream);
+/* `vMF` (train.py:42-52): out[b][j] = exp(kappa*<bin_j, sun(azimuth, elevation[b])>) normalised over the H*W sky bins. */
+int hdrsky_vmf_target(const float* elevation, float azimuth, int B, int H, int W, float kappa, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Distortion-aware panoramic convolution (distortion_aware_ops.py)
  * ---------------------------------------------------------------------------------------- */
 /* conv2d.distortion (distortion_aware_ops.py:198-270), float32 in the reference's operation order:

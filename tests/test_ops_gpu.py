@@ -145,3 +145,36 @@ def test_cam_plz_heads_rad_blend(dev):
     v = d(rng.uniform(0, 50, (1000,)))
     assert_close(K.tonemap(K.tonemap(v, False), True), v, 1e-5, "tonemap round trip")
     assert_close(K.tonemap(v, False), T.hdr_log_compression(v.cpu()), 1e-6, "log compression")
+
+
+def test_device_input_synthesis(dev):
+    """hdrsky_ldr_synth / hdrsky_vmf_target vs the numpy restatement of train.py:42-94 (JPEG excluded), and the
+    device batch generator built on them."""
+    from oracle import preproc
+    K, synth = pkg("kernels"), pkg("synth")
+    rng = np.random.default_rng(31)
+    B, H, W, Kc = 4, 32, 128, 1024
+    hdr = (rng.random((B, H, W, 3)) ** 6 * 40).astype(np.float32)
+    t = (2.0 ** rng.uniform(-3, 3, B)).astype(np.float32)
+    ss = (0.08 / 6 * rng.random((B, 3))).astype(np.float32); sc = (0.005 * rng.random((B, 3))).astype(np.float32)
+    ns, nc = rng.standard_normal((2, B, H, W, 3)).astype(np.float32)
+    xs = np.linspace(0, 1, Kc)
+    crf = np.stack([xs ** (1 / g) for g in (2.2, 1.8, 2.6, 1.0)]).astype(np.float32)
+    ref_t, ref_l = preproc.preprocessing(hdr, t, ss, sc, ns, nc, crf)
+    d = lambda a: torch.from_numpy(a).to(dev)
+    got_t, got_l = K.ldr_synth(d(hdr), d(t), d(ss), d(sc), d(ns), d(nc), d(crf))
+    assert_close(got_t, ref_t, 2e-6, "hdr_t")
+    lat = np.round(got_l.cpu().numpy() * 255.0)
+    assert np.abs(lat / 255.0 - got_l.cpu().numpy()).max() < 1e-6                     # on the k/255 lattice
+    diff = np.abs(lat - np.round(ref_l * 255.0))
+    assert diff.max() <= 1 and (diff > 0).mean() < 1e-3, (diff.max(), (diff > 0).mean())   # ties of the 8-bit rounding only
+    elev = np.array([0.0, 5.0, 17.0, 31.0], np.float32)
+    pm = K.vmf_target(d(elev), W * 0.5 - 1.0, H, W)
+    for b in range(B):
+        assert_close(pm[b], preproc.vmf(W * 0.5 - 1.0, float(elev[b]), H, W), 2e-4, "vMF target %d" % b)
+    assert torch.allclose(pm.sum(dim=1), torch.ones(B, device=dev), atol=1e-5)
+    bt = synth.make_batch_device(8, H, W, seed=5, device=dev)
+    assert tuple(bt["hdr_t"].shape) == (8, H, W, 3) and tuple(bt["sunpose_gt"].shape) == (8, H * W)
+    assert float(bt["ldr"].min()) >= 0.0 and float(bt["ldr"].max()) <= 1.0 and torch.isfinite(bt["hdr_t"]).all()
+    bt2 = synth.make_batch_device(8, H, W, seed=5, device=dev)
+    assert torch.equal(bt["hdr_t"], bt2["hdr_t"]) and torch.equal(bt["sunpose_gt"], bt2["sunpose_gt"])   # seeded

@@ -206,3 +206,23 @@ def test_conv2d_transpose_oracle_against_explicit_construction():
     got1 = T.conv2d_transpose(x, w, None, 5, 7, 1)
     ref1 = T.conv2d(x, w.flip(0, 1).permute(0, 1, 3, 2).contiguous(), None, 1, "SAME")
     assert torch.allclose(got1, ref1, atol=1e-5)
+
+
+def test_preprocessing_oracle_known_answers():
+    """train.py:54-94 restatement: no noise + identity response curve => ldr = round(255*clip(hdr*t))/255; the response
+    LUT is interpolated linearly and its top index is clipped; the vMF target sums to 1 and peaks at the sun's bin."""
+    from oracle import preproc
+    rng = np.random.default_rng(2)
+    hdr = (rng.random((2, 4, 8, 3)) * 3).astype(np.float32)
+    t = np.array([0.5, 2.0], np.float32)
+    z3 = np.zeros((2, 3), np.float32); zn = np.zeros_like(hdr)
+    ident = np.tile(np.linspace(0, 1, 1024, dtype=np.float32)[None], (2, 1))
+    hdr_t, ldr = preproc.preprocessing(hdr, t, z3, z3, zn, zn, ident)
+    assert np.allclose(hdr_t, hdr * t.reshape(2, 1, 1, 1))
+    assert np.abs(ldr - np.round(255 * np.clip(hdr_t, 0, 1)) / 255).max() <= 1.0 / 255 + 1e-6
+    lut = np.array([[0.0, 1.0, 4.0]], np.float32)                      # k = 3: positions 0, 1, 2
+    assert np.allclose(preproc.apply_rf(np.array([[0.0, 0.25, 0.5, 0.75, 1.0]], np.float32), lut), [[0, 0.5, 1, 2.5, 4]])
+    pm = preproc.vmf(63.0, 10.0, 32, 128)
+    assert abs(float(pm.sum()) - 1.0) < 1e-5
+    row, col = divmod(int(pm.argmax()), 128)
+    assert abs(col - 63) <= 1 and abs(row - (32 - 10)) <= 1    # azimuth 63 -> column 63; elevation counts rows from the bottom
