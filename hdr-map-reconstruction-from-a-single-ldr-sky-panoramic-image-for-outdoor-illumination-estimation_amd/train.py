@@ -34,6 +34,7 @@ def main(argv=None):
     ap.add_argument("--dorf", type=str, default=None)
     ap.add_argument("--vgg", type=str, default=None)
     ap.add_argument("--steps-per-epoch", type=int, default=8, help="synthetic mode: steps per epoch")
+    ap.add_argument("--no-graph", action="store_true", help="issue every launch eagerly instead of replaying hipGraphs")
     ap.add_argument("--host-synth", action="store_true",
                     help="build the synthetic batches with numpy on the host (40 ms per batch of 32) instead of on the GPU")
     args = ap.parse_args(argv)
@@ -61,9 +62,13 @@ def main(argv=None):
         tr.gs.ms.copy_(torch.from_numpy(tensors["gen_optimizer/rms"])); tr.ds.ms.copy_(torch.from_numpy(tensors["disc_optimizer/rms"]))
     par.broadcast_params_([tr.gs.flat, tr.ds.flat]); tr.repack()
 
+    # The step is captured once (one hipGraph per segment, see trainer.py) on static input buffers that every batch is
+    # copied into; losses are accumulated on the device and read back once per epoch.
+    bufs, captured = None, False
+    from .trainer import LOSS_SLOTS
     for epoch in range(epoch0 + 1, args.epochs + 1):
         t0 = time.perf_counter()
-        acc = {}
+        loss_acc = torch.zeros(len(LOSS_SLOTS), dtype=torch.float32, device=dev)
         for it in range(args.steps_per_epoch):
             seed = (epoch * 100003 + it) * world + rank
             if args.host_synth:
@@ -72,11 +77,23 @@ def main(argv=None):
             else:   # augmentation + target construction of train.py:42-94 on the GPU
                 b = synth.make_batch_device(args.batchsize, h, w, seed=seed, device=dev)
                 ldr, hdr, gt = b["ldr"], b["hdr_t"], b["sunpose_gt"]
-            out = tr.step(ldr, hdr, gt, update=False)
+            if args.no_graph:
+                out = tr.step(ldr, hdr, gt, update=False)
+            else:
+                if bufs is None:
+                    bufs = (ldr.clone(), hdr.clone(), gt.clone())
+                    out = tr.capture(*bufs)
+                    captured = True
+                for dst, src in zip(bufs, (ldr, hdr, gt)):
+                    dst.copy_(src)
+                tr.replay(update=False)
             par.allreduce_sum_([tr.gs.grad, tr.ds.grad])
             tr.apply_gradients(gscale=1.0 / world)
-            for k, v in tr.loss_dict().items():
-                acc[k] = acc.get(k, 0.0) + v / args.steps_per_epoch
+            loss_acc += tr.losses
+        v = dict(zip(LOSS_SLOTS, (loss_acc / args.steps_per_epoch).tolist()))
+        v["total_gen_loss"] = v["kl"] + 1000.0 * v["dog"] + v["adv"] + 10.0 * v["l1"] + 0.01 * v["perceptual"]
+        v["total_disc_loss"] = 0.5 * (v["disc_generated"] + v["disc_real"])
+        acc = v
         if rank == 0:
             names = (("gen_total_loss", "total_gen_loss"), ("gen_l1_loss", "l1"), ("gen_perceptual_loss", "perceptual"),
                      ("gen_DoG_loss", "dog"), ("gen_adv_loss", "adv"), ("gen_kl_div", "kl"),
