@@ -723,12 +723,14 @@ TileCfg choose_tile(const hdrsky_conv_desc* d) {
     else if (M <= 16384) t = TileCfg{2, 4, 2, 1, 32, 1};               // 64 px x 64 ch, 8 waves
     else t = TileCfg{2, 4, 4, 1, 32, 1};                               // 128 px x 64 ch, 8 waves
   } else if (d->Cout > 16) {
-    if (M >= 65536) t = narrow ? TileCfg{4, 2, 4, 1, 32, 1} : TileCfg{8, 1, 4, 2, 32, 0};  // 256 px x 32 ch
+    // 256 px x 32 ch; in BF16X3 the double-buffered hi+lo weight ring of the LDS variant does not fit beside the
+    // 7x7 halo planes, so that mode streams the weights per wave as well
+    if (M >= 65536) t = (narrow || d->compute == HDRSKY_BF16X3) ? TileCfg{4, 2, 4, 1, 32, 1} : TileCfg{8, 1, 4, 2, 32, 0};
     else t = TileCfg{2, 2, 4, 1, 32, 1};                               // 128 px x 32 ch
   } else {
     // Cout <= 16 (the 3-channel output convs): the 32-wide column block (zero-padded weights) measured
     // faster than the 16-wide one
-    if (M >= 65536) t = TileCfg{8, 1, 4, 2, 32, 0};
+    if (M >= 65536) t = d->compute == HDRSKY_BF16X3 ? TileCfg{4, 2, 4, 1, 32, 1} : TileCfg{8, 1, 4, 2, 32, 0};
     else t = TileCfg{4, 1, 2, 1, 32, 0};
   }
   return t;

@@ -151,15 +151,19 @@ class Trainer:
         for name, _, _ in P.VGG_CHANNELS:
             self.vgg_pk[name] = PackedConv(self.vgg[name + ".w"], pr)
             self.vgg_pkT[name] = PackedConv(self.vgg[name + ".w"], pr, transpose_flip=True)
+        self._make_packer()
+
+    def _make_packer(self):
+        pairs = []
+        for cv in self.conv.values():
+            pairs.append((cv.w, cv.pk))
+            if cv.pkT is not None:
+                pairs.append((cv.w, cv.pkT))
+        self._packer = K.MultiPacker(pairs)      # uploads its job table: must not happen inside a graph capture
 
     def repack(self, fc=True):
         if getattr(self, "_packer", None) is None:
-            pairs = []
-            for cv in self.conv.values():
-                pairs.append((cv.w, cv.pk))
-                if cv.pkT is not None:
-                    pairs.append((cv.w, cv.pkT))
-            self._packer = K.MultiPacker(pairs)
+            self._make_packer()
         self._packer.run()
         if fc:
             self.fc1.repack(self.gs.w["sun.fc1.kernel"])
