@@ -294,10 +294,15 @@ class PackedFC:
                                                 _p(self.nat_lo), _stream()), "fc_pack_weights")
 
 
+FC_MAX_ROWS = 32   # rows one fc launch takes (the reference's batch size); larger batches go in slices of 32 rows
+
+
 def fc_fwd(x, pf: PackedFC, compute=BF16):
     """Split-R partial products [nsplit, M, N] of x[M,K] @ W[K,N]."""
     M, K = x.shape
     _f32(x, M, pf.K)
+    if M > FC_MAX_ROWS:
+        return torch.cat([fc_fwd(x[i:i + FC_MAX_ROWS], pf, compute) for i in range(0, M, FC_MAX_ROWS)], dim=1)
     lib = L.load()
     ns = lib.hdrsky_fc_nsplit(K)
     out = torch.empty((ns, M, pf.N), dtype=torch.float32, device=x.device)
@@ -309,6 +314,8 @@ def fc_dgrad(dy, pf: PackedFC, compute=BF16):
     """Split-R partial products [nsplit, M, K] of dy[M,N] @ W[K,N]^T."""
     M, N = dy.shape
     _f32(dy, M, pf.N)
+    if M > FC_MAX_ROWS:
+        return torch.cat([fc_dgrad(dy[i:i + FC_MAX_ROWS], pf, compute) for i in range(0, M, FC_MAX_ROWS)], dim=1)
     lib = L.load()
     ns = lib.hdrsky_fc_nsplit(N)
     out = torch.empty((ns, M, pf.K), dtype=torch.float32, device=dy.device)
@@ -645,7 +652,10 @@ def fc_wgrad(x, dy, dw, db, accumulate=False):
     M, Kd = x.shape
     N = dy.shape[1]
     _f32(x); _f32(dy, M, N); _f32(dw, Kd, N)
-    L.check(L.load().hdrsky_fc_wgrad(_p(x), _p(dy), M, Kd, N, int(accumulate), _p(dw), _p(db), _stream()), "fc_wgrad")
+    for i in range(0, M, FC_MAX_ROWS):
+        m = min(FC_MAX_ROWS, M - i)
+        L.check(L.load().hdrsky_fc_wgrad(_p(x[i:i + m]), _p(dy[i:i + m]), m, Kd, N, int(accumulate or i > 0), _p(dw), _p(db),
+                                         _stream()), "fc_wgrad")
 
 
 def rmsprop(w, g, ms, lr, rho=0.9, eps=1e-7, gscale=1.0):

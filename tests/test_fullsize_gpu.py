@@ -125,3 +125,22 @@ def test_gradient_sum_rule_for_data_parallelism(dev):
                 dog_weight=0.0)
         acc += tr.gs.grad
     assert_close(0.5 * acc, whole, 2e-4, "mean of the shard gradients = gradient of the whole batch")
+
+
+def test_batch_larger_than_32(dev):
+    """The Dense kernels take 32 rows per launch; larger batches are sliced by the front end.  Forward of batch 48 ==
+    the forwards of its samples in batches of 16 (BF16X3), and one training step at batch 40 runs and stays finite."""
+    K, params, synth, engine, trainer = pkg("kernels"), pkg("params"), pkg("synth"), pkg("engine"), pkg("trainer")
+    gen = params.init_params(params.generator_spec(), 0); sun = params.init_params(params.sunpose_spec(), 1)
+    nets = engine.Nets(gen, sun, device=dev, precise=True)
+    ldr = torch.from_numpy(synth.make_batch(48, seed=3)["ldr"]).to(dev)
+    full = engine.generator_forward(nets, ldr, compute=K.BF16X3)
+    for lo in (0, 16, 32):
+        part = engine.generator_forward(nets, ldr[lo:lo + 16].contiguous(), compute=K.BF16X3)
+        assert_close(part["sunpose_cmf"], full["sunpose_cmf"][lo:lo + 16], 1e-3, "cmf[%d:%d]" % (lo, lo + 16))
+    dis = params.init_params(params.discriminator_spec(), 2); vgg = params.init_params(params.vgg_spec(), 3)
+    bt = {k: torch.from_numpy(v).to(dev) for k, v in synth.make_batch(40, seed=4).items()}
+    tr = trainer.Trainer(gen, sun, dis, vgg, device=dev, precise=False, compute=K.BF16)
+    tr.step(bt["ldr"], bt["hdr_t"], bt["sunpose_gt"], update=True)
+    assert torch.isfinite(tr.gs.flat).all() and torch.isfinite(tr.ds.flat).all()
+    assert all(np.isfinite(v) for v in tr.loss_dict().values())
