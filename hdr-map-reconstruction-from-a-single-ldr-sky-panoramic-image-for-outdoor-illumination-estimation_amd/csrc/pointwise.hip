@@ -764,7 +764,16 @@ int hdrsky_norm_act_bwd(const float* x, const float* part, int nparts, const flo
 
 int hdrsky_softmax_head(const float* part, int nsplit, int M, int N, const float* bias, float* z, float* cmf,
                         void* gmax_bits, void* stream) {
-  if (!part || !cmf || N * (int)sizeof(float) > 60 * 1024) return HDRSKY_EINVAL;
+  if (!part || !cmf) return HDRSKY_EINVAL;
+  if (N * (int)sizeof(float) > 150 * 1024) return HDRSKY_EUNSUPPORTED;   // one row of logits is staged in LDS
+  if (N * (int)sizeof(float) > 48 * 1024) {
+    static bool set = false;
+    if (!set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(softmax_head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              152 * 1024) != hipSuccess) return HDRSKY_ELAUNCH;   // (the kernel also has a few static words)
+      set = true;
+    }
+  }
   hipLaunchKernelGGL(softmax_head_kernel, dim3(M), dim3(256), N * sizeof(float), (hipStream_t)stream, part, nsplit, M,
                      N, bias, z, cmf, (unsigned int*)gmax_bits);
   HDRSKY_CHECK_LAUNCH();

@@ -144,3 +144,23 @@ def test_batch_larger_than_32(dev):
     tr.step(bt["ldr"], bt["hdr_t"], bt["sunpose_gt"], update=True)
     assert torch.isfinite(tr.gs.flat).all() and torch.isfinite(tr.ds.flat).all()
     assert all(np.isfinite(v) for v in tr.loss_dict().values())
+
+
+def test_other_image_size_64x256(dev):
+    """--imheight 64 --imwidth 256: the sun-pose Dense layers grow to 32768x16384 / 16384x16384 and the soft-max row to
+    64 KB of LDS.  Forward + one training step run, stay finite, and the soft-max rows sum to one.  (16x64 and smaller
+    cannot train: the discriminator's VALID 4x4 output conv needs at least 4 rows after three stride-2 stages, as in
+    the reference.)"""
+    K, params, synth, engine, trainer = pkg("kernels"), pkg("params"), pkg("synth"), pkg("engine"), pkg("trainer")
+    h, w = 64, 256
+    gen = params.init_params(params.generator_spec(h, w), 0); sun = params.init_params(params.sunpose_spec(h, w), 1)
+    bt = synth.make_batch_device(2, h, w, seed=1, device=dev)
+    nets = engine.Nets(gen, sun, device=dev, precise=False, im_height=h, im_width=w)
+    out = engine.generator_forward(nets, bt["ldr"], compute=K.BF16)
+    assert tuple(out["y_final_lin"].shape) == (2, h, w, 3) and torch.isfinite(out["y_final_lin"]).all()
+    assert torch.allclose(out["sunpose_cmf"].sum(dim=1), torch.ones(2, device=dev), atol=1e-4)
+    del nets
+    dis = params.init_params(params.discriminator_spec(), 2); vgg = params.init_params(params.vgg_spec(), 3)
+    tr = trainer.Trainer(gen, sun, dis, vgg, device=dev, precise=False, compute=K.BF16, im_height=h, im_width=w)
+    tr.step(bt["ldr"], bt["hdr_t"], bt["sunpose_gt"], update=True)
+    assert all(np.isfinite(v) for v in tr.loss_dict().values()) and torch.isfinite(tr.gs.flat).all()
