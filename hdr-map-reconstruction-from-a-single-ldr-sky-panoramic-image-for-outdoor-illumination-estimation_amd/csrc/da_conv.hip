@@ -51,9 +51,15 @@ __device__ __forceinline__ Tap4 da_tap(float base_y, float base_x, float off_y, 
   return t;
 }
 
-template <bool PRECISE>
-__global__ void __launch_bounds__(256) da_conv_kernel(const DaArgs a) {
-  constexpr int TM = 64, BN = 64;   // 64 output pixels of one row x 64 filters; wave w owns filters [16w, 16w+16)
+// Workgroup = NWV waves: a tile of 64 consecutive output pixels of one sample (row-major, so it spans several rows
+// when W < 64) x NWV*16 filters (wave w owns filters [16w, 16w+16): all 128 filters of a res-block conv in one
+// workgroup, so the gather is not repeated per filter block).  Per filter tap: every thread gathers the four corner
+// pixels of its (pixel, 8-channel) items into REGISTERS one tap ahead - the loads of tap t+1 are in flight while the
+// MFMAs of tap t run - then blends, rounds to bf16 and writes the tap's A tile into the other LDS buffer.
+template <bool PRECISE, int NWV>
+__global__ void __launch_bounds__(NWV * 64) da_conv_kernel(const DaArgs a) {
+  constexpr int TM = 64, NT = NWV * 64;
+  constexpr int IMAX = PRECISE ? 4 : 4;                       // (pixel, chunk) items per thread and tap: Cin <= 8*IMAX*NT/TM
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, lr = lane & 15;
   const int nq = a.Cin >> 3;
@@ -63,51 +69,75 @@ __global__ void __launch_bounds__(256) da_conv_kernel(const DaArgs a) {
 
   int bid = blockIdx.x;
   const int nb = bid % a.nblocks; bid /= a.nblocks;
-  const int tx = bid % a.tiles_x; bid /= a.tiles_x;
-  const int oy = bid % a.H, b = bid / a.H;
-  const int ox0 = tx * TM, n0 = nb * BN;
+  const int tile = bid % a.tiles_x, b = bid / a.tiles_x;      // tiles_x = tiles per sample
+  const int p0 = tile * TM, n0 = nb * (NWV * 16);
+  const int npix = a.H * a.W;
+  const int nitems = TM * nq;
 
   f32x4_t acc[4];
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) acc[mi] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const uint4* wlh = a.whi + (size_t)kq * a.Npad + n0 + wave * 16 + lr;
   const uint4* wll = PRECISE ? a.wlo + (size_t)kq * a.Npad + n0 + wave * 16 + lr : nullptr;
-  const float* xb = a.x + (size_t)b * a.H * a.W * a.Cin;
+  const float* xb = a.x + (size_t)b * npix * a.Cin;
 
-  for (int t = 0; t < a.k2; ++t) {
-    uint4* buf = sA + (t & 1) * buf_units;
-    const float off_y = a.offs[(oy * a.k2 + t) * 2], off_x = a.offs[(oy * a.k2 + t) * 2 + 1];
-    const int ty = t / a.ksize, tx_ = t % a.ksize;
-    // ---- gather + bilinear blend of this tap's 64 samples x Cin channels ---------------------------------
-    for (int i = tid; i < TM * nq; i += 256) {
-      const int m = i / nq, q = i % nq;
-      const int ox = ox0 + m;
-      float v[8];
+  float cr[IMAX][4][8];     // corner pixels of this thread's items for the tap in flight
+  float cw[IMAX][4];        // their bilinear weights (0 for corners in the zero padding / pixels past the image)
+
+  for (int t = -1; t < a.k2; ++t) {
+    // ---- blend + store tap t (registers -> LDS buffer t&1) ------------------------------------------------------
+    if (t >= 0) {
+      uint4* buf = sA + (t & 1) * buf_units;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = 0.f;
-      if (ox < a.W) {
-        // base grid = VALID patches of the padded meshgrid (:152-168): padded coordinate of tap (ty,tx) at (oy,ox)
-        const Tap4 s = da_tap((float)(oy + ty), (float)(ox + tx_), off_y, off_x, a.in_h, a.in_w);
-        const int ys[4] = {s.y0, s.y0, s.y1, s.y1}, xs[4] = {s.x0, s.x1, s.x0, s.x1};
-        const float ws[4] = {s.w0, s.w1, s.w2, s.w3};
+      for (int it = 0; it < IMAX; ++it) {
+        const int i = it * NT + tid;
+        if (i < nitems) {
+          const int m = i / nq, q = i % nq;
+          float v[8];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int yy = ys[k] - a.pad, xx = xs[k] - a.pad;      // back to un-padded coordinates; border = zeros
-          if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
-            const float* p = xb + ((size_t)yy * a.W + xx) * a.Cin + q * 8;
-            const float4 lo = *reinterpret_cast<const float4*>(p), hi = *reinterpret_cast<const float4*>(p + 4);
-            v[0] += ws[k] * lo.x; v[1] += ws[k] * lo.y; v[2] += ws[k] * lo.z; v[3] += ws[k] * lo.w;
-            v[4] += ws[k] * hi.x; v[5] += ws[k] * hi.y; v[6] += ws[k] * hi.z; v[7] += ws[k] * hi.w;
+          for (int j = 0; j < 8; ++j)
+            v[j] = cw[it][0] * cr[it][0][j] + cw[it][1] * cr[it][1][j] + cw[it][2] * cr[it][2][j] + cw[it][3] * cr[it][3][j];
+          uint4 h8, l8;
+          pack8<PRECISE>(v, h8, l8);
+          buf[q * plane + m] = h8;
+          if (PRECISE) buf[nq * plane + q * plane + m] = l8;
+        }
+      }
+      __syncthreads();   // tile t staged; also: every wave is past the MFMAs of tile t-1, so buffer (t+1)&1 is free
+    }
+    // ---- issue the gather of tap t+1 ------------------------------------------------------------------------------
+    if (t + 1 < a.k2) {
+      const int tn = t + 1;
+      const int ty = tn / a.ksize, tx_ = tn % a.ksize;
+#pragma unroll
+      for (int it = 0; it < IMAX; ++it) {
+        const int i = it * NT + tid;
+        if (i < nitems) {
+          const int m = i / nq, q = i % nq;
+          const int pix = p0 + m;
+          const bool live = pix < npix;
+          const int oy = live ? pix / a.W : 0, ox = live ? pix % a.W : 0;
+          const float off_y = a.offs[(oy * a.k2 + tn) * 2], off_x = a.offs[(oy * a.k2 + tn) * 2 + 1];
+          // base grid = VALID patches of the padded meshgrid (:152-168): padded coordinate of tap (ty,tx) at (oy,ox)
+          const Tap4 s = da_tap((float)(oy + ty), (float)(ox + tx_), off_y, off_x, a.in_h, a.in_w);
+          const int ys[4] = {s.y0, s.y0, s.y1, s.y1}, xs[4] = {s.x0, s.x1, s.x0, s.x1};
+          const float ws[4] = {s.w0, s.w1, s.w2, s.w3};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int yy = ys[k] - a.pad, xx = xs[k] - a.pad;      // back to un-padded coordinates; border = zeros
+            const bool in = live && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+            const float* pp = xb + ((size_t)(in ? yy : 0) * a.W + (in ? xx : 0)) * a.Cin + q * 8;
+            const float4 lo = *reinterpret_cast<const float4*>(pp), hi = *reinterpret_cast<const float4*>(pp + 4);
+            cr[it][k][0] = lo.x; cr[it][k][1] = lo.y; cr[it][k][2] = lo.z; cr[it][k][3] = lo.w;
+            cr[it][k][4] = hi.x; cr[it][k][5] = hi.y; cr[it][k][6] = hi.z; cr[it][k][7] = hi.w;
+            cw[it][k] = in ? ws[k] : 0.f;
           }
         }
       }
-      uint4 h8, l8;
-      pack8<PRECISE>(v, h8, l8);
-      buf[q * plane + m] = h8;
-      if (PRECISE) buf[nq * plane + q * plane + m] = l8;
     }
-    __syncthreads();   // tile t staged; also: every wave is past the MFMAs of tile t-1, so buffer (t+1)&1 is free
+    if (t < 0) continue;
     // ---- MFMA: Cin/32 k-steps, 4 pixel fragments x this wave's 16 filters -----------------------------------
+    const uint4* buf = sA + (t & 1) * buf_units;
     for (int cb = 0; cb < a.cin32; ++cb) {
       const size_t o = (size_t)((t * a.cin32 + cb) * 4) * a.Npad;
       const uint4 bh = wlh[o];
@@ -133,8 +163,8 @@ __global__ void __launch_bounds__(256) da_conv_kernel(const DaArgs a) {
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int ox = ox0 + mi * 16 + kq * 4 + j;
-        if (ox < a.W) a.y[((size_t)(b * a.H + oy) * a.W + ox) * a.Cout + n] = acc[mi][j] + bv;
+        const int pix = p0 + mi * 16 + kq * 4 + j;
+        if (pix < npix) a.y[((size_t)b * npix + pix) * a.Cout + n] = acc[mi][j] + bv;
       }
   }
 }
@@ -273,21 +303,27 @@ int hdrsky_da_conv2d_fwd(const float* x, const void* w_hi, const void* w_lo, con
   // conv2d._pad_input (:125-150) for stride 1: pad (k-1)//2 before, rest after, when k > 1
   a.pad = ksize > 1 ? (ksize - 1) / 2 : 0;
   a.in_h = H + (ksize > 1 ? ksize - 1 : 0); a.in_w = W + (ksize > 1 ? ksize - 1 : 0);
-  a.cin32 = Cin / 32; a.nblocks = cdiv(Cout, 64); a.tiles_x = cdiv(W, 64);
+  // workgroup: 64 pixels x 128 filters (8 waves) when the layer has more than 64 filters, else 64 filters (4 waves)
+  const int nwv = Cout > 64 ? 8 : 4;
+  a.cin32 = Cin / 32; a.nblocks = cdiv(Cout, nwv * 16); a.tiles_x = cdiv(H * W, 64);
+  if (64 * (Cin / 8) > 4 * nwv * 64) return HDRSKY_EUNSUPPORTED;   // register prefetch budget (Cin <= 128 / 256)
   const int lds = 2 * (Cin / 8) * 65 * 16 * (precise ? 2 : 1);
   if (lds > 160 * 1024) return HDRSKY_EUNSUPPORTED;
-  const int grid = B * H * a.tiles_x * a.nblocks;
-  if (precise) {
-    auto k = da_conv_kernel<true>;
-    static bool set = false;
-    if (!set) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return HDRSKY_ELAUNCH; set = true; }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
-  } else {
-    auto k = da_conv_kernel<false>;
-    static bool set = false;
-    if (!set) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return HDRSKY_ELAUNCH; set = true; }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+  const int grid = B * a.tiles_x * a.nblocks;
+#define HDRSKY_DA_LAUNCH(PREC_, NWV_)                                                                             \
+  {                                                                                                               \
+    auto k = da_conv_kernel<PREC_, NWV_>;                                                                          \
+    static bool set = false;                                                                                      \
+    if (!set) {                                                                                                   \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                              160 * 1024) != hipSuccess) return HDRSKY_ELAUNCH;                                   \
+      set = true;                                                                                                 \
+    }                                                                                                             \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NWV_ * 64), lds, (hipStream_t)stream, a);                              \
   }
+  if (precise) { if (nwv == 8) HDRSKY_DA_LAUNCH(true, 8) else HDRSKY_DA_LAUNCH(true, 4) }
+  else { if (nwv == 8) HDRSKY_DA_LAUNCH(false, 8) else HDRSKY_DA_LAUNCH(false, 4) }
+#undef HDRSKY_DA_LAUNCH
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }
