@@ -476,13 +476,13 @@ def bn_train_finalize(stats: Stats, gamma, beta, B, C, moving_mean=None, moving_
     return outs
 
 
-def bn_act_bwd(x, dy, mean, rstd, gamma, beta, slope, dgamma=None, dbeta=None):
+def bn_act_bwd(x, dy, mean, rstd, gamma, beta, slope, dgamma=None, dbeta=None, out=None):
     _f32(x); _f32(dy, *x.shape)
     C = x.shape[-1]
     npix = x.numel() // C
     lib = L.load()
     ws = torch.empty((2 * lib.hdrsky_bn_bwd_nblocks() * C + 2 * C,), dtype=torch.float32, device=x.device)
-    dx = torch.empty_like(x)
+    dx = _f32(out, *x.shape) if out is not None else torch.empty_like(x)
     L.check(lib.hdrsky_bn_act_bwd(_p(x), _p(dy), _p(_f32(mean, C)), _p(_f32(rstd, C)), _p(_f32(gamma, C)), _p(_f32(beta, C)),
                                   slope, npix, C, _p(ws), _p(dgamma), _p(dbeta), _p(dx), _stream()), "bn_act_bwd")
     return dx
@@ -565,9 +565,9 @@ def l1(a, b, wl, wg, loss_slot, da=None, accumulate=False):
     L.check(L.load().hdrsky_l1(_p(a), _p(b), a.numel(), wl, wg, _p(loss_slot), _p(da), int(accumulate), _stream()), "l1")
 
 
-def mse(x, target, wl, wg, loss_slot, want_grad=True):
+def mse(x, target, wl, wg, loss_slot, want_grad=True, out=None):
     _f32(x)
-    dx = torch.empty_like(x) if want_grad else None
+    dx = (_f32(out, *x.shape) if out is not None else torch.empty_like(x)) if want_grad else None
     L.check(L.load().hdrsky_mse(_p(x), target, x.numel(), wl, wg, _p(loss_slot), _p(dx), _stream()), "mse")
     return dx
 
@@ -629,9 +629,11 @@ def slice_channels(x, c_off, c_take, scale=1.0, out=None):
     return o
 
 
-def concat2(a, b):
+def concat2(a, b, out=None):
     Ca, Cb = a.shape[-1], b.shape[-1]
-    out = torch.empty(tuple(a.shape[:-1]) + (Ca + Cb,), dtype=torch.float32, device=a.device)
+    if out is None:
+        out = torch.empty(tuple(a.shape[:-1]) + (Ca + Cb,), dtype=torch.float32, device=a.device)
+    _f32(out, *(tuple(a.shape[:-1]) + (Ca + Cb,)))
     L.check(L.load().hdrsky_concat2(_p(_f32(a)), Ca, _p(_f32(b)), Cb, a.numel() // Ca, _p(out), _stream()), "concat2")
     return out
 

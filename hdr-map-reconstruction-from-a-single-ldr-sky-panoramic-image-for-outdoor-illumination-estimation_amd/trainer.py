@@ -279,6 +279,50 @@ class Trainer:
             return c[net + "d1"].dgrad(R["in"], d1pre, cp)
         return None
 
+    # ---- the two training-mode discriminator passes (real | generated) as ONE batch of 2B through the convolutions; the
+    # BatchNorm layers keep the two halves apart (their own batch statistics, moving averages updated real first, then
+    # generated - the reference's program order, train.py:360-361) through per-sample affine tables
+    def _down_stack_pair(self, net, params, x2):
+        c, cp = self.conv, self.compute
+        B = x2.shape[0] // 2
+        R = {"in": x2}
+        R["d1"], _ = c[net + "d1"].fwd(x2, compute=cp, out_slope=0.3)
+        cur, xf = R["d1"], None
+        for d in ("d2", "d3", "d4"):
+            raw, st = c[net + d].fwd(cur, xf, cp, want_stats=True)
+            n, C = net + d + ".norm.", raw.shape[-1]
+            sc2 = torch.empty((2 * B, C), dtype=torch.float32, device=raw.device)
+            sh2 = torch.empty_like(sc2)
+            halves = []
+            for hf in (0, 1):
+                sth = K.Stats(st.part[hf * B:(hf + 1) * B], st.nparts, st.count)
+                mean, rstd, sc, sh = K.bn_train_finalize(sth, params[n + "gamma"], params[n + "beta"], B, C,
+                                                         params[n + "moving_mean"], params[n + "moving_variance"])
+                sc2[hf * B:(hf + 1) * B] = sc      # broadcast row copy
+                sh2[hf * B:(hf + 1) * B] = sh
+                halves.append((mean, rstd))
+            R[d] = dict(x=cur, xf=xf, raw=raw, halves=halves)
+            cur, xf = raw, InXf(mode=L.IN_AFFINE, slope=0.3, scale=sc2, shift=sh2)
+        R["xf_out"] = xf
+        return R
+
+    def _down_stack_pair_bwd(self, net, params, grads, R, dact4):
+        c, cp = self.conv, self.compute
+        dy = dact4
+        B = dy.shape[0] // 2
+        for d in ("d4", "d3", "d2"):
+            r = R[d]
+            n = net + d + ".norm."
+            draw = torch.empty_like(r["raw"])
+            for hf, (mean, rstd) in enumerate(r["halves"]):
+                sl = slice(hf * B, (hf + 1) * B)
+                K.bn_act_bwd(r["raw"][sl], dy[sl], mean, rstd, params[n + "gamma"], params[n + "beta"], 0.3,
+                             grads[n + "gamma"], grads[n + "beta"], out=draw[sl])
+            self._wg(net + d, r["x"], r["xf"], draw)
+            dy = c[net + d].dgrad(r["x"], draw, cp)
+        d1pre = K.affine_act_bwd(R["d1"], dy, None, None, 0.3)
+        self._wg(net + "d1", R["in"], None, d1pre)
+
     def _sunrad_forward(self, ldr, cams, t, S):
         w = self.gs.w
         plz = K.plz_build(ldr, *cams)
@@ -459,15 +503,18 @@ class Trainer:
 
         # ------------------------------------------------------------------ discriminator step (train.py:351-380)
         @seg("disc_step", 1, ["loss_adv"])
-        def _():       # real then generated, BN batch statistics (after the inference-mode call of loss_adv)
+        def _():       # real and generated pass as one batch of 2B (after the inference-mode call of loss_adv)
             cvo = c["dis.out"]
-            for which, img, target, slot in (("real", T["hdr_t"], 1.0, 6), ("fake", T["y_lin"], 0.0, 5)):
-                Rd = self._down_stack("dis.", self.ds.w, K.concat2(T["ldr"], img), training=True)
-                lg, _ = cvo.fwd(Rd["d4"]["raw"], Rd["xf_out"], cp)
-                dl = K.mse(lg, target, 1.0, 0.5, self.losses[slot:slot + 1])
-                self._wg("dis.out", Rd["d4"]["raw"], Rd["xf_out"], dl)
-                da4 = cvo.dgrad(Rd["d4"]["raw"], dl, cp)
-                self._down_stack_bwd("dis.", self.ds.w, self.ds.g, Rd, da4, training=True, want_input_grad=False)
+            x2 = torch.empty((2 * B,) + tuple(T["ldr"].shape[1:3]) + (6,), dtype=torch.float32, device=self.device)
+            K.concat2(T["ldr"], T["hdr_t"], out=x2[:B]); K.concat2(T["ldr"], T["y_lin"], out=x2[B:])
+            Rd = self._down_stack_pair("dis.", self.ds.w, x2)
+            lg, _ = cvo.fwd(Rd["d4"]["raw"], Rd["xf_out"], cp)
+            dl = torch.empty_like(lg)
+            K.mse(lg[:B], 1.0, 1.0, 0.5, self.losses[6:7], out=dl[:B])      # real      (train.py:364)
+            K.mse(lg[B:], 0.0, 1.0, 0.5, self.losses[5:6], out=dl[B:])      # generated (train.py:365)
+            self._wg("dis.out", Rd["d4"]["raw"], Rd["xf_out"], dl)
+            da4 = cvo.dgrad(Rd["d4"]["raw"], dl, cp)
+            self._down_stack_pair_bwd("dis.", self.ds.w, self.ds.g, Rd, da4)
             self._flush_wgrads()
 
         # ------------------------------------------------------------------ sun-pose conv layers (sunpose_net.py:54-62)
