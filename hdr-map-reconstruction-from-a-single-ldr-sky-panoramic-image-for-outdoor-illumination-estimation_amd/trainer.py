@@ -550,7 +550,7 @@ class Trainer:
                 c["gen.conv3_" + sfx].dgrad(T["x"][-1], dd3, cp, out=dres)
             T["wq_dec"] = self._take_wgrads()
 
-        @seg("wg_dec", 2, ["bwd_dec"])
+        @seg("wg_dec", 1, ["bwd_dec"])
         def _():
             K.conv2d_wgrad_multi(T["wq_dec"])
 
@@ -618,7 +618,7 @@ class Trainer:
                 K.rmsprop(self.gs.flat[o:o + n], self.gs.grad[o:o + n], self.gs.ms[o:o + n], self.lr, gscale=self._gscale)
 
         # every gradient is complete here: a data-parallel driver hooks its all-reduce onto this (empty) segment
-        segs.append(("grads_ready", 0, ("disc_step", "bwd_sunpose", "wg_res"), None))
+        segs.append(("grads_ready", 0, ("disc_step", "wg_dec", "bwd_sunpose", "wg_res"), None))
 
         # ------------------------------------------------------------------ optimizers (train.py:403,406)
         @seg("apply", 0, ["apply_fc"])
