@@ -162,30 +162,13 @@ def main():
         # 32 MB follow when every gradient is ready.
         par.broadcast_params_([tr.gs.flat, tr.ds.flat])   # replicas start from rank 0's weights
         tr.repack()
-        fc0, fc1 = tr.fc_grad_range()
-
-        comm = torch.cuda.Stream(device=dev)
-
-        def fc_grads_reduce():
-            # Runs on the stream of the Dense-layer optimizer segment right before it - late in the HOST's launch order,
-            # so the RCCL enqueue cost does not delay the launches of the critical chain - but the collective itself
-            # only waits for the event behind the segment that completes these gradients: it starts on the GPU as
-            # soon as they exist and runs beside the rest of the backward pass.
-            comm.wait_event(tr.event(tr.FC_GRADS_READY))
-            with torch.cuda.stream(comm):
-                work = dist.all_reduce(tr.gs.grad[fc0:fc1], async_op=True)
-            work.wait()
-
-        def grads_ready():
-            dist.all_reduce(tr.gs.grad[:fc0])
-            dist.all_reduce(tr.ds.grad)
-        hooks = {tr.GRADS_READY: grads_ready} if dp else None
-        pre_hooks = {tr.APPLY[0]: fc_grads_reduce} if dp else None
+        ex = par.GradientExchange(tr, device=dev)   # hooks on the segment plan: see parallel.py
+        hooks, pre_hooks = (ex.hooks, ex.pre_hooks) if dp else (None, None)
         roof_pw, roof_b = tr.conv["gen.res.0.conv1"].pk, tr.gs.w["gen.res.0.conv1.b"]
         probe = lambda out: out["y_final_lin"]
         if args.no_graph:
             out = tr.step(ldr, hdr, gt, update=False)
-            one_step = lambda: (tr.step(ldr, hdr, gt, update=False), hooks and [fc_grads_reduce(), grads_ready()],
+            one_step = lambda: (tr.step(ldr, hdr, gt, update=False), dp and [ex.fc_grads_reduce(), ex.grads_ready()],
                                 tr.apply_gradients())
         else:
             out = tr.capture(ldr, hdr, gt)

@@ -4,8 +4,9 @@
 statistics, local reduce_max - and the gradients are averaged, which is exact because every loss term is a batch
 mean (train.py:305-331,364-369).
 
-The exchange is over the two FLAT gradient buffers (one per optimizer, trainer.FlatParams) - two large collectives
+The exchange is over the two FLAT gradient buffers (one per optimizer, trainer.FlatParams) - three large collectives
 per step instead of ~190 small ones; the 1/world factor is folded into the optimizer kernel (`gscale`).
+`GradientExchange` attaches them to the Trainer's segment plan so that the largest one overlaps the backward pass.
 """
 import os
 
@@ -51,3 +52,47 @@ def broadcast_params_(flat_buffers, src=0):
         return
     for t in flat_buffers:
         dist.broadcast(t, src=src)
+
+
+class GradientExchange:
+    """The per-step gradient exchange of a data-parallel `trainer.Trainer`, as hooks for `Trainer.replay`.
+
+    The sun-pose Dense weight gradients (201 of the 233 MB) are complete after the segment `Trainer.FC_GRADS_READY`;
+    their all-reduce is enqueued by the host late (as a pre-hook of the Dense-layer optimizer segment, so the
+    collective's enqueue cost does not sit between the launches of the critical chain) but on a communication stream
+    that waits only for that segment's event: on the GPU it starts as soon as those gradients exist and runs beside
+    the rest of the backward pass.  Everything else (32 MB) is reduced when `Trainer.GRADS_READY` is reached.
+
+        ex = GradientExchange(tr)
+        tr.replay(hooks=ex.hooks, pre_hooks=ex.pre_hooks)      # graph path
+        tr.step(..., update=False); ex.reduce_all(); tr.apply_gradients()   # eager path
+    """
+
+    def __init__(self, trainer, device=None):
+        self.tr = trainer
+        self.fc0, self.fc1 = trainer.fc_grad_range()
+        self.active = dist.is_initialized()     # a process group exists (world 1 only in rehearsals of this path)
+        self.comm = torch.cuda.Stream(device=device) if self.active else None
+
+    def fc_grads_reduce(self):
+        tr = self.tr
+        self.comm.wait_event(tr.event(tr.FC_GRADS_READY))
+        with torch.cuda.stream(self.comm):
+            work = dist.all_reduce(tr.gs.grad[self.fc0:self.fc1], async_op=True)
+        work.wait()          # the CURRENT stream (the optimizer segment's) waits for the collective
+
+    def grads_ready(self):
+        dist.all_reduce(self.tr.gs.grad[:self.fc0])
+        dist.all_reduce(self.tr.ds.grad)
+
+    def reduce_all(self):
+        """Eager path: every gradient buffer, on the current stream."""
+        allreduce_sum_([self.tr.gs.grad, self.tr.ds.grad])
+
+    @property
+    def hooks(self):
+        return {self.tr.GRADS_READY: self.grads_ready} if self.active else None
+
+    @property
+    def pre_hooks(self):
+        return {self.tr.APPLY[0]: self.fc_grads_reduce} if self.active else None

@@ -61,6 +61,7 @@ def main(argv=None):
     if tensors and "gen_optimizer/rms" in tensors:
         tr.gs.ms.copy_(torch.from_numpy(tensors["gen_optimizer/rms"])); tr.ds.ms.copy_(torch.from_numpy(tensors["disc_optimizer/rms"]))
     par.broadcast_params_([tr.gs.flat, tr.ds.flat]); tr.repack()
+    ex = par.GradientExchange(tr, device=dev)
 
     # The step is captured once (one hipGraph per segment, see trainer.py) on static input buffers that every batch is
     # copied into; losses are accumulated on the device and read back once per epoch.
@@ -79,6 +80,8 @@ def main(argv=None):
                 ldr, hdr, gt = b["ldr"], b["hdr_t"], b["sunpose_gt"]
             if args.no_graph:
                 out = tr.step(ldr, hdr, gt, update=False)
+                ex.reduce_all()
+                tr.apply_gradients()
             else:
                 if bufs is None:
                     bufs = (ldr.clone(), hdr.clone(), gt.clone())
@@ -86,9 +89,7 @@ def main(argv=None):
                     captured = True
                 for dst, src in zip(bufs, (ldr, hdr, gt)):
                     dst.copy_(src)
-                tr.replay(update=False)
-            par.allreduce_sum_([tr.gs.grad, tr.ds.grad])
-            tr.apply_gradients(gscale=1.0 / world)
+                tr.replay(hooks=ex.hooks, pre_hooks=ex.pre_hooks)   # gradients are scaled by 1/world in the optimizer
             loss_acc += tr.losses
         v = dict(zip(LOSS_SLOTS, (loss_acc / args.steps_per_epoch).tolist()))
         v["total_gen_loss"] = v["kl"] + 1000.0 * v["dog"] + v["adv"] + 10.0 * v["l1"] + 0.01 * v["perceptual"]

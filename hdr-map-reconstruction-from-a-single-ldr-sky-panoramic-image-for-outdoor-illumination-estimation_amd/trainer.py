@@ -709,8 +709,16 @@ class Trainer:
         """Captures every segment of the step on (ldr, hdr_t, sunpose_gt) - static input buffers the caller refills -
         into its own hipGraph.  `replay()` then runs one step."""
         self._bind(ldr, hdr_t, sunpose_gt)
+        # the warm-up steps (lazy kernel attributes, allocator) must not train: weights, RMSprop slots and BatchNorm
+        # moving statistics are put back afterwards (and replicas of a data-parallel job stay identical)
+        state = [(t, t.clone()) for t in (self.gs.flat, self.gs.ms, self.ds.flat, self.ds.ms)]
         for _ in range(warmup):
             self._execute()
+        torch.cuda.synchronize()
+        for t, saved in state:
+            t.copy_(saved)
+        del state
+        self.repack()
         torch.cuda.synchronize()
         self._graphs = {}
         for name, si, deps, fn in self._segs:

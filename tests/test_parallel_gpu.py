@@ -1,0 +1,108 @@
+"""The data-parallel training step end to end through the HIP kernels: two replicas (two processes sharing the one
+card of the test box, process group on gloo - RCCL refuses two ranks on one device) run the captured step with the
+overlapped gradient exchange of parallel.GradientExchange; the weights they arrive at must be the ones a single
+process gets from the SUM of the two shard gradients applied with gscale = 1/2."""
+import importlib
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import PKG, ROOT
+
+pytestmark = pytest.mark.gpu
+H, W, PER = 32, 128, 2          # two images per replica
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _mods():
+    sys.path.insert(0, ROOT)
+    return [importlib.import_module(PKG + "." + m) for m in ("params", "synth", "trainer", "kernels", "parallel")]
+
+
+def _make_trainer(world, dev):
+    P, synth, trainer, K, par = _mods()
+    nets = [P.init_params(P.generator_spec(H, W), 0), P.init_params(P.sunpose_spec(H, W), 1),
+            P.init_params(P.discriminator_spec(), 2), P.init_params(P.vgg_spec(), 3)]
+    return trainer.Trainer(*nets, device=dev, precise=True, compute=K.BF16X3, im_height=H, im_width=W, world_size=world)
+
+
+def _shard(rank, dev):
+    P, synth, trainer, K, par = _mods()
+    b = synth.make_batch(2 * PER, H, W, seed=21)
+    sl = par.shard_slice(2 * PER, rank, 2)
+    return [torch.from_numpy(b[k][sl]).to(dev).contiguous() for k in ("ldr", "hdr_t", "sunpose_gt")]
+
+
+def _worker(rank, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    P, synth, trainer, K, par = _mods()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    r, world, _ = par.init_from_env(backend="gloo")
+    assert (r, world) == (rank, 2)
+    tr = _make_trainer(2, dev)
+    if rank == 1:
+        tr.gs.flat.mul_(1.5)                                  # diverged replica: the broadcast must repair it
+    par.broadcast_params_([tr.gs.flat, tr.ds.flat]); tr.repack()
+    ex = par.GradientExchange(tr, device=dev)
+    assert ex.active and ex.hooks and ex.pre_hooks
+    tr.capture(*_shard(rank, dev))                            # warm-up inside must leave the weights untouched
+    for _ in range(2):                                        # two optimizer steps on the same shard
+        tr.replay(hooks=ex.hooks, pre_hooks=ex.pre_hooks)
+    torch.cuda.synchronize()
+    torch.save({"gs": tr.gs.flat.cpu(), "ds": tr.ds.flat.cpu(), "gms": tr.gs.ms.cpu(), "losses": tr.losses.cpu()},
+               os.path.join(out_dir, "r%d.pt" % rank))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_replicas_one_card_equal_summed_gradient_step(dev, tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), "r%d.pt" % r)) for r in (0, 1))
+    t0 = _make_trainer(1, dev)
+    nt, ng = t0.ds.ntrain, t0.gs.ntrain
+    w0g, w0d = t0.gs.flat.cpu(), t0.ds.flat.cpu()
+    del t0
+    for k, n in (("gs", ng), ("gms", None), ("ds", nt)):     # replicas stay bit-identical (same reduced buffers) ...
+        bad = (r0[k][:n] != r1[k][:n]).nonzero().flatten()
+        assert bad.numel() == 0, (k, int(bad.numel()), int(bad[0]), int(bad[-1]), r0[k][:n].numel())
+    assert not torch.equal(r0["ds"][nt:], r1["ds"][nt:])      # ... except the BatchNorm moving statistics (local:
+    assert not torch.equal(r0["gs"][ng:], r1["gs"][ng:])      # discriminator and sun-radiance head)
+    assert not torch.equal(r0["losses"], r1["losses"])        # ... while they did see different shards
+
+    # single-process restatement: per step, the two shard gradients summed, RMSprop with gscale 1/2
+    tr = _make_trainer(1, dev)
+    shards = [_shard(r, dev) for r in (0, 1)]
+    # BatchNorm moving statistics are local to a replica (not exchanged): follow replica 0's
+    for _ in range(2):
+        gsum, dsum = torch.zeros_like(tr.gs.grad), torch.zeros_like(tr.ds.grad)
+        dflat0, gflat0 = tr.ds.flat.clone(), tr.gs.flat.clone()
+        for r in (1, 0):                                      # replica 0 last: its BN moving-average update is kept
+            tr.ds.flat.copy_(dflat0); tr.gs.flat.copy_(gflat0)
+            tr.step(*shards[r], update=False)
+            gsum += tr.gs.grad; dsum += tr.ds.grad
+        tr.gs.grad.copy_(gsum); tr.ds.grad.copy_(dsum)
+        tr.apply_gradients(gscale=0.5)
+    torch.cuda.synchronize()
+
+    def rel(a, b):
+        return float((a.double() - b.double()).norm() / b.double().norm())
+    # fp32 everywhere; differences come from atomic summation order in the weight gradients only (RMSprop's first
+    # steps move every weight by ~lr*sign(g), so compare the UPDATE, not the weights)
+    dg_ref, dg_got = tr.gs.flat.cpu()[:ng] - w0g[:ng], r0["gs"][:ng] - w0g[:ng]
+    dd_ref, dd_got = tr.ds.flat.cpu()[:nt] - w0d[:nt], r0["ds"][:nt] - w0d[:nt]
+    assert float(dg_ref.abs().max()) > 0 and float(dd_ref.abs().max()) > 0
+    print("update mismatch gen/sun %.3g disc %.3g, ms %.3g" % (rel(dg_got, dg_ref), rel(dd_got, dd_ref),
+                                                             rel(r0["gms"], tr.gs.ms.cpu())))
+    assert rel(dg_got, dg_ref) < 2e-2, rel(dg_got, dg_ref)
+    assert rel(dd_got, dd_ref) < 2e-2, rel(dd_got, dd_ref)
+    assert rel(r0["gms"], tr.gs.ms.cpu()) < 1e-3
+    assert rel(r0["ds"][nt:], tr.ds.flat.cpu()[nt:]) < 1e-5  # BN moving statistics of replica 0
+    assert rel(r0["gs"][ng:], tr.gs.flat.cpu()[ng:]) < 1e-5
