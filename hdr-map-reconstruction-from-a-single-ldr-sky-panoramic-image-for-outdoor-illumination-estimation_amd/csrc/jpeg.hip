@@ -1,0 +1,221 @@
+// JPEG quality round trip of the training augmentation (train.py:86-92: tf.image.adjust_jpeg_quality = libjpeg baseline
+// encode, 4:2:0, slow-integer DCT, quality-scaled Annex-K tables, then decode with slow-integer IDCT and "fancy" chroma
+// upsampling) without the lossless entropy-coding stage: pure integer / byte work, bit-exact against libjpeg.
+//
+// Two launches per batch:
+//   jpeg_blocks_kernel   8 threads per 8x8 block (Y blocks at full resolution, Cb / Cr blocks of the 2x2-averaged
+//                        planes): float -> u8 -> YCbCr (jccolor.c) -> [h2v2 downsample, jcsample.c] -> level shift ->
+//                        jfdctint.c rows, LDS transpose, columns -> quantise (jcdctmgr.c) -> dequantise -> jidctint.c
+//                        columns, LDS transpose, rows -> range limit -> one 8-byte store per thread into the u8 planes
+//   jpeg_merge_kernel    one thread per output pixel: h2v2 fancy (triangle) upsampling of the decoded chroma planes
+//                        (jdsample.c) + YCbCr -> RGB (jdcolor.c) -> float / 255
+// Algorithmic bytes per image: 12 B/pixel read + 1.5 B/pixel plane write, then 1.5 (+ cached neighbours) read + 12 written.
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+#include "hdrsky.h"
+
+namespace {
+
+__constant__ unsigned char kStdLuma[64] = {16, 11, 10, 16, 24,  40,  51,  61,  12, 12, 14, 19, 26,  58,  60,  55,
+                                           14, 13, 16, 24, 40,  57,  69,  56,  14, 17, 22, 29, 51,  87,  80,  62,
+                                           18, 22, 37, 56, 68,  109, 103, 77,  24, 35, 55, 64, 81,  104, 113, 92,
+                                           49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
+__constant__ unsigned char kStdChroma[64] = {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99,
+                                             24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99,
+                                             99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99,
+                                             99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99};
+
+constexpr int CONST_BITS = 13, PASS1_BITS = 2;
+constexpr int F_0_298 = 2446, F_0_390 = 3196, F_0_541 = 4433, F_0_765 = 6270, F_0_899 = 7373, F_1_175 = 9633;
+constexpr int F_1_501 = 12299, F_1_847 = 15137, F_1_961 = 16069, F_2_053 = 16819, F_2_562 = 20995, F_3_072 = 25172;
+
+__device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+
+// jfdctint.c, one 8-point pass in place
+template <bool FIRST>
+__device__ __forceinline__ void fdct8(int (&d)[8]) {
+  const int t0 = d[0] + d[7], t7 = d[0] - d[7], t1 = d[1] + d[6], t6 = d[1] - d[6];
+  const int t2 = d[2] + d[5], t5 = d[2] - d[5], t3 = d[3] + d[4], t4 = d[3] - d[4];
+  const int t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+  constexpr int N = FIRST ? CONST_BITS - PASS1_BITS : CONST_BITS + PASS1_BITS;
+  if (FIRST) { d[0] = (t10 + t11) << PASS1_BITS; d[4] = (t10 - t11) << PASS1_BITS; }
+  else { d[0] = descale(t10 + t11, PASS1_BITS); d[4] = descale(t10 - t11, PASS1_BITS); }
+  int z1 = (t12 + t13) * F_0_541;
+  d[2] = descale(z1 + t13 * F_0_765, N);
+  d[6] = descale(z1 - t12 * F_1_847, N);
+  z1 = t4 + t7;
+  int z2 = t5 + t6, z3 = t4 + t6, z4 = t5 + t7;
+  const int z5 = (z3 + z4) * F_1_175;
+  const int a4 = t4 * F_0_298, a5 = t5 * F_2_053, a6 = t6 * F_3_072, a7 = t7 * F_1_501;
+  z1 = -z1 * F_0_899; z2 = -z2 * F_2_562; z3 = -z3 * F_1_961 + z5; z4 = -z4 * F_0_390 + z5;
+  d[7] = descale(a4 + z1 + z3, N); d[5] = descale(a5 + z2 + z4, N);
+  d[3] = descale(a6 + z2 + z3, N); d[1] = descale(a7 + z1 + z4, N);
+}
+
+// jidctint.c, one 8-point pass in place
+template <bool FIRST>
+__device__ __forceinline__ void idct8(int (&c)[8]) {
+  int z1 = (c[2] + c[6]) * F_0_541;
+  const int e2 = z1 - c[6] * F_1_847, e3 = z1 + c[2] * F_0_765;
+  const int e0 = (c[0] + c[4]) << CONST_BITS, e1 = (c[0] - c[4]) << CONST_BITS;
+  const int t10 = e0 + e3, t13 = e0 - e3, t11 = e1 + e2, t12 = e1 - e2;
+  int t0 = c[7], t1 = c[5], t2 = c[3], t3 = c[1];
+  z1 = t0 + t3;
+  int z2 = t1 + t2, z3 = t0 + t2, z4 = t1 + t3;
+  const int z5 = (z3 + z4) * F_1_175;
+  t0 *= F_0_298; t1 *= F_2_053; t2 *= F_3_072; t3 *= F_1_501;
+  z1 = -z1 * F_0_899; z2 = -z2 * F_2_562; z3 = -z3 * F_1_961 + z5; z4 = -z4 * F_0_390 + z5;
+  t0 += z1 + z3; t1 += z2 + z4; t2 += z2 + z3; t3 += z1 + z4;
+  constexpr int N = FIRST ? CONST_BITS - PASS1_BITS : CONST_BITS + PASS1_BITS + 3;
+  c[0] = descale(t10 + t3, N); c[7] = descale(t10 - t3, N);
+  c[1] = descale(t11 + t2, N); c[6] = descale(t11 - t2, N);
+  c[2] = descale(t12 + t1, N); c[5] = descale(t12 - t1, N);
+  c[3] = descale(t13 + t0, N); c[4] = descale(t13 - t0, N);
+}
+
+__device__ __forceinline__ int to_u8(float v) { return min(max((int)rintf(v * 255.f), 0), 255); }
+
+// jccolor.c rgb_ycc_convert (16-bit fixed point).  comp: 0 Y, 1 Cb, 2 Cr
+__device__ __forceinline__ int ycc(int r, int g, int b, int comp) {
+  constexpr int HALF = 1 << 15, OFF = 128 << 16;
+  if (comp == 0) return (19595 * r + 38470 * g + 7471 * b + HALF) >> 16;
+  if (comp == 1) return (-11059 * r - 21709 * g + 32768 * b + OFF + HALF - 1) >> 16;
+  return (32768 * r - 27439 * g - 5329 * b + OFF + HALF - 1) >> 16;
+}
+
+constexpr int BLK_PER_WG = 32;   // 256 threads
+
+__global__ void __launch_bounds__(256) jpeg_blocks_kernel(const float* __restrict__ ldr, const int* __restrict__ quality,
+                                                          int B, int H, int W, int bgr, unsigned char* __restrict__ ws) {
+  __shared__ int tile[BLK_PER_WG][8][9];
+  const int lb = threadIdx.x >> 3, r = threadIdx.x & 7;
+  const int ybl = (H >> 3) * (W >> 3), cbl = (H >> 4) * (W >> 4), per_img = ybl + 2 * cbl;
+  const long long gb = (long long)blockIdx.x * BLK_PER_WG + lb;
+  const bool live = gb < (long long)B * per_img;
+  int d[8];
+  int b = 0, comp = 0, by = 0, bx = 0;
+  if (live) {
+    b = (int)(gb / per_img);
+    int k = (int)(gb % per_img);
+    if (k >= ybl) { comp = 1 + (k - ybl) / cbl; k = (k - ybl) % cbl; by = k / (W >> 4); bx = k % (W >> 4); }
+    else { by = k / (W >> 3); bx = k % (W >> 3); }
+    const int ri = bgr ? 2 : 0, bi = bgr ? 0 : 2;
+    if (comp == 0) {
+      const float* src = ldr + (((size_t)b * H + by * 8 + r) * W + bx * 8) * 3;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) d[c] = ycc(to_u8(src[c * 3 + ri]), to_u8(src[c * 3 + 1]), to_u8(src[c * 3 + bi]), 0) - 128;
+    } else {   // jcsample.c h2v2_downsample: (a + b + c + d + bias) >> 2, bias 1,2,1,2,... along the row
+      const float* s0 = ldr + (((size_t)b * H + by * 16 + 2 * r) * W + bx * 16) * 3;
+      const float* s1 = s0 + (size_t)W * 3;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        int s = 0;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float* p0 = s0 + (2 * c + e) * 3;
+          const float* p1 = s1 + (2 * c + e) * 3;
+          s += ycc(to_u8(p0[ri]), to_u8(p0[1]), to_u8(p0[bi]), comp) + ycc(to_u8(p1[ri]), to_u8(p1[1]), to_u8(p1[bi]), comp);
+        }
+        d[c] = ((s + 1 + (c & 1)) >> 2) - 128;
+      }
+    }
+    fdct8<true>(d);                      // row r
+#pragma unroll
+    for (int c = 0; c < 8; ++c) tile[lb][r][c] = d[c];
+  }
+  __syncthreads();
+  if (live) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) d[k] = tile[lb][k][r];    // column r
+    fdct8<false>(d);
+    // jcparam.c jpeg_quality_scaling + force_baseline; jcdctmgr.c: divisor q << 3, round half away from zero
+    const int q = min(max(quality[b], 1), 100);
+    const int scale = q < 50 ? 5000 / q : 200 - 2 * q;
+    const unsigned char* std_tbl = comp == 0 ? kStdLuma : kStdChroma;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int qv = min(max((std_tbl[k * 8 + r] * scale + 50) / 100, 1), 255);
+      const int div = qv << 3, a = abs(d[k]);
+      const int m = (a + (div >> 1)) / div;
+      d[k] = (d[k] < 0 ? -m : m) * qv;    // quantised, then dequantised (jidctint.c DEQUANTIZE)
+    }
+    idct8<true>(d);                      // column r
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tile[lb][k][r] = d[k];
+  }
+  __syncthreads();
+  if (live) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) d[c] = tile[lb][r][c];    // row r
+    idct8<false>(d);
+    unsigned int lo = 0, hi = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      lo |= (unsigned)min(max(d[c] + 128, 0), 255) << (8 * c);
+      hi |= (unsigned)min(max(d[c + 4] + 128, 0), 255) << (8 * c);
+    }
+    const size_t ypl = (size_t)H * W, cpl = ypl >> 2;
+    unsigned char* plane = ws + (size_t)b * (ypl + 2 * cpl) + (comp == 0 ? 0 : ypl + (comp - 1) * cpl);
+    const int pw = comp == 0 ? W : (W >> 1);
+    *reinterpret_cast<uint2*>(plane + (size_t)(by * 8 + r) * pw + bx * 8) = uint2{lo, hi};
+  }
+}
+
+// jdsample.c h2v2_fancy_upsample for one output pixel (y, x) of a decoded half-resolution plane [hc][wc]
+__device__ __forceinline__ int fancy(const unsigned char* __restrict__ p, int hc, int wc, int y, int x) {
+  const int cy = y >> 1, cx = x >> 1;
+  const int oy = (y & 1) ? min(cy + 1, hc - 1) : max(cy - 1, 0);     // the nearer neighbour row (edge: replicated)
+  const int nx = (x & 1) ? min(cx + 1, wc - 1) : max(cx - 1, 0);
+  const int cs = 3 * p[cy * wc + cx] + p[oy * wc + cx];
+  const int ns = 3 * p[cy * wc + nx] + p[oy * wc + nx];
+  return (3 * cs + ns + ((x & 1) ? 7 : 8)) >> 4;
+}
+
+__global__ void __launch_bounds__(256) jpeg_merge_kernel(const unsigned char* __restrict__ ws, int B, int H, int W, int bgr,
+                                                         float* __restrict__ out) {
+  const size_t ypl = (size_t)H * W, cpl = ypl >> 2, total = (size_t)B * ypl;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / ypl), rem = (int)(i % ypl), y = rem / W, x = rem % W;
+    const unsigned char* base = ws + (size_t)b * (ypl + 2 * cpl);
+    const int yy = base[rem];
+    const int cb = fancy(base + ypl, H >> 1, W >> 1, y, x) - 128;
+    const int cr = fancy(base + ypl + cpl, H >> 1, W >> 1, y, x) - 128;
+    constexpr int HALF = 1 << 15;   // jdcolor.c ycc_rgb_convert
+    const int rr = min(max(yy + ((91881 * cr + HALF) >> 16), 0), 255);
+    const int gg = min(max(yy + ((-22554 * cb - 46802 * cr + HALF) >> 16), 0), 255);
+    const int bb = min(max(yy + ((116130 * cb + HALF) >> 16), 0), 255);
+    float* o = out + i * 3;
+    o[bgr ? 2 : 0] = (float)rr / 255.f;
+    o[1] = (float)gg / 255.f;
+    o[bgr ? 0 : 2] = (float)bb / 255.f;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t hdrsky_jpeg_roundtrip_ws_bytes(int B, int H, int W) {
+  if (B <= 0 || H <= 0 || W <= 0) return 0;
+  return (size_t)B * H * W * 3 / 2;
+}
+
+int hdrsky_jpeg_roundtrip(const float* ldr, const int* quality, int B, int H, int W, int bgr, unsigned char* ws, float* out,
+                          void* stream) {
+  if (!ldr || !quality || !ws || !out || B <= 0 || H <= 0 || W <= 0) return HDRSKY_EINVAL;
+  if ((H & 15) || (W & 15)) return HDRSKY_EUNSUPPORTED;   // whole 16x16 MCUs only (libjpeg pads partial ones by replication)
+  if ((reinterpret_cast<uintptr_t>(ws) & 7) != 0) return HDRSKY_EINVAL;
+  const long long nblocks = (long long)B * ((H >> 3) * (W >> 3) + 2 * (H >> 4) * (W >> 4));
+  const long long g1 = (nblocks + BLK_PER_WG - 1) / BLK_PER_WG;
+  if (g1 > 0x7fffffffLL) return HDRSKY_EUNSUPPORTED;
+  hipLaunchKernelGGL(jpeg_blocks_kernel, dim3((unsigned)g1), dim3(256), 0, (hipStream_t)stream, ldr, quality, B, H, W, bgr ? 1 : 0, ws);
+  HDRSKY_CHECK_LAUNCH();
+  size_t g2 = ((size_t)B * H * W + 255) / 256;
+  if (g2 > 8192) g2 = 8192;
+  hipLaunchKernelGGL(jpeg_merge_kernel, dim3((unsigned)g2), dim3(256), 0, (hipStream_t)stream, ws, B, H, W, bgr ? 1 : 0, out);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+}  // extern "C"

@@ -760,6 +760,39 @@ def ldr_synth(hdr, t, sigma_s, sigma_c, noise_s, noise_c, crf):
     return hdr_t, ldr
 
 
+def batch_jpeg_qualities(B):
+    """train.py:89: sample i of a batch of B is re-compressed at quality int(round(i / (B - 1) * 10 + 90))."""
+    return [int(round(float(i) / float(B - 1) * 10.0 + 90.0)) if B > 1 else 90 for i in range(B)]
+
+
+_JPEG_Q = {}
+
+
+def jpeg_roundtrip(ldr, quality=None, order="bgr", out=None):
+    """train.py:86-92: tf.image.adjust_jpeg_quality on the 8-bit image of every sample (libjpeg encode + decode, bit
+    exact, entropy coding skipped).  ldr [B,H,W,3] float holding k/255; quality: per-sample list / int tensor (default:
+    the reference's 90..100 ramp over the batch); order: which channel is red ("rgb" or "bgr")."""
+    B, H, W, C = ldr.shape
+    _f32(ldr)
+    if C != 3 or order not in ("rgb", "bgr"):
+        raise ValueError("jpeg_roundtrip: [B,H,W,3] images, order 'rgb' or 'bgr'")
+    if quality is None:
+        key = (B, ldr.device)
+        if key not in _JPEG_Q:
+            _JPEG_Q[key] = torch.tensor(batch_jpeg_qualities(B), dtype=torch.int32, device=ldr.device)
+        quality = _JPEG_Q[key]
+    elif not torch.is_tensor(quality):
+        quality = torch.tensor([int(q) for q in quality], dtype=torch.int32, device=ldr.device)
+    if quality.dtype != torch.int32 or quality.numel() != B or not quality.is_cuda:
+        raise ValueError("jpeg_roundtrip: one int32 quality per sample on the device")
+    lib = L.load()
+    ws = torch.empty(int(lib.hdrsky_jpeg_roundtrip_ws_bytes(B, H, W)), dtype=torch.uint8, device=ldr.device)
+    out = torch.empty_like(ldr) if out is None else out
+    L.check(lib.hdrsky_jpeg_roundtrip(_p(ldr), _p(quality), B, H, W, 1 if order == "bgr" else 0, _p(ws), _p(out), _stream()),
+            "jpeg_roundtrip")
+    return out
+
+
 def vmf_target(elevation, azimuth, H, W, kappa=80.0):
     """train.py:42-52: von-Mises-Fisher pmf over the H*W sky bins for each sample's sun elevation (row units)."""
     B = elevation.numel()

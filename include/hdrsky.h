@@ -285,7 +285,7 @@ int hdrsky_adam(float* w, const float* g, float* m, float* v, size_t n, float lr
                 float gscale, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Device-side input synthesis (train.py:42-94: the host augmentation, minus the JPEG round trip)
+ * Device-side input synthesis (train.py:42-94: the host augmentation)
  * ---------------------------------------------------------------------------------------- */
 /* `_preprocessing` (train.py:54-94): hdr_t = relu(hdr*t + n_s*(sigma_s*hdr*t) + sigma_c*n_c) per sample b / channel c;
  * ldr = round_half_even(255 * CRF_b(clip(hdr_t, 0, 1))) / 255 with CRF_b a crf_len-sample LUT interpolated linearly
@@ -293,6 +293,15 @@ int hdrsky_adam(float* w, const float* g, float* m, float* v, size_t n, float lr
 int hdrsky_ldr_synth(const float* hdr, const float* t, const float* sigma_s, const float* sigma_c, const float* noise_s,
                      const float* noise_c, const float* crf, int crf_len, int B, int H, int W, float* hdr_t, float* ldr,
                      void* stream);
+/* The JPEG step of `_preprocessing` (train.py:86-92: `tf.image.adjust_jpeg_quality(img_u8, q)` per sample =
+ * libjpeg baseline encode - 4:2:0, slow-integer DCT, Annex-K tables scaled by quality q, force_baseline - and decode -
+ * slow-integer IDCT, fancy chroma upsampling; the lossless entropy coding is skipped).  Integer arithmetic, bit-exact
+ * against libjpeg.  ldr / out [B,H,W,3] float holding k/255 (channel 0 = R, or B when bgr != 0); quality [B] int32 on the
+ * device (train.py:89: round(i/(B-1)*10+90)); ws: hdrsky_jpeg_roundtrip_ws_bytes(B,H,W) bytes of device scratch, 8-byte
+ * aligned.  H and W must be multiples of 16 (else HDRSKY_EUNSUPPORTED).  out may alias ldr. */
+size_t hdrsky_jpeg_roundtrip_ws_bytes(int B, int H, int W);
+int hdrsky_jpeg_roundtrip(const float* ldr, const int* quality, int B, int H, int W, int bgr, unsigned char* ws, float* out,
+                          void* stream);
 /* `vMF` (train.py:42-52): out[b][j] = exp(kappa*<bin_j, sun(azimuth, elevation[b])>) normalised over the H*W sky bins. */
 int hdrsky_vmf_target(const float* elevation, float azimuth, int B, int H, int W, float kappa, float* out, void* stream);
 

@@ -11,6 +11,8 @@ golden vectors, so this oracle could not be checked against outputs of the
 reference itself.  What pins it instead (see DESIGN.md "Oracle"):
 two independent restatements of every risky op cross-checked in tests/,
 closed-form identities, and finite-difference gradient checks.
+Exception: oracle/jpeg.py (the JPEG step of the augmentation) restates libjpeg,
+not TensorFlow, and IS pinned - bit-exact against libjpeg-turbo itself.
 
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
 ``cpu_baseline`` leg may import this package - and only as the checker.

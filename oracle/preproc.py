@@ -1,6 +1,6 @@
 """Host augmentation of the reference restated in numpy (train.py:42-94, tf_utils.py:191-255).
-TEST INFRASTRUCTURE; PARITY UNPINNED (see oracle/__init__.py).  The JPEG round trip (train.py:86-91) is not restated:
-`tf.image.adjust_jpeg_quality` is a libjpeg encode/decode."""
+TEST INFRASTRUCTURE; PARITY UNPINNED (see oracle/__init__.py).  The JPEG round trip that follows (train.py:86-92,
+`tf.image.adjust_jpeg_quality` = a libjpeg encode/decode) is restated - and pinned to libjpeg - in oracle/jpeg.py."""
 import numpy as np
 
 F32 = np.float32
