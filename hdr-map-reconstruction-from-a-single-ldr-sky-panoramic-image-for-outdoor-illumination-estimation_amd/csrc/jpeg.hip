@@ -7,7 +7,7 @@
 //                        planes): float -> u8 -> YCbCr (jccolor.c) -> [h2v2 downsample, jcsample.c] -> level shift ->
 //                        jfdctint.c rows, LDS transpose, columns -> quantise (jcdctmgr.c) -> dequantise -> jidctint.c
 //                        columns, LDS transpose, rows -> range limit -> one 8-byte store per thread into the u8 planes
-//   jpeg_merge_kernel    one thread per output pixel: h2v2 fancy (triangle) upsampling of the decoded chroma planes
+//   jpeg_merge_kernel    one thread per four output pixels: h2v2 fancy (triangle) upsampling of the decoded chroma planes
 //                        (jdsample.c) + YCbCr -> RGB (jdcolor.c) -> float / 255
 // Algorithmic bytes per image: 12 B/pixel read + 1.5 B/pixel plane write, then 1.5 (+ cached neighbours) read + 12 written.
 #include <hip/hip_runtime.h>
@@ -102,23 +102,32 @@ __global__ void __launch_bounds__(256) jpeg_blocks_kernel(const float* __restric
     else { by = k / (W >> 3); bx = k % (W >> 3); }
     const int ri = bgr ? 2 : 0, bi = bgr ? 0 : 2;
     if (comp == 0) {
-      const float* src = ldr + (((size_t)b * H + by * 8 + r) * W + bx * 8) * 3;
+      const float4* src = reinterpret_cast<const float4*>(ldr + (((size_t)b * H + by * 8 + r) * W + bx * 8) * 3);
+      float v[24];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) d[c] = ycc(to_u8(src[c * 3 + ri]), to_u8(src[c * 3 + 1]), to_u8(src[c * 3 + bi]), 0) - 128;
+      for (int k = 0; k < 6; ++k) { const float4 t = src[k]; v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w; }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) d[c] = ycc(to_u8(v[c * 3 + ri]), to_u8(v[c * 3 + 1]), to_u8(v[c * 3 + bi]), 0) - 128;
     } else {   // jcsample.c h2v2_downsample: (a + b + c + d + bias) >> 2, bias 1,2,1,2,... along the row
-      const float* s0 = ldr + (((size_t)b * H + by * 16 + 2 * r) * W + bx * 16) * 3;
-      const float* s1 = s0 + (size_t)W * 3;
+      const float4* s0 = reinterpret_cast<const float4*>(ldr + (((size_t)b * H + by * 16 + 2 * r) * W + bx * 16) * 3);
+      const float4* s1 = s0 + (size_t)W * 3 / 4;
+      int acc[8];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        int s = 0;
+      for (int c = 0; c < 8; ++c) acc[c] = 0;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const float* p0 = s0 + (2 * c + e) * 3;
-          const float* p1 = s1 + (2 * c + e) * 3;
-          s += ycc(to_u8(p0[ri]), to_u8(p0[1]), to_u8(p0[bi]), comp) + ycc(to_u8(p1[ri]), to_u8(p1[1]), to_u8(p1[bi]), comp);
+      for (int row = 0; row < 2; ++row) {
+        const float4* sp = row ? s1 : s0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {      // 8 source pixels (24 floats) at a time
+          float v[24];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) { const float4 t = sp[h * 6 + k]; v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w; }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[h * 4 + e / 2] += ycc(to_u8(v[e * 3 + ri]), to_u8(v[e * 3 + 1]), to_u8(v[e * 3 + bi]), comp);
         }
-        d[c] = ((s + 1 + (c & 1)) >> 2) - 128;
       }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) d[c] = ((acc[c] + 1 + (c & 1)) >> 2) - 128;
     }
     fdct8<true>(d);                      // row r
 #pragma unroll
@@ -162,33 +171,47 @@ __global__ void __launch_bounds__(256) jpeg_blocks_kernel(const float* __restric
   }
 }
 
-// jdsample.c h2v2_fancy_upsample for one output pixel (y, x) of a decoded half-resolution plane [hc][wc]
-__device__ __forceinline__ int fancy(const unsigned char* __restrict__ p, int hc, int wc, int y, int x) {
-  const int cy = y >> 1, cx = x >> 1;
+// jdsample.c h2v2_fancy_upsample for output pixels x0..x0+3 of row y of a decoded half-resolution plane [hc][wc]
+__device__ __forceinline__ void fancy4(const unsigned char* __restrict__ p, int hc, int wc, int y, int x0, int (&o)[4]) {
+  const int cy = y >> 1, c0 = x0 >> 1;
   const int oy = (y & 1) ? min(cy + 1, hc - 1) : max(cy - 1, 0);     // the nearer neighbour row (edge: replicated)
-  const int nx = (x & 1) ? min(cx + 1, wc - 1) : max(cx - 1, 0);
-  const int cs = 3 * p[cy * wc + cx] + p[oy * wc + cx];
-  const int ns = 3 * p[cy * wc + nx] + p[oy * wc + nx];
-  return (3 * cs + ns + ((x & 1) ? 7 : 8)) >> 4;
+  const int cm = max(c0 - 1, 0), cp = min(c0 + 2, wc - 1);
+  const unsigned char* ra = p + (size_t)cy * wc;
+  const unsigned char* rb = p + (size_t)oy * wc;
+  const int sm = 3 * ra[cm] + rb[cm], s0 = 3 * ra[c0] + rb[c0], s1 = 3 * ra[c0 + 1] + rb[c0 + 1], sp = 3 * ra[cp] + rb[cp];
+  o[0] = (3 * s0 + sm + 8) >> 4;
+  o[1] = (3 * s0 + s1 + 7) >> 4;
+  o[2] = (3 * s1 + s0 + 8) >> 4;
+  o[3] = (3 * s1 + sp + 7) >> 4;
 }
 
 __global__ void __launch_bounds__(256) jpeg_merge_kernel(const unsigned char* __restrict__ ws, int B, int H, int W, int bgr,
                                                          float* __restrict__ out) {
-  const size_t ypl = (size_t)H * W, cpl = ypl >> 2, total = (size_t)B * ypl;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int b = (int)(i / ypl), rem = (int)(i % ypl), y = rem / W, x = rem % W;
+  const size_t ypl = (size_t)H * W, cpl = ypl >> 2, total4 = (size_t)B * ypl / 4;
+  for (size_t i4 = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i4 < total4; i4 += (size_t)gridDim.x * blockDim.x) {
+    const size_t i = i4 * 4;
+    const int b = (int)(i / ypl), rem = (int)(i % ypl), y = rem / W, x0 = rem % W;
     const unsigned char* base = ws + (size_t)b * (ypl + 2 * cpl);
-    const int yy = base[rem];
-    const int cb = fancy(base + ypl, H >> 1, W >> 1, y, x) - 128;
-    const int cr = fancy(base + ypl + cpl, H >> 1, W >> 1, y, x) - 128;
+    const unsigned int y4 = *reinterpret_cast<const unsigned int*>(base + rem);
+    int cb[4], cr[4];
+    fancy4(base + ypl, H >> 1, W >> 1, y, x0, cb);
+    fancy4(base + ypl + cpl, H >> 1, W >> 1, y, x0, cr);
+    float v[12];
     constexpr int HALF = 1 << 15;   // jdcolor.c ycc_rgb_convert
-    const int rr = min(max(yy + ((91881 * cr + HALF) >> 16), 0), 255);
-    const int gg = min(max(yy + ((-22554 * cb - 46802 * cr + HALF) >> 16), 0), 255);
-    const int bb = min(max(yy + ((116130 * cb + HALF) >> 16), 0), 255);
-    float* o = out + i * 3;
-    o[bgr ? 2 : 0] = (float)rr / 255.f;
-    o[1] = (float)gg / 255.f;
-    o[bgr ? 0 : 2] = (float)bb / 255.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int yy = (int)((y4 >> (8 * e)) & 255u), u = cb[e] - 128, w = cr[e] - 128;
+      const int rr = min(max(yy + ((91881 * w + HALF) >> 16), 0), 255);
+      const int gg = min(max(yy + ((-22554 * u - 46802 * w + HALF) >> 16), 0), 255);
+      const int bb = min(max(yy + ((116130 * u + HALF) >> 16), 0), 255);
+      v[e * 3 + (bgr ? 2 : 0)] = (float)rr / 255.f;
+      v[e * 3 + 1] = (float)gg / 255.f;
+      v[e * 3 + (bgr ? 0 : 2)] = (float)bb / 255.f;
+    }
+    float4* o = reinterpret_cast<float4*>(out + i * 3);
+    o[0] = float4{v[0], v[1], v[2], v[3]};
+    o[1] = float4{v[4], v[5], v[6], v[7]};
+    o[2] = float4{v[8], v[9], v[10], v[11]};
   }
 }
 
@@ -205,13 +228,15 @@ int hdrsky_jpeg_roundtrip(const float* ldr, const int* quality, int B, int H, in
                           void* stream) {
   if (!ldr || !quality || !ws || !out || B <= 0 || H <= 0 || W <= 0) return HDRSKY_EINVAL;
   if ((H & 15) || (W & 15)) return HDRSKY_EUNSUPPORTED;   // whole 16x16 MCUs only (libjpeg pads partial ones by replication)
-  if ((reinterpret_cast<uintptr_t>(ws) & 7) != 0) return HDRSKY_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(ws) & 7) != 0 || (reinterpret_cast<uintptr_t>(ldr) & 15) != 0 ||
+      (reinterpret_cast<uintptr_t>(out) & 15) != 0)
+    return HDRSKY_EINVAL;
   const long long nblocks = (long long)B * ((H >> 3) * (W >> 3) + 2 * (H >> 4) * (W >> 4));
   const long long g1 = (nblocks + BLK_PER_WG - 1) / BLK_PER_WG;
   if (g1 > 0x7fffffffLL) return HDRSKY_EUNSUPPORTED;
   hipLaunchKernelGGL(jpeg_blocks_kernel, dim3((unsigned)g1), dim3(256), 0, (hipStream_t)stream, ldr, quality, B, H, W, bgr ? 1 : 0, ws);
   HDRSKY_CHECK_LAUNCH();
-  size_t g2 = ((size_t)B * H * W + 255) / 256;
+  size_t g2 = ((size_t)B * H * W / 4 + 255) / 256;
   if (g2 > 8192) g2 = 8192;
   hipLaunchKernelGGL(jpeg_merge_kernel, dim3((unsigned)g2), dim3(256), 0, (hipStream_t)stream, ws, B, H, W, bgr ? 1 : 0, out);
   HDRSKY_CHECK_LAUNCH();
