@@ -3,7 +3,8 @@
 Flags keep the reference's names and defaults: --dir --lr(1e-4) --batchsize(32) --epochs(1000) --imheight(32)
 --imwidth(128) --sky --sun --dorf --vgg.  There is no Laval dataset / dorfCurves.txt / vgg16.npy in this environment:
 without --dir the loop trains on seeded synthetic batches (synth.make_batch); --vgg loads a real vgg16.npy when given.
-Per epoch it prints the reference's scalar names (train.py:480-489) and every 10th epoch saves SKY / SUN checkpoints
+Per epoch it prints the reference's scalar names (train.py:480-489), logs them to a TensorBoard event file
+(<logdir>/tensorboard/SKY/<timestamp>/train, tb_logging.py) and every 10th epoch saves SKY / SUN checkpoints
 with max_to_keep=5 (train.py:516-522).  Launch with torchrun for data parallelism (one process per GPU).
 """
 import argparse
@@ -17,6 +18,7 @@ from . import kernels as K
 from . import parallel as par
 from . import params as P
 from . import synth
+from . import tb_logging
 from .trainer import Trainer
 
 
@@ -33,6 +35,9 @@ def main(argv=None):
     ap.add_argument("--sun", type=str, default=os.path.join(cwd, "checkpoints/SUN"))
     ap.add_argument("--dorf", type=str, default=None)
     ap.add_argument("--vgg", type=str, default=None)
+    ap.add_argument("--logdir", type=str, default=cwd,
+                    help="TensorBoard scalars go to <logdir>/tensorboard/SKY/<timestamp>/train (tf_utils.py:282-292)")
+    ap.add_argument("--no-tensorboard", action="store_true")
     ap.add_argument("--steps-per-epoch", type=int, default=8, help="synthetic mode: steps per epoch")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch eagerly instead of replaying hipGraphs")
     ap.add_argument("--host-synth", action="store_true",
@@ -66,6 +71,10 @@ def main(argv=None):
     # The step is captured once (one hipGraph per segment, see trainer.py) on static input buffers that every batch is
     # copied into; losses are accumulated on the device and read back once per epoch.
     bufs, captured = None, False
+    tb_train = None
+    if rank == 0 and not args.no_tensorboard:
+        tb_train, tb_val, tb_dir = tb_logging.create_directories(args.logdir, "SKY")
+        tb_val.close()            # synthetic mode has no validation split (train.py:491-506 logs the same tags there)
     from .trainer import LOSS_SLOTS
     for epoch in range(epoch0 + 1, args.epochs + 1):
         t0 = time.perf_counter()
@@ -99,6 +108,10 @@ def main(argv=None):
             names = (("gen_total_loss", "total_gen_loss"), ("gen_l1_loss", "l1"), ("gen_perceptual_loss", "perceptual"),
                      ("gen_DoG_loss", "dog"), ("gen_adv_loss", "adv"), ("gen_kl_div", "kl"),
                      ("disc_total_loss", "total_disc_loss"), ("disc_generated_loss", "disc_generated"), ("disc_real_loss", "disc_real"))
+            if tb_train is not None:   # train.py:478-489, 513-514: one point per epoch
+                tb_train.scalars({n: acc[k] for n, k in names}, step=epoch)
+                tb_train.scalars({"g_out": float(out["gamma"].max()), "b_out": float(out["beta"].max())}, step=epoch)
+                tb_train.flush()
             print("[epoch %d] %s  g_out=%.4f b_out=%.4f  Spends : %.2f(s)" %
                   (epoch, "  ".join("%s=%.5g" % (n, acc[k]) for n, k in names), float(out["gamma"].max()),
                    float(out["beta"].max()), time.perf_counter() - t0))

@@ -231,9 +231,17 @@ def test_cli_train_and_inference_smoke(dev, tmp_path, capsys):
     """train CLI (2 synthetic epochs at batch 2) writes nothing before epoch 10; inference CLI turns a jpg into a .hdr."""
     train = pkg("train"); inference = pkg("inference"); hdr_io = pkg("hdr_io")
     sky, sun = str(tmp_path / "SKY"), str(tmp_path / "SUN")
-    train.main(["--batchsize", "2", "--epochs", "2", "--steps-per-epoch", "1", "--sky", sky, "--sun", sun])
+    train.main(["--batchsize", "2", "--epochs", "2", "--steps-per-epoch", "1", "--sky", sky, "--sun", sun,
+                "--logdir", str(tmp_path)])
     out = capsys.readouterr().out
     assert "gen_total_loss=" in out and "disc_real_loss=" in out
+    import glob
+    (evf,) = glob.glob(str(tmp_path / "tensorboard" / "SKY" / "*" / "train" / "events.out.tfevents.*"))
+    ev = pkg("tb_logging").read_events(evf)
+    tags = set().union(*[set(e["scalars"]) for e in ev])
+    assert {"gen_total_loss", "gen_l1_loss", "gen_perceptual_loss", "gen_DoG_loss", "gen_adv_loss", "gen_kl_div",
+            "disc_total_loss", "disc_generated_loss", "disc_real_loss", "g_out", "b_out"} == tags
+    assert sorted({e["step"] for e in ev[1:]}) == [1, 2]
     from PIL import Image
     indir, outdir = tmp_path / "in", tmp_path / "out"
     indir.mkdir()
