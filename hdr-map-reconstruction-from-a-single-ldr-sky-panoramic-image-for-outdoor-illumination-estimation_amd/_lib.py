@@ -69,6 +69,7 @@ SIGNATURES = {
     "hdrsky_ldr_synth": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, P]),
     "hdrsky_vmf_target": (c_int, [P, c_float, c_int, c_int, c_int, c_float, P, P]),
     "hdrsky_jpeg_roundtrip_ws_bytes": (c_size_t, [c_int] * 3),
+    "hdrsky_crc32c": (ctypes.c_uint32, [P, c_size_t, ctypes.c_uint32]),
     "hdrsky_jpeg_roundtrip": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, P]),
     "hdrsky_da_offsets": (c_int, [c_int, c_int, c_int, c_int, c_int, P]),
     "hdrsky_da_conv2d_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),

@@ -1,12 +1,16 @@
 """Checkpoint surface of the reference (train.py:208-220,510-522; tf_utils.py:298-320; inference.py:60-79) in a native
 format: same directories (`checkpoints/SKY`, `checkpoints/SUN`), same retention (`max_to_keep=5`), same cadence hook
 (`ckpt.epoch % 10 == 0`), keys named after the reference's object-graph paths.  One `ckpt-<N>.npz` per save plus a
-`checkpoint` text file naming the latest (the TF tensor-bundle format itself is SURVEY.md section 8f "next")."""
+`checkpoint` text file naming the latest.  Interchange with the reference's own files:
+a directory holding TF tensor-bundle checkpoints (`ckpt-N.index` + `ckpt-N.data-*`, written by `tf.train.Checkpoint`) is
+restored through tf_bundle.py, and `export_tf_bundle` writes one."""
 import glob
 import os
 import re
 
 import numpy as np
+
+_NUM = re.compile(r"ckpt-(\d+)\.(?:npz|index)$")
 
 
 class CheckpointManager:
@@ -20,7 +24,9 @@ class CheckpointManager:
 
     @property
     def latest_checkpoint(self):
-        files = self._all()
+        """Newest `ckpt-N.npz` (native) or `ckpt-N.index` (TF tensor bundle) of the directory."""
+        files = self._all() + glob.glob(os.path.join(self.directory, "ckpt-*.index"))
+        files.sort(key=lambda f: (int(_NUM.search(f).group(1)), f.endswith(".npz")))
         return files[-1] if files else None
 
     def save(self, tensors, epoch):
@@ -38,6 +44,8 @@ class CheckpointManager:
         path = path or self.latest_checkpoint
         if path is None:
             return None, 0
+        if path.endswith(".index"):
+            return import_tf_bundle(path[:-len(".index")])
         z = np.load(path)
         return {k.replace("|", "/"): z[k] for k in z.files if k != "epoch"}, int(z["epoch"])
 
@@ -70,3 +78,36 @@ def load_into(params, tensors, prefix):
             params[k] = np.asarray(tensors[key], np.float32)
             n += 1
     return n
+
+
+# ---- TF object-graph paths <-> native keys -------------------------------------------------------------------
+# The reference's resLayer keeps its blocks in a python list attribute `sequence` (generator.py:41-44), which the
+# object graph spells `res/sequence/<i>/...`; everything else already uses the attribute path.
+def tf_path(key):
+    return re.sub(r"^(gen_model/res)/(\d+)/", r"\1/sequence/\2/", key)
+
+
+def native_path(key):
+    return re.sub(r"^(gen_model/res)/sequence/(\d+)/", r"\1/\2/", key)
+
+
+def import_tf_bundle(prefix):
+    """(tensors, epoch) from a TF tensor-bundle checkpoint prefix (`.../ckpt-3`): variables keyed like the native format
+    (`gen_model/...`, `dis_model/...`, `lin/...`); optimizer slots are not imported (RMSprop restarts its averages)."""
+    from . import tf_bundle
+    tensors = {native_path(k): v for k, v in tf_bundle.variable_tensors(tf_bundle.read_bundle(prefix)).items()}
+    epoch = int(np.asarray(tensors.pop("epoch", 0)).reshape(-1)[0])
+    tensors.pop("save_counter", None)
+    return tensors, epoch
+
+
+def export_tf_bundle(prefix, tensors, epoch):
+    """Writes the model variables of `tensors` (native keys; the flat optimizer buffers are skipped) as a TF tensor
+    bundle with object-graph style keys, plus `epoch` / `save_counter` like tf.train.Checkpoint."""
+    from . import tf_bundle
+    out = {tf_path(k): np.asarray(v) for k, v in tensors.items() if not k.endswith("_optimizer/rms") and not k.startswith("optimizer/")}
+    out["epoch"] = np.asarray(epoch, np.int64)
+    m = re.search(r"ckpt-(\d+)$", prefix)
+    out["save_counter"] = np.asarray(int(m.group(1)) if m else 1, np.int64)
+    tf_bundle.write_bundle(prefix, tf_bundle.to_variable_keys(out))
+    return prefix

@@ -305,6 +305,10 @@ int hdrsky_jpeg_roundtrip(const float* ldr, const int* quality, int B, int H, in
 /* `vMF` (train.py:42-52): out[b][j] = exp(kappa*<bin_j, sun(azimuth, elevation[b])>) normalised over the H*W sky bins. */
 int hdrsky_vmf_target(const float* elevation, float azimuth, int B, int H, int W, float kappa, float* out, void* stream);
 
+/* [host] CRC-32C (Castagnoli) of n HOST bytes continuing from `crc` (0 to start): the checksum of the TFRecord framing
+ * (TensorBoard event files, tf_utils.py:282-292) and of the TF tensor-bundle checkpoint format (train.py:208-220). */
+unsigned int hdrsky_crc32c(const void* data, size_t n, unsigned int crc);
+
 /* ------------------------------------------------------------------------------------------
  * Distortion-aware panoramic convolution (distortion_aware_ops.py)
  * ---------------------------------------------------------------------------------------- */
