@@ -22,7 +22,8 @@ def init_from_env(backend=None, device=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        # HDRSKY_DIST_BACKEND=gloo: rehearsal of the multi-process path with several ranks on ONE card (RCCL refuses that)
+        backend = backend or os.environ.get("HDRSKY_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if backend == "nccl" and device is not None:
             kw["device_id"] = device

@@ -106,3 +106,28 @@ def test_two_replicas_one_card_equal_summed_gradient_step(dev, tmp_path):
     assert rel(r0["gms"], tr.gs.ms.cpu()) < 1e-3
     assert rel(r0["ds"][nt:], tr.ds.flat.cpu()[nt:]) < 1e-5  # BN moving statistics of replica 0
     assert rel(r0["gs"][ng:], tr.gs.flat.cpu()[ng:]) < 1e-5
+
+
+def test_train_cli_two_ranks_one_card(dev, tmp_path):
+    """`python -m <pkg>.train` as torchrun would start it, two ranks (both on the one card, gloo): ten one-step epochs,
+    rank 0 writes the SKY / SUN checkpoints, nobody deadlocks, and the weights moved."""
+    import subprocess
+    import numpy as np
+    port = _free_port()
+    sky, sun = str(tmp_path / "SKY"), str(tmp_path / "SUN")
+    procs = []
+    for rank in (0, 1):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HDRSKY_DIST_BACKEND="gloo", PYTHONPATH=ROOT)
+        procs.append(subprocess.Popen([sys.executable, "-m", PKG + ".train", "--batchsize", "2", "--epochs", "10",
+                                       "--steps-per-epoch", "1", "--sky", sky, "--sun", sun, "--no-tensorboard"],
+                                      env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=420)[0] for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], outs
+    assert "[epoch 10]" in outs[0] and "Saved SKY checkpoint for epoch 10" in outs[0] and "[epoch" not in outs[1]
+    ckpt = importlib.import_module(PKG + ".checkpoint")
+    tensors, epoch = ckpt.CheckpointManager(sky).restore()
+    P = importlib.import_module(PKG + ".params")
+    w0 = P.init_params(P.generator_spec(H, W), 0)["conv1_d.w"]
+    assert epoch == 10 and np.isfinite(tensors["gen_model/conv1_d/w"]).all()
+    assert np.abs(tensors["gen_model/conv1_d/w"] - w0).max() > 1e-4
