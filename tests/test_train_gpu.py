@@ -164,6 +164,32 @@ def test_train_step_gradients_match_oracle(dev):
         assert_close(tr.ds.w["dis." + k], v, 1e-4, "dis " + k)
 
 
+@pytest.mark.parametrize("B", [1, 3])
+def test_train_step_edge_batch_sizes(dev, B):
+    """Batch 1 (BatchNorm over one sample, the reduce_max over a single map) and an odd batch (ragged against every
+    power-of-two split inside the kernels): losses and the gradient direction against the oracle."""
+    tr, (gen, sun, dis, vgg), batch = _mk(dev, B)
+    tt = lambda dd: {k: torch.from_numpy(v) for k, v in dd.items()}
+    ldr, hdr, gt = (torch.from_numpy(batch[k]) for k in ("ldr", "hdr_t", "sunpose_gt"))
+    losses, gg, gs, gd, sg, sd, outs = ostep.train_step_grads(tt(gen), tt(sun), tt(dis), tt(vgg), ldr, hdr, gt)
+    out = tr.step(ldr.to(dev), hdr.to(dev), gt.to(dev), update=False)
+    got = tr.loss_dict()
+    for k, rk in (("kl", "kl"), ("perceptual", "perceptual"), ("dog", "dog"), ("l1", "l1"), ("adv", "adv"),
+                  ("disc_generated", "generated"), ("disc_real", "real")):
+        assert abs(got[k] - losses[rk]) <= 2e-3 * abs(losses[rk]) + 1e-6, (B, k, got[k], losses[rk])
+    assert_close(out["y_final_gamma"], outs["y_final_gamma"], 1e-3, "y_final_gamma")
+    dot = na = nb = 0.0
+    for prefix, ref in (("gen.", gg), ("sun.", gs)):
+        for k, v in ref.items():
+            g = tr.gs.g[prefix + k].cpu().double()
+            dot += float((g * v.double()).sum()); na += float((g * g).sum()); nb += float((v.double() ** 2).sum())
+    cos = dot / (na * nb) ** 0.5
+    print("B=%d: gradient cosine %.6f, norm ratio %.5f" % (B, cos, (na / nb) ** 0.5))
+    assert cos > 0.999 and abs((na / nb) ** 0.5 - 1.0) < 1e-2, (B, cos, (na / nb) ** 0.5)
+    tr.apply_gradients()
+    assert torch.isfinite(tr.gs.flat).all() and torch.isfinite(tr.ds.flat).all()
+
+
 def test_train_step_updates_weights_like_rmsprop(dev):
     tr, _, batch = _mk(dev, 2)
     ldr, hdr, gt = (torch.from_numpy(batch[k]).to(dev) for k in ("ldr", "hdr_t", "sunpose_gt"))
