@@ -39,6 +39,8 @@ def main(argv=None):
                     help="TensorBoard scalars go to <logdir>/tensorboard/SKY/<timestamp>/train (tf_utils.py:282-292)")
     ap.add_argument("--no-tensorboard", action="store_true")
     ap.add_argument("--steps-per-epoch", type=int, default=8, help="synthetic mode: steps per epoch")
+    ap.add_argument("--val-steps", type=int, default=0,
+                    help="synthetic mode: validation batches per epoch through test_step (train.py:491-506); 0 = none")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch eagerly instead of replaying hipGraphs")
     ap.add_argument("--host-synth", action="store_true",
                     help="build the synthetic batches with numpy on the host (40 ms per batch of 32) instead of on the GPU")
@@ -71,10 +73,9 @@ def main(argv=None):
     # The step is captured once (one hipGraph per segment, see trainer.py) on static input buffers that every batch is
     # copied into; losses are accumulated on the device and read back once per epoch.
     bufs, captured = None, False
-    tb_train = None
+    tb_train = tb_val = None
     if rank == 0 and not args.no_tensorboard:
         tb_train, tb_val, tb_dir = tb_logging.create_directories(args.logdir, "SKY")
-        tb_val.close()            # synthetic mode has no validation split (train.py:491-506 logs the same tags there)
     from .trainer import LOSS_SLOTS
     for epoch in range(epoch0 + 1, args.epochs + 1):
         t0 = time.perf_counter()
@@ -118,6 +119,20 @@ def main(argv=None):
             if epoch % 10 == 0:
                 print("Saved SKY checkpoint for epoch {}: {}".format(epoch, sky_mgr.save(ckpt.sky_tensors(tr), epoch)))
                 print("Saved SUN checkpoint for epoch {}: {}".format(epoch, sun_mgr.save(ckpt.sun_tensors(tr), epoch)))
+        if args.val_steps > 0:        # train.py:491-506: test_step over the validation split, same tags, `val` writer
+            vacc = torch.zeros(len(LOSS_SLOTS), dtype=torch.float32, device=dev)
+            for it in range(args.val_steps):
+                vb = synth.make_batch_device(args.batchsize, h, w, seed=(7_000_003 + epoch * 1009 + it) * world + rank, device=dev)
+                tr.test_step(vb["ldr"], vb["hdr_t"], vb["sunpose_gt"])
+                vacc += tr.losses
+            vv = dict(zip(LOSS_SLOTS, (vacc / args.val_steps).tolist()))
+            vv["total_gen_loss"] = vv["kl"] + 1000.0 * vv["dog"] + vv["adv"] + 10.0 * vv["l1"] + 0.01 * vv["perceptual"]
+            vv["total_disc_loss"] = 0.5 * (vv["disc_generated"] + vv["disc_real"])
+            if rank == 0:
+                if tb_val is not None:
+                    tb_val.scalars({n: vv[k] for n, k in names}, step=epoch)
+                    tb_val.flush()
+                print("[epoch %d][val] %s" % (epoch, "  ".join("%s=%.5g" % (n, vv[k]) for n, k in names)))
 
 
 if __name__ == "__main__":

@@ -110,6 +110,7 @@ class Trainer:
         # four hardware queues with each other or with RCCL's stream (measured: 4.6 instead of 4.1 ms per step).
         self._streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
         self._graphs, self._gscale = None, 1.0 / world_size
+        self._bn_training = True            # False only inside test_step (sun-radiance head BatchNorm in inference mode)
         self.losses = torch.zeros(len(LOSS_SLOTS), dtype=torch.float32, device=self.device)
         self._wjobs = {}
         self._build_layers()
@@ -326,7 +327,7 @@ class Trainer:
     def _sunrad_forward(self, ldr, cams, t, S):
         w = self.gs.w
         plz = K.plz_build(ldr, *cams)
-        R = self._down_stack("gen.sun.", w, plz, training=True)
+        R = self._down_stack("gen.sun.", w, plz, training=self._bn_training)
         xf = R["xf_out"]
         part = K.dense_heads(R["d4"]["raw"], xf.scale, xf.shift, 0.3, w["gen.sun.gamma.kernel"], w["gen.sun.beta.kernel"])
         rad_lin, rad_gamma, gamma, beta = K.sun_rad(t["cmf"], t["gmax"], part, w["gen.sun.gamma.bias"], w["gen.sun.beta.bias"],
@@ -689,6 +690,24 @@ class Trainer:
         Returns the dict generator_in_step returns (train.py:349) - losses are in self.losses (device)."""
         self._bind(ldr, hdr_t, sunpose_gt)
         self._execute([n for n, *_ in self._segs if update or n not in self.APPLY])
+        return self._outputs()
+
+    def test_step(self, ldr, hdr_t, sunpose_gt):
+        """`test_step` (train.py:417-442): the validation pass - the training graph (ground-truth-bin Grad-CAM pick) with
+        every BatchNorm in inference mode, all loss terms (generator_in_step / discriminator_in_step with
+        training=False) and no update.  Returns the output dict of `step`; the loss terms are in self.losses /
+        loss_dict().  Issued eagerly (not part of the captured step); gradients buffers are left zeroed / partial."""
+        self._bn_training = False
+        try:
+            self._bind(ldr, hdr_t, sunpose_gt)
+            self._execute(["fwd_sun", "fwd_enc", "vgg_target", "fwd_blend", "loss_main", "loss_vgg", "loss_vgg_b", "loss_adv"])
+            T, cvo = self._T, self.conv["dis.out"]
+            for other, target, slot in ((hdr_t, 1.0, 6), (T["y_lin"], 0.0, 5)):        # train.py:351-369, training=False
+                R = self._down_stack("dis.", self.ds.w, K.concat2(ldr, other), training=False)
+                logits, _ = cvo.fwd(R["d4"]["raw"], R["xf_out"], self.compute)
+                K.mse(logits, target, 1.0, 0.5, self.losses[slot:slot + 1])
+        finally:
+            self._bn_training = True
         return self._outputs()
 
     def apply_gradients(self, gscale=None):

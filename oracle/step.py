@@ -141,6 +141,19 @@ def train_step_grads(gen, sun, dis, vgg, ldr, hdr_t, sunpose_gt):
     return losses, grads_gen, grads_sun, grads_dis, stats_gen, stats_dis, outs
 
 
+def test_step(gen, sun, dis, vgg, ldr, hdr_t, sunpose_gt):
+    """train.py:417-442 (+ the test branches of generator_in_step / discriminator_in_step): the validation step - the
+    training graph with the ground-truth-bin Grad-CAM pick, every BatchNorm in inference mode, no tape, no update.
+    Returns (losses, outputs)."""
+    req = {k: v.detach().clone().requires_grad_(True) for k, v in sun.items()}     # Grad-CAM differentiates the cmf
+    out = generator_graph(gen, req, ldr, y_index=sunpose_gt.argmax(dim=1), training=False)
+    gl = generator_losses(out, dis, vgg, ldr, hdr_t, sunpose_gt)
+    y_final_lin = T.hdr_log_decompression(out["y_final_gamma"])
+    dl = discriminator_losses(dis, ldr, hdr_t, y_final_lin, training=False)
+    losses = {k: float(v.detach()) for k, v in {**gl, **dl}.items()}
+    return losses, {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}
+
+
 def sun_train_step_grads(sun, ldr, sunpose_gt, dog_weight=1.0):
     """train_sun.py:220-264 up to (not including) apply_gradients: sun-pose pre-training.
     loss = KLDivergence(gt, cmf) + sum_4 mean|DoG_i(cmf image) - DoG_i(gt image)|; the Grad-CAM maps are returned

@@ -190,6 +190,33 @@ def test_train_step_edge_batch_sizes(dev, B):
     assert torch.isfinite(tr.gs.flat).all() and torch.isfinite(tr.ds.flat).all()
 
 
+def test_validation_step_matches_oracle(dev):
+    """Trainer.test_step = train.py:417-442: BatchNorm in inference mode everywhere, all nine loss terms, no update and
+    no change of the moving statistics; a captured training step keeps working afterwards."""
+    tr, (gen, sun, dis, vgg), batch = _mk(dev, 2)
+    tt = lambda dd: {k: torch.from_numpy(v) for k, v in dd.items()}
+    ldr, hdr, gt = (torch.from_numpy(batch[k]) for k in ("ldr", "hdr_t", "sunpose_gt"))
+    # make the moving statistics differ from their initial values so that inference-mode BN is really exercised
+    tr.step(ldr.to(dev), hdr.to(dev), gt.to(dev), update=True)
+    torch.cuda.synchronize()
+    gen2 = {k: tr.gs.w["gen." + k].cpu() for k in gen}; sun2 = {k: tr.gs.w["sun." + k].cpu() for k in sun}
+    dis2 = {k: tr.ds.w["dis." + k].cpu() for k in dis}
+    losses, outs = ostep.test_step(gen2, sun2, dis2, tt(vgg), ldr, hdr, gt)
+    g0, d0 = tr.gs.flat.clone(), tr.ds.flat.clone()
+    out = tr.test_step(ldr.to(dev), hdr.to(dev), gt.to(dev))
+    got = tr.loss_dict()
+    for k, rk in (("kl", "kl"), ("perceptual", "perceptual"), ("dog", "dog"), ("l1", "l1"), ("adv", "adv"),
+                  ("disc_generated", "generated"), ("disc_real", "real"), ("total_gen_loss", "total_gen_loss"),
+                  ("total_disc_loss", "total_disc_loss")):
+        assert abs(got[k] - losses[rk]) <= 2e-3 * abs(losses[rk]) + 1e-6, (k, got[k], losses[rk])
+    assert_close(out["y_final_gamma"], outs["y_final_gamma"], 1e-3, "y_final_gamma (validation)")
+    assert_close(out["gamma"], outs["gamma"], 1e-3, "gamma"); assert_close(out["beta"], outs["beta"], 1e-3, "beta")
+    assert torch.equal(tr.gs.flat, g0) and torch.equal(tr.ds.flat, d0)          # nothing trained, no moving-average update
+    # training-mode BN would give a different sun radiance (the batch statistics of 2 samples): the flag matters
+    out_t = tr.step(ldr.to(dev), hdr.to(dev), gt.to(dev), update=False)
+    assert float((out_t["gamma"] - out["gamma"]).abs().max()) > 1e-6
+
+
 def test_train_step_updates_weights_like_rmsprop(dev):
     tr, _, batch = _mk(dev, 2)
     ldr, hdr, gt = (torch.from_numpy(batch[k]).to(dev) for k in ("ldr", "hdr_t", "sunpose_gt"))
@@ -258,9 +285,9 @@ def test_cli_train_and_inference_smoke(dev, tmp_path, capsys):
     train = pkg("train"); inference = pkg("inference"); hdr_io = pkg("hdr_io")
     sky, sun = str(tmp_path / "SKY"), str(tmp_path / "SUN")
     train.main(["--batchsize", "2", "--epochs", "2", "--steps-per-epoch", "1", "--sky", sky, "--sun", sun,
-                "--logdir", str(tmp_path)])
+                "--logdir", str(tmp_path), "--val-steps", "1"])
     out = capsys.readouterr().out
-    assert "gen_total_loss=" in out and "disc_real_loss=" in out
+    assert "gen_total_loss=" in out and "disc_real_loss=" in out and "[epoch 2][val] gen_total_loss=" in out
     import glob
     (evf,) = glob.glob(str(tmp_path / "tensorboard" / "SKY" / "*" / "train" / "events.out.tfevents.*"))
     ev = pkg("tb_logging").read_events(evf)
@@ -268,6 +295,9 @@ def test_cli_train_and_inference_smoke(dev, tmp_path, capsys):
     assert {"gen_total_loss", "gen_l1_loss", "gen_perceptual_loss", "gen_DoG_loss", "gen_adv_loss", "gen_kl_div",
             "disc_total_loss", "disc_generated_loss", "disc_real_loss", "g_out", "b_out"} == tags
     assert sorted({e["step"] for e in ev[1:]}) == [1, 2]
+    (evv,) = glob.glob(str(tmp_path / "tensorboard" / "SKY" / "*" / "val" / "events.out.tfevents.*"))
+    val = pkg("tb_logging").read_events(evv)
+    assert [e["step"] for e in val[1:]] == [1, 2] and "gen_kl_div" in val[1]["scalars"]
     from PIL import Image
     indir, outdir = tmp_path / "in", tmp_path / "out"
     indir.mkdir()
