@@ -7,6 +7,7 @@
 // in x applied once to the coordinate and once to the corner indices, weights from the UNWRAPPED corner indices),
 // and feeds it to v_mfma_f32_16x16x32_bf16 against the packed filter (row = tap*C + c, the HWIO order).
 #include <cmath>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -20,6 +21,7 @@ struct DaArgs {
   const float* offs;  // [h][k*k][2] (y, x), identical for every column
   float* y;
   int B, H, W, Cin, Cout, Npad, ksize, k2, pad, in_h, in_w, cin32, nblocks, tiles_x;
+  int tab_off, use_tab;     // LDS byte offset of the per-(pixel, tap) sample table behind the A tiles; 0: computed per item
 };
 
 // one bilinear sample position of the reference (distortion_aware_ops.py:62-106), all in float32
@@ -56,10 +58,11 @@ __device__ __forceinline__ Tap4 da_tap(float base_y, float base_x, float off_y, 
 // workgroup, so the gather is not repeated per filter block).  Per filter tap: every thread gathers the four corner
 // pixels of its (pixel, 8-channel) items into REGISTERS one tap ahead - the loads of tap t+1 are in flight while the
 // MFMAs of tap t run - then blends, rounds to bf16 and writes the tap's A tile into the other LDS buffer.
-template <bool PRECISE, int NWV>
+template <bool PRECISE, int NWV, int IMAX>
 __global__ void __launch_bounds__(NWV * 64) da_conv_kernel(const DaArgs a) {
   constexpr int TM = 64, NT = NWV * 64;
-  constexpr int IMAX = PRECISE ? 4 : 4;                       // (pixel, chunk) items per thread and tap: Cin <= 8*IMAX*NT/TM
+  constexpr int MAXROWS = 5;                                   // image rows a 64-pixel tile can span (W >= 16)
+  // IMAX: (pixel, chunk) items per thread and tap: Cin <= 8*IMAX*NT/TM
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, lr = lane & 15;
   const int nq = a.Cin >> 3;
@@ -81,68 +84,125 @@ __global__ void __launch_bounds__(NWV * 64) da_conv_kernel(const DaArgs a) {
   const uint4* wll = PRECISE ? a.wlo + (size_t)kq * a.Npad + n0 + wave * 16 + lr : nullptr;
   const float* xb = a.x + (size_t)b * npix * a.Cin;
 
-  float cr[IMAX][4][8];     // corner pixels of this thread's items for the tap in flight
-  float cw[IMAX][4];        // their bilinear weights (0 for corners in the zero padding / pixels past the image)
+  // The sampling offsets of the image rows this tile covers (k*k pairs per row), staged once: the per-tap gather then
+  // starts from an LDS read instead of a dependent global load in front of the corner loads.
+  __shared__ float s_off[MAXROWS * 2 * 128];
+  const int row0 = p0 / a.W;
+  {
+    const int nrow = min(p0 + TM - 1, npix - 1) / a.W - row0 + 1;
+    for (int i = tid; i < nrow * a.k2 * 2; i += NT) s_off[i] = a.offs[(size_t)row0 * a.k2 * 2 + i];
+    __syncthreads();
+  }
 
-  for (int t = -1; t < a.k2; ++t) {
-    // ---- blend + store tap t (registers -> LDS buffer t&1) ------------------------------------------------------
-    if (t >= 0) {
-      uint4* buf = sA + (t & 1) * buf_units;
+  constexpr int CBMAX = IMAX * NWV / 4;                 // 32-channel k-steps per tap (Cin <= 8 * IMAX * NWV)
+  constexpr bool BPF = CBMAX <= 4;                      // filter fragments prefetched a tap ahead where registers allow
+  uint4 bch[BPF ? CBMAX : 1], bcl[BPF && PRECISE ? CBMAX : 1], bnh[BPF ? CBMAX : 1], bnl[BPF && PRECISE ? CBMAX : 1];
 #pragma unroll
-      for (int it = 0; it < IMAX; ++it) {
-        const int i = it * NT + tid;
-        if (i < nitems) {
-          const int m = i / nq, q = i % nq;
-          float v[8];
+  for (int cb = 0; cb < (BPF ? CBMAX : 1); ++cb) { bch[cb] = bnh[cb] = uint4{0, 0, 0, 0}; }
 #pragma unroll
-          for (int j = 0; j < 8; ++j)
-            v[j] = cw[it][0] * cr[it][0][j] + cw[it][1] * cr[it][1][j] + cw[it][2] * cr[it][2][j] + cw[it][3] * cr[it][3][j];
-          uint4 h8, l8;
-          pack8<PRECISE>(v, h8, l8);
-          buf[q * plane + m] = h8;
-          if (PRECISE) buf[nq * plane + q * plane + m] = l8;
+  for (int cb = 0; cb < (BPF && PRECISE ? CBMAX : 1); ++cb) { bcl[cb] = bnl[cb] = uint4{0, 0, 0, 0}; }
+  // Per-(pixel, tap) sample table, built once per workgroup when it fits into LDS: the four corner offsets (floats from
+  // the sample's base, 0 for corners in the zero padding) and bilinear weights.  The 8-channel items of one pixel share
+  // it, so the coordinate arithmetic (float32, reference order: da_tap) is done once per pixel and tap instead of once
+  // per item and tap - the per-tap rounds of this kernel are instruction-issue bound.
+  int4* tabO = reinterpret_cast<int4*>(smem + a.tab_off);
+  float4* tabW = reinterpret_cast<float4*>(smem + a.tab_off + TM * a.k2 * 16);
+  auto sample = [&](int m, int tn, int (&o)[4], float (&w)[4]) {
+    const int pix = p0 + m;
+    const bool live = pix < npix;
+    const int oy = live ? pix / a.W : row0, ox = live ? pix % a.W : 0;
+    const float off_y = s_off[((oy - row0) * a.k2 + tn) * 2], off_x = s_off[((oy - row0) * a.k2 + tn) * 2 + 1];
+    // base grid = VALID patches of the padded meshgrid (:152-168): padded coordinate of tap (ty,tx) at (oy,ox)
+    const Tap4 s = da_tap((float)(oy + tn / a.ksize), (float)(ox + tn % a.ksize), off_y, off_x, a.in_h, a.in_w);
+    const int ys[4] = {s.y0, s.y0, s.y1, s.y1}, xs[4] = {s.x0, s.x1, s.x0, s.x1};
+    const float ws[4] = {s.w0, s.w1, s.w2, s.w3};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int yy = ys[k] - a.pad, xx = xs[k] - a.pad;      // back to un-padded coordinates; border = zeros
+      const bool in = live && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+      o[k] = in ? (yy * a.W + xx) * a.Cin : 0;
+      w[k] = in ? ws[k] : 0.f;
+    }
+  };
+  if (a.use_tab) {
+    for (int e = tid; e < TM * a.k2; e += NT) {
+      int o[4]; float w[4];
+      sample(e % TM, e / TM, o, w);
+      tabO[e] = int4{o[0], o[1], o[2], o[3]};
+      tabW[e] = float4{w[0], w[1], w[2], w[3]};
+    }
+    __syncthreads();
+  }
+
+  float cr0[IMAX][4][8], cw0[IMAX][4];      // corner pixels of this thread's items for the tap in flight / their weights
+
+  auto gather = [&](int tn, float (&cr)[IMAX][4][8], float (&cw)[IMAX][4]) {
+#pragma unroll
+    for (int it = 0; it < IMAX; ++it) {
+      const int i = it * NT + tid;
+      if (i < nitems) {
+        const int m = i / nq, q = i % nq;
+        int o[4]; float w[4];
+        if (a.use_tab) {
+          const int4 to = tabO[tn * TM + m];
+          const float4 tw = tabW[tn * TM + m];
+          o[0] = to.x; o[1] = to.y; o[2] = to.z; o[3] = to.w;
+          w[0] = tw.x; w[1] = tw.y; w[2] = tw.z; w[3] = tw.w;
+        } else {
+          sample(m, tn, o, w);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float* pp = xb + o[k] + q * 8;
+          const float4 lo = *reinterpret_cast<const float4*>(pp), hi = *reinterpret_cast<const float4*>(pp + 4);
+          cr[it][k][0] = lo.x; cr[it][k][1] = lo.y; cr[it][k][2] = lo.z; cr[it][k][3] = lo.w;
+          cr[it][k][4] = hi.x; cr[it][k][5] = hi.y; cr[it][k][6] = hi.z; cr[it][k][7] = hi.w;
+          cw[it][k] = w[k];
         }
       }
-      __syncthreads();   // tile t staged; also: every wave is past the MFMAs of tile t-1, so buffer (t+1)&1 is free
     }
-    // ---- issue the gather of tap t+1 ------------------------------------------------------------------------------
-    if (t + 1 < a.k2) {
-      const int tn = t + 1;
-      const int ty = tn / a.ksize, tx_ = tn % a.ksize;
+  };
+  auto load_b = [&](int tn) {   // this wave's filter fragments of tap tn (registers, one tap ahead)
 #pragma unroll
-      for (int it = 0; it < IMAX; ++it) {
-        const int i = it * NT + tid;
-        if (i < nitems) {
-          const int m = i / nq, q = i % nq;
-          const int pix = p0 + m;
-          const bool live = pix < npix;
-          const int oy = live ? pix / a.W : 0, ox = live ? pix % a.W : 0;
-          const float off_y = a.offs[(oy * a.k2 + tn) * 2], off_x = a.offs[(oy * a.k2 + tn) * 2 + 1];
-          // base grid = VALID patches of the padded meshgrid (:152-168): padded coordinate of tap (ty,tx) at (oy,ox)
-          const Tap4 s = da_tap((float)(oy + ty), (float)(ox + tx_), off_y, off_x, a.in_h, a.in_w);
-          const int ys[4] = {s.y0, s.y0, s.y1, s.y1}, xs[4] = {s.x0, s.x1, s.x0, s.x1};
-          const float ws[4] = {s.w0, s.w1, s.w2, s.w3};
+    for (int cb = 0; cb < CBMAX; ++cb)
+      if (cb < a.cin32) {
+        const size_t o = (size_t)((tn * a.cin32 + cb) * 4) * a.Npad;
+        bnh[cb] = wlh[o];
+        if (PRECISE) bnl[cb] = wll[o];
+      }
+  };
+  // one round: blend + store tap t from the register set, refill it with tap t+1 (in flight during the MFMAs of tap t)
+  auto round = [&](int t, float (&cr)[IMAX][4][8], float (&cw)[IMAX][4]) {
+    uint4* buf = sA + (t & 1) * buf_units;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int yy = ys[k] - a.pad, xx = xs[k] - a.pad;      // back to un-padded coordinates; border = zeros
-            const bool in = live && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
-            const float* pp = xb + ((size_t)(in ? yy : 0) * a.W + (in ? xx : 0)) * a.Cin + q * 8;
-            const float4 lo = *reinterpret_cast<const float4*>(pp), hi = *reinterpret_cast<const float4*>(pp + 4);
-            cr[it][k][0] = lo.x; cr[it][k][1] = lo.y; cr[it][k][2] = lo.z; cr[it][k][3] = lo.w;
-            cr[it][k][4] = hi.x; cr[it][k][5] = hi.y; cr[it][k][6] = hi.z; cr[it][k][7] = hi.w;
-            cw[it][k] = in ? ws[k] : 0.f;
-          }
-        }
+    for (int it = 0; it < IMAX; ++it) {
+      const int i = it * NT + tid;
+      if (i < nitems) {
+        const int m = i / nq, q = i % nq;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          v[j] = cw[it][0] * cr[it][0][j] + cw[it][1] * cr[it][1][j] + cw[it][2] * cr[it][2][j] + cw[it][3] * cr[it][3][j];
+        uint4 h8, l8;
+        pack8<PRECISE>(v, h8, l8);
+        buf[q * plane + m] = h8;
+        if (PRECISE) buf[nq * plane + q * plane + m] = l8;
       }
     }
-    if (t < 0) continue;
+    __syncthreads();   // tile t staged; also: every wave is past the MFMAs of tile t-1, so buffer (t+1)&1 is free
+    if (t + 1 < a.k2) gather(t + 1, cr, cw);
+    if (BPF && t + 1 < a.k2) load_b(t + 1);
     // ---- MFMA: Cin/32 k-steps, 4 pixel fragments x this wave's 16 filters -----------------------------------
-    const uint4* buf = sA + (t & 1) * buf_units;
-    for (int cb = 0; cb < a.cin32; ++cb) {
-      const size_t o = (size_t)((t * a.cin32 + cb) * 4) * a.Npad;
-      const uint4 bh = wlh[o];
-      uint4 bl = uint4{0, 0, 0, 0};
-      if (PRECISE) bl = wll[o];
+#pragma unroll
+    for (int cb = 0; cb < CBMAX; ++cb) {
+      if (cb >= a.cin32) break;
+      uint4 bh, bl = uint4{0, 0, 0, 0};
+      if (BPF) { bh = bch[cb]; if (PRECISE) bl = bcl[cb]; }
+      else {
+        const size_t o = (size_t)((t * a.cin32 + cb) * 4) * a.Npad;
+        bh = wlh[o];
+        if (PRECISE) bl = wll[o];
+      }
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) {
         const uint4 ah = buf[(cb * 4 + kq) * plane + mi * 16 + lr];
@@ -154,7 +214,19 @@ __global__ void __launch_bounds__(NWV * 64) da_conv_kernel(const DaArgs a) {
         acc[mi] = mfma16(ah, bh, acc[mi]);
       }
     }
+    if (BPF) {
+#pragma unroll
+      for (int cb = 0; cb < CBMAX; ++cb) { bch[cb] = bnh[cb]; if (PRECISE) bcl[cb] = bnl[cb]; }
+    }
+  };
+
+  gather(0, cr0, cw0);
+  if (BPF) {
+    load_b(0);
+#pragma unroll
+    for (int cb = 0; cb < CBMAX; ++cb) { bch[cb] = bnh[cb]; if (PRECISE) bcl[cb] = bnl[cb]; }
   }
+  for (int t = 0; t < a.k2; ++t) round(t, cr0, cw0);
   // ---- epilogue: + bias, store -------------------------------------------------------------------------------
   const int n = n0 + wave * 16 + lr;
   if (n < a.Cout) {
@@ -308,22 +380,30 @@ int hdrsky_da_conv2d_fwd(const float* x, const void* w_hi, const void* w_lo, con
   a.cin32 = Cin / 32; a.nblocks = cdiv(Cout, nwv * 16); a.tiles_x = cdiv(H * W, 64);
   if (64 * (Cin / 8) > 4 * nwv * 64) return HDRSKY_EUNSUPPORTED;   // register prefetch budget (Cin <= 128 / 256)
   const int lds = 2 * (Cin / 8) * 65 * 16 * (precise ? 2 : 1);
-  if (lds > 160 * 1024) return HDRSKY_EUNSUPPORTED;
+  if (lds > 152 * 1024) return HDRSKY_EUNSUPPORTED;          // + 5 KB of static LDS (the tile's offset table)
+  a.tab_off = lds;
+  a.use_tab = (lds + 64 * a.k2 * 32 <= 152 * 1024) ? 1 : 0;      // sample table: 32 B per (pixel, tap); 7x7 in BF16X3 does not fit
+  if (const char* e = getenv("HDRSKY_DA_TAB")) { if (atoi(e) == 0) a.use_tab = 0; }   // tuning / test hook
+  if ((64 / W + 2) * a.k2 > 5 * 128) return HDRSKY_EUNSUPPORTED;   // rows a 64-pixel tile spans x taps: the staged offset table
+  const int lds_launch = lds + (a.use_tab ? 64 * a.k2 * 32 : 0);
   const int grid = B * a.tiles_x * a.nblocks;
-#define HDRSKY_DA_LAUNCH(PREC_, NWV_)                                                                             \
+#define HDRSKY_DA_LAUNCH_(PREC_, NWV_, IMAX_)                                                                      \
   {                                                                                                               \
-    auto k = da_conv_kernel<PREC_, NWV_>;                                                                          \
+    auto k = da_conv_kernel<PREC_, NWV_, IMAX_>;                                                                   \
     static bool set = false;                                                                                      \
     if (!set) {                                                                                                   \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,       \
-                              160 * 1024) != hipSuccess) return HDRSKY_ELAUNCH;                                   \
+                              152 * 1024) != hipSuccess) return HDRSKY_ELAUNCH;                                   \
       set = true;                                                                                                 \
     }                                                                                                             \
-    hipLaunchKernelGGL(k, dim3(grid), dim3(NWV_ * 64), lds, (hipStream_t)stream, a);                              \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NWV_ * 64), lds_launch, (hipStream_t)stream, a);                              \
   }
+#define HDRSKY_DA_LAUNCH(PREC_, NWV_) { if (imax2) HDRSKY_DA_LAUNCH_(PREC_, NWV_, 2) else HDRSKY_DA_LAUNCH_(PREC_, NWV_, 4) }
+  const bool imax2 = 64 * (Cin / 8) <= 2 * nwv * 64;   // two items per thread suffice: half the gather registers
   if (precise) { if (nwv == 8) HDRSKY_DA_LAUNCH(true, 8) else HDRSKY_DA_LAUNCH(true, 4) }
   else { if (nwv == 8) HDRSKY_DA_LAUNCH(false, 8) else HDRSKY_DA_LAUNCH(false, 4) }
 #undef HDRSKY_DA_LAUNCH
+#undef HDRSKY_DA_LAUNCH_
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }

@@ -129,3 +129,31 @@ def test_da_layer_backward(dev):
     from oracle import tfsem as T
     (ref_dx2,) = torch.autograd.grad(T.resize_bilinear(xt, 16, 64), xt, torch.from_numpy(rdup).double())
     assert_close(dx2, ref_dx2.float(), 3e-4, "deconv dx")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,shape", [(5, (2, 8, 32, 64, 64)), (7, (1, 16, 64, 32, 32)), (3, (2, 16, 16, 32, 32))])
+def test_da_conv_other_kernel_sizes_and_sample_table(dev, k, shape):
+    """5x5 / 7x7 distortion-aware kernels (25 / 49 taps in the per-workgroup sample table) and a 16-pixel-wide map (a
+    64-pixel tile spans 4 rows) against the oracle; the table path and the per-item coordinate path agree bit for bit."""
+    import os
+    K = pkg("kernels")
+    B, H, W, C, F = shape
+    rng = np.random.default_rng(k * 17 + C)
+    x = rng.standard_normal((B, H, W, C)).astype(np.float32)
+    kern = (rng.standard_normal((k * k * C, F)) / np.sqrt(k * k * C)).astype(np.float32)
+    bias = rng.standard_normal(F).astype(np.float32)
+    offs = K.da_offsets(H, W, k, 1, True)
+    ref = da_ops.da_conv2d(x, kern, bias, da_ops.distortion(H, W, k), k=k)
+    d = lambda a: torch.from_numpy(a).to(dev)
+    pw = K.PackedConv(d(kern).view(k, k, C, F))
+    y = K.da_conv2d(d(x), pw, d(bias), d(offs), K.BF16X3)
+    assert_close(y, ref, 3e-4, "da conv %dx%d" % (k, k))
+    y16 = K.da_conv2d(d(x), pw, d(bias), d(offs), K.BF16)
+    try:
+        os.environ["HDRSKY_DA_TAB"] = "0"
+        y_n = K.da_conv2d(d(x), pw, d(bias), d(offs), K.BF16X3)
+        y16_n = K.da_conv2d(d(x), pw, d(bias), d(offs), K.BF16)
+    finally:
+        os.environ.pop("HDRSKY_DA_TAB", None)
+    assert torch.equal(y, y_n) and torch.equal(y16, y16_n)
