@@ -119,8 +119,14 @@ def main():
     if dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        # Rehearsal of the N>1 path on a one-GPU box: HDRSKY_BENCH_ONE_CARD=1 puts every rank on cuda:0 and
+        # HDRSKY_DIST_BACKEND=gloo replaces RCCL (which refuses two ranks on one device).  Never set by the driver.
+        if os.environ.get("HDRSKY_BENCH_ONE_CARD", "0") == "1":
+            local = 0
+        backend = os.environ.get("HDRSKY_DIST_BACKEND", "nccl")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local if dp else 0)
