@@ -9,6 +9,7 @@
 //                        columns, LDS transpose, rows -> range limit -> one 8-byte store per thread into the u8 planes
 //   jpeg_merge_kernel    one thread per four output pixels: h2v2 fancy (triangle) upsampling of the decoded chroma planes
 //                        (jdsample.c) + YCbCr -> RGB (jdcolor.c) -> float / 255
+// Any image size: partial 16x16 MCUs are completed by libjpeg's edge replication rules (see jpeg_blocks_kernel).
 // Algorithmic bytes per image: 12 B/pixel read + 1.5 B/pixel plane write, then 1.5 (+ cached neighbours) read + 12 written.
 #include <hip/hip_runtime.h>
 
@@ -86,11 +87,16 @@ __device__ __forceinline__ int ycc(int r, int g, int b, int comp) {
 
 constexpr int BLK_PER_WG = 32;   // 256 threads
 
+// Image sizes that are not multiples of 16 follow libjpeg's edge rules: full-resolution rows / columns are replicated
+// (jcsample.c expand_right_edge, jcprepct.c expand_bottom_edge: rows only up to an even count), the DOWNSAMPLED chroma
+// planes are then padded downwards by replicating their last row (jcprepct.c), the decoder crops.  The planes in `ws`
+// have the padded sizes Hp x Wp (multiples of 16) and Hp/2 x Wp/2.
 __global__ void __launch_bounds__(256) jpeg_blocks_kernel(const float* __restrict__ ldr, const int* __restrict__ quality,
-                                                          int B, int H, int W, int bgr, unsigned char* __restrict__ ws) {
+                                                          int B, int H, int W, int Hp, int Wp, int bgr,
+                                                          unsigned char* __restrict__ ws) {
   __shared__ int tile[BLK_PER_WG][8][9];
   const int lb = threadIdx.x >> 3, r = threadIdx.x & 7;
-  const int ybl = (H >> 3) * (W >> 3), cbl = (H >> 4) * (W >> 4), per_img = ybl + 2 * cbl;
+  const int ybl = (Hp >> 3) * (Wp >> 3), cbl = (Hp >> 4) * (Wp >> 4), per_img = ybl + 2 * cbl;
   const long long gb = (long long)blockIdx.x * BLK_PER_WG + lb;
   const bool live = gb < (long long)B * per_img;
   int d[8];
@@ -98,30 +104,51 @@ __global__ void __launch_bounds__(256) jpeg_blocks_kernel(const float* __restric
   if (live) {
     b = (int)(gb / per_img);
     int k = (int)(gb % per_img);
-    if (k >= ybl) { comp = 1 + (k - ybl) / cbl; k = (k - ybl) % cbl; by = k / (W >> 4); bx = k % (W >> 4); }
-    else { by = k / (W >> 3); bx = k % (W >> 3); }
+    if (k >= ybl) { comp = 1 + (k - ybl) / cbl; k = (k - ybl) % cbl; by = k / (Wp >> 4); bx = k % (Wp >> 4); }
+    else { by = k / (Wp >> 3); bx = k % (Wp >> 3); }
     const int ri = bgr ? 2 : 0, bi = bgr ? 0 : 2;
+    const float* img = ldr + (size_t)b * H * W * 3;
+    const bool vec = (W & 3) == 0;            // 16-byte aligned pixel rows: float4 loads for blocks inside the image
     if (comp == 0) {
-      const float4* src = reinterpret_cast<const float4*>(ldr + (((size_t)b * H + by * 8 + r) * W + bx * 8) * 3);
+      const int row = min(by * 8 + r, H - 1), col0 = bx * 8;
       float v[24];
+      if (vec && col0 + 8 <= W) {
+        const float4* src = reinterpret_cast<const float4*>(img + ((size_t)row * W + col0) * 3);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) { const float4 t = src[k]; v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w; }
+        for (int k = 0; k < 6; ++k) { const float4 t = src[k]; v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w; }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const float* px = img + ((size_t)row * W + min(col0 + c, W - 1)) * 3;
+          v[c * 3] = px[0]; v[c * 3 + 1] = px[1]; v[c * 3 + 2] = px[2];
+        }
+      }
 #pragma unroll
       for (int c = 0; c < 8; ++c) d[c] = ycc(to_u8(v[c * 3 + ri]), to_u8(v[c * 3 + 1]), to_u8(v[c * 3 + bi]), 0) - 128;
     } else {   // jcsample.c h2v2_downsample: (a + b + c + d + bias) >> 2, bias 1,2,1,2,... along the row
-      const float4* s0 = reinterpret_cast<const float4*>(ldr + (((size_t)b * H + by * 16 + 2 * r) * W + bx * 16) * 3);
-      const float4* s1 = s0 + (size_t)W * 3 / 4;
+      const int hc = (H + 1) >> 1;
+      const int crow = min(by * 8 + r, hc - 1);                    // rows below the downsampled image replicate its last row
+      const int row0 = 2 * crow, row1 = min(2 * crow + 1, H - 1), col0 = bx * 16;
       int acc[8];
 #pragma unroll
       for (int c = 0; c < 8; ++c) acc[c] = 0;
 #pragma unroll
-      for (int row = 0; row < 2; ++row) {
-        const float4* sp = row ? s1 : s0;
+      for (int rr = 0; rr < 2; ++rr) {
+        const int row = rr ? row1 : row0;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {      // 8 source pixels (24 floats) at a time
           float v[24];
+          if (vec && col0 + h * 8 + 8 <= W) {
+            const float4* sp = reinterpret_cast<const float4*>(img + ((size_t)row * W + col0 + h * 8) * 3);
 #pragma unroll
-          for (int k = 0; k < 6; ++k) { const float4 t = sp[h * 6 + k]; v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w; }
+            for (int k = 0; k < 6; ++k) { const float4 t = sp[k]; v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w; }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float* px = img + ((size_t)row * W + min(col0 + h * 8 + e, W - 1)) * 3;
+              v[e * 3] = px[0]; v[e * 3 + 1] = px[1]; v[e * 3 + 2] = px[2];
+            }
+          }
 #pragma unroll
           for (int e = 0; e < 8; ++e) acc[h * 4 + e / 2] += ycc(to_u8(v[e * 3 + ri]), to_u8(v[e * 3 + 1]), to_u8(v[e * 3 + bi]), comp);
         }
@@ -164,38 +191,46 @@ __global__ void __launch_bounds__(256) jpeg_blocks_kernel(const float* __restric
       lo |= (unsigned)min(max(d[c] + 128, 0), 255) << (8 * c);
       hi |= (unsigned)min(max(d[c + 4] + 128, 0), 255) << (8 * c);
     }
-    const size_t ypl = (size_t)H * W, cpl = ypl >> 2;
+    const size_t ypl = (size_t)Hp * Wp, cpl = ypl >> 2;
     unsigned char* plane = ws + (size_t)b * (ypl + 2 * cpl) + (comp == 0 ? 0 : ypl + (comp - 1) * cpl);
-    const int pw = comp == 0 ? W : (W >> 1);
+    const int pw = comp == 0 ? Wp : (Wp >> 1);
     *reinterpret_cast<uint2*>(plane + (size_t)(by * 8 + r) * pw + bx * 8) = uint2{lo, hi};
   }
 }
 
-// jdsample.c h2v2_fancy_upsample for output pixels x0..x0+3 of row y of a decoded half-resolution plane [hc][wc]
-__device__ __forceinline__ void fancy4(const unsigned char* __restrict__ p, int hc, int wc, int y, int x0, int (&o)[4]) {
-  const int cy = y >> 1, c0 = x0 >> 1;
+// jdsample.c for output pixels x0..x0+3 of row y of a decoded half-resolution plane (hc x wc samples, row stride cs):
+// h2v2_fancy_upsample (triangle filter), or plain 2x2 replication when the plane has at most two columns
+// (jinit_upsampler selects the fancy method only for downsampled_width > 2).
+__device__ __forceinline__ void chroma4(const unsigned char* __restrict__ p, int hc, int wc, int cs, int y, int x0, int (&o)[4]) {
+  const int cy = y >> 1, c0 = x0 >> 1, c1 = min(c0 + 1, wc - 1);
+  const unsigned char* ra = p + (size_t)cy * cs;
+  if (wc <= 2) { o[0] = o[1] = ra[c0]; o[2] = o[3] = ra[c1]; return; }
   const int oy = (y & 1) ? min(cy + 1, hc - 1) : max(cy - 1, 0);     // the nearer neighbour row (edge: replicated)
   const int cm = max(c0 - 1, 0), cp = min(c0 + 2, wc - 1);
-  const unsigned char* ra = p + (size_t)cy * wc;
-  const unsigned char* rb = p + (size_t)oy * wc;
-  const int sm = 3 * ra[cm] + rb[cm], s0 = 3 * ra[c0] + rb[c0], s1 = 3 * ra[c0 + 1] + rb[c0 + 1], sp = 3 * ra[cp] + rb[cp];
+  const unsigned char* rb = p + (size_t)oy * cs;
+  const int sm = 3 * ra[cm] + rb[cm], s0 = 3 * ra[c0] + rb[c0], s1 = 3 * ra[c1] + rb[c1], sp = 3 * ra[cp] + rb[cp];
+  const int s1n = (c0 + 1 <= wc - 1) ? s1 : s0;   // (only read for x0+2, x0+3, which do not exist then)
   o[0] = (3 * s0 + sm + 8) >> 4;
-  o[1] = (3 * s0 + s1 + 7) >> 4;
+  o[1] = (3 * s0 + s1n + 7) >> 4;
   o[2] = (3 * s1 + s0 + 8) >> 4;
   o[3] = (3 * s1 + sp + 7) >> 4;
 }
 
-__global__ void __launch_bounds__(256) jpeg_merge_kernel(const unsigned char* __restrict__ ws, int B, int H, int W, int bgr,
-                                                         float* __restrict__ out) {
-  const size_t ypl = (size_t)H * W, cpl = ypl >> 2, total4 = (size_t)B * ypl / 4;
-  for (size_t i4 = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i4 < total4; i4 += (size_t)gridDim.x * blockDim.x) {
-    const size_t i = i4 * 4;
-    const int b = (int)(i / ypl), rem = (int)(i % ypl), y = rem / W, x0 = rem % W;
+// One thread per group of four pixels of a row (the last group of a row may be shorter).
+__global__ void __launch_bounds__(256) jpeg_merge_kernel(const unsigned char* __restrict__ ws, int B, int H, int W, int Hp,
+                                                         int Wp, int bgr, float* __restrict__ out) {
+  const size_t ypl = (size_t)Hp * Wp, cpl = ypl >> 2;
+  const int gpr = (W + 3) >> 2;                            // groups per row
+  const size_t total = (size_t)B * H * gpr;
+  const int hc = (H + 1) >> 1, wc = (W + 1) >> 1;
+  for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(g / ((size_t)H * gpr)), rem = (int)(g % ((size_t)H * gpr)), y = rem / gpr, x0 = (rem % gpr) * 4;
+    const int n = min(4, W - x0);
     const unsigned char* base = ws + (size_t)b * (ypl + 2 * cpl);
-    const unsigned int y4 = *reinterpret_cast<const unsigned int*>(base + rem);
+    const unsigned int y4 = *reinterpret_cast<const unsigned int*>(base + (size_t)y * Wp + x0);   // Wp % 16 == 0: aligned, in bounds
     int cb[4], cr[4];
-    fancy4(base + ypl, H >> 1, W >> 1, y, x0, cb);
-    fancy4(base + ypl + cpl, H >> 1, W >> 1, y, x0, cr);
+    chroma4(base + ypl, hc, wc, Wp >> 1, y, x0, cb);
+    chroma4(base + ypl + cpl, hc, wc, Wp >> 1, y, x0, cr);
     float v[12];
     constexpr int HALF = 1 << 15;   // jdcolor.c ycc_rgb_convert
 #pragma unroll
@@ -208,10 +243,15 @@ __global__ void __launch_bounds__(256) jpeg_merge_kernel(const unsigned char* __
       v[e * 3 + 1] = (float)gg / 255.f;
       v[e * 3 + (bgr ? 0 : 2)] = (float)bb / 255.f;
     }
-    float4* o = reinterpret_cast<float4*>(out + i * 3);
-    o[0] = float4{v[0], v[1], v[2], v[3]};
-    o[1] = float4{v[4], v[5], v[6], v[7]};
-    o[2] = float4{v[8], v[9], v[10], v[11]};
+    float* o = out + (((size_t)b * H + y) * W + x0) * 3;
+    if (n == 4 && (W & 3) == 0) {
+      float4* o4 = reinterpret_cast<float4*>(o);
+      o4[0] = float4{v[0], v[1], v[2], v[3]};
+      o4[1] = float4{v[4], v[5], v[6], v[7]};
+      o4[2] = float4{v[8], v[9], v[10], v[11]};
+    } else {
+      for (int e = 0; e < n * 3; ++e) o[e] = v[e];
+    }
   }
 }
 
@@ -221,24 +261,27 @@ extern "C" {
 
 size_t hdrsky_jpeg_roundtrip_ws_bytes(int B, int H, int W) {
   if (B <= 0 || H <= 0 || W <= 0) return 0;
-  return (size_t)B * H * W * 3 / 2;
+  const size_t Hp = ((size_t)H + 15) / 16 * 16, Wp = ((size_t)W + 15) / 16 * 16;
+  return (size_t)B * Hp * Wp * 3 / 2;
 }
 
 int hdrsky_jpeg_roundtrip(const float* ldr, const int* quality, int B, int H, int W, int bgr, unsigned char* ws, float* out,
                           void* stream) {
   if (!ldr || !quality || !ws || !out || B <= 0 || H <= 0 || W <= 0) return HDRSKY_EINVAL;
-  if ((H & 15) || (W & 15)) return HDRSKY_EUNSUPPORTED;   // whole 16x16 MCUs only (libjpeg pads partial ones by replication)
   if ((reinterpret_cast<uintptr_t>(ws) & 7) != 0 || (reinterpret_cast<uintptr_t>(ldr) & 15) != 0 ||
       (reinterpret_cast<uintptr_t>(out) & 15) != 0)
     return HDRSKY_EINVAL;
-  const long long nblocks = (long long)B * ((H >> 3) * (W >> 3) + 2 * (H >> 4) * (W >> 4));
+  const int Hp = (H + 15) / 16 * 16, Wp = (W + 15) / 16 * 16;
+  const long long nblocks = (long long)B * ((Hp >> 3) * (Wp >> 3) + 2 * (Hp >> 4) * (Wp >> 4));
   const long long g1 = (nblocks + BLK_PER_WG - 1) / BLK_PER_WG;
   if (g1 > 0x7fffffffLL) return HDRSKY_EUNSUPPORTED;
-  hipLaunchKernelGGL(jpeg_blocks_kernel, dim3((unsigned)g1), dim3(256), 0, (hipStream_t)stream, ldr, quality, B, H, W, bgr ? 1 : 0, ws);
+  hipLaunchKernelGGL(jpeg_blocks_kernel, dim3((unsigned)g1), dim3(256), 0, (hipStream_t)stream, ldr, quality, B, H, W, Hp, Wp,
+                     bgr ? 1 : 0, ws);
   HDRSKY_CHECK_LAUNCH();
-  size_t g2 = ((size_t)B * H * W / 4 + 255) / 256;
+  size_t g2 = ((size_t)B * H * ((W + 3) / 4) + 255) / 256;
   if (g2 > 8192) g2 = 8192;
-  hipLaunchKernelGGL(jpeg_merge_kernel, dim3((unsigned)g2), dim3(256), 0, (hipStream_t)stream, ws, B, H, W, bgr ? 1 : 0, out);
+  hipLaunchKernelGGL(jpeg_merge_kernel, dim3((unsigned)g2), dim3(256), 0, (hipStream_t)stream, ws, B, H, W, Hp, Wp, bgr ? 1 : 0,
+                     out);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }

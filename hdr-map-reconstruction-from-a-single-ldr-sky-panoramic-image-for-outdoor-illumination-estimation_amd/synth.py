@@ -82,8 +82,8 @@ def gamma_crf(n_curves=1, k=1024, gamma=2.2):
 def make_batch_device(batch, h=32, w=128, seed=1234, device="cuda", crf=None, jpeg=True):
     """The same synthetic distribution as make_batch, produced on the GPU: analytic sky-dome + sun lobe (torch ops on
     the device - test/bench plumbing), then the reference's augmentation and target construction in libhdrsky
-    (kernels.ldr_synth = train.py:54-85, kernels.jpeg_roundtrip = train.py:86-92 when `jpeg` and h, w are multiples of
-    16, kernels.vmf_target = train.py:42-52).  Returns dict of CUDA tensors (hdr_t, ldr, sunpose_gt).  Different random
+    (kernels.ldr_synth = train.py:54-85, kernels.jpeg_roundtrip = train.py:86-92 when `jpeg`,
+    kernels.vmf_target = train.py:42-52).  Returns dict of CUDA tensors (hdr_t, ldr, sunpose_gt).  Different random
     stream than make_batch (torch generator instead of numpy; make_batch has no JPEG step)."""
     import torch
     from . import kernels as K
@@ -109,6 +109,6 @@ def make_batch_device(batch, h=32, w=128, seed=1234, device="cuda", crf=None, jp
     if crf is None:
         crf = torch.from_numpy(gamma_crf(batch)).to(dev)
     hdr_t, ldr = K.ldr_synth(img, t, sigma_s.contiguous(), sigma_c.contiguous(), n_s, n_c, crf)
-    if jpeg and h % 16 == 0 and w % 16 == 0:
+    if jpeg:
         K.jpeg_roundtrip(ldr, order="bgr", out=ldr)
     return dict(hdr_t=hdr_t, ldr=ldr, sunpose_gt=K.vmf_target(elev.contiguous(), azimuth, h, w, KAPPA))

@@ -298,7 +298,8 @@ int hdrsky_ldr_synth(const float* hdr, const float* t, const float* sigma_s, con
  * slow-integer IDCT, fancy chroma upsampling; the lossless entropy coding is skipped).  Integer arithmetic, bit-exact
  * against libjpeg.  ldr / out [B,H,W,3] float holding k/255 (channel 0 = R, or B when bgr != 0); quality [B] int32 on the
  * device (train.py:89: round(i/(B-1)*10+90)); ws: hdrsky_jpeg_roundtrip_ws_bytes(B,H,W) bytes of device scratch, 8-byte
- * aligned.  H and W must be multiples of 16 (else HDRSKY_EUNSUPPORTED).  out may alias ldr. */
+ * aligned; ldr / out 16-byte aligned.  Any H, W: partial 16x16 MCUs are completed by libjpeg's edge replication rules.
+ * out may alias ldr. */
 size_t hdrsky_jpeg_roundtrip_ws_bytes(int B, int H, int W);
 int hdrsky_jpeg_roundtrip(const float* ldr, const int* quality, int B, int H, int W, int bgr, unsigned char* ws, float* out,
                           void* stream);

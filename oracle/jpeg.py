@@ -143,16 +143,26 @@ def ycc_to_rgb(y, cb, cr):
 
 
 def adjust_jpeg_quality(img_u8, quality):
-    """img_u8: [H, W, 3] uint8 RGB, H and W multiples of 16.  Returns the decoded uint8 RGB image."""
+    """img_u8: [H, W, 3] uint8 RGB, any size.  Returns the decoded uint8 RGB image.
+    Partial 16x16 MCUs follow libjpeg: full-resolution rows / columns are replicated up to an even row count and to
+    whole MCU columns before the chroma downsampling (jcsample.c expand_right_edge, jcprepct.c expand_bottom_edge), the
+    DOWNSAMPLED planes are then padded downwards by replicating their last row (jcprepct.c), the decoder crops; chroma
+    planes of at most two columns are upsampled by plain replication instead of the triangle filter (jdsample.c
+    jinit_upsampler: fancy upsampling needs downsampled_width > 2)."""
     h, w, _ = img_u8.shape
-    if h % 16 or w % 16:
-        raise ValueError("restated for whole 16x16 MCUs only")
-    y, cb, cr = rgb_to_ycc(img_u8)
+    H16, W16 = -(-h // 16) * 16, -(-w // 16) * 16
+    he = h + (h & 1)
+    pad = np.pad(img_u8, ((0, he - h), (0, W16 - w), (0, 0)), mode="edge")
+    y, cb, cr = rgb_to_ycc(pad)
     ql, qc = quality_table(STD_LUMA, quality), quality_table(STD_CHROMA, quality)
-    yd = codec_plane(y, ql)
-    cbd = h2v2_fancy_upsample(codec_plane(h2v2_downsample(cb), qc))
-    crd = h2v2_fancy_upsample(codec_plane(h2v2_downsample(cr), qc))
-    return ycc_to_rgb(yd, cbd, crd).astype(np.uint8)
+    yd = codec_plane(np.pad(y, ((0, H16 - he), (0, 0)), mode="edge"), ql)[:h, :w]
+    hc, wc = -(-h // 2), -(-w // 2)
+    planes = []
+    for c in (cb, cr):
+        dec = codec_plane(np.pad(h2v2_downsample(c), ((0, H16 // 2 - he // 2), (0, 0)), mode="edge"), qc)[:hc, :wc]
+        up = h2v2_fancy_upsample(dec) if wc > 2 else np.repeat(np.repeat(dec, 2, 0), 2, 1)
+        planes.append(up[:h, :w])
+    return ycc_to_rgb(yd, planes[0], planes[1]).astype(np.uint8)
 
 
 def batch_qualities(b):

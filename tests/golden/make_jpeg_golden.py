@@ -40,6 +40,11 @@ def images():
         "ramp": np.clip(ramp, 0, 255).astype(np.uint8),
         "saturated": np.where(rng.random((h, w, 3)) > 0.5, 255, 0).astype(np.uint8),
         "tall": rng.integers(0, 256, (64, 48, 3), dtype=np.uint8),
+        # partial 16x16 MCUs / tiny chroma planes: libjpeg's edge replication and its plain-upsampling special case
+        "ragged17x33": rng.integers(0, 256, (17, 33, 3), dtype=np.uint8),
+        "ragged40x40": rng.integers(0, 256, (40, 40, 3), dtype=np.uint8),
+        "ragged31x127": sky[0][:31, :127].copy(),
+        "tiny3x2": rng.integers(0, 256, (3, 2, 3), dtype=np.uint8),
     }
 
 

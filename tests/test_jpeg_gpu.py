@@ -52,14 +52,16 @@ def test_batch_of_32_reference_quality_ramp_both_channel_orders(dev):
 def test_other_sizes_random_content_and_errors(dev):
     K = pkg("kernels")
     rng = np.random.default_rng(8)
-    for (b, h, w) in ((1, 16, 16), (3, 64, 256), (5, 48, 80), (2, 128, 512)):
+    # whole MCUs, partial MCUs (H or W not a multiple of 16, odd sizes, W % 4 != 0), chroma planes of <= 2 columns
+    for (b, h, w) in ((1, 16, 16), (3, 64, 256), (5, 48, 80), (2, 128, 512), (2, 17, 33), (3, 40, 40), (2, 31, 127), (4, 5, 7),
+                      (2, 2, 3), (2, 3, 2), (1, 1, 1), (2, 100, 37), (2, 24, 56), (1, 9, 1), (2, 20, 4)):
         ldr = rng.integers(0, 256, (b, h, w, 3)).astype(np.float32) / 255.0
         qs = [int(q) for q in rng.integers(1, 101, b)]
         ref = np.stack([J.adjust_jpeg_quality(np.rint(ldr[i] * 255).astype(np.uint8), qs[i]) for i in range(b)])
         out = K.jpeg_roundtrip(torch.from_numpy(ldr).to(dev), quality=qs, order="rgb")
         assert np.array_equal(torch.round(out * 255).to(torch.uint8).cpu().numpy(), ref), (b, h, w)
     with pytest.raises(Exception):
-        K.jpeg_roundtrip(torch.zeros(1, 24, 32, 3, device=dev))                # partial MCUs: unsupported
+        K.jpeg_roundtrip(torch.zeros(1, 16, 32, 4, device=dev))                # three channels only
 
 
 def test_device_batch_synthesis_applies_jpeg(dev):
