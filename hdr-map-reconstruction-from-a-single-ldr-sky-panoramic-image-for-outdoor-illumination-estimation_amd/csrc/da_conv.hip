@@ -20,6 +20,7 @@ struct DaArgs {
   const float* bias;
   const float* offs;  // [h][k*k][2] (y, x), identical for every column
   float* y;
+  float* stats;       // optional [B][tiles per sample][2][Cout] (sum, sum of squares) of y per 64-pixel tile, like the conv epilogue
   int B, H, W, Cin, Cout, Npad, ksize, k2, pad, in_h, in_w, cin32, nblocks, tiles_x;
   int tab_off, use_tab;     // LDS byte offset of the per-(pixel, tap) sample table behind the A tiles; 0: computed per item
 };
@@ -229,6 +230,7 @@ __global__ void __launch_bounds__(NWV * 64) da_conv_kernel(const DaArgs a) {
   for (int t = 0; t < a.k2; ++t) round(t, cr0, cw0);
   // ---- epilogue: + bias, store -------------------------------------------------------------------------------
   const int n = n0 + wave * 16 + lr;
+  float s1 = 0.f, s2 = 0.f;
   if (n < a.Cout) {
     const float bv = a.bias ? a.bias[n] : 0.f;
 #pragma unroll
@@ -236,8 +238,20 @@ __global__ void __launch_bounds__(NWV * 64) da_conv_kernel(const DaArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int pix = p0 + mi * 16 + kq * 4 + j;
-        if (pix < npix) a.y[((size_t)b * npix + pix) * a.Cout + n] = acc[mi][j] + bv;
+        if (pix < npix) {
+          const float v = acc[mi][j] + bv;
+          a.y[((size_t)b * npix + pix) * a.Cout + n] = v;
+          s1 += v; s2 += v * v;
+        }
       }
+  }
+  if (a.stats) {   // InstanceNorm partials of this tile: lanes lr, lr+16, lr+32, lr+48 hold the same channel
+    s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+    if (kq == 0 && n < a.Cout) {
+      float* dst = a.stats + ((size_t)(b * a.tiles_x + tile) * 2) * a.Cout + n;
+      dst[0] = s1; dst[a.Cout] = s2;
+    }
   }
 }
 
@@ -362,14 +376,16 @@ int hdrsky_da_offsets(int h, int w, int ksize, int dilation_rate, int skydome, f
 
 // y[B,H,W,Cout] = DA-conv(x[B,H,W,Cin]) + bias; weights packed with hdrsky_conv_pack_weights(w, k, k, Cin, Cout, 0, ..)
 // from the reference's [k*k*Cin, Cout] kernel (same memory order as HWIO); offs = device copy of hdrsky_da_offsets.
+int hdrsky_da_conv_stats_nparts(int H, int W) { return (H > 0 && W > 0) ? cdiv(H * W, 64) : 0; }
+
 int hdrsky_da_conv2d_fwd(const float* x, const void* w_hi, const void* w_lo, const float* bias, const float* offs, int B,
-                         int H, int W, int Cin, int Cout, int ksize, int compute, float* y, void* stream) {
+                         int H, int W, int Cin, int Cout, int ksize, int compute, float* y, float* stats_part, void* stream) {
   if (!x || !w_hi || !offs || !y || (ksize & 1) == 0) return HDRSKY_EINVAL;
   if ((Cin % 32) != 0) return HDRSKY_EUNSUPPORTED;
   const bool precise = compute == HDRSKY_BF16X3;
   if (precise && !w_lo) return HDRSKY_EINVAL;
   DaArgs a{};
-  a.x = x; a.whi = (const uint4*)w_hi; a.wlo = (const uint4*)w_lo; a.bias = bias; a.offs = offs; a.y = y;
+  a.x = x; a.whi = (const uint4*)w_hi; a.wlo = (const uint4*)w_lo; a.bias = bias; a.offs = offs; a.y = y; a.stats = stats_part;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.Npad = roundup(Cout, 64);
   a.ksize = ksize; a.k2 = ksize * ksize;
   // conv2d._pad_input (:125-150) for stride 1: pad (k-1)//2 before, rest after, when k > 1

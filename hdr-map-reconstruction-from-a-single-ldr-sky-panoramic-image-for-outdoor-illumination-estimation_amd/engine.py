@@ -40,8 +40,16 @@ class Nets:
         self.gen = _dev(gen_params, self.device) if gen_params is not None else None
         self.sun = _dev(sun_params, self.device) if sun_params is not None else None
         self.pk = {}
+        self._da_offs = {}
         self.side_stream = torch.cuda.Stream(device=self.device)
         self.repack_all()
+
+    def da_offsets(self, h, w, k=3, dilation_rate=1):
+        """Device copy of the distortion-aware sampling offsets for an h x w map (cached)."""
+        key = (h, w, k, dilation_rate)
+        if key not in self._da_offs:
+            self._da_offs[key] = torch.from_numpy(K.da_offsets(h, w, k, dilation_rate, True)).to(self.device)
+        return self._da_offs[key]
 
     def repack_all(self):
         g, s = self.gen, self.sun
@@ -128,8 +136,10 @@ def gradcam_sweep(nets, t, pick_src, compute):
             K.grad_cam_map(t["A3"], w3))
 
 
-def encode(nets, ldr, compute):
-    """generator.model.encode (generator.py:92-108) -> res_out [B,H/4,W/4,128]."""
+def encode(nets, ldr, compute, distortion_aware=False, dilation_rate=1):
+    """generator.model.encode (generator.py:92-108) -> res_out [B,H/4,W/4,128].
+    distortion_aware=True: the variant the reference keeps commented out (generator.py:14,18) - both 3x3 convolutions of
+    every res block are distortion_aware_ops.conv2d (same weights, HWIO == its [k*k*C, F] kernel).  Forward only."""
     g, pk = nets.gen, nets.pk
     r1, s1 = K.conv2d(ldr, pk["gen.conv1_d"], g["conv1_d.b"], want_stats=True, compute=compute)
     r2, s2 = K.conv2d(r1, pk["gen.conv2_d"], g["conv2_d.b"], stride=2, want_stats=True, compute=compute,
@@ -137,6 +147,16 @@ def encode(nets, ldr, compute):
     r3, s3 = K.conv2d(r2, pk["gen.conv3_d"], g["conv3_d.b"], stride=2, want_stats=True, compute=compute,
                       xf=_in_xf(s2, g, "norm2_d", 0.1))
     x = K.norm_apply(r3, s3, g["norm3_d.gamma"], g["norm3_d.beta"], slope=0.1)
+    if distortion_aware:
+        _, h4, w4, _ = x.shape
+        offs = nets.da_offsets(h4, w4, 3, dilation_rate)
+        for i in range(6):
+            p = "res.%d." % i
+            c1, t1 = K.da_conv2d(x, pk["gen." + p + "conv1"], g[p + "conv1.b"], offs, compute, want_stats=True)
+            a1 = K.norm_apply(c1, t1, g[p + "norm1.gamma"], g[p + "norm1.beta"], slope=0.1)
+            c2, t2 = K.da_conv2d(a1, pk["gen." + p + "conv2"], g[p + "conv2.b"], offs, compute, want_stats=True)
+            x = K.norm_apply(c2, t2, g[p + "norm2.gamma"], g[p + "norm2.beta"], slope=1.0, residual=x)
+        return x
     for i in range(6):
         p = "res.%d." % i
         c1, t1 = K.conv2d(x, pk["gen." + p + "conv1"], g[p + "conv1.b"], want_stats=True, compute=compute)

@@ -9,7 +9,12 @@ from .sunrad_net import sunRadNet
 
 class model:
     def __init__(self, batch_size=32, im_height=32, im_width=128, da_kernel_size=3, dilation_rate=1, seed=0,
-                 device="cuda", compute=K.BF16, weights=None):
+                 device="cuda", compute=K.BF16, weights=None, distortion_aware=False):
+        """distortion_aware=True builds the res blocks from distortion_aware_ops.conv2d, the variant generator.py:14,18
+        keeps commented out (da_kernel_size must be 3, the res-block filter size); forward only."""
+        if distortion_aware and da_kernel_size != 3:
+            raise ValueError("the res blocks are 3x3")
+        self.distortion_aware, self.dilation_rate = bool(distortion_aware), dilation_rate
         self.im_height, self.im_width, self.fc_dim = im_height, im_width, im_height * im_width
         self.compute, self.device = compute, torch.device(device)
         w = weights if weights is not None else P.init_params(P.generator_spec(im_height, im_width), seed)
@@ -33,7 +38,8 @@ class model:
         return bool(flag) and flag != "inference"
 
     def encode(self, x, training="training"):
-        return engine.encode(self.nets, x, self.compute)
+        return engine.encode(self.nets, x, self.compute, distortion_aware=self.distortion_aware,
+                             dilation_rate=self.dilation_rate)
 
     def sky_decode(self, x, _input, training="training"):
         return engine.decode(self.nets, x, "f", _input, self.compute)

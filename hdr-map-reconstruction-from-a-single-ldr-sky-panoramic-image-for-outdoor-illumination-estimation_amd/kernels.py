@@ -699,8 +699,9 @@ def da_offsets(h, w, ksize=3, dilation_rate=1, skydome=True):
     return out
 
 
-def da_conv2d(x, pw: PackedConv, bias, offs, compute=BF16):
-    """distortion_aware_ops.conv2d.call: offs = device tensor [H, k*k, 2] from da_offsets(H, W, k, ...)."""
+def da_conv2d(x, pw: PackedConv, bias, offs, compute=BF16, want_stats=False):
+    """distortion_aware_ops.conv2d.call: offs = device tensor [H, k*k, 2] from da_offsets(H, W, k, ...).
+    want_stats: also return the InstanceNorm partials of y (Stats, as conv2d does) -> (y, Stats)."""
     _f32(x)
     B, H, W, C = x.shape
     if C != pw.Cin or pw.KH != pw.KW:
@@ -711,9 +712,14 @@ def da_conv2d(x, pw: PackedConv, bias, offs, compute=BF16):
     if compute == BF16X3 and pw.lo is None:
         raise ValueError("BF16X3 needs the lo weight plane")
     y = torch.empty((B, H, W, pw.Cout), dtype=torch.float32, device=x.device)
-    L.check(L.load().hdrsky_da_conv2d_fwd(_p(x), _p(pw.hi), _p(pw.lo), _p(bias), _p(offs), B, H, W, C, pw.Cout, pw.KH,
-                                          compute, _p(y), _stream()), "da_conv2d_fwd")
-    return y
+    lib = L.load()
+    st = None
+    if want_stats:
+        nparts = lib.hdrsky_da_conv_stats_nparts(H, W)
+        st = Stats(torch.empty((B, nparts, 2, pw.Cout), dtype=torch.float32, device=x.device), nparts, H * W)
+    L.check(lib.hdrsky_da_conv2d_fwd(_p(x), _p(pw.hi), _p(pw.lo), _p(bias), _p(offs), B, H, W, C, pw.Cout, pw.KH,
+                                     compute, _p(y), _p(st.part) if st else None, _stream()), "da_conv2d_fwd")
+    return (y, st) if want_stats else y
 
 
 def da_gather(x, offs, ksize):

@@ -318,9 +318,12 @@ unsigned int hdrsky_crc32c(const void* data, size_t n, unsigned int crc);
 int hdrsky_da_offsets(int h, int w, int ksize, int dilation_rate, int skydome, float* out);
 /* conv2d.call (distortion_aware_ops.py:50-123): bilinear gather with y clamp / 360-degree x wrap fused into an MFMA
  * GEMM; w_* = hdrsky_conv_pack_weights image of the [k*k*Cin, Cout] kernel viewed as [k,k,Cin,Cout]; offs = device
- * copy of hdrsky_da_offsets(H, W, k, ..).  stride 1, Cin % 32 == 0.  deconv2d.call (:321-395) = hdrsky_up2x_fwd + this. */
+ * copy of hdrsky_da_offsets(H, W, k, ..).  stride 1, Cin % 32 == 0.  deconv2d.call (:321-395) = hdrsky_up2x_fwd + this.
+ * stats_part (optional): [B][hdrsky_da_conv_stats_nparts(H,W)][2][Cout] InstanceNorm partial sums of y in the layout the
+ * plain conv emits, for hdrsky_norm_apply - the commented-out distortion-aware res blocks of generator.py:14,18. */
+int hdrsky_da_conv_stats_nparts(int H, int W); /* [host] */
 int hdrsky_da_conv2d_fwd(const float* x, const void* w_hi, const void* w_lo, const float* bias, const float* offs, int B,
-                         int H, int W, int Cin, int Cout, int ksize, int compute, float* y, void* stream);
+                         int H, int W, int Cin, int Cout, int ksize, int compute, float* y, float* stats_part, void* stream);
 /* Backward building blocks of the distortion-aware conv (tf.GradientTape through distortion_aware_ops.py:62-121):
  * with G = hdrsky_da_gather(x) [B,H,W,k*k*C] the layer is a 1x1 conv of G, so dW = hdrsky_conv2d_wgrad(1x1; G, dY),
  * dG = hdrsky_conv2d_fwd(1x1 with the transposed kernel; dY) and dx = hdrsky_da_scatter(dG) (dx zeroed; fp32 atomics). */

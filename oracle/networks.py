@@ -38,13 +38,31 @@ def res_block(p, prefix, x):
     return x + _inorm(p, prefix + ".norm2", c2)
 
 
-def gen_encode(p, x):
+def res_block_da(p, prefix, x, dilation_rate=1):
+    """The res block with the two lines generator.py:14,18 keeps commented out switched on: conv1 / conv2 are
+    distortion_aware_ops.conv2d(filter_out, kernel_size=3, dilation_rate) (numpy restatement oracle/da_ops.py; its
+    [k*k*C, F] kernel is the HWIO filter reshaped).  Forward only."""
+    import numpy as np
+    from . import da_ops
+    _, h, w, c = x.shape
+    offs = da_ops.distortion(h, w, 3, dilation_rate)
+
+    def da(name, t):
+        wk = p[name + ".w"].detach().numpy().reshape(9 * c, -1)
+        return torch.from_numpy(da_ops.da_conv2d(t.detach().numpy(), wk, p[name + ".b"].detach().numpy(), offs).astype(np.float32))
+    c1 = da(prefix + ".conv1", x)
+    a1 = T.leaky_relu(_inorm(p, prefix + ".norm1", c1), 0.1)
+    c2 = da(prefix + ".conv2", a1)
+    return x + _inorm(p, prefix + ".norm2", c2)
+
+
+def gen_encode(p, x, distortion_aware=False):
     """generator.model.encode (generator.py:92-108)."""
     a = T.leaky_relu(_inorm(p, "norm1_d", _conv(p, "conv1_d", x, 1)), 0.1)
     a = T.leaky_relu(_inorm(p, "norm2_d", _conv(p, "conv2_d", a, 2)), 0.1)
     a = T.leaky_relu(_inorm(p, "norm3_d", _conv(p, "conv3_d", a, 2)), 0.1)
     for i in range(6):
-        a = res_block(p, "res.%d" % i, a)
+        a = res_block_da(p, "res.%d" % i, a) if distortion_aware else res_block(p, "res.%d" % i, a)
     return a
 
 

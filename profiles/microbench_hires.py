@@ -30,6 +30,8 @@ rad = torch.rand(B, H, W, 3, device=dev)
 res = engine.encode(nets, ldr, K.BF16)
 ms = timeit(lambda: engine.encode(nets, ldr, K.BF16))
 print("encoder (3 convs + 6 res blocks)      %.3f ms  (%.1f TFLOP/s of 16.3 GFLOP/img)" % (ms, B * 16.32e9 / ms / 1e9))
+ms_da = timeit(lambda: engine.encode(nets, ldr, K.BF16, distortion_aware=True))
+print("encoder, distortion-aware res blocks  %.3f ms  (the variant generator.py:14,18 keeps commented out)" % ms_da)
 ms = timeit(lambda: (engine.decode(nets, res, "f", ldr, K.BF16), engine.decode(nets, res, "u", rad, K.BF16)))
 print("sky + sun decoders                    %.3f ms  (%.1f TFLOP/s of 10.9 GFLOP/img)" % (ms, B * 10.9e9 / ms / 1e9))
 x = torch.randn(B, H // 4, W // 4, 128, device=dev)

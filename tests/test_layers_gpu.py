@@ -176,3 +176,27 @@ def test_vgg16_model(dev, tmp_path):
         assert_close(got[i], ref[i], 1e-3, "pool%d" % (i + 1))
     with pytest.raises(ValueError):
         vgg16.Vgg16(None)
+
+
+def test_distortion_aware_res_stack(dev):
+    """generator.model(distortion_aware=True): the res blocks built from distortion_aware_ops.conv2d (the variant
+    generator.py:14,18 keeps commented out), InstanceNorm statistics from the DA conv epilogue - against the oracle
+    composition, and different from the plain encoder."""
+    from oracle import networks as N
+    P, gen_mod, K = pkg("params"), pkg("generator"), pkg("kernels")
+    w = P.init_params(P.generator_spec(), 0)
+    rng = np.random.default_rng(5)
+    x = rng.uniform(0, 1, (2, 32, 128, 3)).astype(np.float32)
+    ref = N.gen_encode({k: torch.from_numpy(v) for k, v in w.items()}, torch.from_numpy(x), distortion_aware=True)
+    g = gen_mod.model(weights=w, device=dev, compute=K.BF16X3, distortion_aware=True)
+    got = g.encode(torch.from_numpy(x).to(dev))
+    assert_close(got, ref, 1e-3, "distortion-aware res stack")
+    plain = gen_mod.model(weights=w, device=dev, compute=K.BF16X3).encode(torch.from_numpy(x).to(dev))
+    assert float((plain - got).abs().max()) > 1e-2 * float(got.abs().max())
+    # statistics partials of the DA conv epilogue == statistics of its output
+    xin = torch.from_numpy(rng.standard_normal((3, 8, 32, 128)).astype(np.float32)).to(dev)
+    y, st = K.da_conv2d(xin, g.nets.pk["gen.res.0.conv1"], g.nets.gen["res.0.conv1.b"], g.nets.da_offsets(8, 32), K.BF16X3,
+                        want_stats=True)
+    s = st.part.sum(dim=1)
+    assert_close(s[:, 0], y.sum(dim=(1, 2)), 1e-4, "sum partials")
+    assert_close(s[:, 1], (y * y).sum(dim=(1, 2)), 1e-4, "sumsq partials")
