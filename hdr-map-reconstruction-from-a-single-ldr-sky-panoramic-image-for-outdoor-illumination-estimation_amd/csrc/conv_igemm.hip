@@ -367,7 +367,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? 4 :
       constexpr int DPF = (NI == 1) ? 8 : 4;
       const uint4* wlh = a.whi + (size_t)kq * a.Npad + n0 + (wn * NI) * 16 + lr;
       const uint4* wll = PRECISE ? a.wlo + (size_t)kq * a.Npad + n0 + (wn * NI) * 16 + lr : nullptr;
-      const size_t kstride = (size_t)4 * a.Npad;
+      const unsigned kstride = 4u * (unsigned)a.Npad;   // uint4 elements per k-step; 32-bit offsets: the packed filter is < 2^32 elements
       uint4 bqh[DPF][NI], bql[DPF][NI];
       auto kp_of = [&](int ks) {
         const int kc = min(ks, a.ksg - 1);
@@ -375,46 +375,60 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? 4 :
       };
 #pragma unroll
       for (int j = 0; j < DPF; ++j) {
-        const size_t o = (size_t)kp_of(j) * kstride;
+        const unsigned o = (unsigned)kp_of(j) * kstride;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
           bqh[j][ni] = wlh[o + ni * 16];
           if (PRECISE) bql[j][ni] = wll[o + ni * 16];
         }
       }
+      // A fragments are read from LDS one k-step ahead (two register sets, selected by the unrolled step's parity), so
+      // the read latency overlaps the MFMAs of the current step instead of preceding them.
+      auto aoff_of = [&](int ks) {
+        if (NARROW) {
+          const int tap = min(ks * 4 + kq, a.ntaps - 1);
+          const int ky = (tap * a.kw_magic) >> 16;
+          return (ky * a.WT + (tap - ky * a.KW)) * 16;
+        }
+        const int tap = ks >> a.log2cbg, cb = ks & ((1 << a.log2cbg) - 1);
+        const int ky = (tap * a.kw_magic) >> 16;
+        return (ky * a.WT + (tap - ky * a.KW) + cb * 4 * a.NPIXP) * 16;
+      };
+      uint4 ah[2][MI], al[2][MI];
+      {
+        const int aoff = aoff_of(0);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          ah[0][mi] = *reinterpret_cast<const uint4*>(smem + abase[mi] + aoff);
+          if (PRECISE) al[0][mi] = *reinterpret_cast<const uint4*>(smem + a.off_alo + abase[mi] + aoff);
+        }
+      }
+      static_assert((DPF & 1) == 0, "the register set of a step is chosen by its parity");
       for (int ks0 = 0; ks0 < a.ksg; ks0 += DPF) {
         const bool full = ks0 + DPF <= a.ksg;
 #pragma unroll
         for (int j = 0; j < DPF; ++j) {
           const int ks = ks0 + j;
           if (full || ks < a.ksg) {
-            int aoff;
-            if (NARROW) {
-              const int tap = min(ks * 4 + kq, a.ntaps - 1);
-              const int ky = (tap * a.kw_magic) >> 16;
-              aoff = (ky * a.WT + (tap - ky * a.KW)) * 16;
-            } else {
-              const int tap = ks >> a.log2cbg, cb = ks & ((1 << a.log2cbg) - 1);
-              const int ky = (tap * a.kw_magic) >> 16;
-              aoff = (ky * a.WT + (tap - ky * a.KW) + cb * 4 * a.NPIXP) * 16;
-            }
-            uint4 ah[MI], al[MI];
+            if (ks + 1 < a.ksg) {
+              const int aoff = aoff_of(ks + 1);
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-              ah[mi] = *reinterpret_cast<const uint4*>(smem + abase[mi] + aoff);
-              if (PRECISE) al[mi] = *reinterpret_cast<const uint4*>(smem + a.off_alo + abase[mi] + aoff);
+              for (int mi = 0; mi < MI; ++mi) {
+                ah[(j + 1) & 1][mi] = *reinterpret_cast<const uint4*>(smem + abase[mi] + aoff);
+                if (PRECISE) al[(j + 1) & 1][mi] = *reinterpret_cast<const uint4*>(smem + a.off_alo + abase[mi] + aoff);
+              }
             }
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
               for (int ni = 0; ni < NI; ++ni) {
                 if (PRECISE) {
-                  acc[mi][ni] = mfma16(al[mi], bqh[j][ni], acc[mi][ni]);
-                  acc[mi][ni] = mfma16(ah[mi], bql[j][ni], acc[mi][ni]);
+                  acc[mi][ni] = mfma16(al[j & 1][mi], bqh[j][ni], acc[mi][ni]);
+                  acc[mi][ni] = mfma16(ah[j & 1][mi], bql[j][ni], acc[mi][ni]);
                 }
-                acc[mi][ni] = mfma16(ah[mi], bqh[j][ni], acc[mi][ni]);
+                acc[mi][ni] = mfma16(ah[j & 1][mi], bqh[j][ni], acc[mi][ni]);
               }
-            const size_t o = (size_t)kp_of(ks + DPF) * kstride;  // clamped at the end: surplus loads are unused
+            const unsigned o = (unsigned)kp_of(ks + DPF) * kstride;  // clamped at the end: surplus loads are unused
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
               bqh[j][ni] = wlh[o + ni * 16];
