@@ -15,6 +15,8 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -42,7 +44,7 @@ struct ConvKArgs {
   int tiles_x, tiles_y, nblocks;
   int cgs, log2nq, ngroups, ksg, log2cbg, ntaps, kzero;
   int HT, WT, NPIX, NPIXP, wt_magic, kw_magic;
-  int off_alo, off_b, off_ss, off_tap, off_stat;
+  int off_alo, off_b, off_ss, off_tap, off_stat, off_ktab;
   unsigned long long* stamps;  // debug: per-workgroup phase time stamps (null in production)
 };
 
@@ -161,6 +163,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? 4 :
   float* sShift = sScale + a.Cin;
   int* sTap = reinterpret_cast<int*>(smem + a.off_tap);
   float* sStat = reinterpret_cast<float*>(smem + a.off_stat);
+  int2* sKtab = reinterpret_cast<int2*>(smem + a.off_ktab);   // direct-B loop: per k-step {A offset of the next step, filter refill offset}
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -187,6 +190,22 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? 4 :
   HDRSKY_STAMP(0)
   // ---- prologue: tap offset table + input transform tables (identity when in_mode == NONE) ----
   for (int t = tid; t < a.ntaps; t += NT) sTap[t] = (t / a.KW) * a.WT + (t % a.KW);
+  if (DB && !NARROW) {
+    // k-step table of the direct-B main loop (channel group 0; a group only shifts the filter base): entry ks holds the
+    // LDS byte offset of the A fragments of step ks+1 and the packed-filter element offset of step ks+DPF, both clamped
+    // to the last step.  The loop then needs no scalar index arithmetic: one LDS read per DPF steps + v_readlane.
+    constexpr int DPFT = (NI == 1) ? 8 : 4;
+    const int cbm = (1 << a.log2cbg) - 1, cin32t = a.Cin >> 5;
+    const int nent = (a.ksg + DPFT - 1) / DPFT * DPFT;
+    for (int i = tid; i < nent; i += NT) {
+      const int ka = min(i + 1, a.ksg - 1), kb = min(i + DPFT, a.ksg - 1);
+      const int tap = ka >> a.log2cbg, cb = ka & cbm;
+      const int ky = (tap * a.kw_magic) >> 16;
+      const int aoff = (ky * a.WT + (tap - ky * a.KW) + cb * 4 * a.NPIXP) * 16;
+      const int kp = (kb >> a.log2cbg) * cin32t + (kb & cbm);
+      sKtab[i] = int2{aoff, kp * 4 * a.Npad};
+    }
+  }
   if (a.in_mode == HDRSKY_IN_AFFINE) {
     for (int c = tid; c < a.Cin; c += NT) {
       sScale[c] = a.in_scale[b * a.ss_bstride + c];
@@ -382,57 +401,108 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? 4 :
           if (PRECISE) bql[j][ni] = wll[o + ni * 16];
         }
       }
-      // A fragments are read from LDS one k-step ahead (two register sets, selected by the unrolled step's parity), so
-      // the read latency overlaps the MFMAs of the current step instead of preceding them.
-      auto aoff_of = [&](int ks) {
-        if (NARROW) {
-          const int tap = min(ks * 4 + kq, a.ntaps - 1);
-          const int ky = (tap * a.kw_magic) >> 16;
-          return (ky * a.WT + (tap - ky * a.KW)) * 16;
-        }
-        const int tap = ks >> a.log2cbg, cb = ks & ((1 << a.log2cbg) - 1);
-        const int ky = (tap * a.kw_magic) >> 16;
-        return (ky * a.WT + (tap - ky * a.KW) + cb * 4 * a.NPIXP) * 16;
-      };
-      uint4 ah[2][MI], al[2][MI];
-      {
-        const int aoff = aoff_of(0);
+      if constexpr (!NARROW) {
+        // Table-driven form (see the prologue): per group of DPF k-steps one LDS read fetches the A offsets of the next
+        // steps and the filter refill offsets, v_readlane turns them into scalars - no tap / channel-block arithmetic,
+        // no 64-bit index products in the loop (the generic form below spent ~30 scalar instructions per k-step on
+        // them, against two MFMAs; the scalar unit serves a SIMD every fourth cycle).  A fragments are read one k-step
+        // ahead into the register set of the step's parity.
+        const uint4* wgh = wlh + (size_t)(g << a.log2cbg) * kstride;
+        const uint4* wgl = PRECISE ? wll + (size_t)(g << a.log2cbg) * kstride : nullptr;
+        uint4 ah[2][MI], al[2][MI];
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          ah[0][mi] = *reinterpret_cast<const uint4*>(smem + abase[mi] + aoff);
-          if (PRECISE) al[0][mi] = *reinterpret_cast<const uint4*>(smem + a.off_alo + abase[mi] + aoff);
+        for (int mi = 0; mi < MI; ++mi) {   // step 0: tap 0, channel block 0 = offset 0
+          ah[0][mi] = *reinterpret_cast<const uint4*>(smem + abase[mi]);
+          if (PRECISE) al[0][mi] = *reinterpret_cast<const uint4*>(smem + a.off_alo + abase[mi]);
         }
-      }
-      static_assert((DPF & 1) == 0, "the register set of a step is chosen by its parity");
-      for (int ks0 = 0; ks0 < a.ksg; ks0 += DPF) {
-        const bool full = ks0 + DPF <= a.ksg;
+        static_assert((DPF & 1) == 0, "the register set of a step is chosen by its parity");
+        auto group = [&](int ks0, auto checked) {
+          const int2 tv = sKtab[ks0 + (lane & (DPF - 1))];
+          const int rem = a.ksg - ks0;
 #pragma unroll
-        for (int j = 0; j < DPF; ++j) {
-          const int ks = ks0 + j;
-          if (full || ks < a.ksg) {
-            if (ks + 1 < a.ksg) {
-              const int aoff = aoff_of(ks + 1);
+          for (int j = 0; j < DPF; ++j) {
+            if (!decltype(checked)::value || j < rem) {
+              const int aoff = __builtin_amdgcn_readlane(tv.x, j);
+              const unsigned o = (unsigned)__builtin_amdgcn_readlane(tv.y, j);
 #pragma unroll
               for (int mi = 0; mi < MI; ++mi) {
                 ah[(j + 1) & 1][mi] = *reinterpret_cast<const uint4*>(smem + abase[mi] + aoff);
                 if (PRECISE) al[(j + 1) & 1][mi] = *reinterpret_cast<const uint4*>(smem + a.off_alo + abase[mi] + aoff);
               }
-            }
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
+              for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-              for (int ni = 0; ni < NI; ++ni) {
-                if (PRECISE) {
-                  acc[mi][ni] = mfma16(al[j & 1][mi], bqh[j][ni], acc[mi][ni]);
-                  acc[mi][ni] = mfma16(ah[j & 1][mi], bql[j][ni], acc[mi][ni]);
+                for (int ni = 0; ni < NI; ++ni) {
+                  if (PRECISE) {
+                    acc[mi][ni] = mfma16(al[j & 1][mi], bqh[j][ni], acc[mi][ni]);
+                    acc[mi][ni] = mfma16(ah[j & 1][mi], bql[j][ni], acc[mi][ni]);
+                  }
+                  acc[mi][ni] = mfma16(ah[j & 1][mi], bqh[j][ni], acc[mi][ni]);
                 }
-                acc[mi][ni] = mfma16(ah[j & 1][mi], bqh[j][ni], acc[mi][ni]);
-              }
-            const unsigned o = (unsigned)kp_of(ks + DPF) * kstride;  // clamped at the end: surplus loads are unused
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-              bqh[j][ni] = wlh[o + ni * 16];
-              if (PRECISE) bql[j][ni] = wll[o + ni * 16];
+              for (int ni = 0; ni < NI; ++ni) {   // refill with step ks+DPF (clamped in the table: surplus loads are unused)
+                bqh[j][ni] = wgh[o + ni * 16];
+                if (PRECISE) bql[j][ni] = wgl[o + ni * 16];
+              }
+            }
+          }
+        };
+        int ks0 = 0;
+        for (; ks0 + DPF <= a.ksg; ks0 += DPF) group(ks0, std::false_type{});
+        if (ks0 < a.ksg) group(ks0, std::true_type{});
+      } else {
+        // A fragments are read from LDS one k-step ahead (two register sets, selected by the unrolled step's parity), so
+        // the read latency overlaps the MFMAs of the current step instead of preceding them.
+        auto aoff_of = [&](int ks) {
+          if (NARROW) {
+            const int tap = min(ks * 4 + kq, a.ntaps - 1);
+            const int ky = (tap * a.kw_magic) >> 16;
+            return (ky * a.WT + (tap - ky * a.KW)) * 16;
+          }
+          const int tap = ks >> a.log2cbg, cb = ks & ((1 << a.log2cbg) - 1);
+          const int ky = (tap * a.kw_magic) >> 16;
+          return (ky * a.WT + (tap - ky * a.KW) + cb * 4 * a.NPIXP) * 16;
+        };
+        uint4 ah[2][MI], al[2][MI];
+        {
+          const int aoff = aoff_of(0);
+  #pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            ah[0][mi] = *reinterpret_cast<const uint4*>(smem + abase[mi] + aoff);
+            if (PRECISE) al[0][mi] = *reinterpret_cast<const uint4*>(smem + a.off_alo + abase[mi] + aoff);
+          }
+        }
+        static_assert((DPF & 1) == 0, "the register set of a step is chosen by its parity");
+        for (int ks0 = 0; ks0 < a.ksg; ks0 += DPF) {
+          const bool full = ks0 + DPF <= a.ksg;
+  #pragma unroll
+          for (int j = 0; j < DPF; ++j) {
+            const int ks = ks0 + j;
+            if (full || ks < a.ksg) {
+              if (ks + 1 < a.ksg) {
+                const int aoff = aoff_of(ks + 1);
+  #pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                  ah[(j + 1) & 1][mi] = *reinterpret_cast<const uint4*>(smem + abase[mi] + aoff);
+                  if (PRECISE) al[(j + 1) & 1][mi] = *reinterpret_cast<const uint4*>(smem + a.off_alo + abase[mi] + aoff);
+                }
+              }
+  #pragma unroll
+              for (int mi = 0; mi < MI; ++mi)
+  #pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                  if (PRECISE) {
+                    acc[mi][ni] = mfma16(al[j & 1][mi], bqh[j][ni], acc[mi][ni]);
+                    acc[mi][ni] = mfma16(ah[j & 1][mi], bql[j][ni], acc[mi][ni]);
+                  }
+                  acc[mi][ni] = mfma16(ah[j & 1][mi], bqh[j][ni], acc[mi][ni]);
+                }
+              const unsigned o = (unsigned)kp_of(ks + DPF) * kstride;  // clamped at the end: surplus loads are unused
+  #pragma unroll
+              for (int ni = 0; ni < NI; ++ni) {
+                bqh[j][ni] = wlh[o + ni * 16];
+                if (PRECISE) bql[j][ni] = wll[o + ni * 16];
+              }
             }
           }
         }
@@ -673,6 +743,8 @@ int launch_conv(ConvKArgs& a, hipStream_t stream) {
   // the stat scratch
   const int out_bytes = BM * (BN + 4) * 4;
   if (out_bytes > a.off_stat) { a.off_stat = roundup(out_bytes, 16); lds = a.off_stat + NW * BN * 2 * 4; }
+  a.off_ktab = roundup(lds, 16);
+  if (DB && !NARROW) lds = a.off_ktab + (a.ksg + 8) * 8;   // k-step table of the direct-B loop
   if (lds > 160 * 1024) return HDRSKY_EUNSUPPORTED;
   auto kern = conv_igemm_kernel<WM, WN, MI, NI, TW, NARROW, PRECISE, DB>;
   static int max_lds_set = 0;
