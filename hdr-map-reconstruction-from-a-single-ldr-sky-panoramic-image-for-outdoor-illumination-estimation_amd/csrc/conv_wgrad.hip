@@ -108,6 +108,16 @@ __global__ void __launch_bounds__(NW * 64) conv_wgrad_kernel(const MultiArgs m) 
 #pragma unroll
   for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
 
+  // byte offset of each of this wave's taps inside the X' tile (wave-uniform, tile-independent): computed once instead
+  // of per (k-step, tap) in the MFMA phase, which is instruction-issue bound
+  int tapoff[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int tap = min(tgrp + NTG * t, a.ntaps - 1);
+    const int ky = (tap * a.kw_magic) >> 16, kx = tap - ky * a.KW;
+    tapoff[t] = (ky * a.WT + kx) * a.RX;
+  }
+  const int step4 = 4 * a.stride * a.RX;
   const int tile0 = chunk * a.tiles_per_wg;
   const int tile1 = min(a.ntiles, tile0 + a.tiles_per_wg);
   const int tps = a.tiles_x * a.tiles_y;            // tiles per sample
@@ -316,6 +326,7 @@ __global__ void __launch_bounds__(NW * 64) conv_wgrad_kernel(const MultiArgs m) 
     for (int r = 0; r < BM / 32; ++r) {
       const int m = r * 32 + g * 8 + q;        // this lane's row of the first 4-pixel block (second: m+4)
       const int mty = m / TW, mtx = m % TW;
+      const int xbase = ((mty * a.WT + mtx) * a.stride) * a.RX + p * 8;   // + (cih + i) * 32 + tap offset
       uint4 bh[OBH], bl[OBH];
 #pragma unroll
       for (int j = 0; j < OBH; ++j) {
@@ -332,17 +343,14 @@ __global__ void __launch_bounds__(NW * 64) conv_wgrad_kernel(const MultiArgs m) 
       for (int t = 0; t < TPW; ++t) {
         const int tap = tgrp + NTG * t;   // wave-uniform
         if (tap < a.ntaps) {
-          const int ky = (tap * a.kw_magic) >> 16, kx = tap - ky * a.KW;
-          const int xpix = (mty * a.stride + ky) * a.WT + mtx * a.stride + kx;
-          const int step4 = 4 * a.stride * a.RX;
 #pragma unroll
           for (int i = 0; i < CBH; ++i) {
-            const unsigned char* ad = sX + (size_t)xpix * a.RX + ((cih + i) * 16 + p * 4) * 2;
+            const unsigned char* ad = sX + xbase + tapoff[t] + (cih + i) * 32;
             const uint2 v0 = lds_tr(ad), v1 = lds_tr(ad + step4);
             const uint4 ah = uint4{v0.x, v0.y, v1.x, v1.y};
             uint4 al = uint4{0, 0, 0, 0};
             if (PRECISE) {
-              const unsigned char* adl = sXl + (size_t)xpix * a.RX + ((cih + i) * 16 + p * 4) * 2;
+              const unsigned char* adl = sXl + xbase + tapoff[t] + (cih + i) * 32;
               const uint2 w0 = lds_tr(adl), w1 = lds_tr(adl + step4);
               al = uint4{w0.x, w0.y, w1.x, w1.y};
             }
