@@ -256,6 +256,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? 4 :
   const int boff = ((tid % (4 * BN)) / BN) * a.Npad + n0 + (tid % BN);  // (q, n) part of the packed index
   const int cin32 = a.Cin >> 5;
   const float slope = a.in_slope;
+  const bool xf_identity = a.in_mode == HDRSKY_IN_NONE && slope == 1.f;   // staging then skips the affine + activation
 
   for (int g = 0; g < a.ngroups; ++g) {
     if (g > 0 && !DB) __syncthreads();  // everyone finished reading the previous group's planes
@@ -363,10 +364,15 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? 4 :
           for (int u = 0; u < UNR; ++u) {
             const float in[8] = {va[u].x, va[u].y, va[u].z, va[u].w, vb[u].x, vb[u].y, vb[u].z, vb[u].w};
             float v[8];
+            if (xf_identity) {   // workgroup-uniform: no producer transform (already normalised / activated input)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const float t = leaky(in[j] * sc8[j] + sh8[j], slope);
-              v[j] = ok[u] ? t : 0.f;
+              for (int j = 0; j < 8; ++j) v[j] = ok[u] ? in[j] : 0.f;
+            } else {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                const float t = leaky(in[j] * sc8[j] + sh8[j], slope);
+                v[j] = ok[u] ? t : 0.f;
+              }
             }
             uint4 hi, lo;
             pack8<PRECISE>(v, hi, lo);
