@@ -156,10 +156,14 @@ __global__ void __launch_bounds__(NW * 64) conv_wgrad_kernel(const MultiArgs m) 
     }
   }
 
+  // (tx, ty, sample) of the tile being staged and of the next one, advanced incrementally: the three runtime
+  // divisions per phase and tile they replace are ~30-instruction sequences each on this hardware
+  int ctx = 0, cty = 0, cb = 0;                 // tile `tile` (valid once tile >= tile0)
+  int ntx = tile0 % a.tiles_x, nty = (tile0 / a.tiles_x) % a.tiles_y, nb = tile0 / tps;   // tile + 1
   for (int tile = tile0 - 1; tile < tile1; ++tile) {
     // ================= stage tile `tile` from the registers filled one iteration ago =============================
     if (tile >= tile0) {
-      const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, b = tile / tps;
+      const int tx = ctx, ty = cty, b = cb;
       const int oy0 = ty * TH, ox0 = tx * TW;
       const int iy0 = oy0 * a.stride - a.pad_t, ix0 = ox0 * a.stride - a.pad_l;
       const float* tsc = sTab + (b - bfirst) * 2 * CB;
@@ -240,8 +244,7 @@ __global__ void __launch_bounds__(NW * 64) conv_wgrad_kernel(const MultiArgs m) 
     }
     // ================= issue the global loads of tile + 1 =========================================================
     if (tile + 1 < tile1) {
-      const int nt = tile + 1;
-      const int tx = nt % a.tiles_x, ty = (nt / a.tiles_x) % a.tiles_y, b = nt / tps;
+      const int tx = ntx, ty = nty, b = nb;
       const int oy0 = ty * TH, ox0 = tx * TW;
       const int iy0 = oy0 * a.stride - a.pad_t, ix0 = ox0 * a.stride - a.pad_l;
       if (UP) {
@@ -320,6 +323,8 @@ __global__ void __launch_bounds__(NW * 64) conv_wgrad_kernel(const MultiArgs m) 
         }
       }
     }
+    ctx = ntx; cty = nty; cb = nb;               // the tile loaded above is staged next
+    if (++ntx == a.tiles_x) { ntx = 0; if (++nty == a.tiles_y) { nty = 0; ++nb; } }
     if (tile < tile0) continue;
     // ================= MFMA: 4 k-steps of 32 output pixels =========================================================
 #pragma unroll 1
