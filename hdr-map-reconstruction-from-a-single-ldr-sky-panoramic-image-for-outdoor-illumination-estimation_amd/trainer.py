@@ -555,7 +555,7 @@ class Trainer:
         def _():
             K.conv2d_wgrad_multi(T["wq_dec"])
 
-        @seg("bwd_sunrad", 0)
+        @seg("bwd_sunrad", 2, ["bwd_head"])   # independent of the decoder / res-block chain: off the main stream
         def _():       # sun radiance head (generator.py:158-169, sunrad_net.py:46-70)
             R = T["sunrad"]
             xf = R["xf_out"]
