@@ -25,11 +25,12 @@ def main():
     lib.hdrsky_debug_conv_stamps.restype = None
     dev = torch.device("cuda:0")
     B = 32
-    only = sys.argv[1] if len(sys.argv) > 1 else "g.res"
+    only = sys.argv[1] if len(sys.argv) > 1 else "res 128"
     tiles = sys.argv[2].split(";") if len(sys.argv) > 2 else [""]
-    for (name, H, W, Cin, Cout, k, stride, up, xfm, stats) in LAYERS:
+    for (name, H, W, Cin, Cout, k, stride, _cnt) in LAYERS:
         if only not in name:
             continue
+        up, stats = 1, True
         x = torch.randn(B, H, W, Cin, device=dev)
         w = torch.randn(k, k, Cin, Cout, device=dev) / (k * k * Cin) ** 0.5
         pw = K.PackedConv(w, precise=False)
@@ -49,9 +50,7 @@ def main():
             lib.hdrsky_debug_conv_stamps(None)
             raw = buf.cpu().numpy()
             s = raw.reshape(-1, 8)
-            nwg = int((s[:, 0] != 0).sum()) * 2 // 3  # rows: nwg stamp rows + nwg/2 rows of inner-loop counters
-            inner = raw[nwg * 8: nwg * 8 + nwg * 4].reshape(-1, 4).astype(np.float64)
-            s = s[:nwg]
+            s = s[s[:, 0] != 0]
             d = np.stack([s[:, 1] - s[:, 0], s[:, 2] - s[:, 1], s[:, 3] - s[:, 2], s[:, 5] - s[:, 3]], 1).astype(np.float64)
             tot = (s[:, 5] - s[:, 0]).astype(np.float64)
             rt = (s[:, 7] - s[:, 6]).astype(np.float64)
@@ -61,8 +60,6 @@ def main():
                   "total %6.0f cyc = %.2f us @ %.0f MHz | kernel span %.2f us"
                   % ((name, t or "auto", len(s)) + tuple(np.median(d, 0)) + (np.median(tot), np.median(tot) / mhz, mhz, span)),
                   flush=True)
-            print("      main loop split (cycles/WG, wave 0): B-load issue %6.0f | MFMA chunk %6.0f | LDS store + load wait %6.0f | barrier %6.0f"
-                  % tuple(np.median(inner, 0)), flush=True)
 
 
 if __name__ == "__main__":
