@@ -122,14 +122,27 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
 
 // dx = dy * act'(x*scale[c]+shift[c]) * scale[c]   (BatchNorm in inference mode = constant per-channel affine;
 // scale == nullptr: plain activation backward on the ACTIVATED tensor y passed as x: dx = dy * (y > 0 ? 1 : slope))
+template <int V>   // V = 4: float4 per thread (C % 4 == 0, 16-byte aligned tensors), else 1
 __global__ void affine_act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                       const float* __restrict__ scale, const float* __restrict__ shift, float slope,
                                       size_t n, int C, float* __restrict__ dx) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+  for (size_t i = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) * V; i < n; i += (size_t)gridDim.x * blockDim.x * V) {
     const int c = (int)(i % C);
-    const float v = x[i];
-    if (scale) dx[i] = dy[i] * ((v * scale[c] + shift[c]) > 0.f ? 1.f : slope) * scale[c];
-    else dx[i] = dy[i] * (v > 0.f ? 1.f : slope);
+    float v[V], g[V], o[V];
+    if (V == 4) {
+      const float4 a = *reinterpret_cast<const float4*>(x + i), b = *reinterpret_cast<const float4*>(dy + i);
+      v[0] = a.x; v[1 % V] = a.y; v[2 % V] = a.z; v[3 % V] = a.w;
+      g[0] = b.x; g[1 % V] = b.y; g[2 % V] = b.z; g[3 % V] = b.w;
+    } else {
+      v[0] = x[i]; g[0] = dy[i];
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      if (scale) o[e] = g[e] * ((v[e] * scale[c + e] + shift[c + e]) > 0.f ? 1.f : slope) * scale[c + e];
+      else o[e] = g[e] * (v[e] > 0.f ? 1.f : slope);
+    }
+    if (V == 4) *reinterpret_cast<float4*>(dx + i) = make_float4(o[0], o[1 % V], o[2 % V], o[3 % V]);
+    else dx[i] = o[0];
   }
 }
 
@@ -777,7 +790,10 @@ int hdrsky_bn_act_bwd(const float* x, const float* dy, const float* mean, const 
 int hdrsky_affine_act_bwd(const float* x, const float* dy, const float* scale, const float* shift, float slope, size_t n,
                           int C, float* dx, void* stream) {
   if (!x || !dy || !dx) return HDRSKY_EINVAL;
-  hipLaunchKernelGGL(affine_act_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, S_(stream), x, dy, scale, shift, slope, n, C, dx);
+  const bool vec = (C & 3) == 0 && (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) |
+                                                    reinterpret_cast<uintptr_t>(dx)) & 15) == 0;
+  if (vec) hipLaunchKernelGGL(affine_act_bwd_kernel<4>, dim3(grid_for(n / 4)), dim3(256), 0, S_(stream), x, dy, scale, shift, slope, n, C, dx);
+  else hipLaunchKernelGGL(affine_act_bwd_kernel<1>, dim3(grid_for(n)), dim3(256), 0, S_(stream), x, dy, scale, shift, slope, n, C, dx);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }
