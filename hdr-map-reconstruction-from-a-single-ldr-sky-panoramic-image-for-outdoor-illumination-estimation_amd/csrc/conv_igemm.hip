@@ -44,7 +44,7 @@ struct ConvKArgs {
   int tiles_x, tiles_y, nblocks;
   int cgs, log2nq, ngroups, ksg, log2cbg, ntaps, kzero;
   int HT, WT, NPIX, NPIXP, wt_magic, kw_magic;
-  int off_alo, off_b, off_ss, off_tap, off_stat, off_ktab;
+  int off_alo, off_b, off_ss, off_tap, off_stat, off_ktab, off_out;
   unsigned long long* stamps;  // debug: per-workgroup phase time stamps (null in production)
 };
 
@@ -513,7 +513,9 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? 4 :
           }
         }
       }
-      __syncthreads();  // all waves done with the operand planes (next group restages / epilogue reuses them)
+      // all waves done with the operand planes before the next group restages them / the epilogue tile overwrites
+      // them; not needed after the last group when the epilogue tile has its own LDS (off_out != 0)
+      if (g + 1 < a.ngroups || a.off_out == 0) __syncthreads();
     } else {
       // ---- B ring: LDS double buffer; chunk ch+1 is fetched into registers at the top of iteration ch
       // and written to the other buffer after the MFMAs of chunk ch (registers are not loop-carried).
@@ -547,7 +549,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? 4 :
   HDRSKY_STAMP(3)
   // ---- epilogue: accumulators -> LDS tile [BM][BN] -> coalesced 16-byte rows ------------------------
   // (the last __syncthreads of the ring guarantees every wave is done reading the operand planes)
-  float* sOut = reinterpret_cast<float*>(smem);
+  float* sOut = reinterpret_cast<float*>(smem + a.off_out);
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -751,6 +753,10 @@ int launch_conv(ConvKArgs& a, hipStream_t stream) {
   if (out_bytes > a.off_stat) { a.off_stat = roundup(out_bytes, 16); lds = a.off_stat + NW * BN * 2 * 4; }
   a.off_ktab = roundup(lds, 16);
   if (DB && !NARROW) lds = a.off_ktab + (a.ksg + 8) * 8;   // k-step table of the direct-B loop
+  // direct-B variant: give the epilogue tile its own LDS when it fits, so that a wave that has finished its main
+  // loop can write its accumulators without waiting for the slowest wave to stop reading the operand planes
+  a.off_out = 0;
+  if (DB && roundup(lds, 16) + out_bytes <= 80 * 1024) { a.off_out = roundup(lds, 16); lds = a.off_out + out_bytes; }   // (two workgroups per CU must still fit)
   if (lds > 160 * 1024) return HDRSKY_EUNSUPPORTED;
   auto kern = conv_igemm_kernel<WM, WN, MI, NI, TW, NARROW, PRECISE, DB>;
   static int max_lds_set = 0;
