@@ -73,6 +73,25 @@ def make_batch(batch, h=32, w=128, seed=1234):
     return dict(hdr_t=hdr, ldr=ldr.astype(np.float32), sunpose_gt=gt)
 
 
+def batch_from_hdr(hdr, exposure=1.0):
+    """A training / inference batch from real HDR panoramas [B,H,W,3] (BGR, linear radiance), e.g. the reference's two
+    Radiance images: the mean normalisation of train.py:109-110 (``0.5*hdr/(mean+1e-6)``), a fixed exposure instead of
+    the random one (utils.py:86-91), the same gamma + 8-bit stand-in for CRF/JPEG as make_batch, and the vMF target
+    (train.py:42-52) centred on the brightest pixel.  Returns dict(hdr_t, ldr, sunpose_gt) of np.float32 arrays."""
+    hdr = np.asarray(hdr, np.float64)
+    b, h, w, _ = hdr.shape
+    out = np.empty_like(hdr)
+    gt = np.empty((b, h * w), np.float32)
+    for i in range(b):
+        img = 0.5 * hdr[i] / (hdr[i].mean() + 1e-6) * float(exposure)
+        out[i] = img
+        row, col = np.unravel_index(img.max(-1).argmax(), (h, w))
+        gt[i] = vmf_target(float(col), float(row), h, w)
+    out = out.astype(np.float32)
+    ldr = np.round(255.0 * np.clip(out, 0.0, 1.0) ** (1.0 / 2.2)) / 255.0
+    return dict(hdr_t=out, ldr=ldr.astype(np.float32), sunpose_gt=gt)
+
+
 def gamma_crf(n_curves=1, k=1024, gamma=2.2):
     """Stand-in for the DoRF response curves (dorfCurves.txt is not available): k samples of x^(1/gamma) on [0,1]."""
     x = np.linspace(0.0, 1.0, k)

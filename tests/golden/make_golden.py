@@ -100,8 +100,23 @@ def ops_fixture():
     np.savez_compressed(os.path.join(HERE, "ops_small.npz"), **d)
 
 
+def ref_hdr_fixture():
+    """The reference's two Radiance images (tests/golden/ref_*.hdr: data the reference holds) as inputs of the
+    restated inference graph and of one restated training step (B=2).  Outputs are this repo's oracle's."""
+    hdr_io = importlib.import_module(PKG + ".hdr_io")
+    hdr = np.stack([hdr_io.read_hdr(os.path.join(HERE, n)) for n in ("ref_1_gt.hdr", "ref_test.hdr")])
+    batch = synth.batch_from_hdr(hdr)
+    gen = params.init_params(params.generator_spec(), 0)
+    sun = params.init_params(params.sunpose_spec(), 1)
+    out = step.inference(tt(gen), tt(sun), torch.from_numpy(batch["ldr"]))
+    keep = ("y_final_gamma", "y_final_lin", "sunpose_cmf", "gamma", "beta", "sun_rad_lin", "alpha_c3")
+    np.savez_compressed(os.path.join(HERE, "ref_hdr_forward.npz"), **{k: out[k].numpy().astype(np.float32) for k in keep})
+
+
+
 if __name__ == "__main__":
     ops_fixture()
     forward_fixture()
     train_fixture()
+    ref_hdr_fixture()
     print("golden fixtures written to", HERE)
