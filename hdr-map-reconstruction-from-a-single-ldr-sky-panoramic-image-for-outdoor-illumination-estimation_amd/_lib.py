@@ -34,6 +34,16 @@ class WgradJob(ctypes.Structure):
                                        ("x", "dy", "in_scale", "in_shift", "in_part", "in_gamma", "in_beta", "dw", "db")]
 
 
+class ResconvArgs(ctypes.Structure):
+    """Mirror of ``hdrsky_resconv_args`` (include/hdrsky.h)."""
+    _fields_ = [("B", ctypes.c_int32), ("Cin", ctypes.c_int32), ("Cout", ctypes.c_int32), ("mode", ctypes.c_int32),
+                ("slope", c_float), ("eps", c_float)] + \
+               [(n, c_void_p) for n in ("x", "w", "bias", "gamma", "beta", "res", "xhat_in", "inv_in", "y_bf16", "y_f32",
+                                        "xhat_out", "inv_out", "dgb")]
+
+
+RC_FWD, RC_BWD = 0, 1
+
 # name -> (restype, argtypes); every symbol include/hdrsky.h declares
 SIGNATURES = {
     "hdrsky_version": (ctypes.c_char_p, []),
@@ -103,6 +113,10 @@ SIGNATURES = {
     "hdrsky_rmsprop": (c_int, [P, P, P, c_size_t, c_float, c_float, c_float, c_float, P]),
     "hdrsky_rmsprop_fc": (c_int, [P, P, P, c_int, c_int, c_float, c_float, c_float, c_float, P, P, P]),
     "hdrsky_adam": (c_int, [P, P, P, P, c_size_t, c_float, c_float, c_float, c_float, c_float, P]),
+    "hdrsky_resconv_supported": (c_int, [c_int] * 6),
+    "hdrsky_resconv": (c_int, [ctypes.POINTER(ResconvArgs), P]),
+    "hdrsky_dgb_reduce": (c_int, [P, c_int, c_int, c_int, P]),
+    "hdrsky_to_bf16": (c_int, [P, P, c_size_t, P]),
 }
 
 _lib = None

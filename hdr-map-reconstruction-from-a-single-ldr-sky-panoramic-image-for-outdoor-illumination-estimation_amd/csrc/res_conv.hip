@@ -1,0 +1,426 @@
+// Sample-resident 3x3 convolution with the InstanceNorm around it fused in, for the quarter-resolution maps of the
+// generator (8 x 32 pixels, 64 or 128 channels): generator.resBlock (generator.py:26-35: conv -> tfa InstanceNorm ->
+// leaky 0.1 -> conv -> InstanceNorm -> + identity) forward, and its data-gradient chain (train.py:402).
+//
+// Why a second conv kernel: at 8 x 32 a whole sample (256 pixels x 128 channels bf16 = 64 KB) fits the 160 KB LDS of one
+// CU.  One workgroup therefore owns (sample, 16 output channels) - 32 x 8 = 256 workgroups at batch 32, one per CU -
+// and sees ALL 256 pixels of its channels, so the InstanceNorm statistics are local to the workgroup:
+//   forward : y = leaky(gamma * xhat + beta) [+ residual], xhat = (conv + bias - mean) * rstd     - finished here;
+//   backward: dc = gamma * rstd * (dz - mean(dz) - xhat * mean(dz * xhat)), dz = leaky'(.) * (dgrad conv [+ skip])
+// come out of the conv's own epilogue.  Activations travel between these kernels as FINAL bf16 tensors (exactly the
+// values the matrix cores consume), so the operand needs no transform: it is copied global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4), never through registers, and the generic kernel's per-tile statistics partials, its
+// consumer-side finalisation and the separate norm / norm-backward launches disappear.
+//
+// Work split inside the workgroup: 8 waves = the 8 image rows; a wave owns one output row (2 strips of 16 pixels) x 16
+// channels over the whole reduction:
+//   * MFMA orientation D[cout][pixel] += W[cout][k] * X[k][pixel] (v_mfma_f32_16x16x32_bf16): a lane ends up with 4
+//     consecutive channels of one pixel = 8 contiguous bytes of the NHWC bf16 output;
+//   * the three horizontal taps are NOT three shifted operand reads: each tap column kx accumulates into its own
+//     accumulator from the same ALIGNED operand fragment, and the +-1 pixel shift is applied once to the accumulators
+//     (pixels sit on the 16 lanes of a DPP row: row_shr / row_shl, the column crossing the strip boundary by row_ror
+//     from the other strip's accumulator).  The LDS image therefore needs neither halo columns nor halo rows (rows
+//     outside the image are skipped, wave-uniformly): the sample is DMA-ed 1:1, and nothing but the per-channel
+//     statistics (1 KB) is exchanged between waves - one barrier in the epilogue;
+//   * filter fragments are read from the DMA-ed 36 KB slice of the packed filter image as they are used.
+// The operand image is two planes of two 32-channel blocks; the second plane's DMA stays in flight across the barrier
+// while the first is being multiplied (counted vmcnt, raw s_barrier).
+#include <cstdio>
+
+#include "common.h"
+
+namespace {
+
+struct RcArgs {
+  hdrsky_resconv_args u;
+  int Npad, NS, log2NS;
+  unsigned long long* stamps;   // debug: per-workgroup s_memtime stamps (null in production)
+};
+
+#define RC_STAMP(k)                                                                                  \
+  if (a.stamps != nullptr && threadIdx.x == 0) {                                                     \
+    a.stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime();                            \
+    if ((k) == 0 || (k) == 6) a.stamps[(size_t)gridDim.x * 8 + (size_t)blockIdx.x * 2 + ((k) ? 1 : 0)] = __builtin_amdgcn_s_memrealtime(); \
+  }
+
+// LDS-DMA of 16 bytes per lane: LDS destination = lds_dst (wave-uniform byte address) + lane * 16.  Inline asm so that
+// the compiler's vmcnt bookkeeping does not see it (it would drain every DMA before the first ds_read): completion is
+// waited for by the explicit counted s_waitcnt below.  M0 is saved / restored inside the statement.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_zero(float v) {   // cross-lane move inside rows of 16 lanes, zero where no source lane
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {   // sum over the 16 lanes of a row, result in every lane
+  v += dpp_zero<0x121>(v);   // row_ror:1
+  v += dpp_zero<0x122>(v);   // row_ror:2
+  v += dpp_zero<0x124>(v);   // row_ror:4
+  v += dpp_zero<0x128>(v);   // row_ror:8
+  return v;
+}
+
+__device__ __forceinline__ uint2 pack4(const float (&v)[4]) {
+  return uint2{(unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16)};
+}
+__device__ __forceinline__ void unpack4(uint2 u, float (&v)[4]) {
+  v[0] = __builtin_bit_cast(float, u.x << 16); v[1] = __builtin_bit_cast(float, u.x & 0xffff0000u);
+  v[2] = __builtin_bit_cast(float, u.y << 16); v[3] = __builtin_bit_cast(float, u.y & 0xffff0000u);
+}
+
+template <int NCB>
+struct RcGeo {
+  static constexpr int NPL = NCB / 2;                  // operand planes = pipeline stages (two 32-channel blocks each)
+  static constexpr int NKS = 9 * NCB;                  // k-steps of the packed filter
+  static constexpr int PLANE = 256 * 128;              // bytes of one operand plane: 256 pixels x (2 blocks x 64 B)
+  static constexpr int OFF_W = NPL * PLANE;
+  static constexpr int OFF_STAT = OFF_W + NKS * 1024;  // [wave 8][kq 4][2][4] float
+  static constexpr int OFF_ZERO = OFF_STAT + 8 * 4 * 2 * 4 * 4;   // 2 KB of zeros: the operand rows outside the image
+  static constexpr int LDS = OFF_ZERO + 2048;
+};
+
+template <int NCB>
+__global__ void __launch_bounds__(512, 2) resconv_kernel(const RcArgs a) {
+  using G = RcGeo<NCB>;
+  constexpr int NPL = G::NPL;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const hdrsky_resconv_args& u = a.u;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // = output row of this wave
+  const int lr = lane & 15, kq = lane >> 4;
+
+  // XCD-aware order (hardware deals workgroup ids round-robin over the 8 XCDs): each XCD owns a contiguous range of
+  // (sample, channel slice) pairs, so the 8 slices of a sample pull that sample through the fabric once.  Bijective.
+  int bid;
+  {
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int qd = nwg >> 3, rm = nwg & 7;
+    bid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+  }
+  RC_STAMP(0)
+  const int b = bid >> a.log2NS, n0 = (bid & (a.NS - 1)) * 16;
+  const int Cin = NCB * 32, Cout = u.Cout;
+  const int c0 = n0 + kq * 4;                       // this lane's 4 output channels
+  const bool fwd = u.mode == HDRSKY_RC_FWD;
+  const bool norm = fwd || u.xhat_in != nullptr;
+  const bool has_res = u.res != nullptr, bwd_norm = !fwd && norm;
+
+  // ---- epilogue operands: issued first (oldest in the vector-memory queue), consumed after the main loop.  They stay
+  // raw vectors read only under the flag that loaded them (no merge with a default value: the compiler would wait for
+  // each load right here to shuffle its components) ------------------------------------------------------------------
+  // fragment i of this wave's tile = output row `wave`, pixels 16i .. 16i+15 (this lane: 16i + lr)
+  size_t eoff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) eoff[i] = ((size_t)b * 256 + wave * 32 + 16 * i + lr) * Cout + c0;
+  float4 gam_v, bet_v, inv_v, res_v[2];
+  uint2 xh_v[2];
+  if (norm) {
+    gam_v = *reinterpret_cast<const float4*>(u.gamma + c0);
+    bet_v = *reinterpret_cast<const float4*>(u.beta + c0);
+  }
+  if (has_res) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) res_v[i] = *reinterpret_cast<const float4*>(u.res + eoff[i]);
+  }
+  if (bwd_norm) {
+    inv_v = *reinterpret_cast<const float4*>(u.inv_in + (size_t)b * Cout + c0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) xh_v[i] = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(u.xhat_in) + eoff[i]);
+  }
+
+  f32x4_t acc[3][2];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) acc[kx][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  if (u.x != nullptr) {
+    reinterpret_cast<unsigned*>(smem + G::OFF_ZERO)[tid] = 0u;   // (visible after the barrier below)
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    // ---- LDS-DMA: filter slice (one 1 KB k-step fragment per instruction), then the operand planes; wave w copies
+    // image row w of each plane (4 instructions of 8 pixels x 128 bytes) ----------------------------------------------
+    {
+      const uint4* wsrc = reinterpret_cast<const uint4*>(u.w) + (size_t)kq * a.Npad + n0 + lr;
+      for (int ks = wave; ks < G::NKS; ks += 8)
+        glds16(wsrc + (size_t)ks * 4 * a.Npad, lds_base + G::OFF_W + ks * 1024);
+      const unsigned short* xb = reinterpret_cast<const unsigned short*>(u.x) + (size_t)b * 256 * Cin;
+#pragma unroll
+      for (int p = 0; p < NPL; ++p)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int i = wave * 4 + j;
+          const int pix = i * 8 + (lane >> 3);
+          const int c = (lane & 7) ^ ((pix >> 1) & 7);      // logical 16-byte chunk stored at physical chunk lane & 7
+          const int cb = 2 * p + (c >> 2);
+          glds16(xb + (size_t)pix * Cin + cb * 32 + (c & 3) * 8, lds_base + p * G::PLANE + i * 1024);
+        }
+    }
+    RC_STAMP(1)
+    // filter + plane 0 landed (this wave's share), plane 1 (its 4 youngest DMAs) may still be in flight
+    if (NPL == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    RC_STAMP(2)
+
+    // this lane's chunk of a pixel's 128 bytes: (block h, k quarter kq) swizzled by (pixel >> 1) & 7 (conflict-free
+    // ds_read_b128 over 16 consecutive pixels).  Input rows outside the image read a zero page instead of being skipped:
+    // the stage is then straight-line code (every LDS read can be issued ahead of the MFMAs that consume it) and the
+    // extra products only fall on the two border rows, whose waves would otherwise idle at the barrier.
+    const int lchunk[2] = {lr * 128 + ((0 * 4 + kq) ^ ((lr >> 1) & 7)) * 16, lr * 128 + ((1 * 4 + kq) ^ ((lr >> 1) & 7)) * 16};
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) {
+      if (p == 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+      uint4 wf[2][9], f[2][3][2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const unsigned char* wl = smem + G::OFF_W + (2 * p + h) * 1024 + lane * 16;   // k-step (tap, cb) at (tap * NCB + cb) * 1024
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+          const int r = wave - 1 + rr;                     // input row (wave-uniform); tap row ky = rr
+          const int rowoff = (r >= 0 && r < 8) ? p * G::PLANE + r * 32 * 128 : G::OFF_ZERO;
+          const int step = (r >= 0 && r < 8) ? 16 * 128 : 0;
+          f[h][rr][0] = *reinterpret_cast<const uint4*>(smem + rowoff + lchunk[h]);
+          f[h][rr][1] = *reinterpret_cast<const uint4*>(smem + rowoff + step + lchunk[h]);
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) wf[h][rr * 3 + kx] = *reinterpret_cast<const uint4*>(wl + (rr * 3 + kx) * NCB * 1024);
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            acc[kx][0] = mfma16(wf[h][rr * 3 + kx], f[h][rr][0], acc[kx][0]);
+            acc[kx][1] = mfma16(wf[h][rr * 3 + kx], f[h][rr][1], acc[kx][1]);
+          }
+    }
+  }
+  RC_STAMP(3)
+
+  // ---- horizontal taps: out[x] = P1[x] + P0[x-1] + P2[x+1].  Pixels sit on the 16 lanes of a DPP row, so the shift
+  // is a row shift of the accumulators; the column that crosses the strip boundary comes from the other strip's
+  // accumulator by a row rotation (lane 0 <- lane 15 / lane 15 <- lane 0 of the same row) ------------------------------
+  float* sStat = reinterpret_cast<float*>(smem + G::OFF_STAT);
+  float v[2][4];
+  {
+    // every DPP move is executed by ALL lanes (a lane-dependent select around it could be lowered to EXEC-masked code,
+    // and a DPP read from a disabled lane returns the bound_ctrl zero): the boundary column is blended in by a mask
+    const float m0 = (lr == 0) ? 1.f : 0.f, m15 = (lr == 15) ? 1.f : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float p0a = acc[0][0][j], p0b = acc[0][1][j], p2a = acc[2][0][j], p2b = acc[2][1][j];
+      const float l0 = dpp_zero<0x111>(p0a);                                  // strip 0: x-1, nothing left of column 0
+      const float l1 = dpp_zero<0x111>(p0b) + m0 * dpp_zero<0x121>(p0a);      // strip 1: column 16 takes column 15 (row_ror:1)
+      const float r0 = dpp_zero<0x101>(p2a) + m15 * dpp_zero<0x12F>(p2b);     // strip 0: column 15 takes column 16 (row_ror:15)
+      const float r1 = dpp_zero<0x101>(p2b);                                  // strip 1: nothing right of column 31
+      v[0][j] = acc[1][0][j] + l0 + r0;
+      v[1][j] = acc[1][1][j] + l1 + r1;
+    }
+  }
+  RC_STAMP(4)
+
+  // per-channel sums over the 256 pixels of the sample: lanes of a row (16 pixels) by DPP, the 8 waves through LDS
+  float t0[4], t1[4];
+  auto cross_wave = [&](const float (&p0)[4], const float (&p1)[4]) {
+    if (lr == 0) {
+      *reinterpret_cast<float4*>(sStat + ((wave * 4 + kq) * 2 + 0) * 4) = float4{p0[0], p0[1], p0[2], p0[3]};
+      *reinterpret_cast<float4*>(sStat + ((wave * 4 + kq) * 2 + 1) * 4) = float4{p1[0], p1[1], p1[2], p1[3]};
+    }
+    __syncthreads();
+    RC_STAMP(5)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t0[j] = t1[j] = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {   // fixed order: bit-reproducible
+      const float4 q0 = *reinterpret_cast<const float4*>(sStat + ((w * 4 + kq) * 2 + 0) * 4);
+      const float4 q1 = *reinterpret_cast<const float4*>(sStat + ((w * 4 + kq) * 2 + 1) * 4);
+      t0[0] += q0.x; t0[1] += q0.y; t0[2] += q0.z; t0[3] += q0.w;
+      t1[0] += q1.x; t1[1] += q1.y; t1[2] += q1.z; t1[3] += q1.w;
+    }
+  };
+
+  if (fwd) {
+    // ---- forward: InstanceNorm over the sample (biased variance, eps inside the root; the statistics are taken
+    // before the bias is added: the variance does not see it, the mean moves with it), activation, residual ----------
+    float s1[4], s2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s1[j] = row16_sum(v[0][j] + v[1][j]);
+      s2[j] = row16_sum(v[0][j] * v[0][j] + v[1][j] * v[1][j]);
+    }
+    cross_wave(s1, s2);
+    const float gam4[4] = {gam_v.x, gam_v.y, gam_v.z, gam_v.w}, bet4[4] = {bet_v.x, bet_v.y, bet_v.z, bet_v.w};
+    float y[2][4], xh[2][4], rstd[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float mean = t0[j] * (1.f / 256.f);
+      const float var = fmaxf(t1[j] * (1.f / 256.f) - mean * mean, 0.f);
+      rstd[j] = rsqrtf(var + u.eps);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        xh[i][j] = (v[i][j] - mean) * rstd[j];
+        y[i][j] = leaky(gam4[j] * xh[i][j] + bet4[j], u.slope);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (has_res) { y[i][0] += res_v[i].x; y[i][1] += res_v[i].y; y[i][2] += res_v[i].z; y[i][3] += res_v[i].w; }
+      if (u.y_f32 != nullptr) *reinterpret_cast<float4*>(u.y_f32 + eoff[i]) = float4{y[i][0], y[i][1], y[i][2], y[i][3]};
+      if (u.y_bf16 != nullptr) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(u.y_bf16) + eoff[i]) = pack4(y[i]);
+      if (u.xhat_out != nullptr) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(u.xhat_out) + eoff[i]) = pack4(xh[i]);
+    }
+    if (u.inv_out != nullptr && wave == 0 && lr == 0)
+      *reinterpret_cast<float4*>(u.inv_out + (size_t)b * Cout + c0) = float4{rstd[0], rstd[1], rstd[2], rstd[3]};
+    // (u.bias is never read: a per-channel constant in front of the InstanceNorm cancels exactly)
+  } else {
+    // ---- backward: g = dgrad conv [+ skip gradient]; optional InstanceNorm (+ activation) backward with the saved xhat --
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (has_res) { v[i][0] += res_v[i].x; v[i][1] += res_v[i].y; v[i][2] += res_v[i].z; v[i][3] += res_v[i].w; }
+      if (u.y_f32 != nullptr) *reinterpret_cast<float4*>(u.y_f32 + eoff[i]) = float4{v[i][0], v[i][1], v[i][2], v[i][3]};
+    }
+    if (norm) {
+      const float gam4[4] = {gam_v.x, gam_v.y, gam_v.z, gam_v.w}, bet4[4] = {bet_v.x, bet_v.y, bet_v.z, bet_v.w};
+      const float inv4[4] = {inv_v.x, inv_v.y, inv_v.z, inv_v.w};
+      float xh[2][4], s1[4], s2[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) unpack4(xh_v[i], xh[i]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const float pre = gam4[j] * xh[i][j] + bet4[j];
+          v[i][j] *= (pre > 0.f ? 1.f : u.slope);
+        }
+        s1[j] = row16_sum(v[0][j] + v[1][j]);
+        s2[j] = row16_sum(v[0][j] * xh[0][j] + v[1][j] * xh[1][j]);
+      }
+      cross_wave(s1, s2);
+      float dc[2][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float k = gam4[j] * inv4[j];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) dc[i][j] = k * (v[i][j] - t0[j] * (1.f / 256.f) - xh[i][j] * t1[j] * (1.f / 256.f));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        if (u.y_bf16 != nullptr) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(u.y_bf16) + eoff[i]) = pack4(dc[i]);
+      if (u.dgb != nullptr && wave == 0 && lr == 0) {
+        *reinterpret_cast<float4*>(u.dgb + ((size_t)b * 2 + 0) * Cout + c0) = float4{t1[0], t1[1], t1[2], t1[3]};   // d gamma
+        *reinterpret_cast<float4*>(u.dgb + ((size_t)b * 2 + 1) * Cout + c0) = float4{t0[0], t0[1], t0[2], t0[3]};   // d beta
+      }
+    } else if (u.y_bf16 != nullptr) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(u.y_bf16) + eoff[i]) = pack4(v[i]);
+    }
+  }
+  RC_STAMP(6)
+}
+
+// out[j][c] += sum_b part[j][b][which][c] in a fixed order: the (d gamma, d beta) of every norm layer of the chain in
+// one launch.  table[j] = {part ptr, dgamma ptr, dbeta ptr} (3 x int64).
+__global__ void __launch_bounds__(256) dgb_reduce_kernel(const long long* __restrict__ table, int B, int C) {
+  const long long* e = table + (size_t)blockIdx.x * 3;
+  const float* part = reinterpret_cast<const float*>(e[0]);
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    const int which = i / C, c = i % C;
+    float* dst = reinterpret_cast<float*>(e[1 + which]);
+    if (dst == nullptr) continue;
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) acc += part[((size_t)b * 2 + which) * C + c];
+    dst[c] += acc;
+  }
+}
+
+// fp32 -> bf16 copy (round to nearest even) of a contiguous tensor, 8 elements per thread
+__global__ void __launch_bounds__(256) to_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, size_t n8) {
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    const float4 a = reinterpret_cast<const float4*>(x)[2 * i], b = reinterpret_cast<const float4*>(x)[2 * i + 1];
+    const float lo[4] = {a.x, a.y, a.z, a.w}, hi[4] = {b.x, b.y, b.z, b.w};
+    const uint2 p = pack4(lo), q = pack4(hi);
+    reinterpret_cast<uint4*>(y)[i] = uint4{p.x, p.y, q.x, q.y};
+  }
+}
+
+template <int NCB>
+int launch_resconv(const RcArgs& a, hipStream_t stream) {
+  auto kern = resconv_kernel<NCB>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RcGeo<NCB>::LDS) != hipSuccess)
+      return HDRSKY_ELAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.u.B * a.NS), dim3(512), RcGeo<NCB>::LDS, stream, a);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+}  // namespace
+
+static unsigned long long* g_rc_stamps = nullptr;
+
+extern "C" {
+
+/* debug only: per-workgroup s_memtime stamps of subsequent hdrsky_resconv launches (8 x u64 per workgroup, then 2 x u64
+ * s_memrealtime per workgroup); null disables */
+void hdrsky_debug_resconv_stamps(void* buf) { g_rc_stamps = (unsigned long long*)buf; }
+
+int hdrsky_resconv_supported(int H, int W, int Cin, int Cout, int KH, int KW) {
+  const int ns = Cout / 16;
+  return (H == 8 && W == 32 && (Cin == 64 || Cin == 128) && Cout > 0 && (Cout % 16) == 0 && (ns & (ns - 1)) == 0 && KH == 3 &&
+          KW == 3) ? 1 : 0;
+}
+
+int hdrsky_resconv(const hdrsky_resconv_args* args, void* stream) {
+  if (!args) return HDRSKY_EINVAL;
+  const hdrsky_resconv_args& u = *args;
+  if (u.B <= 0 || !hdrsky_resconv_supported(8, 32, u.Cin, u.Cout, 3, 3)) return HDRSKY_EUNSUPPORTED;
+  if (u.mode != HDRSKY_RC_FWD && u.mode != HDRSKY_RC_BWD) return HDRSKY_EINVAL;
+  if (u.x != nullptr && u.w == nullptr) return HDRSKY_EINVAL;
+  if (u.x == nullptr && (u.mode == HDRSKY_RC_FWD || u.res == nullptr)) return HDRSKY_EINVAL;   // no-conv form: norm backward of `res`
+  if (u.mode == HDRSKY_RC_FWD && (!u.gamma || !u.beta)) return HDRSKY_EINVAL;
+  if (u.mode == HDRSKY_RC_BWD && u.xhat_in != nullptr && (!u.gamma || !u.beta || !u.inv_in)) return HDRSKY_EINVAL;
+  RcArgs a{};
+  a.u = u;
+  a.Npad = roundup(u.Cout, 64);
+  a.NS = u.Cout / 16;
+  a.log2NS = 0;
+  while ((1 << a.log2NS) < a.NS) ++a.log2NS;
+  if ((1 << a.log2NS) != a.NS) return HDRSKY_EUNSUPPORTED;   // channel slices per sample: a power of two
+  a.stamps = g_rc_stamps;
+  return u.Cin == 128 ? launch_resconv<4>(a, (hipStream_t)stream) : launch_resconv<2>(a, (hipStream_t)stream);
+}
+
+int hdrsky_dgb_reduce(const void* table, int nlayers, int B, int C, void* stream) {
+  if (!table || nlayers <= 0 || B <= 0 || C <= 0) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(dgb_reduce_kernel, dim3(nlayers), dim3(256), 0, (hipStream_t)stream, (const long long*)table, B, C);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_to_bf16(const float* x, void* y, size_t n, void* stream) {
+  if (!x || !y || (n & 7)) return HDRSKY_EINVAL;
+  const size_t n8 = n / 8;
+  if (n8 == 0) return HDRSKY_OK;
+  const size_t blocks = (n8 + 255) / 256;
+  hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, (hipStream_t)stream, x,
+                     (unsigned short*)y, n8);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+}  // extern "C"

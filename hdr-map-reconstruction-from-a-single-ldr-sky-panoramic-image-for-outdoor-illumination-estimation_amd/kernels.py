@@ -677,6 +677,119 @@ def rmsprop_fc(w, g, ms, pf, lr, rho=0.9, eps=1e-7, gscale=1.0):
 
 
 # ------------------------------------------------------------------------------------------------
+# sample-resident 3x3 conv + InstanceNorm (csrc/res_conv.hip): the res-block chain on bf16 activations
+# ------------------------------------------------------------------------------------------------
+def _bf16(t, *shape):
+    if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous()):
+        raise ValueError("expected a contiguous CUDA bfloat16 tensor")
+    if shape and tuple(t.shape) != tuple(shape):
+        raise ValueError("shape %s != expected %s" % (tuple(t.shape), tuple(shape)))
+    return t
+
+
+def resconv_supported(H, W, Cin, Cout, KH=3, KW=3):
+    return bool(L.load().hdrsky_resconv_supported(H, W, Cin, Cout, KH, KW))
+
+
+def to_bf16(x, out=None):
+    """bf16 copy (round to nearest even) of a contiguous fp32 tensor: entry of a bf16 activation chain."""
+    _f32(x)
+    y = out if out is not None else torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    _bf16(y, *x.shape)
+    L.check(L.load().hdrsky_to_bf16(_p(x), _p(y), x.numel(), _stream()), "to_bf16")
+    return y
+
+
+def resconv_fwd(x, pw: PackedConv, bias, gamma, beta, slope, residual=None, want_bf16=True, want_f32=False,
+                save=False, eps=IN_EPS):
+    """One half of generator.resBlock.call (generator.py:26-35) in one launch:
+    y = leaky(InstanceNorm(conv3x3(x) + bias), slope) [+ residual].  x: bf16 [B,8,32,Cin] final activations.
+    Returns dict(bf16=, f32=, xhat=, inv=): the output as bf16 / fp32 and - save=True - what the backward launch
+    re-reads (bf16 normalised pre-activation, rstd [B,Cout])."""
+    B, H, W, Cin = x.shape
+    _bf16(x)
+    Cout = pw.Cout
+    if pw.Cin != Cin or (pw.KH, pw.KW) != (3, 3) or pw.flip or not resconv_supported(H, W, Cin, Cout):
+        raise ValueError("resconv_fwd: unsupported layer")
+    a = L.ResconvArgs()
+    a.B, a.Cin, a.Cout, a.mode, a.slope, a.eps = B, Cin, Cout, L.RC_FWD, float(slope), float(eps)
+    out = {}
+    if want_bf16:
+        out["bf16"] = torch.empty((B, H, W, Cout), dtype=torch.bfloat16, device=x.device)
+    if want_f32:
+        out["f32"] = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
+    if save:
+        out["xhat"] = torch.empty((B, H, W, Cout), dtype=torch.bfloat16, device=x.device)
+        out["inv"] = torch.empty((B, Cout), dtype=torch.float32, device=x.device)
+    if residual is not None:
+        _f32(residual, B, H, W, Cout)
+    if bias is not None:
+        _f32(bias, Cout)
+    a.x, a.w, a.bias, a.gamma, a.beta, a.res = _p(x), _p(pw.hi), _p(bias), _p(_f32(gamma, Cout)), _p(_f32(beta, Cout)), _p(residual)
+    a.y_bf16, a.y_f32, a.xhat_out, a.inv_out = _p(out.get("bf16")), _p(out.get("f32")), _p(out.get("xhat")), _p(out.get("inv"))
+    L.check(L.load().hdrsky_resconv(a, _stream()), "resconv (fwd)")
+    return out
+
+
+def resconv_bwd(dy, pwT, skip=None, norm=None, want_f32=False, want_bf16=True, shape=None):
+    """Data gradient of a 3x3 conv on the 8x32 maps fused with what follows it in the backward chain:
+    g = conv3x3(dy; flipped filter pwT) [+ skip]                (fp32, returned when want_f32: the residual stream's gradient)
+    norm = dict(xhat=, inv=, gamma=, beta=, slope=, dgb=): then the gradient through leaky(InstanceNorm(.)) whose forward
+    launch saved xhat / inv:  dc = gamma*inv*(dz - mean(dz) - xhat*mean(dz*xhat)), dz = g*leaky'(gamma*xhat+beta), written
+    as bf16 (the next data gradient's operand) and dgb[B,2,C] receives the per-sample (d gamma, d beta) terms.
+    dy=None (then skip is required): no convolution - the norm backward of `skip` alone (entry of the chain)."""
+    if dy is not None:
+        _bf16(dy)
+        B, H, W, Cin = dy.shape
+        if pwT.Cin != Cin or (pwT.KH, pwT.KW) != (3, 3) or not pwT.flip:
+            raise ValueError("resconv_bwd: needs the transpose_flip image of a 3x3 filter matching dy")
+        Cout = pwT.Cout
+    else:
+        B, H, W, Cout = skip.shape
+        Cin = Cout
+    if not resconv_supported(H, W, Cin, Cout):
+        raise ValueError("resconv_bwd: unsupported layer")
+    a = L.ResconvArgs()
+    a.B, a.Cin, a.Cout, a.mode, a.eps = B, Cin, Cout, L.RC_BWD, IN_EPS
+    a.slope = float(norm["slope"]) if norm else 1.0
+    out = {}
+    if want_bf16:
+        out["bf16"] = torch.empty((B, H, W, Cout), dtype=torch.bfloat16, device=(dy if dy is not None else skip).device)
+    if want_f32:
+        out["f32"] = torch.empty((B, H, W, Cout), dtype=torch.float32, device=(dy if dy is not None else skip).device)
+    if skip is not None:
+        _f32(skip, B, H, W, Cout)
+    a.x, a.w, a.res = _p(dy), _p(pwT.hi) if dy is not None else None, _p(skip)
+    if norm:
+        _bf16(norm["xhat"], B, H, W, Cout); _f32(norm["inv"], B, Cout)
+        a.xhat_in, a.inv_in = _p(norm["xhat"]), _p(norm["inv"])
+        a.gamma, a.beta = _p(_f32(norm["gamma"], Cout)), _p(_f32(norm["beta"], Cout))
+        if norm.get("dgb") is not None:
+            a.dgb = _p(_f32(norm["dgb"], B, 2, Cout))
+    a.y_bf16, a.y_f32 = _p(out.get("bf16")), _p(out.get("f32"))
+    L.check(L.load().hdrsky_resconv(a, _stream()), "resconv (bwd)")
+    return out
+
+
+class DgbReducer:
+    """One-launch, fixed-order reduction of the per-sample (d gamma, d beta) terms of several norm layers
+    (hdrsky_dgb_reduce): entries = [(dgb [B,2,C], dgamma [C], dbeta [C]), ...] (gradients are added to)."""
+
+    def __init__(self, entries):
+        self.B, _, self.C = entries[0][0].shape
+        rows = []
+        for dgb, dg, db in entries:
+            _f32(dgb, self.B, 2, self.C); _f32(dg, self.C); _f32(db, self.C)
+            rows.append([dgb.data_ptr(), dg.data_ptr(), db.data_ptr()])
+        self.n = len(rows)
+        self.table = torch.tensor(rows, dtype=torch.int64, device=entries[0][0].device)
+        self._keep = entries
+
+    def run(self):
+        L.check(L.load().hdrsky_dgb_reduce(_p(self.table), self.n, self.B, self.C, _stream()), "dgb_reduce")
+
+
+# ------------------------------------------------------------------------------------------------
 # distortion-aware convolution (csrc/da_conv.hip)
 # ------------------------------------------------------------------------------------------------
 def adam(w, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-7, gscale=1.0):

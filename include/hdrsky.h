@@ -330,6 +330,52 @@ int hdrsky_da_conv2d_fwd(const float* x, const void* w_hi, const void* w_lo, con
 int hdrsky_da_gather(const float* x, const float* offs, int B, int H, int W, int C, int ksize, float* G, void* stream);
 int hdrsky_da_scatter(const float* dG, const float* offs, int B, int H, int W, int C, int ksize, float* dx, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Sample-resident 3x3 convolution with the InstanceNormalization around it fused in (csrc/res_conv.hip).
+ * Replaces, for the 8 x 32-pixel maps of the 32 x 128 configuration, one half of generator.resBlock.call
+ * (generator.py:26-35: `ops.conv2d` -> tfa InstanceNormalization -> tf.nn.leaky_relu(0.1) | -> tf.add(identity)) in
+ * ONE launch, and in the backward pass (train.py:402, tape.gradient through those lines) the data gradient of the conv
+ * together with the gradient through the normalisation (and activation) in front of it.  Tensors that travel between
+ * these launches are FINAL bf16 activations [B,8,32,C] (the values the matrix cores consume; compute mode
+ * HDRSKY_BF16 only) - the residual stream and its gradient stay fp32.
+ * ---------------------------------------------------------------------------------------- */
+#define HDRSKY_RC_FWD 0
+#define HDRSKY_RC_BWD 1
+typedef struct hdrsky_resconv_args {
+  int32_t B, Cin, Cout;  /* x [B,8,32,Cin] bf16 (Cin 64 or 128), outputs [B,8,32,Cout], Cout % 16 == 0 */
+  int32_t mode;          /* HDRSKY_RC_FWD | HDRSKY_RC_BWD */
+  float slope;           /* leaky slope of the activation behind the norm (1 = none, 0 = relu) */
+  float eps;             /* variance epsilon (1e-3 for tfa InstanceNormalization) */
+  const void* x;         /* conv operand, bf16, final values (no transform).  NULL (BWD only): no convolution, the
+                          * "conv result" is zero and `res` alone is differentiated through the norm */
+  const void* w;         /* hi plane of hdrsky_conv_pack_weights(3,3,Cin,Cout) (transpose_flip=1 image for BWD) */
+  const float* bias;     /* FWD: the conv bias [Cout] or NULL - accepted and NOT read: a per-channel constant in front of
+                          * an InstanceNormalization cancels exactly (its gradient is zero for the same reason) */
+  const float* gamma;    /* [Cout] scale / offset of the norm: FWD required; BWD when xhat_in != NULL */
+  const float* beta;
+  const float* res;      /* fp32 [B,8,32,Cout] or NULL.  FWD: added after the activation (identity branch);
+                          * BWD: added to the conv result before the norm backward (gradient of the identity branch) */
+  const void* xhat_in;   /* BWD: bf16 normalised pre-activation (conv - mean) * rstd saved by the forward launch of the
+                          * norm being differentiated, or NULL = no norm behind this data gradient */
+  const float* inv_in;   /* BWD: rstd [B,Cout] saved by that forward launch */
+  void* y_bf16;          /* FWD: act(norm(conv + bias)) + res as bf16.  BWD: gradient w.r.t. the conv output in front of
+                          * the differentiated norm (or the plain data gradient when xhat_in == NULL).  Nullable */
+  float* y_f32;          /* FWD: the same value as fp32 (the residual stream).  BWD: conv result + res (the stream's
+                          * gradient, before the norm backward).  Nullable */
+  void* xhat_out;        /* FWD: bf16 normalised pre-activation for the backward pass.  Nullable */
+  float* inv_out;        /* FWD: rstd [B,Cout].  Nullable */
+  float* dgb;            /* BWD with a norm: per-sample [B][2][Cout] (d gamma, d beta) terms; reduce over B with
+                          * hdrsky_dgb_reduce.  Nullable */
+} hdrsky_resconv_args;
+/* 1 when hdrsky_resconv handles this layer geometry (8 x 32 pixels, 3x3, Cin 64|128, Cout % 16 == 0). [host] */
+int hdrsky_resconv_supported(int H, int W, int Cin, int Cout, int KH, int KW);
+int hdrsky_resconv(const hdrsky_resconv_args* args, void* stream);
+/* d gamma / d beta of `nlayers` norm layers in one launch, batch order fixed (bit-reproducible):
+ * table: device array [nlayers][3] of int64 {dgb ptr ([B][2][C]), dgamma ptr ([C], +=), dbeta ptr ([C], +=)}. */
+int hdrsky_dgb_reduce(const void* table, int nlayers, int B, int C, void* stream);
+/* y (bf16) = round-to-nearest-even(x) for n contiguous floats, n % 8 == 0: entry of a bf16 activation chain. */
+int hdrsky_to_bf16(const float* x, void* y, size_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
