@@ -4,15 +4,23 @@
   python bench.py --gpus N --steps K --warmup W            (N=1)
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the workload over one batch of 32 synthetic 32x128 sky panoramas per GPU
-(inputs resident in HBM before the timed region; the pass is replayed as hipGraphs).
-Rank 0 prints ONE JSON line (metric/value/... + "roofline" + "cpu_baseline").
+One "step" = one pass of the workload over one batch of synthetic sky panoramas per GPU (inputs resident in HBM before the
+timed region; the pass is replayed as hipGraphs).  Rank 0 prints ONE JSON line.
 
 Workloads (BASELINE.json configs):
-  train (default) = configs[2]/[3]: the full train.py step - generator + sun-pose + Grad-CAM + sun-radiance forward,
+  all (default)   = the whole BASELINE metric in one line: `train` timed first (metric / value / ms_per_step), then `fwd`
+                    (object "fwd": ms_per_step, ms_per_img, images_per_s, algorithmic_tflops), plus "roofline" (the
+                    dominant MFMA kernel timed live), "roofline_hbm" (the HBM-bound kernels timed live against 8 TB/s),
+                    "parity" (bf16 bench mode vs the fp32-class BF16X3 mode on the bench batch) and "cpu_baseline".
+  train           = configs[2]/[3]: the full train.py step - generator + sun-pose + Grad-CAM + sun-radiance forward,
                     discriminator x3, VGG16 perceptual, DoG/L1/KL/LSGAN losses, both backward passes, RMSprop x2,
                     weight re-packing - batch 32 per GPU; N > 1: data parallel, gradients all-reduced (RCCL).
   fwd             = configs[1]: generator + sun-pose net (+ Grad-CAM sweep) forward only, batch 32 (replicas).
+  hires           = configs[4] on one GPU: 128x512 panoramas, 8 per GPU - generator encoder with plain AND with
+                    distortion-aware res blocks, both decoders, blending, discriminator, VGG16 x2 and the L1 / DoG /
+                    perceptual / LSGAN loss values (forward + losses).  The faithful 128x512 sun-pose net has 12.9 G
+                    parameters: it is not part of the step; its first Dense layer is timed
+                    separately as an HBM-bound weight-streaming GEMM slice ("sunpose_fc").
 """
 import argparse
 import importlib
@@ -26,8 +34,10 @@ sys.path.insert(0, ROOT)
 PKG = "hdr-map-reconstruction-from-a-single-ldr-sky-panoramic-image-for-outdoor-illumination-estimation_amd"
 
 MFMA_PEAK_TFLOPS = 2500.0    # dense bf16, MI355X_MICROARCH.md "Chip-level parameters"
+HBM_PEAK_GBS = 8000.0        # HBM3E spec, same table (6.3 TB/s is what a float4 copy reaches)
 FWD_MFLOP_PER_IMG = 3220.3   # G + S + C (algorithmic 2*MAC of conv/dense contractions)
 TRAIN_MFLOP_PER_IMG = 16900.0  # 3(G+S) + C + 8D + 3V
+HIRES_MFLOP_PER_IMG = 2 * 16320.0 + 10900.0 + 6657.0 + 2 * 24390.0   # two encoders + decoders + discriminator + VGG x2
 
 
 def parse():
@@ -35,53 +45,115 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE configs[1..3]: 32)")
-    ap.add_argument("--workload", default="train", choices=["train", "fwd"])
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (configs[1..3]: 32, configs[4]: 8)")
+    ap.add_argument("--workload", default="all", choices=["all", "train", "fwd", "hires"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--dp-mode", default=None, help="gradient exchange of the N > 1 training step (parallel.py: MODES)")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run only the timed loop of the roofline kernel and print its object (the command behind "
-                         "profiles/r01_roofline_kernel_stats.csv: in the full run the same kernel template also "
-                         "serves other layers, beside other streams, so its rocprof average there is not this launch)")
+                         "profiles/r02_roofline_kernel_stats.csv)")
     return ap.parse_args()
 
 
-def dominant_kernel_roofline(torch, K, pw, bias, batch, h, w, iters=200):
-    """The res-block convolution (3x3, 128->128 on [B,8,32,128]: 12 forward launches + their data-gradient twins per
-    step) timed live with HIP events on the launch stream.  Algorithmic FLOPs per launch = 2*(B*8*32)*(3*3*128)*128."""
-    dev = bias.device
-    x = torch.randn(batch, h // 4, w // 4, 128, device=dev)
-    y = torch.empty_like(x)
-    for _ in range(10):
-        K.conv2d(x, pw, bias, want_stats=True, compute=K.BF16, out=y)
+def _graph_time(torch, launch, iters, warm=10):
+    """Average launch-to-launch time (us) of `launch` replayed `iters` times from one hipGraph, HIP events on the
+    launch stream."""
+    for _ in range(warm):
+        launch()
     stream = torch.cuda.current_stream()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     g = torch.cuda.CUDAGraph()
-    # thread_local: with a process group alive RCCL's watchdog thread queries events while this thread captures
     with torch.cuda.graph(g, capture_error_mode="thread_local"):
         for _ in range(iters):
-            K.conv2d(x, pw, bias, want_stats=True, compute=K.BF16, out=y)
+            launch()
     g.replay()
     torch.cuda.synchronize()
     e0.record(stream)
     g.replay()
     e1.record(stream)
     torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / iters
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def dominant_kernel_roofline(torch, K, pw, batch, h, w, iters=200):
+    """The res-block convolution (3x3, 128->128 on [B,8,32,128]: 12 forward launches + their data-gradient twins per
+    step) timed live with HIP events on the launch stream: the sample-resident launch of csrc/res_conv.hip in its
+    training-forward form (conv + InstanceNorm + leaky, bf16 activation out, xhat / rstd saved for the backward pass).
+    Algorithmic FLOPs per launch = 2*(B*8*32)*(3*3*128)*128; algorithmic bytes = x + y + xhat (bf16) + the filter."""
+    dev = pw.hi.device
+    x = torch.randn(batch, h // 4, w // 4, 128, device=dev).to(torch.bfloat16)
+    gamma, beta = torch.ones(128, device=dev), torch.zeros(128, device=dev)
+    us = _graph_time(torch, lambda: K.resconv_fwd(x, pw, None, gamma, beta, 0.1, save=True), iters)
     flop = 2.0 * (batch * (h // 4) * (w // 4)) * (9 * 128) * 128
     achieved = flop / (us * 1e-6) / 1e12
-    traffic = None   # HBM-side bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE)
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_resconv.json")
+    # HBM-side bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE): a RECORDED value
+    # (traffic_source names the file and the commit it was measured at), null when no record exists for this batch
+    traffic, source = None, None
+    pmc = os.path.join(ROOT, "profiles", "r02_pmc_resconv.json")
     if batch == 32 and os.path.exists(pmc):
         with open(pmc) as f:
-            traffic = json.load(f).get("hbm_bytes_per_launch")
-    return {"bound": "mfma", "kernel": "conv_igemm_kernel (res-block 3x3 128->128, B=%d)" % batch,
+            rec = json.load(f)
+        traffic, source = rec.get("hbm_bytes_per_launch"), "profiles/r02_pmc_resconv.json @ %s" % rec.get("commit", "?")
+    return {"bound": "mfma", "kernel": "resconv_kernel<4> (res-block 3x3 128->128 + InstanceNorm + leaky, B=%d)" % batch,
             "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / MFMA_PEAK_TFLOPS, 5), "traffic": traffic,
-            "avg_launch_us": round(us, 3), "flop_per_launch": flop}
+            "frac": round(achieved / MFMA_PEAK_TFLOPS, 5), "traffic": traffic, "traffic_source": source,
+            "avg_launch_us": round(us, 3), "flop_per_launch": flop,
+            "algorithmic_bytes": batch * 256 * 128 * 2 * 3 + 9 * 128 * 128 * 2}
 
 
-def cpu_baseline(torch, workload, nets_np, batch_np):
+def hbm_rooflines(torch, K, batch=32, iters=20):
+    """The HBM-bound kernels of the step timed live (their own tensors, hipGraph replay, HIP events): the fused Dense
+    RMSprop + bf16 re-pack, the fc1 forward weight stream and the fc1 weight-gradient write.  achieved = algorithmic
+    bytes per launch / average launch time, against the 8 TB/s HBM3E peak."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    Kd, N = 8192, 4096
+    w = torch.randn(Kd, N, device=dev) * 0.01
+    g, ms = torch.randn(Kd, N, device=dev) * 1e-3, torch.zeros(Kd, N, device=dev)
+    pf = K.PackedFC(w, precise=False)
+    x = torch.randn(batch, Kd, device=dev)
+    dy = torch.randn(batch, N, device=dev)
+    db = torch.zeros(N, device=dev)
+    rows = [
+        ("rmsprop_fc_kernel (fc1 8192x4096: w, g, ms read; w, ms, two bf16 images written)", 24 * Kd * N,
+         lambda: K.rmsprop_fc(w, g, ms, pf, 1e-4)),
+        ("fc_mfma_kernel (fc1 forward, M=%d: bf16 weights streamed once)" % batch, 2 * Kd * N + 4 * batch * (Kd + 4 * N),
+         lambda: K.fc_fwd(x, pf, K.BF16)),
+        ("fc_wgrad_kernel (fc1, M=%d: fp32 gradient written once)" % batch, 4 * Kd * N + 4 * batch * (Kd + N),
+         lambda: K.fc_wgrad(x, dy, g, db)),
+    ]
+    out = []
+    for name, nbytes, fn in rows:
+        us = _graph_time(torch, fn, iters, warm=3)
+        gbs = nbytes / (us * 1e-6) / 1e9
+        out.append({"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gbs / HBM_PEAK_GBS, 4), "avg_launch_us": round(us, 2), "algorithmic_bytes": nbytes})
+    return out
+
+
+def parity_object(torch, engine, K, gen, sun, ldr, hdr):
+    """north_star: 'output PSNR within 0.05 dB of the reference'.  The reference's own fp32 output cannot be produced
+    here, so the bench mode (HDRSKY_BF16: one bf16 MFMA product, bf16 res-chain activations) is
+    compared with the fp32-class BF16X3 mode (the one the tight oracle parity tests pin) on the bench batch:
+    psnr_bf16_vs_x3_db = PSNR of the bf16 y_final_gamma against the BF16X3 one (peak = its maximum);
+    delta_psnr_vs_target_db = PSNR(y_bf16, target) - PSNR(y_x3, target), target = log-compressed hdr_t."""
+    nets = engine.Nets(gen, sun, device=ldr.device, precise=True)
+    y16 = engine.generator_forward(nets, ldr, compute=K.BF16)["y_final_gamma"].double()
+    y3 = engine.generator_forward(nets, ldr, compute=K.BF16X3)["y_final_gamma"].double()
+    tgt = K.tonemap(hdr, False).double()
+    torch.cuda.synchronize()
+
+    def psnr(a, b, peak):
+        return float(10.0 * torch.log10(peak * peak / ((a - b) ** 2).mean()))
+    p16, p3 = psnr(y16, tgt, tgt.abs().max()), psnr(y3, tgt, tgt.abs().max())
+    return {"psnr_bf16_vs_x3_db": round(psnr(y16, y3, y3.abs().max()), 2),
+            "psnr_bf16_vs_target_db": round(p16, 4), "psnr_x3_vs_target_db": round(p3, 4),
+            "delta_psnr_vs_target_db": round(p16 - p3, 4), "within_0p05_db": bool(abs(p16 - p3) <= 0.05),
+            "images": int(ldr.shape[0]), "note": "random-init weights: the target PSNR itself is low; the DIFFERENCE between "
+            "the two compute modes is what the 0.05 dB clause bounds"}
+
+
+def cpu_baseline(torch, workload, nets_np, batch_np, budget_s=12.0):
     """CPU restatement (oracle/, NOT TensorFlow) of the same workload on this host's cores: bounded sample."""
     from oracle import step as ostep
     tt = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}
@@ -96,13 +168,103 @@ def cpu_baseline(torch, workload, nets_np, batch_np):
     fn(2)  # warm-up
     t0 = time.perf_counter()
     n = 0
-    while time.perf_counter() - t0 < 12.0:
+    while time.perf_counter() - t0 < budget_s:
         fn(ldr.shape[0])
         n += ldr.shape[0]
     dt = time.perf_counter() - t0
     return {"value": round(n / dt, 2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "%d images (batches of %d) of the same synthetic workload through %s "
                       "(torch-CPU fp32 restatement, not TF2), %.1f s" % (n, ldr.shape[0], what, dt)}
+
+
+def timed(torch, dist, one_step, steps, warmup, dp, dev):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks (seconds)."""
+    for _ in range(warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if dp:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_step()
+    torch.cuda.synchronize()
+    if dp:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dp:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    return dt
+
+
+def capture_forward(torch, fn, dp, no_graph):
+    """Warm-up on a side stream (lazy kernel attributes, allocator), then the whole pass as one hipGraph."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            out = fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    if no_graph:
+        return fn, out
+    g = torch.cuda.CUDAGraph()
+    # thread_local: RCCL's watchdog thread may query events while this thread captures
+    with torch.cuda.graph(g, capture_error_mode="thread_local" if dp else "global"):
+        out = fn()
+    return g.replay, out
+
+
+def hires_workload(torch, mods, dev, batch):
+    """configs[4] on one GPU (see the module docstring).  Returns (step function, probe tensor getter, sun-pose FC row)."""
+    params, engine, K = mods["params"], mods["engine"], mods["kernels"]
+    disc_mod, vgg_mod = mods["discriminator"], mods["vgg16"]
+    H, W = 128, 512
+    gen = params.init_params(params.generator_spec(H, W), 0)
+    nets = engine.Nets(gen, None, device=dev, precise=False, im_height=H, im_width=W)
+    g = torch.Generator(device=dev); g.manual_seed(1234)
+    ldr = torch.rand(batch, H, W, 3, device=dev, generator=g)
+    hdr = torch.rand(batch, H, W, 3, device=dev, generator=g) * 4.0
+    rad = torch.rand(batch, H, W, 3, device=dev, generator=g)
+    dis = disc_mod.model(device=dev, compute=K.BF16)
+    vgg = vgg_mod.Vgg16(weights=params.init_params(params.vgg_spec(), 3), device=dev, compute=K.BF16)
+    losses = torch.zeros(4, device=dev)
+    state = {}
+
+    def step():
+        losses.zero_()
+        res = engine.encode(nets, ldr, K.BF16)
+        res_da = engine.encode(nets, ldr, K.BF16, distortion_aware=True)
+        sky = engine.decode(nets, res, "f", ldr, K.BF16)
+        sunp = engine.decode(nets, res_da, "u", rad, K.BF16)
+        y_gamma, y_lin, _, _, _ = K.blend(sky, sunp, engine.THRESHOLD, extras=False)
+        d_fake = dis([ldr, y_lin], training=False)
+        K.mse(d_fake, 1.0, 1.0, 1.0, losses[0:1], want_grad=False)                 # LSGAN (train.py:327)
+        K.l1(y_lin, hdr, 1.0, 0.0, losses[1:2])                                   # L1 (train.py:324)
+        scratch = torch.empty_like(y_lin)
+        K.dog_loss(y_lin, hdr, 1.0, losses[2:3], scratch)                         # DoG pyramid (train.py:316-322)
+        for p, q in zip(vgg(y_gamma), vgg(K.tonemap(hdr, False))):                # perceptual (train.py:308-313)
+            K.l1(p, q, 1.0, 0.0, losses[3:4])
+        state["y"] = y_lin
+        return state
+
+    # the sun-pose net's first Dense layer at 128x512 as a weight-streaming GEMM slice: K = 16*64*128 inputs, 4096 of
+    # its 65536 outputs (1.07 GB of bf16 weights; the full layer is 16 such slices per GPU, or one per GPU when sharded)
+    Kd, N = (H // 8) * (W // 8) * 128, 4096
+    wfc = torch.randn(Kd, N, device=dev) * 0.01
+    pf = K.PackedFC(wfc, precise=False, need_dgrad=False)
+    del wfc
+    xfc = torch.randn(batch, Kd, device=dev)
+    us = _graph_time(torch, lambda: K.fc_fwd(xfc, pf, K.BF16), 10, warm=2)
+    nbytes = 2 * Kd * N
+    fc_row = {"bound": "hbm", "kernel": "fc_mfma_kernel (128x512 sun-pose fc1 slice %dx%d, M=%d)" % (Kd, N, batch),
+              "achieved": round(nbytes / (us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+              "frac": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_us": round(us, 1),
+              "algorithmic_bytes": nbytes, "slices_in_full_layer": 16}
+    return step, (lambda: state["y"]), fc_row
 
 
 def main():
@@ -131,121 +293,126 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local if dp else 0)
 
-    params = importlib.import_module(PKG + ".params")
-    synth = importlib.import_module(PKG + ".synth")
-    engine = importlib.import_module(PKG + ".engine")
-    trainer = importlib.import_module(PKG + ".trainer")
-    par = importlib.import_module(PKG + ".parallel")
-    K = importlib.import_module(PKG + ".kernels")
+    mods = {m: importlib.import_module(PKG + "." + m) for m in
+            ("params", "synth", "engine", "trainer", "parallel", "kernels", "discriminator", "vgg16")}
+    params, synth, engine, trainer, par, K = (mods[m] for m in ("params", "synth", "engine", "trainer", "parallel", "kernels"))
+    hires = args.workload == "hires"
+    batch = args.batch if args.batch is not None else (8 if hires else 32)
 
     gen = params.init_params(params.generator_spec(), 0)
-    sun = params.init_params(params.sunpose_spec(), 1)
-    dis = params.init_params(params.discriminator_spec(), 2)
-    vgg = params.init_params(params.vgg_spec(), 3)
-    batch_np = synth.make_batch(args.batch, seed=1234 + rank)
-    ldr = torch.from_numpy(batch_np["ldr"]).to(dev)
-    hdr = torch.from_numpy(batch_np["hdr_t"]).to(dev)
-    gt = torch.from_numpy(batch_np["sunpose_gt"]).to(dev)
-
     if args.roofline_only:
         w = torch.from_numpy(gen["res.0.conv1.w"]).to(dev)
-        print(json.dumps(dominant_kernel_roofline(torch, K, K.PackedConv(w, False), torch.zeros(128, device=dev),
-                                                  args.batch, 32, 128)))
+        print(json.dumps(dominant_kernel_roofline(torch, K, K.PackedConv(w, False), batch, 32, 128)))
         return
-    if args.workload == "fwd":
-        nets = engine.Nets(gen, sun, device=dev, precise=False)
-        phases = [lambda: engine.generator_forward(nets, ldr, compute=K.BF16)]
-        roof_pw, roof_b = nets.pk["gen.res.0.conv1"], nets.gen["res.0.conv1.b"]
-        probe = lambda out: out["y_final_lin"]
-    else:
-        tr = trainer.Trainer(gen, sun, dis, vgg, device=dev, precise=False, compute=K.BF16, world_size=world)
-        # One step = the Trainer's segment plan (forward, losses, both backward passes, RMSprop x2 + weight re-packing),
-        # every segment captured into its own hipGraph and replayed on its stream.  N > 1: each replica runs the
-        # reference's batch-32 step on its shard; gradients are summed over replicas (RCCL all-reduce; every loss is a
-        # batch mean, so the data-parallel gradient is the replica average: SURVEY.md section 8e) and scaled by 1/world
-        # inside the RMSprop kernel.  The all-reduce of the sun-pose Dense gradients (201 of the 233 MB) is started as
-        # soon as they are complete and runs on RCCL's stream beside the rest of the backward pass; the remaining
-        # 32 MB follow when every gradient is ready.
-        par.broadcast_params_([tr.gs.flat, tr.ds.flat])   # replicas start from rank 0's weights
-        tr.repack()
-        ex = par.GradientExchange(tr, device=dev)   # hooks on the segment plan: see parallel.py
-        hooks, pre_hooks = (ex.hooks, ex.pre_hooks) if dp else (None, None)
-        roof_pw, roof_b = tr.conv["gen.res.0.conv1"].pk, tr.gs.w["gen.res.0.conv1.b"]
-        probe = lambda out: out["y_final_lin"]
-        if args.no_graph:
-            out = tr.step(ldr, hdr, gt, update=False)
-            one_step = lambda: (tr.step(ldr, hdr, gt, update=False), dp and [ex.fc_grads_reduce(), ex.grads_ready()],
-                                tr.apply_gradients())
-        else:
-            out = tr.capture(ldr, hdr, gt)
-            one_step = lambda: tr.replay(hooks=hooks, pre_hooks=pre_hooks)
-        phases = None
-
-    if phases is not None:   # forward workload: warm-up (eager), then the whole forward captured as one hipGraph
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                out = phases[0]()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        if args.no_graph:
-            one_step = phases[0]
-        else:
-            g = torch.cuda.CUDAGraph()
-            # thread_local: RCCL's watchdog thread may query events while this thread captures
-            with torch.cuda.graph(g, capture_error_mode="thread_local" if dp else "global"):
-                out = phases[0]()
-            one_step = g.replay
-
-    for _ in range(args.warmup):
-        one_step()
-    torch.cuda.synchronize()
-    if dp:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    torch.cuda.synchronize()
-    if dp:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dp:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    assert torch.isfinite(probe(out)).all()
-
-    if rank == 0:
-        imgs = args.batch * world * args.steps
-        value = imgs / dt
-        train = args.workload == "train"
-        res = {
-            "metric": "training images/sec (32x128 sky panoramas)" if train else "generator fwd images/sec (32x128 sky panoramas)",
-            "value": round(value, 1), "unit": "images/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+    res = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "bf16"}
+    fc_row = None
+    if hires:
+        step, probe, fc_row = hires_workload(torch, mods, dev, batch)
+        one_step, out = capture_forward(torch, step, dp, args.no_graph)
+        dt = timed(torch, dist, one_step, args.steps, args.warmup, dp, dev)
+        assert torch.isfinite(probe()).all()
+        imgs = batch * world * args.steps
+        res.update({
+            "metric": "forward + losses images/sec (128x512 sky panoramas)", "value": round(imgs / dt, 1), "unit": "images/s",
             "ms_per_step": round(dt / args.steps * 1e3, 4), "ms_per_img": round(dt / imgs * world * 1e3, 6),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
-            "data": "synthetic (seeded sky-dome + sun lobe + sensor noise, random-init weights, synthetic VGG16 weights)",
-            "config": {"workload": ("BASELINE configs[2]: full train.py step (gen + sunpose + disc + VGG16 perceptual + "
-                                    "tone-map/DoG/L1/KL/LSGAN losses, RMSprop x2), batch=%d per GPU, 32x128x3" % args.batch)
-                       if train else
-                       ("BASELINE configs[1]: generator + sunpose_net forward (incl. the Grad-CAM sweep and sun-radiance "
-                        "head of the generator graph), batch=%d per GPU, 32x128x3" % args.batch),
-                       "per_gpu_batch": args.batch, "global_batch": args.batch * world,
-                       "parallelism": ("dp%d (RCCL all-reduce of fp32 gradients)" % world if train else "replicas") if world > 1 else "single",
-                       "hipgraph": not args.no_graph},
-            "algorithmic_tflops": round(value * (TRAIN_MFLOP_PER_IMG if train else FWD_MFLOP_PER_IMG) * 1e6 / 1e12, 2),
-        }
-        res["roofline"] = dominant_kernel_roofline(torch, K, roof_pw, roof_b, args.batch, 32, 128)
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(torch, args.workload, (gen, sun, dis, vgg), batch_np)
-        print(json.dumps(res))
+            "data": "synthetic (uniform random 128x512 panoramas, random-init weights, synthetic VGG16 weights)",
+            "config": {"workload": "BASELINE configs[4] on one GPU: 128x512, batch=%d per GPU - generator encoder with plain "
+                                   "and with distortion-aware res blocks, both decoders, blending, discriminator, VGG16 x2, "
+                                   "L1 / DoG / perceptual / LSGAN loss values (forward + losses).  SUBSTITUTION (SURVEY.md "
+                                   "section 8d): the 12.9 G-parameter sun-pose net is not in the step; its fc1 is timed "
+                                   "separately as a weight-streaming GEMM slice (sunpose_fc)" % batch,
+                       "per_gpu_batch": batch, "global_batch": batch * world,
+                       "parallelism": "replicas" if world > 1 else "single", "hipgraph": not args.no_graph},
+            "algorithmic_tflops": round(imgs / dt * HIRES_MFLOP_PER_IMG * 1e6 / 1e12, 2)})
+    else:
+        sun = params.init_params(params.sunpose_spec(), 1)
+        dis = params.init_params(params.discriminator_spec(), 2)
+        vgg = params.init_params(params.vgg_spec(), 3)
+        batch_np = synth.make_batch(batch, seed=1234 + rank)
+        ldr = torch.from_numpy(batch_np["ldr"]).to(dev)
+        hdr = torch.from_numpy(batch_np["hdr_t"]).to(dev)
+        gt = torch.from_numpy(batch_np["sunpose_gt"]).to(dev)
+        res["data"] = "synthetic (seeded sky-dome + sun lobe + sensor noise, random-init weights, synthetic VGG16 weights)"
+        do_train, do_fwd = args.workload in ("all", "train"), args.workload in ("all", "fwd")
+        roof_pw = None
+        if do_train:
+            tr = trainer.Trainer(gen, sun, dis, vgg, device=dev, precise=False, compute=K.BF16, world_size=world)
+            # One step = the Trainer's segment plan (forward, losses, both backward passes, RMSprop x2 + weight
+            # re-packing), every segment captured into its own hipGraph and replayed on its stream.  N > 1: each replica
+            # runs the reference's batch-32 step on its shard; gradients are summed over replicas (RCCL; every loss is a
+            # batch mean, so the data-parallel gradient is the replica average: SURVEY.md section 8e) and scaled by
+            # 1/world inside the RMSprop kernel.  How the sum travels is parallel.GradientExchange's mode.
+            par.broadcast_params_([tr.gs.flat, tr.ds.flat])   # replicas start from rank 0's weights
+            tr.repack()
+            ex = par.GradientExchange(tr, device=dev, mode=args.dp_mode)   # hooks on the segment plan: see parallel.py
+            hooks, pre_hooks = (ex.hooks, ex.pre_hooks) if dp else (None, None)
+            roof_pw = tr.conv["gen.res.0.conv1"].pk
+            if args.no_graph:
+                out = tr.step(ldr, hdr, gt, update=False)
+                one_step = lambda: (tr.step(ldr, hdr, gt, update=False), dp and ex.reduce_all(), tr.apply_gradients())
+            else:
+                out = tr.capture(ldr, hdr, gt)
+                one_step = lambda: tr.replay(hooks=hooks, pre_hooks=pre_hooks)
+            dt = timed(torch, dist, one_step, args.steps, args.warmup, dp, dev)
+            assert torch.isfinite(out["y_final_lin"]).all()
+            imgs = batch * world * args.steps
+            res.update({
+                "metric": "training images/sec (32x128 sky panoramas); generator fwd ms/img in `fwd`" if do_fwd else
+                          "training images/sec (32x128 sky panoramas)",
+                "value": round(imgs / dt, 1), "unit": "images/s",
+                "ms_per_step": round(dt / args.steps * 1e3, 4), "ms_per_img": round(dt / imgs * world * 1e3, 6),
+                "config": {"workload": "BASELINE configs[2]: full train.py step (gen + sunpose + disc + VGG16 perceptual + "
+                                       "tone-map/DoG/L1/KL/LSGAN losses, RMSprop x2), batch=%d per GPU, 32x128x3" % batch,
+                           "per_gpu_batch": batch, "global_batch": batch * world,
+                           "parallelism": ("dp%d (%s)" % (world, ex.describe())) if world > 1 else "single",
+                           "hipgraph": not args.no_graph},
+                "algorithmic_tflops": round(imgs / dt * TRAIN_MFLOP_PER_IMG * 1e6 / 1e12, 2)})
+            del tr, ex, one_step, out
+            torch.cuda.empty_cache()
+        if do_fwd:
+            nets = engine.Nets(gen, sun, device=dev, precise=False)
+            roof_pw = roof_pw if roof_pw is not None else nets.pk["gen.res.0.conv1"]
+            one_step, out = capture_forward(torch, lambda: engine.generator_forward(nets, ldr, compute=K.BF16), dp, args.no_graph)
+            dtf = timed(torch, dist, one_step, args.steps, args.warmup, dp, dev)
+            assert torch.isfinite(out["y_final_lin"]).all()
+            imgs = batch * world * args.steps
+            fwd = {"ms_per_step": round(dtf / args.steps * 1e3, 4), "ms_per_img": round(dtf / imgs * world * 1e3, 6),
+                   "images_per_s": round(imgs / dtf, 1),
+                   "algorithmic_tflops": round(imgs / dtf * FWD_MFLOP_PER_IMG * 1e6 / 1e12, 2),
+                   "workload": "BASELINE configs[1]: generator + sunpose_net forward (incl. the Grad-CAM sweep and "
+                               "sun-radiance head of the generator graph), batch=%d per GPU, 32x128x3%s" %
+                               (batch, ", replicas" if world > 1 else "")}
+            if do_train:
+                res["fwd"] = fwd
+            else:
+                res.update({"metric": "generator fwd images/sec (32x128 sky panoramas)", "value": fwd["images_per_s"],
+                            "unit": "images/s", "ms_per_step": fwd["ms_per_step"], "ms_per_img": fwd["ms_per_img"],
+                            "config": {"workload": fwd["workload"], "per_gpu_batch": batch, "global_batch": batch * world,
+                                       "parallelism": "replicas" if world > 1 else "single", "hipgraph": not args.no_graph},
+                            "algorithmic_tflops": fwd["algorithmic_tflops"]})
+            del one_step, out
+    # the single-GPU probes run without a process group (RCCL's communicator closed, the other ranks gone)
     if dp:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        if hires:
+            res["roofline_hbm"] = [fc_row]
+            res["sunpose_fc"] = fc_row
+        else:
+            res["roofline"] = dominant_kernel_roofline(torch, K, roof_pw, batch, 32, 128)
+            res["roofline_hbm"] = hbm_rooflines(torch, K, batch)
+            res["parity"] = parity_object(torch, engine, K, gen, sun, ldr, hdr)
+            if not args.no_cpu_baseline:
+                nets_np = (gen, sun, dis, vgg)
+                if do_train:
+                    res["cpu_baseline"] = cpu_baseline(torch, "train", nets_np, batch_np)
+                    if do_fwd:
+                        res["cpu_baseline_fwd"] = cpu_baseline(torch, "fwd", nets_np, batch_np, budget_s=6.0)
+                else:
+                    res["cpu_baseline"] = cpu_baseline(torch, "fwd", nets_np, batch_np)
+        print(json.dumps(res))
 
 
 if __name__ == "__main__":

@@ -31,7 +31,8 @@ P = c_void_p
 class WgradJob(ctypes.Structure):
     """Mirror of ``hdrsky_wgrad_job`` (include/hdrsky.h)."""
     _fields_ = [("desc", ConvDesc)] + [(n, c_void_p) for n in
-                                       ("x", "dy", "in_scale", "in_shift", "in_part", "in_gamma", "in_beta", "dw", "db")]
+                                       ("x", "dy", "in_scale", "in_shift", "in_part", "in_gamma", "in_beta", "dw", "db")] + \
+               [("x_bf16", ctypes.c_int32), ("dy_bf16", ctypes.c_int32)]
 
 
 class ResconvArgs(ctypes.Structure):

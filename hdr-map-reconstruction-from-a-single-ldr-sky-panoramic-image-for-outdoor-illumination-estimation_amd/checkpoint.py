@@ -69,14 +69,41 @@ def sun_tensors(trainer):
     return {"lin/" + k[4:].replace(".", "/"): v.detach().cpu().numpy() for k, v in trainer.gs.w.items() if k.startswith("sun.")}
 
 
-def load_into(params, tensors, prefix):
-    """Copies `prefix/<path>` entries into an OrderedDict name->np.array (names use '.' separators)."""
-    n = 0
+# The last path component of a variable: the native files use the names the reference passes to add_weight ('w' / 'b',
+# 'kernel_deconv2d' / 'bias_deconv2d': ops.py:30-37,76-108), whereas a tf.train.Checkpoint object graph is keyed by the
+# ATTRIBUTE the layer stores the variable under (`self.w` / `self.biases`, `self.kernel` / `self.biases`: the same
+# lines).  Both spellings are accepted when restoring.
+_ALIASES = {"b": ("biases",), "kernel_deconv2d": ("kernel",), "bias_deconv2d": ("biases",)}
+
+
+def _candidates(prefix, name):
+    parts = name.split(".")
+    yield prefix + "/" + "/".join(parts)
+    for alt in _ALIASES.get(parts[-1], ()):
+        yield prefix + "/" + "/".join(parts[:-1] + [alt])
+
+
+def load_into(params, tensors, prefix, strict=True):
+    """Copies `prefix/<path>` entries of a restored checkpoint into an OrderedDict name -> np.array (names use '.'
+    separators).  Every loaded array must have the shape the model declares (a checkpoint written at another
+    --imheight/--imwidth is rejected, not silently adopted).  strict: every variable of `params` must be found -
+    a partial restore (e.g. a key-spelling mismatch that leaves the biases at their initial values) raises instead of
+    producing a half-initialised model.  Returns the number of variables loaded."""
+    n, missing = 0, []
     for k in list(params.keys()):
-        key = prefix + "/" + k.replace(".", "/")
-        if key in tensors:
-            params[k] = np.asarray(tensors[key], np.float32)
-            n += 1
+        key = next((c for c in _candidates(prefix, k) if c in tensors), None)
+        if key is None:
+            missing.append(k)
+            continue
+        v = np.asarray(tensors[key], np.float32)
+        if tuple(v.shape) != tuple(np.shape(params[k])):
+            raise ValueError("checkpoint variable %s has shape %s, the model expects %s for %s"
+                             % (key, tuple(v.shape), tuple(np.shape(params[k])), k))
+        params[k] = v
+        n += 1
+    if strict and missing:
+        raise KeyError("checkpoint holds no `%s/...` entry for %d of %d variables (first: %s)"
+                       % (prefix, len(missing), len(params), ", ".join(missing[:4])))
     return n
 
 

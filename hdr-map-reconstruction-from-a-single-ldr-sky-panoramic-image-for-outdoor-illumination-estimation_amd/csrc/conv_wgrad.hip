@@ -39,6 +39,7 @@ struct WgradArgs {
   int RX, RY;                    // LDS row strides (bytes) of the X / dY tiles
   int off_xlo, off_y, off_ylo, off_ss, off_red;
   int nchunks;                   // pixel split of this job
+  int x_bf16, dy_bf16;           // operands stored as bf16 (the sample-resident conv chain) instead of fp32
 };
 
 constexpr int WG_MAXJ = 12;      // jobs per launch (the argument block must stay below 4 KB)
@@ -48,6 +49,15 @@ struct MultiArgs {
   WgradArgs job[WG_MAXJ];
 };
 static_assert(sizeof(MultiArgs) <= 4096, "kernel argument block");
+
+__device__ __forceinline__ void unpack8(const uint4& u, float (&v)[8]) {   // 8 bf16 -> 8 floats
+  const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    v[2 * k] = __builtin_bit_cast(float, w[k] << 16);
+    v[2 * k + 1] = __builtin_bit_cast(float, w[k] & 0xffff0000u);
+  }
+}
 
 __device__ __forceinline__ uint2 lds_tr(const unsigned char* p) {
   const s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
@@ -289,11 +299,17 @@ __global__ void __launch_bounds__(NW * 64) conv_wgrad_kernel(const MultiArgs m) 
                 xr[it][j] = src[c < a.Cin ? c : 0];
               }
             } else {
-              const float* src = a.x + ((size_t)(b * a.H + (ok ? cy : 0)) * a.W + (ok ? cx : 0)) * a.Cin + cb0 + qc * 8;
-              const float4 va = *reinterpret_cast<const float4*>(src);
-              const float4 vb = *reinterpret_cast<const float4*>(src + 4);
-              xr[it][0] = va.x; xr[it][1] = va.y; xr[it][2] = va.z; xr[it][3] = va.w;
-              xr[it][4] = vb.x; xr[it][5] = vb.y; xr[it][6] = vb.z; xr[it][7] = vb.w;
+              const size_t eo = ((size_t)(b * a.H + (ok ? cy : 0)) * a.W + (ok ? cx : 0)) * a.Cin + cb0 + qc * 8;
+              if (a.x_bf16) {   // job-uniform
+                const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(a.x) + eo);
+                unpack8(u, xr[it]);
+              } else {
+                const float* src = a.x + eo;
+                const float4 va = *reinterpret_cast<const float4*>(src);
+                const float4 vb = *reinterpret_cast<const float4*>(src + 4);
+                xr[it][0] = va.x; xr[it][1] = va.y; xr[it][2] = va.z; xr[it][3] = va.w;
+                xr[it][4] = vb.x; xr[it][5] = vb.y; xr[it][6] = vb.z; xr[it][7] = vb.w;
+              }
             }
           }
         }
@@ -306,8 +322,16 @@ __global__ void __launch_bounds__(NW * 64) conv_wgrad_kernel(const MultiArgs m) 
           const int oy = oy0 + m / TW, ox = ox0 + m % TW;
           const bool ok = oy < a.Ho && ox < a.Wo;
           const int n0 = ob0 + qc * 8;
-          const float* src = a.dy + ((size_t)(b * a.Ho + (ok ? oy : 0)) * a.Wo + (ok ? ox : 0)) * a.Cout;
-          if ((a.Cout & 7) == 0 && n0 + 8 <= a.Cout) {
+          const size_t yo = ((size_t)(b * a.Ho + (ok ? oy : 0)) * a.Wo + (ok ? ox : 0)) * a.Cout;
+          const float* src = a.dy + yo;
+          if (a.dy_bf16) {    // job-uniform; Cout % 8 == 0 checked on the host
+            if (n0 + 8 <= a.Cout) {
+              const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(a.dy) + yo + n0);
+              unpack8(u, yr[it]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) yr[it][j] = (ok && n0 + 8 <= a.Cout) ? yr[it][j] : 0.f;
+          } else if ((a.Cout & 7) == 0 && n0 + 8 <= a.Cout) {
             const float4 va = *reinterpret_cast<const float4*>(src + n0);
             const float4 vb = *reinterpret_cast<const float4*>(src + n0 + 4);
             yr[it][0] = ok ? va.x : 0.f; yr[it][1] = ok ? va.y : 0.f; yr[it][2] = ok ? va.z : 0.f; yr[it][3] = ok ? va.w : 0.f;
@@ -534,6 +558,9 @@ static int fill_job(WgradArgs& a, const hdrsky_wgrad_job& j) {
   a.upsample = d->upsample; a.Hc = d->Hc; a.Wc = d->Wc;
   a.in_mode = d->in_mode; a.ss_bstride = d->ss_bstride; a.in_nparts = d->in_nparts;
   a.in_eps = d->in_eps; a.in_inv_count = 1.f / (float)(d->H * d->W); a.in_slope = d->in_slope;
+  a.x_bf16 = j.x_bf16; a.dy_bf16 = j.dy_bf16;
+  if (j.x_bf16 && (narrow || d->upsample != 1 || d->in_mode != HDRSKY_IN_NONE || d->in_slope != 1.f)) return HDRSKY_EUNSUPPORTED;
+  if (j.dy_bf16 && (d->Cout & 7) != 0) return HDRSKY_EUNSUPPORTED;
   return HDRSKY_OK;
 }
 

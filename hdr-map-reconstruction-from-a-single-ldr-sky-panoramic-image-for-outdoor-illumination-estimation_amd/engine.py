@@ -157,6 +157,17 @@ def encode(nets, ldr, compute, distortion_aware=False, dilation_rate=1):
             c2, t2 = K.da_conv2d(a1, pk["gen." + p + "conv2"], g[p + "conv2.b"], offs, compute, want_stats=True)
             x = K.norm_apply(c2, t2, g[p + "norm2.gamma"], g[p + "norm2.beta"], slope=1.0, residual=x)
         return x
+    if compute == BF16 and K.resconv_supported(x.shape[1], x.shape[2], 128, 128):
+        # 8x32 maps, single-product mode: each half of a res block is one sample-resident launch with the InstanceNorm
+        # (+ activation / identity add) in its epilogue; activations between them are final bf16 tensors
+        xb = K.to_bf16(x)
+        for i in range(6):
+            p = "res.%d." % i
+            a1 = K.resconv_fwd(xb, pk["gen." + p + "conv1"], None, g[p + "norm1.gamma"], g[p + "norm1.beta"], 0.1)["bf16"]
+            o = K.resconv_fwd(a1, pk["gen." + p + "conv2"], None, g[p + "norm2.gamma"], g[p + "norm2.beta"], 1.0, residual=x,
+                              want_f32=True, want_bf16=(i < 5))
+            x, xb = o["f32"], o.get("bf16")
+        return x
     for i in range(6):
         p = "res.%d." % i
         c1, t1 = K.conv2d(x, pk["gen." + p + "conv1"], g[p + "conv1.b"], want_stats=True, compute=compute)

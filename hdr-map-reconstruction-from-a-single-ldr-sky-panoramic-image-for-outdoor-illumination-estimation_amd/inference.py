@@ -44,10 +44,10 @@ def main(argv=None):
             sun = P.init_params(P.sunpose_spec(h, w), 1)
             t, _ = ckpt.CheckpointManager(args.sky).restore()
             if t:
-                ckpt.load_into(gen, t, "gen_model"); print("Latest SKY checkpoint has restored!!")
+                print("Latest SKY checkpoint has restored!! (%d variables)" % ckpt.load_into(gen, t, "gen_model"))
             t, _ = ckpt.CheckpointManager(args.sun).restore()
             if t:
-                ckpt.load_into(sun, t, "lin"); print("Latest SUN checkpoint has restored!!")
+                print("Latest SUN checkpoint has restored!! (%d variables)" % ckpt.load_into(sun, t, "lin"))
             nets, shape = E.Nets(gen, sun, device="cuda:0", precise=False, im_height=h, im_width=w), (h, w)
         x = torch.from_numpy(np.ascontiguousarray(ldr[None])).to("cuda:0")
         pred = E.generator_forward(nets, x, compute=K.BF16)["y_final_lin"][0].cpu().numpy()

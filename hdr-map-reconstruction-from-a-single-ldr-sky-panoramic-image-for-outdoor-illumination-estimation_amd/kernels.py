@@ -194,8 +194,13 @@ def conv2d_wgrad(x, dy, KH, KW, stride=1, same=True, upsample=1, xf: Optional[In
 
 def wgrad_job(x, dy, KH, KW, dw, db=None, stride=1, same=True, upsample=1, xf: Optional[InXf] = None, compute=BF16):
     """One entry for conv2d_wgrad_multi: dw [KH,KW,Cin,Cout] (+= ; must hold valid values, e.g. zeros), db [Cout] or None.
+    x / dy may be bf16 tensors (the final activations / gradients of the sample-resident conv chain; no operand transform).
     The returned job references its tensors, which keeps them alive until the launch."""
-    _f32(x); _f32(dy)
+    for t in (x, dy):
+        if not (torch.is_tensor(t) and t.is_cuda and t.is_contiguous() and t.dtype in (torch.float32, torch.bfloat16)):
+            raise ValueError("expected contiguous CUDA float32 / bfloat16 tensors")
+    if x.dtype == torch.bfloat16 and xf is not None and (xf.mode != L.IN_NONE or xf.slope != 1.0):
+        raise ValueError("a bf16 operand is final: no transform")
     B, H, W, C = x.shape
     Cout = dy.shape[-1]
     d = conv_desc(B, H, W, C, Cout, KH, KW, stride, same, upsample)
@@ -219,6 +224,7 @@ def conv2d_wgrad_multi(jobs):
         j.desc = d
         j.x, j.dy, j.dw, j.db = _p(x), _p(dy), _p(dw), _p(db)
         j.in_scale, j.in_shift, j.in_part, j.in_gamma, j.in_beta = [_p(t) for t in tabs]
+        j.x_bf16, j.dy_bf16 = int(x.dtype == torch.bfloat16), int(dy.dtype == torch.bfloat16)
     L.check(L.load().hdrsky_conv2d_wgrad_multi(arr, len(jobs), _stream()), "conv2d_wgrad_multi")
 
 

@@ -55,40 +55,126 @@ def broadcast_params_(flat_buffers, src=0):
         dist.broadcast(t, src=src)
 
 
+MODES = ("allreduce", "allreduce_bf16", "gather_dense")
+
+
 class GradientExchange:
     """The per-step gradient exchange of a data-parallel `trainer.Trainer`, as hooks for `Trainer.replay`.
 
-    The sun-pose Dense weight gradients (201 of the 233 MB) are complete after the segment `Trainer.FC_GRADS_READY`;
-    their all-reduce is enqueued by the host late (as a pre-hook of the Dense-layer optimizer segment, so the
-    collective's enqueue cost does not sit between the launches of the critical chain) but on a communication stream
-    that waits only for that segment's event: on the GPU it starts as soon as those gradients exist and runs beside
-    the rest of the backward pass.  Everything else (32 MB) is reduced when `Trainer.GRADS_READY` is reached.
+    What has to travel per step and replica (32x128, fp32): the two sun-pose Dense kernels 201 MB, everything else of the
+    generator / sun-pose optimizer 21 MB, the discriminator 11 MB.  xGMI is point-to-point (7 links x ~153 GB/s per GPU),
+    so a ring all-reduce of S bytes costs about 2 (N-1)/N S / (one link's ~300 GB/s both ways); modes (`mode=` or the
+    environment variable HDRSKY_DP_MODE):
 
-        ex = GradientExchange(tr)
+      allreduce       three flat all-reduces (SUM; the 1/world goes into the optimizer kernel).  The Dense slice (201 MB)
+                      is complete after segment `Trainer.FC_GRADS_READY`: its collective is enqueued by the host late (as
+                      a pre-hook of the Dense-layer optimizer segment, so the enqueue cost does not sit between the
+                      launches of the critical chain) but on a communication stream that waits only for that segment's
+                      event - on the GPU it starts as soon as those gradients exist and runs beside the remaining ~60 % of
+                      the backward pass.  The other 32 MB are reduced when `Trainer.GRADS_READY` is reached.
+                      233 MB per step; ring at N=8: ~1.4 ms, of which 86 % is overlapped.
+      allreduce_bf16  the same schedule with a bf16 payload (the gradient slices are rounded to bf16, summed by RCCL in
+                      bf16 and widened again): 116 MB per step.  Changes the arithmetic (2^-9 relative per term and per
+                      addition): offered for bandwidth-starved topologies, not the default.
+      gather_dense    the Dense kernels' gradients never travel.  A Dense weight gradient is X^T dY; the replicas
+                      all-gather X and dY instead - flat [B,8192], df1 [B,4096], f1 [B,4096], dz [B,4096], 2.6 MB per
+                      replica, 21 MB gathered at N=8 - and every replica recomputes the FULL-batch weight gradients of
+                      fc1 / fc2 (its local Dense weight-gradient launches are skipped: `Trainer.dense_wgrad_external`).
+                      The sum over replicas is the same number the all-reduce produces (fp32 summation order differs).
+                      32 MB all-reduced + 21 MB gathered per step at N=8 instead of 233 MB.
+
+        ex = GradientExchange(tr, mode="gather_dense")
         tr.replay(hooks=ex.hooks, pre_hooks=ex.pre_hooks)      # graph path
         tr.step(..., update=False); ex.reduce_all(); tr.apply_gradients()   # eager path
     """
 
-    def __init__(self, trainer, device=None):
-        self.tr = trainer
+    def __init__(self, trainer, device=None, mode=None):
+        mode = mode or os.environ.get("HDRSKY_DP_MODE") or "allreduce"
+        if mode not in MODES:
+            raise ValueError("unknown data-parallel mode %r (one of %s)" % (mode, ", ".join(MODES)))
+        self.tr, self.mode = trainer, mode
         self.fc0, self.fc1 = trainer.fc_grad_range()
         self.active = dist.is_initialized()     # a process group exists (world 1 only in rehearsals of this path)
+        self.world = dist.get_world_size() if self.active else 1
         self.comm = torch.cuda.Stream(device=device) if self.active else None
+        if mode == "gather_dense" and self.active:
+            trainer.dense_wgrad_external = True   # bwd_head leaves the Dense weight gradients to dense_exchange()
+        self._gbuf = {}
 
+    def describe(self):
+        return {"allreduce": "RCCL all-reduce of fp32 gradients, Dense slice overlapped with backward",
+                "allreduce_bf16": "RCCL all-reduce of bf16-rounded gradients, Dense slice overlapped with backward",
+                "gather_dense": "Dense gradients recomputed from all-gathered activations; RCCL all-reduce of the rest"}[self.mode]
+
+    # ---- payload helpers ------------------------------------------------------------------------------------------
+    def _allreduce(self, t, async_op=False):
+        if self.mode == "allreduce_bf16":
+            key = (t.data_ptr(), t.numel())
+            buf = self._gbuf.get(key)
+            if buf is None:
+                buf = self._gbuf[key] = torch.empty(t.numel(), dtype=torch.bfloat16, device=t.device)
+            buf.copy_(t)
+            dist.all_reduce(buf)
+            t.copy_(buf)
+            return None
+        return dist.all_reduce(t, async_op=async_op)
+
+    def _dense_gather(self):
+        """all-gather (flat | df1 | f1 | dz) of every replica and recompute both Dense weight (and bias) gradients on the
+        global batch, in place of the local ones."""
+        from . import kernels as K
+        tr = self.tr
+        T, g = tr._T, tr.gs.g
+        parts = [T["t"]["flat"], T["df1"], T["t"]["f1"], T["dz"]]
+        B = parts[0].shape[0]
+        widths = [p.shape[1] for p in parts]
+        key = ("dense", B)
+        st = self._gbuf.get(key)
+        if st is None:
+            st = self._gbuf[key] = (torch.empty((B, sum(widths)), dtype=torch.float32, device=parts[0].device),
+                                    torch.empty((self.world * B, sum(widths)), dtype=torch.float32, device=parts[0].device))
+        local, allp = st
+        torch.cat(parts, dim=1, out=local)
+        dist.all_gather_into_tensor(allp, local)
+        o = [0]
+        for wd in widths:
+            o.append(o[-1] + wd)
+        flat, df1, f1, dz = (allp[:, o[i]:o[i + 1]].contiguous() for i in range(4))
+        K.fc_wgrad(f1, dz, g["sun.fc2.kernel"], g["sun.fc2.bias"])
+        K.fc_wgrad(flat, df1, g["sun.fc1.kernel"], g["sun.fc1.bias"])
+
+    # ---- the two hook points ----------------------------------------------------------------------------------------
     def fc_grads_reduce(self):
+        """Dense-layer slice: runs on the communication stream from the moment the slice (or, gather_dense, its operands)
+        exists; the CURRENT stream (the Dense optimizer segment's) waits for it."""
         tr = self.tr
         self.comm.wait_event(tr.event(tr.FC_GRADS_READY))
+        work = None
         with torch.cuda.stream(self.comm):
-            work = dist.all_reduce(tr.gs.grad[self.fc0:self.fc1], async_op=True)
-        work.wait()          # the CURRENT stream (the optimizer segment's) waits for the collective
+            if self.mode == "gather_dense":
+                self._dense_gather()
+            else:
+                work = self._allreduce(tr.gs.grad[self.fc0:self.fc1], async_op=True)
+        if work is not None:
+            work.wait()
+        else:
+            torch.cuda.current_stream().wait_stream(self.comm)
 
     def grads_ready(self):
-        dist.all_reduce(self.tr.gs.grad[:self.fc0])
-        dist.all_reduce(self.tr.ds.grad)
+        self._allreduce(self.tr.gs.grad[:self.fc0])
+        self._allreduce(self.tr.ds.grad)
 
     def reduce_all(self):
         """Eager path: every gradient buffer, on the current stream."""
-        allreduce_sum_([self.tr.gs.grad, self.tr.ds.grad])
+        if not self.active:
+            return
+        if self.mode == "gather_dense":
+            self._dense_gather()
+            self.grads_ready()
+        elif self.mode == "allreduce_bf16":
+            self._allreduce(self.tr.gs.grad); self._allreduce(self.tr.ds.grad)
+        else:
+            allreduce_sum_([self.tr.gs.grad, self.tr.ds.grad])
 
     @property
     def hooks(self):
@@ -97,3 +183,14 @@ class GradientExchange:
     @property
     def pre_hooks(self):
         return {self.tr.APPLY[0]: self.fc_grads_reduce} if self.active else None
+
+
+def sync_moving_stats_(trainer, src=0):
+    """BatchNorm moving statistics (discriminator, sun-radiance head) are replica-local by construction (SURVEY.md section
+    8e: local BN statistics).  Before a checkpoint or a validation pass every replica takes rank `src`'s copy, so that
+    what is saved / evaluated does not depend on which replica happens to write or on its data shard."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    for fp in (trainer.gs, trainer.ds):
+        if fp.flat.numel() > fp.ntrain:
+            dist.broadcast(fp.flat[fp.ntrain:], src=src)

@@ -58,12 +58,11 @@ def main(argv=None):
     sky_mgr, sun_mgr = ckpt.CheckpointManager(args.sky), ckpt.CheckpointManager(args.sun)
     tensors, epoch0 = sky_mgr.restore()
     if tensors:
-        ckpt.load_into(gen, tensors, "gen_model"); ckpt.load_into(dis, tensors, "dis_model")
-        print("Latest SKY checkpoint has restored!!")
+        n = ckpt.load_into(gen, tensors, "gen_model") + ckpt.load_into(dis, tensors, "dis_model")
+        print("Latest SKY checkpoint has restored!! (%d variables)" % n)
     sun_t, _ = sun_mgr.restore()
     if sun_t:
-        ckpt.load_into(sun, sun_t, "lin")
-        print("Latest SUN checkpoint has restored!!")
+        print("Latest SUN checkpoint has restored!! (%d variables)" % ckpt.load_into(sun, sun_t, "lin"))
     tr = Trainer(gen, sun, dis, vgg, device=dev, lr=args.lr, im_height=h, im_width=w, compute=K.BF16, world_size=world)
     if tensors and "gen_optimizer/rms" in tensors:
         tr.gs.ms.copy_(torch.from_numpy(tensors["gen_optimizer/rms"])); tr.ds.ms.copy_(torch.from_numpy(tensors["disc_optimizer/rms"]))

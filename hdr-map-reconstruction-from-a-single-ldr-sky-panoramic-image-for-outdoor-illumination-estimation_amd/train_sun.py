@@ -52,8 +52,7 @@ def main(argv=None):
     mgr = ckpt.CheckpointManager(args.sun)
     tensors, epoch0 = mgr.restore()
     if tensors:
-        ckpt.load_into(sun, tensors, "lin")
-        print("Latest checkpoint has restored!!")
+        print("Latest checkpoint has restored!! (%d variables)" % ckpt.load_into(sun, tensors, "lin"))
     tr = SunPoseTrainer(sun, device=dev, lr=args.lr, im_height=h, im_width=w, compute=K.BF16, world_size=world)
     if tensors and "optimizer/m" in tensors:
         tr.adam_m.copy_(torch.from_numpy(tensors["optimizer/m"])); tr.adam_v.copy_(torch.from_numpy(tensors["optimizer/v"]))

@@ -95,10 +95,16 @@ class _Conv:
 
 class Trainer:
     def __init__(self, gen_params, sun_params, dis_params, vgg_params, device="cuda", lr=1e-4, im_height=32,
-                 im_width=128, precise=False, compute=BF16, world_size=1):
+                 im_width=128, precise=False, compute=BF16, world_size=1, resconv=True):
         self.device = torch.device(device)
         self.h, self.w = im_height, im_width
         self.lr, self.compute, self.precise, self.world = lr, compute, precise, world_size
+        # res-block chain on bf16 activations through the sample-resident conv + InstanceNorm launches (HDRSKY_BF16
+        # mode, 8x32 maps); otherwise the generic conv / norm launches on fp32 activations
+        self.use_resconv = bool(resconv) and compute == BF16 and not precise and \
+            K.resconv_supported(im_height // 4, im_width // 4, 128, 128)
+        self._rc = {}
+        self.dense_wgrad_external = False   # a data-parallel driver recomputes the Dense weight gradients (parallel.py)
         named = OrderedDict(("gen." + k, v) for k, v in gen_params.items())
         named.update(("sun." + k, v) for k, v in sun_params.items())
         self.gs = FlatParams(named, self.device)          # optimizer_gen: _gen + _sun variables (train.py:402-403)
@@ -179,6 +185,21 @@ class Trainer:
         w, g = self.gs.w, self.gs.g
         return K.norm_act_bwd(x, stats, w[name + ".gamma"], w[name + ".beta"], slope, dy, pooled,
                               dgamma=g[name + ".gamma"], dbeta=g[name + ".beta"])
+
+    def _rc_state(self, B):
+        """Per-batch-size state of the sample-resident res chain: the per-sample (d gamma, d beta) terms of its 12 norm
+        layers and the one-launch reducer into the gradient vectors (its pointer table is uploaded here, outside any
+        graph capture)."""
+        st = self._rc.get(B)
+        if st is None:
+            dgb = torch.zeros((12, B, 2, 128), dtype=torch.float32, device=self.device)
+            g, entries = self.gs.g, []
+            for i in range(6):
+                for j in (1, 2):
+                    n = "gen.res.%d.norm%d" % (i, j)
+                    entries.append((dgb[2 * i + j - 1], g[n + ".gamma"], g[n + ".beta"]))
+            st = self._rc[B] = (dgb, K.DgbReducer(entries))
+        return st
 
     def _wg(self, name, x, xf, dy):
         """Queues the weight gradient of one conv layer.  Nothing in the backward chain consumes it, and ~40 of them
@@ -429,7 +450,18 @@ class Trainer:
             T["c3"], T["s3"] = c["gen.conv3_d"].fwd(T["c2"], T["xf3"], cp, want_stats=True)
             x = K.norm_apply(T["c3"], T["s3"], w["gen.norm3_d.gamma"], w["gen.norm3_d.beta"], slope=0.1)
             T["x"] = [x]
-            for i in range(6):
+            if self.use_resconv:      # generator.py:26-35 x6: two launches per block, InstanceNorm inside them
+                xb = K.to_bf16(x)
+                T["xb"] = [xb]
+                for i in range(6):
+                    p = "gen.res.%d." % i
+                    o1 = K.resconv_fwd(xb, c[p + "conv1"].pk, None, w[p + "norm1.gamma"], w[p + "norm1.beta"], 0.1, save=True)
+                    o2 = K.resconv_fwd(o1["bf16"], c[p + "conv2"].pk, None, w[p + "norm2.gamma"], w[p + "norm2.beta"], 1.0,
+                                       residual=x, want_f32=True, want_bf16=(i < 5), save=True)
+                    T["res%d" % i] = (o1, o2)
+                    x, xb = o2["f32"], o2.get("bf16")
+                    T["x"].append(x); T["xb"].append(xb)
+            for i in range(0 if self.use_resconv else 6):   # generic launches (BF16X3, other image sizes)
                 p = "gen.res.%d." % i
                 r1, t1 = c[p + "conv1"].fwd(x, compute=cp, want_stats=True)
                 xf = self._inxf(t1, p + "norm1", 0.1)
@@ -496,10 +528,12 @@ class Trainer:
                 y, residual = T["dec_" + sfx][6], T["dec_" + sfx][7]
                 tails[sfx] = K.decoder_tail_bwd(y, residual, dy, want_dres=(sfx == "u"))
             T["dpre"] = K.sun_rad_bwd(t["cmf"], t["gmax"], T["gamma"], T["beta"], tails["u"][1], T["dcmf"])
-            dz = K.softmax_bwd(t["cmf"], T["dcmf"], t["z"])       # KL + the sun-radiance path meet in dcmf
-            K.fc_wgrad(t["f1"], dz, g["sun.fc2.kernel"], g["sun.fc2.bias"])
+            dz = T["dz"] = K.softmax_bwd(t["cmf"], T["dcmf"], t["z"])       # KL + the sun-radiance path meet in dcmf
+            if not self.dense_wgrad_external:
+                K.fc_wgrad(t["f1"], dz, g["sun.fc2.kernel"], g["sun.fc2.bias"])
             df1 = T["df1"] = K.fc_finalize(K.fc_dgrad(dz, self.fc2, cp), None, relu=False, mask_src=t["f1"])
-            K.fc_wgrad(t["flat"], df1, g["sun.fc1.kernel"], g["sun.fc1.bias"])
+            if not self.dense_wgrad_external:
+                K.fc_wgrad(t["flat"], df1, g["sun.fc1.kernel"], g["sun.fc1.bias"])
             T["dP3"] = K.fc_finalize(K.fc_dgrad(df1, self.fc1, cp)).reshape(B, h // 8, wd // 8, 128)
 
         # ------------------------------------------------------------------ discriminator step (train.py:351-380)
@@ -572,7 +606,30 @@ class Trainer:
         @seg("bwd_res", 0)
         def _():       # encoder res blocks (generator.py:26-35)
             dx = T["dres"]
-            for i in range(5, -1, -1):
+            if self.use_resconv:
+                # every data gradient carries the norm (+ activation) backward that follows it in its epilogue and hands
+                # the next one a final bf16 operand; the identity branch's gradient stays fp32 (`skip`)
+                dgb, reducer = self._rc_state(B)
+
+                def nd(i, j, slope):
+                    o, n = T["res%d" % i][j - 1], "gen.res.%d.norm%d" % (i, j)
+                    return dict(xhat=o["xhat"], inv=o["inv"], gamma=w[n + ".gamma"], beta=w[n + ".beta"], slope=slope,
+                                dgb=dgb[2 * i + j - 1])
+                cur = K.resconv_bwd(None, None, skip=dx, norm=nd(5, 2, 1.0))          # through norm2 of the last block
+                for i in range(5, -1, -1):
+                    p = "gen.res.%d." % i
+                    o1, _ = T["res%d" % i]
+                    dc2 = cur["bf16"]
+                    self._wg(p + "conv2", o1["bf16"], None, dc2)
+                    dc1 = K.resconv_bwd(dc2, c[p + "conv2"].pkT, norm=nd(i, 1, 0.1))["bf16"]
+                    self._wg(p + "conv1", T["xb"][i], None, dc1)
+                    if i > 0:    # + identity branch, then through norm2 of the previous block
+                        cur = K.resconv_bwd(dc1, c[p + "conv1"].pkT, skip=dx, norm=nd(i - 1, 2, 1.0), want_f32=True)
+                        dx = cur["f32"]
+                    else:
+                        dx = K.resconv_bwd(dc1, c[p + "conv1"].pkT, skip=dx, want_f32=True, want_bf16=False)["f32"]
+                reducer.run()
+            for i in range(-1 if self.use_resconv else 5, -1, -1):
                 p = "gen.res.%d." % i
                 r1, t1, xf, r2, t2 = T["res%d" % i]
                 dr2 = self._in_bwd(r2, t2, p + "norm2", 1.0, dx)

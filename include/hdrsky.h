@@ -217,6 +217,8 @@ typedef struct hdrsky_wgrad_job {
   const float* in_beta;
   float* dw;
   float* db;
+  int32_t x_bf16;   /* 1: x points to bf16 data (final activations of the bf16 chain, see hdrsky_resconv; needs */
+  int32_t dy_bf16;  /* 1: dy points to bf16 data                             in_mode NONE / Cin, Cout % 8 == 0) */
 } hdrsky_wgrad_job;
 int hdrsky_conv2d_wgrad_multi(const hdrsky_wgrad_job* jobs, int njobs, void* stream);
 

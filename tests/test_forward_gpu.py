@@ -44,7 +44,9 @@ def test_generator_graph_inference_mode(dev, B):
     # the arg-max - hence which pixel receives the gradient - is decided by last-bit noise, in the oracle
     # as much as here (measured: feeding the ORACLE's own tensors through hdrsky_norm_act_bwd reproduces
     # autograd to 7e-7 except in the one or two channels per sample that contain such a tie).  The maps
-    # therefore get a looser tolerance than the smooth tensors.
+    # therefore get a looser tolerance than the smooth tensors.  The claim itself is pinned where it can be separated:
+    # tests/test_ops_gpu.py::test_norm_act_bwd_pool_routing_tight_off_the_tie_channels asserts 1e-4 on every
+    # (sample, channel) slice without a tie and the loose bound only on the slices the oracle flags.
     for k in ("sun_cam1", "sun_cam2", "sun_cam3"):
         assert_close(out[k], ref[k], 5e-2, k)
         assert rel_rms(out[k], ref[k]) < 3e-2, k

@@ -2,6 +2,7 @@
 import os
 
 import numpy as np
+import pytest
 
 from conftest import pkg
 
@@ -35,4 +36,27 @@ def test_checkpoint_manager_retention_and_restore(tmp_path):
     t, epoch = m.restore()
     assert epoch == 70 and float(t["gen_model/conv1_d/w"][0, 0]) == 7.0
     params = {"conv1_d.w": np.zeros((2, 2), np.float32), "conv1_d.b": np.zeros(2, np.float32)}
-    assert ck.load_into(params, t, "gen_model") == 1 and params["conv1_d.w"][1, 1] == 7.0
+    assert ck.load_into(params, t, "gen_model", strict=False) == 1 and params["conv1_d.w"][1, 1] == 7.0
+    with pytest.raises(KeyError):                      # a partial restore must not pass silently
+        ck.load_into(params, t, "gen_model")
+    with pytest.raises(ValueError):                    # nor one written for another geometry
+        ck.load_into({"conv1_d.w": np.zeros((3, 2), np.float32)}, t, "gen_model")
+
+
+def test_load_into_accepts_the_object_graph_attribute_spelling():
+    """tf.train.Checkpoint keys a variable by the attribute the layer stores it under: ops.conv2d keeps `self.w` /
+    `self.biases` (add_weight names 'w' / 'b', ops.py:30-37), ops.deconv2d `self.kernel` / `self.biases` (names
+    'kernel_deconv2d' / 'bias_deconv2d', ops.py:96-108).  Both spellings restore every variable."""
+    ck, P = pkg("checkpoint"), pkg("params")
+    spec = P.generator_spec()
+    ref = P.init_params(spec, 5)
+    alias = {"b": "biases", "kernel_deconv2d": "kernel", "bias_deconv2d": "biases"}
+    native, graph = {}, {}
+    for k, v in ref.items():
+        parts = k.split(".")
+        native["gen_model/" + "/".join(parts)] = v
+        graph["gen_model/" + "/".join(parts[:-1] + [alias.get(parts[-1], parts[-1])])] = v
+    for tensors in (native, graph):
+        got = P.init_params(spec, 6)
+        assert ck.load_into(got, tensors, "gen_model") == len(spec)
+        assert all(np.array_equal(got[k], ref[k]) for k in ref)

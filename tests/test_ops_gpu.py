@@ -60,6 +60,44 @@ def test_norm_act_bwd(dev, shape, pooled):
     assert_close(got, gx, 2e-4, "norm_act_bwd")
 
 
+def test_norm_act_bwd_pool_routing_tight_off_the_tie_channels(dev):
+    """Grad-CAM conditioning, encoded: the backward of max-pool(relu(InstanceNorm(x))) routes each
+    pooled gradient to the window's arg-max.  Where two activations of a window tie to within rounding, the winner is
+    decided by last-bit noise - in torch autograd as much as here - and that (sample, channel) slice may legitimately
+    differ; everywhere else the kernel must match autograd to fp32 accuracy.  The input has EXACT ties planted in a few
+    channels (bitwise-equal values in a window, as flat image regions produce them) plus whatever near-ties random data
+    holds; the tie mask is computed on the oracle side from the activations (top two of every window within 1e-5 of
+    the slice's scale).  A 3 % routing bug would fail the tight bound on the ~95 % of slices that are tie-free."""
+    K = pkg("kernels")
+    rng = np.random.default_rng(17)
+    B, H, W, C = 2, 8, 32, 128
+    x = (rng.standard_normal((B, H, W, C)) * 1.3 + 0.2).astype(np.float32)
+    planted = [(0, 3), (0, 77), (1, 5), (1, 126)]
+    for b, c in planted:                       # a flat 2x2 window with a large value -> a four-way tie above zero
+        x[b, 2:4, 6:8, c] = 2.5
+    gam = rng.uniform(0.5, 1.5, C).astype(np.float32); bet = (rng.standard_normal(C) * 0.5).astype(np.float32)
+    d = lambda a: torch.from_numpy(a).to(dev)
+    xr, st = _stats_for(K, d(x), C)
+    xt = xr.cpu().clone().requires_grad_(True)
+    act = torch.relu(T.instance_norm(xt, torch.from_numpy(gam), torch.from_numpy(bet)))
+    y = T.maxpool2x2(act)
+    dy = rng.standard_normal(tuple(y.shape)).astype(np.float32)
+    (gx,) = torch.autograd.grad(y, xt, torch.from_numpy(dy))
+    got = K.norm_act_bwd(xr, st, d(gam), d(bet), 0.0, d(dy), True).cpu()
+    # tie mask per (sample, channel): top two activations of some window closer than 1e-5 of the slice's maximum, top > 0
+    a = act.detach().reshape(B, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 5, 2, 4).reshape(B, H // 2, W // 2, C, 4)
+    top2 = a.topk(2, dim=-1).values
+    scale = act.detach().amax(dim=(1, 2)).clamp_min(1e-12)                     # [B, C]
+    tie = (((top2[..., 0] - top2[..., 1]) <= 1e-5 * scale[:, None, None, :]) & (top2[..., 0] > 0)).any(dim=1).any(dim=1)
+    assert all(bool(tie[b, c]) for b, c in planted)
+    assert 4 <= int(tie.sum()) <= B * C // 8, int(tie.sum())                   # the planted ones, a few natural ones at most
+    err = (got - gx).abs().amax(dim=(1, 2)) / gx.abs().amax(dim=(1, 2)).clamp_min(1e-30)   # [B, C] relative max error
+    clean, tied = err[~tie], err[tie]
+    print("tie-free slices: %d, worst %.2e | tie slices: %d, worst %.2e" % (clean.numel(), float(clean.max()), tied.numel(), float(tied.max())))
+    assert float(clean.max()) <= 1e-4, float(clean.max())
+    assert float(tied.max()) <= 2.0            # a re-routed gradient: wrong pixel, same magnitude - bounded, not tight
+
+
 @pytest.mark.parametrize("M", [1, 4, 32])
 def test_fc_fwd_dgrad_softmax(dev, M):
     K = pkg("kernels")

@@ -40,7 +40,7 @@ def _shard(rank, dev):
     return [torch.from_numpy(b[k][sl]).to(dev).contiguous() for k in ("ldr", "hdr_t", "sunpose_gt")]
 
 
-def _worker(rank, port, out_dir):
+def _worker(rank, port, out_dir, mode="allreduce"):
     os.environ.update(RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     P, synth, trainer, K, par = _mods()
     dev = torch.device("cuda", 0)
@@ -51,8 +51,8 @@ def _worker(rank, port, out_dir):
     if rank == 1:
         tr.gs.flat.mul_(1.5)                                  # diverged replica: the broadcast must repair it
     par.broadcast_params_([tr.gs.flat, tr.ds.flat]); tr.repack()
-    ex = par.GradientExchange(tr, device=dev)
-    assert ex.active and ex.hooks and ex.pre_hooks
+    ex = par.GradientExchange(tr, device=dev, mode=mode)
+    assert ex.active and ex.hooks and ex.pre_hooks and tr.dense_wgrad_external == (mode == "gather_dense")
     tr.capture(*_shard(rank, dev))                            # warm-up inside must leave the weights untouched
     for _ in range(2):                                        # two optimizer steps on the same shard
         tr.replay(hooks=ex.hooks, pre_hooks=ex.pre_hooks)
@@ -106,6 +106,29 @@ def test_two_replicas_one_card_equal_summed_gradient_step(dev, tmp_path):
     assert rel(r0["gms"], tr.gs.ms.cpu()) < 1e-3
     assert rel(r0["ds"][nt:], tr.ds.flat.cpu()[nt:]) < 1e-5  # BN moving statistics of replica 0
     assert rel(r0["gs"][ng:], tr.gs.flat.cpu()[ng:]) < 1e-5
+
+
+@pytest.mark.parametrize("mode,tol", [("gather_dense", 2e-3), ("allreduce_bf16", 6e-2)])
+def test_exchange_modes_agree_with_the_plain_allreduce(dev, tmp_path, mode, tol):
+    """parallel.GradientExchange modes: exchanging the Dense layers as all-gathered activations / output gradients (and
+    recomputing their weight gradients on the global batch) produces the update of the flat fp32 all-reduce up to fp32
+    summation order; the bf16 payload up to bf16 rounding of the summed gradients.  Two replicas on the one card (gloo)."""
+    outs = {}
+    for m in ("allreduce", mode):
+        d = tmp_path / m
+        d.mkdir()
+        mp.spawn(_worker, args=(_free_port(), str(d), m), nprocs=2, join=True)
+        r0, r1 = (torch.load(os.path.join(str(d), "r%d.pt" % r)) for r in (0, 1))
+        t0 = _make_trainer(1, dev)
+        ng = t0.gs.ntrain
+        w0 = t0.gs.flat.cpu()[:ng]
+        del t0
+        assert torch.equal(r0["gs"][:ng], r1["gs"][:ng]), m          # replicas stay identical in every mode
+        outs[m] = (r0["gs"][:ng] - w0, r0["gms"])
+    ref, got = outs["allreduce"], outs[mode]
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    print(mode, "update mismatch %.3g, rms slots %.3g" % (rel(got[0], ref[0]), rel(got[1], ref[1])))
+    assert rel(got[0], ref[0]) < tol and rel(got[1], ref[1]) < tol
 
 
 def test_train_cli_two_ranks_one_card(dev, tmp_path):
