@@ -57,6 +57,8 @@ SIGNATURES = {
     "hdrsky_conv2d_fwd": (c_int, [ctypes.POINTER(ConvDesc)] + [P] * 13),
     "hdrsky_conv2d_wgrad": (c_int, [ctypes.POINTER(ConvDesc)] + [P] * 10),
     "hdrsky_conv2d_wgrad_multi": (c_int, [ctypes.POINTER(WgradJob), c_int, P]),
+    "hdrsky_conv2d_wgrad_ws_bytes": (c_size_t, [ctypes.POINTER(WgradJob), c_int]),
+    "hdrsky_conv2d_wgrad_multi_det": (c_int, [ctypes.POINTER(WgradJob), c_int, P, c_size_t, P]),
     "hdrsky_norm_apply": (c_int, [P, P, c_int, P, P, c_float, c_float, P, P, P, c_int, c_int, c_int, c_int, P]),
     "hdrsky_in_finalize": (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_float, P, P, P, P, P]),
     "hdrsky_bn_eval_affine": (c_int, [P, P, P, P, c_float, c_int, P, P, P]),
@@ -116,7 +118,7 @@ SIGNATURES = {
     "hdrsky_adam": (c_int, [P, P, P, P, c_size_t, c_float, c_float, c_float, c_float, c_float, P]),
     "hdrsky_resconv_supported": (c_int, [c_int] * 6),
     "hdrsky_resconv": (c_int, [ctypes.POINTER(ResconvArgs), P]),
-    "hdrsky_dgb_reduce": (c_int, [P, c_int, c_int, c_int, P]),
+    "hdrsky_dgb_reduce": (c_int, [P, c_int, c_int, P]),
     "hdrsky_to_bf16": (c_int, [P, P, c_size_t, P]),
 }
 

@@ -40,12 +40,15 @@ struct WgradArgs {
   int off_xlo, off_y, off_ylo, off_ss, off_red;
   int nchunks;                   // pixel split of this job
   int x_bf16, dy_bf16;           // operands stored as bf16 (the sample-resident conv chain) instead of fp32
+  float* ws;                     // deterministic mode: this job's workspace (per (chunk, block) slabs [taps][CB][OB], then
+  float* ws_db;                  //   per (chunk, co block) bias slabs [OB]); null = fp32 atomics straight into dw / db
 };
 
 constexpr int WG_MAXJ = 12;      // jobs per launch (the argument block must stay below 4 KB)
 struct MultiArgs {
   int njobs;
   int first[WG_MAXJ + 1];        // first block of each job (prefix sums), first[njobs] = grid size
+  int rfirst[WG_MAXJ + 1];       // the same for the reduce launch of the deterministic mode
   WgradArgs job[WG_MAXJ];
 };
 static_assert(sizeof(MultiArgs) <= 4096, "kernel argument block");
@@ -408,8 +411,11 @@ __global__ void __launch_bounds__(NW * 64) conv_wgrad_kernel(const MultiArgs m) 
         for (int j = 0; j < OBH; ++j)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const int ci = cb0 + (cih + i) * 16 + kq * 4 + e, co = ob0 + (ojh + j) * 16 + lr;
-            if (ci < a.Cin && co < a.Cout) atomicAdd(a.dw + ((size_t)tap * a.Cin + ci) * a.Cout + co, acc[t][i][j][e]);
+            const int cl = (cih + i) * 16 + kq * 4 + e, ol = (ojh + j) * 16 + lr;
+            const int ci = cb0 + cl, co = ob0 + ol;
+            if (a.ws != nullptr)   // split-K partial of this (chunk, block): plain stores, summed in a fixed order by wgrad_reduce_kernel
+              a.ws[(((size_t)chunk * nblk + blk) * a.ntaps + tap) * (CB * OB) + cl * OB + ol] = acc[t][i][j][e];
+            else if (ci < a.Cin && co < a.Cout) atomicAdd(a.dw + ((size_t)tap * a.Cin + ci) * a.Cout + co, acc[t][i][j][e]);
           }
     }
   }
@@ -422,7 +428,66 @@ __global__ void __launch_bounds__(NW * 64) conv_wgrad_kernel(const MultiArgs m) 
       const int qc = tid / 8, j = tid % 8;
       float s = 0.f;
       for (int k = qc; k < NT; k += NQY) s += sRed[k * 8 + j];
-      if (ob0 + tid < a.Cout) atomicAdd(a.db + ob0 + tid, s);
+      if (a.ws_db != nullptr) a.ws_db[((size_t)chunk * a.oblocks + blk % a.oblocks) * OB + tid] = s;
+      else if (ob0 + tid < a.Cout) atomicAdd(a.db + ob0 + tid, s);
+    }
+  }
+}
+
+// Second stage of the deterministic split-K: dw[tap][ci][co] += sum over the job's pixel chunks of the workgroup
+// partials, db likewise - always in the same order.  One launch for the jobs of a conv_wgrad_kernel launch; CB / OB = that
+// launch's block size in channels.  A block owns 64 float4 of a (block, tap) slab row set; its four waves each sum every
+// fourth chunk (16-byte loads, four independent chains in flight per thread), then wave 0 adds the four partial sums in
+// wave order.  (A single chain per element was latency bound: ~200 blocks of dependent strided loads, 58 us per launch.)
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const MultiArgs m, int CB, int OB) {
+  __shared__ float4 sPart[3][64];
+  int job = 0;
+  while (job + 1 < m.njobs && (int)blockIdx.x >= m.rfirst[job + 1]) ++job;
+  const WgradArgs& a = m.job[job];
+  const int nblk = a.cblocks * a.oblocks, ob4 = OB >> 2;
+  const size_t slab = (size_t)a.ntaps * CB * OB;                 // floats of one (chunk, block) partial
+  const size_t nvec = (size_t)nblk * a.ntaps * CB * ob4;         // float4 of one chunk
+  const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int rb = blockIdx.x - m.rfirst[job];
+  const size_t v = (size_t)rb * 64 + lane;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (v < nvec) {
+    const float4* src = reinterpret_cast<const float4*>(a.ws) + v;   // slabs of a chunk are contiguous: [blk][tap][cl][ol]
+    const size_t cstride = (size_t)nblk * slab / 4;
+    int c = slice;
+    for (; c + 12 < a.nchunks; c += 16) {
+      const float4 q0 = src[(size_t)c * cstride], q1 = src[(size_t)(c + 4) * cstride];
+      const float4 q2 = src[(size_t)(c + 8) * cstride], q3 = src[(size_t)(c + 12) * cstride];
+      acc.x += (q0.x + q1.x) + (q2.x + q3.x); acc.y += (q0.y + q1.y) + (q2.y + q3.y);
+      acc.z += (q0.z + q1.z) + (q2.z + q3.z); acc.w += (q0.w + q1.w) + (q2.w + q3.w);
+    }
+    for (; c < a.nchunks; c += 4) {
+      const float4 q = src[(size_t)c * cstride];
+      acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w;
+    }
+  }
+  if (slice > 0) sPart[slice - 1][lane] = acc;
+  __syncthreads();
+  if (slice == 0 && v < nvec) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const float4 q = sPart[k][lane]; acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w; }
+    const int ol = (int)(v % ob4) * 4, cl = (int)((v / ob4) % CB), tap = (int)((v / ((size_t)ob4 * CB)) % a.ntaps);
+    const int blk = (int)(v / ((size_t)ob4 * CB * a.ntaps));
+    const int ci = (blk / a.oblocks) * CB + cl, co = (blk % a.oblocks) * OB + ol;
+    if (ci < a.Cin) {
+      float* dst = a.dw + ((size_t)tap * a.Cin + ci) * a.Cout + co;
+      const float r[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (co + k < a.Cout) dst[k] += r[k];
+    }
+  }
+  if (rb == 0 && a.db != nullptr) {   // bias gradient of this job: [chunk][co block][OB] partials, tiny
+    for (int co = threadIdx.x; co < a.Cout; co += 256) {
+      const float* src = a.ws_db + (size_t)(co / OB) * OB + co % OB;
+      float t = 0.f;
+      for (int c = 0; c < a.nchunks; ++c) t += src[(size_t)c * a.oblocks * OB];
+      a.db[co] += t;
     }
   }
 }
@@ -571,9 +636,14 @@ static bool same_geo(const Geo& p, const Geo& q) {
 
 }  // namespace
 
-extern "C" int hdrsky_conv2d_wgrad_multi(const hdrsky_wgrad_job* jobs, int njobs, void* stream) {
+// Shared body of the two entry points.  ws == nullptr: split-K by fp32 atomics.  Otherwise deterministic: `ws` receives
+// the per-workgroup partials (ws_floats floats available; when plan_only, nothing is launched and *need_floats returns
+// the requirement), and a reduce launch per group adds them to dw / db in a fixed order.
+static int wgrad_multi_impl(const hdrsky_wgrad_job* jobs, int njobs, float* ws, size_t ws_floats, bool plan_only,
+                            size_t* need_floats, void* stream) {
   if (njobs < 0 || (njobs > 0 && !jobs)) return HDRSKY_EINVAL;
   if (njobs > 256) return HDRSKY_EUNSUPPORTED;
+  size_t ws_used = 0;
   // workgroups per launch (measured, profiles/microbench_wgrad.py): 256 for a layer on its own, 192 for a group
   int wg_hook = 0, force_small = 0;
   if (const char* e = getenv("HDRSKY_WGRAD")) sscanf(e, "%d,%d", &wg_hook, &force_small);   // tuning hook
@@ -603,25 +673,58 @@ extern "C" int hdrsky_conv2d_wgrad_multi(const hdrsky_wgrad_job* jobs, int njobs
       m.njobs = cnt;
       int lds = 0, rc = HDRSKY_OK;
       rc = with_variant(geo[i], [&](auto v) {
-        int blocks = 0;
+        using V = decltype(v);
+        int blocks = 0, rblocks = 0;
         for (int q = 0; q < cnt; ++q) {
           WgradArgs& a = m.job[q];
           int r = fill_job(a, jobs[members[base + q]]);
           if (r != HDRSKY_OK) return r;
           int target = (int)(wg_total * work[base + q] / wsum + 0.5);
-          r = decltype(v)::prepare(a, target);
+          r = V::prepare(a, target);
           if (r < 0) return r;
           if (r > lds) lds = r;
           m.first[q] = blocks;
           blocks += a.cblocks * a.oblocks * a.nchunks;
+          if (ws != nullptr || plan_only) {
+            const size_t nslab = (size_t)a.nchunks * a.cblocks * a.oblocks * a.ntaps * V::CB * V::OB;
+            const size_t nbias = (size_t)a.nchunks * a.oblocks * V::OB;
+            a.ws = ws + ws_used;
+            a.ws_db = a.db != nullptr ? ws + ws_used + nslab : nullptr;
+            ws_used += nslab + (a.db != nullptr ? nbias : 0);
+            m.rfirst[q] = rblocks;
+            rblocks += (int)(((size_t)a.cblocks * a.oblocks * a.ntaps * V::CB * (V::OB / 4) + 63) / 64);
+          }
         }
         m.first[cnt] = blocks;
-        return decltype(v)::launch(m, lds, (hipStream_t)stream);
+        m.rfirst[cnt] = rblocks;
+        if (plan_only) return (int)HDRSKY_OK;
+        if (ws != nullptr && ws_used > ws_floats) return (int)HDRSKY_EINVAL;
+        int r = V::launch(m, lds, (hipStream_t)stream);
+        if (r != HDRSKY_OK || ws == nullptr) return r;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(256), 0, (hipStream_t)stream, m, V::CB, V::OB);
+        HDRSKY_CHECK_LAUNCH();
+        return (int)HDRSKY_OK;
       });
       if (rc != HDRSKY_OK) return rc;
     }
   }
+  if (need_floats) *need_floats = ws_used;
   return HDRSKY_OK;
+}
+
+extern "C" int hdrsky_conv2d_wgrad_multi(const hdrsky_wgrad_job* jobs, int njobs, void* stream) {
+  return wgrad_multi_impl(jobs, njobs, nullptr, 0, false, nullptr, stream);
+}
+
+extern "C" size_t hdrsky_conv2d_wgrad_ws_bytes(const hdrsky_wgrad_job* jobs, int njobs) {
+  size_t need = 0;
+  if (wgrad_multi_impl(jobs, njobs, nullptr, 0, true, &need, nullptr) != HDRSKY_OK) return 0;
+  return need * sizeof(float);
+}
+
+extern "C" int hdrsky_conv2d_wgrad_multi_det(const hdrsky_wgrad_job* jobs, int njobs, void* ws, size_t ws_bytes, void* stream) {
+  if (!ws) return HDRSKY_EINVAL;
+  return wgrad_multi_impl(jobs, njobs, (float*)ws, ws_bytes / sizeof(float), false, nullptr, stream);
 }
 
 extern "C" int hdrsky_conv2d_wgrad(const hdrsky_conv_desc* d, const float* x, const float* dy, const float* in_scale,

@@ -330,11 +330,12 @@ __global__ void __launch_bounds__(512, 2) resconv_kernel(const RcArgs a) {
   RC_STAMP(6)
 }
 
-// out[j][c] += sum_b part[j][b][which][c] in a fixed order: the (d gamma, d beta) of every norm layer of the chain in
-// one launch.  table[j] = {part ptr, dgamma ptr, dbeta ptr} (3 x int64).
-__global__ void __launch_bounds__(256) dgb_reduce_kernel(const long long* __restrict__ table, int B, int C) {
-  const long long* e = table + (size_t)blockIdx.x * 3;
+// dst_which[j][c] += sum_b part[j][b][which][c] in a fixed batch order: the (d gamma, d beta) of every norm layer of a chain
+// in one launch.  table[j] = {part ptr ([B][2][C]), dst0 ptr ([C]), dst1 ptr ([C]), C} (4 x int64).
+__global__ void __launch_bounds__(256) dgb_reduce_kernel(const long long* __restrict__ table, int B) {
+  const long long* e = table + (size_t)blockIdx.x * 4;
   const float* part = reinterpret_cast<const float*>(e[0]);
+  const int C = (int)e[3];
   for (int i = threadIdx.x; i < 2 * C; i += 256) {
     const int which = i / C, c = i % C;
     float* dst = reinterpret_cast<float*>(e[1 + which]);
@@ -405,9 +406,9 @@ int hdrsky_resconv(const hdrsky_resconv_args* args, void* stream) {
   return u.Cin == 128 ? launch_resconv<4>(a, (hipStream_t)stream) : launch_resconv<2>(a, (hipStream_t)stream);
 }
 
-int hdrsky_dgb_reduce(const void* table, int nlayers, int B, int C, void* stream) {
-  if (!table || nlayers <= 0 || B <= 0 || C <= 0) return HDRSKY_EINVAL;
-  hipLaunchKernelGGL(dgb_reduce_kernel, dim3(nlayers), dim3(256), 0, (hipStream_t)stream, (const long long*)table, B, C);
+int hdrsky_dgb_reduce(const void* table, int nlayers, int B, void* stream) {
+  if (!table || nlayers <= 0 || B <= 0) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(dgb_reduce_kernel, dim3(nlayers), dim3(256), 0, (hipStream_t)stream, (const long long*)table, B);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }

@@ -171,7 +171,7 @@ def _xf_args(d, xf, B, H, W, C):
 
 
 def conv2d_wgrad(x, dy, KH, KW, stride=1, same=True, upsample=1, xf: Optional[InXf] = None, compute=BF16,
-                 want_db=True, dw=None, db=None):
+                 want_db=True, dw=None, db=None, deterministic=True):
     """(dw [KH,KW,Cin,Cout], db [Cout]) of the conv whose forward consumed xf(x) and produced dy's shape.
     Accumulates into dw/db when given (they must then already hold valid values), else allocates zeros."""
     _f32(x); _f32(dy)
@@ -187,8 +187,7 @@ def conv2d_wgrad(x, dy, KH, KW, stride=1, same=True, upsample=1, xf: Optional[In
     if db is None and want_db:
         db = torch.zeros((Cout,), dtype=torch.float32, device=x.device)
     _f32(dw, KH, KW, C, Cout)
-    L.check(L.load().hdrsky_conv2d_wgrad(d, _p(x), _p(dy), *[_p(t) for t in tabs], _p(dw), _p(db), _stream()),
-            "conv2d_wgrad")
+    conv2d_wgrad_multi([(d, x, dy, tabs, dw, db)], deterministic=deterministic)
     return dw, db
 
 
@@ -214,8 +213,10 @@ def wgrad_job(x, dy, KH, KW, dw, db=None, stride=1, same=True, upsample=1, xf: O
     return (d, x, dy, tabs, dw, db)
 
 
-def conv2d_wgrad_multi(jobs):
-    """Weight gradients of several independent conv layers in as few launches as the library can manage."""
+def conv2d_wgrad_multi(jobs, deterministic=True):
+    """Weight gradients of several independent conv layers in as few launches as the library can manage.
+    deterministic (default): the split-K partials go through a scratch buffer and are added in a fixed order - the
+    gradients are bit-reproducible; False: fp32 atomics straight into dw (no scratch, arrival-order summation)."""
     if not jobs:
         return
     arr = (L.WgradJob * len(jobs))()
@@ -225,7 +226,15 @@ def conv2d_wgrad_multi(jobs):
         j.x, j.dy, j.dw, j.db = _p(x), _p(dy), _p(dw), _p(db)
         j.in_scale, j.in_shift, j.in_part, j.in_gamma, j.in_beta = [_p(t) for t in tabs]
         j.x_bf16, j.dy_bf16 = int(x.dtype == torch.bfloat16), int(dy.dtype == torch.bfloat16)
-    L.check(L.load().hdrsky_conv2d_wgrad_multi(arr, len(jobs), _stream()), "conv2d_wgrad_multi")
+    lib = L.load()
+    if not deterministic:
+        L.check(lib.hdrsky_conv2d_wgrad_multi(arr, len(jobs), _stream()), "conv2d_wgrad_multi")
+        return
+    nbytes = int(lib.hdrsky_conv2d_wgrad_ws_bytes(arr, len(jobs)))
+    if nbytes <= 0:
+        raise L.HdrSkyError("conv2d_wgrad_multi: unsupported layer geometry")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=jobs[0][1].device)
+    L.check(lib.hdrsky_conv2d_wgrad_multi_det(arr, len(jobs), _p(ws), nbytes, _stream()), "conv2d_wgrad_multi_det")
 
 
 def norm_apply(x, stats: Stats, gamma, beta, slope=1.0, residual=None, pool=False, eps=IN_EPS):
@@ -264,14 +273,21 @@ def bn_eval_affine(gamma, beta, mm, mv, eps=IN_EPS):
     return scale, shift
 
 
-def norm_act_bwd(x, stats: Stats, gamma, beta, slope, dy, pooled, eps=IN_EPS, want_sums=False, dgamma=None, dbeta=None):
-    """dx of y = leaky(IN(x)) [-> maxpool2x2]; dy is the gradient wrt y (or wrt the pooled y)."""
+def norm_act_bwd(x, stats: Stats, gamma, beta, slope, dy, pooled, eps=IN_EPS, want_sums=False, dgamma=None, dbeta=None,
+                 sums=None):
+    """dx of y = leaky(IN(x)) [-> maxpool2x2]; dy is the gradient wrt y (or wrt the pooled y).
+    sums [B,2,C] (given, or allocated when want_sums): per-sample (d beta, d gamma) terms - reduce them over the batch with
+    DgbReducer for bit-reproducible gradients; dgamma / dbeta: accumulated by fp32 atomics instead (arrival order)."""
     _f32(x)
     B, H, W, C = x.shape
     _f32(stats.part, B, stats.nparts, 2, C)
     _f32(dy, B, H // 2 if pooled else H, W // 2 if pooled else W, C)
     dx = torch.empty_like(x)
-    sums = torch.empty((B, 2, C), dtype=torch.float32, device=x.device) if want_sums else None
+    if sums is not None:
+        _f32(sums, B, 2, C)
+        want_sums = False
+    elif want_sums:
+        sums = torch.empty((B, 2, C), dtype=torch.float32, device=x.device)
     S = L.load().hdrsky_norm_act_bwd_nslices(B, H, W, C, int(pooled))
     ws = torch.empty((B, S, 2, C), dtype=torch.float32, device=x.device) if S > 1 else None
     L.check(L.load().hdrsky_norm_act_bwd(_p(x), _p(stats.part), stats.nparts, _p(_f32(gamma, C)), _p(_f32(beta, C)),
@@ -778,21 +794,27 @@ def resconv_bwd(dy, pwT, skip=None, norm=None, want_f32=False, want_bf16=True, s
 
 
 class DgbReducer:
-    """One-launch, fixed-order reduction of the per-sample (d gamma, d beta) terms of several norm layers
-    (hdrsky_dgb_reduce): entries = [(dgb [B,2,C], dgamma [C], dbeta [C]), ...] (gradients are added to)."""
+    """One-launch, fixed-order reduction over the batch of several per-sample tables (hdrsky_dgb_reduce):
+    entries = [(part [B,2,C], dst0 [C] or None, dst1 [C] or None), ...]; dst_k += sum_b part[b, k].  resconv's `dgb` holds
+    (d gamma, d beta), norm_act_bwd's `sums` (d beta, d gamma).  The pointer table is uploaded in the constructor (not
+    capturable); run() is one launch."""
 
     def __init__(self, entries):
-        self.B, _, self.C = entries[0][0].shape
+        self.B = entries[0][0].shape[0]
         rows = []
-        for dgb, dg, db in entries:
-            _f32(dgb, self.B, 2, self.C); _f32(dg, self.C); _f32(db, self.C)
-            rows.append([dgb.data_ptr(), dg.data_ptr(), db.data_ptr()])
+        for part, d0, d1 in entries:
+            C = part.shape[2]
+            _f32(part, self.B, 2, C)
+            for d in (d0, d1):
+                if d is not None:
+                    _f32(d, C)
+            rows.append([part.data_ptr(), d0.data_ptr() if d0 is not None else 0, d1.data_ptr() if d1 is not None else 0, C])
         self.n = len(rows)
         self.table = torch.tensor(rows, dtype=torch.int64, device=entries[0][0].device)
         self._keep = entries
 
     def run(self):
-        L.check(L.load().hdrsky_dgb_reduce(_p(self.table), self.n, self.B, self.C, _stream()), "dgb_reduce")
+        L.check(L.load().hdrsky_dgb_reduce(_p(self.table), self.n, self.B, _stream()), "dgb_reduce")
 
 
 # ------------------------------------------------------------------------------------------------

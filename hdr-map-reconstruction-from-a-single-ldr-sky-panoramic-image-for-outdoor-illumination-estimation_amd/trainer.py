@@ -181,10 +181,43 @@ class Trainer:
         w = self.gs.w
         return InXf(mode=L.IN_PARTIALS, slope=slope, stats=stats, gamma=w[name + ".gamma"], beta=w[name + ".beta"])
 
+    # InstanceNorm layers whose (d gamma, d beta) are produced by hdrsky_norm_act_bwd, by the plan segment that
+    # differentiates them: their per-sample terms land in persistent tables and one fixed-order launch per segment adds
+    # them to the gradient vectors (bit-reproducible; fp32 atomics would sum in arrival order)
+    NORM_GROUPS = {
+        "bwd_sunpose": ["sun.sunlayer%d.norm%d" % (l, j) for l in (3, 2, 1) for j in (2, 1)],
+        "bwd_dec": ["gen.norm%d_%s" % (k, sfx) for sfx in ("f", "u") for k in (2, 3)],
+        "bwd_res": ["gen.res.%d.norm%d" % (i, j) for i in range(6) for j in (1, 2)],
+        "bwd_enc": ["gen.norm3_d", "gen.norm2_d", "gen.norm1_d"],
+    }
+
+    def _norm_state(self, B):
+        st = getattr(self, "_nstate", None)
+        if st is None:
+            st = self._nstate = {}
+        if B not in st:
+            w, g, sums, red = self.gs.w, self.gs.g, {}, {}
+            for seg, names in self.NORM_GROUPS.items():
+                entries = []
+                for n in names:
+                    if n + ".gamma" not in w:
+                        continue
+                    t = torch.zeros((B, 2, w[n + ".gamma"].numel()), dtype=torch.float32, device=self.device)
+                    sums[n] = t
+                    entries.append((t, g[n + ".beta"], g[n + ".gamma"]))      # norm_act_bwd's table: (d beta, d gamma)
+                if entries:
+                    red[seg] = K.DgbReducer(entries)
+            st[B] = (sums, red)
+        return st[B]
+
     def _in_bwd(self, x, stats, name, slope, dy, pooled=False):
-        w, g = self.gs.w, self.gs.g
+        w = self.gs.w
         return K.norm_act_bwd(x, stats, w[name + ".gamma"], w[name + ".beta"], slope, dy, pooled,
-                              dgamma=g[name + ".gamma"], dbeta=g[name + ".beta"])
+                              sums=self._norm_state(x.shape[0])[0][name])
+
+    def _norm_grads(self, seg, B):
+        """Adds the per-sample (d gamma, d beta) terms of segment `seg`'s norm layers to the gradient vectors."""
+        self._norm_state(B)[1][seg].run()
 
     def _rc_state(self, B):
         """Per-batch-size state of the sample-resident res chain: the per-sample (d gamma, d beta) terms of its 12 norm
@@ -565,6 +598,7 @@ class Trainer:
                 self._wg(n + ".conv1", t["in%d" % l], None, dr1)
                 if l > 1:
                     dP = c[n + ".conv1"].dgrad(t["in%d" % l], dr1, cp)
+            self._norm_grads("bwd_sunpose", B)
             self._flush_wgrads()
 
         # ------------------------------------------------------------------ generator backward; its weight gradients
@@ -583,6 +617,7 @@ class Trainer:
                 dd3 = self._in_bwd(d3, s3, "gen.norm3_" + sfx, 0.1, da3)
                 self._wg("gen.conv3_" + sfx, T["x"][-1], None, dd3)
                 c["gen.conv3_" + sfx].dgrad(T["x"][-1], dd3, cp, out=dres)
+            self._norm_grads("bwd_dec", B)
             T["wq_dec"] = self._take_wgrads()
 
         @seg("wg_dec", 1, ["bwd_dec"])
@@ -638,6 +673,8 @@ class Trainer:
                 dr1 = self._in_bwd(r1, t1, p + "norm1", 0.1, da1)
                 self._wg(p + "conv1", T["x"][i], None, dr1)
                 dx = c[p + "conv1"].dgrad(T["x"][i], dr1, cp, residual=dx)      # + identity branch
+            if not self.use_resconv:
+                self._norm_grads("bwd_res", B)
             T["dx_enc"] = dx
             T["wq_res"] = self._take_wgrads()
 
@@ -655,6 +692,7 @@ class Trainer:
             da1 = c["gen.conv2_d"].dgrad(T["c1"], dc2, cp)
             dc1 = self._in_bwd(T["c1"], T["s1"], "gen.norm1_d", 0.1, da1)
             self._wg("gen.conv1_d", T["ldr"], None, dc1)
+            self._norm_grads("bwd_enc", B)
             self._flush_wgrads()
 
         # The two Dense layers hold 50.3 M of the 58.3 M parameters and nothing reads their weights or gradients after
@@ -732,6 +770,9 @@ class Trainer:
         return self._events[name]
 
     def _bind(self, ldr, hdr_t, sunpose_gt):
+        self._norm_state(ldr.shape[0])            # pointer tables are uploaded here, never inside a graph capture
+        if self.use_resconv:
+            self._rc_state(ldr.shape[0])
         self._T = dict(ldr=ldr, hdr_t=hdr_t, gt=sunpose_gt)
         self._segs = self._plan()
         self._events = {}
@@ -874,6 +915,7 @@ class SunPoseTrainer(Trainer):
             self._wg(n + ".conv1", t["in%d" % l], None, dr1)
             if l > 1:
                 dP = c[n + ".conv1"].dgrad(t["in%d" % l], dr1, cp)
+        self._norm_grads("bwd_sunpose", B)
         self._flush_wgrads()
         if update:
             self.apply_gradients()

@@ -221,6 +221,12 @@ typedef struct hdrsky_wgrad_job {
   int32_t dy_bf16;  /* 1: dy points to bf16 data                             in_mode NONE / Cin, Cout % 8 == 0) */
 } hdrsky_wgrad_job;
 int hdrsky_conv2d_wgrad_multi(const hdrsky_wgrad_job* jobs, int njobs, void* stream);
+/* The same weight gradients, BIT-REPRODUCIBLE: hdrsky_conv2d_wgrad(_multi) splits the pixel reduction over workgroups
+ * and adds their partial blocks into dw with fp32 atomics (arrival order = summation order).  Here every workgroup
+ * stores its partial block into `ws` (device scratch, hdrsky_conv2d_wgrad_ws_bytes(jobs, njobs) bytes, 16-byte aligned)
+ * and a second launch per group adds the partials to dw / db in a fixed order.  [host] for the size query. */
+size_t hdrsky_conv2d_wgrad_ws_bytes(const hdrsky_wgrad_job* jobs, int njobs);
+int hdrsky_conv2d_wgrad_multi_det(const hdrsky_wgrad_job* jobs, int njobs, void* ws, size_t ws_bytes, void* stream);
 
 /* Keras BatchNormalization(training=True) statistics from the producing conv's partials [nparts_total][2][C]
  * (discriminator.py:25, sunrad_net.py:26): mean/rstd/scale/shift tables + moving-stat update (momentum 0.99,
@@ -372,9 +378,11 @@ typedef struct hdrsky_resconv_args {
 /* 1 when hdrsky_resconv handles this layer geometry (8 x 32 pixels, 3x3, Cin 64|128, Cout % 16 == 0). [host] */
 int hdrsky_resconv_supported(int H, int W, int Cin, int Cout, int KH, int KW);
 int hdrsky_resconv(const hdrsky_resconv_args* args, void* stream);
-/* d gamma / d beta of `nlayers` norm layers in one launch, batch order fixed (bit-reproducible):
- * table: device array [nlayers][3] of int64 {dgb ptr ([B][2][C]), dgamma ptr ([C], +=), dbeta ptr ([C], +=)}. */
-int hdrsky_dgb_reduce(const void* table, int nlayers, int B, int C, void* stream);
+/* Per-channel sums over the batch of `nlayers` per-sample tables in one launch, batch order fixed (bit-reproducible): the
+ * (d gamma, d beta) of norm layers from hdrsky_resconv's `dgb` ([B][2][C]: d gamma, d beta) or from hdrsky_norm_act_bwd's
+ * `sums` ([B][2][C]: d beta, d gamma).  table: device array [nlayers][4] of int64
+ * {part ptr ([B][2][C]), dst0 ptr ([C], += sum_b part[b][0], nullable), dst1 ptr ([C], += sum_b part[b][1], nullable), C}. */
+int hdrsky_dgb_reduce(const void* table, int nlayers, int B, void* stream);
 /* y (bf16) = round-to-nearest-even(x) for n contiguous floats, n % 8 == 0: entry of a bf16 activation chain. */
 int hdrsky_to_bf16(const float* x, void* y, size_t n, void* stream);
 
