@@ -27,18 +27,20 @@ __global__ void __launch_bounds__(64) bn_train_finalize_kernel(const float* __re
                                                                float count, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float eps, float momentum,
                                                                float* moving_mean, float* moving_var, float* mean,
-                                                               float* rstd, float* scale, float* shift) {
+                                                               float* rstd, float* scale, float* shift, int rows) {
   const int c = blockIdx.x;  // one wave per channel; lanes stride over the partials (fixed shuffle tree: deterministic)
   float s = 0.f, ss = 0.f;
   for (int p = threadIdx.x; p < nparts_total; p += 64) { s += part[(size_t)(2 * p) * C + c]; ss += part[(size_t)(2 * p + 1) * C + c]; }
   s = wave_sum(s); ss = wave_sum(ss);
-  if (threadIdx.x != 0) return;
   const float m = s / count;
   const float var = fmaxf(ss / count - m * m, 0.f);
   const float r = 1.f / sqrtf(var + eps);
-  mean[c] = m; rstd[c] = r;
   const float inv = gamma[c] * r;
-  scale[c] = inv; shift[c] = beta[c] - m * inv;
+  // scale / shift as `rows` identical rows of a [rows][C] table (per-sample affine tables of a batch that holds several
+  // BatchNorm groups: the paired discriminator passes)
+  for (int q = threadIdx.x; q < rows; q += 64) { scale[(size_t)q * C + c] = inv; shift[(size_t)q * C + c] = beta[c] - m * inv; }
+  if (threadIdx.x != 0) return;
+  mean[c] = m; rstd[c] = r;
   if (moving_mean) {
     moving_mean[c] = moving_mean[c] * momentum + m * (1.f - momentum);
     moving_var[c] = moving_var[c] * momentum + var * (count / fmaxf(count - 1.f, 1.f)) * (1.f - momentum);
@@ -759,10 +761,10 @@ extern "C" {
 
 int hdrsky_bn_train_finalize(const float* part, int nparts_total, int C, int count, const float* gamma, const float* beta,
                              float eps, float momentum, float* moving_mean, float* moving_var, float* mean, float* rstd,
-                             float* scale, float* shift, void* stream) {
-  if (!part || !gamma || !beta || !mean || !rstd || !scale || !shift) return HDRSKY_EINVAL;
+                             float* scale, float* shift, int rows, void* stream) {
+  if (!part || !gamma || !beta || !mean || !rstd || !scale || !shift || rows < 1) return HDRSKY_EINVAL;
   hipLaunchKernelGGL(bn_train_finalize_kernel, dim3(C), dim3(64), 0, S_(stream), part, nparts_total, C,
-                     (float)count, gamma, beta, eps, momentum, moving_mean, moving_var, mean, rstd, scale, shift);
+                     (float)count, gamma, beta, eps, momentum, moving_mean, moving_var, mean, rstd, scale, shift, rows);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }
@@ -962,6 +964,12 @@ int hdrsky_fc_wgrad(const float* x, const float* dy, int M, int K, int N, int ac
   hipLaunchKernelGGL(fc_wgrad_kernel, dim3(cdiv(N / 4, 256), K / 8), dim3(256), 0, S_(stream), x, dy, M, K, N, accumulate, dw, db);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
+}
+
+int hdrsky_zero(void* p, size_t nbytes, void* stream) {
+  if (!p) return HDRSKY_EINVAL;
+  if (nbytes == 0) return HDRSKY_OK;
+  return hipMemsetAsync(p, 0, nbytes, S_(stream)) == hipSuccess ? HDRSKY_OK : HDRSKY_ELAUNCH;
 }
 
 int hdrsky_adam(float* w, const float* g, float* m, float* v, size_t n, float lr_t, float beta1, float beta2, float eps,

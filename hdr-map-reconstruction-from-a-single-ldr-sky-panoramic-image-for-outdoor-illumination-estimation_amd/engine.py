@@ -106,7 +106,7 @@ def sunpose_forward(nets, ldr, compute):
     t["flat"] = flat
     t["f1"] = K.fc_finalize(K.fc_fwd(flat, pk["sun.fc1"], compute), s["fc1.bias"], relu=True)
     part2 = K.fc_fwd(t["f1"], pk["sun.fc2"], compute)
-    t["gmax"] = torch.zeros(1, dtype=torch.int32, device=ldr.device)
+    t["gmax"] = K.zero_(torch.empty(1, dtype=torch.int32, device=ldr.device))
     t["z"], t["cmf"] = K.softmax_head(part2, s["fc2.bias"], t["gmax"])
     return t
 

@@ -488,14 +488,32 @@ def _empty_like_shape(t, shape):
     return torch.empty(shape, dtype=torch.float32, device=t.device)
 
 
-def bn_train_finalize(stats: Stats, gamma, beta, B, C, moving_mean=None, moving_var=None, eps=IN_EPS, momentum=0.99):
-    """Batch statistics over (N,H,W) from conv partials -> (mean, rstd, scale, shift) [C]; updates moving stats in place."""
+def bn_train_finalize(stats: Stats, gamma, beta, B, C, moving_mean=None, moving_var=None, eps=IN_EPS, momentum=0.99,
+                      scale_rows=None, shift_rows=None):
+    """Batch statistics over (N,H,W) from conv partials -> (mean, rstd, scale, shift) [C]; updates moving stats in place.
+    scale_rows / shift_rows [R,C] (given together): scale / shift are written as R identical rows into them instead (the
+    per-sample affine tables of a batch that holds several BatchNorm groups)."""
     _f32(stats.part, B, stats.nparts, 2, C)
-    outs = [torch.empty((C,), dtype=torch.float32, device=gamma.device) for _ in range(4)]
+    outs = [torch.empty((C,), dtype=torch.float32, device=gamma.device) for _ in range(2)]
+    rows = 1
+    if scale_rows is not None:
+        rows = scale_rows.shape[0]
+        _f32(scale_rows, rows, C); _f32(shift_rows, rows, C)
+        outs += [scale_rows, shift_rows]
+    else:
+        outs += [torch.empty((C,), dtype=torch.float32, device=gamma.device) for _ in range(2)]
     L.check(L.load().hdrsky_bn_train_finalize(_p(stats.part), B * stats.nparts, C, B * stats.count, _p(_f32(gamma, C)),
                                               _p(_f32(beta, C)), eps, momentum, _p(moving_mean), _p(moving_var),
-                                              *[_p(o) for o in outs], _stream()), "bn_train_finalize")
+                                              *[_p(o) for o in outs], rows, _stream()), "bn_train_finalize")
     return outs
+
+
+def zero_(t):
+    """Zero-fill of a contiguous tensor on the current stream (hipMemsetAsync: a memset node under graph capture)."""
+    if not (torch.is_tensor(t) and t.is_cuda and t.is_contiguous()):
+        raise ValueError("expected a contiguous CUDA tensor")
+    L.check(L.load().hdrsky_zero(_p(t), t.numel() * t.element_size(), _stream()), "zero")
+    return t
 
 
 def bn_act_bwd(x, dy, mean, rstd, gamma, beta, slope, dgamma=None, dbeta=None, out=None):

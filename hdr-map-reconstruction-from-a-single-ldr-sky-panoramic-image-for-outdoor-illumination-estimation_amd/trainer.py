@@ -265,7 +265,7 @@ class Trainer:
         B = ldr.shape[0]
         t["flat"] = x.reshape(B, -1)
         t["f1"] = K.fc_finalize(K.fc_fwd(t["flat"], self.fc1, cp), w["sun.fc1.bias"], relu=True)
-        t["gmax"] = torch.zeros(1, dtype=torch.int32, device=ldr.device)
+        t["gmax"] = K.zero_(torch.empty(1, dtype=torch.int32, device=ldr.device))
         t["z"], t["cmf"] = K.softmax_head(K.fc_fwd(t["f1"], self.fc2, cp), w["sun.fc2.bias"], t["gmax"])
         return t
 
@@ -351,10 +351,9 @@ class Trainer:
             halves = []
             for hf in (0, 1):
                 sth = K.Stats(st.part[hf * B:(hf + 1) * B], st.nparts, st.count)
-                mean, rstd, sc, sh = K.bn_train_finalize(sth, params[n + "gamma"], params[n + "beta"], B, C,
-                                                         params[n + "moving_mean"], params[n + "moving_variance"])
-                sc2[hf * B:(hf + 1) * B] = sc      # broadcast row copy
-                sh2[hf * B:(hf + 1) * B] = sh
+                mean, rstd, _, _ = K.bn_train_finalize(sth, params[n + "gamma"], params[n + "beta"], B, C,
+                                                       params[n + "moving_mean"], params[n + "moving_variance"],
+                                                       scale_rows=sc2[hf * B:(hf + 1) * B], shift_rows=sh2[hf * B:(hf + 1) * B])
                 halves.append((mean, rstd))
             R[d] = dict(x=cur, xf=xf, raw=raw, halves=halves)
             cur, xf = raw, InXf(mode=L.IN_AFFINE, slope=0.3, scale=sc2, shift=sh2)
@@ -474,7 +473,8 @@ class Trainer:
 
         @seg("fwd_enc", 0)
         def _():
-            self.gs.grad.zero_(); self.ds.grad.zero_(); self.losses.zero_()
+            # (the two Dense kernels + biases, 201 of the 222 MB, are overwritten by their weight-gradient launches)
+            K.zero_(self.gs.grad[:self.fc_grad_range()[0]]); K.zero_(self.ds.grad); K.zero_(self.losses)
             ldr = T["ldr"]
             T["c1"], T["s1"] = c["gen.conv1_d"].fwd(ldr, compute=cp, want_stats=True)        # generator.py:92-108
             T["xf2"] = self._inxf(T["s1"], "gen.norm1_d", 0.1)
@@ -605,7 +605,7 @@ class Trainer:
         # are launched in groups on stream 3 as soon as each stretch of the chain has produced their operands
         @seg("bwd_dec", 0)
         def _():
-            dres = T["dres"] = torch.zeros_like(T["x"][-1])
+            dres = T["dres"] = K.zero_(torch.empty_like(T["x"][-1]))
             for sfx in ("f", "u"):
                 d3, s3, xf2, d2, s2, xf1, y, residual = T["dec_" + sfx]
                 dc = T["tails"][sfx][0]
@@ -894,7 +894,7 @@ class SunPoseTrainer(Trainer):
         dog_weight is 1 in the reference (train_sun.py:255)."""
         w, g, c, cp = self.gs.w, self.gs.g, self.conv, self.compute
         B = ldr.shape[0]
-        self.gs.grad.zero_(); self.losses.zero_()
+        K.zero_(self.gs.grad); K.zero_(self.losses)
         t = self._sunpose_forward(ldr)
         cams = self._gradcam(t, sunpose_gt) if want_cams else None              # under stop_recording: constants
         dcmf = K.kl(sunpose_gt, t["cmf"], self.losses[0:1])                     # d KL / d cmf

@@ -231,7 +231,11 @@ int hdrsky_conv2d_wgrad_multi_det(const hdrsky_wgrad_job* jobs, int njobs, void*
 /* Keras BatchNormalization(training=True) statistics from the producing conv's partials [nparts_total][2][C]
  * (discriminator.py:25, sunrad_net.py:26): mean/rstd/scale/shift tables + moving-stat update (momentum 0.99,
  * Bessel-corrected variance).  moving_* nullable. */
-int hdrsky_bn_train_finalize(const float* part, int nparts_total, int C, int count, const float* gamma, const float* beta, float eps, float momentum, float* moving_mean, float* moving_var, float* mean, float* rstd, float* scale, float* shift, void* stream);
+int hdrsky_bn_train_finalize(const float* part, int nparts_total, int C, int count, const float* gamma, const float* beta, float eps, float momentum, float* moving_mean, float* moving_var, float* mean, float* rstd, float* scale, float* shift, int rows, void* stream);
+/* (scale / shift are written as `rows` identical rows of a [rows][C] table: rows = 1 for per-channel tables, rows = B to
+ * fill the per-sample affine tables of a batch that carries several BatchNorm groups side by side.)
+ * Zero-fill of device memory on `stream` (a memset node under graph capture): gradient / loss accumulators. */
+int hdrsky_zero(void* p, size_t nbytes, void* stream);
 /* [host] number of reduction blocks hdrsky_bn_act_bwd uses; its workspace is (2*nblocks*C + 2*C) floats. */
 int hdrsky_bn_bwd_nblocks(void);
 /* Backward of y = leaky(BN_train(x)): dx, and dgamma/dbeta ACCUMULATED into the given buffers (nullable). */
