@@ -112,6 +112,7 @@ SIGNATURES = {
     "hdrsky_slice_channels": (c_int, [P, c_size_t, c_int, c_int, c_int, c_float, c_int, P, P]),
     "hdrsky_concat2": (c_int, [P, c_int, P, c_int, c_size_t, P, P]),
     "hdrsky_vgg_pre": (c_int, [P, c_size_t, P, P]),
+    "hdrsky_flip_rgb": (c_int, [P, c_size_t, P, P]),
     "hdrsky_axpby": (c_int, [P, c_float, P, c_float, c_size_t, P, P]),
     "hdrsky_fc_wgrad": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, P]),
     "hdrsky_rmsprop": (c_int, [P, P, P, c_size_t, c_float, c_float, c_float, c_float, P]),

@@ -128,13 +128,55 @@ def import_tf_bundle(prefix):
     return tensors, epoch
 
 
-def export_tf_bundle(prefix, tensors, epoch):
-    """Writes the model variables of `tensors` (native keys; the flat optimizer buffers are skipped) as a TF tensor
-    bundle with object-graph style keys, plus `epoch` / `save_counter` like tf.train.Checkpoint."""
+_ATTR = {"b": "biases", "kernel_deconv2d": "kernel", "bias_deconv2d": "biases"}     # add_weight name -> layer attribute (ops.py)
+
+
+def _attr_path(key):
+    """Native key -> the object-graph path a tf.train.Checkpoint of the reference's classes uses: `res/<i>` ->
+    `res/sequence/<i>` and the LAST component spelled like the attribute the layer keeps the variable under."""
+    parts = tf_path(key).split("/")
+    if parts[0] in ("gen_model", "lin") and len(parts) >= 3 and parts[-1] in _ATTR and "sun" not in parts[1:2] \
+            and not parts[-2].startswith("norm") and parts[-2] not in ("fc1", "fc2"):
+        parts[-1] = _ATTR[parts[-1]]
+    return "/".join(parts)
+
+
+def export_tf_bundle(prefix, tensors, epoch, slots=None):
+    """Writes the model variables of `tensors` (native keys; the flat optimizer buffers are skipped) as a TF tensor bundle
+    in the layout of `tf.train.Checkpoint(epoch=..., gen_model=..., dis_model=..., gen_optimizer=..., disc_optimizer=...)
+    .save` (train.py:208-220) / `Checkpoint(epoch, lin, optimizer)` (tf_utils.py:309-312): every variable under
+    `<attribute path>/.ATTRIBUTES/VARIABLE_VALUE`, `epoch` and `save_counter`, per-variable optimizer slots
+    (`slots`: {optimizer name: {native variable key: array}}, e.g. from `sky_slots`) under
+    `<variable path>/.OPTIMIZER_SLOT/<optimizer>/rms/...`, and the `_CHECKPOINTABLE_OBJECT_GRAPH` string entry that
+    `Checkpoint.restore` walks (tf_bundle.object_graph).  UNPINNED against TensorFlow itself: written from the public
+    format definition; no TF build and no reference checkpoint exist in this environment to read it back with."""
     from . import tf_bundle
-    out = {tf_path(k): np.asarray(v) for k, v in tensors.items() if not k.endswith("_optimizer/rms") and not k.startswith("optimizer/")}
-    out["epoch"] = np.asarray(epoch, np.int64)
+    out, names = {}, {}
+    for k, v in tensors.items():
+        if k.endswith("_optimizer/rms") or k.startswith("optimizer/"):
+            continue
+        path = _attr_path(k)
+        out[path + tf_bundle.SUFFIX] = np.asarray(v)
+        names[path] = k.split("/", 1)[-1]          # full_name: the variable's own name (informational in TF)
+    for opt, per_var in (slots or {}).items():
+        for k, v in per_var.items():
+            out[_attr_path(k) + tf_bundle.SLOT + opt + "/rms" + tf_bundle.SUFFIX] = np.asarray(v, np.float32)
+    out["epoch" + tf_bundle.SUFFIX] = np.asarray(epoch, np.int64)
     m = re.search(r"ckpt-(\d+)$", prefix)
-    out["save_counter"] = np.asarray(int(m.group(1)) if m else 1, np.int64)
-    tf_bundle.write_bundle(prefix, tf_bundle.to_variable_keys(out))
+    out["save_counter" + tf_bundle.SUFFIX] = np.asarray(int(m.group(1)) if m else 1, np.int64)
+    out[tf_bundle.OBJECT_GRAPH_KEY] = tf_bundle.object_graph(list(out), names)
+    tf_bundle.write_bundle(prefix, out)
     return prefix
+
+
+def sky_slots(trainer):
+    """Per-variable RMSprop slots of the SKY checkpoint's optimizers, cut out of the flat slot buffers:
+    {"gen_optimizer": {native key: rms array}, "disc_optimizer": {...}} for the variables the checkpoint's object graph
+    reaches (gen_model, dis_model; the sun-pose net's slots live in optimizer_gen but its variables are not in this graph)."""
+    out = {"gen_optimizer": {}, "disc_optimizer": {}}
+    for fp, opt, pre, model in ((trainer.gs, "gen_optimizer", "gen.", "gen_model/"), (trainer.ds, "disc_optimizer", "dis.", "dis_model/")):
+        ms = fp.ms.detach().cpu().numpy()
+        for k, (o, n, shape) in fp.offsets.items():
+            if k.startswith(pre) and o < fp.ntrain:
+                out[opt][model + k[len(pre):].replace(".", "/")] = ms[o:o + n].reshape(shape)
+    return out

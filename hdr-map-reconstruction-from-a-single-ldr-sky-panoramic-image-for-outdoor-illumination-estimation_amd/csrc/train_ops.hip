@@ -951,6 +951,21 @@ int hdrsky_vgg_pre(const float* x, size_t n, float* y, void* stream) {
   return HDRSKY_OK;
 }
 
+__global__ void __launch_bounds__(256) flip3_kernel(const float* __restrict__ x, size_t npix, float* __restrict__ y) {
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
+    const float a = x[3 * i], b = x[3 * i + 1], c = x[3 * i + 2];
+    y[3 * i] = c; y[3 * i + 1] = b; y[3 * i + 2] = a;
+  }
+}
+
+int hdrsky_flip_rgb(const float* x, size_t npix, float* y, void* stream) {
+  if (!x || !y) return HDRSKY_EINVAL;
+  if (npix == 0) return HDRSKY_OK;
+  hipLaunchKernelGGL(flip3_kernel, dim3(grid_for(npix)), dim3(256), 0, S_(stream), x, npix, y);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
 int hdrsky_axpby(const float* a, float sa, const float* b, float sb, size_t n, float* y, void* stream) {
   if (!a || !y) return HDRSKY_EINVAL;
   hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(256), 0, S_(stream), a, sa, b, sb, n, y);

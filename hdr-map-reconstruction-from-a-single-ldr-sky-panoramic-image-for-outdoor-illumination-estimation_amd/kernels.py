@@ -684,6 +684,16 @@ def vgg_pre(x):
     return y
 
 
+def flip_rgb(x):
+    """Channel reversal of a [...,3] tensor (tf_utils.py:85-93)."""
+    _f32(x)
+    if x.shape[-1] != 3:
+        raise ValueError("3-channel images expected")
+    y = torch.empty_like(x)
+    L.check(L.load().hdrsky_flip_rgb(_p(x), x.numel() // 3, _p(y), _stream()), "flip_rgb")
+    return y
+
+
 def axpby(a, sa, b=None, sb=0.0, out=None):
     y = out if out is not None else torch.empty_like(a)
     L.check(L.load().hdrsky_axpby(_p(_f32(a)), sa, _p(b), sb, a.numel(), _p(y), _stream()), "axpby")

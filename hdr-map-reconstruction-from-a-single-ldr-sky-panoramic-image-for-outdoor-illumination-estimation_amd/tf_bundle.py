@@ -11,9 +11,14 @@ little-endian tensor bytes back to back.  Object-based checkpoints name variable
 read_bundle(prefix)          -> {key: ndarray} of every numeric tensor (CRCs of blocks and tensors verified; string
                                 entries such as the object graph are skipped); reads uncompressed and snappy blocks.
 write_bundle(prefix, dict)   -> the two files, single shard, uncompressed blocks (what TF's BundleWriter emits), readable
-                                through TF's low-level reader (`tf.train.load_checkpoint(prefix).get_tensor(key)`).  The
-                                object-graph entry that `tf.train.Checkpoint.restore` additionally wants is NOT
-                                synthesised.
+                                through TF's low-level reader (`tf.train.load_checkpoint(prefix).get_tensor(key)`); `bytes`
+                                values are written as scalar DT_STRING tensors.
+object_graph(keys)           -> the serialized TrackableObjectGraph proto (trackable_object_graph.proto) that
+                                `tf.train.Checkpoint.restore` walks: one node per object on the variables' attribute
+                                paths, `children` edges named after the path components, a VARIABLE_VALUE attribute per
+                                variable, `slot_variables` for `<var>/.OPTIMIZER_SLOT/<optimizer>/<slot>` keys; stored
+                                under the key `_CHECKPOINTABLE_OBJECT_GRAPH`.
+parse_object_graph(bytes)    -> the node list back ({children, attributes, slots}) for tools and tests.
 variable_tensors(bundle)     -> strips the `/.ATTRIBUTES/VARIABLE_VALUE` suffix (drops optimizer-slot entries), giving
                                 the `gen_model/...`, `dis_model/...`, `lin/...` keys checkpoint.load_into expects.
 
@@ -259,6 +264,19 @@ def write_bundle(prefix, tensors):
         for key in sorted(tensors, key=lambda s: s.encode()):
             if not key:
                 raise ValueError("the empty key is reserved for the bundle header")
+            if isinstance(tensors[key], (bytes, bytearray)):
+                # scalar DT_STRING (tensor_bundle.cc WriteStringTensor): [varint64 length][masked crc32c of the lengths, each
+                # taken as a little-endian uint32][bytes]; the entry's checksum runs over the uint32 lengths, that 4-byte
+                # length checksum and the bytes
+                blob = bytes(tensors[key])
+                c = crc32c(struct.pack("<I", len(blob)))
+                lc = struct.pack("<I", mask(c))
+                raw = _varint(len(blob)) + lc + blob
+                c = crc32c(blob, crc32c(lc, c))
+                f.write(raw)
+                entries.append((key.encode(), _entry_proto(DT_STRING, (), offset, len(raw), mask(c))))
+                offset += len(raw)
+                continue
             arr = np.asarray(tensors[key])            # (ascontiguousarray would turn a scalar into shape (1,))
             dt = arr.dtype.newbyteorder("<") if arr.dtype.byteorder == ">" else arr.dtype
             if np.dtype(dt) not in _DT_OF:
@@ -268,6 +286,29 @@ def write_bundle(prefix, tensors):
             entries.append((key.encode(), _entry_proto(_DT_OF[np.dtype(dt)], arr.shape, offset, raw.nbytes, mask(crc32c(raw)))))
             offset += raw.nbytes
     write_table(prefix + ".index", entries)
+
+
+def read_string_entry(prefix, key):
+    """The bytes of a scalar DT_STRING entry (e.g. the object graph), checksum verified; None when absent."""
+    table = dict(read_table(prefix + ".index"))
+    if key.encode() not in table:
+        return None
+    e = _parse(table[key.encode()])
+    if e.get(1, [0])[0] != DT_STRING:
+        raise ValueError("%s is not a string tensor" % key)
+    nshards = _parse(table[b""]).get(1, [1])[0]
+    shard, offset, size = e.get(3, [0])[0], e.get(4, [0])[0], e.get(5, [0])[0]
+    with open("%s.data-%05d-of-%05d" % (prefix, shard, nshards), "rb") as f:
+        f.seek(offset)
+        raw = f.read(size)
+    n, pos = _read_varint(raw, 0)
+    lc, blob = raw[pos:pos + 4], raw[pos + 4:pos + 4 + n]
+    c = crc32c(struct.pack("<I", n))
+    if struct.unpack("<I", lc)[0] != mask(c) or len(blob) != n:
+        raise ValueError("string tensor %s: bad length checksum" % key)
+    if 6 in e and mask(crc32c(blob, crc32c(lc, c))) != struct.unpack("<I", e[6][0])[0]:
+        raise ValueError("string tensor %s: checksum mismatch" % key)
+    return blob
 
 
 def read_bundle(prefix, verify=True):
@@ -303,6 +344,81 @@ def read_bundle(prefix, verify=True):
             raise ValueError("unsupported dtype enum %d for %s" % (dtype, key.decode()))
         out[key.decode()] = arr.reshape(shape).copy()
     return out
+
+
+# ---- object graph (tensorflow/core/protobuf/trackable_object_graph.proto) ------------------------------------------
+OBJECT_GRAPH_KEY = "_CHECKPOINTABLE_OBJECT_GRAPH"
+SLOT = "/.OPTIMIZER_SLOT/"
+
+
+def _str(num, text):
+    return _ld(num, text.encode())
+
+
+def object_graph(keys, full_names=None):
+    """keys: checkpoint keys of an object-based checkpoint (`a/b/w/.ATTRIBUTES/VARIABLE_VALUE`, optimizer slots as
+    `a/b/w/.OPTIMIZER_SLOT/<optimizer path>/<slot>/.ATTRIBUTES/VARIABLE_VALUE`).  Returns the serialized
+    TrackableObjectGraph: node 0 is the root (the tf.train.Checkpoint object); every path component is a child edge
+    (ObjectReference{node_id, local_name}); a variable node carries SerializedTensor{name: "VARIABLE_VALUE", full_name,
+    checkpoint_key}; a slot variable is a node referenced from its optimizer's node through
+    SlotVariableReference{original_variable_node_id, slot_name, slot_variable_node_id} (and not through a child edge).
+    Nodes are numbered breadth-first from the root with children in sorted order - any consistent numbering is valid."""
+    full_names = full_names or {}
+    children = [dict()]                 # node id -> {local_name: child id}
+    attrs, slots = {}, {}               # node id -> SerializedTensor fields / optimizer node id -> [(orig, slot name, slot node)]
+
+    def walk(path):
+        node = 0
+        for comp in path:
+            nxt = children[node].get(comp)
+            if nxt is None:
+                nxt = len(children)
+                children.append(dict())
+                children[node][comp] = nxt
+            node = nxt
+        return node
+    plain = sorted(k for k in keys if k.endswith(SUFFIX) and SLOT not in k)
+    for k in plain:
+        path = k[:-len(SUFFIX)]
+        attrs[walk(path.split("/"))] = ("VARIABLE_VALUE", full_names.get(path, path.split("/")[-1]), k)
+    for k in sorted(k for k in keys if k.endswith(SUFFIX) and SLOT in k):
+        var_path, rest = k[:-len(SUFFIX)].split(SLOT)
+        opt_path, slot_name = rest.rsplit("/", 1)
+        var_node, opt_node = walk(var_path.split("/")), walk(opt_path.split("/"))
+        slot_node = len(children)
+        children.append(dict())
+        attrs[slot_node] = ("VARIABLE_VALUE", "%s/%s" % (full_names.get(var_path, var_path.split("/")[-1]), slot_name), k)
+        slots.setdefault(opt_node, []).append((var_node, slot_name, slot_node))
+    out = b""
+    for nid, ch in enumerate(children):
+        node = b""
+        for name in sorted(ch):
+            node += _ld(1, _varint(1 << 3) + _varint(ch[name]) + _str(2, name))                       # children
+        if nid in attrs:
+            name, full, key = attrs[nid]
+            node += _ld(2, _str(1, name) + _str(2, full) + _str(3, key))                              # attributes
+        for orig, sname, snode in slots.get(nid, ()):
+            node += _ld(3, _varint(1 << 3) + _varint(orig) + _str(2, sname) + _varint(3 << 3) + _varint(snode))   # slot_variables
+        out += _ld(1, node)
+    return out
+
+
+def parse_object_graph(blob):
+    """[{children: {name: id}, attributes: [(name, full_name, checkpoint_key)], slots: [(orig id, slot name, slot id)]}]"""
+    nodes = []
+    for raw in _parse(blob).get(1, []):
+        f = _parse(raw)
+        ch = {}
+        for c in f.get(1, []):
+            cf = _parse(c)
+            ch[cf[2][0].decode()] = cf.get(1, [0])[0]
+        at = [tuple(_parse(a).get(i, [b""])[0].decode() for i in (1, 2, 3)) for a in f.get(2, [])]
+        sl = []
+        for r in f.get(3, []):
+            rf = _parse(r)
+            sl.append((rf.get(1, [0])[0], rf[2][0].decode(), rf.get(3, [0])[0]))
+        nodes.append(dict(children=ch, attributes=at, slots=sl))
+    return nodes
 
 
 def variable_tensors(bundle):

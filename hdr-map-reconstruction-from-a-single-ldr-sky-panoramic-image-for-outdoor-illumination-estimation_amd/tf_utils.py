@@ -22,8 +22,9 @@ def hdr_logDecompression(x, validDR=10.):
 
 
 def rgb2bgr(x):
-    """Channel reversal (tf_utils.py:85-88).  The fused plans fold this into their load indexing."""
-    return x.flip(-1).contiguous()
+    """Channel reversal (tf_utils.py:85-88): one hdrsky_flip_rgb launch.  (The CLIs reverse the channels while staging
+    the decoded image on the host, inference.py:load_ldr; the training step's inputs are BGR already.)"""
+    return K.flip_rgb(x.contiguous())
 
 
 bgr2rgb = rgb2bgr   # tf_utils.py:90-93

@@ -281,6 +281,8 @@ int hdrsky_slice_channels(const float* x, size_t npix, int C, int c_off, int c_t
 int hdrsky_concat2(const float* a, int Ca, const float* b, int Cb, size_t npix, float* out, void* stream);
 /* x*255 - VGG_MEAN (vgg16.py:133-141). */
 int hdrsky_vgg_pre(const float* x, size_t n, float* y, void* stream);
+/* tf_utils.rgb2bgr / bgr2rgb (tf_utils.py:85-93): channel reversal of npix 3-channel pixels; x == y is allowed. */
+int hdrsky_flip_rgb(const float* x, size_t npix, float* y, void* stream);
 /* y = sa*a + sb*b (b nullable). */
 int hdrsky_axpby(const float* a, float sa, const float* b, float sb, size_t n, float* y, void* stream);
 /* Dense weight / bias gradient dW[K][N] (+)= x^T dy, db (+)= sum_m dy (M <= 32). */

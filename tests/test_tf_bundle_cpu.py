@@ -128,3 +128,112 @@ def test_checkpoint_manager_reads_and_writes_tf_bundles(tmp_path):
     for _ in range(3):
         mgr.save({"gen_model/conv1_d/b": np.zeros(32, np.float32)}, epoch=50)
     assert mgr.latest_checkpoint.endswith("ckpt-4.npz") and mgr.restore()[1] == 50
+
+
+# ---- an independent, minimal protobuf reader for the object-graph test (deliberately not tf_bundle._parse) --------------
+def _pb_fields(buf):
+    i, out = 0, []
+    while i < len(buf):
+        tag = shift = 0
+        while True:
+            b = buf[i]; i += 1
+            tag |= (b & 0x7F) << shift; shift += 7
+            if b < 0x80:
+                break
+        num, wire = tag >> 3, tag & 7
+        if wire == 0:
+            val = shift = 0
+            while True:
+                b = buf[i]; i += 1
+                val |= (b & 0x7F) << shift; shift += 7
+                if b < 0x80:
+                    break
+            out.append((num, val))
+        elif wire == 2:
+            ln = shift = 0
+            while True:
+                b = buf[i]; i += 1
+                ln |= (b & 0x7F) << shift; shift += 7
+                if b < 0x80:
+                    break
+            out.append((num, bytes(buf[i:i + ln]))); i += ln
+        else:
+            raise AssertionError("unexpected wire type %d" % wire)
+    return out
+
+
+def test_exported_bundle_carries_the_object_graph_checkpoint_restore_walks(tmp_path):
+    """export_tf_bundle writes the structure of `tf.train.Checkpoint(epoch, gen_model, dis_model, gen_optimizer,
+    disc_optimizer).save` (train.py:208-220): the `_CHECKPOINTABLE_OBJECT_GRAPH` string entry is a TrackableObjectGraph in
+    which every saved variable is reached from the root by child edges spelling its attribute path, carries a
+    VARIABLE_VALUE attribute whose checkpoint_key is its bundle key, and every optimizer slot hangs off its optimizer's
+    node with the right original variable.  Parsed here with a separate minimal protobuf reader.  (Unpinned against TF.)"""
+    ckpt, tfb, P = pkg("checkpoint"), pkg("tf_bundle"), pkg("params")
+    gen, dis = P.init_params(P.generator_spec(), 0), P.init_params(P.discriminator_spec(), 2)
+    native = {"gen_model/" + k.replace(".", "/"): v for k, v in gen.items()}
+    native.update({"dis_model/" + k.replace(".", "/"): v for k, v in dis.items()})
+    native["gen_optimizer/rms"] = np.ones(10, np.float32)          # flat buffers are not exported
+    slots = {"gen_optimizer": {"gen_model/conv1_d/w": np.full((7, 7, 3, 32), 0.5, np.float32),
+                               "gen_model/res/3/conv2/b": np.full(128, 0.25, np.float32)},
+             "disc_optimizer": {"dis_model/out/kernel": np.full((4, 4, 512, 1), 2.0, np.float32)}}
+    prefix = str(tmp_path / "SKY" / "ckpt-7")
+    ckpt.export_tf_bundle(prefix, native, epoch=70, slots=slots)
+    bundle = tfb.read_bundle(prefix)
+    blob = tfb.read_string_entry(prefix, "_CHECKPOINTABLE_OBJECT_GRAPH")
+    assert blob is not None and tfb.read_string_entry(prefix, "no/such/key") is None
+    # --- decode with the independent reader ---
+    nodes = []
+    for num, raw in _pb_fields(blob):
+        assert num == 1
+        ch, at, sl = {}, [], []
+        for fnum, val in _pb_fields(raw):
+            sub = dict(_pb_fields(val))
+            if fnum == 1:
+                ch[sub[2].decode()] = sub.get(1, 0)
+            elif fnum == 2:
+                at.append((sub[1].decode(), sub[2].decode(), sub[3].decode()))
+            elif fnum == 3:
+                sl.append((sub.get(1, 0), sub[2].decode(), sub.get(3, 0)))
+        nodes.append((ch, at, sl))
+    # the root is the Checkpoint object: its edges are the keyword arguments of train.py:208-213 (+ save_counter)
+    assert set(nodes[0][0]) == {"epoch", "gen_model", "dis_model", "gen_optimizer", "disc_optimizer", "save_counter"}
+    assert all(0 < cid < len(nodes) for ch, _, _ in nodes for cid in ch.values())
+    # every variable key of the bundle is reachable by walking its attribute path from the root
+    var_keys = [k for k in bundle if k.endswith(tfb.SUFFIX) and tfb.SLOT not in k]
+    assert len(var_keys) == len(gen) + len(dis) + 2
+    for k in var_keys:
+        nid = 0
+        for comp in k[:-len(tfb.SUFFIX)].split("/"):
+            nid = nodes[nid][0][comp]
+        (name, full, key), = nodes[nid][1]
+        assert name == "VARIABLE_VALUE" and key == k and full
+    # attribute spelling of the reference's layers: conv2d keeps `w` / `biases`, deconv2d `kernel` / `biases` (ops.py)
+    assert "gen_model/conv1_d/biases" + tfb.SUFFIX in bundle and "gen_model/conv3_f/kernel" + tfb.SUFFIX in bundle
+    assert "gen_model/res/sequence/3/conv2/biases" + tfb.SUFFIX in bundle and "dis_model/d2/norm/moving_mean" + tfb.SUFFIX in bundle
+    # slot variables: referenced from the optimizer node, pointing at the original variable's node, keyed the TF way
+    def node_of(path):
+        nid = 0
+        for comp in path.split("/"):
+            nid = nodes[nid][0][comp]
+        return nid
+    gslots = nodes[node_of("gen_optimizer")][2]
+    assert sorted(s[1] for s in gslots) == ["rms", "rms"] and {s[0] for s in gslots} == {node_of("gen_model/conv1_d/w"), node_of("gen_model/res/sequence/3/conv2/biases")}
+    for orig, sname, snode in gslots + nodes[node_of("disc_optimizer")][2]:
+        (name, full, key), = nodes[snode][1]
+        assert tfb.SLOT in key and key.endswith("/rms" + tfb.SUFFIX) and key in bundle
+    assert float(bundle["dis_model/out/kernel" + tfb.SLOT + "disc_optimizer/rms" + tfb.SUFFIX][0, 0, 0, 0]) == 2.0
+    # tf_bundle's own parser agrees with the independent one
+    own = tfb.parse_object_graph(blob)
+    assert [(n["children"], n["attributes"], n["slots"]) for n in own] == [(c, a, s) for c, a, s in nodes]
+    # and the file still restores through the checkpoint manager (attribute spelling accepted by load_into)
+    tensors, epoch = ckpt.CheckpointManager(str(tmp_path / "SKY")).restore()
+    gen2 = P.init_params(P.generator_spec(), 9)
+    assert epoch == 70 and ckpt.load_into(gen2, tensors, "gen_model") == len(gen2)
+    assert all(np.array_equal(gen[k], gen2[k]) for k in gen)
+    # a corrupted string entry is detected
+    raw = bytearray(open(prefix + ".data-00000-of-00001", "rb").read())
+    pos = raw.find(b"gen_optimizer")
+    raw[pos] ^= 0x20
+    open(prefix + ".data-00000-of-00001", "wb").write(bytes(raw))
+    with pytest.raises(ValueError):
+        tfb.read_string_entry(prefix, "_CHECKPOINTABLE_OBJECT_GRAPH")
