@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--workload", default="all", choices=["all", "train", "fwd", "hires"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--da", action="store_true",
+                    help="train workload with the distortion-aware res blocks (distortion_aware_ops.conv2d in generator.py:14,18's "
+                         "commented-out variant), forward and backward")
     ap.add_argument("--dp-mode", default=None, help="gradient exchange of the N > 1 training step (parallel.py: MODES)")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run only the timed loop of the roofline kernel and print its object (the command behind "
@@ -337,7 +340,8 @@ def main():
         do_train, do_fwd = args.workload in ("all", "train"), args.workload in ("all", "fwd")
         roof_pw = None
         if do_train:
-            tr = trainer.Trainer(gen, sun, dis, vgg, device=dev, precise=False, compute=K.BF16, world_size=world)
+            tr = trainer.Trainer(gen, sun, dis, vgg, device=dev, precise=False, compute=K.BF16, world_size=world,
+                                 distortion_aware=args.da)
             # One step = the Trainer's segment plan (forward, losses, both backward passes, RMSprop x2 + weight
             # re-packing), every segment captured into its own hipGraph and replayed on its stream.  N > 1: each replica
             # runs the reference's batch-32 step on its shard; gradients are summed over replicas (RCCL; every loss is a
@@ -366,7 +370,7 @@ def main():
                                        "tone-map/DoG/L1/KL/LSGAN losses, RMSprop x2), batch=%d per GPU, 32x128x3" % batch,
                            "per_gpu_batch": batch, "global_batch": batch * world,
                            "parallelism": ("dp%d (%s)" % (world, ex.describe())) if world > 1 else "single",
-                           "hipgraph": not args.no_graph},
+                           "hipgraph": not args.no_graph, "distortion_aware_res_blocks": bool(args.da)},
                 "algorithmic_tflops": round(imgs / dt * TRAIN_MFLOP_PER_IMG * 1e6 / 1e12, 2)})
             del tr, ex, one_step, out
             torch.cuda.empty_cache()

@@ -900,21 +900,25 @@ def da_gather(x, offs, ksize):
     return G
 
 
-def da_conv2d_bwd(x, dy, kernel, offs, ksize, compute=BF16, want_dx=True):
-    """Gradients of y = da_conv2d(x; kernel [k*k*C, F], bias): returns (dx or None, dkernel [k*k*C, F], dbias [F])."""
+def da_conv2d_bwd(x, dy, kernel, offs, ksize, compute=BF16, want_dx=True, pwT=None, dw=None, db=None):
+    """Gradients of y = da_conv2d(x; kernel [k*k*C, F], bias): returns (dx or None, dkernel [k*k*C, F], dbias [F]).
+    pwT: PackedConv(kernel.view(1,1,k*k*C,F), transpose_flip=True) when the caller keeps one (a training loop re-packs it
+    with the other filters); dw [k*k*C, F] / db [F]: gradients are ADDED to these instead of freshly allocated ones."""
     B, H, W, C = x.shape
     F = dy.shape[-1]
     k2 = ksize * ksize
     _f32(dy, B, H, W, F); _f32(kernel, k2 * C, F)
     G = da_gather(x, offs, ksize)
-    dw, db = conv2d_wgrad(G, dy, 1, 1, compute=compute)                       # [1,1,k2*C,F]
+    dw4 = dw.view(1, 1, k2 * C, F) if dw is not None else None
+    dw4, db = conv2d_wgrad(G, dy, 1, 1, compute=compute, dw=dw4, db=db)            # [1,1,k2*C,F]
     dx = None
     if want_dx:
-        wT = kernel.t().contiguous().view(1, 1, F, k2 * C)                   # dG = dY W^T as a 1x1 conv
-        dG, _ = conv2d(dy, PackedConv(wT, precise=(compute == BF16X3)), None, compute=compute)
-        dx = torch.zeros_like(x)
+        if pwT is None:   # dG = dY W^T as a 1x1 conv: the transpose_flip image of the kernel viewed as a 1x1 filter
+            pwT = PackedConv(kernel.view(1, 1, k2 * C, F), precise=(compute == BF16X3), transpose_flip=True)
+        dG, _ = conv2d(dy, pwT, None, compute=compute)
+        dx = zero_(torch.empty_like(x))
         L.check(L.load().hdrsky_da_scatter(_p(dG), _p(offs), B, H, W, C, ksize, _p(dx), _stream()), "da_scatter")
-    return dx, dw.view(k2 * C, F), db
+    return dx, dw4.view(k2 * C, F), db
 
 
 # ------------------------------------------------------------------------------------------------

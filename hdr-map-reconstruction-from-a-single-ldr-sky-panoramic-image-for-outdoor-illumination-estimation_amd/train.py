@@ -42,6 +42,8 @@ def main(argv=None):
     ap.add_argument("--val-steps", type=int, default=0,
                     help="synthetic mode: validation batches per epoch through test_step (train.py:491-506); 0 = none")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch eagerly instead of replaying hipGraphs")
+    ap.add_argument("--dp-mode", default=None, choices=list(par.MODES),
+                    help="gradient exchange between data-parallel replicas (parallel.GradientExchange)")
     ap.add_argument("--host-synth", action="store_true",
                     help="build the synthetic batches with numpy on the host (40 ms per batch of 32) instead of on the GPU")
     args = ap.parse_args(argv)
@@ -67,7 +69,7 @@ def main(argv=None):
     if tensors and "gen_optimizer/rms" in tensors:
         tr.gs.ms.copy_(torch.from_numpy(tensors["gen_optimizer/rms"])); tr.ds.ms.copy_(torch.from_numpy(tensors["disc_optimizer/rms"]))
     par.broadcast_params_([tr.gs.flat, tr.ds.flat]); tr.repack()
-    ex = par.GradientExchange(tr, device=dev)
+    ex = par.GradientExchange(tr, device=dev, mode=args.dp_mode)
 
     # The step is captured once (one hipGraph per segment, see trainer.py) on static input buffers that every batch is
     # copied into; losses are accumulated on the device and read back once per epoch.
@@ -104,6 +106,11 @@ def main(argv=None):
         v["total_gen_loss"] = v["kl"] + 1000.0 * v["dog"] + v["adv"] + 10.0 * v["l1"] + 0.01 * v["perceptual"]
         v["total_disc_loss"] = 0.5 * (v["disc_generated"] + v["disc_real"])
         acc = v
+        if epoch % 10 == 0 or args.val_steps > 0:
+            # BatchNorm moving statistics are replica-local: what is saved / validated is rank 0's copy on every replica
+            par.sync_moving_stats_(tr)
+            if args.val_steps > 0:
+                tr.refresh_eval()
         if rank == 0:
             names = (("gen_total_loss", "total_gen_loss"), ("gen_l1_loss", "l1"), ("gen_perceptual_loss", "perceptual"),
                      ("gen_DoG_loss", "dog"), ("gen_adv_loss", "adv"), ("gen_kl_div", "kl"),

@@ -95,14 +95,18 @@ class _Conv:
 
 class Trainer:
     def __init__(self, gen_params, sun_params, dis_params, vgg_params, device="cuda", lr=1e-4, im_height=32,
-                 im_width=128, precise=False, compute=BF16, world_size=1, resconv=True):
+                 im_width=128, precise=False, compute=BF16, world_size=1, resconv=True, distortion_aware=False):
         self.device = torch.device(device)
         self.h, self.w = im_height, im_width
         self.lr, self.compute, self.precise, self.world = lr, compute, precise, world_size
         # res-block chain on bf16 activations through the sample-resident conv + InstanceNorm launches (HDRSKY_BF16
         # mode, 8x32 maps); otherwise the generic conv / norm launches on fp32 activations
-        self.use_resconv = bool(resconv) and compute == BF16 and not precise and \
+        # distortion_aware: the res blocks' 3x3 convolutions are distortion_aware_ops.conv2d (the variant generator.py:14,18
+        # keeps commented out; same HWIO weights = its [k*k*C, F] kernel), forward and backward
+        self.da = bool(distortion_aware)
+        self.use_resconv = bool(resconv) and not self.da and compute == BF16 and not precise and \
             K.resconv_supported(im_height // 4, im_width // 4, 128, 128)
+        self._da_offs = torch.from_numpy(K.da_offsets(im_height // 4, im_width // 4, 3, 1, True)).to(self.device) if self.da else None
         self._rc = {}
         self.dense_wgrad_external = False   # a data-parallel driver recomputes the Dense weight gradients (parallel.py)
         named = OrderedDict(("gen." + k, v) for k, v in gen_params.items())
@@ -162,10 +166,16 @@ class Trainer:
 
     def _make_packer(self):
         pairs = []
-        for cv in self.conv.values():
+        for name, cv in self.conv.items():
             pairs.append((cv.w, cv.pk))
             if cv.pkT is not None:
                 pairs.append((cv.w, cv.pkT))
+            if getattr(self, "da", False) and name.startswith("gen.res."):
+                # data gradient of the distortion-aware conv: dG = dY W^T as a 1x1 conv with the transposed [9C, F] kernel
+                if getattr(cv, "pkDA", None) is None:
+                    cv.wDA = cv.w.view(1, 1, cv.kh * cv.kw * cv.cin, cv.cout)
+                    cv.pkDA = PackedConv(cv.wDA, self.precise, transpose_flip=True)
+                pairs.append((cv.wDA, cv.pkDA))
         self._packer = K.MultiPacker(pairs)      # uploads its job table: must not happen inside a graph capture
 
     def repack(self, fc=True):
@@ -494,7 +504,19 @@ class Trainer:
                     T["res%d" % i] = (o1, o2)
                     x, xb = o2["f32"], o2.get("bf16")
                     T["x"].append(x); T["xb"].append(xb)
-            for i in range(0 if self.use_resconv else 6):   # generic launches (BF16X3, other image sizes)
+            if self.da:               # generator.py:14,18: both 3x3 convolutions of a block are distortion-aware
+                offs = self._da_offs
+                for i in range(6):
+                    p = "gen.res.%d." % i
+                    cv1, cv2 = c[p + "conv1"], c[p + "conv2"]
+                    c1, t1 = K.da_conv2d(x, cv1.pk, cv1.b, offs, cp, want_stats=True)
+                    a1 = K.norm_apply(c1, t1, w[p + "norm1.gamma"], w[p + "norm1.beta"], slope=0.1)
+                    c2, t2 = K.da_conv2d(a1, cv2.pk, cv2.b, offs, cp, want_stats=True)
+                    xn = K.norm_apply(c2, t2, w[p + "norm2.gamma"], w[p + "norm2.beta"], slope=1.0, residual=x)
+                    T["res%d" % i] = (c1, t1, a1, c2, t2)
+                    x = xn
+                    T["x"].append(x)
+            for i in range(0 if (self.use_resconv or self.da) else 6):   # generic launches (BF16X3, other image sizes)
                 p = "gen.res.%d." % i
                 r1, t1 = c[p + "conv1"].fwd(x, compute=cp, want_stats=True)
                 xf = self._inxf(t1, p + "norm1", 0.1)
@@ -664,7 +686,25 @@ class Trainer:
                     else:
                         dx = K.resconv_bwd(dc1, c[p + "conv1"].pkT, skip=dx, want_f32=True, want_bf16=False)["f32"]
                 reducer.run()
-            for i in range(-1 if self.use_resconv else 5, -1, -1):
+            if self.da:
+                # y = G(x) W + b with G the bilinear gather: dW = G^T dY (1x1 weight gradient on the gathered tensor), dG = dY W^T
+                # (1x1 conv), dx = G^T dG (bilinear scatter) - kernels.da_conv2d_bwd
+                offs = self._da_offs
+                for i in range(5, -1, -1):
+                    p = "gen.res.%d." % i
+                    c1, t1, a1, c2, t2 = T["res%d" % i]
+                    dr2 = self._in_bwd(c2, t2, p + "norm2", 1.0, dx)
+                    for cvn, xin, dy_ in ((p + "conv2", a1, dr2),):
+                        cv = c[cvn]
+                        da1, _, _ = K.da_conv2d_bwd(xin, dy_, cv.wDA.view(cv.kh * cv.kw * cv.cin, cv.cout), offs, 3, cp, True, cv.pkDA,
+                                                    dw=g[cv.wkey].view(cv.kh * cv.kw * cv.cin, cv.cout), db=g[cv.bkey])
+                    dr1 = self._in_bwd(c1, t1, p + "norm1", 0.1, da1)
+                    cv = c[p + "conv1"]
+                    dxx, _, _ = K.da_conv2d_bwd(T["x"][i], dr1, cv.wDA.view(cv.kh * cv.kw * cv.cin, cv.cout), offs, 3, cp, True, cv.pkDA,
+                                                dw=g[cv.wkey].view(cv.kh * cv.kw * cv.cin, cv.cout), db=g[cv.bkey])
+                    dx = K.axpby(dx, 1.0, dxx, 1.0)                                     # + identity branch
+                self._norm_grads("bwd_res", B)
+            for i in range(-1 if (self.use_resconv or self.da) else 5, -1, -1):
                 p = "gen.res.%d." % i
                 r1, t1, xf, r2, t2 = T["res%d" % i]
                 dr2 = self._in_bwd(r2, t2, p + "norm2", 1.0, dx)
@@ -673,7 +713,7 @@ class Trainer:
                 dr1 = self._in_bwd(r1, t1, p + "norm1", 0.1, da1)
                 self._wg(p + "conv1", T["x"][i], None, dr1)
                 dx = c[p + "conv1"].dgrad(T["x"][i], dr1, cp, residual=dx)      # + identity branch
-            if not self.use_resconv:
+            if not self.use_resconv and not self.da:
                 self._norm_grads("bwd_res", B)
             T["dx_enc"] = dx
             T["wq_res"] = self._take_wgrads()
@@ -796,6 +836,7 @@ class Trainer:
         training=False) and no update.  Returns the output dict of `step`; the loss terms are in self.losses /
         loss_dict().  Issued eagerly (not part of the captured step); gradients buffers are left zeroed / partial."""
         self._bn_training = False
+        saved = (getattr(self, "_T", None), getattr(self, "_segs", None), getattr(self, "_events", None))
         try:
             self._bind(ldr, hdr_t, sunpose_gt)
             self._execute(["fwd_sun", "fwd_enc", "vgg_target", "fwd_blend", "loss_main", "loss_vgg", "loss_vgg_b", "loss_adv"])
@@ -804,9 +845,19 @@ class Trainer:
                 R = self._down_stack("dis.", self.ds.w, K.concat2(ldr, other), training=False)
                 logits, _ = cvo.fwd(R["d4"]["raw"], R["xf_out"], self.compute)
                 K.mse(logits, target, 1.0, 0.5, self.losses[slot:slot + 1])
+            outs = self._outputs()
         finally:
             self._bn_training = True
-        return self._outputs()
+            if self._graphs is not None and saved[1] is not None:
+                # a captured step keeps replaying ITS plan (segment list, static tensors, events): the validation plan -
+                # possibly another batch size, hence other segments - must not replace it
+                self._T, self._segs, self._events = saved
+        return outs
+
+    def refresh_eval(self):
+        """Hook for callers that changed the BatchNorm moving statistics from outside (parallel.sync_moving_stats_):
+        nothing is cached on this side - the inference-mode affines are recomputed from the flat buffers at every use."""
+        return None
 
     def apply_gradients(self, gscale=None):
         """optimizer_gen / optimizer_disc .apply_gradients (train.py:403,406): RMSprop(lr) on gradients scaled by

@@ -38,18 +38,42 @@ def res_block(p, prefix, x):
     return x + _inorm(p, prefix + ".norm2", c2)
 
 
+class _DAConv(torch.autograd.Function):
+    """distortion_aware_ops.conv2d.call (:50-123) as a differentiable torch op: forward = the numpy restatement
+    oracle/da_ops.da_conv2d, backward = da_ops.da_conv2d_grads (what the tape returns: the layer is linear in x and in
+    the kernel).  The HWIO filter is the layer's [k*k*C, F] kernel reshaped."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, offs):
+        import numpy as np
+        from . import da_ops
+        c = x.shape[-1]
+        k = w.shape[0]
+        ctx.save_for_backward(x, w)
+        ctx.offs, ctx.k = offs, k
+        y = da_ops.da_conv2d(x.detach().numpy(), w.detach().numpy().reshape(k * k * c, -1), b.detach().numpy(), offs, k=k)
+        return torch.from_numpy(y.astype(np.float32))
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import da_ops
+        x, w = ctx.saved_tensors
+        k, c = ctx.k, x.shape[-1]
+        dx, dk, db = da_ops.da_conv2d_grads(x.detach().numpy(), w.detach().numpy().reshape(k * k * c, -1), ctx.offs,
+                                            dy.detach().numpy(), k=k)
+        return torch.from_numpy(dx), torch.from_numpy(dk).view_as(w), torch.from_numpy(db), None
+
+
 def res_block_da(p, prefix, x, dilation_rate=1):
     """The res block with the two lines generator.py:14,18 keeps commented out switched on: conv1 / conv2 are
     distortion_aware_ops.conv2d(filter_out, kernel_size=3, dilation_rate) (numpy restatement oracle/da_ops.py; its
-    [k*k*C, F] kernel is the HWIO filter reshaped).  Forward only."""
-    import numpy as np
+    [k*k*C, F] kernel is the HWIO filter reshaped).  Differentiable (see _DAConv)."""
     from . import da_ops
     _, h, w, c = x.shape
     offs = da_ops.distortion(h, w, 3, dilation_rate)
 
     def da(name, t):
-        wk = p[name + ".w"].detach().numpy().reshape(9 * c, -1)
-        return torch.from_numpy(da_ops.da_conv2d(t.detach().numpy(), wk, p[name + ".b"].detach().numpy(), offs).astype(np.float32))
+        return _DAConv.apply(t, p[name + ".w"], p[name + ".b"], offs)
     c1 = da(prefix + ".conv1", x)
     a1 = T.leaky_relu(_inorm(p, prefix + ".norm1", c1), 0.1)
     c2 = da(prefix + ".conv2", a1)

@@ -19,7 +19,7 @@ def _alpha_mask(sky_pred_lin, thr=THRESHOLD):
     return alpha.unsqueeze(-1).repeat(1, 1, 1, 3)
 
 
-def generator_graph(gen, sun, ldr, y_index=None, training=False, new_stats=None):
+def generator_graph(gen, sun, ldr, y_index=None, training=False, new_stats=None, distortion_aware=False):
     """The generator graph shared by inference.py:81-115 and train.py:239-299.
 
     y_index: None -> y_c = max_j cmf[b,j] (inference.py:98); LongTensor [B] ->
@@ -29,7 +29,7 @@ def generator_graph(gen, sun, ldr, y_index=None, training=False, new_stats=None)
     Returns a dict of every tensor the reference returns from generator_in_step.
     """
     b, h, w, _ = ldr.shape
-    res_out = N.gen_encode(gen, ldr)
+    res_out = N.gen_encode(gen, ldr, distortion_aware=distortion_aware)   # generator.py:14,18 variant when set
     sky_pred_gamma = N.gen_sky_decode(gen, res_out, ldr)
     sky_pred_lin = T.hdr_log_decompression(sky_pred_gamma)
 
@@ -101,7 +101,7 @@ def discriminator_losses(dis, ldr, hdr_t, y_final_lin, training, new_stats=None)
     return dict(total_disc_loss=total, real=real_loss, generated=gen_loss)
 
 
-def train_step_grads(gen, sun, dis, vgg, ldr, hdr_t, sunpose_gt):
+def train_step_grads(gen, sun, dis, vgg, ldr, hdr_t, sunpose_gt, distortion_aware=False):
     """train.py:382-406 up to (not including) apply_gradients.
 
     Both tapes see the same pre-update weights.  Returns (losses, grads_gen, grads_sun,
@@ -117,7 +117,8 @@ def train_step_grads(gen, sun, dis, vgg, ldr, hdr_t, sunpose_gt):
 
     y_index = sunpose_gt.argmax(dim=1)
     stats_gen, stats_dis = {}, {}
-    out = generator_graph(gen_r, sun_r, ldr, y_index=y_index, training=True, new_stats=stats_gen)
+    out = generator_graph(gen_r, sun_r, ldr, y_index=y_index, training=True, new_stats=stats_gen,
+                          distortion_aware=distortion_aware)
     gl = generator_losses(out, dis_r, vgg, ldr, hdr_t, sunpose_gt)
     # train.py:391-396: y_final_lin recomputed from y_final_gamma, still on both tapes
     y_final_lin = T.hdr_log_decompression(out["y_final_gamma"])

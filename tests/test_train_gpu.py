@@ -361,6 +361,45 @@ def test_step_is_repeatable_under_stream_concurrency(dev, mode):
             assert float((first["losses"] - snap["losses"]).abs().max()) <= 1e-5 * float(first["losses"].abs().max())
 
 
+def test_train_step_distortion_aware_res_stack(dev):
+    """Trainer(distortion_aware=True): the res blocks' convolutions are distortion_aware_ops.conv2d (generator.py:14,18's
+    commented-out variant) in the forward AND the backward pass; one step at B=2 against the oracle's autograd through the
+    numpy restatement of the layer and its adjoint (oracle/networks._DAConv)."""
+    params, synth, trainer, K = pkg("params"), pkg("synth"), pkg("trainer"), pkg("kernels")
+    nets = [params.init_params(params.generator_spec(), 0), params.init_params(params.sunpose_spec(), 1),
+            params.init_params(params.discriminator_spec(), 2), params.init_params(params.vgg_spec(), 3)]
+    batch = synth.make_batch(2, seed=1234)
+    tt = lambda dd: {k: torch.from_numpy(v) for k, v in dd.items()}
+    ldr, hdr, gt = (torch.from_numpy(batch[k]) for k in ("ldr", "hdr_t", "sunpose_gt"))
+    losses, gg, gs, gd, sg, sd, outs = ostep.train_step_grads(*[tt(n) for n in nets], ldr, hdr, gt, distortion_aware=True)
+    plain = ostep.generator_graph(tt(nets[0]), {k: v.clone().requires_grad_(True) for k, v in tt(nets[1]).items()}, ldr,
+                                  y_index=gt.argmax(dim=1), training=True, new_stats={})
+    assert float((plain["res_out"].detach() - outs["res_out"]).abs().max()) > 1e-3      # the variant really differs
+    tr = trainer.Trainer(*nets, device=dev, precise=True, compute=K.BF16X3, distortion_aware=True)
+    out = tr.step(ldr.to(dev), hdr.to(dev), gt.to(dev), update=False)
+    got = tr.loss_dict()
+    for k, rk in (("kl", "kl"), ("perceptual", "perceptual"), ("dog", "dog"), ("l1", "l1"), ("adv", "adv")):
+        assert abs(got[k] - losses[rk]) <= 2e-3 * abs(losses[rk]) + 1e-6, (k, got[k], losses[rk])
+    assert_close(out["y_final_gamma"], outs["y_final_gamma"], 1e-3, "y_final_gamma (distortion-aware res stack)")
+    worst = []
+    for i in range(6):
+        for j in (1, 2):
+            for leaf in ("conv%d.w" % j, "norm%d.gamma" % j, "norm%d.beta" % j):
+                k = "res.%d.%s" % (i, leaf)
+                worst.append((rel_max(tr.gs.g["gen." + k], gg[k]), k))
+    worst.sort(reverse=True)
+    print("worst distortion-aware res-stack gradient errors:", worst[:4])
+    assert worst[0][0] < 5e-2 and np.median([e for e, _ in worst]) < 3e-3, worst[:4]
+    for k in ("conv3_d.w", "conv1_d.w"):          # and what lies behind the stack in the backward chain
+        assert rel_max(tr.gs.g["gen." + k], gg[k]) < 5e-2, k
+    tr.apply_gradients()
+    assert torch.isfinite(tr.gs.flat).all()
+    # bench mode of the same variant runs and stays finite
+    tr16 = trainer.Trainer(*nets, device=dev, precise=False, compute=K.BF16, distortion_aware=True)
+    tr16.step(ldr.to(dev), hdr.to(dev), gt.to(dev), update=True)
+    assert all(np.isfinite(v) for v in tr16.loss_dict().values()) and torch.isfinite(tr16.gs.flat).all()
+
+
 def test_adam_kernel(dev):
     """hdrsky_adam vs the oracle's Keras-OptimizerV2 Adam over three consecutive steps."""
     K = pkg("kernels")
