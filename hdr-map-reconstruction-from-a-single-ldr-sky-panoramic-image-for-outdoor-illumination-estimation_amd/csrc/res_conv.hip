@@ -145,13 +145,14 @@ __global__ void __launch_bounds__(512, 2) resconv_kernel(const RcArgs a) {
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     // ---- LDS-DMA: filter slice (one 1 KB k-step fragment per instruction), then the operand planes; wave w copies
     // image row w of each plane (4 instructions of 8 pixels x 128 bytes) ----------------------------------------------
+    // Issue order: filter k-steps of the first plane's two channel blocks, plane 0, the other k-steps, plane 1 - the first
+    // stage then starts after 18 + 32 KB instead of 36 + 32 KB (the CU's vector-memory path moves ~64 B per clock: the
+    // copy itself, not its latency, is what the prologue waits for).
+    int nlate = 0;      // this wave's DMAs that belong to the second stage (NPL == 2): they stay in flight across stage 0
     {
       const uint4* wsrc = reinterpret_cast<const uint4*>(u.w) + (size_t)kq * a.Npad + n0 + lr;
-      for (int ks = wave; ks < G::NKS; ks += 8)
-        glds16(wsrc + (size_t)ks * 4 * a.Npad, lds_base + G::OFF_W + ks * 1024);
       const unsigned short* xb = reinterpret_cast<const unsigned short*>(u.x) + (size_t)b * 256 * Cin;
-#pragma unroll
-      for (int p = 0; p < NPL; ++p)
+      auto dma_plane = [&](int p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int i = wave * 4 + j;
@@ -160,10 +161,27 @@ __global__ void __launch_bounds__(512, 2) resconv_kernel(const RcArgs a) {
           const int cb = 2 * p + (c >> 2);
           glds16(xb + (size_t)pix * Cin + cb * 32 + (c & 3) * 8, lds_base + p * G::PLANE + i * 1024);
         }
+      };
+      // k-step ks = tap * NCB + cb; stage p uses cb in {2p, 2p+1}: the 18 k-steps of a stage, dealt round-robin to the waves
+      for (int e = wave; e < 18; e += 8) {
+        const int ks = (e >> 1) * NCB + (e & 1);
+        glds16(wsrc + (size_t)ks * 4 * a.Npad, lds_base + G::OFF_W + ks * 1024);
+      }
+      dma_plane(0);
+      if (NPL == 2) {
+        for (int e = wave; e < 18; e += 8) {
+          const int ks = (e >> 1) * NCB + 2 + (e & 1);
+          glds16(wsrc + (size_t)ks * 4 * a.Npad, lds_base + G::OFF_W + ks * 1024);
+          ++nlate;
+        }
+        dma_plane(1);
+        nlate += 4;
+      }
     }
     RC_STAMP(1)
-    // filter + plane 0 landed (this wave's share), plane 1 (its 4 youngest DMAs) may still be in flight
-    if (NPL == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    // first-stage data landed (this wave's share); the second stage's DMAs (its 6 or 7 youngest) may still be in flight
+    if (nlate == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else if (nlate == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -231,24 +249,31 @@ __global__ void __launch_bounds__(512, 2) resconv_kernel(const RcArgs a) {
   }
   RC_STAMP(4)
 
-  // per-channel sums over the 256 pixels of the sample: lanes of a row (16 pixels) by DPP, the 8 waves through LDS
+  // per-channel sums over the 256 pixels of the sample: lanes of a row (16 pixels) by DPP, the 8 waves through LDS.
+  // Table layout [kq 4][which 2][wave 8] float4: after the barrier ONE ds_read_b128 per lane fetches the partial of
+  // (which = lr >> 3, wave = lr & 7) and three DPP steps (quad_perm xor 1, xor 2, row_half_mirror) add the eight waves in
+  // a fixed tree - the same bits in every lane (each step adds the same two numbers on both sides) - instead of sixteen
+  // dependent LDS round trips; row_ror:8 then hands each half-row the other quantity.
   float t0[4], t1[4];
   auto cross_wave = [&](const float (&p0)[4], const float (&p1)[4]) {
     if (lr == 0) {
-      *reinterpret_cast<float4*>(sStat + ((wave * 4 + kq) * 2 + 0) * 4) = float4{p0[0], p0[1], p0[2], p0[3]};
-      *reinterpret_cast<float4*>(sStat + ((wave * 4 + kq) * 2 + 1) * 4) = float4{p1[0], p1[1], p1[2], p1[3]};
+      *reinterpret_cast<float4*>(sStat + (((kq * 2 + 0) * 8 + wave) * 4)) = float4{p0[0], p0[1], p0[2], p0[3]};
+      *reinterpret_cast<float4*>(sStat + (((kq * 2 + 1) * 8 + wave) * 4)) = float4{p1[0], p1[1], p1[2], p1[3]};
     }
     __syncthreads();
     RC_STAMP(5)
+    const float4 q = *reinterpret_cast<const float4*>(sStat + (((kq * 2 + (lr >> 3)) * 8 + (lr & 7)) * 4));
+    float r[4] = {q.x, q.y, q.z, q.w}, o[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) t0[j] = t1[j] = 0.f;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) {   // fixed order: bit-reproducible
-      const float4 q0 = *reinterpret_cast<const float4*>(sStat + ((w * 4 + kq) * 2 + 0) * 4);
-      const float4 q1 = *reinterpret_cast<const float4*>(sStat + ((w * 4 + kq) * 2 + 1) * 4);
-      t0[0] += q0.x; t0[1] += q0.y; t0[2] += q0.z; t0[3] += q0.w;
-      t1[0] += q1.x; t1[1] += q1.y; t1[2] += q1.z; t1[3] += q1.w;
+    for (int j = 0; j < 4; ++j) {
+      r[j] += dpp_zero<0xB1>(r[j]);     // quad_perm [1,0,3,2]
+      r[j] += dpp_zero<0x4E>(r[j]);     // quad_perm [2,3,0,1]
+      r[j] += dpp_zero<0x141>(r[j]);    // row_half_mirror: the other quad of this half-row
+      o[j] = dpp_zero<0x128>(r[j]);     // row_ror:8: the other half-row's total
     }
+    const bool lo = lr < 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { t0[j] = lo ? r[j] : o[j]; t1[j] = lo ? o[j] : r[j]; }
   };
 
   if (fwd) {
