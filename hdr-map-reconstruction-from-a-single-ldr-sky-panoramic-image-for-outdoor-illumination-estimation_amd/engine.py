@@ -13,6 +13,7 @@ The whole sequence is enqueued on one HIP stream and is capturable into a hipGra
 synchronisation, no allocation outside torch's caching allocator).
 """
 from collections import OrderedDict
+import os
 
 import torch
 
@@ -86,6 +87,40 @@ def _in_xf(stats, p, name, slope):
     return InXf(mode=L.IN_PARTIALS, slope=slope, stats=stats, gamma=p[name + ".gamma"], beta=p[name + ".beta"])
 
 
+def sun3_supported(x, compute):
+    """sunlayer3 (3x3 64->128->128 on the 8x32 maps of a 32x128 image) can run on the sample-resident launches."""
+    # Opt-in (HDRSKY_SUN3=1).  Measured on one box, same process order (profiles/ab_bench.sh): forward 0.621 vs 0.621 ms, training
+    # step 3.64 vs 3.61 ms with / without - the two launches are each faster than the generic conv + norm pair alone
+    # (6-7 us vs 15 + 8 us), but a sample-resident workgroup owns its CU (100 KB of LDS, 512 threads), so the kernels of
+    # the other streams cannot run beside it and the step loses the overlap it gains in kernel time.
+    if os.environ.get("HDRSKY_SUN3", "0") != "1":
+        return False
+    return compute == BF16 and K.resconv_supported(x.shape[1], x.shape[2], 64, 128) and K.resconv_supported(x.shape[1], x.shape[2], 128, 128)
+
+
+def sun3_forward(x, pk1, pk2, g1, b1, g2, b2):
+    """sunposeLayer.call (sunpose_net.py:20-30) + the max-pool behind it for sunlayer3, on two sample-resident launches:
+    conv -> InstanceNorm -> relu twice (bf16 between them), A3 in fp32 (Grad-CAM multiplies it), P3 = 2x2 max-pool.
+    Returns the record the Grad-CAM sweep and the training backward re-read."""
+    xb = K.to_bf16(x)
+    o1 = K.resconv_fwd(xb, pk1, None, g1, b1, 0.0, save=True)
+    o2 = K.resconv_fwd(o1["bf16"], pk2, None, g2, b2, 0.0, want_bf16=False, want_f32=True, save=True)
+    return dict(xb=xb, o1=o1, o2=o2, A=o2["f32"], P=K.maxpool(o2["f32"]))
+
+
+def sun3_backward(rec, dP, pkT1, pkT2, g1, b1, g2, b2, dgb1=None, dgb2=None):
+    """Gradient chain through sunlayer3 from dP (w.r.t. the pooled output) to the layer's input: pool routing + relu mask
+    (hdrsky_maxpool_relu_bwd on the post-relu map), then norm2 backward, the two data gradients and norm1 + relu backward
+    inside sample-resident launches.  Returns (dc2, dc1, dx): bf16 gradients w.r.t. the two conv outputs (weight-gradient
+    operands) and the fp32 gradient w.r.t. the layer input."""
+    o1, o2 = rec["o1"], rec["o2"]
+    dz = K.maxpool_relu_bwd(rec["A"], dP)
+    dc2 = K.resconv_bwd(None, None, skip=dz, norm=dict(xhat=o2["xhat"], inv=o2["inv"], gamma=g2, beta=b2, slope=1.0, dgb=dgb2))["bf16"]
+    dc1 = K.resconv_bwd(dc2, pkT2, norm=dict(xhat=o1["xhat"], inv=o1["inv"], gamma=g1, beta=b1, slope=0.0, dgb=dgb1))["bf16"]
+    dx = K.resconv_bwd(dc1, pkT1, want_f32=True, want_bf16=False)["f32"]
+    return dc2, dc1, dx
+
+
 def sunpose_forward(nets, ldr, compute):
     """sunpose_net.model.sunposeEstimation (sunpose_net.py:54-72) -> dict with cmf, z, A1..3 (+ what the
     Grad-CAM sweep re-reads: raw conv outputs and their IN partials)."""
@@ -94,6 +129,12 @@ def sunpose_forward(nets, ldr, compute):
     x = ldr
     for l in (1, 2, 3):
         n1, n2 = "sunlayer%d.conv1" % l, "sunlayer%d.conv2" % l
+        if l == 3 and sun3_supported(x, compute):
+            t["s3"] = sun3_forward(x, pk["sun." + n1], pk["sun." + n2], s["sunlayer3.norm1.gamma"], s["sunlayer3.norm1.beta"],
+                                   s["sunlayer3.norm2.gamma"], s["sunlayer3.norm2.beta"])
+            t["A3"], t["P3"] = t["s3"]["A"], t["s3"]["P"]
+            x = t["P3"]
+            continue
         r1, st1 = K.conv2d(x, pk["sun." + n1], s[n1 + ".b"], want_stats=True, compute=compute)
         r2, st2 = K.conv2d(r1, pk["sun." + n2], s[n2 + ".b"], want_stats=True, compute=compute,
                            xf=_in_xf(st1, s, "sunlayer%d.norm1" % l, 0.0))
@@ -123,17 +164,23 @@ def gradcam_sweep(nets, t, pick_src, compute):
     dP3 = dflat.reshape(B, h // 8, w // 8, 128)
     w3 = K.spatial_sum(dP3, 1.0 / ((h // 4) * (w // 4)))
     # layer 3 backward: pool3 + relu + IN2 -> dgrad conv2 -> relu + IN1 -> dgrad conv1
-    g = K.norm_act_bwd(t["r3b"], t["st3b"], s["sunlayer3.norm2.gamma"], s["sunlayer3.norm2.beta"], 0.0, dP3, True)
-    g, _ = K.conv2d(g, pk["sun.sunlayer3.conv2.T"], None, compute=compute)
-    g = K.norm_act_bwd(t["r3a"], t["st3a"], s["sunlayer3.norm1.gamma"], s["sunlayer3.norm1.beta"], 0.0, g, False)
-    dP2, sP2 = K.conv2d(g, pk["sun.sunlayer3.conv1.T"], None, compute=compute, want_stats=True)
+    if "s3" in t:
+        _, _, dP2 = sun3_backward(t["s3"], dP3, pk["sun.sunlayer3.conv1.T"], pk["sun.sunlayer3.conv2.T"],
+                                  s["sunlayer3.norm1.gamma"], s["sunlayer3.norm1.beta"], s["sunlayer3.norm2.gamma"],
+                                  s["sunlayer3.norm2.beta"])
+        sP2 = K.spatial_sum(dP2, 1.0 / ((h // 2) * (w // 2)))         # GAP numerator of d y_c / d A2 as a [B,C] table
+    else:
+        g = K.norm_act_bwd(t["r3b"], t["st3b"], s["sunlayer3.norm2.gamma"], s["sunlayer3.norm2.beta"], 0.0, dP3, True)
+        g, _ = K.conv2d(g, pk["sun.sunlayer3.conv2.T"], None, compute=compute)
+        g = K.norm_act_bwd(t["r3a"], t["st3a"], s["sunlayer3.norm1.gamma"], s["sunlayer3.norm1.beta"], 0.0, g, False)
+        dP2, sP2 = K.conv2d(g, pk["sun.sunlayer3.conv1.T"], None, compute=compute, want_stats=True)
     g = K.norm_act_bwd(t["r2b"], t["st2b"], s["sunlayer2.norm2.gamma"], s["sunlayer2.norm2.beta"], 0.0, dP2, True)
     g, _ = K.conv2d(g, pk["sun.sunlayer2.conv2.T"], None, compute=compute)
     g = K.norm_act_bwd(t["r2a"], t["st2a"], s["sunlayer2.norm1.gamma"], s["sunlayer2.norm1.beta"], 0.0, g, False)
     _, sP1 = K.conv2d(g, pk["sun.sunlayer2.conv1.T"], None, compute=compute, want_stats=True)
     # GAP of d y_c / d A_k == sum of the pooled-map gradient / (H_k*W_k): the dgrad conv's per-tile sums
-    return (K.grad_cam_map(t["A1"], sP1, 1.0 / (h * w)), K.grad_cam_map(t["A2"], sP2, 1.0 / ((h // 2) * (w // 2))),
-            K.grad_cam_map(t["A3"], w3))
+    cam2 = K.grad_cam_map(t["A2"], sP2) if "s3" in t else K.grad_cam_map(t["A2"], sP2, 1.0 / ((h // 2) * (w // 2)))
+    return (K.grad_cam_map(t["A1"], sP1, 1.0 / (h * w)), cam2, K.grad_cam_map(t["A3"], w3))
 
 
 def encode(nets, ldr, compute, distortion_aware=False, dilation_rate=1):

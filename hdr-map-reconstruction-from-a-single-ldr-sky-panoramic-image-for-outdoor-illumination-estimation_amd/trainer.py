@@ -201,6 +201,12 @@ class Trainer:
         "bwd_enc": ["gen.norm3_d", "gen.norm2_d", "gen.norm1_d"],
     }
 
+    RESCONV_NORMS = ("sun.sunlayer3.norm1", "sun.sunlayer3.norm2")
+
+    def _sun3_ok(self):
+        return self.compute == BF16 and not self.precise and K.resconv_supported(self.h // 4, self.w // 4, 64, 128) and \
+            os.environ.get("HDRSKY_SUN3", "0") == "1"
+
     def _norm_state(self, B):
         st = getattr(self, "_nstate", None)
         if st is None:
@@ -214,11 +220,26 @@ class Trainer:
                         continue
                     t = torch.zeros((B, 2, w[n + ".gamma"].numel()), dtype=torch.float32, device=self.device)
                     sums[n] = t
-                    entries.append((t, g[n + ".beta"], g[n + ".gamma"]))      # norm_act_bwd's table: (d beta, d gamma)
+                    if n in self.RESCONV_NORMS and self._sun3_ok():
+                        entries.append((t, g[n + ".gamma"], g[n + ".beta"]))  # hdrsky_resconv's table: (d gamma, d beta)
+                    else:
+                        entries.append((t, g[n + ".beta"], g[n + ".gamma"]))  # hdrsky_norm_act_bwd's table: (d beta, d gamma)
                 if entries:
                     red[seg] = K.DgbReducer(entries)
             st[B] = (sums, red)
         return st[B]
+
+    def _sun3_bwd(self, t, dP, B):
+        """Training backward through sunlayer3 on the sample-resident launches (engine.sun3_backward) + its two weight
+        gradients on bf16 operands; the norm layers' per-sample (d gamma, d beta) terms go to the segment's tables."""
+        n, w, c = "sun.sunlayer3", self.gs.w, self.conv
+        sums = self._norm_state(B)[0]
+        dc2, dc1, dx = E.sun3_backward(t["s3"], dP, c[n + ".conv1"].pkT, c[n + ".conv2"].pkT, w[n + ".norm1.gamma"],
+                                       w[n + ".norm1.beta"], w[n + ".norm2.gamma"], w[n + ".norm2.beta"],
+                                       dgb1=sums[n + ".norm1"], dgb2=sums[n + ".norm2"])
+        self._wg(n + ".conv2", t["s3"]["o1"]["bf16"], None, dc2)
+        self._wg(n + ".conv1", t["s3"]["xb"], None, dc1)
+        return dx
 
     def _in_bwd(self, x, stats, name, slope, dy, pooled=False):
         w = self.gs.w
@@ -265,6 +286,13 @@ class Trainer:
         t, x = {}, ldr
         for l in (1, 2, 3):
             n = "sun.sunlayer%d" % l
+            if l == 3 and E.sun3_supported(x, cp) and not self.precise:
+                t["in3"] = x
+                t["s3"] = E.sun3_forward(x, c[n + ".conv1"].pk, c[n + ".conv2"].pk, w[n + ".norm1.gamma"], w[n + ".norm1.beta"],
+                                         w[n + ".norm2.gamma"], w[n + ".norm2.beta"])
+                t["A3"], t["P3"] = t["s3"]["A"], t["s3"]["P"]
+                x = t["P3"]
+                continue
             r1, st1 = c[n + ".conv1"].fwd(x, compute=cp, want_stats=True)
             xf = self._inxf(st1, n + ".norm1", 0.0)
             r2, st2 = c[n + ".conv2"].fwd(r1, xf, cp, want_stats=True)
@@ -288,16 +316,21 @@ class Trainer:
         dP3 = K.fc_finalize(K.fc_dgrad(df1, self.fc1, cp)).reshape(B, h // 8, wd // 8, 128)
         w3 = K.spatial_sum(dP3, 1.0 / ((h // 4) * (wd // 4)))
         n3, n2 = "sun.sunlayer3", "sun.sunlayer2"
-        g = K.norm_act_bwd(t["r3b"], t["st3b"], w[n3 + ".norm2.gamma"], w[n3 + ".norm2.beta"], 0.0, dP3, True)
-        g = c[n3 + ".conv2"].dgrad(t["r3a"], g, cp)
-        g = K.norm_act_bwd(t["r3a"], t["st3a"], w[n3 + ".norm1.gamma"], w[n3 + ".norm1.beta"], 0.0, g, False)
-        dP2, sP2 = c[n3 + ".conv1"].dgrad(t["in3"], g, cp, want_stats=True)
+        if "s3" in t:
+            _, _, dP2 = E.sun3_backward(t["s3"], dP3, c[n3 + ".conv1"].pkT, c[n3 + ".conv2"].pkT, w[n3 + ".norm1.gamma"],
+                                        w[n3 + ".norm1.beta"], w[n3 + ".norm2.gamma"], w[n3 + ".norm2.beta"])
+            sP2 = K.spatial_sum(dP2, 1.0 / ((h // 2) * (wd // 2)))
+        else:
+            g = K.norm_act_bwd(t["r3b"], t["st3b"], w[n3 + ".norm2.gamma"], w[n3 + ".norm2.beta"], 0.0, dP3, True)
+            g = c[n3 + ".conv2"].dgrad(t["r3a"], g, cp)
+            g = K.norm_act_bwd(t["r3a"], t["st3a"], w[n3 + ".norm1.gamma"], w[n3 + ".norm1.beta"], 0.0, g, False)
+            dP2, sP2 = c[n3 + ".conv1"].dgrad(t["in3"], g, cp, want_stats=True)
         g = K.norm_act_bwd(t["r2b"], t["st2b"], w[n2 + ".norm2.gamma"], w[n2 + ".norm2.beta"], 0.0, dP2, True)
         g = c[n2 + ".conv2"].dgrad(t["r2a"], g, cp)
         g = K.norm_act_bwd(t["r2a"], t["st2a"], w[n2 + ".norm1.gamma"], w[n2 + ".norm1.beta"], 0.0, g, False)
         _, sP1 = c[n2 + ".conv1"].dgrad(t["in2"], g, cp, want_stats=True)
-        return (K.grad_cam_map(t["A1"], sP1, 1.0 / (h * wd)), K.grad_cam_map(t["A2"], sP2, 1.0 / ((h // 2) * (wd // 2))),
-                K.grad_cam_map(t["A3"], w3))
+        cam2 = K.grad_cam_map(t["A2"], sP2) if "s3" in t else K.grad_cam_map(t["A2"], sP2, 1.0 / ((h // 2) * (wd // 2)))
+        return (K.grad_cam_map(t["A1"], sP1, 1.0 / (h * wd)), cam2, K.grad_cam_map(t["A3"], w3))
 
     def _down_stack(self, net, params, x, training):
         """downsampling x4 (discriminator.py:20-27 == sunrad_net.py:21-28).  Returns records for the backward pass:
@@ -613,6 +646,9 @@ class Trainer:
             t, dP = T["t"], T["dP3"]
             for l in (3, 2, 1):
                 n = "sun.sunlayer%d" % l
+                if l == 3 and "s3" in t:
+                    dP = self._sun3_bwd(t, dP, B)
+                    continue
                 dr2 = self._in_bwd(t["r%db" % l], t["st%db" % l], n + ".norm2", 0.0, dP, pooled=True)
                 self._wg(n + ".conv2", t["r%da" % l], t["xf%d" % l], dr2)
                 da = c[n + ".conv2"].dgrad(t["r%da" % l], dr2, cp)
@@ -959,6 +995,9 @@ class SunPoseTrainer(Trainer):
         dP = K.fc_finalize(K.fc_dgrad(df1, self.fc1, cp)).reshape(B, self.h // 8, self.w // 8, 128)
         for l in (3, 2, 1):
             n = "sun.sunlayer%d" % l
+            if l == 3 and "s3" in t:
+                dP = self._sun3_bwd(t, dP, B)
+                continue
             dr2 = self._in_bwd(t["r%db" % l], t["st%db" % l], n + ".norm2", 0.0, dP, pooled=True)
             self._wg(n + ".conv2", t["r%da" % l], t["xf%d" % l], dr2)
             da = c[n + ".conv2"].dgrad(t["r%da" % l], dr2, cp)

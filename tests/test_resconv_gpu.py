@@ -146,3 +146,36 @@ def test_resconv_is_bit_reproducible_and_rejects_other_shapes(dev):
     args = L.ResconvArgs()
     args.B, args.Cin, args.Cout, args.mode = 1, 96, 128, L.RC_FWD
     assert L.load().hdrsky_resconv(args, None) == -2          # HDRSKY_EUNSUPPORTED before anything is launched
+
+
+def test_sunlayer3_on_the_sample_resident_launches(dev, monkeypatch):
+    """Opt-in path (HDRSKY_SUN3=1): sunlayer3 (3x3 64->128->128 + InstanceNorm + relu, sunpose_net.py:20-30) forward, its part
+    of the Grad-CAM sweep and its training backward on hdrsky_resconv.  Same bf16 operands as the default path, so the
+    two agree at fp32 accumulation level in the forward and at bf16-xhat level in the gradients."""
+    params, synth, engine, trainer, K = pkg("params"), pkg("synth"), pkg("engine"), pkg("trainer"), pkg("kernels")
+    gen = params.init_params(params.generator_spec(), 0); sun = params.init_params(params.sunpose_spec(), 1)
+    dis = params.init_params(params.discriminator_spec(), 2); vgg = params.init_params(params.vgg_spec(), 3)
+    batch = synth.make_batch(2, seed=1234)
+    ldr, hdr, gt = (torch.from_numpy(batch[k]).to(dev) for k in ("ldr", "hdr_t", "sunpose_gt"))
+    nets = engine.Nets(gen, sun, device=dev, precise=False)
+    base = engine.generator_forward(nets, ldr, compute=K.BF16)
+    tr0 = trainer.Trainer(gen, sun, dis, vgg, device=dev, precise=False, compute=K.BF16)
+    tr0.step(ldr, hdr, gt, update=False)
+    g0 = {k: tr0.gs.g[k].clone() for k in tr0.gs.g if k.startswith("sun.")}
+    monkeypatch.setenv("HDRSKY_SUN3", "1")
+    out = engine.generator_forward(nets, ldr, compute=K.BF16)
+    for k, tol in (("sunpose_cmf", 2e-3), ("sun_cam3", 2e-2), ("sun_cam2", 5e-2), ("y_final_gamma", 5e-3)):
+        _close(out[k], base[k].cpu(), tol, k)
+    tr1 = trainer.Trainer(gen, sun, dis, vgg, device=dev, precise=False, compute=K.BF16)
+    tr1.step(ldr, hdr, gt, update=False)
+    assert "s3" in tr1._T["t"]
+    dot = na = nb = 0.0
+    for k, v in g0.items():
+        a, b = tr1.gs.g[k].double(), v.double()
+        dot += float((a * b).sum()); na += float((a * a).sum()); nb += float((b * b).sum())
+    cos = dot / (na * nb) ** 0.5
+    print("sun-pose gradient cosine, sunlayer3 on resconv vs default: %.5f" % cos)
+    assert cos > 0.995 and abs((na / nb) ** 0.5 - 1.0) < 2e-2
+    for leaf in ("conv1.w", "conv2.w", "norm1.gamma", "norm2.beta"):
+        a, b = tr1.gs.g["sun.sunlayer3." + leaf], g0["sun.sunlayer3." + leaf]
+        assert float((a - b).abs().max()) <= 6e-2 * float(b.abs().max()), leaf
