@@ -140,7 +140,7 @@ __device__ __forceinline__ void compute_chunk(const ConvKArgs& a, const unsigned
 // 8-wave variants are compiled for 4 waves per SIMD (<= 128 VGPRs; they need 77-106 and no scratch): two workgroups
 // then fit a CU, which is what lets kernels of the other streams of the training step overlap with this one.
 template <int WM, int WN, int MI, int NI, int TW, bool NARROW, bool PRECISE, bool DB>
-__global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? 4 : 1) conv_igemm_kernel(const ConvKArgs a) {
+__global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB ? 4 : 2) : 1) conv_igemm_kernel(const ConvKArgs a) {
   constexpr int NW = WM * WN;                // waves per workgroup (4 or 8)
   constexpr int NT = NW * 64;
   constexpr int BM = WM * MI * 16;

@@ -436,41 +436,42 @@ __global__ void __launch_bounds__(NW * 64) conv_wgrad_kernel(const MultiArgs m) 
 
 // Second stage of the deterministic split-K: dw[tap][ci][co] += sum over the job's pixel chunks of the workgroup
 // partials, db likewise - always in the same order.  One launch for the jobs of a conv_wgrad_kernel launch; CB / OB = that
-// launch's block size in channels.  A block owns 64 float4 of a (block, tap) slab row set; its four waves each sum every
-// fourth chunk (16-byte loads, four independent chains in flight per thread), then wave 0 adds the four partial sums in
-// wave order.  (A single chain per element was latency bound: ~200 blocks of dependent strided loads, 58 us per launch.)
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const MultiArgs m, int CB, int OB) {
-  __shared__ float4 sPart[3][64];
+// launch's block size in channels.  A block owns 256/S float4 of a chunk's slab set and S chunk slices: slice q sums the
+// chunks q, q+S, ... (16-byte loads, independent chains in flight), then slice 0 adds the S partial sums in slice order.
+// S = 4 for shallow splits, 16 when a job is split over >= 32 chunks (the 7x7 / narrow layers: few dW elements, many
+// chunks - one chain per element was latency bound there: ~200 blocks of 128 dependent strided loads).
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const MultiArgs m, int CB, int OB, int S) {
+  __shared__ float4 sPart[15 * 64];
   int job = 0;
   while (job + 1 < m.njobs && (int)blockIdx.x >= m.rfirst[job + 1]) ++job;
   const WgradArgs& a = m.job[job];
   const int nblk = a.cblocks * a.oblocks, ob4 = OB >> 2;
   const size_t slab = (size_t)a.ntaps * CB * OB;                 // floats of one (chunk, block) partial
   const size_t nvec = (size_t)nblk * a.ntaps * CB * ob4;         // float4 of one chunk
-  const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int per = 256 / S;                                        // float4 per block
+  const int lane = threadIdx.x % per, slice = threadIdx.x / per;
   const int rb = blockIdx.x - m.rfirst[job];
-  const size_t v = (size_t)rb * 64 + lane;
+  const size_t v = (size_t)rb * per + lane;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (v < nvec) {
     const float4* src = reinterpret_cast<const float4*>(a.ws) + v;   // slabs of a chunk are contiguous: [blk][tap][cl][ol]
     const size_t cstride = (size_t)nblk * slab / 4;
     int c = slice;
-    for (; c + 12 < a.nchunks; c += 16) {
-      const float4 q0 = src[(size_t)c * cstride], q1 = src[(size_t)(c + 4) * cstride];
-      const float4 q2 = src[(size_t)(c + 8) * cstride], q3 = src[(size_t)(c + 12) * cstride];
+    for (; c + 3 * S < a.nchunks; c += 4 * S) {
+      const float4 q0 = src[(size_t)c * cstride], q1 = src[(size_t)(c + S) * cstride];
+      const float4 q2 = src[(size_t)(c + 2 * S) * cstride], q3 = src[(size_t)(c + 3 * S) * cstride];
       acc.x += (q0.x + q1.x) + (q2.x + q3.x); acc.y += (q0.y + q1.y) + (q2.y + q3.y);
       acc.z += (q0.z + q1.z) + (q2.z + q3.z); acc.w += (q0.w + q1.w) + (q2.w + q3.w);
     }
-    for (; c < a.nchunks; c += 4) {
+    for (; c < a.nchunks; c += S) {
       const float4 q = src[(size_t)c * cstride];
       acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w;
     }
   }
-  if (slice > 0) sPart[slice - 1][lane] = acc;
+  if (slice > 0) sPart[(slice - 1) * per + lane] = acc;
   __syncthreads();
   if (slice == 0 && v < nvec) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { const float4 q = sPart[k][lane]; acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w; }
+    for (int k = 0; k < S - 1; ++k) { const float4 q = sPart[k * per + lane]; acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w; }
     const int ol = (int)(v % ob4) * 4, cl = (int)((v / ob4) % CB), tap = (int)((v / ((size_t)ob4 * CB)) % a.ntaps);
     const int blk = (int)(v / ((size_t)ob4 * CB * a.ntaps));
     const int ci = (blk / a.oblocks) * CB + cl, co = (blk % a.oblocks) * OB + ol;
@@ -674,7 +675,14 @@ static int wgrad_multi_impl(const hdrsky_wgrad_job* jobs, int njobs, float* ws, 
       int lds = 0, rc = HDRSKY_OK;
       rc = with_variant(geo[i], [&](auto v) {
         using V = decltype(v);
-        int blocks = 0, rblocks = 0;
+        int blocks = 0, rblocks = 0, maxchunks = 1;
+        for (int q = 0; q < cnt; ++q) {   // pass 1: geometry (the reduce launch's slice count follows the deepest split)
+          WgradArgs tmp;
+          if (fill_job(tmp, jobs[members[base + q]]) != HDRSKY_OK) continue;
+          if (V::prepare(tmp, (int)(wg_total * work[base + q] / wsum + 0.5)) < 0) continue;
+          if (tmp.nchunks > maxchunks) maxchunks = tmp.nchunks;
+        }
+        const int S = maxchunks >= 32 ? 16 : 4;
         for (int q = 0; q < cnt; ++q) {
           WgradArgs& a = m.job[q];
           int r = fill_job(a, jobs[members[base + q]]);
@@ -692,7 +700,7 @@ static int wgrad_multi_impl(const hdrsky_wgrad_job* jobs, int njobs, float* ws, 
             a.ws_db = a.db != nullptr ? ws + ws_used + nslab : nullptr;
             ws_used += nslab + (a.db != nullptr ? nbias : 0);
             m.rfirst[q] = rblocks;
-            rblocks += (int)(((size_t)a.cblocks * a.oblocks * a.ntaps * V::CB * (V::OB / 4) + 63) / 64);
+            rblocks += (int)(((size_t)a.cblocks * a.oblocks * a.ntaps * V::CB * (V::OB / 4) + 256 / S - 1) / (256 / S));
           }
         }
         m.first[cnt] = blocks;
@@ -701,7 +709,7 @@ static int wgrad_multi_impl(const hdrsky_wgrad_job* jobs, int njobs, float* ws, 
         if (ws != nullptr && ws_used > ws_floats) return (int)HDRSKY_EINVAL;
         int r = V::launch(m, lds, (hipStream_t)stream);
         if (r != HDRSKY_OK || ws == nullptr) return r;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(256), 0, (hipStream_t)stream, m, V::CB, V::OB);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(256), 0, (hipStream_t)stream, m, V::CB, V::OB, S);
         HDRSKY_CHECK_LAUNCH();
         return (int)HDRSKY_OK;
       });
