@@ -23,6 +23,10 @@ struct DaArgs {
   float* stats;       // optional [B][tiles per sample][2][Cout] (sum, sum of squares) of y per 64-pixel tile, like the conv epilogue
   int B, H, W, Cin, Cout, Npad, ksize, k2, pad, in_h, in_w, cin32, nblocks, tiles_x;
   int tab_off, use_tab;     // LDS byte offset of the per-(pixel, tap) sample table behind the A tiles; 0: computed per item
+  // general sample table (data gradient: the TRANSPOSE of the gather is again a weighted gather, with up to KM source
+  // pixels per (pixel, tap)): gidx / gw [H*W][k*k][KM] = source pixel index (row-major, -1 = none) and weight
+  const int* gidx;
+  const float* gw;
 };
 
 // one bilinear sample position of the reference (distortion_aware_ops.py:62-106), all in float32
@@ -31,16 +35,16 @@ struct Tap4 {
   float w0, w1, w2, w3;
 };
 
-__device__ __forceinline__ Tap4 da_tap(float base_y, float base_x, float off_y, float off_x, int in_h, int in_w) {
+__host__ __device__ __forceinline__ Tap4 da_tap(float base_y, float base_x, float off_y, float off_x, int in_h, int in_w) {
   float y = base_y + off_y;
   float x = base_x + off_x;
-  y = fminf(fmaxf(y, 0.f), (float)(in_h - 1));
+  y = y < 0.f ? 0.f : y; y = y > (float)(in_h - 1) ? (float)(in_h - 1) : y;
   x = x < 0.f ? x + (float)in_w : x;
   x = x > (float)(in_w - 1) ? x - (float)in_w : x;
   int y0 = (int)floorf(y), x0 = (int)floorf(x);
   int y1 = y0 + 1, x1 = x0 + 1;
-  y0 = min(max(y0, 0), in_h - 1);
-  y1 = min(max(y1, 0), in_h - 1);
+  y0 = y0 < 0 ? 0 : (y0 > in_h - 1 ? in_h - 1 : y0);
+  y1 = y1 < 0 ? 0 : (y1 > in_h - 1 ? in_h - 1 : y1);
   const int x0w = x0, x1w = x1;  // unwrapped: used for the weights (:89, :100-106)
   x0 = x0 < 0 ? x0 + in_w : x0; x1 = x1 < 0 ? x1 + in_w : x1;
   x0 = x0 > in_w - 1 ? x0 - in_w : x0; x1 = x1 > in_w - 1 ? x1 - in_w : x1;
@@ -59,7 +63,8 @@ __device__ __forceinline__ Tap4 da_tap(float base_y, float base_x, float off_y, 
 // workgroup, so the gather is not repeated per filter block).  Per filter tap: every thread gathers the four corner
 // pixels of its (pixel, 8-channel) items into REGISTERS one tap ahead - the loads of tap t+1 are in flight while the
 // MFMAs of tap t run - then blends, rounds to bf16 and writes the tap's A tile into the other LDS buffer.
-template <bool PRECISE, int NWV, int IMAX>
+// KM = source pixels per (pixel, tap): 4 (the forward's bilinear corners) or 8 (general table: the data gradient).
+template <bool PRECISE, int NWV, int IMAX, int KM>
 __global__ void __launch_bounds__(NWV * 64) da_conv_kernel(const DaArgs a) {
   constexpr int TM = 64, NT = NWV * 64;
   constexpr int MAXROWS = 5;                                   // image rows a 64-pixel tile can span (W >= 16)
@@ -89,7 +94,7 @@ __global__ void __launch_bounds__(NWV * 64) da_conv_kernel(const DaArgs a) {
   // starts from an LDS read instead of a dependent global load in front of the corner loads.
   __shared__ float s_off[MAXROWS * 2 * 128];
   const int row0 = p0 / a.W;
-  {
+  if constexpr (KM == 4) {
     const int nrow = min(p0 + TM - 1, npix - 1) / a.W - row0 + 1;
     for (int i = tid; i < nrow * a.k2 * 2; i += NT) s_off[i] = a.offs[(size_t)row0 * a.k2 * 2 + i];
     __syncthreads();
@@ -125,7 +130,7 @@ __global__ void __launch_bounds__(NWV * 64) da_conv_kernel(const DaArgs a) {
       w[k] = in ? ws[k] : 0.f;
     }
   };
-  if (a.use_tab) {
+  if (KM == 4 && a.use_tab) {
     for (int e = tid; e < TM * a.k2; e += NT) {
       int o[4]; float w[4];
       sample(e % TM, e / TM, o, w);
@@ -135,25 +140,39 @@ __global__ void __launch_bounds__(NWV * 64) da_conv_kernel(const DaArgs a) {
     __syncthreads();
   }
 
-  float cr0[IMAX][4][8], cw0[IMAX][4];      // corner pixels of this thread's items for the tap in flight / their weights
+  float cr0[IMAX][KM][8], cw0[IMAX][KM];    // source pixels of this thread's items for the tap in flight / their weights
 
-  auto gather = [&](int tn, float (&cr)[IMAX][4][8], float (&cw)[IMAX][4]) {
+  auto gather = [&](int tn, float (&cr)[IMAX][KM][8], float (&cw)[IMAX][KM]) {
 #pragma unroll
     for (int it = 0; it < IMAX; ++it) {
       const int i = it * NT + tid;
       if (i < nitems) {
         const int m = i / nq, q = i % nq;
-        int o[4]; float w[4];
-        if (a.use_tab) {
+        int o[KM]; float w[KM];
+        if constexpr (KM != 4) {
+          const int pix = min(p0 + m, npix - 1);
+          const bool live = p0 + m < npix;
+          const int* gi = a.gidx + ((size_t)pix * a.k2 + tn) * KM;
+          const float* gwp = a.gw + ((size_t)pix * a.k2 + tn) * KM;
+#pragma unroll
+          for (int k = 0; k < KM; ++k) {
+            const int si = gi[k];
+            o[k] = (live && si >= 0) ? si * a.Cin : 0;
+            w[k] = (live && si >= 0) ? gwp[k] : 0.f;
+          }
+        } else if (a.use_tab) {
           const int4 to = tabO[tn * TM + m];
           const float4 tw = tabW[tn * TM + m];
           o[0] = to.x; o[1] = to.y; o[2] = to.z; o[3] = to.w;
           w[0] = tw.x; w[1] = tw.y; w[2] = tw.z; w[3] = tw.w;
         } else {
-          sample(m, tn, o, w);
+          int o4[4]; float w4[4];
+          sample(m, tn, o4, w4);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { o[k] = o4[k]; w[k] = w4[k]; }
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < KM; ++k) {
           const float* pp = xb + o[k] + q * 8;
           const float4 lo = *reinterpret_cast<const float4*>(pp), hi = *reinterpret_cast<const float4*>(pp + 4);
           cr[it][k][0] = lo.x; cr[it][k][1] = lo.y; cr[it][k][2] = lo.z; cr[it][k][3] = lo.w;
@@ -173,7 +192,7 @@ __global__ void __launch_bounds__(NWV * 64) da_conv_kernel(const DaArgs a) {
       }
   };
   // one round: blend + store tap t from the register set, refill it with tap t+1 (in flight during the MFMAs of tap t)
-  auto round = [&](int t, float (&cr)[IMAX][4][8], float (&cw)[IMAX][4]) {
+  auto round = [&](int t, float (&cr)[IMAX][KM][8], float (&cw)[IMAX][KM]) {
     uint4* buf = sA + (t & 1) * buf_units;
 #pragma unroll
     for (int it = 0; it < IMAX; ++it) {
@@ -182,8 +201,11 @@ __global__ void __launch_bounds__(NWV * 64) da_conv_kernel(const DaArgs a) {
         const int m = i / nq, q = i % nq;
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < 8; ++j) {
           v[j] = cw[it][0] * cr[it][0][j] + cw[it][1] * cr[it][1][j] + cw[it][2] * cr[it][2][j] + cw[it][3] * cr[it][3][j];
+          if constexpr (KM == 8)
+            v[j] += cw[it][4] * cr[it][4][j] + cw[it][5] * cr[it][5][j] + cw[it][6] * cr[it][6][j] + cw[it][7] * cr[it][7][j];
+        }
         uint4 h8, l8;
         pack8<PRECISE>(v, h8, l8);
         buf[q * plane + m] = h8;
@@ -405,7 +427,7 @@ int hdrsky_da_conv2d_fwd(const float* x, const void* w_hi, const void* w_lo, con
   const int grid = B * a.tiles_x * a.nblocks;
 #define HDRSKY_DA_LAUNCH_(PREC_, NWV_, IMAX_)                                                                      \
   {                                                                                                               \
-    auto k = da_conv_kernel<PREC_, NWV_, IMAX_>;                                                                   \
+    auto k = da_conv_kernel<PREC_, NWV_, IMAX_, 4>;                                                                \
     static bool set = false;                                                                                      \
     if (!set) {                                                                                                   \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,       \
@@ -420,6 +442,77 @@ int hdrsky_da_conv2d_fwd(const float* x, const void* w_hi, const void* w_lo, con
   else { if (nwv == 8) HDRSKY_DA_LAUNCH(false, 8) else HDRSKY_DA_LAUNCH(false, 4) }
 #undef HDRSKY_DA_LAUNCH
 #undef HDRSKY_DA_LAUNCH_
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+// [host] The forward's sample table for an H x W map: for every (pixel p = oy*W + ox, tap t) the four bilinear corners as
+// source pixel indices (row-major, -1 = in the zero padding) and weights - the arithmetic of da_tap (float32, reference
+// order), i.e. exactly what the kernels gather.  idx / w: [H*W][k*k][4].  Its transpose (per target pixel: which
+// (pixel, tap) samples read it, with which weight) is the table hdrsky_da_conv2d_dgrad wants; kernels.da_transpose_table
+// builds it.
+int hdrsky_da_sample_table(const float* offs, int H, int W, int ksize, int* idx, float* w) {
+  if (!offs || !idx || !w || H <= 0 || W <= 0 || (ksize & 1) == 0) return HDRSKY_EINVAL;
+  const int k2 = ksize * ksize, pad = ksize > 1 ? (ksize - 1) / 2 : 0;
+  const int in_h = H + (ksize > 1 ? ksize - 1 : 0), in_w = W + (ksize > 1 ? ksize - 1 : 0);
+  for (int oy = 0; oy < H; ++oy)
+    for (int ox = 0; ox < W; ++ox)
+      for (int t = 0; t < k2; ++t) {
+        const Tap4 s = da_tap((float)(oy + t / ksize), (float)(ox + t % ksize), offs[(oy * k2 + t) * 2], offs[(oy * k2 + t) * 2 + 1],
+                              in_h, in_w);
+        const int ys[4] = {s.y0, s.y0, s.y1, s.y1}, xs[4] = {s.x0, s.x1, s.x0, s.x1};
+        const float ws[4] = {s.w0, s.w1, s.w2, s.w3};
+        for (int k = 0; k < 4; ++k) {
+          const int yy = ys[k] - pad, xx = xs[k] - pad;
+          const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+          const size_t e = (((size_t)oy * W + ox) * k2 + t) * 4 + k;
+          idx[e] = in ? yy * W + xx : -1;
+          w[e] = in ? ws[k] : 0.f;
+        }
+      }
+  return HDRSKY_OK;
+}
+
+// Data gradient of the distortion-aware conv without the k*k x tensor and without atomics:
+//   dx[q][c] = sum_t sum_f ( sum_{(p,w) in L(q,t)} w * dy[p][f] ) * W[t][c][f]
+// i.e. the SAME kernel as the forward - a weighted gather into the LDS tile per tap, then MFMA against the tap's filter -
+// with (a) the transposed sample table L (gidx / gw [H*W][k*k][8]: up to 8 source pixels per (target pixel, tap), tap
+// order of the packed filter) and (b) the transpose_flip image of the kernel (Cin = the layer's filters, Cout = its input
+// channels; its taps are flipped, which the table's tap order accounts for).  Deterministic.
+int hdrsky_da_conv2d_dgrad(const float* dy, const void* wT_hi, const void* wT_lo, const int* gidx, const float* gw, int B, int H,
+                           int W, int F, int C, int ksize, int compute, float* dx, void* stream) {
+  if (!dy || !wT_hi || !gidx || !gw || !dx || (ksize & 1) == 0) return HDRSKY_EINVAL;
+  if ((F % 32) != 0) return HDRSKY_EUNSUPPORTED;
+  const bool precise = compute == HDRSKY_BF16X3;
+  if (precise && !wT_lo) return HDRSKY_EINVAL;
+  DaArgs a{};
+  a.x = dy; a.whi = (const uint4*)wT_hi; a.wlo = (const uint4*)wT_lo; a.y = dx; a.gidx = gidx; a.gw = gw;
+  a.B = B; a.H = H; a.W = W; a.Cin = F; a.Cout = C; a.Npad = roundup(C, 64);
+  a.ksize = ksize; a.k2 = ksize * ksize;
+  a.pad = ksize > 1 ? (ksize - 1) / 2 : 0;
+  a.in_h = H + (ksize > 1 ? ksize - 1 : 0); a.in_w = W + (ksize > 1 ? ksize - 1 : 0);
+  const int nwv = C > 64 ? 8 : 4;
+  a.cin32 = F / 32; a.nblocks = cdiv(C, nwv * 16); a.tiles_x = cdiv(H * W, 64);
+  if (64 * (F / 8) > 2 * nwv * 64) return HDRSKY_EUNSUPPORTED;     // two items per thread (8 sources each in registers)
+  const int lds = 2 * (F / 8) * 65 * 16 * (precise ? 2 : 1);
+  if (lds > 152 * 1024) return HDRSKY_EUNSUPPORTED;
+  if ((64 / W + 2) * a.k2 > 5 * 128) return HDRSKY_EUNSUPPORTED;
+  a.tab_off = lds; a.use_tab = 0;
+  const int grid = B * a.tiles_x * a.nblocks;
+#define HDRSKY_DAG_LAUNCH(PREC_, NWV_)                                                                             \
+  {                                                                                                               \
+    auto k = da_conv_kernel<PREC_, NWV_, 2, 8>;                                                                    \
+    static bool set = false;                                                                                      \
+    if (!set) {                                                                                                   \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                              152 * 1024) != hipSuccess) return HDRSKY_ELAUNCH;                                   \
+      set = true;                                                                                                 \
+    }                                                                                                             \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NWV_ * 64), lds, (hipStream_t)stream, a);                                \
+  }
+  if (precise) { if (nwv == 8) HDRSKY_DAG_LAUNCH(true, 8) else HDRSKY_DAG_LAUNCH(true, 4) }
+  else { if (nwv == 8) HDRSKY_DAG_LAUNCH(false, 8) else HDRSKY_DAG_LAUNCH(false, 4) }
+#undef HDRSKY_DAG_LAUNCH
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }

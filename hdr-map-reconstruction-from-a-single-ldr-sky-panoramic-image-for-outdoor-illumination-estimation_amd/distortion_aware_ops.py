@@ -47,7 +47,9 @@ class conv2d:
 
     def backward(self, inputs, dy, want_dx=True):
         """What a tape returns for this layer: (d inputs, d kernel [k*k*Cin, filters], d bias)."""
-        return K.da_conv2d_bwd(inputs, dy, self.kernel, self._offs, self.kernel_size, self.compute, want_dx)
+        _, h, w, _ = inputs.shape
+        table = K.da_transpose_table(h, w, self.kernel_size, self.dilation_rate, self.skydome, inputs.device) if want_dx else None
+        return K.da_conv2d_bwd(inputs, dy, self.kernel, self._offs, self.kernel_size, self.compute, want_dx, table=table)
 
 
 class deconv2d(conv2d):

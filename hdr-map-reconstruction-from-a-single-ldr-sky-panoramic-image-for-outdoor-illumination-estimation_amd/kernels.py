@@ -901,10 +901,70 @@ def da_gather(x, offs, ksize):
     return G
 
 
-def da_conv2d_bwd(x, dy, kernel, offs, ksize, compute=BF16, want_dx=True, pwT=None, dw=None, db=None):
+DA_KMAX = 8   # source pixels per (target pixel, tap) the data-gradient kernel gathers
+_DA_TT = {}
+
+
+def da_transpose_table(h, w, ksize=3, dilation_rate=1, skydome=True, device="cuda"):
+    """Transposed sample table of the distortion-aware conv on an h x w map, for da_conv2d_dgrad: (gidx, gw) device tensors
+    [h*w, k*k, DA_KMAX] - for target pixel q and tap slot s (the tap order of the transpose_flip filter image: slot s =
+    forward tap k*k-1-s) the forward samples (p, tap) that read q and their weights.  Built once per geometry on the host
+    from hdrsky_da_sample_table (the forward's own float32 arithmetic).  Returns None when some (q, tap) has more than
+    DA_KMAX readers (not the case for the 3x3 layers of the model)."""
+    import ctypes
+    import numpy as np
+    key = (h, w, ksize, dilation_rate, bool(skydome), str(device))
+    if key not in _DA_TT:
+        k2 = ksize * ksize
+        offs = da_offsets(h, w, ksize, dilation_rate, skydome)
+        idx = np.zeros((h * w, k2, 4), np.int32)
+        wt = np.zeros((h * w, k2, 4), np.float32)
+        L.check(L.load().hdrsky_da_sample_table(offs.ctypes.data_as(ctypes.c_void_p), h, w, ksize,
+                                                idx.ctypes.data_as(ctypes.c_void_p), wt.ctypes.data_as(ctypes.c_void_p)),
+                "da_sample_table")
+        p, t, c = np.nonzero((idx >= 0) & (wt != 0.0))
+        q = idx[p, t, c]
+        slot = k2 - 1 - t
+        order = np.lexsort((c, p, slot, q))                 # fixed order inside each (q, slot) list: deterministic sums
+        q, slot, p, wv = q[order], slot[order], p[order], wt[p, t, c][order]
+        grp = q.astype(np.int64) * k2 + slot
+        start = np.r_[0, np.flatnonzero(np.diff(grp)) + 1]
+        pos = np.arange(grp.size) - np.repeat(start, np.diff(np.r_[start, grp.size]))
+        if pos.size and int(pos.max()) >= DA_KMAX:
+            _DA_TT[key] = None
+        else:
+            gidx = np.full((h * w, k2, DA_KMAX), -1, np.int32)
+            gw = np.zeros((h * w, k2, DA_KMAX), np.float32)
+            gidx[q, slot, pos] = p
+            gw[q, slot, pos] = wv
+            _DA_TT[key] = (torch.from_numpy(gidx).to(device), torch.from_numpy(gw).to(device))
+    return _DA_TT[key]
+
+
+def da_conv2d_dgrad(dy, pwT: PackedConv, table, ksize, compute=BF16):
+    """dx of y = da_conv2d(x; kernel): deterministic, no k*k-fold tensor.  pwT = PackedConv(kernel.view(k,k,C,F),
+    transpose_flip=True); table = da_transpose_table(H, W, k, ...)."""
+    _f32(dy)
+    B, H, W, F = dy.shape
+    gidx, gw = table
+    if pwT.Cin != F or not pwT.flip or (pwT.KH, pwT.KW) != (ksize, ksize):
+        raise ValueError("da_conv2d_dgrad: needs the transpose_flip image of the k x k filter")
+    if tuple(gidx.shape) != (H * W, ksize * ksize, DA_KMAX) or gidx.dtype != torch.int32:
+        raise ValueError("da_conv2d_dgrad: table does not match the map")
+    if compute == BF16X3 and pwT.lo is None:
+        raise ValueError("BF16X3 needs the lo weight plane")
+    dx = torch.empty((B, H, W, pwT.Cout), dtype=torch.float32, device=dy.device)
+    L.check(L.load().hdrsky_da_conv2d_dgrad(_p(dy), _p(pwT.hi), _p(pwT.lo), _p(gidx), _p(_f32(gw)), B, H, W, F, pwT.Cout, ksize,
+                                            compute, _p(dx), _stream()), "da_conv2d_dgrad")
+    return dx
+
+
+def da_conv2d_bwd(x, dy, kernel, offs, ksize, compute=BF16, want_dx=True, pwT=None, dw=None, db=None, table=None, pwT3=None):
     """Gradients of y = da_conv2d(x; kernel [k*k*C, F], bias): returns (dx or None, dkernel [k*k*C, F], dbias [F]).
-    pwT: PackedConv(kernel.view(1,1,k*k*C,F), transpose_flip=True) when the caller keeps one (a training loop re-packs it
-    with the other filters); dw [k*k*C, F] / db [F]: gradients are ADDED to these instead of freshly allocated ones."""
+    table (da_transpose_table) [+ pwT3 = PackedConv(kernel.view(k,k,C,F), transpose_flip=True)]: dx by the deterministic
+    gather-form data gradient (hdrsky_da_conv2d_dgrad).  Without a table: dG = dY W^T as a 1x1 conv (pwT =
+    PackedConv(kernel.view(1,1,k*k*C,F), transpose_flip=True)) + bilinear scatter with fp32 atomics.
+    dw [k*k*C, F] / db [F]: gradients are ADDED to these instead of freshly allocated ones."""
     B, H, W, C = x.shape
     F = dy.shape[-1]
     k2 = ksize * ksize
@@ -913,7 +973,12 @@ def da_conv2d_bwd(x, dy, kernel, offs, ksize, compute=BF16, want_dx=True, pwT=No
     dw4 = dw.view(1, 1, k2 * C, F) if dw is not None else None
     dw4, db = conv2d_wgrad(G, dy, 1, 1, compute=compute, dw=dw4, db=db)            # [1,1,k2*C,F]
     dx = None
-    if want_dx:
+    if want_dx and table is not None:
+        # the transpose of the gather as a gather (da_conv2d_dgrad): deterministic, nothing k*k-fold in memory
+        if pwT3 is None:
+            pwT3 = PackedConv(kernel.view(ksize, ksize, C, F), precise=(compute == BF16X3), transpose_flip=True)
+        dx = da_conv2d_dgrad(dy, pwT3, table, ksize, compute)
+    elif want_dx:
         if pwT is None:   # dG = dY W^T as a 1x1 conv: the transpose_flip image of the kernel viewed as a 1x1 filter
             pwT = PackedConv(kernel.view(1, 1, k2 * C, F), precise=(compute == BF16X3), transpose_flip=True)
         dG, _ = conv2d(dy, pwT, None, compute=compute)

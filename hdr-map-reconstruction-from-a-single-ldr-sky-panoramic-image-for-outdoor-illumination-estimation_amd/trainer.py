@@ -107,6 +107,7 @@ class Trainer:
         self.use_resconv = bool(resconv) and not self.da and compute == BF16 and not precise and \
             K.resconv_supported(im_height // 4, im_width // 4, 128, 128)
         self._da_offs = torch.from_numpy(K.da_offsets(im_height // 4, im_width // 4, 3, 1, True)).to(self.device) if self.da else None
+        self._da_table = K.da_transpose_table(im_height // 4, im_width // 4, 3, 1, True, self.device) if self.da else None
         self._rc = {}
         self.dense_wgrad_external = False   # a data-parallel driver recomputes the Dense weight gradients (parallel.py)
         named = OrderedDict(("gen." + k, v) for k, v in gen_params.items())
@@ -733,11 +734,13 @@ class Trainer:
                     for cvn, xin, dy_ in ((p + "conv2", a1, dr2),):
                         cv = c[cvn]
                         da1, _, _ = K.da_conv2d_bwd(xin, dy_, cv.wDA.view(cv.kh * cv.kw * cv.cin, cv.cout), offs, 3, cp, True, cv.pkDA,
-                                                    dw=g[cv.wkey].view(cv.kh * cv.kw * cv.cin, cv.cout), db=g[cv.bkey])
+                                                    dw=g[cv.wkey].view(cv.kh * cv.kw * cv.cin, cv.cout), db=g[cv.bkey],
+                                                    table=self._da_table, pwT3=cv.pkT)
                     dr1 = self._in_bwd(c1, t1, p + "norm1", 0.1, da1)
                     cv = c[p + "conv1"]
                     dxx, _, _ = K.da_conv2d_bwd(T["x"][i], dr1, cv.wDA.view(cv.kh * cv.kw * cv.cin, cv.cout), offs, 3, cp, True, cv.pkDA,
-                                                dw=g[cv.wkey].view(cv.kh * cv.kw * cv.cin, cv.cout), db=g[cv.bkey])
+                                                dw=g[cv.wkey].view(cv.kh * cv.kw * cv.cin, cv.cout), db=g[cv.bkey],
+                                                table=self._da_table, pwT3=cv.pkT)
                     dx = K.axpby(dx, 1.0, dxx, 1.0)                                     # + identity branch
                 self._norm_grads("bwd_res", B)
             for i in range(-1 if (self.use_resconv or self.da) else 5, -1, -1):

@@ -343,6 +343,16 @@ int hdrsky_da_conv2d_fwd(const float* x, const void* w_hi, const void* w_lo, con
  * dG = hdrsky_conv2d_fwd(1x1 with the transposed kernel; dY) and dx = hdrsky_da_scatter(dG) (dx zeroed; fp32 atomics). */
 int hdrsky_da_gather(const float* x, const float* offs, int B, int H, int W, int C, int ksize, float* G, void* stream);
 int hdrsky_da_scatter(const float* dG, const float* offs, int B, int H, int W, int C, int ksize, float* dx, void* stream);
+/* [host] The forward's sample table of an H x W map: per (pixel oy*W+ox, tap) the four bilinear corners as source pixel
+ * indices (row-major, -1 = zero padding) and weights, [H*W][k*k][4] each - exactly what hdrsky_da_conv2d_fwd gathers
+ * (distortion_aware_ops.py:62-106 in float32).  offs: HOST copy of hdrsky_da_offsets. */
+int hdrsky_da_sample_table(const float* offs, int H, int W, int ksize, int* idx, float* w);
+/* Data gradient of the distortion-aware conv (tape through distortion_aware_ops.py:62-121) WITHOUT the k*k-fold tensor and
+ * without atomics: dx[q][c] = sum_t sum_f (sum_{(p,w) in L(q,t)} w dy[p][f]) W[t][c][f] - the forward kernel run on the
+ * transposed sample table.  gidx / gw: device [H*W][k*k][8] (source pixel, -1 = none / weight), tap order of wT_*;
+ * wT_* = hdrsky_conv_pack_weights(kernel viewed [k,k,C,F], ..., transpose_flip=1) (Cin = F filters, Cout = C). */
+int hdrsky_da_conv2d_dgrad(const float* dy, const void* wT_hi, const void* wT_lo, const int* gidx, const float* gw, int B, int H,
+                           int W, int F, int C, int ksize, int compute, float* dx, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Sample-resident 3x3 convolution with the InstanceNormalization around it fused in (csrc/res_conv.hip).
