@@ -8,6 +8,8 @@
 // columns x one reduction slice (split-R for occupancy: 64 column blocks x 4 slices = 256
 // workgroups at N = 4096); weights go HBM -> VGPR directly (streamed once, not shared between
 // waves), activations are staged as bf16 through a double-buffered LDS image shared by the 4 waves.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -149,7 +151,10 @@ int hdrsky_fc_pack_weights(const float* w, int K, int N, void* packed_hi, void* 
 }
 
 int hdrsky_fc_nsplit(int R) {
-  int ns = 4;
+  // 64 column blocks x 8 slices = 512 workgroups at N = 4096: two per CU, i.e. 64 KB of weight loads in flight per CU
+  // (one workgroup keeps 32 KB in flight: ~3 TB/s against ~2 us of HBM latency; HDRSKY_FC_NSPLIT overrides for A/B runs)
+  static const int pref = getenv("HDRSKY_FC_NSPLIT") ? atoi(getenv("HDRSKY_FC_NSPLIT")) : 8;
+  int ns = pref > 0 ? pref : 8;
   while (ns > 1 && (R % (ns * RCH)) != 0) ns >>= 1;
   return ns;
 }

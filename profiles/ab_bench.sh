@@ -2,8 +2,9 @@
 # A/B of bench.py variants back to back on ONE box (different boxes differ by +-2 %): usage  bash profiles/ab_bench.sh
 cd $GRAFT_REPO_ROOT
 run() { echo "== $1"; shift; env "$@" python bench.py --no-cpu-baseline --steps 60 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('train %.4f ms  fwd %.4f ms  roof %.3f us' % (d['ms_per_step'], d['fwd']['ms_per_step'], d['roofline']['avg_launch_us']))"; }
+import json,sys; d=json.loads(sys.stdin.read()); print('train %.4f ms  fwd %.4f ms  roof %.3f us  fc_mfma %.0f GB/s' % (d['ms_per_step'], d['fwd']['ms_per_step'], d['roofline']['avg_launch_us'], d['roofline_hbm'][1]['achieved']))"; }
 for rep in 1 2; do
 run "default" X=1
-run "wgrad atomics" HDRSKY_WGRAD_ATOMIC=1
+run "fc nsplit 4" HDRSKY_FC_NSPLIT=4
+run "fc nsplit 16" HDRSKY_FC_NSPLIT=16
 done
