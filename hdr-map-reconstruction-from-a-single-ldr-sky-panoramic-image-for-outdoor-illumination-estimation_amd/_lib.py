@@ -119,6 +119,9 @@ SIGNATURES = {
     "hdrsky_fc_wgrad": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, P]),
     "hdrsky_rmsprop": (c_int, [P, P, P, c_size_t, c_float, c_float, c_float, c_float, P]),
     "hdrsky_rmsprop_fc": (c_int, [P, P, P, c_int, c_int, c_float, c_float, c_float, c_float, P, P, P]),
+    "hdrsky_fc_wgrad_bf16": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
+    "hdrsky_rmsprop_fc_fused": (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float,
+                                        P, P, P, P]),
     "hdrsky_adam": (c_int, [P, P, P, P, c_size_t, c_float, c_float, c_float, c_float, c_float, P]),
     "hdrsky_resconv_supported": (c_int, [c_int] * 6),
     "hdrsky_resconv": (c_int, [ctypes.POINTER(ResconvArgs), P]),

@@ -711,6 +711,37 @@ def fc_wgrad(x, dy, dw, db, accumulate=False):
                                          _stream()), "fc_wgrad")
 
 
+def _rows2d(t, name):
+    """[M, C] fp32 view whose rows may be strided (a column block of a wider buffer): (pointer, row stride in floats)."""
+    if not (torch.is_tensor(t) and t.is_cuda) or t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1 or (t.stride(0) & 3) or (t.data_ptr() & 15):
+        raise ValueError("%s: fp32 [M, C] with unit column stride, a row stride that is a multiple of 4 and a 16-byte "
+                         "aligned base expected" % name)
+    return _p(t), t.stride(0)
+
+
+def fc_wgrad_bf16(x, dy, dw, db, accumulate=False):
+    """Dense weight / bias gradient on the matrix cores (bf16 operands, fp32 accumulation) - any number of rows."""
+    (M, Kd), N = x.shape, dy.shape[1]
+    _f32(dw, Kd, N)
+    px, ldx = _rows2d(x, "fc_wgrad_bf16 x"); pd, ldy = _rows2d(dy, "fc_wgrad_bf16 dy")
+    if dy.shape[0] != M:
+        raise ValueError("fc_wgrad_bf16: x and dy disagree on the number of rows")
+    L.check(L.load().hdrsky_fc_wgrad_bf16(px, ldx, pd, ldy, M, Kd, N, int(accumulate), _p(dw), _p(db), _stream()),
+            "fc_wgrad_bf16")
+
+
+def rmsprop_fc_fused(w, ms, x, dy, pf, lr, db=None, rho=0.9, eps=1e-7, gscale=1.0):
+    """RMSprop of a Dense kernel with its gradient gscale * x^T dy recomputed inside the update (never materialised);
+    refreshes the bf16 images of `pf`; db (optional) receives the bias gradient."""
+    (M, Kd), N = x.shape, dy.shape[1]
+    _f32(w, Kd, N); _f32(ms, Kd, N)
+    if pf.pk_lo is not None or (pf.K, pf.N) != (Kd, N) or dy.shape[0] != M:
+        raise ValueError("rmsprop_fc_fused: BF16 images of the same kernel and matching operand rows only")
+    px, ldx = _rows2d(x, "rmsprop_fc_fused x"); pd, ldy = _rows2d(dy, "rmsprop_fc_fused dy")
+    L.check(L.load().hdrsky_rmsprop_fc_fused(_p(w), _p(ms), px, ldx, pd, ldy, M, Kd, N, lr, rho, eps, gscale, _p(pf.pk_hi),
+                                             _p(pf.nat_hi), _p(db), _stream()), "rmsprop_fc_fused")
+
+
 def rmsprop(w, g, ms, lr, rho=0.9, eps=1e-7, gscale=1.0):
     n = w.numel()
     _f32(w); _f32(g, n); _f32(ms, n)

@@ -81,6 +81,8 @@ class GradientExchange:
                       replica, 21 MB gathered at N=8 - and every replica recomputes the FULL-batch weight gradients of
                       fc1 / fc2 (its local Dense weight-gradient launches are skipped: `Trainer.dense_wgrad_external`).
                       The sum over replicas is the same number the all-reduce produces (fp32 summation order differs).
+                      With `Trainer.fused_dense` (HDRSKY_BF16 mode) that gradient is not even written: the Dense
+                      optimizer launch contracts the gathered rows tile by tile (hdrsky_rmsprop_fc_fused, M = N * B).
                       32 MB all-reduced + 21 MB gathered per step at N=8 instead of 233 MB.
 
         ex = GradientExchange(tr, mode="gather_dense")
@@ -97,8 +99,13 @@ class GradientExchange:
         self.active = dist.is_initialized()     # a process group exists (world 1 only in rehearsals of this path)
         self.world = dist.get_world_size() if self.active else 1
         self.comm = torch.cuda.Stream(device=device) if self.active else None
+        if getattr(trainer, "_graphs", None) is not None:
+            raise RuntimeError("GradientExchange: construct before Trainer.capture (it changes which launches the plan holds)")
         if mode == "gather_dense" and self.active:
-            trainer.dense_wgrad_external = True   # bwd_head leaves the Dense weight gradients to dense_exchange()
+            trainer.dense_wgrad_external = True   # the local Dense weight-gradient launches are left out (see _dense_gather)
+            trainer.on_bind = self._on_bind
+        elif self.active:
+            trainer.fused_dense = False           # the Dense gradients travel: they have to be written out
         self._gbuf = {}
 
     def describe(self):
@@ -126,22 +133,39 @@ class GradientExchange:
         tr = self.tr
         T, g = tr._T, tr.gs.g
         parts = [T["t"]["flat"], T["df1"], T["t"]["f1"], T["dz"]]
-        B = parts[0].shape[0]
-        widths = [p.shape[1] for p in parts]
-        key = ("dense", B)
-        st = self._gbuf.get(key)
-        if st is None:
-            st = self._gbuf[key] = (torch.empty((B, sum(widths)), dtype=torch.float32, device=parts[0].device),
-                                    torch.empty((self.world * B, sum(widths)), dtype=torch.float32, device=parts[0].device))
-        local, allp = st
+        local, allp, views = self._dense_buffers(parts[0].shape[0])
         torch.cat(parts, dim=1, out=local)
         dist.all_gather_into_tensor(allp, local)
-        o = [0]
-        for wd in widths:
-            o.append(o[-1] + wd)
-        flat, df1, f1, dz = (allp[:, o[i]:o[i + 1]].contiguous() for i in range(4))
-        K.fc_wgrad(f1, dz, g["sun.fc2.kernel"], g["sun.fc2.bias"])
-        K.fc_wgrad(flat, df1, g["sun.fc1.kernel"], g["sun.fc1.bias"])
+        if tr.fused_dense:
+            return     # the Dense optimizer launch contracts the gathered rows itself (Trainer.dense_operands = views)
+        flat, df1, f1, dz = views
+        if tr.precise:
+            K.fc_wgrad(f1.contiguous(), dz.contiguous(), g["sun.fc2.kernel"], g["sun.fc2.bias"])
+            K.fc_wgrad(flat.contiguous(), df1.contiguous(), g["sun.fc1.kernel"], g["sun.fc1.bias"])
+        else:
+            K.fc_wgrad_bf16(f1, dz, g["sun.fc2.kernel"], g["sun.fc2.bias"])
+            K.fc_wgrad_bf16(flat, df1, g["sun.fc1.kernel"], g["sun.fc1.bias"])
+
+    def _dense_buffers(self, B):
+        """Static buffers of the operand exchange for a per-replica batch of B: (local [B, W], gathered [world*B, W],
+        the four column blocks flat | df1 | f1 | dz of the gathered one - row-strided views)."""
+        st = self._gbuf.get(("dense", B))
+        if st is None:
+            tr = self.tr
+            widths = [tr.fc1.K, tr.fc1.N, tr.fc2.K, tr.fc2.N]
+            dev = tr.gs.flat.device
+            local = torch.empty((B, sum(widths)), dtype=torch.float32, device=dev)
+            allp = torch.empty((self.world * B, sum(widths)), dtype=torch.float32, device=dev)
+            o = [0]
+            for wd in widths:
+                o.append(o[-1] + wd)
+            st = self._gbuf[("dense", B)] = (local, allp, tuple(allp[:, o[i]:o[i + 1]] for i in range(4)))
+        return st
+
+    def _on_bind(self, B):
+        # the Dense optimizer launch of a fused_dense trainer reads the gathered rows: they have to be known when the
+        # plan is built (and captured), not only when the first gather has run
+        self.tr.dense_operands = self._dense_buffers(B)[2] if self.tr.fused_dense else None
 
     # ---- the two hook points ----------------------------------------------------------------------------------------
     def fc_grads_reduce(self):

@@ -95,7 +95,8 @@ class _Conv:
 
 class Trainer:
     def __init__(self, gen_params, sun_params, dis_params, vgg_params, device="cuda", lr=1e-4, im_height=32,
-                 im_width=128, precise=False, compute=BF16, world_size=1, resconv=True, distortion_aware=False):
+                 im_width=128, precise=False, compute=BF16, world_size=1, resconv=True, distortion_aware=False,
+                 fused_dense=True):
         self.device = torch.device(device)
         self.h, self.w = im_height, im_width
         self.lr, self.compute, self.precise, self.world = lr, compute, precise, world_size
@@ -110,6 +111,13 @@ class Trainer:
         self._da_table = K.da_transpose_table(im_height // 4, im_width // 4, 3, 1, True, self.device) if self.da else None
         self._rc = {}
         self.dense_wgrad_external = False   # a data-parallel driver recomputes the Dense weight gradients (parallel.py)
+        # fused_dense (HDRSKY_BF16 mode): on an updating step the two Dense kernels' gradients are never written - their
+        # RMSprop launch recomputes x^T dy tile by tile (hdrsky_rmsprop_fc_fused).  gs.g["sun.fc*.kernel"] then holds
+        # nothing of that step; step(update=False) / replay(update=False) materialise them as before.  A data-parallel
+        # driver that all-reduces gradients switches this off; one that gathers the operands sets `dense_operands`.
+        self.fused_dense = bool(fused_dense) and compute == BF16 and not precise
+        self.dense_operands = None          # (flat, df1, f1, dz) of the GLOBAL batch, set by parallel.GradientExchange
+        self.on_bind = None                 # callable(B) run when a step is bound to a batch (static exchange buffers)
         named = OrderedDict(("gen." + k, v) for k, v in gen_params.items())
         named.update(("sun." + k, v) for k, v in sun_params.items())
         self.gs = FlatParams(named, self.device)          # optimizer_gen: _gen + _sun variables (train.py:402-403)
@@ -618,11 +626,7 @@ class Trainer:
                 tails[sfx] = K.decoder_tail_bwd(y, residual, dy, want_dres=(sfx == "u"))
             T["dpre"] = K.sun_rad_bwd(t["cmf"], t["gmax"], T["gamma"], T["beta"], tails["u"][1], T["dcmf"])
             dz = T["dz"] = K.softmax_bwd(t["cmf"], T["dcmf"], t["z"])       # KL + the sun-radiance path meet in dcmf
-            if not self.dense_wgrad_external:
-                K.fc_wgrad(t["f1"], dz, g["sun.fc2.kernel"], g["sun.fc2.bias"])
             df1 = T["df1"] = K.fc_finalize(K.fc_dgrad(dz, self.fc2, cp), None, relu=False, mask_src=t["f1"])
-            if not self.dense_wgrad_external:
-                K.fc_wgrad(t["flat"], df1, g["sun.fc1.kernel"], g["sun.fc1.bias"])
             T["dP3"] = K.fc_finalize(K.fc_dgrad(df1, self.fc1, cp)).reshape(B, h // 8, wd // 8, 128)
 
         # ------------------------------------------------------------------ discriminator step (train.py:351-380)
@@ -774,12 +778,30 @@ class Trainer:
             self._norm_grads("bwd_enc", B)
             self._flush_wgrads()
 
+        # Materialised Dense weight gradients (skipped on an updating step of a fused_dense trainer, see _skip)
+        @seg("wg_dense", 1, ["bwd_head"])
+        def _():
+            if self.dense_wgrad_external:
+                return
+            fn = K.fc_wgrad if self.precise else K.fc_wgrad_bf16
+            fn(T["t"]["f1"], T["dz"], g["sun.fc2.kernel"], g["sun.fc2.bias"])
+            fn(T["t"]["flat"], T["df1"], g["sun.fc1.kernel"], g["sun.fc1.bias"])
+
         # The two Dense layers hold 50.3 M of the 58.3 M parameters and nothing reads their weights or gradients after
-        # bwd_head: their RMSprop update and bf16 re-packing (~1 GB of HBM traffic) run here, beside the rest of the
-        # backward pass, instead of at the end of the step.  (Data-parallel: after the all-reduce of that slice.)
-        @seg("apply_fc", 1, ["bwd_head"])
+        # bwd_head: their RMSprop update and bf16 re-packing run here, beside the rest of the backward pass, instead of
+        # at the end of the step.  (Data-parallel: after the all-reduce of that slice / the all-gather of the operands.)
+        @seg("apply_fc", 1, ["bwd_head", "wg_dense"])
         def _():
             fc0, fc1 = self.fc_grad_range()
+            if self.fused_dense:
+                flat, df1, f1, dz = self.dense_operands or (T["t"]["flat"], T["df1"], T["t"]["f1"], T["dz"])
+                for name, pf, x_, dy_ in (("sun.fc2", self.fc2, f1, dz), ("sun.fc1", self.fc1, flat, df1)):
+                    o, n, shape = self.gs.offsets[name + ".kernel"]
+                    K.rmsprop_fc_fused(w[name + ".kernel"], self.gs.ms[o:o + n].view(shape), x_, dy_, pf, self.lr,
+                                       db=g[name + ".bias"], gscale=self._gscale)
+                    o, n, _ = self.gs.offsets[name + ".bias"]
+                    K.rmsprop(self.gs.flat[o:o + n], self.gs.grad[o:o + n], self.gs.ms[o:o + n], self.lr, gscale=self._gscale)
+                return
             if self.precise:      # BF16X3 keeps residual planes: plain update, then re-pack
                 K.rmsprop(self.gs.flat[fc0:fc1], self.gs.grad[fc0:fc1], self.gs.ms[fc0:fc1], self.lr, gscale=self._gscale)
                 self.fc1.repack(w["sun.fc1.kernel"])
@@ -805,8 +827,19 @@ class Trainer:
 
         return segs
 
-    FC_GRADS_READY, GRADS_READY = "bwd_head", "grads_ready"      # hook points of a data-parallel driver
+    GRADS_READY = "grads_ready"                                  # hook point of a data-parallel driver
     APPLY = ("apply_fc", "apply")                                # the optimizer segments
+
+    @property
+    def FC_GRADS_READY(self):
+        """Segment after which the Dense slice of the gradients (fused_dense: the operands of its contraction) exists."""
+        return "bwd_head" if self.fused_dense or self.dense_wgrad_external else "wg_dense"
+
+    def _skip(self, update):
+        """Segments an `update` / gradient-only step leaves out."""
+        if not update:
+            return self.APPLY
+        return ("wg_dense",) if self.fused_dense else ()
 
     def _take_wgrads(self):
         return self._wjobs.pop(torch.cuda.current_stream().cuda_stream, [])
@@ -849,6 +882,8 @@ class Trainer:
         return self._events[name]
 
     def _bind(self, ldr, hdr_t, sunpose_gt):
+        if self.on_bind is not None:
+            self.on_bind(ldr.shape[0])
         self._norm_state(ldr.shape[0])            # pointer tables are uploaded here, never inside a graph capture
         if self.use_resconv:
             self._rc_state(ldr.shape[0])
@@ -866,7 +901,8 @@ class Trainer:
         """ldr / hdr_t [B,H,W,3] BGR (train.py:386-387 rgb2bgr already applied), sunpose_gt [B,H*W].
         Returns the dict generator_in_step returns (train.py:349) - losses are in self.losses (device)."""
         self._bind(ldr, hdr_t, sunpose_gt)
-        self._execute([n for n, *_ in self._segs if update or n not in self.APPLY])
+        skip = self._skip(update)
+        self._execute([n for n, *_ in self._segs if n not in skip])
         return self._outputs()
 
     def test_step(self, ldr, hdr_t, sunpose_gt):
@@ -941,8 +977,8 @@ class Trainer:
     def replay(self, update=True, hooks=None, pre_hooks=None):
         """One step from the captured graphs; hooks / pre_hooks: {segment name: callable run on that segment's stream
         after / before it}."""
-        names = None if update else [n for n, *_ in self._segs if n not in self.APPLY]
-        self._execute(names, graphs=self._graphs, hooks=hooks, pre_hooks=pre_hooks)
+        skip = self._skip(update)
+        self._execute([n for n, *_ in self._segs if n not in skip], graphs=self._graphs, hooks=hooks, pre_hooks=pre_hooks)
 
     def loss_dict(self):
         """Host copy of the loss terms with the reference's names (train.py:480-489) - synchronises."""
@@ -992,9 +1028,10 @@ class SunPoseTrainer(Trainer):
         if dog_weight != 0.0:
             K.dog_loss(pred, gt_img, float(dog_weight), self.losses[1:2], dcmf.view(B, self.h, self.w, 1))
         dz = K.softmax_bwd(t["cmf"], dcmf, t["z"])
-        K.fc_wgrad(t["f1"], dz, g["sun.fc2.kernel"], g["sun.fc2.bias"])
+        fc_wgrad = K.fc_wgrad if self.precise else K.fc_wgrad_bf16
+        fc_wgrad(t["f1"], dz, g["sun.fc2.kernel"], g["sun.fc2.bias"])
         df1 = K.fc_finalize(K.fc_dgrad(dz, self.fc2, cp), None, relu=False, mask_src=t["f1"])
-        K.fc_wgrad(t["flat"], df1, g["sun.fc1.kernel"], g["sun.fc1.bias"])
+        fc_wgrad(t["flat"], df1, g["sun.fc1.kernel"], g["sun.fc1.bias"])
         dP = K.fc_finalize(K.fc_dgrad(df1, self.fc1, cp)).reshape(B, self.h // 8, self.w // 8, 128)
         for l in (3, 2, 1):
             n = "sun.sunlayer%d" % l

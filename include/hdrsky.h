@@ -293,6 +293,18 @@ int hdrsky_rmsprop(float* w, const float* g, float* ms, size_t n, float lr, floa
  * packed_hi [K/8][N][8], natural_hi [K][N] or NULL) - HDRSKY_BF16 mode only (no residual planes). */
 int hdrsky_rmsprop_fc(float* w, const float* g, float* ms, int K, int N, float lr, float rho, float eps, float gscale,
                       void* packed_hi, void* natural_hi, void* stream);
+/* The Dense weight gradient on the matrix cores: dW[K][N] (+)= x^T dy with both operands rounded to bf16 (fp32
+ * accumulation; HDRSKY_BF16's contract), db (+)= fp32 column sums of dy.  x [M][ldx >= K], dy [M][ldy >= N] (row strides
+ * in floats, multiples of 4, 16-byte aligned bases), any M >= 1; K and N multiples of 128.  Replaces tf.gradients through
+ * Keras Dense (sunpose_net.py:48-51,65-68) for the materialised gradient (all-reduce, inspection). */
+int hdrsky_fc_wgrad_bf16(const float* x, int ldx, const float* dy, int ldy, int M, int K, int N, int accumulate, float* dw,
+                         float* db, void* stream);
+/* hdrsky_rmsprop_fc with the gradient g = gscale * x^T dy recomputed tile by tile inside the update (operands as for
+ * hdrsky_fc_wgrad_bf16) instead of read from memory: w, ms and the bf16 images are updated in place, the weight gradient is
+ * never written.  db (nullable) receives the bias gradient (unscaled) for a following hdrsky_rmsprop of the bias. */
+int hdrsky_rmsprop_fc_fused(float* w, float* ms, const float* x, int ldx, const float* dy, int ldy, int M, int K, int N,
+                            float lr, float rho, float eps, float gscale, void* packed_hi, void* natural_hi, float* db,
+                            void* stream);
 /* tf.keras.optimizers.Adam (train_sun.py:191 / tf_utils.py:324; defaults beta 0.9 / 0.999, eps 1e-7) over a flat buffer:
  * m, v are the slots; lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t) is computed by the caller for step t; g is scaled by gscale. */
 int hdrsky_adam(float* w, const float* g, float* m, float* v, size_t n, float lr_t, float beta1, float beta2, float eps,

@@ -26,11 +26,12 @@ def _mods():
     return [importlib.import_module(PKG + "." + m) for m in ("params", "synth", "trainer", "kernels", "parallel")]
 
 
-def _make_trainer(world, dev):
+def _make_trainer(world, dev, bf16=False):
     P, synth, trainer, K, par = _mods()
     nets = [P.init_params(P.generator_spec(H, W), 0), P.init_params(P.sunpose_spec(H, W), 1),
             P.init_params(P.discriminator_spec(), 2), P.init_params(P.vgg_spec(), 3)]
-    return trainer.Trainer(*nets, device=dev, precise=True, compute=K.BF16X3, im_height=H, im_width=W, world_size=world)
+    return trainer.Trainer(*nets, device=dev, precise=not bf16, compute=K.BF16 if bf16 else K.BF16X3, im_height=H,
+                           im_width=W, world_size=world)
 
 
 def _shard(rank, dev):
@@ -40,19 +41,20 @@ def _shard(rank, dev):
     return [torch.from_numpy(b[k][sl]).to(dev).contiguous() for k in ("ldr", "hdr_t", "sunpose_gt")]
 
 
-def _worker(rank, port, out_dir, mode="allreduce"):
+def _worker(rank, port, out_dir, mode="allreduce", bf16=False):
     os.environ.update(RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     P, synth, trainer, K, par = _mods()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     r, world, _ = par.init_from_env(backend="gloo")
     assert (r, world) == (rank, 2)
-    tr = _make_trainer(2, dev)
+    tr = _make_trainer(2, dev, bf16)
     if rank == 1:
         tr.gs.flat.mul_(1.5)                                  # diverged replica: the broadcast must repair it
     par.broadcast_params_([tr.gs.flat, tr.ds.flat]); tr.repack()
     ex = par.GradientExchange(tr, device=dev, mode=mode)
     assert ex.active and ex.hooks and ex.pre_hooks and tr.dense_wgrad_external == (mode == "gather_dense")
+    assert tr.fused_dense == (bf16 and mode == "gather_dense")   # written-out Dense gradients whenever they travel
     tr.capture(*_shard(rank, dev))                            # warm-up inside must leave the weights untouched
     for _ in range(2):                                        # two optimizer steps on the same shard
         tr.replay(hooks=ex.hooks, pre_hooks=ex.pre_hooks)
@@ -129,6 +131,28 @@ def test_exchange_modes_agree_with_the_plain_allreduce(dev, tmp_path, mode, tol)
     rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
     print(mode, "update mismatch %.3g, rms slots %.3g" % (rel(got[0], ref[0]), rel(got[1], ref[1])))
     assert rel(got[0], ref[0]) < tol and rel(got[1], ref[1]) < tol
+
+
+def test_gather_dense_with_the_fused_dense_update(dev, tmp_path):
+    """HDRSKY_BF16 trainers: in gather_dense mode the Dense kernels' gradients are not even written - the optimizer launch
+    contracts the all-gathered rows (hdrsky_rmsprop_fc_fused, M = 2 replicas x batch).  Same update as the all-reduce of
+    the materialised bf16-operand gradients (hdrsky_fc_wgrad_bf16) up to fp32 summation order."""
+    outs = {}
+    for m in ("allreduce", "gather_dense"):
+        d = tmp_path / m
+        d.mkdir()
+        mp.spawn(_worker, args=(_free_port(), str(d), m, True), nprocs=2, join=True)
+        r0, r1 = (torch.load(os.path.join(str(d), "r%d.pt" % r)) for r in (0, 1))
+        t0 = _make_trainer(1, dev, True)
+        ng = t0.gs.ntrain
+        w0 = t0.gs.flat.cpu()[:ng]
+        del t0
+        assert torch.equal(r0["gs"][:ng], r1["gs"][:ng]), m
+        outs[m] = (r0["gs"][:ng] - w0, r0["gms"])
+    ref, got = outs["allreduce"], outs["gather_dense"]
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    print("fused gather_dense: update mismatch %.3g, rms slots %.3g" % (rel(got[0], ref[0]), rel(got[1], ref[1])))
+    assert rel(got[0], ref[0]) < 2e-3 and rel(got[1], ref[1]) < 2e-3
 
 
 def test_train_cli_two_ranks_one_card(dev, tmp_path):

@@ -260,6 +260,75 @@ def test_train_step_in_bench_mode_bf16(dev):
     assert cos > 0.98, cos
 
 
+def test_fc_wgrad_bf16_and_fused_update(dev):
+    """hdrsky_fc_wgrad_bf16: x^T dy with bf16-rounded operands and fp32 accumulation, any row count, row-strided operands;
+    hdrsky_rmsprop_fc_fused: the same update hdrsky_rmsprop_fc applies to that gradient, without writing it."""
+    K = pkg("kernels")
+    rng = np.random.default_rng(5)
+    bf = lambda t: t.to(torch.bfloat16).to(torch.float64)
+    Kd, N = 256, 384
+    for M in (1, 2, 31, 32, 33, 70):
+        wide = torch.from_numpy(rng.standard_normal((M, Kd + N + 8)).astype(np.float32)).to(dev)
+        x, dy = wide[:, 4:4 + Kd], wide[:, 4 + Kd:4 + Kd + N]          # column blocks of one buffer: strided rows
+        dw = torch.full((Kd, N), 7.0, device=dev); db = torch.full((N,), 7.0, device=dev)
+        K.fc_wgrad_bf16(x, dy, dw, db)
+        ref = bf(x).T @ bf(dy)
+        assert_close(dw, ref, 2e-6, "fc_wgrad_bf16 M=%d" % M)
+        assert_close(db, dy.double().sum(0), 2e-6, "fc_wgrad_bf16 bias M=%d" % M)
+        K.fc_wgrad_bf16(x, dy, dw, db, accumulate=True)
+        assert_close(dw, 2 * ref, 2e-6, "fc_wgrad_bf16 accumulate")
+        assert_close(db, 2 * dy.double().sum(0), 2e-6, "fc_wgrad_bf16 bias accumulate")
+    with pytest.raises(ValueError):
+        K.fc_wgrad_bf16(wide[:, 1:1 + Kd], dy, dw, db)                  # misaligned base
+    # fused update == materialise + hdrsky_rmsprop_fc
+    M = 48
+    x = torch.from_numpy(rng.standard_normal((M, Kd)).astype(np.float32)).to(dev)
+    dy = torch.from_numpy((rng.standard_normal((M, N)) * 0.1).astype(np.float32)).to(dev)
+    w0 = torch.from_numpy(rng.standard_normal((Kd, N)).astype(np.float32)).to(dev)
+    ms0 = torch.from_numpy(rng.uniform(0, 1e-2, (Kd, N)).astype(np.float32)).to(dev)
+    g = torch.empty_like(w0); gb = torch.empty(N, device=dev)
+    K.fc_wgrad_bf16(x, dy, g, gb)
+    wa, msa, pfa = w0.clone(), ms0.clone(), K.PackedFC(w0, precise=False)
+    K.rmsprop_fc(wa, g, msa, pfa, 1e-3, gscale=0.5)
+    wb, msb, pfb = w0.clone(), ms0.clone(), K.PackedFC(w0, precise=False)
+    gb2 = torch.empty(N, device=dev)
+    K.rmsprop_fc_fused(wb, msb, x, dy, pfb, 1e-3, db=gb2, gscale=0.5)
+    assert torch.equal(gb, gb2)
+    assert_close(wb, wa, 1e-7, "fused RMSprop: weights"); assert_close(msb, msa, 1e-6, "fused RMSprop: slots")
+    fresh = K.PackedFC(wb, precise=False)
+    assert torch.equal(fresh.pk_hi.view(torch.int16), pfb.pk_hi.view(torch.int16))
+    assert torch.equal(fresh.nat_hi.view(torch.int16), pfb.nat_hi.view(torch.int16))
+
+
+def test_fused_dense_step_equals_materialised_step(dev):
+    """Trainer(fused_dense=True) (the HDRSKY_BF16 default): two updating steps leave the same weights and RMSprop slots
+    as the trainer that writes the Dense gradients out and reads them back; the Dense kernel gradient buffers of the
+    fused trainer are untouched by an updating step and filled by step(update=False)."""
+    params, synth, trainer, K = pkg("params"), pkg("synth"), pkg("trainer"), pkg("kernels")
+    nets = [params.init_params(params.generator_spec(), 0), params.init_params(params.sunpose_spec(), 1),
+            params.init_params(params.discriminator_spec(), 2), params.init_params(params.vgg_spec(), 3)]
+    batch = synth.make_batch(3, seed=77)
+    ldr, hdr, gt = (torch.from_numpy(batch[k]).to(dev) for k in ("ldr", "hdr_t", "sunpose_gt"))
+    res = []
+    for fused in (True, False):
+        tr = trainer.Trainer(*nets, device=dev, precise=False, compute=K.BF16, fused_dense=fused)
+        assert tr.fused_dense == fused
+        for _ in range(2):
+            tr.step(ldr, hdr, gt, update=True)
+        gk = tr.gs.g["sun.fc1.kernel"]
+        if fused:
+            assert float(gk.abs().max()) == 0.0                         # never written on an updating step
+        res.append((tr.gs.flat.clone(), tr.gs.ms.clone(), [p.pk_hi.clone() for p in (tr.fc1, tr.fc2)]))
+        if fused:
+            tr.step(ldr, hdr, gt, update=False)
+            assert float(gk.abs().max()) > 0.0                          # a gradient-only step materialises it
+    (wa, ma, pa), (wb, mb, pb) = res
+    assert_close(wa, wb, 1e-6, "fused vs materialised Dense update: weights")
+    assert_close(ma, mb, 1e-5, "fused vs materialised Dense update: RMSprop slots")
+    for u, v in zip(pa, pb):
+        assert float((u.view(torch.int16) != v.view(torch.int16)).float().mean()) < 1e-4
+
+
 def test_bf16_step_fused_dense_optimizer(dev):
     """BF16 trainer: the Dense kernels are updated by hdrsky_rmsprop_fc, which also refreshes their bf16 MFMA images -
     same weights as the closed form and bit-identical images to a fresh hdrsky_fc_pack_weights of the result."""
@@ -267,7 +336,7 @@ def test_bf16_step_fused_dense_optimizer(dev):
     gen = params.init_params(params.generator_spec(), 0); sun = params.init_params(params.sunpose_spec(), 1)
     dis = params.init_params(params.discriminator_spec(), 2); vgg = params.init_params(params.vgg_spec(), 3)
     batch = synth.make_batch(2, seed=1234)
-    tr = trainer.Trainer(gen, sun, dis, vgg, device=dev, precise=False, compute=K.BF16)
+    tr = trainer.Trainer(gen, sun, dis, vgg, device=dev, precise=False, compute=K.BF16, fused_dense=False)
     ldr, hdr, gt = (torch.from_numpy(batch[k]).to(dev) for k in ("ldr", "hdr_t", "sunpose_gt"))
     w0 = tr.gs.flat[:tr.gs.ntrain].clone()
     tr.step(ldr, hdr, gt, update=True)
@@ -342,7 +411,8 @@ def test_step_is_repeatable_under_stream_concurrency(dev, mode):
         tr.step(ldr, hdr, gt, update=False)
         torch.cuda.synchronize()
         T = tr._T
-        ref = T["t"]["flat"].double().t() @ T["df1"].double()
+        opd = (lambda t: t.to(torch.bfloat16).double()) if mode == "BF16" else (lambda t: t.double())   # hdrsky_fc_wgrad_bf16
+        ref = opd(T["t"]["flat"]).t() @ opd(T["df1"])
         got = tr.gs.g["sun.fc1.kernel"]
         assert float((got.double() - ref).abs().max()) <= 1e-6 * float(ref.abs().max()), it
         snap = {"gs": tr.gs.grad.clone(), "ds": tr.ds.grad.clone(), "y": T["y_lin"].clone(), "losses": tr.losses.clone()}
