@@ -106,8 +106,9 @@ def dominant_kernel_roofline(torch, K, pw, batch, h, w, iters=200):
 
 
 def hbm_rooflines(torch, K, batch=32, iters=20):
-    """The HBM-bound kernels of the step timed live (their own tensors, hipGraph replay, HIP events): the fused Dense
-    RMSprop + bf16 re-pack, the fc1 forward weight stream and the fc1 weight-gradient write.  achieved = algorithmic
+    """The HBM-bound kernels of the step timed live (their own tensors, hipGraph replay, HIP events): the Dense RMSprop that
+    recomputes its gradient (+ bf16 re-pack), the same from a materialised gradient, the fc1 forward weight stream and
+    the fc1 weight-gradient write.  achieved = algorithmic
     bytes per launch / average launch time, against the 8 TB/s HBM3E peak."""
     dev = torch.device("cuda", torch.cuda.current_device())
     Kd, N = 8192, 4096
@@ -118,12 +119,15 @@ def hbm_rooflines(torch, K, batch=32, iters=20):
     dy = torch.randn(batch, N, device=dev)
     db = torch.zeros(N, device=dev)
     rows = [
-        ("rmsprop_fc_kernel (fc1 8192x4096: w, g, ms read; w, ms, two bf16 images written)", 24 * Kd * N,
-         lambda: K.rmsprop_fc(w, g, ms, pf, 1e-4)),
+        ("fc_xtdy_kernel<fused> (fc1 8192x4096 RMSprop with its gradient recomputed from M=%d rows: w, ms read; w, ms, two "
+         "bf16 images written)" % batch, 20 * Kd * N + 4 * batch * (Kd + N),
+         lambda: K.rmsprop_fc_fused(w, ms, x, dy, pf, 1e-4, db=db)),
+        ("rmsprop_fc_kernel (the same update from a materialised gradient - data-parallel all-reduce modes: w, g, ms "
+         "read; w, ms, two bf16 images written)", 24 * Kd * N, lambda: K.rmsprop_fc(w, g, ms, pf, 1e-4)),
         ("fc_mfma_kernel (fc1 forward, M=%d: bf16 weights streamed once)" % batch, 2 * Kd * N + 4 * batch * (Kd + 4 * N),
          lambda: K.fc_fwd(x, pf, K.BF16)),
-        ("fc_wgrad_kernel (fc1, M=%d: fp32 gradient written once)" % batch, 4 * Kd * N + 4 * batch * (Kd + N),
-         lambda: K.fc_wgrad(x, dy, g, db)),
+        ("fc_xtdy_kernel<store> (fc1 weight gradient, M=%d: fp32 gradient written once)" % batch,
+         4 * Kd * N + 4 * batch * (Kd + N), lambda: K.fc_wgrad_bf16(x, dy, g, db)),
     ]
     out = []
     for name, nbytes, fn in rows:

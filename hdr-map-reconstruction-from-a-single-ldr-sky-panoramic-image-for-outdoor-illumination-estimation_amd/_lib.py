@@ -32,7 +32,8 @@ class WgradJob(ctypes.Structure):
     """Mirror of ``hdrsky_wgrad_job`` (include/hdrsky.h)."""
     _fields_ = [("desc", ConvDesc)] + [(n, c_void_p) for n in
                                        ("x", "dy", "in_scale", "in_shift", "in_part", "in_gamma", "in_beta", "dw", "db")] + \
-               [("x_bf16", ctypes.c_int32), ("dy_bf16", ctypes.c_int32)]
+               [("x_bf16", ctypes.c_int32), ("dy_bf16", ctypes.c_int32), ("da_offs", c_void_p), ("da_ksize", ctypes.c_int32),
+                ("da_C", ctypes.c_int32)]
 
 
 class ResconvArgs(ctypes.Structure):
@@ -119,9 +120,10 @@ SIGNATURES = {
     "hdrsky_fc_wgrad": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, P]),
     "hdrsky_rmsprop": (c_int, [P, P, P, c_size_t, c_float, c_float, c_float, c_float, P]),
     "hdrsky_rmsprop_fc": (c_int, [P, P, P, c_int, c_int, c_float, c_float, c_float, c_float, P, P, P]),
-    "hdrsky_fc_wgrad_bf16": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
+    "hdrsky_fc_wgrad_bf16": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P]),
+    "hdrsky_fc_xtdy_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "hdrsky_rmsprop_fc_fused": (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float,
-                                        P, P, P, P]),
+                                        P, P, P, P, P]),
     "hdrsky_adam": (c_int, [P, P, P, P, c_size_t, c_float, c_float, c_float, c_float, c_float, P]),
     "hdrsky_resconv_supported": (c_int, [c_int] * 6),
     "hdrsky_resconv": (c_int, [ctypes.POINTER(ResconvArgs), P]),

@@ -65,3 +65,32 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
   return v;
 }
+
+// one bilinear sample position of the reference (distortion_aware_ops.py:62-106), all in float32
+struct Tap4 {
+  int y0, y1, x0, x1;      // corner indices in PADDED coordinates (x wrapped, y clamped)
+  float w0, w1, w2, w3;
+};
+
+__host__ __device__ __forceinline__ Tap4 da_tap(float base_y, float base_x, float off_y, float off_x, int in_h, int in_w) {
+  float y = base_y + off_y;
+  float x = base_x + off_x;
+  y = y < 0.f ? 0.f : y; y = y > (float)(in_h - 1) ? (float)(in_h - 1) : y;
+  x = x < 0.f ? x + (float)in_w : x;
+  x = x > (float)(in_w - 1) ? x - (float)in_w : x;
+  int y0 = (int)floorf(y), x0 = (int)floorf(x);
+  int y1 = y0 + 1, x1 = x0 + 1;
+  y0 = y0 < 0 ? 0 : (y0 > in_h - 1 ? in_h - 1 : y0);
+  y1 = y1 < 0 ? 0 : (y1 > in_h - 1 ? in_h - 1 : y1);
+  const int x0w = x0, x1w = x1;  // unwrapped: used for the weights (:89, :100-106)
+  x0 = x0 < 0 ? x0 + in_w : x0; x1 = x1 < 0 ? x1 + in_w : x1;
+  x0 = x0 > in_w - 1 ? x0 - in_w : x0; x1 = x1 > in_w - 1 ? x1 - in_w : x1;
+  Tap4 t;
+  t.y0 = y0; t.y1 = y1; t.x0 = x0; t.x1 = x1;
+  const float fy0 = (float)y0, fy1 = (float)y1, fx0 = (float)x0w, fx1 = (float)x1w;
+  t.w0 = (fy1 - y) * (fx1 - x);
+  t.w1 = (fy1 - y) * (x - fx0);
+  t.w2 = (y - fy0) * (fx1 - x);
+  t.w3 = (y - fy0) * (x - fx0);
+  return t;
+}

@@ -42,6 +42,11 @@ struct WgradArgs {
   int x_bf16, dy_bf16;           // operands stored as bf16 (the sample-resident conv chain) instead of fp32
   float* ws;                     // deterministic mode: this job's workspace (per (chunk, block) slabs [taps][CB][OB], then
   float* ws_db;                  //   per (chunk, co block) bias slabs [OB]); null = fp32 atomics straight into dw / db
+  // distortion-aware layer (UP == 2): the job is a 1x1 weight gradient over k*k*da_C VIRTUAL input channels - channel
+  // (tap, c) of pixel (oy, ox) is the bilinear sample of x[.., c] the layer's gather takes for that tap
+  // (distortion_aware_ops.py:62-113), recomputed while staging: the [B,H,W,k*k*C] operand never exists in memory
+  const float* da_offs;          // [H][k*k][2] row offsets (hdrsky_da_offsets)
+  int da_k, da_C;
 };
 
 constexpr int WG_MAXJ = 12;      // jobs per launch (the argument block must stay below 4 KB)
@@ -74,8 +79,9 @@ __device__ __forceinline__ uint2 lds_tr(const unsigned char* p) {
 // Geometry (template): NW waves = NTG tap groups x CS splits of the ci fragments x OS splits of the co fragments;
 // the staging phase (global -> registers -> transform -> bf16 -> LDS) is issue-bound VALU work shared by all
 // NW*64 threads.  XR: rows of the X' register prefetch array (items per thread; UP: 4 source pixels per item).
-// UP: the forward conv resized its input 2x (resize-deconv): an X' item is interpolated from four source pixels.
-template <int TPW, int CBF, int OBF, int TW, bool NARROW, bool PRECISE, bool UP, int NW, int CS, int OS, int XR, int BM>
+// UP = 1: the forward conv resized its input 2x (resize-deconv): an X' item is interpolated from four source pixels.
+// UP = 2: distortion-aware layer: an X' item (pixel, 8 virtual channels of one tap) is the layer's bilinear sample.
+template <int TPW, int CBF, int OBF, int TW, bool NARROW, bool PRECISE, int UP, int NW, int CS, int OS, int XR, int BM>
 __global__ void __launch_bounds__(NW * 64) conv_wgrad_kernel(const MultiArgs m) {
   constexpr int NT = NW * 64;
   constexpr int CB = CBF * 16, OB = OBF * 16;
@@ -141,6 +147,7 @@ __global__ void __launch_bounds__(NW * 64) conv_wgrad_kernel(const MultiArgs m) 
   // tile t and are transformed + written to LDS at the top of the next iteration.
   float xr[XR][8];   // X' items of this thread; UP: the four source pixels of its one item
   float yr[YMAX][8];
+  float wr[UP == 2 ? XI : 1][4];   // UP == 2: bilinear weights of the four source pixels
 
   // ---- per-sample operand transform tables for every sample this workgroup touches ----------------------------
   {
@@ -182,7 +189,24 @@ __global__ void __launch_bounds__(NW * 64) conv_wgrad_kernel(const MultiArgs m) 
       const float* tsc = sTab + (b - bfirst) * 2 * CB;
       const float* tsh = tsc + CB;
       __syncthreads();  // previous tile fully consumed (first pass: transform tables visible)
-      if (UP) {
+      if (UP == 2) {
+#pragma unroll
+        for (int it = 0; it < XI; ++it) {
+          const int i = it * NT + tid;
+          if (i < nitems) {
+            const int px = i / NQX, qc = i % NQX;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)      // corners outside the image / pixels outside the map carry weight 0
+              v[j] = (xr[(it * 4 + 0) % XR][j] * wr[it][0] + xr[(it * 4 + 1) % XR][j] * wr[it][1]) +
+                     (xr[(it * 4 + 2) % XR][j] * wr[it][2] + xr[(it * 4 + 3) % XR][j] * wr[it][3]);
+            uint4 hi, lo;
+            pack8<PRECISE>(v, hi, lo);
+            *reinterpret_cast<uint4*>(sX + (size_t)px * a.RX + qc * 16) = hi;
+            if (PRECISE) *reinterpret_cast<uint4*>(sXl + (size_t)px * a.RX + qc * 16) = lo;
+          }
+        }
+      } else if (UP == 1) {
 #pragma unroll
         for (int it = 0; it < XI; ++it) {
           const int i = it * NT + tid;
@@ -260,7 +284,40 @@ __global__ void __launch_bounds__(NW * 64) conv_wgrad_kernel(const MultiArgs m) 
       const int tx = ntx, ty = nty, b = nb;
       const int oy0 = ty * TH, ox0 = tx * TW;
       const int iy0 = oy0 * a.stride - a.pad_t, ix0 = ox0 * a.stride - a.pad_l;
-      if (UP) {
+      if (UP == 2) {
+        const int k = a.da_k, k2 = k * k, pad = (k - 1) / 2, in_h = a.H + k - 1, in_w = a.W + k - 1;
+#pragma unroll
+        for (int it = 0; it < XI; ++it) {
+          const int i = it * NT + tid;
+          if (i < nitems) {
+            const int px = i / NQX, qc = i % NQX;
+            const int hy = (int)(((unsigned)px * (unsigned)a.wt_magic) >> 24);
+            const int hx = px - hy * a.WT;
+            const int oy = iy0 + hy, ox = ix0 + hx;               // 1x1, stride 1: tile pixel = output pixel
+            const bool live = oy < a.H && ox < a.W;
+            const int vq = cb0 + qc * 8;                            // first virtual channel of the item
+            const int tap = vq / a.da_C, c0 = vq - tap * a.da_C;
+            const int tky = tap / k, tkx = tap - tky * k;
+            const int oyc = live ? oy : 0;
+            const float off_y = a.da_offs[(oyc * k2 + tap) * 2], off_x = a.da_offs[(oyc * k2 + tap) * 2 + 1];
+            const Tap4 sp4 = da_tap((float)(oyc + tky), (float)((live ? ox : 0) + tkx), off_y, off_x, in_h, in_w);
+            const int ys[4] = {sp4.y0, sp4.y0, sp4.y1, sp4.y1}, xs[4] = {sp4.x0, sp4.x1, sp4.x0, sp4.x1};
+            const float ws4[4] = {sp4.w0, sp4.w1, sp4.w2, sp4.w3};
+            const float* xb = a.x + (size_t)b * a.H * a.W * a.da_C + c0;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+              const int yy = ys[kk] - pad, xx = xs[kk] - pad;      // back to un-padded coordinates; border = zeros
+              const bool in = live && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+              const float* src = xb + (size_t)(in ? yy * a.W + xx : 0) * a.da_C;
+              const float4 va = *reinterpret_cast<const float4*>(src);
+              const float4 vb = *reinterpret_cast<const float4*>(src + 4);
+              float* d = xr[(it * 4 + kk) % XR];
+              d[0] = va.x; d[1] = va.y; d[2] = va.z; d[3] = va.w; d[4] = vb.x; d[5] = vb.y; d[6] = vb.z; d[7] = vb.w;
+              wr[it][kk] = in ? ws4[kk] : 0.f;
+            }
+          }
+        }
+      } else if (UP == 1) {
 #pragma unroll
         for (int it = 0; it < XI; ++it) {
           const int i = it * NT + tid;
@@ -494,14 +551,14 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const MultiArgs m, in
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------
-struct Geo { int tpw, cbf, obf, tw, nw, cs, os, xr, bm; bool narrow, precise, up; };
+struct Geo { int tpw, cbf, obf, tw, nw, cs, os, xr, bm; bool narrow, precise; int up; };
 
-template <int TPW, int CBF, int OBF, int TW, bool NARROW, bool PRECISE, bool UP, int NW, int CS, int OS, int XR, int BM>
+template <int TPW, int CBF, int OBF, int TW, bool NARROW, bool PRECISE, int UP, int NW, int CS, int OS, int XR, int BM>
 struct WgradVariant {
   static constexpr int NT = NW * 64, CB = CBF * 16, OB = OBF * 16, TH = BM / TW, NTG = NW / (CS * OS);
   // fills the geometry-dependent fields of one job; returns the LDS bytes it needs, or a negative error
   static int prepare(WgradArgs& a, int wg_target) {
-    if (UP != (a.upsample == 2)) return HDRSKY_EUNSUPPORTED;
+    if (UP != (a.da_k > 0 ? 2 : (a.upsample == 2 ? 1 : 0))) return HDRSKY_EUNSUPPORTED;
     a.tiles_x = cdiv(a.Wo, TW);
     a.tiles_y = cdiv(a.Ho, TH);
     a.ntiles = a.B * a.tiles_x * a.tiles_y;
@@ -567,28 +624,38 @@ int with_variant(const Geo& g, F&& fn) {
   HDRSKY_WG_(TPW_, CBF_, OBF_, NARROW_, UP_, NW_, CS_, OS_, XR_, 128, 32)                                            \
   HDRSKY_WG_(TPW_, CBF_, OBF_, NARROW_, UP_, NW_, CS_, OS_, XR_, 128, 16)
   // 16 waves, 32x32-channel dW blocks (a layer on its own)
-  HDRSKY_WG(3, 2, 2, false, false, 16, 2, 2, 3) HDRSKY_WG(3, 2, 2, false, true, 16, 2, 2, 4)
-  HDRSKY_WG(4, 2, 2, false, false, 16, 2, 2, 3) HDRSKY_WG(7, 2, 1, false, false, 16, 2, 1, 3)
-  HDRSKY_WG(2, 1, 4, true, false, 16, 1, 2, 3) HDRSKY_WG(2, 1, 2, true, false, 16, 1, 2, 3)
-  HDRSKY_WG(7, 1, 2, true, false, 16, 1, 2, 3)
+  HDRSKY_WG(3, 2, 2, false, 0, 16, 2, 2, 3) HDRSKY_WG(3, 2, 2, false, 1, 16, 2, 2, 4)
+  HDRSKY_WG(4, 2, 2, false, 0, 16, 2, 2, 3) HDRSKY_WG(7, 2, 1, false, 0, 16, 2, 1, 3)
+  HDRSKY_WG(2, 1, 4, true, 0, 16, 1, 2, 3) HDRSKY_WG(2, 1, 2, true, 0, 16, 1, 2, 3)
+  HDRSKY_WG(7, 1, 2, true, 0, 16, 1, 2, 3)
   // 64-pixel tiles for outputs of at most four 16-pixel rows (the 4x16 maps of the discriminator / sun-radiance stacks)
-  HDRSKY_WG_(4, 2, 2, false, false, 16, 2, 2, 3, 64, 16) HDRSKY_WG_(3, 2, 2, false, false, 16, 2, 2, 3, 64, 16)
+  HDRSKY_WG_(4, 2, 2, false, 0, 16, 2, 2, 3, 64, 16) HDRSKY_WG_(3, 2, 2, false, 0, 16, 2, 2, 3, 64, 16)
   // 8 waves, 64x64-channel dW blocks (several wide layers in one launch)
-  HDRSKY_WG(3, 4, 4, false, false, 8, 2, 1, 4)
+  HDRSKY_WG(3, 4, 4, false, 0, 8, 2, 1, 4)
+  // distortion-aware layers (1x1 over k*k*C virtual channels, every wave on the one tap): 64x64 blocks when C % 64 == 0,
+  // else 32x32
+  HDRSKY_WG(1, 4, 4, false, 2, 8, 4, 2, 8) HDRSKY_WG(1, 2, 2, false, 2, 4, 2, 2, 8)
 #undef HDRSKY_WG
 #undef HDRSKY_WG_
   return HDRSKY_EUNSUPPORTED;
 }
 
 // Geometry for one layer: `big` = 64x64-channel blocks (grouped launches of wide stride-1 layers).
-static Geo choose_geo(const hdrsky_conv_desc* d, bool big) {
+static Geo choose_geo(const hdrsky_wgrad_job& job, bool big) {
+  const hdrsky_conv_desc* d = &job.desc;
   Geo g{};
   const int ntaps = d->KH * d->KW;
   g.narrow = d->Cin <= 8;
   g.precise = d->compute == HDRSKY_BF16X3;
-  g.up = d->upsample == 2;
+  g.up = d->upsample == 2 ? 1 : 0;
   g.tw = d->Wo >= 32 ? 32 : 16;
   g.bm = 128;
+  if (job.da_ksize > 0) {     // distortion-aware layer: 1x1 over k*k*C virtual channels
+    g.up = 2; g.tpw = 1; g.narrow = false;
+    if (job.da_C % 64 == 0) { g.nw = 8; g.cs = 4; g.os = 2; g.cbf = 4; g.obf = 4; }
+    else { g.nw = 4; g.cs = 2; g.os = 2; g.cbf = 2; g.obf = 2; }
+    return g;
+  }
   if (big) {
     g.nw = 8; g.cs = 2; g.os = 1; g.cbf = 4; g.obf = 4; g.tpw = ntaps <= 12 ? 3 : 4;
     return g;
@@ -603,8 +670,9 @@ static Geo choose_geo(const hdrsky_conv_desc* d, bool big) {
   return g;
 }
 
-static bool can_go_big(const hdrsky_conv_desc* d) {
-  return d->Cin >= 64 && d->Cout >= 64 && (d->Cin % 64) == 0 && d->stride == 1 && d->upsample == 1 && d->KH * d->KW <= 9;
+static bool can_go_big(const hdrsky_wgrad_job& job) {
+  const hdrsky_conv_desc* d = &job.desc;
+  return job.da_ksize == 0 && d->Cin >= 64 && d->Cout >= 64 && (d->Cin % 64) == 0 && d->stride == 1 && d->upsample == 1 && d->KH * d->KW <= 9;
 }
 
 static int fill_job(WgradArgs& a, const hdrsky_wgrad_job& j) {
@@ -627,6 +695,14 @@ static int fill_job(WgradArgs& a, const hdrsky_wgrad_job& j) {
   a.x_bf16 = j.x_bf16; a.dy_bf16 = j.dy_bf16;
   if (j.x_bf16 && (narrow || d->upsample != 1 || d->in_mode != HDRSKY_IN_NONE || d->in_slope != 1.f)) return HDRSKY_EUNSUPPORTED;
   if (j.dy_bf16 && (d->Cout & 7) != 0) return HDRSKY_EUNSUPPORTED;
+  if (j.da_ksize > 0) {
+    // desc describes the 1x1 weight gradient over the virtual channels; x is the layer's real input [B,H,W,da_C] fp32
+    const int k = j.da_ksize;
+    if (!j.da_offs || (k & 1) == 0 || k > 7 || j.da_C <= 0 || (j.da_C % 32) != 0 || d->Cin != k * k * j.da_C) return HDRSKY_EINVAL;
+    if (d->KH != 1 || d->KW != 1 || d->stride != 1 || d->upsample != 1 || d->H != d->Ho || d->W != d->Wo) return HDRSKY_EINVAL;
+    if (d->in_mode != HDRSKY_IN_NONE || d->in_slope != 1.f || j.x_bf16) return HDRSKY_EUNSUPPORTED;
+    a.da_offs = j.da_offs; a.da_k = k; a.da_C = j.da_C;
+  }
   return HDRSKY_OK;
 }
 
@@ -650,11 +726,11 @@ static int wgrad_multi_impl(const hdrsky_wgrad_job* jobs, int njobs, float* ws, 
   if (const char* e = getenv("HDRSKY_WGRAD")) sscanf(e, "%d,%d", &wg_hook, &force_small);   // tuning hook
   // wide stride-1 layers use 64x64-channel blocks when at least three of them share a launch
   int nwide = 0;
-  for (int i = 0; i < njobs; ++i) nwide += can_go_big(&jobs[i].desc) ? 1 : 0;
+  for (int i = 0; i < njobs; ++i) nwide += can_go_big(jobs[i]) ? 1 : 0;
   const bool use_big = nwide >= 3 && !force_small;
   Geo geo[256];
   bool done[256];
-  for (int i = 0; i < njobs; ++i) { geo[i] = choose_geo(&jobs[i].desc, use_big && can_go_big(&jobs[i].desc)); done[i] = false; }
+  for (int i = 0; i < njobs; ++i) { geo[i] = choose_geo(jobs[i], use_big && can_go_big(jobs[i])); done[i] = false; }
   for (int i = 0; i < njobs; ++i) {
     if (done[i]) continue;
     int members[256], nm = 0;

@@ -192,6 +192,24 @@ def conv2d_wgrad(x, dy, KH, KW, stride=1, same=True, upsample=1, xf: Optional[In
     return dw, db
 
 
+def da_wgrad_job(x, dy, ksize, offs, dw, db=None, compute=BF16):
+    """conv2d_wgrad_multi entry for a distortion-aware layer (distortion_aware_ops.conv2d, kernel [k*k*C, F]): dw [k*k*C, F]
+    += G^T dY with the gathered operand G recomputed inside the launch (never in memory).  x [B,H,W,C] fp32, C % 32 == 0."""
+    _f32(x); _f32(dy); _f32(offs)
+    B, H, W, C = x.shape
+    F = dy.shape[-1]
+    k2 = ksize * ksize
+    if tuple(dy.shape) != (B, H, W, F) or C % 32 or tuple(offs.shape) != (H, k2, 2):
+        raise ValueError("da_wgrad_job: x %s, dy %s, offs %s" % (tuple(x.shape), tuple(dy.shape), tuple(offs.shape)))
+    d = conv_desc(B, H, W, k2 * C, F, 1, 1, 1, True, 1)
+    d.compute = compute
+    tabs = _xf_args(d, None, B, H, W, k2 * C)
+    _f32(dw, k2 * C, F)
+    if db is not None:
+        _f32(db, F)
+    return (d, x, dy, tabs, dw, db, (offs, ksize, C))
+
+
 def wgrad_job(x, dy, KH, KW, dw, db=None, stride=1, same=True, upsample=1, xf: Optional[InXf] = None, compute=BF16):
     """One entry for conv2d_wgrad_multi: dw [KH,KW,Cin,Cout] (+= ; must hold valid values, e.g. zeros), db [Cout] or None.
     x / dy may be bf16 tensors (the final activations / gradients of the sample-resident conv chain; no operand transform).
@@ -221,8 +239,12 @@ def conv2d_wgrad_multi(jobs, deterministic=True):
     if not jobs:
         return
     arr = (L.WgradJob * len(jobs))()
-    for i, (d, x, dy, tabs, dw, db) in enumerate(jobs):
+    for i, job in enumerate(jobs):
+        d, x, dy, tabs, dw, db = job[:6]
         j = arr[i]
+        if len(job) > 6:
+            offs, j.da_ksize, j.da_C = job[6]
+            j.da_offs = _p(offs)
         j.desc = d
         j.x, j.dy, j.dw, j.db = _p(x), _p(dy), _p(dw), _p(db)
         j.in_scale, j.in_shift, j.in_part, j.in_gamma, j.in_beta = [_p(t) for t in tabs]
@@ -719,6 +741,13 @@ def _rows2d(t, name):
     return _p(t), t.stride(0)
 
 
+def _xtdy_ws(M, Kd, N, device):
+    n = L.load().hdrsky_fc_xtdy_ws_bytes(M, Kd, N)
+    if n == 0:
+        raise ValueError("fc x^T dy: bad shape M=%d K=%d N=%d" % (M, Kd, N))
+    return torch.empty(n, dtype=torch.uint8, device=device)
+
+
 def fc_wgrad_bf16(x, dy, dw, db, accumulate=False):
     """Dense weight / bias gradient on the matrix cores (bf16 operands, fp32 accumulation) - any number of rows."""
     (M, Kd), N = x.shape, dy.shape[1]
@@ -726,7 +755,8 @@ def fc_wgrad_bf16(x, dy, dw, db, accumulate=False):
     px, ldx = _rows2d(x, "fc_wgrad_bf16 x"); pd, ldy = _rows2d(dy, "fc_wgrad_bf16 dy")
     if dy.shape[0] != M:
         raise ValueError("fc_wgrad_bf16: x and dy disagree on the number of rows")
-    L.check(L.load().hdrsky_fc_wgrad_bf16(px, ldx, pd, ldy, M, Kd, N, int(accumulate), _p(dw), _p(db), _stream()),
+    ws = _xtdy_ws(M, Kd, N, x.device)
+    L.check(L.load().hdrsky_fc_wgrad_bf16(px, ldx, pd, ldy, M, Kd, N, int(accumulate), _p(dw), _p(db), _p(ws), _stream()),
             "fc_wgrad_bf16")
 
 
@@ -738,8 +768,9 @@ def rmsprop_fc_fused(w, ms, x, dy, pf, lr, db=None, rho=0.9, eps=1e-7, gscale=1.
     if pf.pk_lo is not None or (pf.K, pf.N) != (Kd, N) or dy.shape[0] != M:
         raise ValueError("rmsprop_fc_fused: BF16 images of the same kernel and matching operand rows only")
     px, ldx = _rows2d(x, "rmsprop_fc_fused x"); pd, ldy = _rows2d(dy, "rmsprop_fc_fused dy")
+    ws = _xtdy_ws(M, Kd, N, x.device)
     L.check(L.load().hdrsky_rmsprop_fc_fused(_p(w), _p(ms), px, ldx, pd, ldy, M, Kd, N, lr, rho, eps, gscale, _p(pf.pk_hi),
-                                             _p(pf.nat_hi), _p(db), _stream()), "rmsprop_fc_fused")
+                                             _p(pf.nat_hi), _p(db), _p(ws), _stream()), "rmsprop_fc_fused")
 
 
 def rmsprop(w, g, ms, lr, rho=0.9, eps=1e-7, gscale=1.0):
@@ -991,7 +1022,7 @@ def da_conv2d_dgrad(dy, pwT: PackedConv, table, ksize, compute=BF16):
 
 
 def da_conv2d_bwd(x, dy, kernel, offs, ksize, compute=BF16, want_dx=True, pwT=None, dw=None, db=None, table=None, pwT3=None):
-    """Gradients of y = da_conv2d(x; kernel [k*k*C, F], bias): returns (dx or None, dkernel [k*k*C, F], dbias [F]).
+    """Gradients of y = da_conv2d(x; kernel [k*k*C, F], bias), C % 32 == 0: returns (dx or None, dkernel [k*k*C, F], dbias [F]).
     table (da_transpose_table) [+ pwT3 = PackedConv(kernel.view(k,k,C,F), transpose_flip=True)]: dx by the deterministic
     gather-form data gradient (hdrsky_da_conv2d_dgrad).  Without a table: dG = dY W^T as a 1x1 conv (pwT =
     PackedConv(kernel.view(1,1,k*k*C,F), transpose_flip=True)) + bilinear scatter with fp32 atomics.
@@ -1000,9 +1031,13 @@ def da_conv2d_bwd(x, dy, kernel, offs, ksize, compute=BF16, want_dx=True, pwT=No
     F = dy.shape[-1]
     k2 = ksize * ksize
     _f32(dy, B, H, W, F); _f32(kernel, k2 * C, F)
-    G = da_gather(x, offs, ksize)
-    dw4 = dw.view(1, 1, k2 * C, F) if dw is not None else None
-    dw4, db = conv2d_wgrad(G, dy, 1, 1, compute=compute, dw=dw4, db=db)            # [1,1,k2*C,F]
+    # dW = G^T dY with the gather recomputed inside the weight-gradient launch (hdrsky_wgrad_job.da_*): G never exists
+    if dw is None:
+        dw = zero_(torch.empty((k2 * C, F), dtype=torch.float32, device=x.device))
+    if db is None:
+        db = zero_(torch.empty((F,), dtype=torch.float32, device=x.device))
+    conv2d_wgrad_multi([da_wgrad_job(x, dy, ksize, offs, dw, db, compute)])
+    dw4 = dw
     dx = None
     if want_dx and table is not None:
         # the transpose of the gather as a gather (da_conv2d_dgrad): deterministic, nothing k*k-fold in memory

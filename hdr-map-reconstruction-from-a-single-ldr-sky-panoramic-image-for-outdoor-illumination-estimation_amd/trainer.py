@@ -109,6 +109,9 @@ class Trainer:
             K.resconv_supported(im_height // 4, im_width // 4, 128, 128)
         self._da_offs = torch.from_numpy(K.da_offsets(im_height // 4, im_width // 4, 3, 1, True)).to(self.device) if self.da else None
         self._da_table = K.da_transpose_table(im_height // 4, im_width // 4, 3, 1, True, self.device) if self.da else None
+        if self.da and self._da_table is None:
+            raise ValueError("distortion-aware training: the transposed sample table of this map size needs more than "
+                             "%d readers per (pixel, tap)" % K.DA_KMAX)
         self._rc = {}
         self.dense_wgrad_external = False   # a data-parallel driver recomputes the Dense weight gradients (parallel.py)
         # fused_dense (HDRSKY_BF16 mode): on an updating step the two Dense kernels' gradients are never written - their
@@ -179,12 +182,6 @@ class Trainer:
             pairs.append((cv.w, cv.pk))
             if cv.pkT is not None:
                 pairs.append((cv.w, cv.pkT))
-            if getattr(self, "da", False) and name.startswith("gen.res."):
-                # data gradient of the distortion-aware conv: dG = dY W^T as a 1x1 conv with the transposed [9C, F] kernel
-                if getattr(cv, "pkDA", None) is None:
-                    cv.wDA = cv.w.view(1, 1, cv.kh * cv.kw * cv.cin, cv.cout)
-                    cv.pkDA = PackedConv(cv.wDA, self.precise, transpose_flip=True)
-                pairs.append((cv.wDA, cv.pkDA))
         self._packer = K.MultiPacker(pairs)      # uploads its job table: must not happen inside a graph capture
 
     def repack(self, fc=True):
@@ -283,6 +280,14 @@ class Trainer:
         grads = self.ds.g if name.startswith("dis.") else self.gs.g
         q = self._wjobs.setdefault(torch.cuda.current_stream().cuda_stream, [])
         q.append(cv.wgrad_job(x, xf, dy, grads[cv.wkey], grads[cv.bkey] if cv.bkey else None, self.compute))
+
+    def _wg_da(self, name, x, dy):
+        """Queues the kernel gradient of a distortion-aware 3x3 layer of the res stack (same HWIO weights viewed [9C, F])."""
+        cv = self.conv[name]
+        g = self.gs.g
+        q = self._wjobs.setdefault(torch.cuda.current_stream().cuda_stream, [])
+        q.append(K.da_wgrad_job(x, dy, cv.kh, self._da_offs, g[cv.wkey].view(cv.kh * cv.kw * cv.cin, cv.cout), g[cv.bkey],
+                                self.compute))
 
     def _flush_wgrads(self):
         """Launches the weight gradients queued on the current stream."""
@@ -728,23 +733,18 @@ class Trainer:
                         dx = K.resconv_bwd(dc1, c[p + "conv1"].pkT, skip=dx, want_f32=True, want_bf16=False)["f32"]
                 reducer.run()
             if self.da:
-                # y = G(x) W + b with G the bilinear gather: dW = G^T dY (1x1 weight gradient on the gathered tensor), dG = dY W^T
-                # (1x1 conv), dx = G^T dG (bilinear scatter) - kernels.da_conv2d_bwd
-                offs = self._da_offs
+                # y = G(x) W + b with G the bilinear gather.  dx = G^T (dY W^T): the transpose of the gather is again a
+                # (table-driven) gather, one launch with the flipped filter image (hdrsky_da_conv2d_dgrad); dW = G^T dY is
+                # queued like every other weight gradient - the twelve layers share one launch that recomputes G tile by tile
                 for i in range(5, -1, -1):
                     p = "gen.res.%d." % i
                     c1, t1, a1, c2, t2 = T["res%d" % i]
                     dr2 = self._in_bwd(c2, t2, p + "norm2", 1.0, dx)
-                    for cvn, xin, dy_ in ((p + "conv2", a1, dr2),):
-                        cv = c[cvn]
-                        da1, _, _ = K.da_conv2d_bwd(xin, dy_, cv.wDA.view(cv.kh * cv.kw * cv.cin, cv.cout), offs, 3, cp, True, cv.pkDA,
-                                                    dw=g[cv.wkey].view(cv.kh * cv.kw * cv.cin, cv.cout), db=g[cv.bkey],
-                                                    table=self._da_table, pwT3=cv.pkT)
+                    self._wg_da(p + "conv2", a1, dr2)
+                    da1 = K.da_conv2d_dgrad(dr2, c[p + "conv2"].pkT, self._da_table, 3, cp)
                     dr1 = self._in_bwd(c1, t1, p + "norm1", 0.1, da1)
-                    cv = c[p + "conv1"]
-                    dxx, _, _ = K.da_conv2d_bwd(T["x"][i], dr1, cv.wDA.view(cv.kh * cv.kw * cv.cin, cv.cout), offs, 3, cp, True, cv.pkDA,
-                                                dw=g[cv.wkey].view(cv.kh * cv.kw * cv.cin, cv.cout), db=g[cv.bkey],
-                                                table=self._da_table, pwT3=cv.pkT)
+                    self._wg_da(p + "conv1", T["x"][i], dr1)
+                    dxx = K.da_conv2d_dgrad(dr1, c[p + "conv1"].pkT, self._da_table, 3, cp)
                     dx = K.axpby(dx, 1.0, dxx, 1.0)                                     # + identity branch
                 self._norm_grads("bwd_res", B)
             for i in range(-1 if (self.use_resconv or self.da) else 5, -1, -1):

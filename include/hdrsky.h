@@ -219,6 +219,13 @@ typedef struct hdrsky_wgrad_job {
   float* db;
   int32_t x_bf16;   /* 1: x points to bf16 data (final activations of the bf16 chain, see hdrsky_resconv; needs */
   int32_t dy_bf16;  /* 1: dy points to bf16 data                             in_mode NONE / Cin, Cout % 8 == 0) */
+  /* Distortion-aware layer (distortion_aware_ops.py:5-270, kernel [k*k*C, F]): da_ksize = k > 0 makes the job the weight
+   * gradient dW[k*k*C][F] = G^T dY without G in memory - desc = the 1x1 layer over Cin = k*k*da_C virtual channels at the
+   * map size, x = the layer's input [B,H,W,da_C] fp32 (da_C % 32 == 0, no operand transform), da_offs = hdrsky_da_offsets'
+   * table [H][k*k][2]; the bilinear samples (:62-113) are recomputed while the operand tile is staged. */
+  const float* da_offs;
+  int32_t da_ksize;
+  int32_t da_C;
 } hdrsky_wgrad_job;
 int hdrsky_conv2d_wgrad_multi(const hdrsky_wgrad_job* jobs, int njobs, void* stream);
 /* The same weight gradients, BIT-REPRODUCIBLE: hdrsky_conv2d_wgrad(_multi) splits the pixel reduction over workgroups
@@ -295,16 +302,18 @@ int hdrsky_rmsprop_fc(float* w, const float* g, float* ms, int K, int N, float l
                       void* packed_hi, void* natural_hi, void* stream);
 /* The Dense weight gradient on the matrix cores: dW[K][N] (+)= x^T dy with both operands rounded to bf16 (fp32
  * accumulation; HDRSKY_BF16's contract), db (+)= fp32 column sums of dy.  x [M][ldx >= K], dy [M][ldy >= N] (row strides
- * in floats, multiples of 4, 16-byte aligned bases), any M >= 1; K and N multiples of 128.  Replaces tf.gradients through
+ * in floats, multiples of 4, 16-byte aligned bases), any M >= 1; K a multiple of 32, N of 256.  Replaces tf.gradients through
  * Keras Dense (sunpose_net.py:48-51,65-68) for the materialised gradient (all-reduce, inspection). */
 int hdrsky_fc_wgrad_bf16(const float* x, int ldx, const float* dy, int ldy, int M, int K, int N, int accumulate, float* dw,
-                         float* db, void* stream);
+                         float* db, void* ws, void* stream);
+/* Scratch both entry points need (the bf16 transposed operand images their first launch writes): ws of this many bytes. */
+size_t hdrsky_fc_xtdy_ws_bytes(int M, int K, int N);
 /* hdrsky_rmsprop_fc with the gradient g = gscale * x^T dy recomputed tile by tile inside the update (operands as for
  * hdrsky_fc_wgrad_bf16) instead of read from memory: w, ms and the bf16 images are updated in place, the weight gradient is
  * never written.  db (nullable) receives the bias gradient (unscaled) for a following hdrsky_rmsprop of the bias. */
 int hdrsky_rmsprop_fc_fused(float* w, float* ms, const float* x, int ldx, const float* dy, int ldy, int M, int K, int N,
                             float lr, float rho, float eps, float gscale, void* packed_hi, void* natural_hi, float* db,
-                            void* stream);
+                            void* ws, void* stream);
 /* tf.keras.optimizers.Adam (train_sun.py:191 / tf_utils.py:324; defaults beta 0.9 / 0.999, eps 1e-7) over a flat buffer:
  * m, v are the slots; lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t) is computed by the caller for step t; g is scaled by gscale. */
 int hdrsky_adam(float* w, const float* g, float* m, float* v, size_t n, float lr_t, float beta1, float beta2, float eps,

@@ -43,22 +43,31 @@ def test_da_conv_gradient_oracle_is_the_adjoint():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(2, 8, 32, 128, 128), (2, 16, 64, 64, 64), (1, 8, 32, 32, 64)])
-def test_da_conv_backward_matches_oracle(dev, shape):
-    """hdrsky_da_gather / 1x1 wgrad / 1x1 conv / hdrsky_da_scatter composed as the layer's backward pass."""
+@pytest.mark.parametrize("k,shape", [(3, (2, 8, 32, 128, 128)), (3, (2, 16, 64, 64, 64)), (3, (1, 8, 32, 32, 64)),
+                                     (3, (3, 32, 128, 64, 64)), (5, (2, 8, 32, 64, 64)), (7, (1, 16, 64, 32, 32))])
+def test_da_conv_backward_matches_oracle(dev, k, shape):
+    """The layer's backward pass: kernel gradient G^T dY with the gather recomputed inside the weight-gradient launch
+    (hdrsky_wgrad_job.da_*: 64x64-channel blocks for C % 64 == 0, 32x32 otherwise; ragged pixel tiles at B=3), data gradient
+    as 1x1 conv + hdrsky_da_scatter; twice into the same buffers = accumulation; bit-identical repeats."""
     K = pkg("kernels")
     B, H, W, C, F = shape
-    rng = np.random.default_rng(B * 17 + C + F)
+    rng = np.random.default_rng(B * 17 + C + F + k)
     x = rng.standard_normal((B, H, W, C)).astype(np.float32)
-    kern = (rng.standard_normal((9 * C, F)) / np.sqrt(9 * C)).astype(np.float32)
+    kern = (rng.standard_normal((k * k * C, F)) / np.sqrt(k * k * C)).astype(np.float32)
     dy = rng.standard_normal((B, H, W, F)).astype(np.float32)
-    offs = K.da_offsets(H, W, 3, 1, True)
-    rdx, rdk, rdb = da_ops.da_conv2d_grads(x, kern, da_ops.distortion(H, W), dy)
+    offs = K.da_offsets(H, W, k, 1, True)
+    rdx, rdk, rdb = da_ops.da_conv2d_grads(x, kern, da_ops.distortion(H, W, k), dy, k=k)
     d = lambda a: torch.from_numpy(a).to(dev)
-    dx, dk, db = K.da_conv2d_bwd(d(x), d(dy), d(kern), d(offs), 3, compute=K.BF16X3)
+    dx, dk, db = K.da_conv2d_bwd(d(x), d(dy), d(kern), d(offs), k, compute=K.BF16X3)
     assert_close(dx, rdx, 3e-4, "da conv dx"); assert_close(dk, rdk, 3e-4, "da conv dkernel"); assert_close(db, rdb, 1e-4, "da conv dbias")
-    dx16, dk16, _ = K.da_conv2d_bwd(d(x), d(dy), d(kern), d(offs), 3, compute=K.BF16)
+    _, dk2, db2 = K.da_conv2d_bwd(d(x), d(dy), d(kern), d(offs), k, compute=K.BF16X3, want_dx=False)
+    assert torch.equal(dk, dk2) and torch.equal(db, db2)                          # deterministic split-K
+    K.da_conv2d_bwd(d(x), d(dy), d(kern), d(offs), k, compute=K.BF16X3, want_dx=False, dw=dk2, db=db2)
+    assert_close(dk2, 2 * rdk, 3e-4, "da conv dkernel accumulates"); assert_close(db2, 2 * rdb, 1e-4, "da conv dbias accumulates")
+    dx16, dk16, _ = K.da_conv2d_bwd(d(x), d(dy), d(kern), d(offs), k, compute=K.BF16)
     assert_close_bf16(dx16, rdx, "da conv dx bf16"); assert_close_bf16(dk16, rdk, "da conv dkernel bf16")
+    if k != 3:
+        return
     # gathered operand against the forward pass: G(x) W + b == da_conv2d(x)
     G = K.da_gather(d(x), d(offs), 3)
     y = K.da_conv2d(d(x), K.PackedConv(d(kern).view(3, 3, C, F)), torch.zeros(F, device=dev), d(offs), K.BF16X3)

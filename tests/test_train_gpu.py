@@ -266,7 +266,7 @@ def test_fc_wgrad_bf16_and_fused_update(dev):
     K = pkg("kernels")
     rng = np.random.default_rng(5)
     bf = lambda t: t.to(torch.bfloat16).to(torch.float64)
-    Kd, N = 256, 384
+    Kd, N = 160, 512
     for M in (1, 2, 31, 32, 33, 70):
         wide = torch.from_numpy(rng.standard_normal((M, Kd + N + 8)).astype(np.float32)).to(dev)
         x, dy = wide[:, 4:4 + Kd], wide[:, 4 + Kd:4 + Kd + N]          # column blocks of one buffer: strided rows
