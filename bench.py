@@ -49,9 +49,11 @@ def parse():
     ap.add_argument("--workload", default="all", choices=["all", "train", "fwd", "hires"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
-    ap.add_argument("--da", action="store_true",
-                    help="train workload with the distortion-aware res blocks (distortion_aware_ops.conv2d in generator.py:14,18's "
-                         "commented-out variant), forward and backward")
+    ap.add_argument("--da", nargs="?", const="res", default="", metavar="PARTS",
+                    help="train / fwd workload with distortion-aware layers, forward and backward: comma list of res "
+                         "(distortion_aware_ops.conv2d in the res blocks, generator.py:14,18's commented-out variant; the "
+                         "default of a bare --da), sunpose (sunpose_net.py:11,16), decoders (distortion_aware_ops.deconv2d in "
+                         "both decoders), or all")
     ap.add_argument("--dp-mode", default=None, help="gradient exchange of the N > 1 training step (parallel.py: MODES)")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run only the timed loop of the roofline kernel and print its object (the command behind "
@@ -374,14 +376,14 @@ def main():
                                        "tone-map/DoG/L1/KL/LSGAN losses, RMSprop x2), batch=%d per GPU, 32x128x3" % batch,
                            "per_gpu_batch": batch, "global_batch": batch * world,
                            "parallelism": ("dp%d (%s)" % (world, ex.describe())) if world > 1 else "single",
-                           "hipgraph": not args.no_graph, "distortion_aware_res_blocks": bool(args.da)},
+                           "hipgraph": not args.no_graph, "distortion_aware": sorted(engine.da_parts(args.da))},
                 "algorithmic_tflops": round(imgs / dt * TRAIN_MFLOP_PER_IMG * 1e6 / 1e12, 2)})
             del tr, ex, one_step, out
             torch.cuda.empty_cache()
         if do_fwd:
             nets = engine.Nets(gen, sun, device=dev, precise=False)
             roof_pw = roof_pw if roof_pw is not None else nets.pk["gen.res.0.conv1"]
-            one_step, out = capture_forward(torch, lambda: engine.generator_forward(nets, ldr, compute=K.BF16), dp, args.no_graph)
+            one_step, out = capture_forward(torch, lambda: engine.generator_forward(nets, ldr, compute=K.BF16, distortion_aware=args.da), dp, args.no_graph)
             dtf = timed(torch, dist, one_step, args.steps, args.warmup, dp, dev)
             assert torch.isfinite(out["y_final_lin"]).all()
             imgs = batch * world * args.steps

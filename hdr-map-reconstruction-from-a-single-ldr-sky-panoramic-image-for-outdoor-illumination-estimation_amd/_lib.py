@@ -113,6 +113,7 @@ SIGNATURES = {
     "hdrsky_sun_rad_bwd": (c_int, [P, P, P, P, P, c_int, c_int, P, P, P, P]),
     "hdrsky_dense_heads_bwd": (c_int, [P, P, P, c_float, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P]),
     "hdrsky_slice_channels": (c_int, [P, c_size_t, c_int, c_int, c_int, c_float, c_int, P, P]),
+    "hdrsky_pad_channels": (c_int, [P, c_size_t, c_int, c_int, P, P]),
     "hdrsky_concat2": (c_int, [P, c_int, P, c_int, c_size_t, P, P]),
     "hdrsky_vgg_pre": (c_int, [P, c_size_t, P, P]),
     "hdrsky_flip_rgb": (c_int, [P, c_size_t, P, P]),

@@ -57,8 +57,11 @@ __global__ void __launch_bounds__(NWV * 64) da_conv_kernel(const DaArgs a) {
   f32x4_t acc[4];
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) acc[mi] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  const uint4* wlh = a.whi + (size_t)kq * a.Npad + n0 + wave * 16 + lr;
-  const uint4* wll = PRECISE ? a.wlo + (size_t)kq * a.Npad + n0 + wave * 16 + lr : nullptr;
+  // (a workgroup may be wider than the filter image - the data gradient of a layer with few input channels uses 8 waves
+  // for their gather registers: the waves beyond the image read column block 0 and store nothing)
+  const int wcol = (n0 + wave * 16 < a.Npad) ? n0 + wave * 16 : 0;
+  const uint4* wlh = a.whi + (size_t)kq * a.Npad + wcol + lr;
+  const uint4* wll = PRECISE ? a.wlo + (size_t)kq * a.Npad + wcol + lr : nullptr;
   const float* xb = a.x + (size_t)b * npix * a.Cin;
 
   // The sampling offsets of the image rows this tile covers (k*k pairs per row), staged once: the per-tap gather then
@@ -462,9 +465,11 @@ int hdrsky_da_conv2d_dgrad(const float* dy, const void* wT_hi, const void* wT_lo
   a.ksize = ksize; a.k2 = ksize * ksize;
   a.pad = ksize > 1 ? (ksize - 1) / 2 : 0;
   a.in_h = H + (ksize > 1 ? ksize - 1 : 0); a.in_w = W + (ksize > 1 ? ksize - 1 : 0);
-  const int nwv = C > 64 ? 8 : 4;
+  // 8 waves when dx has more than 64 channels - or when dy has (two (pixel, 8-channel) items of 8 sources each per thread
+  // is the register budget: 64 pixels x F/8 items need F/16 waves)
+  const int nwv = (C > 64 || F > 64) ? 8 : 4;
   a.cin32 = F / 32; a.nblocks = cdiv(C, nwv * 16); a.tiles_x = cdiv(H * W, 64);
-  if (64 * (F / 8) > 2 * nwv * 64) return HDRSKY_EUNSUPPORTED;     // two items per thread (8 sources each in registers)
+  if (64 * (F / 8) > 2 * nwv * 64) return HDRSKY_EUNSUPPORTED;
   const int lds = 2 * (F / 8) * 65 * 16 * (precise ? 2 : 1);
   if (lds > 152 * 1024) return HDRSKY_EUNSUPPORTED;
   if ((64 / W + 2) * a.k2 > 5 * 128) return HDRSKY_EUNSUPPORTED;

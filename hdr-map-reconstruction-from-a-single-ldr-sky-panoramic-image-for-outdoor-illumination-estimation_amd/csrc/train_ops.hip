@@ -608,6 +608,16 @@ __global__ void slice_channels_kernel(const float* __restrict__ x, size_t npix, 
   }
 }
 
+// out[p, 0..Cpad) = [x[p, 0..C), zeros]: channel padding of an image / of a filter's input-channel axis (the
+// distortion-aware kernels read 32-channel groups: the 3-channel input layer of the sun-pose net runs on a padded copy)
+__global__ void pad_channels_kernel(const float* __restrict__ x, size_t npix, int C, int Cpad, float* __restrict__ out) {
+  const size_t n = npix * Cpad;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cpad);
+    out[i] = c < C ? x[(i / Cpad) * C + c] : 0.f;
+  }
+}
+
 // concat along channels: out[b,p,:] = [a (Ca), b (Cb)]      (discriminator.py:43)
 __global__ void concat2_kernel(const float* __restrict__ a, int Ca, const float* __restrict__ b, int Cb, size_t npix,
                                float* __restrict__ out) {
@@ -933,6 +943,14 @@ int hdrsky_slice_channels(const float* x, size_t npix, int C, int c_off, int c_t
   if (!x || !out || c_off + c_take > C) return HDRSKY_EINVAL;
   hipLaunchKernelGGL(slice_channels_kernel, dim3(grid_for(npix * c_take)), dim3(256), 0, S_(stream), x, npix, C, c_off,
                      c_take, scale, accumulate, out);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_pad_channels(const float* x, size_t npix, int C, int Cpad, float* out, void* stream) {
+  if (!x || !out || C <= 0 || Cpad < C) return HDRSKY_EINVAL;
+  if (npix == 0) return HDRSKY_OK;
+  hipLaunchKernelGGL(pad_channels_kernel, dim3(grid_for(npix * Cpad)), dim3(256), 0, S_(stream), x, npix, C, Cpad, out);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }

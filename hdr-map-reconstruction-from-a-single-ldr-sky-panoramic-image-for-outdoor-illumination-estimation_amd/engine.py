@@ -24,6 +24,27 @@ from .kernels import BF16, BF16X3, InXf, PackedConv, PackedFC
 THRESHOLD = 0.12  # inference.py:36 / train.py:247
 
 
+DA_PARTS = ("res", "sunpose", "decoders")
+
+
+def da_parts(spec):
+    """Which layer families run as distortion_aware_ops layers.  False / None: none.  True: the res blocks (generator.py:14,18).
+    "all", a comma list or an iterable of DA_PARTS: "sunpose" = both convolutions of every sunposeLayer
+    (sunpose_net.py:11,16: kernel_size = k_h, i.e. 7 / 3 / 3), "decoders" = distortion_aware_ops.deconv2d (:272-542: bilinear
+    resize, then the distortion-aware conv at the output size) in place of ops.deconv2d in sky_decode / sun_decode
+    (generator.py:110-156).  The variables are the plain layers' (an HWIO filter is the [k*k*C, F] kernel reshaped)."""
+    if not spec:
+        return frozenset()
+    if spec is True:
+        return frozenset({"res"})
+    if isinstance(spec, str):
+        spec = DA_PARTS if spec == "all" else [t.strip() for t in spec.split(",") if t.strip()]
+    parts = frozenset(spec)
+    if not parts <= frozenset(DA_PARTS):
+        raise ValueError("distortion_aware: unknown part(s) %s (known: %s)" % (sorted(parts - frozenset(DA_PARTS)), DA_PARTS))
+    return parts
+
+
 def _dev(params, device):
     return OrderedDict((k, torch.as_tensor(v).to(device=device, dtype=torch.float32).contiguous())
                        for k, v in params.items())
@@ -51,6 +72,24 @@ class Nets:
         if key not in self._da_offs:
             self._da_offs[key] = torch.from_numpy(K.da_offsets(h, w, k, dilation_rate, True)).to(self.device)
         return self._da_offs[key]
+
+    def da_table(self, h, w, k=3):
+        """Transposed sample table of a k x k distortion-aware conv on an h x w map (kernels.da_transpose_table, cached)."""
+        tab = K.da_transpose_table(h, w, k, 1, True, self.device)
+        if tab is None:
+            raise ValueError("distortion-aware data gradient: more than %d readers per (pixel, tap) at %dx%d, k=%d" % (K.DA_KMAX, h, w, k))
+        return tab
+
+    def da_pk(self, name, cpad=32):
+        """Packed image of filter `name` ("sun.sunlayer1.conv1") with its input-channel axis zero-padded to cpad (the
+        distortion-aware kernels read 32-channel groups; the padded input channels are zeros as well)."""
+        key = name + ".da%d" % cpad
+        if key not in self.pk:
+            net, _, rest = name.partition(".")
+            wgt = (self.gen if net == "gen" else self.sun)[rest + ".w"]
+            kh, kw, cin, cout = wgt.shape
+            self.pk[key] = PackedConv(K.pad_channels(wgt.reshape(kh * kw, cin * cout), cpad * cout).view(kh, kw, cpad, cout), self.precise)
+        return self.pk[key]
 
     def repack_all(self):
         g, s = self.gen, self.sun
@@ -121,14 +160,30 @@ def sun3_backward(rec, dP, pkT1, pkT2, g1, b1, g2, b2, dgb1=None, dgb2=None):
     return dc2, dc1, dx
 
 
-def sunpose_forward(nets, ldr, compute):
+def sunpose_forward(nets, ldr, compute, distortion_aware=False):
     """sunpose_net.model.sunposeEstimation (sunpose_net.py:54-72) -> dict with cmf, z, A1..3 (+ what the
-    Grad-CAM sweep re-reads: raw conv outputs and their IN partials)."""
+    Grad-CAM sweep re-reads: raw conv outputs and their IN partials).  distortion_aware ("sunpose" in da_parts): the
+    convolutions are distortion_aware_ops.conv2d (sunpose_net.py:11,16)."""
     s, pk = nets.sun, nets.pk
-    t = {}
+    da = "sunpose" in da_parts(distortion_aware)
+    t = {"da": da}
     x = ldr
     for l in (1, 2, 3):
         n1, n2 = "sunlayer%d.conv1" % l, "sunlayer%d.conv2" % l
+        if da:
+            k = s[n1 + ".w"].shape[0]
+            offs = nets.da_offsets(x.shape[1], x.shape[2], k)
+            padded = x.shape[-1] % 32 != 0                          # the RGB image: zero channels up to 32
+            xin = K.pad_channels(x, 32) if padded else x
+            r1, st1 = K.da_conv2d(xin, nets.da_pk("sun." + n1) if padded else pk["sun." + n1], s[n1 + ".b"], offs, compute,
+                                  want_stats=True)
+            a1 = K.norm_apply(r1, st1, s["sunlayer%d.norm1.gamma" % l], s["sunlayer%d.norm1.beta" % l], slope=0.0)
+            r2, st2 = K.da_conv2d(a1, pk["sun." + n2], s[n2 + ".b"], offs, compute, want_stats=True)
+            a, pooled = K.norm_apply(r2, st2, s["sunlayer%d.norm2.gamma" % l], s["sunlayer%d.norm2.beta" % l], slope=0.0,
+                                     pool=True)
+            t["r%da" % l], t["st%da" % l], t["r%db" % l], t["st%db" % l], t["A%d" % l], t["P%d" % l] = r1, st1, r2, st2, a, pooled
+            x = pooled
+            continue
         if l == 3 and sun3_supported(x, compute):
             t["s3"] = sun3_forward(x, pk["sun." + n1], pk["sun." + n2], s["sunlayer3.norm1.gamma"], s["sunlayer3.norm1.beta"],
                                    s["sunlayer3.norm2.gamma"], s["sunlayer3.norm2.beta"])
@@ -154,7 +209,8 @@ def sunpose_forward(nets, ldr, compute):
 
 def gradcam_sweep(nets, t, pick_src, compute):
     """grad_cam.layer x3 (grad_cam.py:29-44) as ONE backward sweep from y_c = cmf[b, argmax pick_src[b]]
-    down to the input of pool1.  Returns (cam1, cam2, cam3)."""
+    down to the input of pool1.  Returns (cam1, cam2, cam3).  (A distortion-aware sun-pose net - t["da"] - sweeps back
+    through hdrsky_da_conv2d_dgrad.)"""
     s, pk = nets.sun, nets.pk
     B = t["cmf"].shape[0]
     h, w = nets.h, nets.w
@@ -163,6 +219,19 @@ def gradcam_sweep(nets, t, pick_src, compute):
     dflat = K.fc_finalize(K.fc_dgrad(df1, pk["sun.fc1"], compute))
     dP3 = dflat.reshape(B, h // 8, w // 8, 128)
     w3 = K.spatial_sum(dP3, 1.0 / ((h // 4) * (w // 4)))
+    if t.get("da"):
+        dP = dP3
+        sums = {}
+        for l in (3, 2):
+            n = "sunlayer%d" % l
+            hl, wl = h >> (l - 1), w >> (l - 1)
+            tab = nets.da_table(hl, wl, 3)
+            g = K.norm_act_bwd(t["r%db" % l], t["st%db" % l], s[n + ".norm2.gamma"], s[n + ".norm2.beta"], 0.0, dP, True)
+            g = K.da_conv2d_dgrad(g, pk["sun." + n + ".conv2.T"], tab, 3, compute)
+            g = K.norm_act_bwd(t["r%da" % l], t["st%da" % l], s[n + ".norm1.gamma"], s[n + ".norm1.beta"], 0.0, g, False)
+            dP = K.da_conv2d_dgrad(g, pk["sun." + n + ".conv1.T"], tab, 3, compute)       # gradient at the pooled map below
+            sums[l - 1] = K.spatial_sum(dP, 1.0 / ((2 * hl) * (2 * wl)))
+        return K.grad_cam_map(t["A1"], sums[1]), K.grad_cam_map(t["A2"], sums[2]), K.grad_cam_map(t["A3"], w3)
     # layer 3 backward: pool3 + relu + IN2 -> dgrad conv2 -> relu + IN1 -> dgrad conv1
     if "s3" in t:
         _, _, dP2 = sun3_backward(t["s3"], dP3, pk["sun.sunlayer3.conv1.T"], pk["sun.sunlayer3.conv2.T"],
@@ -224,10 +293,21 @@ def encode(nets, ldr, compute, distortion_aware=False, dilation_rate=1):
     return x
 
 
-def decode(nets, res_out, sfx, residual, compute):
+def decode(nets, res_out, sfx, residual, compute, distortion_aware=False):
     """generator.model.sky_decode / sun_decode (generator.py:110-156): `residual` is the LDR input (sky)
-    or the log-compressed sun radiance (sun)."""
+    or the log-compressed sun radiance (sun).  distortion_aware ("decoders" in da_parts): the two resize-deconvolutions are
+    distortion_aware_ops.deconv2d (:272-542) - bilinear 2x resize, then the distortion-aware 3x3 conv at the output size."""
     g, pk = nets.gen, nets.pk
+    if "decoders" in da_parts(distortion_aware):
+        u3 = K.up2x(res_out)
+        r3, s3 = K.da_conv2d(u3, pk["gen.conv3_" + sfx], g["conv3_%s.bias_deconv2d" % sfx], nets.da_offsets(u3.shape[1], u3.shape[2]),
+                             compute, want_stats=True)
+        u2 = K.up2x(K.norm_apply(r3, s3, g["norm3_%s.gamma" % sfx], g["norm3_%s.beta" % sfx], slope=0.1))
+        r2, s2 = K.da_conv2d(u2, pk["gen.conv2_" + sfx], g["conv2_%s.bias_deconv2d" % sfx], nets.da_offsets(u2.shape[1], u2.shape[2]),
+                             compute, want_stats=True)
+        y, _ = K.conv2d(r2, pk["gen.conv1_" + sfx], g["conv1_%s.b" % sfx], compute=compute,
+                        xf=_in_xf(s2, g, "norm2_" + sfx, 0.1), out_slope=0.1, residual=residual, final_relu=True)
+        return y
     r3, s3 = K.conv2d(res_out, pk["gen.conv3_" + sfx], g["conv3_%s.bias_deconv2d" % sfx], upsample=2, want_stats=True,
                       compute=compute)
     r2, s2 = K.conv2d(r3, pk["gen.conv2_" + sfx], g["conv2_%s.bias_deconv2d" % sfx], upsample=2, want_stats=True,
@@ -273,9 +353,11 @@ def sun_rad_estimation(nets, ldr, cams, t, compute, training=False):
     return rad_lin, rad_gamma, gamma, beta
 
 
-def generator_forward(nets, ldr, pick_src=None, compute=BF16):
+def generator_forward(nets, ldr, pick_src=None, compute=BF16, distortion_aware=False):
     """inference.py:81-115 (pick_src=None: y_c = max cmf) / train.py:239-299 in test mode
-    (pick_src = sunpose_gt).  ldr [B,H,W,3] BGR in [0,1].  Returns the reference's outputs as a dict."""
+    (pick_src = sunpose_gt).  ldr [B,H,W,3] BGR in [0,1].  Returns the reference's outputs as a dict.
+    distortion_aware: see da_parts."""
+    da = da_parts(distortion_aware)
     B, H, W, _ = ldr.shape
     # two independent branches (generator encoder + sky decoder | sun-pose net + Grad-CAM + sun radiance) run on
     # two HIP streams; under hipGraph capture this becomes a fork/join in the graph.
@@ -283,13 +365,13 @@ def generator_forward(nets, ldr, pick_src=None, compute=BF16):
     side = nets.side_stream
     side.wait_stream(main)
     with torch.cuda.stream(side):
-        t = sunpose_forward(nets, ldr, compute)
+        t = sunpose_forward(nets, ldr, compute, da)
         cams = gradcam_sweep(nets, t, t["cmf"] if pick_src is None else pick_src, compute)
         rad_lin, rad_gamma, gamma, beta = sun_rad_estimation(nets, ldr, cams, t, compute)
-    res_out = encode(nets, ldr, compute)
-    sky_gamma = decode(nets, res_out, "f", ldr, compute)
+    res_out = encode(nets, ldr, compute, distortion_aware="res" in da)
+    sky_gamma = decode(nets, res_out, "f", ldr, compute, da)
     main.wait_stream(side)
-    sun_gamma = decode(nets, res_out, "u", rad_gamma, compute)
+    sun_gamma = decode(nets, res_out, "u", rad_gamma, compute, da)
     y_gamma, y_lin, alpha, sky_lin, sun_lin = K.blend(sky_gamma, sun_gamma, THRESHOLD)
     return dict(y_final_lin=y_lin, y_final_gamma=y_gamma, sky_pred_lin=sky_lin, sun_pred_lin=sun_lin, gamma=gamma,
                 beta=beta, alpha_c3=alpha, sunpose_cmf=t["cmf"], sunpose_pred=t["cmf"].reshape(B, H, W, 1),

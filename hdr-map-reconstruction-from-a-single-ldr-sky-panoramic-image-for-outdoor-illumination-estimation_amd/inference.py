@@ -30,6 +30,9 @@ def main(argv=None):
     ap.add_argument("--outdir", type=str, default="inference_output")
     ap.add_argument("--sky", type=str, default=os.path.join(cwd, "checkpoints/SKY"))
     ap.add_argument("--sun", type=str, default=os.path.join(cwd, "checkpoints/SUN"))
+    ap.add_argument("--distortion-aware", default="", metavar="PARTS",
+                    help="the checkpoints were trained with these layer families as distortion_aware_ops layers: comma list of "
+                         "res, sunpose, decoders, or all (train.py --distortion-aware)")
     args = ap.parse_args(argv)
     if args.indir == "None":
         raise SystemExit("Please specify your input LDR directory")
@@ -50,7 +53,7 @@ def main(argv=None):
                 print("Latest SUN checkpoint has restored!! (%d variables)" % ckpt.load_into(sun, t, "lin"))
             nets, shape = E.Nets(gen, sun, device="cuda:0", precise=False, im_height=h, im_width=w), (h, w)
         x = torch.from_numpy(np.ascontiguousarray(ldr[None])).to("cuda:0")
-        pred = E.generator_forward(nets, x, compute=K.BF16)["y_final_lin"][0].cpu().numpy()
+        pred = E.generator_forward(nets, x, compute=K.BF16, distortion_aware=args.distortion_aware)["y_final_lin"][0].cpu().numpy()
         name = os.path.split(f)[-1].split(".")[0] + ".hdr"
         hdr_io.write_hdr(os.path.join(args.outdir, name), pred)
         print("wrote", os.path.join(args.outdir, name))

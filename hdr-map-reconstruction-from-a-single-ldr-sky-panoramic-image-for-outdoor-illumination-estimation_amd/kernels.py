@@ -692,6 +692,17 @@ def slice_channels(x, c_off, c_take, scale=1.0, out=None):
     return o
 
 
+def pad_channels(x, Cpad, out=None):
+    """[..., C] -> [..., Cpad] with zero channels appended (out: a preallocated destination)."""
+    C = x.shape[-1]
+    shape = tuple(x.shape[:-1]) + (Cpad,)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=x.device)
+    _f32(out, *shape)
+    L.check(L.load().hdrsky_pad_channels(_p(_f32(x)), x.numel() // C, C, Cpad, _p(out), _stream()), "pad_channels")
+    return out
+
+
 def concat2(a, b, out=None):
     Ca, Cb = a.shape[-1], b.shape[-1]
     if out is None:

@@ -44,6 +44,10 @@ def main(argv=None):
     ap.add_argument("--no-graph", action="store_true", help="issue every launch eagerly instead of replaying hipGraphs")
     ap.add_argument("--dp-mode", default=None, choices=list(par.MODES),
                     help="gradient exchange between data-parallel replicas (parallel.GradientExchange)")
+    ap.add_argument("--distortion-aware", default="", metavar="PARTS",
+                    help="run these layer families as distortion_aware_ops layers (the variants the reference keeps commented "
+                         "out): comma list of res (generator.py:14,18), sunpose (sunpose_net.py:11,16), decoders "
+                         "(distortion_aware_ops.deconv2d in sky_decode / sun_decode), or all")
     ap.add_argument("--host-synth", action="store_true",
                     help="build the synthetic batches with numpy on the host (40 ms per batch of 32) instead of on the GPU")
     args = ap.parse_args(argv)
@@ -65,7 +69,8 @@ def main(argv=None):
     sun_t, _ = sun_mgr.restore()
     if sun_t:
         print("Latest SUN checkpoint has restored!! (%d variables)" % ckpt.load_into(sun, sun_t, "lin"))
-    tr = Trainer(gen, sun, dis, vgg, device=dev, lr=args.lr, im_height=h, im_width=w, compute=K.BF16, world_size=world)
+    tr = Trainer(gen, sun, dis, vgg, device=dev, lr=args.lr, im_height=h, im_width=w, compute=K.BF16, world_size=world,
+                 distortion_aware=args.distortion_aware)
     if tensors and "gen_optimizer/rms" in tensors:
         tr.gs.ms.copy_(torch.from_numpy(tensors["gen_optimizer/rms"])); tr.ds.ms.copy_(torch.from_numpy(tensors["disc_optimizer/rms"]))
     par.broadcast_params_([tr.gs.flat, tr.ds.flat]); tr.repack()

@@ -39,6 +39,8 @@ def main(argv=None):
     ap.add_argument("--dorf", type=str, default=None)
     ap.add_argument("--sun", type=str, default=os.path.join(cwd, "checkpoints/SUN"))
     ap.add_argument("--steps-per-epoch", type=int, default=8, help="synthetic mode: steps per epoch")
+    ap.add_argument("--distortion-aware", action="store_true",
+                    help="distortion_aware_ops.conv2d in every sunposeLayer (the lines sunpose_net.py:11,16 keep commented out)")
     ap.add_argument("--host-synth", action="store_true",
                     help="build the synthetic batches with numpy on the host (40 ms per batch of 32) instead of on the GPU")
     args = ap.parse_args(argv)
@@ -53,7 +55,8 @@ def main(argv=None):
     tensors, epoch0 = mgr.restore()
     if tensors:
         print("Latest checkpoint has restored!! (%d variables)" % ckpt.load_into(sun, tensors, "lin"))
-    tr = SunPoseTrainer(sun, device=dev, lr=args.lr, im_height=h, im_width=w, compute=K.BF16, world_size=world)
+    tr = SunPoseTrainer(sun, device=dev, lr=args.lr, im_height=h, im_width=w, compute=K.BF16, world_size=world,
+                        distortion_aware=args.distortion_aware)
     if tensors and "optimizer/m" in tensors:
         tr.adam_m.copy_(torch.from_numpy(tensors["optimizer/m"])); tr.adam_v.copy_(torch.from_numpy(tensors["optimizer/v"]))
         tr.steps_done = int(tensors["optimizer/iter"])

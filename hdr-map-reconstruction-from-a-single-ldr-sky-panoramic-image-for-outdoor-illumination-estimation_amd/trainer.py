@@ -104,14 +104,13 @@ class Trainer:
         # mode, 8x32 maps); otherwise the generic conv / norm launches on fp32 activations
         # distortion_aware: the res blocks' 3x3 convolutions are distortion_aware_ops.conv2d (the variant generator.py:14,18
         # keeps commented out; same HWIO weights = its [k*k*C, F] kernel), forward and backward
-        self.da = bool(distortion_aware)
+        # ("res" / "sunpose" / "decoders" parts: engine.da_parts; True = the res blocks)
+        self.da_parts = E.da_parts(distortion_aware)
+        self.da, self.da_sun, self.da_dec = ("res" in self.da_parts), ("sunpose" in self.da_parts), ("decoders" in self.da_parts)
+        self._da_geo = {}                   # (h, w, k) -> (offsets on the device, transposed sample table)
         self.use_resconv = bool(resconv) and not self.da and compute == BF16 and not precise and \
             K.resconv_supported(im_height // 4, im_width // 4, 128, 128)
-        self._da_offs = torch.from_numpy(K.da_offsets(im_height // 4, im_width // 4, 3, 1, True)).to(self.device) if self.da else None
-        self._da_table = K.da_transpose_table(im_height // 4, im_width // 4, 3, 1, True, self.device) if self.da else None
-        if self.da and self._da_table is None:
-            raise ValueError("distortion-aware training: the transposed sample table of this map size needs more than "
-                             "%d readers per (pixel, tap)" % K.DA_KMAX)
+        self._da_offs, self._da_table = self._da(im_height // 4, im_width // 4, 3) if self.da else (None, None)
         self._rc = {}
         self.dense_wgrad_external = False   # a data-parallel driver recomputes the Dense weight gradients (parallel.py)
         # fused_dense (HDRSKY_BF16 mode): on an updating step the two Dense kernels' gradients are never written - their
@@ -136,6 +135,8 @@ class Trainer:
         self.losses = torch.zeros(len(LOSS_SLOTS), dtype=torch.float32, device=self.device)
         self._wjobs = {}
         self._build_layers()
+        if self.da_sun:
+            self._init_da_sun()
 
     # -------------------------------------------------------------------------------------------------
     def _build_layers(self):
@@ -182,11 +183,16 @@ class Trainer:
             pairs.append((cv.w, cv.pk))
             if cv.pkT is not None:
                 pairs.append((cv.w, cv.pkT))
+        if getattr(self, "da_sun", False) and hasattr(self, "_w1pad"):
+            pairs.append((self._w1pad, self._pk1pad))
         self._packer = K.MultiPacker(pairs)      # uploads its job table: must not happen inside a graph capture
 
     def repack(self, fc=True):
         if getattr(self, "_packer", None) is None:
             self._make_packer()
+        if getattr(self, "da_sun", False) and hasattr(self, "_w1pad"):
+            cv = self.conv["sun.sunlayer1.conv1"]
+            K.pad_channels(cv.w.reshape(cv.kh * cv.kw, cv.cin * cv.cout), 32 * cv.cout, out=self._w1pad.view(cv.kh * cv.kw, 32 * cv.cout))
         self._packer.run()
         if fc:
             self.fc1.repack(self.gs.w["sun.fc1.kernel"])
@@ -281,13 +287,26 @@ class Trainer:
         q = self._wjobs.setdefault(torch.cuda.current_stream().cuda_stream, [])
         q.append(cv.wgrad_job(x, xf, dy, grads[cv.wkey], grads[cv.bkey] if cv.bkey else None, self.compute))
 
-    def _wg_da(self, name, x, dy):
-        """Queues the kernel gradient of a distortion-aware 3x3 layer of the res stack (same HWIO weights viewed [9C, F])."""
+    def _da(self, h, w, k=3):
+        """(offsets on the device, transposed sample table) of a k x k distortion-aware layer on an h x w map (cached)."""
+        key = (h, w, k)
+        if key not in self._da_geo:
+            tab = K.da_transpose_table(h, w, k, 1, True, self.device)
+            if tab is None:
+                raise ValueError("distortion-aware training: the transposed sample table of a %dx%d map (k=%d) needs more "
+                                 "than %d readers per (pixel, tap)" % (h, w, k, K.DA_KMAX))
+            self._da_geo[key] = (torch.from_numpy(K.da_offsets(h, w, k, 1, True)).to(self.device), tab)
+        return self._da_geo[key]
+
+    def _wg_da(self, name, x, dy, dw=None):
+        """Queues the kernel gradient of a distortion-aware layer (same HWIO weights viewed [k*k*C, F]); the gathered
+        operand is recomputed inside the launch.  dw: another destination (the channel-padded first sun-pose layer)."""
         cv = self.conv[name]
         g = self.gs.g
         q = self._wjobs.setdefault(torch.cuda.current_stream().cuda_stream, [])
-        q.append(K.da_wgrad_job(x, dy, cv.kh, self._da_offs, g[cv.wkey].view(cv.kh * cv.kw * cv.cin, cv.cout), g[cv.bkey],
-                                self.compute))
+        offs = self._da(x.shape[1], x.shape[2], cv.kh)[0]
+        q.append(K.da_wgrad_job(x, dy, cv.kh, offs, dw if dw is not None else g[cv.wkey].view(cv.kh * cv.kw * cv.cin, cv.cout),
+                                g[cv.bkey], self.compute))
 
     def _flush_wgrads(self):
         """Launches the weight gradients queued on the current stream."""
@@ -297,9 +316,21 @@ class Trainer:
 
     def _sunpose_forward(self, ldr):
         w, c, cp = self.gs.w, self.conv, self.compute
-        t, x = {}, ldr
+        t, x = {"da": self.da_sun}, ldr
         for l in (1, 2, 3):
             n = "sun.sunlayer%d" % l
+            if self.da_sun:       # sunpose_net.py:11,16: distortion_aware_ops.conv2d(filter_out, kernel_size=k_h)
+                cv1, cv2 = c[n + ".conv1"], c[n + ".conv2"]
+                offs = self._da(x.shape[1], x.shape[2], cv1.kh)[0]
+                xin, pk1 = (K.pad_channels(x, 32), self._pk1pad) if l == 1 else (x, cv1.pk)
+                r1, st1 = K.da_conv2d(xin, pk1, cv1.b, offs, cp, want_stats=True)
+                a1 = K.norm_apply(r1, st1, w[n + ".norm1.gamma"], w[n + ".norm1.beta"], slope=0.0)
+                r2, st2 = K.da_conv2d(a1, cv2.pk, cv2.b, offs, cp, want_stats=True)
+                a, pooled = K.norm_apply(r2, st2, w[n + ".norm2.gamma"], w[n + ".norm2.beta"], slope=0.0, pool=True)
+                t["in%d" % l], t["r%da" % l], t["st%da" % l], t["a%da" % l] = xin, r1, st1, a1
+                t["r%db" % l], t["st%db" % l], t["A%d" % l], t["P%d" % l] = r2, st2, a, pooled
+                x = pooled
+                continue
             if l == 3 and E.sun3_supported(x, cp) and not self.precise:
                 t["in3"] = x
                 t["s3"] = E.sun3_forward(x, c[n + ".conv1"].pk, c[n + ".conv2"].pk, w[n + ".norm1.gamma"], w[n + ".norm1.beta"],
@@ -321,6 +352,41 @@ class Trainer:
         t["z"], t["cmf"] = K.softmax_head(K.fc_fwd(t["f1"], self.fc2, cp), w["sun.fc2.bias"], t["gmax"])
         return t
 
+    def _init_da_sun(self):
+        """sunlayer1.conv1 reads the RGB image: the distortion-aware kernels work on 32-channel groups, so it runs on a
+        zero-padded copy of the image with a zero-padded copy of its filter (refreshed with every re-pack); its kernel
+        gradient lands in a padded buffer whose three real input-channel rows are then added to the gradient."""
+        cv = self.conv["sun.sunlayer1.conv1"]
+        self._w1pad = torch.zeros((cv.kh, cv.kw, 32, cv.cout), dtype=torch.float32, device=self.device)
+        self._pk1pad = PackedConv(self._w1pad, self.precise)
+        self._dw1pad = torch.zeros((cv.kh * cv.kw * 32, cv.cout), dtype=torch.float32, device=self.device)
+        self._packer = None
+        self.repack(fc=False)
+
+    def _sunpose_bwd_da(self, t, dP, B):
+        """Backward pass of the distortion-aware sun-pose layers from dP = d loss / d pool3 output: data gradients by
+        hdrsky_da_conv2d_dgrad, kernel gradients queued (the gather is recomputed inside their launch) and launched here."""
+        c, cp, g = self.conv, self.compute, self.gs.g
+        for l in (3, 2, 1):
+            n = "sun.sunlayer%d" % l
+            k = c[n + ".conv1"].kh
+            tab = self._da(self.h >> (l - 1), self.w >> (l - 1), k)[1]
+            dr2 = self._in_bwd(t["r%db" % l], t["st%db" % l], n + ".norm2", 0.0, dP, pooled=True)
+            self._wg_da(n + ".conv2", t["a%da" % l], dr2)
+            da = K.da_conv2d_dgrad(dr2, c[n + ".conv2"].pkT, tab, k, cp)
+            dr1 = self._in_bwd(t["r%da" % l], t["st%da" % l], n + ".norm1", 0.0, da)
+            if l > 1:
+                self._wg_da(n + ".conv1", t["in%d" % l], dr1)
+                dP = K.da_conv2d_dgrad(dr1, c[n + ".conv1"].pkT, tab, k, cp)
+            else:
+                K.zero_(self._dw1pad)
+                self._wg_da(n + ".conv1", t["in1"], dr1, dw=self._dw1pad)
+        self._norm_grads("bwd_sunpose", B)
+        self._flush_wgrads()
+        cv = c["sun.sunlayer1.conv1"]      # rows of the three real input channels out of the padded kernel gradient
+        K.slice_channels(self._dw1pad.view(cv.kh * cv.kw, 32 * cv.cout), 0, cv.cin * cv.cout,
+                         out=g[cv.wkey].view(cv.kh * cv.kw, cv.cin * cv.cout))
+
     def _gradcam(self, t, pick_src):
         """grad_cam.layer x3 under gen_tape.stop_recording() (train.py:257-271): constants for the gradient."""
         w, c, cp = self.gs.w, self.conv, self.compute
@@ -329,6 +395,18 @@ class Trainer:
         df1 = K.fc_finalize(K.fc_dgrad(dz, self.fc2, cp), None, relu=False, mask_src=t["f1"])
         dP3 = K.fc_finalize(K.fc_dgrad(df1, self.fc1, cp)).reshape(B, h // 8, wd // 8, 128)
         w3 = K.spatial_sum(dP3, 1.0 / ((h // 4) * (wd // 4)))
+        if self.da_sun:
+            dP, sums = dP3, {}
+            for l in (3, 2):
+                n = "sun.sunlayer%d" % l
+                hl, wl = h >> (l - 1), wd >> (l - 1)
+                tab = self._da(hl, wl, 3)[1]
+                g_ = K.norm_act_bwd(t["r%db" % l], t["st%db" % l], w[n + ".norm2.gamma"], w[n + ".norm2.beta"], 0.0, dP, True)
+                g_ = K.da_conv2d_dgrad(g_, c[n + ".conv2"].pkT, tab, 3, cp)
+                g_ = K.norm_act_bwd(t["r%da" % l], t["st%da" % l], w[n + ".norm1.gamma"], w[n + ".norm1.beta"], 0.0, g_, False)
+                dP = K.da_conv2d_dgrad(g_, c[n + ".conv1"].pkT, tab, 3, cp)
+                sums[l - 1] = K.spatial_sum(dP, 1.0 / ((2 * hl) * (2 * wl)))
+            return K.grad_cam_map(t["A1"], sums[1]), K.grad_cam_map(t["A2"], sums[2]), K.grad_cam_map(t["A3"], w3)
         n3, n2 = "sun.sunlayer3", "sun.sunlayer2"
         if "s3" in t:
             _, _, dP2 = E.sun3_backward(t["s3"], dP3, c[n3 + ".conv1"].pkT, c[n3 + ".conv2"].pkT, w[n3 + ".norm1.gamma"],
@@ -512,6 +590,16 @@ class Trainer:
 
         def decode(sfx, residual):
             res_out = T["x"][-1]
+            if self.da_dec:       # distortion_aware_ops.deconv2d (:272-542): bilinear 2x resize, then the distortion-aware 3x3
+                c3, c2 = c["gen.conv3_" + sfx], c["gen.conv2_" + sfx]
+                u3 = K.up2x(res_out)
+                d3, s3 = K.da_conv2d(u3, c3.pk, c3.b, self._da(u3.shape[1], u3.shape[2])[0], cp, want_stats=True)
+                u2 = K.up2x(K.norm_apply(d3, s3, w["gen.norm3_%s.gamma" % sfx], w["gen.norm3_%s.beta" % sfx], slope=0.1))
+                d2, s2 = K.da_conv2d(u2, c2.pk, c2.b, self._da(u2.shape[1], u2.shape[2])[0], cp, want_stats=True)
+                xf1 = self._inxf(s2, "gen.norm2_" + sfx, 0.1)
+                y, _ = c["gen.conv1_" + sfx].fwd(d2, xf1, cp, out_slope=0.1, residual=residual, final_relu=True)
+                T["dec_" + sfx] = (d3, s3, u3, d2, s2, xf1, y, residual, u2)
+                return y
             d3, s3 = c["gen.conv3_" + sfx].fwd(res_out, compute=cp, want_stats=True)
             xf2 = self._inxf(s3, "gen.norm3_" + sfx, 0.1)
             d2, s2 = c["gen.conv2_" + sfx].fwd(d3, xf2, cp, want_stats=True)
@@ -654,6 +742,9 @@ class Trainer:
         @seg("bwd_sunpose", 2, ["bwd_head"])
         def _():
             t, dP = T["t"], T["dP3"]
+            if self.da_sun:
+                self._sunpose_bwd_da(t, dP, B)
+                return
             for l in (3, 2, 1):
                 n = "sun.sunlayer%d" % l
                 if l == 3 and "s3" in t:
@@ -674,7 +765,19 @@ class Trainer:
         @seg("bwd_dec", 0)
         def _():
             dres = T["dres"] = K.zero_(torch.empty_like(T["x"][-1]))
-            for sfx in ("f", "u"):
+            for sfx in ("f", "u") if self.da_dec else ():
+                d3, s3, u3, d2, s2, xf1, y, residual, u2 = T["dec_" + sfx]
+                dc = T["tails"][sfx][0]
+                self._wg("gen.conv1_" + sfx, d2, xf1, dc)
+                da2 = c["gen.conv1_" + sfx].dgrad(d2, dc, cp)
+                dd2 = self._in_bwd(d2, s2, "gen.norm2_" + sfx, 0.1, da2)
+                self._wg_da("gen.conv2_" + sfx, u2, dd2)
+                du2 = K.da_conv2d_dgrad(dd2, c["gen.conv2_" + sfx].pkT, self._da(u2.shape[1], u2.shape[2])[1], 3, cp)
+                dd3 = self._in_bwd(d3, s3, "gen.norm3_" + sfx, 0.1, K.up2x_bwd(du2))
+                self._wg_da("gen.conv3_" + sfx, u3, dd3)
+                du3 = K.da_conv2d_dgrad(dd3, c["gen.conv3_" + sfx].pkT, self._da(u3.shape[1], u3.shape[2])[1], 3, cp)
+                K.up2x_bwd(du3, 1.0, out=dres)
+            for sfx in () if self.da_dec else ("f", "u"):
                 d3, s3, xf2, d2, s2, xf1, y, residual = T["dec_" + sfx]
                 dc = T["tails"][sfx][0]
                 self._wg("gen.conv1_" + sfx, d2, xf1, dc)
@@ -998,10 +1101,12 @@ class SunPoseTrainer(Trainer):
     LOSSES = ("kl", "dog")
 
     def __init__(self, sun_params, device="cuda", lr=1e-4, im_height=32, im_width=128, precise=False, compute=BF16,
-                 world_size=1):
+                 world_size=1, distortion_aware=False):
         self.device = torch.device(device)
         self.h, self.w = im_height, im_width
         self.lr, self.compute, self.precise, self.world = lr, compute, precise, world_size
+        # distortion_aware: sunpose_net.py:11,16 - every sunposeLayer convolution is distortion_aware_ops.conv2d
+        self.da_sun, self._da_geo = bool(distortion_aware), {}
         self.gs = FlatParams(OrderedDict(("sun." + k, v) for k, v in sun_params.items()), self.device)
         self.adam_m, self.adam_v = torch.zeros_like(self.gs.grad), torch.zeros_like(self.gs.grad)
         self.steps_done = 0
@@ -1014,6 +1119,8 @@ class SunPoseTrainer(Trainer):
                 c[n] = _Conv(w[n + ".w"], w[n + ".b"], n + ".w", n + ".b", precise=precise, need_dgrad=not (l == 1 and j == 1))
         self.conv = c
         self.fc1, self.fc2 = PackedFC(w["sun.fc1.kernel"], precise), PackedFC(w["sun.fc2.kernel"], precise)
+        if self.da_sun:
+            self._init_da_sun()
 
     def step(self, ldr, sunpose_gt, update=True, want_cams=True, dog_weight=1.0):
         """ldr [B,H,W,3] BGR in [0,1], sunpose_gt [B,H*W].  Returns (pred [B,H,W,1], target image, [cam1,cam2,cam3]).
@@ -1033,7 +1140,7 @@ class SunPoseTrainer(Trainer):
         df1 = K.fc_finalize(K.fc_dgrad(dz, self.fc2, cp), None, relu=False, mask_src=t["f1"])
         fc_wgrad(t["flat"], df1, g["sun.fc1.kernel"], g["sun.fc1.bias"])
         dP = K.fc_finalize(K.fc_dgrad(df1, self.fc1, cp)).reshape(B, self.h // 8, self.w // 8, 128)
-        for l in (3, 2, 1):
+        for l in (3, 2, 1) if not self.da_sun else ():
             n = "sun.sunlayer%d" % l
             if l == 3 and "s3" in t:
                 dP = self._sun3_bwd(t, dP, B)
@@ -1045,8 +1152,11 @@ class SunPoseTrainer(Trainer):
             self._wg(n + ".conv1", t["in%d" % l], None, dr1)
             if l > 1:
                 dP = c[n + ".conv1"].dgrad(t["in%d" % l], dr1, cp)
-        self._norm_grads("bwd_sunpose", B)
-        self._flush_wgrads()
+        if self.da_sun:
+            self._sunpose_bwd_da(t, dP, B)
+        else:
+            self._norm_grads("bwd_sunpose", B)
+            self._flush_wgrads()
         if update:
             self.apply_gradients()
         return pred, gt_img, cams

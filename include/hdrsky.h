@@ -284,6 +284,9 @@ int hdrsky_sun_rad_bwd(const float* cmf, const void* gmax_bits, const float* gam
 int hdrsky_dense_heads_bwd(const float* x, const float* scale, const float* shift, float slope, int B, int F, int C, const float* kg, const float* kb, const float* dpre, float* dact, float* dkg, float* dkb, float* dbg, float* dbb, void* stream);
 /* out (+)= scale * x[..., c_off:c_off+c_take]  (gradient of tf.concat, discriminator.py:43). */
 int hdrsky_slice_channels(const float* x, size_t npix, int C, int c_off, int c_take, float scale, int accumulate, float* out, void* stream);
+/* out[npix][Cpad] = x[npix][C] followed by Cpad - C zero channels (the operand a distortion_aware_ops.conv2d with fewer
+ * than 32 input channels - sunpose_net.py:11 on the RGB image - is run on; also pads a filter's input-channel axis). */
+int hdrsky_pad_channels(const float* x, size_t npix, int C, int Cpad, float* out, void* stream);
 /* tf.concat([a, b], axis=-1) (discriminator.py:43). */
 int hdrsky_concat2(const float* a, int Ca, const float* b, int Cb, size_t npix, float* out, void* stream);
 /* x*255 - VGG_MEAN (vgg16.py:133-141). */

@@ -64,6 +64,39 @@ class _DAConv(torch.autograd.Function):
         return torch.from_numpy(dx), torch.from_numpy(dk).view_as(w), torch.from_numpy(db), None
 
 
+DA_PARTS = ("res", "sunpose", "decoders")
+
+
+def da_parts(spec):
+    """Which layer families run as distortion_aware_ops layers: False/None -> none; True -> the res blocks (generator.py:14,18,
+    the switch earlier rounds had); "all" or a comma list / iterable of DA_PARTS: "sunpose" = sunposeLayer.conv1/conv2
+    (sunpose_net.py:11,16), "decoders" = distortion_aware_ops.deconv2d (:272-542) in place of ops.deconv2d (generator.py:110-156)."""
+    if not spec:
+        return frozenset()
+    if spec is True:
+        return frozenset({"res"})
+    if isinstance(spec, str):
+        spec = DA_PARTS if spec == "all" else [t.strip() for t in spec.split(",") if t.strip()]
+    parts = frozenset(spec)
+    if not parts <= frozenset(DA_PARTS):
+        raise ValueError("distortion_aware: unknown part(s) %s" % sorted(parts - frozenset(DA_PARTS)))
+    return parts
+
+
+def _da_conv(p, wname, bname, x, dilation_rate=1):
+    """distortion_aware_ops.conv2d(filters, kernel_size=k) on x with the HWIO filter p[wname] as its [k*k*C, F] kernel."""
+    from . import da_ops
+    _, h, w, _ = x.shape
+    k = p[wname].shape[0]
+    return _DAConv.apply(x, p[wname], p[bname], da_ops.distortion(h, w, k, dilation_rate))
+
+
+def _deconv_da(p, name, x, out_h, out_w):
+    """distortion_aware_ops.deconv2d.call (:318-390): bilinear resize to output_imshape, then the distortion-aware conv at
+    the output resolution; same variables as ops.deconv2d (kernel_deconv2d / bias_deconv2d)."""
+    return _da_conv(p, name + ".kernel_deconv2d", name + ".bias_deconv2d", T.resize_bilinear(x, out_h, out_w))
+
+
 def res_block_da(p, prefix, x, dilation_rate=1):
     """The res block with the two lines generator.py:14,18 keeps commented out switched on: conv1 / conv2 are
     distortion_aware_ops.conv2d(filter_out, kernel_size=3, dilation_rate) (numpy restatement oracle/da_ops.py; its
@@ -86,26 +119,27 @@ def gen_encode(p, x, distortion_aware=False):
     a = T.leaky_relu(_inorm(p, "norm2_d", _conv(p, "conv2_d", a, 2)), 0.1)
     a = T.leaky_relu(_inorm(p, "norm3_d", _conv(p, "conv3_d", a, 2)), 0.1)
     for i in range(6):
-        a = res_block_da(p, "res.%d" % i, a) if distortion_aware else res_block(p, "res.%d" % i, a)
+        a = res_block_da(p, "res.%d" % i, a) if "res" in da_parts(distortion_aware) else res_block(p, "res.%d" % i, a)
     return a
 
 
-def _decode(p, sfx, x, h, w):
-    a = T.leaky_relu(_inorm(p, "norm3_" + sfx, _deconv(p, "conv3_" + sfx, x, h // 2, w // 2)), 0.1)
-    a = T.leaky_relu(_inorm(p, "norm2_" + sfx, _deconv(p, "conv2_" + sfx, a, h, w)), 0.1)
+def _decode(p, sfx, x, h, w, da=False):
+    dc = _deconv_da if da else _deconv
+    a = T.leaky_relu(_inorm(p, "norm3_" + sfx, dc(p, "conv3_" + sfx, x, h // 2, w // 2)), 0.1)
+    a = T.leaky_relu(_inorm(p, "norm2_" + sfx, dc(p, "conv2_" + sfx, a, h, w)), 0.1)
     return T.leaky_relu(_conv(p, "conv1_" + sfx, a), 0.1)
 
 
-def gen_sky_decode(p, x, inp):
+def gen_sky_decode(p, x, inp, distortion_aware=False):
     """generator.model.sky_decode (generator.py:110-125)."""
     h, w = inp.shape[1], inp.shape[2]
-    return torch.relu(inp + _decode(p, "f", x, h, w))
+    return torch.relu(inp + _decode(p, "f", x, h, w, "decoders" in da_parts(distortion_aware)))
 
 
-def gen_sun_decode(p, x, sun_rad):
+def gen_sun_decode(p, x, sun_rad, distortion_aware=False):
     """generator.model.sun_decode (generator.py:127-156); sun_cam* args are unused there."""
     h, w = sun_rad.shape[1], sun_rad.shape[2]
-    return torch.relu(sun_rad + _decode(p, "u", x, h, w))
+    return torch.relu(sun_rad + _decode(p, "u", x, h, w, "decoders" in da_parts(distortion_aware)))
 
 
 def _down(p, prefix, x, stride, apply_norm, training, new_stats):
@@ -163,18 +197,21 @@ def gen_sun_rad_estimation(p, ldr, cam1, cam2, cam3, sunpose_pred, training, new
 # ----------------------------------------------------------------------------
 # sunpose_net.py
 # ----------------------------------------------------------------------------
-def _sunpose_layer(p, prefix, x):
-    """sunposeLayer.call (sunpose_net.py:20-30)."""
-    a = torch.relu(_inorm(p, prefix + ".norm1", _conv(p, prefix + ".conv1", x)))
-    return torch.relu(_inorm(p, prefix + ".norm2", _conv(p, prefix + ".conv2", a)))
+def _sunpose_layer(p, prefix, x, da=False):
+    """sunposeLayer.call (sunpose_net.py:20-30); da: the commented-out lines :11,16 (distortion_aware_ops.conv2d with
+    kernel_size = k_h) instead of ops.conv2d."""
+    cv = (lambda n, t: _da_conv(p, n + ".w", n + ".b", t)) if da else (lambda n, t: _conv(p, n, t))
+    a = torch.relu(_inorm(p, prefix + ".norm1", cv(prefix + ".conv1", x)))
+    return torch.relu(_inorm(p, prefix + ".norm2", cv(prefix + ".conv2", a)))
 
 
-def sunpose_estimation(p, x):
+def sunpose_estimation(p, x, distortion_aware=False):
     """sunpose_net.model.sunposeEstimation (sunpose_net.py:54-72).
     Returns (softmax [B,H*W], [A1,A2,A3], logits-after-relu)."""
-    a1 = _sunpose_layer(p, "sunlayer1", x)
-    a2 = _sunpose_layer(p, "sunlayer2", T.maxpool2x2(a1))
-    a3 = _sunpose_layer(p, "sunlayer3", T.maxpool2x2(a2))
+    da = "sunpose" in da_parts(distortion_aware)
+    a1 = _sunpose_layer(p, "sunlayer1", x, da)
+    a2 = _sunpose_layer(p, "sunlayer2", T.maxpool2x2(a1), da)
+    a3 = _sunpose_layer(p, "sunlayer3", T.maxpool2x2(a2), da)
     flat = T.flatten_nhwc(T.maxpool2x2(a3))
     f1 = torch.relu(T.dense(flat, p["fc1.kernel"], p["fc1.bias"]))
     f2 = torch.relu(T.dense(f1, p["fc2.kernel"], p["fc2.bias"]))

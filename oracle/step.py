@@ -30,10 +30,10 @@ def generator_graph(gen, sun, ldr, y_index=None, training=False, new_stats=None,
     """
     b, h, w, _ = ldr.shape
     res_out = N.gen_encode(gen, ldr, distortion_aware=distortion_aware)   # generator.py:14,18 variant when set
-    sky_pred_gamma = N.gen_sky_decode(gen, res_out, ldr)
+    sky_pred_gamma = N.gen_sky_decode(gen, res_out, ldr, distortion_aware)
     sky_pred_lin = T.hdr_log_decompression(sky_pred_gamma)
 
-    cmf, (a1, a2, a3) = N.sunpose_estimation(sun, ldr)
+    cmf, (a1, a2, a3) = N.sunpose_estimation(sun, ldr, distortion_aware)
     sunpose_pred = cmf.reshape(-1, h, w, 1)
 
     alpha_c3 = _alpha_mask(sky_pred_lin).detach()
@@ -48,7 +48,7 @@ def generator_graph(gen, sun, ldr, y_index=None, training=False, new_stats=None,
     sun_rad_lin, gamma, beta = N.gen_sun_rad_estimation(gen, ldr, cam1, cam2, cam3, sunpose_pred,
                                                         training, new_stats)
     sun_rad_gamma = T.hdr_log_compression(sun_rad_lin)
-    sun_pred_gamma = N.gen_sun_decode(gen, res_out, sun_rad_gamma)
+    sun_pred_gamma = N.gen_sun_decode(gen, res_out, sun_rad_gamma, distortion_aware)
 
     sky_pred_gamma = (1.0 - alpha_c3) * sky_pred_gamma
     sky_pred_lin = T.hdr_log_decompression(sky_pred_gamma)
@@ -62,10 +62,10 @@ def generator_graph(gen, sun, ldr, y_index=None, training=False, new_stats=None,
                 sun_cam3=cam3, sun_rad_lin=sun_rad_lin, res_out=res_out, actv_maps=(a1, a2, a3))
 
 
-def inference(gen, sun, ldr):
+def inference(gen, sun, ldr, distortion_aware=False):
     """inference.py:81-119: returns y_final_lin [B,H,W,3] (BGR, linear radiance)."""
     req = {k: v.detach().clone().requires_grad_(True) for k, v in sun.items()}
-    out = generator_graph(gen, req, ldr, y_index=None, training=False)
+    out = generator_graph(gen, req, ldr, y_index=None, training=False, distortion_aware=distortion_aware)
     return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}
 
 
