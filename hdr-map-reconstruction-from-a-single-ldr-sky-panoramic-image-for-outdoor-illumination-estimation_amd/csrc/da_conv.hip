@@ -23,6 +23,7 @@ struct DaArgs {
   float* stats;       // optional [B][tiles per sample][2][Cout] (sum, sum of squares) of y per 64-pixel tile, like the conv epilogue
   int B, H, W, Cin, Cout, Npad, ksize, k2, pad, in_h, in_w, cin32, nblocks, tiles_x;
   int tab_off, use_tab;     // LDS byte offset of the per-(pixel, tap) sample table behind the A tiles; 0: computed per item
+  int tpr, nrounds;         // filter taps blended per barrier round (their channels side by side in the A tile), rounds
   // general sample table (data gradient: the TRANSPOSE of the gather is again a weighted gather, with up to KM source
   // pixels per (pixel, tap)): gidx / gw [H*W][k*k][KM] = source pixel index (row-major, -1 = none) and weight
   const int* gidx;
@@ -42,9 +43,11 @@ __global__ void __launch_bounds__(NWV * 64) da_conv_kernel(const DaArgs a) {
   // IMAX: (pixel, chunk) items per thread and tap: Cin <= 8*IMAX*NT/TM
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, lr = lane & 15;
-  const int nq = a.Cin >> 3;
+  const int nq = a.Cin >> 3;                                  // 8-channel groups of one tap
+  const int nqr = nq * a.tpr;                                 // ... of one round: tpr taps side by side (a layer with few
+                                                              // input channels would otherwise pay a barrier per MFMA)
   const int plane = TM + 1;                                   // 16-byte units per channel-chunk plane
-  const int buf_units = nq * plane * (PRECISE ? 2 : 1);
+  const int buf_units = nqr * plane * (PRECISE ? 2 : 1);
   uint4* sA = reinterpret_cast<uint4*>(smem);
 
   int bid = blockIdx.x;
@@ -52,7 +55,7 @@ __global__ void __launch_bounds__(NWV * 64) da_conv_kernel(const DaArgs a) {
   const int tile = bid % a.tiles_x, b = bid / a.tiles_x;      // tiles_x = tiles per sample
   const int p0 = tile * TM, n0 = nb * (NWV * 16);
   const int npix = a.H * a.W;
-  const int nitems = TM * nq;
+  const int nitems = TM * nqr;
 
   f32x4_t acc[4];
 #pragma unroll
@@ -116,12 +119,15 @@ __global__ void __launch_bounds__(NWV * 64) da_conv_kernel(const DaArgs a) {
 
   float cr0[IMAX][KM][8], cw0[IMAX][KM];    // source pixels of this thread's items for the tap in flight / their weights
 
-  auto gather = [&](int tn, float (&cr)[IMAX][KM][8], float (&cw)[IMAX][KM]) {
+  auto gather = [&](int rnd, float (&cr)[IMAX][KM][8], float (&cw)[IMAX][KM]) {
 #pragma unroll
     for (int it = 0; it < IMAX; ++it) {
       const int i = it * NT + tid;
       if (i < nitems) {
-        const int m = i / nq, q = i % nq;
+        const int m = i / nqr, qr = i % nqr;
+        const int tsub = qr / nq, q = qr - tsub * nq;
+        const bool tap_ok = rnd * a.tpr + tsub < a.k2;            // the last round of a 7x7 layer is partly empty
+        const int tn = tap_ok ? rnd * a.tpr + tsub : a.k2 - 1;
         int o[KM]; float w[KM];
         if constexpr (KM != 4) {
           const int pix = min(p0 + m, npix - 1);
@@ -151,16 +157,18 @@ __global__ void __launch_bounds__(NWV * 64) da_conv_kernel(const DaArgs a) {
           const float4 lo = *reinterpret_cast<const float4*>(pp), hi = *reinterpret_cast<const float4*>(pp + 4);
           cr[it][k][0] = lo.x; cr[it][k][1] = lo.y; cr[it][k][2] = lo.z; cr[it][k][3] = lo.w;
           cr[it][k][4] = hi.x; cr[it][k][5] = hi.y; cr[it][k][6] = hi.z; cr[it][k][7] = hi.w;
-          cw[it][k] = w[k];
+          cw[it][k] = tap_ok ? w[k] : 0.f;
         }
       }
     }
   };
-  auto load_b = [&](int tn) {   // this wave's filter fragments of tap tn (registers, one tap ahead)
+  const int ksteps = a.k2 * a.cin32;      // 32-channel k-steps of the whole filter, tap-major
+  const int spr = a.tpr * a.cin32;        // ... per round
+  auto load_b = [&](int rnd) {   // this wave's filter fragments of round rnd (registers, one round ahead)
 #pragma unroll
     for (int cb = 0; cb < CBMAX; ++cb)
-      if (cb < a.cin32) {
-        const size_t o = (size_t)((tn * a.cin32 + cb) * 4) * a.Npad;
+      if (cb < spr && rnd * spr + cb < ksteps) {
+        const size_t o = (size_t)((rnd * spr + cb) * 4) * a.Npad;
         bnh[cb] = wlh[o];
         if (PRECISE) bnl[cb] = wll[o];
       }
@@ -172,7 +180,7 @@ __global__ void __launch_bounds__(NWV * 64) da_conv_kernel(const DaArgs a) {
     for (int it = 0; it < IMAX; ++it) {
       const int i = it * NT + tid;
       if (i < nitems) {
-        const int m = i / nq, q = i % nq;
+        const int m = i / nqr, q = i % nqr;
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -183,20 +191,20 @@ __global__ void __launch_bounds__(NWV * 64) da_conv_kernel(const DaArgs a) {
         uint4 h8, l8;
         pack8<PRECISE>(v, h8, l8);
         buf[q * plane + m] = h8;
-        if (PRECISE) buf[nq * plane + q * plane + m] = l8;
+        if (PRECISE) buf[nqr * plane + q * plane + m] = l8;
       }
     }
     __syncthreads();   // tile t staged; also: every wave is past the MFMAs of tile t-1, so buffer (t+1)&1 is free
-    if (t + 1 < a.k2) gather(t + 1, cr, cw);
-    if (BPF && t + 1 < a.k2) load_b(t + 1);
+    if (t + 1 < a.nrounds) gather(t + 1, cr, cw);
+    if (BPF && t + 1 < a.nrounds) load_b(t + 1);
     // ---- MFMA: Cin/32 k-steps, 4 pixel fragments x this wave's 16 filters -----------------------------------
 #pragma unroll
     for (int cb = 0; cb < CBMAX; ++cb) {
-      if (cb >= a.cin32) break;
+      if (cb >= spr || t * spr + cb >= ksteps) break;
       uint4 bh, bl = uint4{0, 0, 0, 0};
       if (BPF) { bh = bch[cb]; if (PRECISE) bl = bcl[cb]; }
       else {
-        const size_t o = (size_t)((t * a.cin32 + cb) * 4) * a.Npad;
+        const size_t o = (size_t)((t * spr + cb) * 4) * a.Npad;
         bh = wlh[o];
         if (PRECISE) bl = wll[o];
       }
@@ -204,7 +212,7 @@ __global__ void __launch_bounds__(NWV * 64) da_conv_kernel(const DaArgs a) {
       for (int mi = 0; mi < 4; ++mi) {
         const uint4 ah = buf[(cb * 4 + kq) * plane + mi * 16 + lr];
         if (PRECISE) {
-          const uint4 al = buf[nq * plane + (cb * 4 + kq) * plane + mi * 16 + lr];
+          const uint4 al = buf[nqr * plane + (cb * 4 + kq) * plane + mi * 16 + lr];
           acc[mi] = mfma16(al, bh, acc[mi]);
           acc[mi] = mfma16(ah, bl, acc[mi]);
         }
@@ -223,7 +231,7 @@ __global__ void __launch_bounds__(NWV * 64) da_conv_kernel(const DaArgs a) {
 #pragma unroll
     for (int cb = 0; cb < CBMAX; ++cb) { bch[cb] = bnh[cb]; if (PRECISE) bcl[cb] = bnl[cb]; }
   }
-  for (int t = 0; t < a.k2; ++t) round(t, cr0, cw0);
+  for (int t = 0; t < a.nrounds; ++t) round(t, cr0, cw0);
   // ---- epilogue: + bias, store -------------------------------------------------------------------------------
   const int n = n0 + wave * 16 + lr;
   float s1 = 0.f, s2 = 0.f;
@@ -309,6 +317,20 @@ __global__ void __launch_bounds__(256) da_gather_scatter_kernel(const DaGsArgs a
   }
 }
 
+// Taps per barrier round for a layer with C input channels on nwv waves when a thread may hold up to imax_max (pixel,
+// 8-channel) items per round; returns whether two items per thread suffice (the smaller register variant of the forward).
+// HDRSKY_DA_TPR caps it (1 = one tap per round, the layout before): tuning / test hook.
+static bool da_taps_per_round(int C, int nwv, int k2, int imax_max, int* tpr) {
+  const int nq = C / 8;
+  int cap = imax_max * nwv;                 // 8-channel groups per round: imax * (64 nwv threads) / 64 pixels
+  int t = cap / nq;
+  if (t < 1) t = 1;
+  if (t > k2) t = k2;
+  if (const char* e = getenv("HDRSKY_DA_TPR")) { const int lim = atoi(e); if (lim >= 1 && t > lim) t = lim; }
+  *tpr = t;
+  return t * nq <= 2 * nwv;
+}
+
 static int da_gs_launch(bool scatter, const float* src, const float* offs, int B, int H, int W, int C, int ksize, float* dst,
                         void* stream) {
   if (!src || !offs || !dst || (ksize & 1) == 0 || (C & 7)) return HDRSKY_EINVAL;
@@ -391,7 +413,10 @@ int hdrsky_da_conv2d_fwd(const float* x, const void* w_hi, const void* w_lo, con
   const int nwv = Cout > 64 ? 8 : 4;
   a.cin32 = Cin / 32; a.nblocks = cdiv(Cout, nwv * 16); a.tiles_x = cdiv(H * W, 64);
   if (64 * (Cin / 8) > 4 * nwv * 64) return HDRSKY_EUNSUPPORTED;   // register prefetch budget (Cin <= 128 / 256)
-  const int lds = 2 * (Cin / 8) * 65 * 16 * (precise ? 2 : 1);
+  // taps per round: as many as the per-round capacity (IMAX items per thread = 8 * IMAX * nwv channels) holds
+  const bool imax2 = da_taps_per_round(Cin, nwv, a.k2, 4, &a.tpr);
+  a.nrounds = cdiv(a.k2, a.tpr);
+  const int lds = 2 * a.tpr * (Cin / 8) * 65 * 16 * (precise ? 2 : 1);
   if (lds > 152 * 1024) return HDRSKY_EUNSUPPORTED;          // + 5 KB of static LDS (the tile's offset table)
   a.tab_off = lds;
   a.use_tab = (lds + 64 * a.k2 * 32 <= 152 * 1024) ? 1 : 0;      // sample table: 32 B per (pixel, tap); 7x7 in BF16X3 does not fit
@@ -411,7 +436,6 @@ int hdrsky_da_conv2d_fwd(const float* x, const void* w_hi, const void* w_lo, con
     hipLaunchKernelGGL(k, dim3(grid), dim3(NWV_ * 64), lds_launch, (hipStream_t)stream, a);                              \
   }
 #define HDRSKY_DA_LAUNCH(PREC_, NWV_) { if (imax2) HDRSKY_DA_LAUNCH_(PREC_, NWV_, 2) else HDRSKY_DA_LAUNCH_(PREC_, NWV_, 4) }
-  const bool imax2 = 64 * (Cin / 8) <= 2 * nwv * 64;   // two items per thread suffice: half the gather registers
   if (precise) { if (nwv == 8) HDRSKY_DA_LAUNCH(true, 8) else HDRSKY_DA_LAUNCH(true, 4) }
   else { if (nwv == 8) HDRSKY_DA_LAUNCH(false, 8) else HDRSKY_DA_LAUNCH(false, 4) }
 #undef HDRSKY_DA_LAUNCH
@@ -470,7 +494,9 @@ int hdrsky_da_conv2d_dgrad(const float* dy, const void* wT_hi, const void* wT_lo
   const int nwv = (C > 64 || F > 64) ? 8 : 4;
   a.cin32 = F / 32; a.nblocks = cdiv(C, nwv * 16); a.tiles_x = cdiv(H * W, 64);
   if (64 * (F / 8) > 2 * nwv * 64) return HDRSKY_EUNSUPPORTED;
-  const int lds = 2 * (F / 8) * 65 * 16 * (precise ? 2 : 1);
+  da_taps_per_round(F, nwv, a.k2, 2, &a.tpr);
+  a.nrounds = cdiv(a.k2, a.tpr);
+  const int lds = 2 * a.tpr * (F / 8) * 65 * 16 * (precise ? 2 : 1);
   if (lds > 152 * 1024) return HDRSKY_EUNSUPPORTED;
   if ((64 / W + 2) * a.k2 > 5 * 128) return HDRSKY_EUNSUPPORTED;
   a.tab_off = lds; a.use_tab = 0;

@@ -166,3 +166,10 @@ def test_da_conv_other_kernel_sizes_and_sample_table(dev, k, shape):
     finally:
         os.environ.pop("HDRSKY_DA_TAB", None)
     assert torch.equal(y, y_n) and torch.equal(y16, y16_n)
+    try:      # several taps per barrier round (layers with few input channels) vs one: the same MFMA sequence
+        os.environ["HDRSKY_DA_TPR"] = "1"
+        y_1 = K.da_conv2d(d(x), pw, d(bias), d(offs), K.BF16X3)
+        y16_1 = K.da_conv2d(d(x), pw, d(bias), d(offs), K.BF16)
+    finally:
+        os.environ.pop("HDRSKY_DA_TPR", None)
+    assert torch.equal(y, y_1) and torch.equal(y16, y16_1)

@@ -127,5 +127,6 @@ def test_sunpose_pretraining_step_distortion_aware(dev):
     print("worst:", worst[:4], "cosine", dot / (n1 * n2))
     # the contraction error is fp32-class; single ReLU / max-pool mask flips move individual elements at the 1e-2 level
     # (test_train_gpu.test_sunpose_pretraining_step_matches_oracle picks a batch with a margin; this one does not)
-    assert worst[0][0] < 1e-1 and np.median([e for e, _ in worst]) < 3e-3, worst[:4]
-    assert dot / (n1 * n2) > 0.9995
+    # (the layers' own backward kernels are held to 5e-2 / 3e-3 by test_train_step_all_distortion_aware; here: the plumbing)
+    assert worst[0][0] < 1e-1 and np.median([e for e, _ in worst]) < 1.5e-2, worst[:4]
+    assert dot / (n1 * n2) > 0.9998
