@@ -39,7 +39,11 @@ def run(steps=40):
 base = [run() for _ in range(2)]
 print("baseline %.4f %.4f ms" % tuple(base), flush=True)
 base = min(base)
-names = sys.argv[1:] or [n for n in L.SIGNATURES if L.SIGNATURES[n][0] is L.c_int and not n.endswith("_supported")]
+# Default: entry points whose outputs nothing downstream uses as an index.  Removing a producer of index data (pooling
+# routes, arg-max bins, gather tables) makes its consumers read out of bounds - a GPU memory fault: never ablate those.
+SAFE = ["hdrsky_conv2d_wgrad_multi_det", "hdrsky_norm_act_bwd", "hdrsky_rmsprop_fc_fused", "hdrsky_rmsprop",
+        "hdrsky_fc_dgrad", "hdrsky_dgb_reduce", "hdrsky_bn_act_bwd", "hdrsky_affine_act_bwd", "hdrsky_conv_pack_weights_multi"]
+names = sys.argv[1:] or SAFE
 rows = []
 for n in names:
     real = getattr(lib, n)
