@@ -326,45 +326,66 @@ __global__ void __launch_bounds__(256) norm_act_bwd_kernel(const float* __restri
 // whole batch tensor) via an order-independent integer atomicMax on the (positive) float bits.
 // One block per row.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) softmax_head_kernel(const float* __restrict__ part, int nsplit, int M, int N,
-                                                           const float* __restrict__ bias, float* __restrict__ z,
-                                                           float* __restrict__ cmf, unsigned int* gmax_bits) {
-  __shared__ float sred[4];
-  const int m = blockIdx.x;
-  extern __shared__ float srow[];  // N floats
-  float lmax = -INFINITY;
-  for (int n = threadIdx.x; n < N; n += 256) {
-    float v = bias ? bias[n] : 0.f;
-    for (int s = 0; s < nsplit; ++s) v += part[((size_t)s * M + m) * N + n];
-    v = fmaxf(v, 0.f);
-    srow[n] = v;
-    if (z) z[(size_t)m * N + n] = v;
-    lmax = fmaxf(lmax, v);
+// One 1024-thread block per row; a thread owns float4 groups n4 = tid, tid + 1024, ... (RV of them, 4 at N = 16384:
+// everything stays in registers, the split-R partials of a group are 16-byte loads issued together).
+template <int RV>
+__global__ void __launch_bounds__(1024) softmax_head_kernel(const float* __restrict__ part, int nsplit, int M, int N,
+                                                            const float* __restrict__ bias, float* __restrict__ z,
+                                                            float* __restrict__ cmf, unsigned int* gmax_bits) {
+  __shared__ float sred[16];
+  const int m = blockIdx.x, tid = threadIdx.x, n4 = N >> 2;
+  float4 v[RV];
+  float lmax = 0.f;                                   // relu output: >= 0
+#pragma unroll
+  for (int r = 0; r < RV; ++r) {
+    const int q = tid + r * 1024;
+    v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < n4) {
+      float4 a = bias ? reinterpret_cast<const float4*>(bias)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int s = 0; s < nsplit; ++s) {              // summation order as in fc_finalize: bias, then slices ascending
+        const float4 t = reinterpret_cast<const float4*>(part + ((size_t)s * M + m) * N)[q];
+        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+      }
+      a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
+      v[r] = a;
+      if (z) reinterpret_cast<float4*>(z + (size_t)m * N)[q] = a;
+      lmax = fmaxf(lmax, fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)));
+    }
   }
   lmax = wave_max(lmax);
-  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = lmax;
+  if ((tid & 63) == 0) sred[tid >> 6] = lmax;
   __syncthreads();
-  const float rmax = fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3]));
+  float rmax = sred[0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) rmax = fmaxf(rmax, sred[w]);
   __syncthreads();
   float lsum = 0.f;
-  for (int n = threadIdx.x; n < N; n += 256) {
-    const float e = expf(srow[n] - rmax);
-    srow[n] = e;
-    lsum += e;
+#pragma unroll
+  for (int r = 0; r < RV; ++r) {
+    if (tid + r * 1024 < n4) {
+      v[r].x = expf(v[r].x - rmax); v[r].y = expf(v[r].y - rmax); v[r].z = expf(v[r].z - rmax); v[r].w = expf(v[r].w - rmax);
+      lsum += (v[r].x + v[r].y) + (v[r].z + v[r].w);
+    }
   }
   lsum = wave_sum(lsum);
-  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = lsum;
+  if ((tid & 63) == 0) sred[tid >> 6] = lsum;
   __syncthreads();
-  const float rsum = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+  float rsum = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) rsum += sred[w];
   float pmax = 0.f;
-  for (int n = threadIdx.x; n < N; n += 256) {
-    const float p = srow[n] / rsum;
-    cmf[(size_t)m * N + n] = p;
-    pmax = fmaxf(pmax, p);
+#pragma unroll
+  for (int r = 0; r < RV; ++r) {
+    const int q = tid + r * 1024;
+    if (q < n4) {
+      const float4 pv = make_float4(v[r].x / rsum, v[r].y / rsum, v[r].z / rsum, v[r].w / rsum);
+      reinterpret_cast<float4*>(cmf + (size_t)m * N)[q] = pv;
+      pmax = fmaxf(pmax, fmaxf(fmaxf(pv.x, pv.y), fmaxf(pv.z, pv.w)));
+    }
   }
   if (gmax_bits) {
     pmax = wave_max(pmax);
-    if ((threadIdx.x & 63) == 0) atomicMax(gmax_bits, __float_as_uint(pmax));
+    if ((tid & 63) == 0) atomicMax(gmax_bits, __float_as_uint(pmax));
   }
 }
 
@@ -372,17 +393,17 @@ __global__ void __launch_bounds__(256) softmax_head_kernel(const float* __restri
 //   dz_j = y_c * ((j == idx) - cmf_j) * [z_j > 0]
 // idx_m = first argmax of pick_src[m, :] (cmf itself at inference, inference.py:98;
 // sunpose_gt in training, train.py:265-267).
-__global__ void __launch_bounds__(256) softmax_pick_bwd_kernel(const float* __restrict__ cmf,
-                                                               const float* __restrict__ z,
-                                                               const float* __restrict__ pick_src, int N,
-                                                               float* __restrict__ dz, int* __restrict__ idx_out) {
-  __shared__ float sv[4];
-  __shared__ int si[4];
-  const int m = blockIdx.x;
+__global__ void __launch_bounds__(1024) softmax_pick_bwd_kernel(const float* __restrict__ cmf,
+                                                                const float* __restrict__ z,
+                                                                const float* __restrict__ pick_src, int N,
+                                                                float* __restrict__ dz, int* __restrict__ idx_out) {
+  __shared__ float sv[16];
+  __shared__ int si[16];
+  const int m = blockIdx.x, tid = threadIdx.x;
   const float* pr = pick_src + (size_t)m * N;
   float best = -INFINITY;
   int bi = 0x7fffffff;
-  for (int n = threadIdx.x; n < N; n += 256) {
+  for (int n = tid; n < N; n += 1024) {           // ascending n per thread: strict > keeps the first maximum
     const float v = pr[n];
     if (v > best) { best = v; bi = n; }
   }
@@ -392,14 +413,14 @@ __global__ void __launch_bounds__(256) softmax_pick_bwd_kernel(const float* __re
     const int oi = __shfl_xor(bi, o);
     if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
   }
-  if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
+  if ((tid & 63) == 0) { sv[tid >> 6] = best; si[tid >> 6] = bi; }
   __syncthreads();
   best = sv[0]; bi = si[0];
-  for (int w = 1; w < 4; ++w)
+  for (int w = 1; w < 16; ++w)
     if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
   const float yc = cmf[(size_t)m * N + bi];
-  if (threadIdx.x == 0 && idx_out) idx_out[m] = bi;
-  for (int n = threadIdx.x; n < N; n += 256) {
+  if (tid == 0 && idx_out) idx_out[m] = bi;
+  for (int n = tid; n < N; n += 1024) {
     const float p = cmf[(size_t)m * N + n];
     const float g = yc * ((n == bi ? 1.f : 0.f) - p);
     dz[(size_t)m * N + n] = z[(size_t)m * N + n] > 0.f ? g : 0.f;
@@ -765,17 +786,13 @@ int hdrsky_norm_act_bwd(const float* x, const float* part, int nparts, const flo
 int hdrsky_softmax_head(const float* part, int nsplit, int M, int N, const float* bias, float* z, float* cmf,
                         void* gmax_bits, void* stream) {
   if (!part || !cmf) return HDRSKY_EINVAL;
-  if (N * (int)sizeof(float) > 150 * 1024) return HDRSKY_EUNSUPPORTED;   // one row of logits is staged in LDS
-  if (N * (int)sizeof(float) > 48 * 1024) {
-    static bool set = false;
-    if (!set) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(softmax_head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              152 * 1024) != hipSuccess) return HDRSKY_ELAUNCH;   // (the kernel also has a few static words)
-      set = true;
-    }
-  }
-  hipLaunchKernelGGL(softmax_head_kernel, dim3(M), dim3(256), N * sizeof(float), (hipStream_t)stream, part, nsplit, M,
-                     N, bias, z, cmf, (unsigned int*)gmax_bits);
+  if ((N & 3) || N > 4 * 4 * 1024) return HDRSKY_EUNSUPPORTED;   // a row lives in the registers of one 1024-thread block
+  if (N <= 4096)
+    hipLaunchKernelGGL(softmax_head_kernel<1>, dim3(M), dim3(1024), 0, (hipStream_t)stream, part, nsplit, M, N, bias, z, cmf,
+                       (unsigned int*)gmax_bits);
+  else
+    hipLaunchKernelGGL(softmax_head_kernel<4>, dim3(M), dim3(1024), 0, (hipStream_t)stream, part, nsplit, M, N, bias, z, cmf,
+                       (unsigned int*)gmax_bits);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }
@@ -783,7 +800,7 @@ int hdrsky_softmax_head(const float* part, int nsplit, int M, int N, const float
 int hdrsky_softmax_pick_bwd(const float* cmf, const float* z, const float* pick_src, int M, int N, float* dz,
                             int* idx_out, void* stream) {
   if (!cmf || !z || !pick_src || !dz) return HDRSKY_EINVAL;
-  hipLaunchKernelGGL(softmax_pick_bwd_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, cmf, z, pick_src, N, dz,
+  hipLaunchKernelGGL(softmax_pick_bwd_kernel, dim3(M), dim3(1024), 0, (hipStream_t)stream, cmf, z, pick_src, N, dz,
                      idx_out);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
