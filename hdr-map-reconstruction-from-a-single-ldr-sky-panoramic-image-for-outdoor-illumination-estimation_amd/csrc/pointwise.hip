@@ -430,8 +430,9 @@ __global__ void __launch_bounds__(1024) softmax_pick_bwd_kernel(const float* __r
 // y[m][n] = (sum_s part[s][m][n] + bias[n]) with optional relu and optional mask [mask_src > 0]
 __global__ void fc_finalize_kernel(const float* __restrict__ part, int nsplit, int M, int N,
                                    const float* __restrict__ bias, int relu, const float* __restrict__ mask_src,
-                                   float* __restrict__ y) {
+                                   float* __restrict__ y, unsigned int* __restrict__ zero_word) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && zero_word) *zero_word = 0u;      // the max accumulator of a later hdrsky_softmax_head: no memset launch
   if (i >= M * N) return;
   float v = bias ? bias[i % N] : 0.f;
   for (int s = 0; s < nsplit; ++s) v += part[(size_t)s * M * N + i];
@@ -465,12 +466,16 @@ __global__ void __launch_bounds__(256) cam_kernel(const float* __restrict__ A, c
                                                   float* __restrict__ cam) {
   extern __shared__ float sw[];
   const int b = blockIdx.y;
-  // w_nparts == 0: w is a [B][C] table; else w is a conv statistics tensor [B][nparts][2][C] whose sum plane is
-  // reduced here (the GAP of the activation gradient, grad_cam.py:34)
+  // w_nparts == 0: w is a [B][C] table; > 0: w is a conv statistics tensor [B][nparts][2][C] whose sum plane is
+  // reduced here (the GAP of the activation gradient, grad_cam.py:34); < 0: w is the gradient map itself,
+  // [B][-nparts pixels][C] (a small one: every block of a sample repeats the sum)
   for (int c = threadIdx.x; c < C; c += 256) {
     float t;
     if (w_nparts == 0) t = w[(size_t)b * C + c];
-    else {
+    else if (w_nparts < 0) {
+      t = 0.f;
+      for (int p = 0; p < -w_nparts; ++p) t += w[((size_t)b * (-w_nparts) + p) * C + c];
+    } else {
       t = 0.f;
       for (int p = 0; p < w_nparts; ++p) t += w[((size_t)(b * w_nparts + p) * 2) * C + c];
     }
@@ -807,10 +812,10 @@ int hdrsky_softmax_pick_bwd(const float* cmf, const float* z, const float* pick_
 }
 
 int hdrsky_fc_finalize(const float* part, int nsplit, int M, int N, const float* bias, int relu, const float* mask_src,
-                       float* y, void* stream) {
+                       float* y, void* zero_word, void* stream) {
   if (!part || !y) return HDRSKY_EINVAL;
   hipLaunchKernelGGL(fc_finalize_kernel, dim3(cdiv(M * N, 256)), dim3(256), 0, (hipStream_t)stream, part, nsplit, M, N,
-                     bias, relu, mask_src, y);
+                     bias, relu, mask_src, y, (unsigned int*)zero_word);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }
@@ -824,7 +829,7 @@ int hdrsky_spatial_sum(const float* x, int B, int P, int C, float scale, float* 
 
 int hdrsky_grad_cam(const float* A, const float* w, int w_nparts, float w_scale, int B, int P, int C, float* cam,
                     void* stream) {
-  if (!A || !w || !cam || (C & 3) || C > 256 || (256 % (C / 4)) != 0 || w_nparts < 0) return HDRSKY_EINVAL;
+  if (!A || !w || !cam || (C & 3) || C > 256 || (256 % (C / 4)) != 0 || w_nparts < -256) return HDRSKY_EINVAL;
   const int ppb = 256 / (C / 4);
   int gx = cdiv(P, ppb); if (gx > 64) gx = 64;
   hipLaunchKernelGGL(cam_kernel, dim3(gx, B), dim3(256), C * sizeof(float), (hipStream_t)stream, A, w, w_nparts, w_scale,

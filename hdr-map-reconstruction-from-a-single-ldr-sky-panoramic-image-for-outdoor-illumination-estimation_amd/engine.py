@@ -200,9 +200,9 @@ def sunpose_forward(nets, ldr, compute, distortion_aware=False):
     B = ldr.shape[0]
     flat = x.reshape(B, -1)
     t["flat"] = flat
-    t["f1"] = K.fc_finalize(K.fc_fwd(flat, pk["sun.fc1"], compute), s["fc1.bias"], relu=True)
+    t["gmax"] = torch.empty(1, dtype=torch.int32, device=ldr.device)      # cleared by the finalize launch below
+    t["f1"] = K.fc_finalize(K.fc_fwd(flat, pk["sun.fc1"], compute), s["fc1.bias"], relu=True, zero_word=t["gmax"])
     part2 = K.fc_fwd(t["f1"], pk["sun.fc2"], compute)
-    t["gmax"] = K.zero_(torch.empty(1, dtype=torch.int32, device=ldr.device))
     t["z"], t["cmf"] = K.softmax_head(part2, s["fc2.bias"], t["gmax"])
     return t
 
@@ -218,7 +218,9 @@ def gradcam_sweep(nets, t, pick_src, compute):
     df1 = K.fc_finalize(K.fc_dgrad(dz, pk["sun.fc2"], compute), None, relu=False, mask_src=t["f1"])
     dflat = K.fc_finalize(K.fc_dgrad(df1, pk["sun.fc1"], compute))
     dP3 = dflat.reshape(B, h // 8, w // 8, 128)
-    w3 = K.spatial_sum(dP3, 1.0 / ((h // 4) * (w // 4)))
+    small = (h // 8) * (w // 8) <= 256        # cam3's GAP weights: summed inside its own launch when the map is small
+    w3 = dP3 if small else K.spatial_sum(dP3, 1.0 / ((h // 4) * (w // 4)))
+    s3 = 1.0 / ((h // 4) * (w // 4)) if small else 1.0
     if t.get("da"):
         dP = dP3
         sums = {}
@@ -231,7 +233,7 @@ def gradcam_sweep(nets, t, pick_src, compute):
             g = K.norm_act_bwd(t["r%da" % l], t["st%da" % l], s[n + ".norm1.gamma"], s[n + ".norm1.beta"], 0.0, g, False)
             dP = K.da_conv2d_dgrad(g, pk["sun." + n + ".conv1.T"], tab, 3, compute)       # gradient at the pooled map below
             sums[l - 1] = K.spatial_sum(dP, 1.0 / ((2 * hl) * (2 * wl)))
-        return K.grad_cam_map(t["A1"], sums[1]), K.grad_cam_map(t["A2"], sums[2]), K.grad_cam_map(t["A3"], w3)
+        return K.grad_cam_map(t["A1"], sums[1]), K.grad_cam_map(t["A2"], sums[2]), K.grad_cam_map(t["A3"], w3, s3)
     # layer 3 backward: pool3 + relu + IN2 -> dgrad conv2 -> relu + IN1 -> dgrad conv1
     if "s3" in t:
         _, _, dP2 = sun3_backward(t["s3"], dP3, pk["sun.sunlayer3.conv1.T"], pk["sun.sunlayer3.conv2.T"],
@@ -249,7 +251,7 @@ def gradcam_sweep(nets, t, pick_src, compute):
     _, sP1 = K.conv2d(g, pk["sun.sunlayer2.conv1.T"], None, compute=compute, want_stats=True)
     # GAP of d y_c / d A_k == sum of the pooled-map gradient / (H_k*W_k): the dgrad conv's per-tile sums
     cam2 = K.grad_cam_map(t["A2"], sP2) if "s3" in t else K.grad_cam_map(t["A2"], sP2, 1.0 / ((h // 2) * (w // 2)))
-    return (K.grad_cam_map(t["A1"], sP1, 1.0 / (h * w)), cam2, K.grad_cam_map(t["A3"], w3))
+    return (K.grad_cam_map(t["A1"], sP1, 1.0 / (h * w)), cam2, K.grad_cam_map(t["A3"], w3, s3))
 
 
 def encode(nets, ldr, compute, distortion_aware=False, dilation_rate=1):

@@ -369,7 +369,8 @@ def fc_dgrad(dy, pf: PackedFC, compute=BF16):
     return out
 
 
-def fc_finalize(part, bias=None, relu=False, mask_src=None):
+def fc_finalize(part, bias=None, relu=False, mask_src=None, zero_word=None):
+    """zero_word: an int32[1] tensor this launch clears (softmax_head's max accumulator further down the chain)."""
     ns, M, N = part.shape
     _f32(part)
     y = torch.empty((M, N), dtype=torch.float32, device=part.device)
@@ -377,8 +378,8 @@ def fc_finalize(part, bias=None, relu=False, mask_src=None):
         _f32(bias, N)
     if mask_src is not None:
         _f32(mask_src, M, N)
-    L.check(L.load().hdrsky_fc_finalize(_p(part), ns, M, N, _p(bias), int(relu), _p(mask_src), _p(y), _stream()),
-            "fc_finalize")
+    L.check(L.load().hdrsky_fc_finalize(_p(part), ns, M, N, _p(bias), int(relu), _p(mask_src), _p(y), _p(zero_word),
+                                        _stream()), "fc_finalize")
     return y
 
 
@@ -420,6 +421,10 @@ def grad_cam_map(A, w, scale=1.0):
     if isinstance(w, Stats):
         _f32(w.part, B, w.nparts, 2, C)
         wp, nparts = w.part, w.nparts
+    elif w.dim() == 4:      # the activation gradient itself [B,h,w,C] (a small map): its spatial sum is taken in the launch
+        if w.shape[0] != B or w.shape[3] != C or w.shape[1] * w.shape[2] > 256:
+            raise ValueError("grad_cam_map: gradient map %s" % (tuple(w.shape),))
+        wp, nparts = _f32(w), -(w.shape[1] * w.shape[2])
     else:
         wp, nparts = _f32(w, B, C), 0
     L.check(L.load().hdrsky_grad_cam(_p(A), _p(wp), nparts, scale, B, H * W, C, _p(cam), _stream()), "grad_cam")

@@ -347,8 +347,8 @@ class Trainer:
             x = pooled
         B = ldr.shape[0]
         t["flat"] = x.reshape(B, -1)
-        t["f1"] = K.fc_finalize(K.fc_fwd(t["flat"], self.fc1, cp), w["sun.fc1.bias"], relu=True)
-        t["gmax"] = K.zero_(torch.empty(1, dtype=torch.int32, device=ldr.device))
+        t["gmax"] = torch.empty(1, dtype=torch.int32, device=ldr.device)      # cleared by the finalize launch below
+        t["f1"] = K.fc_finalize(K.fc_fwd(t["flat"], self.fc1, cp), w["sun.fc1.bias"], relu=True, zero_word=t["gmax"])
         t["z"], t["cmf"] = K.softmax_head(K.fc_fwd(t["f1"], self.fc2, cp), w["sun.fc2.bias"], t["gmax"])
         return t
 
@@ -394,7 +394,9 @@ class Trainer:
         dz, _ = K.softmax_pick_bwd(t["cmf"], t["z"], pick_src)
         df1 = K.fc_finalize(K.fc_dgrad(dz, self.fc2, cp), None, relu=False, mask_src=t["f1"])
         dP3 = K.fc_finalize(K.fc_dgrad(df1, self.fc1, cp)).reshape(B, h // 8, wd // 8, 128)
-        w3 = K.spatial_sum(dP3, 1.0 / ((h // 4) * (wd // 4)))
+        small = (h // 8) * (wd // 8) <= 256       # cam3's GAP weights: summed inside its own launch when the map is small
+        w3 = dP3 if small else K.spatial_sum(dP3, 1.0 / ((h // 4) * (wd // 4)))
+        s3 = 1.0 / ((h // 4) * (wd // 4)) if small else 1.0
         if self.da_sun:
             dP, sums = dP3, {}
             for l in (3, 2):
@@ -406,7 +408,7 @@ class Trainer:
                 g_ = K.norm_act_bwd(t["r%da" % l], t["st%da" % l], w[n + ".norm1.gamma"], w[n + ".norm1.beta"], 0.0, g_, False)
                 dP = K.da_conv2d_dgrad(g_, c[n + ".conv1"].pkT, tab, 3, cp)
                 sums[l - 1] = K.spatial_sum(dP, 1.0 / ((2 * hl) * (2 * wl)))
-            return K.grad_cam_map(t["A1"], sums[1]), K.grad_cam_map(t["A2"], sums[2]), K.grad_cam_map(t["A3"], w3)
+            return K.grad_cam_map(t["A1"], sums[1]), K.grad_cam_map(t["A2"], sums[2]), K.grad_cam_map(t["A3"], w3, s3)
         n3, n2 = "sun.sunlayer3", "sun.sunlayer2"
         if "s3" in t:
             _, _, dP2 = E.sun3_backward(t["s3"], dP3, c[n3 + ".conv1"].pkT, c[n3 + ".conv2"].pkT, w[n3 + ".norm1.gamma"],
@@ -422,7 +424,7 @@ class Trainer:
         g = K.norm_act_bwd(t["r2a"], t["st2a"], w[n2 + ".norm1.gamma"], w[n2 + ".norm1.beta"], 0.0, g, False)
         _, sP1 = c[n2 + ".conv1"].dgrad(t["in2"], g, cp, want_stats=True)
         cam2 = K.grad_cam_map(t["A2"], sP2) if "s3" in t else K.grad_cam_map(t["A2"], sP2, 1.0 / ((h // 2) * (wd // 2)))
-        return (K.grad_cam_map(t["A1"], sP1, 1.0 / (h * wd)), cam2, K.grad_cam_map(t["A3"], w3))
+        return (K.grad_cam_map(t["A1"], sP1, 1.0 / (h * wd)), cam2, K.grad_cam_map(t["A3"], w3, s3))
 
     def _down_stack(self, net, params, x, training):
         """downsampling x4 (discriminator.py:20-27 == sunrad_net.py:21-28).  Returns records for the backward pass:

@@ -152,9 +152,10 @@ int hdrsky_fc_fwd(const float* x, const void* packed_hi, const void* packed_lo, 
                   int compute, float* out_part, void* stream);
 int hdrsky_fc_dgrad(const float* dy, const void* natural_hi, const void* natural_lo, int M, int K, int N, int nsplit,
                     int compute, float* dx_part, void* stream);
-/* y = [relu](sum_s part[s] + bias) [* (mask_src > 0)] */
+/* y = [relu](sum_s part[s] + bias) [* (mask_src > 0)]; zero_word (nullable): a 4-byte word this launch clears - the max
+ * accumulator of a hdrsky_softmax_head later on the same stream, saving a memset launch in the chain. */
 int hdrsky_fc_finalize(const float* part, int nsplit, int M, int N, const float* bias, int relu, const float* mask_src,
-                       float* y, void* stream);
+                       float* y, void* zero_word, void* stream);
 /* z = relu(sum_s part[s] + bias); cmf = softmax(z); *gmax_bits = max(*gmax_bits, bits(max cmf)) (zero it first). */
 int hdrsky_softmax_head(const float* part, int nsplit, int M, int N, const float* bias, float* z, float* cmf,
                         void* gmax_bits, void* stream);
@@ -165,7 +166,8 @@ int hdrsky_softmax_pick_bwd(const float* cmf, const float* z, const float* pick_
 int hdrsky_spatial_sum(const float* x, int B, int P, int C, float scale, float* out, void* stream);
 /* cam[b][p] = relu(sum_c w[b][c]*A[b][p][c])  (grad_cam.py:34-38).  w_nparts == 0: w is a [B][C] table;
  * w_nparts > 0: w is the statistics tensor [B][w_nparts][2][C] of the conv that produced the activation
- * gradient and its per-tile sums are reduced here; either way the weights are multiplied by w_scale. */
+ * gradient and its per-tile sums are reduced here; w_nparts < 0: w is the activation gradient itself, [B][-w_nparts
+ * pixels][C] (at most 256 pixels: the sum is repeated by every block of a sample); the weights are multiplied by w_scale. */
 int hdrsky_grad_cam(const float* A, const float* w, int w_nparts, float w_scale, int B, int P, int C, float* cam,
                     void* stream);
 
