@@ -216,3 +216,25 @@ def test_device_input_synthesis(dev):
     assert float(bt["ldr"].min()) >= 0.0 and float(bt["ldr"].max()) <= 1.0 and torch.isfinite(bt["hdr_t"]).all()
     bt2 = synth.make_batch_device(8, H, W, seed=5, device=dev)
     assert torch.equal(bt["hdr_t"], bt2["hdr_t"]) and torch.equal(bt["sunpose_gt"], bt2["sunpose_gt"])   # seeded
+
+
+def test_pad_channels_zero_word_and_cam_from_the_gradient_map(dev):
+    """hdrsky_pad_channels; hdrsky_fc_finalize clearing a word for a later hdrsky_softmax_head; hdrsky_grad_cam summing
+    the activation-gradient map itself (w_nparts < 0) = hdrsky_spatial_sum + the table form."""
+    K = pkg("kernels")
+    rng = np.random.default_rng(9)
+    x = torch.from_numpy(rng.standard_normal((2, 5, 7, 3)).astype(np.float32)).to(dev)
+    y = K.pad_channels(x, 32)
+    assert y.shape == (2, 5, 7, 32) and torch.equal(y[..., :3], x) and float(y[..., 3:].abs().max()) == 0.0
+    part = torch.from_numpy(rng.standard_normal((4, 3, 64)).astype(np.float32)).to(dev)
+    word = torch.full((1,), 123456, dtype=torch.int32, device=dev)
+    out = K.fc_finalize(part, None, relu=True, zero_word=word)
+    assert int(word) == 0 and torch.allclose(out, torch.relu(part.sum(0)), atol=1e-6)
+    A = torch.from_numpy(rng.standard_normal((3, 8, 32, 128)).astype(np.float32)).to(dev)
+    dP = torch.from_numpy(rng.standard_normal((3, 4, 16, 128)).astype(np.float32)).to(dev)
+    scale = 1.0 / 256.0
+    ref = K.grad_cam_map(A, K.spatial_sum(dP, scale))
+    got = K.grad_cam_map(A, dP, scale)
+    assert_close(got, ref, 1e-5, "cam from the gradient map")
+    expect = torch.relu(torch.einsum("bc,bhwc->bhw", dP.sum(dim=(1, 2)) * scale, A)).unsqueeze(-1)
+    assert_close(got, expect, 1e-4, "cam formula")

@@ -164,3 +164,52 @@ def test_reference_hdr_inputs_run_through_the_oracle():
     for k in ("y_final_gamma", "sunpose_cmf", "gamma", "beta"):
         ref = g[k]
         assert np.abs(out[k].numpy() - ref).max() <= 2e-4 * (np.abs(ref).max() + 1e-30), k
+
+
+def test_norms_optimizers_and_kl_against_torch_library_code():
+    """(c) The oracle's hand-written InstanceNorm / BatchNorm / RMSprop / Adam / KL formulas against the library
+    implementations that ship with torch (torch.nn.functional, torch.optim - independent code of the same published
+    algorithms).  What stays a TF-side assumption: eps = 1e-3 and its place inside the root (Keras / tfa defaults), the
+    Bessel-corrected moving variance of the fused BatchNorm path, eps OUTSIDE the root in both optimizers."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 6, 10, 8, generator=g) * 2.0 + 0.5
+    gamma, beta = torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g)
+    nchw = x.permute(0, 3, 1, 2)
+    ref = F.instance_norm(nchw, weight=gamma, bias=beta, eps=1e-3).permute(0, 2, 3, 1)
+    assert torch.allclose(T.instance_norm(x, gamma, beta), ref, rtol=1e-5, atol=1e-5)
+    # BatchNorm, training: batch statistics + moving averages (torch's momentum is 1 - Keras' momentum, and torch feeds
+    # the running variance with the unbiased estimate - the same convention the oracle assumes for the fused TF path)
+    mm, mv = torch.randn(8, generator=g), torch.rand(8, generator=g) + 0.5
+    y, nm, nv = T.batch_norm(x, gamma, beta, mm, mv, training=True)
+    rm, rv = mm.clone(), mv.clone()
+    ref = F.batch_norm(nchw, rm, rv, weight=gamma, bias=beta, training=True, momentum=0.01, eps=1e-3).permute(0, 2, 3, 1)
+    assert torch.allclose(y, ref, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(nm, rm, rtol=1e-6, atol=1e-6) and torch.allclose(nv, rv, rtol=1e-6, atol=1e-6)
+    ye, _, _ = T.batch_norm(x, gamma, beta, mm, mv, training=False)
+    ref = F.batch_norm(nchw, mm, mv, weight=gamma, bias=beta, training=False, eps=1e-3).permute(0, 2, 3, 1)
+    assert torch.allclose(ye, ref, rtol=1e-5, atol=1e-5)
+    # RMSprop (rho 0.9, eps 1e-7 outside the root, no momentum, not centred) and Adam over four steps
+    w0 = torch.randn(50, generator=g)
+    grads = [torch.randn(50, generator=g) * 10.0 ** float(e) for e in (-3, 0, -1, 1)]
+    p = torch.nn.Parameter(w0.clone())
+    opt = torch.optim.RMSprop([p], lr=1e-3, alpha=0.9, eps=1e-7)
+    w, ms = w0.clone(), torch.zeros(50)
+    for gr in grads:
+        p.grad = gr.clone(); opt.step()
+        w, ms = T.rmsprop_update(w, gr, ms, 1e-3)
+        assert torch.allclose(w, p.detach(), rtol=1e-6, atol=1e-7)
+    p = torch.nn.Parameter(w0.clone())
+    opt = torch.optim.Adam([p], lr=1e-3, betas=(0.9, 0.999), eps=1e-7)
+    w, m, v = w0.clone(), torch.zeros(50), torch.zeros(50)
+    for step, gr in enumerate(grads, 1):
+        gr = gr.sign() * gr.abs().clamp_min(0.05)
+        p.grad = gr.clone(); opt.step()
+        w, m, v = T.adam_update(w, gr, m, v, 1e-3, step)
+        # Keras folds the bias correction into lr_t, i.e. its eps is torch's eps scaled by sqrt(1 - b2^t): the two forms
+        # differ by O(eps / sqrt(v)) - compared here on gradients large enough for that to vanish
+        assert torch.allclose(w, p.detach(), rtol=1e-5, atol=1e-6), step
+    # KLDivergence (Keras clips both arguments to [1e-7, 1]; sum over the last axis, mean over the batch)
+    yt = torch.softmax(torch.randn(4, 64, generator=g) * 3, -1); yp = torch.softmax(torch.randn(4, 64, generator=g), -1)
+    ref = F.kl_div(yp.clamp(1e-7, 1).log(), yt.clamp(1e-7, 1), reduction="none").sum(-1).mean()
+    assert abs(float(T.kl_divergence(yt, yp)) - float(ref)) <= 1e-6 * abs(float(ref))
