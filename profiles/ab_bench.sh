@@ -5,4 +5,5 @@ run() { echo "== $1"; shift; env "$@" python bench.py --no-cpu-baseline --steps 
 import json,sys; d=json.loads(sys.stdin.read()); print('train %.4f ms  fwd %.4f ms  roof %.3f us' % (d['ms_per_step'], d['fwd']['ms_per_step'], d['roofline']['avg_launch_us']))"; }
 for rep in 1 2; do
 run "default" X=1
+run "decoder tail on the MFMA path" HDRSKY_CONV_TAIL=0
 done

@@ -21,6 +21,7 @@ LAYERS = [
     ("l1b 7x7 32->32 @32x128", 32, 128, 32, 32, 7, 1, 2),
     ("conv2_d 3x3s2 32->64", 32, 128, 32, 64, 3, 2, 2),
     ("d2 4x4s2 64->128", 32 // 2, 128 // 2, 64, 128, 4, 2, 6),
+    ("dec1 7x7 32->3 @32x128", 32, 128, 32, 3, 7, 1, 2),
 ]
 
 def main():
