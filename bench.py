@@ -296,7 +296,7 @@ def main():
             local = 0
         backend = os.environ.get("HDRSKY_DIST_BACKEND", "nccl")
         if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
-            os.environ["NCCL_DEBUG"] = "WARN"       # the image exports VERSION: RCCL would print its banner to STDOUT, in
+            del os.environ["NCCL_DEBUG"]            # the image exports VERSION: RCCL would print its banner to STDOUT, in
                                                     # front of the one JSON line this script owes its caller
         torch.cuda.set_device(local)
         kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
