@@ -22,6 +22,8 @@ LAYERS = [
     ("conv2_d 3x3s2 32->64", 32, 128, 32, 64, 3, 2, 2),
     ("d2 4x4s2 64->128", 32 // 2, 128 // 2, 64, 128, 4, 2, 6),
     ("dec1 7x7 32->3 @32x128", 32, 128, 32, 3, 7, 1, 2),
+    ("d3 4x4s2 128->256 @8x32", 8, 32, 128, 256, 4, 2, 8),
+    ("d4 4x4 256->512 @4x16", 4, 16, 256, 512, 4, 1, 8),
 ]
 
 def main():
