@@ -119,24 +119,20 @@ __device__ __forceinline__ void compute_chunk(const ConvKArgs& a, const unsigned
   }
 }
 
-// B chunk `chunk_` -> registers R##h / R##l (k-step index is wave-uniform; clamped at the end of the reduction:
-// surplus k-steps are fetched but never multiplied)
-#define HDRSKY_LOAD_B(R, chunk_)                                                                          \
+// B chunk `chunk_` (k-step index is wave-uniform; clamped at the end of the reduction: surplus k-steps are fetched but
+// never multiplied) by LDS-DMA straight into ring buffer buf_ - no registers in between (a register copy in flight across
+// the long operand staging / the MFMA phase was parked in scratch by the compiler); completion: s_waitcnt vmcnt(0) before
+// the barrier that publishes it
+#define HDRSKY_DMA_B(chunk_, buf_)                                                                        \
   _Pragma("unroll") for (int j = 0; j < BPT; ++j) {                                                      \
     const int ks_ = min((chunk_) * KC + j * RPP + bsub, a.ksg - 1);                                       \
     int kp_;                                                                                              \
     if (NARROW) kp_ = ks_;                                                                                \
     else kp_ = (ks_ >> a.log2cbg) * cin32 + (g << a.log2cbg) + (ks_ & ((1 << a.log2cbg) - 1));           \
     const size_t src_ = (size_t)(kp_ * 4) * a.Npad + boff;                                                \
-    R##h[j] = a.whi[src_];                                                                                \
-    if (PRECISE) R##l[j] = a.wlo[src_];                                                                   \
+    glds16(a.whi + src_, sb_lds + (((buf_) * BPLANES + 0) * BITEMS + wave_base + j * NT) * 16);           \
+    if (PRECISE) glds16(a.wlo + src_, sb_lds + (((buf_) * BPLANES + 1) * BITEMS + wave_base + j * NT) * 16); \
   }
-#define HDRSKY_STORE_B(R, buf_)                                                                           \
-  _Pragma("unroll") for (int j = 0; j < BPT; ++j) {                                                      \
-    sB[((buf_) * BPLANES + 0) * BITEMS + tid + j * NT] = R##h[j];                                        \
-    if (PRECISE) sB[((buf_) * BPLANES + 1) * BITEMS + tid + j * NT] = R##l[j];                           \
-  }
-
 // 8-wave variants are compiled for 4 waves per SIMD (<= 128 VGPRs; they need 77-106 and no scratch): two workgroups
 // then fit a CU, which is what lets kernels of the other streams of the training step overlap with this one.
 template <int WM, int WN, int MI, int NI, int TW, bool NARROW, bool PRECISE, bool DB>
@@ -253,6 +249,8 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB
   const int nchunks = (a.ksg + KC - 1) / KC;
   constexpr int RPP = NT / (4 * BN);  // k-steps covered by one pass of the block over a B chunk
   const int bsub = __builtin_amdgcn_readfirstlane(tid / (4 * BN));
+  const unsigned sb_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(smem + a.off_b);
+  const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
   const int boff = ((tid % (4 * BN)) / BN) * a.Npad + n0 + (tid % BN);  // (q, n) part of the packed index
   const int cin32 = a.Cin >> 5;
   const float slope = a.in_slope;
@@ -261,9 +259,8 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB
   for (int g = 0; g < a.ngroups; ++g) {
     if (g > 0 && !DB) __syncthreads();  // everyone finished reading the previous group's planes
 
-    // LDS-ring variant: first B chunk goes in flight before the (long) A staging
-    uint4 brh[BPT], brl[BPT];
-    if (!DB) { HDRSKY_LOAD_B(br, 0) }
+    // LDS-ring variant: first B chunk goes in flight (LDS-DMA into ring buffer 0) before the (long) A staging
+    if (!DB) { HDRSKY_DMA_B(0, 0) }
 
     // ---- stage the halo patch of this channel group into LDS (branch-free per item) ----------
     if (NARROW) {
@@ -517,25 +514,24 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB
       // them; not needed after the last group when the epilogue tile has its own LDS (off_out != 0)
       if (g + 1 < a.ngroups || a.off_out == 0) __syncthreads();
     } else {
-      // ---- B ring: LDS double buffer; chunk ch+1 is fetched into registers at the top of iteration ch
-      // and written to the other buffer after the MFMAs of chunk ch (registers are not loop-carried).
-      HDRSKY_STORE_B(br, 0)
+      // ---- B ring: LDS double buffer; chunk ch+1 is copied by LDS-DMA into the other buffer (free since the barrier
+      // that ended iteration ch-1) while the MFMAs of chunk ch run: no registers, no ds_write, nothing in scratch.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // chunk 0 (DMA) landed
       __syncthreads();
       unsigned long long tl = 0, tc = 0, ts = 0, tb = 0;  // debug: cycles in load-issue / MFMA / LDS-store(+load wait) / barrier
       for (int ch = 0; ch < nchunks; ++ch) {
-        uint4 nxh[BPT], nxl[BPT];
         const bool dbg = a.stamps != nullptr;
         unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
         if (dbg) t0 = __builtin_amdgcn_s_memtime();
-        HDRSKY_LOAD_B(nx, ch + 1)
+        HDRSKY_DMA_B(ch + 1, (ch + 1) & 1)
         if (dbg) t1 = __builtin_amdgcn_s_memtime();
         if (ch + 1 < nchunks)
           compute_chunk<MI, NI, BN, KC, BPLANES, BITEMS, NARROW, PRECISE, false>(a, smem, sB, sTap, ch, kq, abase, bbase, acc);
         else
           compute_chunk<MI, NI, BN, KC, BPLANES, BITEMS, NARROW, PRECISE, true>(a, smem, sB, sTap, ch, kq, abase, bbase, acc);
         if (dbg) { asm volatile("" ::"v"(acc[0][0][0])); t2 = __builtin_amdgcn_s_memtime(); }
-        HDRSKY_STORE_B(nx, (ch + 1) & 1)
-        if (dbg) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); t3 = __builtin_amdgcn_s_memtime(); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // chunk ch+1 landed
+        if (dbg) t3 = __builtin_amdgcn_s_memtime();
         __syncthreads();
         if (dbg) { t4 = __builtin_amdgcn_s_memtime(); tl += t1 - t0; tc += t2 - t1; ts += t3 - t2; tb += t4 - t3; }
       }

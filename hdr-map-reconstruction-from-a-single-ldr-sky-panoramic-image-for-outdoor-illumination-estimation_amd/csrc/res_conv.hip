@@ -43,17 +43,6 @@ struct RcArgs {
     if ((k) == 0 || (k) == 6) a.stamps[(size_t)gridDim.x * 8 + (size_t)blockIdx.x * 2 + ((k) ? 1 : 0)] = __builtin_amdgcn_s_memrealtime(); \
   }
 
-// LDS-DMA of 16 bytes per lane: LDS destination = lds_dst (wave-uniform byte address) + lane * 16.  Inline asm so that
-// the compiler's vmcnt bookkeeping does not see it (it would drain every DMA before the first ds_read): completion is
-// waited for by the explicit counted s_waitcnt below.  M0 is saved / restored inside the statement.
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(lds_dst)
-               : "memory");
-}
-
 template <int CTRL>
 __device__ __forceinline__ float dpp_zero(float v) {   // cross-lane move inside rows of 16 lanes, zero where no source lane
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
