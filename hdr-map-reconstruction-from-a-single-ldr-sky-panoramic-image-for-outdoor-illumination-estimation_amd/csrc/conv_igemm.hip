@@ -792,114 +792,6 @@ int dispatch_tile(ConvKArgs& a, const TileCfg& t, hipStream_t s) {
   return HDRSKY_EUNSUPPORTED;
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// The decoders' last layer (generator.py:121,152: 7x7, 32 -> 3 channels at full resolution, leaky 0.1, + the LDR image /
-// the sun radiance, ReLU).  Three output channels on 16- or 32-wide MFMA columns waste 5-10x of the matrix cores' work
-// (measured 32 us per launch at batch 32).  Here every thread owns one output pixel and its <= 4 channels: the input
-// halo tile (producer transform applied, bf16, 80-byte pixel stride: 16 consecutive pixels hit 16 different bank
-// groups) and the filter slice sit in LDS; per (tap, 8 input channels) a lane reads its 16 bytes once and the filter
-// words are LDS broadcasts; v_dot2c_f32_bf16 accumulates in fp32.  Measured: 25 us standalone - the same as the MFMA
-// path (v_dot2c issues at well below the plain-FMA rate; filter words from scalar loads instead of LDS: 26 us) - but 8-12 us
-// per forward pass in context (no 64-column epilogue tile, no weight ring).  The real fix is a width-packed MFMA
-// formulation (columns = 3 channels x 5 pixel shifts over an 11-tap window: 3.2x less matrix work), DESIGN.md section 8.  Same packed weight image as the MFMA path.
-// ------------------------------------------------------------------------------------------------------------
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-__device__ __forceinline__ float dot8(const uint4& d, const uint4& w, float acc) {
-  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, d.x), __builtin_bit_cast(bf16x2_t, w.x), acc, false);
-  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, d.y), __builtin_bit_cast(bf16x2_t, w.y), acc, false);
-  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, d.z), __builtin_bit_cast(bf16x2_t, w.z), acc, false);
-  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, d.w), __builtin_bit_cast(bf16x2_t, w.w), acc, false);
-  return acc;
-}
-
-template <int KS, int NQ, int NCO>
-__global__ void __launch_bounds__(256) conv_tail_kernel(const ConvKArgs a) {
-  constexpr int TH = 8, TW = 32, PAD = (KS - 1) / 2, HT = TH + KS - 1, WT = TW + KS - 1;
-  constexpr int PXB = NQ * 16 + 16;                  // bytes of a staged pixel
-  constexpr int CIN = NQ * 8;
-  __shared__ __attribute__((aligned(16))) unsigned char sX[HT * WT * PXB];
-  __shared__ uint4 sW[KS * KS * NQ * NCO];
-  __shared__ float sSc[CIN], sSh[CIN];
-  const int tid = threadIdx.x;
-  int bid = blockIdx.x;
-  const int tx = bid % a.tiles_x; bid /= a.tiles_x;
-  const int ty = bid % a.tiles_y, b = bid / a.tiles_y;
-  const int oy0 = ty * TH, ox0 = tx * TW;
-
-  if (tid < CIN) {
-    float sc = 1.f, sh = 0.f;
-    if (a.in_mode == HDRSKY_IN_AFFINE) {
-      sc = a.in_scale[b * a.ss_bstride + tid]; sh = a.in_shift[b * a.ss_bstride + tid];
-    } else if (a.in_mode == HDRSKY_IN_PARTIALS) {
-      float s = 0.f, ss = 0.f;
-      const float* pp = a.in_part + (size_t)b * a.in_nparts * 2 * CIN + tid;
-      for (int p = 0; p < a.in_nparts; ++p) { s += pp[(2 * p) * CIN]; ss += pp[(2 * p + 1) * CIN]; }
-      const float mean = s * a.in_inv_count;
-      const float var = fmaxf(ss * a.in_inv_count - mean * mean, 0.f);
-      sc = a.in_gamma[tid] / sqrtf(var + a.in_eps);
-      sh = a.in_beta[tid] - mean * sc;
-    }
-    sSc[tid] = sc; sSh[tid] = sh;
-  }
-  for (int i = tid; i < KS * KS * NQ * NCO; i += 256) {
-    const int co = i % NCO, kg = i / NCO;            // kg = tap * NQ + q: 16-byte k group of the packed image
-    sW[i] = a.whi[(size_t)kg * a.Npad + co];         // (columns beyond Cout hold zeros)
-  }
-  __syncthreads();
-  const bool xf = a.in_mode != HDRSKY_IN_NONE;
-  for (int i = tid; i < HT * WT * NQ; i += 256) {
-    const int q = i % NQ, px = i / NQ;
-    const int hy = px / WT, hx = px - hy * WT;
-    const int iy = oy0 + hy - PAD, ix = ox0 + hx - PAD;
-    uint4 hi = uint4{0, 0, 0, 0}, lo;
-    if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
-      float v[8];
-      load8_xf(a.x + ((size_t)(b * a.H + iy) * a.W + ix) * CIN + q * 8, sSc + q * 8, sSh + q * 8, xf, a.in_slope, v);
-      pack8<false>(v, hi, lo);
-    }
-    *reinterpret_cast<uint4*>(sX + px * PXB + q * 16) = hi;
-  }
-  __syncthreads();
-
-  const int r = tid / TW, c = tid % TW;
-  float acc[NCO];
-#pragma unroll
-  for (int co = 0; co < NCO; ++co) acc[co] = 0.f;
-#pragma unroll 1
-  for (int ky = 0; ky < KS; ++ky) {
-    const unsigned char* row = sX + ((r + ky) * WT + c) * PXB;
-    const uint4* wrow = sW + ky * KS * NQ * NCO;
-#pragma unroll
-    for (int kx = 0; kx < KS; ++kx)
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const uint4 d = *reinterpret_cast<const uint4*>(row + kx * PXB + q * 16);
-#pragma unroll
-        for (int co = 0; co < NCO; ++co) acc[co] = dot8(d, wrow[(kx * NQ + q) * NCO + co], acc[co]);
-      }
-  }
-  const int oy = oy0 + r, ox = ox0 + c;
-  if (oy < a.Ho && ox < a.Wo) {
-    const size_t idx = ((size_t)(b * a.Ho + oy) * a.Wo + ox) * a.Cout;
-#pragma unroll
-    for (int co = 0; co < NCO; ++co)
-      if (co < a.Cout) {
-        float v = leaky(acc[co] + (a.bias ? a.bias[co] : 0.f), a.out_slope);
-        if (a.residual != nullptr) v += a.residual[idx + co];
-        if (a.final_relu) v = fmaxf(v, 0.f);
-        a.y[idx + co] = v;
-      }
-  }
-}
-
-// the layers conv_tail_kernel takes (single-product mode only; HDRSKY_CONV_TAIL=0 keeps them on the MFMA path: A/B hook)
-static bool conv_tail_ok(const hdrsky_conv_desc* d) {
-  const char* e = getenv("HDRSKY_CONV_TAIL");
-  return !(e && atoi(e) == 0) && d->compute == HDRSKY_BF16 && d->KH == 7 && d->KW == 7 && d->Cin == 32 && d->Cout <= 3 && d->stride == 1 &&
-         d->upsample == 1 && d->dilate == 1 && !d->want_stats && d->Ho == d->H && d->Wo == d->W && d->pad_t == 3 &&
-         d->pad_l == 3;
-}
-
 // Tile heuristic: widest N block the layer fills, then the largest pixel tile that still
 // yields >= ~1 workgroup per CU (256 CUs), preferring more workgroups for small problems.
 TileCfg choose_tile(const hdrsky_conv_desc* d) {
@@ -1048,12 +940,6 @@ int hdrsky_conv2d_fwd(const hdrsky_conv_desc* d, const float* x, const void* w_h
   a.out_slope = d->out_slope; a.final_relu = d->final_relu; a.want_stats = d->want_stats;
   a.stamps = g_stamps;
   hipStream_t s = (hipStream_t)stream;
-  if (conv_tail_ok(d)) {
-    a.tiles_x = cdiv(d->Wo, 32); a.tiles_y = cdiv(d->Ho, 8);
-    hipLaunchKernelGGL((conv_tail_kernel<7, 4, 3>), dim3(d->B * a.tiles_x * a.tiles_y), dim3(256), 0, s, a);
-    HDRSKY_CHECK_LAUNCH();
-    return HDRSKY_OK;
-  }
   const TileCfg t = choose_tile(d);
   if (narrow) return precise ? dispatch_tile<true, true>(a, t, s) : dispatch_tile<true, false>(a, t, s);
   return precise ? dispatch_tile<false, true>(a, t, s) : dispatch_tile<false, false>(a, t, s);

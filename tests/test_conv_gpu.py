@@ -89,38 +89,6 @@ def test_conv_fused_in_stats_residual(dev):
     assert_close(y, ref, 3e-4, "fused consumer")
 
 
-@pytest.mark.parametrize("B,H,W,Cout", [(2, 32, 128, 3), (3, 24, 64, 3), (1, 13, 45, 2)])
-def test_decoder_tail_conv_on_the_dot_product_path(dev, monkeypatch, B, H, W, Cout):
-    """The decoders' 7x7 32 -> 3 layer (generator.py:121,152) in HDRSKY_BF16 mode runs on conv_tail_kernel (one pixel per
-    thread, v_dot2c_f32_bf16): producer InstanceNorm + leaky fused into its staging, leaky 0.1 + residual + ReLU epilogue;
-    against the oracle and against the MFMA path (HDRSKY_CONV_TAIL=0), ragged tiles included."""
-    K = pkg("kernels"); L = pkg("_lib")
-    rng = np.random.default_rng(B * 100 + W)
-    x = rng.standard_normal((B, H, W, 32)).astype(np.float32) * 1.5 + 0.3
-    w0 = (rng.standard_normal((3, 3, 32, 32)) / 17).astype(np.float32); b0 = rng.standard_normal(32).astype(np.float32)
-    w = (rng.standard_normal((7, 7, 32, Cout)) / 40).astype(np.float32); b = rng.standard_normal(Cout).astype(np.float32)
-    gam = rng.uniform(0.5, 1.5, 32).astype(np.float32); bet = rng.standard_normal(32).astype(np.float32)
-    res = rng.uniform(0, 1, (B, H, W, Cout)).astype(np.float32)
-    t = torch.from_numpy
-    c0 = T.conv2d(t(x), t(w0), t(b0))
-    a0 = T.leaky_relu(T.instance_norm(c0, t(gam), t(bet)), 0.1)
-    ref = torch.relu(T.leaky_relu(T.conv2d(a0, t(w), t(b)), 0.1) + t(res))
-    d = lambda a: torch.from_numpy(a).to(dev)
-    r0, st = K.conv2d(d(x), K.PackedConv(d(w0)), d(b0), want_stats=True, compute=K.BF16X3)
-    xf = K.InXf(mode=L.IN_PARTIALS, slope=0.1, stats=st, gamma=d(gam), beta=d(bet))
-    pw = K.PackedConv(d(w))
-    y, _ = K.conv2d(r0, pw, d(b), xf=xf, out_slope=0.1, residual=d(res), final_relu=True, compute=K.BF16)
-    assert_close_bf16(y, ref, "decoder tail (dot-product path)")
-    monkeypatch.setenv("HDRSKY_CONV_TAIL", "0")
-    y_mfma, _ = K.conv2d(r0, pw, d(b), xf=xf, out_slope=0.1, residual=d(res), final_relu=True, compute=K.BF16)
-    monkeypatch.delenv("HDRSKY_CONV_TAIL")
-    # same bf16 operands, fp32 accumulation in another order
-    assert_close(y, y_mfma, 2e-5, "dot-product path vs MFMA path")
-    # no transform, no residual
-    y2, _ = K.conv2d(d(x), pw, None, compute=K.BF16)
-    assert_close_bf16(y2, T.conv2d(t(x), t(w), None), "plain 7x7 32->%d" % Cout)
-
-
 def test_conv_dgrad_via_flipped_filter(dev):
     """data gradient of a stride-1 SAME conv == conv with the transposed/flipped packed filter."""
     K = pkg("kernels")
