@@ -64,8 +64,11 @@ __device__ __forceinline__ void load8_xf(const float* __restrict__ p, const floa
   }
 }
 
+#ifndef HDRSKY_STAMP_TID
+#define HDRSKY_STAMP_TID 0      // the thread that writes the phase stamps (diagnostic builds: another wave's first lane)
+#endif
 #define HDRSKY_STAMP(k)                                                               \
-  if (a.stamps != nullptr && threadIdx.x == 0) {                                      \
+  if (a.stamps != nullptr && threadIdx.x == HDRSKY_STAMP_TID) {                       \
     a.stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime();            \
     if ((k) == 0 || (k) == 5) a.stamps[(size_t)blockIdx.x * 8 + 6 + ((k) ? 1 : 0)] = __builtin_amdgcn_s_memrealtime(); \
   }
