@@ -46,6 +46,7 @@ struct ConvKArgs {
   int HT, WT, NPIX, NPIXP, wt_magic, kw_magic;
   int off_alo, off_b, off_ss, off_tap, off_stat, off_ktab, off_out;
   unsigned long long* stamps;  // debug: per-workgroup phase time stamps (null in production)
+  int x_bf16, y_bf16;          // activation storage (hdrsky_conv_desc)
 };
 
 // load 8 consecutive channels and apply the producer's affine + leaky activation
@@ -356,9 +357,19 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB
             cy >>= dsh; cx >>= dsh;
             ok[u] = v;
             dst[u] = (i < nitems) ? q * a.NPIXP + p : dummy;
-            const float* src = xb + ((size_t)(v ? cy : 0) * a.W + (v ? cx : 0)) * a.Cin + q * 8;
-            va[u] = *reinterpret_cast<const float4*>(src);
-            vb[u] = *reinterpret_cast<const float4*>(src + 4);
+            const size_t eo = ((size_t)(v ? cy : 0) * a.W + (v ? cx : 0)) * a.Cin + q * 8;
+            if (!PRECISE && a.x_bf16) {   // workgroup-uniform: a final bf16 activation is copied, not converted
+              va[u] = __builtin_bit_cast(float4, *reinterpret_cast<const uint4*>(
+                                                     reinterpret_cast<const unsigned short*>(a.x) + (size_t)b * a.H * a.W * a.Cin + g * a.cgs + eo));
+            } else {
+              va[u] = *reinterpret_cast<const float4*>(xb + eo);
+              vb[u] = *reinterpret_cast<const float4*>(xb + eo + 4);
+            }
+          }
+          if (!PRECISE && a.x_bf16) {
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) sAhi[dst[u]] = ok[u] ? __builtin_bit_cast(uint4, va[u]) : uint4{0, 0, 0, 0};
+            continue;
           }
 #pragma unroll
           for (int u = 0; u < UNR; ++u) {
@@ -588,7 +599,11 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
-        *reinterpret_cast<float4*>(a.y + idx) = make_float4(v[0], v[1], v[2], v[3]);
+        if (a.y_bf16)
+          *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.y) + idx) =
+              uint2{(unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16)};
+        else
+          *reinterpret_cast<float4*>(a.y + idx) = make_float4(v[0], v[1], v[2], v[3]);
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -929,6 +944,9 @@ int hdrsky_conv2d_fwd(const hdrsky_conv_desc* d, const float* x, const void* w_h
   if (d->in_mode == HDRSKY_IN_AFFINE && (!in_scale || !in_shift)) return HDRSKY_EINVAL;
   if (d->in_mode == HDRSKY_IN_PARTIALS && (!in_part || !in_gamma || !in_beta || d->in_nparts <= 0)) return HDRSKY_EINVAL;
   if (d->want_stats && !stats_part) return HDRSKY_EINVAL;
+  if (d->x_bf16 && (precise || narrow || d->upsample != 1 || d->in_mode != HDRSKY_IN_NONE || d->in_slope != 1.f))
+    return HDRSKY_EUNSUPPORTED;   // a bf16 operand is a final activation of the single-product mode
+  if (d->y_bf16 && (precise || (d->Cout & 3))) return HDRSKY_EUNSUPPORTED;
   ConvKArgs a{};
   a.x = x; a.whi = (const uint4*)w_hi; a.wlo = (const uint4*)w_lo; a.bias = bias;
   a.in_scale = in_scale; a.in_shift = in_shift; a.in_part = in_part; a.in_gamma = in_gamma; a.in_beta = in_beta;
@@ -942,6 +960,7 @@ int hdrsky_conv2d_fwd(const hdrsky_conv_desc* d, const float* x, const void* w_h
   a.in_eps = d->in_eps; a.in_inv_count = 1.f / (float)(d->H * d->W); a.in_slope = d->in_slope;
   a.out_slope = d->out_slope; a.final_relu = d->final_relu; a.want_stats = d->want_stats;
   a.stamps = g_stamps;
+  a.x_bf16 = d->x_bf16; a.y_bf16 = d->y_bf16;
   hipStream_t s = (hipStream_t)stream;
   const TileCfg t = choose_tile(d);
   if (narrow) return precise ? dispatch_tile<true, true>(a, t, s) : dispatch_tile<true, false>(a, t, s);

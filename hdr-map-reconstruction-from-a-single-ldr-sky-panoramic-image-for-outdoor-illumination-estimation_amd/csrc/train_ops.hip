@@ -203,6 +203,80 @@ __global__ void maxpool_relu_bwd_kernel(const float* __restrict__ y, const float
   }
 }
 
+// ---- the same three on bf16 activations (the VGG16 chain in HDRSKY_BF16 mode) --------------------------------------
+__device__ __forceinline__ void ld4bf(const unsigned short* p, size_t i4, float (&v)[4]) {   // element group i4 (4 bf16)
+  const uint2 u = reinterpret_cast<const uint2*>(p)[i4];
+  v[0] = __builtin_bit_cast(float, u.x << 16); v[1] = __builtin_bit_cast(float, u.x & 0xffff0000u);
+  v[2] = __builtin_bit_cast(float, u.y << 16); v[3] = __builtin_bit_cast(float, u.y & 0xffff0000u);
+}
+
+__global__ void maxpool_fwd_bf16_kernel(const unsigned short* __restrict__ y, int B, int H, int W, int C,
+                                        float* __restrict__ p32, unsigned short* __restrict__ p16) {
+  const int c4 = C >> 2, Hp = H >> 1, Wp = W >> 1;
+  const size_t total = (size_t)B * Hp * Wp * c4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int cq = (int)(i % c4);
+    const size_t pix = i / c4;
+    const int pw = (int)(pix % Wp), ph = (int)((pix / Wp) % Hp), b = (int)(pix / ((size_t)Wp * Hp));
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float v[4];
+      ld4bf(y, ((size_t)(b * H + 2 * ph + (k >> 1)) * W + 2 * pw + (k & 1)) * c4 + cq, v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
+    }
+    if (p32) reinterpret_cast<float4*>(p32)[i] = make_float4(m[0], m[1], m[2], m[3]);
+    if (p16)      // the maximum of bf16 values is one of them: exact
+      reinterpret_cast<uint2*>(p16)[i] = uint2{(unsigned)f2bf(m[0]) | ((unsigned)f2bf(m[1]) << 16),
+                                               (unsigned)f2bf(m[2]) | ((unsigned)f2bf(m[3]) << 16)};
+  }
+}
+
+__global__ void maxpool_relu_bwd_bf16_kernel(const unsigned short* __restrict__ y, const float* __restrict__ dp, int B, int H,
+                                             int W, int C, float* __restrict__ dy) {
+  const int c4 = C >> 2, Hp = H >> 1, Wp = W >> 1;
+  const size_t total = (size_t)B * Hp * Wp * c4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int cq = (int)(i % c4);
+    const size_t pix = i / c4;
+    const int pw = (int)(pix % Wp), ph = (int)((pix / Wp) % Hp), b = (int)(pix / ((size_t)Wp * Hp));
+    const float4 up = reinterpret_cast<const float4*>(dp)[i];
+    const float us[4] = {up.x, up.y, up.z, up.w};
+    float v[4][4];
+    size_t idx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      idx[k] = ((size_t)(b * H + 2 * ph + (k >> 1)) * W + 2 * pw + (k & 1)) * c4 + cq;
+      ld4bf(y, idx[k], v[k]);
+    }
+    float o[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int am = 0;
+      float best = v[0][j];
+#pragma unroll
+      for (int k = 1; k < 4; ++k)
+        if (v[k][j] > best) { best = v[k][j]; am = k; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k][j] = (k == am && v[k][j] > 0.f) ? us[j] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) reinterpret_cast<float4*>(dy)[idx[k]] = make_float4(o[k][0], o[k][1], o[k][2], o[k][3]);
+  }
+}
+
+__global__ void act_bwd_bf16_kernel(const unsigned short* __restrict__ y, const float* __restrict__ dy, float slope, size_t n4,
+                                    float* __restrict__ dx) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float v[4];
+    ld4bf(y, i, v);
+    const float4 g = reinterpret_cast<const float4*>(dy)[i];
+    reinterpret_cast<float4*>(dx)[i] = make_float4(g.x * (v[0] > 0.f ? 1.f : slope), g.y * (v[1] > 0.f ? 1.f : slope),
+                                                   g.z * (v[2] > 0.f ? 1.f : slope), g.w * (v[3] > 0.f ? 1.f : slope));
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // bilinear 2x resize (half-pixel centres) forward on an optional difference a-b, and its adjoint
 // ------------------------------------------------------------------------------------------------------------
@@ -821,6 +895,31 @@ int hdrsky_maxpool_relu_bwd(const float* y, const float* dp, int B, int H, int W
   if (!y || !dp || !dy || (C & 3) || ((H | W) & 1)) return HDRSKY_EINVAL;
   hipLaunchKernelGGL(maxpool_relu_bwd_kernel, dim3(grid_for((size_t)B * H * W * C / 16)), dim3(256), 0, S_(stream), y, dp, B,
                      H, W, C, dy);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_maxpool_fwd_bf16(const void* y, int B, int H, int W, int C, float* p32, void* p16, void* stream) {
+  if (!y || (!p32 && !p16) || (C & 3) || ((H | W) & 1)) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(maxpool_fwd_bf16_kernel, dim3(grid_for((size_t)B * H * W * C / 16)), dim3(256), 0, S_(stream),
+                     (const unsigned short*)y, B, H, W, C, p32, (unsigned short*)p16);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_maxpool_relu_bwd_bf16(const void* y, const float* dp, int B, int H, int W, int C, float* dy, void* stream) {
+  if (!y || !dp || !dy || (C & 3) || ((H | W) & 1)) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(maxpool_relu_bwd_bf16_kernel, dim3(grid_for((size_t)B * H * W * C / 16)), dim3(256), 0, S_(stream),
+                     (const unsigned short*)y, dp, B, H, W, C, dy);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_act_bwd_bf16(const void* y, const float* dy, float slope, size_t n, float* dx, void* stream) {
+  if (!y || !dy || !dx || (n & 3)) return HDRSKY_EINVAL;
+  if (n == 0) return HDRSKY_OK;
+  hipLaunchKernelGGL(act_bwd_bf16_kernel, dim3(grid_for(n / 4)), dim3(256), 0, S_(stream), (const unsigned short*)y, dy,
+                     slope, n / 4, dx);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }

@@ -100,11 +100,24 @@ def conv_desc(B, H, W, Cin, Cout, KH, KW, stride=1, same=True, upsample=1):
     return d
 
 
+def _bf16(t, *shape):
+    if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous()):
+        raise ValueError("expected a contiguous CUDA bfloat16 tensor")
+    if shape and tuple(t.shape) != tuple(shape):
+        raise ValueError("shape %s != expected %s" % (tuple(t.shape), tuple(shape)))
+    return t
+
+
 def conv2d(x, pw: PackedConv, bias=None, stride=1, same=True, upsample=1, xf: Optional[InXf] = None,
-           out_slope=1.0, residual=None, final_relu=False, want_stats=False, compute=BF16, desc=None, out=None):
-    """y = final_relu(act(conv(xf(x)) + bias) + residual); returns (y, Stats|None)."""
+           out_slope=1.0, residual=None, final_relu=False, want_stats=False, compute=BF16, desc=None, out=None,
+           out_bf16=False):
+    """y = final_relu(act(conv(xf(x)) + bias) + residual); returns (y, Stats|None).
+    HDRSKY_BF16 mode: x may be a bfloat16 tensor (a final activation: no xf), out_bf16 stores y as bfloat16."""
     lib = L.load()
-    _f32(x)
+    if torch.is_tensor(x) and x.dtype == torch.bfloat16:
+        _bf16(x)
+    else:
+        _f32(x)
     B, H, W, C = x.shape
     if C != pw.Cin:
         raise ValueError("Cin mismatch: x has %d, filter %d" % (C, pw.Cin))
@@ -135,10 +148,12 @@ def conv2d(x, pw: PackedConv, bias=None, stride=1, same=True, upsample=1, xf: Op
         in_gamma, in_beta = _f32(xf.gamma, C), _f32(xf.beta, C)
         d.in_nparts, d.in_eps = st.nparts, float(xf.eps)
     d.out_slope, d.final_relu, d.want_stats = float(out_slope), int(bool(final_relu)), int(bool(want_stats))
+    d.x_bf16, d.y_bf16 = int(x.dtype == torch.bfloat16), int(bool(out_bf16))
     if bias is not None:
         _f32(bias, pw.Cout)
-    y = out if out is not None else torch.empty((B, d.Ho, d.Wo, pw.Cout), dtype=torch.float32, device=x.device)
-    _f32(y, B, d.Ho, d.Wo, pw.Cout)
+    ydt = torch.bfloat16 if out_bf16 else torch.float32
+    y = out if out is not None else torch.empty((B, d.Ho, d.Wo, pw.Cout), dtype=ydt, device=x.device)
+    (_bf16 if out_bf16 else _f32)(y, B, d.Ho, d.Wo, pw.Cout)
     if residual is not None:
         _f32(residual, B, d.Ho, d.Wo, pw.Cout)
     stats = None
@@ -557,6 +572,13 @@ def bn_act_bwd(x, dy, mean, rstd, gamma, beta, slope, dgamma=None, dbeta=None, o
 
 
 def affine_act_bwd(x, dy, scale, shift, slope):
+    if x.dtype == torch.bfloat16:      # plain activation backward on an ACTIVATED bf16 tensor
+        if scale is not None or shift is not None:
+            raise ValueError("a bf16 operand is a final activation: no affine")
+        _bf16(x); _f32(dy, *x.shape)
+        dx = torch.empty_like(dy)
+        L.check(L.load().hdrsky_act_bwd_bf16(_p(x), _p(dy), slope, x.numel(), _p(dx), _stream()), "act_bwd_bf16")
+        return dx
     _f32(x); _f32(dy, *x.shape)
     C = x.shape[-1]
     dx = torch.empty_like(x)
@@ -565,18 +587,28 @@ def affine_act_bwd(x, dy, scale, shift, slope):
     return dx
 
 
-def maxpool(y):
+def maxpool(y, want_bf16=False):
+    """2x2 max-pool.  A bfloat16 map returns (fp32 pool, bf16 pool or None)."""
     B, H, W, C = y.shape
-    _f32(y)
     p = torch.empty((B, H // 2, W // 2, C), dtype=torch.float32, device=y.device)
+    if y.dtype == torch.bfloat16:
+        _bf16(y)
+        pb = torch.empty((B, H // 2, W // 2, C), dtype=torch.bfloat16, device=y.device) if want_bf16 else None
+        L.check(L.load().hdrsky_maxpool_fwd_bf16(_p(y), B, H, W, C, _p(p), _p(pb), _stream()), "maxpool_fwd_bf16")
+        return p, pb
+    _f32(y)
     L.check(L.load().hdrsky_maxpool_fwd(_p(y), B, H, W, C, _p(p), _stream()), "maxpool_fwd")
     return p
 
 
 def maxpool_relu_bwd(y, dp):
     B, H, W, C = y.shape
-    _f32(y); _f32(dp, B, H // 2, W // 2, C)
-    dy = torch.empty_like(y)
+    _f32(dp, B, H // 2, W // 2, C)
+    dy = torch.empty((B, H, W, C), dtype=torch.float32, device=y.device)
+    if y.dtype == torch.bfloat16:
+        L.check(L.load().hdrsky_maxpool_relu_bwd_bf16(_p(_bf16(y)), _p(dp), B, H, W, C, _p(dy), _stream()), "maxpool_relu_bwd_bf16")
+        return dy
+    _f32(y)
     L.check(L.load().hdrsky_maxpool_relu_bwd(_p(y), _p(dp), B, H, W, C, _p(dy), _stream()), "maxpool_relu_bwd")
     return dy
 

@@ -533,15 +533,23 @@ class Trainer:
         cp = self.compute
         x = K.vgg_pre(x_gamma)
         pools = []
+        # HDRSKY_BF16: the chain's activations live in bf16 (ReLU only, so they are final: the next conv would round them to
+        # bf16 anyway - its result is bit-identical - and the fp32 input / output bursts of these launches halve); the
+        # pooled features of the perceptual term are returned in fp32
+        b16 = cp == BF16 and not self.precise and os.environ.get("HDRSKY_VGG_BF16", "1") != "0"     # (the variable: an A/B hook)
         for blk in self.VGG_BLOCKS:
             for name in blk:
                 if keep is not None:
                     keep[name + ".in"] = x
-                x, _ = K.conv2d(x, self.vgg_pk[name], self.vgg[name + ".b"], out_slope=0.0, compute=cp)
+                x, _ = K.conv2d(x, self.vgg_pk[name], self.vgg[name + ".b"], out_slope=0.0, compute=cp, out_bf16=b16)
                 if keep is not None:
                     keep[name] = x
-            x = K.maxpool(x)
-            pools.append(x)
+            if b16:
+                p32, x = K.maxpool(x, want_bf16=blk is not self.VGG_BLOCKS[-1])
+                pools.append(p32)
+            else:
+                x = K.maxpool(x)
+                pools.append(x)
         return pools
 
     def _vgg_target(self, hdr_t):

@@ -76,6 +76,11 @@ typedef struct hdrsky_conv_desc {
   float out_slope;        /* 1 = none, 0 = relu, else leaky slope */
   int32_t final_relu;     /* apply relu after the residual add */
   int32_t want_stats;     /* write per-tile (sum, sumsq) of conv+bias into stats_part */
+  /* bf16 activation storage (HDRSKY_BF16 only; both 0 after hdrsky_conv_desc_init): */
+  int32_t x_bf16;         /* x points to bf16 [B,H,W,Cin]: a FINAL activation (in_mode NONE, in_slope 1, Cin % 32 == 0,
+                             upsample 1) - what the staging would have rounded the fp32 tensor to anyway */
+  int32_t y_bf16;         /* y points to bf16 [B,Ho,Wo,Cout] (Cout % 4 == 0): the epilogue result rounded to nearest even;
+                             the statistics are still taken from the fp32 values */
 } hdrsky_conv_desc;
 
 /* Fills Ho/Wo/pad/Hc/Wc for TF padding ("SAME": same=1, "VALID": same=0); returns 0 or HDRSKY_EINVAL. [host] */
@@ -289,6 +294,12 @@ int hdrsky_slice_channels(const float* x, size_t npix, int C, int c_off, int c_t
 /* out[npix][Cpad] = x[npix][C] followed by Cpad - C zero channels (the operand a distortion_aware_ops.conv2d with fewer
  * than 32 input channels - sunpose_net.py:11 on the RGB image - is run on; also pads a filter's input-channel axis). */
 int hdrsky_pad_channels(const float* x, size_t npix, int C, int Cpad, float* out, void* stream);
+/* The ReLU-only VGG16 chain on bf16 activations (vgg16.py:88-165; bit-neutral for the next conv, which rounds its
+ * operand to bf16 anyway): 2x2 max-pool of a bf16 map -> fp32 pool (the perceptual feature) and / or bf16 pool (the next
+ * conv's operand); the pool + ReLU backward and the plain activation backward with the ACTIVATED tensor given as bf16. */
+int hdrsky_maxpool_fwd_bf16(const void* y_bf16, int B, int H, int W, int C, float* p_f32, void* p_bf16, void* stream);
+int hdrsky_maxpool_relu_bwd_bf16(const void* y_bf16, const float* dp, int B, int H, int W, int C, float* dy, void* stream);
+int hdrsky_act_bwd_bf16(const void* y_bf16, const float* dy, float slope, size_t n, float* dx, void* stream);
 /* tf.concat([a, b], axis=-1) (discriminator.py:43). */
 int hdrsky_concat2(const float* a, int Ca, const float* b, int Cb, size_t npix, float* out, void* stream);
 /* x*255 - VGG_MEAN (vgg16.py:133-141). */

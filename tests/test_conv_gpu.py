@@ -136,3 +136,36 @@ def test_every_tile_instantiation(dev, tile, monkeypatch):
         assert_close(mean, torch.from_numpy(ref).mean(dim=(1, 2)), 2e-4, "stats " + tile)
         y16, _ = K.conv2d(xd, pw, bd, stride=stride, compute=K.BF16)
         assert_close_bf16(y16, ref, tile + " bf16")
+
+
+def test_bf16_activation_storage_is_bit_neutral_for_relu_chains(dev):
+    """HDRSKY_BF16 mode, bf16 activation storage (hdrsky_conv_desc.x_bf16 / y_bf16; the VGG16 chain): a conv writing
+    bf16 = the fp32 result rounded to nearest even; a conv reading a bf16 activation = the same conv on its fp32 widening,
+    bit for bit (the staging rounds its operand to bf16 anyway); pool / ReLU backward variants on bf16 maps likewise."""
+    K = pkg("kernels")
+    rng = np.random.default_rng(33)
+    d = lambda a: torch.from_numpy(a).to(dev)
+    for (B, H, W, Cin, Cout, k) in ((2, 32, 128, 64, 64, 3), (3, 16, 64, 64, 128, 3), (2, 8, 32, 256, 256, 3), (2, 32, 128, 3, 64, 3)):
+        x = d(rng.standard_normal((B, H, W, Cin)).astype(np.float32))
+        w = d((rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32))
+        b = d(rng.standard_normal(Cout).astype(np.float32))
+        pw = K.PackedConv(w)
+        y32, _ = K.conv2d(x, pw, b, out_slope=0.0, compute=K.BF16)
+        y16, st = K.conv2d(x, pw, b, out_slope=0.0, compute=K.BF16, out_bf16=True, want_stats=True)
+        assert y16.dtype == torch.bfloat16 and torch.equal(y16, y32.to(torch.bfloat16))
+        _, st32 = K.conv2d(x, pw, b, out_slope=0.0, compute=K.BF16, want_stats=True)
+        assert torch.equal(st.part, st32.part)                       # statistics come from the fp32 values
+        if Cin % 32 == 0:
+            xb = x.to(torch.bfloat16)
+            ya, _ = K.conv2d(xb, pw, b, out_slope=0.0, compute=K.BF16)
+            yb, _ = K.conv2d(xb.float(), pw, b, out_slope=0.0, compute=K.BF16)
+            assert torch.equal(ya, yb)
+            with pytest.raises(Exception):
+                K.conv2d(xb, pw, b, compute=K.BF16X3)
+    y = d(rng.standard_normal((3, 16, 64, 128)).astype(np.float32)).to(torch.bfloat16)
+    p32, p16 = K.maxpool(y, want_bf16=True)
+    assert torch.equal(p32, K.maxpool(y.float())) and torch.equal(p16, p32.to(torch.bfloat16))
+    dp = d(rng.standard_normal((3, 8, 32, 128)).astype(np.float32))
+    assert torch.equal(K.maxpool_relu_bwd(y, dp), K.maxpool_relu_bwd(y.float(), dp))
+    g = d(rng.standard_normal((3, 16, 64, 128)).astype(np.float32))
+    assert torch.equal(K.affine_act_bwd(y, g, None, None, 0.0), K.affine_act_bwd(y.float(), g, None, None, 0.0))
