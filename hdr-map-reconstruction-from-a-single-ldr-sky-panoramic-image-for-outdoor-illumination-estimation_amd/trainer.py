@@ -432,7 +432,9 @@ class Trainer:
         c, cp = self.conv, self.compute
         B = x.shape[0]
         R = {"in": x}
-        R["d1"], _ = c[net + "d1"].fwd(x, compute=cp, out_slope=0.3)
+        # d1 has no norm: its LeakyReLU output is a final activation - stored as bf16 in the single-product mode (what d2's
+        # conv and weight gradient would round it to anyway)
+        R["d1"], _ = c[net + "d1"].fwd(x, compute=cp, out_slope=0.3, out_bf16=self._act_bf16())
         cur, xf = R["d1"], None
         for d in ("d2", "d3", "d4"):
             raw, st = c[net + d].fwd(cur, xf, cp, want_stats=training)
@@ -478,7 +480,7 @@ class Trainer:
         c, cp = self.conv, self.compute
         B = x2.shape[0] // 2
         R = {"in": x2}
-        R["d1"], _ = c[net + "d1"].fwd(x2, compute=cp, out_slope=0.3)
+        R["d1"], _ = c[net + "d1"].fwd(x2, compute=cp, out_slope=0.3, out_bf16=self._act_bf16())
         cur, xf = R["d1"], None
         for d in ("d2", "d3", "d4"):
             raw, st = c[net + d].fwd(cur, xf, cp, want_stats=True)
@@ -528,6 +530,10 @@ class Trainer:
     # ---- VGG16 perceptual term (vgg16.py:127-165, train.py:308-313) ---------------------------------------
     VGG_BLOCKS = (("conv1_1", "conv1_2"), ("conv2_1", "conv2_2"), ("conv3_1", "conv3_2", "conv3_3"))
 
+    def _act_bf16(self):
+        """Final activations of ReLU / LeakyReLU-only stretches are stored as bf16 (HDRSKY_BF16 mode; HDRSKY_VGG_BF16=0: A/B hook)."""
+        return self.compute == BF16 and not self.precise and os.environ.get("HDRSKY_VGG_BF16", "1") != "0"
+
     def _vgg_forward(self, x_gamma, keep):
         """pool1..3 of a gamma-domain BGR batch; `keep` collects what the backward pass re-reads."""
         cp = self.compute
@@ -536,7 +542,7 @@ class Trainer:
         # HDRSKY_BF16: the chain's activations live in bf16 (ReLU only, so they are final: the next conv would round them to
         # bf16 anyway - its result is bit-identical - and the fp32 input / output bursts of these launches halve); the
         # pooled features of the perceptual term are returned in fp32
-        b16 = cp == BF16 and not self.precise and os.environ.get("HDRSKY_VGG_BF16", "1") != "0"     # (the variable: an A/B hook)
+        b16 = self._act_bf16()
         for blk in self.VGG_BLOCKS:
             for name in blk:
                 if keep is not None:
