@@ -24,9 +24,16 @@ class Vgg16:
         """bgr01: gamma-domain BGR in [0,1] -> *255 - mean (vgg16.py:133-141) -> three pooled feature maps."""
         x = K.vgg_pre(bgr01)
         pools = []
+        # single-product mode: the chain's (ReLU-only, hence final) activations are stored as bf16 - what the next conv
+        # rounds its operand to anyway, so its result is bit-identical; the pooled features come back in fp32
+        b16 = self.compute == K.BF16
         for blk in BLOCKS:
             for name in blk:
-                x, _ = K.conv2d(x, self._pk[name], self.p[name + ".b"], out_slope=0.0, compute=self.compute)
-            x = K.maxpool(x)
-            pools.append(x)
+                x, _ = K.conv2d(x, self._pk[name], self.p[name + ".b"], out_slope=0.0, compute=self.compute, out_bf16=b16)
+            if b16:
+                p32, x = K.maxpool(x, want_bf16=blk is not BLOCKS[-1])
+                pools.append(p32)
+            else:
+                x = K.maxpool(x)
+                pools.append(x)
         return tuple(pools)
