@@ -23,7 +23,7 @@ class ConvDesc(ctypes.Structure):
                  "upsample", "dilate", "Hc", "Wc", "compute", "in_mode", "ss_bstride", "in_nparts")] + \
                [("in_eps", c_float), ("in_slope", c_float), ("out_slope", c_float),
                 ("final_relu", ctypes.c_int32), ("want_stats", ctypes.c_int32), ("x_bf16", ctypes.c_int32),
-                ("y_bf16", ctypes.c_int32)]
+                ("y_bf16", ctypes.c_int32), ("res_mode", ctypes.c_int32), ("mask_slope", c_float)]
 
 
 P = c_void_p
@@ -116,7 +116,7 @@ SIGNATURES = {
     "hdrsky_slice_channels": (c_int, [P, c_size_t, c_int, c_int, c_int, c_float, c_int, P, P]),
     "hdrsky_pad_channels": (c_int, [P, c_size_t, c_int, c_int, P, P]),
     "hdrsky_maxpool_fwd_bf16": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P]),
-    "hdrsky_maxpool_relu_bwd_bf16": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P]),
+    "hdrsky_maxpool_relu_bwd_bf16": (c_int, [P, P, c_int, c_int, c_int, c_int, P, c_int, P]),
     "hdrsky_act_bwd_bf16": (c_int, [P, P, c_float, c_size_t, P, P]),
     "hdrsky_concat2": (c_int, [P, c_int, P, c_int, c_size_t, P, P]),
     "hdrsky_vgg_pre": (c_int, [P, c_size_t, P, P]),

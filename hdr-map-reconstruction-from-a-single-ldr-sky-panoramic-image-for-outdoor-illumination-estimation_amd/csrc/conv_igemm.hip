@@ -47,6 +47,7 @@ struct ConvKArgs {
   int off_alo, off_b, off_ss, off_tap, off_stat, off_ktab, off_out;
   unsigned long long* stamps;  // debug: per-workgroup phase time stamps (null in production)
   int x_bf16, y_bf16;          // activation storage (hdrsky_conv_desc)
+  int res_mode; float mask_slope;
 };
 
 // load 8 consecutive channels and apply the producer's affine + leaky activation
@@ -592,8 +593,16 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB
       }
       if (vec) {
         if (a.residual != nullptr) {
-          const float4 r = *reinterpret_cast<const float4*>(a.residual + idx);
-          v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+          if (a.res_mode == 1) {   // bf16 activated tensor: gradient mask of the activation behind this data gradient
+            const uint2 mk = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(a.residual) + idx);
+            const float m4[4] = {__builtin_bit_cast(float, mk.x << 16), __builtin_bit_cast(float, mk.x & 0xffff0000u),
+                                 __builtin_bit_cast(float, mk.y << 16), __builtin_bit_cast(float, mk.y & 0xffff0000u)};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= (m4[e] > 0.f ? 1.f : a.mask_slope);
+          } else {
+            const float4 r = *reinterpret_cast<const float4*>(a.residual + idx);
+            v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+          }
         }
         if (a.final_relu) {
 #pragma unroll
@@ -947,6 +956,7 @@ int hdrsky_conv2d_fwd(const hdrsky_conv_desc* d, const float* x, const void* w_h
   if (d->x_bf16 && (precise || narrow || d->upsample != 1 || d->in_mode != HDRSKY_IN_NONE || d->in_slope != 1.f))
     return HDRSKY_EUNSUPPORTED;   // a bf16 operand is a final activation of the single-product mode
   if (d->y_bf16 && (precise || (d->Cout & 3))) return HDRSKY_EUNSUPPORTED;
+  if (d->res_mode != 0 && (d->res_mode != 1 || !residual || (d->Cout & 3))) return HDRSKY_EINVAL;
   ConvKArgs a{};
   a.x = x; a.whi = (const uint4*)w_hi; a.wlo = (const uint4*)w_lo; a.bias = bias;
   a.in_scale = in_scale; a.in_shift = in_shift; a.in_part = in_part; a.in_gamma = in_gamma; a.in_beta = in_beta;
@@ -960,7 +970,7 @@ int hdrsky_conv2d_fwd(const hdrsky_conv_desc* d, const float* x, const void* w_h
   a.in_eps = d->in_eps; a.in_inv_count = 1.f / (float)(d->H * d->W); a.in_slope = d->in_slope;
   a.out_slope = d->out_slope; a.final_relu = d->final_relu; a.want_stats = d->want_stats;
   a.stamps = g_stamps;
-  a.x_bf16 = d->x_bf16; a.y_bf16 = d->y_bf16;
+  a.x_bf16 = d->x_bf16; a.y_bf16 = d->y_bf16; a.res_mode = d->res_mode; a.mask_slope = d->mask_slope;
   hipStream_t s = (hipStream_t)stream;
   const TileCfg t = choose_tile(d);
   if (narrow) return precise ? dispatch_tile<true, true>(a, t, s) : dispatch_tile<true, false>(a, t, s);

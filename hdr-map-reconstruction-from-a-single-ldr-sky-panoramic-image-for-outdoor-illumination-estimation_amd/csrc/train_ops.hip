@@ -233,8 +233,9 @@ __global__ void maxpool_fwd_bf16_kernel(const unsigned short* __restrict__ y, in
   }
 }
 
+template <bool OB>
 __global__ void maxpool_relu_bwd_bf16_kernel(const unsigned short* __restrict__ y, const float* __restrict__ dp, int B, int H,
-                                             int W, int C, float* __restrict__ dy) {
+                                             int W, int C, void* __restrict__ dyv) {
   const int c4 = C >> 2, Hp = H >> 1, Wp = W >> 1;
   const size_t total = (size_t)B * Hp * Wp * c4;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -262,7 +263,13 @@ __global__ void maxpool_relu_bwd_bf16_kernel(const unsigned short* __restrict__ 
       for (int k = 0; k < 4; ++k) o[k][j] = (k == am && v[k][j] > 0.f) ? us[j] : 0.f;
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) reinterpret_cast<float4*>(dy)[idx[k]] = make_float4(o[k][0], o[k][1], o[k][2], o[k][3]);
+    for (int k = 0; k < 4; ++k) {
+      if (OB)
+        reinterpret_cast<uint2*>(dyv)[idx[k]] = uint2{(unsigned)f2bf(o[k][0]) | ((unsigned)f2bf(o[k][1]) << 16),
+                                                      (unsigned)f2bf(o[k][2]) | ((unsigned)f2bf(o[k][3]) << 16)};
+      else
+        reinterpret_cast<float4*>(dyv)[idx[k]] = make_float4(o[k][0], o[k][1], o[k][2], o[k][3]);
+    }
   }
 }
 
@@ -907,10 +914,15 @@ int hdrsky_maxpool_fwd_bf16(const void* y, int B, int H, int W, int C, float* p3
   return HDRSKY_OK;
 }
 
-int hdrsky_maxpool_relu_bwd_bf16(const void* y, const float* dp, int B, int H, int W, int C, float* dy, void* stream) {
+int hdrsky_maxpool_relu_bwd_bf16(const void* y, const float* dp, int B, int H, int W, int C, void* dy, int dy_bf16,
+                                 void* stream) {
   if (!y || !dp || !dy || (C & 3) || ((H | W) & 1)) return HDRSKY_EINVAL;
-  hipLaunchKernelGGL(maxpool_relu_bwd_bf16_kernel, dim3(grid_for((size_t)B * H * W * C / 16)), dim3(256), 0, S_(stream),
-                     (const unsigned short*)y, dp, B, H, W, C, dy);
+  if (dy_bf16)
+    hipLaunchKernelGGL(maxpool_relu_bwd_bf16_kernel<true>, dim3(grid_for((size_t)B * H * W * C / 16)), dim3(256), 0, S_(stream),
+                       (const unsigned short*)y, dp, B, H, W, C, dy);
+  else
+    hipLaunchKernelGGL(maxpool_relu_bwd_bf16_kernel<false>, dim3(grid_for((size_t)B * H * W * C / 16)), dim3(256), 0, S_(stream),
+                       (const unsigned short*)y, dp, B, H, W, C, dy);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }

@@ -110,9 +110,11 @@ def _bf16(t, *shape):
 
 def conv2d(x, pw: PackedConv, bias=None, stride=1, same=True, upsample=1, xf: Optional[InXf] = None,
            out_slope=1.0, residual=None, final_relu=False, want_stats=False, compute=BF16, desc=None, out=None,
-           out_bf16=False):
+           out_bf16=False, mask_bf16=None, mask_slope=0.0):
     """y = final_relu(act(conv(xf(x)) + bias) + residual); returns (y, Stats|None).
-    HDRSKY_BF16 mode: x may be a bfloat16 tensor (a final activation: no xf), out_bf16 stores y as bfloat16."""
+    HDRSKY_BF16 mode: x may be a bfloat16 tensor (a final activation: no xf), out_bf16 stores y as bfloat16; mask_bf16
+    (instead of residual): a bfloat16 ACTIVATED tensor of y's shape - y is multiplied by (it > 0 ? 1 : mask_slope), the
+    activation backward fused into a data-gradient conv."""
     lib = L.load()
     if torch.is_tensor(x) and x.dtype == torch.bfloat16:
         _bf16(x)
@@ -154,7 +156,12 @@ def conv2d(x, pw: PackedConv, bias=None, stride=1, same=True, upsample=1, xf: Op
     ydt = torch.bfloat16 if out_bf16 else torch.float32
     y = out if out is not None else torch.empty((B, d.Ho, d.Wo, pw.Cout), dtype=ydt, device=x.device)
     (_bf16 if out_bf16 else _f32)(y, B, d.Ho, d.Wo, pw.Cout)
-    if residual is not None:
+    if mask_bf16 is not None:
+        if residual is not None:
+            raise ValueError("residual and mask_bf16 exclude each other")
+        residual = _bf16(mask_bf16, B, d.Ho, d.Wo, pw.Cout)
+        d.res_mode, d.mask_slope = 1, float(mask_slope)
+    elif residual is not None:
         _f32(residual, B, d.Ho, d.Wo, pw.Cout)
     stats = None
     if want_stats:
@@ -522,9 +529,11 @@ def conv_dgrad_desc(fwd):
     return d
 
 
-def conv2d_dgrad(dy, pwT: PackedConv, fwd_desc, residual=None, compute=BF16, want_stats=False):
-    """Gradient wrt the conv-input domain of the forward conv `fwd_desc` (pwT = PackedConv(w, transpose_flip=True))."""
-    return conv2d(dy, pwT, None, desc=conv_dgrad_desc(fwd_desc), residual=residual, compute=compute, want_stats=want_stats)
+def conv2d_dgrad(dy, pwT: PackedConv, fwd_desc, residual=None, compute=BF16, want_stats=False, **kw):
+    """Gradient wrt the conv-input domain of the forward conv `fwd_desc` (pwT = PackedConv(w, transpose_flip=True)).
+    kw: out_bf16 / mask_bf16 / mask_slope of conv2d (the activation backward in front of the NEXT data gradient)."""
+    return conv2d(dy, pwT, None, desc=conv_dgrad_desc(fwd_desc), residual=residual, compute=compute, want_stats=want_stats,
+                  **kw)
 
 
 def _empty_like_shape(t, shape):
@@ -601,13 +610,16 @@ def maxpool(y, want_bf16=False):
     return p
 
 
-def maxpool_relu_bwd(y, dp):
+def maxpool_relu_bwd(y, dp, out_bf16=False):
     B, H, W, C = y.shape
     _f32(dp, B, H // 2, W // 2, C)
-    dy = torch.empty((B, H, W, C), dtype=torch.float32, device=y.device)
+    dy = torch.empty((B, H, W, C), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=y.device)
     if y.dtype == torch.bfloat16:
-        L.check(L.load().hdrsky_maxpool_relu_bwd_bf16(_p(_bf16(y)), _p(dp), B, H, W, C, _p(dy), _stream()), "maxpool_relu_bwd_bf16")
+        L.check(L.load().hdrsky_maxpool_relu_bwd_bf16(_p(_bf16(y)), _p(dp), B, H, W, C, _p(dy), int(out_bf16), _stream()),
+                "maxpool_relu_bwd_bf16")
         return dy
+    if out_bf16:
+        raise ValueError("bf16 output: bf16 activation input only")
     _f32(y)
     L.check(L.load().hdrsky_maxpool_relu_bwd(_p(y), _p(dp), B, H, W, C, _p(dy), _stream()), "maxpool_relu_bwd")
     return dy

@@ -576,11 +576,16 @@ class Trainer:
         g = None
         for bi, blk in reversed(list(enumerate(self.VGG_BLOCKS))):
             dp = dps[bi] if g is None else K.axpby(dps[bi], 1.0, g, 1.0)
-            g = K.maxpool_relu_bwd(acts[blk[-1]], dp)          # wrt the pre-ReLU output of the block's last conv
+            b16 = acts[blk[-1]].dtype == torch.bfloat16     # bf16 chain: gradients between the data-gradient convs are final
+            g = K.maxpool_relu_bwd(acts[blk[-1]], dp, out_bf16=b16)   # wrt the pre-ReLU output of the block's last conv
             for k in range(len(blk) - 1, -1, -1):
                 name = blk[k]
                 xin = acts[name + ".in"]
                 d = K.conv_desc(B, xin.shape[1], xin.shape[2], xin.shape[3], self.vgg_pk[name].Cout, 3, 3, 1, True, 1)
+                if b16 and k > 0:     # the ReLU mask of the layer below rides in this conv's epilogue, bf16 out
+                    g, _ = K.conv2d_dgrad(g, self.vgg_pkT[name], d, compute=cp, mask_bf16=acts[blk[k - 1]], mask_slope=0.0,
+                                          out_bf16=True)
+                    continue
                 g, _ = K.conv2d_dgrad(g, self.vgg_pkT[name], d, compute=cp)   # wrt this conv's (post-ReLU) input
                 if k > 0:
                     g = K.affine_act_bwd(acts[blk[k - 1]], g, None, None, 0.0)

@@ -81,6 +81,10 @@ typedef struct hdrsky_conv_desc {
                              upsample 1) - what the staging would have rounded the fp32 tensor to anyway */
   int32_t y_bf16;         /* y points to bf16 [B,Ho,Wo,Cout] (Cout % 4 == 0): the epilogue result rounded to nearest even;
                              the statistics are still taken from the fp32 values */
+  int32_t res_mode;       /* 0: `residual` is an fp32 tensor that is added.  1: `residual` points to a bf16 ACTIVATED tensor of
+                             y's shape and the result is multiplied by (it > 0 ? 1 : mask_slope) - the activation backward
+                             fused into a data-gradient conv (grad through ReLU: mask_slope 0) */
+  float mask_slope;
 } hdrsky_conv_desc;
 
 /* Fills Ho/Wo/pad/Hc/Wc for TF padding ("SAME": same=1, "VALID": same=0); returns 0 or HDRSKY_EINVAL. [host] */
@@ -298,7 +302,8 @@ int hdrsky_pad_channels(const float* x, size_t npix, int C, int Cpad, float* out
  * operand to bf16 anyway): 2x2 max-pool of a bf16 map -> fp32 pool (the perceptual feature) and / or bf16 pool (the next
  * conv's operand); the pool + ReLU backward and the plain activation backward with the ACTIVATED tensor given as bf16. */
 int hdrsky_maxpool_fwd_bf16(const void* y_bf16, int B, int H, int W, int C, float* p_f32, void* p_bf16, void* stream);
-int hdrsky_maxpool_relu_bwd_bf16(const void* y_bf16, const float* dp, int B, int H, int W, int C, float* dy, void* stream);
+int hdrsky_maxpool_relu_bwd_bf16(const void* y_bf16, const float* dp, int B, int H, int W, int C, void* dy, int dy_bf16,
+                                 void* stream);   /* dy_bf16: dy is stored as bf16 (the operand of the next data-gradient conv) */
 int hdrsky_act_bwd_bf16(const void* y_bf16, const float* dy, float slope, size_t n, float* dx, void* stream);
 /* tf.concat([a, b], axis=-1) (discriminator.py:43). */
 int hdrsky_concat2(const float* a, int Ca, const float* b, int Cb, size_t npix, float* out, void* stream);

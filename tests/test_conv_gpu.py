@@ -162,10 +162,21 @@ def test_bf16_activation_storage_is_bit_neutral_for_relu_chains(dev):
             assert torch.equal(ya, yb)
             with pytest.raises(Exception):
                 K.conv2d(xb, pw, b, compute=K.BF16X3)
+    # the activation backward in the epilogue of a data-gradient conv (res_mode 1) + bf16 output
+    x = d(rng.standard_normal((2, 16, 64, 128)).astype(np.float32)).to(torch.bfloat16)
+    w = d((rng.standard_normal((3, 3, 64, 128)) / 24).astype(np.float32))            # forward filter 64 -> 128
+    act = d(rng.standard_normal((2, 16, 64, 64)).astype(np.float32)).to(torch.bfloat16)
+    pT = K.PackedConv(w, transpose_flip=True)
+    fd = K.conv_desc(2, 16, 64, 64, 128, 3, 3, 1, True, 1)
+    g_plain, _ = K.conv2d_dgrad(x, pT, fd, compute=K.BF16)
+    g_mask, _ = K.conv2d_dgrad(x, pT, fd, compute=K.BF16, mask_bf16=act, mask_slope=0.0, out_bf16=True)
+    assert torch.equal(g_mask, (g_plain * (act.float() > 0)).to(torch.bfloat16))
+    assert torch.equal(g_mask.float(), K.affine_act_bwd(act, g_plain, None, None, 0.0).to(torch.bfloat16).float())
     y = d(rng.standard_normal((3, 16, 64, 128)).astype(np.float32)).to(torch.bfloat16)
     p32, p16 = K.maxpool(y, want_bf16=True)
     assert torch.equal(p32, K.maxpool(y.float())) and torch.equal(p16, p32.to(torch.bfloat16))
     dp = d(rng.standard_normal((3, 8, 32, 128)).astype(np.float32))
     assert torch.equal(K.maxpool_relu_bwd(y, dp), K.maxpool_relu_bwd(y.float(), dp))
+    assert torch.equal(K.maxpool_relu_bwd(y, dp, out_bf16=True), K.maxpool_relu_bwd(y.float(), dp).to(torch.bfloat16))
     g = d(rng.standard_normal((3, 16, 64, 128)).astype(np.float32))
     assert torch.equal(K.affine_act_bwd(y, g, None, None, 0.0), K.affine_act_bwd(y.float(), g, None, None, 0.0))
