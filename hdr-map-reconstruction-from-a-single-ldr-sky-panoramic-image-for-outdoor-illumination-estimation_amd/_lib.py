@@ -64,7 +64,7 @@ SIGNATURES = {
     "hdrsky_norm_apply": (c_int, [P, P, c_int, P, P, c_float, c_float, P, P, P, c_int, c_int, c_int, c_int, P]),
     "hdrsky_in_finalize": (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_float, P, P, P, P, P]),
     "hdrsky_bn_eval_affine": (c_int, [P, P, P, P, c_float, c_int, P, P, P]),
-    "hdrsky_norm_act_bwd": (c_int, [P, P, c_int, P, P, c_float, c_float, P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "hdrsky_norm_act_bwd": (c_int, [P, P, c_int, P, P, c_float, c_float, P, c_int, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "hdrsky_norm_act_bwd_nslices": (c_int, [c_int] * 5),
     "hdrsky_fc_pack_weights": (c_int, [P, c_int, c_int, P, P, P, P, P]),
     "hdrsky_fc_nsplit": (c_int, [c_int]),
@@ -96,8 +96,8 @@ SIGNATURES = {
     "hdrsky_bn_train_finalize": (c_int, [P, c_int, c_int, c_int, P, P, c_float, c_float, P, P, P, P, P, P, c_int, P]),
     "hdrsky_zero": (c_int, [P, c_size_t, P]),
     "hdrsky_bn_bwd_nblocks": (c_int, []),
-    "hdrsky_bn_act_bwd": (c_int, [P, P, P, P, P, P, c_float, c_int, c_int, P, P, P, P, P]),
-    "hdrsky_affine_act_bwd": (c_int, [P, P, P, P, c_float, c_size_t, c_int, P, P]),
+    "hdrsky_bn_act_bwd": (c_int, [P, P, P, P, P, P, c_float, c_int, c_int, P, P, P, P, c_int, P]),
+    "hdrsky_affine_act_bwd": (c_int, [P, P, P, P, c_float, c_size_t, c_int, P, c_int, P]),
     "hdrsky_maxpool_fwd": (c_int, [P, c_int, c_int, c_int, c_int, P, P]),
     "hdrsky_maxpool_relu_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P]),
     "hdrsky_up2x_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P]),
@@ -117,7 +117,7 @@ SIGNATURES = {
     "hdrsky_pad_channels": (c_int, [P, c_size_t, c_int, c_int, P, P]),
     "hdrsky_maxpool_fwd_bf16": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P]),
     "hdrsky_maxpool_relu_bwd_bf16": (c_int, [P, P, c_int, c_int, c_int, c_int, P, c_int, P]),
-    "hdrsky_act_bwd_bf16": (c_int, [P, P, c_float, c_size_t, P, P]),
+    "hdrsky_act_bwd_bf16": (c_int, [P, P, c_float, c_size_t, P, c_int, P]),
     "hdrsky_concat2": (c_int, [P, c_int, P, c_int, c_size_t, P, P]),
     "hdrsky_vgg_pre": (c_int, [P, c_size_t, P, P]),
     "hdrsky_flip_rgb": (c_int, [P, c_size_t, P, P]),

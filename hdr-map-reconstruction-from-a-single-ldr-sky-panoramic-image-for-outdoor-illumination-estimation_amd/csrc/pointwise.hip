@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(256) norm_act_bwd_kernel(const float* __restri
                                                            int nparts, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps, float slope,
                                                            const float* __restrict__ dy, int pooled,
-                                                           float* __restrict__ dx, float* __restrict__ sums,
+                                                           void* __restrict__ dxv, int dx_bf16, float* __restrict__ sums,
                                                            float* dgamma, float* dbeta, float* __restrict__ ws, int S,
                                                            int B, int H, int W, int C) {
   __shared__ float sRed[64][2][16];
@@ -185,7 +185,15 @@ __global__ void __launch_bounds__(256) norm_act_bwd_kernel(const float* __restri
     }
   }
   const float* xb = x + (size_t)b * H * W * C + c;
-  float* dxb = dx + (size_t)b * H * W * C + c;
+  // dx: fp32, or bf16 when its only readers are a data-gradient conv and a weight gradient (both round it to bf16 anyway)
+  float* dxb = reinterpret_cast<float*>(dxv) + (size_t)b * H * W * C + c;
+  unsigned short* dxh = reinterpret_cast<unsigned short*>(dxv) + (size_t)b * H * W * C + c;
+  auto put = [&](size_t off, const float4& o) {
+    if (dx_bf16)
+      *reinterpret_cast<uint2*>(dxh + off) = uint2{(unsigned)f2bf(o.x) | ((unsigned)f2bf(o.y) << 16), (unsigned)f2bf(o.z) | ((unsigned)f2bf(o.w) << 16)};
+    else
+      *reinterpret_cast<float4*>(dxb + off) = o;
+  };
   const int Hp = H >> 1, Wp = W >> 1;
   const int nunits = pooled ? Hp * Wp : H * W;            // pixels, or 2x2 windows
   const int per = (nunits + S - 1) / S;
@@ -236,7 +244,7 @@ __global__ void __launch_bounds__(256) norm_act_bwd_kernel(const float* __restri
           o.y = gm[1] * rstd[1] * (g[1] - s1[1] - xh[1] * s2[1]);
           o.z = gm[2] * rstd[2] * (g[2] - s1[2] - xh[2] * s2[2]);
           o.w = gm[3] * rstd[3] * (g[3] - s1[3] - xh[3] * s2[3]);
-          *reinterpret_cast<float4*>(dxb + (size_t)p * C) = o;
+          put((size_t)p * C, o);
         }
       }
     } else {
@@ -287,7 +295,7 @@ __global__ void __launch_bounds__(256) norm_act_bwd_kernel(const float* __restri
             o.y = gm[1] * rstd[1] * (g[k][1] - s1[1] - xh[k][1] * s2[1]);
             o.z = gm[2] * rstd[2] * (g[k][2] - s1[2] - xh[k][2] * s2[2]);
             o.w = gm[3] * rstd[3] * (g[k][3] - s1[3] - xh[k][3] * s2[3]);
-            *reinterpret_cast<float4*>(dxb + (size_t)p * C) = o;
+            put((size_t)p * C, o);
           }
         }
       }
@@ -766,24 +774,24 @@ int hdrsky_norm_act_bwd_nslices(int B, int H, int W, int C, int pooled) {
 }
 
 int hdrsky_norm_act_bwd(const float* x, const float* part, int nparts, const float* gamma, const float* beta,
-                        float eps, float slope, const float* dy, int pooled, float* dx, float* sums, float* dgamma,
-                        float* dbeta, float* ws, int B, int H, int W, int C, void* stream) {
+                        float eps, float slope, const float* dy, int pooled, void* dx, int dx_bf16, float* sums,
+                        float* dgamma, float* dbeta, float* ws, int B, int H, int W, int C, void* stream) {
   if (!x || !part || !gamma || !beta || !dy || !dx || (C & 15)) return HDRSKY_EINVAL;
   if (pooled && ((H | W) & 1)) return HDRSKY_EINVAL;
   const int S = hdrsky_norm_act_bwd_nslices(B, H, W, C, pooled);
   const int groups = B * (C / 16);
   if (S == 1) {
     hipLaunchKernelGGL(norm_act_bwd_kernel<2>, dim3(groups), dim3(256), 0, (hipStream_t)stream, x, part, nparts, gamma,
-                       beta, eps, slope, dy, pooled, dx, sums, dgamma, dbeta, ws, 1, B, H, W, C);
+                       beta, eps, slope, dy, pooled, dx, dx_bf16, sums, dgamma, dbeta, ws, 1, B, H, W, C);
     HDRSKY_CHECK_LAUNCH();
     return HDRSKY_OK;
   }
   if (!ws) return HDRSKY_EINVAL;
   hipLaunchKernelGGL(norm_act_bwd_kernel<0>, dim3(groups * S), dim3(256), 0, (hipStream_t)stream, x, part, nparts, gamma,
-                     beta, eps, slope, dy, pooled, dx, sums, dgamma, dbeta, ws, S, B, H, W, C);
+                     beta, eps, slope, dy, pooled, dx, dx_bf16, sums, dgamma, dbeta, ws, S, B, H, W, C);
   HDRSKY_CHECK_LAUNCH();
   hipLaunchKernelGGL(norm_act_bwd_kernel<1>, dim3(groups * S), dim3(256), 0, (hipStream_t)stream, x, part, nparts, gamma,
-                     beta, eps, slope, dy, pooled, dx, sums, dgamma, dbeta, ws, S, B, H, W, C);
+                     beta, eps, slope, dy, pooled, dx, dx_bf16, sums, dgamma, dbeta, ws, S, B, H, W, C);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }

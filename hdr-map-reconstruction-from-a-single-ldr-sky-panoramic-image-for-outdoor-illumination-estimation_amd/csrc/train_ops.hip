@@ -101,10 +101,18 @@ __global__ void __launch_bounds__(64) bn_bwd_finalize_kernel(const float* __rest
   if (dgamma) dgamma[c] += s2;
 }
 
+// four consecutive elements of a gradient tensor, fp32 or bf16 (element group i4)
+__device__ __forceinline__ void st4(void* p, int as_bf16, size_t i4, const float (&o)[4]) {
+  if (as_bf16)
+    reinterpret_cast<uint2*>(p)[i4] = uint2{(unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16), (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16)};
+  else
+    reinterpret_cast<float4*>(p)[i4] = make_float4(o[0], o[1], o[2], o[3]);
+}
+
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                     const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
-                                    const float* __restrict__ m1m2, size_t n4, int C, float* __restrict__ dx) {
+                                    const float* __restrict__ m1m2, size_t n4, int C, void* __restrict__ dx, int dx_bf16) {
   const int c4 = C >> 2;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % c4) * 4;
@@ -118,7 +126,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
       const float g = ds[j] * ((xh * gamma[c + j] + beta[c + j]) > 0.f ? 1.f : slope);
       o[j] = gamma[c + j] * rstd[c + j] * (g - m1m2[c + j] - xh * m1m2[C + c + j]);
     }
-    reinterpret_cast<float4*>(dx)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    st4(dx, dx_bf16, i, o);
   }
 }
 
@@ -127,7 +135,8 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
 template <int V>   // V = 4: float4 per thread (C % 4 == 0, 16-byte aligned tensors), else 1
 __global__ void affine_act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                       const float* __restrict__ scale, const float* __restrict__ shift, float slope,
-                                      size_t n, int C, float* __restrict__ dx) {
+                                      size_t n, int C, void* __restrict__ dxv, int dx_bf16) {
+  float* dx = reinterpret_cast<float*>(dxv);
   for (size_t i = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) * V; i < n; i += (size_t)gridDim.x * blockDim.x * V) {
     const int c = (int)(i % C);
     float v[V], g[V], o[V];
@@ -143,7 +152,7 @@ __global__ void affine_act_bwd_kernel(const float* __restrict__ x, const float* 
       if (scale) o[e] = g[e] * ((v[e] * scale[c + e] + shift[c + e]) > 0.f ? 1.f : slope) * scale[c + e];
       else o[e] = g[e] * (v[e] > 0.f ? 1.f : slope);
     }
-    if (V == 4) *reinterpret_cast<float4*>(dx + i) = make_float4(o[0], o[1 % V], o[2 % V], o[3 % V]);
+    if (V == 4) { const float o4[4] = {o[0], o[1 % V], o[2 % V], o[3 % V]}; st4(dxv, dx_bf16, i >> 2, o4); }
     else dx[i] = o[0];
   }
 }
@@ -274,13 +283,14 @@ __global__ void maxpool_relu_bwd_bf16_kernel(const unsigned short* __restrict__ 
 }
 
 __global__ void act_bwd_bf16_kernel(const unsigned short* __restrict__ y, const float* __restrict__ dy, float slope, size_t n4,
-                                    float* __restrict__ dx) {
+                                    void* __restrict__ dx, int dx_bf16) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     float v[4];
     ld4bf(y, i, v);
     const float4 g = reinterpret_cast<const float4*>(dy)[i];
-    reinterpret_cast<float4*>(dx)[i] = make_float4(g.x * (v[0] > 0.f ? 1.f : slope), g.y * (v[1] > 0.f ? 1.f : slope),
-                                                   g.z * (v[2] > 0.f ? 1.f : slope), g.w * (v[3] > 0.f ? 1.f : slope));
+    const float o[4] = {g.x * (v[0] > 0.f ? 1.f : slope), g.y * (v[1] > 0.f ? 1.f : slope),
+                        g.z * (v[2] > 0.f ? 1.f : slope), g.w * (v[3] > 0.f ? 1.f : slope)};
+    st4(dx, dx_bf16, i, o);
   }
 }
 
@@ -865,7 +875,7 @@ int hdrsky_bn_bwd_nblocks(void) { return 128; }
 
 int hdrsky_bn_act_bwd(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
                       const float* beta, float slope, int npix, int C, float* workspace, float* dgamma, float* dbeta,
-                      float* dx, void* stream) {
+                      void* dx, int dx_bf16, void* stream) {
   if (!x || !dy || !mean || !rstd || !gamma || !beta || !workspace || !dx || (C & 3) || C > 1024) return HDRSKY_EINVAL;
   const int nb = 128;
   float* part = workspace;
@@ -875,18 +885,19 @@ int hdrsky_bn_act_bwd(const float* x, const float* dy, const float* mean, const 
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, S_(stream), part, nb, C, (float)npix, m1m2,
                      dgamma, dbeta);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for((size_t)npix * C / 4)), dim3(256), 0, S_(stream), x, dy, mean,
-                     rstd, gamma, beta, slope, m1m2, (size_t)npix * C / 4, C, dx);
+                     rstd, gamma, beta, slope, m1m2, (size_t)npix * C / 4, C, dx, dx_bf16);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }
 
 int hdrsky_affine_act_bwd(const float* x, const float* dy, const float* scale, const float* shift, float slope, size_t n,
-                          int C, float* dx, void* stream) {
+                          int C, void* dx, int dx_bf16, void* stream) {
   if (!x || !dy || !dx) return HDRSKY_EINVAL;
   const bool vec = (C & 3) == 0 && (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) |
                                                     reinterpret_cast<uintptr_t>(dx)) & 15) == 0;
-  if (vec) hipLaunchKernelGGL(affine_act_bwd_kernel<4>, dim3(grid_for(n / 4)), dim3(256), 0, S_(stream), x, dy, scale, shift, slope, n, C, dx);
-  else hipLaunchKernelGGL(affine_act_bwd_kernel<1>, dim3(grid_for(n)), dim3(256), 0, S_(stream), x, dy, scale, shift, slope, n, C, dx);
+  if (dx_bf16 && !vec) return HDRSKY_EUNSUPPORTED;
+  if (vec) hipLaunchKernelGGL(affine_act_bwd_kernel<4>, dim3(grid_for(n / 4)), dim3(256), 0, S_(stream), x, dy, scale, shift, slope, n, C, dx, dx_bf16);
+  else hipLaunchKernelGGL(affine_act_bwd_kernel<1>, dim3(grid_for(n)), dim3(256), 0, S_(stream), x, dy, scale, shift, slope, n, C, dx, 0);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }
@@ -927,11 +938,11 @@ int hdrsky_maxpool_relu_bwd_bf16(const void* y, const float* dp, int B, int H, i
   return HDRSKY_OK;
 }
 
-int hdrsky_act_bwd_bf16(const void* y, const float* dy, float slope, size_t n, float* dx, void* stream) {
+int hdrsky_act_bwd_bf16(const void* y, const float* dy, float slope, size_t n, void* dx, int dx_bf16, void* stream) {
   if (!y || !dy || !dx || (n & 3)) return HDRSKY_EINVAL;
   if (n == 0) return HDRSKY_OK;
   hipLaunchKernelGGL(act_bwd_bf16_kernel, dim3(grid_for(n / 4)), dim3(256), 0, S_(stream), (const unsigned short*)y, dy,
-                     slope, n / 4, dx);
+                     slope, n / 4, dx, dx_bf16);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }

@@ -241,13 +241,13 @@ def gradcam_sweep(nets, t, pick_src, compute):
                                   s["sunlayer3.norm2.beta"])
         sP2 = K.spatial_sum(dP2, 1.0 / ((h // 2) * (w // 2)))         # GAP numerator of d y_c / d A2 as a [B,C] table
     else:
-        g = K.norm_act_bwd(t["r3b"], t["st3b"], s["sunlayer3.norm2.gamma"], s["sunlayer3.norm2.beta"], 0.0, dP3, True)
+        g = K.norm_act_bwd(t["r3b"], t["st3b"], s["sunlayer3.norm2.gamma"], s["sunlayer3.norm2.beta"], 0.0, dP3, True, out_bf16=compute == BF16)
         g, _ = K.conv2d(g, pk["sun.sunlayer3.conv2.T"], None, compute=compute)
-        g = K.norm_act_bwd(t["r3a"], t["st3a"], s["sunlayer3.norm1.gamma"], s["sunlayer3.norm1.beta"], 0.0, g, False)
+        g = K.norm_act_bwd(t["r3a"], t["st3a"], s["sunlayer3.norm1.gamma"], s["sunlayer3.norm1.beta"], 0.0, g, False, out_bf16=compute == BF16)
         dP2, sP2 = K.conv2d(g, pk["sun.sunlayer3.conv1.T"], None, compute=compute, want_stats=True)
-    g = K.norm_act_bwd(t["r2b"], t["st2b"], s["sunlayer2.norm2.gamma"], s["sunlayer2.norm2.beta"], 0.0, dP2, True)
+    g = K.norm_act_bwd(t["r2b"], t["st2b"], s["sunlayer2.norm2.gamma"], s["sunlayer2.norm2.beta"], 0.0, dP2, True, out_bf16=compute == BF16)
     g, _ = K.conv2d(g, pk["sun.sunlayer2.conv2.T"], None, compute=compute)
-    g = K.norm_act_bwd(t["r2a"], t["st2a"], s["sunlayer2.norm1.gamma"], s["sunlayer2.norm1.beta"], 0.0, g, False)
+    g = K.norm_act_bwd(t["r2a"], t["st2a"], s["sunlayer2.norm1.gamma"], s["sunlayer2.norm1.beta"], 0.0, g, False, out_bf16=compute == BF16)
     _, sP1 = K.conv2d(g, pk["sun.sunlayer2.conv1.T"], None, compute=compute, want_stats=True)
     # GAP of d y_c / d A_k == sum of the pooled-map gradient / (H_k*W_k): the dgrad conv's per-tile sums
     cam2 = K.grad_cam_map(t["A2"], sP2) if "s3" in t else K.grad_cam_map(t["A2"], sP2, 1.0 / ((h // 2) * (w // 2)))

@@ -319,7 +319,7 @@ def bn_eval_affine(gamma, beta, mm, mv, eps=IN_EPS):
 
 
 def norm_act_bwd(x, stats: Stats, gamma, beta, slope, dy, pooled, eps=IN_EPS, want_sums=False, dgamma=None, dbeta=None,
-                 sums=None):
+                 sums=None, out_bf16=False):
     """dx of y = leaky(IN(x)) [-> maxpool2x2]; dy is the gradient wrt y (or wrt the pooled y).
     sums [B,2,C] (given, or allocated when want_sums): per-sample (d beta, d gamma) terms - reduce them over the batch with
     DgbReducer for bit-reproducible gradients; dgamma / dbeta: accumulated by fp32 atomics instead (arrival order)."""
@@ -327,7 +327,8 @@ def norm_act_bwd(x, stats: Stats, gamma, beta, slope, dy, pooled, eps=IN_EPS, wa
     B, H, W, C = x.shape
     _f32(stats.part, B, stats.nparts, 2, C)
     _f32(dy, B, H // 2 if pooled else H, W // 2 if pooled else W, C)
-    dx = torch.empty_like(x)
+    # out_bf16: dx only feeds a data-gradient conv / a weight gradient, which round it to bf16 anyway (HDRSKY_BF16 mode)
+    dx = torch.empty(x.shape, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
     if sums is not None:
         _f32(sums, B, 2, C)
         want_sums = False
@@ -336,8 +337,8 @@ def norm_act_bwd(x, stats: Stats, gamma, beta, slope, dy, pooled, eps=IN_EPS, wa
     S = L.load().hdrsky_norm_act_bwd_nslices(B, H, W, C, int(pooled))
     ws = torch.empty((B, S, 2, C), dtype=torch.float32, device=x.device) if S > 1 else None
     L.check(L.load().hdrsky_norm_act_bwd(_p(x), _p(stats.part), stats.nparts, _p(_f32(gamma, C)), _p(_f32(beta, C)),
-                                         eps, slope, _p(dy), int(pooled), _p(dx), _p(sums), _p(dgamma), _p(dbeta),
-                                         _p(ws), B, H, W, C, _stream()),
+                                         eps, slope, _p(dy), int(pooled), _p(dx), int(out_bf16), _p(sums), _p(dgamma),
+                                         _p(dbeta), _p(ws), B, H, W, C, _stream()),
             "norm_act_bwd")
     return (dx, sums) if want_sums else dx
 
@@ -568,31 +569,35 @@ def zero_(t):
     return t
 
 
-def bn_act_bwd(x, dy, mean, rstd, gamma, beta, slope, dgamma=None, dbeta=None, out=None):
+def bn_act_bwd(x, dy, mean, rstd, gamma, beta, slope, dgamma=None, dbeta=None, out=None, out_bf16=False):
     _f32(x); _f32(dy, *x.shape)
     C = x.shape[-1]
     npix = x.numel() // C
     lib = L.load()
     ws = torch.empty((2 * lib.hdrsky_bn_bwd_nblocks() * C + 2 * C,), dtype=torch.float32, device=x.device)
-    dx = _f32(out, *x.shape) if out is not None else torch.empty_like(x)
+    if out_bf16:
+        dx = _bf16(out, *x.shape) if out is not None else torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    else:
+        dx = _f32(out, *x.shape) if out is not None else torch.empty_like(x)
     L.check(lib.hdrsky_bn_act_bwd(_p(x), _p(dy), _p(_f32(mean, C)), _p(_f32(rstd, C)), _p(_f32(gamma, C)), _p(_f32(beta, C)),
-                                  slope, npix, C, _p(ws), _p(dgamma), _p(dbeta), _p(dx), _stream()), "bn_act_bwd")
+                                  slope, npix, C, _p(ws), _p(dgamma), _p(dbeta), _p(dx), int(out_bf16), _stream()), "bn_act_bwd")
     return dx
 
 
-def affine_act_bwd(x, dy, scale, shift, slope):
+def affine_act_bwd(x, dy, scale, shift, slope, out_bf16=False):
+    odt = torch.bfloat16 if out_bf16 else torch.float32
     if x.dtype == torch.bfloat16:      # plain activation backward on an ACTIVATED bf16 tensor
         if scale is not None or shift is not None:
             raise ValueError("a bf16 operand is a final activation: no affine")
         _bf16(x); _f32(dy, *x.shape)
-        dx = torch.empty_like(dy)
-        L.check(L.load().hdrsky_act_bwd_bf16(_p(x), _p(dy), slope, x.numel(), _p(dx), _stream()), "act_bwd_bf16")
+        dx = torch.empty(dy.shape, dtype=odt, device=dy.device)
+        L.check(L.load().hdrsky_act_bwd_bf16(_p(x), _p(dy), slope, x.numel(), _p(dx), int(out_bf16), _stream()), "act_bwd_bf16")
         return dx
     _f32(x); _f32(dy, *x.shape)
     C = x.shape[-1]
-    dx = torch.empty_like(x)
-    L.check(L.load().hdrsky_affine_act_bwd(_p(x), _p(dy), _p(scale), _p(shift), slope, x.numel(), C, _p(dx), _stream()),
-            "affine_act_bwd")
+    dx = torch.empty(x.shape, dtype=odt, device=x.device)
+    L.check(L.load().hdrsky_affine_act_bwd(_p(x), _p(dy), _p(scale), _p(shift), slope, x.numel(), C, _p(dx), int(out_bf16),
+                                           _stream()), "affine_act_bwd")
     return dx
 
 

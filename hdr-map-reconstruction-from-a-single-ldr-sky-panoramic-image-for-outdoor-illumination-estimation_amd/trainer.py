@@ -253,10 +253,13 @@ class Trainer:
         self._wg(n + ".conv1", t["s3"]["xb"], None, dc1)
         return dx
 
-    def _in_bwd(self, x, stats, name, slope, dy, pooled=False):
+    def _in_bwd(self, x, stats, name, slope, dy, pooled=False, f32=False):
+        """Gradient wrt the raw conv output in front of InstanceNorm `name`.  Its readers are that conv's data gradient and
+        weight gradient, which round it to bf16 while staging: in the single-product mode it is stored as bf16 (f32=True:
+        a reader that needs fp32, i.e. the distortion-aware kernels)."""
         w = self.gs.w
         return K.norm_act_bwd(x, stats, w[name + ".gamma"], w[name + ".beta"], slope, dy, pooled,
-                              sums=self._norm_state(x.shape[0])[0][name])
+                              sums=self._norm_state(x.shape[0])[0][name], out_bf16=self._act_bf16() and not f32)
 
     def _norm_grads(self, seg, B):
         """Adds the per-sample (d gamma, d beta) terms of segment `seg`'s norm layers to the gradient vectors."""
@@ -371,10 +374,10 @@ class Trainer:
             n = "sun.sunlayer%d" % l
             k = c[n + ".conv1"].kh
             tab = self._da(self.h >> (l - 1), self.w >> (l - 1), k)[1]
-            dr2 = self._in_bwd(t["r%db" % l], t["st%db" % l], n + ".norm2", 0.0, dP, pooled=True)
+            dr2 = self._in_bwd(t["r%db" % l], t["st%db" % l], n + ".norm2", 0.0, dP, pooled=True, f32=True)
             self._wg_da(n + ".conv2", t["a%da" % l], dr2)
             da = K.da_conv2d_dgrad(dr2, c[n + ".conv2"].pkT, tab, k, cp)
-            dr1 = self._in_bwd(t["r%da" % l], t["st%da" % l], n + ".norm1", 0.0, da)
+            dr1 = self._in_bwd(t["r%da" % l], t["st%da" % l], n + ".norm1", 0.0, da, f32=True)
             if l > 1:
                 self._wg_da(n + ".conv1", t["in%d" % l], dr1)
                 dP = K.da_conv2d_dgrad(dr1, c[n + ".conv1"].pkT, tab, k, cp)
@@ -415,13 +418,13 @@ class Trainer:
                                         w[n3 + ".norm1.beta"], w[n3 + ".norm2.gamma"], w[n3 + ".norm2.beta"])
             sP2 = K.spatial_sum(dP2, 1.0 / ((h // 2) * (wd // 2)))
         else:
-            g = K.norm_act_bwd(t["r3b"], t["st3b"], w[n3 + ".norm2.gamma"], w[n3 + ".norm2.beta"], 0.0, dP3, True)
+            g = K.norm_act_bwd(t["r3b"], t["st3b"], w[n3 + ".norm2.gamma"], w[n3 + ".norm2.beta"], 0.0, dP3, True, out_bf16=self._act_bf16())
             g = c[n3 + ".conv2"].dgrad(t["r3a"], g, cp)
-            g = K.norm_act_bwd(t["r3a"], t["st3a"], w[n3 + ".norm1.gamma"], w[n3 + ".norm1.beta"], 0.0, g, False)
+            g = K.norm_act_bwd(t["r3a"], t["st3a"], w[n3 + ".norm1.gamma"], w[n3 + ".norm1.beta"], 0.0, g, False, out_bf16=self._act_bf16())
             dP2, sP2 = c[n3 + ".conv1"].dgrad(t["in3"], g, cp, want_stats=True)
-        g = K.norm_act_bwd(t["r2b"], t["st2b"], w[n2 + ".norm2.gamma"], w[n2 + ".norm2.beta"], 0.0, dP2, True)
+        g = K.norm_act_bwd(t["r2b"], t["st2b"], w[n2 + ".norm2.gamma"], w[n2 + ".norm2.beta"], 0.0, dP2, True, out_bf16=self._act_bf16())
         g = c[n2 + ".conv2"].dgrad(t["r2a"], g, cp)
-        g = K.norm_act_bwd(t["r2a"], t["st2a"], w[n2 + ".norm1.gamma"], w[n2 + ".norm1.beta"], 0.0, g, False)
+        g = K.norm_act_bwd(t["r2a"], t["st2a"], w[n2 + ".norm1.gamma"], w[n2 + ".norm1.beta"], 0.0, g, False, out_bf16=self._act_bf16())
         _, sP1 = c[n2 + ".conv1"].dgrad(t["in2"], g, cp, want_stats=True)
         cam2 = K.grad_cam_map(t["A2"], sP2) if "s3" in t else K.grad_cam_map(t["A2"], sP2, 1.0 / ((h // 2) * (wd // 2)))
         return (K.grad_cam_map(t["A1"], sP1, 1.0 / (h * wd)), cam2, K.grad_cam_map(t["A3"], w3, s3))
@@ -458,15 +461,17 @@ class Trainer:
         for d in ("d4", "d3", "d2"):
             r = R[d]
             n = net + d + ".norm."
+            b16 = self._act_bf16()      # gradients wrt raw conv outputs: read by a data-gradient conv / a weight gradient only
             if training:
                 draw = K.bn_act_bwd(r["raw"], dy, r["mean"], r["rstd"], params[n + "gamma"], params[n + "beta"], 0.3,
-                                    grads[n + "gamma"] if do_wgrad else None, grads[n + "beta"] if do_wgrad else None)
+                                    grads[n + "gamma"] if do_wgrad else None, grads[n + "beta"] if do_wgrad else None,
+                                    out_bf16=b16)
             else:
-                draw = K.affine_act_bwd(r["raw"], dy, r["scale"], r["shift"], 0.3)
+                draw = K.affine_act_bwd(r["raw"], dy, r["scale"], r["shift"], 0.3, out_bf16=b16)
             if do_wgrad:
                 self._wg(net + d, r["x"], r["xf"], draw)
             dy = c[net + d].dgrad(r["x"], draw, cp)   # gradient wrt the activated input of this layer
-        d1pre = K.affine_act_bwd(R["d1"], dy, None, None, 0.3)
+        d1pre = K.affine_act_bwd(R["d1"], dy, None, None, 0.3, out_bf16=self._act_bf16())
         if do_wgrad:
             self._wg(net + "d1", R["in"], None, d1pre)
         if want_input_grad:
@@ -506,14 +511,15 @@ class Trainer:
         for d in ("d4", "d3", "d2"):
             r = R[d]
             n = net + d + ".norm."
-            draw = torch.empty_like(r["raw"])
+            b16 = self._act_bf16()
+            draw = torch.empty(r["raw"].shape, dtype=torch.bfloat16 if b16 else torch.float32, device=r["raw"].device)
             for hf, (mean, rstd) in enumerate(r["halves"]):
                 sl = slice(hf * B, (hf + 1) * B)
                 K.bn_act_bwd(r["raw"][sl], dy[sl], mean, rstd, params[n + "gamma"], params[n + "beta"], 0.3,
-                             grads[n + "gamma"], grads[n + "beta"], out=draw[sl])
+                             grads[n + "gamma"], grads[n + "beta"], out=draw[sl], out_bf16=b16)
             self._wg(net + d, r["x"], r["xf"], draw)
             dy = c[net + d].dgrad(r["x"], draw, cp)
-        d1pre = K.affine_act_bwd(R["d1"], dy, None, None, 0.3)
+        d1pre = K.affine_act_bwd(R["d1"], dy, None, None, 0.3, out_bf16=self._act_bf16())
         self._wg(net + "d1", R["in"], None, d1pre)
 
     def _sunrad_forward(self, ldr, cams, t, S):
@@ -791,10 +797,10 @@ class Trainer:
                 dc = T["tails"][sfx][0]
                 self._wg("gen.conv1_" + sfx, d2, xf1, dc)
                 da2 = c["gen.conv1_" + sfx].dgrad(d2, dc, cp)
-                dd2 = self._in_bwd(d2, s2, "gen.norm2_" + sfx, 0.1, da2)
+                dd2 = self._in_bwd(d2, s2, "gen.norm2_" + sfx, 0.1, da2, f32=True)
                 self._wg_da("gen.conv2_" + sfx, u2, dd2)
                 du2 = K.da_conv2d_dgrad(dd2, c["gen.conv2_" + sfx].pkT, self._da(u2.shape[1], u2.shape[2])[1], 3, cp)
-                dd3 = self._in_bwd(d3, s3, "gen.norm3_" + sfx, 0.1, K.up2x_bwd(du2))
+                dd3 = self._in_bwd(d3, s3, "gen.norm3_" + sfx, 0.1, K.up2x_bwd(du2), f32=True)
                 self._wg_da("gen.conv3_" + sfx, u3, dd3)
                 du3 = K.da_conv2d_dgrad(dd3, c["gen.conv3_" + sfx].pkT, self._da(u3.shape[1], u3.shape[2])[1], 3, cp)
                 K.up2x_bwd(du3, 1.0, out=dres)
@@ -863,10 +869,10 @@ class Trainer:
                 for i in range(5, -1, -1):
                     p = "gen.res.%d." % i
                     c1, t1, a1, c2, t2 = T["res%d" % i]
-                    dr2 = self._in_bwd(c2, t2, p + "norm2", 1.0, dx)
+                    dr2 = self._in_bwd(c2, t2, p + "norm2", 1.0, dx, f32=True)
                     self._wg_da(p + "conv2", a1, dr2)
                     da1 = K.da_conv2d_dgrad(dr2, c[p + "conv2"].pkT, self._da_table, 3, cp)
-                    dr1 = self._in_bwd(c1, t1, p + "norm1", 0.1, da1)
+                    dr1 = self._in_bwd(c1, t1, p + "norm1", 0.1, da1, f32=True)
                     self._wg_da(p + "conv1", T["x"][i], dr1)
                     dxx = K.da_conv2d_dgrad(dr1, c[p + "conv1"].pkT, self._da_table, 3, cp)
                     dx = K.axpby(dx, 1.0, dxx, 1.0)                                     # + identity branch

@@ -146,8 +146,11 @@ int hdrsky_bn_eval_affine(const float* gamma, const float* beta, const float* mo
  * sums (nullable) receives [B][2][C] = (sum g, sum g*xhat) planes; dgamma/dbeta (nullable) are ACCUMULATED with
  * fp32 atomics.  tf.gradients path of grad_cam.py:31 and the IN backward of train.py:402. */
 int hdrsky_norm_act_bwd(const float* x, const float* part, int nparts, const float* gamma, const float* beta,
-                        float eps, float slope, const float* dy, int pooled, float* dx, float* sums, float* dgamma,
-                        float* dbeta, float* ws, int B, int H, int W, int C, void* stream);
+                        float eps, float slope, const float* dy, int pooled, void* dx, int dx_bf16, float* sums,
+                        float* dgamma, float* dbeta, float* ws, int B, int H, int W, int C, void* stream);
+/* (dx_bf16 here and in hdrsky_bn_act_bwd / hdrsky_affine_act_bwd / hdrsky_act_bwd_bf16: dx is stored as bf16 - for a gradient
+ * whose only readers are a data-gradient conv (hdrsky_conv_desc.x_bf16) and a weight gradient (hdrsky_wgrad_job.dy_bf16),
+ * which round it to bf16 while staging anyway: bit-neutral, half the bytes.) */
 /* Spatial slices S the call above splits each sample into; when S > 1 it needs the workspace ws [B][S][2][C]. [host] */
 int hdrsky_norm_act_bwd_nslices(int B, int H, int W, int C, int pooled);
 
@@ -257,10 +260,10 @@ int hdrsky_zero(void* p, size_t nbytes, void* stream);
 /* [host] number of reduction blocks hdrsky_bn_act_bwd uses; its workspace is (2*nblocks*C + 2*C) floats. */
 int hdrsky_bn_bwd_nblocks(void);
 /* Backward of y = leaky(BN_train(x)): dx, and dgamma/dbeta ACCUMULATED into the given buffers (nullable). */
-int hdrsky_bn_act_bwd(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma, const float* beta, float slope, int npix, int C, float* workspace, float* dgamma, float* dbeta, float* dx, void* stream);
+int hdrsky_bn_act_bwd(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma, const float* beta, float slope, int npix, int C, float* workspace, float* dgamma, float* dbeta, void* dx, int dx_bf16, void* stream);
 /* dx = dy*act'(x*scale[c]+shift[c])*scale[c] (BN in inference mode); scale==NULL: x is the ACTIVATED tensor and
  * dx = dy*(x>0 ? 1 : slope)  (Keras LeakyReLU / ReLU backward). */
-int hdrsky_affine_act_bwd(const float* x, const float* dy, const float* scale, const float* shift, float slope, size_t n, int C, float* dx, void* stream);
+int hdrsky_affine_act_bwd(const float* x, const float* dy, const float* scale, const float* shift, float slope, size_t n, int C, void* dx, int dx_bf16, void* stream);
 /* 2x2/2 max-pool (vgg16.py:85-86). */
 int hdrsky_maxpool_fwd(const float* y, int B, int H, int W, int C, float* p, void* stream);
 /* Backward of maxpool(relu(.)) given the post-ReLU tensor y: gradient to the first arg-max where y > 0. */
@@ -304,7 +307,7 @@ int hdrsky_pad_channels(const float* x, size_t npix, int C, int Cpad, float* out
 int hdrsky_maxpool_fwd_bf16(const void* y_bf16, int B, int H, int W, int C, float* p_f32, void* p_bf16, void* stream);
 int hdrsky_maxpool_relu_bwd_bf16(const void* y_bf16, const float* dp, int B, int H, int W, int C, void* dy, int dy_bf16,
                                  void* stream);   /* dy_bf16: dy is stored as bf16 (the operand of the next data-gradient conv) */
-int hdrsky_act_bwd_bf16(const void* y_bf16, const float* dy, float slope, size_t n, float* dx, void* stream);
+int hdrsky_act_bwd_bf16(const void* y_bf16, const float* dy, float slope, size_t n, void* dx, int dx_bf16, void* stream);
 /* tf.concat([a, b], axis=-1) (discriminator.py:43). */
 int hdrsky_concat2(const float* a, int Ca, const float* b, int Cb, size_t npix, float* out, void* stream);
 /* x*255 - VGG_MEAN (vgg16.py:133-141). */
