@@ -1,9 +1,9 @@
 #!/bin/bash
 # A/B of bench.py variants back to back on ONE box (different boxes differ by +-2 %): usage  bash profiles/ab_bench.sh
 cd $GRAFT_REPO_ROOT
-run() { echo "== $1"; shift; env "$@" python bench.py --workload train --no-cpu-baseline --steps 100 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('train %.4f ms' % (d['ms_per_step']))"; }
-for rep in 1 2 3; do
-run "VGG16 chain on bf16 activations" X=1
-run "VGG16 chain on fp32 activations" HDRSKY_VGG_BF16=0
+run() { echo "== $1"; shift; env "$@" python bench.py --no-cpu-baseline --steps 100 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('train %.4f ms  fwd %.4f ms  roof %.3f us' % (d['ms_per_step'], d['fwd']['ms_per_step'], d['roofline']['avg_launch_us']))"; }
+for rep in 1 2; do
+run "bf16 storage of final activations / conv-output gradients" X=1
+run "fp32 storage" HDRSKY_VGG_BF16=0
 done
