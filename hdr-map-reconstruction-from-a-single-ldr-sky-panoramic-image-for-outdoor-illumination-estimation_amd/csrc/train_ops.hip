@@ -322,6 +322,73 @@ __global__ void up2x_fwd_kernel(const float* __restrict__ a, const float* __rest
   }
 }
 
+// The operand of a resize-deconvolution (ops.py:44-126: tf.image.resize 2x, then the conv), materialised once as bf16:
+// y = bf16( resize2x( leaky( IN(x) ) ) ) with the InstanceNorm affine built from the producing conv's statistics partials
+// (part == nullptr: x is already an activation).  Exactly the arithmetic - and the operation order - of the conv kernel's
+// fused-upsample staging (conv_igemm.hip), so a plain conv on y returns what the fused one returns; the plain conv and
+// the plain weight gradient are the faster kernels (no four-source blend per staged element), and the two decoders
+// share the upsampled encoder output.  Block = (sample, run of output pixels); thread = (pixel, 8 channels).
+__global__ void __launch_bounds__(256) up2x_xf_bf16_kernel(const float* __restrict__ x, int B, int H, int W, int C,
+                                                           const float* __restrict__ part, int nparts,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float eps, float slope, uint4* __restrict__ y, int blocks_per_sample) {
+  __shared__ float sSc[512], sSh[512];
+  const int b = blockIdx.x / blocks_per_sample, blk = blockIdx.x % blocks_per_sample;
+  const bool xf = part != nullptr;
+  if (xf) {
+    const float inv_count = 1.f / (float)(H * W);
+    for (int c = threadIdx.x; c < C; c += 256) {
+      float s = 0.f, ss = 0.f;
+      const float* pp = part + (size_t)b * nparts * 2 * C + c;
+      for (int p = 0; p < nparts; ++p) { s += pp[(2 * p) * C]; ss += pp[(2 * p + 1) * C]; }
+      const float mean = s * inv_count;
+      const float var = fmaxf(ss * inv_count - mean * mean, 0.f);
+      const float inv = gamma[c] / sqrtf(var + eps);
+      sSc[c] = inv; sSh[c] = beta[c] - mean * inv;
+    }
+    __syncthreads();
+  }
+  const int nq = C >> 3, OW = 2 * W, OH = 2 * H;
+  const int nitems = OH * OW * nq;
+  const int per = (nitems + blocks_per_sample - 1) / blocks_per_sample;
+  const int i1 = min(nitems, (blk + 1) * per);
+  const float* xb = x + (size_t)b * H * W * C;
+  for (int i = blk * per + threadIdx.x; i < i1; i += 256) {
+    const int q = i % nq, pix = i / nq;
+    const int cx = pix % OW, cy = pix / OW;
+    const float sy = (cy + 0.5f) * 0.5f - 0.5f, sx = (cx + 0.5f) * 0.5f - 0.5f;
+    const float fy = floorf(sy), fx = floorf(sx);
+    const int ylo = min(max((int)fy, 0), H - 1), yhi = max(min((int)ceilf(sy), H - 1), 0);
+    const int xlo = min(max((int)fx, 0), W - 1), xhi = max(min((int)ceilf(sx), W - 1), 0);
+    const float ly = sy - fy, lx = sx - fx;
+    const float* s00 = xb + ((size_t)ylo * W + xlo) * C + q * 8;
+    const float* s01 = xb + ((size_t)ylo * W + xhi) * C + q * 8;
+    const float* s10 = xb + ((size_t)yhi * W + xlo) * C + q * 8;
+    const float* s11 = xb + ((size_t)yhi * W + xhi) * C + q * 8;
+    float4 t[8];
+    t[0] = *reinterpret_cast<const float4*>(s00); t[1] = *reinterpret_cast<const float4*>(s00 + 4);
+    t[2] = *reinterpret_cast<const float4*>(s01); t[3] = *reinterpret_cast<const float4*>(s01 + 4);
+    t[4] = *reinterpret_cast<const float4*>(s10); t[5] = *reinterpret_cast<const float4*>(s10 + 4);
+    t[6] = *reinterpret_cast<const float4*>(s11); t[7] = *reinterpret_cast<const float4*>(s11 + 4);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float sc = xf ? sSc[q * 8 + j] : 1.f, sh = xf ? sSh[q * 8 + j] : 0.f;
+      const int w = j >> 2, e = j & 3;
+      const float tl = leaky(((const float*)&t[0 + w])[e] * sc + sh, slope);
+      const float tr = leaky(((const float*)&t[2 + w])[e] * sc + sh, slope);
+      const float bl = leaky(((const float*)&t[4 + w])[e] * sc + sh, slope);
+      const float br = leaky(((const float*)&t[6 + w])[e] * sc + sh, slope);
+      const float top = tl + (tr - tl) * lx;
+      const float bot = bl + (br - bl) * lx;
+      v[j] = top + (bot - top) * ly;
+    }
+    uint4 hi, lo;
+    pack8<false>(v, hi, lo);
+    y[(size_t)b * nitems + i] = hi;
+  }
+}
+
 // dx[b,iy,ix,c] = sum over the <= 4x4 outputs that sample (iy,ix) of their bilinear weight * dy   (exact adjoint)
 // V = channels per thread (4: float4 loads when C % 4 == 0; 1: the 3-channel DoG images)
 template <int V>
@@ -950,6 +1017,19 @@ int hdrsky_act_bwd_bf16(const void* y, const float* dy, float slope, size_t n, v
 int hdrsky_up2x_fwd(const float* a, const float* b, int B, int H, int W, int C, float* y, void* stream) {
   if (!a || !y) return HDRSKY_EINVAL;
   hipLaunchKernelGGL(up2x_fwd_kernel, dim3(grid_for((size_t)B * 4 * H * W * C)), dim3(256), 0, S_(stream), a, b, B, H, W, C, y);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_up2x_xf_bf16(const float* x, int B, int H, int W, int C, const float* in_part, int in_nparts, const float* gamma,
+                        const float* beta, float eps, float slope, void* y_bf16, void* stream) {
+  if (!x || !y_bf16 || (C & 7) || C > 512 || B <= 0) return HDRSKY_EINVAL;
+  if (in_part && (!gamma || !beta || in_nparts <= 0)) return HDRSKY_EINVAL;
+  const int nitems = 4 * H * W * (C / 8);
+  int bps = cdiv(nitems, 256 * 8);          // ~8 items per thread
+  if (bps < 1) bps = 1;
+  hipLaunchKernelGGL(up2x_xf_bf16_kernel, dim3(B * bps), dim3(256), 0, S_(stream), x, B, H, W, C, in_part, in_nparts, gamma,
+                     beta, eps, slope, (uint4*)y_bf16, bps);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }

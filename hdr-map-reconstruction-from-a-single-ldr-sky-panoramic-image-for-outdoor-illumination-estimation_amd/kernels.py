@@ -640,6 +640,34 @@ def up2x(a, b=None):
     return y
 
 
+def deconv_materialised(compute):
+    """Whether the training step runs its resize-deconvolutions as (operand written once as bf16) + plain conv + plain
+    weight gradient - single-product mode; HDRSKY_DECONV_MAT=0 keeps the resize fused into the staging of both (A/B hook:
+    step -0.4 %, all of it from the weight gradients; the forward pass alone gains nothing, engine.decode stays fused)."""
+    return compute == BF16 and os.environ.get("HDRSKY_DECONV_MAT", "1") != "0"
+
+
+def up2x_act_bf16(x, xf: Optional[InXf] = None):
+    """bf16 [B,2H,2W,C] = resize2x(leaky(IN(x))) - the materialised operand of a resize-deconvolution (xf: IN_PARTIALS
+    transform of the producing conv, or None for an activation); feed it to conv2d / wgrad_job with upsample=1."""
+    _f32(x)
+    B, H, W, C = x.shape
+    y = torch.empty((B, 2 * H, 2 * W, C), dtype=torch.bfloat16, device=x.device)
+    part = gamma = beta = None
+    nparts, eps, slope = 0, IN_EPS, 1.0
+    if xf is not None:
+        if xf.mode != L.IN_PARTIALS:
+            raise ValueError("up2x_act_bf16: InstanceNorm-partials transform (or none) only")
+        st = xf.stats
+        part, nparts, eps, slope = _f32(st.part, B, st.nparts, 2, C), st.nparts, float(xf.eps), float(xf.slope)
+        gamma, beta = _f32(xf.gamma, C), _f32(xf.beta, C)
+        if st.count != H * W:
+            raise ValueError("partials were not accumulated over this tensor's H*W")
+    L.check(L.load().hdrsky_up2x_xf_bf16(_p(x), B, H, W, C, _p(part), nparts, _p(gamma), _p(beta), eps, slope, _p(y), _stream()),
+            "up2x_xf_bf16")
+    return y
+
+
 def up2x_bwd(dy, scale=1.0, out=None):
     B, H2, W2, C = dy.shape
     _f32(dy)

@@ -301,6 +301,15 @@ class Trainer:
             self._da_geo[key] = (torch.from_numpy(K.da_offsets(h, w, k, 1, True)).to(self.device), tab)
         return self._da_geo[key]
 
+    def _wg_plain(self, name, x, dy):
+        """Queues the weight gradient of layer `name` computed on a materialised operand x (its final, already resized bf16
+        activation) as a plain stride-1 layer - what a resize-deconvolution's gradient is with respect to its conv."""
+        cv = self.conv[name]
+        g = self.gs.g
+        q = self._wjobs.setdefault(torch.cuda.current_stream().cuda_stream, [])
+        q.append(K.wgrad_job(x, dy, cv.kh, cv.kw, g[cv.wkey], g[cv.bkey] if cv.bkey else None, stride=1, same=True, upsample=1,
+                             xf=None, compute=self.compute))
+
     def _wg_da(self, name, x, dy, dw=None):
         """Queues the kernel gradient of a distortion-aware layer (same HWIO weights viewed [k*k*C, F]); the gathered
         operand is recomputed inside the launch.  dw: another destination (the channel-padded first sun-pose layer)."""
@@ -540,6 +549,9 @@ class Trainer:
         """Final activations of ReLU / LeakyReLU-only stretches are stored as bf16 (HDRSKY_BF16 mode; HDRSKY_VGG_BF16=0: A/B hook)."""
         return self.compute == BF16 and not self.precise and os.environ.get("HDRSKY_VGG_BF16", "1") != "0"
 
+    def _deconv_mat(self):
+        return not self.precise and K.deconv_materialised(self.compute)
+
     def _vgg_forward(self, x_gamma, keep):
         """pool1..3 of a gamma-domain BGR batch; `keep` collects what the backward pass re-reads."""
         cp = self.compute
@@ -627,12 +639,26 @@ class Trainer:
                 y, _ = c["gen.conv1_" + sfx].fwd(d2, xf1, cp, out_slope=0.1, residual=residual, final_relu=True)
                 T["dec_" + sfx] = (d3, s3, u3, d2, s2, xf1, y, residual, u2)
                 return y
+            if self._deconv_mat():
+                # single-product mode: the operand of each resize-deconvolution is written once as bf16 (hdrsky_up2x_xf_bf16:
+                # the fused staging's own arithmetic); the plain conv and - later - the plain weight gradient run on it, and
+                # the two decoders share the upsampled encoder output
+                c3, c2 = c["gen.conv3_" + sfx], c["gen.conv2_" + sfx]
+                u3 = T["u3"]          # written by fwd_enc, in front of the first decoder
+                d3, s3 = K.conv2d(u3, c3.pk, c3.b, compute=cp, want_stats=True)
+                xf2 = self._inxf(s3, "gen.norm3_" + sfx, 0.1)
+                u2 = K.up2x_act_bf16(d3, xf2)
+                d2, s2 = K.conv2d(u2, c2.pk, c2.b, compute=cp, want_stats=True)
+                xf1 = self._inxf(s2, "gen.norm2_" + sfx, 0.1)
+                y, _ = c["gen.conv1_" + sfx].fwd(d2, xf1, cp, out_slope=0.1, residual=residual, final_relu=True)
+                T["dec_" + sfx] = (d3, s3, xf2, d2, s2, xf1, y, residual, u3, u2)
+                return y
             d3, s3 = c["gen.conv3_" + sfx].fwd(res_out, compute=cp, want_stats=True)
             xf2 = self._inxf(s3, "gen.norm3_" + sfx, 0.1)
             d2, s2 = c["gen.conv2_" + sfx].fwd(d3, xf2, cp, want_stats=True)
             xf1 = self._inxf(s2, "gen.norm2_" + sfx, 0.1)
             y, _ = c["gen.conv1_" + sfx].fwd(d2, xf1, cp, out_slope=0.1, residual=residual, final_relu=True)
-            T["dec_" + sfx] = (d3, s3, xf2, d2, s2, xf1, y, residual)
+            T["dec_" + sfx] = (d3, s3, xf2, d2, s2, xf1, y, residual, None, None)
             return y
 
         # ------------------------------------------------------------------ forward (train.py:239-299)
@@ -686,6 +712,8 @@ class Trainer:
                 x = K.norm_apply(r2, t2, w[p + "norm2.gamma"], w[p + "norm2.beta"], slope=1.0, residual=x)
                 T["res%d" % i] = (r1, t1, xf, r2, t2)
                 T["x"].append(x)
+            if self._deconv_mat() and not self.da_dec:
+                T["u3"] = K.up2x_act_bf16(T["x"][-1])      # the resized encoder output, shared by both decoders
             T["sky_gamma"] = decode("f", ldr)
 
         @seg("vgg_target", 2)
@@ -805,15 +833,21 @@ class Trainer:
                 du3 = K.da_conv2d_dgrad(dd3, c["gen.conv3_" + sfx].pkT, self._da(u3.shape[1], u3.shape[2])[1], 3, cp)
                 K.up2x_bwd(du3, 1.0, out=dres)
             for sfx in () if self.da_dec else ("f", "u"):
-                d3, s3, xf2, d2, s2, xf1, y, residual = T["dec_" + sfx]
+                d3, s3, xf2, d2, s2, xf1, y, residual, u3, u2 = T["dec_" + sfx]
                 dc = T["tails"][sfx][0]
                 self._wg("gen.conv1_" + sfx, d2, xf1, dc)
                 da2 = c["gen.conv1_" + sfx].dgrad(d2, dc, cp)
                 dd2 = self._in_bwd(d2, s2, "gen.norm2_" + sfx, 0.1, da2)
-                self._wg("gen.conv2_" + sfx, d3, xf2, dd2)
+                if u2 is not None:       # weight gradients on the materialised (bf16, already resized) operands
+                    self._wg_plain("gen.conv2_" + sfx, u2, dd2)
+                else:
+                    self._wg("gen.conv2_" + sfx, d3, xf2, dd2)
                 da3 = c["gen.conv2_" + sfx].dgrad(d3, dd2, cp)
                 dd3 = self._in_bwd(d3, s3, "gen.norm3_" + sfx, 0.1, da3)
-                self._wg("gen.conv3_" + sfx, T["x"][-1], None, dd3)
+                if u3 is not None:
+                    self._wg_plain("gen.conv3_" + sfx, u3, dd3)
+                else:
+                    self._wg("gen.conv3_" + sfx, T["x"][-1], None, dd3)
                 c["gen.conv3_" + sfx].dgrad(T["x"][-1], dd3, cp, out=dres)
             self._norm_grads("bwd_dec", B)
             T["wq_dec"] = self._take_wgrads()

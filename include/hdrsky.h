@@ -308,6 +308,12 @@ int hdrsky_maxpool_fwd_bf16(const void* y_bf16, int B, int H, int W, int C, floa
 int hdrsky_maxpool_relu_bwd_bf16(const void* y_bf16, const float* dp, int B, int H, int W, int C, void* dy, int dy_bf16,
                                  void* stream);   /* dy_bf16: dy is stored as bf16 (the operand of the next data-gradient conv) */
 int hdrsky_act_bwd_bf16(const void* y_bf16, const float* dy, float slope, size_t n, void* dx, int dx_bf16, void* stream);
+/* The operand of a resize-deconvolution (ops.py:44-126 method 'resize': tf.image.resize 2x, then the conv) as a bf16
+ * tensor: y [B,2H,2W,C] = bf16(resize2x(leaky(IN(x), slope))) with the InstanceNorm affine from the producing conv's
+ * statistics partials in_part [B][in_nparts][2][C] (NULL: x is already an activation) - the arithmetic and operation
+ * order of hdrsky_conv2d_fwd's upsample = 2 staging, so a plain conv (x_bf16) on y equals the fused one.  C % 8 == 0. */
+int hdrsky_up2x_xf_bf16(const float* x, int B, int H, int W, int C, const float* in_part, int in_nparts, const float* gamma,
+                        const float* beta, float eps, float slope, void* y_bf16, void* stream);
 /* tf.concat([a, b], axis=-1) (discriminator.py:43). */
 int hdrsky_concat2(const float* a, int Ca, const float* b, int Cb, size_t npix, float* out, void* stream);
 /* x*255 - VGG_MEAN (vgg16.py:133-141). */

@@ -4,6 +4,6 @@ cd $GRAFT_REPO_ROOT
 run() { echo "== $1"; shift; env "$@" python bench.py --no-cpu-baseline --steps 100 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('train %.4f ms  fwd %.4f ms  roof %.3f us' % (d['ms_per_step'], d['fwd']['ms_per_step'], d['roofline']['avg_launch_us']))"; }
 for rep in 1 2; do
-run "bf16 storage of final activations / conv-output gradients" X=1
-run "fp32 storage" HDRSKY_VGG_BF16=0
+run "resize-deconvolutions on materialised bf16 operands" X=1
+run "resize fused into the conv staging" HDRSKY_DECONV_MAT=0
 done

@@ -180,3 +180,31 @@ def test_bf16_activation_storage_is_bit_neutral_for_relu_chains(dev):
     assert torch.equal(K.maxpool_relu_bwd(y, dp, out_bf16=True), K.maxpool_relu_bwd(y.float(), dp).to(torch.bfloat16))
     g = d(rng.standard_normal((3, 16, 64, 128)).astype(np.float32))
     assert torch.equal(K.affine_act_bwd(y, g, None, None, 0.0), K.affine_act_bwd(y.float(), g, None, None, 0.0))
+
+
+def test_materialised_deconv_operand_equals_the_fused_upsample(dev):
+    """hdrsky_up2x_xf_bf16: the resize-deconvolution's operand bf16(resize2x(leaky(IN(x)))) written once; a plain conv on
+    it (x_bf16) against the conv that resizes while staging (upsample = 2), and the plain weight gradient likewise."""
+    K = pkg("kernels"); L = pkg("_lib")
+    rng = np.random.default_rng(41)
+    d = lambda a: torch.from_numpy(a).to(dev)
+    for (B, H, W, Cin, Cout) in ((2, 8, 32, 128, 64), (3, 16, 64, 64, 32)):
+        x0 = d(rng.standard_normal((B, H, W, Cin)).astype(np.float32))
+        w0 = d((rng.standard_normal((3, 3, Cin, Cin)) / np.sqrt(9 * Cin)).astype(np.float32))
+        raw, st = K.conv2d(x0, K.PackedConv(w0), None, want_stats=True, compute=K.BF16)
+        gam = d(rng.uniform(0.5, 1.5, Cin).astype(np.float32)); bet = d(rng.standard_normal(Cin).astype(np.float32))
+        w = d((rng.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32))
+        b = d(rng.standard_normal(Cout).astype(np.float32))
+        pw = K.PackedConv(w)
+        for xf in (None, K.InXf(mode=L.IN_PARTIALS, slope=0.1, stats=st, gamma=gam, beta=bet)):
+            y_fused, s_fused = K.conv2d(raw, pw, b, upsample=2, xf=xf, want_stats=True, compute=K.BF16)
+            u = K.up2x_act_bf16(raw, xf)
+            assert u.shape == (B, 2 * H, 2 * W, Cin) and u.dtype == torch.bfloat16
+            y_plain, s_plain = K.conv2d(u, pw, b, want_stats=True, compute=K.BF16)
+            assert_close(y_plain, y_fused, 2e-6, "plain conv on the materialised operand vs fused upsample")
+            dy = d(rng.standard_normal((B, 2 * H, 2 * W, Cout)).astype(np.float32))
+            dw_f, db_f = K.conv2d_wgrad(raw, dy, 3, 3, upsample=2, xf=xf, compute=K.BF16)
+            dw_p = torch.zeros_like(dw_f); db_p = torch.zeros_like(db_f)
+            K.conv2d_wgrad_multi([K.wgrad_job(u, dy, 3, 3, dw_p, db_p, compute=K.BF16)])
+            assert_close(dw_p, dw_f, 2e-5, "plain weight gradient on the materialised operand vs fused upsample")
+            assert_close(db_p, db_f, 1e-6, "bias gradient")
