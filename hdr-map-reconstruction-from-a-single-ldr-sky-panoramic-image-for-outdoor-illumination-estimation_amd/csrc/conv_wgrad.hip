@@ -721,9 +721,12 @@ static int wgrad_multi_impl(const hdrsky_wgrad_job* jobs, int njobs, float* ws, 
   if (njobs < 0 || (njobs > 0 && !jobs)) return HDRSKY_EINVAL;
   if (njobs > 256) return HDRSKY_EUNSUPPORTED;
   size_t ws_used = 0;
-  // workgroups per launch (measured, profiles/microbench_wgrad.py): 256 for a layer on its own, 192 for a group
-  int wg_hook = 0, force_small = 0;
-  if (const char* e = getenv("HDRSKY_WGRAD")) sscanf(e, "%d,%d", &wg_hook, &force_small);   // tuning hook
+  // workgroups per launch: 128 for a layer on its own, 192 for a group.  Measured INSIDE the three-stream training step
+  // (profiles/ab_bench.sh, HDRSKY_WGRAD=alone,0,group): a launch there does not have the chip to itself, and every pixel
+  // chunk costs a partial slab that the reduce launch reads back - alone 256 (the best value for a launch timed on its own,
+  // profiles/microbench_wgrad.py) -> 128 shortened the step by 3 %; 96 / 64 and group 160 / 224 / 256 were worse.
+  int wg_hook = 0, force_small = 0, wg_hook_group = 0;
+  if (const char* e = getenv("HDRSKY_WGRAD")) sscanf(e, "%d,%d,%d", &wg_hook, &force_small, &wg_hook_group);   // tuning hook
   // wide stride-1 layers use 64x64-channel blocks when at least three of them share a launch
   int nwide = 0;
   for (int i = 0; i < njobs; ++i) nwide += can_go_big(jobs[i]) ? 1 : 0;
@@ -743,7 +746,7 @@ static int wgrad_multi_impl(const hdrsky_wgrad_job* jobs, int njobs, float* ws, 
         members[nm++] = k;
         done[k] = true;
       }
-    const int wg_total = wg_hook > 0 ? wg_hook : (nm == 1 ? 256 : 192);
+    const int wg_total = nm == 1 ? (wg_hook > 0 ? wg_hook : 128) : (wg_hook_group > 0 ? wg_hook_group : (wg_hook > 0 ? wg_hook : 192));
     for (int base = 0; base < nm; base += WG_MAXJ) {   // kernel argument block holds WG_MAXJ jobs
       const int cnt = nm - base < WG_MAXJ ? nm - base : WG_MAXJ;
       MultiArgs m{};
