@@ -151,10 +151,12 @@ int hdrsky_fc_pack_weights(const float* w, int K, int N, void* packed_hi, void* 
 }
 
 int hdrsky_fc_nsplit(int R) {
-  // 64 column blocks x 8 slices = 512 workgroups at N = 4096: two per CU, i.e. 64 KB of weight loads in flight per CU
-  // (one workgroup keeps 32 KB in flight: ~3 TB/s against ~2 us of HBM latency; HDRSKY_FC_NSPLIT overrides for A/B runs)
-  static const int pref = getenv("HDRSKY_FC_NSPLIT") ? atoi(getenv("HDRSKY_FC_NSPLIT")) : 8;
-  int ns = pref > 0 ? pref : 8;
+  // 64 column blocks x 4 slices = 256 workgroups at N = 4096.  8 slices (two workgroups per CU, 64 KB of weight loads in
+  // flight per CU) stream the weights faster on their own (3.0 -> 4.1 TB/s), but every consumer of the partial sums
+  // (fc_finalize, softmax_head, the next layer's staging) reads twice as many: inside the forward pass 4 is 12 us faster
+  // and the training step does not care (profiles/ab_bench.sh; HDRSKY_FC_NSPLIT overrides for A/B runs).
+  static const int pref = getenv("HDRSKY_FC_NSPLIT") ? atoi(getenv("HDRSKY_FC_NSPLIT")) : 4;
+  int ns = pref > 0 ? pref : 4;
   while (ns > 1 && (R % (ns * RCH)) != 0) ns >>= 1;
   return ns;
 }

@@ -41,7 +41,7 @@ def test_conv_desc_matches_tf_padding():
     d = L.ConvDesc()
     assert lib.hdrsky_conv_desc_init(d, 2, 8, 32, 128, 64, 3, 3, 1, 1, 2) == 0 and (d.Ho, d.Wo, d.Hc, d.Wc) == (16, 64, 16, 64)
     assert lib.hdrsky_conv_desc_init(d, 2, 8, 32, 128, 64, 3, 3, 3, 1, 1) == L.HDRSKY_BF16 - 1  # stride 3 -> EINVAL
-    assert lib.hdrsky_fc_nsplit(8192) == 8 and lib.hdrsky_fc_nsplit(512) == 2
+    assert lib.hdrsky_fc_nsplit(8192) == 4 and lib.hdrsky_fc_nsplit(512) == 2
     assert lib.hdrsky_conv_packed_elems(3, 3, 128, 128) == (9 * 4 + 1) * 4 * 128 * 8
 
 
