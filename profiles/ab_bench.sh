@@ -1,11 +1,9 @@
 #!/bin/bash
 # A/B of bench.py variants back to back on ONE box (different boxes differ by +-2 %): usage  bash profiles/ab_bench.sh
 cd $GRAFT_REPO_ROOT
-run() { echo "== $1"; shift; env "$@" python bench.py --no-cpu-baseline --steps 100 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('train %.4f ms  fwd %.4f ms' % (d['ms_per_step'], d['fwd']['ms_per_step']))"; }
+run() { echo "== $1"; shift; env "$@" python bench.py --workload train --no-cpu-baseline --steps 100 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('train %.4f ms' % (d['ms_per_step']))"; }
 for rep in 1 2; do
-run "default" X=1
-run "fc update: one 32x32 block per wave" HDRSKY_FC_UPDATE_NB=1
-run "fc split 4" HDRSKY_FC_NSPLIT=4
-run "sunlayer3 on the sample-resident launches" HDRSKY_SUN3=1
+run "three streams" X=1
+run "four streams (weight-gradient segments on their own)" HDRSKY_STREAMS=4
 done
