@@ -87,12 +87,12 @@ SIGNATURES = {
     "hdrsky_crc32c": (ctypes.c_uint32, [P, c_size_t, ctypes.c_uint32]),
     "hdrsky_jpeg_roundtrip": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, P]),
     "hdrsky_da_offsets": (c_int, [c_int, c_int, c_int, c_int, c_int, P]),
-    "hdrsky_da_conv2d_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P]),
+    "hdrsky_da_conv2d_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "hdrsky_da_conv_stats_nparts": (c_int, [c_int, c_int]),
     "hdrsky_da_gather": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
     "hdrsky_da_scatter": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
     "hdrsky_da_sample_table": (c_int, [P, c_int, c_int, c_int, P, P]),
-    "hdrsky_da_conv2d_dgrad": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "hdrsky_da_conv2d_dgrad": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     "hdrsky_bn_train_finalize": (c_int, [P, c_int, c_int, c_int, P, P, c_float, c_float, P, P, P, P, P, P, c_int, P]),
     "hdrsky_zero": (c_int, [P, c_size_t, P]),
     "hdrsky_bn_bwd_nblocks": (c_int, []),

@@ -28,6 +28,10 @@ struct DaArgs {
   // pixels per (pixel, tap)): gidx / gw [H*W][k*k][KM] = source pixel index (row-major, -1 = none) and weight
   const int* gidx;
   const float* gw;
+  // region variant (da_region_kernel): first source row of every group of grp_tiles 64-pixel tiles (host table) and the
+  // number of source rows staged (>= what any group reads); LDS byte offsets of the table ring and of the region
+  const int* row_lo;
+  int src_rows, tb_off, reg_off, nq_sh, grp_tiles, groups_x;
 };
 
 // Workgroup = NWV waves: a tile of 64 consecutive output pixels of one sample (row-major, so it spans several rows
@@ -259,6 +263,315 @@ __global__ void __launch_bounds__(NWV * 64) da_conv_kernel(const DaArgs a) {
   }
 }
 
+// Region variant of the kernel above (BF16 compute mode).  The offsets of this layer depend on the image ROW only, so the
+// samples of a 64-pixel tile fall into a few consecutive source rows (5-6 for the 3x3 layers, 13-14 for 7x7 at 32x128:
+// kernels.da_row_lo computes the span from the host sample table).  The workgroup stages those rows ONCE (fp32 -> bf16,
+// a linear copy) and then takes every corner of every tap from LDS instead of from L2: the legacy kernel pulls
+// k*k x 4 corner rows per pixel and channel through the vector memory path (7x7, 32 channels, B = 32: 3.3 GB per launch).
+// Per barrier round: (a) gather + blend + store the round's A tile from the region via a small per-(pixel, tap) table
+// (region pixel index as u16 + fp32 weight per source) that was written one round earlier, (b) write the NEXT round's
+// table (KM = 4: da_tap, exact reference arithmetic; KM = 8: the transposed table from global memory, fetched a round
+// ahead), barrier, (c) the MFMAs of the round.  Sources are rounded to bf16 before the blend (the legacy kernel blends
+// fp32 sources); the blend itself is fp32 and its result is rounded once more, as there.
+template <int NWV, int KM, int CBMAX>
+__global__ void __launch_bounds__(NWV * 64) da_region_kernel(const DaArgs a) {
+  constexpr int TM = 64, NT = NWV * 64;
+  constexpr int MAXROWS = 5, EMAX = 2;                          // CBMAX: 32-channel k-steps per round (register sets)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, lr = lane & 15;
+  const int nq = a.Cin >> 3, nqr = nq * a.tpr, plane = TM + 1, buf_units = nqr * plane;
+  uint4* sA = reinterpret_cast<uint4*>(smem);
+  const int nent = TM * a.tpr;                                  // table entries per round
+  unsigned char* sTb = smem + a.tb_off;                         // [2] x { u16 idx[nent][KM], float w[nent][KM] }
+  const int tb_bytes = nent * KM * 6;
+  const uint4* sReg = reinterpret_cast<const uint4*>(smem + a.reg_off);
+
+  int bid = blockIdx.x;
+  const int nb = bid % a.nblocks; bid /= a.nblocks;
+  const int grp = bid % a.groups_x, b = bid / a.groups_x;     // group = grp_tiles consecutive tiles sharing one region
+  const int n0 = nb * (NWV * 16);
+  const int npix = a.H * a.W;
+  const int ylo = a.row_lo[grp];
+  const int nrows = min(a.src_rows, a.H - ylo);
+  const int regpix = nrows * a.W;
+  const int tile_end = min((grp + 1) * a.grp_tiles, a.tiles_x);
+
+  f32x4_t acc[4];
+  const bool wave_live = n0 + wave * 16 < a.Npad;     // waves beyond the filter image only help with the gather
+  const int wcol = wave_live ? n0 + wave * 16 : 0;
+  const uint4* wlh = a.whi + (size_t)kq * a.Npad + wcol + lr;
+
+  __shared__ float s_off[MAXROWS * 2 * 128];
+  // ---- the source rows of this group: a linear fp32 -> bf16 copy -------------------------------------------------
+  {
+    const float* src = a.x + ((size_t)b * npix + (size_t)ylo * a.W) * a.Cin;
+    uint4* dst = reinterpret_cast<uint4*>(smem + a.reg_off);
+    const int nunits = regpix * nq;
+    int u = tid;
+    for (; u + 3 * NT < nunits; u += 4 * NT) {
+      float4 lo[4], hi[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float* pp = src + (size_t)(u + k * NT) * 8;
+        lo[k] = *reinterpret_cast<const float4*>(pp); hi[k] = *reinterpret_cast<const float4*>(pp + 4);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float v[8] = {lo[k].x, lo[k].y, lo[k].z, lo[k].w, hi[k].x, hi[k].y, hi[k].z, hi[k].w};
+        uint4 h8, l8;
+        pack8<false>(v, h8, l8);
+        dst[u + k * NT] = h8;
+      }
+    }
+    for (; u < nunits; u += NT) {
+      const float* pp = src + (size_t)u * 8;
+      const float4 lo = *reinterpret_cast<const float4*>(pp), hi = *reinterpret_cast<const float4*>(pp + 4);
+      const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      uint4 h8, l8;
+      pack8<false>(v, h8, l8);
+      dst[u] = h8;
+    }
+  }
+  uint4 bch[CBMAX], bnh[CBMAX];
+  const int ksteps = a.k2 * a.cin32, spr = a.tpr * a.cin32;
+  const int nitems = TM * nqr;
+  for (int tile = grp * a.grp_tiles; tile < tile_end; ++tile) {
+  const int p0 = tile * TM;
+  const int row0 = p0 / a.W;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) acc[mi] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  if constexpr (KM == 4) {
+    const int nrow = min(p0 + TM - 1, npix - 1) / a.W - row0 + 1;
+    for (int i = tid; i < nrow * a.k2 * 2; i += NT) s_off[i] = a.offs[(size_t)row0 * a.k2 * 2 + i];
+    __syncthreads();     // s_off visible to the table writers
+  }
+
+  // ---- the per-round sample table ---------------------------------------------------------------------------------
+  int pend_i[KM == 8 ? EMAX : 1][8];
+  float pend_w[KM == 8 ? EMAX : 1][8];
+  auto table_fetch = [&](int rnd) {            // KM = 8: global loads of round rnd's entries into registers
+    if constexpr (KM == 8) {
+#pragma unroll
+      for (int k = 0; k < EMAX; ++k) {
+        const int e = k * NT + tid;
+        if (e < nent) {
+          const int m = e % TM, tn = min(rnd * a.tpr + e / TM, a.k2 - 1);
+          const int pix = min(p0 + m, npix - 1);
+          const int4* gi = reinterpret_cast<const int4*>(a.gidx + ((size_t)pix * a.k2 + tn) * 8);
+          const float4* gwp = reinterpret_cast<const float4*>(a.gw + ((size_t)pix * a.k2 + tn) * 8);
+          const int4 i0 = gi[0], i1 = gi[1];
+          const float4 w0 = gwp[0], w1 = gwp[1];
+          pend_i[k][0] = i0.x; pend_i[k][1] = i0.y; pend_i[k][2] = i0.z; pend_i[k][3] = i0.w;
+          pend_i[k][4] = i1.x; pend_i[k][5] = i1.y; pend_i[k][6] = i1.z; pend_i[k][7] = i1.w;
+          pend_w[k][0] = w0.x; pend_w[k][1] = w0.y; pend_w[k][2] = w0.z; pend_w[k][3] = w0.w;
+          pend_w[k][4] = w1.x; pend_w[k][5] = w1.y; pend_w[k][6] = w1.z; pend_w[k][7] = w1.w;
+        }
+      }
+    }
+  };
+  auto table_write = [&](int rnd) {            // entries of round rnd -> ring buffer rnd & 1
+    unsigned short* ti = reinterpret_cast<unsigned short*>(sTb + (rnd & 1) * tb_bytes);
+    float* tw = reinterpret_cast<float*>(sTb + (rnd & 1) * tb_bytes + nent * KM * 2);
+#pragma unroll
+    for (int k = 0; k < EMAX; ++k) {
+      const int e = k * NT + tid;
+      if (e < nent) {
+        const int m = e % TM, tsub = e / TM;
+        const bool tap_ok = rnd * a.tpr + tsub < a.k2;
+        const int tn = tap_ok ? rnd * a.tpr + tsub : a.k2 - 1;
+        const bool live = p0 + m < npix;
+        unsigned short oi[KM];
+        float ow[KM];
+        if constexpr (KM == 4) {
+          const int pix = p0 + m;
+          const int oy = live ? pix / a.W : row0, ox = live ? pix % a.W : 0;
+          const float off_y = s_off[((oy - row0) * a.k2 + tn) * 2], off_x = s_off[((oy - row0) * a.k2 + tn) * 2 + 1];
+          const Tap4 s = da_tap((float)(oy + tn / a.ksize), (float)(ox + tn % a.ksize), off_y, off_x, a.in_h, a.in_w);
+          const int ys[4] = {s.y0, s.y0, s.y1, s.y1}, xs[4] = {s.x0, s.x1, s.x0, s.x1};
+          const float ws[4] = {s.w0, s.w1, s.w2, s.w3};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int yy = ys[c] - a.pad - ylo, xx = xs[c] - a.pad;     // region row / column; outside = zero padding
+            const bool in = live && tap_ok && yy >= 0 && yy < nrows && ys[c] - a.pad < a.H && xx >= 0 && xx < a.W;
+            oi[c] = (unsigned short)(in ? yy * a.W + xx : 0);
+            ow[c] = in ? ws[c] : 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            const int si = pend_i[k][c] - ylo * a.W;
+            const bool in = live && tap_ok && pend_i[k][c] >= 0 && si >= 0 && si < regpix;
+            oi[c] = (unsigned short)(in ? si : 0);
+            ow[c] = in ? pend_w[k][c] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < KM; c += 4) {
+          *reinterpret_cast<uint2*>(ti + (size_t)e * KM + c) =
+              uint2{(unsigned)oi[c] | ((unsigned)oi[c + 1] << 16), (unsigned)oi[c + 2] | ((unsigned)oi[c + 3] << 16)};
+          *reinterpret_cast<float4*>(tw + (size_t)e * KM + c) = float4{ow[c], ow[c + 1], ow[c + 2], ow[c + 3]};
+        }
+      }
+    }
+  };
+
+#pragma unroll
+  for (int cb = 0; cb < CBMAX; ++cb) bch[cb] = bnh[cb] = uint4{0, 0, 0, 0};
+  // this wave's filter fragments of the next round (fetching them two rounds ahead into a ring of three register sets was
+  // tried: the registers it costs halve the taps per round, and the rounds, not the filter fetch, are what a tile pays for)
+  auto load_b = [&](int rnd) {
+#pragma unroll
+    for (int cb = 0; cb < CBMAX; ++cb)
+      if (cb < spr && rnd * spr + cb < ksteps) bnh[cb] = wlh[(size_t)((rnd * spr + cb) * 4) * a.Npad];
+  };
+
+  table_fetch(0);
+  table_write(0);
+  if (a.nrounds > 1) table_fetch(1);
+  load_b(0);
+#pragma unroll
+  for (int cb = 0; cb < CBMAX; ++cb) bch[cb] = bnh[cb];
+  __syncthreads();                              // region + table 0 staged
+
+  for (int t = 0; t < a.nrounds; ++t) {
+    uint4* buf = sA + (t & 1) * buf_units;
+    const unsigned short* ti = reinterpret_cast<const unsigned short*>(sTb + (t & 1) * tb_bytes);
+    const float* tw = reinterpret_cast<const float*>(sTb + (t & 1) * tb_bytes + nent * KM * 2);
+#pragma unroll(KM == 4 ? 2 : 1)
+    for (int i = tid; i < nitems; i += NT) {
+      // item order (tap of the round, pixel, 8-channel group): nq is a power of two and TM = 64, so no division - the
+      // nq lanes of a (pixel, tap) share one table entry (LDS broadcast)
+      const int e = i >> a.nq_sh, q = i & (nq - 1);
+      const int m = e & (TM - 1), qr = (e >> 6) * nq + q;
+      unsigned short oi[KM];
+      float ow[KM];
+#pragma unroll
+      for (int c = 0; c < KM; c += 4) {
+        const uint2 pi = *reinterpret_cast<const uint2*>(ti + (size_t)e * KM + c);
+        const float4 pw = *reinterpret_cast<const float4*>(tw + (size_t)e * KM + c);
+        oi[c] = (unsigned short)(pi.x & 0xffffu); oi[c + 1] = (unsigned short)(pi.x >> 16);
+        oi[c + 2] = (unsigned short)(pi.y & 0xffffu); oi[c + 3] = (unsigned short)(pi.y >> 16);
+        ow[c] = pw.x; ow[c + 1] = pw.y; ow[c + 2] = pw.z; ow[c + 3] = pw.w;
+      }
+      uint4 src[KM];
+#pragma unroll
+      for (int c = 0; c < KM; ++c) src[c] = sReg[(int)oi[c] * nq + q];
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = 0.f;
+#pragma unroll
+      for (int c = 0; c < KM; ++c) {
+        const unsigned w4[4] = {src[c].x, src[c].y, src[c].z, src[c].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[2 * j] += ow[c] * __builtin_bit_cast(float, w4[j] << 16);
+          v[2 * j + 1] += ow[c] * __builtin_bit_cast(float, w4[j] & 0xffff0000u);
+        }
+      }
+      uint4 h8, l8;
+      pack8<false>(v, h8, l8);
+      buf[qr * plane + m] = h8;
+    }
+    if (t + 1 < a.nrounds) table_write(t + 1);
+    __syncthreads();   // A tile t and table t+1 staged; every wave is past the MFMAs of round t-1
+    if (t + 2 < a.nrounds) table_fetch(t + 2);
+    if (wave_live) {
+      if (t + 1 < a.nrounds) load_b(t + 1);
+#pragma unroll
+      for (int cb = 0; cb < CBMAX; ++cb) {
+        if (cb >= spr || t * spr + cb >= ksteps) break;
+        const uint4 bh = bch[cb];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) acc[mi] = mfma16(buf[(cb * 4 + kq) * plane + mi * 16 + lr], bh, acc[mi]);
+      }
+#pragma unroll
+      for (int cb = 0; cb < CBMAX; ++cb) bch[cb] = bnh[cb];
+    }
+  }
+  // ---- epilogue: + bias, store (as da_conv_kernel) --------------------------------------------------------------
+  const int n = n0 + wave * 16 + lr;
+  float s1 = 0.f, s2 = 0.f;
+  if (n < a.Cout) {
+    const float bv = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int pix = p0 + mi * 16 + kq * 4 + j;
+        if (pix < npix) {
+          const float v = acc[mi][j] + bv;
+          a.y[((size_t)b * npix + pix) * a.Cout + n] = v;
+          s1 += v; s2 += v * v;
+        }
+      }
+  }
+  if (a.stats) {
+    s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+    if (kq == 0 && n < a.Cout) {
+      float* dst = a.stats + ((size_t)(b * a.tiles_x + tile) * 2) * a.Cout + n;
+      dst[0] = s1; dst[a.Cout] = s2;
+    }
+  }
+  __syncthreads();      // the next tile reuses s_off, the table ring and the A buffers
+  }   // tiles of the group
+}
+
+// Plans the region variant for a layer whose gather source has C channels on an H x W map: taps per round, LDS layout.
+// Returns the dynamic LDS bytes, or 0 when the layer does not fit (the caller then uses da_conv_kernel).
+static int da_region_plan(DaArgs& a, int C, int nwv, int km, const int* spans, int B) {
+  // spans (host): rows a group of 1, 2, 4, 8, 16 consecutive tiles reads (kernels.da_row_lo); a.row_lo (device): the
+  // first row of every group, [5][tiles_x].  Larger groups re-read fewer source rows (a 7x7 tile of 64 pixels stages 13
+  // rows of 128 pixels: 26 x its own size; 8 tiles sharing 16 rows: 4 x) - taken while the launch keeps >= 256 workgroups.
+  if (!spans || !a.row_lo || (C % 32) != 0) return 0;
+  if ((64 / a.W + 2) * a.k2 > 5 * 128) return 0;
+  int hook_level = -1;
+  if (const char* e = getenv("HDRSKY_DA_REGION")) { if (atoi(e) == 0) return 0; }   // tuning / test hooks
+  if (const char* e = getenv("HDRSKY_DA_GROUP")) hook_level = atoi(e);
+  const int nq = C / 8, cin32 = C / 32, nt = nwv * 64;
+  if (nq & (nq - 1)) return 0;                                  // the item indexing wants a power of two
+  a.nq_sh = __builtin_ctz(nq);
+  const int* row_lo_base = a.row_lo;
+  for (int level = 4; level >= 0; --level) {
+    const int G = 1 << level, groups = cdiv(a.tiles_x, G), src_rows = spans[level];
+    if (level != (hook_level >= 0 ? hook_level : 0)) continue;   // measured: groups of tiles do not pay (see DESIGN), hook only
+    if (src_rows <= 0 || (size_t)src_rows * a.W > 65535) continue;   // u16 region pixel indices
+    const int region = src_rows * a.W * C * 2;
+    for (int tpr = a.k2 < 8 ? a.k2 : 8; tpr >= 1; --tpr) {
+      if (tpr * cin32 > 8 || 64 * tpr > 2 * nt) continue;     // filter prefetch registers, table entries per thread
+      const int abytes = 2 * tpr * nq * 65 * 16, tb = 2 * 64 * tpr * km * 6;
+      if (abytes + tb + region > 152 * 1024) continue;
+      a.tpr = tpr; a.nrounds = cdiv(a.k2, tpr);
+      a.tb_off = abytes; a.reg_off = abytes + tb; a.src_rows = src_rows;
+      a.grp_tiles = G; a.groups_x = groups; a.row_lo = row_lo_base + (size_t)level * a.tiles_x;
+      return abytes + tb + region;
+    }
+  }
+  return 0;
+}
+
+// HDRSKY_DA_REGION=2: fail instead of falling back to the global-memory gather (tests: proves which kernel ran)
+static bool da_region_forced() { const char* e = getenv("HDRSKY_DA_REGION"); return e && atoi(e) == 2; }
+
+template <int NWV, int KM, int CBMAX>
+static int da_region_launch_(const DaArgs& a, int grid, int lds, void* stream) {
+  auto k = da_region_kernel<NWV, KM, CBMAX>;
+  static bool set = false;
+  if (!set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
+      return HDRSKY_ELAUNCH;
+    set = true;
+  }
+  hipLaunchKernelGGL(k, dim3(grid), dim3(NWV * 64), lds, (hipStream_t)stream, a);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+template <int NWV, int KM>
+static int da_region_launch(const DaArgs& a, int grid, int lds, void* stream) {
+  return a.tpr * a.cin32 <= 4 ? da_region_launch_<NWV, KM, 4>(a, grid, lds, stream) : da_region_launch_<NWV, KM, 8>(a, grid, lds, stream);
+}
+
 // ---- backward building blocks ----------------------------------------------------------------------------------
 // The layer is y = G(x) W + b with G the (linear) bilinear gather [B,h,w,k*k*C].  Its gradients are
 //   dW = G(x)^T dY   (a 1x1-conv weight gradient on the gathered tensor),   db = sum dY,
@@ -396,8 +709,9 @@ int hdrsky_da_offsets(int h, int w, int ksize, int dilation_rate, int skydome, f
 // from the reference's [k*k*Cin, Cout] kernel (same memory order as HWIO); offs = device copy of hdrsky_da_offsets.
 int hdrsky_da_conv_stats_nparts(int H, int W) { return (H > 0 && W > 0) ? cdiv(H * W, 64) : 0; }
 
-int hdrsky_da_conv2d_fwd(const float* x, const void* w_hi, const void* w_lo, const float* bias, const float* offs, int B,
-                         int H, int W, int Cin, int Cout, int ksize, int compute, float* y, float* stats_part, void* stream) {
+int hdrsky_da_conv2d_fwd(const float* x, const void* w_hi, const void* w_lo, const float* bias, const float* offs,
+                         const int* row_lo, const int* spans, int B, int H, int W, int Cin, int Cout, int ksize, int compute,
+                         float* y, float* stats_part, void* stream) {
   if (!x || !w_hi || !offs || !y || (ksize & 1) == 0) return HDRSKY_EINVAL;
   if ((Cin % 32) != 0) return HDRSKY_EUNSUPPORTED;
   const bool precise = compute == HDRSKY_BF16X3;
@@ -412,6 +726,14 @@ int hdrsky_da_conv2d_fwd(const float* x, const void* w_hi, const void* w_lo, con
   // workgroup: 64 pixels x 128 filters (8 waves) when the layer has more than 64 filters, else 64 filters (4 waves)
   const int nwv = Cout > 64 ? 8 : 4;
   a.cin32 = Cin / 32; a.nblocks = cdiv(Cout, nwv * 16); a.tiles_x = cdiv(H * W, 64);
+  a.row_lo = row_lo;
+  if (!precise) {    // the source rows of a tile staged once in LDS (da_region_kernel) when the caller knows their span
+    a.nblocks = cdiv(Cout, 128);
+    if (const int lds_r = da_region_plan(a, Cin, 8, 4, spans, B)) return da_region_launch<8, 4>(a, B * a.groups_x * a.nblocks, lds_r, stream);
+    if (da_region_forced()) return HDRSKY_EUNSUPPORTED;
+    a.row_lo = nullptr;
+    a.nblocks = cdiv(Cout, nwv * 16);
+  }
   if (64 * (Cin / 8) > 4 * nwv * 64) return HDRSKY_EUNSUPPORTED;   // register prefetch budget (Cin <= 128 / 256)
   // taps per round: as many as the per-round capacity (IMAX items per thread = 8 * IMAX * nwv channels) holds
   const bool imax2 = da_taps_per_round(Cin, nwv, a.k2, 4, &a.tpr);
@@ -477,8 +799,9 @@ int hdrsky_da_sample_table(const float* offs, int H, int W, int ksize, int* idx,
 // with (a) the transposed sample table L (gidx / gw [H*W][k*k][8]: up to 8 source pixels per (target pixel, tap), tap
 // order of the packed filter) and (b) the transpose_flip image of the kernel (Cin = the layer's filters, Cout = its input
 // channels; its taps are flipped, which the table's tap order accounts for).  Deterministic.
-int hdrsky_da_conv2d_dgrad(const float* dy, const void* wT_hi, const void* wT_lo, const int* gidx, const float* gw, int B, int H,
-                           int W, int F, int C, int ksize, int compute, float* dx, void* stream) {
+int hdrsky_da_conv2d_dgrad(const float* dy, const void* wT_hi, const void* wT_lo, const int* gidx, const float* gw,
+                           const int* row_lo, const int* spans, int B, int H, int W, int F, int C, int ksize, int compute, float* dx,
+                           void* stream) {
   if (!dy || !wT_hi || !gidx || !gw || !dx || (ksize & 1) == 0) return HDRSKY_EINVAL;
   if ((F % 32) != 0) return HDRSKY_EUNSUPPORTED;
   const bool precise = compute == HDRSKY_BF16X3;
@@ -493,6 +816,14 @@ int hdrsky_da_conv2d_dgrad(const float* dy, const void* wT_hi, const void* wT_lo
   // is the register budget: 64 pixels x F/8 items need F/16 waves)
   const int nwv = (C > 64 || F > 64) ? 8 : 4;
   a.cin32 = F / 32; a.nblocks = cdiv(C, nwv * 16); a.tiles_x = cdiv(H * W, 64);
+  a.row_lo = row_lo;
+  if (!precise) {
+    a.nblocks = cdiv(C, 128);
+    if (const int lds_r = da_region_plan(a, F, 8, 8, spans, B)) return da_region_launch<8, 8>(a, B * a.groups_x * a.nblocks, lds_r, stream);
+    if (da_region_forced()) return HDRSKY_EUNSUPPORTED;
+    a.row_lo = nullptr;
+    a.nblocks = cdiv(C, nwv * 16);
+  }
   if (64 * (F / 8) > 2 * nwv * 64) return HDRSKY_EUNSUPPORTED;
   da_taps_per_round(F, nwv, a.k2, 2, &a.tpr);
   a.nrounds = cdiv(a.k2, a.tpr);

@@ -30,7 +30,7 @@ class conv2d:
         self.kernel = torch.from_numpy(rng.uniform(-lim, lim, (k * k * c, self.filters)).astype(np.float32)).to(device)
         self.bias = torch.zeros(self.filters, dtype=torch.float32, device=device)
         self._offs_np = K.da_offsets(h, w, k, self.dilation_rate, self.skydome)
-        self._offs = torch.from_numpy(self._offs_np).to(device)
+        self._offs = K.da_offsets_device(h, w, k, self.dilation_rate, self.skydome, device)
         self.offset = np.broadcast_to(self._offs_np[None, :, None], (1, h, w, k * k, 2))   # reference attribute
         self._cin = c
         self.repack()

@@ -70,7 +70,7 @@ class Nets:
         """Device copy of the distortion-aware sampling offsets for an h x w map (cached)."""
         key = (h, w, k, dilation_rate)
         if key not in self._da_offs:
-            self._da_offs[key] = torch.from_numpy(K.da_offsets(h, w, k, dilation_rate, True)).to(self.device)
+            self._da_offs[key] = K.da_offsets_device(h, w, k, dilation_rate, True, self.device)
         return self._da_offs[key]
 
     def da_table(self, h, w, k=3):

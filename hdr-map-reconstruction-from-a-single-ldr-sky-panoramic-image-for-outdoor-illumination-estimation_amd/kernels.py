@@ -1024,6 +1024,70 @@ def da_offsets(h, w, ksize=3, dilation_rate=1, skydome=True):
     return out
 
 
+def _da_host_table(h, w, ksize, dilation_rate, skydome):
+    """hdrsky_da_sample_table of the geometry: (idx, wt) [h*w, k*k, 4] numpy arrays (the forward's corners / weights)."""
+    import ctypes
+    import numpy as np
+    k2 = ksize * ksize
+    offs = da_offsets(h, w, ksize, dilation_rate, skydome)
+    idx = np.zeros((h * w, k2, 4), np.int32)
+    wt = np.zeros((h * w, k2, 4), np.float32)
+    L.check(L.load().hdrsky_da_sample_table(offs.ctypes.data_as(ctypes.c_void_p), h, w, ksize,
+                                            idx.ctypes.data_as(ctypes.c_void_p), wt.ctypes.data_as(ctypes.c_void_p)),
+            "da_sample_table")
+    return offs, idx, wt
+
+
+DA_GROUPS = (1, 2, 4, 8, 16)   # tiles per workgroup the region kernels may choose from
+
+
+def da_row_lo(idx, w):
+    """Source rows of groups of 1, 2, 4, 8, 16 consecutive 64-pixel tiles (row-major) of a sample table idx [h*w, k*k, KM]
+    (pixel indices, < 0 = none): (row_lo int32 [5, tiles], spans int32 [5]) - group g of level l reads rows
+    row_lo[l, g] .. row_lo[l, g] + spans[l] - 1 at most.  What hdrsky_da_conv2d_fwd / _dgrad need to stage a group's source
+    rows in LDS."""
+    import numpy as np
+    hw = idx.shape[0]
+    nt = (hw + 63) // 64
+    rows = np.where(idx >= 0, idx // w, -1).reshape(hw, -1)
+    big = np.iinfo(np.int32).max
+    lo_all = np.zeros((len(DA_GROUPS), nt), np.int32)
+    spans = np.zeros(len(DA_GROUPS), np.int32)
+    for l, G in enumerate(DA_GROUPS):
+        ng = (nt + G - 1) // G
+        pad = ng * G * 64 - hw
+        r = np.concatenate([rows, np.full((pad, rows.shape[1]), -1, rows.dtype)], 0) if pad else rows
+        r = r.reshape(ng, -1)
+        hi = r.max(1)
+        lo = np.where(hi >= 0, np.where(r >= 0, r, big).min(1), 0)
+        lo_all[l, :ng] = lo
+        spans[l] = int(np.where(hi >= 0, hi - lo + 1, 1).max())
+    return lo_all, spans
+
+
+_DA_OFFS = {}
+
+
+def da_offsets_device(h, w, ksize=3, dilation_rate=1, skydome=True, device="cuda"):
+    """Device copy of da_offsets(...) for da_conv2d, carrying the source-row table of its 64-pixel tiles (attribute
+    `da_rows` = (row_lo device int32 [5, tiles], spans host int32 [5]: kernels.da_row_lo) so that the forward can stage the
+    source rows of a group of tiles in LDS."""
+    key = (h, w, ksize, dilation_rate, bool(skydome), str(device))
+    if key not in _DA_OFFS:
+        offs, idx, _ = _da_host_table(h, w, ksize, dilation_rate, skydome)
+        lo, spans = da_row_lo(idx, w)
+        t = torch.from_numpy(offs).to(device)
+        t.da_rows = (torch.from_numpy(lo).to(device), spans)
+        _DA_OFFS[key] = t
+    return _DA_OFFS[key]
+
+
+def _da_rows(t):
+    """(device pointer of row_lo, host pointer of spans) of a tensor made by da_offsets_device / da_transpose_table."""
+    r = getattr(t, "da_rows", None)
+    return (r[0].data_ptr(), r[1].ctypes.data) if r is not None else (None, None)
+
+
 def da_conv2d(x, pw: PackedConv, bias, offs, compute=BF16, want_stats=False):
     """distortion_aware_ops.conv2d.call: offs = device tensor [H, k*k, 2] from da_offsets(H, W, k, ...).
     want_stats: also return the InstanceNorm partials of y (Stats, as conv2d does) -> (y, Stats)."""
@@ -1042,7 +1106,8 @@ def da_conv2d(x, pw: PackedConv, bias, offs, compute=BF16, want_stats=False):
     if want_stats:
         nparts = lib.hdrsky_da_conv_stats_nparts(H, W)
         st = Stats(torch.empty((B, nparts, 2, pw.Cout), dtype=torch.float32, device=x.device), nparts, H * W)
-    L.check(lib.hdrsky_da_conv2d_fwd(_p(x), _p(pw.hi), _p(pw.lo), _p(bias), _p(offs), B, H, W, C, pw.Cout, pw.KH,
+    row_lo, spans = _da_rows(offs)
+    L.check(lib.hdrsky_da_conv2d_fwd(_p(x), _p(pw.hi), _p(pw.lo), _p(bias), _p(offs), row_lo, spans, B, H, W, C, pw.Cout, pw.KH,
                                      compute, _p(y), _p(st.part) if st else None, _stream()), "da_conv2d_fwd")
     return (y, st) if want_stats else y
 
@@ -1071,12 +1136,7 @@ def da_transpose_table(h, w, ksize=3, dilation_rate=1, skydome=True, device="cud
     key = (h, w, ksize, dilation_rate, bool(skydome), str(device))
     if key not in _DA_TT:
         k2 = ksize * ksize
-        offs = da_offsets(h, w, ksize, dilation_rate, skydome)
-        idx = np.zeros((h * w, k2, 4), np.int32)
-        wt = np.zeros((h * w, k2, 4), np.float32)
-        L.check(L.load().hdrsky_da_sample_table(offs.ctypes.data_as(ctypes.c_void_p), h, w, ksize,
-                                                idx.ctypes.data_as(ctypes.c_void_p), wt.ctypes.data_as(ctypes.c_void_p)),
-                "da_sample_table")
+        _, idx, wt = _da_host_table(h, w, ksize, dilation_rate, skydome)
         p, t, c = np.nonzero((idx >= 0) & (wt != 0.0))
         q = idx[p, t, c]
         slot = k2 - 1 - t
@@ -1092,7 +1152,10 @@ def da_transpose_table(h, w, ksize=3, dilation_rate=1, skydome=True, device="cud
             gw = np.zeros((h * w, k2, DA_KMAX), np.float32)
             gidx[q, slot, pos] = p
             gw[q, slot, pos] = wv
-            _DA_TT[key] = (torch.from_numpy(gidx).to(device), torch.from_numpy(gw).to(device))
+            lo, spans = da_row_lo(gidx, w)
+            tg = torch.from_numpy(gidx).to(device)
+            tg.da_rows = (torch.from_numpy(lo).to(device), spans)    # source rows (of dy) of every 64-pixel tile
+            _DA_TT[key] = (tg, torch.from_numpy(gw).to(device))
     return _DA_TT[key]
 
 
@@ -1109,7 +1172,8 @@ def da_conv2d_dgrad(dy, pwT: PackedConv, table, ksize, compute=BF16):
     if compute == BF16X3 and pwT.lo is None:
         raise ValueError("BF16X3 needs the lo weight plane")
     dx = torch.empty((B, H, W, pwT.Cout), dtype=torch.float32, device=dy.device)
-    L.check(L.load().hdrsky_da_conv2d_dgrad(_p(dy), _p(pwT.hi), _p(pwT.lo), _p(gidx), _p(_f32(gw)), B, H, W, F, pwT.Cout, ksize,
+    row_lo, spans = _da_rows(gidx)
+    L.check(L.load().hdrsky_da_conv2d_dgrad(_p(dy), _p(pwT.hi), _p(pwT.lo), _p(gidx), _p(_f32(gw)), row_lo, spans, B, H, W, F, pwT.Cout, ksize,
                                             compute, _p(dx), _stream()), "da_conv2d_dgrad")
     return dx
 

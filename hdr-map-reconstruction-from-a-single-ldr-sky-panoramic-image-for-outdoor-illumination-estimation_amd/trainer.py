@@ -298,7 +298,7 @@ class Trainer:
             if tab is None:
                 raise ValueError("distortion-aware training: the transposed sample table of a %dx%d map (k=%d) needs more "
                                  "than %d readers per (pixel, tap)" % (h, w, k, K.DA_KMAX))
-            self._da_geo[key] = (torch.from_numpy(K.da_offsets(h, w, k, 1, True)).to(self.device), tab)
+            self._da_geo[key] = (K.da_offsets_device(h, w, k, 1, True, self.device), tab)
         return self._da_geo[key]
 
     def _wg_plain(self, name, x, dy):

@@ -387,8 +387,15 @@ int hdrsky_da_offsets(int h, int w, int ksize, int dilation_rate, int skydome, f
  * stats_part (optional): [B][hdrsky_da_conv_stats_nparts(H,W)][2][Cout] InstanceNorm partial sums of y in the layout the
  * plain conv emits, for hdrsky_norm_apply - the commented-out distortion-aware res blocks of generator.py:14,18. */
 int hdrsky_da_conv_stats_nparts(int H, int W); /* [host] */
-int hdrsky_da_conv2d_fwd(const float* x, const void* w_hi, const void* w_lo, const float* bias, const float* offs, int B,
-                         int H, int W, int Cin, int Cout, int ksize, int compute, float* y, float* stats_part, void* stream);
+/* row_lo / spans (optional, BF16 mode): the offsets depend on the image row only, so a group of consecutive 64-pixel tiles
+ * (row-major) samples a few consecutive source rows.  For group sizes G = 1, 2, 4, 8, 16 (level l = log2 G): row_lo =
+ * device int32 [5][ceil(H*W/64)], first source row of group g at [l][g]; spans = HOST int32 [5], rows from there that cover
+ * every group's samples (both from hdrsky_da_sample_table on the host: kernels.da_row_lo).  With them a workgroup stages the
+ * rows of its group once in LDS (bf16) and gathers every corner from there instead of from L2; NULL, BF16X3, or spans that
+ * do not fit LDS: the corners come from global memory (fp32 sources). */
+int hdrsky_da_conv2d_fwd(const float* x, const void* w_hi, const void* w_lo, const float* bias, const float* offs,
+                         const int* row_lo, const int* spans, int B, int H, int W, int Cin, int Cout, int ksize, int compute,
+                         float* y, float* stats_part, void* stream);
 /* Backward building blocks of the distortion-aware conv (tf.GradientTape through distortion_aware_ops.py:62-121):
  * with G = hdrsky_da_gather(x) [B,H,W,k*k*C] the layer is a 1x1 conv of G, so dW = hdrsky_conv2d_wgrad(1x1; G, dY),
  * dG = hdrsky_conv2d_fwd(1x1 with the transposed kernel; dY) and dx = hdrsky_da_scatter(dG) (dx zeroed; fp32 atomics). */
@@ -401,9 +408,11 @@ int hdrsky_da_sample_table(const float* offs, int H, int W, int ksize, int* idx,
 /* Data gradient of the distortion-aware conv (tape through distortion_aware_ops.py:62-121) WITHOUT the k*k-fold tensor and
  * without atomics: dx[q][c] = sum_t sum_f (sum_{(p,w) in L(q,t)} w dy[p][f]) W[t][c][f] - the forward kernel run on the
  * transposed sample table.  gidx / gw: device [H*W][k*k][8] (source pixel, -1 = none / weight), tap order of wT_*;
- * wT_* = hdrsky_conv_pack_weights(kernel viewed [k,k,C,F], ..., transpose_flip=1) (Cin = F filters, Cout = C). */
-int hdrsky_da_conv2d_dgrad(const float* dy, const void* wT_hi, const void* wT_lo, const int* gidx, const float* gw, int B, int H,
-                           int W, int F, int C, int ksize, int compute, float* dx, void* stream);
+ * wT_* = hdrsky_conv_pack_weights(kernel viewed [k,k,C,F], ..., transpose_flip=1) (Cin = F filters, Cout = C).
+ * row_lo / spans: as for hdrsky_da_conv2d_fwd, for the rows of dy the table's sources of a tile lie in. */
+int hdrsky_da_conv2d_dgrad(const float* dy, const void* wT_hi, const void* wT_lo, const int* gidx, const float* gw,
+                           const int* row_lo, const int* spans, int B, int H, int W, int F, int C, int ksize, int compute, float* dx,
+                           void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Sample-resident 3x3 convolution with the InstanceNormalization around it fused in (csrc/res_conv.hip).

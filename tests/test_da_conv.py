@@ -173,3 +173,52 @@ def test_da_conv_other_kernel_sizes_and_sample_table(dev, k, shape):
     finally:
         os.environ.pop("HDRSKY_DA_TPR", None)
     assert torch.equal(y, y_1) and torch.equal(y16, y16_1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,shape", [(3, (2, 8, 32, 128, 128)), (7, (2, 32, 128, 32, 32)), (5, (2, 16, 64, 64, 64)),
+                                     (3, (3, 4, 16, 256, 256)), (3, (2, 32, 128, 64, 32)), (3, (2, 16, 16, 32, 64)),
+                                     (5, (1, 16, 64, 32, 64)), (3, (2, 16, 64, 128, 64))])
+def test_da_region_variant(dev, k, shape, monkeypatch):
+    """BF16 mode with the source-row table (kernels.da_offsets_device / da_transpose_table): the tile's source rows staged
+    once in LDS, forward and data gradient, against the oracle and against the global-memory gather.  HDRSKY_DA_REGION=2
+    makes the entry points fail rather than fall back, so a pass proves the region kernel ran."""
+    K = pkg("kernels")
+    B, H, W, C, F = shape
+    rng = np.random.default_rng(k * 31 + C + H)
+    x = rng.standard_normal((B, H, W, C)).astype(np.float32)
+    kern = (rng.standard_normal((k * k * C, F)) / np.sqrt(k * k * C)).astype(np.float32)
+    bias = rng.standard_normal(F).astype(np.float32)
+    dy = rng.standard_normal((B, H, W, F)).astype(np.float32)
+    d = lambda a: torch.from_numpy(a).to(dev)
+    ref = da_ops.da_conv2d(x, kern, bias, da_ops.distortion(H, W, k), k=k)
+    rdx, _, _ = da_ops.da_conv2d_grads(x, kern, da_ops.distortion(H, W, k), dy, k=k)
+    pw = K.PackedConv(d(kern).view(k, k, C, F))
+    pwT = K.PackedConv(d(kern).view(k, k, C, F), transpose_flip=True)
+    offs_r = K.da_offsets_device(H, W, k, 1, True, dev)
+    table = K.da_transpose_table(H, W, k, 1, True, dev)
+    row_lo, spans = offs_r.da_rows[:2]
+    assert tuple(row_lo.shape) == (5, (H * W + 63) // 64) and all(1 <= s <= H for s in spans) and list(spans) == sorted(spans)
+    monkeypatch.setenv("HDRSKY_DA_REGION", "0")
+    y_g = K.da_conv2d(d(x), pw, d(bias), offs_r, K.BF16)
+    try:
+        dx_g = K.da_conv2d_dgrad(d(dy), pwT, table, k, K.BF16)
+    except pkg("_lib").HdrSkyError:      # 256 filters: beyond the register budget of the global-memory gather
+        assert F > 128
+        dx_g = None
+    monkeypatch.setenv("HDRSKY_DA_REGION", "2")
+    y_r, st = K.da_conv2d(d(x), pw, d(bias), offs_r, K.BF16, want_stats=True)
+    dx_r = K.da_conv2d_dgrad(d(dy), pwT, table, k, K.BF16)
+    monkeypatch.delenv("HDRSKY_DA_REGION")
+    assert_close_bf16(y_r, ref, "da conv, region"); assert_close_bf16(dx_r, rdx, "da dgrad, region")
+    # the two gathers differ only by the bf16 rounding of the sources before the blend
+    for a, b, what in ((y_r, y_g, "fwd"), (dx_r, dx_g, "dgrad")):
+        if b is None:
+            continue
+        err = (a - b).abs().max().item() / b.abs().max().item()
+        assert err < 1.5e-2, (what, err)
+    # InstanceNorm partials of the region kernel's own output
+    s1 = st.part[:, :, 0].sum(1); s2 = st.part[:, :, 1].sum(1)
+    yr = y_r.reshape(B, -1, F).double()
+    assert_close(s1, yr.sum(1), 1e-4, "region stats sum"); assert_close(s2, (yr * yr).sum(1), 1e-4, "region stats sumsq")
+    assert torch.equal(y_r, K.da_conv2d(d(x), pw, d(bias), offs_r, K.BF16))      # repeatable
