@@ -92,6 +92,8 @@ SIGNATURES = {
     "hdrsky_da_gather": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
     "hdrsky_da_scatter": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
     "hdrsky_da_sample_table": (c_int, [P, c_int, c_int, c_int, P, P]),
+    "hdrsky_da_conv2d_wgrad_ws_bytes": (c_size_t, [P, P, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "hdrsky_da_conv2d_wgrad": (c_int, [P, P, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, c_size_t, P]),
     "hdrsky_da_conv2d_dgrad": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     "hdrsky_bn_train_finalize": (c_int, [P, c_int, c_int, c_int, P, P, c_float, c_float, P, P, P, P, P, P, c_int, P]),
     "hdrsky_zero": (c_int, [P, c_size_t, P]),

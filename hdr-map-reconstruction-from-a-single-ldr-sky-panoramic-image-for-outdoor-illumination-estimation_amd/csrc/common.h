@@ -72,26 +72,50 @@ struct Tap4 {
   float w0, w1, w2, w3;
 };
 
-__host__ __device__ __forceinline__ Tap4 da_tap(float base_y, float base_x, float off_y, float off_x, int in_h, int in_w) {
+// The sample position is separable: the row part depends on (image row, tap) only, the column part on (column, tap).
+// da_tap composes the two halves, so a kernel that computes them separately (the row half once per row and tap) gets
+// bit-identical corners and weights.
+struct TapAxis {
+  int i0, i1;        // corner indices in PADDED coordinates
+  float wa, wb;      // (f(i1) - pos) and (pos - f(i0)): the weights of i0 and i1 along this axis
+};
+
+__host__ __device__ __forceinline__ TapAxis da_tap_y(float base_y, float off_y, int in_h) {
   float y = base_y + off_y;
-  float x = base_x + off_x;
   y = y < 0.f ? 0.f : y; y = y > (float)(in_h - 1) ? (float)(in_h - 1) : y;
-  x = x < 0.f ? x + (float)in_w : x;
-  x = x > (float)(in_w - 1) ? x - (float)in_w : x;
-  int y0 = (int)floorf(y), x0 = (int)floorf(x);
-  int y1 = y0 + 1, x1 = x0 + 1;
+  int y0 = (int)floorf(y);
+  int y1 = y0 + 1;
   y0 = y0 < 0 ? 0 : (y0 > in_h - 1 ? in_h - 1 : y0);
   y1 = y1 < 0 ? 0 : (y1 > in_h - 1 ? in_h - 1 : y1);
+  TapAxis t;
+  t.i0 = y0; t.i1 = y1;
+  t.wa = (float)y1 - y; t.wb = y - (float)y0;
+  return t;
+}
+
+__host__ __device__ __forceinline__ TapAxis da_tap_x(float base_x, float off_x, int in_w) {
+  float x = base_x + off_x;
+  x = x < 0.f ? x + (float)in_w : x;
+  x = x > (float)(in_w - 1) ? x - (float)in_w : x;
+  int x0 = (int)floorf(x);
+  int x1 = x0 + 1;
   const int x0w = x0, x1w = x1;  // unwrapped: used for the weights (:89, :100-106)
   x0 = x0 < 0 ? x0 + in_w : x0; x1 = x1 < 0 ? x1 + in_w : x1;
   x0 = x0 > in_w - 1 ? x0 - in_w : x0; x1 = x1 > in_w - 1 ? x1 - in_w : x1;
+  TapAxis t;
+  t.i0 = x0; t.i1 = x1;
+  t.wa = (float)x1w - x; t.wb = x - (float)x0w;
+  return t;
+}
+
+__host__ __device__ __forceinline__ Tap4 da_tap(float base_y, float base_x, float off_y, float off_x, int in_h, int in_w) {
+  const TapAxis ty = da_tap_y(base_y, off_y, in_h), tx = da_tap_x(base_x, off_x, in_w);
   Tap4 t;
-  t.y0 = y0; t.y1 = y1; t.x0 = x0; t.x1 = x1;
-  const float fy0 = (float)y0, fy1 = (float)y1, fx0 = (float)x0w, fx1 = (float)x1w;
-  t.w0 = (fy1 - y) * (fx1 - x);
-  t.w1 = (fy1 - y) * (x - fx0);
-  t.w2 = (y - fy0) * (fx1 - x);
-  t.w3 = (y - fy0) * (x - fx0);
+  t.y0 = ty.i0; t.y1 = ty.i1; t.x0 = tx.i0; t.x1 = tx.i1;
+  t.w0 = ty.wa * tx.wa;
+  t.w1 = ty.wa * tx.wb;
+  t.w2 = ty.wb * tx.wa;
+  t.w3 = ty.wb * tx.wb;
   return t;
 }
 

@@ -37,7 +37,7 @@ struct WgradArgs {
   int tiles_x, tiles_y, ntiles, tiles_per_wg, cblocks, oblocks;
   int HT, WT, NPIX, wt_magic, kw_magic, ntaps;
   int RX, RY;                    // LDS row strides (bytes) of the X / dY tiles
-  int off_xlo, off_y, off_ylo, off_ss, off_red;
+  int off_xlo, off_y, off_ylo, off_ss, off_red, off_da;
   int nchunks;                   // pixel split of this job
   int x_bf16, dy_bf16;           // operands stored as bf16 (the sample-resident conv chain) instead of fp32
   float* ws;                     // deterministic mode: this job's workspace (per (chunk, block) slabs [taps][CB][OB], then
@@ -149,6 +149,15 @@ __global__ void __launch_bounds__(NW * 64) conv_wgrad_kernel(const MultiArgs m) 
   float yr[YMAX][8];
   float wr[UP == 2 ? XI : 1][4];   // UP == 2: bilinear weights of the four source pixels
 
+  // UP == 2: the block's virtual channels belong to ONE filter tap (CB <= da_C); its sampling offsets of every image row go
+  // to LDS once, so that the gather of a tile starts from an LDS read instead of a dependent global load (the three
+  // dependent round trips per item - offsets, then corners - were what a tile visit cost: 17 us for 2 items per thread)
+  float* sOffDA = reinterpret_cast<float*>(smem + a.off_da);
+  if (UP == 2) {
+    const int tap = cb0 / a.da_C, k2 = a.da_k * a.da_k;
+    for (int i = tid; i < a.H * 2; i += NT) sOffDA[i] = a.da_offs[((i >> 1) * k2 + tap) * 2 + (i & 1)];
+    __syncthreads();   // read by the first tile's load phase, which runs before any other barrier
+  }
   // ---- per-sample operand transform tables for every sample this workgroup touches ----------------------------
   {
     const int blast = (tile1 - 1) / tps;
@@ -285,7 +294,7 @@ __global__ void __launch_bounds__(NW * 64) conv_wgrad_kernel(const MultiArgs m) 
       const int oy0 = ty * TH, ox0 = tx * TW;
       const int iy0 = oy0 * a.stride - a.pad_t, ix0 = ox0 * a.stride - a.pad_l;
       if (UP == 2) {
-        const int k = a.da_k, k2 = k * k, pad = (k - 1) / 2, in_h = a.H + k - 1, in_w = a.W + k - 1;
+        const int k = a.da_k, pad = (k - 1) / 2, in_h = a.H + k - 1, in_w = a.W + k - 1;
 #pragma unroll
         for (int it = 0; it < XI; ++it) {
           const int i = it * NT + tid;
@@ -299,7 +308,7 @@ __global__ void __launch_bounds__(NW * 64) conv_wgrad_kernel(const MultiArgs m) 
             const int tap = vq / a.da_C, c0 = vq - tap * a.da_C;
             const int tky = tap / k, tkx = tap - tky * k;
             const int oyc = live ? oy : 0;
-            const float off_y = a.da_offs[(oyc * k2 + tap) * 2], off_x = a.da_offs[(oyc * k2 + tap) * 2 + 1];
+            const float off_y = sOffDA[oyc * 2], off_x = sOffDA[oyc * 2 + 1];
             const Tap4 sp4 = da_tap((float)(oyc + tky), (float)((live ? ox : 0) + tkx), off_y, off_x, in_h, in_w);
             const int ys[4] = {sp4.y0, sp4.y0, sp4.y1, sp4.y1}, xs[4] = {sp4.x0, sp4.x1, sp4.x0, sp4.x1};
             const float ws4[4] = {sp4.w0, sp4.w1, sp4.w2, sp4.w3};
@@ -592,7 +601,9 @@ struct WgradVariant {
     const int tps = a.tiles_x * a.tiles_y;
     const int nsamp = (a.tiles_per_wg + tps - 2) / tps + 1;          // samples a run of tiles_per_wg tiles can touch
     a.off_red = a.off_ss + nsamp * 2 * CB * 4;
-    const int lds = a.off_red + NT * 8 * 4;
+    a.off_da = a.off_red + NT * 8 * 4;
+    if (UP == 2 && (a.da_C % CB) != 0) return HDRSKY_EUNSUPPORTED;   // one tap per block of virtual channels
+    const int lds = a.off_da + (UP == 2 ? a.H * 2 * 4 : 0);
     if (lds > 160 * 1024) return HDRSKY_EUNSUPPORTED;
     return lds;
   }

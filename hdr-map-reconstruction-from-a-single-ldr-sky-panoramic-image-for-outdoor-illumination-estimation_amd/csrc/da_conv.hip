@@ -31,7 +31,9 @@ struct DaArgs {
   // region variant (da_region_kernel): first source row of every group of grp_tiles 64-pixel tiles (host table) and the
   // number of source rows staged (>= what any group reads); LDS byte offsets of the table ring and of the region
   const int* row_lo;
-  int src_rows, tb_off, reg_off, nq_sh, grp_tiles, groups_x;
+  int src_rows, tb_off, reg_off, nq_sh, grp_tiles, groups_x, so_off, rt_cap, w_sh;
+  int tm;                   // pixels per tile of the region kernel (64, or 32 when 64-pixel tiles leave half the chip idle)
+  int nparts;               // statistics slots per sample: one per 32 pixels (a 64-pixel tile fills the even one, zeroes the odd)
 };
 
 // Workgroup = NWV waves: a tile of 64 consecutive output pixels of one sample (row-major, so it spans several rows
@@ -257,8 +259,9 @@ __global__ void __launch_bounds__(NWV * 64) da_conv_kernel(const DaArgs a) {
     s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
     s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
     if (kq == 0 && n < a.Cout) {
-      float* dst = a.stats + ((size_t)(b * a.tiles_x + tile) * 2) * a.Cout + n;
+      float* dst = a.stats + ((size_t)(b * a.nparts + 2 * tile) * 2) * a.Cout + n;
       dst[0] = s1; dst[a.Cout] = s2;
+      if (2 * tile + 1 < a.nparts) { dst[2 * a.Cout] = 0.f; dst[3 * a.Cout] = 0.f; }
     }
   }
 }
@@ -273,10 +276,10 @@ __global__ void __launch_bounds__(NWV * 64) da_conv_kernel(const DaArgs a) {
 // table (KM = 4: da_tap, exact reference arithmetic; KM = 8: the transposed table from global memory, fetched a round
 // ahead), barrier, (c) the MFMAs of the round.  Sources are rounded to bf16 before the blend (the legacy kernel blends
 // fp32 sources); the blend itself is fp32 and its result is rounded once more, as there.
-template <int NWV, int KM, int CBMAX>
+template <int NWV, int KM, int CBMAX, int TM>
 __global__ void __launch_bounds__(NWV * 64) da_region_kernel(const DaArgs a) {
-  constexpr int TM = 64, NT = NWV * 64;
-  constexpr int MAXROWS = 5, EMAX = 2;                          // CBMAX: 32-channel k-steps per round (register sets)
+  constexpr int NT = NWV * 64, TSH = TM == 64 ? 6 : 5, MF = TM / 16;   // TM = 64 or 32 pixels per tile
+  constexpr int EMAX = 2;                                       // CBMAX: 32-channel k-steps per round (register sets)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, lr = lane & 15;
   const int nq = a.Cin >> 3, nqr = nq * a.tpr, plane = TM + 1, buf_units = nqr * plane;
@@ -291,17 +294,21 @@ __global__ void __launch_bounds__(NWV * 64) da_region_kernel(const DaArgs a) {
   const int grp = bid % a.groups_x, b = bid / a.groups_x;     // group = grp_tiles consecutive tiles sharing one region
   const int n0 = nb * (NWV * 16);
   const int npix = a.H * a.W;
-  const int ylo = a.row_lo[grp];
+  const int ylo = a.row_lo[TM == 64 ? grp : grp >> 1];          // a 32-pixel tile stages the rows of the 64-pixel tile it lies in
   const int nrows = min(a.src_rows, a.H - ylo);
   const int regpix = nrows * a.W;
   const int tile_end = min((grp + 1) * a.grp_tiles, a.tiles_x);
 
-  f32x4_t acc[4];
+  f32x4_t acc[MF];
   const bool wave_live = n0 + wave * 16 < a.Npad;     // waves beyond the filter image only help with the gather
   const int wcol = wave_live ? n0 + wave * 16 : 0;
   const uint4* wlh = a.whi + (size_t)kq * a.Npad + wcol + lr;
 
-  __shared__ float s_off[MAXROWS * 2 * 128];
+  // row halves of the sample positions of the tile's rows (da_tap_y: region row * W or -1, the two row weights), the
+  // column offsets and tap % k - the per-entry work left is da_tap_x, four products and four index sums
+  int4* sRT = reinterpret_cast<int4*>(smem + a.so_off);
+  float* sOx = reinterpret_cast<float*>(smem + a.so_off + a.rt_cap * 16);
+  int* sKx = reinterpret_cast<int*>(smem + a.so_off + a.rt_cap * 20);
   // ---- the source rows of this group: a linear fp32 -> bf16 copy -------------------------------------------------
   {
     const float* src = a.x + ((size_t)b * npix + (size_t)ylo * a.W) * a.Cin;
@@ -339,11 +346,20 @@ __global__ void __launch_bounds__(NWV * 64) da_region_kernel(const DaArgs a) {
   const int p0 = tile * TM;
   const int row0 = p0 / a.W;
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) acc[mi] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int mi = 0; mi < MF; ++mi) acc[mi] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   if constexpr (KM == 4) {
     const int nrow = min(p0 + TM - 1, npix - 1) / a.W - row0 + 1;
-    for (int i = tid; i < nrow * a.k2 * 2; i += NT) s_off[i] = a.offs[(size_t)row0 * a.k2 * 2 + i];
-    __syncthreads();     // s_off visible to the table writers
+    for (int i = tid; i < nrow * a.k2; i += NT) {
+      const int r = i / a.k2, tn = i - r * a.k2;
+      const float2 o = *reinterpret_cast<const float2*>(a.offs + ((size_t)row0 * a.k2 + i) * 2);
+      const TapAxis ty = da_tap_y((float)(row0 + r + tn / a.ksize), o.x, a.in_h);
+      const int r0 = ty.i0 - a.pad - ylo, r1 = ty.i1 - a.pad - ylo;
+      sRT[i] = int4{(r0 >= 0 && r0 < nrows) ? r0 * a.W : -1, (r1 >= 0 && r1 < nrows) ? r1 * a.W : -1,
+                    __builtin_bit_cast(int, ty.wa), __builtin_bit_cast(int, ty.wb)};
+      sOx[i] = o.y;
+    }
+    for (int tn = tid; tn < a.k2; tn += NT) sKx[tn] = tn % a.ksize;
+    __syncthreads();     // visible to the table writers
   }
 
   // ---- the per-round sample table ---------------------------------------------------------------------------------
@@ -355,7 +371,7 @@ __global__ void __launch_bounds__(NWV * 64) da_region_kernel(const DaArgs a) {
       for (int k = 0; k < EMAX; ++k) {
         const int e = k * NT + tid;
         if (e < nent) {
-          const int m = e % TM, tn = min(rnd * a.tpr + e / TM, a.k2 - 1);
+          const int m = e & (TM - 1), tn = min(rnd * a.tpr + (e >> TSH), a.k2 - 1);
           const int pix = min(p0 + m, npix - 1);
           const int4* gi = reinterpret_cast<const int4*>(a.gidx + ((size_t)pix * a.k2 + tn) * 8);
           const float4* gwp = reinterpret_cast<const float4*>(a.gw + ((size_t)pix * a.k2 + tn) * 8);
@@ -376,24 +392,24 @@ __global__ void __launch_bounds__(NWV * 64) da_region_kernel(const DaArgs a) {
     for (int k = 0; k < EMAX; ++k) {
       const int e = k * NT + tid;
       if (e < nent) {
-        const int m = e % TM, tsub = e / TM;
+        const int m = e & (TM - 1), tsub = e >> TSH;
         const bool tap_ok = rnd * a.tpr + tsub < a.k2;
         const int tn = tap_ok ? rnd * a.tpr + tsub : a.k2 - 1;
         const bool live = p0 + m < npix;
         unsigned short oi[KM];
         float ow[KM];
         if constexpr (KM == 4) {
-          const int pix = p0 + m;
-          const int oy = live ? pix / a.W : row0, ox = live ? pix % a.W : 0;
-          const float off_y = s_off[((oy - row0) * a.k2 + tn) * 2], off_x = s_off[((oy - row0) * a.k2 + tn) * 2 + 1];
-          const Tap4 s = da_tap((float)(oy + tn / a.ksize), (float)(ox + tn % a.ksize), off_y, off_x, a.in_h, a.in_w);
-          const int ys[4] = {s.y0, s.y0, s.y1, s.y1}, xs[4] = {s.x0, s.x1, s.x0, s.x1};
-          const float ws[4] = {s.w0, s.w1, s.w2, s.w3};
+          const int pix = live ? p0 + m : p0;
+          const int ri = ((pix >> a.w_sh) - row0) * a.k2 + tn, ox = pix & (a.W - 1);      // W is a power of two
+          const int4 rt = sRT[ri];
+          const TapAxis tx = da_tap_x((float)(ox + sKx[tn]), sOx[ri], a.in_w);
+          const float wya = __builtin_bit_cast(float, rt.z), wyb = __builtin_bit_cast(float, rt.w);
+          const int rys[4] = {rt.x, rt.x, rt.y, rt.y}, xs[4] = {tx.i0 - a.pad, tx.i1 - a.pad, tx.i0 - a.pad, tx.i1 - a.pad};
+          const float ws[4] = {wya * tx.wa, wya * tx.wb, wyb * tx.wa, wyb * tx.wb};        // = da_tap's w0..w3
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const int yy = ys[c] - a.pad - ylo, xx = xs[c] - a.pad;     // region row / column; outside = zero padding
-            const bool in = live && tap_ok && yy >= 0 && yy < nrows && ys[c] - a.pad < a.H && xx >= 0 && xx < a.W;
-            oi[c] = (unsigned short)(in ? yy * a.W + xx : 0);
+          for (int c = 0; c < 4; ++c) {     // outside the image = the layer's zero padding
+            const bool in = live && tap_ok && rys[c] >= 0 && xs[c] >= 0 && xs[c] < a.W;
+            oi[c] = (unsigned short)(in ? rys[c] + xs[c] : 0);
             ow[c] = in ? ws[c] : 0.f;
           }
         } else {
@@ -439,10 +455,10 @@ __global__ void __launch_bounds__(NWV * 64) da_region_kernel(const DaArgs a) {
     const float* tw = reinterpret_cast<const float*>(sTb + (t & 1) * tb_bytes + nent * KM * 2);
 #pragma unroll(KM == 4 ? 2 : 1)
     for (int i = tid; i < nitems; i += NT) {
-      // item order (tap of the round, pixel, 8-channel group): nq is a power of two and TM = 64, so no division - the
+      // item order (tap of the round, pixel, 8-channel group): nq and TM are powers of two, so no division - the
       // nq lanes of a (pixel, tap) share one table entry (LDS broadcast)
       const int e = i >> a.nq_sh, q = i & (nq - 1);
-      const int m = e & (TM - 1), qr = (e >> 6) * nq + q;
+      const int m = e & (TM - 1), qr = (e >> TSH) * nq + q;
       unsigned short oi[KM];
       float ow[KM];
 #pragma unroll
@@ -482,7 +498,7 @@ __global__ void __launch_bounds__(NWV * 64) da_region_kernel(const DaArgs a) {
         if (cb >= spr || t * spr + cb >= ksteps) break;
         const uint4 bh = bch[cb];
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) acc[mi] = mfma16(buf[(cb * 4 + kq) * plane + mi * 16 + lr], bh, acc[mi]);
+        for (int mi = 0; mi < MF; ++mi) acc[mi] = mfma16(buf[(cb * 4 + kq) * plane + mi * 16 + lr], bh, acc[mi]);
       }
 #pragma unroll
       for (int cb = 0; cb < CBMAX; ++cb) bch[cb] = bnh[cb];
@@ -494,7 +510,7 @@ __global__ void __launch_bounds__(NWV * 64) da_region_kernel(const DaArgs a) {
   if (n < a.Cout) {
     const float bv = a.bias ? a.bias[n] : 0.f;
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < MF; ++mi)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int pix = p0 + mi * 16 + kq * 4 + j;
@@ -509,8 +525,10 @@ __global__ void __launch_bounds__(NWV * 64) da_region_kernel(const DaArgs a) {
     s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
     s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
     if (kq == 0 && n < a.Cout) {
-      float* dst = a.stats + ((size_t)(b * a.tiles_x + tile) * 2) * a.Cout + n;
+      const int slot = TM == 64 ? 2 * tile : tile;
+      float* dst = a.stats + ((size_t)(b * a.nparts + slot) * 2) * a.Cout + n;
       dst[0] = s1; dst[a.Cout] = s2;
+      if (TM == 64 && slot + 1 < a.nparts) { dst[2 * a.Cout] = 0.f; dst[3 * a.Cout] = 0.f; }
     }
   }
   __syncthreads();      // the next tile reuses s_off, the table ring and the A buffers
@@ -524,41 +542,48 @@ static int da_region_plan(DaArgs& a, int C, int nwv, int km, const int* spans, i
   // first row of every group, [5][tiles_x].  Larger groups re-read fewer source rows (a 7x7 tile of 64 pixels stages 13
   // rows of 128 pixels: 26 x its own size; 8 tiles sharing 16 rows: 4 x) - taken while the launch keeps >= 256 workgroups.
   if (!spans || !a.row_lo || (C % 32) != 0) return 0;
-  if ((64 / a.W + 2) * a.k2 > 5 * 128) return 0;
   int hook_level = -1;
   if (const char* e = getenv("HDRSKY_DA_REGION")) { if (atoi(e) == 0) return 0; }   // tuning / test hooks
   if (const char* e = getenv("HDRSKY_DA_GROUP")) hook_level = atoi(e);
   const int nq = C / 8, cin32 = C / 32, nt = nwv * 64;
-  if (nq & (nq - 1)) return 0;                                  // the item indexing wants a power of two
-  a.nq_sh = __builtin_ctz(nq);
+  if ((nq & (nq - 1)) || (a.W & (a.W - 1))) return 0;           // the item / pixel indexing wants powers of two
+  a.nq_sh = __builtin_ctz(nq); a.w_sh = __builtin_ctz(a.W);
+  // 32-pixel tiles when 64-pixel tiles would leave half the CUs without a workgroup (the 8x32 / 4x16 maps at batch 32)
+  a.tm = (B * a.tiles_x * a.nblocks <= 128 && hook_level <= 0) ? 32 : 64;
+  if (const char* e = getenv("HDRSKY_DA_TM")) { const int t = atoi(e); if (t == 32 || t == 64) a.tm = t; }
+  if (a.tm == 32) a.tiles_x = cdiv(a.H * a.W, 32);
+  a.rt_cap = km == 4 ? (64 / a.W + 2) * a.k2 : 0;              // (row, tap) entries of a tile: 16 + 4 bytes each, + k2 ints
+  const int so = km == 4 ? roundup(a.rt_cap * 20 + a.k2 * 4, 16) : 0;
   const int* row_lo_base = a.row_lo;
   for (int level = 4; level >= 0; --level) {
+    if (a.tm == 32 && level != 0) continue;
     const int G = 1 << level, groups = cdiv(a.tiles_x, G), src_rows = spans[level];
     if (level != (hook_level >= 0 ? hook_level : 0)) continue;   // measured: groups of tiles do not pay (see DESIGN), hook only
     if (src_rows <= 0 || (size_t)src_rows * a.W > 65535) continue;   // u16 region pixel indices
     const int region = src_rows * a.W * C * 2;
     for (int tpr = a.k2 < 8 ? a.k2 : 8; tpr >= 1; --tpr) {
       if (tpr * cin32 > 8 || 64 * tpr > 2 * nt) continue;     // filter prefetch registers, table entries per thread
-      const int abytes = 2 * tpr * nq * 65 * 16, tb = 2 * 64 * tpr * km * 6;
-      if (abytes + tb + region > 152 * 1024) continue;
+      const int abytes = 2 * tpr * nq * (a.tm + 1) * 16, tb = 2 * a.tm * tpr * km * 6;
+      if (abytes + tb + so + region > 160 * 1024) continue;
       a.tpr = tpr; a.nrounds = cdiv(a.k2, tpr);
-      a.tb_off = abytes; a.reg_off = abytes + tb; a.src_rows = src_rows;
+      a.tb_off = abytes; a.so_off = abytes + tb; a.reg_off = abytes + tb + so; a.src_rows = src_rows;
       a.grp_tiles = G; a.groups_x = groups; a.row_lo = row_lo_base + (size_t)level * a.tiles_x;
-      return abytes + tb + region;
+      return abytes + tb + so + region;
     }
   }
+  a.tiles_x = cdiv(a.H * a.W, 64);      // (the caller falls back to da_conv_kernel's 64-pixel tiles)
   return 0;
 }
 
 // HDRSKY_DA_REGION=2: fail instead of falling back to the global-memory gather (tests: proves which kernel ran)
 static bool da_region_forced() { const char* e = getenv("HDRSKY_DA_REGION"); return e && atoi(e) == 2; }
 
-template <int NWV, int KM, int CBMAX>
+template <int NWV, int KM, int CBMAX, int TM>
 static int da_region_launch_(const DaArgs& a, int grid, int lds, void* stream) {
-  auto k = da_region_kernel<NWV, KM, CBMAX>;
+  auto k = da_region_kernel<NWV, KM, CBMAX, TM>;
   static bool set = false;
   if (!set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return HDRSKY_ELAUNCH;
     set = true;
   }
@@ -569,7 +594,9 @@ static int da_region_launch_(const DaArgs& a, int grid, int lds, void* stream) {
 
 template <int NWV, int KM>
 static int da_region_launch(const DaArgs& a, int grid, int lds, void* stream) {
-  return a.tpr * a.cin32 <= 4 ? da_region_launch_<NWV, KM, 4>(a, grid, lds, stream) : da_region_launch_<NWV, KM, 8>(a, grid, lds, stream);
+  if (a.tm == 32)
+    return a.tpr * a.cin32 <= 4 ? da_region_launch_<NWV, KM, 4, 32>(a, grid, lds, stream) : da_region_launch_<NWV, KM, 8, 32>(a, grid, lds, stream);
+  return a.tpr * a.cin32 <= 4 ? da_region_launch_<NWV, KM, 4, 64>(a, grid, lds, stream) : da_region_launch_<NWV, KM, 8, 64>(a, grid, lds, stream);
 }
 
 // ---- backward building blocks ----------------------------------------------------------------------------------
@@ -644,6 +671,384 @@ static bool da_taps_per_round(int C, int nwv, int k2, int imax_max, int* tpr) {
   return t * nq <= 2 * nwv;
 }
 
+// ---- kernel gradient with the region gather ---------------------------------------------------------------------
+// dW[tap][ci][co] = sum over pixels of G[pixel][tap][ci] * dY[pixel][co] with G the layer's bilinear samples.  The weight-
+// gradient kernel of conv_wgrad.hip (UP = 2) gathers from global memory, one tap's channels per workgroup and tile visit:
+// every visit pays the dY tile, two barriers and a round trip to L2 for a handful of MFMAs (12 res layers: 1.5 ms per
+// step, the two 7x7 layers 1.7 ms).  Here a workgroup stages the source rows of a GROUP of tiles of one sample once
+// (as da_region_kernel) and loops rounds (tpr taps) outside, the group's tiles inside: per (round, tile) it gathers the A
+// tile [64 pixels][tpr*C] from LDS, stages the dY tile [64][F block], and accumulates the round's dW fragments with
+// K = pixels (transposing LDS reads, as conv_wgrad_kernel); after the group's tiles the round's block goes to the
+// workgroup's partial slab ws[chunk = (sample, group)][k*k*C][F] with plain stores, and da_wgrad_reduce_kernel adds
+// the chunks to dW in a fixed order (deterministic).  Rounds are dealt to `nsplit` workgroups per chunk.
+typedef __attribute__((ext_vector_type(4))) short da_s16x4_t;
+__device__ __forceinline__ uint2 da_lds_tr(const unsigned char* p) {
+  const da_s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) da_s16x4_t*)(p));
+  return __builtin_bit_cast(uint2, v);
+}
+
+struct DaWgArgs {
+  const float* x;
+  const void* dy;
+  const float* offs;
+  const int* row_lo;
+  float* ws;
+  float* ws_db;
+  int dy_bf16;
+  int B, H, W, C, F, ksize, k2, pad, in_h, in_w;
+  int tiles_x, grp_tiles, groups_x, src_rows, grp_rows;
+  int tpr, nrounds, nsplit, nfblk, FB;
+  int nq_sh, nqy_sh, cif_sh, cof_sh, nfr, w_sh, rt_cap;   // log2 of C/8, FB/8, C/16, FB/16; fragments per round; log2 W
+  int RA, RY, y_off, tb_off, so_off, reg_off;   // LDS row strides / byte offsets
+};
+
+template <int NFR>
+__global__ void __launch_bounds__(512) da_wgrad_region_kernel(const DaWgArgs a) {
+  constexpr int TM = 64, NT = 512;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ float s_bias[8][128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, q4 = (lane & 15) >> 2, p = lane & 3, kq = g, lr = lane & 15;
+  const int nq = a.C >> 3, nqr = nq * a.tpr, nqy = a.FB >> 3;
+  unsigned char* sA = smem;                                  // [2][64 rows of RA bytes]
+  unsigned char* sY = smem + a.y_off;                         // [2][64 rows of RY bytes]
+  unsigned char* sTb = smem + a.tb_off;                       // [2] x { u16 idx[nent][4], float w[nent][4] }
+  int4* sRT = reinterpret_cast<int4*>(smem + a.so_off);       // row halves of the sample positions of the group's rows
+  float* sOx = reinterpret_cast<float*>(smem + a.so_off + a.rt_cap * 16);   // (as da_region_kernel), column offsets, tap % k
+  int* sKx = reinterpret_cast<int*>(smem + a.so_off + a.rt_cap * 20);
+  const uint4* sReg = reinterpret_cast<const uint4*>(smem + a.reg_off);
+  const int nent = TM * a.tpr, tb_bytes = nent * 24;
+
+  int bid = blockIdx.x;
+  const int fb = bid % a.nfblk; bid /= a.nfblk;
+  const int split = bid % a.nsplit; bid /= a.nsplit;
+  const int grp = bid % a.groups_x, b = bid / a.groups_x;
+  const int chunk = b * a.groups_x + grp;
+  const int npix = a.H * a.W;
+  const int ylo = a.row_lo[grp];
+  const int nrows = min(a.src_rows, a.H - ylo);
+  const int regpix = nrows * a.W;
+  const int tile0 = grp * a.grp_tiles, ntl = min(a.grp_tiles, a.tiles_x - tile0);
+  const int grow0 = (tile0 * TM) / a.W;                       // first image row of the group's output pixels
+  const int f0 = fb * a.FB;
+
+  // ---- group prologue: sampling offsets of its rows, source rows fp32 -> bf16 ----------------------------------
+  {
+    const int last = min((tile0 + ntl) * TM, npix) - 1;
+    const int nr = last / a.W - grow0 + 1;
+    for (int i = tid; i < nr * a.k2; i += NT) {
+      const int r = i / a.k2, tn = i - r * a.k2;
+      const float2 o = *reinterpret_cast<const float2*>(a.offs + ((size_t)grow0 * a.k2 + i) * 2);
+      const TapAxis ty = da_tap_y((float)(grow0 + r + tn / a.ksize), o.x, a.in_h);
+      const int r0 = ty.i0 - a.pad - ylo, r1 = ty.i1 - a.pad - ylo;
+      sRT[i] = int4{(r0 >= 0 && r0 < nrows) ? r0 * a.W : -1, (r1 >= 0 && r1 < nrows) ? r1 * a.W : -1,
+                    __builtin_bit_cast(int, ty.wa), __builtin_bit_cast(int, ty.wb)};
+      sOx[i] = o.y;
+    }
+    for (int tn = tid; tn < a.k2; tn += NT) sKx[tn] = tn % a.ksize;
+    const float* src = a.x + ((size_t)b * npix + (size_t)ylo * a.W) * a.C;
+    uint4* dst = reinterpret_cast<uint4*>(smem + a.reg_off);
+    const int nunits = regpix * nq;
+    int u = tid;
+    for (; u + 3 * NT < nunits; u += 4 * NT) {
+      float4 lo[4], hi[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float* pp = src + (size_t)(u + k * NT) * 8;
+        lo[k] = *reinterpret_cast<const float4*>(pp); hi[k] = *reinterpret_cast<const float4*>(pp + 4);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float v[8] = {lo[k].x, lo[k].y, lo[k].z, lo[k].w, hi[k].x, hi[k].y, hi[k].z, hi[k].w};
+        uint4 h8, l8;
+        pack8<false>(v, h8, l8);
+        dst[u + k * NT] = h8;
+      }
+    }
+    for (; u < nunits; u += NT) {
+      const float* pp = src + (size_t)u * 8;
+      const float4 lo = *reinterpret_cast<const float4*>(pp), hi = *reinterpret_cast<const float4*>(pp + 4);
+      const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      uint4 h8, l8;
+      pack8<false>(v, h8, l8);
+      dst[u] = h8;
+    }
+  }
+  // this wave's dW fragments of a round: fr = k * 8 + wave -> (tap of the round ts, ci fragment i, co fragment j), i fastest
+  int abase[NFR], ybase[NFR];
+#pragma unroll
+  for (int k = 0; k < NFR; ++k) {
+    const int fr = k * 8 + wave;
+    const int i = fr & ((1 << a.cif_sh) - 1), rest = fr >> a.cif_sh;
+    const int j = rest & ((1 << a.cof_sh) - 1), ts = rest >> a.cof_sh;
+    abase[k] = fr < a.nfr ? (ts * a.C + i * 16) * 2 : -1;
+    ybase[k] = j * 32;
+  }
+  f32x4_t acc[NFR];
+#pragma unroll
+  for (int k = 0; k < NFR; ++k) acc[k] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float bsum[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
+  const int my_rounds = (a.nrounds - split + a.nsplit - 1) / a.nsplit;     // rounds split, split + nsplit, ...
+  const int niter = my_rounds * ntl;
+  const bool bias_wg = split == 0 && a.ws_db != nullptr;                    // sums dY over the group's tiles in its first round
+
+  auto table_write = [&](int rnd, int tile, int slot) {
+    unsigned short* ti = reinterpret_cast<unsigned short*>(sTb + slot * tb_bytes);
+    float* tw = reinterpret_cast<float*>(sTb + slot * tb_bytes + nent * 8);
+    const int p0 = tile * TM;
+    for (int e = tid; e < nent; e += NT) {
+      const int m = e & (TM - 1), tsub = e >> 6;
+      const bool tap_ok = rnd * a.tpr + tsub < a.k2;
+      const int tn = tap_ok ? rnd * a.tpr + tsub : a.k2 - 1;
+      const bool live = p0 + m < npix;
+      const int pix = live ? p0 + m : p0;
+      const int ri = ((pix >> a.w_sh) - grow0) * a.k2 + tn, ox = pix & (a.W - 1);
+      const int4 rt = sRT[ri];
+      const TapAxis tx = da_tap_x((float)(ox + sKx[tn]), sOx[ri], a.in_w);
+      const float wya = __builtin_bit_cast(float, rt.z), wyb = __builtin_bit_cast(float, rt.w);
+      const int rys[4] = {rt.x, rt.x, rt.y, rt.y}, xs[4] = {tx.i0 - a.pad, tx.i1 - a.pad, tx.i0 - a.pad, tx.i1 - a.pad};
+      const float ws4[4] = {wya * tx.wa, wya * tx.wb, wyb * tx.wa, wyb * tx.wb};
+      unsigned short oi[4];
+      float ow[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const bool in = live && tap_ok && rys[c] >= 0 && xs[c] >= 0 && xs[c] < a.W;
+        oi[c] = (unsigned short)(in ? rys[c] + xs[c] : 0);
+        ow[c] = in ? ws4[c] : 0.f;
+      }
+      *reinterpret_cast<uint2*>(ti + (size_t)e * 4) =
+          uint2{(unsigned)oi[0] | ((unsigned)oi[1] << 16), (unsigned)oi[2] | ((unsigned)oi[3] << 16)};
+      *reinterpret_cast<float4*>(tw + (size_t)e * 4) = float4{ow[0], ow[1], ow[2], ow[3]};
+    }
+  };
+  // dY tile of `tile` -> registers (fp32 values), two (pixel, 8-channel) items per thread at most
+  float yr[2][8];
+  auto load_dy = [&](int tile) {
+    const int p0 = tile * TM;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int idx = k * NT + tid;
+      if (idx < TM * nqy) {
+        const int m = idx >> a.nqy_sh, qc = idx & (nqy - 1);
+        const bool live = p0 + m < npix;
+        const size_t eo = ((size_t)b * npix + (live ? p0 + m : 0)) * a.F + f0 + qc * 8;
+        if (a.dy_bf16) {
+          const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(a.dy) + eo);
+          const unsigned w4[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            yr[k][2 * j] = live ? __builtin_bit_cast(float, w4[j] << 16) : 0.f;
+            yr[k][2 * j + 1] = live ? __builtin_bit_cast(float, w4[j] & 0xffff0000u) : 0.f;
+          }
+        } else {
+          const float* src = reinterpret_cast<const float*>(a.dy) + eo;
+          const float4 va = *reinterpret_cast<const float4*>(src), vb = *reinterpret_cast<const float4*>(src + 4);
+          yr[k][0] = live ? va.x : 0.f; yr[k][1] = live ? va.y : 0.f; yr[k][2] = live ? va.z : 0.f; yr[k][3] = live ? va.w : 0.f;
+          yr[k][4] = live ? vb.x : 0.f; yr[k][5] = live ? vb.y : 0.f; yr[k][6] = live ? vb.z : 0.f; yr[k][7] = live ? vb.w : 0.f;
+        }
+      }
+    }
+  };
+
+  __syncthreads();                               // offsets + region staged
+  if (niter > 0) { table_write(split, tile0, 0); load_dy(tile0); }
+  __syncthreads();
+  int rr = 0, tl = 0;                            // iteration -> (round index of this workgroup, tile of the group)
+  for (int it = 0; it < niter; ++it) {
+    const int rnd = split + rr * a.nsplit, tile = tile0 + tl;
+    const int nrr = tl + 1 == ntl ? rr + 1 : rr, ntl1 = tl + 1 == ntl ? 0 : tl + 1;   // the next iteration
+    unsigned char* bufA = sA + (it & 1) * TM * a.RA;
+    unsigned char* bufY = sY + (it & 1) * TM * a.RY;
+    const unsigned short* ti = reinterpret_cast<const unsigned short*>(sTb + (it & 1) * tb_bytes);
+    const float* tw = reinterpret_cast<const float*>(sTb + (it & 1) * tb_bytes + nent * 8);
+    // ---- A tile: bilinear samples of tpr taps, pixel-major rows --------------------------------------------------
+#pragma unroll 2
+    for (int i = tid; i < TM * nqr; i += NT) {
+      const int e = i >> a.nq_sh, q = i & (nq - 1);
+      const int m = e & (TM - 1), qr = (e >> 6) * nq + q;
+      const uint2 pi = *reinterpret_cast<const uint2*>(ti + (size_t)e * 4);
+      const float4 pw = *reinterpret_cast<const float4*>(tw + (size_t)e * 4);
+      const int oi[4] = {(int)(pi.x & 0xffffu), (int)(pi.x >> 16), (int)(pi.y & 0xffffu), (int)(pi.y >> 16)};
+      const float ow[4] = {pw.x, pw.y, pw.z, pw.w};
+      uint4 src[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) src[c] = sReg[oi[c] * nq + q];
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const unsigned w4[4] = {src[c].x, src[c].y, src[c].z, src[c].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[2 * j] += ow[c] * __builtin_bit_cast(float, w4[j] << 16);
+          v[2 * j + 1] += ow[c] * __builtin_bit_cast(float, w4[j] & 0xffff0000u);
+        }
+      }
+      uint4 h8, l8;
+      pack8<false>(v, h8, l8);
+      *reinterpret_cast<uint4*>(bufA + (size_t)m * a.RA + qr * 16) = h8;
+    }
+    // ---- dY tile (loaded an iteration ago) ------------------------------------------------------------------------
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int idx = k * NT + tid;
+      if (idx < TM * nqy) {
+        const int m = idx >> a.nqy_sh, qc = idx & (nqy - 1);
+        if (bias_wg && rr == 0) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bsum[j] += yr[k][j];
+        }
+        uint4 h8, l8;
+        pack8<false>(yr[k], h8, l8);
+        *reinterpret_cast<uint4*>(bufY + (size_t)m * a.RY + qc * 16) = h8;
+      }
+    }
+    if (it + 1 < niter) table_write(split + nrr * a.nsplit, tile0 + ntl1, (it + 1) & 1);
+    __syncthreads();
+    if (it + 1 < niter) load_dy(tile0 + ntl1);
+    // ---- MFMA: K = the tile's 64 pixels ----------------------------------------------------------------------------
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int m = r * 32 + g * 8 + q4;
+#pragma unroll
+      for (int k = 0; k < NFR; ++k) {
+        if (abase[k] >= 0) {    // wave-uniform
+          const unsigned char* ad = bufA + (size_t)m * a.RA + abase[k] + p * 8;
+          const uint2 v0 = da_lds_tr(ad), v1 = da_lds_tr(ad + 4 * a.RA);
+          const unsigned char* yd = bufY + (size_t)m * a.RY + ybase[k] + p * 8;
+          const uint2 w0 = da_lds_tr(yd), w1 = da_lds_tr(yd + 4 * a.RY);
+          acc[k] = mfma16(uint4{v0.x, v0.y, v1.x, v1.y}, uint4{w0.x, w0.y, w1.x, w1.y}, acc[k]);
+        }
+      }
+    }
+    if (tl + 1 == ntl) {      // the group's tiles are through: this round's block of dW goes to the partial slab
+#pragma unroll
+      for (int k = 0; k < NFR; ++k) {
+        if (abase[k] >= 0) {
+          const int fr = k * 8 + wave;
+          const int i = fr & ((1 << a.cif_sh) - 1), rest = fr >> a.cif_sh;
+          const int j = rest & ((1 << a.cof_sh) - 1), ts = rest >> a.cof_sh;
+          const int tap = rnd * a.tpr + ts;
+          if (tap < a.k2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int row = tap * a.C + i * 16 + kq * 4 + e, col = f0 + j * 16 + lr;
+              a.ws[((size_t)chunk * a.k2 * a.C + row) * a.F + col] = acc[k][e];
+            }
+          }
+        }
+        acc[k] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    rr = nrr; tl = ntl1;
+  }
+  if (bias_wg) {      // column sums of dY over the group: lanes sharing a channel group, then the eight waves
+    for (int mask = 32; mask >= nqy; mask >>= 1) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bsum[j] += __shfl_xor(bsum[j], mask);
+    }
+    __syncthreads();
+    if (lane < nqy) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s_bias[wave][lane * 8 + j] = bsum[j];
+    }
+    __syncthreads();
+    if (tid < a.FB) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) t += s_bias[w][tid];
+      a.ws_db[(size_t)chunk * a.F + f0 + tid] = t;
+    }
+  }
+}
+
+// dw[i] += sum over chunks of ws[c][i], db likewise - always in the same order.  A block owns 256/S float4 of the slab
+// and S chunk slices: slice q sums the chunks q, q+S, ... (independent 16-byte loads in flight), then slice 0 adds the S
+// partial sums in slice order (one chain over hundreds of chunks per element would be latency bound).
+__global__ void __launch_bounds__(256) da_wgrad_reduce_kernel(const float4* ws, int nchunks, size_t n4, float4* dw,
+                                                               const float* ws_db, int F, float* db, int S) {
+  __shared__ float4 sPart[15 * 64];
+  const int per = 256 / S, col = threadIdx.x % per, slice = threadIdx.x / per;
+  const size_t v = (size_t)blockIdx.x * per + col;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (v < n4) {
+    const float4* src = ws + v;
+    int c = slice;
+    for (; c + 3 * S < nchunks; c += 4 * S) {
+      const float4 q0 = src[(size_t)c * n4], q1 = src[(size_t)(c + S) * n4];
+      const float4 q2 = src[(size_t)(c + 2 * S) * n4], q3 = src[(size_t)(c + 3 * S) * n4];
+      acc.x += (q0.x + q1.x) + (q2.x + q3.x); acc.y += (q0.y + q1.y) + (q2.y + q3.y);
+      acc.z += (q0.z + q1.z) + (q2.z + q3.z); acc.w += (q0.w + q1.w) + (q2.w + q3.w);
+    }
+    for (; c < nchunks; c += S) {
+      const float4 q = src[(size_t)c * n4];
+      acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w;
+    }
+  }
+  if (slice > 0) sPart[(slice - 1) * per + col] = acc;
+  __syncthreads();
+  if (slice == 0 && v < n4) {
+    for (int k = 0; k < S - 1; ++k) { const float4 q = sPart[k * per + col]; acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w; }
+    float4 d = dw[v];
+    d.x += acc.x; d.y += acc.y; d.z += acc.z; d.w += acc.w;
+    dw[v] = d;
+  }
+  if (blockIdx.x == 0 && db != nullptr) {
+    for (int co = threadIdx.x; co < F; co += 256) {
+      float t = 0.f;
+      for (int c = 0; c < nchunks; ++c) t += ws_db[(size_t)c * F + co];
+      db[co] += t;
+    }
+  }
+}
+
+static int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
+
+// Plans the kernel above for a layer; returns the dynamic LDS bytes (0 = not supported here) and fills the geometry.
+static int da_wgrad_plan(DaWgArgs& a, const int* spans) {
+  const int C = a.C, F = a.F;
+  if (!spans || !a.row_lo || (C % 32) != 0 || (F % 16) != 0) return 0;
+  const int nq = C / 8;
+  if ((nq & (nq - 1)) || C > 256 || (a.W & (a.W - 1))) return 0;
+  a.w_sh = ilog2(a.W);
+  a.FB = F > 128 ? 128 : F;
+  if ((F % a.FB) != 0 || (a.FB & (a.FB - 1))) return 0;
+  a.nfblk = F / a.FB;
+  a.nq_sh = ilog2(nq); a.nqy_sh = ilog2(a.FB / 8); a.cif_sh = ilog2(C / 16); a.cof_sh = ilog2(a.FB / 16);
+  int hook_level = -1;
+  if (const char* e = getenv("HDRSKY_DA_WG_GROUP")) hook_level = atoi(e);
+  const int* row_lo_base = a.row_lo;
+  for (int level = 4; level >= 0; --level) {      // the largest group that fits: fewest partial slabs
+    const int G = 1 << level, groups = cdiv(a.tiles_x, G), src_rows = spans[level];
+    if (hook_level >= 0 && level != hook_level) continue;
+    if (level > 0 && G >= 2 * a.tiles_x) continue;                  // (no point in groups beyond the sample)
+    if (src_rows <= 0 || (size_t)src_rows * a.W > 65535) continue;
+    const int region = src_rows * a.W * C * 2;
+    const int grp_rows = (G * 64) / a.W + 2;
+    const int so = roundup(grp_rows * a.k2 * 20 + a.k2 * 4, 16);
+    for (int tpr = a.k2 < 8 ? a.k2 : 8; tpr >= 1; --tpr) {
+      const int nfr = tpr * (C / 16) * (a.FB / 16);
+      if (nfr > 16 * 8 || 64 * tpr > 2 * 512) continue;
+      const int RA = tpr * C * 2 + 16, RY = a.FB * 2 + 16;
+      const int abytes = 2 * 64 * RA, ybytes = 2 * 64 * RY, tb = 2 * 64 * tpr * 24;
+      if (abytes + ybytes + tb + so + region > 156 * 1024) continue;   // + 4 KB of static LDS (bias sums)
+      a.tpr = tpr; a.nrounds = cdiv(a.k2, tpr); a.nfr = nfr;
+      a.RA = RA; a.RY = RY; a.y_off = abytes; a.tb_off = abytes + ybytes; a.so_off = a.tb_off + tb; a.reg_off = a.so_off + so;
+      a.src_rows = src_rows; a.grp_tiles = G; a.groups_x = groups; a.grp_rows = grp_rows; a.rt_cap = grp_rows * a.k2;
+      a.row_lo = row_lo_base + (size_t)level * a.tiles_x;
+      int nsplit = cdiv(256, a.B * groups * a.nfblk);     // rounds dealt to enough workgroups to fill the chip, evenly
+      if (nsplit > a.nrounds) nsplit = a.nrounds;
+      if (nsplit < 1) nsplit = 1;
+      a.nsplit = cdiv(a.nrounds, cdiv(a.nrounds, nsplit));
+      return abytes + ybytes + tb + so + region;
+    }
+  }
+  return 0;
+}
+
 static int da_gs_launch(bool scatter, const float* src, const float* offs, int B, int H, int W, int C, int ksize, float* dst,
                         void* stream) {
   if (!src || !offs || !dst || (ksize & 1) == 0 || (C & 7)) return HDRSKY_EINVAL;
@@ -707,7 +1112,7 @@ int hdrsky_da_offsets(int h, int w, int ksize, int dilation_rate, int skydome, f
 
 // y[B,H,W,Cout] = DA-conv(x[B,H,W,Cin]) + bias; weights packed with hdrsky_conv_pack_weights(w, k, k, Cin, Cout, 0, ..)
 // from the reference's [k*k*Cin, Cout] kernel (same memory order as HWIO); offs = device copy of hdrsky_da_offsets.
-int hdrsky_da_conv_stats_nparts(int H, int W) { return (H > 0 && W > 0) ? cdiv(H * W, 64) : 0; }
+int hdrsky_da_conv_stats_nparts(int H, int W) { return (H > 0 && W > 0) ? cdiv(H * W, 32) : 0; }
 
 int hdrsky_da_conv2d_fwd(const float* x, const void* w_hi, const void* w_lo, const float* bias, const float* offs,
                          const int* row_lo, const int* spans, int B, int H, int W, int Cin, int Cout, int ksize, int compute,
@@ -726,7 +1131,7 @@ int hdrsky_da_conv2d_fwd(const float* x, const void* w_hi, const void* w_lo, con
   // workgroup: 64 pixels x 128 filters (8 waves) when the layer has more than 64 filters, else 64 filters (4 waves)
   const int nwv = Cout > 64 ? 8 : 4;
   a.cin32 = Cin / 32; a.nblocks = cdiv(Cout, nwv * 16); a.tiles_x = cdiv(H * W, 64);
-  a.row_lo = row_lo;
+  a.row_lo = row_lo; a.nparts = cdiv(H * W, 32);
   if (!precise) {    // the source rows of a tile staged once in LDS (da_region_kernel) when the caller knows their span
     a.nblocks = cdiv(Cout, 128);
     if (const int lds_r = da_region_plan(a, Cin, 8, 4, spans, B)) return da_region_launch<8, 4>(a, B * a.groups_x * a.nblocks, lds_r, stream);
@@ -858,6 +1263,62 @@ int hdrsky_da_gather(const float* x, const float* offs, int B, int H, int W, int
 // dx[B,H,W,C] += transpose of the gather applied to dG[B,H,W,k*k*C] (fp32 atomics: zero dx first)
 int hdrsky_da_scatter(const float* dG, const float* offs, int B, int H, int W, int C, int ksize, float* dx, void* stream) {
   return da_gs_launch(true, dG, offs, B, H, W, C, ksize, dx, stream);
+}
+
+// Kernel gradient of the distortion-aware conv with the region gather (BF16 mode): dw [k*k*C, F] += G(x)^T dy,
+// db [F] += column sums of dy (db may be NULL).  offs = device offsets, row_lo / spans as for hdrsky_da_conv2d_fwd.
+// ws: hdrsky_da_conv2d_wgrad_ws_bytes(...) bytes of device scratch (partial slabs per (sample, tile group)).
+// Returns HDRSKY_EUNSUPPORTED when the layer does not fit (callers then use hdrsky_conv2d_wgrad_multi's da_* job).
+static int da_wgrad_setup(DaWgArgs& a, const int* row_lo, const int* spans, int B, int H, int W, int C, int F, int ksize) {
+  a = DaWgArgs{};
+  a.row_lo = row_lo; a.B = B; a.H = H; a.W = W; a.C = C; a.F = F; a.ksize = ksize; a.k2 = ksize * ksize;
+  a.pad = ksize > 1 ? (ksize - 1) / 2 : 0;
+  a.in_h = H + (ksize > 1 ? ksize - 1 : 0); a.in_w = W + (ksize > 1 ? ksize - 1 : 0);
+  a.tiles_x = cdiv(H * W, 64);
+  if (B <= 0 || H <= 0 || W <= 0 || (ksize & 1) == 0 || ksize > 7) return 0;
+  return da_wgrad_plan(a, spans);
+}
+
+size_t hdrsky_da_conv2d_wgrad_ws_bytes(const int* row_lo, const int* spans, int B, int H, int W, int C, int F, int ksize) {
+  DaWgArgs a;
+  if (!da_wgrad_setup(a, row_lo, spans, B, H, W, C, F, ksize)) return 0;
+  const size_t chunks = (size_t)B * a.groups_x;
+  return (chunks * a.k2 * C * F + chunks * F) * sizeof(float);
+}
+
+int hdrsky_da_conv2d_wgrad(const float* x, const void* dy, int dy_bf16, const float* offs, const int* row_lo, const int* spans,
+                           int B, int H, int W, int C, int F, int ksize, float* dw, float* db, void* ws, size_t ws_bytes,
+                           void* stream) {
+  if (!x || !dy || !offs || !dw || !ws) return HDRSKY_EINVAL;
+  DaWgArgs a;
+  const int lds = da_wgrad_setup(a, row_lo, spans, B, H, W, C, F, ksize);
+  if (!lds) return HDRSKY_EUNSUPPORTED;
+  const size_t chunks = (size_t)B * a.groups_x, slab = (size_t)a.k2 * C * F;
+  if (ws_bytes < (chunks * slab + chunks * F) * sizeof(float)) return HDRSKY_EINVAL;
+  a.x = x; a.dy = dy; a.dy_bf16 = dy_bf16; a.offs = offs;
+  a.ws = (float*)ws; a.ws_db = db ? (float*)ws + chunks * slab : nullptr;
+  const int grid = B * a.groups_x * a.nsplit * a.nfblk;
+  const int nfr_wave = cdiv(a.nfr, 8);
+#define HDRSKY_DAWG(NFR_)                                                                                          \
+  {                                                                                                               \
+    auto k = da_wgrad_region_kernel<NFR_>;                                                                        \
+    static bool set = false;                                                                                      \
+    if (!set) {                                                                                                   \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                              156 * 1024) != hipSuccess) return HDRSKY_ELAUNCH;                                   \
+      set = true;                                                                                                 \
+    }                                                                                                             \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, (hipStream_t)stream, a);                                    \
+  }
+  if (nfr_wave <= 4) HDRSKY_DAWG(4) else if (nfr_wave <= 8) HDRSKY_DAWG(8) else HDRSKY_DAWG(16)
+#undef HDRSKY_DAWG
+  HDRSKY_CHECK_LAUNCH();
+  const size_t n4 = slab / 4;
+  const int S = chunks >= 64 ? 16 : 4, per = 256 / S;
+  hipLaunchKernelGGL(da_wgrad_reduce_kernel, dim3((unsigned)((n4 + per - 1) / per)), dim3(256), 0, (hipStream_t)stream,
+                     (const float4*)ws, (int)chunks, n4, (float4*)dw, a.ws_db, F, db, S);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
 }
 
 }  // extern "C"

@@ -232,6 +232,26 @@ def da_wgrad_job(x, dy, ksize, offs, dw, db=None, compute=BF16):
     return (d, x, dy, tabs, dw, db, (offs, ksize, C))
 
 
+def _da_wgrad_region(job):
+    """Kernel gradient of one distortion-aware layer through hdrsky_da_conv2d_wgrad (the tile group's source rows staged in
+    LDS; BF16 mode, offsets from da_offsets_device).  False: not applicable here - the job stays in the generic launch."""
+    d, x, dy, _, dw, db, (offs, ksize, C) = job
+    rows = getattr(offs, "da_rows", None)
+    if rows is None or d.compute != BF16 or C > int(os.environ.get("HDRSKY_DA_WGRAD_REGION_MAXC", "64")):
+        return False      # (wide layers: measured inside the training step, the grouped generic launch is no slower)
+    B, H, W, _ = x.shape
+    F = dy.shape[-1]
+    lib = L.load()
+    row_lo, spans = rows[0].data_ptr(), rows[1].ctypes.data
+    nbytes = int(lib.hdrsky_da_conv2d_wgrad_ws_bytes(row_lo, spans, B, H, W, C, F, ksize))
+    if nbytes <= 0:
+        return False
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    L.check(lib.hdrsky_da_conv2d_wgrad(_p(x), _p(dy), int(dy.dtype == torch.bfloat16), _p(offs), row_lo, spans, B, H, W, C, F,
+                                       ksize, _p(dw), _p(db), _p(ws), nbytes, _stream()), "da_conv2d_wgrad")
+    return True
+
+
 def wgrad_job(x, dy, KH, KW, dw, db=None, stride=1, same=True, upsample=1, xf: Optional[InXf] = None, compute=BF16):
     """One entry for conv2d_wgrad_multi: dw [KH,KW,Cin,Cout] (+= ; must hold valid values, e.g. zeros), db [Cout] or None.
     x / dy may be bf16 tensors (the final activations / gradients of the sample-resident conv chain; no operand transform).
@@ -258,6 +278,8 @@ def conv2d_wgrad_multi(jobs, deterministic=True):
     """Weight gradients of several independent conv layers in as few launches as the library can manage.
     deterministic (default): the split-K partials go through a scratch buffer and are added in a fixed order - the
     gradients are bit-reproducible; False: fp32 atomics straight into dw (no scratch, arrival-order summation)."""
+    if deterministic and os.environ.get("HDRSKY_DA_WGRAD_REGION", "1") != "0":
+        jobs = [job for job in jobs if not (len(job) > 6 and _da_wgrad_region(job))]
     if not jobs:
         return
     arr = (L.WgradJob * len(jobs))()

@@ -413,6 +413,16 @@ int hdrsky_da_sample_table(const float* offs, int H, int W, int ksize, int* idx,
 int hdrsky_da_conv2d_dgrad(const float* dy, const void* wT_hi, const void* wT_lo, const int* gidx, const float* gw,
                            const int* row_lo, const int* spans, int B, int H, int W, int F, int C, int ksize, int compute, float* dx,
                            void* stream);
+/* Kernel gradient of the distortion-aware conv (tape through distortion_aware_ops.py:62-121) with the gather taken from LDS
+ * (BF16 mode): dw [k*k*C, F] += G(x)^T dy, db [F] += column sums of dy (db may be NULL); the [B,H,W,k*k,C] operand never
+ * exists.  dy fp32 or (dy_bf16) bf16; offs = device offsets; row_lo / spans as for hdrsky_da_conv2d_fwd.  A workgroup
+ * stages the source rows of a group of tiles of one sample once and walks (taps, tiles); partial slabs per (sample, group)
+ * in ws (hdrsky_da_conv2d_wgrad_ws_bytes bytes; 0 = layer not supported here) are added to dw by a second launch in a
+ * fixed order: deterministic.  HDRSKY_EUNSUPPORTED: use hdrsky_conv2d_wgrad_multi with the job's da_* fields instead. */
+size_t hdrsky_da_conv2d_wgrad_ws_bytes(const int* row_lo, const int* spans, int B, int H, int W, int C, int F, int ksize); /* [host] */
+int hdrsky_da_conv2d_wgrad(const float* x, const void* dy, int dy_bf16, const float* offs, const int* row_lo, const int* spans,
+                           int B, int H, int W, int C, int F, int ksize, float* dw, float* db, void* ws, size_t ws_bytes,
+                           void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Sample-resident 3x3 convolution with the InstanceNormalization around it fused in (csrc/res_conv.hip).

@@ -207,9 +207,17 @@ def test_da_region_variant(dev, k, shape, monkeypatch):
         assert F > 128
         dx_g = None
     monkeypatch.setenv("HDRSKY_DA_REGION", "2")
+    monkeypatch.setenv("HDRSKY_DA_TM", "64")
     y_r, st = K.da_conv2d(d(x), pw, d(bias), offs_r, K.BF16, want_stats=True)
     dx_r = K.da_conv2d_dgrad(d(dy), pwT, table, k, K.BF16)
+    monkeypatch.setenv("HDRSKY_DA_TM", "32")        # 32-pixel tiles (what under-filled launches use): the same sums
+    y_32, st_32 = K.da_conv2d(d(x), pw, d(bias), offs_r, K.BF16, want_stats=True)
+    dx_32 = K.da_conv2d_dgrad(d(dy), pwT, table, k, K.BF16)
+    monkeypatch.delenv("HDRSKY_DA_TM")
+    y_auto = K.da_conv2d(d(x), pw, d(bias), offs_r, K.BF16)
     monkeypatch.delenv("HDRSKY_DA_REGION")
+    assert torch.equal(y_r, y_32) and torch.equal(dx_r, dx_32) and torch.equal(y_auto, y_r)
+    assert_close(st_32.part.sum(1), st.part.sum(1), 1e-5, "statistics, 32- vs 64-pixel tiles")
     assert_close_bf16(y_r, ref, "da conv, region"); assert_close_bf16(dx_r, rdx, "da dgrad, region")
     # the two gathers differ only by the bf16 rounding of the sources before the blend
     for a, b, what in ((y_r, y_g, "fwd"), (dx_r, dx_g, "dgrad")):
@@ -222,3 +230,59 @@ def test_da_region_variant(dev, k, shape, monkeypatch):
     yr = y_r.reshape(B, -1, F).double()
     assert_close(s1, yr.sum(1), 1e-4, "region stats sum"); assert_close(s2, (yr * yr).sum(1), 1e-4, "region stats sumsq")
     assert torch.equal(y_r, K.da_conv2d(d(x), pw, d(bias), offs_r, K.BF16))      # repeatable
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,shape", [(3, (2, 8, 32, 128, 128)), (7, (2, 32, 128, 32, 32)), (5, (3, 16, 64, 64, 64)),
+                                     (3, (2, 4, 16, 256, 256)), (3, (2, 32, 128, 64, 32)), (3, (2, 16, 16, 32, 64)),
+                                     (5, (1, 16, 64, 32, 64)), (3, (2, 8, 32, 64, 128)), (3, (33, 8, 32, 128, 128))])
+def test_da_region_kernel_gradient(dev, k, shape, monkeypatch):
+    """hdrsky_da_conv2d_wgrad (BF16 mode, offsets from da_offsets_device): the gather of the kernel gradient taken from the
+    tile group's source rows in LDS - against the oracle, against the global-memory gather of the generic weight-gradient
+    launch, accumulation into dw / db, bit-identical repeats, every tile-group level that fits."""
+    K = pkg("kernels"); L = pkg("_lib")
+    B, H, W, C, F = shape
+    rng = np.random.default_rng(k * 7 + C + H + B)
+    x = rng.standard_normal((B, H, W, C)).astype(np.float32)
+    dy = rng.standard_normal((B, H, W, F)).astype(np.float32)
+    kern = np.zeros((k * k * C, F), np.float32)
+    d = lambda a: torch.from_numpy(a).to(dev)
+    if B <= 3:
+        _, rdk, rdb = da_ops.da_conv2d_grads(x, kern, da_ops.distortion(H, W, k), dy, k=k)
+    offs_r = K.da_offsets_device(H, W, k, 1, True, dev)
+    xd, dyd = d(x), d(dy)
+    monkeypatch.setenv("HDRSKY_DA_WGRAD_REGION_MAXC", "256")      # (by default only layers of <= 64 channels take this path)
+
+    def run(**env):
+        for kk, v in env.items():
+            monkeypatch.setenv(kk, v)
+        dw = torch.zeros(k * k * C, F, device=dev); db = torch.zeros(F, device=dev)
+        K.conv2d_wgrad_multi([K.da_wgrad_job(xd, dyd, k, offs_r, dw, db, K.BF16)])
+        for kk in env:
+            monkeypatch.delenv(kk)
+        return dw, db
+
+    dw_g, db_g = run(HDRSKY_DA_WGRAD_REGION="0")
+    dw_r, db_r = run()
+    nbytes = int(L.load().hdrsky_da_conv2d_wgrad_ws_bytes(offs_r.da_rows[0].data_ptr(), offs_r.da_rows[1].ctypes.data, B, H, W, C, F, k))
+    assert nbytes > 0                                   # the region kernel is what ran
+    if B <= 3:
+        assert_close_bf16(dw_r, rdk, "da kernel gradient, region"); assert_close(db_r, rdb, 1e-4, "da bias gradient, region")
+    err = (dw_r - dw_g).abs().max().item() / dw_g.abs().max().item()
+    assert err < 1.5e-2, err
+    assert_close(db_r, db_g, 1e-5, "bias gradient vs generic launch")
+    dw2, db2 = run()
+    assert torch.equal(dw_r, dw2) and torch.equal(db_r, db2)
+    K.conv2d_wgrad_multi([K.da_wgrad_job(xd, dyd, k, offs_r, dw2, db2, K.BF16)])          # accumulates
+    assert_close(dw2, 2 * dw_r, 1e-6, "accumulation"); assert_close(db2, 2 * db_r, 1e-6, "bias accumulation")
+    for level in range(5):
+        if (1 << level) >= 2 * ((H * W + 63) // 64) and level > 0:
+            break
+        monkeypatch.setenv("HDRSKY_DA_WG_GROUP", str(level))
+        fits = int(L.load().hdrsky_da_conv2d_wgrad_ws_bytes(offs_r.da_rows[0].data_ptr(), offs_r.da_rows[1].ctypes.data, B, H, W, C, F, k))
+        monkeypatch.delenv("HDRSKY_DA_WG_GROUP")
+        if not fits:
+            continue
+        dw_l, _ = run(HDRSKY_DA_WG_GROUP=str(level))
+        e2 = (dw_l - dw_r).abs().max().item() / dw_r.abs().max().item()
+        assert e2 < 1e-5, (level, e2)
