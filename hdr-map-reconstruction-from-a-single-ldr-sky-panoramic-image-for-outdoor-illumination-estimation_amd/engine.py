@@ -295,10 +295,11 @@ def encode(nets, ldr, compute, distortion_aware=False, dilation_rate=1):
     return x
 
 
-def decode(nets, res_out, sfx, residual, compute, distortion_aware=False):
-    """generator.model.sky_decode / sun_decode (generator.py:110-156): `residual` is the LDR input (sky)
-    or the log-compressed sun radiance (sun).  distortion_aware ("decoders" in da_parts): the two resize-deconvolutions are
-    distortion_aware_ops.deconv2d (:272-542) - bilinear 2x resize, then the distortion-aware 3x3 conv at the output size."""
+def decode_head(nets, res_out, sfx, compute, distortion_aware=False):
+    """The two resize-deconvolutions of generator.model.sky_decode / sun_decode (generator.py:110-156) - all of a decoder that
+    does not need the residual input of its last layer: (raw output of the second one, its InstanceNorm transform).
+    distortion_aware ("decoders" in da_parts): they are distortion_aware_ops.deconv2d (:272-542) - bilinear 2x resize, then
+    the distortion-aware 3x3 conv at the output size."""
     g, pk = nets.gen, nets.pk
     if "decoders" in da_parts(distortion_aware):
         u3 = K.up2x(res_out)
@@ -307,16 +308,26 @@ def decode(nets, res_out, sfx, residual, compute, distortion_aware=False):
         u2 = K.up2x(K.norm_apply(r3, s3, g["norm3_%s.gamma" % sfx], g["norm3_%s.beta" % sfx], slope=0.1))
         r2, s2 = K.da_conv2d(u2, pk["gen.conv2_" + sfx], g["conv2_%s.bias_deconv2d" % sfx], nets.da_offsets(u2.shape[1], u2.shape[2]),
                              compute, want_stats=True)
-        y, _ = K.conv2d(r2, pk["gen.conv1_" + sfx], g["conv1_%s.b" % sfx], compute=compute,
-                        xf=_in_xf(s2, g, "norm2_" + sfx, 0.1), out_slope=0.1, residual=residual, final_relu=True)
-        return y
+        return r2, _in_xf(s2, g, "norm2_" + sfx, 0.1)
     r3, s3 = K.conv2d(res_out, pk["gen.conv3_" + sfx], g["conv3_%s.bias_deconv2d" % sfx], upsample=2, want_stats=True,
                       compute=compute)
     r2, s2 = K.conv2d(r3, pk["gen.conv2_" + sfx], g["conv2_%s.bias_deconv2d" % sfx], upsample=2, want_stats=True,
                       compute=compute, xf=_in_xf(s3, g, "norm3_" + sfx, 0.1))
-    y, _ = K.conv2d(r2, pk["gen.conv1_" + sfx], g["conv1_%s.b" % sfx], compute=compute,
-                    xf=_in_xf(s2, g, "norm2_" + sfx, 0.1), out_slope=0.1, residual=residual, final_relu=True)
+    return r2, _in_xf(s2, g, "norm2_" + sfx, 0.1)
+
+
+def decode_tail(nets, head, sfx, residual, compute):
+    """The decoder's last layer: 7x7 conv + `residual` (the LDR input for the sky, the log-compressed sun radiance for the
+    sun decoder) + ReLU, on decode_head's result."""
+    r2, xf = head
+    y, _ = K.conv2d(r2, nets.pk["gen.conv1_" + sfx], nets.gen["conv1_%s.b" % sfx], compute=compute, xf=xf, out_slope=0.1,
+                    residual=residual, final_relu=True)
     return y
+
+
+def decode(nets, res_out, sfx, residual, compute, distortion_aware=False):
+    """generator.model.sky_decode / sun_decode (generator.py:110-156)."""
+    return decode_tail(nets, decode_head(nets, res_out, sfx, compute, distortion_aware), sfx, residual, compute)
 
 
 def down_stack(x, pk, p, prefix, compute, training=False, bn_eval=None):
@@ -372,8 +383,9 @@ def generator_forward(nets, ldr, pick_src=None, compute=BF16, distortion_aware=F
         rad_lin, rad_gamma, gamma, beta = sun_rad_estimation(nets, ldr, cams, t, compute)
     res_out = encode(nets, ldr, compute, distortion_aware="res" in da)
     sky_gamma = decode(nets, res_out, "f", ldr, compute, da)
+    sun_head = decode_head(nets, res_out, "u", compute, da)      # (only its last layer needs the sun branch's radiance map)
     main.wait_stream(side)
-    sun_gamma = decode(nets, res_out, "u", rad_gamma, compute, da)
+    sun_gamma = decode_tail(nets, sun_head, "u", rad_gamma, compute)
     y_gamma, y_lin, alpha, sky_lin, sun_lin = K.blend(sky_gamma, sun_gamma, THRESHOLD)
     return dict(y_final_lin=y_lin, y_final_gamma=y_gamma, sky_pred_lin=sky_lin, sun_pred_lin=sun_lin, gamma=gamma,
                 beta=beta, alpha_c3=alpha, sunpose_cmf=t["cmf"], sunpose_pred=t["cmf"].reshape(B, H, W, 1),

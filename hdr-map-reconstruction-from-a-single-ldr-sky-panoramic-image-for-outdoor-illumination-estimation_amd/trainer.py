@@ -627,7 +627,10 @@ class Trainer:
                 return fn
             return deco
 
-        def decode(sfx, residual):
+        def decode_head(sfx):
+            """The two resize-deconvolutions of a decoder (generator.py:110-156) - everything that does not need the
+            residual input of its last layer; decode_tail finishes it.  (The sun decoder's residual is the sun-radiance map,
+            the last thing fwd_sun produces: its two deconvolutions run in fwd_enc, while stream 0 would wait for it.)"""
             res_out = T["x"][-1]
             if self.da_dec:       # distortion_aware_ops.deconv2d (:272-542): bilinear 2x resize, then the distortion-aware 3x3
                 c3, c2 = c["gen.conv3_" + sfx], c["gen.conv2_" + sfx]
@@ -636,10 +639,8 @@ class Trainer:
                 u2 = K.up2x(K.norm_apply(d3, s3, w["gen.norm3_%s.gamma" % sfx], w["gen.norm3_%s.beta" % sfx], slope=0.1))
                 d2, s2 = K.da_conv2d(u2, c2.pk, c2.b, self._da(u2.shape[1], u2.shape[2])[0], cp, want_stats=True)
                 xf1 = self._inxf(s2, "gen.norm2_" + sfx, 0.1)
-                y, _ = c["gen.conv1_" + sfx].fwd(d2, xf1, cp, out_slope=0.1, residual=residual, final_relu=True)
-                T["dec_" + sfx] = (d3, s3, u3, d2, s2, xf1, y, residual, u2)
-                return y
-            if self._deconv_mat():
+                T["dech_" + sfx] = (d3, s3, u3, d2, s2, xf1, u2)
+            elif self._deconv_mat():
                 # single-product mode: the operand of each resize-deconvolution is written once as bf16 (hdrsky_up2x_xf_bf16:
                 # the fused staging's own arithmetic); the plain conv and - later - the plain weight gradient run on it, and
                 # the two decoders share the upsampled encoder output
@@ -650,15 +651,26 @@ class Trainer:
                 u2 = K.up2x_act_bf16(d3, xf2)
                 d2, s2 = K.conv2d(u2, c2.pk, c2.b, compute=cp, want_stats=True)
                 xf1 = self._inxf(s2, "gen.norm2_" + sfx, 0.1)
-                y, _ = c["gen.conv1_" + sfx].fwd(d2, xf1, cp, out_slope=0.1, residual=residual, final_relu=True)
-                T["dec_" + sfx] = (d3, s3, xf2, d2, s2, xf1, y, residual, u3, u2)
-                return y
-            d3, s3 = c["gen.conv3_" + sfx].fwd(res_out, compute=cp, want_stats=True)
-            xf2 = self._inxf(s3, "gen.norm3_" + sfx, 0.1)
-            d2, s2 = c["gen.conv2_" + sfx].fwd(d3, xf2, cp, want_stats=True)
-            xf1 = self._inxf(s2, "gen.norm2_" + sfx, 0.1)
+                T["dech_" + sfx] = (d3, s3, xf2, d2, s2, xf1, u3, u2)
+            else:
+                d3, s3 = c["gen.conv3_" + sfx].fwd(res_out, compute=cp, want_stats=True)
+                xf2 = self._inxf(s3, "gen.norm3_" + sfx, 0.1)
+                d2, s2 = c["gen.conv2_" + sfx].fwd(d3, xf2, cp, want_stats=True)
+                xf1 = self._inxf(s2, "gen.norm2_" + sfx, 0.1)
+                T["dech_" + sfx] = (d3, s3, xf2, d2, s2, xf1, None, None)
+
+        early_head = os.environ.get("HDRSKY_DEC_HEAD_EARLY", "1") != "0"     # A/B hook
+
+        def decode_tail(sfx, residual):
+            hd = T["dech_" + sfx]
+            d2, xf1 = hd[3], hd[5]
             y, _ = c["gen.conv1_" + sfx].fwd(d2, xf1, cp, out_slope=0.1, residual=residual, final_relu=True)
-            T["dec_" + sfx] = (d3, s3, xf2, d2, s2, xf1, y, residual, None, None)
+            if self.da_dec:
+                d3, s3, u3, d2, s2, xf1, u2 = hd
+                T["dec_" + sfx] = (d3, s3, u3, d2, s2, xf1, y, residual, u2)
+            else:
+                d3, s3, xf2, d2, s2, xf1, u3, u2 = hd
+                T["dec_" + sfx] = (d3, s3, xf2, d2, s2, xf1, y, residual, u3, u2)
             return y
 
         # ------------------------------------------------------------------ forward (train.py:239-299)
@@ -714,7 +726,10 @@ class Trainer:
                 T["x"].append(x)
             if self._deconv_mat() and not self.da_dec:
                 T["u3"] = K.up2x_act_bf16(T["x"][-1])      # the resized encoder output, shared by both decoders
-            T["sky_gamma"] = decode("f", ldr)
+            decode_head("f")
+            T["sky_gamma"] = decode_tail("f", ldr)
+            if early_head:
+                decode_head("u")
 
         @seg("vgg_target", 2)
         def _():
@@ -723,7 +738,9 @@ class Trainer:
         @seg("fwd_blend", 0, ["fwd_sun"])
         def _():
             rad_lin, rad_gamma, gamma, beta = T["rad"]
-            sun_gamma = decode("u", rad_gamma)
+            if not early_head:
+                decode_head("u")
+            sun_gamma = decode_tail("u", rad_gamma)
             y_gamma, y_lin, alpha, sky_lin, sun_lin = K.blend(T["sky_gamma"], sun_gamma, E.THRESHOLD)
             T.update(y_gamma=y_gamma, y_lin=y_lin, alpha=alpha, sun_gamma=sun_gamma, gamma=gamma, beta=beta,
                      rad_gamma=rad_gamma, rad_lin=rad_lin, sky_lin=sky_lin, sun_lin=sun_lin,
@@ -925,7 +942,12 @@ class Trainer:
             T["dx_enc"] = dx
             T["wq_res"] = self._take_wgrads()
 
-        @seg("wg_res", 2, ["bwd_res"])
+        # (stream 1, behind wg_dec: on stream 2 these launches queued behind bwd_sunpose / bwd_sunrad / wg_sunrad and the
+        # step ended 80 us later - per-segment timeline of the captured step, profiles/segment_timeline.py.  Other orders of
+        # the tail that were timed - the sun-radiance backward in front of the sun-pose backward with its weight gradients on
+        # stream 1, the Dense update at the end of stream 2, wg_res behind bwd_enc on stream 0, the discriminator step split
+        # into an early real half and a generated half - all lengthened the step: HDRSKY_WG_RES_STREAM is the A/B hook.)
+        @seg("wg_res", int(os.environ.get("HDRSKY_WG_RES_STREAM", "1")), ["bwd_res"])
         def _():
             K.conv2d_wgrad_multi(T["wq_res"])
 
@@ -979,7 +1001,7 @@ class Trainer:
                 K.rmsprop(self.gs.flat[o:o + n], self.gs.grad[o:o + n], self.gs.ms[o:o + n], self.lr, gscale=self._gscale)
 
         # every gradient is complete here: a data-parallel driver hooks its all-reduce onto this (empty) segment
-        segs.append(("grads_ready", 0, ("disc_step", "wg_dec", "bwd_sunpose", "wg_res"), None))
+        segs.append(("grads_ready", 0, ("disc_step", "wg_dec", "bwd_sunpose", "wg_res", "wg_sunrad"), None))
 
         # ------------------------------------------------------------------ optimizers (train.py:403,406)
         @seg("apply", 0, ["apply_fc"])
