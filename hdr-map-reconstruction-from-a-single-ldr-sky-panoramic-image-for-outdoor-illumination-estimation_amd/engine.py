@@ -63,7 +63,7 @@ class Nets:
         self.sun = _dev(sun_params, self.device) if sun_params is not None else None
         self.pk = {}
         self._da_offs = {}
-        self.side_stream = torch.cuda.Stream(device=self.device)
+        self.side_stream = torch.cuda.Stream(device=self.device)      # (a higher stream priority for the longer sun branch: no effect)
         self.repack_all()
 
     def da_offsets(self, h, w, k=3, dilation_rate=1):
