@@ -33,7 +33,7 @@ struct DaArgs {
   const int* row_lo;
   int src_rows, tb_off, reg_off, nq_sh, grp_tiles, groups_x, so_off, rt_cap, w_sh;
   int tm;                   // pixels per tile of the region kernel (64, or 32 when 64-pixel tiles leave half the chip idle)
-  int nparts;               // statistics slots per sample: one per 32 pixels (a 64-pixel tile fills the even one, zeroes the odd)
+  int nparts;               // statistics slots per sample: one per 64-pixel tile
 };
 
 // Workgroup = NWV waves: a tile of 64 consecutive output pixels of one sample (row-major, so it spans several rows
@@ -259,9 +259,8 @@ __global__ void __launch_bounds__(NWV * 64) da_conv_kernel(const DaArgs a) {
     s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
     s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
     if (kq == 0 && n < a.Cout) {
-      float* dst = a.stats + ((size_t)(b * a.nparts + 2 * tile) * 2) * a.Cout + n;
+      float* dst = a.stats + ((size_t)(b * a.nparts + tile) * 2) * a.Cout + n;
       dst[0] = s1; dst[a.Cout] = s2;
-      if (2 * tile + 1 < a.nparts) { dst[2 * a.Cout] = 0.f; dst[3 * a.Cout] = 0.f; }
     }
   }
 }
@@ -525,10 +524,8 @@ __global__ void __launch_bounds__(NWV * 64) da_region_kernel(const DaArgs a) {
     s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
     s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
     if (kq == 0 && n < a.Cout) {
-      const int slot = TM == 64 ? 2 * tile : tile;
-      float* dst = a.stats + ((size_t)(b * a.nparts + slot) * 2) * a.Cout + n;
+      float* dst = a.stats + ((size_t)(b * a.nparts + tile) * 2) * a.Cout + n;   // (host: statistics only with TM = 64)
       dst[0] = s1; dst[a.Cout] = s2;
-      if (TM == 64 && slot + 1 < a.nparts) { dst[2 * a.Cout] = 0.f; dst[3 * a.Cout] = 0.f; }
     }
   }
   __syncthreads();      // the next tile reuses s_off, the table ring and the A buffers
@@ -551,6 +548,7 @@ static int da_region_plan(DaArgs& a, int C, int nwv, int km, const int* spans, i
   // 32-pixel tiles when 64-pixel tiles would leave half the CUs without a workgroup (the 8x32 / 4x16 maps at batch 32)
   a.tm = (B * a.tiles_x * a.nblocks <= 128 && hook_level <= 0) ? 32 : 64;
   if (const char* e = getenv("HDRSKY_DA_TM")) { const int t = atoi(e); if (t == 32 || t == 64) a.tm = t; }
+  if (a.stats) a.tm = 64;       // the InstanceNorm partials are per 64-pixel tile (one writer per slot)
   if (a.tm == 32) a.tiles_x = cdiv(a.H * a.W, 32);
   a.rt_cap = km == 4 ? (64 / a.W + 2) * a.k2 : 0;              // (row, tap) entries of a tile: 16 + 4 bytes each, + k2 ints
   const int so = km == 4 ? roundup(a.rt_cap * 20 + a.k2 * 4, 16) : 0;
@@ -1112,7 +1110,7 @@ int hdrsky_da_offsets(int h, int w, int ksize, int dilation_rate, int skydome, f
 
 // y[B,H,W,Cout] = DA-conv(x[B,H,W,Cin]) + bias; weights packed with hdrsky_conv_pack_weights(w, k, k, Cin, Cout, 0, ..)
 // from the reference's [k*k*Cin, Cout] kernel (same memory order as HWIO); offs = device copy of hdrsky_da_offsets.
-int hdrsky_da_conv_stats_nparts(int H, int W) { return (H > 0 && W > 0) ? cdiv(H * W, 32) : 0; }
+int hdrsky_da_conv_stats_nparts(int H, int W) { return (H > 0 && W > 0) ? cdiv(H * W, 64) : 0; }
 
 int hdrsky_da_conv2d_fwd(const float* x, const void* w_hi, const void* w_lo, const float* bias, const float* offs,
                          const int* row_lo, const int* spans, int B, int H, int W, int Cin, int Cout, int ksize, int compute,
@@ -1131,7 +1129,7 @@ int hdrsky_da_conv2d_fwd(const float* x, const void* w_hi, const void* w_lo, con
   // workgroup: 64 pixels x 128 filters (8 waves) when the layer has more than 64 filters, else 64 filters (4 waves)
   const int nwv = Cout > 64 ? 8 : 4;
   a.cin32 = Cin / 32; a.nblocks = cdiv(Cout, nwv * 16); a.tiles_x = cdiv(H * W, 64);
-  a.row_lo = row_lo; a.nparts = cdiv(H * W, 32);
+  a.row_lo = row_lo; a.nparts = cdiv(H * W, 64);
   if (!precise) {    // the source rows of a tile staged once in LDS (da_region_kernel) when the caller knows their span
     a.nblocks = cdiv(Cout, 128);
     if (const int lds_r = da_region_plan(a, Cin, 8, 4, spans, B)) return da_region_launch<8, 4>(a, B * a.groups_x * a.nblocks, lds_r, stream);

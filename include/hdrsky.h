@@ -385,8 +385,7 @@ int hdrsky_da_offsets(int h, int w, int ksize, int dilation_rate, int skydome, f
  * GEMM; w_* = hdrsky_conv_pack_weights image of the [k*k*Cin, Cout] kernel viewed as [k,k,Cin,Cout]; offs = device
  * copy of hdrsky_da_offsets(H, W, k, ..).  stride 1, Cin % 32 == 0.  deconv2d.call (:321-395) = hdrsky_up2x_fwd + this.
  * stats_part (optional): [B][hdrsky_da_conv_stats_nparts(H,W)][2][Cout] InstanceNorm partial sums of y in the layout the
- * plain conv emits (one slot per 32 pixels; a 64-pixel tile fills the even slot and zeroes the odd one), for
- * hdrsky_norm_apply - the commented-out distortion-aware res blocks of generator.py:14,18. */
+ * plain conv emits, for hdrsky_norm_apply - the commented-out distortion-aware res blocks of generator.py:14,18. */
 int hdrsky_da_conv_stats_nparts(int H, int W); /* [host] */
 /* row_lo / spans (optional, BF16 mode): the offsets depend on the image row only, so a group of consecutive 64-pixel tiles
  * (row-major) samples a few consecutive source rows.  For group sizes G = 1, 2, 4, 8, 16 (level l = log2 G): row_lo =

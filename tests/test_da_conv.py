@@ -210,14 +210,13 @@ def test_da_region_variant(dev, k, shape, monkeypatch):
     monkeypatch.setenv("HDRSKY_DA_TM", "64")
     y_r, st = K.da_conv2d(d(x), pw, d(bias), offs_r, K.BF16, want_stats=True)
     dx_r = K.da_conv2d_dgrad(d(dy), pwT, table, k, K.BF16)
-    monkeypatch.setenv("HDRSKY_DA_TM", "32")        # 32-pixel tiles (what under-filled launches use): the same sums
-    y_32, st_32 = K.da_conv2d(d(x), pw, d(bias), offs_r, K.BF16, want_stats=True)
+    monkeypatch.setenv("HDRSKY_DA_TM", "32")        # 32-pixel tiles (what under-filled launches without statistics use)
+    y_32 = K.da_conv2d(d(x), pw, d(bias), offs_r, K.BF16)
     dx_32 = K.da_conv2d_dgrad(d(dy), pwT, table, k, K.BF16)
     monkeypatch.delenv("HDRSKY_DA_TM")
     y_auto = K.da_conv2d(d(x), pw, d(bias), offs_r, K.BF16)
     monkeypatch.delenv("HDRSKY_DA_REGION")
     assert torch.equal(y_r, y_32) and torch.equal(dx_r, dx_32) and torch.equal(y_auto, y_r)
-    assert_close(st_32.part.sum(1), st.part.sum(1), 1e-5, "statistics, 32- vs 64-pixel tiles")
     assert_close_bf16(y_r, ref, "da conv, region"); assert_close_bf16(dx_r, rdx, "da dgrad, region")
     # the two gathers differ only by the bf16 rounding of the sources before the blend
     for a, b, what in ((y_r, y_g, "fwd"), (dx_r, dx_g, "dgrad")):
