@@ -477,17 +477,33 @@ __global__ void __launch_bounds__(256) cam_kernel(const float* __restrict__ A, c
   // w_nparts == 0: w is a [B][C] table; > 0: w is a conv statistics tensor [B][nparts][2][C] whose sum plane is
   // reduced here (the GAP of the activation gradient, grad_cam.py:34); < 0: w is the gradient map itself,
   // [B][-nparts pixels][C] (a small one: every block of a sample repeats the sum)
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float t;
-    if (w_nparts == 0) t = w[(size_t)b * C + c];
-    else if (w_nparts < 0) {
-      t = 0.f;
-      for (int p = 0; p < -w_nparts; ++p) t += w[((size_t)b * (-w_nparts) + p) * C + c];
-    } else {
-      t = 0.f;
-      for (int p = 0; p < w_nparts; ++p) t += w[((size_t)(b * w_nparts + p) * 2) * C + c];
+  if (w_nparts < 0) {
+    // the map's pixels are dealt to 256 / (C/4) slices of threads (16-byte loads, 4 channels per thread), then the slices
+    // are added in slice order: one thread per channel walking all pixels was a 256-deep chain of dependent loads (18 us)
+    const int np = -w_nparts, c4n = C >> 2, nsl = 256 / c4n, cq = threadIdx.x % c4n, sl = threadIdx.x / c4n;
+    float* sred = sw + C;                       // [nsl][C]
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = sl; p < np; p += nsl) {
+      const float4 v = *reinterpret_cast<const float4*>(w + ((size_t)b * np + p) * C + cq * 4);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
-    sw[c] = t * w_scale;
+    *reinterpret_cast<float4*>(sred + sl * C + cq * 4) = acc;
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+      float t = 0.f;
+      for (int k = 0; k < nsl; ++k) t += sred[k * C + c];
+      sw[c] = t * w_scale;
+    }
+  } else {
+    for (int c = threadIdx.x; c < C; c += 256) {
+      float t;
+      if (w_nparts == 0) t = w[(size_t)b * C + c];
+      else {
+        t = 0.f;
+        for (int p = 0; p < w_nparts; ++p) t += w[((size_t)(b * w_nparts + p) * 2) * C + c];
+      }
+      sw[c] = t * w_scale;
+    }
   }
   __syncthreads();
   const int c4 = C >> 2;                    // threads per pixel
@@ -840,8 +856,8 @@ int hdrsky_grad_cam(const float* A, const float* w, int w_nparts, float w_scale,
   if (!A || !w || !cam || (C & 3) || C > 256 || (256 % (C / 4)) != 0 || w_nparts < -256) return HDRSKY_EINVAL;
   const int ppb = 256 / (C / 4);
   int gx = cdiv(P, ppb); if (gx > 64) gx = 64;
-  hipLaunchKernelGGL(cam_kernel, dim3(gx, B), dim3(256), C * sizeof(float), (hipStream_t)stream, A, w, w_nparts, w_scale,
-                     P, C, cam);
+  const size_t lds = (C + (w_nparts < 0 ? 1024 : 0)) * sizeof(float);     // + [256 / (C/4) slices][C] partial sums
+  hipLaunchKernelGGL(cam_kernel, dim3(gx, B), dim3(256), lds, (hipStream_t)stream, A, w, w_nparts, w_scale, P, C, cam);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }
