@@ -659,44 +659,53 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB
 // ---------------------------------------------------------------------------------------------------
 // weight packing: fp32 HWIO -> [kstep][4][Npad][8] bf16 (hi / lo planes)
 // ---------------------------------------------------------------------------------------------------
-// one element of the packed image (index i) from the fp32 HWIO filter
-__device__ __forceinline__ void pack_one(const float* __restrict__ w, int KH, int KW, int Cin, int Cout, int Npad,
-                                         int narrow, int flip, int ksteps, size_t i, unsigned short* __restrict__ hi,
-                                         unsigned short* __restrict__ lo) {
-  const int j = i & 7;
-  size_t r = i >> 3;
+// one 16-byte group of the packed image (8 consecutive k of one column; group index g = element index / 8) from the fp32
+// HWIO filter.  A thread per group: the index arithmetic (five divisions) once per 8 elements, the eight source values of
+// adjacent lanes (adjacent columns n) are adjacent in memory, one 16-byte store per plane.  (One element per thread with
+// 2-byte stores took 48 us for the step's 16 M elements, all of it on the serial tail of the step.)
+__device__ __forceinline__ void pack_group(const float* __restrict__ w, int KH, int KW, int Cin, int Cout, int Npad,
+                                           int narrow, int flip, int ksteps, size_t g, unsigned short* __restrict__ hi,
+                                           unsigned short* __restrict__ lo) {
+  size_t r = g;
   const int n = r % Npad; r /= Npad;
   const int q = r & 3;
   const int kp = (int)(r >> 2);
-  int tap, c;
-  if (narrow) { tap = kp * 4 + q; c = j; }
-  else { const int cin32 = Cin >> 5; tap = kp / cin32; c = (kp % cin32) * 32 + q * 8 + j; }
-  float v = 0.f;
-  if (kp < ksteps && tap < KH * KW && c < Cin && n < Cout) {
+  int tap, c0;
+  if (narrow) { tap = kp * 4 + q; c0 = 0; }
+  else { const int cin32 = Cin >> 5; tap = kp / cin32; c0 = (kp % cin32) * 32 + q * 8; }
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = 0.f;
+  if (kp < ksteps && tap < KH * KW && n < Cout) {
     int ky = tap / KW, kx = tap % KW;
     if (flip) {
       // packed filter w'[ky,kx,c(=co of w),n(=ci of w)] = w[KH-1-ky, KW-1-kx, n, c]; w is [KH,KW,Cout',Cin']
       ky = KH - 1 - ky; kx = KW - 1 - kx;
-      v = w[((size_t)(ky * KW + kx) * Cout + n) * Cin + c];
+      const float* src = w + ((size_t)(ky * KW + kx) * Cout + n) * Cin + c0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) if (c0 + j < Cin) v[j] = src[j];
     } else {
-      v = w[((size_t)(ky * KW + kx) * Cin + c) * Cout + n];
+      const float* src = w + ((size_t)(ky * KW + kx) * Cin + c0) * Cout + n;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) if (c0 + j < Cin) v[j] = src[(size_t)j * Cout];
     }
   }
-  const unsigned short h = f2bf(v);
-  hi[i] = h;
-  if (lo != nullptr) lo[i] = f2bf(v - bf2f(h));
+  uint4 h8, l8;
+  if (lo != nullptr) pack8<true>(v, h8, l8); else pack8<false>(v, h8, l8);
+  reinterpret_cast<uint4*>(hi)[g] = h8;
+  if (lo != nullptr) reinterpret_cast<uint4*>(lo)[g] = l8;
 }
 
 __global__ void pack_weights_kernel(const float* __restrict__ w, int KH, int KW, int Cin, int Cout, int Npad,
                                     int narrow, int flip, int ksteps, unsigned short* __restrict__ hi,
                                     unsigned short* __restrict__ lo) {
-  const size_t total = (size_t)(ksteps + 1) * 4 * Npad * 8;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
-    pack_one(w, KH, KW, Cin, Cout, Npad, narrow, flip, ksteps, i, hi, lo);
+  const size_t groups = (size_t)(ksteps + 1) * 4 * Npad;
+  for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < groups; g += (size_t)gridDim.x * blockDim.x)
+    pack_group(w, KH, KW, Cin, Cout, Npad, narrow, flip, ksteps, g, hi, lo);
 }
 
 // Multi-tensor re-pack after an optimizer step: one launch for every conv filter of a network.
-// jobs[j] = {w, hi, lo, KH, KW, Cin, Cout, flip, first_block} (9 x int64); a block packs 2048 elements.
+// jobs[j] = {w, hi, lo, KH, KW, Cin, Cout, flip, first_block} (9 x int64); a block packs 2048 elements = 256 groups.
 __global__ void __launch_bounds__(256) pack_multi_kernel(const long long* __restrict__ jobs, int njobs) {
   int lo_j = 0, hi_j = njobs - 1;
   while (lo_j < hi_j) {  // last job whose first_block <= blockIdx.x
@@ -711,13 +720,9 @@ __global__ void __launch_bounds__(256) pack_multi_kernel(const long long* __rest
   const int narrow = Cin <= 8 ? 1 : 0;
   const int ksteps = narrow ? (KH * KW + 3) / 4 : KH * KW * (Cin / 32);
   const int Npad = (Cout + 63) / 64 * 64;
-  const size_t total = (size_t)(ksteps + 1) * 4 * Npad * 8;
-  const size_t base = (size_t)(blockIdx.x - (int)jb[8]) * 2048;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const size_t i = base + k * 256 + threadIdx.x;
-    if (i < total) pack_one(w, KH, KW, Cin, Cout, Npad, narrow, flip, ksteps, i, hi, lo);
-  }
+  const size_t groups = (size_t)(ksteps + 1) * 4 * Npad;
+  const size_t g = (size_t)(blockIdx.x - (int)jb[8]) * 256 + threadIdx.x;
+  if (g < groups) pack_group(w, KH, KW, Cin, Cout, Npad, narrow, flip, ksteps, g, hi, lo);
 }
 
 int conv_ksteps(int KH, int KW, int Cin) {
