@@ -666,10 +666,22 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB
 __device__ __forceinline__ void pack_group(const float* __restrict__ w, int KH, int KW, int Cin, int Cout, int Npad,
                                            int narrow, int flip, int ksteps, size_t g, unsigned short* __restrict__ hi,
                                            unsigned short* __restrict__ lo) {
-  size_t r = g;
-  const int n = r % Npad; r /= Npad;
-  const int q = r & 3;
-  const int kp = (int)(r >> 2);
+  // thread -> group: columns n fastest for the plain image (the 8 source values of adjacent lanes are adjacent in memory);
+  // for the transpose_flip image the source is contiguous along c, so there the four 8-channel quarters q of a k-step
+  // are the fastest index (four lanes read one 128-byte line) and the destination index is permuted instead
+  int n, q, kp;
+  if (flip) {
+    const size_t per = (size_t)4 * Npad;
+    kp = (int)(g / per);
+    const int gl = (int)(g - (size_t)kp * per);
+    q = gl & 3; n = gl >> 2;
+    g = ((size_t)kp * 4 + q) * Npad + n;
+  } else {
+    size_t r = g;
+    n = r % Npad; r /= Npad;
+    q = r & 3;
+    kp = (int)(r >> 2);
+  }
   int tap, c0;
   if (narrow) { tap = kp * 4 + q; c0 = 0; }
   else { const int cin32 = Cin >> 5; tap = kp / cin32; c0 = (kp % cin32) * 32 + q * 8; }
