@@ -354,9 +354,16 @@ __global__ void __launch_bounds__(256) dgb_reduce_kernel(const long long* __rest
     const int which = i / C, c = i % C;
     float* dst = reinterpret_cast<float*>(e[1 + which]);
     if (dst == nullptr) continue;
-    float acc = 0.f;
-    for (int b = 0; b < B; ++b) acc += part[((size_t)b * 2 + which) * C + c];
-    dst[c] += acc;
+    // eight independent chains (samples b, b+8, ...), combined in a fixed order: one chain over the batch was 32
+    // dependent loads deep - 23 us at the end of each backward segment
+    float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int b = 0;
+    for (; b + 7 < B; b += 8) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a8[k] += part[((size_t)(b + k) * 2 + which) * C + c];
+    }
+    for (int k = 0; b < B; ++b, ++k) a8[k] += part[((size_t)b * 2 + which) * C + c];
+    dst[c] += ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
   }
 }
 
