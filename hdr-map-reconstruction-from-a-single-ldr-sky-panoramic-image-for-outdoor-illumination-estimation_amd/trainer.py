@@ -976,7 +976,9 @@ class Trainer:
         # The two Dense layers hold 50.3 M of the 58.3 M parameters and nothing reads their weights or gradients after
         # bwd_head: their RMSprop update and bf16 re-packing run here, beside the rest of the backward pass, instead of
         # at the end of the step.  (Data-parallel: after the all-reduce of that slice / the all-gather of the operands.)
-        @seg("apply_fc", 1, ["bwd_head", "wg_dense"])
+        # (stream 1, beside the backward chains: at the END of stream 0 or 2, where nothing compute-bound is left to overlap
+        # its HBM stream with, the step is 1.3-1.7 % longer - HDRSKY_APPLY_FC_STREAM is the A/B hook)
+        @seg("apply_fc", int(os.environ.get("HDRSKY_APPLY_FC_STREAM", "1")), ["bwd_head", "wg_dense"])
         def _():
             fc0, fc1 = self.fc_grad_range()
             if self.fused_dense:
