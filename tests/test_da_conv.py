@@ -285,3 +285,28 @@ def test_da_region_kernel_gradient(dev, k, shape, monkeypatch):
         dw_l, _ = run(HDRSKY_DA_WG_GROUP=str(level))
         e2 = (dw_l - dw_r).abs().max().item() / dw_r.abs().max().item()
         assert e2 < 1e-5, (level, e2)
+
+
+@pytest.mark.parametrize("h,w,k", [(8, 32, 3), (32, 128, 7), (16, 64, 5), (4, 16, 3), (16, 16, 3)])
+def test_source_row_table_covers_every_sample(h, w, k):
+    """kernels.da_row_lo (host): for every group size the table's [first row, first row + span) interval contains every
+    source row a group of 64-pixel tiles samples - forward corners (hdrsky_da_sample_table) and a synthetic transposed table
+    with holes (-1 entries) alike; spans grow with the group size and never exceed the map."""
+    K = pkg("kernels")
+    _, idx, wt = K._da_host_table(h, w, k, 1, True)
+    rng = np.random.default_rng(h + k)
+    holes = idx.copy(); holes[rng.random(idx.shape) < 0.3] = -1
+    for table in (idx, holes, np.full_like(idx, -1)):
+        lo, spans = K.da_row_lo(table, w)
+        nt = (h * w + 63) // 64
+        assert lo.shape == (len(K.DA_GROUPS), nt) and spans.shape == (len(K.DA_GROUPS),)
+        assert all(1 <= int(s) <= h for s in spans) and list(spans) == sorted(spans)
+        for l, G in enumerate(K.DA_GROUPS):
+            for g in range((nt + G - 1) // G):
+                rows = table[g * G * 64:(g + 1) * G * 64].ravel()
+                rows = rows[rows >= 0] // w
+                if rows.size:
+                    assert lo[l, g] <= rows.min() and rows.max() < lo[l, g] + spans[l], (l, g)
+    # the sample table's weights: the four bilinear weights of a sample sum to 1 wherever all four corners are inside
+    inside = (idx >= 0).all(-1)
+    assert np.abs(wt[inside].sum(-1) - 1.0).max() < 1e-4
