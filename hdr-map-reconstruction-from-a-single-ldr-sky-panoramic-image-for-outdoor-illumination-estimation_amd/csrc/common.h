@@ -49,6 +49,24 @@ __device__ __forceinline__ void pack8(const float (&v)[8], uint4& hi, uint4& lo)
 
 __device__ __forceinline__ float leaky(float v, float slope) { return v >= 0.f ? v : v * slope; }
 
+// (sum, sum of squares) of one channel over the nparts tile partials of a sample: pp -> the channel's sum in tile 0, tiles
+// 2*C floats apart, the squares C floats behind the sums.  Loads go out eight at a time (independent, all in flight), the
+// additions stay in tile order: bit-identical to the plain loop, without its chain of nparts dependent loads - which sat
+// in the prologue of every kernel that normalises on the fly (64 tiles at 32x128: ~10 us).  Adding in interleaved chains
+// instead would move the statistics by an ulp - enough to flip max-pool arg-max ties in the Grad-CAM sweep.
+__device__ __forceinline__ void in_partial_sums(const float* __restrict__ pp, int nparts, int C, float& s, float& ss) {
+  s = 0.f; ss = 0.f;
+  int p = 0;
+  for (; p + 7 < nparts; p += 8) {
+    float a8[8], q8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { a8[k] = pp[(size_t)(2 * (p + k)) * C]; q8[k] = pp[(size_t)(2 * (p + k) + 1) * C]; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s += a8[k]; ss += q8[k]; }
+  }
+  for (; p < nparts; ++p) { s += pp[(size_t)(2 * p) * C]; ss += pp[(size_t)(2 * p + 1) * C]; }
+}
+
 __device__ __forceinline__ f32x4_t mfma16(const uint4& a, const uint4& b, f32x4_t c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b),
                                                  c, 0, 0, 0);

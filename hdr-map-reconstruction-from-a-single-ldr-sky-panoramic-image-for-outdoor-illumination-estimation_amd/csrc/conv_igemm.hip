@@ -214,12 +214,8 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB
     }
   } else if (a.in_mode == HDRSKY_IN_PARTIALS) {
     for (int c = tid; c < a.Cin; c += NT) {
-      float s = 0.f, ss = 0.f;
-      const float* pp = a.in_part + (size_t)b * a.in_nparts * 2 * a.Cin + c;
-      for (int p = 0; p < a.in_nparts; ++p) {
-        s += pp[(2 * p) * a.Cin];
-        ss += pp[(2 * p + 1) * a.Cin];
-      }
+      float s, ss;
+      in_partial_sums(a.in_part + (size_t)b * a.in_nparts * 2 * a.Cin + c, a.in_nparts, a.Cin, s, ss);
       const float mean = s * a.in_inv_count;
       const float var = fmaxf(ss * a.in_inv_count - mean * mean, 0.f);
       const float inv = a.in_gamma[c] / sqrtf(var + a.in_eps);

@@ -170,10 +170,8 @@ __global__ void __launch_bounds__(NW * 64) conv_wgrad_kernel(const MultiArgs m) 
           sc = a.in_scale[b * a.ss_bstride + cc];
           sh = a.in_shift[b * a.ss_bstride + cc];
         } else if (a.in_mode == HDRSKY_IN_PARTIALS) {
-          float s0 = 0.f, ss = 0.f;
-          const float* pp = a.in_part + (size_t)b * a.in_nparts * 2 * a.Cin + cc;
-#pragma unroll 4
-          for (int k = 0; k < a.in_nparts; ++k) { s0 += pp[(2 * k) * a.Cin]; ss += pp[(2 * k + 1) * a.Cin]; }
+          float s0, ss;
+          in_partial_sums(a.in_part + (size_t)b * a.in_nparts * 2 * a.Cin + cc, a.in_nparts, a.Cin, s0, ss);
           const float mean = s0 * a.in_inv_count;
           const float var = fmaxf(ss * a.in_inv_count - mean * mean, 0.f);
           sc = a.in_gamma[cc] / sqrtf(var + a.in_eps);

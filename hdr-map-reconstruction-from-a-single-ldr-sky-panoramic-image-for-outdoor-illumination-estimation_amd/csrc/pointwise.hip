@@ -15,21 +15,8 @@ __device__ __forceinline__ void in_tables_from_partials(const float* __restrict_
                                                         float eps, float* sScale, float* sShift, float* sMean,
                                                         float* sInv) {
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    // the tiles' partials are loaded eight at a time (independent loads in flight) and added in tile order: the sums are
-    // bit-identical to a plain loop, without its chain of nparts dependent loads in front of every element-wise pass
-    // (64 tiles at 32x128: ~10 us).  (Adding them in eight interleaved chains instead moves the statistics by an ulp, which
-    // is enough to flip max-pool arg-max ties in the Grad-CAM sweep - tests/test_forward_gpu.py.)
-    float s = 0.f, ss = 0.f;
-    const float* pp = part + (size_t)b * nparts * 2 * C + c;
-    int p = 0;
-    for (; p + 7 < nparts; p += 8) {
-      float a8[8], q8[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) { a8[k] = pp[(2 * (p + k)) * C]; q8[k] = pp[(2 * (p + k) + 1) * C]; }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) { s += a8[k]; ss += q8[k]; }
-    }
-    for (; p < nparts; ++p) { s += pp[(2 * p) * C]; ss += pp[(2 * p + 1) * C]; }
+    float s, ss;
+    in_partial_sums(part + (size_t)b * nparts * 2 * C + c, nparts, C, s, ss);
     const float mean = s * inv_count;
     const float var = fmaxf(ss * inv_count - mean * mean, 0.f);
     const float rstd = 1.f / sqrtf(var + eps);
@@ -116,9 +103,8 @@ __global__ void in_finalize_kernel(const float* __restrict__ part, int nparts, i
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * C) return;
   const int b = i / C, c = i % C;
-  float s = 0.f, ss = 0.f;
-  const float* pp = part + (size_t)b * nparts * 2 * C + c;
-  for (int p = 0; p < nparts; ++p) { s += pp[(2 * p) * C]; ss += pp[(2 * p + 1) * C]; }
+  float s, ss;
+  in_partial_sums(part + (size_t)b * nparts * 2 * C + c, nparts, C, s, ss);
   const float m = s * inv_count;
   const float var = fmaxf(ss * inv_count - m * m, 0.f);
   const float r = 1.f / sqrtf(var + eps);
@@ -508,8 +494,8 @@ __global__ void __launch_bounds__(256) cam_kernel(const float* __restrict__ A, c
       float t;
       if (w_nparts == 0) t = w[(size_t)b * C + c];
       else {
-        t = 0.f;
-        for (int p = 0; p < w_nparts; ++p) t += w[((size_t)(b * w_nparts + p) * 2) * C + c];
+        float unused;
+        in_partial_sums(w + ((size_t)b * w_nparts * 2) * C + c, w_nparts, C, t, unused);
       }
       sw[c] = t * w_scale;
     }
