@@ -62,6 +62,7 @@ SIGNATURES = {
     "hdrsky_conv2d_wgrad_ws_bytes": (c_size_t, [ctypes.POINTER(WgradJob), c_int]),
     "hdrsky_conv2d_wgrad_multi_det": (c_int, [ctypes.POINTER(WgradJob), c_int, P, c_size_t, P]),
     "hdrsky_norm_apply": (c_int, [P, P, c_int, P, P, c_float, c_float, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "hdrsky_in_affine": (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_float, P, P, P]),
     "hdrsky_in_finalize": (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_float, P, P, P, P, P]),
     "hdrsky_bn_eval_affine": (c_int, [P, P, P, P, c_float, c_int, P, P, P]),
     "hdrsky_norm_act_bwd": (c_int, [P, P, c_int, P, P, c_float, c_float, P, c_int, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, P]),

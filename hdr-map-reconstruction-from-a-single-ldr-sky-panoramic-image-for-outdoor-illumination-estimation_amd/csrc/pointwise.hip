@@ -97,6 +97,24 @@ __global__ void __launch_bounds__(256) norm_apply_kernel(const float* __restrict
 }
 
 // mean / rstd / scale / shift tables [B][C] (needed by backward kernels and host-side checks)
+// scale / shift [B][C] of the fused operand transform, in the arithmetic of the conv prologues (gamma / sqrt(var + eps)):
+// what every workgroup of a consumer launch computes for itself in HDRSKY_IN_PARTIALS mode, once per tensor instead - a
+// 128x512 map has 512 tile partials per sample and a 64-channel layer on it 4096 workgroups (1 GB of L2 reads for tables)
+__global__ void in_affine_kernel(const float* __restrict__ part, int nparts, int B, int C, float inv_count,
+                                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                 float* __restrict__ scale, float* __restrict__ shift) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i % C;
+  float s, ss;
+  in_partial_sums(part + (size_t)b * nparts * 2 * C + c, nparts, C, s, ss);
+  const float mean = s * inv_count;
+  const float var = fmaxf(ss * inv_count - mean * mean, 0.f);
+  const float inv = gamma[c] / sqrtf(var + eps);
+  scale[i] = inv;
+  shift[i] = beta[c] - mean * inv;
+}
+
 __global__ void in_finalize_kernel(const float* __restrict__ part, int nparts, int B, int C, float inv_count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float* mean, float* rstd, float* scale, float* shift) {
@@ -759,6 +777,15 @@ int hdrsky_in_finalize(const float* part, int nparts, int B, int C, int count, c
   if (!part || !gamma || !beta) return HDRSKY_EINVAL;
   hipLaunchKernelGGL(in_finalize_kernel, dim3(cdiv(B * C, 256)), dim3(256), 0, (hipStream_t)stream, part, nparts, B, C,
                      1.f / (float)count, gamma, beta, eps, mean, rstd, scale, shift);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_in_affine(const float* part, int nparts, int B, int C, int count, const float* gamma, const float* beta, float eps,
+                     float* scale, float* shift, void* stream) {
+  if (!part || !gamma || !beta || !scale || !shift || nparts <= 0 || count <= 0) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(in_affine_kernel, dim3(cdiv(B * C, 64)), dim3(64), 0, (hipStream_t)stream, part, nparts, B, C,
+                     1.f / (float)count, gamma, beta, eps, scale, shift);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }

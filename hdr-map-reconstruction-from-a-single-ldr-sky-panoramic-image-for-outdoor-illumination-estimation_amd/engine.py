@@ -123,7 +123,7 @@ class Nets:
 
 
 def _in_xf(stats, p, name, slope):
-    return InXf(mode=L.IN_PARTIALS, slope=slope, stats=stats, gamma=p[name + ".gamma"], beta=p[name + ".beta"])
+    return K.in_xf(stats, p[name + ".gamma"], p[name + ".beta"], slope)
 
 
 def sun3_supported(x, compute):

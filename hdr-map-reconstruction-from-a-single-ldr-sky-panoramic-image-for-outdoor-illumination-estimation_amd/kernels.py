@@ -321,6 +321,23 @@ def norm_apply(x, stats: Stats, gamma, beta, slope=1.0, residual=None, pool=Fals
     return (y, yp) if pool else y
 
 
+INXF_AFFINE_MIN = int(os.environ.get("HDRSKY_INXF_AFFINE_MIN", "64"))
+
+
+def in_xf(stats: Stats, gamma, beta, slope, eps=IN_EPS):
+    """The fused operand transform leaky(InstanceNorm(x)) for the conv / weight-gradient that consumes the raw tensor x:
+    the tile partials themselves (every workgroup of the consumer derives the tables in its prologue) while a sample has
+    few tiles, tables computed once by hdrsky_in_affine (bit-identical) from INXF_AFFINE_MIN tiles per sample on."""
+    B, nparts, _, C = stats.part.shape
+    if nparts < INXF_AFFINE_MIN:
+        return InXf(mode=L.IN_PARTIALS, slope=slope, stats=stats, gamma=gamma, beta=beta, eps=eps)
+    scale = torch.empty((B, C), dtype=torch.float32, device=gamma.device)
+    shift = torch.empty_like(scale)
+    L.check(L.load().hdrsky_in_affine(_p(stats.part), nparts, B, C, stats.count, _p(_f32(gamma, C)), _p(_f32(beta, C)), eps,
+                                      _p(scale), _p(shift), _stream()), "in_affine")
+    return InXf(mode=L.IN_AFFINE, slope=slope, scale=scale, shift=shift)
+
+
 def in_finalize(stats: Stats, gamma, beta, B, C, eps=IN_EPS):
     """(mean, rstd, scale, shift) tables [B,C]."""
     _f32(stats.part, B, stats.nparts, 2, C)

@@ -199,9 +199,11 @@ class Trainer:
             self.fc2.repack(self.gs.w["sun.fc2.kernel"])
 
     # ---- small helpers ------------------------------------------------------------------------------
-    def _inxf(self, stats, name, slope):
+    def _inxf(self, stats, name, slope, partials=False):
         w = self.gs.w
-        return InXf(mode=L.IN_PARTIALS, slope=slope, stats=stats, gamma=w[name + ".gamma"], beta=w[name + ".beta"])
+        if partials:      # consumers that derive the tables themselves (hdrsky_up2x_xf_bf16)
+            return InXf(mode=L.IN_PARTIALS, slope=slope, stats=stats, gamma=w[name + ".gamma"], beta=w[name + ".beta"])
+        return K.in_xf(stats, w[name + ".gamma"], w[name + ".beta"], slope)
 
     # InstanceNorm layers whose (d gamma, d beta) are produced by hdrsky_norm_act_bwd, by the plan segment that
     # differentiates them: their per-sample terms land in persistent tables and one fixed-order launch per segment adds
@@ -647,7 +649,7 @@ class Trainer:
                 c3, c2 = c["gen.conv3_" + sfx], c["gen.conv2_" + sfx]
                 u3 = T["u3"]          # written by fwd_enc, in front of the first decoder
                 d3, s3 = K.conv2d(u3, c3.pk, c3.b, compute=cp, want_stats=True)
-                xf2 = self._inxf(s3, "gen.norm3_" + sfx, 0.1)
+                xf2 = self._inxf(s3, "gen.norm3_" + sfx, 0.1, partials=True)
                 u2 = K.up2x_act_bf16(d3, xf2)
                 d2, s2 = K.conv2d(u2, c2.pk, c2.b, compute=cp, want_stats=True)
                 xf1 = self._inxf(s2, "gen.norm2_" + sfx, 0.1)
