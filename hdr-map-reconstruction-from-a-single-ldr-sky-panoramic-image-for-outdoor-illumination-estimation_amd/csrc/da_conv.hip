@@ -32,6 +32,7 @@ struct DaArgs {
   // number of source rows staged (>= what any group reads); LDS byte offsets of the table ring and of the region
   const int* row_lo;
   int src_rows, tb_off, reg_off, nq_sh, grp_tiles, groups_x, so_off, rt_cap, w_sh;
+  int ncg, cgc, cg32_sh;    // channel groups of the region kernel: count, channels each, log2(cgc / 32)
   int tm;                   // pixels per tile of the region kernel (64, or 32 when 64-pixel tiles leave half the chip idle)
   int nparts;               // statistics slots per sample: one per 64-pixel tile
 };
@@ -281,7 +282,9 @@ __global__ void __launch_bounds__(NWV * 64) da_region_kernel(const DaArgs a) {
   constexpr int EMAX = 2;                                       // CBMAX: 32-channel k-steps per round (register sets)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, lr = lane & 15;
-  const int nq = a.Cin >> 3, nqr = nq * a.tpr, plane = TM + 1, buf_units = nqr * plane;
+  // channel groups: when the rows of a tile do not fit LDS with all channels, the region holds cgc of them at a time and
+  // the rounds run once per group (the accumulators carry over; k-step = tap * Cin/32 + the group's 32-channel block)
+  const int nq = a.cgc >> 3, nqr = nq * a.tpr, plane = TM + 1, buf_units = nqr * plane;
   uint4* sA = reinterpret_cast<uint4*>(smem);
   const int nent = TM * a.tpr;                                  // table entries per round
   unsigned char* sTb = smem + a.tb_off;                         // [2] x { u16 idx[nent][KM], float w[nent][KM] }
@@ -308,17 +311,18 @@ __global__ void __launch_bounds__(NWV * 64) da_region_kernel(const DaArgs a) {
   int4* sRT = reinterpret_cast<int4*>(smem + a.so_off);
   float* sOx = reinterpret_cast<float*>(smem + a.so_off + a.rt_cap * 16);
   int* sKx = reinterpret_cast<int*>(smem + a.so_off + a.rt_cap * 20);
-  // ---- the source rows of this group: a linear fp32 -> bf16 copy -------------------------------------------------
-  {
-    const float* src = a.x + ((size_t)b * npix + (size_t)ylo * a.W) * a.Cin;
+  // ---- the source rows of this group (channels [cg * cgc, (cg + 1) * cgc)): fp32 -> bf16 ---------------------------
+  auto stage_region = [&](int cg) {
+    const float* src = a.x + ((size_t)b * npix + (size_t)ylo * a.W) * a.Cin + cg * a.cgc;
     uint4* dst = reinterpret_cast<uint4*>(smem + a.reg_off);
     const int nunits = regpix * nq;
+    auto addr = [&](int u) { return src + (size_t)(u >> a.nq_sh) * a.Cin + (u & (nq - 1)) * 8; };
     int u = tid;
     for (; u + 3 * NT < nunits; u += 4 * NT) {
       float4 lo[4], hi[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float* pp = src + (size_t)(u + k * NT) * 8;
+        const float* pp = addr(u + k * NT);
         lo[k] = *reinterpret_cast<const float4*>(pp); hi[k] = *reinterpret_cast<const float4*>(pp + 4);
       }
 #pragma unroll
@@ -330,16 +334,17 @@ __global__ void __launch_bounds__(NWV * 64) da_region_kernel(const DaArgs a) {
       }
     }
     for (; u < nunits; u += NT) {
-      const float* pp = src + (size_t)u * 8;
+      const float* pp = addr(u);
       const float4 lo = *reinterpret_cast<const float4*>(pp), hi = *reinterpret_cast<const float4*>(pp + 4);
       const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
       uint4 h8, l8;
       pack8<false>(v, h8, l8);
       dst[u] = h8;
     }
-  }
+  };
+  if (a.ncg == 1) stage_region(0);
   uint4 bch[CBMAX], bnh[CBMAX];
-  const int ksteps = a.k2 * a.cin32, spr = a.tpr * a.cin32;
+  const int cg32 = a.cgc >> 5, spr = a.tpr * cg32;               // 32-channel k-steps of a group / of a round
   const int nitems = TM * nqr;
   for (int tile = grp * a.grp_tiles; tile < tile_end; ++tile) {
   const int p0 = tile * TM;
@@ -361,6 +366,8 @@ __global__ void __launch_bounds__(NWV * 64) da_region_kernel(const DaArgs a) {
     __syncthreads();     // visible to the table writers
   }
 
+  for (int cg = 0; cg < a.ncg; ++cg) {
+  if (a.ncg > 1) stage_region(cg);               // (the barrier behind table 0 below publishes it)
   // ---- the per-round sample table ---------------------------------------------------------------------------------
   int pend_i[KM == 8 ? EMAX : 1][8];
   float pend_w[KM == 8 ? EMAX : 1][8];
@@ -437,7 +444,8 @@ __global__ void __launch_bounds__(NWV * 64) da_region_kernel(const DaArgs a) {
   auto load_b = [&](int rnd) {
 #pragma unroll
     for (int cb = 0; cb < CBMAX; ++cb)
-      if (cb < spr && rnd * spr + cb < ksteps) bnh[cb] = wlh[(size_t)((rnd * spr + cb) * 4) * a.Npad];
+      if (cb < spr && rnd * a.tpr + (cb >> a.cg32_sh) < a.k2)
+        bnh[cb] = wlh[(size_t)(((rnd * a.tpr + (cb >> a.cg32_sh)) * a.cin32 + cg * cg32 + (cb & (cg32 - 1))) * 4) * a.Npad];
   };
 
   table_fetch(0);
@@ -494,7 +502,7 @@ __global__ void __launch_bounds__(NWV * 64) da_region_kernel(const DaArgs a) {
       if (t + 1 < a.nrounds) load_b(t + 1);
 #pragma unroll
       for (int cb = 0; cb < CBMAX; ++cb) {
-        if (cb >= spr || t * spr + cb >= ksteps) break;
+        if (cb >= spr || t * a.tpr + (cb >> a.cg32_sh) >= a.k2) break;
         const uint4 bh = bch[cb];
 #pragma unroll
         for (int mi = 0; mi < MF; ++mi) acc[mi] = mfma16(buf[(cb * 4 + kq) * plane + mi * 16 + lr], bh, acc[mi]);
@@ -503,6 +511,8 @@ __global__ void __launch_bounds__(NWV * 64) da_region_kernel(const DaArgs a) {
       for (int cb = 0; cb < CBMAX; ++cb) bch[cb] = bnh[cb];
     }
   }
+  if (a.ncg > 1) __syncthreads();    // the next channel group overwrites the region, the table ring and the A buffers
+  }   // channel groups
   // ---- epilogue: + bias, store (as da_conv_kernel) --------------------------------------------------------------
   const int n = n0 + wave * 16 + lr;
   float s1 = 0.f, s2 = 0.f;
@@ -542,9 +552,9 @@ static int da_region_plan(DaArgs& a, int C, int nwv, int km, const int* spans, i
   int hook_level = -1;
   if (const char* e = getenv("HDRSKY_DA_REGION")) { if (atoi(e) == 0) return 0; }   // tuning / test hooks
   if (const char* e = getenv("HDRSKY_DA_GROUP")) hook_level = atoi(e);
-  const int nq = C / 8, cin32 = C / 32, nt = nwv * 64;
+  const int nq = C / 8, nt = nwv * 64;
   if ((nq & (nq - 1)) || (a.W & (a.W - 1))) return 0;           // the item / pixel indexing wants powers of two
-  a.nq_sh = __builtin_ctz(nq); a.w_sh = __builtin_ctz(a.W);
+  a.w_sh = __builtin_ctz(a.W);
   // 32-pixel tiles when 64-pixel tiles would leave half the CUs without a workgroup (the 8x32 / 4x16 maps at batch 32)
   a.tm = (B * a.tiles_x * a.nblocks <= 128 && hook_level <= 0) ? 32 : 64;
   if (const char* e = getenv("HDRSKY_DA_TM")) { const int t = atoi(e); if (t == 32 || t == 64) a.tm = t; }
@@ -558,15 +568,23 @@ static int da_region_plan(DaArgs& a, int C, int nwv, int km, const int* spans, i
     const int G = 1 << level, groups = cdiv(a.tiles_x, G), src_rows = spans[level];
     if (level != (hook_level >= 0 ? hook_level : 0)) continue;   // measured: groups of tiles do not pay (see DESIGN), hook only
     if (src_rows <= 0 || (size_t)src_rows * a.W > 65535) continue;   // u16 region pixel indices
-    const int region = src_rows * a.W * C * 2;
-    for (int tpr = a.k2 < 8 ? a.k2 : 8; tpr >= 1; --tpr) {
-      if (tpr * cin32 > 8 || 64 * tpr > 2 * nt) continue;     // filter prefetch registers, table entries per thread
-      const int abytes = 2 * tpr * nq * (a.tm + 1) * 16, tb = 2 * a.tm * tpr * km * 6;
-      if (abytes + tb + so + region > 160 * 1024) continue;
-      a.tpr = tpr; a.nrounds = cdiv(a.k2, tpr);
-      a.tb_off = abytes; a.so_off = abytes + tb; a.reg_off = abytes + tb + so; a.src_rows = src_rows;
-      a.grp_tiles = G; a.groups_x = groups; a.row_lo = row_lo_base + (size_t)level * a.tiles_x;
-      return abytes + tb + so + region;
+    // all channels in the region when they fit; else, for the data gradient, 2 or 4 channel groups (one tile per workgroup
+    // then).  Measured at [8,32,128,128]: data gradient 97 -> 75 us; the forward pass gains nothing from two groups (64 us
+    // either way: twice the tables and barriers), so it keeps da_conv_kernel there.
+    for (int ncg = 1; ncg <= (level == 0 && km == 8 ? 4 : 1); ncg *= 2) {
+      const int cgc = C / ncg, nqg = cgc / 8;
+      if ((C % ncg) != 0 || (cgc % 32) != 0) continue;
+      const int region = src_rows * a.W * cgc * 2;
+      for (int tpr = a.k2 < 8 ? a.k2 : 8; tpr >= 1; --tpr) {
+        if (tpr * (cgc / 32) > 8 || 64 * tpr > 2 * nt) continue;   // filter prefetch registers, table entries per thread
+        const int abytes = 2 * tpr * nqg * (a.tm + 1) * 16, tb = 2 * a.tm * tpr * km * 6;
+        if (abytes + tb + so + region > 160 * 1024) continue;
+        a.tpr = tpr; a.nrounds = cdiv(a.k2, tpr);
+        a.ncg = ncg; a.cgc = cgc; a.cg32_sh = __builtin_ctz(cgc / 32); a.nq_sh = __builtin_ctz(nqg);
+        a.tb_off = abytes; a.so_off = abytes + tb; a.reg_off = abytes + tb + so; a.src_rows = src_rows;
+        a.grp_tiles = G; a.groups_x = groups; a.row_lo = row_lo_base + (size_t)level * a.tiles_x;
+        return abytes + tb + so + region;
+      }
     }
   }
   a.tiles_x = cdiv(a.H * a.W, 64);      // (the caller falls back to da_conv_kernel's 64-pixel tiles)
@@ -593,8 +611,8 @@ static int da_region_launch_(const DaArgs& a, int grid, int lds, void* stream) {
 template <int NWV, int KM>
 static int da_region_launch(const DaArgs& a, int grid, int lds, void* stream) {
   if (a.tm == 32)
-    return a.tpr * a.cin32 <= 4 ? da_region_launch_<NWV, KM, 4, 32>(a, grid, lds, stream) : da_region_launch_<NWV, KM, 8, 32>(a, grid, lds, stream);
-  return a.tpr * a.cin32 <= 4 ? da_region_launch_<NWV, KM, 4, 64>(a, grid, lds, stream) : da_region_launch_<NWV, KM, 8, 64>(a, grid, lds, stream);
+    return a.tpr * (a.cgc / 32) <= 4 ? da_region_launch_<NWV, KM, 4, 32>(a, grid, lds, stream) : da_region_launch_<NWV, KM, 8, 32>(a, grid, lds, stream);
+  return a.tpr * (a.cgc / 32) <= 4 ? da_region_launch_<NWV, KM, 4, 64>(a, grid, lds, stream) : da_region_launch_<NWV, KM, 8, 64>(a, grid, lds, stream);
 }
 
 // ---- backward building blocks ----------------------------------------------------------------------------------

@@ -178,7 +178,8 @@ def test_da_conv_other_kernel_sizes_and_sample_table(dev, k, shape):
 @pytest.mark.gpu
 @pytest.mark.parametrize("k,shape", [(3, (2, 8, 32, 128, 128)), (7, (2, 32, 128, 32, 32)), (5, (2, 16, 64, 64, 64)),
                                      (3, (3, 4, 16, 256, 256)), (3, (2, 32, 128, 64, 32)), (3, (2, 16, 16, 32, 64)),
-                                     (5, (1, 16, 64, 32, 64)), (3, (2, 16, 64, 128, 64))])
+                                     (5, (1, 16, 64, 32, 64)), (3, (2, 16, 64, 128, 64)),
+                                     (3, (1, 32, 128, 64, 128)), (3, (2, 8, 32, 128, 256))])   # (data gradient: two channel groups)
 def test_da_region_variant(dev, k, shape, monkeypatch):
     """BF16 mode with the source-row table (kernels.da_offsets_device / da_transpose_table): the tile's source rows staged
     once in LDS, forward and data gradient, against the oracle and against the global-memory gather.  HDRSKY_DA_REGION=2
@@ -216,7 +217,12 @@ def test_da_region_variant(dev, k, shape, monkeypatch):
     monkeypatch.delenv("HDRSKY_DA_TM")
     y_auto = K.da_conv2d(d(x), pw, d(bias), offs_r, K.BF16)
     monkeypatch.delenv("HDRSKY_DA_REGION")
-    assert torch.equal(y_r, y_32) and torch.equal(dx_r, dx_32) and torch.equal(y_auto, y_r)
+    # (bit-equal unless the two tile sizes split the channels into a different number of region groups - the k-steps are
+    # then accumulated in another order)
+    assert_close(y_32, y_r, 2e-6, "32- vs 64-pixel tiles"); assert_close(dx_32, dx_r, 2e-6, "32- vs 64-pixel tiles, dgrad")
+    assert_close(y_auto, y_r, 2e-6, "default tile size")
+    if C <= 128 and F <= 128 and H * W * max(C, F) <= 8 * 32 * 128:
+        assert torch.equal(y_r, y_32) and torch.equal(dx_r, dx_32)
     assert_close_bf16(y_r, ref, "da conv, region"); assert_close_bf16(dx_r, rdx, "da dgrad, region")
     # the two gathers differ only by the bf16 rounding of the sources before the blend
     for a, b, what in ((y_r, y_g, "fwd"), (dx_r, dx_g, "dgrad")):
@@ -228,7 +234,7 @@ def test_da_region_variant(dev, k, shape, monkeypatch):
     s1 = st.part[:, :, 0].sum(1); s2 = st.part[:, :, 1].sum(1)
     yr = y_r.reshape(B, -1, F).double()
     assert_close(s1, yr.sum(1), 1e-4, "region stats sum"); assert_close(s2, (yr * yr).sum(1), 1e-4, "region stats sumsq")
-    assert torch.equal(y_r, K.da_conv2d(d(x), pw, d(bias), offs_r, K.BF16))      # repeatable
+    assert torch.equal(y_auto, K.da_conv2d(d(x), pw, d(bias), offs_r, K.BF16))      # repeatable
 
 
 @pytest.mark.gpu
