@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(256) norm_apply_kernel(const float* __restrict
 }
 
 // mean / rstd / scale / shift tables [B][C] (needed by backward kernels and host-side checks)
-// scale / shift [B][C] of the fused operand transform, in the arithmetic of the conv prologues (gamma / sqrt(var + eps)):
+// scale / shift [B][C] of the fused operand transform, in the formula of the conv prologues (gamma / sqrt(var + eps)):
 // what every workgroup of a consumer launch computes for itself in HDRSKY_IN_PARTIALS mode, once per tensor instead - a
 // 128x512 map has 512 tile partials per sample and a 64-channel layer on it 4096 workgroups (1 GB of L2 reads for tables)
 __global__ void in_affine_kernel(const float* __restrict__ part, int nparts, int B, int C, float inv_count,

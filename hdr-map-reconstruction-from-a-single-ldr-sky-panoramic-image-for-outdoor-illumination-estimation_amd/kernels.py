@@ -327,7 +327,8 @@ INXF_AFFINE_MIN = int(os.environ.get("HDRSKY_INXF_AFFINE_MIN", "64"))
 def in_xf(stats: Stats, gamma, beta, slope, eps=IN_EPS):
     """The fused operand transform leaky(InstanceNorm(x)) for the conv / weight-gradient that consumes the raw tensor x:
     the tile partials themselves (every workgroup of the consumer derives the tables in its prologue) while a sample has
-    few tiles, tables computed once by hdrsky_in_affine (bit-identical) from INXF_AFFINE_MIN tiles per sample on."""
+    few tiles, tables computed once by hdrsky_in_affine (same formula, equal to an ulp or two) from INXF_AFFINE_MIN tiles per
+    sample on."""
     B, nparts, _, C = stats.part.shape
     if nparts < INXF_AFFINE_MIN:
         return InXf(mode=L.IN_PARTIALS, slope=slope, stats=stats, gamma=gamma, beta=beta, eps=eps)

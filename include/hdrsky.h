@@ -134,8 +134,8 @@ int hdrsky_norm_apply(const float* x, const float* part, int nparts, const float
                       void* stream);
 
 /* scale / shift tables [B][C] of the fused operand transform HDRSKY_IN_PARTIALS describes (InstanceNormalization of a conv
- * output from its tile partials, generator.py:26-35), bit-identical to what the consumer kernels derive in that mode -
- * computed once, for HDRSKY_IN_AFFINE consumers (ss_bstride = C): worth it when a sample has many tiles (128x512 maps: 512),
+ * output from its tile partials, generator.py:26-35), what the consumer kernels derive in that mode (same formula; equal to
+ * an ulp or two) - computed once, for HDRSKY_IN_AFFINE consumers (ss_bstride = C): worth it when a sample has many tiles (128x512 maps: 512),
  * because in PARTIALS mode every workgroup of every consumer launch walks all of them. */
 int hdrsky_in_affine(const float* part, int nparts, int B, int C, int count, const float* gamma, const float* beta, float eps,
                      float* scale, float* shift, void* stream);

@@ -87,6 +87,28 @@ def test_conv_fused_in_stats_residual(dev):
     xf = K.InXf(mode=L.IN_PARTIALS, slope=0.1, stats=st, gamma=d(gam), beta=d(bet))
     y, _ = K.conv2d(r1, p2, d(b2), xf=xf, out_slope=0.1, residual=d(res), final_relu=True, compute=K.BF16X3)
     assert_close(y, ref, 3e-4, "fused consumer")
+    # the tables computed once per tensor (hdrsky_in_affine, what kernels.in_xf switches to from INXF_AFFINE_MIN tiles per
+    # sample on) are what every workgroup derives from the partials, to the last ulp or two (same formula; the compiler
+    # contracts the multiply-adds of each kernel its own way): forward and weight gradient agree to fp32 round-off
+    import importlib
+    Kmod = importlib.import_module(K.__name__)
+    saved = Kmod.INXF_AFFINE_MIN
+    try:
+        Kmod.INXF_AFFINE_MIN = 1
+        xa = K.in_xf(st, d(gam), d(bet), 0.1)
+        Kmod.INXF_AFFINE_MIN = 1 << 30
+        xp = K.in_xf(st, d(gam), d(bet), 0.1)
+    finally:
+        Kmod.INXF_AFFINE_MIN = saved
+    assert xa.mode == L.IN_AFFINE and xp.mode == L.IN_PARTIALS
+    for cp in (K.BF16X3, K.BF16):
+        ya, _ = K.conv2d(r1, p2, d(b2), xf=xa, out_slope=0.1, residual=d(res), final_relu=True, compute=cp)
+        yp, _ = K.conv2d(r1, p2, d(b2), xf=xp, out_slope=0.1, residual=d(res), final_relu=True, compute=cp)
+        tol = 2e-6 if cp == K.BF16X3 else 4e-3      # (bf16 operands: an ulp of the table can move a rounding boundary)
+        assert_close(ya, yp, tol, "affine tables vs partials, forward")
+        dy = torch.randn_like(ya)
+        ga = K.conv2d_wgrad(r1, dy, 3, 3, xf=xa, compute=cp); gp = K.conv2d_wgrad(r1, dy, 3, 3, xf=xp, compute=cp)
+        assert_close(ga[0], gp[0], tol, "affine tables vs partials, weight gradient"); assert torch.equal(ga[1], gp[1])
 
 
 def test_conv_dgrad_via_flipped_filter(dev):
