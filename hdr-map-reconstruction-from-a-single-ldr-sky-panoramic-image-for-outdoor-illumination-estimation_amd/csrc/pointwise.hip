@@ -100,19 +100,27 @@ __global__ void __launch_bounds__(256) norm_apply_kernel(const float* __restrict
 // scale / shift [B][C] of the fused operand transform, in the formula of the conv prologues (gamma / sqrt(var + eps)):
 // what every workgroup of a consumer launch computes for itself in HDRSKY_IN_PARTIALS mode, once per tensor instead - a
 // 128x512 map has 512 tile partials per sample and a 64-channel layer on it 4096 workgroups (1 GB of L2 reads for tables)
-__global__ void in_affine_kernel(const float* __restrict__ part, int nparts, int B, int C, float inv_count,
-                                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                 float* __restrict__ scale, float* __restrict__ shift) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * C) return;
-  const int b = i / C, c = i % C;
-  float s, ss;
-  in_partial_sums(part + (size_t)b * nparts * 2 * C + c, nparts, C, s, ss);
+__global__ void __launch_bounds__(256) in_affine_kernel(const float* __restrict__ part, int nparts, int B, int C, float inv_count,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float eps, float* __restrict__ scale, float* __restrict__ shift) {
+  // block = (sample, 32 channels) x 8 slices of the tile range: slice q adds the tiles [q * per, (q + 1) * per) in order
+  // (loads eight at a time), then the slices are added in slice order - a fixed order
+  __shared__ float sS[8][32], sQ[8][32];
+  const int cb = C / 32 + ((C % 32) ? 1 : 0);
+  const int b = blockIdx.x / cb, c = (blockIdx.x % cb) * 32 + (threadIdx.x & 31), q = threadIdx.x >> 5;
+  const int per = (nparts + 7) / 8, p0 = q * per, np = max(0, min(per, nparts - p0));
+  float s = 0.f, ss = 0.f;
+  if (c < C && np > 0) in_partial_sums(part + ((size_t)b * nparts + p0) * 2 * C + c, np, C, s, ss);
+  sS[q][threadIdx.x & 31] = s; sQ[q][threadIdx.x & 31] = ss;
+  __syncthreads();
+  if (q != 0 || c >= C) return;
+#pragma unroll
+  for (int k = 1; k < 8; ++k) { s += sS[k][threadIdx.x]; ss += sQ[k][threadIdx.x]; }
   const float mean = s * inv_count;
   const float var = fmaxf(ss * inv_count - mean * mean, 0.f);
   const float inv = gamma[c] / sqrtf(var + eps);
-  scale[i] = inv;
-  shift[i] = beta[c] - mean * inv;
+  scale[(size_t)b * C + c] = inv;
+  shift[(size_t)b * C + c] = beta[c] - mean * inv;
 }
 
 __global__ void in_finalize_kernel(const float* __restrict__ part, int nparts, int B, int C, float inv_count,
@@ -784,7 +792,7 @@ int hdrsky_in_finalize(const float* part, int nparts, int B, int C, int count, c
 int hdrsky_in_affine(const float* part, int nparts, int B, int C, int count, const float* gamma, const float* beta, float eps,
                      float* scale, float* shift, void* stream) {
   if (!part || !gamma || !beta || !scale || !shift || nparts <= 0 || count <= 0) return HDRSKY_EINVAL;
-  hipLaunchKernelGGL(in_affine_kernel, dim3(cdiv(B * C, 64)), dim3(64), 0, (hipStream_t)stream, part, nparts, B, C,
+  hipLaunchKernelGGL(in_affine_kernel, dim3(B * cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, part, nparts, B, C,
                      1.f / (float)count, gamma, beta, eps, scale, shift);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
