@@ -914,6 +914,17 @@ __global__ void __launch_bounds__(256) rmsprop_fc_kernel(float* __restrict__ w, 
   }
 }
 
+// words [0, n) <- 0; head / tail by single words, the aligned middle by 16-byte stores
+__global__ void __launch_bounds__(256) zero_words_kernel(unsigned* __restrict__ p, size_t n) {
+  const size_t head = min(n, (size_t)((4 - ((reinterpret_cast<uintptr_t>(p) >> 2) & 3)) & 3));
+  const size_t n4 = (n - head) / 4, tail0 = head + n4 * 4;
+  const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+  uint4* q = reinterpret_cast<uint4*>(p + head);
+  for (size_t i = tid; i < n4; i += nth) q[i] = uint4{0u, 0u, 0u, 0u};
+  if (tid < head) p[tid] = 0u;
+  if (tid < n - tail0) p[tail0 + tid] = 0u;
+}
+
 inline unsigned grid_for(size_t n, int per = 256) {
   size_t g = (n + per - 1) / per;
   if (g > 4096) g = 4096;
@@ -1121,7 +1132,7 @@ int hdrsky_sun_rad_bwd(const float* cmf, const void* gmax_bits, const float* gam
   float* dx = scratch;
   float* dotx = scratch + (size_t)B * P;
   int* claimed = reinterpret_cast<int*>(dotx + B);
-  if (hipMemsetAsync(claimed, 0, sizeof(int), S_(stream)) != hipSuccess) return HDRSKY_ELAUNCH;
+  hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, S_(stream), (unsigned*)claimed, (size_t)1);   // (see hdrsky_zero)
   hipLaunchKernelGGL(sun_rad_bwd_kernel, dim3(B), dim3(256), 0, S_(stream), cmf, (const unsigned int*)gmax_bits, gamma, beta,
                      drg3, P, dx, dpre, dotx);
   hipLaunchKernelGGL(sun_rad_bwd_cmf_kernel, dim3(grid_for((size_t)B * P)), dim3(256), 0, S_(stream), cmf,
@@ -1204,7 +1215,15 @@ int hdrsky_fc_wgrad(const float* x, const float* dy, int M, int K, int N, int ac
 int hdrsky_zero(void* p, size_t nbytes, void* stream) {
   if (!p) return HDRSKY_EINVAL;
   if (nbytes == 0) return HDRSKY_OK;
-  return hipMemsetAsync(p, 0, nbytes, S_(stream)) == hipSuccess ? HDRSKY_OK : HDRSKY_ELAUNCH;
+  // A kernel, not hipMemsetAsync: memset nodes captured into the per-segment hipGraphs of the training step did their
+  // job in the FIRST replay only (ROCm 7.2) - from the second replay on, accumulators that are cleared this way (the
+  // gradient reaching the res stack, the arg-max claim word of the sun-radiance backward) kept stale or foreign contents
+  // and the captured step diverged from the eager one (tests/test_train_gpu.py::test_captured_replays_match_eager_steps).
+  if ((reinterpret_cast<uintptr_t>(p) & 3) || (nbytes & 3)) return HDRSKY_EINVAL;
+  const size_t nw = nbytes / 4;
+  hipLaunchKernelGGL(zero_words_kernel, dim3(grid_for(nw, 1024)), dim3(256), 0, S_(stream), (unsigned*)p, nw);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
 }
 
 int hdrsky_adam(float* w, const float* g, float* m, float* v, size_t n, float lr_t, float beta1, float beta2, float eps,

@@ -602,7 +602,8 @@ def bn_train_finalize(stats: Stats, gamma, beta, B, C, moving_mean=None, moving_
 
 
 def zero_(t):
-    """Zero-fill of a contiguous tensor on the current stream (hipMemsetAsync: a memset node under graph capture)."""
+    """Zero-fill of a contiguous tensor on the current stream (a kernel: hipGraph memset nodes only worked in the first
+    replay of a captured segment, see hdrsky_zero)."""
     if not (torch.is_tensor(t) and t.is_cuda and t.is_contiguous()):
         raise ValueError("expected a contiguous CUDA tensor")
     L.check(L.load().hdrsky_zero(_p(t), t.numel() * t.element_size(), _stream()), "zero")

@@ -9,7 +9,8 @@ dev = torch.device("cuda:0")
 gen = params.init_params(params.generator_spec(), 0); sun = params.init_params(params.sunpose_spec(), 1)
 dis = params.init_params(params.discriminator_spec(), 2); vgg = params.init_params(params.vgg_spec(), 3)
 bt = {k: torch.from_numpy(v).to(dev) for k, v in synth.make_batch(32, seed=7).items()}
-tr = trainer.Trainer(gen, sun, dis, vgg, device=dev, precise=False, compute=K.BF16)
+tr = trainer.Trainer(gen, sun, dis, vgg, device=dev, precise=False, compute=K.BF16,
+                     distortion_aware=os.environ.get("STRESS_DA", "") or False)      # STRESS_DA=all: the distortion-aware variant
 w0g, w0d = tr.gs.flat.clone(), tr.ds.flat.clone()
 tr.capture(bt["ldr"], bt["hdr_t"], bt["sunpose_gt"])
 ref = None

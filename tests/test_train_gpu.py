@@ -567,3 +567,55 @@ def test_three_optimizer_steps_follow_the_oracle(dev):
             for k, g in grads.items():
                 net[k], ms[pre + k] = T.rmsprop_update(net[k], g, ms.get(pre + k, torch.zeros_like(g)), tr.lr)
         g_.update(sg); d_.update(sd)
+
+
+@pytest.mark.parametrize("B,mode,da", [(4, "BF16", False), (32, "BF16", False), (3, "BF16X3", False), (4, "BF16", "all")])
+def test_captured_replays_match_eager_steps(dev, B, mode, da):
+    """The captured step (one hipGraph per segment, three streams) replayed several times against the same number of eager
+    steps from the same state: weights of both optimizers, BatchNorm moving statistics and every loss term stay equal step
+    after step - and a gradient-only replay repeated from a restored state reproduces its gradients bit for bit.  (hipGraph
+    memset nodes did their job in the first replay only: from the second replay on accumulators cleared that way were stale
+    and the captured step diverged from the eager one; hdrsky_zero is a kernel since.)"""
+    params, synth, trainer, K = pkg("params"), pkg("synth"), pkg("trainer"), pkg("kernels")
+    mk = lambda: trainer.Trainer(params.init_params(params.generator_spec(), 0), params.init_params(params.sunpose_spec(), 1),
+                                 params.init_params(params.discriminator_spec(), 2), params.init_params(params.vgg_spec(), 3),
+                                 device=dev, precise=(mode == "BF16X3"), compute=getattr(K, mode), distortion_aware=da)
+    batch = synth.make_batch(B, seed=4321)
+    ldr, hdr, gt = (torch.from_numpy(batch[k]).to(dev) for k in ("ldr", "hdr_t", "sunpose_gt"))
+    te, tc = mk(), mk()
+    tc.capture(ldr, hdr, gt)
+    for it in range(4):
+        te.step(ldr, hdr, gt, update=True)
+        tc.replay(update=True)
+        torch.cuda.synchronize()
+        spare = [torch.empty(1 << 20, device=dev).normal_() for _ in range(8)]     # (eager allocations between replays)
+        for name, a, b in (("generator + sun-pose", te.gs.flat, tc.gs.flat), ("discriminator", te.ds.flat, tc.ds.flat)):
+            assert torch.isfinite(b).all(), (it, name)
+            err = float((a - b).abs().max())
+            assert err <= 1e-6 * float(a.abs().max()), (it, name, err)
+        le, lc = te.losses.double(), tc.losses.double()
+        assert float((le - lc).abs().max()) <= 1e-4 * float(le.abs().max()), (it, te.losses.tolist(), tc.losses.tolist())
+        del spare
+    # gradient-only replays from a restored state: the same gradients every time.  Bit for bit for the discriminator and
+    # the generator; the sun-pose net's (tiny, at random init) gradients repeat to fp32 round-off of their own scale:
+    # the gradient of the batch-global maximum (generator.py:160) goes to whichever of several tied maximal elements is
+    # claimed first (hdrsky_sun_rad_bwd), and random-init batches do tie.
+    w0g, w0d = tc.gs.flat.clone(), tc.ds.flat.clone()
+    ref = None
+    for it in range(3):
+        tc.gs.flat.copy_(w0g); tc.ds.flat.copy_(w0d)
+        tc.replay(update=False)
+        torch.cuda.synchronize()
+        snap = (tc.gs.grad.clone(), tc.ds.grad.clone())
+        if ref is None:
+            ref = snap
+            continue
+        assert torch.equal(ref[1], snap[1]), it
+        for name, (o, cnt, _) in tc.gs.offsets.items():
+            if o >= tc.gs.ntrain:
+                continue
+            a, b = ref[0][o:o + cnt], snap[0][o:o + cnt]
+            if name.startswith("gen."):
+                assert torch.equal(a, b), (it, name)
+            else:
+                assert float((a - b).abs().max()) <= 1e-3 * float(a.abs().max()) + 1e-30, (it, name)
