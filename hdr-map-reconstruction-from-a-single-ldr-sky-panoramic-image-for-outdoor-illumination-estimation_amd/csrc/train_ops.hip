@@ -678,7 +678,8 @@ __global__ void decoder_tail_bwd_kernel(const float* __restrict__ y, const float
 __global__ void __launch_bounds__(256) sun_rad_bwd_kernel(const float* __restrict__ cmf, const unsigned int* gmax_bits,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* __restrict__ drg3, int P, float* __restrict__ dx,
-                                                          float* __restrict__ dpre, float* __restrict__ dotx) {
+                                                          float* __restrict__ dpre, float* __restrict__ dotx, int n,
+                                                          int* __restrict__ claimed) {
   __shared__ float sred[3][4];
   const int b = blockIdx.x;
   const float gmax = __uint_as_float(*gmax_bits);
@@ -701,6 +702,10 @@ __global__ void __launch_bounds__(256) sun_rad_bwd_kernel(const float* __restric
     const float dxi = dr * g * E * 2.f * d1 / be / D;
     dx[i] = dxi;
     sd += dxi * cmf[i];
+    // the FIRST element of the batch tensor that equals its maximum receives the maximum's gradient (second launch):
+    // n - i is largest there.  (An atomicCAS "first to arrive" claim gave it to any of several tied elements - the
+    // gradients of the sun-pose net then repeated only to round-off.)
+    if (cmf[i] == gmax) atomicMax(claimed, n - (int)i);
   }
   sg = wave_sum(sg); sb = wave_sum(sb); sd = wave_sum(sd);
   if ((threadIdx.x & 63) == 0) { sred[0][threadIdx.x >> 6] = sg; sred[1][threadIdx.x >> 6] = sb; sred[2][threadIdx.x >> 6] = sd; }
@@ -718,14 +723,15 @@ __global__ void __launch_bounds__(256) sun_rad_bwd_kernel(const float* __restric
 // (tf.reduce_max over the batch tensor, generator.py:160)
 __global__ void sun_rad_bwd_cmf_kernel(const float* __restrict__ cmf, const unsigned int* gmax_bits,
                                        const float* __restrict__ dx, const float* __restrict__ dotx, int B, int P,
-                                       int* claimed, float* __restrict__ dcmf) {
+                                       const int* __restrict__ claimed, float* __restrict__ dcmf) {
   const float gmax = __uint_as_float(*gmax_bits);
   float tot = 0.f;
   for (int b = 0; b < B; ++b) tot += dotx[b];
   const size_t n = (size_t)B * P;
+  const size_t first = n - (size_t)*claimed;        // (index n when nothing equals gmax: never matches)
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     float g = dx[i] / gmax;
-    if (cmf[i] == gmax && atomicCAS(claimed, 0, 1) == 0) g -= tot / (gmax * gmax);
+    if (i == first) g -= tot / (gmax * gmax);
     dcmf[i] += g;
   }
 }
@@ -1128,13 +1134,13 @@ int hdrsky_decoder_tail_bwd(const float* y, const float* res, const float* dy, s
 /* scratch: B*P + B floats + 1 int (claimed flag, zeroed here); dcmf is accumulated into */
 int hdrsky_sun_rad_bwd(const float* cmf, const void* gmax_bits, const float* gamma, const float* beta, const float* drg3,
                        int B, int P, float* scratch, float* dpre, float* dcmf, void* stream) {
-  if (!cmf || !gmax_bits || !gamma || !beta || !drg3 || !scratch || !dpre || !dcmf) return HDRSKY_EINVAL;
+  if (!cmf || !gmax_bits || !gamma || !beta || !drg3 || !scratch || !dpre || !dcmf || (size_t)B * P > 0x7fffffffu) return HDRSKY_EINVAL;
   float* dx = scratch;
   float* dotx = scratch + (size_t)B * P;
   int* claimed = reinterpret_cast<int*>(dotx + B);
   hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, S_(stream), (unsigned*)claimed, (size_t)1);   // (see hdrsky_zero)
   hipLaunchKernelGGL(sun_rad_bwd_kernel, dim3(B), dim3(256), 0, S_(stream), cmf, (const unsigned int*)gmax_bits, gamma, beta,
-                     drg3, P, dx, dpre, dotx);
+                     drg3, P, dx, dpre, dotx, B * P, claimed);
   hipLaunchKernelGGL(sun_rad_bwd_cmf_kernel, dim3(grid_for((size_t)B * P)), dim3(256), 0, S_(stream), cmf,
                      (const unsigned int*)gmax_bits, dx, dotx, B, P, claimed, dcmf);
   HDRSKY_CHECK_LAUNCH();
