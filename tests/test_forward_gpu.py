@@ -75,3 +75,25 @@ def test_generator_graph_picks_gt_bin(dev):
         # (picking a low-probability bin makes the maps even smaller and more tie-dominated than the max-bin case)
         assert rel_rms(out[k], ref[k].detach()) < 6e-2, k
     assert_close(out["y_final_gamma"], ref["y_final_gamma"].detach(), 1e-3, "y_final_gamma")
+
+
+@pytest.mark.parametrize("da", [False, "all"])
+def test_captured_forward_replays_match_eager(dev, da):
+    """The forward pass as ONE hipGraph (what bench.py times: two branches forked onto two streams inside the capture)
+    replayed several times, with eager allocations in between, against the eager pass: every output bit for bit."""
+    K = pkg("kernels")
+    engine, nets, gen, sun, batch = _setup(dev, 8)
+    ldr = torch.from_numpy(batch["ldr"]).to(dev)
+    fn = lambda: engine.generator_forward(nets, ldr, compute=K.BF16, distortion_aware=da)
+    ref = {k: v.clone() for k, v in fn().items() if torch.is_tensor(v)}
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = fn()
+    for it in range(4):
+        g.replay()
+        torch.cuda.synchronize()
+        spare = [torch.empty(1 << 20, device=dev).normal_() for _ in range(4)]
+        for k, v in ref.items():
+            assert torch.equal(out[k], v), (it, k)
+        del spare
