@@ -73,6 +73,7 @@ SIGNATURES = {
     "hdrsky_fc_dgrad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
     "hdrsky_fc_finalize": (c_int, [P, c_int, c_int, c_int, P, c_int, P, P, P, P]),
     "hdrsky_softmax_head": (c_int, [P, c_int, c_int, c_int, P, P, P, P, P]),
+    "hdrsky_softmax_head_pick": (c_int, [P, c_int, c_int, c_int, P, P, P, P, P, P, P, P]),
     "hdrsky_softmax_pick_bwd": (c_int, [P, P, P, c_int, c_int, P, P, P]),
     "hdrsky_spatial_sum": (c_int, [P, c_int, c_int, c_int, c_float, P, P]),
     "hdrsky_grad_cam": (c_int, [P, P, c_int, c_float, c_int, c_int, c_int, P, P]),

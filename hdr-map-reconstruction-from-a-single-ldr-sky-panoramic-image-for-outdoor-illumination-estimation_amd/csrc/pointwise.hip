@@ -357,13 +357,21 @@ __global__ void __launch_bounds__(256) norm_act_bwd_kernel(const float* __restri
 // ---------------------------------------------------------------------------------------------
 // One 1024-thread block per row; a thread owns float4 groups n4 = tid, tid + 1024, ... (RV of them, 4 at N = 16384:
 // everything stays in registers, the split-R partials of a group are 16-byte loads issued together).
-template <int RV>
+// PICK: also the Grad-CAM seed d y_c / d z of softmax_pick_bwd_kernel below (same arithmetic, same first-arg-max rule), from
+// the row that is in registers anyway - one launch less on the forward pass's critical chain.  pick_src == nullptr: the
+// row's own cmf picks the class (inference.py:98), else pick_src[m, :] (sunpose_gt in training, train.py:265-267).
+template <int RV, bool PICK>
 __global__ void __launch_bounds__(1024) softmax_head_kernel(const float* __restrict__ part, int nsplit, int M, int N,
                                                             const float* __restrict__ bias, float* __restrict__ z,
-                                                            float* __restrict__ cmf, unsigned int* gmax_bits) {
+                                                            float* __restrict__ cmf, unsigned int* gmax_bits,
+                                                            const float* __restrict__ pick_src, float* __restrict__ dz,
+                                                            int* __restrict__ idx_out) {
   __shared__ float sred[16];
+  __shared__ int sidx[16];
+  __shared__ float syc;
   const int m = blockIdx.x, tid = threadIdx.x, n4 = N >> 2;
   float4 v[RV];
+  unsigned zpos = 0u;                                 // PICK: bit 4r + j = [z > 0] of this thread's element (r, j)
   float lmax = 0.f;                                   // relu output: >= 0
 #pragma unroll
   for (int r = 0; r < RV; ++r) {
@@ -377,6 +385,7 @@ __global__ void __launch_bounds__(1024) softmax_head_kernel(const float* __restr
       }
       a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
       v[r] = a;
+      if (PICK) zpos |= ((a.x > 0.f ? 1u : 0u) | (a.y > 0.f ? 2u : 0u) | (a.z > 0.f ? 4u : 0u) | (a.w > 0.f ? 8u : 0u)) << (4 * r);
       if (z) reinterpret_cast<float4*>(z + (size_t)m * N)[q] = a;
       lmax = fmaxf(lmax, fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)));
     }
@@ -410,11 +419,63 @@ __global__ void __launch_bounds__(1024) softmax_head_kernel(const float* __restr
       const float4 pv = make_float4(v[r].x / rsum, v[r].y / rsum, v[r].z / rsum, v[r].w / rsum);
       reinterpret_cast<float4*>(cmf + (size_t)m * N)[q] = pv;
       pmax = fmaxf(pmax, fmaxf(fmaxf(pv.x, pv.y), fmaxf(pv.z, pv.w)));
+      if (PICK) v[r] = pv;
     }
   }
   if (gmax_bits) {
     pmax = wave_max(pmax);
     if ((tid & 63) == 0) atomicMax(gmax_bits, __float_as_uint(pmax));
+  }
+  if (PICK) {
+    // first arg-max of the picking row: ascending element index per thread with a strict >, ties between threads to the
+    // smaller index (softmax_pick_bwd_kernel's rule)
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int r = 0; r < RV; ++r) {
+      const int q = tid + r * 1024;
+      if (q < n4) {
+        const float4 pk = pick_src ? reinterpret_cast<const float4*>(pick_src + (size_t)m * N)[q] : v[r];
+        const float e[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (e[j] > best) { best = e[j]; bi = 4 * q + j; }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o);
+      const int oi = __shfl_xor(bi, o);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    __syncthreads();                                  // (sred was read above by every thread)
+    if ((tid & 63) == 0) { sred[tid >> 6] = best; sidx[tid >> 6] = bi; }
+    __syncthreads();
+    best = sred[0]; bi = sidx[0];
+    for (int w = 1; w < 16; ++w)
+      if (sred[w] > best || (sred[w] == best && sidx[w] < bi)) { best = sred[w]; bi = sidx[w]; }
+#pragma unroll
+    for (int r = 0; r < RV; ++r) {                    // the owner of element bi publishes y_c = cmf[m, bi]
+      const int q = tid + r * 1024;
+      if (q == (bi >> 2)) { const float e[4] = {v[r].x, v[r].y, v[r].z, v[r].w}; syc = e[bi & 3]; }
+    }
+    __syncthreads();
+    const float yc = syc;
+    if (tid == 0 && idx_out) idx_out[m] = bi;
+#pragma unroll
+    for (int r = 0; r < RV; ++r) {
+      const int q = tid + r * 1024;
+      if (q < n4) {
+        const float p4[4] = {v[r].x, v[r].y, v[r].z, v[r].w};
+        float g4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float g = yc * ((4 * q + j == bi ? 1.f : 0.f) - p4[j]);
+          g4[j] = ((zpos >> (4 * r + j)) & 1u) ? g : 0.f;
+        }
+        reinterpret_cast<float4*>(dz + (size_t)m * N)[q] = make_float4(g4[0], g4[1], g4[2], g4[3]);
+      }
+    }
   }
 }
 
@@ -847,11 +908,25 @@ int hdrsky_softmax_head(const float* part, int nsplit, int M, int N, const float
   if (!part || !cmf) return HDRSKY_EINVAL;
   if ((N & 3) || N > 4 * 4 * 1024) return HDRSKY_EUNSUPPORTED;   // a row lives in the registers of one 1024-thread block
   if (N <= 4096)
-    hipLaunchKernelGGL(softmax_head_kernel<1>, dim3(M), dim3(1024), 0, (hipStream_t)stream, part, nsplit, M, N, bias, z, cmf,
-                       (unsigned int*)gmax_bits);
+    hipLaunchKernelGGL((softmax_head_kernel<1, false>), dim3(M), dim3(1024), 0, (hipStream_t)stream, part, nsplit, M, N, bias, z,
+                       cmf, (unsigned int*)gmax_bits, nullptr, nullptr, nullptr);
   else
-    hipLaunchKernelGGL(softmax_head_kernel<4>, dim3(M), dim3(1024), 0, (hipStream_t)stream, part, nsplit, M, N, bias, z, cmf,
-                       (unsigned int*)gmax_bits);
+    hipLaunchKernelGGL((softmax_head_kernel<4, false>), dim3(M), dim3(1024), 0, (hipStream_t)stream, part, nsplit, M, N, bias, z,
+                       cmf, (unsigned int*)gmax_bits, nullptr, nullptr, nullptr);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_softmax_head_pick(const float* part, int nsplit, int M, int N, const float* bias, float* z, float* cmf,
+                             void* gmax_bits, const float* pick_src, float* dz, int* idx_out, void* stream) {
+  if (!part || !cmf || !dz) return HDRSKY_EINVAL;
+  if ((N & 3) || N > 4 * 4 * 1024) return HDRSKY_EUNSUPPORTED;
+  if (N <= 4096)
+    hipLaunchKernelGGL((softmax_head_kernel<1, true>), dim3(M), dim3(1024), 0, (hipStream_t)stream, part, nsplit, M, N, bias, z,
+                       cmf, (unsigned int*)gmax_bits, pick_src, dz, idx_out);
+  else
+    hipLaunchKernelGGL((softmax_head_kernel<4, true>), dim3(M), dim3(1024), 0, (hipStream_t)stream, part, nsplit, M, N, bias, z,
+                       cmf, (unsigned int*)gmax_bits, pick_src, dz, idx_out);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }

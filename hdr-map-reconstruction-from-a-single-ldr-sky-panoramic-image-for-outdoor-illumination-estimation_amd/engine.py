@@ -160,7 +160,7 @@ def sun3_backward(rec, dP, pkT1, pkT2, g1, b1, g2, b2, dgb1=None, dgb2=None):
     return dc2, dc1, dx
 
 
-def sunpose_forward(nets, ldr, compute, distortion_aware=False):
+def sunpose_forward(nets, ldr, compute, distortion_aware=False, pick=None):
     """sunpose_net.model.sunposeEstimation (sunpose_net.py:54-72) -> dict with cmf, z, A1..3 (+ what the
     Grad-CAM sweep re-reads: raw conv outputs and their IN partials).  distortion_aware ("sunpose" in da_parts): the
     convolutions are distortion_aware_ops.conv2d (sunpose_net.py:11,16)."""
@@ -203,7 +203,10 @@ def sunpose_forward(nets, ldr, compute, distortion_aware=False):
     t["gmax"] = torch.empty(1, dtype=torch.int32, device=ldr.device)      # cleared by the finalize launch below
     t["f1"] = K.fc_finalize(K.fc_fwd(flat, pk["sun.fc1"], compute), s["fc1.bias"], relu=True, zero_word=t["gmax"])
     part2 = K.fc_fwd(t["f1"], pk["sun.fc2"], compute)
-    t["z"], t["cmf"] = K.softmax_head(part2, s["fc2.bias"], t["gmax"])
+    if pick is None:
+        t["z"], t["cmf"] = K.softmax_head(part2, s["fc2.bias"], t["gmax"])
+    else:     # the Grad-CAM seed comes out of the same launch: pick = "self" (the row's own argmax) or the picking tensor
+        t["z"], t["cmf"], t["dz_pick"] = K.softmax_head_pick(part2, s["fc2.bias"], t["gmax"], None if pick == "self" else pick)
     return t
 
 
@@ -214,7 +217,7 @@ def gradcam_sweep(nets, t, pick_src, compute):
     s, pk = nets.sun, nets.pk
     B = t["cmf"].shape[0]
     h, w = nets.h, nets.w
-    dz, _ = K.softmax_pick_bwd(t["cmf"], t["z"], pick_src)
+    dz = t["dz_pick"] if "dz_pick" in t else K.softmax_pick_bwd(t["cmf"], t["z"], pick_src)[0]
     df1 = K.fc_finalize(K.fc_dgrad(dz, pk["sun.fc2"], compute), None, relu=False, mask_src=t["f1"])
     dflat = K.fc_finalize(K.fc_dgrad(df1, pk["sun.fc1"], compute))
     dP3 = dflat.reshape(B, h // 8, w // 8, 128)
@@ -378,7 +381,7 @@ def generator_forward(nets, ldr, pick_src=None, compute=BF16, distortion_aware=F
     side = nets.side_stream
     side.wait_stream(main)
     with torch.cuda.stream(side):
-        t = sunpose_forward(nets, ldr, compute, da)
+        t = sunpose_forward(nets, ldr, compute, da, pick="self" if pick_src is None else pick_src)
         cams = gradcam_sweep(nets, t, t["cmf"] if pick_src is None else pick_src, compute)
         rad_lin, rad_gamma, gamma, beta = sun_rad_estimation(nets, ldr, cams, t, compute)
     res_out = encode(nets, ldr, compute, distortion_aware="res" in da)

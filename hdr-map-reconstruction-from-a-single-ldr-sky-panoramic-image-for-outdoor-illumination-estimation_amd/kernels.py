@@ -457,6 +457,19 @@ def softmax_head(part, bias, gmax_bits=None):
     return z, cmf
 
 
+def softmax_head_pick(part, bias, gmax_bits=None, pick_src=None):
+    """softmax_head + softmax_pick_bwd in one launch -> (z, cmf, dz); pick_src None: the row's own cmf picks the class."""
+    ns, M, N = part.shape
+    _f32(part); _f32(bias, N)
+    if pick_src is not None:
+        _f32(pick_src, M, N)
+    z = torch.empty((M, N), dtype=torch.float32, device=part.device)
+    cmf, dz = torch.empty_like(z), torch.empty_like(z)
+    L.check(L.load().hdrsky_softmax_head_pick(_p(part), ns, M, N, _p(bias), _p(z), _p(cmf), _p(gmax_bits), _p(pick_src), _p(dz),
+                                              None, _stream()), "softmax_head_pick")
+    return z, cmf, dz
+
+
 def softmax_pick_bwd(cmf, z, pick_src):
     M, N = cmf.shape
     _f32(cmf); _f32(z, M, N); _f32(pick_src, M, N)

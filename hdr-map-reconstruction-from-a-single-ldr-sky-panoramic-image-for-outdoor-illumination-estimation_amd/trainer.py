@@ -328,7 +328,7 @@ class Trainer:
         if q:
             K.conv2d_wgrad_multi(q)
 
-    def _sunpose_forward(self, ldr):
+    def _sunpose_forward(self, ldr, pick=None):
         w, c, cp = self.gs.w, self.conv, self.compute
         t, x = {"da": self.da_sun}, ldr
         for l in (1, 2, 3):
@@ -363,7 +363,10 @@ class Trainer:
         t["flat"] = x.reshape(B, -1)
         t["gmax"] = torch.empty(1, dtype=torch.int32, device=ldr.device)      # cleared by the finalize launch below
         t["f1"] = K.fc_finalize(K.fc_fwd(t["flat"], self.fc1, cp), w["sun.fc1.bias"], relu=True, zero_word=t["gmax"])
-        t["z"], t["cmf"] = K.softmax_head(K.fc_fwd(t["f1"], self.fc2, cp), w["sun.fc2.bias"], t["gmax"])
+        if pick is None:
+            t["z"], t["cmf"] = K.softmax_head(K.fc_fwd(t["f1"], self.fc2, cp), w["sun.fc2.bias"], t["gmax"])
+        else:     # Grad-CAM seed of the class pick[m].argmax() from the same launch (train.py:265-267)
+            t["z"], t["cmf"], t["dz_pick"] = K.softmax_head_pick(K.fc_fwd(t["f1"], self.fc2, cp), w["sun.fc2.bias"], t["gmax"], pick)
         return t
 
     def _init_da_sun(self):
@@ -405,7 +408,7 @@ class Trainer:
         """grad_cam.layer x3 under gen_tape.stop_recording() (train.py:257-271): constants for the gradient."""
         w, c, cp = self.gs.w, self.conv, self.compute
         B, h, wd = t["cmf"].shape[0], self.h, self.w
-        dz, _ = K.softmax_pick_bwd(t["cmf"], t["z"], pick_src)
+        dz = t["dz_pick"] if "dz_pick" in t else K.softmax_pick_bwd(t["cmf"], t["z"], pick_src)[0]
         df1 = K.fc_finalize(K.fc_dgrad(dz, self.fc2, cp), None, relu=False, mask_src=t["f1"])
         dP3 = K.fc_finalize(K.fc_dgrad(df1, self.fc1, cp)).reshape(B, h // 8, wd // 8, 128)
         small = (h // 8) * (wd // 8) <= 256       # cam3's GAP weights: summed inside its own launch when the map is small
@@ -679,7 +682,7 @@ class Trainer:
         # (the longest independent chain is enqueued first; segment order = host launch order)
         @seg("fwd_sun", 1)
         def _():       # sun-pose net, Grad-CAM (constants for the gradient: train.py:257-271), sun radiance head
-            t = T["t"] = self._sunpose_forward(T["ldr"])
+            t = T["t"] = self._sunpose_forward(T["ldr"], pick=T["gt"])
             T["cams"] = self._gradcam(t, T["gt"])
             T["rad"] = self._sunrad_forward(T["ldr"], T["cams"], t, T)
 

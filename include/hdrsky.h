@@ -177,6 +177,11 @@ int hdrsky_fc_finalize(const float* part, int nsplit, int M, int N, const float*
 /* z = relu(sum_s part[s] + bias); cmf = softmax(z); *gmax_bits = max(*gmax_bits, bits(max cmf)) (zero it first). */
 int hdrsky_softmax_head(const float* part, int nsplit, int M, int N, const float* bias, float* z, float* cmf,
                         void* gmax_bits, void* stream);
+/* hdrsky_softmax_head and hdrsky_softmax_pick_bwd in one launch (the row is in registers anyway): additionally
+ * dz = d cmf[m, c] / d z with c = first argmax of pick_src[m, :] - or of cmf[m, :] itself when pick_src is NULL
+ * (inference.py:98) - and idx_out[m] = c (nullable).  Same arithmetic and tie rule as the two separate launches. */
+int hdrsky_softmax_head_pick(const float* part, int nsplit, int M, int N, const float* bias, float* z, float* cmf,
+                             void* gmax_bits, const float* pick_src, float* dz, int* idx_out, void* stream);
 /* dz = d cmf[m, argmax(pick_src[m])] / d z  (inference.py:98 ; train.py:265-267) */
 int hdrsky_softmax_pick_bwd(const float* cmf, const float* z, const float* pick_src, int M, int N, float* dz,
                             int* idx_out, void* stream);

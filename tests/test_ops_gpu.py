@@ -238,3 +238,24 @@ def test_pad_channels_zero_word_and_cam_from_the_gradient_map(dev):
     assert_close(got, ref, 1e-5, "cam from the gradient map")
     expect = torch.relu(torch.einsum("bc,bhwc->bhw", dP.sum(dim=(1, 2)) * scale, A)).unsqueeze(-1)
     assert_close(got, expect, 1e-4, "cam formula")
+
+
+@pytest.mark.parametrize("N,self_pick", [(4096, True), (4096, False), (16384, True), (1024, False)])
+def test_softmax_head_pick_equals_the_two_launches(dev, N, self_pick):
+    """hdrsky_softmax_head_pick = hdrsky_softmax_head + hdrsky_softmax_pick_bwd, bit for bit (z, cmf, the global maximum and
+    the Grad-CAM seed), including rows with tied maxima in the picking tensor (first index wins)."""
+    K = pkg("kernels")
+    rng = np.random.default_rng(N + self_pick)
+    M, ns = 7, 4
+    part = torch.from_numpy(rng.standard_normal((ns, M, N)).astype(np.float32)).to(dev)
+    bias = torch.from_numpy(rng.standard_normal(N).astype(np.float32)).to(dev)
+    pick = rng.random((M, N)).astype(np.float32)
+    pick[2, 100] = pick[2, 900] = 2.0                     # a tie: element 100 wins
+    pick = torch.from_numpy(pick).to(dev)
+    g0 = torch.zeros(1, dtype=torch.int32, device=dev); g1 = torch.zeros(1, dtype=torch.int32, device=dev)
+    z0, c0 = K.softmax_head(part, bias, g0)
+    dz0, idx0 = K.softmax_pick_bwd(c0, z0, c0 if self_pick else pick)
+    z1, c1, dz1 = K.softmax_head_pick(part, bias, g1, None if self_pick else pick)
+    assert torch.equal(z0, z1) and torch.equal(c0, c1) and torch.equal(g0, g1) and torch.equal(dz0, dz1)
+    if not self_pick:
+        assert int(idx0[2]) == 100
