@@ -931,6 +931,10 @@ __global__ void __launch_bounds__(256) zero_words_kernel(unsigned* __restrict__ 
   if (tid < n - tail0) p[tail0 + tid] = 0u;
 }
 
+__global__ void __launch_bounds__(256) zero_bytes_kernel(unsigned char* __restrict__ p, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0;
+}
+
 inline unsigned grid_for(size_t n, int per = 256) {
   size_t g = (n + per - 1) / per;
   if (g > 4096) g = 4096;
@@ -1225,7 +1229,11 @@ int hdrsky_zero(void* p, size_t nbytes, void* stream) {
   // job in the FIRST replay only (ROCm 7.2) - from the second replay on, accumulators that are cleared this way (the
   // gradient reaching the res stack, the arg-max claim word of the sun-radiance backward) kept stale or foreign contents
   // and the captured step diverged from the eager one (tests/test_train_gpu.py::test_captured_replays_match_eager_steps).
-  if ((reinterpret_cast<uintptr_t>(p) & 3) || (nbytes & 3)) return HDRSKY_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(p) & 3) || (nbytes & 3)) {      // odd-sized / unaligned buffers: byte stores
+    hipLaunchKernelGGL(zero_bytes_kernel, dim3(grid_for(nbytes, 1024)), dim3(256), 0, S_(stream), (unsigned char*)p, nbytes);
+    HDRSKY_CHECK_LAUNCH();
+    return HDRSKY_OK;
+  }
   const size_t nw = nbytes / 4;
   hipLaunchKernelGGL(zero_words_kernel, dim3(grid_for(nw, 1024)), dim3(256), 0, S_(stream), (unsigned*)p, nw);
   HDRSKY_CHECK_LAUNCH();

@@ -259,3 +259,26 @@ def test_softmax_head_pick_equals_the_two_launches(dev, N, self_pick):
     assert torch.equal(z0, z1) and torch.equal(c0, c1) and torch.equal(g0, g1) and torch.equal(dz0, dz1)
     if not self_pick:
         assert int(idx0[2]) == 100
+
+
+def test_zero_fill_kernel_sizes_and_alignments_also_under_graph_replay(dev):
+    """hdrsky_zero (a kernel, not a memset node): every size / alignment class, guard elements on both sides untouched,
+    and the fill repeats in every replay of a captured graph (the property the memset nodes did not have)."""
+    K = pkg("kernels")
+    for n, off in ((1, 0), (3, 1), (4, 0), (5, 3), (64, 2), (1000, 1), (4099, 5), (1 << 20, 0)):
+        buf = torch.full((n + 16,), 7.0, device=dev)
+        K.zero_(buf[off:off + n])
+        assert float(buf[off:off + n].abs().max()) == 0.0 and float(buf[:off].sum()) == 7.0 * off
+        assert float(buf[off + n:].sum()) == 7.0 * (16 - off)
+    b8 = torch.full((1031,), 9, dtype=torch.uint8, device=dev)
+    K.zero_(b8[1:1030])
+    assert int(b8[1:1030].max()) == 0 and int(b8[0]) == 9 and int(b8[1030]) == 9
+    x = torch.ones(4096, device=dev)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        K.zero_(x)
+        x.add_(1.0)
+    for it in range(4):
+        g.replay()
+        torch.cuda.synchronize()
+        assert float(x.min()) == 1.0 and float(x.max()) == 1.0, it
