@@ -266,7 +266,8 @@ int hdrsky_conv2d_wgrad_multi_det(const hdrsky_wgrad_job* jobs, int njobs, void*
 int hdrsky_bn_train_finalize(const float* part, int nparts_total, int C, int count, const float* gamma, const float* beta, float eps, float momentum, float* moving_mean, float* moving_var, float* mean, float* rstd, float* scale, float* shift, int rows, void* stream);
 /* (scale / shift are written as `rows` identical rows of a [rows][C] table: rows = 1 for per-channel tables, rows = B to
  * fill the per-sample affine tables of a batch that carries several BatchNorm groups side by side.)
- * Zero-fill of device memory on `stream` (a memset node under graph capture): gradient / loss accumulators. */
+ * Zero-fill of device memory on `stream` (a kernel launch, deliberately not hipMemsetAsync: memset nodes of a captured
+ * hipGraph wrote wrong patterns from the second replay on, profiles/repro_memset_node.py): gradient / loss accumulators. */
 int hdrsky_zero(void* p, size_t nbytes, void* stream);
 /* [host] number of reduction blocks hdrsky_bn_act_bwd uses; its workspace is (2*nblocks*C + 2*C) floats. */
 int hdrsky_bn_bwd_nblocks(void);
