@@ -77,6 +77,7 @@ SIGNATURES = {
     "hdrsky_softmax_pick_bwd": (c_int, [P, P, P, c_int, c_int, P, P, P]),
     "hdrsky_spatial_sum": (c_int, [P, c_int, c_int, c_int, c_float, P, P]),
     "hdrsky_grad_cam": (c_int, [P, P, c_int, c_float, c_int, c_int, c_int, P, P]),
+    "hdrsky_grad_cam3": (c_int, [P, P, P, P, P, P, P, c_int, P]),
     "hdrsky_plz_build": (c_int, [P, P, P, P, c_int, c_int, c_int, P, P]),
     "hdrsky_dense_heads": (c_int, [P, P, P, c_float, c_int, c_int, c_int, P, P, c_int, P, P]),
     "hdrsky_sun_rad": (c_int, [P, P, P, c_int, P, P, c_int, c_int, P, P, P, P, P]),

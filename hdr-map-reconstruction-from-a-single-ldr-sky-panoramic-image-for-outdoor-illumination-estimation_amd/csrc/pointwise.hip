@@ -551,11 +551,8 @@ __global__ void __launch_bounds__(256) spatial_sum_kernel(const float* __restric
 }
 
 // cam[b][p] = relu(sum_c w[b][c] * A[b][p][c])   (grad_cam.py:35-38); one wave per pixel group
-__global__ void __launch_bounds__(256) cam_kernel(const float* __restrict__ A, const float* __restrict__ w,
-                                                  int w_nparts, float w_scale, int P, int C,
-                                                  float* __restrict__ cam) {
-  extern __shared__ float sw[];
-  const int b = blockIdx.y;
+__device__ __forceinline__ void cam_body(const float* __restrict__ A, const float* __restrict__ w, int w_nparts,
+                                         float w_scale, int P, int C, float* __restrict__ cam, float* sw, int b, int bx, int gdx) {
   // w_nparts == 0: w is a [B][C] table; > 0: w is a conv statistics tensor [B][nparts][2][C] whose sum plane is
   // reduced here (the GAP of the activation gradient, grad_cam.py:34); < 0: w is the gradient map itself,
   // [B][-nparts pixels][C] (a small one: every block of a sample repeats the sum)
@@ -591,12 +588,29 @@ __global__ void __launch_bounds__(256) cam_kernel(const float* __restrict__ A, c
   const int c4 = C >> 2;                    // threads per pixel
   const int ppb = 256 / c4;                 // pixels per block iteration
   const int sub = threadIdx.x % c4, pl = threadIdx.x / c4;
-  for (int p = blockIdx.x * ppb + pl; p < P; p += gridDim.x * ppb) {
+  for (int p = bx * ppb + pl; p < P; p += gdx * ppb) {
     const float4 v = *reinterpret_cast<const float4*>(A + ((size_t)b * P + p) * C + sub * 4);
     float s = v.x * sw[sub * 4] + v.y * sw[sub * 4 + 1] + v.z * sw[sub * 4 + 2] + v.w * sw[sub * 4 + 3];
     for (int o = c4 >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (sub == 0) cam[(size_t)b * P + p] = fmaxf(s, 0.f);
   }
+}
+
+__global__ void __launch_bounds__(256) cam_kernel(const float* __restrict__ A, const float* __restrict__ w,
+                                                  int w_nparts, float w_scale, int P, int C,
+                                                  float* __restrict__ cam) {
+  extern __shared__ float sw[];
+  cam_body(A, w, w_nparts, w_scale, P, C, cam, sw, blockIdx.y, blockIdx.x, gridDim.x);
+}
+
+// the three Grad-CAM maps of a sweep (grad_cam.layer x3) in one launch: blockIdx.z picks the map
+struct CamJob { const float* A; const float* w; float* cam; int nparts, P, C, gx; float scale; };
+struct CamJobs { CamJob j[3]; };
+__global__ void __launch_bounds__(256) cam3_kernel(const CamJobs js) {
+  extern __shared__ float sw[];
+  const CamJob& j = js.j[blockIdx.z];
+  if ((int)blockIdx.x >= j.gx) return;
+  cam_body(j.A, j.w, j.nparts, j.scale, j.P, j.C, j.cam, sw, blockIdx.y, blockIdx.x, j.gx);
 }
 
 __device__ __forceinline__ float bilinear_1ch(const float* __restrict__ src, int h, int w, int oy, int ox, int OH,
@@ -963,6 +977,26 @@ int hdrsky_grad_cam(const float* A, const float* w, int w_nparts, float w_scale,
   int gx = cdiv(P, ppb); if (gx > 64) gx = 64;
   const size_t lds = (C + (w_nparts < 0 ? 1024 : 0)) * sizeof(float);     // + [256 / (C/4) slices][C] partial sums
   hipLaunchKernelGGL(cam_kernel, dim3(gx, B), dim3(256), lds, (hipStream_t)stream, A, w, w_nparts, w_scale, P, C, cam);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_grad_cam3(const float* const* A, const float* const* w, const int* w_nparts, const float* w_scale, const int* P,
+                     const int* C, float* const* cam, int B, void* stream) {
+  if (!A || !w || !w_nparts || !w_scale || !P || !C || !cam || B <= 0) return HDRSKY_EINVAL;
+  CamJobs js;
+  int gmax = 1;
+  size_t lds = 0;
+  for (int k = 0; k < 3; ++k) {
+    if (!A[k] || !w[k] || !cam[k] || (C[k] & 3) || C[k] > 256 || (256 % (C[k] / 4)) != 0 || w_nparts[k] < -256) return HDRSKY_EINVAL;
+    const int ppb = 256 / (C[k] / 4);
+    int gx = cdiv(P[k], ppb); if (gx > 64) gx = 64;
+    js.j[k] = CamJob{A[k], w[k], cam[k], w_nparts[k], P[k], C[k], gx, w_scale[k]};
+    if (gx > gmax) gmax = gx;
+    const size_t need = (C[k] + (w_nparts[k] < 0 ? 1024 : 0)) * sizeof(float);
+    if (need > lds) lds = need;
+  }
+  hipLaunchKernelGGL(cam3_kernel, dim3(gmax, B, 3), dim3(256), lds, (hipStream_t)stream, js);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }

@@ -236,7 +236,7 @@ def gradcam_sweep(nets, t, pick_src, compute):
             g = K.norm_act_bwd(t["r%da" % l], t["st%da" % l], s[n + ".norm1.gamma"], s[n + ".norm1.beta"], 0.0, g, False)
             dP = K.da_conv2d_dgrad(g, pk["sun." + n + ".conv1.T"], tab, 3, compute)       # gradient at the pooled map below
             sums[l - 1] = K.spatial_sum(dP, 1.0 / ((2 * hl) * (2 * wl)))
-        return K.grad_cam_map(t["A1"], sums[1]), K.grad_cam_map(t["A2"], sums[2]), K.grad_cam_map(t["A3"], w3, s3)
+        return K.grad_cam_maps([(t["A1"], sums[1], 1.0), (t["A2"], sums[2], 1.0), (t["A3"], w3, s3)])
     # layer 3 backward: pool3 + relu + IN2 -> dgrad conv2 -> relu + IN1 -> dgrad conv1
     if "s3" in t:
         _, _, dP2 = sun3_backward(t["s3"], dP3, pk["sun.sunlayer3.conv1.T"], pk["sun.sunlayer3.conv2.T"],
@@ -253,8 +253,8 @@ def gradcam_sweep(nets, t, pick_src, compute):
     g = K.norm_act_bwd(t["r2a"], t["st2a"], s["sunlayer2.norm1.gamma"], s["sunlayer2.norm1.beta"], 0.0, g, False, out_bf16=compute == BF16)
     _, sP1 = K.conv2d(g, pk["sun.sunlayer2.conv1.T"], None, compute=compute, want_stats=True)
     # GAP of d y_c / d A_k == sum of the pooled-map gradient / (H_k*W_k): the dgrad conv's per-tile sums
-    cam2 = K.grad_cam_map(t["A2"], sP2) if "s3" in t else K.grad_cam_map(t["A2"], sP2, 1.0 / ((h // 2) * (w // 2)))
-    return (K.grad_cam_map(t["A1"], sP1, 1.0 / (h * w)), cam2, K.grad_cam_map(t["A3"], w3, s3))
+    sc2 = 1.0 if "s3" in t else 1.0 / ((h // 2) * (w // 2))
+    return K.grad_cam_maps([(t["A1"], sP1, 1.0 / (h * w)), (t["A2"], sP2, sc2), (t["A3"], w3, s3)])
 
 
 def encode(nets, ldr, compute, distortion_aware=False, dilation_rate=1):

@@ -4,6 +4,7 @@ PyTorch is plumbing here: device allocations (``torch.empty``), the current HIP 
 ``data_ptr()``; every FLOP happens inside libhdrsky.so.  All functions validate shapes / dtypes /
 contiguity on the host before a kernel is enqueued (a mis-shaped operand must never reach the GPU).
 """
+import ctypes
 import os
 from dataclasses import dataclass
 from typing import Optional
@@ -488,23 +489,46 @@ def spatial_sum(x, scale=1.0):
     return out
 
 
+def _cam_weights(A, w):
+    B, H, W, C = A.shape
+    _f32(A)
+    if isinstance(w, Stats):
+        _f32(w.part, B, w.nparts, 2, C)
+        return w.part, w.nparts
+    if w.dim() == 4:        # the activation gradient itself [B,h,w,C] (a small map): its spatial sum is taken in the launch
+        if w.shape[0] != B or w.shape[3] != C or w.shape[1] * w.shape[2] > 256:
+            raise ValueError("grad_cam_map: gradient map %s" % (tuple(w.shape),))
+        return _f32(w), -(w.shape[1] * w.shape[2])
+    return _f32(w, B, C), 0
+
+
 def grad_cam_map(A, w, scale=1.0):
     """cam = relu(sum_c w_c * A[..., c]).  w: [B,C] table, or the Stats of the conv that produced the activation
     gradient (its per-tile sums are the GAP numerator)."""
     B, H, W, C = A.shape
-    _f32(A)
+    wp, nparts = _cam_weights(A, w)
     cam = torch.empty((B, H, W, 1), dtype=torch.float32, device=A.device)
-    if isinstance(w, Stats):
-        _f32(w.part, B, w.nparts, 2, C)
-        wp, nparts = w.part, w.nparts
-    elif w.dim() == 4:      # the activation gradient itself [B,h,w,C] (a small map): its spatial sum is taken in the launch
-        if w.shape[0] != B or w.shape[3] != C or w.shape[1] * w.shape[2] > 256:
-            raise ValueError("grad_cam_map: gradient map %s" % (tuple(w.shape),))
-        wp, nparts = _f32(w), -(w.shape[1] * w.shape[2])
-    else:
-        wp, nparts = _f32(w, B, C), 0
     L.check(L.load().hdrsky_grad_cam(_p(A), _p(wp), nparts, scale, B, H * W, C, _p(cam), _stream()), "grad_cam")
     return cam
+
+
+def grad_cam_maps(jobs):
+    """The three maps of one Grad-CAM sweep, [(A, w, scale)] x 3 as for grad_cam_map, in one launch (same values)."""
+    if len(jobs) != 3:
+        raise ValueError("grad_cam_maps: three (A, w, scale) jobs")
+    B = jobs[0][0].shape[0]
+    wps, cams = [], []
+    for A, w, _ in jobs:
+        if A.shape[0] != B:
+            raise ValueError("grad_cam_maps: batch sizes differ")
+        wps.append(_cam_weights(A, w))
+        cams.append(torch.empty(tuple(A.shape[:3]) + (1,), dtype=torch.float32, device=A.device))
+    vp, ci, cf = ctypes.c_void_p * 3, ctypes.c_int * 3, ctypes.c_float * 3
+    L.check(L.load().hdrsky_grad_cam3(vp(*[_p(j[0]) for j in jobs]), vp(*[_p(wp[0]) for wp in wps]), ci(*[wp[1] for wp in wps]),
+                                      cf(*[float(j[2]) for j in jobs]), ci(*[j[0].shape[1] * j[0].shape[2] for j in jobs]),
+                                      ci(*[j[0].shape[3] for j in jobs]), vp(*[_p(c) for c in cams]), B, _stream()),
+            "grad_cam3")
+    return tuple(cams)
 
 
 def plz_build(ldr, cam1, cam2, cam3):

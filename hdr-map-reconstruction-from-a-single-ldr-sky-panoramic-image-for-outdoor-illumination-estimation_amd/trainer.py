@@ -425,7 +425,7 @@ class Trainer:
                 g_ = K.norm_act_bwd(t["r%da" % l], t["st%da" % l], w[n + ".norm1.gamma"], w[n + ".norm1.beta"], 0.0, g_, False)
                 dP = K.da_conv2d_dgrad(g_, c[n + ".conv1"].pkT, tab, 3, cp)
                 sums[l - 1] = K.spatial_sum(dP, 1.0 / ((2 * hl) * (2 * wl)))
-            return K.grad_cam_map(t["A1"], sums[1]), K.grad_cam_map(t["A2"], sums[2]), K.grad_cam_map(t["A3"], w3, s3)
+            return K.grad_cam_maps([(t["A1"], sums[1], 1.0), (t["A2"], sums[2], 1.0), (t["A3"], w3, s3)])
         n3, n2 = "sun.sunlayer3", "sun.sunlayer2"
         if "s3" in t:
             _, _, dP2 = E.sun3_backward(t["s3"], dP3, c[n3 + ".conv1"].pkT, c[n3 + ".conv2"].pkT, w[n3 + ".norm1.gamma"],
@@ -440,8 +440,8 @@ class Trainer:
         g = c[n2 + ".conv2"].dgrad(t["r2a"], g, cp)
         g = K.norm_act_bwd(t["r2a"], t["st2a"], w[n2 + ".norm1.gamma"], w[n2 + ".norm1.beta"], 0.0, g, False, out_bf16=self._act_bf16())
         _, sP1 = c[n2 + ".conv1"].dgrad(t["in2"], g, cp, want_stats=True)
-        cam2 = K.grad_cam_map(t["A2"], sP2) if "s3" in t else K.grad_cam_map(t["A2"], sP2, 1.0 / ((h // 2) * (wd // 2)))
-        return (K.grad_cam_map(t["A1"], sP1, 1.0 / (h * wd)), cam2, K.grad_cam_map(t["A3"], w3, s3))
+        sc2 = 1.0 if "s3" in t else 1.0 / ((h // 2) * (wd // 2))
+        return K.grad_cam_maps([(t["A1"], sP1, 1.0 / (h * wd)), (t["A2"], sP2, sc2), (t["A3"], w3, s3)])
 
     def _down_stack(self, net, params, x, training):
         """downsampling x4 (discriminator.py:20-27 == sunrad_net.py:21-28).  Returns records for the backward pass:

@@ -193,6 +193,10 @@ int hdrsky_spatial_sum(const float* x, int B, int P, int C, float scale, float* 
  * pixels][C] (at most 256 pixels: the sum is repeated by every block of a sample); the weights are multiplied by w_scale. */
 int hdrsky_grad_cam(const float* A, const float* w, int w_nparts, float w_scale, int B, int P, int C, float* cam,
                     void* stream);
+/* the three maps of one sweep (grad_cam.py:52-60: layer1, layer2, layer3) in one launch; every argument is a host array of
+ * three with the meaning it has in hdrsky_grad_cam; the values are those of three separate calls */
+int hdrsky_grad_cam3(const float* const* A, const float* const* w, const int* w_nparts, const float* w_scale, const int* P,
+                     const int* C, float* const* cam, int B, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Sun-radiance head, tone mapping, blending

@@ -240,6 +240,24 @@ def test_pad_channels_zero_word_and_cam_from_the_gradient_map(dev):
     assert_close(got, expect, 1e-4, "cam formula")
 
 
+def test_three_grad_cam_maps_in_one_launch_equal_three_launches(dev):
+    """grad_cam.py:52-60: the maps of the three layers; the sweep issues them as one launch (hdrsky_grad_cam3)."""
+    K = pkg("kernels")
+    rng = np.random.default_rng(21)
+    t = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32)).to(dev)
+    B = 3
+    A1, A2, A3 = t(B, 32, 128, 32), t(B, 16, 64, 64), t(B, 8, 32, 128)
+    st1 = K.Stats(t(B, 64, 2, 32), 64, 32 * 128)
+    for jobs in ([(A1, st1, 1.0 / 4096), (A2, t(B, 64), 1.0), (A3, t(B, 4, 16, 128), 1.0 / 512)],
+                 [(A1, t(B, 32), 1.0), (A2, K.Stats(t(B, 16, 2, 64), 16, 1024), 0.5), (A3, t(B, 128), 2.0)]):
+        got = K.grad_cam_maps(jobs)
+        for g, (A, w, sc) in zip(got, jobs):
+            assert g.shape == A.shape[:3] + (1,)
+            assert torch.equal(g, K.grad_cam_map(A, w, sc))
+    with pytest.raises(ValueError):
+        K.grad_cam_maps([(A1, t(B, 32), 1.0)] * 2)
+
+
 @pytest.mark.parametrize("N,self_pick", [(4096, True), (4096, False), (16384, True), (1024, False)])
 def test_softmax_head_pick_equals_the_two_launches(dev, N, self_pick):
     """hdrsky_softmax_head_pick = hdrsky_softmax_head + hdrsky_softmax_pick_bwd, bit for bit (z, cmf, the global maximum and
