@@ -848,7 +848,13 @@ TileCfg choose_tile(const hdrsky_conv_desc* d) {
   const bool narrow = d->Cin <= 8;
   TileCfg t{2, 2, 2, 2, tw, 0};
   if (tw == 16) {
-    if (d->Cout >= 128) t = TileCfg{1, 8, 2, 1, 16, 1};               // 32 px x 128 ch, 8 waves (the 4x16-pixel layers)
+    if (d->Cout >= 128) {
+      t = TileCfg{1, 8, 2, 1, 16, 1};                                  // 32 px x 128 ch, 8 waves (the 4x16-pixel layers)
+      if (const char* e = getenv("HDRSKY_TILE_T16")) {                 // A/B hook for this class inside the step
+        TileCfg o; o.db = 0;
+        if (sscanf(e, "%d,%d,%d,%d,%d,%d", &o.wm, &o.wn, &o.mi, &o.ni, &o.tw, &o.db) >= 5) t = o;
+      }
+    }
     else if (d->Cout >= 64) t = (d->Ho >= 4) ? TileCfg{1, 4, 4, 1, 16, 1} : TileCfg{1, 4, 2, 1, 16, 1};
     else if (d->Cout > 16) t = TileCfg{2, 2, 2, 1, 16, 0};
     else t = TileCfg{4, 1, 1, 1, 16, 0};
@@ -861,11 +867,21 @@ TileCfg choose_tile(const hdrsky_conv_desc* d) {
     // 7x7 halo planes, so that mode streams the weights per wave as well
     if (M >= 65536) t = (narrow || d->compute == HDRSKY_BF16X3) ? TileCfg{4, 2, 4, 1, 32, 1} : TileCfg{8, 1, 4, 2, 32, 0};
     else t = TileCfg{2, 2, 4, 1, 32, 1};                               // 128 px x 32 ch
+    if (M >= 65536 && !narrow && d->compute != HDRSKY_BF16X3)
+      if (const char* e = getenv("HDRSKY_TILE_C32")) {                 // A/B hook for this class inside the step
+        TileCfg o; o.db = 0;
+        if (sscanf(e, "%d,%d,%d,%d,%d,%d", &o.wm, &o.wn, &o.mi, &o.ni, &o.tw, &o.db) >= 5) t = o;
+      }
   } else {
     // Cout <= 16 (the 3-channel output convs): the 32-wide column block (zero-padded weights) measured
     // faster than the 16-wide one
     if (M >= 65536) t = d->compute == HDRSKY_BF16X3 ? TileCfg{4, 2, 4, 1, 32, 1} : TileCfg{8, 1, 4, 2, 32, 0};
     else t = TileCfg{4, 1, 2, 1, 32, 0};
+    if (M >= 65536 && d->compute != HDRSKY_BF16X3)
+      if (const char* e = getenv("HDRSKY_TILE_C16")) {
+        TileCfg o; o.db = 0;
+        if (sscanf(e, "%d,%d,%d,%d,%d,%d", &o.wm, &o.wn, &o.mi, &o.ni, &o.tw, &o.db) >= 5) t = o;
+      }
   }
   return t;
 }
