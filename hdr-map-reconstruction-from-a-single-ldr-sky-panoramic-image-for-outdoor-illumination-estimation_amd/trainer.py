@@ -1165,11 +1165,17 @@ class Trainer:
                 fn()
             self._graphs[name] = gr
         torch.cuda.synchronize()
+        self._captured = (self._T, self._segs)    # an eager step() / test_step() in between re-binds both (see replay)
         return self._outputs()
 
     def replay(self, update=True, hooks=None, pre_hooks=None):
         """One step from the captured graphs; hooks / pre_hooks: {segment name: callable run on that segment's stream
         after / before it}."""
+        if getattr(self, "_graphs", None) is None:
+            raise RuntimeError("Trainer.replay: capture() first")
+        if self._T is not self._captured[0]:      # an eager pass ran since: the graphs (and outputs()) belong to the captured binding
+            self._T, self._segs = self._captured
+            self._events = {}
         skip = self._skip(update)
         self._execute([n for n, *_ in self._segs if n not in skip], graphs=self._graphs, hooks=hooks, pre_hooks=pre_hooks)
 

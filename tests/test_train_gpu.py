@@ -615,3 +615,27 @@ def test_captured_replays_match_eager_steps(dev, B, mode, da):
                 continue
             a, b = ref[0][o:o + cnt], snap[0][o:o + cnt]
             assert torch.equal(a, b), (it, name)
+
+
+def test_replay_after_an_eager_step_runs_the_captured_binding(dev):
+    """An eager step() between two replays (another batch, another batch size) re-binds the trainer's plan; replay() goes
+    back to the captured binding: same gradients as before the eager pass, bit for bit, and the captured output tensors."""
+    params, synth, trainer, K = pkg("params"), pkg("synth"), pkg("trainer"), pkg("kernels")
+    tr = trainer.Trainer(params.init_params(params.generator_spec(), 0), params.init_params(params.sunpose_spec(), 1),
+                         params.init_params(params.discriminator_spec(), 2), params.init_params(params.vgg_spec(), 3), device=dev)
+    with pytest.raises(RuntimeError):
+        tr.replay()
+    b4, b2 = synth.make_batch(4, seed=77), synth.make_batch(2, seed=78)
+    t = lambda b: tuple(torch.from_numpy(b[k]).to(dev) for k in ("ldr", "hdr_t", "sunpose_gt"))
+    out = tr.capture(*t(b4))
+    state = (tr.gs.flat.clone(), tr.ds.flat.clone())          # (BatchNorm moving statistics move even without an update)
+    tr.replay(update=False)
+    torch.cuda.synchronize()
+    ref = (tr.gs.grad.clone(), tr.ds.grad.clone(), out["y_final_gamma"].clone())
+    eager = tr.step(*t(b2), update=False)
+    assert eager["y_final_gamma"].shape[0] == 2
+    tr.gs.flat.copy_(state[0]); tr.ds.flat.copy_(state[1])
+    tr.replay(update=False)
+    torch.cuda.synchronize()
+    assert tr._outputs()["y_final_gamma"] is out["y_final_gamma"]
+    assert torch.equal(tr.gs.grad, ref[0]) and torch.equal(tr.ds.grad, ref[1]) and torch.equal(out["y_final_gamma"], ref[2])
