@@ -702,10 +702,11 @@ __global__ void __launch_bounds__(256) sun_rad_bwd_kernel(const float* __restric
     const float dxi = dr * g * E * 2.f * d1 / be / D;
     dx[i] = dxi;
     sd += dxi * cmf[i];
-    // the FIRST element of the batch tensor that equals its maximum receives the maximum's gradient (second launch):
-    // n - i is largest there.  (An atomicCAS "first to arrive" claim gave it to any of several tied elements - the
-    // gradients of the sun-pose net then repeated only to round-off.)
-    if (cmf[i] == gmax) atomicMax(claimed, n - (int)i);
+    // every element of the batch tensor that equals its maximum receives an equal share of the maximum's gradient
+    // (second launch) - tf.reduce_max's gradient (indicators / num_selected) - so the tied elements are counted here: an
+    // integer count, the same whatever order the blocks arrive in.  (An atomicCAS "first to arrive" claim gave the whole
+    // term to any one of several tied elements - the gradients of the sun-pose net then repeated only to round-off.)
+    if (cmf[i] == gmax) atomicAdd(claimed, 1);
   }
   sg = wave_sum(sg); sb = wave_sum(sb); sd = wave_sum(sd);
   if ((threadIdx.x & 63) == 0) { sred[0][threadIdx.x >> 6] = sg; sred[1][threadIdx.x >> 6] = sb; sred[2][threadIdx.x >> 6] = sd; }
@@ -719,8 +720,8 @@ __global__ void __launch_bounds__(256) sun_rad_bwd_kernel(const float* __restric
   }
 }
 
-// dcmf (+)= dx/gmax, and at the (first) arg-max element of the whole batch: -= sum_b dotx[b] / gmax^2
-// (tf.reduce_max over the batch tensor, generator.py:160)
+// dcmf (+)= dx/gmax, and at the arg-max element(s) of the whole batch: -= sum_b dotx[b] / gmax^2 / (number of them)
+// (tf.reduce_max over the batch tensor, generator.py:160; ties share the gradient evenly as in TF's _MinOrMaxGrad)
 __global__ void sun_rad_bwd_cmf_kernel(const float* __restrict__ cmf, const unsigned int* gmax_bits,
                                        const float* __restrict__ dx, const float* __restrict__ dotx, int B, int P,
                                        const int* __restrict__ claimed, float* __restrict__ dcmf) {
@@ -728,10 +729,11 @@ __global__ void sun_rad_bwd_cmf_kernel(const float* __restrict__ cmf, const unsi
   float tot = 0.f;
   for (int b = 0; b < B; ++b) tot += dotx[b];
   const size_t n = (size_t)B * P;
-  const size_t first = n - (size_t)*claimed;        // (index n when nothing equals gmax: never matches)
+  const int ties = *claimed;
+  const float share = ties > 0 ? tot / (gmax * gmax) / (float)ties : 0.f;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     float g = dx[i] / gmax;
-    if (i == first) g -= tot / (gmax * gmax);
+    if (cmf[i] == gmax) g -= share;
     dcmf[i] += g;
   }
 }
@@ -1135,7 +1137,7 @@ int hdrsky_decoder_tail_bwd(const float* y, const float* res, const float* dy, s
   return HDRSKY_OK;
 }
 
-/* scratch: B*P + B floats + 1 int (claimed flag, zeroed here); dcmf is accumulated into */
+/* scratch: B*P + B floats + 1 int (count of the elements equal to the maximum, zeroed here); dcmf is accumulated into */
 int hdrsky_sun_rad_bwd(const float* cmf, const void* gmax_bits, const float* gamma, const float* beta, const float* drg3,
                        int B, int P, float* scratch, float* dpre, float* dcmf, void* stream) {
   if (!cmf || !gmax_bits || !gamma || !beta || !drg3 || !scratch || !dpre || !dcmf || (size_t)B * P > 0x7fffffffu) return HDRSKY_EINVAL;

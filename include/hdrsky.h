@@ -308,7 +308,8 @@ int hdrsky_blend_bwd(const float* y_gamma, const float* alpha, const float* dyg,
 /* Backward of y = relu(res + lrelu(c,0.1)) (generator.py:119-124,151-155): dc and (nullable) dres. */
 int hdrsky_decoder_tail_bwd(const float* y, const float* res, const float* dy, size_t n, float* dc, float* dres, void* stream);
 /* Backward of hdrsky_sun_rad: dpre[B][2] (pre-sigmoid gamma/beta), dcmf += (incl. the batch reduce_max term,
- * generator.py:160).  scratch: B*P + B floats + 1 int. */
+ * generator.py:160: elements tied for the maximum share its gradient evenly, as tf.reduce_max's gradient does - counted
+ * with integer atomics, so the result does not depend on the order of arrival).  scratch: B*P + B floats + 1 int. */
 int hdrsky_sun_rad_bwd(const float* cmf, const void* gmax_bits, const float* gamma, const float* beta, const float* drg3, int B, int P, float* scratch, float* dpre, float* dcmf, void* stream);
 /* Backward of the two Dense(1) heads: dact (wrt the activated flatten), dkg/dkb/dbg/dbb accumulated. */
 int hdrsky_dense_heads_bwd(const float* x, const float* scale, const float* shift, float slope, int B, int F, int C, const float* kg, const float* kb, const float* dpre, float* dact, float* dkg, float* dkb, float* dbg, float* dbb, void* stream);

@@ -240,6 +240,52 @@ def test_pad_channels_zero_word_and_cam_from_the_gradient_map(dev):
     assert_close(got, expect, 1e-4, "cam formula")
 
 
+@pytest.mark.parametrize("ties", [1, 3])
+def test_sun_rad_bwd_shares_the_maximum_gradient_among_ties(dev, ties):
+    """generator.py:160 divides the cmf by tf.reduce_max over the whole batch tensor; TF's gradient of reduce_max
+    (_MinOrMaxGrad: indicators / num_selected) gives every element equal to the maximum an equal share - torch's full-reduce
+    max does the same, so autograd through the formula of sunrad_net.py:55-69 + the log compression is the reference."""
+    import math
+    K = pkg("kernels")
+    rng = np.random.default_rng(31)
+    B, H, W = 3, 8, 16
+    P = H * W
+    cmf = rng.uniform(0.0, 0.01, (B, P)).astype(np.float32)
+    top = np.float32(0.0371)
+    for b, p in [(1, 9), (0, 5), (2, 100)][:ties]:
+        cmf[b, p] = top
+    pre = rng.standard_normal((B, 2)).astype(np.float32)
+    drg3 = rng.standard_normal((B, H, W, 3)).astype(np.float32)
+    # reference: torch autograd
+    c = torch.from_numpy(cmf).double().requires_grad_(True)
+    pr = torch.from_numpy(pre).double().requires_grad_(True)
+    gam, bet = torch.sigmoid(pr[:, 0]).view(B, 1), torch.sigmoid(pr[:, 1]).view(B, 1)
+    x = c / c.max()
+    const = float(torch.sqrt(torch.tensor(math.pi, dtype=torch.float32)))
+    y = torch.exp(-(1.0 - x) ** 2 / (bet + 1e-5)) * gam / (bet * const + 1e-5)
+    y = torch.where(y > 30000.0, torch.full_like(y, 30000.0), y)
+    rg = torch.log(1.0 + 10.0 * y) / math.log(11.0)
+    (rg.view(B, H, W, 1) * torch.from_numpy(drg3).double()).sum().backward()
+    # kernel
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    gmax = d(np.array([top]).view(np.int32))
+    g32 = torch.sigmoid(torch.from_numpy(pre[:, 0])).view(B, 1, 1, 1).to(dev)
+    b32 = torch.sigmoid(torch.from_numpy(pre[:, 1])).view(B, 1, 1, 1).to(dev)
+    runs = []
+    for _ in range(2):
+        dcmf = torch.zeros((B, P), dtype=torch.float32, device=dev)
+        dpre = K.sun_rad_bwd(d(cmf), gmax, g32, b32, d(drg3), dcmf)
+        runs.append((dcmf, dpre))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    ref = c.grad
+    scale = float(ref.abs().max())
+    assert float((runs[0][0].double().cpu() - ref).abs().max()) <= 1e-4 * scale
+    sel = torch.from_numpy(cmf == top)
+    assert int(sel.sum()) == ties
+    assert float((runs[0][0].cpu()[sel].double() - ref[sel]).abs().max()) <= 1e-4 * scale      # the shares themselves
+    assert_close(runs[0][1], pr.grad.float(), 1e-4, "dpre")
+
+
 def test_three_grad_cam_maps_in_one_launch_equal_three_launches(dev):
     """grad_cam.py:52-60: the maps of the three layers; the sweep issues them as one launch (hdrsky_grad_cam3)."""
     K = pkg("kernels")

@@ -598,7 +598,7 @@ def test_captured_replays_match_eager_steps(dev, B, mode, da):
         del spare
     # gradient-only replays from a restored state: the same gradients every time, bit for bit.  (This caught the gradient
     # of the batch-global maximum, generator.py:160, going to whichever of several TIED maximal elements a thread claimed
-    # first: hdrsky_sun_rad_bwd now gives it to the first one in memory order.)
+    # first: hdrsky_sun_rad_bwd now counts the tied elements and gives each an equal share, tf.reduce_max's gradient.)
     w0g, w0d = tc.gs.flat.clone(), tc.ds.flat.clone()
     ref = None
     for it in range(3):
