@@ -162,8 +162,10 @@ def parity_object(torch, engine, K, gen, sun, ldr, hdr):
             "the two compute modes is what the 0.05 dB clause bounds"}
 
 
-def cpu_baseline(torch, workload, nets_np, batch_np, budget_s=12.0):
-    """CPU restatement (oracle/, NOT TensorFlow) of the same workload on this host's cores: bounded sample."""
+def cpu_baseline(torch, workload, nets_np, batch_np, budget_s=24.0, iters=20, warmups=3):
+    """CPU restatement (oracle/, NOT TensorFlow) of the same workload on this host's cores, BASELINE.md's protocol (3
+    warm-ups, median of >= 20 iterations) on a BOUNDED sample: the sample batch is halved from the bench batch until
+    warm-ups + iterations fit the time budget (a full batch-32 training step takes ~5 s on the CPU)."""
     from oracle import step as ostep
     tt = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}
     gen, sun, dis, vgg = (tt(d) for d in nets_np)
@@ -174,16 +176,24 @@ def cpu_baseline(torch, workload, nets_np, batch_np, budget_s=12.0):
     else:
         fn = lambda n: ostep.train_step_grads(gen, sun, dis, vgg, ldr[:n], hdr[:n], gt[:n])
         what = "oracle/step.train_step_grads (forward + both backward passes; optimizer excluded)"
-    fn(2)  # warm-up
-    t0 = time.perf_counter()
-    n = 0
-    while time.perf_counter() - t0 < budget_s:
-        fn(ldr.shape[0])
-        n += ldr.shape[0]
-    dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d images (batches of %d) of the same synthetic workload through %s "
-                      "(torch-CPU fp32 restatement, not TF2), %.1f s" % (n, ldr.shape[0], what, dt)}
+    n = int(ldr.shape[0])
+    t_start = time.perf_counter()
+    while True:                     # first warm-up doubles as the probe that sizes the sample
+        t0 = time.perf_counter(); fn(n); t1 = time.perf_counter() - t0
+        if n == 1 or t1 * (iters + warmups - 1) <= budget_s:
+            break
+        n = max(1, n // 2)
+    for _ in range(warmups - 1):
+        fn(n)
+    times = []
+    for _ in range(iters):
+        t0 = time.perf_counter(); fn(n); times.append(time.perf_counter() - t0)
+    times.sort()
+    med = 0.5 * (times[(iters - 1) // 2] + times[iters // 2])
+    return {"value": round(n / med, 2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "median of %d iterations after %d warm-ups, batches of %d images of the same synthetic workload through "
+                      "%s (torch-CPU fp32 restatement, not TF2); %.1f s in all" % (iters, warmups, n, what,
+                                                                                   time.perf_counter() - t_start)}
 
 
 def timed(torch, dist, one_step, steps, warmup, dp, dev):
@@ -422,7 +432,7 @@ def main():
                 if do_train:
                     res["cpu_baseline"] = cpu_baseline(torch, "train", nets_np, batch_np)
                     if do_fwd:
-                        res["cpu_baseline_fwd"] = cpu_baseline(torch, "fwd", nets_np, batch_np, budget_s=6.0)
+                        res["cpu_baseline_fwd"] = cpu_baseline(torch, "fwd", nets_np, batch_np, budget_s=8.0)
                 else:
                     res["cpu_baseline"] = cpu_baseline(torch, "fwd", nets_np, batch_np)
         print(json.dumps(res))

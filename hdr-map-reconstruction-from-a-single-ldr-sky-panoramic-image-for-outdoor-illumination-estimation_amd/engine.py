@@ -94,6 +94,8 @@ class Nets:
     def repack_all(self):
         g, s = self.gen, self.sun
         pk = self.pk
+        for key in [k for k in pk if k.rsplit(".", 1)[-1][:2] == "da" and k.rsplit(".", 1)[-1][2:].isdigit()]:
+            del pk[key]                           # channel-padded images (da_pk): rebuilt from the current weights on demand
         for name in (["conv1_d", "conv2_d", "conv3_d", "conv1_f", "conv1_u"] +
                      ["res.%d.conv%d" % (i, j) for i in range(6) for j in (1, 2)]) if g is not None else ():
             pk["gen." + name] = PackedConv(g[name + ".w"], self.precise)

@@ -919,6 +919,13 @@ def _xtdy_ws(M, Kd, N, device):
     return torch.empty(n, dtype=torch.uint8, device=device)
 
 
+def fc_xtdy_supported(Kd, N):
+    """Shapes hdrsky_fc_wgrad_bf16 / hdrsky_rmsprop_fc_fused take (csrc/fc_update.hip shapes_ok: 32-row k tiles, 256-column
+    workgroups).  im_height * im_width is only guaranteed to be a multiple of 64 (both multiples of 8): callers fall back to
+    hdrsky_fc_wgrad + hdrsky_rmsprop_fc for the other sizes."""
+    return Kd % 32 == 0 and N % 256 == 0 and Kd * N < (1 << 30)
+
+
 def fc_wgrad_bf16(x, dy, dw, db, accumulate=False):
     """Dense weight / bias gradient on the matrix cores (bf16 operands, fp32 accumulation) - any number of rows."""
     (M, Kd), N = x.shape, dy.shape[1]

@@ -141,7 +141,7 @@ class GradientExchange:
         if tr.fused_dense:
             return     # the Dense optimizer launch contracts the gathered rows itself (Trainer.dense_operands = views)
         flat, df1, f1, dz = views
-        if tr.precise:
+        if not tr.dense_mfma:
             K.fc_wgrad(f1.contiguous(), dz.contiguous(), g["sun.fc2.kernel"], g["sun.fc2.bias"])
             K.fc_wgrad(flat.contiguous(), df1.contiguous(), g["sun.fc1.kernel"], g["sun.fc1.bias"])
         else:
@@ -156,8 +156,10 @@ class GradientExchange:
             tr = self.tr
             widths = [tr.fc1.K, tr.fc1.N, tr.fc2.K, tr.fc2.N]
             dev = tr.gs.flat.device
-            local = torch.empty((B, sum(widths)), dtype=torch.float32, device=dev)
-            allp = torch.empty((self.world * B, sum(widths)), dtype=torch.float32, device=dev)
+            # zeros, not empty: Trainer.capture's warm-up steps run without the exchange hooks, i.e. the fused Dense update
+            # contracts these rows before any all-gather has filled them (its effect is undone afterwards - it must be finite)
+            local = torch.zeros((B, sum(widths)), dtype=torch.float32, device=dev)
+            allp = torch.zeros((self.world * B, sum(widths)), dtype=torch.float32, device=dev)
             o = [0]
             for wd in widths:
                 o.append(o[-1] + wd)

@@ -98,6 +98,26 @@ def gamma_crf(n_curves=1, k=1024, gamma=2.2):
     return np.tile((x ** (1.0 / gamma)).astype(np.float32)[None], (n_curves, 1))
 
 
+def load_dorf(path, n_train=175):
+    """utils.getDoRF (utils.py:105-116): `dorfCurves.txt` holds six lines per camera response curve - name, type, a label
+    and the irradiance samples, a label and the BRIGHTNESS samples; the sixth line of every record (index 5) is the
+    response curve as k whitespace-separated floats.  The first 175 curves train, the rest (26 in the published file)
+    test.  Returns (train [n,k] float32, test [m,k] float32)."""
+    with open(path, "r") as f:
+        lines = [ln.strip() for ln in f.readlines()]
+    rows = [lines[i + 5].split() for i in range(0, len(lines) - 5, 6)]
+    if not rows or len({len(r) for r in rows}) != 1:
+        raise ValueError("%s: not a DoRF curve file (six lines per curve, the sixth holding its samples)" % path)
+    crf = np.asarray(rows, dtype=np.float32)
+    return crf[:n_train], crf[n_train:]
+
+
+def pick_crf(curves, batch, seed):
+    """train.py:58: one response curve per sample, drawn uniformly from the list."""
+    idx = np.random.default_rng(int(seed) ^ 0x5EED).integers(0, len(curves), size=batch)
+    return np.ascontiguousarray(curves[idx])
+
+
 def make_batch_device(batch, h=32, w=128, seed=1234, device="cuda", crf=None, jpeg=True):
     """The same synthetic distribution as make_batch, produced on the GPU: analytic sky-dome + sun lobe (torch ops on
     the device - test/bench plumbing), then the reference's augmentation and target construction in libhdrsky
@@ -127,6 +147,8 @@ def make_batch_device(batch, h=32, w=128, seed=1234, device="cuda", crf=None, jp
     n_c = torch.randn(batch, h, w, 3, device=dev, generator=g)
     if crf is None:
         crf = torch.from_numpy(gamma_crf(batch)).to(dev)
+    elif isinstance(crf, np.ndarray):      # a curve list (load_dorf): one curve per sample (train.py:58)
+        crf = torch.from_numpy(pick_crf(crf, batch, seed)).to(dev)
     hdr_t, ldr = K.ldr_synth(img, t, sigma_s.contiguous(), sigma_c.contiguous(), n_s, n_c, crf)
     if jpeg:
         K.jpeg_roundtrip(ldr, order="bgr", out=ldr)

@@ -33,7 +33,8 @@ def main(argv=None):
     ap.add_argument("--imwidth", type=int, default=128)
     ap.add_argument("--sky", type=str, default=os.path.join(cwd, "checkpoints/SKY"))
     ap.add_argument("--sun", type=str, default=os.path.join(cwd, "checkpoints/SUN"))
-    ap.add_argument("--dorf", type=str, default=None)
+    ap.add_argument("--dorf", type=str, default=None,
+                    help="dorfCurves.txt (utils.getDoRF): camera response curves of the LDR synthesis; default: a 1/2.2 gamma")
     ap.add_argument("--vgg", type=str, default=None)
     ap.add_argument("--logdir", type=str, default=cwd,
                     help="TensorBoard scalars go to <logdir>/tensorboard/SKY/<timestamp>/train (tf_utils.py:282-292)")
@@ -57,6 +58,12 @@ def main(argv=None):
     torch.cuda.set_device(dev)
     rank, world, _ = par.init_from_env(device=dev)
     h, w = args.imheight, args.imwidth
+    crf_train = crf_test = None
+    if args.dorf:                    # utils.py:105-116, train.py:140-141: the first 175 curves train, the rest validate
+        if args.host_synth:
+            raise SystemExit("--dorf needs the device-side LDR synthesis (drop --host-synth)")
+        crf_train, crf_test = synth.load_dorf(args.dorf)
+        crf_test = crf_test if len(crf_test) else crf_train
     gen = P.init_params(P.generator_spec(h, w), 0)
     sun = P.init_params(P.sunpose_spec(h, w), 1)
     dis = P.init_params(P.discriminator_spec(), 2)
@@ -92,7 +99,7 @@ def main(argv=None):
                 b = synth.make_batch(args.batchsize, h, w, seed=seed)
                 ldr, hdr, gt = (torch.from_numpy(b[k]).to(dev) for k in ("ldr", "hdr_t", "sunpose_gt"))
             else:   # augmentation + target construction of train.py:42-94 on the GPU
-                b = synth.make_batch_device(args.batchsize, h, w, seed=seed, device=dev)
+                b = synth.make_batch_device(args.batchsize, h, w, seed=seed, device=dev, crf=crf_train)
                 ldr, hdr, gt = b["ldr"], b["hdr_t"], b["sunpose_gt"]
             if args.no_graph:
                 out = tr.step(ldr, hdr, gt, update=False)
@@ -133,7 +140,8 @@ def main(argv=None):
         if args.val_steps > 0:        # train.py:491-506: test_step over the validation split, same tags, `val` writer
             vacc = torch.zeros(len(LOSS_SLOTS), dtype=torch.float32, device=dev)
             for it in range(args.val_steps):
-                vb = synth.make_batch_device(args.batchsize, h, w, seed=(7_000_003 + epoch * 1009 + it) * world + rank, device=dev)
+                vb = synth.make_batch_device(args.batchsize, h, w, seed=(7_000_003 + epoch * 1009 + it) * world + rank, device=dev,
+                                              crf=crf_test)
                 tr.test_step(vb["ldr"], vb["hdr_t"], vb["sunpose_gt"])
                 vacc += tr.losses
             vv = dict(zip(LOSS_SLOTS, (vacc / args.val_steps).tolist()))

@@ -36,7 +36,8 @@ def main(argv=None):
     ap.add_argument("--epochs", type=int, default=1000)
     ap.add_argument("--imheight", type=int, default=32)
     ap.add_argument("--imwidth", type=int, default=128)
-    ap.add_argument("--dorf", type=str, default=None)
+    ap.add_argument("--dorf", type=str, default=None,
+                    help="dorfCurves.txt (utils.getDoRF): camera response curves of the LDR synthesis; default: a 1/2.2 gamma")
     ap.add_argument("--sun", type=str, default=os.path.join(cwd, "checkpoints/SUN"))
     ap.add_argument("--steps-per-epoch", type=int, default=8, help="synthetic mode: steps per epoch")
     ap.add_argument("--distortion-aware", action="store_true",
@@ -50,6 +51,11 @@ def main(argv=None):
     torch.cuda.set_device(dev)
     rank, world, _ = par.init_from_env(device=dev)
     h, w = args.imheight, args.imwidth
+    crf_train = None
+    if args.dorf:                    # utils.py:105-116 (the script's `args.dorfpath`, train_sun.py:167, is this flag)
+        if args.host_synth:
+            raise SystemExit("--dorf needs the device-side LDR synthesis (drop --host-synth)")
+        crf_train = synth.load_dorf(args.dorf)[0]
     sun = P.init_params(P.sunpose_spec(h, w), 1)
     mgr = ckpt.CheckpointManager(args.sun)
     tensors, epoch0 = mgr.restore()
@@ -74,7 +80,7 @@ def main(argv=None):
                 b = synth.make_batch(args.batchsize, h, w, seed=seed)
                 ldr, gt = torch.from_numpy(b["ldr"]).to(dev), torch.from_numpy(b["sunpose_gt"]).to(dev)
             else:
-                b = synth.make_batch_device(args.batchsize, h, w, seed=seed, device=dev)
+                b = synth.make_batch_device(args.batchsize, h, w, seed=seed, device=dev, crf=crf_train)
                 ldr, gt = b["ldr"], b["sunpose_gt"]
             tr.step(ldr, gt, update=False, want_cams=False)
             par.allreduce_sum_([tr.gs.grad])

@@ -117,7 +117,11 @@ class Trainer:
         # RMSprop launch recomputes x^T dy tile by tile (hdrsky_rmsprop_fc_fused).  gs.g["sun.fc*.kernel"] then holds
         # nothing of that step; step(update=False) / replay(update=False) materialise them as before.  A data-parallel
         # driver that all-reduces gradients switches this off; one that gathers the operands sets `dense_operands`.
-        self.fused_dense = bool(fused_dense) and compute == BF16 and not precise
+        # (the matrix-core Dense gradient wants N = im_height * im_width in multiples of 256: other sizes keep the fp32 FMA
+        # weight gradient + the plain Dense RMSprop)
+        hw = im_height * im_width
+        self.dense_mfma = compute == BF16 and not precise and K.fc_xtdy_supported(hw // 64 * 128, hw) and K.fc_xtdy_supported(hw, hw)
+        self.fused_dense = bool(fused_dense) and self.dense_mfma
         self.dense_operands = None          # (flat, df1, f1, dz) of the GLOBAL batch, set by parallel.GradientExchange
         self.on_bind = None                 # callable(B) run when a step is bound to a batch (static exchange buffers)
         named = OrderedDict(("gen." + k, v) for k, v in gen_params.items())
@@ -218,8 +222,9 @@ class Trainer:
     RESCONV_NORMS = ("sun.sunlayer3.norm1", "sun.sunlayer3.norm2")
 
     def _sun3_ok(self):
-        return self.compute == BF16 and not self.precise and K.resconv_supported(self.h // 4, self.w // 4, 64, 128) and \
-            os.environ.get("HDRSKY_SUN3", "0") == "1"
+        # (mirrors the forward's condition: a distortion-aware sun-pose net never takes the sample-resident launches)
+        return self.compute == BF16 and not self.precise and not self.da_sun and \
+            K.resconv_supported(self.h // 4, self.w // 4, 64, 128) and os.environ.get("HDRSKY_SUN3", "0") == "1"
 
     def _norm_state(self, B):
         st = getattr(self, "_nstate", None)
@@ -974,7 +979,7 @@ class Trainer:
         def _():
             if self.dense_wgrad_external:
                 return
-            fn = K.fc_wgrad if self.precise else K.fc_wgrad_bf16
+            fn = K.fc_wgrad_bf16 if self.dense_mfma else K.fc_wgrad
             fn(T["t"]["f1"], T["dz"], g["sun.fc2.kernel"], g["sun.fc2.bias"])
             fn(T["t"]["flat"], T["df1"], g["sun.fc1.kernel"], g["sun.fc1.bias"])
 
@@ -1203,6 +1208,8 @@ class SunPoseTrainer(Trainer):
         self.lr, self.compute, self.precise, self.world = lr, compute, precise, world_size
         # distortion_aware: sunpose_net.py:11,16 - every sunposeLayer convolution is distortion_aware_ops.conv2d
         self.da_sun, self._da_geo = bool(distortion_aware), {}
+        hw = im_height * im_width
+        self.dense_mfma = compute == BF16 and not precise and K.fc_xtdy_supported(hw // 64 * 128, hw) and K.fc_xtdy_supported(hw, hw)
         self.gs = FlatParams(OrderedDict(("sun." + k, v) for k, v in sun_params.items()), self.device)
         self.adam_m, self.adam_v = torch.zeros_like(self.gs.grad), torch.zeros_like(self.gs.grad)
         self.steps_done = 0
@@ -1231,7 +1238,7 @@ class SunPoseTrainer(Trainer):
         if dog_weight != 0.0:
             K.dog_loss(pred, gt_img, float(dog_weight), self.losses[1:2], dcmf.view(B, self.h, self.w, 1))
         dz = K.softmax_bwd(t["cmf"], dcmf, t["z"])
-        fc_wgrad = K.fc_wgrad if self.precise else K.fc_wgrad_bf16
+        fc_wgrad = K.fc_wgrad_bf16 if self.dense_mfma else K.fc_wgrad
         fc_wgrad(t["f1"], dz, g["sun.fc2.kernel"], g["sun.fc2.bias"])
         df1 = K.fc_finalize(K.fc_dgrad(dz, self.fc2, cp), None, relu=False, mask_src=t["f1"])
         fc_wgrad(t["flat"], df1, g["sun.fc1.kernel"], g["sun.fc1.bias"])

@@ -60,3 +60,27 @@ def test_load_into_accepts_the_object_graph_attribute_spelling():
         got = P.init_params(spec, 6)
         assert ck.load_into(got, tensors, "gen_model") == len(spec)
         assert all(np.array_equal(got[k], ref[k]) for k in ref)
+
+
+def test_dorf_curve_file_is_parsed_like_getDoRF(tmp_path):
+    """utils.getDoRF (utils.py:105-116): six lines per curve, the sixth holds the response samples; first 175 train."""
+    synth = pkg("synth")
+    rng = np.random.default_rng(3)
+    k, n = 16, 9
+    curves = np.sort(rng.uniform(0, 1, (n, k)).astype(np.float32), axis=1)
+    curves[:, 0], curves[:, -1] = 0.0, 1.0
+    p = os.path.join(str(tmp_path), "dorfCurves.txt")
+    with open(p, "w") as f:
+        for i, c in enumerate(curves):
+            f.write("curve%d\nsRGB\nI =\n%s\nB =\n  %s  \n" % (i, " ".join("%.6f" % v for v in np.linspace(0, 1, k)),
+                                                          "   ".join("%.8f" % v for v in c)))
+    tr, te = synth.load_dorf(p, n_train=6)
+    assert tr.shape == (6, k) and te.shape == (3, k) and tr.dtype == np.float32
+    np.testing.assert_allclose(np.concatenate([tr, te]), curves, atol=1e-7)
+    pick = synth.pick_crf(tr, 32, seed=11)
+    assert pick.shape == (32, k) and all(any(np.array_equal(r, c) for c in tr) for r in pick)
+    assert np.array_equal(pick, synth.pick_crf(tr, 32, seed=11))           # seeded
+    with open(p, "a") as f:
+        f.write("x\ny\nI =\n0 1\nB =\n0 0.5 1\n")                           # a curve of another length: rejected
+    with pytest.raises(ValueError):
+        synth.load_dorf(p)
