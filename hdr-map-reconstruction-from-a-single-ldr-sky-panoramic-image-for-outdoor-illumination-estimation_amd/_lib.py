@@ -47,9 +47,14 @@ class ResconvArgs(ctypes.Structure):
 
 RC_FWD, RC_BWD = 0, 1
 
+ABI_VERSION = 3      # HDRSKY_ABI_VERSION of the include/hdrsky.h these mirrors were written against
+STRUCTS = {"hdrsky_conv_desc": ConvDesc, "hdrsky_wgrad_job": WgradJob, "hdrsky_resconv_args": ResconvArgs}
+
 # name -> (restype, argtypes); every symbol include/hdrsky.h declares
 SIGNATURES = {
     "hdrsky_version": (ctypes.c_char_p, []),
+    "hdrsky_abi_version": (c_int, []),
+    "hdrsky_sizeof": (c_size_t, [ctypes.c_char_p]),
     "hdrsky_conv_desc_init": (c_int, [ctypes.POINTER(ConvDesc)] + [c_int] * 10),
     "hdrsky_conv_desc_init_dgrad": (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvDesc)]),
     "hdrsky_conv_packed_elems": (c_size_t, [c_int] * 4),
@@ -159,6 +164,14 @@ def load():
         fn = getattr(lib, name)  # AttributeError -> symbol missing: fail loudly
         fn.restype = res
         fn.argtypes = args
+    # struct-layout contract: a mirror that is smaller than the library's structure would be overrun by the *_init calls
+    if lib.hdrsky_abi_version() != ABI_VERSION:
+        raise RuntimeError("libhdrsky.so speaks ABI %d, this binding %d - rebuild the library (make -C csrc)" %
+                           (lib.hdrsky_abi_version(), ABI_VERSION))
+    for cname, mirror in STRUCTS.items():
+        if lib.hdrsky_sizeof(cname.encode()) != ctypes.sizeof(mirror):
+            raise RuntimeError("%s: the library's layout has %d bytes, the ctypes mirror %d" %
+                               (cname, lib.hdrsky_sizeof(cname.encode()), ctypes.sizeof(mirror)))
     _lib = lib
     return lib
 

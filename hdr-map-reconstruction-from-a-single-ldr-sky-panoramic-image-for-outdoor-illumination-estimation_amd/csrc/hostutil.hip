@@ -39,3 +39,13 @@ extern "C" unsigned int hdrsky_crc32c(const void* data, size_t n, unsigned int c
   while (n--) c = g_tab[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
   return ~c;
 }
+
+extern "C" int hdrsky_abi_version(void) { return HDRSKY_ABI_VERSION; }
+
+extern "C" size_t hdrsky_sizeof(const char* name) {
+  if (!name) return 0;
+  if (!std::strcmp(name, "hdrsky_conv_desc")) return sizeof(hdrsky_conv_desc);
+  if (!std::strcmp(name, "hdrsky_wgrad_job")) return sizeof(hdrsky_wgrad_job);
+  if (!std::strcmp(name, "hdrsky_resconv_args")) return sizeof(hdrsky_resconv_args);
+  return 0;
+}

@@ -45,6 +45,17 @@ extern "C" {
 
 const char* hdrsky_version(void);
 
+/* Struct-layout contract of this header.  hdrsky_sizeof("hdrsky_conv_desc" | "hdrsky_wgrad_job" |
+ * "hdrsky_resconv_args") = sizeof of that structure as the LIBRARY was compiled (0: unknown name);
+ * HDRSKY_ABI_VERSION is bumped whenever a structure or a signature changes (hdrsky_abi_version() returns
+ * the library's).  A binding checks both once at load time - the library itself cannot see the caller's
+ * layout, and a structure that grew (round 2: hdrsky_conv_desc 25 -> 29 fields) would otherwise be
+ * written past the end of a stale mirror by hdrsky_conv_desc_init.  (The reference has no FFI: SURVEY.md
+ * section 8b; this is the convention a ctypes / cffi binding needs.) */
+#define HDRSKY_ABI_VERSION 3
+int hdrsky_abi_version(void);
+size_t hdrsky_sizeof(const char* struct_name);
+
 /* ------------------------------------------------------------------------------------------
  * Convolution family.  Replaces:
  *   ops.conv2d.call            ops.py:41-42     tf.nn.conv2d(x, w, [1,s,s,1], 'SAME') + bias_add

@@ -55,3 +55,61 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         assert "no CPU/PyTorch fallback" in str(e)
     else:
         raise AssertionError("load() must raise when libhdrsky.so is absent")
+
+
+def _header_struct_fields(name):
+    """[(ctype, field)] of `typedef struct name {...}` in include/hdrsky.h (comments stripped)."""
+    text = open(os.path.join(ROOT, "include", "hdrsky.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), text, flags=re.S).group(1)
+    out = []
+    for decl in body.split(";"):
+        decl = " ".join(decl.split())
+        if not decl:
+            continue
+        m = re.match(r"(.*?)([A-Za-z_][A-Za-z0-9_]*(?:\s*,\s*\**\s*[A-Za-z_][A-Za-z0-9_]*)*)$", decl)
+        ctype, names = m.group(1).strip(), [n.strip() for n in m.group(2).split(",")]
+        for n in names:
+            out.append((ctype + ("*" if n.startswith("*") else ""), n.lstrip("* ")))
+    return out
+
+
+def test_struct_layouts_match_the_library_and_the_header():
+    """The layout contract (hdrsky_sizeof / hdrsky_abi_version): every ctypes mirror has the library's size, the field
+    names and order of the header, and load() refuses a mismatching mirror."""
+    L = pkg("_lib")
+    lib = L.load()
+    assert lib.hdrsky_abi_version() == L.ABI_VERSION
+    assert lib.hdrsky_sizeof(b"no_such_struct") == 0
+    for cname, mirror in L.STRUCTS.items():
+        assert lib.hdrsky_sizeof(cname.encode()) == ctypes.sizeof(mirror), cname
+        hdr = _header_struct_fields(cname)
+        assert [n for _, n in hdr] == [n for n, _ in mirror._fields_], cname
+        for (ctype, n), (_, ft) in zip(hdr, mirror._fields_):
+            want = (ctypes.c_void_p if "*" in ctype else {"int": ctypes.c_int32, "int32_t": ctypes.c_int32, "float": ctypes.c_float,
+                                                          "hdrsky_conv_desc": L.ConvDesc}[ctype.replace("const ", "").strip()])
+            assert ft is want, (cname, n, ctype, ft)
+    assert ctypes.sizeof(L.ConvDesc) == 29 * 4
+
+
+def test_integration_md_binding_stub_matches_the_built_library(monkeypatch):
+    """INTEGRATION.md section 2 is what a maintainer copies: its code block is evaluated here (CPU only, nothing is
+    launched) against the built library - its own size assertions run, and hdrsky_conv_desc_init must stay inside
+    the structure it declares (round 2's stub was 16 bytes short)."""
+    L = pkg("_lib")
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = re.search(r"```python\n(# hdrsky_binding\.py.*?)```", text, flags=re.S).group(1)
+    monkeypatch.setenv("HDRSKY_LIB", L.LIB_PATH)
+    ns = {}
+    exec(compile(block, "INTEGRATION.md#2", "exec"), ns)
+    stub = ns["ConvDesc"]
+    assert ctypes.sizeof(stub) == ctypes.sizeof(L.ConvDesc) == ns["lib"].hdrsky_sizeof(b"hdrsky_conv_desc")
+    assert [n for n, _ in stub._fields_] == [n for n, _ in L.ConvDesc._fields_]
+    # a guard word right behind the structure survives the init call
+    class Guarded(ctypes.Structure):
+        _fields_ = [("d", stub), ("guard", ctypes.c_uint32 * 8)]
+    g = Guarded()
+    for i in range(8):
+        g.guard[i] = 0xA5A5A5A5
+    assert ns["lib"].hdrsky_conv_desc_init(ctypes.cast(ctypes.pointer(g), ctypes.POINTER(stub)), 2, 32, 128, 3, 32, 7, 7, 1, 1, 1) == 0
+    assert all(v == 0xA5A5A5A5 for v in g.guard) and (g.d.Ho, g.d.Wo, g.d.pad_t) == (32, 128, 3)
