@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Throughput bench of the hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W            (N=1)
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W            (N = 1: in this process; N > 1: this process starts the N ranks
+                                                            as a child torchrun job and relays rank 0's line)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W      (one rank per GPU, RCCL)
+A rank count that differs from --gpus (WORLD_SIZE, visible devices) is fatal: the line never reports an n_gpus it did not run on.
 
 One "step" = one pass of the workload over one batch of synthetic sky panoramas per GPU (inputs resident in HBM before the
 timed region; the pass is replayed as hipGraphs).  Rank 0 prints ONE JSON line.
@@ -286,14 +288,45 @@ def hires_workload(torch, mods, dev, batch):
     return step, (lambda: state["y"]), fc_row
 
 
+def _free_port():
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` (N > 1) outside a torchrun job: this process - which has not touched the GPU and never
+    will - starts the N ranks as a CHILD `python -m torch.distributed.run --nproc-per-node N bench.py <same flags>`
+    (never an exec: a process that initialised the GPU must not be replaced), relays what rank 0 prints and returns the
+    child's exit code (non-zero as soon as any rank fails).  Fewer than N devices: refuse instead of timing fewer GPUs."""
+    import subprocess
+    import torch                    # device_count() does not initialise the GPU on this image
+    have = torch.cuda.device_count()
+    one_card = os.environ.get("HDRSKY_BENCH_ONE_CARD", "0") == "1"      # rehearsal: every rank on cuda:0 over gloo
+    if have < args.gpus and not one_card:
+        sys.stderr.write("bench.py: --gpus %d asked for, %d GPU(s) visible - refusing to report an n_gpus=%d number from "
+                         "fewer devices\n" % (args.gpus, have, args.gpus))
+        return 2
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:          # a torchrun job of another size than the flag says: never report the wrong n_gpus
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     # HDRSKY_BENCH_FORCE_DP=1 runs the N>1 code path (process group, phase split, overlapped all-reduces) with a
     # single rank, so that path can be rehearsed on a one-GPU box.
     dp = world > 1 or os.environ.get("HDRSKY_BENCH_FORCE_DP", "0") == "1"
@@ -311,7 +344,11 @@ def main():
         torch.cuda.set_device(local)
         kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: process group of %d ranks for --gpus %d" % (dist.get_world_size(), args.gpus))
+        comm_ranks, comm_backend = dist.get_world_size(), ("rccl" if backend == "nccl" else backend)
     else:
+        comm_ranks, comm_backend = 1, None
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local if dp else 0)
 
@@ -326,7 +363,8 @@ def main():
         w = torch.from_numpy(gen["res.0.conv1.w"]).to(dev)
         print(json.dumps(dominant_kernel_roofline(torch, K, K.PackedConv(w, False), batch, 32, 128)))
         return
-    res = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
+    res = {"n_gpus": world, "rccl_ranks": comm_ranks if comm_backend in ("rccl", None) else 0, "comm_backend": comm_backend,
+           "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "bf16"}
     fc_row = None
     if hires:
@@ -345,7 +383,8 @@ def main():
                                    "section 8d): the 12.9 G-parameter sun-pose net is not in the step; its fc1 is timed "
                                    "separately as a weight-streaming GEMM slice (sunpose_fc)" % batch,
                        "per_gpu_batch": batch, "global_batch": batch * world,
-                       "parallelism": "replicas" if world > 1 else "single", "hipgraph": not args.no_graph},
+                       "parallelism": ("replicas x%d (%s barrier only)" % (world, comm_backend)) if world > 1 else "single",
+                       "hipgraph": not args.no_graph},
             "algorithmic_tflops": round(imgs / dt * HIRES_MFLOP_PER_IMG * 1e6 / 1e12, 2)})
     else:
         sun = params.init_params(params.sunpose_spec(), 1)
@@ -388,7 +427,8 @@ def main():
                 "config": {"workload": "BASELINE configs[2]: full train.py step (gen + sunpose + disc + VGG16 perceptual + "
                                        "tone-map/DoG/L1/KL/LSGAN losses, RMSprop x2), batch=%d per GPU, 32x128x3" % batch,
                            "per_gpu_batch": batch, "global_batch": batch * world,
-                           "parallelism": ("dp%d (%s)" % (world, ex.describe())) if world > 1 else "single",
+                           "parallelism": ("dp%d over %s, %d ranks (%s: %s)" % (world, comm_backend, comm_ranks, ex.mode, ex.describe()))
+                                          if world > 1 else "single",
                            "hipgraph": not args.no_graph, "distortion_aware": sorted(engine.da_parts(args.da))},
                 "algorithmic_tflops": round(imgs / dt * TRAIN_MFLOP_PER_IMG * 1e6 / 1e12, 2)})
             del tr, ex, one_step, out
@@ -412,7 +452,8 @@ def main():
                 res.update({"metric": "generator fwd images/sec (32x128 sky panoramas)", "value": fwd["images_per_s"],
                             "unit": "images/s", "ms_per_step": fwd["ms_per_step"], "ms_per_img": fwd["ms_per_img"],
                             "config": {"workload": fwd["workload"], "per_gpu_batch": batch, "global_batch": batch * world,
-                                       "parallelism": "replicas" if world > 1 else "single", "hipgraph": not args.no_graph},
+                                       "parallelism": ("replicas x%d (%s barrier only)" % (world, comm_backend)) if world > 1 else "single",
+                                       "hipgraph": not args.no_graph},
                             "algorithmic_tflops": fwd["algorithmic_tflops"]})
             del one_step, out
     # the single-GPU probes run without a process group (RCCL's communicator closed, the other ranks gone)

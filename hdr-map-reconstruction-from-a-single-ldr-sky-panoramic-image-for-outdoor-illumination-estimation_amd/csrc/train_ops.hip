@@ -796,6 +796,20 @@ __global__ void concat2_kernel(const float* __restrict__ a, int Ca, const float*
   }
 }
 
+// out[m, :] = [s0[m, :w0] | s1[m, :w1] | s2[m, :w2] | s3[m, :w3]]: the four Dense operands of a replica (flat | df1 | f1 | dz)
+// as ONE row block for the all-gather of the gather_dense exchange (parallel.py) - 16-byte copies, widths % 4 == 0
+struct ConcatRows4 { const float4* src[4]; int w4[4]; };
+__global__ void concat_rows4_kernel(ConcatRows4 j, int M, float4* __restrict__ out) {
+  const int W4 = j.w4[0] + j.w4[1] + j.w4[2] + j.w4[3];
+  const size_t n = (size_t)M * W4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t m = i / W4;
+    int c = (int)(i - m * W4), k = 0;
+    while (c >= j.w4[k]) { c -= j.w4[k]; ++k; }
+    out[i] = j.src[k][m * j.w4[k] + c];
+  }
+}
+
 // VGG input: x*255 - mean[c]  (vgg16.py:133-141); backward is a multiply by 255 (folded into the caller's scale)
 __global__ void vgg_pre_kernel(const float* __restrict__ x, size_t n, float* __restrict__ y) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -1183,6 +1197,18 @@ int hdrsky_pad_channels(const float* x, size_t npix, int C, int Cpad, float* out
 int hdrsky_concat2(const float* a, int Ca, const float* b, int Cb, size_t npix, float* out, void* stream) {
   if (!a || !b || !out) return HDRSKY_EINVAL;
   hipLaunchKernelGGL(concat2_kernel, dim3(grid_for(npix * (Ca + Cb))), dim3(256), 0, S_(stream), a, Ca, b, Cb, npix, out);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_concat_rows4(const float* s0, int w0, const float* s1, int w1, const float* s2, int w2, const float* s3, int w3,
+                        int M, float* out, void* stream) {
+  if (!s0 || !s1 || !s2 || !s3 || !out || M <= 0 || w0 <= 0 || w1 <= 0 || w2 <= 0 || w3 <= 0 || ((w0 | w1 | w2 | w3) & 3) ||
+      (((uintptr_t)s0 | (uintptr_t)s1 | (uintptr_t)s2 | (uintptr_t)s3 | (uintptr_t)out) & 15))
+    return HDRSKY_EINVAL;
+  ConcatRows4 j{{(const float4*)s0, (const float4*)s1, (const float4*)s2, (const float4*)s3}, {w0 / 4, w1 / 4, w2 / 4, w3 / 4}};
+  hipLaunchKernelGGL(concat_rows4_kernel, dim3(grid_for((size_t)M * (w0 + w1 + w2 + w3) / 4)), dim3(256), 0, S_(stream), j, M,
+                     (float4*)out);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }

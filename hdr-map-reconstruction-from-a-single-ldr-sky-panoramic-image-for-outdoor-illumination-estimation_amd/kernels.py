@@ -872,6 +872,18 @@ def concat2(a, b, out=None):
     return out
 
 
+def concat_rows4(parts, out):
+    """out [M, sum w_i] = the four [M, w_i] fp32 matrices side by side (one launch; parallel.GradientExchange)."""
+    M = parts[0].shape[0]
+    for t in parts:
+        _f32(t, M, t.shape[1])
+    _f32(out, M, sum(t.shape[1] for t in parts))
+    a, b, c, d = parts
+    L.check(L.load().hdrsky_concat_rows4(_p(a), a.shape[1], _p(b), b.shape[1], _p(c), c.shape[1], _p(d), d.shape[1], M,
+                                         _p(out), _stream()), "concat_rows4")
+    return out
+
+
 def vgg_pre(x):
     y = torch.empty_like(x)
     L.check(L.load().hdrsky_vgg_pre(_p(_f32(x)), x.numel(), _p(y), _stream()), "vgg_pre")

@@ -116,7 +116,7 @@ class GradientExchange:
                 "gather_dense": "Dense gradients recomputed from all-gathered activations; RCCL all-reduce of the rest"}[self.mode]
 
     # ---- payload helpers ------------------------------------------------------------------------------------------
-    def _allreduce(self, t, async_op=False):
+    def _allreduce(self, t):
         if self.mode == "allreduce_bf16":
             key = (t.data_ptr(), t.numel())
             buf = self._gbuf.get(key)
@@ -126,7 +126,8 @@ class GradientExchange:
             dist.all_reduce(buf)
             t.copy_(buf)
             return None
-        return dist.all_reduce(t, async_op=async_op)
+        dist.all_reduce(t)
+        return None
 
     def _dense_gather(self):
         """all-gather (flat | df1 | f1 | dz) of every replica and recompute both Dense weight (and bias) gradients on the
@@ -136,7 +137,7 @@ class GradientExchange:
         T, g = tr._T, tr.gs.g
         parts = [T["t"]["flat"], T["df1"], T["t"]["f1"], T["dz"]]
         local, allp, views = self._dense_buffers(parts[0].shape[0])
-        torch.cat(parts, dim=1, out=local)
+        K.concat_rows4(parts, local)           # one libhdrsky launch (no torch-owned kernel in the step)
         dist.all_gather_into_tensor(allp, local)
         if tr.fused_dense:
             return     # the Dense optimizer launch contracts the gathered rows itself (Trainer.dense_operands = views)
@@ -171,26 +172,41 @@ class GradientExchange:
         # plan is built (and captured), not only when the first gather has run
         self.tr.dense_operands = self._dense_buffers(B)[2] if self.tr.fused_dense else None
 
-    # ---- the two hook points ----------------------------------------------------------------------------------------
+    # ---- the hook points ---------------------------------------------------------------------------------------------
+    # Every collective is enqueued on ONE communication stream, in plan order (identical on every rank): the
+    # discriminator slice behind `disc_step` (it is complete ~1 ms before the end of the backward pass), the Dense slice
+    # / operands behind FC_GRADS_READY, the remaining conv slice behind GRADS_READY.  The compute streams only wait where
+    # they consume the result (apply_fc: the Dense slice; apply: everything).
+    def _on_comm(self, fn, after=None):
+        """Runs fn() (collectives) on the communication stream, ordered behind `after` (an event) or - default - behind
+        everything the current stream has been told to wait for so far."""
+        if after is None:
+            after = torch.cuda.Event()
+            after.record(torch.cuda.current_stream())
+        self.comm.wait_event(after)
+        with torch.cuda.stream(self.comm):
+            fn()
+
     def fc_grads_reduce(self):
         """Dense-layer slice: runs on the communication stream from the moment the slice (or, gather_dense, its operands)
         exists; the CURRENT stream (the Dense optimizer segment's) waits for it."""
         tr = self.tr
-        self.comm.wait_event(tr.event(tr.FC_GRADS_READY))
-        work = None
-        with torch.cuda.stream(self.comm):
-            if self.mode == "gather_dense":
-                self._dense_gather()
-            else:
-                work = self._allreduce(tr.gs.grad[self.fc0:self.fc1], async_op=True)
-        if work is not None:
-            work.wait()
+        if self.mode == "gather_dense":
+            self._on_comm(self._dense_gather, after=tr.event(tr.FC_GRADS_READY))
         else:
-            torch.cuda.current_stream().wait_stream(self.comm)
+            self._on_comm(lambda: self._allreduce(tr.gs.grad[self.fc0:self.fc1]), after=tr.event(tr.FC_GRADS_READY))
+        torch.cuda.current_stream().wait_stream(self.comm)
+
+    def disc_grads_reduce(self):
+        """Hook behind `disc_step` (its weight gradients are flushed inside the segment): the discriminator's 11 MB travel
+        while the generator's backward pass is still running."""
+        self._on_comm(lambda: self._allreduce(self.tr.ds.grad))
 
     def grads_ready(self):
-        self._allreduce(self.tr.gs.grad[:self.fc0])
-        self._allreduce(self.tr.ds.grad)
+        """Hook of the (empty) GRADS_READY segment, whose stream has waited for every gradient producer: the conv slice of
+        the generator / sun-pose optimizer; the optimizer segment behind it waits for the communication stream."""
+        self._on_comm(lambda: self._allreduce(self.tr.gs.grad[:self.fc0]))
+        torch.cuda.current_stream().wait_stream(self.comm)
 
     def reduce_all(self):
         """Eager path: every gradient buffer, on the current stream."""
@@ -198,7 +214,7 @@ class GradientExchange:
             return
         if self.mode == "gather_dense":
             self._dense_gather()
-            self.grads_ready()
+            self._allreduce(self.tr.gs.grad[:self.fc0]); self._allreduce(self.tr.ds.grad)
         elif self.mode == "allreduce_bf16":
             self._allreduce(self.tr.gs.grad); self._allreduce(self.tr.ds.grad)
         else:
@@ -206,7 +222,7 @@ class GradientExchange:
 
     @property
     def hooks(self):
-        return {self.tr.GRADS_READY: self.grads_ready} if self.active else None
+        return {self.tr.DISC_GRADS_READY: self.disc_grads_reduce, self.tr.GRADS_READY: self.grads_ready} if self.active else None
 
     @property
     def pre_hooks(self):

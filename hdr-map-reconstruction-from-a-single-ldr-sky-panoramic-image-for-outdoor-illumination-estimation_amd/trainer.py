@@ -1026,6 +1026,7 @@ class Trainer:
         return segs
 
     GRADS_READY = "grads_ready"                                  # hook point of a data-parallel driver
+    DISC_GRADS_READY = "disc_step"                               # the discriminator's gradients are complete behind it
     APPLY = ("apply_fc", "apply")                                # the optimizer segments
 
     @property

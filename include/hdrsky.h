@@ -344,6 +344,12 @@ int hdrsky_up2x_xf_bf16(const float* x, int B, int H, int W, int C, const float*
                         const float* beta, float eps, float slope, void* y_bf16, void* stream);
 /* tf.concat([a, b], axis=-1) (discriminator.py:43). */
 int hdrsky_concat2(const float* a, int Ca, const float* b, int Cb, size_t npix, float* out, void* stream);
+/* Row-wise concatenation of four [M, w_i] fp32 matrices into out [M, w0+w1+w2+w3] (w_i % 4 == 0, 16-byte aligned
+ * bases): the operand block (flat | df1 | f1 | dz) a data-parallel replica contributes to the all-gather from which
+ * every replica recomputes the Keras Dense kernels' tape.gradient on the global batch (sunpose_net.py:48-51,
+ * train.py:402; <pkg>/parallel.py mode gather_dense). */
+int hdrsky_concat_rows4(const float* s0, int w0, const float* s1, int w1, const float* s2, int w2, const float* s3, int w3,
+                        int M, float* out, void* stream);
 /* x*255 - VGG_MEAN (vgg16.py:133-141). */
 int hdrsky_vgg_pre(const float* x, size_t n, float* y, void* stream);
 /* tf_utils.rgb2bgr / bgr2rgb (tf_utils.py:85-93): channel reversal of npix 3-channel pixels; x == y is allowed. */

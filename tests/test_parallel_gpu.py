@@ -41,12 +41,14 @@ def _shard(rank, dev):
     return [torch.from_numpy(b[k][sl]).to(dev).contiguous() for k in ("ldr", "hdr_t", "sunpose_gt")]
 
 
-def _worker(rank, port, out_dir, mode="allreduce", bf16=False):
-    os.environ.update(RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+def _worker(rank, port, out_dir, mode="allreduce", bf16=False, rccl=False):
+    """rccl=False: both ranks on cuda:0 over gloo (one-GPU test box); rccl=True: rank r on cuda:r over RCCL."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank if rccl else 0), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     P, synth, trainer, K, par = _mods()
-    dev = torch.device("cuda", 0)
+    dev = torch.device("cuda", rank if rccl else 0)
     torch.cuda.set_device(dev)
-    r, world, _ = par.init_from_env(backend="gloo")
+    r, world, _ = par.init_from_env(backend="nccl" if rccl else "gloo", device=dev if rccl else None)
     assert (r, world) == (rank, 2)
     tr = _make_trainer(2, dev, bf16)
     if rank == 1:
@@ -108,6 +110,53 @@ def test_two_replicas_one_card_equal_summed_gradient_step(dev, tmp_path):
     assert rel(r0["gms"], tr.gs.ms.cpu()) < 1e-3
     assert rel(r0["ds"][nt:], tr.ds.flat.cpu()[nt:]) < 1e-5  # BN moving statistics of replica 0
     assert rel(r0["gs"][ng:], tr.gs.flat.cpu()[ng:]) < 1e-5
+
+
+@pytest.mark.parametrize("mode,bf16,tol", [("allreduce", False, 2e-2), ("gather_dense", False, 2e-2), ("gather_dense", True, 2e-2),
+                                           ("allreduce_bf16", False, 8e-2)])
+def test_two_ranks_over_rccl_equal_the_summed_gradient_step(tmp_path, mode, bf16, tol):
+    """The real thing: two ranks on two GPUs, process group on RCCL (backend "nccl"), captured step with the overlapped
+    exchange in every mode; both replicas end bit-identical and equal the single-process step on the summed shard
+    gradients with gscale = 1/2.  Needs two devices: skipped on the one-GPU test box."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("RCCL refuses two ranks on one device: needs >= 2 GPUs (%d visible)" % torch.cuda.device_count())
+    dev = torch.device("cuda", 0)
+    mp.spawn(_worker, args=(_free_port(), str(tmp_path), mode, bf16, True), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), "r%d.pt" % r)) for r in (0, 1))
+    tr = _make_trainer(1, dev, bf16)
+    ng, nt = tr.gs.ntrain, tr.ds.ntrain
+    w0g, w0d = tr.gs.flat.cpu(), tr.ds.flat.cpu()
+    assert torch.equal(r0["gs"][:ng], r1["gs"][:ng]) and torch.equal(r0["ds"][:nt], r1["ds"][:nt]) and torch.equal(r0["gms"], r1["gms"])
+    assert not torch.equal(r0["losses"], r1["losses"])
+    shards = [_shard(r, dev) for r in (0, 1)]
+    for _ in range(2):
+        gsum, dsum = torch.zeros_like(tr.gs.grad), torch.zeros_like(tr.ds.grad)
+        dflat0, gflat0 = tr.ds.flat.clone(), tr.gs.flat.clone()
+        for r in (1, 0):
+            tr.ds.flat.copy_(dflat0); tr.gs.flat.copy_(gflat0)
+            tr.step(*shards[r], update=False)
+            gsum += tr.gs.grad; dsum += tr.ds.grad
+        tr.gs.grad.copy_(gsum); tr.ds.grad.copy_(dsum)
+        tr.apply_gradients(gscale=0.5)
+    torch.cuda.synchronize()
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    eg = rel(r0["gs"][:ng] - w0g[:ng], tr.gs.flat.cpu()[:ng] - w0g[:ng])
+    ed = rel(r0["ds"][:nt] - w0d[:nt], tr.ds.flat.cpu()[:nt] - w0d[:nt])
+    print("RCCL %s bf16=%s: update mismatch gen/sun %.3g disc %.3g" % (mode, bf16, eg, ed))
+    assert eg < tol and ed < tol, (eg, ed)
+
+
+def test_bench_py_gpus2_runs_two_rccl_ranks():
+    """`python bench.py --gpus 2` on a >= 2-GPU box: the parent starts two ranks itself and the line says n_gpus 2 over RCCL."""
+    import json
+    import subprocess
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload",
+                        "train", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["comm_backend"] == "rccl" and line["value"] > 0
 
 
 @pytest.mark.parametrize("mode,tol", [("gather_dense", 2e-3), ("allreduce_bf16", 6e-2)])
@@ -178,3 +227,16 @@ def test_train_cli_two_ranks_one_card(dev, tmp_path):
     w0 = P.init_params(P.generator_spec(H, W), 0)["conv1_d.w"]
     assert epoch == 10 and np.isfinite(tensors["gen_model/conv1_d/w"]).all()
     assert np.abs(tensors["gen_model/conv1_d/w"] - w0).max() > 1e-4
+
+
+def test_concat_rows4_is_the_row_wise_concatenation(dev):
+    """hdrsky_concat_rows4 (the operand block of the gather_dense exchange) == torch.cat(dim=1), bit for bit."""
+    K = importlib.import_module(PKG + ".kernels")
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    for M, widths in ((32, (8192, 4096, 4096, 4096)), (3, (4, 8, 12, 4)), (1, (2880, 2880, 360, 2880))):
+        parts = [torch.randn(M, w, device=dev, generator=g) for w in widths]
+        out = torch.full((M, sum(widths)), float("nan"), device=dev)
+        K.concat_rows4(parts, out)
+        assert torch.equal(out, torch.cat(parts, dim=1))
+    with pytest.raises(Exception):
+        K.concat_rows4([torch.zeros(2, 6, device=dev)] * 4, torch.zeros(2, 24, device=dev))     # widths must be multiples of 4

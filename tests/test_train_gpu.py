@@ -639,3 +639,33 @@ def test_replay_after_an_eager_step_runs_the_captured_binding(dev):
     torch.cuda.synchronize()
     assert tr._outputs()["y_final_gamma"] is out["y_final_gamma"]
     assert torch.equal(tr.gs.grad, ref[0]) and torch.equal(tr.ds.grad, ref[1]) and torch.equal(out["y_final_gamma"], ref[2])
+
+
+def test_train_step_at_a_size_outside_the_mfma_dense_tile(dev):
+    """--imheight 40 --imwidth 72 (both multiples of 8, as the three stride-2 stages need): H*W = 2880 is not a multiple of
+    the 256-column tile of the matrix-core Dense gradient (csrc/fc_update.hip), so the bench-mode trainer must fall back
+    to hdrsky_fc_wgrad + hdrsky_rmsprop_fc instead of failing with EINVAL at the first step; losses and the Dense
+    gradients against the oracle, then two updating steps."""
+    params, synth, trainer, K = pkg("params"), pkg("synth"), pkg("trainer"), pkg("kernels")
+    H, W, B = 40, 72, 2
+    assert not K.fc_xtdy_supported(H * W, H * W) and K.fc_xtdy_supported(4096, 4096)
+    gen = params.init_params(params.generator_spec(H, W), 0); sun = params.init_params(params.sunpose_spec(H, W), 1)
+    dis = params.init_params(params.discriminator_spec(), 2); vgg = params.init_params(params.vgg_spec(), 3)
+    batch = synth.make_batch(B, H, W, seed=77)
+    tr = trainer.Trainer(gen, sun, dis, vgg, device=dev, precise=False, compute=K.BF16, im_height=H, im_width=W)
+    assert not tr.dense_mfma and not tr.fused_dense
+    tt = lambda dd: {k: torch.from_numpy(v) for k, v in dd.items()}
+    ldr, hdr, gt = (torch.from_numpy(batch[k]) for k in ("ldr", "hdr_t", "sunpose_gt"))
+    losses, gg, gs, gd, sg, sd, outs = ostep.train_step_grads(tt(gen), tt(sun), tt(dis), tt(vgg), ldr, hdr, gt)
+    tr.step(ldr.to(dev), hdr.to(dev), gt.to(dev), update=False)
+    got = tr.loss_dict()
+    for k, rk in (("kl", "kl"), ("perceptual", "perceptual"), ("dog", "dog"), ("l1", "l1"), ("adv", "adv")):
+        assert abs(got[k] - losses[rk]) <= 2e-2 * abs(losses[rk]) + 1e-6, (k, got[k], losses[rk])
+    for k in ("fc1.kernel", "fc2.kernel", "fc1.bias", "fc2.bias"):
+        g, v = tr.gs.g["sun." + k].cpu().double(), gs[k].double()
+        cos = float((g * v).sum() / (g.norm() * v.norm() + 1e-300))
+        assert cos > 0.98, (k, cos)
+    w0 = tr.gs.flat.clone()
+    for _ in range(2):
+        tr.step(ldr.to(dev), hdr.to(dev), gt.to(dev), update=True)
+    assert torch.isfinite(tr.gs.flat).all() and torch.isfinite(tr.ds.flat).all() and not torch.equal(w0, tr.gs.flat)
