@@ -61,6 +61,7 @@ SIGNATURES = {
     "hdrsky_conv_pack_weights": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "hdrsky_conv_pack_weights_multi": (c_int, [P, c_int, c_int, P]),
     "hdrsky_conv_stats_nparts": (c_int, [ctypes.POINTER(ConvDesc)]),
+    "hdrsky_conv_kernel_name": (c_int, [ctypes.POINTER(ConvDesc), ctypes.c_char_p, c_int]),
     "hdrsky_conv2d_fwd": (c_int, [ctypes.POINTER(ConvDesc)] + [P] * 13),
     "hdrsky_conv2d_wgrad": (c_int, [ctypes.POINTER(ConvDesc)] + [P] * 10),
     "hdrsky_conv2d_wgrad_multi": (c_int, [ctypes.POINTER(WgradJob), c_int, P]),
@@ -77,6 +78,7 @@ SIGNATURES = {
     "hdrsky_fc_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
     "hdrsky_fc_dgrad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
     "hdrsky_fc_finalize": (c_int, [P, c_int, c_int, c_int, P, c_int, P, P, P, P]),
+    "hdrsky_global_max": (c_int, [P, c_size_t, P, P]),
     "hdrsky_softmax_head": (c_int, [P, c_int, c_int, c_int, P, P, P, P, P]),
     "hdrsky_softmax_head_pick": (c_int, [P, c_int, c_int, c_int, P, P, P, P, P, P, P, P]),
     "hdrsky_softmax_pick_bwd": (c_int, [P, P, P, c_int, c_int, P, P, P]),

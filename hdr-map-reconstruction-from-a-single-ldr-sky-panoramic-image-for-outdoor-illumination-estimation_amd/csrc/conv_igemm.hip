@@ -961,6 +961,14 @@ int hdrsky_conv_pack_weights_multi(const void* jobs, int njobs, int total_blocks
   return HDRSKY_OK;
 }
 
+int hdrsky_conv_kernel_name(const hdrsky_conv_desc* d, char* buf, int n) {
+  if (!d || !buf || n <= 0) return HDRSKY_EINVAL;
+  const TileCfg t = choose_tile(d);
+  snprintf(buf, (size_t)n, "conv_igemm_kernel<%d, %d, %d, %d, %d, %s, %s, %s>", t.wm, t.wn, t.mi, t.ni, t.tw,
+           d->Cin <= 8 ? "true" : "false", d->compute == HDRSKY_BF16X3 ? "true" : "false", t.db ? "true" : "false");
+  return HDRSKY_OK;
+}
+
 int hdrsky_conv_stats_nparts(const hdrsky_conv_desc* d) {
   if (!d) return HDRSKY_EINVAL;
   const TileCfg t = choose_tile(d);

@@ -27,7 +27,7 @@ __global__ void __launch_bounds__(256) fc_mfma_kernel(const float* __restrict__ 
   const int ob = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
   const int rslice = R / nsplit;
   const int r0 = sp * rslice;
-  const int nchunks = rslice / RCH;
+  const int nchunks = (rslice + RCH - 1) / RCH;   // the last chunk may be partial (rslice % 8 == 0): zero-filled
   const int col = ob * 64 + wave * 16 + lr;
   const bool col_ok = col < O;
   const long wbase = (long)(col_ok ? col : 0) * stride_col;
@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(256) fc_mfma_kernel(const float* __restrict__ 
       float v[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = 0.f;
-      if (m < M) {
+      if (m < M && chunk * RCH + kg * 8 < rslice) {
         const float* p = x + (size_t)m * R + r0 + chunk * RCH + kg * 8;
         const float4 a = *reinterpret_cast<const float4*>(p);
         const float4 b = *reinterpret_cast<const float4*>(p + 4);
@@ -59,11 +59,23 @@ __global__ void __launch_bounds__(256) fc_mfma_kernel(const float* __restrict__ 
   uint4 bh[8], bl[8];
   auto load_w = [&](int chunk) {
     const long kg0 = (long)(r0 + chunk * RCH) / 8;
+    if ((chunk + 1) * RCH <= rslice) {      // (wave-uniform) full chunk: unguarded stream
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const long idx = wbase + (kg0 + s * 4 + kq) * stride_kg;
-      bh[s] = whi[idx];
-      if (PRECISE) bl[s] = wlo[idx];
+      for (int s = 0; s < 8; ++s) {
+        const long idx = wbase + (kg0 + s * 4 + kq) * stride_kg;
+        bh[s] = whi[idx];
+        if (PRECISE) bl[s] = wlo[idx];
+      }
+    } else {                                // partial last chunk (reduction lengths that are not multiples of 256)
+      const int left = (rslice - chunk * RCH) >> 3;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const bool ok = s * 4 + kq < left;
+        const long idx = wbase + (kg0 + (ok ? s * 4 + kq : 0)) * stride_kg;
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        bh[s] = ok ? whi[idx] : z;
+        if (PRECISE) bl[s] = ok ? wlo[idx] : z;
+      }
     }
   };
 
@@ -164,7 +176,7 @@ int hdrsky_fc_nsplit(int R) {
 // forward: out_part[nsplit][M][N] = x[M][K] @ W[K][N]   (bias / activation: hdrsky_fc_finalize or hdrsky_softmax_head)
 int hdrsky_fc_fwd(const float* x, const void* packed_hi, const void* packed_lo, int M, int K, int N, int nsplit,
                   int compute, float* out_part, void* stream) {
-  if (!x || !packed_hi || !out_part || M <= 0 || M > 32 || nsplit <= 0 || (K % (nsplit * RCH)) != 0 || (N & 7))
+  if (!x || !packed_hi || !out_part || M <= 0 || M > 32 || nsplit <= 0 || (K % (nsplit * 8)) != 0 || (N & 7))
     return HDRSKY_EINVAL;
   if (compute == HDRSKY_BF16X3) {
     if (!packed_lo) return HDRSKY_EINVAL;
@@ -176,7 +188,7 @@ int hdrsky_fc_fwd(const float* x, const void* packed_hi, const void* packed_lo, 
 // data gradient: dx_part[nsplit][M][K] = dy[M][N] @ W[K][N]^T   (weights in the natural bf16 image)
 int hdrsky_fc_dgrad(const float* dy, const void* natural_hi, const void* natural_lo, int M, int K, int N, int nsplit,
                     int compute, float* dx_part, void* stream) {
-  if (!dy || !natural_hi || !dx_part || M <= 0 || M > 32 || nsplit <= 0 || (N % (nsplit * RCH)) != 0 || (K & 7))
+  if (!dy || !natural_hi || !dx_part || M <= 0 || M > 32 || nsplit <= 0 || (N % (nsplit * 8)) != 0 || (K & 7))
     return HDRSKY_EINVAL;
   if (compute == HDRSKY_BF16X3) {
     if (!natural_lo) return HDRSKY_EINVAL;

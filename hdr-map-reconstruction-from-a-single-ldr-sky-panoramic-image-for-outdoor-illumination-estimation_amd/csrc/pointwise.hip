@@ -678,6 +678,16 @@ __global__ void __launch_bounds__(256) dense_heads_kernel(const float* __restric
 //   gamma/beta = sigmoid(sum_slices part + bias)
 //   x = cmf / max(cmf); rad = min(gamma*exp(-(1-x)^2/(beta+1e-5)) / (beta*sqrt(pi)+1e-5), 30000)
 // writes rad tiled to 3 channels and its log-compressed (gamma-domain) image.
+// *gmax_bits = max(*gmax_bits, bits(max_i x[i])) for NON-NEGATIVE x (the bit pattern of a non-negative float orders like
+// the float: an order-independent integer atomicMax) - tf.reduce_max(sunpose_pred) (generator.py:160) when the sun-position
+// map is an input of the step instead of the soft-max head's output
+__global__ void __launch_bounds__(256) global_max_kernel(const float* __restrict__ x, size_t n, unsigned int* gmax_bits) {
+  float m = 0.f;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) m = fmaxf(m, x[i]);
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(gmax_bits, __float_as_uint(m));
+}
+
 __global__ void sun_rad_kernel(const float* __restrict__ cmf, const unsigned int* __restrict__ gmax_bits,
                                const float* __restrict__ part, int S, const float* __restrict__ bg,
                                const float* __restrict__ bb, int B, int P, float* __restrict__ gamma_out,
@@ -913,6 +923,15 @@ int hdrsky_norm_act_bwd(const float* x, const float* part, int nparts, const flo
   HDRSKY_CHECK_LAUNCH();
   hipLaunchKernelGGL(norm_act_bwd_kernel<1>, dim3(groups * S), dim3(256), 0, (hipStream_t)stream, x, part, nparts, gamma,
                      beta, eps, slope, dy, pooled, dx, dx_bf16, sums, dgamma, dbeta, ws, S, B, H, W, C);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_global_max(const float* x, size_t n, void* gmax_bits, void* stream) {
+  if (!x || !gmax_bits || n == 0) return HDRSKY_EINVAL;
+  const size_t blocks = (n + 1023) / 1024;
+  hipLaunchKernelGGL(global_max_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, (hipStream_t)stream, x, n,
+                     (unsigned int*)gmax_bits);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }

@@ -21,6 +21,30 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# ---- launch trace (bench.py's per-layer roofline rows) -----------------------------------------------------------------
+# TRACE = [] switches it on: every matrix-core conv / weight-gradient / sample-resident launch appends
+# dict(kind, label, kernel, shape, flop, relaunch): `flop` = ALGORITHMIC 2*MAC of the layer (a zero-stuffed stride-2 data
+# gradient counts the forward conv's work, not the stuffed zeros), `relaunch()` re-enqueues the identical launch on the
+# current stream (it keeps its operands alive).  label(name) names the next traced launch(es) - the trainer sets it.
+TRACE = None
+_LABEL = [None]
+
+
+def label(name):
+    _LABEL[0] = name
+
+
+def _trace(kind, kernel, shape, flop, relaunch):
+    if TRACE is not None:
+        TRACE.append(dict(kind=kind, label=_LABEL[0], kernel=kernel, shape=shape, flop=float(flop), relaunch=relaunch))
+
+
+def conv_kernel_name(d):
+    buf = ctypes.create_string_buffer(160)
+    L.check(L.load().hdrsky_conv_kernel_name(d, buf, 160), "conv_kernel_name")
+    return buf.value.decode()
+
+
 def _p(t):
     return None if t is None else t.data_ptr()
 
@@ -168,9 +192,17 @@ def conv2d(x, pw: PackedConv, bias=None, stride=1, same=True, upsample=1, xf: Op
     if want_stats:
         nparts = lib.hdrsky_conv_stats_nparts(d)
         stats = Stats(torch.empty((B, nparts, 2, pw.Cout), dtype=torch.float32, device=x.device), nparts, d.Ho * d.Wo)
-    L.check(lib.hdrsky_conv2d_fwd(d, _p(x), _p(pw.hi), _p(pw.lo), _p(bias), _p(in_scale), _p(in_shift), _p(in_part),
-                                  _p(in_gamma), _p(in_beta), _p(residual), _p(y),
-                                  _p(stats.part) if stats else None, _stream()), "conv2d_fwd")
+    args = (d, _p(x), _p(pw.hi), _p(pw.lo), _p(bias), _p(in_scale), _p(in_shift), _p(in_part), _p(in_gamma), _p(in_beta),
+            _p(residual), _p(y), _p(stats.part) if stats else None)
+    L.check(lib.hdrsky_conv2d_fwd(*args, _stream()), "conv2d_fwd")
+    if TRACE is not None:
+        keep = (x, pw, bias, in_scale, in_shift, in_part, in_gamma, in_beta, residual, y, stats)
+        stuffed = 4 if d.dilate == 2 else 1
+        _trace("dgrad" if pw.flip else "conv", conv_kernel_name(d),
+               "%dx%d %d->%d @%dx%d B=%d%s%s" % (d.KH, d.KW, C, pw.Cout, d.Ho, d.Wo, B, " s2" if d.stride == 2 else "",
+                                                 " up2" if d.upsample == 2 else (" zero-stuffed" if stuffed == 4 else "")),
+               2.0 * B * d.Ho * d.Wo * d.KH * d.KW * C * pw.Cout / stuffed,
+               lambda a_=args, k_=keep: L.check(lib.hdrsky_conv2d_fwd(*a_, _stream()), "conv2d_fwd"))
     return y, stats
 
 
@@ -303,6 +335,13 @@ def conv2d_wgrad_multi(jobs, deterministic=True):
         raise L.HdrSkyError("conv2d_wgrad_multi: unsupported layer geometry")
     ws = torch.empty(nbytes, dtype=torch.uint8, device=jobs[0][1].device)
     L.check(lib.hdrsky_conv2d_wgrad_multi_det(arr, len(jobs), _p(ws), nbytes, _stream()), "conv2d_wgrad_multi_det")
+    if TRACE is not None:
+        flop = sum(2.0 * j[0].B * j[0].Ho * j[0].Wo * j[0].KH * j[0].KW * j[0].Cin * j[0].Cout for j in jobs)
+        d0 = jobs[0][0]
+        _trace("wgrad", "conv_wgrad_kernel + wgrad_reduce_kernel (%d layers in one call)" % len(jobs),
+               "%d x e.g. %dx%d %d->%d @%dx%d B=%d" % (len(jobs), d0.KH, d0.KW, d0.Cin, d0.Cout, d0.Ho, d0.Wo, d0.B), flop,
+               lambda a_=arr, n_=len(jobs), w_=ws, k_=jobs: L.check(
+                   lib.hdrsky_conv2d_wgrad_multi_det(a_, n_, _p(w_), w_.numel(), _stream()), "conv2d_wgrad_multi_det"))
 
 
 def norm_apply(x, stats: Stats, gamma, beta, slope=1.0, residual=None, pool=False, eps=IN_EPS):
@@ -445,6 +484,17 @@ def fc_finalize(part, bias=None, relu=False, mask_src=None, zero_word=None):
     L.check(L.load().hdrsky_fc_finalize(_p(part), ns, M, N, _p(bias), int(relu), _p(mask_src), _p(y), _p(zero_word),
                                         _stream()), "fc_finalize")
     return y
+
+
+def global_max(x, gmax_bits=None):
+    """int32[1] holding the bit pattern of max(x) for a non-negative fp32 tensor (tf.reduce_max, generator.py:160): what
+    softmax_head leaves in its max accumulator, for a sun-position map that is an input of the step."""
+    _f32(x)
+    if gmax_bits is None:
+        gmax_bits = torch.empty(1, dtype=torch.int32, device=x.device)
+    zero_(gmax_bits)
+    L.check(L.load().hdrsky_global_max(_p(x), x.numel(), _p(gmax_bits), _stream()), "global_max")
+    return gmax_bits
 
 
 def softmax_head(part, bias, gmax_bits=None):
@@ -1031,6 +1081,10 @@ def resconv_fwd(x, pw: PackedConv, bias, gamma, beta, slope, residual=None, want
     a.x, a.w, a.bias, a.gamma, a.beta, a.res = _p(x), _p(pw.hi), _p(bias), _p(_f32(gamma, Cout)), _p(_f32(beta, Cout)), _p(residual)
     a.y_bf16, a.y_f32, a.xhat_out, a.inv_out = _p(out.get("bf16")), _p(out.get("f32")), _p(out.get("xhat")), _p(out.get("inv"))
     L.check(L.load().hdrsky_resconv(a, _stream()), "resconv (fwd)")
+    if TRACE is not None:
+        _trace("resconv", "resconv_kernel<%d>" % (Cin // 32), "3x3 %d->%d @%dx%d B=%d + InstanceNorm fwd" % (Cin, Cout, H, W, B),
+               2.0 * B * H * W * 9 * Cin * Cout,
+               lambda a_=a, k_=(x, pw, bias, gamma, beta, residual, out): L.check(L.load().hdrsky_resconv(a_, _stream()), "resconv"))
     return out
 
 
@@ -1071,6 +1125,10 @@ def resconv_bwd(dy, pwT, skip=None, norm=None, want_f32=False, want_bf16=True, s
             a.dgb = _p(_f32(norm["dgb"], B, 2, Cout))
     a.y_bf16, a.y_f32 = _p(out.get("bf16")), _p(out.get("f32"))
     L.check(L.load().hdrsky_resconv(a, _stream()), "resconv (bwd)")
+    if TRACE is not None and dy is not None:
+        _trace("resconv", "resconv_kernel<%d>" % (Cin // 32), "3x3 %d->%d @%dx%d B=%d data gradient + InstanceNorm bwd" % (Cin, Cout, H, W, B),
+               2.0 * B * H * W * 9 * Cin * Cout,
+               lambda a_=a, k_=(dy, pwT, skip, norm, out): L.check(L.load().hdrsky_resconv(a_, _stream()), "resconv"))
     return out
 
 

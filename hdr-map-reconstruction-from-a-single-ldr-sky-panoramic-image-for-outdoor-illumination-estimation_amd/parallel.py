@@ -103,7 +103,10 @@ class GradientExchange:
         self.comm = torch.cuda.Stream(device=device) if self.active else None
         if getattr(trainer, "_graphs", None) is not None:
             raise RuntimeError("GradientExchange: construct before Trainer.capture (it changes which launches the plan holds)")
-        if mode == "gather_dense" and self.active:
+        self.has_dense = self.fc1 > self.fc0    # False for a sunpose="external" trainer: nothing but the conv slices travels
+        if not self.has_dense:
+            pass
+        elif mode == "gather_dense" and self.active:
             trainer.dense_wgrad_external = True   # the local Dense weight-gradient launches are left out (see _dense_gather)
             trainer.on_bind = self._on_bind
         elif self.active:
@@ -213,7 +216,8 @@ class GradientExchange:
         if not self.active:
             return
         if self.mode == "gather_dense":
-            self._dense_gather()
+            if self.has_dense:
+                self._dense_gather()
             self._allreduce(self.tr.gs.grad[:self.fc0]); self._allreduce(self.tr.ds.grad)
         elif self.mode == "allreduce_bf16":
             self._allreduce(self.tr.gs.grad); self._allreduce(self.tr.ds.grad)
@@ -226,7 +230,7 @@ class GradientExchange:
 
     @property
     def pre_hooks(self):
-        return {self.tr.APPLY[0]: self.fc_grads_reduce} if self.active else None
+        return {self.tr.APPLY[0]: self.fc_grads_reduce} if self.active and self.has_dense else None
 
 
 def sync_moving_stats_(trainer, src=0):

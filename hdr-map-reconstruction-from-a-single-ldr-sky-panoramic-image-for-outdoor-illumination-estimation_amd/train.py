@@ -22,6 +22,47 @@ from . import tb_logging
 from .trainer import Trainer
 
 
+def fit_synthetic(tr, steps, batchsize, seed0=0, world=1, rank=0, crf=None, jpeg=True, exchange=None):
+    """`steps` optimizer steps of the captured training step on seeded device-side synthetic batches (the epoch loop of
+    `main` without logging / checkpoints): batch `it` is synth.make_batch_device(seed = (seed0 + it) * world + rank).
+    Used by main(), by bench.py and the parity tests to produce TRAINED-LIKE weights from a committed procedure instead of
+    a weight blob (there is no dataset and no published checkpoint)."""
+    h, w, dev = tr.h, tr.w, tr.device
+    bufs = getattr(tr, "_fit_bufs", None)
+    for it in range(steps):
+        b = synth.make_batch_device(batchsize, h, w, seed=(seed0 + it) * world + rank, device=dev, crf=crf, jpeg=jpeg)
+        if bufs is None or bufs[0].shape[0] != batchsize:
+            bufs = tr._fit_bufs = (b["ldr"].clone(), b["hdr_t"].clone(), b["sunpose_gt"].clone())
+            tr.capture(*bufs)
+        for dst, src in zip(bufs, (b["ldr"], b["hdr_t"], b["sunpose_gt"])):
+            dst.copy_(src)
+        tr.replay(hooks=exchange.hooks if exchange else None, pre_hooks=exchange.pre_hooks if exchange else None)
+    return tr
+
+
+def psnr_db(a, b, peak):
+    """10 log10(peak^2 / mean((a-b)^2)) in float64."""
+    a, b = a.double(), b.double()
+    return float(10.0 * torch.log10(float(peak) ** 2 / ((a - b) ** 2).mean()))
+
+
+def quality_report(tr, ldr, hdr_t, compute_modes=("BF16", "BF16X3")):
+    """PSNR of the inference graph's y_final_gamma (the trainer's CURRENT weights, inference-mode BatchNorm) against the
+    log-compressed target hdr_logCompression(hdr_t) (tf_utils.py:263-271), per compute mode, and between the modes."""
+    from . import engine
+    gen = {k[4:]: v for k, v in tr.gs.w.items() if k.startswith("gen.")}
+    sun = {k[4:]: v for k, v in tr.gs.w.items() if k.startswith("sun.")}
+    nets = engine.Nets(gen, sun, device=tr.device, precise=True, im_height=tr.h, im_width=tr.w)
+    tgt = K.tonemap(hdr_t, False)
+    peak = float(tgt.abs().max())
+    ys = {m: engine.generator_forward(nets, ldr, compute=getattr(K, m))["y_final_gamma"] for m in compute_modes}
+    rep = {"psnr_%s_vs_target_db" % m.lower(): round(psnr_db(y, tgt, peak), 3) for m, y in ys.items()}
+    if len(compute_modes) == 2:
+        a, b = (ys[m] for m in compute_modes)
+        rep["psnr_%s_vs_%s_db" % tuple(m.lower() for m in compute_modes)] = round(psnr_db(a, b, float(b.abs().max())), 3)
+    return rep
+
+
 def main(argv=None):
     cwd = os.getcwd()
     ap = argparse.ArgumentParser(description="training the LDR->HDR sky model")

@@ -77,6 +77,7 @@ class _Conv:
         return K.conv_desc(B, H, W, C, self.cout, self.kh, self.kw, self.stride, self.same, self.upsample)
 
     def fwd(self, x, xf=None, compute=BF16, **kw):
+        K.label(self.wkey)
         return K.conv2d(x, self.pk, self.b, stride=self.stride, same=self.same, upsample=self.upsample, xf=xf,
                         compute=compute, **kw)
 
@@ -86,6 +87,7 @@ class _Conv:
 
     def dgrad(self, x, dy, compute, residual=None, want_stats=False, out=None):
         """Gradient wrt the (transformed, pre-resize) conv operand."""
+        K.label(self.wkey + " (data gradient)")
         d, st = K.conv2d_dgrad(dy, self.pkT, self.desc(x), residual=None if self.upsample == 2 else residual,
                                compute=compute, want_stats=want_stats)
         if self.upsample == 2:
@@ -96,7 +98,15 @@ class _Conv:
 class Trainer:
     def __init__(self, gen_params, sun_params, dis_params, vgg_params, device="cuda", lr=1e-4, im_height=32,
                  im_width=128, precise=False, compute=BF16, world_size=1, resconv=True, distortion_aware=False,
-                 fused_dense=True):
+                 fused_dense=True, sunpose="net"):
+        """sunpose="external": the step takes the sun-pose net's outputs - cmf [B,H*W] and the three Grad-CAM maps - as
+        INPUTS (step(..., cmf=, cams=)) instead of owning the net: SURVEY.md section 8d's substitution for the 128x512
+        configuration, whose faithful sun-pose net has 12.9 G parameters (sun_params may be None).  Everything else of
+        train.py:382-415 - generator, sun-radiance head, discriminator step, VGG16 / DoG / L1 / LSGAN terms, both
+        backward passes, RMSprop x2 - is the same plan; the KL term is reported but is a constant of such a step."""
+        if sunpose not in ("net", "external"):
+            raise ValueError("sunpose: 'net' or 'external'")
+        self.ext_sun = sunpose == "external"
         self.device = torch.device(device)
         self.h, self.w = im_height, im_width
         self.lr, self.compute, self.precise, self.world = lr, compute, precise, world_size
@@ -107,6 +117,8 @@ class Trainer:
         # ("res" / "sunpose" / "decoders" parts: engine.da_parts; True = the res blocks)
         self.da_parts = E.da_parts(distortion_aware)
         self.da, self.da_sun, self.da_dec = ("res" in self.da_parts), ("sunpose" in self.da_parts), ("decoders" in self.da_parts)
+        if self.ext_sun and self.da_sun:
+            raise ValueError("sunpose='external': there is no sun-pose net to make distortion-aware")
         self._da_geo = {}                   # (h, w, k) -> (offsets on the device, transposed sample table)
         self.use_resconv = bool(resconv) and not self.da and compute == BF16 and not precise and \
             K.resconv_supported(im_height // 4, im_width // 4, 128, 128)
@@ -120,12 +132,14 @@ class Trainer:
         # (the matrix-core Dense gradient wants N = im_height * im_width in multiples of 256: other sizes keep the fp32 FMA
         # weight gradient + the plain Dense RMSprop)
         hw = im_height * im_width
-        self.dense_mfma = compute == BF16 and not precise and K.fc_xtdy_supported(hw // 64 * 128, hw) and K.fc_xtdy_supported(hw, hw)
+        self.dense_mfma = compute == BF16 and not precise and not self.ext_sun and \
+            K.fc_xtdy_supported(hw // 64 * 128, hw) and K.fc_xtdy_supported(hw, hw)
         self.fused_dense = bool(fused_dense) and self.dense_mfma
         self.dense_operands = None          # (flat, df1, f1, dz) of the GLOBAL batch, set by parallel.GradientExchange
         self.on_bind = None                 # callable(B) run when a step is bound to a batch (static exchange buffers)
         named = OrderedDict(("gen." + k, v) for k, v in gen_params.items())
-        named.update(("sun." + k, v) for k, v in sun_params.items())
+        if not self.ext_sun:
+            named.update(("sun." + k, v) for k, v in sun_params.items())
         self.gs = FlatParams(named, self.device)          # optimizer_gen: _gen + _sun variables (train.py:402-403)
         self.ds = FlatParams(OrderedDict(("dis." + k, v) for k, v in dis_params.items()), self.device)
         self.vgg = E._dev(vgg_params, self.device)
@@ -168,12 +182,12 @@ class Trainer:
             add(net + "d3", net + "d3.conv.kernel", None, stride=2)
             add(net + "d4", net + "d4.conv.kernel", None, stride=1)
         add("dis.out", "dis.out.kernel", "dis.out.bias", same=False)
-        for l in (1, 2, 3):
+        for l in (1, 2, 3) if not self.ext_sun else ():
             for j in (1, 2):
                 n = "sun.sunlayer%d.conv%d" % (l, j)
                 add(n, n + ".w", n + ".b", need_dgrad=not (l == 1 and j == 1))
-        self.fc1 = PackedFC(w["sun.fc1.kernel"], pr)
-        self.fc2 = PackedFC(w["sun.fc2.kernel"], pr)
+        self.fc1 = PackedFC(w["sun.fc1.kernel"], pr) if not self.ext_sun else None
+        self.fc2 = PackedFC(w["sun.fc2.kernel"], pr) if not self.ext_sun else None
         # frozen VGG16: forward filters + data-gradient filters
         self.vgg_pk, self.vgg_pkT = {}, {}
         for name, _, _ in P.VGG_CHANNELS:
@@ -198,7 +212,7 @@ class Trainer:
             cv = self.conv["sun.sunlayer1.conv1"]
             K.pad_channels(cv.w.reshape(cv.kh * cv.kw, cv.cin * cv.cout), 32 * cv.cout, out=self._w1pad.view(cv.kh * cv.kw, 32 * cv.cout))
         self._packer.run()
-        if fc:
+        if fc and self.fc1 is not None:
             self.fc1.repack(self.gs.w["sun.fc1.kernel"])
             self.fc2.repack(self.gs.w["sun.fc2.kernel"])
 
@@ -575,6 +589,7 @@ class Trainer:
             for name in blk:
                 if keep is not None:
                     keep[name + ".in"] = x
+                K.label("vgg." + name)
                 x, _ = K.conv2d(x, self.vgg_pk[name], self.vgg[name + ".b"], out_slope=0.0, compute=cp, out_bf16=b16)
                 if keep is not None:
                     keep[name] = x
@@ -610,6 +625,7 @@ class Trainer:
                 name = blk[k]
                 xin = acts[name + ".in"]
                 d = K.conv_desc(B, xin.shape[1], xin.shape[2], xin.shape[3], self.vgg_pk[name].Cout, 3, 3, 1, True, 1)
+                K.label("vgg." + name + " (data gradient)")
                 if b16 and k > 0:     # the ReLU mask of the layer below rides in this conv's epilogue, bf16 out
                     g, _ = K.conv2d_dgrad(g, self.vgg_pkT[name], d, compute=cp, mask_bf16=acts[blk[k - 1]], mask_slope=0.0,
                                           out_bf16=True)
@@ -687,8 +703,12 @@ class Trainer:
         # (the longest independent chain is enqueued first; segment order = host launch order)
         @seg("fwd_sun", 1)
         def _():       # sun-pose net, Grad-CAM (constants for the gradient: train.py:257-271), sun radiance head
-            t = T["t"] = self._sunpose_forward(T["ldr"], pick=T["gt"])
-            T["cams"] = self._gradcam(t, T["gt"])
+            if self.ext_sun:      # the net's outputs are inputs of the step; tf.reduce_max(sunpose_pred) from its own launch
+                t = T["t"] = {"cmf": T["cmf_in"], "gmax": K.global_max(T["cmf_in"])}
+                T["cams"] = T["cams_in"]
+            else:
+                t = T["t"] = self._sunpose_forward(T["ldr"], pick=T["gt"])
+                T["cams"] = self._gradcam(t, T["gt"])
             T["rad"] = self._sunrad_forward(T["ldr"], T["cams"], t, T)
 
         @seg("fwd_enc", 0)
@@ -800,6 +820,8 @@ class Trainer:
                 y, residual = T["dec_" + sfx][6], T["dec_" + sfx][7]
                 tails[sfx] = K.decoder_tail_bwd(y, residual, dy, want_dres=(sfx == "u"))
             T["dpre"] = K.sun_rad_bwd(t["cmf"], t["gmax"], T["gamma"], T["beta"], tails["u"][1], T["dcmf"])
+            if self.ext_sun:      # cmf is an input: its gradient (KL + sun-radiance path) has no consumer
+                return
             dz = T["dz"] = K.softmax_bwd(t["cmf"], T["dcmf"], t["z"])       # KL + the sun-radiance path meet in dcmf
             df1 = T["df1"] = K.fc_finalize(K.fc_dgrad(dz, self.fc2, cp), None, relu=False, mask_src=t["f1"])
             T["dP3"] = K.fc_finalize(K.fc_dgrad(df1, self.fc1, cp)).reshape(B, h // 8, wd // 8, 128)
@@ -1023,11 +1045,16 @@ class Trainer:
             K.rmsprop(self.ds.flat[:self.ds.ntrain], self.ds.grad, self.ds.ms, self.lr, gscale=gscale)
             self.repack(fc=False)
 
+        if self.ext_sun:          # no sun-pose net: its backward, Dense weight gradients and Dense optimizer segments go
+            gone = ("bwd_sunpose", "wg_dense", "apply_fc")
+            segs[:] = [(n, si, tuple(d for d in deps if d not in gone), fn) for n, si, deps, fn in segs if n not in gone]
         return segs
 
     GRADS_READY = "grads_ready"                                  # hook point of a data-parallel driver
     DISC_GRADS_READY = "disc_step"                               # the discriminator's gradients are complete behind it
-    APPLY = ("apply_fc", "apply")                                # the optimizer segments
+    @property
+    def APPLY(self):                                             # the optimizer segments
+        return ("apply",) if self.ext_sun else ("apply_fc", "apply")
 
     @property
     def FC_GRADS_READY(self):
@@ -1080,13 +1107,25 @@ class Trainer:
         """The HIP event recorded after segment `name` in the current step (for drivers that order their own work)."""
         return self._events[name]
 
-    def _bind(self, ldr, hdr_t, sunpose_gt):
+    def _bind(self, ldr, hdr_t, sunpose_gt, cmf=None, cams=None):
+        if self.ext_sun:
+            B, h, w = ldr.shape[0], self.h, self.w
+            if cmf is None or cams is None or len(cams) != 3:
+                raise ValueError("sunpose='external': step(..., cmf=[B,H*W], cams=(cam1, cam2, cam3)) expected")
+            want = [(B, h * w), (B, h, w, 1), (B, h // 2, w // 2, 1), (B, h // 4, w // 4, 1)]
+            for t, shp in zip((cmf,) + tuple(cams), want):
+                if tuple(t.shape) != shp or t.dtype != torch.float32 or not t.is_contiguous():
+                    raise ValueError("sunpose='external': expected contiguous fp32 %s, got %s" % (shp, tuple(t.shape)))
+        elif cmf is not None or cams is not None:
+            raise ValueError("cmf / cams are inputs of a sunpose='external' trainer only")
         if self.on_bind is not None:
             self.on_bind(ldr.shape[0])
         self._norm_state(ldr.shape[0])            # pointer tables are uploaded here, never inside a graph capture
         if self.use_resconv:
             self._rc_state(ldr.shape[0])
         self._T = dict(ldr=ldr, hdr_t=hdr_t, gt=sunpose_gt)
+        if self.ext_sun:
+            self._T.update(cmf_in=cmf, cams_in=tuple(cams))
         self._segs = self._plan()
         self._events = {}
 
@@ -1096,15 +1135,16 @@ class Trainer:
                     gamma=T["gamma"], beta=T["beta"], alpha_c3=T["alpha"], sunpose_cmf=T["t"]["cmf"],
                     sun_cam1=T["cams"][0], sun_cam2=T["cams"][1], sun_cam3=T["cams"][2], sun_rad_lin=T["rad_lin"])
 
-    def step(self, ldr, hdr_t, sunpose_gt, update=True):
-        """ldr / hdr_t [B,H,W,3] BGR (train.py:386-387 rgb2bgr already applied), sunpose_gt [B,H*W].
+    def step(self, ldr, hdr_t, sunpose_gt, update=True, cmf=None, cams=None):
+        """ldr / hdr_t [B,H,W,3] BGR (train.py:386-387 rgb2bgr already applied), sunpose_gt [B,H*W]; cmf / cams: the
+        sun-pose net's outputs for a sunpose='external' trainer.
         Returns the dict generator_in_step returns (train.py:349) - losses are in self.losses (device)."""
-        self._bind(ldr, hdr_t, sunpose_gt)
+        self._bind(ldr, hdr_t, sunpose_gt, cmf, cams)
         skip = self._skip(update)
         self._execute([n for n, *_ in self._segs if n not in skip])
         return self._outputs()
 
-    def test_step(self, ldr, hdr_t, sunpose_gt):
+    def test_step(self, ldr, hdr_t, sunpose_gt, cmf=None, cams=None):
         """`test_step` (train.py:417-442): the validation pass - the training graph (ground-truth-bin Grad-CAM pick) with
         every BatchNorm in inference mode, all loss terms (generator_in_step / discriminator_in_step with
         training=False) and no update.  Returns the output dict of `step`; the loss terms are in self.losses /
@@ -1112,7 +1152,7 @@ class Trainer:
         self._bn_training = False
         saved = (getattr(self, "_T", None), getattr(self, "_segs", None), getattr(self, "_events", None))
         try:
-            self._bind(ldr, hdr_t, sunpose_gt)
+            self._bind(ldr, hdr_t, sunpose_gt, cmf, cams)
             self._execute(["fwd_sun", "fwd_enc", "vgg_target", "fwd_blend", "loss_main", "loss_vgg", "loss_vgg_b", "loss_adv"])
             T, cvo = self._T, self.conv["dis.out"]
             for other, target, slot in ((hdr_t, 1.0, 6), (T["y_lin"], 0.0, 5)):        # train.py:351-369, training=False
@@ -1144,13 +1184,15 @@ class Trainer:
         """[start, end) of the two Dense layers' gradients inside gs.grad - contiguous, the last trainables of the
         sun-pose net (50.3 M of the 58.3 M parameters); complete once segment FC_GRADS_READY has run, so a data-parallel
         driver starts their all-reduce there (hook) and it overlaps the rest of the backward pass."""
+        if self.ext_sun:
+            return self.gs.ntrain, self.gs.ntrain
         o = self.gs.offsets["sun.fc1.kernel"][0]
         return o, self.gs.ntrain
 
-    def capture(self, ldr, hdr_t, sunpose_gt, warmup=2):
-        """Captures every segment of the step on (ldr, hdr_t, sunpose_gt) - static input buffers the caller refills -
-        into its own hipGraph.  `replay()` then runs one step."""
-        self._bind(ldr, hdr_t, sunpose_gt)
+    def capture(self, ldr, hdr_t, sunpose_gt, warmup=2, cmf=None, cams=None):
+        """Captures every segment of the step on (ldr, hdr_t, sunpose_gt[, cmf, cams]) - static input buffers the caller
+        refills - into its own hipGraph.  `replay()` then runs one step."""
+        self._bind(ldr, hdr_t, sunpose_gt, cmf, cams)
         # the warm-up steps (lazy kernel attributes, allocator) must not train: weights, RMSprop slots and BatchNorm
         # moving statistics are put back afterwards (and replicas of a data-parallel job stay identical)
         state = [(t, t.clone()) for t in (self.gs.flat, self.gs.ms, self.ds.flat, self.ds.ms)]

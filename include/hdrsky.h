@@ -120,6 +120,10 @@ int hdrsky_conv_pack_weights(const float* w, int KH, int KW, int Cin, int Cout, 
  * [first_block_j, first_block_{j+1}) with ceil(packed_elems/2048) blocks each; total_blocks = their sum. */
 int hdrsky_conv_pack_weights_multi(const void* jobs, int njobs, int total_blocks, void* stream);
 
+/* [host] Name of the kernel instantiation hdrsky_conv2d_fwd launches for this descriptor (the tile table of
+ * csrc/conv_igemm.hip), as rocprofv3 --kernel-trace prints it: lets bench.py's per-layer roofline rows be matched with
+ * the committed kernel statistics under profiles/. */
+int hdrsky_conv_kernel_name(const hdrsky_conv_desc* d, char* buf, int n);
 /* Number of (sum,sumsq) tiles per sample this descriptor's launch writes to stats_part
  * ([B][nparts][2][Cout] fp32). [host] */
 int hdrsky_conv_stats_nparts(const hdrsky_conv_desc* d);
@@ -188,6 +192,10 @@ int hdrsky_fc_finalize(const float* part, int nsplit, int M, int N, const float*
 /* z = relu(sum_s part[s] + bias); cmf = softmax(z); *gmax_bits = max(*gmax_bits, bits(max cmf)) (zero it first). */
 int hdrsky_softmax_head(const float* part, int nsplit, int M, int N, const float* bias, float* z, float* cmf,
                         void* gmax_bits, void* stream);
+/* *gmax_bits = max(*gmax_bits, bits(max_i x[i])), x >= 0 (zero the word first): tf.reduce_max(sunpose_pred)
+ * (generator.py:160) for a sun-position map that is an INPUT of the step (the 128x512 configuration, SURVEY.md
+ * section 8d: its 12.9 G-parameter sun-pose net is substituted by its outputs). */
+int hdrsky_global_max(const float* x, size_t n, void* gmax_bits, void* stream);
 /* hdrsky_softmax_head and hdrsky_softmax_pick_bwd in one launch (the row is in registers anyway): additionally
  * dz = d cmf[m, c] / d z with c = first argmax of pick_src[m, :] - or of cmf[m, :] itself when pick_src is NULL
  * (inference.py:98) - and idx_out[m] = c (nullable).  Same arithmetic and tie rule as the two separate launches. */

@@ -19,13 +19,17 @@ def _alpha_mask(sky_pred_lin, thr=THRESHOLD):
     return alpha.unsqueeze(-1).repeat(1, 1, 1, 3)
 
 
-def generator_graph(gen, sun, ldr, y_index=None, training=False, new_stats=None, distortion_aware=False):
+def generator_graph(gen, sun, ldr, y_index=None, training=False, new_stats=None, distortion_aware=False,
+                    sunpose_external=None):
     """The generator graph shared by inference.py:81-115 and train.py:239-299.
 
     y_index: None -> y_c = max_j cmf[b,j] (inference.py:98); LongTensor [B] ->
              y_c = cmf[b, y_index[b]] (train.py:265-267, argmax of sunpose_gt).
     Grad-CAM maps and the alpha mask are constants for gradients
     (train.py:257 `gen_tape.stop_recording()`).
+    sunpose_external: (cmf [B,H*W], cam1 [B,H,W,1], cam2 [B,H/2,W/2,1], cam3 [B,H/4,W/4,1]) - the outputs of the
+             sun-pose net + Grad-CAM as INPUTS of the graph (constants), `sun` unused: SURVEY.md section 8d's
+             substitution for the 128x512 configuration, whose faithful sun-pose net has 12.9 G parameters.
     Returns a dict of every tensor the reference returns from generator_in_step.
     """
     b, h, w, _ = ldr.shape
@@ -33,17 +37,20 @@ def generator_graph(gen, sun, ldr, y_index=None, training=False, new_stats=None,
     sky_pred_gamma = N.gen_sky_decode(gen, res_out, ldr, distortion_aware)
     sky_pred_lin = T.hdr_log_decompression(sky_pred_gamma)
 
-    cmf, (a1, a2, a3) = N.sunpose_estimation(sun, ldr, distortion_aware)
-    sunpose_pred = cmf.reshape(-1, h, w, 1)
-
     alpha_c3 = _alpha_mask(sky_pred_lin).detach()
-    if y_index is None:
-        y_c = cmf.max(dim=1).values
+    if sunpose_external is not None:
+        cmf, cam1, cam2, cam3 = (t.detach() for t in sunpose_external)
+        a1 = a2 = a3 = None
     else:
-        y_c = cmf.gather(1, y_index.view(-1, 1)).squeeze(1)
-    cam1 = N.grad_cam_layer(y_c, a1).detach()
-    cam2 = N.grad_cam_layer(y_c, a2).detach()
-    cam3 = N.grad_cam_layer(y_c, a3).detach()
+        cmf, (a1, a2, a3) = N.sunpose_estimation(sun, ldr, distortion_aware)
+        if y_index is None:
+            y_c = cmf.max(dim=1).values
+        else:
+            y_c = cmf.gather(1, y_index.view(-1, 1)).squeeze(1)
+        cam1 = N.grad_cam_layer(y_c, a1).detach()
+        cam2 = N.grad_cam_layer(y_c, a2).detach()
+        cam3 = N.grad_cam_layer(y_c, a3).detach()
+    sunpose_pred = cmf.reshape(-1, h, w, 1)
 
     sun_rad_lin, gamma, beta = N.gen_sun_rad_estimation(gen, ldr, cam1, cam2, cam3, sunpose_pred,
                                                         training, new_stats)
@@ -101,24 +108,26 @@ def discriminator_losses(dis, ldr, hdr_t, y_final_lin, training, new_stats=None)
     return dict(total_disc_loss=total, real=real_loss, generated=gen_loss)
 
 
-def train_step_grads(gen, sun, dis, vgg, ldr, hdr_t, sunpose_gt, distortion_aware=False):
+def train_step_grads(gen, sun, dis, vgg, ldr, hdr_t, sunpose_gt, distortion_aware=False, sunpose_external=None):
     """train.py:382-406 up to (not including) apply_gradients.
 
     Both tapes see the same pre-update weights.  Returns (losses, grads_gen, grads_sun,
     grads_dis, new_bn_stats_gen, new_bn_stats_dis, outputs).  `ldr` / `hdr_t` are already BGR.
     Trainable variable sets: everything in `gen` and `sun` except BN moving stats; same for `dis`.
+    sunpose_external: see generator_graph - `sun` may be None then and grads_sun comes back empty; the KL term is a
+    constant of the step (its value is still reported).
     """
     def trainable(d):
         return {k: v for k, v in d.items() if "moving_" not in k}
 
     gen_r = {k: v.detach().clone().requires_grad_("moving_" not in k) for k, v in gen.items()}
-    sun_r = {k: v.detach().clone().requires_grad_(True) for k, v in sun.items()}
+    sun_r = {} if sunpose_external is not None else {k: v.detach().clone().requires_grad_(True) for k, v in sun.items()}
     dis_r = {k: v.detach().clone().requires_grad_("moving_" not in k) for k, v in dis.items()}
 
     y_index = sunpose_gt.argmax(dim=1)
     stats_gen, stats_dis = {}, {}
     out = generator_graph(gen_r, sun_r, ldr, y_index=y_index, training=True, new_stats=stats_gen,
-                          distortion_aware=distortion_aware)
+                          distortion_aware=distortion_aware, sunpose_external=sunpose_external)
     gl = generator_losses(out, dis_r, vgg, ldr, hdr_t, sunpose_gt)
     # train.py:391-396: y_final_lin recomputed from y_final_gamma, still on both tapes
     y_final_lin = T.hdr_log_decompression(out["y_final_gamma"])

@@ -166,17 +166,27 @@ def test_other_image_size_64x256(dev):
     assert all(np.isfinite(v) for v in tr.loss_dict().values()) and torch.isfinite(tr.gs.flat).all()
 
 
-def test_bench_mode_psnr_within_0p05_db_of_the_fp32_class_mode(dev):
-    """north_star: 'output PSNR within 0.05 dB of the reference'.  bench.py's `parity` object at the bench size (B = 32):
-    PSNR against the log-compressed target in the benchmarked single-product bf16 mode and in the BF16X3 mode the tight
-    oracle tests pin; the tolerance is the clause's 0.05 dB."""
+def test_bench_mode_psnr_at_trained_like_weights(dev):
+    """north_star: 'output PSNR within 0.05 dB of the reference' - checked where it can fail.  At random initialisation
+    PSNR(output, target) is 14 dB and any error 48 dB down moves it by 0.002 dB whatever the kernels do; here the weights
+    come from bench.PARITY_FIT_STEPS steps of the product's own training step on seeded synthetic data (no weight blob:
+    <pkg>/train.py::fit_synthetic), after which the output must be a reconstruction (PSNR >= 30 dB against the
+    log-compressed target).  bench.py's `parity` object at the bench size (B = 32): the benchmarked bf16 mode and the
+    BF16X3 mode against the ORACLE's fp32 output on a 4-image subset and against the target; tolerance = the clause's
+    0.05 dB, and the modes' mutual PSNR must leave room for it (q_max above the quality reached)."""
     import bench
-    params, synth, engine, K = pkg("params"), pkg("synth"), pkg("engine"), pkg("kernels")
-    gen = params.init_params(params.generator_spec(), 0)
-    sun = params.init_params(params.sunpose_spec(), 1)
-    batch = synth.make_batch(B, seed=2024)
-    ldr, hdr = (torch.from_numpy(batch[k]).to(dev) for k in ("ldr", "hdr_t"))
-    p = bench.parity_object(torch, engine, K, gen, sun, ldr, hdr)
-    assert p["images"] == B and p["within_0p05_db"], p
-    assert abs(p["delta_psnr_vs_target_db"]) <= 0.05, p
-    assert p["psnr_bf16_vs_x3_db"] > 40.0, p
+    import importlib
+    from conftest import PKG
+    mods = {m: importlib.import_module(PKG + "." + m) for m in ("params", "synth", "engine", "trainer", "kernels", "train")}
+    params = mods["params"]
+    nets = (params.init_params(params.generator_spec(), 0), params.init_params(params.sunpose_spec(), 1),
+            params.init_params(params.discriminator_spec(), 2), params.init_params(params.vgg_spec(), 3))
+    p = bench.parity_object(torch, mods, dev, nets, B, bench.oracle_outputs_fn(torch, 4))
+    print(p)
+    assert p["images"] == B and p["oracle_images"] == 4
+    assert p["psnr_x3_vs_target_db"] >= 30.0 and p["psnr_oracle_vs_target_db"] >= 30.0, p      # trained-like, not noise
+    assert abs(p["delta_psnr_vs_target_db"]) <= 0.05 and abs(p["delta_psnr_vs_oracle_target_db"]) <= 0.05, p
+    assert abs(p["delta_psnr_x3_vs_oracle_target_db"]) <= 0.01, p
+    assert p["psnr_x3_vs_oracle_db"] >= 70.0 and p["psnr_bf16_vs_oracle_db"] >= 55.0, p
+    assert p["q_max_db"] >= p["psnr_bf16_vs_target_db"], p       # the bound the clause needs at the quality reached
+    assert p["within_0p05_db"], p

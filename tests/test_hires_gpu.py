@@ -137,3 +137,123 @@ def test_hires_batch8_properties(dev):
         out = fn()
     g.replay(); torch.cuda.synchronize()
     assert torch.equal(out, eager) and torch.isfinite(out).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# configs[4] as a TRAINING step: Trainer(im_height=128, im_width=512, sunpose="external") - train.py:382-415 with the
+# 12.9 G-parameter sun-pose net substituted by its outputs (cmf + the three Grad-CAM maps are inputs of the step,
+# SURVEY.md section 8d); oracle/step.train_step_grads(sunpose_external=...) is the same substitution on the CPU.
+# ---------------------------------------------------------------------------------------------------------------------
+def _sun_inputs(B, seed=17):
+    rng = np.random.default_rng(seed)
+    soft = lambda z: (lambda e: (e / e.sum(1, keepdims=True)).astype(np.float32))(np.exp(z - z.max(1, keepdims=True)))
+    cmf = soft(3.0 * rng.standard_normal((B, H * W)))
+    gt = soft(3.0 * rng.standard_normal((B, H * W)))
+    cams = [np.maximum(rng.standard_normal((B, H >> i, W >> i, 1)), 0.0).astype(np.float32) for i in range(3)]
+    return cmf, gt, cams
+
+
+def _hires_trainer(dev, mode, da=False):
+    params, trainer, K = pkg("params"), pkg("trainer"), pkg("kernels")
+    nets = (params.init_params(params.generator_spec(H, W), 0), None, params.init_params(params.discriminator_spec(), 2),
+            params.init_params(params.vgg_spec(), 3))
+    tr = trainer.Trainer(*nets, device=dev, precise=(mode == "BF16X3"), compute=getattr(K, mode), im_height=H, im_width=W,
+                         distortion_aware=da, sunpose="external")
+    return tr, nets
+
+
+@pytest.mark.parametrize("da", [False, "res,decoders"])
+def test_hires_training_step_gradients_match_oracle(dev, da):
+    """One 128x512 training step, B = 1, fp32-class contractions, plain and with distortion-aware res blocks + decoders
+    (distortion_aware_ops.py:5-542 where generator.py:14,18 / the decoders would use them): every loss term, the
+    generator's gradients and - at OUR prediction, see test_train_gpu - the discriminator's, against the oracle's autograd."""
+    from oracle import step as ostep
+    torch.set_num_threads(max(torch.get_num_threads(), 4))
+    tr, (gen, _, dis, vgg) = _hires_trainer(dev, "BF16X3", da)
+    assert tr.ext_sun and tr.fc1 is None and not any(k.startswith("sun.") for k in tr.gs.w)
+    ldr, hdr = _inputs(1, seed=41)
+    cmf, gt, cams = _sun_inputs(1)
+    ext = [torch.from_numpy(cmf)] + [torch.from_numpy(c) for c in cams]
+    losses, gg, gs, gd, sg, sd, outs = ostep.train_step_grads(_tt(gen), None, _tt(dis), _tt(vgg), torch.from_numpy(ldr),
+                                                              torch.from_numpy(hdr), torch.from_numpy(gt), distortion_aware=da,
+                                                              sunpose_external=ext)
+    assert not gs
+    d = lambda a: torch.from_numpy(a).to(dev)
+    out = tr.step(d(ldr), d(hdr), d(gt), update=False, cmf=d(cmf), cams=[d(c) for c in cams])
+    got = tr.loss_dict()
+    for k, rk in (("kl", "kl"), ("perceptual", "perceptual"), ("dog", "dog"), ("l1", "l1"), ("adv", "adv"),
+                  ("disc_generated", "generated"), ("disc_real", "real"), ("total_gen_loss", "total_gen_loss")):
+        assert abs(got[k] - losses[rk]) <= 2e-3 * abs(losses[rk]) + 1e-6, (k, got[k], losses[rk])
+    assert_close(out["y_final_gamma"], outs["y_final_gamma"], 1e-3, "y_final_gamma 128x512 (training mode)")
+    assert_close(out["sun_rad_lin"], outs["sun_rad_lin"], 2e-3, "sun_rad_lin 128x512")
+    worst = []
+    for k, v in gg.items():
+        g = tr.gs.g["gen." + k]
+        is_bias = k.endswith(".b") or k.endswith("bias_deconv2d")
+        if is_bias and not k.startswith("conv1_f") and not k.startswith("conv1_u"):
+            wk = k[:-2] + ".w" if k.endswith(".b") else k.replace("bias_deconv2d", "kernel_deconv2d")
+            scale = float(gg[wk].abs().max()) * float(np.prod(gg[wk].shape[:3]))
+            assert float(g.abs().max()) <= 1e-4 * scale, (k, float(g.abs().max()), scale)     # exactly zero in exact arithmetic
+            continue
+        worst.append((rel_max(g, v), k))
+    worst.sort(reverse=True)
+    print("128x512 da=%s worst generator gradient errors:" % (da,), worst[:6])
+    assert worst[0][0] < 5e-2 and np.median([e for e, _ in worst]) < 3e-3, worst[:5]
+    for k, v in sg.items():
+        assert_close(tr.gs.w["gen." + k], v, 1e-4, "gen " + k)
+    dr = {k: torch.from_numpy(v).clone().requires_grad_("moving" not in k) for k, v in dis.items()}
+    stats = {}
+    dl = ostep.discriminator_losses(dr, torch.from_numpy(ldr), torch.from_numpy(hdr), out["y_final_lin"].cpu(), training=True,
+                                    new_stats=stats)
+    names = [k for k in dr if "moving" not in k]
+    for k, v in zip(names, torch.autograd.grad(dl["total_disc_loss"], [dr[k] for k in names])):
+        assert_close(tr.ds.g["dis." + k], v, 5e-4, "dis grad " + k)
+
+
+@pytest.mark.parametrize("da", [False, "res,decoders"])
+def test_hires_training_step_b8_replay_equals_eager(dev, da):
+    """The configuration's per-GPU batch of 8 in the bench mode (single bf16 product): three captured replays equal three
+    eager steps from the same state (weights of both optimizers, BatchNorm moving statistics, every loss term), the
+    weights move, and gradient-only replays from a restored state are bit-reproducible."""
+    B = 8
+    ldr, hdr = _inputs(B, seed=43)
+    cmf, gt, cams = _sun_inputs(B, seed=19)
+    d = lambda a: torch.from_numpy(a).to(dev)
+    args = (d(ldr), d(hdr), d(gt))
+    kw = dict(cmf=d(cmf), cams=[d(c) for c in cams])
+    te, _ = _hires_trainer(dev, "BF16", da)
+    tc, _ = _hires_trainer(dev, "BF16", da)
+    w0 = te.gs.flat.clone()
+    tc.capture(*args, **kw)
+    for it in range(3):
+        te.step(*args, update=True, **kw)
+        tc.replay(update=True)
+        torch.cuda.synchronize()
+        for name, a, b in (("generator", te.gs.flat, tc.gs.flat), ("discriminator", te.ds.flat, tc.ds.flat)):
+            assert torch.isfinite(b).all(), (it, name)
+            assert float((a - b).abs().max()) <= 1e-6 * float(a.abs().max()), (it, name)
+        le, lc = te.losses.double(), tc.losses.double()
+        assert float((le - lc).abs().max()) <= 1e-4 * float(le.abs().max()), (it, te.losses.tolist(), tc.losses.tolist())
+    assert float((tc.gs.flat[:tc.gs.ntrain] - w0[:tc.gs.ntrain]).abs().max()) > 1e-5
+    wg, wd = tc.gs.flat.clone(), tc.ds.flat.clone()
+    ref = None
+    for it in range(2):
+        tc.gs.flat.copy_(wg); tc.ds.flat.copy_(wd)
+        tc.replay(update=False)
+        torch.cuda.synchronize()
+        snap = (tc.gs.grad.clone(), tc.ds.grad.clone())
+        assert torch.isfinite(snap[0]).all() and torch.isfinite(snap[1]).all()
+        if ref is not None:
+            assert torch.equal(ref[0], snap[0]) and torch.equal(ref[1], snap[1])
+        ref = snap
+
+
+def test_external_sunpose_inputs_are_checked(dev):
+    tr, _ = _hires_trainer(dev, "BF16")
+    ldr, hdr = _inputs(1)
+    cmf, gt, cams = _sun_inputs(1)
+    d = lambda a: torch.from_numpy(a).to(dev)
+    with pytest.raises(ValueError):
+        tr.step(d(ldr), d(hdr), d(gt))                                   # the substituted outputs are mandatory
+    with pytest.raises(ValueError):
+        tr.step(d(ldr), d(hdr), d(gt), cmf=d(cmf), cams=[d(cams[0])] * 3)   # wrong map sizes

@@ -98,11 +98,12 @@ def test_norm_act_bwd_pool_routing_tight_off_the_tie_channels(dev):
     assert float(tied.max()) <= 2.0            # a re-routed gradient: wrong pixel, same magnitude - bounded, not tight
 
 
-@pytest.mark.parametrize("M", [1, 4, 32])
-def test_fc_fwd_dgrad_softmax(dev, M):
+@pytest.mark.parametrize("M,Kd,Nd", [(1, 1024, 512), (4, 1024, 512), (32, 1024, 512), (3, 5760, 2880), (2, 2880, 2880), (5, 72, 8)])
+def test_fc_fwd_dgrad_softmax(dev, M, Kd, Nd):
+    """Dense forward / data gradient / soft-max head; the ragged cases are the Dense shapes of a 40x72 image (5*9*128 ->
+    2880 -> 2880: reduction lengths that are not multiples of the kernel's 256-element chunk) and a sub-chunk layer."""
     K = pkg("kernels")
     rng = np.random.default_rng(9)
-    Kd, Nd = 1024, 512
     x = rng.standard_normal((M, Kd)).astype(np.float32)
     w = (rng.standard_normal((Kd, Nd)) / 32).astype(np.float32)
     b = rng.standard_normal(Nd).astype(np.float32)
@@ -124,6 +125,7 @@ def test_fc_fwd_dgrad_softmax(dev, M):
     cr = torch.softmax(zr, dim=-1)
     assert_close(cmf, cr, 5e-4, "softmax")
     assert abs(float(gmax.view(torch.float32).item()) - float(cr.max())) <= 5e-4 * float(cr.max())
+    assert K.global_max(cmf).view(torch.float32).item() == float(cmf.max())      # hdrsky_global_max: the same word, exactly
     yc = cr.max(dim=1).values.sum()
     (gz,) = torch.autograd.grad(yc, zr)
     dz, idx = K.softmax_pick_bwd(cmf, z, cmf)

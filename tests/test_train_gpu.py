@@ -659,8 +659,10 @@ def test_train_step_at_a_size_outside_the_mfma_dense_tile(dev):
     losses, gg, gs, gd, sg, sd, outs = ostep.train_step_grads(tt(gen), tt(sun), tt(dis), tt(vgg), ldr, hdr, gt)
     tr.step(ldr.to(dev), hdr.to(dev), gt.to(dev), update=False)
     got = tr.loss_dict()
-    for k, rk in (("kl", "kl"), ("perceptual", "perceptual"), ("dog", "dog"), ("l1", "l1"), ("adv", "adv")):
-        assert abs(got[k] - losses[rk]) <= 2e-2 * abs(losses[rk]) + 1e-6, (k, got[k], losses[rk])
+    # (the adversarial term sees the prediction through the randomly initialised discriminator, which amplifies the bf16
+    # rounding of y_final_lin - DESIGN.md section 2, "chaotic w.r.t. its input": 10 % there, 2 % on the direct terms)
+    for k, rk, tol in (("kl", "kl", 2e-2), ("perceptual", "perceptual", 2e-2), ("dog", "dog", 2e-2), ("l1", "l1", 2e-2), ("adv", "adv", 1e-1)):
+        assert abs(got[k] - losses[rk]) <= tol * abs(losses[rk]) + 1e-6, (k, got[k], losses[rk])
     for k in ("fc1.kernel", "fc2.kernel", "fc1.bias", "fc2.bias"):
         g, v = tr.gs.g["sun." + k].cpu().double(), gs[k].double()
         cos = float((g * v).sum() / (g.norm() * v.norm() + 1e-300))
