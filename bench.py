@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--workload", default="all", choices=["all", "train", "fwd", "hires", "hires-train"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-roofline-top", action="store_true", help="skip the per-layer roofline table of the training step")
     ap.add_argument("--da", nargs="?", const="res", default="", metavar="PARTS",
                     help="train / fwd workload with distortion-aware layers, forward and backward: comma list of res "
                          "(distortion_aware_ops.conv2d in the res blocks, generator.py:14,18's commented-out variant; the "
@@ -111,10 +112,54 @@ def dominant_kernel_roofline(torch, K, pw, batch, h, w, iters=200):
             rec = json.load(f)
         traffic, source = rec.get("hbm_bytes_per_launch"), "profiles/r02_pmc_resconv.json @ %s" % rec.get("commit", "?")
     return {"bound": "mfma", "kernel": "resconv_kernel<4> (res-block 3x3 128->128 + InstanceNorm + leaky, B=%d)" % batch,
+            "role": "the res-block launch: 36 of the step's launches, ~6 % of its kernel time - see roofline_top for the "
+                    "launches that cost the most",
             "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / MFMA_PEAK_TFLOPS, 5), "traffic": traffic, "traffic_source": source,
             "avg_launch_us": round(us, 3), "flop_per_launch": flop,
             "algorithmic_bytes": batch * 256 * 128 * 2 * 3 + 9 * 128 * 128 * 2}
+
+
+def roofline_top(torch, K, tr, ldr, hdr, gt, top=5, iters=30):
+    """The matrix-core launches of ONE training step ranked by the kernel time they cost: an eager step is traced
+    (kernels.TRACE: every conv / data-gradient / weight-gradient / sample-resident launch with its layer label, kernel
+    instantiation and ALGORITHMIC flop count), identical launches are grouped, each group's launch is re-issued `iters` times
+    from one hipGraph and timed with HIP events on the launch stream (alone on the chip, back to back), and the `top` groups
+    by launches x time are reported: frac = flop_per_launch / avg_launch_us / 2.5 PFLOP/s.  `share` = the group's part of
+    the traced launches' summed time.  The same kernel names appear in profiles/r03_train_b32_kernel_stats.csv (in-step
+    durations: three streams share the chip there, so they are longer)."""
+    K.TRACE = []
+    try:
+        tr.step(ldr, hdr, gt, update=False)
+        torch.cuda.synchronize()
+        trace = K.TRACE
+    finally:
+        K.TRACE = None
+    groups = {}
+    for e in trace:
+        key = (e["kind"], e["kernel"], e["shape"])
+        g = groups.setdefault(key, dict(e, labels=[], launches=0))
+        g["launches"] += 1
+        if e["label"] and e["label"] not in g["labels"]:
+            g["labels"].append(e["label"])
+    rows = []
+    for (kind, kernel, shape), g in groups.items():
+        us = _graph_time(torch, g["relaunch"], iters, warm=2)
+        rows.append({"layers": g["labels"][:6] + (["+%d more" % (len(g["labels"]) - 6)] if len(g["labels"]) > 6 else []),
+                     "kind": kind, "kernel": kernel, "shape": shape, "launches_per_step": g["launches"],
+                     "flop_per_launch": g["flop"], "avg_launch_us": round(us, 2),
+                     "achieved": round(g["flop"] / (us * 1e-6) / 1e12, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(g["flop"] / (us * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4), "step_us": round(us * g["launches"], 1)})
+    total = sum(r["step_us"] for r in rows) or 1.0
+    flops = sum(r["flop_per_launch"] * r["launches_per_step"] for r in rows)
+    for r in rows:
+        r["share"] = round(r["step_us"] / total, 4)
+    rows.sort(key=lambda r: -r["step_us"])
+    return {"bound": "mfma", "note": "each row timed alone (back-to-back launches of one hipGraph); step_us = launches_per_step x "
+                                     "avg_launch_us; share = of the traced matrix-core launches' summed time",
+            "traced_launches": len(trace), "traced_gflop_per_step": round(flops / 1e9, 1), "traced_us_per_step": round(total, 1),
+            "traced_frac_of_peak": round(flops / (total * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4), "top": rows[:top],
+            "by_kind_us": {k: round(sum(r["step_us"] for r in rows if r["kind"] == k), 1) for k in sorted({r["kind"] for r in rows})}}
 
 
 def hbm_rooflines(torch, K, batch=32, iters=20):
@@ -500,7 +545,7 @@ def main():
         gt = torch.from_numpy(batch_np["sunpose_gt"]).to(dev)
         res["data"] = "synthetic (seeded sky-dome + sun lobe + sensor noise, random-init weights, synthetic VGG16 weights)"
         do_train, do_fwd = args.workload in ("all", "train"), args.workload in ("all", "fwd")
-        roof_pw = None
+        roof_pw, roof_top = None, None
         if do_train:
             tr = trainer.Trainer(gen, sun, dis, vgg, device=dev, precise=False, compute=K.BF16, world_size=world,
                                  distortion_aware=args.da)
@@ -522,6 +567,8 @@ def main():
                 one_step = lambda: tr.replay(hooks=hooks, pre_hooks=pre_hooks)
             dt = timed(torch, dist, one_step, args.steps, args.warmup, dp, dev)
             assert torch.isfinite(out["y_final_lin"]).all()
+            if rank == 0 and not args.no_roofline_top:
+                roof_top = roofline_top(torch, K, tr, ldr, hdr, gt)
             imgs = batch * world * args.steps
             res.update({
                 "metric": "training images/sec (32x128 sky panoramas); generator fwd ms/img in `fwd`" if do_fwd else
@@ -572,6 +619,8 @@ def main():
             res["sunpose_fc"] = fc_row
         else:
             res["roofline"] = dominant_kernel_roofline(torch, K, roof_pw, batch, 32, 128)
+            if roof_top is not None:
+                res["roofline_top"] = roof_top
             res["roofline_hbm"] = hbm_rooflines(torch, K, batch)
             res["parity"] = parity_object(torch, mods, dev, (gen, sun, dis, vgg), batch,
                                           None if args.no_cpu_baseline else oracle_outputs_fn(torch))

@@ -109,6 +109,11 @@ SIGNATURES = {
     "hdrsky_zero": (c_int, [P, c_size_t, P]),
     "hdrsky_bn_bwd_nblocks": (c_int, []),
     "hdrsky_bn_act_bwd": (c_int, [P, P, P, P, P, P, c_float, c_int, c_int, P, P, P, P, c_int, P]),
+    "hdrsky_bn_act_bwd_reduce": (c_int, [P, P, P, P, P, P, c_float, c_int, c_int, P, P]),
+    "hdrsky_bn_act_bwd_apply": (c_int, [P, P, P, P, P, P, c_float, c_int, c_int, P, c_int, ctypes.c_double, P, c_int, P, P, P, P,
+                                        c_int, P]),
+    "hdrsky_sun_rad_bwd_reduce": (c_int, [P, P, P, P, P, c_int, c_int, P, P, P]),
+    "hdrsky_sun_rad_bwd_apply": (c_int, [P, P, P, P, c_int, c_int, c_int, P, P]),
     "hdrsky_affine_act_bwd": (c_int, [P, P, P, P, c_float, c_size_t, c_int, P, c_int, P]),
     "hdrsky_maxpool_fwd": (c_int, [P, c_int, c_int, c_int, c_int, P, P]),
     "hdrsky_maxpool_relu_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P]),

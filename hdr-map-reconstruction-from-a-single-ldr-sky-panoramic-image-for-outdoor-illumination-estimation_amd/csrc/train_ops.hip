@@ -101,6 +101,23 @@ __global__ void __launch_bounds__(64) bn_bwd_finalize_kernel(const float* __rest
   if (dgamma) dgamma[c] += s2;
 }
 
+// The same for a batch that is spread over several replicas (SyncBN, parallel.py sync_batch_stats): the two means of the
+// apply pass run over the partial blocks of EVERY replica (part_all, gathered; count_all = the global pixel count), while
+// the parameter gradients receive this replica's blocks only (the gradient exchange sums them over the replicas)
+__global__ void __launch_bounds__(64) bn_bwd_finalize2_kernel(const float* __restrict__ part_all, int nblocks_all, float count_all,
+                                                              const float* __restrict__ part_local, int nblocks_local, int C,
+                                                              float* m1m2, float* dgamma, float* dbeta) {
+  const int c = blockIdx.x;
+  float s1 = 0.f, s2 = 0.f, l1 = 0.f, l2 = 0.f;
+  for (int b = threadIdx.x; b < nblocks_all; b += 64) { s1 += part_all[((size_t)b * 2) * C + c]; s2 += part_all[((size_t)b * 2 + 1) * C + c]; }
+  for (int b = threadIdx.x; b < nblocks_local; b += 64) { l1 += part_local[((size_t)b * 2) * C + c]; l2 += part_local[((size_t)b * 2 + 1) * C + c]; }
+  s1 = wave_sum(s1); s2 = wave_sum(s2); l1 = wave_sum(l1); l2 = wave_sum(l2);
+  if (threadIdx.x != 0) return;
+  m1m2[c] = s1 / count_all; m1m2[C + c] = s2 / count_all;
+  if (dbeta) dbeta[c] += l1;
+  if (dgamma) dgamma[c] += l2;
+}
+
 // four consecutive elements of a gradient tensor, fp32 or bf16 (element group i4)
 __device__ __forceinline__ void st4(void* p, int as_bf16, size_t i4, const float (&o)[4]) {
   if (as_bf16)
@@ -722,14 +739,20 @@ __global__ void __launch_bounds__(256) sun_rad_bwd_kernel(const float* __restric
 
 // dcmf (+)= dx/gmax, and at the arg-max element(s) of the whole batch: -= sum_b dotx[b] / gmax^2 / (number of them)
 // (tf.reduce_max over the batch tensor, generator.py:160; ties share the gradient evenly as in TF's _MinOrMaxGrad)
+// rec: nrec records of (dotx[B], tie count) - one for a batch on one GPU; one per replica (all-gathered) when the maximum
+// runs over the batch of every replica (parallel.py sync_batch_stats)
 __global__ void sun_rad_bwd_cmf_kernel(const float* __restrict__ cmf, const unsigned int* gmax_bits,
-                                       const float* __restrict__ dx, const float* __restrict__ dotx, int B, int P,
-                                       const int* __restrict__ claimed, float* __restrict__ dcmf) {
+                                       const float* __restrict__ dx, const float* __restrict__ rec, int nrec, int B, int P,
+                                       float* __restrict__ dcmf) {
   const float gmax = __uint_as_float(*gmax_bits);
   float tot = 0.f;
-  for (int b = 0; b < B; ++b) tot += dotx[b];
+  int ties = 0;
+  for (int r = 0; r < nrec; ++r) {
+    const float* dotx = rec + (size_t)r * (B + 1);
+    for (int b = 0; b < B; ++b) tot += dotx[b];
+    ties += __float_as_int(dotx[B]);
+  }
   const size_t n = (size_t)B * P;
-  const int ties = *claimed;
   const float share = ties > 0 ? tot / (gmax * gmax) / (float)ties : 0.f;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     float g = dx[i] / gmax;
@@ -977,6 +1000,30 @@ int hdrsky_bn_train_finalize(const float* part, int nparts_total, int C, int cou
 /* workspace: (2*nblocks*C + 2*C) floats, nblocks = hdrsky_bn_bwd_nblocks() */
 int hdrsky_bn_bwd_nblocks(void) { return 128; }
 
+int hdrsky_bn_act_bwd_reduce(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
+                             const float* beta, float slope, int npix, int C, float* part, void* stream) {
+  if (!x || !dy || !mean || !rstd || !gamma || !beta || !part || (C & 3) || C > 1024) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(128), dim3(256), 256 * 8 * sizeof(float), S_(stream), x, dy, mean, rstd,
+                     gamma, beta, slope, (size_t)npix, C, part);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_bn_act_bwd_apply(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
+                            const float* beta, float slope, int npix, int C, const float* part_all, int nblocks_all,
+                            double count_all, const float* part_local, int nblocks_local, float* m1m2, float* dgamma,
+                            float* dbeta, void* dx, int dx_bf16, void* stream) {
+  if (!x || !dy || !mean || !rstd || !gamma || !beta || !part_all || !part_local || !m1m2 || !dx || (C & 3) || C > 1024 ||
+      nblocks_all < 1 || nblocks_local < 0 || !(count_all > 0.0))
+    return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(bn_bwd_finalize2_kernel, dim3(C), dim3(64), 0, S_(stream), part_all, nblocks_all, (float)count_all,
+                     part_local, nblocks_local, C, m1m2, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for((size_t)npix * C / 4)), dim3(256), 0, S_(stream), x, dy, mean,
+                     rstd, gamma, beta, slope, m1m2, (size_t)npix * C / 4, C, dx, dx_bf16);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
 int hdrsky_bn_act_bwd(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
                       const float* beta, float slope, int npix, int C, float* workspace, float* dgamma, float* dbeta,
                       void* dx, int dx_bf16, void* stream) {
@@ -1152,19 +1199,34 @@ int hdrsky_decoder_tail_bwd(const float* y, const float* res, const float* dy, s
 }
 
 /* scratch: B*P + B floats + 1 int (count of the elements equal to the maximum, zeroed here); dcmf is accumulated into */
-int hdrsky_sun_rad_bwd(const float* cmf, const void* gmax_bits, const float* gamma, const float* beta, const float* drg3,
-                       int B, int P, float* scratch, float* dpre, float* dcmf, void* stream) {
-  if (!cmf || !gmax_bits || !gamma || !beta || !drg3 || !scratch || !dpre || !dcmf || (size_t)B * P > 0x7fffffffu) return HDRSKY_EINVAL;
+int hdrsky_sun_rad_bwd_reduce(const float* cmf, const void* gmax_bits, const float* gamma, const float* beta, const float* drg3,
+                              int B, int P, float* scratch, float* dpre, void* stream) {
+  if (!cmf || !gmax_bits || !gamma || !beta || !drg3 || !scratch || !dpre || (size_t)B * P > 0x7fffffffu) return HDRSKY_EINVAL;
   float* dx = scratch;
   float* dotx = scratch + (size_t)B * P;
   int* claimed = reinterpret_cast<int*>(dotx + B);
   hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, S_(stream), (unsigned*)claimed, (size_t)1);   // (see hdrsky_zero)
   hipLaunchKernelGGL(sun_rad_bwd_kernel, dim3(B), dim3(256), 0, S_(stream), cmf, (const unsigned int*)gmax_bits, gamma, beta,
                      drg3, P, dx, dpre, dotx, B * P, claimed);
-  hipLaunchKernelGGL(sun_rad_bwd_cmf_kernel, dim3(grid_for((size_t)B * P)), dim3(256), 0, S_(stream), cmf,
-                     (const unsigned int*)gmax_bits, dx, dotx, B, P, claimed, dcmf);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
+}
+
+int hdrsky_sun_rad_bwd_apply(const float* cmf, const void* gmax_bits, const float* scratch, const float* rec, int nrec, int B,
+                             int P, float* dcmf, void* stream) {
+  if (!cmf || !gmax_bits || !scratch || !rec || nrec < 1 || !dcmf) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(sun_rad_bwd_cmf_kernel, dim3(grid_for((size_t)B * P)), dim3(256), 0, S_(stream), cmf,
+                     (const unsigned int*)gmax_bits, scratch, rec, nrec, B, P, dcmf);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_sun_rad_bwd(const float* cmf, const void* gmax_bits, const float* gamma, const float* beta, const float* drg3,
+                       int B, int P, float* scratch, float* dpre, float* dcmf, void* stream) {
+  if (!dcmf) return HDRSKY_EINVAL;
+  const int rc = hdrsky_sun_rad_bwd_reduce(cmf, gmax_bits, gamma, beta, drg3, B, P, scratch, dpre, stream);
+  if (rc != HDRSKY_OK) return rc;
+  return hdrsky_sun_rad_bwd_apply(cmf, gmax_bits, scratch, scratch + (size_t)B * P, 1, B, P, dcmf, stream);
 }
 
 int hdrsky_dense_heads_bwd(const float* x, const float* scale, const float* shift, float slope, int B, int F, int C,

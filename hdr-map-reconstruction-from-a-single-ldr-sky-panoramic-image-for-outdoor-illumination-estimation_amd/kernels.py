@@ -28,6 +28,7 @@ def _stream():
 # current stream (it keeps its operands alive).  label(name) names the next traced launch(es) - the trainer sets it.
 TRACE = None
 _LABEL = [None]
+WG_NAMES = {}          # data_ptr of a weight-gradient destination -> layer name (set by the trainer; labels of traced calls)
 
 
 def label(name):
@@ -338,6 +339,7 @@ def conv2d_wgrad_multi(jobs, deterministic=True):
     if TRACE is not None:
         flop = sum(2.0 * j[0].B * j[0].Ho * j[0].Wo * j[0].KH * j[0].KW * j[0].Cin * j[0].Cout for j in jobs)
         d0 = jobs[0][0]
+        _LABEL[0] = ", ".join(WG_NAMES.get(j[4].data_ptr(), "?") for j in jobs)
         _trace("wgrad", "conv_wgrad_kernel + wgrad_reduce_kernel (%d layers in one call)" % len(jobs),
                "%d x e.g. %dx%d %d->%d @%dx%d B=%d" % (len(jobs), d0.KH, d0.KW, d0.Cin, d0.Cout, d0.Ho, d0.Wo, d0.B), flop,
                lambda a_=arr, n_=len(jobs), w_=ws, k_=jobs: L.check(
@@ -697,18 +699,30 @@ def zero_(t):
     return t
 
 
-def bn_act_bwd(x, dy, mean, rstd, gamma, beta, slope, dgamma=None, dbeta=None, out=None, out_bf16=False):
+def bn_act_bwd(x, dy, mean, rstd, gamma, beta, slope, dgamma=None, dbeta=None, out=None, out_bf16=False, sync=None):
+    """Gradient through LeakyReLU(BatchNorm(x)) in training mode.  sync (parallel.BatchSync): the batch statistics ran over
+    every replica's batch - the two means of the formula then run over the all-gathered partial blocks, d gamma / d beta
+    over this replica's (the gradient exchange sums them)."""
     _f32(x); _f32(dy, *x.shape)
     C = x.shape[-1]
     npix = x.numel() // C
     lib = L.load()
-    ws = torch.empty((2 * lib.hdrsky_bn_bwd_nblocks() * C + 2 * C,), dtype=torch.float32, device=x.device)
+    nb = lib.hdrsky_bn_bwd_nblocks()
+    ws = torch.empty((2 * nb * C + 2 * C,), dtype=torch.float32, device=x.device)
     if out_bf16:
         dx = _bf16(out, *x.shape) if out is not None else torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
     else:
         dx = _f32(out, *x.shape) if out is not None else torch.empty_like(x)
-    L.check(lib.hdrsky_bn_act_bwd(_p(x), _p(dy), _p(_f32(mean, C)), _p(_f32(rstd, C)), _p(_f32(gamma, C)), _p(_f32(beta, C)),
-                                  slope, npix, C, _p(ws), _p(dgamma), _p(dbeta), _p(dx), int(out_bf16), _stream()), "bn_act_bwd")
+    args = (_p(x), _p(dy), _p(_f32(mean, C)), _p(_f32(rstd, C)), _p(_f32(gamma, C)), _p(_f32(beta, C)), slope, npix, C)
+    if sync is None:
+        L.check(lib.hdrsky_bn_act_bwd(*args, _p(ws), _p(dgamma), _p(dbeta), _p(dx), int(out_bf16), _stream()), "bn_act_bwd")
+        return dx
+    part = ws[:2 * nb * C].view(nb, 2, C)
+    L.check(lib.hdrsky_bn_act_bwd_reduce(*args, _p(part), _stream()), "bn_act_bwd_reduce")
+    allp = sync.gather_rows(part)                       # [world * nb, 2, C], replica order
+    L.check(lib.hdrsky_bn_act_bwd_apply(*args, _p(allp), allp.shape[0], float(npix) * sync.world, _p(part), nb,
+                                        _p(ws[2 * nb * C:]), _p(dgamma), _p(dbeta), _p(dx), int(out_bf16), _stream()),
+            "bn_act_bwd_apply")
     return dx
 
 
@@ -876,12 +890,22 @@ def decoder_tail_bwd(y, res, dy, want_dres):
     return dc, dres
 
 
-def sun_rad_bwd(cmf, gmax_bits, gamma, beta, drg3, dcmf):
+def sun_rad_bwd(cmf, gmax_bits, gamma, beta, drg3, dcmf, sync=None):
+    """sync (parallel.BatchSync): gmax is the maximum over every replica's batch - the maximum's gradient term and the
+    tie count are then summed over the all-gathered per-replica records."""
     B, P = cmf.shape
     scratch = torch.empty((B * P + B + 4,), dtype=torch.float32, device=cmf.device)
     dpre = torch.empty((B, 2), dtype=torch.float32, device=cmf.device)
-    L.check(L.load().hdrsky_sun_rad_bwd(_p(cmf), _p(gmax_bits), _p(gamma), _p(beta), _p(_f32(drg3)), B, P, _p(scratch), _p(dpre),
-                                        _p(_f32(dcmf, B, P)), _stream()), "sun_rad_bwd")
+    lib = L.load()
+    if sync is None:
+        L.check(lib.hdrsky_sun_rad_bwd(_p(cmf), _p(gmax_bits), _p(gamma), _p(beta), _p(_f32(drg3)), B, P, _p(scratch), _p(dpre),
+                                       _p(_f32(dcmf, B, P)), _stream()), "sun_rad_bwd")
+        return dpre
+    L.check(lib.hdrsky_sun_rad_bwd_reduce(_p(cmf), _p(gmax_bits), _p(gamma), _p(beta), _p(_f32(drg3)), B, P, _p(scratch), _p(dpre),
+                                          _stream()), "sun_rad_bwd_reduce")
+    rec = sync.gather_rows(scratch[B * P:B * P + B + 1].view(1, B + 1))      # [world, B + 1]
+    L.check(lib.hdrsky_sun_rad_bwd_apply(_p(cmf), _p(gmax_bits), _p(scratch), _p(rec), rec.shape[0], B, P, _p(_f32(dcmf, B, P)),
+                                         _stream()), "sun_rad_bwd_apply")
     return dpre
 
 

@@ -55,6 +55,38 @@ def broadcast_params_(flat_buffers, src=0):
         dist.broadcast(t, src=src)
 
 
+class BatchSync:
+    """The in-step collectives of the optional "one global batch" semantics: with it N replicas of
+    batch B compute the reference's step at batch N*B exactly - Keras BatchNormalization statistics (discriminator.py:16,24,
+    sunrad_net.py:17,25) and tf.reduce_max(sunpose_pred) (generator.py:160) run over the batch of EVERY replica, forward
+    and backward - instead of the default N independent batch-B steps whose gradients are averaged.  The trainer calls these
+    at the four coupling points; every call is a small collective on the step's own stream (a few KB: per-tile moment
+    partials, partial gradient sums, one word), so such a step is issued eagerly, not replayed from hipGraphs."""
+
+    def __init__(self):
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+
+    def gather_rows(self, t):
+        """[n, ...] -> [world * n, ...]: the rows of every replica, in replica order (identical on every replica)."""
+        t = t.contiguous()
+        if self.world == 1:
+            return t
+        out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t)
+        return out
+
+    def gather_stats(self, st):
+        """Per-tile moment partials [B, nparts, 2, C] of a conv output -> those of the global batch [world * B, ...]."""
+        from .kernels import Stats
+        return Stats(self.gather_rows(st.part), st.nparts, st.count)
+
+    def max_word(self, w):
+        """int32[1] holding the bit pattern of a non-negative float (the soft-max head's max accumulator): max over replicas."""
+        if self.world > 1:
+            dist.all_reduce(w, op=dist.ReduceOp.MAX)
+        return w
+
+
 MODES = ("allreduce", "allreduce_bf16", "gather_dense")
 DEFAULT_MODE = "gather_dense"      # 53 MB per step instead of 233 MB, and the Dense gradients are never even written
 
@@ -92,7 +124,11 @@ class GradientExchange:
         tr.step(..., update=False); ex.reduce_all(); tr.apply_gradients()   # eager path
     """
 
-    def __init__(self, trainer, device=None, mode=None):
+    def __init__(self, trainer, device=None, mode=None, sync_batch_stats=False):
+        """sync_batch_stats=True: BatchNorm batch statistics and the batch-global maximum run over every replica's batch
+        (BatchSync) - N replicas of batch B then take the reference's batch N*B step, to fp32 round-off.  Such a step couples
+        the replicas inside the forward and backward passes, so it is issued eagerly (step / reduce_all /
+        apply_gradients), not captured."""
         mode = mode or os.environ.get("HDRSKY_DP_MODE") or DEFAULT_MODE
         if mode not in MODES:
             raise ValueError("unknown data-parallel mode %r (one of %s)" % (mode, ", ".join(MODES)))
@@ -112,6 +148,9 @@ class GradientExchange:
         elif self.active:
             trainer.fused_dense = False           # the Dense gradients travel: they have to be written out
         self._gbuf = {}
+        self.sync_batch_stats = bool(sync_batch_stats)
+        if self.sync_batch_stats:
+            trainer.sync = BatchSync()
 
     def describe(self):
         return {"allreduce": "RCCL all-reduce of fp32 gradients, Dense slice overlapped with backward",

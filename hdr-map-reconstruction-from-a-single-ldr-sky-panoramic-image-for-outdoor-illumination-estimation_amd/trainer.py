@@ -137,6 +137,7 @@ class Trainer:
         self.fused_dense = bool(fused_dense) and self.dense_mfma
         self.dense_operands = None          # (flat, df1, f1, dz) of the GLOBAL batch, set by parallel.GradientExchange
         self.on_bind = None                 # callable(B) run when a step is bound to a batch (static exchange buffers)
+        self.sync = None                    # parallel.BatchSync: batch statistics / the batch maximum over every replica's batch
         named = OrderedDict(("gen." + k, v) for k, v in gen_params.items())
         if not self.ext_sun:
             named.update(("sun." + k, v) for k, v in sun_params.items())
@@ -309,6 +310,7 @@ class Trainer:
         cv = self.conv[name]
         grads = self.ds.g if name.startswith("dis.") else self.gs.g
         q = self._wjobs.setdefault(torch.cuda.current_stream().cuda_stream, [])
+        K.WG_NAMES[grads[cv.wkey].data_ptr()] = name
         q.append(cv.wgrad_job(x, xf, dy, grads[cv.wkey], grads[cv.bkey] if cv.bkey else None, self.compute))
 
     def _da(self, h, w, k=3):
@@ -328,6 +330,7 @@ class Trainer:
         cv = self.conv[name]
         g = self.gs.g
         q = self._wjobs.setdefault(torch.cuda.current_stream().cuda_stream, [])
+        K.WG_NAMES[g[cv.wkey].data_ptr()] = name
         q.append(K.wgrad_job(x, dy, cv.kh, cv.kw, g[cv.wkey], g[cv.bkey] if cv.bkey else None, stride=1, same=True, upsample=1,
                              xf=None, compute=self.compute))
 
@@ -476,7 +479,9 @@ class Trainer:
             raw, st = c[net + d].fwd(cur, xf, cp, want_stats=training)
             n = net + d + ".norm."
             if training:
-                mean, rstd, sc, sh = K.bn_train_finalize(st, params[n + "gamma"], params[n + "beta"], B, raw.shape[-1],
+                if self.sync is not None:      # batch statistics over the batch of every replica
+                    st = self.sync.gather_stats(st)
+                mean, rstd, sc, sh = K.bn_train_finalize(st, params[n + "gamma"], params[n + "beta"], st.part.shape[0], raw.shape[-1],
                                                          params[n + "moving_mean"], params[n + "moving_variance"])
             else:
                 sc, sh = K.bn_eval_affine(params[n + "gamma"], params[n + "beta"], params[n + "moving_mean"],
@@ -498,7 +503,7 @@ class Trainer:
             if training:
                 draw = K.bn_act_bwd(r["raw"], dy, r["mean"], r["rstd"], params[n + "gamma"], params[n + "beta"], 0.3,
                                     grads[n + "gamma"] if do_wgrad else None, grads[n + "beta"] if do_wgrad else None,
-                                    out_bf16=b16)
+                                    out_bf16=b16, sync=self.sync)
             else:
                 draw = K.affine_act_bwd(r["raw"], dy, r["scale"], r["shift"], 0.3, out_bf16=b16)
             if do_wgrad:
@@ -528,7 +533,9 @@ class Trainer:
             halves = []
             for hf in (0, 1):
                 sth = K.Stats(st.part[hf * B:(hf + 1) * B], st.nparts, st.count)
-                mean, rstd, _, _ = K.bn_train_finalize(sth, params[n + "gamma"], params[n + "beta"], B, C,
+                if self.sync is not None:
+                    sth = self.sync.gather_stats(sth)
+                mean, rstd, _, _ = K.bn_train_finalize(sth, params[n + "gamma"], params[n + "beta"], sth.part.shape[0], C,
                                                        params[n + "moving_mean"], params[n + "moving_variance"],
                                                        scale_rows=sc2[hf * B:(hf + 1) * B], shift_rows=sh2[hf * B:(hf + 1) * B])
                 halves.append((mean, rstd))
@@ -549,7 +556,7 @@ class Trainer:
             for hf, (mean, rstd) in enumerate(r["halves"]):
                 sl = slice(hf * B, (hf + 1) * B)
                 K.bn_act_bwd(r["raw"][sl], dy[sl], mean, rstd, params[n + "gamma"], params[n + "beta"], 0.3,
-                             grads[n + "gamma"], grads[n + "beta"], out=draw[sl], out_bf16=b16)
+                             grads[n + "gamma"], grads[n + "beta"], out=draw[sl], out_bf16=b16, sync=self.sync)
             self._wg(net + d, r["x"], r["xf"], draw)
             dy = c[net + d].dgrad(r["x"], draw, cp)
         d1pre = K.affine_act_bwd(R["d1"], dy, None, None, 0.3, out_bf16=self._act_bf16())
@@ -561,6 +568,8 @@ class Trainer:
         R = self._down_stack("gen.sun.", w, plz, training=self._bn_training)
         xf = R["xf_out"]
         part = K.dense_heads(R["d4"]["raw"], xf.scale, xf.shift, 0.3, w["gen.sun.gamma.kernel"], w["gen.sun.beta.kernel"])
+        if self.sync is not None:          # tf.reduce_max(sunpose_pred) (generator.py:160) over the batch of every replica
+            self.sync.max_word(t["gmax"])
         rad_lin, rad_gamma, gamma, beta = K.sun_rad(t["cmf"], t["gmax"], part, w["gen.sun.gamma.bias"], w["gen.sun.beta.bias"],
                                                     self.h, self.w)
         S["sunrad"] = R
@@ -819,7 +828,7 @@ class Trainer:
             for sfx, dy in (("f", dsky), ("u", dsun)):
                 y, residual = T["dec_" + sfx][6], T["dec_" + sfx][7]
                 tails[sfx] = K.decoder_tail_bwd(y, residual, dy, want_dres=(sfx == "u"))
-            T["dpre"] = K.sun_rad_bwd(t["cmf"], t["gmax"], T["gamma"], T["beta"], tails["u"][1], T["dcmf"])
+            T["dpre"] = K.sun_rad_bwd(t["cmf"], t["gmax"], T["gamma"], T["beta"], tails["u"][1], T["dcmf"], sync=self.sync)
             if self.ext_sun:      # cmf is an input: its gradient (KL + sun-radiance path) has no consumer
                 return
             dz = T["dz"] = K.softmax_bwd(t["cmf"], T["dcmf"], t["z"])       # KL + the sun-radiance path meet in dcmf

@@ -296,6 +296,19 @@ int hdrsky_zero(void* p, size_t nbytes, void* stream);
 int hdrsky_bn_bwd_nblocks(void);
 /* Backward of y = leaky(BN_train(x)): dx, and dgamma/dbeta ACCUMULATED into the given buffers (nullable). */
 int hdrsky_bn_act_bwd(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma, const float* beta, float slope, int npix, int C, float* workspace, float* dgamma, float* dbeta, void* dx, int dx_bf16, void* stream);
+/* The same in two halves, for a BatchNorm whose batch is spread over several data-parallel replicas (the optional
+ * "one batch-256 step" semantics of SURVEY.md section 8e; Keras BatchNormalization over the GLOBAL batch,
+ * discriminator.py:16,24, sunrad_net.py:17,25).  _reduce writes this replica's hdrsky_bn_bwd_nblocks() partial blocks
+ * part [nblocks][2][C] = per-block (sum g, sum g*xhat); the caller all-gathers them; _apply takes the gathered blocks
+ * (part_all, nblocks_all, count_all = pixels of the global batch) for the two means of the formula and this replica's
+ * own blocks (part_local) for d gamma / d beta (+=; the gradient exchange then sums them over the replicas).
+ * m1m2: 2*C floats of scratch. */
+int hdrsky_bn_act_bwd_reduce(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
+                             const float* beta, float slope, int npix, int C, float* part, void* stream);
+int hdrsky_bn_act_bwd_apply(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
+                            const float* beta, float slope, int npix, int C, const float* part_all, int nblocks_all,
+                            double count_all, const float* part_local, int nblocks_local, float* m1m2, float* dgamma,
+                            float* dbeta, void* dx, int dx_bf16, void* stream);
 /* dx = dy*act'(x*scale[c]+shift[c])*scale[c] (BN in inference mode); scale==NULL: x is the ACTIVATED tensor and
  * dx = dy*(x>0 ? 1 : slope)  (Keras LeakyReLU / ReLU backward). */
 int hdrsky_affine_act_bwd(const float* x, const float* dy, const float* scale, const float* shift, float slope, size_t n, int C, void* dx, int dx_bf16, void* stream);
@@ -330,6 +343,14 @@ int hdrsky_decoder_tail_bwd(const float* y, const float* res, const float* dy, s
  * generator.py:160: elements tied for the maximum share its gradient evenly, as tf.reduce_max's gradient does - counted
  * with integer atomics, so the result does not depend on the order of arrival).  scratch: B*P + B floats + 1 int. */
 int hdrsky_sun_rad_bwd(const float* cmf, const void* gmax_bits, const float* gamma, const float* beta, const float* drg3, int B, int P, float* scratch, float* dpre, float* dcmf, void* stream);
+/* The same in two halves, for tf.reduce_max(sunpose_pred) (generator.py:160) taken over the batch of EVERY data-parallel
+ * replica: _reduce leaves d(cmf/max) in scratch [B*P] and, behind it, the record (dotx[B], tie count as int bits) =
+ * scratch + B*P, B+1 words; the caller all-gathers the records; _apply adds d cmf with the maximum's gradient term summed
+ * over the nrec records (rec = the local record and nrec = 1 reproduce hdrsky_sun_rad_bwd). */
+int hdrsky_sun_rad_bwd_reduce(const float* cmf, const void* gmax_bits, const float* gamma, const float* beta, const float* drg3,
+                              int B, int P, float* scratch, float* dpre, void* stream);
+int hdrsky_sun_rad_bwd_apply(const float* cmf, const void* gmax_bits, const float* scratch, const float* rec, int nrec, int B,
+                             int P, float* dcmf, void* stream);
 /* Backward of the two Dense(1) heads: dact (wrt the activated flatten), dkg/dkb/dbg/dbb accumulated. */
 int hdrsky_dense_heads_bwd(const float* x, const float* scale, const float* shift, float slope, int B, int F, int C, const float* kg, const float* kb, const float* dpre, float* dact, float* dkg, float* dkb, float* dbg, float* dbb, void* stream);
 /* out (+)= scale * x[..., c_off:c_off+c_take]  (gradient of tf.concat, discriminator.py:43). */

@@ -240,3 +240,74 @@ def test_concat_rows4_is_the_row_wise_concatenation(dev):
         assert torch.equal(out, torch.cat(parts, dim=1))
     with pytest.raises(Exception):
         K.concat_rows4([torch.zeros(2, 6, device=dev)] * 4, torch.zeros(2, 24, device=dev))     # widths must be multiples of 4
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The optional "one global batch" semantics: GradientExchange(sync_batch_stats=True)
+# ---------------------------------------------------------------------------------------------------------------------
+def _sync_worker(rank, port, out_dir, sync):
+    os.environ.update(RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    P, synth, trainer, K, par = _mods()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    par.init_from_env(backend="gloo")
+    tr = _make_trainer(2, dev)                        # fp32-class contractions
+    par.broadcast_params_([tr.gs.flat, tr.ds.flat]); tr.repack()
+    ex = par.GradientExchange(tr, device=dev, mode="allreduce", sync_batch_stats=sync)
+    assert (tr.sync is not None) == sync
+    if sync:
+        with pytest.raises(RuntimeError):
+            tr.capture(*_shard(rank, dev))            # collectives inside the segments: eager only
+    out = tr.step(*_shard(rank, dev), update=False)
+    ex.reduce_all()
+    torch.cuda.synchronize()
+    torch.save({"gg": tr.gs.grad.cpu(), "dg": tr.ds.grad.cpu(), "gs": tr.gs.flat.cpu(), "ds": tr.ds.flat.cpu(),
+                "losses": tr.losses.cpu(), "gamma": out["gamma"].cpu(), "y": out["y_final_gamma"].cpu()},
+               os.path.join(out_dir, "s%d.pt" % rank))
+    torch.distributed.destroy_process_group()
+
+
+def test_sync_batch_stats_two_replicas_equal_one_step_on_the_global_batch(dev, tmp_path):
+    """Two replicas of batch 2 with BatchNorm statistics and the batch maximum taken over BOTH batches
+    (GradientExchange(sync_batch_stats=True): all-gathered moment partials, partial gradient sums, an all-reduced max word)
+    compute the step of ONE process on the 4 images - outputs, every loss term, the moving statistics and, after the
+    exchange with gscale = 1/2, every gradient, to fp32 summation order.  Without the flag (the default: every replica its
+    own batch statistics) they do not.  The single-process step at B = 4 is itself checked against the oracle."""
+    from oracle import step as ostep
+    P, synth, trainer, K, par = _mods()
+    res = {}
+    for sync in (True, False):
+        d = tmp_path / ("sync" if sync else "local")
+        d.mkdir()
+        mp.spawn(_sync_worker, args=(_free_port(), str(d), sync), nprocs=2, join=True)
+        res[sync] = [torch.load(os.path.join(str(d), "s%d.pt" % r)) for r in (0, 1)]
+    b = synth.make_batch(2 * PER, H, W, seed=21)
+    full = [torch.from_numpy(b[k]).to(dev).contiguous() for k in ("ldr", "hdr_t", "sunpose_gt")]
+    tr = _make_trainer(1, dev)
+    nets = [{k[4:]: v.cpu().clone() for k, v in tr.gs.w.items() if k.startswith(p)} for p in ("gen.", "sun.")] + \
+           [{k[4:]: v.cpu().clone() for k, v in tr.ds.w.items()}, {k: v.cpu() for k, v in tr.vgg.items()}]
+    out = tr.step(*full, update=False)
+    torch.cuda.synchronize()
+    ng, nt = tr.gs.ntrain, tr.ds.ntrain
+    rel = lambda a, c: float((a.double() - c.double()).norm() / c.double().norm())
+    r0, r1 = res[True]
+    assert torch.equal(r0["gg"], r1["gg"]) and torch.equal(r0["dg"], r1["dg"])
+    assert torch.equal(r0["gs"][ng:], r1["gs"][ng:]) and torch.equal(r0["ds"][nt:], r1["ds"][nt:])   # identical moving statistics
+    eg, ed = rel(r0["gg"] * 0.5, tr.gs.grad.cpu()), rel(r0["dg"] * 0.5, tr.ds.grad.cpu())
+    el = rel(0.5 * (r0["losses"] + r1["losses"]), tr.losses.cpu())
+    em = max(rel(r0["gs"][ng:], tr.gs.flat.cpu()[ng:]), rel(r0["ds"][nt:], tr.ds.flat.cpu()[nt:]))
+    ey = rel(torch.cat([r0["y"], r1["y"]]), out["y_final_gamma"].cpu())
+    print("sync: gradient mismatch gen/sun %.3g disc %.3g, losses %.3g, moving stats %.3g, output %.3g" % (eg, ed, el, em, ey))
+    assert eg < 1e-4 and ed < 1e-4 and el < 1e-5 and em < 1e-5 and ey < 1e-5, (eg, ed, el, em, ey)
+    for name, (o, n, _) in tr.gs.offsets.items():     # and tensor by tensor (weights whose gradient is not rounding noise)
+        if o < ng and float(tr.gs.grad[o:o + n].abs().max()) > 1e-6:
+            assert rel(r0["gg"][o:o + n] * 0.5, tr.gs.grad[o:o + n].cpu()) < 2e-3, name
+    q0, q1 = res[False]                                # default semantics: local statistics - a different (valid) step
+    assert rel(q0["dg"] * 0.5, tr.ds.grad.cpu()) > 1e-3 and rel(torch.cat([q0["gamma"], q1["gamma"]]), out["gamma"].cpu()) > 1e-4
+    # the single-process reference point itself against the oracle at B = 4
+    ldr, hdr, gt = (torch.from_numpy(b[k]) for k in ("ldr", "hdr_t", "sunpose_gt"))
+    losses = ostep.train_step_grads(*nets, ldr, hdr, gt)[0]
+    got = tr.loss_dict()
+    for k, rk in (("kl", "kl"), ("perceptual", "perceptual"), ("dog", "dog"), ("l1", "l1"), ("adv", "adv"),
+                  ("disc_generated", "generated"), ("disc_real", "real")):
+        assert abs(got[k] - losses[rk]) <= 2e-3 * abs(losses[rk]) + 1e-6, (k, got[k], losses[rk])
