@@ -137,6 +137,8 @@ SIGNATURES = {
     "hdrsky_up2x_xf_bf16": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, P, P, c_float, c_float, P, P]),
     "hdrsky_act_bwd_bf16": (c_int, [P, P, c_float, c_size_t, P, c_int, P]),
     "hdrsky_concat2": (c_int, [P, c_int, P, c_int, c_size_t, P, P]),
+    "hdrsky_debug_wgrad2_stamps": (None, [P]),
+    "hdrsky_act_bf16": (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_int, P, c_int, P, P, c_float, c_float, P, P]),
     "hdrsky_concat_rows4": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, c_int, P, P]),
     "hdrsky_vgg_pre": (c_int, [P, c_size_t, P, P]),
     "hdrsky_flip_rgb": (c_int, [P, c_size_t, P, P]),

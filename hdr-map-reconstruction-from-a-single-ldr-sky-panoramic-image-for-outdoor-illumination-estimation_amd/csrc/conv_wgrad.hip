@@ -498,6 +498,230 @@ __global__ void __launch_bounds__(NW * 64) conv_wgrad_kernel(const MultiArgs m) 
   }
 }
 
+// ====================================================================================================================
+// v2: weight gradient of layers whose BOTH operands are final bf16 tensors (x' = the activated input the forward conv
+// consumed, dY = the gradient w.r.t. its output): the tiles are copied global -> LDS by LDS-DMA (no registers, no VALU
+// conversion) into a ring of NS stages, one barrier per tile, the copies of the next NS-1 tiles in flight under the MFMA
+// phase of the current one.  The kernel above needs ~6 us per 128-pixel tile for ~1.3 us of MFMA work: global -> registers
+// -> convert -> LDS -> barrier -> transposed reads -> barrier, nothing but one register-held tile overlapped.
+// Decomposition: workgroup = (dW block of CB x OB channels, tap group of `tgs` filter taps, pixel chunk).  Tap groups
+// are whole filter rows where the filter is larger than the group, so a group stages only the halo rows its taps read.
+// The 8 waves share the (tap, ci fragment) units of the group round robin; every unit multiplies against all OBF co
+// fragments.  LDS rows are padded by one 16-byte slot (the existing kernel's RX = 2 CB + 16 layout and therefore its
+// transposed-read addressing); the pad slot is DMA'd from a zero page like every pixel outside the image.
+// Partials go to the same [chunk][block][tap][CB][OB] slabs, summed by wgrad_reduce_kernel in a fixed order.
+// ====================================================================================================================
+__device__ __attribute__((aligned(16))) unsigned g_zero_page[4] = {0u, 0u, 0u, 0u};
+
+struct Wg2Args {
+  const unsigned short* x;       // bf16 [B,H,W,Cin]
+  const unsigned short* dy;      // bf16 [B,Ho,Wo,Cout]
+  float* ws;                     // partial slabs (as WgradArgs::ws)
+  float* ws_db;                  // bias partials, or null
+  int B, H, W, Cin, Ho, Wo, Cout;
+  int KH, KW, stride, pad_t, pad_l, ntaps;
+  int tiles_x, tiles_y, ntiles, tiles_per_wg, nchunks, cblocks, oblocks;
+  int tgs, ntg;                  // taps per group, groups
+  int TH, tw_shift, BM;          // pixel tile: TH rows x (1 << tw_shift) columns = BM pixels
+  int WT, wt_magic;              // halo row length, magic for / WT
+  int xbytes, stage_bytes, ns;   // LDS bytes of the X' part of a stage (piece-rounded), of a whole stage, ring depth
+};
+constexpr int WG2_MAXJ = 12;
+struct Multi2Args {
+  int njobs;
+  unsigned long long* stamps;    // debug: per-workgroup s_memtime phase stamps (hdrsky_debug_wgrad2_stamps), null in production
+  int first[WG2_MAXJ + 1];
+  Wg2Args job[WG2_MAXJ];
+};
+static_assert(sizeof(Multi2Args) <= 4096, "kernel argument block");
+
+__device__ __forceinline__ void wait_vmcnt(int n) {   // n: wave-uniform; larger counts than listed wait for everything (safe)
+  switch (n) {
+#define HDRSKY_VMC(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    HDRSKY_VMC(0) HDRSKY_VMC(1) HDRSKY_VMC(2) HDRSKY_VMC(3) HDRSKY_VMC(4) HDRSKY_VMC(5) HDRSKY_VMC(6) HDRSKY_VMC(7)
+    HDRSKY_VMC(8) HDRSKY_VMC(9) HDRSKY_VMC(10) HDRSKY_VMC(11) HDRSKY_VMC(12) HDRSKY_VMC(13) HDRSKY_VMC(14) HDRSKY_VMC(15)
+    HDRSKY_VMC(16) HDRSKY_VMC(17) HDRSKY_VMC(18) HDRSKY_VMC(19) HDRSKY_VMC(20) HDRSKY_VMC(21) HDRSKY_VMC(22) HDRSKY_VMC(23)
+    HDRSKY_VMC(24) HDRSKY_VMC(25) HDRSKY_VMC(26) HDRSKY_VMC(27) HDRSKY_VMC(28) HDRSKY_VMC(29) HDRSKY_VMC(30) HDRSKY_VMC(31)
+    HDRSKY_VMC(32) HDRSKY_VMC(33) HDRSKY_VMC(34) HDRSKY_VMC(35) HDRSKY_VMC(36) HDRSKY_VMC(37) HDRSKY_VMC(38) HDRSKY_VMC(39)
+    HDRSKY_VMC(40) HDRSKY_VMC(41) HDRSKY_VMC(42) HDRSKY_VMC(43) HDRSKY_VMC(44) HDRSKY_VMC(45) HDRSKY_VMC(46) HDRSKY_VMC(47)
+#undef HDRSKY_VMC
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+template <int CBF, int OBF, int UPW>
+__global__ void __launch_bounds__(512) conv_wgrad2_kernel(const Multi2Args m) {
+  constexpr int NW = 8, NT = 512;
+  constexpr int CB = CBF * 16, OB = OBF * 16;
+  constexpr int SPX = CB / 8 + 1, SPY = OB / 8 + 1;     // 16-byte slots per LDS row (the last one is padding)
+  constexpr int RX = SPX * 16, RY = SPY * 16;
+  int job = 0;
+  while (job + 1 < m.njobs && (int)blockIdx.x >= m.first[job + 1]) ++job;
+  const Wg2Args& a = m.job[job];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3, kq = g, lr = lane & 15;
+
+  const int nblk = a.cblocks * a.oblocks;
+  int l = blockIdx.x - m.first[job];
+  const int chunk = l / (nblk * a.ntg);
+  l -= chunk * nblk * a.ntg;
+  const int tg = l / nblk, blk = l - tg * nblk;
+  const int cb0 = (blk / a.oblocks) * CB, ob0 = (blk % a.oblocks) * OB;
+  const int t0 = tg * a.tgs, t1 = min(a.ntaps, t0 + a.tgs);
+  const int ky0 = t0 / a.KW, ky1 = (t1 - 1) / a.KW;
+  const int HTg = (a.TH - 1) * a.stride + (ky1 - ky0) + 1;
+  const int NPIXg = HTg * a.WT;
+  const int TW = 1 << a.tw_shift;
+
+  // ---- this wave's units -----------------------------------------------------------------------------------------------
+  const int nunits = (t1 - t0) * CBF;
+  int nmy = 0;
+  int tapoff[UPW], utap[UPW], ucif[UPW];
+#pragma unroll
+  for (int k = 0; k < UPW; ++k) {
+    const int u = wave + NW * k;
+    const int uc = min(u, nunits - 1);
+    const int tap = t0 + uc / CBF, cif = uc % CBF;
+    utap[k] = tap; ucif[k] = cif;
+    tapoff[k] = ((tap / a.KW - ky0) * a.WT + tap % a.KW) * RX + cif * 32;
+    if (u < nunits) nmy = k + 1;
+  }
+  f32x4_t acc[UPW][OBF];
+#pragma unroll
+  for (int k = 0; k < UPW; ++k)
+#pragma unroll
+    for (int j = 0; j < OBF; ++j) acc[k][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int tile0 = chunk * a.tiles_per_wg;
+  const int ntl = min(a.ntiles, tile0 + a.tiles_per_wg) - tile0;
+  const int tps = a.tiles_x * a.tiles_y;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+  // DMA pieces (1 KiB = 64 slots) of a stage: X' pieces first, then dY pieces; wave w issues pieces w, w + 8, ...
+  const int px_pieces = (NPIXg * SPX + 63) >> 6, py_pieces = (a.BM * SPY + 63) >> 6;
+  const int n_w = (px_pieces - wave + NW - 1) / NW + (py_pieces - wave + NW - 1) / NW;   // DMA instructions per tile, this wave
+
+  auto issue = [&](int tile, int st) {
+    const int b = tile / tps, tr_ = tile - b * tps;
+    const int ty = tr_ / a.tiles_x, tx = tr_ - ty * a.tiles_x;
+    const int oy0 = ty * a.TH, ox0 = tx * TW;
+    const int iy0 = oy0 * a.stride - a.pad_t + ky0, ix0 = ox0 * a.stride - a.pad_l;
+    const unsigned sbase = lds0 + (unsigned)st * (unsigned)a.stage_bytes;
+    const unsigned short* xb = a.x + (size_t)b * a.H * a.W * a.Cin + cb0;
+    for (int pc = wave; pc < px_pieces; pc += NW) {
+      const int S = pc * 64 + lane;
+      const int R = S / SPX, c = S - R * SPX;
+      const int hy = (int)(((unsigned)R * (unsigned)a.wt_magic) >> 24), hx = R - hy * a.WT;
+      const int cy = iy0 + hy, cx = ix0 + hx;
+      const bool ok = c < CB / 8 && R < NPIXg && cy >= 0 && cy < a.H && cx >= 0 && cx < a.W;
+      const void* src = ok ? (const void*)(xb + ((size_t)cy * a.W + cx) * a.Cin + c * 8) : (const void*)g_zero_page;
+      glds16(src, sbase + (unsigned)pc * 1024u);
+    }
+    const unsigned short* yb = a.dy + (size_t)b * a.Ho * a.Wo * a.Cout + ob0;
+    for (int pc = wave; pc < py_pieces; pc += NW) {
+      const int S = pc * 64 + lane;
+      const int mr = S / SPY, c = S - mr * SPY;
+      const int oy = oy0 + (mr >> a.tw_shift), ox = ox0 + (mr & (TW - 1));
+      const bool ok = c < OB / 8 && mr < a.BM && oy < a.Ho && ox < a.Wo;
+      const void* src = ok ? (const void*)(yb + ((size_t)oy * a.Wo + ox) * a.Cout + c * 8) : (const void*)g_zero_page;
+      glds16(src, sbase + (unsigned)a.xbytes + (unsigned)pc * 1024u);
+    }
+  };
+
+  const bool do_bias = a.ws_db != nullptr && cb0 == 0 && tg == 0;
+  float bsum = 0.f;
+  const int step4 = 4 * a.stride * RX;
+  const int ahead = a.ns - 1;
+  unsigned long long tw = 0, ti = 0, tc = 0, t_a = 0, t_b = 0, t_c = 0, t_d = 0;
+  const bool dbg = m.stamps != nullptr;
+  if (dbg && tid == 0) m.stamps[(size_t)blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memtime();
+  for (int i = 0; i < ahead && i < ntl; ++i) issue(tile0 + i, i);
+  if (dbg && tid == 0) m.stamps[(size_t)blockIdx.x * 8 + 1] = __builtin_amdgcn_s_memtime();
+  int st = 0;
+  for (int i = 0; i < ntl; ++i) {
+    if (dbg) t_a = __builtin_amdgcn_s_memtime();
+    wait_vmcnt(n_w * min(a.ns - 2, ntl - 1 - i));   // this wave's copies of tile i have landed (later tiles may still fly)
+    __syncthreads();                                // ... everybody's have, and everybody is done with tile i - 1's stage
+    if (dbg) t_b = __builtin_amdgcn_s_memtime();
+    if (i + ahead < ntl) { int s2 = st + ahead; if (s2 >= a.ns) s2 -= a.ns; issue(tile0 + i + ahead, s2); }
+    if (dbg) t_c = __builtin_amdgcn_s_memtime();
+    const unsigned char* sX = smem + (size_t)st * a.stage_bytes;
+    const unsigned char* sY = sX + a.xbytes;
+    if (do_bias) {
+      const int col = tid & (OB - 1);
+      for (int mr = tid / OB; mr < a.BM; mr += NT / OB)
+        bsum += bf2f(*reinterpret_cast<const unsigned short*>(sY + (size_t)mr * RY + col * 2));
+    }
+    // A fragments are read one unit ahead of the MFMAs that consume them (two register sets), the dY fragments of a k-step
+    // before its first unit: with two waves per SIMD the ~100-cycle LDS round trip of a fragment read right in front of
+    // its MFMAs was what the loop waited for (7 units x 2 MFMAs per k-step for the 7x7 32->32 layer)
+#pragma unroll 1
+    for (int r = 0; r < (a.BM >> 5); ++r) {
+      const int mm = r * 32 + g * 8 + q;
+      const int mty = mm >> a.tw_shift, mtx = mm & (TW - 1);
+      const unsigned char* xrow = sX + ((mty * a.WT + mtx) * a.stride) * RX + p * 8;
+      uint4 bh[OBF];
+#pragma unroll
+      for (int j = 0; j < OBF; ++j) {
+        const unsigned char* ad = sY + (size_t)mm * RY + (j * 16 + p * 4) * 2;
+        const uint2 v0 = lds_tr(ad), v1 = lds_tr(ad + 4 * RY);
+        bh[j] = uint4{v0.x, v0.y, v1.x, v1.y};
+      }
+      uint4 af[2];
+      {
+        const uint2 v0 = lds_tr(xrow + tapoff[0]), v1 = lds_tr(xrow + tapoff[0] + step4);
+        af[0] = uint4{v0.x, v0.y, v1.x, v1.y};
+      }
+#pragma unroll
+      for (int k = 0; k < UPW; ++k) {
+        if (k < nmy) {
+          if (k + 1 < UPW) {     // (the clamped unit of a wave with fewer units re-reads a valid address; its result is unused)
+            const uint2 v0 = lds_tr(xrow + tapoff[k + 1 < UPW ? k + 1 : k]), v1 = lds_tr(xrow + tapoff[k + 1 < UPW ? k + 1 : k] + step4);
+            af[(k + 1) & 1] = uint4{v0.x, v0.y, v1.x, v1.y};
+          }
+#pragma unroll
+          for (int j = 0; j < OBF; ++j) acc[k][j] = mfma16(af[k & 1], bh[j], acc[k][j]);
+        }
+      }
+    }
+    if (dbg) { asm volatile("" ::"v"(acc[0][0][0])); t_d = __builtin_amdgcn_s_memtime(); tw += t_b - t_a; ti += t_c - t_b; tc += t_d - t_c; }
+    if (++st == a.ns) st = 0;
+  }
+  if (dbg && tid == 0) {
+    unsigned long long* d = m.stamps + (size_t)blockIdx.x * 8;
+    d[2] = __builtin_amdgcn_s_memtime(); d[3] = tw; d[4] = ti; d[5] = tc; d[6] = (unsigned long long)ntl;
+  }
+
+  // ---- epilogue: this workgroup's partial of its (chunk, block, taps) slab --------------------------------------------------
+#pragma unroll
+  for (int k = 0; k < UPW; ++k) {
+    if (k < nmy) {
+      float* dst = a.ws + (((size_t)chunk * nblk + blk) * a.ntaps + utap[k]) * (CB * OB);
+#pragma unroll
+      for (int j = 0; j < OBF; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[(ucif[k] * 16 + kq * 4 + e) * OB + j * 16 + lr] = acc[k][j][e];
+    }
+  }
+  if (do_bias) {
+    __syncthreads();                                // every wave is past its last LDS read of the ring
+    float* sRed = reinterpret_cast<float*>(smem);
+    sRed[tid] = bsum;
+    __syncthreads();
+    if (tid < OB) {
+      float s = 0.f;
+      for (int k = tid; k < NT; k += OB) s += sRed[k];
+      a.ws_db[((size_t)chunk * a.oblocks + blk % a.oblocks) * OB + tid] = s;
+    }
+  }
+  if (dbg) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) m.stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime();
+  }
+}
+
+
 // Second stage of the deterministic split-K: dw[tap][ci][co] += sum over the job's pixel chunks of the workgroup
 // partials, db likewise - always in the same order.  One launch for the jobs of a conv_wgrad_kernel launch; CB / OB = that
 // launch's block size in channels.  A block owns 256/S float4 of a chunk's slab set and S chunk slices: slice q sums the
@@ -720,6 +944,165 @@ static bool same_geo(const Geo& p, const Geo& q) {
          p.precise == q.precise && p.up == q.up;
 }
 
+
+// ---- v2 host side -------------------------------------------------------------------------------------------------------
+static bool v2_eligible(const hdrsky_wgrad_job& j) {
+  const hdrsky_conv_desc* d = &j.desc;
+  return j.x_bf16 && j.dy_bf16 && j.da_ksize == 0 && d->compute == HDRSKY_BF16 && d->upsample == 1 && d->dilate == 1 &&
+         (d->stride == 1 || d->stride == 2) && d->Cin >= 32 && (d->Cin % 32) == 0 && d->Cout >= 32 && (d->Cout % 32) == 0 &&
+         d->in_mode == HDRSKY_IN_NONE && d->in_slope == 1.f && j.x && j.dy && j.dw && d->KH * d->KW <= 64;
+}
+
+template <int CBF, int OBF, int UPW>
+struct Wgrad2Variant {
+  static constexpr int CB = CBF * 16, OB = OBF * 16, SPX = CB / 8 + 1, SPY = OB / 8 + 1;
+  // fills a job's geometry; returns the LDS bytes of its launch, or a negative error
+  static int prepare(Wg2Args& a, const hdrsky_wgrad_job& j, int wg_target) {
+    const hdrsky_conv_desc* d = &j.desc;
+    a = Wg2Args{};
+    a.x = (const unsigned short*)j.x; a.dy = (const unsigned short*)j.dy;
+    a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
+    a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.ntaps = d->KH * d->KW;
+    if ((a.Cin % CB) != 0 || (a.Cout % OB) != 0) return HDRSKY_EUNSUPPORTED;
+    const int TW = d->Wo >= 32 ? 32 : 16;
+    a.tw_shift = TW == 32 ? 5 : 4;
+    a.BM = (TW == 16 && d->Ho <= 4) ? 64 : 128;
+    a.TH = a.BM / TW;
+    a.tiles_x = cdiv(a.Wo, TW); a.tiles_y = cdiv(a.Ho, a.TH);
+    a.ntiles = a.B * a.tiles_x * a.tiles_y;
+    a.cblocks = a.Cin / CB; a.oblocks = a.Cout / OB;
+    const int maxt = UPW * 8 / CBF;
+    if (a.ntaps <= maxt) a.tgs = a.ntaps;
+    else { const int rows = maxt / a.KW; if (rows < 1) return HDRSKY_EUNSUPPORTED; a.tgs = rows * a.KW; }
+    a.ntg = cdiv(a.ntaps, a.tgs);
+    a.WT = (TW - 1) * a.stride + a.KW;
+    a.wt_magic = ((1 << 24) + a.WT - 1) / a.WT;
+    const int rows_g = cdiv(a.tgs, a.KW) < a.KH ? cdiv(a.tgs, a.KW) : a.KH;
+    const int npix = ((a.TH - 1) * a.stride + rows_g) * a.WT;
+    if ((long)npix * a.wt_magic >= (1L << 32)) return HDRSKY_EUNSUPPORTED;
+    a.xbytes = roundup(npix * SPX * 16, 1024);
+    a.stage_bytes = a.xbytes + roundup(a.BM * SPY * 16, 1024);
+    a.ns = 3 * a.stage_bytes <= 160 * 1024 ? 3 : (2 * a.stage_bytes <= 160 * 1024 ? 2 : 0);
+    if (a.ns == 0) return HDRSKY_EUNSUPPORTED;
+    // pixel split: what the launch's workgroup budget allows, but (a) at least eight tiles per workgroup - a workgroup's
+    // fixed cost (ring start-up, its partial slab) is a few tiles' worth, and a one-tile workgroup pipelines nothing - and
+    // (b) at most ~16 MB of partial slabs per layer for the reduce launch to read back (measured, batch 32: 3x3 32->64 at
+    // 16x64 split 256 ways = 15 us + 57 us of reduce; 3x3 128->128 at 8x32 split 64 ways = 17 + 21 us)
+    const int base = a.cblocks * a.oblocks * a.ntg;
+    int chunks = (wg_target + base / 2) / base;
+    const long dw_bytes = (long)a.ntaps * a.Cin * a.Cout * 4;
+    if (chunks > a.ntiles / 8) chunks = a.ntiles / 8;
+    if ((long)chunks * dw_bytes > (16L << 20)) chunks = (int)((16L << 20) / dw_bytes);
+    if (chunks < 1) chunks = 1;
+    if (chunks > a.ntiles) chunks = a.ntiles;
+    a.tiles_per_wg = cdiv(a.ntiles, chunks);
+    a.nchunks = cdiv(a.ntiles, a.tiles_per_wg);
+    return a.ns * a.stage_bytes;
+  }
+  static int launch(Multi2Args& m, int lds, hipStream_t stream) {
+    auto kern = conv_wgrad2_kernel<CBF, OBF, UPW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+          hipSuccess)
+        return HDRSKY_ELAUNCH;
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(m.first[m.njobs]), dim3(512), lds, stream, m);
+    HDRSKY_CHECK_LAUNCH();
+    return HDRSKY_OK;
+  }
+};
+
+// the four block shapes (ci fragments, co fragments); units per wave sized for <= 80 accumulator registers
+template <typename F>
+static int with_variant2(int cbf, int obf, F&& fn) {
+  if (cbf == 4 && obf == 4) return fn(Wgrad2Variant<4, 4, 5>());
+  if (cbf == 2 && obf == 4) return fn(Wgrad2Variant<2, 4, 5>());
+  if (cbf == 4 && obf == 2) return fn(Wgrad2Variant<4, 2, 8>());
+  if (cbf == 2 && obf == 2) return fn(Wgrad2Variant<2, 2, 8>());
+  return HDRSKY_EUNSUPPORTED;
+}
+
+// Launches (or, plan_only, sizes) the v2 kernel + the shared reduce for the eligible jobs among jobs[0..njobs); marks them
+// in done[].  Jobs the variant cannot take (LDS budget, geometry) stay unmarked: the caller's v1 path handles them.
+static unsigned long long* g_wg2_stamps = nullptr;
+extern "C" void hdrsky_debug_wgrad2_stamps(void* buf) { g_wg2_stamps = (unsigned long long*)buf; }
+
+static int wgrad2_groups(const hdrsky_wgrad_job* jobs, int njobs, bool* done, float* ws, size_t ws_floats, size_t* ws_used,
+                         bool plan_only, void* stream) {
+  static const int wg_hook = getenv("HDRSKY_WGRAD2_WGS") ? atoi(getenv("HDRSKY_WGRAD2_WGS")) : 0;
+  const int wg_total = wg_hook > 0 ? wg_hook : 256;
+  for (int cbf = 4; cbf >= 2; cbf -= 2)
+    for (int obf = 4; obf >= 2; obf -= 2) {
+      int members[256], nm = 0;
+      double work[256], wsum = 0.0;
+      for (int k = 0; k < njobs; ++k) {
+        if (done[k] || !v2_eligible(jobs[k])) continue;
+        const hdrsky_conv_desc& d = jobs[k].desc;
+        const int want_c = (d.Cin % 64) == 0 ? 4 : 2, want_o = (d.Cout % 64) == 0 ? 4 : 2;
+        if (want_c != cbf || want_o != obf) continue;
+        Wg2Args probe;
+        const int r = with_variant2(cbf, obf, [&](auto v) { return decltype(v)::prepare(probe, jobs[k], 1); });
+        if (r < 0) continue;
+        work[nm] = (double)d.B * d.Ho * d.Wo * d.KH * d.KW * d.Cin * d.Cout;
+        wsum += work[nm];
+        members[nm++] = k;
+      }
+      for (int base = 0; base < nm; base += WG2_MAXJ) {
+        const int cnt = nm - base < WG2_MAXJ ? nm - base : WG2_MAXJ;
+        double wpart = 0.0;
+        for (int q = 0; q < cnt; ++q) wpart += work[base + q];
+        const int rc = with_variant2(cbf, obf, [&](auto v) {
+          using V = decltype(v);
+          Multi2Args m2{};
+          MultiArgs mr{};
+          m2.njobs = mr.njobs = cnt;
+          m2.stamps = g_wg2_stamps;
+          int lds = 0, blocks = 0, rblocks = 0, maxchunks = 1;
+          for (int q = 0; q < cnt; ++q) {
+            Wg2Args tmp;
+            if (V::prepare(tmp, jobs[members[base + q]], (int)(wg_total * work[base + q] / wpart + 0.5)) >= 0 && tmp.nchunks > maxchunks)
+              maxchunks = tmp.nchunks;
+          }
+          const int S = maxchunks >= 32 ? 16 : 4;
+          for (int q = 0; q < cnt; ++q) {
+            const hdrsky_wgrad_job& j = jobs[members[base + q]];
+            Wg2Args& a = m2.job[q];
+            const int r = V::prepare(a, j, (int)(wg_total * work[base + q] / wpart + 0.5));
+            if (r < 0) return r;
+            if (r > lds) lds = r;
+            m2.first[q] = blocks;
+            blocks += a.cblocks * a.oblocks * a.ntg * a.nchunks;
+            const size_t nslab = (size_t)a.nchunks * a.cblocks * a.oblocks * a.ntaps * V::CB * V::OB;
+            const size_t nbias = (size_t)a.nchunks * a.oblocks * V::OB;
+            a.ws = ws + *ws_used;
+            a.ws_db = j.db != nullptr ? ws + *ws_used + nslab : nullptr;
+            *ws_used += nslab + (j.db != nullptr ? nbias : 0);
+            WgradArgs& ar = mr.job[q];     // what wgrad_reduce_kernel reads
+            ar = WgradArgs{};
+            ar.dw = j.dw; ar.db = j.db; ar.ws = a.ws; ar.ws_db = a.ws_db; ar.Cin = a.Cin; ar.Cout = a.Cout;
+            ar.nchunks = a.nchunks; ar.cblocks = a.cblocks; ar.oblocks = a.oblocks; ar.ntaps = a.ntaps;
+            mr.rfirst[q] = rblocks;
+            rblocks += (int)(((size_t)a.cblocks * a.oblocks * a.ntaps * V::CB * (V::OB / 4) + 256 / S - 1) / (256 / S));
+          }
+          m2.first[cnt] = blocks;
+          mr.rfirst[cnt] = rblocks;
+          if (plan_only) return (int)HDRSKY_OK;
+          if (*ws_used > ws_floats) return (int)HDRSKY_EINVAL;
+          const int r = V::launch(m2, lds, (hipStream_t)stream);
+          if (r != HDRSKY_OK) return r;
+          hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(256), 0, (hipStream_t)stream, mr, V::CB, V::OB, S);
+          HDRSKY_CHECK_LAUNCH();
+          return (int)HDRSKY_OK;
+        });
+        if (rc != HDRSKY_OK) return rc;
+        for (int q = 0; q < cnt; ++q) done[members[base + q]] = true;
+      }
+    }
+  return HDRSKY_OK;
+}
+
 }  // namespace
 
 // Shared body of the two entry points.  ws == nullptr: split-K by fp32 atomics.  Otherwise deterministic: `ws` receives
@@ -737,12 +1120,19 @@ static int wgrad_multi_impl(const hdrsky_wgrad_job* jobs, int njobs, float* ws, 
   int wg_hook = 0, force_small = 0, wg_hook_group = 0;
   if (const char* e = getenv("HDRSKY_WGRAD")) sscanf(e, "%d,%d,%d", &wg_hook, &force_small, &wg_hook_group);   // tuning hook
   // wide stride-1 layers use 64x64-channel blocks when at least three of them share a launch
-  int nwide = 0;
-  for (int i = 0; i < njobs; ++i) nwide += can_go_big(jobs[i]) ? 1 : 0;
-  const bool use_big = nwide >= 3 && !force_small;
   Geo geo[256];
   bool done[256];
-  for (int i = 0; i < njobs; ++i) { geo[i] = choose_geo(jobs[i], use_big && can_go_big(jobs[i])); done[i] = false; }
+  for (int i = 0; i < njobs; ++i) done[i] = false;
+  // layers with two final bf16 operands: the LDS-DMA ring kernel (deterministic mode only; HDRSKY_WGRAD2=0: A/B hook)
+  const bool v2_on = !(getenv("HDRSKY_WGRAD2") && atoi(getenv("HDRSKY_WGRAD2")) == 0);
+  if (v2_on && (ws != nullptr || plan_only)) {
+    const int rc2 = wgrad2_groups(jobs, njobs, done, ws, ws_floats, &ws_used, plan_only, stream);
+    if (rc2 != HDRSKY_OK) return rc2;
+  }
+  int nwide = 0;
+  for (int i = 0; i < njobs; ++i) nwide += (!done[i] && can_go_big(jobs[i])) ? 1 : 0;
+  const bool use_big = nwide >= 3 && !force_small;
+  for (int i = 0; i < njobs; ++i) if (!done[i]) geo[i] = choose_geo(jobs[i], use_big && can_go_big(jobs[i]));
   for (int i = 0; i < njobs; ++i) {
     if (done[i]) continue;
     int members[256], nm = 0;

@@ -819,6 +819,53 @@ __global__ void concat2_kernel(const float* __restrict__ a, int Ca, const float*
   }
 }
 
+
+// y = bf16(leaky(x * scale + shift, slope)) with the per-(sample, channel) affine of the consumer-side operand transform
+// (hdrsky_conv_desc in_mode: none / affine table / InstanceNorm finalised from the producer's partials, the formula of the
+// conv and weight-gradient staging): the activated input x' of a conv as a final bf16 tensor, what the LDS-DMA weight-
+// gradient kernel (conv_wgrad2_kernel) reads.  Block = (sample, slice of its pixels); thread = (pixel, 8 channels).
+__global__ void __launch_bounds__(256) act_bf16_kernel(const float* __restrict__ x, int HW, int C, int mode,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       int ss_bstride, const float* __restrict__ part, int nparts,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                       float slope, uint4* __restrict__ y, int bps) {
+  __shared__ float sSc[1024], sSh[1024];
+  const int b = blockIdx.x / bps, blk = blockIdx.x % bps;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float sc = 1.f, sh = 0.f;
+    if (mode == HDRSKY_IN_AFFINE) {
+      sc = scale[b * ss_bstride + c]; sh = shift[b * ss_bstride + c];
+    } else if (mode == HDRSKY_IN_PARTIALS) {
+      float s0, ss;
+      in_partial_sums(part + (size_t)b * nparts * 2 * C + c, nparts, C, s0, ss);
+      const float inv_count = 1.f / (float)HW;
+      const float mean = s0 * inv_count;
+      const float var = fmaxf(ss * inv_count - mean * mean, 0.f);
+      sc = gamma[c] / sqrtf(var + eps);
+      sh = beta[c] - mean * sc;
+    }
+    sSc[c] = sc; sSh[c] = sh;
+  }
+  __syncthreads();
+  const int nq = C >> 3, nitems = HW * nq;
+  const int per = (nitems + bps - 1) / bps;
+  const int i1 = min(nitems, (blk + 1) * per);
+  const float* xb = x + (size_t)b * HW * C;
+  const bool xf = mode != HDRSKY_IN_NONE;
+  for (int i = blk * per + threadIdx.x; i < i1; i += 256) {
+    const int qc = i % nq;
+    const float4 va = *reinterpret_cast<const float4*>(xb + (size_t)i * 8);
+    const float4 vb = *reinterpret_cast<const float4*>(xb + (size_t)i * 8 + 4);
+    const float in[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = xf ? leaky(in[j] * sSc[qc * 8 + j] + sSh[qc * 8 + j], slope) : leaky(in[j], slope);
+    uint4 hi, lo;
+    pack8<false>(v, hi, lo);
+    y[(size_t)b * nitems + i] = hi;
+  }
+}
+
 // out[m, :] = [s0[m, :w0] | s1[m, :w1] | s2[m, :w2] | s3[m, :w3]]: the four Dense operands of a replica (flat | df1 | f1 | dz)
 // as ONE row block for the all-gather of the gather_dense exchange (parallel.py) - 16-byte copies, widths % 4 == 0
 struct ConcatRows4 { const float4* src[4]; int w4[4]; };
@@ -1259,6 +1306,21 @@ int hdrsky_pad_channels(const float* x, size_t npix, int C, int Cpad, float* out
 int hdrsky_concat2(const float* a, int Ca, const float* b, int Cb, size_t npix, float* out, void* stream) {
   if (!a || !b || !out) return HDRSKY_EINVAL;
   hipLaunchKernelGGL(concat2_kernel, dim3(grid_for(npix * (Ca + Cb))), dim3(256), 0, S_(stream), a, Ca, b, Cb, npix, out);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_act_bf16(const float* x, int B, int HW, int C, int in_mode, const float* in_scale, const float* in_shift, int ss_bstride,
+                    const float* in_part, int in_nparts, const float* gamma, const float* beta, float eps, float slope,
+                    void* y_bf16, void* stream) {
+  if (!x || !y_bf16 || B <= 0 || HW <= 0 || C <= 0 || (C & 7) || C > 1024) return HDRSKY_EINVAL;
+  if (in_mode == HDRSKY_IN_AFFINE && (!in_scale || !in_shift)) return HDRSKY_EINVAL;
+  if (in_mode == HDRSKY_IN_PARTIALS && (!in_part || !gamma || !beta || in_nparts <= 0)) return HDRSKY_EINVAL;
+  if ((size_t)HW * (C >> 3) > 0x7fffffffu) return HDRSKY_EINVAL;
+  int bps = cdiv(HW * (C >> 3), 256 * 8);          // ~8 items per thread
+  if (bps < 1) bps = 1;
+  hipLaunchKernelGGL(act_bf16_kernel, dim3(B * bps), dim3(256), 0, S_(stream), x, HW, C, in_mode, in_scale, in_shift, ss_bstride,
+                     in_part, in_nparts, gamma, beta, eps, slope, (uint4*)y_bf16, bps);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }

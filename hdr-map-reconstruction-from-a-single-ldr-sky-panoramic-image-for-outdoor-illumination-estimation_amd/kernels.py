@@ -308,6 +308,34 @@ def wgrad_job(x, dy, KH, KW, dw, db=None, stride=1, same=True, upsample=1, xf: O
     return (d, x, dy, tabs, dw, db)
 
 
+def wgrad2_on():
+    """The LDS-DMA weight-gradient kernel (csrc/conv_wgrad.hip, conv_wgrad2_kernel) takes layers whose operands are both final
+    bf16 tensors; HDRSKY_WGRAD2=0 keeps everything on the register-staged kernel (A/B hook)."""
+    return os.environ.get("HDRSKY_WGRAD2", "1") != "0"
+
+
+def _materialise_bf16_operand(job):
+    """A weight-gradient job whose fp32 input x still needs its operand transform (InstanceNorm / BatchNorm affine +
+    activation), rewritten onto the final bf16 tensor x' = hdrsky_act_bf16(x): the LDS-DMA kernel copies its tiles without
+    touching a register.  Only for the layers that kernel takes (single-product mode, bf16 dY, 32-channel multiples,
+    no resize / distortion-aware gather); everything else is returned unchanged."""
+    if len(job) > 6:
+        return job
+    d, x, dy, tabs, dw, db = job
+    if d.compute != BF16 or dy.dtype != torch.bfloat16 or x.dtype != torch.float32 or d.upsample != 1 or d.dilate != 1 or \
+            d.Cin < 32 or d.Cin % 32 or d.Cout < 32 or d.Cout % 32 or d.Cin > 1024:
+        return job
+    B, H, W, C = x.shape
+    xb = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=x.device)
+    in_scale, in_shift, in_part, in_gamma, in_beta = tabs
+    L.check(L.load().hdrsky_act_bf16(_p(x), B, H * W, C, d.in_mode, _p(in_scale), _p(in_shift), d.ss_bstride, _p(in_part),
+                                     d.in_nparts, _p(in_gamma), _p(in_beta), d.in_eps, d.in_slope, _p(xb), _stream()), "act_bf16")
+    d2 = L.ConvDesc()
+    ctypes.memmove(ctypes.byref(d2), ctypes.byref(d), ctypes.sizeof(d))
+    d2.in_mode, d2.in_slope, d2.ss_bstride, d2.in_nparts = L.IN_NONE, 1.0, 0, 0
+    return (d2, xb, dy, (None, None, None, None, None), dw, db)
+
+
 def conv2d_wgrad_multi(jobs, deterministic=True):
     """Weight gradients of several independent conv layers in as few launches as the library can manage.
     deterministic (default): the split-K partials go through a scratch buffer and are added in a fixed order - the
@@ -316,6 +344,8 @@ def conv2d_wgrad_multi(jobs, deterministic=True):
         jobs = [job for job in jobs if not (len(job) > 6 and _da_wgrad_region(job))]
     if not jobs:
         return
+    if deterministic and wgrad2_on() and os.environ.get("HDRSKY_WGRAD_ATOMIC", "0") != "1":
+        jobs = [_materialise_bf16_operand(job) for job in jobs]
     arr = (L.WgradJob * len(jobs))()
     for i, job in enumerate(jobs):
         d, x, dy, tabs, dw, db = job[:6]

@@ -1201,6 +1201,9 @@ class Trainer:
     def capture(self, ldr, hdr_t, sunpose_gt, warmup=2, cmf=None, cams=None):
         """Captures every segment of the step on (ldr, hdr_t, sunpose_gt[, cmf, cams]) - static input buffers the caller
         refills - into its own hipGraph.  `replay()` then runs one step."""
+        if self.sync is not None:
+            raise RuntimeError("Trainer.capture: a step with batch statistics over several replicas (parallel.BatchSync) holds "
+                               "collectives inside its segments - issue it eagerly (step / reduce_all / apply_gradients)")
         self._bind(ldr, hdr_t, sunpose_gt, cmf, cams)
         # the warm-up steps (lazy kernel attributes, allocator) must not train: weights, RMSprop slots and BatchNorm
         # moving statistics are put back afterwards (and replicas of a data-parallel job stay identical)

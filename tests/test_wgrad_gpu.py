@@ -98,3 +98,89 @@ def test_wgrad_multi_matches_autograd(dev):
             else:
                 assert_close(job[4], gw, tol, name + " dw (multi)")
             assert_close(job[5], gb, 1e-4, name + " db (multi)")
+
+
+# (name, H, W, Cin, Cout, k, stride): every layer geometry the LDS-DMA weight-gradient kernel (conv_wgrad2_kernel) takes in
+# the training step, both strides, all four dW block shapes, odd map sizes, the 128x512 configuration's res maps
+V2_LAYERS = [
+    ("res 3x3 128->128 @8x32", 8, 32, 128, 128, 3, 1), ("l3a 3x3 64->128 @8x32", 8, 32, 64, 128, 3, 1),
+    ("l2b 3x3 64->64 @16x64", 16, 64, 64, 64, 3, 1), ("l2a 3x3 32->64 @16x64", 16, 64, 32, 64, 3, 1),
+    ("dec2 3x3 64->32 @32x128", 32, 128, 64, 32, 3, 1), ("l1b 7x7 32->32 @32x128", 32, 128, 32, 32, 7, 1),
+    ("d4 4x4 256->512 @4x16", 4, 16, 256, 512, 4, 1), ("d2 4x4 s2 64->128 @16x64", 16, 64, 64, 128, 4, 2),
+    ("d3 4x4 s2 128->256 @8x32", 8, 32, 128, 256, 4, 2), ("conv2_d 3x3 s2 32->64 @32x128", 32, 128, 32, 64, 3, 2),
+    ("conv3_d 3x3 s2 64->128 @16x64", 16, 64, 64, 128, 3, 2), ("odd 3x3 64->64 @10x36", 10, 36, 64, 64, 3, 1),
+    ("odd 5x5 32->32 @7x19", 7, 19, 32, 32, 5, 1), ("hires res 3x3 128->128 @32x128", 32, 128, 128, 128, 3, 1),
+]
+
+
+@pytest.mark.parametrize("case", V2_LAYERS, ids=[c[0] for c in V2_LAYERS])
+@pytest.mark.parametrize("B", [1, 5])
+def test_wgrad_dma_kernel_layers(dev, case, B, monkeypatch):
+    """Both operands final bf16 tensors -> conv_wgrad2_kernel (LDS-DMA ring, tap groups x dW blocks x pixel chunks, shared
+    fixed-order reduce).  On the SAME bf16 operands: (a) torch autograd of the oracle conv in float64 - only the fp32
+    accumulation order differs, (b) the register-staged kernel (HDRSKY_WGRAD2=0), (c) bit-reproducible on a second call."""
+    K = pkg("kernels")
+    name, H, W, Cin, Cout, k, stride = case
+    rng = np.random.default_rng(zlib.crc32((name + str(B)).encode()))
+    xb = torch.from_numpy(rng.standard_normal((B, H, W, Cin)).astype(np.float32)).to(torch.bfloat16)
+    w = torch.zeros(k, k, Cin, Cout, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    y = T.conv2d(xb.double(), w, b, stride, "SAME")
+    dyb = torch.from_numpy(rng.standard_normal(tuple(y.shape)).astype(np.float32)).to(torch.bfloat16)
+    gw, gb = torch.autograd.grad(y, (w, b), dyb.double())
+
+    def run():
+        dw, db = torch.zeros(k, k, Cin, Cout, device=dev), torch.zeros(Cout, device=dev)
+        K.conv2d_wgrad_multi([K.wgrad_job(xb.to(dev), dyb.to(dev), k, k, dw, db, stride=stride, compute=K.BF16)])
+        return dw, db
+    dw, db = run()
+    assert_close(dw, gw, 2e-5, name + " dw (LDS-DMA kernel)")
+    assert_close(db, gb, 2e-5, name + " db (LDS-DMA kernel)")
+    dw2, db2 = run()
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    monkeypatch.setenv("HDRSKY_WGRAD2", "0")
+    dw1, db1 = run()
+    assert_close(dw1, dw, 2e-5, name + " register-staged vs LDS-DMA kernel")
+    assert_close(db1, db, 2e-5, name + " db register-staged vs LDS-DMA kernel")
+
+
+def test_wgrad_dma_kernel_on_materialised_operands(dev, monkeypatch):
+    """fp32 inputs that still need their operand transform - InstanceNorm from the producer's partials + leaky, a per-sample
+    BatchNorm affine + LeakyReLU(0.3), a plain fp32 activation - are materialised once as bf16 (hdrsky_act_bf16, the staging's
+    own arithmetic) and go through the LDS-DMA kernel: same result as the register-staged kernel that transforms while
+    staging (bf16 operands in both: only the summation order differs), several layers in one call."""
+    K = pkg("kernels"); L = pkg("_lib")
+    rng = np.random.default_rng(12)
+    B = 4
+    d = lambda a: torch.from_numpy(a).to(dev)
+
+    def jobs():
+        out = []
+        x1 = d(rng.standard_normal((B, 16, 64, 32)).astype(np.float32) * 2 + 0.3)
+        r1, st = K.conv2d(x1, K.PackedConv(d((rng.standard_normal((3, 3, 32, 64)) / 17).astype(np.float32))), None, want_stats=True,
+                          compute=K.BF16)
+        xf1 = K.InXf(mode=L.IN_PARTIALS, slope=0.1, stats=st, gamma=d(rng.uniform(0.5, 1.5, 64).astype(np.float32)),
+                     beta=d(rng.standard_normal(64).astype(np.float32)))
+        dy1 = d(rng.standard_normal((B, 16, 64, 64)).astype(np.float32)).to(torch.bfloat16)
+        out.append(K.wgrad_job(r1, dy1, 3, 3, torch.zeros(3, 3, 64, 64, device=dev), torch.zeros(64, device=dev), xf=xf1, compute=K.BF16))
+        x2 = d(rng.standard_normal((B, 8, 32, 128)).astype(np.float32))
+        xf2 = K.InXf(mode=L.IN_AFFINE, slope=0.3, scale=d(rng.uniform(0.5, 1.5, (B, 128)).astype(np.float32)),
+                     shift=d(rng.standard_normal((B, 128)).astype(np.float32)))
+        dy2 = d(rng.standard_normal((B, 4, 16, 256)).astype(np.float32)).to(torch.bfloat16)
+        out.append(K.wgrad_job(x2, dy2, 4, 4, torch.zeros(4, 4, 128, 256, device=dev), None, stride=2, xf=xf2, compute=K.BF16))
+        x3 = d(np.maximum(rng.standard_normal((B, 16, 64, 32)), 0).astype(np.float32))
+        dy3 = d(rng.standard_normal((B, 16, 64, 64)).astype(np.float32)).to(torch.bfloat16)
+        out.append(K.wgrad_job(x3, dy3, 3, 3, torch.zeros(3, 3, 32, 64, device=dev), torch.zeros(64, device=dev), compute=K.BF16))
+        return out
+    state = rng.bit_generator.state
+    a = jobs()
+    K.conv2d_wgrad_multi(a)
+    rng.bit_generator.state = state
+    monkeypatch.setenv("HDRSKY_WGRAD2", "0")
+    b = jobs()
+    K.conv2d_wgrad_multi(b)
+    for i, (ja, jb) in enumerate(zip(a, b)):
+        assert float(ja[4].abs().max()) > 0
+        assert_close(ja[4], jb[4], 3e-5, "layer %d dw: materialised bf16 operand + LDS-DMA kernel vs transform while staging" % i)
+        if ja[5] is not None:
+            assert_close(ja[5], jb[5], 3e-5, "layer %d db" % i)
