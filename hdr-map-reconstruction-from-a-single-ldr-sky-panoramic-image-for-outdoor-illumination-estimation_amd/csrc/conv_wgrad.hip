@@ -511,17 +511,21 @@ __global__ void __launch_bounds__(NW * 64) conv_wgrad_kernel(const MultiArgs m) 
 // transposed-read addressing); the pad slot is DMA'd from a zero page like every pixel outside the image.
 // Partials go to the same [chunk][block][tap][CB][OB] slabs, summed by wgrad_reduce_kernel in a fixed order.
 // ====================================================================================================================
-__device__ __attribute__((aligned(16))) unsigned g_zero_page[4] = {0u, 0u, 0u, 0u};
+__device__ __attribute__((aligned(1024))) unsigned g_zero_page[256];   // zero-initialised: 16 bytes per lane (one line-sized run per piece)
 
 struct Wg2Args {
   const unsigned short* x;       // bf16 [B,H,W,Cin]
   const unsigned short* dy;      // bf16 [B,Ho,Wo,Cout]
   float* ws;                     // partial slabs (as WgradArgs::ws)
   float* ws_db;                  // bias partials, or null
+  float* dw;                     // direct != 0 (a job that is not split over pixels): the gradient itself, += (no reduce launch)
+  float* db;
+  int direct;
   int B, H, W, Cin, Ho, Wo, Cout;
   int KH, KW, stride, pad_t, pad_l, ntaps;
   int tiles_x, tiles_y, ntiles, tiles_per_wg, nchunks, cblocks, oblocks;
   int tgs, ntg;                  // taps per group, groups
+  int cbf, obf;                  // 16-channel fragments of the dW block along ci / co (2 or 4 each)
   int TH, tw_shift, BM;          // pixel tile: TH rows x (1 << tw_shift) columns = BM pixels
   int WT, wt_magic;              // halo row length, magic for / WT
   int xbytes, stage_bytes, ns;   // LDS bytes of the X' part of a stage (piece-rounded), of a whole stage, ring depth
@@ -549,18 +553,29 @@ __device__ __forceinline__ void wait_vmcnt(int n) {   // n: wave-uniform; larger
   }
 }
 
-template <int CBF, int OBF, int UPW>
-__global__ void __launch_bounds__(512) conv_wgrad2_kernel(const Multi2Args m) {
-  constexpr int NW = 8, NT = 512;
-  constexpr int CB = CBF * 16, OB = OBF * 16;
-  constexpr int SPX = CB / 8 + 1, SPY = OB / 8 + 1;     // 16-byte slots per LDS row (the last one is padding)
-  constexpr int RX = SPX * 16, RY = SPY * 16;
+// One instantiation serves every block shape: cbf / obf (ci / co fragments of the dW block: 2 or 4 each) are job fields, so
+// that all eligible layers of a call share ONE launch and one reduce launch.  12 waves: 8 compute waves (two per SIMD) and 4
+// loader waves (one per SIMD) that only issue the LDS-DMA copies of the tile NS-1 ahead - the first version had all 8 waves
+// issue, then wait, then multiply: per tile 1.4 k cycles of issue + 1.3 k of waiting in front of 3.4 k of MFMA phase
+// (profiles/stamp_wgrad2.py).  Everybody meets at one barrier per tile.
+template <int UPW>
+__global__ void __launch_bounds__(768) conv_wgrad2_kernel(const Multi2Args m) {
+  constexpr int NWC = 8, NWL = 4, NTC = NWC * 64;
+  constexpr int OBFM = 4;                               // co fragments the accumulator array holds (obf <= 4)
+  constexpr int MAXPX = 16, MAXPY = 6;                  // DMA pieces per loader wave and tile the slot registers hold
   int job = 0;
   while (job + 1 < m.njobs && (int)blockIdx.x >= m.first[job + 1]) ++job;
   const Wg2Args& a = m.job[job];
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3, kq = g, lr = lane & 15;
+  const int cbf = a.cbf, obf = a.obf;
+  const int CB = cbf * 16, OB = obf * 16;
+  // 16-byte slots per LDS row: the channels + 2 slots of padding, i.e. row strides of 160 / 96 bytes = 32 (mod 64).  With the
+  // k permutation below the 32 lanes that a transposed read serves together touch 8 CONSECUTIVE rows x 32 bytes, and
+  // 8 consecutive multiples of such a stride cover the 64 banks exactly once: no bank conflicts
+  const int SPX = CB / 8 + 2, SPY = OB / 8 + 2;
+  const int RX = SPX * 16, RY = SPY * 16;
 
   const int nblk = a.cblocks * a.oblocks;
   int l = blockIdx.x - m.first[job];
@@ -573,100 +588,139 @@ __global__ void __launch_bounds__(512) conv_wgrad2_kernel(const Multi2Args m) {
   const int HTg = (a.TH - 1) * a.stride + (ky1 - ky0) + 1;
   const int NPIXg = HTg * a.WT;
   const int TW = 1 << a.tw_shift;
+  const int tile0 = chunk * a.tiles_per_wg;
+  const int ntl = min(a.ntiles, tile0 + a.tiles_per_wg) - tile0;
+  const int tps = a.tiles_x * a.tiles_y;
+  const int ahead = a.ns - 1;
+  const bool dbg = m.stamps != nullptr;
+  if (dbg && tid == 0) m.stamps[(size_t)blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memtime();
 
-  // ---- this wave's units -----------------------------------------------------------------------------------------------
-  const int nunits = (t1 - t0) * CBF;
+  if (wave >= NWC) {
+    // ================================ loader waves ====================================================================
+    // DMA pieces (1 KiB = 64 slots) of a stage: X' pieces first, then dY pieces; loader w issues pieces w, w + 4, ...  What
+    // a lane copies in piece k is the same in every tile up to the tile's origin: (row, column, channel chunk) of its slot
+    // are decoded once into a register per piece (bit 31: a real slot - not padding, not past the tile); per tile it is
+    // an add, two bounds tests and the address
+    const int lw = wave - NWC;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int px_pieces = (NPIXg * SPX + 63) >> 6, py_pieces = (a.BM * SPY + 63) >> 6;
+    const int nx_w = (px_pieces - lw + NWL - 1) / NWL, ny_w = (py_pieces - lw + NWL - 1) / NWL;
+    const int n_w = nx_w + ny_w;                        // DMA instructions per tile, this wave
+    unsigned xslot[MAXPX], yslot[MAXPY];
+#pragma unroll
+    for (int k = 0; k < MAXPX; ++k) {
+      const int S = (lw + NWL * k) * 64 + lane;
+      const int R = S / SPX, c = S - R * SPX;
+      const int hy = (int)(((unsigned)R * (unsigned)a.wt_magic) >> 24), hx = R - hy * a.WT;
+      xslot[k] = (unsigned)hy | ((unsigned)hx << 10) | ((unsigned)c << 20) | ((c < CB / 8 && R < NPIXg) ? 0x80000000u : 0u);
+    }
+#pragma unroll
+    for (int k = 0; k < MAXPY; ++k) {
+      const int S = (lw + NWL * k) * 64 + lane;
+      const int mr = S / SPY, c = S - mr * SPY;
+      yslot[k] = (unsigned)(mr >> a.tw_shift) | ((unsigned)(mr & (TW - 1)) << 10) | ((unsigned)c << 20) |
+                 ((c < OB / 8 && mr < a.BM) ? 0x80000000u : 0u);
+    }
+    int ib = tile0 / tps;                               // cursor of the next tile to copy, advanced incrementally
+    int ity = (tile0 - ib * tps) / a.tiles_x, itx = (tile0 - ib * tps) - ity * a.tiles_x;
+    auto issue = [&](int st) {
+      const int oy0 = ity * a.TH, ox0 = itx * TW;
+      const int iy0 = oy0 * a.stride - a.pad_t + ky0, ix0 = ox0 * a.stride - a.pad_l;
+      const unsigned sbase = lds0 + (unsigned)st * (unsigned)a.stage_bytes + (unsigned)lw * 1024u;
+      const unsigned short* xb = a.x + (size_t)ib * a.H * a.W * a.Cin + cb0;
+      const unsigned short* yb = a.dy + (size_t)ib * a.Ho * a.Wo * a.Cout + ob0;
+#pragma unroll
+      for (int k = 0; k < MAXPX; ++k) {
+        if (k < nx_w) {
+          const unsigned sl = xslot[k];
+          const int cy = iy0 + (int)(sl & 1023u), cx = ix0 + (int)((sl >> 10) & 1023u);
+          const bool ok = (int)sl < 0 && (unsigned)cy < (unsigned)a.H && (unsigned)cx < (unsigned)a.W;
+          const void* src = ok ? (const void*)(xb + (size_t)(cy * a.W + cx) * a.Cin + ((sl >> 20) & 15u) * 8) : (const void*)(g_zero_page + lane * 4);
+          glds16(src, sbase + (unsigned)k * (NWL * 1024u));
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < MAXPY; ++k) {
+        if (k < ny_w) {
+          const unsigned sl = yslot[k];
+          const int oy = oy0 + (int)(sl & 1023u), ox = ox0 + (int)((sl >> 10) & 1023u);
+          const bool ok = (int)sl < 0 && oy < a.Ho && ox < a.Wo;
+          const void* src = ok ? (const void*)(yb + (size_t)(oy * a.Wo + ox) * a.Cout + ((sl >> 20) & 15u) * 8) : (const void*)(g_zero_page + lane * 4);
+          glds16(src, sbase + (unsigned)a.xbytes + (unsigned)k * (NWL * 1024u));
+        }
+      }
+      if (++itx == a.tiles_x) { itx = 0; if (++ity == a.tiles_y) { ity = 0; ++ib; } }
+    };
+    for (int i = 0; i < ahead && i < ntl; ++i) issue(i);
+    int st = 0;
+    for (int i = 0; i < ntl; ++i) {
+      wait_vmcnt(n_w * min(a.ns - 2, ntl - 1 - i));   // this wave's copies of tile i have landed (later tiles may still fly)
+      __builtin_amdgcn_s_barrier();                   // tile i is complete; the compute waves are done with tile i - 1's stage
+      if (i + ahead < ntl) { int s2 = st + ahead; if (s2 >= a.ns) s2 -= a.ns; issue(s2); }
+      if (++st == a.ns) st = 0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (a.ws_db != nullptr || (a.direct && a.db != nullptr)) {   // the two barriers of the bias reduction below
+      if (cb0 == 0 && tg == 0) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }
+    }
+    return;
+  }
+
+  // ================================== compute waves ======================================================================
+  // units of this wave: (tap of the group, ci fragment), round robin over the 8 compute waves
+  const int nunits = (t1 - t0) * cbf;
   int nmy = 0;
   int tapoff[UPW], utap[UPW], ucif[UPW];
 #pragma unroll
   for (int k = 0; k < UPW; ++k) {
-    const int u = wave + NW * k;
+    const int u = wave + NWC * k;
     const int uc = min(u, nunits - 1);
-    const int tap = t0 + uc / CBF, cif = uc % CBF;
+    const int tl = uc / cbf, cif = uc - tl * cbf, tap = t0 + tl;
     utap[k] = tap; ucif[k] = cif;
     tapoff[k] = ((tap / a.KW - ky0) * a.WT + tap % a.KW) * RX + cif * 32;
     if (u < nunits) nmy = k + 1;
   }
-  f32x4_t acc[UPW][OBF];
+  f32x4_t acc[UPW][OBFM];
 #pragma unroll
   for (int k = 0; k < UPW; ++k)
 #pragma unroll
-    for (int j = 0; j < OBF; ++j) acc[k][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < OBFM; ++j) acc[k][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  const int tile0 = chunk * a.tiles_per_wg;
-  const int ntl = min(a.ntiles, tile0 + a.tiles_per_wg) - tile0;
-  const int tps = a.tiles_x * a.tiles_y;
-  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-
-  // DMA pieces (1 KiB = 64 slots) of a stage: X' pieces first, then dY pieces; wave w issues pieces w, w + 8, ...
-  const int px_pieces = (NPIXg * SPX + 63) >> 6, py_pieces = (a.BM * SPY + 63) >> 6;
-  const int n_w = (px_pieces - wave + NW - 1) / NW + (py_pieces - wave + NW - 1) / NW;   // DMA instructions per tile, this wave
-
-  auto issue = [&](int tile, int st) {
-    const int b = tile / tps, tr_ = tile - b * tps;
-    const int ty = tr_ / a.tiles_x, tx = tr_ - ty * a.tiles_x;
-    const int oy0 = ty * a.TH, ox0 = tx * TW;
-    const int iy0 = oy0 * a.stride - a.pad_t + ky0, ix0 = ox0 * a.stride - a.pad_l;
-    const unsigned sbase = lds0 + (unsigned)st * (unsigned)a.stage_bytes;
-    const unsigned short* xb = a.x + (size_t)b * a.H * a.W * a.Cin + cb0;
-    for (int pc = wave; pc < px_pieces; pc += NW) {
-      const int S = pc * 64 + lane;
-      const int R = S / SPX, c = S - R * SPX;
-      const int hy = (int)(((unsigned)R * (unsigned)a.wt_magic) >> 24), hx = R - hy * a.WT;
-      const int cy = iy0 + hy, cx = ix0 + hx;
-      const bool ok = c < CB / 8 && R < NPIXg && cy >= 0 && cy < a.H && cx >= 0 && cx < a.W;
-      const void* src = ok ? (const void*)(xb + ((size_t)cy * a.W + cx) * a.Cin + c * 8) : (const void*)g_zero_page;
-      glds16(src, sbase + (unsigned)pc * 1024u);
-    }
-    const unsigned short* yb = a.dy + (size_t)b * a.Ho * a.Wo * a.Cout + ob0;
-    for (int pc = wave; pc < py_pieces; pc += NW) {
-      const int S = pc * 64 + lane;
-      const int mr = S / SPY, c = S - mr * SPY;
-      const int oy = oy0 + (mr >> a.tw_shift), ox = ox0 + (mr & (TW - 1));
-      const bool ok = c < OB / 8 && mr < a.BM && oy < a.Ho && ox < a.Wo;
-      const void* src = ok ? (const void*)(yb + ((size_t)oy * a.Wo + ox) * a.Cout + c * 8) : (const void*)g_zero_page;
-      glds16(src, sbase + (unsigned)a.xbytes + (unsigned)pc * 1024u);
-    }
-  };
-
-  const bool do_bias = a.ws_db != nullptr && cb0 == 0 && tg == 0;
+  const bool do_bias = (a.direct ? a.db != nullptr : a.ws_db != nullptr) && cb0 == 0 && tg == 0;
   float bsum = 0.f;
-  const int step4 = 4 * a.stride * RX;
-  const int ahead = a.ns - 1;
-  unsigned long long tw = 0, ti = 0, tc = 0, t_a = 0, t_b = 0, t_c = 0, t_d = 0;
-  const bool dbg = m.stamps != nullptr;
-  if (dbg && tid == 0) m.stamps[(size_t)blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memtime();
-  for (int i = 0; i < ahead && i < ntl; ++i) issue(tile0 + i, i);
+  // second half of a lane's k values: 16 pixels on - the same tile row when the tile is 32 wide, the next one when 16
+  const int step4 = (TW == 32 ? 16 * a.stride : a.WT * a.stride) * RX;
+  unsigned long long tw = 0, tc = 0, t_a = 0, t_b = 0, t_d = 0;
   if (dbg && tid == 0) m.stamps[(size_t)blockIdx.x * 8 + 1] = __builtin_amdgcn_s_memtime();
   int st = 0;
   for (int i = 0; i < ntl; ++i) {
     if (dbg) t_a = __builtin_amdgcn_s_memtime();
-    wait_vmcnt(n_w * min(a.ns - 2, ntl - 1 - i));   // this wave's copies of tile i have landed (later tiles may still fly)
-    __syncthreads();                                // ... everybody's have, and everybody is done with tile i - 1's stage
+    __builtin_amdgcn_s_barrier();                     // tile i has landed (the loaders waited for it)
     if (dbg) t_b = __builtin_amdgcn_s_memtime();
-    if (i + ahead < ntl) { int s2 = st + ahead; if (s2 >= a.ns) s2 -= a.ns; issue(tile0 + i + ahead, s2); }
-    if (dbg) t_c = __builtin_amdgcn_s_memtime();
     const unsigned char* sX = smem + (size_t)st * a.stage_bytes;
     const unsigned char* sY = sX + a.xbytes;
     if (do_bias) {
       const int col = tid & (OB - 1);
-      for (int mr = tid / OB; mr < a.BM; mr += NT / OB)
+      for (int mr = tid / OB; mr < a.BM; mr += NTC / OB)
         bsum += bf2f(*reinterpret_cast<const unsigned short*>(sY + (size_t)mr * RY + col * 2));
     }
     // A fragments are read one unit ahead of the MFMAs that consume them (two register sets), the dY fragments of a k-step
-    // before its first unit: with two waves per SIMD the ~100-cycle LDS round trip of a fragment read right in front of
-    // its MFMAs was what the loop waited for (7 units x 2 MFMAs per k-step for the 7x7 32->32 layer)
+    // before its first unit
 #pragma unroll 1
     for (int r = 0; r < (a.BM >> 5); ++r) {
-      const int mm = r * 32 + g * 8 + q;
+      // k permutation: lane group g multiplies pixels {4g..4g+3} and {16+4g..16+4g+3} of the k-step's 32 (both operands
+      // alike), so that the two lane groups one transposed read serves together (g = 0,1 | 2,3) read 8 consecutive rows
+      const int mm = r * 32 + g * 4 + q;
       const int mty = mm >> a.tw_shift, mtx = mm & (TW - 1);
       const unsigned char* xrow = sX + ((mty * a.WT + mtx) * a.stride) * RX + p * 8;
-      uint4 bh[OBF];
+      uint4 bh[OBFM];
 #pragma unroll
-      for (int j = 0; j < OBF; ++j) {
-        const unsigned char* ad = sY + (size_t)mm * RY + (j * 16 + p * 4) * 2;
-        const uint2 v0 = lds_tr(ad), v1 = lds_tr(ad + 4 * RY);
-        bh[j] = uint4{v0.x, v0.y, v1.x, v1.y};
+      for (int j = 0; j < OBFM; ++j) {
+        if (j < obf) {
+          const unsigned char* ad = sY + (size_t)mm * RY + (j * 16 + p * 4) * 2;
+          const uint2 v0 = lds_tr(ad), v1 = lds_tr(ad + 16 * RY);
+          bh[j] = uint4{v0.x, v0.y, v1.x, v1.y};
+        }
       }
       uint4 af[2];
       {
@@ -681,38 +735,53 @@ __global__ void __launch_bounds__(512) conv_wgrad2_kernel(const Multi2Args m) {
             af[(k + 1) & 1] = uint4{v0.x, v0.y, v1.x, v1.y};
           }
 #pragma unroll
-          for (int j = 0; j < OBF; ++j) acc[k][j] = mfma16(af[k & 1], bh[j], acc[k][j]);
+          for (int j = 0; j < OBFM; ++j)
+            if (j < obf) acc[k][j] = mfma16(af[k & 1], bh[j], acc[k][j]);
         }
       }
     }
-    if (dbg) { asm volatile("" ::"v"(acc[0][0][0])); t_d = __builtin_amdgcn_s_memtime(); tw += t_b - t_a; ti += t_c - t_b; tc += t_d - t_c; }
+    if (dbg) { asm volatile("" ::"v"(acc[0][0][0])); t_d = __builtin_amdgcn_s_memtime(); tw += t_b - t_a; tc += t_d - t_b; }
     if (++st == a.ns) st = 0;
   }
   if (dbg && tid == 0) {
     unsigned long long* d = m.stamps + (size_t)blockIdx.x * 8;
-    d[2] = __builtin_amdgcn_s_memtime(); d[3] = tw; d[4] = ti; d[5] = tc; d[6] = (unsigned long long)ntl;
+    d[2] = __builtin_amdgcn_s_memtime(); d[3] = tw; d[4] = 0; d[5] = tc; d[6] = (unsigned long long)ntl;
   }
 
   // ---- epilogue: this workgroup's partial of its (chunk, block, taps) slab --------------------------------------------------
 #pragma unroll
   for (int k = 0; k < UPW; ++k) {
     if (k < nmy) {
-      float* dst = a.ws + (((size_t)chunk * nblk + blk) * a.ntaps + utap[k]) * (CB * OB);
+      if (a.direct) {      // the only pixel chunk: this workgroup owns these elements of dW
+        float* dst = a.dw + ((size_t)utap[k] * a.Cin + cb0) * a.Cout + ob0;
 #pragma unroll
-      for (int j = 0; j < OBF; ++j)
+        for (int j = 0; j < OBFM; ++j)
+          if (j < obf) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dst[(ucif[k] * 16 + kq * 4 + e) * OB + j * 16 + lr] = acc[k][j][e];
+            for (int e = 0; e < 4; ++e) dst[(size_t)(ucif[k] * 16 + kq * 4 + e) * a.Cout + j * 16 + lr] += acc[k][j][e];
+          }
+      } else {
+        float* dst = a.ws + (((size_t)chunk * nblk + blk) * a.ntaps + utap[k]) * (CB * OB);
+#pragma unroll
+        for (int j = 0; j < OBFM; ++j)
+          if (j < obf) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[(ucif[k] * 16 + kq * 4 + e) * OB + j * 16 + lr] = acc[k][j][e];
+          }
+      }
     }
   }
   if (do_bias) {
-    __syncthreads();                                // every wave is past its last LDS read of the ring
+    __builtin_amdgcn_s_barrier();                     // every compute wave is past its last LDS read of the ring
     float* sRed = reinterpret_cast<float*>(smem);
     sRed[tid] = bsum;
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     if (tid < OB) {
-      float s = 0.f;
-      for (int k = tid; k < NT; k += OB) s += sRed[k];
-      a.ws_db[((size_t)chunk * a.oblocks + blk % a.oblocks) * OB + tid] = s;
+      float s2 = 0.f;
+      for (int k = tid; k < NTC; k += OB) s2 += sRed[k];
+      if (a.direct) a.db[ob0 + tid] += s2;
+      else a.ws_db[((size_t)chunk * a.oblocks + blk % a.oblocks) * OB + tid] = s2;
     }
   }
   if (dbg) {
@@ -733,6 +802,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const MultiArgs m, in
   int job = 0;
   while (job + 1 < m.njobs && (int)blockIdx.x >= m.rfirst[job + 1]) ++job;
   const WgradArgs& a = m.job[job];
+  if (CB == 0) { CB = a.RX; OB = a.RY; }               // launch of conv_wgrad2_kernel: the block shape is a job field
   const int nblk = a.cblocks * a.oblocks, ob4 = OB >> 2;
   const size_t slab = (size_t)a.ntaps * CB * OB;                 // floats of one (chunk, block) partial
   const size_t nvec = (size_t)nblk * a.ntaps * CB * ob4;         // float4 of one chunk
@@ -953,153 +1023,141 @@ static bool v2_eligible(const hdrsky_wgrad_job& j) {
          d->in_mode == HDRSKY_IN_NONE && d->in_slope == 1.f && j.x && j.dy && j.dw && d->KH * d->KW <= 64;
 }
 
-template <int CBF, int OBF, int UPW>
-struct Wgrad2Variant {
-  static constexpr int CB = CBF * 16, OB = OBF * 16, SPX = CB / 8 + 1, SPY = OB / 8 + 1;
-  // fills a job's geometry; returns the LDS bytes of its launch, or a negative error
-  static int prepare(Wg2Args& a, const hdrsky_wgrad_job& j, int wg_target) {
-    const hdrsky_conv_desc* d = &j.desc;
-    a = Wg2Args{};
-    a.x = (const unsigned short*)j.x; a.dy = (const unsigned short*)j.dy;
-    a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
-    a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.ntaps = d->KH * d->KW;
-    if ((a.Cin % CB) != 0 || (a.Cout % OB) != 0) return HDRSKY_EUNSUPPORTED;
-    const int TW = d->Wo >= 32 ? 32 : 16;
-    a.tw_shift = TW == 32 ? 5 : 4;
-    a.BM = (TW == 16 && d->Ho <= 4) ? 64 : 128;
-    a.TH = a.BM / TW;
-    a.tiles_x = cdiv(a.Wo, TW); a.tiles_y = cdiv(a.Ho, a.TH);
-    a.ntiles = a.B * a.tiles_x * a.tiles_y;
-    a.cblocks = a.Cin / CB; a.oblocks = a.Cout / OB;
-    const int maxt = UPW * 8 / CBF;
-    if (a.ntaps <= maxt) a.tgs = a.ntaps;
-    else { const int rows = maxt / a.KW; if (rows < 1) return HDRSKY_EUNSUPPORTED; a.tgs = rows * a.KW; }
-    a.ntg = cdiv(a.ntaps, a.tgs);
-    a.WT = (TW - 1) * a.stride + a.KW;
-    a.wt_magic = ((1 << 24) + a.WT - 1) / a.WT;
-    const int rows_g = cdiv(a.tgs, a.KW) < a.KH ? cdiv(a.tgs, a.KW) : a.KH;
-    const int npix = ((a.TH - 1) * a.stride + rows_g) * a.WT;
-    if ((long)npix * a.wt_magic >= (1L << 32)) return HDRSKY_EUNSUPPORTED;
-    a.xbytes = roundup(npix * SPX * 16, 1024);
-    a.stage_bytes = a.xbytes + roundup(a.BM * SPY * 16, 1024);
-    a.ns = 3 * a.stage_bytes <= 160 * 1024 ? 3 : (2 * a.stage_bytes <= 160 * 1024 ? 2 : 0);
-    if (a.ns == 0) return HDRSKY_EUNSUPPORTED;
-    // pixel split: what the launch's workgroup budget allows, but (a) at least eight tiles per workgroup - a workgroup's
-    // fixed cost (ring start-up, its partial slab) is a few tiles' worth, and a one-tile workgroup pipelines nothing - and
-    // (b) at most ~16 MB of partial slabs per layer for the reduce launch to read back (measured, batch 32: 3x3 32->64 at
-    // 16x64 split 256 ways = 15 us + 57 us of reduce; 3x3 128->128 at 8x32 split 64 ways = 17 + 21 us)
-    const int base = a.cblocks * a.oblocks * a.ntg;
-    int chunks = (wg_target + base / 2) / base;
-    const long dw_bytes = (long)a.ntaps * a.Cin * a.Cout * 4;
-    if (chunks > a.ntiles / 8) chunks = a.ntiles / 8;
-    if ((long)chunks * dw_bytes > (16L << 20)) chunks = (int)((16L << 20) / dw_bytes);
-    if (chunks < 1) chunks = 1;
-    if (chunks > a.ntiles) chunks = a.ntiles;
-    a.tiles_per_wg = cdiv(a.ntiles, chunks);
-    a.nchunks = cdiv(a.ntiles, a.tiles_per_wg);
-    return a.ns * a.stage_bytes;
-  }
-  static int launch(Multi2Args& m, int lds, hipStream_t stream) {
-    auto kern = conv_wgrad2_kernel<CBF, OBF, UPW>;
-    static bool attr_set = false;
-    if (!attr_set) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
-          hipSuccess)
-        return HDRSKY_ELAUNCH;
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(m.first[m.njobs]), dim3(512), lds, stream, m);
-    HDRSKY_CHECK_LAUNCH();
-    return HDRSKY_OK;
-  }
-};
+constexpr int WG2_UPW = 5;      // units per compute wave (80 accumulator registers at 4 co fragments)
 
-// the four block shapes (ci fragments, co fragments); units per wave sized for <= 80 accumulator registers
-template <typename F>
-static int with_variant2(int cbf, int obf, F&& fn) {
-  if (cbf == 4 && obf == 4) return fn(Wgrad2Variant<4, 4, 5>());
-  if (cbf == 2 && obf == 4) return fn(Wgrad2Variant<2, 4, 5>());
-  if (cbf == 4 && obf == 2) return fn(Wgrad2Variant<4, 2, 8>());
-  if (cbf == 2 && obf == 2) return fn(Wgrad2Variant<2, 2, 8>());
-  return HDRSKY_EUNSUPPORTED;
+// fills a job's geometry; returns the LDS bytes of its launch, or a negative error
+static int wg2_prepare(Wg2Args& a, const hdrsky_wgrad_job& j, int wg_target) {
+  const hdrsky_conv_desc* d = &j.desc;
+  a = Wg2Args{};
+  a.x = (const unsigned short*)j.x; a.dy = (const unsigned short*)j.dy;
+  a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
+  a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.ntaps = d->KH * d->KW;
+  a.cbf = (a.Cin % 64) == 0 ? 4 : 2;
+  a.obf = (a.Cout % 64) == 0 ? 4 : 2;
+  const int CB = a.cbf * 16, OB = a.obf * 16, SPX = CB / 8 + 2, SPY = OB / 8 + 2;
+  const int TW = d->Wo >= 32 ? 32 : 16;
+  a.tw_shift = TW == 32 ? 5 : 4;
+  a.BM = (TW == 16 && d->Ho <= 4) ? 64 : 128;
+  a.TH = a.BM / TW;
+  a.tiles_x = cdiv(a.Wo, TW); a.tiles_y = cdiv(a.Ho, a.TH);
+  a.ntiles = a.B * a.tiles_x * a.tiles_y;
+  a.cblocks = a.Cin / CB; a.oblocks = a.Cout / OB;
+  const int maxt = WG2_UPW * 8 / a.cbf;
+  if (a.ntaps <= maxt) a.tgs = a.ntaps;
+  else { const int rows = maxt / a.KW; if (rows < 1) return HDRSKY_EUNSUPPORTED; a.tgs = rows * a.KW; }
+  a.ntg = cdiv(a.ntaps, a.tgs);
+  a.WT = (TW - 1) * a.stride + a.KW;
+  a.wt_magic = ((1 << 24) + a.WT - 1) / a.WT;
+  const int rows_g = cdiv(a.tgs, a.KW) < a.KH ? cdiv(a.tgs, a.KW) : a.KH;
+  const int npix = ((a.TH - 1) * a.stride + rows_g) * a.WT;
+  if ((long)npix * SPX * a.wt_magic >= (1L << 32)) return HDRSKY_EUNSUPPORTED;
+  a.xbytes = roundup(npix * SPX * 16, 1024);
+  const int ybytes = roundup(a.BM * SPY * 16, 1024);
+  a.stage_bytes = a.xbytes + ybytes;
+  a.ns = 3 * a.stage_bytes <= 160 * 1024 ? 3 : (2 * a.stage_bytes <= 160 * 1024 ? 2 : 0);
+  if (a.ns == 0) return HDRSKY_EUNSUPPORTED;
+  if (a.xbytes > 16 * 4 * 1024 || ybytes > 6 * 4 * 1024) return HDRSKY_EUNSUPPORTED;   // slot registers: 16 + 6 pieces per loader wave
+  if (a.WT >= 1024 || (a.TH - 1) * a.stride + rows_g >= 1024) return HDRSKY_EUNSUPPORTED;
+  // pixel split: what the launch's workgroup budget allows, but (a) at least eight tiles per workgroup - a workgroup's
+  // fixed cost (ring start-up, its partial slab) is a few tiles' worth, and a one-tile workgroup pipelines nothing - and
+  // (b) at most ~34 MB of partial slabs per layer for the reduce launch to read back (measured, batch 32: 3x3 32->64 at
+  // 16x64 split 256 ways = 15 us + 57 us of reduce; 3x3 128->128 at 8x32 split 64 ways = 17 + 21 us)
+  const int base = a.cblocks * a.oblocks * a.ntg;
+  int chunks = (wg_target + base / 2) / base;
+  const long dw_bytes = (long)a.ntaps * a.Cin * a.Cout * 4;
+  if (chunks > a.ntiles / 8) chunks = a.ntiles / 8;
+  if ((long)chunks * dw_bytes > (34L << 20)) chunks = (int)((34L << 20) / dw_bytes);
+  if (chunks < 1) chunks = 1;
+  if (chunks > a.ntiles) chunks = a.ntiles;
+  a.tiles_per_wg = cdiv(a.ntiles, chunks);
+  a.nchunks = cdiv(a.ntiles, a.tiles_per_wg);
+  return a.ns * a.stage_bytes;
 }
 
-// Launches (or, plan_only, sizes) the v2 kernel + the shared reduce for the eligible jobs among jobs[0..njobs); marks them
-// in done[].  Jobs the variant cannot take (LDS budget, geometry) stay unmarked: the caller's v1 path handles them.
+static int wg2_launch(Multi2Args& m, int lds, hipStream_t stream) {
+  auto kern = conv_wgrad2_kernel<WG2_UPW>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return HDRSKY_ELAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(m.first[m.njobs]), dim3(768), lds, stream, m);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
 static unsigned long long* g_wg2_stamps = nullptr;
 extern "C" void hdrsky_debug_wgrad2_stamps(void* buf) { g_wg2_stamps = (unsigned long long*)buf; }
 
+// Launches (or, plan_only, sizes) the v2 kernel + the shared reduce for the eligible jobs among jobs[0..njobs); marks them
+// in done[].  Jobs the kernel cannot take (LDS budget, geometry) stay unmarked: the caller's v1 path handles them.
 static int wgrad2_groups(const hdrsky_wgrad_job* jobs, int njobs, bool* done, float* ws, size_t ws_floats, size_t* ws_used,
                          bool plan_only, void* stream) {
-  static const int wg_hook = getenv("HDRSKY_WGRAD2_WGS") ? atoi(getenv("HDRSKY_WGRAD2_WGS")) : 0;
+  const int wg_hook = getenv("HDRSKY_WGRAD2_WGS") ? atoi(getenv("HDRSKY_WGRAD2_WGS")) : 0;
   const int wg_total = wg_hook > 0 ? wg_hook : 256;
-  for (int cbf = 4; cbf >= 2; cbf -= 2)
-    for (int obf = 4; obf >= 2; obf -= 2) {
-      int members[256], nm = 0;
-      double work[256], wsum = 0.0;
-      for (int k = 0; k < njobs; ++k) {
-        if (done[k] || !v2_eligible(jobs[k])) continue;
-        const hdrsky_conv_desc& d = jobs[k].desc;
-        const int want_c = (d.Cin % 64) == 0 ? 4 : 2, want_o = (d.Cout % 64) == 0 ? 4 : 2;
-        if (want_c != cbf || want_o != obf) continue;
-        Wg2Args probe;
-        const int r = with_variant2(cbf, obf, [&](auto v) { return decltype(v)::prepare(probe, jobs[k], 1); });
-        if (r < 0) continue;
-        work[nm] = (double)d.B * d.Ho * d.Wo * d.KH * d.KW * d.Cin * d.Cout;
-        wsum += work[nm];
-        members[nm++] = k;
-      }
-      for (int base = 0; base < nm; base += WG2_MAXJ) {
-        const int cnt = nm - base < WG2_MAXJ ? nm - base : WG2_MAXJ;
-        double wpart = 0.0;
-        for (int q = 0; q < cnt; ++q) wpart += work[base + q];
-        const int rc = with_variant2(cbf, obf, [&](auto v) {
-          using V = decltype(v);
-          Multi2Args m2{};
-          MultiArgs mr{};
-          m2.njobs = mr.njobs = cnt;
-          m2.stamps = g_wg2_stamps;
-          int lds = 0, blocks = 0, rblocks = 0, maxchunks = 1;
-          for (int q = 0; q < cnt; ++q) {
-            Wg2Args tmp;
-            if (V::prepare(tmp, jobs[members[base + q]], (int)(wg_total * work[base + q] / wpart + 0.5)) >= 0 && tmp.nchunks > maxchunks)
-              maxchunks = tmp.nchunks;
-          }
-          const int S = maxchunks >= 32 ? 16 : 4;
-          for (int q = 0; q < cnt; ++q) {
-            const hdrsky_wgrad_job& j = jobs[members[base + q]];
-            Wg2Args& a = m2.job[q];
-            const int r = V::prepare(a, j, (int)(wg_total * work[base + q] / wpart + 0.5));
-            if (r < 0) return r;
-            if (r > lds) lds = r;
-            m2.first[q] = blocks;
-            blocks += a.cblocks * a.oblocks * a.ntg * a.nchunks;
-            const size_t nslab = (size_t)a.nchunks * a.cblocks * a.oblocks * a.ntaps * V::CB * V::OB;
-            const size_t nbias = (size_t)a.nchunks * a.oblocks * V::OB;
-            a.ws = ws + *ws_used;
-            a.ws_db = j.db != nullptr ? ws + *ws_used + nslab : nullptr;
-            *ws_used += nslab + (j.db != nullptr ? nbias : 0);
-            WgradArgs& ar = mr.job[q];     // what wgrad_reduce_kernel reads
-            ar = WgradArgs{};
-            ar.dw = j.dw; ar.db = j.db; ar.ws = a.ws; ar.ws_db = a.ws_db; ar.Cin = a.Cin; ar.Cout = a.Cout;
-            ar.nchunks = a.nchunks; ar.cblocks = a.cblocks; ar.oblocks = a.oblocks; ar.ntaps = a.ntaps;
-            mr.rfirst[q] = rblocks;
-            rblocks += (int)(((size_t)a.cblocks * a.oblocks * a.ntaps * V::CB * (V::OB / 4) + 256 / S - 1) / (256 / S));
-          }
-          m2.first[cnt] = blocks;
-          mr.rfirst[cnt] = rblocks;
-          if (plan_only) return (int)HDRSKY_OK;
-          if (*ws_used > ws_floats) return (int)HDRSKY_EINVAL;
-          const int r = V::launch(m2, lds, (hipStream_t)stream);
-          if (r != HDRSKY_OK) return r;
-          hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(256), 0, (hipStream_t)stream, mr, V::CB, V::OB, S);
-          HDRSKY_CHECK_LAUNCH();
-          return (int)HDRSKY_OK;
-        });
-        if (rc != HDRSKY_OK) return rc;
-        for (int q = 0; q < cnt; ++q) done[members[base + q]] = true;
+  int members[256], nm = 0;
+  double work[256];
+  for (int k = 0; k < njobs; ++k) {
+    if (done[k] || !v2_eligible(jobs[k])) continue;
+    Wg2Args probe;
+    if (wg2_prepare(probe, jobs[k], 1) < 0) continue;
+    const hdrsky_conv_desc& d = jobs[k].desc;
+    work[nm] = (double)d.B * d.Ho * d.Wo * d.KH * d.KW * d.Cin * d.Cout;
+    members[nm++] = k;
+  }
+  for (int base = 0; base < nm; base += WG2_MAXJ) {
+    const int cnt = nm - base < WG2_MAXJ ? nm - base : WG2_MAXJ;
+    double wpart = 0.0;
+    for (int q = 0; q < cnt; ++q) wpart += work[base + q];
+    Multi2Args m2{};
+    MultiArgs mr{};
+    m2.njobs = mr.njobs = cnt;
+    m2.stamps = g_wg2_stamps;
+    int lds = 0, blocks = 0, rblocks = 0, maxchunks = 1;
+    for (int q = 0; q < cnt; ++q) {
+      Wg2Args tmp;
+      if (wg2_prepare(tmp, jobs[members[base + q]], (int)(wg_total * work[base + q] / wpart + 0.5)) >= 0 && tmp.nchunks > maxchunks)
+        maxchunks = tmp.nchunks;
+    }
+    const int S = maxchunks >= 32 ? 16 : 4;
+    for (int q = 0; q < cnt; ++q) {
+      const hdrsky_wgrad_job& j = jobs[members[base + q]];
+      Wg2Args& a = m2.job[q];
+      const int r = wg2_prepare(a, j, (int)(wg_total * work[base + q] / wpart + 0.5));
+      if (r < 0) return r;
+      if (r > lds) lds = r;
+      const int CB = a.cbf * 16, OB = a.obf * 16;
+      m2.first[q] = blocks;
+      blocks += a.cblocks * a.oblocks * a.ntg * a.nchunks;
+      a.direct = a.nchunks == 1 ? 1 : 0;
+      a.dw = j.dw; a.db = j.db;
+      const size_t nslab = a.direct ? 0 : (size_t)a.nchunks * a.cblocks * a.oblocks * a.ntaps * CB * OB;
+      const size_t nbias = a.direct ? 0 : (size_t)a.nchunks * a.oblocks * OB;
+      a.ws = ws + *ws_used;
+      a.ws_db = (j.db != nullptr && !a.direct) ? ws + *ws_used + nslab : nullptr;
+      *ws_used += nslab + (j.db != nullptr ? nbias : 0);
+      WgradArgs& ar = mr.job[q];     // what wgrad_reduce_kernel reads
+      ar = WgradArgs{};
+      ar.dw = j.dw; ar.db = j.db; ar.ws = a.ws; ar.ws_db = a.ws_db; ar.Cin = a.Cin; ar.Cout = a.Cout;
+      ar.nchunks = a.nchunks; ar.cblocks = a.cblocks; ar.oblocks = a.oblocks; ar.ntaps = a.ntaps;
+      ar.RX = CB; ar.RY = OB;        // per-job block shape of the reduce launch (CB = OB = 0 arguments)
+      mr.rfirst[q] = rblocks;
+      if (!a.direct) rblocks += (int)(((size_t)a.cblocks * a.oblocks * a.ntaps * CB * (OB / 4) + 256 / S - 1) / (256 / S));
+    }
+    m2.first[cnt] = blocks;
+    mr.rfirst[cnt] = rblocks;
+    if (!plan_only) {
+      if (*ws_used > ws_floats) return HDRSKY_EINVAL;
+      const int r = wg2_launch(m2, lds, (hipStream_t)stream);
+      if (r != HDRSKY_OK) return r;
+      if (rblocks > 0) {
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(256), 0, (hipStream_t)stream, mr, 0, 0, S);
+        HDRSKY_CHECK_LAUNCH();
       }
     }
+    for (int q = 0; q < cnt; ++q) done[members[base + q]] = true;
+  }
   return HDRSKY_OK;
 }
 
@@ -1205,7 +1263,7 @@ extern "C" int hdrsky_conv2d_wgrad_multi(const hdrsky_wgrad_job* jobs, int njobs
 extern "C" size_t hdrsky_conv2d_wgrad_ws_bytes(const hdrsky_wgrad_job* jobs, int njobs) {
   size_t need = 0;
   if (wgrad_multi_impl(jobs, njobs, nullptr, 0, true, &need, nullptr) != HDRSKY_OK) return 0;
-  return need * sizeof(float);
+  return (need > 0 ? need : 4) * sizeof(float);         // (0 = error: a call whose layers need no scratch still gets a token buffer)
 }
 
 extern "C" int hdrsky_conv2d_wgrad_multi_det(const hdrsky_wgrad_job* jobs, int njobs, void* ws, size_t ws_bytes, void* stream) {
