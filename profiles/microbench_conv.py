@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--only", default="")
     ap.add_argument("--tiles", default="", help="semicolon-separated HDRSKY_TILE values to compare with the table")
+    ap.add_argument("--bf16", action="store_true", help="bf16 activations in and out + ReLU epilogue (the VGG16 chain of the step)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     B = args.batch
@@ -41,6 +42,9 @@ def main():
         if args.only and args.only not in name:
             continue
         x = torch.randn(B, H, W, Cin, device=dev)
+        kw = {}
+        if args.bf16 and Cin >= 32:
+            x = x.to(torch.bfloat16); kw = dict(out_bf16=True, out_slope=0.0)
         w = torch.randn(k, k, Cin, Cout, device=dev) / (k * k * Cin) ** 0.5
         pw = K.PackedConv(w, False); bias = torch.zeros(Cout, device=dev)
         res = []
@@ -48,13 +52,13 @@ def main():
             if t: os.environ["HDRSKY_TILE"] = t
             else: os.environ.pop("HDRSKY_TILE", None)
             try:
-                y = K.conv2d(x, pw, bias, stride=stride)[0]
+                y = K.conv2d(x, pw, bias, stride=stride, **kw)[0]
             except Exception as e:
                 res.append("%s n/a" % t); continue
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 for _ in range(args.iters):
-                    K.conv2d(x, pw, bias, stride=stride)
+                    K.conv2d(x, pw, bias, stride=stride, **kw)
             g.replay(); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()

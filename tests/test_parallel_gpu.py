@@ -299,8 +299,9 @@ def test_sync_batch_stats_two_replicas_equal_one_step_on_the_global_batch(dev, t
     ey = rel(torch.cat([r0["y"], r1["y"]]), out["y_final_gamma"].cpu())
     print("sync: gradient mismatch gen/sun %.3g disc %.3g, losses %.3g, moving stats %.3g, output %.3g" % (eg, ed, el, em, ey))
     assert eg < 1e-4 and ed < 1e-4 and el < 1e-5 and em < 1e-5 and ey < 1e-5, (eg, ed, el, em, ey)
-    for name, (o, n, _) in tr.gs.offsets.items():     # and tensor by tensor (weights whose gradient is not rounding noise)
-        if o < ng and float(tr.gs.grad[o:o + n].abs().max()) > 1e-6:
+    for name, (o, n, _) in tr.gs.offsets.items():     # and tensor by tensor (a conv bias in front of an InstanceNorm has an
+        noise = name.endswith(".b") or name.endswith("bias_deconv2d")      # exactly-zero gradient: rounding noise on both sides)
+        if o < ng and not noise and float(tr.gs.grad[o:o + n].abs().max()) > 1e-6:
             assert rel(r0["gg"][o:o + n] * 0.5, tr.gs.grad[o:o + n].cpu()) < 2e-3, name
     q0, q1 = res[False]                                # default semantics: local statistics - a different (valid) step
     assert rel(q0["dg"] * 0.5, tr.ds.grad.cpu()) > 1e-3 and rel(torch.cat([q0["gamma"], q1["gamma"]]), out["gamma"].cpu()) > 1e-4
