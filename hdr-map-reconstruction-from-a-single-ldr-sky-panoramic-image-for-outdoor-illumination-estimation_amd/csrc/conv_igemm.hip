@@ -886,6 +886,82 @@ TileCfg choose_tile(const hdrsky_conv_desc* d) {
   return t;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// One output channel (the discriminator's patch-logit conv, discriminator.py:39-40: Conv2D(1, 4) VALID on [B,4,16,512]):
+// an implicit GEMM with N = 1 uses one of 16 MFMA columns and one workgroup per sample walks 256 k-steps through the weight
+// ring - 32 us for 7 MFLOP.  Here it is what it is, a dot product per output pixel: 16-byte loads of the fp32 input with the
+// producer's affine + activation applied on the fly, the filter straight from the packed bf16 image (hi [+ lo]), fp32
+// accumulation, wave + block reduction, + bias.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) conv_dot1_kernel(const ConvKArgs a) {
+  // workgroup = one output pixel; thread = items (tap, 8-channel group) tid, tid + 256, ...: every load of a thread is
+  // issued before the first use (a first version - workgroup per sample, a wave per output, one item per loop trip - ran
+  // at one L2 round trip per item: 61 us)
+  __shared__ float sRed[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bid = blockIdx.x;
+  const int ox = bid % a.Wo; bid /= a.Wo;
+  const int oy = bid % a.Ho, b = bid / a.Ho;
+  const int cin32 = a.Cin >> 5, nq = a.Cin >> 3, nitems = a.ntaps * nq;
+  const float* xb = a.x + (size_t)b * a.H * a.W * a.Cin;
+  const bool affine = a.in_mode == HDRSKY_IN_AFFINE;
+  constexpr int IPT = 4;                                      // items per thread and pass
+  float acc = 0.f;
+  for (int i0 = tid; i0 < nitems; i0 += 256 * IPT) {
+    float4 xa[IPT], xc[IPT], sa[IPT], sc_[IPT], ha[IPT], hc[IPT];
+    uint4 wh[IPT], wl[IPT];
+    bool ok[IPT];
+#pragma unroll
+    for (int u = 0; u < IPT; ++u) {
+      const int i = i0 + u * 256;
+      const int ic = min(i, nitems - 1);
+      const int tap = ic / nq, qc = ic - tap * nq;
+      const int ky = tap / a.KW, kx = tap - ky * a.KW;
+      const int iy = oy * a.stride - a.pad_t + ky, ix = ox * a.stride - a.pad_l + kx;
+      ok[u] = i < nitems && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      const float* src = xb + ((size_t)(ok[u] ? iy : 0) * a.W + (ok[u] ? ix : 0)) * a.Cin + qc * 8;
+      xa[u] = *reinterpret_cast<const float4*>(src); xc[u] = *reinterpret_cast<const float4*>(src + 4);
+      const size_t g = ((size_t)(tap * cin32 + (qc >> 2)) * 4 + (qc & 3)) * a.Npad;   // column n = 0 of the packed image
+      wh[u] = a.whi[g];
+      if (a.wlo != nullptr) wl[u] = a.wlo[g];
+      if (affine) {
+        const float* ps = a.in_scale + b * a.ss_bstride + qc * 8;
+        const float* ph = a.in_shift + b * a.ss_bstride + qc * 8;
+        sa[u] = *reinterpret_cast<const float4*>(ps); sc_[u] = *reinterpret_cast<const float4*>(ps + 4);
+        ha[u] = *reinterpret_cast<const float4*>(ph); hc[u] = *reinterpret_cast<const float4*>(ph + 4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < IPT; ++u) {
+      if (!ok[u]) continue;
+      const float in[8] = {xa[u].x, xa[u].y, xa[u].z, xa[u].w, xc[u].x, xc[u].y, xc[u].z, xc[u].w};
+      const float sc8[8] = {sa[u].x, sa[u].y, sa[u].z, sa[u].w, sc_[u].x, sc_[u].y, sc_[u].z, sc_[u].w};
+      const float sh8[8] = {ha[u].x, ha[u].y, ha[u].z, ha[u].w, hc[u].x, hc[u].y, hc[u].z, hc[u].w};
+      const unsigned hw[4] = {wh[u].x, wh[u].y, wh[u].z, wh[u].w};
+      const unsigned lw[4] = {wl[u].x, wl[u].y, wl[u].z, wl[u].w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float w = __builtin_bit_cast(float, (j & 1) ? (hw[j >> 1] & 0xffff0000u) : (hw[j >> 1] << 16));
+        if (a.wlo != nullptr) w += __builtin_bit_cast(float, (j & 1) ? (lw[j >> 1] & 0xffff0000u) : (lw[j >> 1] << 16));
+        const float t = affine ? leaky(in[j] * sc8[j] + sh8[j], a.in_slope) : leaky(in[j], a.in_slope);
+        acc += t * w;
+      }
+    }
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) sRed[wave] = acc;
+  __syncthreads();
+  if (tid == 0)
+    a.y[((size_t)b * a.Ho + oy) * a.Wo + ox] = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]) + (a.bias != nullptr ? a.bias[0] : 0.f);
+}
+
+static bool dot1_applies(const hdrsky_conv_desc* d, const float* residual) {
+  return d->Cout == 1 && d->Cin >= 32 && (d->Cin % 32) == 0 && d->upsample == 1 && d->dilate == 1 && !d->want_stats && !residual &&
+         !d->x_bf16 && !d->y_bf16 && d->out_slope == 1.f && !d->final_relu && d->res_mode == 0 &&
+         d->in_mode != HDRSKY_IN_PARTIALS && !getenv("HDRSKY_NO_DOT1");
+}
+
 }  // namespace
 
 static unsigned long long* g_stamps = nullptr;
@@ -963,6 +1039,7 @@ int hdrsky_conv_pack_weights_multi(const void* jobs, int njobs, int total_blocks
 
 int hdrsky_conv_kernel_name(const hdrsky_conv_desc* d, char* buf, int n) {
   if (!d || !buf || n <= 0) return HDRSKY_EINVAL;
+  if (dot1_applies(d, nullptr)) { snprintf(buf, (size_t)n, "conv_dot1_kernel"); return HDRSKY_OK; }
   const TileCfg t = choose_tile(d);
   snprintf(buf, (size_t)n, "conv_igemm_kernel<%d, %d, %d, %d, %d, %s, %s, %s>", t.wm, t.wn, t.mi, t.ni, t.tw,
            d->Cin <= 8 ? "true" : "false", d->compute == HDRSKY_BF16X3 ? "true" : "false", t.db ? "true" : "false");
@@ -1009,6 +1086,13 @@ int hdrsky_conv2d_fwd(const hdrsky_conv_desc* d, const float* x, const void* w_h
   a.stamps = g_stamps;
   a.x_bf16 = d->x_bf16; a.y_bf16 = d->y_bf16; a.res_mode = d->res_mode; a.mask_slope = d->mask_slope;
   hipStream_t s = (hipStream_t)stream;
+  if (dot1_applies(d, residual)) {       // one output channel: a dot product per pixel, not a 16-column MFMA tile
+    a.ntaps = d->KH * d->KW;
+    if (!precise) a.wlo = nullptr;
+    hipLaunchKernelGGL(conv_dot1_kernel, dim3(a.B * a.Ho * a.Wo), dim3(256), 0, s, a);
+    HDRSKY_CHECK_LAUNCH();
+    return HDRSKY_OK;
+  }
   const TileCfg t = choose_tile(d);
   if (narrow) return precise ? dispatch_tile<true, true>(a, t, s) : dispatch_tile<true, false>(a, t, s);
   return precise ? dispatch_tile<false, true>(a, t, s) : dispatch_tile<false, false>(a, t, s);

@@ -681,9 +681,11 @@ class Trainer:
                 # the two decoders share the upsampled encoder output
                 c3, c2 = c["gen.conv3_" + sfx], c["gen.conv2_" + sfx]
                 u3 = T["u3"]          # written by fwd_enc, in front of the first decoder
+                K.label(c3.wkey)
                 d3, s3 = K.conv2d(u3, c3.pk, c3.b, compute=cp, want_stats=True)
                 xf2 = self._inxf(s3, "gen.norm3_" + sfx, 0.1, partials=True)
                 u2 = K.up2x_act_bf16(d3, xf2)
+                K.label(c2.wkey)
                 d2, s2 = K.conv2d(u2, c2.pk, c2.b, compute=cp, want_stats=True)
                 xf1 = self._inxf(s2, "gen.norm2_" + sfx, 0.1)
                 T["dech_" + sfx] = (d3, s3, xf2, d2, s2, xf1, u3, u2)
