@@ -835,10 +835,16 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const MultiArgs m, in
     const int ci = (blk / a.oblocks) * CB + cl, co = (blk % a.oblocks) * OB + ol;
     if (ci < a.Cin) {
       float* dst = a.dw + ((size_t)tap * a.Cin + ci) * a.Cout + co;
-      const float r[4] = {acc.x, acc.y, acc.z, acc.w};
+      if ((a.Cout & 3) == 0 && co + 3 < a.Cout) {      // one 16-byte read-modify-write (co is a multiple of 4, dW 16-byte aligned)
+        float4 t = *reinterpret_cast<float4*>(dst);
+        t.x += acc.x; t.y += acc.y; t.z += acc.z; t.w += acc.w;
+        *reinterpret_cast<float4*>(dst) = t;
+      } else {
+        const float r[4] = {acc.x, acc.y, acc.z, acc.w};
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (co + k < a.Cout) dst[k] += r[k];
+        for (int k = 0; k < 4; ++k)
+          if (co + k < a.Cout) dst[k] += r[k];
+      }
     }
   }
   if (rb == 0 && a.db != nullptr) {   // bias gradient of this job: [chunk][co block][OB] partials, tiny

@@ -852,17 +852,28 @@ __global__ void __launch_bounds__(256) act_bf16_kernel(const float* __restrict__
   const int i1 = min(nitems, (blk + 1) * per);
   const float* xb = x + (size_t)b * HW * C;
   const bool xf = mode != HDRSKY_IN_NONE;
-  for (int i = blk * per + threadIdx.x; i < i1; i += 256) {
-    const int qc = i % nq;
-    const float4 va = *reinterpret_cast<const float4*>(xb + (size_t)i * 8);
-    const float4 vb = *reinterpret_cast<const float4*>(xb + (size_t)i * 8 + 4);
-    const float in[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
-    float v[8];
+  constexpr int UNR = 4;                                   // items per thread in flight (all loads before the first use)
+  for (int i0 = blk * per + threadIdx.x; i0 < i1; i0 += 256 * UNR) {
+    float4 va[UNR], vb[UNR];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = xf ? leaky(in[j] * sSc[qc * 8 + j] + sSh[qc * 8 + j], slope) : leaky(in[j], slope);
-    uint4 hi, lo;
-    pack8<false>(v, hi, lo);
-    y[(size_t)b * nitems + i] = hi;
+    for (int u = 0; u < UNR; ++u) {
+      const int i = min(i0 + u * 256, i1 - 1);
+      va[u] = *reinterpret_cast<const float4*>(xb + (size_t)i * 8);
+      vb[u] = *reinterpret_cast<const float4*>(xb + (size_t)i * 8 + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int i = i0 + u * 256;
+      if (i >= i1) break;
+      const int qc = i % nq;
+      const float in[8] = {va[u].x, va[u].y, va[u].z, va[u].w, vb[u].x, vb[u].y, vb[u].z, vb[u].w};
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = xf ? leaky(in[j] * sSc[qc * 8 + j] + sSh[qc * 8 + j], slope) : leaky(in[j], slope);
+      uint4 hi, lo;
+      pack8<false>(v, hi, lo);
+      y[(size_t)b * nitems + i] = hi;
+    }
   }
 }
 
@@ -1317,8 +1328,8 @@ int hdrsky_act_bf16(const float* x, int B, int HW, int C, int in_mode, const flo
   if (in_mode == HDRSKY_IN_AFFINE && (!in_scale || !in_shift)) return HDRSKY_EINVAL;
   if (in_mode == HDRSKY_IN_PARTIALS && (!in_part || !gamma || !beta || in_nparts <= 0)) return HDRSKY_EINVAL;
   if ((size_t)HW * (C >> 3) > 0x7fffffffu) return HDRSKY_EINVAL;
-  int bps = cdiv(HW * (C >> 3), 256 * 8);          // ~8 items per thread
-  if (bps < 1) bps = 1;
+  int bps = cdiv(HW * (C >> 3), 256 * 16);         // ~16 items per thread: the per-block affine table (a pass over the
+  if (bps < 1) bps = 1;                            // producer's partials) is a fixed cost worth amortising
   hipLaunchKernelGGL(act_bf16_kernel, dim3(B * bps), dim3(256), 0, S_(stream), x, HW, C, in_mode, in_scale, in_shift, ss_bstride,
                      in_part, in_nparts, gamma, beta, eps, slope, (uint4*)y_bf16, bps);
   HDRSKY_CHECK_LAUNCH();
