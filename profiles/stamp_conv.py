@@ -32,6 +32,9 @@ def main():
             continue
         up, stats = 1, True
         x = torch.randn(B, H, W, Cin, device=dev)
+        kw = dict(want_stats=stats)
+        if os.environ.get("STAMP_BF16", "0") == "1":      # the VGG16 chain's form: bf16 in, bf16 out, ReLU epilogue, no statistics
+            x = x.to(torch.bfloat16); kw = dict(out_bf16=True, out_slope=0.0)
         w = torch.randn(k, k, Cin, Cout, device=dev) / (k * k * Cin) ** 0.5
         pw = K.PackedConv(w, precise=False)
         bias = torch.zeros(Cout, device=dev)
@@ -42,10 +45,10 @@ def main():
                 os.environ.pop("HDRSKY_TILE", None)
             buf = torch.zeros(65536 * 8, dtype=torch.int64, device=dev)
             for _ in range(20):
-                K.conv2d(x, pw, bias, stride=stride, upsample=up, want_stats=stats)
+                K.conv2d(x, pw, bias, stride=stride, upsample=up, **kw)
             torch.cuda.synchronize()
             lib.hdrsky_debug_conv_stamps(buf.data_ptr())
-            K.conv2d(x, pw, bias, stride=stride, upsample=up, want_stats=stats)
+            K.conv2d(x, pw, bias, stride=stride, upsample=up, **kw)
             torch.cuda.synchronize()
             lib.hdrsky_debug_conv_stamps(None)
             raw = buf.cpu().numpy()
