@@ -934,11 +934,11 @@ int with_variant(const Geo& g, F&& fn) {
   HDRSKY_WG_(TPW_, CBF_, OBF_, NARROW_, UP_, NW_, CS_, OS_, XR_, 128, 16)
   // 16 waves, 32x32-channel dW blocks (a layer on its own)
   HDRSKY_WG(3, 2, 2, false, 0, 16, 2, 2, 3) HDRSKY_WG(3, 2, 2, false, 1, 16, 2, 2, 4)
-  HDRSKY_WG(4, 2, 2, false, 0, 16, 2, 2, 3) HDRSKY_WG(7, 2, 1, false, 0, 16, 2, 1, 3)
+  HDRSKY_WG(4, 2, 2, false, 0, 16, 2, 2, 3) HDRSKY_WG(7, 2, 1, false, 0, 16, 2, 1, 2)
   HDRSKY_WG(2, 1, 4, true, 0, 16, 1, 2, 3) HDRSKY_WG(2, 1, 2, true, 0, 16, 1, 2, 3)
-  HDRSKY_WG(7, 1, 2, true, 0, 16, 1, 2, 3)
+  HDRSKY_WG(7, 1, 2, true, 0, 16, 1, 2, 2)
   // 64-pixel tiles for outputs of at most four 16-pixel rows (the 4x16 maps of the discriminator / sun-radiance stacks)
-  HDRSKY_WG_(4, 2, 2, false, 0, 16, 2, 2, 3, 64, 16) HDRSKY_WG_(3, 2, 2, false, 0, 16, 2, 2, 3, 64, 16)
+  HDRSKY_WG_(4, 2, 2, false, 0, 16, 2, 2, 2, 64, 16) HDRSKY_WG_(3, 2, 2, false, 0, 16, 2, 2, 3, 64, 16)
   // 8 waves, 64x64-channel dW blocks (several wide layers in one launch)
   HDRSKY_WG(3, 4, 4, false, 0, 8, 2, 1, 4)
   // distortion-aware layers (1x1 over k*k*C virtual channels, every wave on the one tap): 64x64 blocks when C % 64 == 0,
