@@ -112,6 +112,7 @@ SIGNATURES = {
     "hdrsky_bn_act_bwd_reduce": (c_int, [P, P, P, P, P, P, c_float, c_int, c_int, P, P]),
     "hdrsky_bn_act_bwd_apply": (c_int, [P, P, P, P, P, P, c_float, c_int, c_int, P, c_int, ctypes.c_double, P, c_int, P, P, P, P,
                                         c_int, P]),
+    "hdrsky_sun_rad_bwd_slices": (c_int, [c_int]),
     "hdrsky_sun_rad_bwd_reduce": (c_int, [P, P, P, P, P, c_int, c_int, P, P, P]),
     "hdrsky_sun_rad_bwd_apply": (c_int, [P, P, P, P, c_int, c_int, c_int, P, P]),
     "hdrsky_affine_act_bwd": (c_int, [P, P, P, P, c_float, c_size_t, c_int, P, c_int, P]),

@@ -696,14 +696,19 @@ __global__ void __launch_bounds__(256) sun_rad_bwd_kernel(const float* __restric
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* __restrict__ drg3, int P, float* __restrict__ dx,
                                                           float* __restrict__ dpre, float* __restrict__ dotx, int n,
-                                                          int* __restrict__ claimed) {
+                                                          int* __restrict__ claimed, int S, float* __restrict__ part) {
+  // S == 1: block = sample (the 32x128 maps).  S > 1: block = (sample, pixel slice) - a 128x512 map is 65 536 pixels and one
+  // block per sample was 8 blocks on 256 CUs (293 us per call) -, partial sums to part[b][s][3], summed in slice order by
+  // sun_rad_bwd_fin_kernel
   __shared__ float sred[3][4];
-  const int b = blockIdx.x;
+  const int b = blockIdx.x / S, sl = blockIdx.x % S;
+  const int per = (P + S - 1) / S;
+  const int p0 = sl * per, p1 = min(P, p0 + per);
   const float gmax = __uint_as_float(*gmax_bits);
   const float g = gamma[b], bt = beta[b];
   const float D = bt * 1.7724539f + 1e-5f, be = bt + 1e-5f;
   float sg = 0.f, sb = 0.f, sd = 0.f;
-  for (int p = threadIdx.x; p < P; p += 256) {
+  for (int p = p0 + threadIdx.x; p < p1; p += 256) {
     const size_t i = (size_t)b * P + p;
     const float x = cmf[i] / gmax;
     const float d1 = 1.f - x;
@@ -731,10 +736,29 @@ __global__ void __launch_bounds__(256) sun_rad_bwd_kernel(const float* __restric
   if (threadIdx.x == 0) {
     const float tg = (sred[0][0] + sred[0][1]) + (sred[0][2] + sred[0][3]);
     const float tb = (sred[1][0] + sred[1][1]) + (sred[1][2] + sred[1][3]);
-    dpre[b * 2 + 0] = tg * g * (1.f - g);
-    dpre[b * 2 + 1] = tb * bt * (1.f - bt);
-    dotx[b] = (sred[2][0] + sred[2][1]) + (sred[2][2] + sred[2][3]);
+    const float td = (sred[2][0] + sred[2][1]) + (sred[2][2] + sred[2][3]);
+    if (S == 1) {
+      dpre[b * 2 + 0] = tg * g * (1.f - g);
+      dpre[b * 2 + 1] = tb * bt * (1.f - bt);
+      dotx[b] = td;
+    } else {
+      float* q = part + ((size_t)b * S + sl) * 3;
+      q[0] = tg; q[1] = tb; q[2] = td;
+    }
   }
+}
+
+__global__ void __launch_bounds__(64) sun_rad_bwd_fin_kernel(const float* __restrict__ part, int S, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float* __restrict__ dpre,
+                                                             float* __restrict__ dotx) {
+  const int b = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  float tg = 0.f, tb = 0.f, td = 0.f;
+  for (int s = 0; s < S; ++s) { const float* q = part + ((size_t)b * S + s) * 3; tg += q[0]; tb += q[1]; td += q[2]; }
+  const float g = gamma[b], bt = beta[b];
+  dpre[b * 2 + 0] = tg * g * (1.f - g);
+  dpre[b * 2 + 1] = tb * bt * (1.f - bt);
+  dotx[b] = td;
 }
 
 // dcmf (+)= dx/gmax, and at the arg-max element(s) of the whole batch: -= sum_b dotx[b] / gmax^2 / (number of them)
@@ -1257,6 +1281,11 @@ int hdrsky_decoder_tail_bwd(const float* y, const float* res, const float* dy, s
 }
 
 /* scratch: B*P + B floats + 1 int (count of the elements equal to the maximum, zeroed here); dcmf is accumulated into */
+int hdrsky_sun_rad_bwd_slices(int P) {   // pixel slices per sample of the reduce pass (scratch: B*P + B + 4 + 3*B*slices floats)
+  int S = P / 4096;
+  return S < 1 ? 1 : (S > 64 ? 64 : S);
+}
+
 int hdrsky_sun_rad_bwd_reduce(const float* cmf, const void* gmax_bits, const float* gamma, const float* beta, const float* drg3,
                               int B, int P, float* scratch, float* dpre, void* stream) {
   if (!cmf || !gmax_bits || !gamma || !beta || !drg3 || !scratch || !dpre || (size_t)B * P > 0x7fffffffu) return HDRSKY_EINVAL;
@@ -1264,8 +1293,11 @@ int hdrsky_sun_rad_bwd_reduce(const float* cmf, const void* gmax_bits, const flo
   float* dotx = scratch + (size_t)B * P;
   int* claimed = reinterpret_cast<int*>(dotx + B);
   hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, S_(stream), (unsigned*)claimed, (size_t)1);   // (see hdrsky_zero)
-  hipLaunchKernelGGL(sun_rad_bwd_kernel, dim3(B), dim3(256), 0, S_(stream), cmf, (const unsigned int*)gmax_bits, gamma, beta,
-                     drg3, P, dx, dpre, dotx, B * P, claimed);
+  const int S = hdrsky_sun_rad_bwd_slices(P);
+  float* part = dotx + B + 4;                       // behind the record (dotx[B], tie count): 3 * B * S floats
+  hipLaunchKernelGGL(sun_rad_bwd_kernel, dim3(B * S), dim3(256), 0, S_(stream), cmf, (const unsigned int*)gmax_bits, gamma, beta,
+                     drg3, P, dx, dpre, dotx, B * P, claimed, S, part);
+  if (S > 1) hipLaunchKernelGGL(sun_rad_bwd_fin_kernel, dim3(B), dim3(64), 0, S_(stream), part, S, gamma, beta, dpre, dotx);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }

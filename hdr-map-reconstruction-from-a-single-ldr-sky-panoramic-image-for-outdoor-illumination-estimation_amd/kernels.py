@@ -924,9 +924,9 @@ def sun_rad_bwd(cmf, gmax_bits, gamma, beta, drg3, dcmf, sync=None):
     """sync (parallel.BatchSync): gmax is the maximum over every replica's batch - the maximum's gradient term and the
     tie count are then summed over the all-gathered per-replica records."""
     B, P = cmf.shape
-    scratch = torch.empty((B * P + B + 4,), dtype=torch.float32, device=cmf.device)
-    dpre = torch.empty((B, 2), dtype=torch.float32, device=cmf.device)
     lib = L.load()
+    scratch = torch.empty((B * P + B + 4 + 3 * B * lib.hdrsky_sun_rad_bwd_slices(P),), dtype=torch.float32, device=cmf.device)
+    dpre = torch.empty((B, 2), dtype=torch.float32, device=cmf.device)
     if sync is None:
         L.check(lib.hdrsky_sun_rad_bwd(_p(cmf), _p(gmax_bits), _p(gamma), _p(beta), _p(_f32(drg3)), B, P, _p(scratch), _p(dpre),
                                        _p(_f32(dcmf, B, P)), _stream()), "sun_rad_bwd")

@@ -347,6 +347,7 @@ int hdrsky_sun_rad_bwd(const float* cmf, const void* gmax_bits, const float* gam
  * replica: _reduce leaves d(cmf/max) in scratch [B*P] and, behind it, the record (dotx[B], tie count as int bits) =
  * scratch + B*P, B+1 words; the caller all-gathers the records; _apply adds d cmf with the maximum's gradient term summed
  * over the nrec records (rec = the local record and nrec = 1 reproduce hdrsky_sun_rad_bwd). */
+int hdrsky_sun_rad_bwd_slices(int P); /* [host] pixel slices per sample; scratch of hdrsky_sun_rad_bwd* = B*P + B + 4 + 3*B*slices floats */
 int hdrsky_sun_rad_bwd_reduce(const float* cmf, const void* gmax_bits, const float* gamma, const float* beta, const float* drg3,
                               int B, int P, float* scratch, float* dpre, void* stream);
 int hdrsky_sun_rad_bwd_apply(const float* cmf, const void* gmax_bits, const float* scratch, const float* rec, int nrec, int B,
