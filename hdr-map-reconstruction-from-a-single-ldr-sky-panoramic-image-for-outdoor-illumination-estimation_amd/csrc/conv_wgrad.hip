@@ -1024,10 +1024,11 @@ static bool same_geo(const Geo& p, const Geo& q) {
 // ---- v2 host side -------------------------------------------------------------------------------------------------------
 static bool v2_eligible(const hdrsky_wgrad_job& j) {
   const hdrsky_conv_desc* d = &j.desc;
+  static const int s2min = getenv("HDRSKY_WGRAD2_S2MIN") ? atoi(getenv("HDRSKY_WGRAD2_S2MIN")) : 32;   // A/B hook
   return j.x_bf16 && j.dy_bf16 && j.da_ksize == 0 && d->compute == HDRSKY_BF16 && d->upsample == 1 && d->dilate == 1 &&
-         // (stride 2: a tile's input patch is ~4x its output and every pixel of it is copied; measured, batch 32: the 3x3
-         // 32->64 and 64->128 encoder layers are no faster than on the register-staged kernel, 4x4 128->256 is 1.3-1.7x)
-         (d->stride == 1 || (d->stride == 2 && d->Cin >= 128)) && d->Cin >= 32 && (d->Cin % 32) == 0 && d->Cout >= 32 && (d->Cout % 32) == 0 &&
+         // (stride 2: a tile's input patch is ~4x its output and every pixel of it is copied - such layers run on 64-pixel
+         // tiles (wg2_prepare); measured, batch 32: 1.25-1.8x the register-staged kernel, 1.9-2.5x at 128x512)
+         (d->stride == 1 || (d->stride == 2 && d->Cin >= s2min)) && d->Cin >= 32 && (d->Cin % 32) == 0 && d->Cout >= 32 && (d->Cout % 32) == 0 &&
          d->in_mode == HDRSKY_IN_NONE && d->in_slope == 1.f && j.x && j.dy && j.dw && d->KH * d->KW <= 64;
 }
 
@@ -1045,7 +1046,9 @@ static int wg2_prepare(Wg2Args& a, const hdrsky_wgrad_job& j, int wg_target) {
   const int CB = a.cbf * 16, OB = a.obf * 16, SPX = CB / 8 + 2, SPY = OB / 8 + 2;
   const int TW = d->Wo >= 32 ? 32 : 16;
   a.tw_shift = TW == 32 ? 5 : 4;
-  a.BM = (TW == 16 && d->Ho <= 4) ? 64 : 128;
+  // 64-pixel tiles for 4-row maps (a 128-pixel tile would be half padding) and for stride 2 (a tile's input patch is ~4x its
+  // output: 128 output pixels of a 4x4 stride-2 layer need 84 KB per stage)
+  a.BM = ((TW == 16 && d->Ho <= 4) || d->stride == 2) ? 64 : 128;
   a.TH = a.BM / TW;
   a.tiles_x = cdiv(a.Wo, TW); a.tiles_y = cdiv(a.Ho, a.TH);
   a.ntiles = a.B * a.tiles_x * a.tiles_y;

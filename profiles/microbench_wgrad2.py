@@ -21,6 +21,9 @@ LAYERS = [("res 3x3 128->128 @8x32", 32, 8, 32, 128, 128, 3, 1), ("l3b 3x3 128->
           ("sunrad d2 4x4 s2 64->128 @16x64", 32, 16, 64, 64, 128, 4, 2), ("sunrad d3 4x4 s2 128->256 @8x32", 32, 8, 32, 128, 256, 4, 2),
           ("sunrad d4 4x4 256->512 @4x16", 32, 4, 16, 256, 512, 4, 1), ("disc d2 4x4 s2 64->128 @16x64 B=64", 64, 16, 64, 64, 128, 4, 2),
           ("disc d3 4x4 s2 128->256 @8x32 B=64", 64, 8, 32, 128, 256, 4, 2), ("disc d4 4x4 256->512 @4x16 B=64", 64, 4, 16, 256, 512, 4, 1)]
+LAYERS += [("hires d2 4x4 s2 64->128 @64x256 B=8", 8, 64, 256, 64, 128, 4, 2), ("hires d2 4x4 s2 64->128 @64x256 B=16", 16, 64, 256, 64, 128, 4, 2),
+           ("hires conv2_d 3x3 s2 32->64 @128x512 B=8", 8, 128, 512, 32, 64, 3, 2), ("hires conv3_d 3x3 s2 64->128 @64x256 B=8", 8, 64, 256, 64, 128, 3, 2),
+           ("hires d3 4x4 s2 128->256 @32x128 B=8", 8, 32, 128, 128, 256, 4, 2), ("hires res 3x3 128->128 @32x128 B=8", 8, 32, 128, 128, 128, 3, 1)]
 GROUPS = {"sunpose": [1, 2, 3, 4, 5], "decoders x2": [6, 7, 6, 7], "encoder": [8, 9], "sunrad": [10, 11, 12], "disc": [13, 14, 15],
           "res x12": [0] * 12}
 
