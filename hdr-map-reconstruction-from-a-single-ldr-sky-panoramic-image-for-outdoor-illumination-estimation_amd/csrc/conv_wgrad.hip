@@ -791,6 +791,313 @@ __global__ void __launch_bounds__(768) conv_wgrad2_kernel(const Multi2Args m) {
 }
 
 
+// ====================================================================================================================
+// v3: layers with a NARROW side - at most 8 input channels (the 7x7 3->32 stems, the 4x4 stride-2 6->64 first layers of the
+// discriminator / sun-radiance stacks) or at most 4 output channels (the 7x7 32->3 decoder tails, the 4x4 512->1
+// discriminator head).  On the kernels above such a layer pays a whole 16-row MFMA fragment per filter tap for its 3 useful
+// rows (49 fragments for 7x7) and a partial slab of 16 padded channels per tap and workgroup: 75-80 us per layer for 1.2
+// GFLOP.  Here the narrow tensor sits in LDS as [row][column][CP channels] bf16 (CP = 4 or 8: 8 / 16 bytes per pixel),
+// so that the 32 bytes a transposed read takes per k pixel are 4 (2) NEIGHBOURING pixels x CP channels: an M fragment's
+// 16 rows are (kx .. kx+3, channel) of one filter row - 14 fragments for 7x7 x 3, 8 for 4x4 x 6.  Consecutive k pixels read
+// overlapping windows (row stride = one pixel), which LDS does not mind.
+// One formulation serves both sides.  "wide" = the tensor the k pixels run over, "narrow" = the one read through the tap
+// window: narrow pixel = k pixel * stride + tap' - P.
+//   Cin <= 8:  wide = dY, narrow = X, tap' = tap, P = SAME padding            D[(tap', ci)][co]
+//   Cout <= 4: wide = X' (k = INPUT pixels), narrow = dY, tap' = K-1-tap, P = K-1-pad (stride 1)   D[(tap', co)][ci]
+// Both operands go through registers (fp32 -> bf16; the wide one with its producer's normalisation + activation when it
+// is the raw fp32 tensor of an X'), prefetched one tile ahead into a double-buffered LDS stage: one barrier per tile.
+// Workgroup = (block of <= 64 wide channels, pixel chunk); partial slabs in the reduce launch's [chunk][block][tap][CB][OB]
+// layout with (CB, OB) = (CP, wide block) or (wide block, 4): compact, 25 KB per workgroup for 7x7 3->32.
+// ====================================================================================================================
+struct Wg3Args {
+  const void* wide;              // [B,Hk,Wk,Cw] fp32 or bf16
+  const float* narrow;           // [B,Hn,Wn,Cn] fp32
+  const float* in_scale;         // operand transform of the wide tensor (Cout <= 4 side, fp32 X only)
+  const float* in_shift;
+  const float* in_part;
+  const float* in_gamma;
+  const float* in_beta;
+  float* ws;
+  float* ws_db;
+  int B, Hk, Wk, Cw, Hn, Wn, Cn;
+  int KH, KW, stride, PT, PL;
+  int in_mode, ss_bstride, in_nparts;
+  float in_eps, in_inv_count, in_slope;
+  int wide_bf16, transposed, bias_mode;   // bias_mode: 0 none, 1 column sums of the wide tile (Cin <= 8), 2 sums of the narrow tensor
+  int CP, XPF, NFX, NMF;         // padded narrow channels (4 / 8), columns per fragment (16 / CP), fragments per filter row, KH * NFX
+  int NB, NF, nblocks;           // wide channels per workgroup, NB / 16, Cw / NB
+  int nsplit, nunits;            // waves per M fragment (each a share of the NF wide fragments), NMF * nsplit
+  int TH, tw_shift, BM, tiles_x, tiles_y, ntiles, tiles_per_wg, nchunks;
+  int HT, WTn, wt_magic, npixn;  // narrow tile: rows, pixels per row, magic of / WTn, pixels
+  int RY, nbytes, stage_bytes, off_ss, nsamp;
+  int slabCB, slabOB;
+};
+constexpr int WG3_MAXJ = 8;
+struct Multi3Args {
+  int njobs;
+  int first[WG3_MAXJ + 1];
+  Wg3Args job[WG3_MAXJ];
+};
+static_assert(sizeof(Multi3Args) <= 4096, "kernel argument block");
+
+// WI / NI: 8-channel items of the wide tile / pixels of the narrow tile a thread prefetches (compile-time bounds of the
+// register arrays; the job's real counts are smaller or equal), UPW: (M fragment, wide share) units per wave
+template <int WI, int NI, int UPW>
+__global__ void __launch_bounds__(512, 2) conv_wgrad3_kernel(const Multi3Args m) {
+  constexpr int NT = 512, NW = 8;
+  int job = 0;
+  while (job + 1 < m.njobs && (int)blockIdx.x >= m.first[job + 1]) ++job;
+  const Wg3Args& a = m.job[job];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3, kq = g, lr = lane & 15;
+  const int l = blockIdx.x - m.first[job];
+  const int chunk = l / a.nblocks, blk = l - chunk * a.nblocks;
+  const int n0 = blk * a.NB;
+  const int TW = 1 << a.tw_shift;
+  const int PB = a.CP * 2;                              // bytes per narrow pixel
+  const int tile0 = chunk * a.tiles_per_wg;
+  const int ntl = min(a.ntiles, tile0 + a.tiles_per_wg) - tile0;
+  const int tps = a.tiles_x * a.tiles_y;
+  const int bfirst = tile0 / tps;
+  const int NQ = a.NB >> 3;                             // 8-channel items per wide row
+  const int nwitems = a.BM * NQ;
+  const float slope = a.in_slope;
+  const bool xform = a.in_mode != HDRSKY_IN_NONE || slope != 1.f;
+  float* sTab = reinterpret_cast<float*>(smem + a.off_ss);
+
+  // ---- per-sample transform tables of the wide operand -------------------------------------------------------------------
+  if (xform) {
+    const int blast = (tile0 + ntl - 1) / tps;
+    const int ntab = (blast - bfirst + 1) * a.NB;
+    for (int idx = tid; idx < ntab; idx += NT) {
+      const int sb = idx / a.NB, c = idx - sb * a.NB, b = bfirst + sb, cc = n0 + c;
+      float sc = 1.f, sh = 0.f;
+      if (a.in_mode == HDRSKY_IN_AFFINE) {
+        sc = a.in_scale[b * a.ss_bstride + cc];
+        sh = a.in_shift[b * a.ss_bstride + cc];
+      } else if (a.in_mode == HDRSKY_IN_PARTIALS) {
+        float s0, ss;
+        in_partial_sums(a.in_part + (size_t)b * a.in_nparts * 2 * a.Cw + cc, a.in_nparts, a.Cw, s0, ss);
+        const float mean = s0 * a.in_inv_count;
+        const float var = fmaxf(ss * a.in_inv_count - mean * mean, 0.f);
+        sc = a.in_gamma[cc] / sqrtf(var + a.in_eps);
+        sh = a.in_beta[cc] - mean * sc;
+      }
+      sTab[sb * 2 * a.NB + c] = sc;
+      sTab[sb * 2 * a.NB + a.NB + c] = sh;
+    }
+    __syncthreads();
+  }
+
+  // ---- units of this wave ---------------------------------------------------------------------------------------------------
+  const int jcnt = a.NF / a.nsplit;                     // wide fragments per unit (<= 4)
+  int nmy = 0;
+  const int uj0w = (wave % a.nsplit) * jcnt;             // nsplit divides the wave count: every unit of a wave has the same share
+  int tapoff[UPW], umf[UPW];
+#pragma unroll
+  for (int k = 0; k < UPW; ++k) {
+    const int u = wave + NW * k;
+    const int uc = min(u, a.nunits - 1);
+    const int mf = uc / a.nsplit;
+    const int ky = mf / a.NFX, f = mf - ky * a.NFX;
+    umf[k] = mf;
+    tapoff[k] = ky * a.WTn * PB + f * 32;
+    if (u < a.nunits) nmy = k + 1;
+  }
+  f32x4_t acc[UPW][4];
+#pragma unroll
+  for (int k = 0; k < UPW; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[k][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float bsum[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
+
+  float wr[WI][8], nr[NI][8];
+  int ib = bfirst;                                      // cursor of the next tile to load
+  int ity = (tile0 - ib * tps) / a.tiles_x, itx = (tile0 - ib * tps) - ity * a.tiles_x;
+  int sb_cur = 0;                                       // sample (relative to bfirst) of the tile held in the registers
+
+  auto load_tile = [&]() {
+    const int ky0 = ity * a.TH, kx0 = itx * TW;
+    const int ny0 = ky0 * a.stride - a.PT, nx0 = kx0 * a.stride - a.PL;
+#pragma unroll
+    for (int it = 0; it < WI; ++it) {
+      const int i = it * NT + tid;
+      if (i < nwitems) {
+        const int mr = i / NQ, qc = i - mr * NQ;
+        const int oy = ky0 + (mr >> a.tw_shift), ox = kx0 + (mr & (TW - 1));
+        const bool ok = oy < a.Hk && ox < a.Wk;
+        const size_t eo = ((size_t)(ib * a.Hk + (ok ? oy : 0)) * a.Wk + (ok ? ox : 0)) * a.Cw + n0 + qc * 8;
+        if (a.wide_bf16) {
+          const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(a.wide) + eo);
+          unpack8(u, wr[it]);
+        } else {
+          const float* src = reinterpret_cast<const float*>(a.wide) + eo;
+          const float4 va = *reinterpret_cast<const float4*>(src);
+          const float4 vb = *reinterpret_cast<const float4*>(src + 4);
+          wr[it][0] = va.x; wr[it][1] = va.y; wr[it][2] = va.z; wr[it][3] = va.w;
+          wr[it][4] = vb.x; wr[it][5] = vb.y; wr[it][6] = vb.z; wr[it][7] = vb.w;
+        }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const int i = it * NT + tid;
+      if (i < a.npixn) {
+        const int hy = (int)(((unsigned)i * (unsigned)a.wt_magic) >> 24), hx = i - hy * a.WTn;
+        const int cy = ny0 + hy, cx = nx0 + hx;
+        const bool ok = (unsigned)cy < (unsigned)a.Hn && (unsigned)cx < (unsigned)a.Wn;
+        const float* src = a.narrow + ((size_t)(ib * a.Hn + (ok ? cy : 0)) * a.Wn + (ok ? cx : 0)) * a.Cn;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float t = src[j < a.Cn ? j : 0];
+          nr[it][j] = (ok && j < a.Cn) ? t : 0.f;
+        }
+      }
+    }
+    sb_cur = ib - bfirst;
+    if (++itx == a.tiles_x) { itx = 0; if (++ity == a.tiles_y) { ity = 0; ++ib; } }
+  };
+  // registers -> stage `st` (note: the cursor has already moved on; what the position-dependent parts need is recomputed
+  // from the item index alone)
+  auto store_tile = [&](int st, int ky0, int kx0) {
+    unsigned char* sN = smem + (size_t)st * a.stage_bytes;
+    unsigned char* sY = sN + a.nbytes;
+    const float* tsc = sTab + sb_cur * 2 * a.NB;
+    const float* tsh = tsc + a.NB;
+#pragma unroll
+    for (int it = 0; it < WI; ++it) {
+      const int i = it * NT + tid;
+      if (i < nwitems) {
+        const int mr = i / NQ, qc = i - mr * NQ;
+        const int oy = ky0 + (mr >> a.tw_shift), ox = kx0 + (mr & (TW - 1));
+        const bool ok = oy < a.Hk && ox < a.Wk;
+        float v[8];
+        if (xform) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = ok ? leaky(wr[it][j] * tsc[qc * 8 + j] + tsh[qc * 8 + j], slope) : 0.f;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = ok ? wr[it][j] : 0.f;
+        }
+        if (a.bias_mode == 1) {            // NT % NQ == 0: a thread always holds the same 8 wide channels
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bsum[j] += v[j];
+        }
+        uint4 hi, lo;
+        pack8<false>(v, hi, lo);
+        *reinterpret_cast<uint4*>(sY + (size_t)mr * a.RY + qc * 16) = hi;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const int i = it * NT + tid;
+      if (i < a.npixn) {
+        if (a.bias_mode == 2 && blk == 0) {   // the tile's own pixels (tap' = P), not its halo
+          const int hy = (int)(((unsigned)i * (unsigned)a.wt_magic) >> 24), hx = i - hy * a.WTn;
+          if (hy >= a.PT && hy < a.PT + a.TH && hx >= a.PL && hx < a.PL + TW) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bsum[j] += nr[it][j];
+          }
+        }
+        uint4 hi, lo;
+        pack8<false>(nr[it], hi, lo);
+        if (a.CP == 4) *reinterpret_cast<uint2*>(sN + (size_t)i * 8) = uint2{hi.x, hi.y};
+        else *reinterpret_cast<uint4*>(sN + (size_t)i * 16) = hi;
+      }
+    }
+  };
+
+  int cty = ity, ctx = itx;                             // origin of the tile in the registers
+  load_tile();
+  store_tile(0, cty * a.TH, ctx * TW);
+  for (int i = 0; i < ntl; ++i) {
+    __syncthreads();                                    // stage i & 1 is complete; everybody is done with the other one
+    const bool more = i + 1 < ntl;
+    if (more) { cty = ity; ctx = itx; load_tile(); }
+    const unsigned char* sN = smem + (size_t)(i & 1) * a.stage_bytes;
+    const unsigned char* sY = sN + a.nbytes;
+#pragma unroll 1
+    for (int r = 0; r < (a.BM >> 5); ++r) {
+      // k permutation of conv_wgrad2_kernel: lane group g multiplies pixels {4g..4g+3} and {16+4g..16+4g+3} of the k-step
+      const int mm = r * 32 + g * 4 + q, mm2 = mm + 16;
+      const int ab0 = (((mm >> a.tw_shift) * a.WTn + (mm & (TW - 1))) * a.stride) * PB + p * 8;
+      const int ab1 = (((mm2 >> a.tw_shift) * a.WTn + (mm2 & (TW - 1))) * a.stride) * PB + p * 8;
+      const unsigned char* yrow = sY + (size_t)mm * a.RY + uj0w * 32 + p * 8;
+      uint4 bh[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (j < jcnt) {
+          const uint2 v0 = lds_tr(yrow + j * 32), v1 = lds_tr(yrow + j * 32 + 16 * a.RY);
+          bh[j] = uint4{v0.x, v0.y, v1.x, v1.y};
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < UPW; ++k) {
+        if (k < nmy) {
+          const uint2 a0 = lds_tr(sN + ab0 + tapoff[k]), a1 = lds_tr(sN + ab1 + tapoff[k]);
+          const uint4 af = uint4{a0.x, a0.y, a1.x, a1.y};
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (j < jcnt) acc[k][j] = mfma16(af, bh[j], acc[k][j]);
+        }
+      }
+    }
+    if (more) store_tile((i + 1) & 1, cty * a.TH, ctx * TW);
+  }
+
+  // ---- epilogue: this workgroup's slab ---------------------------------------------------------------------------------------
+  const int ntaps = a.KH * a.KW;
+  float* slab = a.ws + ((size_t)chunk * a.nblocks + blk) * ntaps * a.slabCB * a.slabOB;
+#pragma unroll
+  for (int k = 0; k < UPW; ++k) {
+    if (k < nmy) {
+      const int ky = umf[k] / a.NFX, f = umf[k] - ky * a.NFX;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int mrow = kq * 4 + e;
+        const int xo = f * a.XPF + mrow / a.CP, c = mrow % a.CP;
+        if (xo < a.KW) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (j < jcnt) {
+              const int n = (uj0w + j) * 16 + lr;
+              if (a.transposed) {
+                const int tap = (a.KH - 1 - ky) * a.KW + (a.KW - 1 - xo);
+                if (c < a.slabOB) slab[((size_t)tap * a.slabCB + n) * a.slabOB + c] = acc[k][j][e];
+              } else {
+                slab[((size_t)(ky * a.KW + xo) * a.slabCB + c) * a.slabOB + n] = acc[k][j][e];
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  if (a.ws_db != nullptr && (a.bias_mode == 1 || (a.bias_mode == 2 && blk == 0))) {
+    __syncthreads();                                    // every wave is past its last read of the stages
+    float* sRed = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sRed[tid * 8 + j] = bsum[j];
+    __syncthreads();
+    if (a.bias_mode == 1) {
+      if (tid < a.NB) {                                 // thread t staged 8-channel item t % NQ
+        const int qc = tid >> 3, j = tid & 7;
+        float s = 0.f;
+        for (int k = qc; k < NT; k += NQ) s += sRed[k * 8 + j];
+        a.ws_db[((size_t)chunk * a.nblocks + blk) * a.NB + tid] = s;
+      }
+    } else if (tid < 4) {
+      float s = 0.f;
+      for (int k = 0; k < NT; ++k) s += sRed[k * 8 + tid];
+      a.ws_db[(size_t)chunk * 4 + tid] = s;
+    }
+  }
+}
+
+
 // Second stage of the deterministic split-K: dw[tap][ci][co] += sum over the job's pixel chunks of the workgroup
 // partials, db likewise - always in the same order.  One launch for the jobs of a conv_wgrad_kernel launch; CB / OB = that
 // launch's block size in channels.  A block owns 256/S float4 of a chunk's slab set and S chunk slices: slice q sums the
@@ -848,11 +1155,33 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const MultiArgs m, in
     }
   }
   if (rb == 0 && a.db != nullptr) {   // bias gradient of this job: [chunk][co block][OB] partials, tiny
-    for (int co = threadIdx.x; co < a.Cout; co += 256) {
-      const float* src = a.ws_db + (size_t)(co / OB) * OB + co % OB;
+    // 16 output channels x 16 chunk slices at a time (slice q: chunks q, q+16, ... in order; then the 16 slice sums in order).
+    // One thread per channel walking all chunks was a chain of up to 256 dependent-latency loads in ONE block: 20-27 us of a
+    // launch whose other blocks finish in ~5
+    __syncthreads();                  // sPart is free again
+    float* sB = reinterpret_cast<float*>(sPart);
+    const int bl = threadIdx.x & 15, bs = threadIdx.x >> 4;
+    for (int co0 = 0; co0 < a.Cout; co0 += 16) {
+      const int co = co0 + bl;
       float t = 0.f;
-      for (int c = 0; c < a.nchunks; ++c) t += src[(size_t)c * a.oblocks * OB];
-      a.db[co] += t;
+      if (co < a.Cout) {
+        const float* src = a.ws_db + (size_t)(co / OB) * OB + co % OB;
+        const size_t cs = (size_t)a.oblocks * OB;
+        int c = bs;
+        for (; c + 48 < a.nchunks; c += 64) {
+          const float q0 = src[(size_t)c * cs], q1 = src[(size_t)(c + 16) * cs], q2 = src[(size_t)(c + 32) * cs], q3 = src[(size_t)(c + 48) * cs];
+          t += (q0 + q1) + (q2 + q3);
+        }
+        for (; c < a.nchunks; c += 16) t += src[(size_t)c * cs];
+      }
+      sB[threadIdx.x] = t;
+      __syncthreads();
+      if (bs == 0 && co < a.Cout) {
+        float s2 = 0.f;
+        for (int k = 0; k < 16; ++k) s2 += sB[k * 16 + bl];
+        a.db[co] += s2;
+      }
+      __syncthreads();
     }
   }
 }
@@ -1172,6 +1501,156 @@ static int wgrad2_groups(const hdrsky_wgrad_job* jobs, int njobs, bool* done, fl
   return HDRSKY_OK;
 }
 
+// ---- v3 host side -------------------------------------------------------------------------------------------------------
+constexpr int WG3_WI = 2, WG3_NI = 2, WG3_UPW = 2;
+
+// 0: not for conv_wgrad3_kernel, 1: narrow input (Cin <= 8), 2: narrow output (Cout <= 4)
+static int wg3_kind(const hdrsky_wgrad_job& j) {
+  const hdrsky_conv_desc* d = &j.desc;
+  if (j.da_ksize != 0 || d->compute != HDRSKY_BF16 || d->upsample != 1 || d->dilate != 1 || !j.x || !j.dy || !j.dw) return 0;
+  if (d->Cin <= 8 && d->Cout >= 16 && (d->Cout % 16) == 0 && !j.x_bf16 && d->in_mode == HDRSKY_IN_NONE && d->in_slope == 1.f &&
+      (d->stride == 1 || d->stride == 2))
+    return 1;
+  if (d->Cout <= 4 && d->Cin >= 16 && (d->Cin % 16) == 0 && d->stride == 1 && !j.dy_bf16) {
+    if (j.x_bf16 && (d->in_mode != HDRSKY_IN_NONE || d->in_slope != 1.f)) return 0;
+    if (d->in_mode == HDRSKY_IN_AFFINE && (!j.in_scale || !j.in_shift)) return 0;
+    if (d->in_mode == HDRSKY_IN_PARTIALS && (!j.in_part || !j.in_gamma || !j.in_beta || d->in_nparts <= 0)) return 0;
+    return 2;
+  }
+  return 0;
+}
+
+// fills a job's geometry (wg_target workgroups, if the layer has that many 4-tile chunks); returns its LDS bytes or an error
+static int wg3_prepare(Wg3Args& a, const hdrsky_wgrad_job& j, int wg_target) {
+  const hdrsky_conv_desc* d = &j.desc;
+  const int kind = wg3_kind(j);
+  if (kind == 0) return HDRSKY_EUNSUPPORTED;
+  a = Wg3Args{};
+  a.B = d->B; a.KH = d->KH; a.KW = d->KW;
+  if (kind == 1) {
+    a.wide = j.dy; a.wide_bf16 = j.dy_bf16; a.Hk = d->Ho; a.Wk = d->Wo; a.Cw = d->Cout;
+    a.narrow = j.x; a.Hn = d->H; a.Wn = d->W; a.Cn = d->Cin;
+    a.stride = d->stride; a.PT = d->pad_t; a.PL = d->pad_l; a.transposed = 0; a.bias_mode = j.db ? 1 : 0;
+    a.in_mode = HDRSKY_IN_NONE; a.in_slope = 1.f;
+  } else {
+    a.wide = j.x; a.wide_bf16 = j.x_bf16; a.Hk = d->H; a.Wk = d->W; a.Cw = d->Cin;
+    a.narrow = j.dy; a.Hn = d->Ho; a.Wn = d->Wo; a.Cn = d->Cout;
+    a.stride = 1; a.PT = d->KH - 1 - d->pad_t; a.PL = d->KW - 1 - d->pad_l; a.transposed = 1; a.bias_mode = j.db ? 2 : 0;
+    a.in_scale = j.in_scale; a.in_shift = j.in_shift; a.in_part = j.in_part; a.in_gamma = j.in_gamma; a.in_beta = j.in_beta;
+    a.in_mode = d->in_mode; a.ss_bstride = d->ss_bstride; a.in_nparts = d->in_nparts; a.in_eps = d->in_eps;
+    a.in_inv_count = 1.f / (float)(d->H * d->W); a.in_slope = d->in_slope;
+  }
+  a.CP = a.Cn <= 4 ? 4 : 8;
+  a.XPF = 16 / a.CP;
+  a.NFX = cdiv(a.KW, a.XPF);
+  a.NMF = a.KH * a.NFX;
+  a.NB = (a.Cw % 64) == 0 ? 64 : ((a.Cw % 32) == 0 ? 32 : 16);
+  a.NF = a.NB / 16;
+  a.nblocks = a.Cw / a.NB;
+  a.nsplit = (a.NMF <= 4 && a.NF >= 2) ? 2 : 1;
+  a.nunits = a.NMF * a.nsplit;
+  if (cdiv(a.nunits, 8) > WG3_UPW) return HDRSKY_EUNSUPPORTED;
+  const int TW = a.Wk >= 32 ? 32 : 16;
+  a.tw_shift = TW == 32 ? 5 : 4;
+  a.BM = (TW == 16 && a.Hk <= 4) ? 64 : 128;
+  a.TH = a.BM / TW;
+  a.tiles_x = cdiv(a.Wk, TW); a.tiles_y = cdiv(a.Hk, a.TH);
+  a.ntiles = a.B * a.tiles_x * a.tiles_y;
+  a.HT = (a.TH - 1) * a.stride + a.KH;
+  a.WTn = (TW - 1) * a.stride + a.NFX * a.XPF;
+  a.npixn = a.HT * a.WTn;
+  a.wt_magic = ((1 << 24) + a.WTn - 1) / a.WTn;
+  if (cdiv(a.npixn, 512) > WG3_NI || cdiv(a.BM * a.NB / 8, 512) > WG3_WI || a.HT >= 256) return HDRSKY_EUNSUPPORTED;
+  a.RY = (a.NB / 8 + 2) * 16;
+  a.nbytes = roundup(a.npixn * a.CP * 2, 16);
+  a.stage_bytes = a.nbytes + a.BM * a.RY;
+  a.off_ss = 2 * a.stage_bytes;
+  if (a.off_ss < 512 * 8 * 4) a.off_ss = 512 * 8 * 4;   // the bias reduction's scratch overlays the stages
+  int chunks = wg_target / a.nblocks;
+  if (chunks > a.ntiles / 4) chunks = a.ntiles / 4;
+  if (chunks < 1) chunks = 1;
+  a.tiles_per_wg = cdiv(a.ntiles, chunks);
+  a.nchunks = cdiv(a.ntiles, a.tiles_per_wg);
+  const int tps = a.tiles_x * a.tiles_y;
+  a.nsamp = (a.tiles_per_wg + tps - 2) / tps + 1;
+  if (kind == 1) { a.slabCB = a.CP; a.slabOB = a.NB; } else { a.slabCB = a.NB; a.slabOB = 4; }
+  const int lds = a.off_ss + a.nsamp * 2 * a.NB * 4;
+  if (lds > 80 * 1024) return HDRSKY_EUNSUPPORTED;       // two workgroups per CU
+  return lds;
+}
+
+static int wg3_launch(Multi3Args& m, int lds, hipStream_t stream) {
+  auto kern = conv_wgrad3_kernel<WG3_WI, WG3_NI, WG3_UPW>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)
+      return HDRSKY_ELAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(m.first[m.njobs]), dim3(512), lds, stream, m);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+// Launches (or, plan_only, sizes) the narrow-layer kernel + the shared reduce for the jobs it takes; marks them in done[].
+static int wgrad3_groups(const hdrsky_wgrad_job* jobs, int njobs, bool* done, float* ws, size_t ws_floats, size_t* ws_used,
+                         bool plan_only, void* stream) {
+  const int wg_each = getenv("HDRSKY_WGRAD3_WGS") ? atoi(getenv("HDRSKY_WGRAD3_WGS")) : 256;   // tuning hook: workgroups per layer
+  int members[256], nm = 0;
+  for (int k = 0; k < njobs; ++k) {
+    if (done[k]) continue;
+    Wg3Args probe;
+    if (wg3_prepare(probe, jobs[k], wg_each) < 0) continue;
+    members[nm++] = k;
+  }
+  for (int base = 0; base < nm; base += WG3_MAXJ) {
+    const int cnt = nm - base < WG3_MAXJ ? nm - base : WG3_MAXJ;
+    Multi3Args m3{};
+    MultiArgs mr{};
+    m3.njobs = mr.njobs = cnt;
+    int lds = 0, blocks = 0, rblocks = 0, maxchunks = 1;
+    for (int q = 0; q < cnt; ++q) {
+      Wg3Args tmp;
+      if (wg3_prepare(tmp, jobs[members[base + q]], wg_each) >= 0 && tmp.nchunks > maxchunks) maxchunks = tmp.nchunks;
+    }
+    const int S = maxchunks >= 32 ? 16 : 4;
+    for (int q = 0; q < cnt; ++q) {
+      const hdrsky_wgrad_job& j = jobs[members[base + q]];
+      Wg3Args& a = m3.job[q];
+      const int r = wg3_prepare(a, j, wg_each);
+      if (r < 0) return r;
+      if (r > lds) lds = r;
+      m3.first[q] = blocks;
+      blocks += a.nblocks * a.nchunks;
+      const int ntaps = a.KH * a.KW;
+      const size_t nslab = (size_t)a.nchunks * a.nblocks * ntaps * a.slabCB * a.slabOB;
+      const int oblocks = a.transposed ? 1 : a.nblocks, cblocks = a.transposed ? a.nblocks : 1;
+      const size_t nbias = (size_t)a.nchunks * oblocks * a.slabOB;
+      a.ws = ws + *ws_used;
+      a.ws_db = j.db != nullptr ? ws + *ws_used + nslab : nullptr;
+      *ws_used += nslab + (j.db != nullptr ? nbias : 0);
+      WgradArgs& ar = mr.job[q];     // what wgrad_reduce_kernel reads
+      ar = WgradArgs{};
+      ar.dw = j.dw; ar.db = j.db; ar.ws = a.ws; ar.ws_db = a.ws_db; ar.Cin = j.desc.Cin; ar.Cout = j.desc.Cout;
+      ar.nchunks = a.nchunks; ar.cblocks = cblocks; ar.oblocks = oblocks; ar.ntaps = ntaps;
+      ar.RX = a.slabCB; ar.RY = a.slabOB;
+      mr.rfirst[q] = rblocks;
+      rblocks += (int)(((size_t)a.nblocks * ntaps * a.slabCB * (a.slabOB / 4) + 256 / S - 1) / (256 / S));
+    }
+    m3.first[cnt] = blocks;
+    mr.rfirst[cnt] = rblocks;
+    if (!plan_only) {
+      if (*ws_used > ws_floats) return HDRSKY_EINVAL;
+      const int r = wg3_launch(m3, lds, (hipStream_t)stream);
+      if (r != HDRSKY_OK) return r;
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(256), 0, (hipStream_t)stream, mr, 0, 0, S);
+      HDRSKY_CHECK_LAUNCH();
+    }
+    for (int q = 0; q < cnt; ++q) done[members[base + q]] = true;
+  }
+  return HDRSKY_OK;
+}
+
 }  // namespace
 
 // Shared body of the two entry points.  ws == nullptr: split-K by fp32 atomics.  Otherwise deterministic: `ws` receives
@@ -1197,6 +1676,12 @@ static int wgrad_multi_impl(const hdrsky_wgrad_job* jobs, int njobs, float* ws, 
   if (v2_on && (ws != nullptr || plan_only)) {
     const int rc2 = wgrad2_groups(jobs, njobs, done, ws, ws_floats, &ws_used, plan_only, stream);
     if (rc2 != HDRSKY_OK) return rc2;
+  }
+  // layers with a narrow side (<= 8 input or <= 4 output channels): their own kernel (HDRSKY_WGRAD3=0: A/B hook)
+  const bool v3_on = !(getenv("HDRSKY_WGRAD3") && atoi(getenv("HDRSKY_WGRAD3")) == 0);
+  if (v3_on && (ws != nullptr || plan_only)) {
+    const int rc3 = wgrad3_groups(jobs, njobs, done, ws, ws_floats, &ws_used, plan_only, stream);
+    if (rc3 != HDRSKY_OK) return rc3;
   }
   int nwide = 0;
   for (int i = 0; i < njobs; ++i) nwide += (!done[i] && can_go_big(jobs[i])) ? 1 : 0;

@@ -184,3 +184,117 @@ def test_wgrad_dma_kernel_on_materialised_operands(dev, monkeypatch):
         assert_close(ja[4], jb[4], 3e-5, "layer %d dw: materialised bf16 operand + LDS-DMA kernel vs transform while staging" % i)
         if ja[5] is not None:
             assert_close(ja[5], jb[5], 3e-5, "layer %d db" % i)
+
+
+# (name, H, W, Cin, Cout, k, stride, same): the layers with a narrow side (conv_wgrad3_kernel): <= 8 input channels or <= 4
+# output channels, both block widths, both pixel paddings (4 / 8 channels), stride 2, VALID, odd map sizes, the 128x512 stem
+V3_LAYERS = [
+    ("stem 7x7 3->32 @32x128", 32, 128, 3, 32, 7, 1, True), ("tail 7x7 32->3 @32x128", 32, 128, 32, 3, 7, 1, True),
+    ("d1 4x4 s2 6->64 @32x128", 32, 128, 6, 64, 4, 2, True), ("dis.out 4x4 VALID 512->1 @4x16", 4, 16, 512, 1, 4, 1, False),
+    ("odd 5x5 4->16 @9x37", 9, 37, 4, 16, 5, 1, True), ("odd 3x3 s2 8->48 @11x21", 11, 21, 8, 48, 3, 2, True),
+    ("odd 3x3 48->2 @7x19", 7, 19, 48, 2, 3, 1, True), ("odd 4x4 64->4 @6x10", 6, 10, 64, 4, 4, 1, True),
+    ("valid 3x3 1->16 @8x40", 8, 40, 1, 16, 3, 1, False), ("hires stem 7x7 3->32 @128x512", 128, 512, 3, 32, 7, 1, True),
+]
+
+
+def _bf16_values(rng, shape):
+    """fp32 tensor whose values are bf16-representable: both kernels (and float64 autograd) then multiply the same numbers."""
+    return torch.from_numpy(rng.standard_normal(shape).astype(np.float32)).to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize("case", V3_LAYERS, ids=[c[0] for c in V3_LAYERS])
+@pytest.mark.parametrize("B", [1, 5])
+def test_wgrad_narrow_kernel_layers(dev, case, B, monkeypatch):
+    """Layers with a narrow side -> conv_wgrad3_kernel (the narrow tensor as [row][column][4 or 8 channels] in LDS, M fragments =
+    neighbouring columns x channels of a filter row; narrow OUTPUT: the same with the roles of x and dy swapped, taps
+    flipped).  On bf16-representable operands: (a) float64 autograd of the oracle conv, (b) the register-staged kernel
+    (HDRSKY_WGRAD3=0), (c) bit-reproducible, (d) the wide operand handed over as a bf16 tensor gives the same bits."""
+    K = pkg("kernels")
+    name, H, W, Cin, Cout, k, stride, same = case
+    if H * W * B > 200000:
+        B = min(B, 2)
+    rng = np.random.default_rng(zlib.crc32((name + str(B)).encode()))
+    x = _bf16_values(rng, (B, H, W, Cin))
+    if Cout == 1:    # (float64 autograd of a one-filter conv trips torch's slow_conv2d contiguity check: the sum written out)
+        pt, pl = (T.same_pad(H, k, stride)[0], T.same_pad(W, k, stride)[0]) if same else (0, 0)
+        Ho, Wo = (-(-H // stride), -(-W // stride)) if same else ((H - k) // stride + 1, (W - k) // stride + 1)
+        dy = _bf16_values(rng, (B, Ho, Wo, Cout))
+        xp = torch.zeros(B, H + 2 * k, W + 2 * k, Cin, dtype=torch.float64)
+        xp[:, pt:pt + H, pl:pl + W] = x.double()
+        gw = torch.zeros(k, k, Cin, Cout, dtype=torch.float64)
+        for ky in range(k):
+            for kx in range(k):
+                win = xp[:, ky:ky + (Ho - 1) * stride + 1:stride, kx:kx + (Wo - 1) * stride + 1:stride]
+                gw[ky, kx] = torch.einsum("bhwc,bhwo->co", win, dy.double())
+        gb = dy.double().sum((0, 1, 2))
+    else:
+        w = torch.zeros(k, k, Cin, Cout, dtype=torch.float64, requires_grad=True)
+        b = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+        y = T.conv2d(x.double(), w, b, stride, "SAME" if same else "VALID")
+        dy = _bf16_values(rng, tuple(y.shape))
+        gw, gb = torch.autograd.grad(y, (w, b), dy.double())
+
+    def run(xd, dyd):
+        dw, db = torch.zeros(k, k, Cin, Cout, device=dev), torch.zeros(Cout, device=dev)
+        K.conv2d_wgrad_multi([K.wgrad_job(xd, dyd, k, k, dw, db, stride=stride, same=same, compute=K.BF16)])
+        return dw, db
+    dw, db = run(x.to(dev), dy.to(dev))
+    assert_close(dw, gw, 2e-5, name + " dw (narrow kernel)")
+    assert_close(db, gb, 2e-5, name + " db (narrow kernel)")
+    dw2, db2 = run(x.to(dev), dy.to(dev))
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    if Cin > 8:
+        dwb, dbb = run(x.to(dev).to(torch.bfloat16), dy.to(dev))
+        assert torch.equal(dw, dwb) and torch.equal(db, dbb)
+    elif Cout % 8 == 0:
+        dwb, dbb = run(x.to(dev), dy.to(dev).to(torch.bfloat16))
+        assert torch.equal(dw, dwb) and torch.equal(db, dbb)
+    if Cin > 8 and Cin % 32:
+        return      # (the register-staged kernel takes 32-channel multiples only)
+    monkeypatch.setenv("HDRSKY_WGRAD3", "0")
+    dw1, db1 = run(x.to(dev), dy.to(dev))
+    assert_close(dw1, dw, 2e-5, name + " register-staged vs narrow kernel")
+    assert_close(db1, db, 2e-5, name + " db register-staged vs narrow kernel")
+
+
+def test_wgrad_narrow_kernel_with_operand_transform(dev, monkeypatch):
+    """The decoder tails (7x7 32->3) read a raw conv output through InstanceNorm-from-partials + leaky, the discriminator head
+    a BatchNorm affine per sample + LeakyReLU(0.3): conv_wgrad3_kernel applies the wide operand's transform while staging,
+    like the register-staged kernel - same bf16 operands, only the summation order differs.  Both in one call, together with
+    a stem layer and a wide layer that goes to the LDS-DMA kernel."""
+    K = pkg("kernels"); L = pkg("_lib")
+    B = 4
+    d = lambda a: torch.from_numpy(a).to(dev)
+
+    def jobs():
+        rng = np.random.default_rng(21)
+        out = []
+        x1 = d(rng.standard_normal((B, 16, 64, 64)).astype(np.float32) * 2 + 0.3)
+        r1, st = K.conv2d(x1, K.PackedConv(d((rng.standard_normal((3, 3, 64, 32)) / 24).astype(np.float32))), None, want_stats=True,
+                          compute=K.BF16)
+        xf1 = K.InXf(mode=L.IN_PARTIALS, slope=0.1, stats=st, gamma=d(rng.uniform(0.5, 1.5, 32).astype(np.float32)),
+                     beta=d(rng.standard_normal(32).astype(np.float32)))
+        dy1 = d(rng.standard_normal((B, 16, 64, 3)).astype(np.float32))
+        out.append(K.wgrad_job(r1, dy1, 7, 7, torch.zeros(7, 7, 32, 3, device=dev), torch.zeros(3, device=dev), xf=xf1, compute=K.BF16))
+        x2 = d(rng.standard_normal((B, 4, 16, 512)).astype(np.float32))
+        xf2 = K.InXf(mode=L.IN_AFFINE, slope=0.3, scale=d(rng.uniform(0.5, 1.5, (B, 512)).astype(np.float32)),
+                     shift=d(rng.standard_normal((B, 512)).astype(np.float32)))
+        dy2 = d(rng.standard_normal((B, 1, 13, 1)).astype(np.float32))
+        out.append(K.wgrad_job(x2, dy2, 4, 4, torch.zeros(4, 4, 512, 1, device=dev), torch.zeros(1, device=dev), same=False, xf=xf2,
+                               compute=K.BF16))
+        x3 = d(rng.standard_normal((B, 32, 128, 3)).astype(np.float32))
+        dy3 = d(rng.standard_normal((B, 32, 128, 32)).astype(np.float32)).to(torch.bfloat16)
+        out.append(K.wgrad_job(x3, dy3, 7, 7, torch.zeros(7, 7, 3, 32, device=dev), torch.zeros(32, device=dev), compute=K.BF16))
+        x4 = d(rng.standard_normal((B, 8, 32, 128)).astype(np.float32)).to(torch.bfloat16)
+        dy4 = d(rng.standard_normal((B, 8, 32, 128)).astype(np.float32)).to(torch.bfloat16)
+        out.append(K.wgrad_job(x4, dy4, 3, 3, torch.zeros(3, 3, 128, 128, device=dev), torch.zeros(128, device=dev), compute=K.BF16))
+        return out
+    a = jobs()
+    K.conv2d_wgrad_multi(a)
+    monkeypatch.setenv("HDRSKY_WGRAD3", "0")
+    b = jobs()
+    K.conv2d_wgrad_multi(b)
+    for i, (ja, jb) in enumerate(zip(a, b)):
+        assert float(ja[4].abs().max()) > 0
+        assert_close(ja[4], jb[4], 3e-5, "layer %d dw: narrow kernel vs register-staged kernel" % i)
+        assert_close(ja[5], jb[5], 3e-5, "layer %d db" % i)
