@@ -831,20 +831,25 @@ struct Wg3Args {
   int HT, WTn, wt_magic, npixn;  // narrow tile: rows, pixels per row, magic of / WTn, pixels
   int RY, nbytes, stage_bytes, off_ss, nsamp;
   int slabCB, slabOB;
+  int deep;                      // host only: one wide item and one narrow pixel per thread and tile -> the D = 4 instantiations
 };
 constexpr int WG3_MAXJ = 8;
 struct Multi3Args {
   int njobs;
+  unsigned long long* stamps;    // debug: per-workgroup s_memtime phase stamps (hdrsky_debug_wgrad2_stamps), null in production
   int first[WG3_MAXJ + 1];
   Wg3Args job[WG3_MAXJ];
 };
 static_assert(sizeof(Multi3Args) <= 4096, "kernel argument block");
 
-// WI / NI: 8-channel items of the wide tile / pixels of the narrow tile a thread prefetches (compile-time bounds of the
-// register arrays; the job's real counts are smaller or equal), UPW: (M fragment, wide share) units per wave
-template <int WI, int NI, int UPW>
+// D: tiles whose global loads are all issued before the first of them is consumed (a workgroup walks its chunk in groups of D;
+// the first version prefetched one tile ahead and paid a global round trip per 128-pixel tile: 22 us for 4 tiles), WI / NI:
+// 8-channel items of the wide tile / pixels of the narrow tile per thread and tile, CPR: registers per narrow pixel (>= the
+// job's CP), UPW: (M fragment, wide share) units per wave.  The register arrays hold RAW data (wide: 16 / 32 bytes per item).
+template <int D, int WI, int NI, int CPR, int UPW>
 __global__ void __launch_bounds__(512, 2) conv_wgrad3_kernel(const Multi3Args m) {
   constexpr int NT = 512, NW = 8;
+  static_assert((D & 1) == 0, "the LDS stage of a tile is its parity within the group");
   int job = 0;
   while (job + 1 < m.njobs && (int)blockIdx.x >= m.first[job + 1]) ++job;
   const Wg3Args& a = m.job[job];
@@ -865,6 +870,9 @@ __global__ void __launch_bounds__(512, 2) conv_wgrad3_kernel(const Multi3Args m)
   const float slope = a.in_slope;
   const bool xform = a.in_mode != HDRSKY_IN_NONE || slope != 1.f;
   float* sTab = reinterpret_cast<float*>(smem + a.off_ss);
+  const bool dbg = m.stamps != nullptr;
+  unsigned long long t_ld = 0, t_st = 0, t_bar = 0, t_cp = 0, t_a = 0, t_b = 0;
+  if (dbg && tid == 0) m.stamps[(size_t)blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memtime();
 
   // ---- per-sample transform tables of the wide operand -------------------------------------------------------------------
   if (xform) {
@@ -887,7 +895,7 @@ __global__ void __launch_bounds__(512, 2) conv_wgrad3_kernel(const Multi3Args m)
       sTab[sb * 2 * a.NB + c] = sc;
       sTab[sb * 2 * a.NB + a.NB + c] = sh;
     }
-    __syncthreads();
+    __syncthreads();                                    // read by store_tile of the first tile, ahead of any other barrier
   }
 
   // ---- units of this wave ---------------------------------------------------------------------------------------------------
@@ -914,138 +922,181 @@ __global__ void __launch_bounds__(512, 2) conv_wgrad3_kernel(const Multi3Args m)
 #pragma unroll
   for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
 
-  float wr[WI][8], nr[NI][8];
+  uint4 wq[D][WI][2];                                   // raw wide items: 8 fp32 (both) or 8 bf16 ([0])
+  float nr[D][NI][CPR];
+  int torg[D], tsb[D];                                  // (row << 16 | column) of the tile's origin in k pixels, its sample - bfirst
   int ib = bfirst;                                      // cursor of the next tile to load
   int ity = (tile0 - ib * tps) / a.tiles_x, itx = (tile0 - ib * tps) - ity * a.tiles_x;
-  int sb_cur = 0;                                       // sample (relative to bfirst) of the tile held in the registers
+  int nloaded = 0;
 
-  auto load_tile = [&]() {
+  // what a thread loads / stores is the same in every tile up to the tile's origin: decoded once.  Wide item: (row, column) in
+  // the tile, channel offset, LDS byte offset (negative: no item); narrow pixel: (row, column) of the halo tile, LDS offset,
+  // bit 30 of the packed position: one of the tile's own pixels (bias sums of a narrow dY)
+  int w_pos[WI], w_lds[WI], w_c8[WI], n_pos[NI], n_lds[NI];
+#pragma unroll
+  for (int it = 0; it < WI; ++it) {
+    const int i = it * NT + tid, ic = min(i, nwitems - 1);
+    const int mr = ic / NQ, qc = ic - mr * NQ;
+    w_pos[it] = ((mr >> a.tw_shift) << 16) | (mr & (TW - 1));
+    w_c8[it] = qc * 8;
+    w_lds[it] = i < nwitems ? mr * a.RY + qc * 16 : -1;
+  }
+#pragma unroll
+  for (int it = 0; it < NI; ++it) {
+    const int i = it * NT + tid, ic = min(i, a.npixn - 1);
+    const int hy = (int)(((unsigned)ic * (unsigned)a.wt_magic) >> 24), hx = ic - hy * a.WTn;
+    const bool own = hy >= a.PT && hy < a.PT + a.TH && hx >= a.PL && hx < a.PL + TW;
+    n_pos[it] = (hy << 16) | hx | (own ? (1 << 30) : 0);
+    n_lds[it] = i < a.npixn ? ic * PB : -1;
+  }
+
+  // all loads of a tile, unconditionally (past the chunk's end the last tile is loaded again: straight-line code, so that the
+  // compiler's counted waits let the first tile of a group be consumed while the loads of the others are still in flight)
+  auto load_tile = [&](int t) {
     const int ky0 = ity * a.TH, kx0 = itx * TW;
     const int ny0 = ky0 * a.stride - a.PT, nx0 = kx0 * a.stride - a.PL;
+    torg[t] = (ky0 << 16) | kx0; tsb[t] = ib - bfirst;
 #pragma unroll
     for (int it = 0; it < WI; ++it) {
-      const int i = it * NT + tid;
-      if (i < nwitems) {
-        const int mr = i / NQ, qc = i - mr * NQ;
-        const int oy = ky0 + (mr >> a.tw_shift), ox = kx0 + (mr & (TW - 1));
-        const bool ok = oy < a.Hk && ox < a.Wk;
-        const size_t eo = ((size_t)(ib * a.Hk + (ok ? oy : 0)) * a.Wk + (ok ? ox : 0)) * a.Cw + n0 + qc * 8;
-        if (a.wide_bf16) {
-          const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(a.wide) + eo);
-          unpack8(u, wr[it]);
-        } else {
-          const float* src = reinterpret_cast<const float*>(a.wide) + eo;
-          const float4 va = *reinterpret_cast<const float4*>(src);
-          const float4 vb = *reinterpret_cast<const float4*>(src + 4);
-          wr[it][0] = va.x; wr[it][1] = va.y; wr[it][2] = va.z; wr[it][3] = va.w;
-          wr[it][4] = vb.x; wr[it][5] = vb.y; wr[it][6] = vb.z; wr[it][7] = vb.w;
-        }
+      const int oy = ky0 + (w_pos[it] >> 16), ox = kx0 + (w_pos[it] & 0xffff);
+      const bool ok = oy < a.Hk && ox < a.Wk;
+      const size_t eo = ((size_t)(ib * a.Hk + (ok ? oy : 0)) * a.Wk + (ok ? ox : 0)) * a.Cw + n0 + w_c8[it];
+      if (a.wide_bf16) {
+        wq[t][it][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(a.wide) + eo);
+      } else {
+        const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(a.wide) + eo);
+        wq[t][it][0] = src[0]; wq[t][it][1] = src[1];
       }
     }
 #pragma unroll
     for (int it = 0; it < NI; ++it) {
-      const int i = it * NT + tid;
-      if (i < a.npixn) {
-        const int hy = (int)(((unsigned)i * (unsigned)a.wt_magic) >> 24), hx = i - hy * a.WTn;
-        const int cy = ny0 + hy, cx = nx0 + hx;
-        const bool ok = (unsigned)cy < (unsigned)a.Hn && (unsigned)cx < (unsigned)a.Wn;
-        const float* src = a.narrow + ((size_t)(ib * a.Hn + (ok ? cy : 0)) * a.Wn + (ok ? cx : 0)) * a.Cn;
+      const int cy = ny0 + ((n_pos[it] >> 16) & 0x3fff), cx = nx0 + (n_pos[it] & 0xffff);
+      const bool ok = (unsigned)cy < (unsigned)a.Hn && (unsigned)cx < (unsigned)a.Wn;
+      const float* src = a.narrow + ((size_t)(ib * a.Hn + (ok ? cy : 0)) * a.Wn + (ok ? cx : 0)) * a.Cn;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float t = src[j < a.Cn ? j : 0];
-          nr[it][j] = (ok && j < a.Cn) ? t : 0.f;
-        }
+      for (int j = 0; j < CPR; ++j) {
+        const float v = src[j < a.Cn ? j : 0];
+        nr[t][it][j] = (ok && j < a.Cn) ? v : 0.f;
       }
     }
-    sb_cur = ib - bfirst;
-    if (++itx == a.tiles_x) { itx = 0; if (++ity == a.tiles_y) { ity = 0; ++ib; } }
+    if (++nloaded < ntl) { if (++itx == a.tiles_x) { itx = 0; if (++ity == a.tiles_y) { ity = 0; ++ib; } } }
   };
-  // registers -> stage `st` (note: the cursor has already moved on; what the position-dependent parts need is recomputed
-  // from the item index alone)
-  auto store_tile = [&](int st, int ky0, int kx0) {
+  auto store_tile = [&](int t, int st) {
     unsigned char* sN = smem + (size_t)st * a.stage_bytes;
     unsigned char* sY = sN + a.nbytes;
-    const float* tsc = sTab + sb_cur * 2 * a.NB;
+    const float* tsc = sTab + tsb[t] * 2 * a.NB;
     const float* tsh = tsc + a.NB;
+    const int ky0 = torg[t] >> 16, kx0 = torg[t] & 0xffff;
 #pragma unroll
     for (int it = 0; it < WI; ++it) {
-      const int i = it * NT + tid;
-      if (i < nwitems) {
-        const int mr = i / NQ, qc = i - mr * NQ;
-        const int oy = ky0 + (mr >> a.tw_shift), ox = kx0 + (mr & (TW - 1));
+      if (w_lds[it] >= 0) {
+        const int oy = ky0 + (w_pos[it] >> 16), ox = kx0 + (w_pos[it] & 0xffff);
         const bool ok = oy < a.Hk && ox < a.Wk;
-        float v[8];
-        if (xform) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = ok ? leaky(wr[it][j] * tsc[qc * 8 + j] + tsh[qc * 8 + j], slope) : 0.f;
+        if (a.wide_bf16 && !xform && a.bias_mode != 1) {     // a final bf16 tensor: copied
+          *reinterpret_cast<uint4*>(sY + w_lds[it]) = ok ? wq[t][it][0] : uint4{0, 0, 0, 0};
         } else {
+          float v[8];
+          if (a.wide_bf16) unpack8(wq[t][it][0], v);
+          else {
+            const uint4 u0 = wq[t][it][0], u1 = wq[t][it][1];
+            v[0] = __builtin_bit_cast(float, u0.x); v[1] = __builtin_bit_cast(float, u0.y); v[2] = __builtin_bit_cast(float, u0.z);
+            v[3] = __builtin_bit_cast(float, u0.w); v[4] = __builtin_bit_cast(float, u1.x); v[5] = __builtin_bit_cast(float, u1.y);
+            v[6] = __builtin_bit_cast(float, u1.z); v[7] = __builtin_bit_cast(float, u1.w);
+          }
+          if (xform) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = ok ? wr[it][j] : 0.f;
-        }
-        if (a.bias_mode == 1) {            // NT % NQ == 0: a thread always holds the same 8 wide channels
+            for (int j = 0; j < 8; ++j) v[j] = ok ? leaky(v[j] * tsc[w_c8[it] + j] + tsh[w_c8[it] + j], slope) : 0.f;
+          } else {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) bsum[j] += v[j];
+            for (int j = 0; j < 8; ++j) v[j] = ok ? v[j] : 0.f;
+          }
+          if (a.bias_mode == 1) {          // NT % NQ == 0: a thread always holds the same 8 wide channels
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bsum[j] += v[j];
+          }
+          uint4 hi, lo;
+          pack8<false>(v, hi, lo);
+          *reinterpret_cast<uint4*>(sY + w_lds[it]) = hi;
         }
-        uint4 hi, lo;
-        pack8<false>(v, hi, lo);
-        *reinterpret_cast<uint4*>(sY + (size_t)mr * a.RY + qc * 16) = hi;
       }
     }
 #pragma unroll
     for (int it = 0; it < NI; ++it) {
-      const int i = it * NT + tid;
-      if (i < a.npixn) {
-        if (a.bias_mode == 2 && blk == 0) {   // the tile's own pixels (tap' = P), not its halo
-          const int hy = (int)(((unsigned)i * (unsigned)a.wt_magic) >> 24), hx = i - hy * a.WTn;
-          if (hy >= a.PT && hy < a.PT + a.TH && hx >= a.PL && hx < a.PL + TW) {
+      if (n_lds[it] >= 0) {
+        if (a.bias_mode == 2 && blk == 0 && (n_pos[it] >> 30) != 0) {   // the tile's own pixels (tap' = P), not its halo
 #pragma unroll
-            for (int j = 0; j < 8; ++j) bsum[j] += nr[it][j];
-          }
+          for (int j = 0; j < 4; ++j) bsum[j] += nr[t][it][j];
         }
-        uint4 hi, lo;
-        pack8<false>(nr[it], hi, lo);
-        if (a.CP == 4) *reinterpret_cast<uint2*>(sN + (size_t)i * 8) = uint2{hi.x, hi.y};
-        else *reinterpret_cast<uint4*>(sN + (size_t)i * 16) = hi;
+        const unsigned w0 = f2bf(nr[t][it][0]) | ((unsigned)f2bf(nr[t][it][1]) << 16);
+        const unsigned w1 = f2bf(nr[t][it][2]) | ((unsigned)f2bf(nr[t][it][3]) << 16);
+        if (CPR == 4 || a.CP == 4) *reinterpret_cast<uint2*>(sN + n_lds[it]) = uint2{w0, w1};
+        else {
+          const unsigned w2 = f2bf(nr[t][it][4 % CPR]) | ((unsigned)f2bf(nr[t][it][5 % CPR]) << 16);
+          const unsigned w3 = f2bf(nr[t][it][6 % CPR]) | ((unsigned)f2bf(nr[t][it][7 % CPR]) << 16);
+          *reinterpret_cast<uint4*>(sN + n_lds[it]) = uint4{w0, w1, w2, w3};
+        }
       }
     }
   };
-
-  int cty = ity, ctx = itx;                             // origin of the tile in the registers
-  load_tile();
-  store_tile(0, cty * a.TH, ctx * TW);
-  for (int i = 0; i < ntl; ++i) {
-    __syncthreads();                                    // stage i & 1 is complete; everybody is done with the other one
-    const bool more = i + 1 < ntl;
-    if (more) { cty = ity; ctx = itx; load_tile(); }
-    const unsigned char* sN = smem + (size_t)(i & 1) * a.stage_bytes;
-    const unsigned char* sY = sN + a.nbytes;
-#pragma unroll 1
-    for (int r = 0; r < (a.BM >> 5); ++r) {
-      // k permutation of conv_wgrad2_kernel: lane group g multiplies pixels {4g..4g+3} and {16+4g..16+4g+3} of the k-step
-      const int mm = r * 32 + g * 4 + q, mm2 = mm + 16;
-      const int ab0 = (((mm >> a.tw_shift) * a.WTn + (mm & (TW - 1))) * a.stride) * PB + p * 8;
-      const int ab1 = (((mm2 >> a.tw_shift) * a.WTn + (mm2 & (TW - 1))) * a.stride) * PB + p * 8;
-      const unsigned char* yrow = sY + (size_t)mm * a.RY + uj0w * 32 + p * 8;
-      uint4 bh[4];
+  // k permutation of conv_wgrad2_kernel: lane group g multiplies pixels {4g..4g+3} and {16+4g..16+4g+3} of a k-step.  With 32-pixel
+  // tile rows a k-step is one row (second half 16 columns on), with 16-pixel rows two (second half = the next row): the lane's
+  // byte offsets of k-step 0, and what a k-step adds
+  const int mm0 = g * 4 + q;
+  const int ab0_0 = (mm0 * a.stride) * PB + p * 8;
+  const int ab1_0 = ab0_0 + (TW == 32 ? 16 * a.stride : a.WTn * a.stride) * PB;
+  const int astep = (TW == 32 ? 1 : 2) * a.WTn * a.stride * PB;
+  const int yb_0 = mm0 * a.RY + uj0w * 32 + p * 8;
+  auto kstep = [&](const unsigned char* sN, const unsigned char* sY, int r) {
+    const unsigned char* yrow = sY + yb_0 + r * 32 * a.RY;
+    uint4 bh[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (j < jcnt) {
-          const uint2 v0 = lds_tr(yrow + j * 32), v1 = lds_tr(yrow + j * 32 + 16 * a.RY);
-          bh[j] = uint4{v0.x, v0.y, v1.x, v1.y};
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < UPW; ++k) {
-        if (k < nmy) {
-          const uint2 a0 = lds_tr(sN + ab0 + tapoff[k]), a1 = lds_tr(sN + ab1 + tapoff[k]);
-          const uint4 af = uint4{a0.x, a0.y, a1.x, a1.y};
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (j < jcnt) acc[k][j] = mfma16(af, bh[j], acc[k][j]);
-        }
+    for (int j = 0; j < 4; ++j) {
+      if (j < jcnt) {
+        const uint2 v0 = lds_tr(yrow + j * 32), v1 = lds_tr(yrow + j * 32 + 16 * a.RY);
+        bh[j] = uint4{v0.x, v0.y, v1.x, v1.y};
       }
     }
-    if (more) store_tile((i + 1) & 1, cty * a.TH, ctx * TW);
+#pragma unroll
+    for (int k = 0; k < UPW; ++k) {
+      if (k < nmy) {
+        const uint2 a0 = lds_tr(sN + ab0_0 + r * astep + tapoff[k]), a1 = lds_tr(sN + ab1_0 + r * astep + tapoff[k]);
+        const uint4 af = uint4{a0.x, a0.y, a1.x, a1.y};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j < jcnt) acc[k][j] = mfma16(af, bh[j], acc[k][j]);
+      }
+    }
+  };
+  auto compute_tile = [&](int st) {
+    const unsigned char* sN = smem + (size_t)st * a.stage_bytes;
+    const unsigned char* sY = sN + a.nbytes;
+    kstep(sN, sY, 0); kstep(sN, sY, 1);
+    if (a.BM == 128) { kstep(sN, sY, 2); kstep(sN, sY, 3); }
+  };
+
+  if (dbg && tid == 0) m.stamps[(size_t)blockIdx.x * 8 + 1] = __builtin_amdgcn_s_memtime();
+  for (int grp = 0; grp < ntl; grp += D) {
+    if (dbg) t_a = __builtin_amdgcn_s_memtime();
+#pragma unroll
+    for (int t = 0; t < D; ++t) load_tile(t);
+    if (dbg) { t_b = __builtin_amdgcn_s_memtime(); t_ld += t_b - t_a; }
+#pragma unroll
+    for (int t = 0; t < D; ++t) {
+      if (grp + t < ntl) {
+        // stage t & 1 was last read by the tile two back; every wave has passed the barrier of the tile in between since
+        if (dbg) t_a = __builtin_amdgcn_s_memtime();
+        store_tile(t, t & 1);
+        if (dbg) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t_b = __builtin_amdgcn_s_memtime(); t_st += t_b - t_a; }
+        __syncthreads();
+        if (dbg) { t_a = __builtin_amdgcn_s_memtime(); t_bar += t_a - t_b; }
+        compute_tile(t & 1);
+        if (dbg) { asm volatile("" ::"v"(acc[0][0][0])); t_b = __builtin_amdgcn_s_memtime(); t_cp += t_b - t_a; }
+      }
+    }
+  }
+  if (dbg && tid == 0) {
+    unsigned long long* d = m.stamps + (size_t)blockIdx.x * 8;
+    d[2] = __builtin_amdgcn_s_memtime(); d[3] = t_ld; d[4] = t_st; d[5] = t_bar; d[6] = t_cp;
   }
 
   // ---- epilogue: this workgroup's slab ---------------------------------------------------------------------------------------
@@ -1077,23 +1128,45 @@ __global__ void __launch_bounds__(512, 2) conv_wgrad3_kernel(const Multi3Args m)
     }
   }
   if (a.ws_db != nullptr && (a.bias_mode == 1 || (a.bias_mode == 2 && blk == 0))) {
+    // within a wave by shuffles (lanes of equal lane % NQ hold the same 8 channels), across the 8 waves through LDS, in a
+    // fixed order (one thread per channel walking all 512 partials was 13-17 k cycles of dependent LDS reads)
     __syncthreads();                                    // every wave is past its last read of the stages
     float* sRed = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) sRed[tid * 8 + j] = bsum[j];
-    __syncthreads();
     if (a.bias_mode == 1) {
-      if (tid < a.NB) {                                 // thread t staged 8-channel item t % NQ
-        const int qc = tid >> 3, j = tid & 7;
-        float s = 0.f;
-        for (int k = qc; k < NT; k += NQ) s += sRed[k * 8 + j];
-        a.ws_db[((size_t)chunk * a.nblocks + blk) * a.NB + tid] = s;
+      for (int o = NQ; o < 64; o <<= 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bsum[j] += __shfl_xor(bsum[j], o);
       }
-    } else if (tid < 4) {
-      float s = 0.f;
-      for (int k = 0; k < NT; ++k) s += sRed[k * 8 + tid];
-      a.ws_db[(size_t)chunk * 4 + tid] = s;
+      if (lane < NQ) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sRed[wave * a.NB + lane * 8 + j] = bsum[j];
+      }
+      __syncthreads();
+      if (tid < a.NB) {
+        float s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s2 += sRed[w * a.NB + tid];
+        a.ws_db[((size_t)chunk * a.nblocks + blk) * a.NB + tid] = s2;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bsum[j] = wave_sum(bsum[j]);
+      if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sRed[wave * 4 + j] = bsum[j];
+      }
+      __syncthreads();
+      if (tid < 4) {
+        float s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s2 += sRed[w * 4 + tid];
+        a.ws_db[(size_t)chunk * 4 + tid] = s2;
+      }
     }
+  }
+  if (dbg) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) m.stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime();
   }
 }
 
@@ -1502,7 +1575,7 @@ static int wgrad2_groups(const hdrsky_wgrad_job* jobs, int njobs, bool* done, fl
 }
 
 // ---- v3 host side -------------------------------------------------------------------------------------------------------
-constexpr int WG3_WI = 2, WG3_NI = 2, WG3_UPW = 2;
+constexpr int WG3_UPW = 2;
 
 // 0: not for conv_wgrad3_kernel, 1: narrow input (Cin <= 8), 2: narrow output (Cout <= 4)
 static int wg3_kind(const hdrsky_wgrad_job& j) {
@@ -1552,22 +1625,35 @@ static int wg3_prepare(Wg3Args& a, const hdrsky_wgrad_job& j, int wg_target) {
   if (cdiv(a.nunits, 8) > WG3_UPW) return HDRSKY_EUNSUPPORTED;
   const int TW = a.Wk >= 32 ? 32 : 16;
   a.tw_shift = TW == 32 ? 5 : 4;
-  a.BM = (TW == 16 && a.Hk <= 4) ? 64 : 128;
-  a.TH = a.BM / TW;
+  // 128-pixel tiles, or 64 when that is what lets a thread hold ONE wide item and ONE narrow pixel per tile (the D = 4
+  // instantiations: four tiles' loads in flight) - the stride-2 layers, 64-channel blocks - and for 4-row maps
+  for (a.BM = (TW == 16 && a.Hk <= 4) ? 64 : 128;; a.BM = 64) {
+    a.TH = a.BM / TW;
+    a.HT = (a.TH - 1) * a.stride + a.KH;
+    a.WTn = (TW - 1) * a.stride + a.NFX * a.XPF;
+    a.npixn = a.HT * a.WTn;
+    a.deep = (cdiv(a.npixn, 512) <= 1 && cdiv(a.BM * a.NB / 8, 512) <= 1) ? 1 : 0;
+    if (a.deep || a.BM == 64) break;
+  }
+  if (!a.deep) {                                          // the 2-deep instantiation: up to two of each, 128-pixel tiles
+    a.BM = (TW == 16 && a.Hk <= 4) ? 64 : 128;
+    a.TH = a.BM / TW;
+    a.HT = (a.TH - 1) * a.stride + a.KH;
+    a.npixn = a.HT * a.WTn;
+    if (cdiv(a.npixn, 512) > 2 || cdiv(a.BM * a.NB / 8, 512) > 2) return HDRSKY_EUNSUPPORTED;
+  }
+  if (a.HT >= 256) return HDRSKY_EUNSUPPORTED;
   a.tiles_x = cdiv(a.Wk, TW); a.tiles_y = cdiv(a.Hk, a.TH);
   a.ntiles = a.B * a.tiles_x * a.tiles_y;
-  a.HT = (a.TH - 1) * a.stride + a.KH;
-  a.WTn = (TW - 1) * a.stride + a.NFX * a.XPF;
-  a.npixn = a.HT * a.WTn;
   a.wt_magic = ((1 << 24) + a.WTn - 1) / a.WTn;
-  if (cdiv(a.npixn, 512) > WG3_NI || cdiv(a.BM * a.NB / 8, 512) > WG3_WI || a.HT >= 256) return HDRSKY_EUNSUPPORTED;
   a.RY = (a.NB / 8 + 2) * 16;
   a.nbytes = roundup(a.npixn * a.CP * 2, 16);
   a.stage_bytes = a.nbytes + a.BM * a.RY;
   a.off_ss = 2 * a.stage_bytes;
   if (a.off_ss < 512 * 8 * 4) a.off_ss = 512 * 8 * 4;   // the bias reduction's scratch overlays the stages
   int chunks = wg_target / a.nblocks;
-  if (chunks > a.ntiles / 4) chunks = a.ntiles / 4;
+  const int mint = 512 / a.BM;                            // at least 512 pixels per workgroup
+  if (chunks > a.ntiles / mint) chunks = a.ntiles / mint;
   if (chunks < 1) chunks = 1;
   a.tiles_per_wg = cdiv(a.ntiles, chunks);
   a.nchunks = cdiv(a.ntiles, a.tiles_per_wg);
@@ -1579,8 +1665,10 @@ static int wg3_prepare(Wg3Args& a, const hdrsky_wgrad_job& j, int wg_target) {
   return lds;
 }
 
-static int wg3_launch(Multi3Args& m, int lds, hipStream_t stream) {
-  auto kern = conv_wgrad3_kernel<WG3_WI, WG3_NI, WG3_UPW>;
+// variant: 0 = D 4, four registers per narrow pixel; 1 = D 4, eight; 2 = D 2, two wide items + two narrow pixels per thread
+template <int D, int WI, int NI, int CPR>
+static int wg3_launch_as(Multi3Args& m, int lds, hipStream_t stream) {
+  auto kern = conv_wgrad3_kernel<D, WI, NI, CPR, WG3_UPW>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)
@@ -1591,23 +1679,36 @@ static int wg3_launch(Multi3Args& m, int lds, hipStream_t stream) {
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }
+static int wg3_launch(int variant, Multi3Args& m, int lds, hipStream_t stream) {
+  if (variant == 0) return wg3_launch_as<4, 1, 1, 4>(m, lds, stream);
+  if (variant == 1) return wg3_launch_as<4, 1, 1, 8>(m, lds, stream);
+  return wg3_launch_as<2, 2, 2, 8>(m, lds, stream);
+}
 
 // Launches (or, plan_only, sizes) the narrow-layer kernel + the shared reduce for the jobs it takes; marks them in done[].
 static int wgrad3_groups(const hdrsky_wgrad_job* jobs, int njobs, bool* done, float* ws, size_t ws_floats, size_t* ws_used,
                          bool plan_only, void* stream) {
   const int wg_each = getenv("HDRSKY_WGRAD3_WGS") ? atoi(getenv("HDRSKY_WGRAD3_WGS")) : 256;   // tuning hook: workgroups per layer
-  int members[256], nm = 0;
+  int all[256], na = 0, cls[256];
+  bool deep8 = false;
   for (int k = 0; k < njobs; ++k) {
     if (done[k]) continue;
     Wg3Args probe;
     if (wg3_prepare(probe, jobs[k], wg_each) < 0) continue;
-    members[nm++] = k;
+    cls[na] = probe.deep ? 0 : 2;
+    if (probe.deep && probe.CP == 8) deep8 = true;
+    all[na++] = k;
   }
+  for (int pass = 0; pass < 2; ++pass) {                  // the deep jobs of a call share a launch, the others another
+  int members[256], nm = 0;
+  for (int q = 0; q < na; ++q) if ((cls[q] == 2) == (pass == 1)) members[nm++] = all[q];
+  const int variant = pass == 1 ? 2 : (deep8 ? 1 : 0);
   for (int base = 0; base < nm; base += WG3_MAXJ) {
     const int cnt = nm - base < WG3_MAXJ ? nm - base : WG3_MAXJ;
     Multi3Args m3{};
     MultiArgs mr{};
     m3.njobs = mr.njobs = cnt;
+    m3.stamps = g_wg2_stamps;
     int lds = 0, blocks = 0, rblocks = 0, maxchunks = 1;
     for (int q = 0; q < cnt; ++q) {
       Wg3Args tmp;
@@ -1641,12 +1742,13 @@ static int wgrad3_groups(const hdrsky_wgrad_job* jobs, int njobs, bool* done, fl
     mr.rfirst[cnt] = rblocks;
     if (!plan_only) {
       if (*ws_used > ws_floats) return HDRSKY_EINVAL;
-      const int r = wg3_launch(m3, lds, (hipStream_t)stream);
+      const int r = wg3_launch(variant, m3, lds, (hipStream_t)stream);
       if (r != HDRSKY_OK) return r;
       hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(256), 0, (hipStream_t)stream, mr, 0, 0, S);
       HDRSKY_CHECK_LAUNCH();
     }
     for (int q = 0; q < cnt; ++q) done[members[base + q]] = true;
+  }
   }
   return HDRSKY_OK;
 }
