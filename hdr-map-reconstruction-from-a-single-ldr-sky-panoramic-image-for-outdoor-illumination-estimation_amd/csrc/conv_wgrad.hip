@@ -1471,14 +1471,16 @@ static int wg2_prepare(Wg2Args& a, const hdrsky_wgrad_job& j, int wg_target) {
   if (a.ns == 0) return HDRSKY_EUNSUPPORTED;
   if (a.xbytes > 16 * 4 * 1024 || ybytes > 6 * 4 * 1024) return HDRSKY_EUNSUPPORTED;   // slot registers: 16 + 6 pieces per loader wave
   if (a.WT >= 1024 || (a.TH - 1) * a.stride + rows_g >= 1024) return HDRSKY_EUNSUPPORTED;
-  // pixel split: what the launch's workgroup budget allows, but (a) at least eight tiles per workgroup - a workgroup's
-  // fixed cost (ring start-up, its partial slab) is a few tiles' worth, and a one-tile workgroup pipelines nothing - and
+  // pixel split: what the launch's workgroup budget allows, but (a) at least two tiles per workgroup (a one-tile workgroup
+  // pipelines nothing; eight - the first rule - left the encoder's stride-2 layers on 96 workgroups: 35 -> 30 us alone, step
+  // -0.5 %; every other call is bounded by its work share first) and
   // (b) at most ~34 MB of partial slabs per layer for the reduce launch to read back (measured, batch 32: 3x3 32->64 at
   // 16x64 split 256 ways = 15 us + 57 us of reduce; 3x3 128->128 at 8x32 split 64 ways = 17 + 21 us)
   const int base = a.cblocks * a.oblocks * a.ntg;
   int chunks = (wg_target + base / 2) / base;
   const long dw_bytes = (long)a.ntaps * a.Cin * a.Cout * 4;
-  if (chunks > a.ntiles / 8) chunks = a.ntiles / 8;
+  static const int mint = getenv("HDRSKY_WGRAD2_MINT") ? atoi(getenv("HDRSKY_WGRAD2_MINT")) : 2;   // A/B hook
+  if (chunks > a.ntiles / mint) chunks = a.ntiles / mint;
   if ((long)chunks * dw_bytes > (34L << 20)) chunks = (int)((34L << 20) / dw_bytes);
   if (chunks < 1) chunks = 1;
   if (chunks > a.ntiles) chunks = a.ntiles;

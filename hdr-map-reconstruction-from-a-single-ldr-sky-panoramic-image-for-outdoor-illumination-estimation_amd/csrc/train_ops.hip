@@ -854,36 +854,74 @@ __global__ void __launch_bounds__(256) act_bf16_kernel(const float* __restrict__
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                        float slope, uint4* __restrict__ y, int bps) {
   __shared__ float sSc[1024], sSh[1024];
+  __shared__ float sP[4096];
   const int b = blockIdx.x / bps, blk = blockIdx.x % bps;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float sc = 1.f, sh = 0.f;
-    if (mode == HDRSKY_IN_AFFINE) {
-      sc = scale[b * ss_bstride + c]; sh = shift[b * ss_bstride + c];
-    } else if (mode == HDRSKY_IN_PARTIALS) {
-      float s0, ss;
-      in_partial_sums(part + (size_t)b * nparts * 2 * C + c, nparts, C, s0, ss);
-      const float inv_count = 1.f / (float)HW;
-      const float mean = s0 * inv_count;
-      const float var = fmaxf(ss * inv_count - mean * mean, 0.f);
-      sc = gamma[c] / sqrtf(var + eps);
-      sh = beta[c] - mean * sc;
-    }
-    sSc[c] = sc; sSh[c] = sh;
-  }
-  __syncthreads();
   const int nq = C >> 3, nitems = HW * nq;
   const int per = (nitems + bps - 1) / bps;
   const int i1 = min(nitems, (blk + 1) * per);
   const float* xb = x + (size_t)b * HW * C;
   const bool xf = mode != HDRSKY_IN_NONE;
   constexpr int UNR = 4;                                   // items per thread in flight (all loads before the first use)
-  for (int i0 = blk * per + threadIdx.x; i0 < i1; i0 += 256 * UNR) {
-    float4 va[UNR], vb[UNR];
+  float4 va[UNR], vb[UNR];
+  int i0 = blk * per + threadIdx.x;
+  if (i0 < i1) {                                           // the first (normally only) round's loads fly under the table prologue
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int i = min(i0 + u * 256, i1 - 1);
       va[u] = *reinterpret_cast<const float4*>(xb + (size_t)i * 8);
       vb[u] = *reinterpret_cast<const float4*>(xb + (size_t)i * 8 + 4);
+    }
+  }
+  if (mode == HDRSKY_IN_PARTIALS && C <= 256) {
+    // the sample's tile partials ([tile][sum | squares][C], contiguous) go through LDS a chunk at a time - every thread
+    // copies, all loads in flight - and thread c adds its channel's entries in tile order: the same additions as
+    // in_partial_sums (bit-identical statistics), without a chain of nparts / 8 dependent global round trips in front of
+    // every block (64 tiles at 32x128: ~5 us, more than the block's own work)
+    const int pch = 2048 / C;
+    const float* pb = part + (size_t)b * nparts * 2 * C;
+    float s0 = 0.f, ss = 0.f;
+    for (int p0 = 0; p0 < nparts; p0 += pch) {
+      const int np = min(pch, nparts - p0), n = np * 2 * C;
+      for (int i = threadIdx.x; i < n; i += 256) sP[i] = pb[(size_t)p0 * 2 * C + i];
+      __syncthreads();
+      if ((int)threadIdx.x < C)
+        for (int k = 0; k < np; ++k) { s0 += sP[k * 2 * C + threadIdx.x]; ss += sP[k * 2 * C + C + threadIdx.x]; }
+      __syncthreads();
+    }
+    if ((int)threadIdx.x < C) {
+      const int c = threadIdx.x;
+      const float inv_count = 1.f / (float)HW;
+      const float mean = s0 * inv_count;
+      const float var = fmaxf(ss * inv_count - mean * mean, 0.f);
+      const float sc = gamma[c] / sqrtf(var + eps);
+      sSc[c] = sc; sSh[c] = beta[c] - mean * sc;
+    }
+  } else {
+    for (int c = threadIdx.x; c < C; c += 256) {
+      float sc = 1.f, sh = 0.f;
+      if (mode == HDRSKY_IN_AFFINE) {
+        sc = scale[b * ss_bstride + c]; sh = shift[b * ss_bstride + c];
+      } else if (mode == HDRSKY_IN_PARTIALS) {
+        float s0, ss;
+        in_partial_sums(part + (size_t)b * nparts * 2 * C + c, nparts, C, s0, ss);
+        const float inv_count = 1.f / (float)HW;
+        const float mean = s0 * inv_count;
+        const float var = fmaxf(ss * inv_count - mean * mean, 0.f);
+        sc = gamma[c] / sqrtf(var + eps);
+        sh = beta[c] - mean * sc;
+      }
+      sSc[c] = sc; sSh[c] = sh;
+    }
+  }
+  __syncthreads();
+  for (bool first = true; i0 < i1; i0 += 256 * UNR, first = false) {
+    if (!first) {
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int i = min(i0 + u * 256, i1 - 1);
+        va[u] = *reinterpret_cast<const float4*>(xb + (size_t)i * 8);
+        vb[u] = *reinterpret_cast<const float4*>(xb + (size_t)i * 8 + 4);
+      }
     }
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
@@ -1360,8 +1398,8 @@ int hdrsky_act_bf16(const float* x, int B, int HW, int C, int in_mode, const flo
   if (in_mode == HDRSKY_IN_AFFINE && (!in_scale || !in_shift)) return HDRSKY_EINVAL;
   if (in_mode == HDRSKY_IN_PARTIALS && (!in_part || !gamma || !beta || in_nparts <= 0)) return HDRSKY_EINVAL;
   if ((size_t)HW * (C >> 3) > 0x7fffffffu) return HDRSKY_EINVAL;
-  int bps = cdiv(HW * (C >> 3), 256 * 16);         // ~16 items per thread: the per-block affine table (a pass over the
-  if (bps < 1) bps = 1;                            // producer's partials) is a fixed cost worth amortising
+  int bps = cdiv(HW * (C >> 3), 256 * 4);          // ~4 items per thread, all in flight at once (16 behind a dependent-load
+  if (bps < 1) bps = 1;                            // prologue: 63 us for 17 MB on 128 blocks)
   hipLaunchKernelGGL(act_bf16_kernel, dim3(B * bps), dim3(256), 0, S_(stream), x, HW, C, in_mode, in_scale, in_shift, ss_bstride,
                      in_part, in_nparts, gamma, beta, eps, slope, (uint4*)y_bf16, bps);
   HDRSKY_CHECK_LAUNCH();
