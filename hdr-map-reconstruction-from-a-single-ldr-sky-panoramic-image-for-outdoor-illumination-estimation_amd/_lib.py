@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libhdrsky.so")
 c_int, c_float, c_void_p, c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 
 HDRSKY_BF16, HDRSKY_BF16X3 = 0, 1
+HDRSKY_EUNSUPPORTED = -2
 IN_NONE, IN_AFFINE, IN_PARTIALS = 0, 1, 2
 
 
@@ -123,6 +124,7 @@ SIGNATURES = {
     "hdrsky_blur3": (c_int, [P, c_int, c_int, c_int, c_int, c_float, c_int, P, P]),
     "hdrsky_dog_mid": (c_int, [P, c_int, c_int, c_int, c_int, c_float, P, P, P]),
     "hdrsky_dog_mid_bwd": (c_int, [P, c_int, c_int, c_int, c_int, P, P]),
+    "hdrsky_dog_loss": (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, P, P, P]),
     "hdrsky_l1": (c_int, [P, P, c_size_t, c_float, c_float, P, P, c_int, P]),
     "hdrsky_mse": (c_int, [P, c_float, c_size_t, c_float, c_float, P, P, P]),
     "hdrsky_kl": (c_int, [P, P, c_int, c_int, P, P, P]),

@@ -597,6 +597,209 @@ __global__ void dog_mid_bwd_kernel(const float* __restrict__ h, int B, int H, in
   }
 }
 
+
+// The whole DoG term - resize, base blur, five-level pyramid, L1, and the adjoint chain back to d y - in ONE launch: a workgroup
+// owns RB low-resolution rows of a sample (full width) and carries the chain through LDS, recomputing the few halo rows every
+// stage needs (up: +-5 high-resolution rows, base +-4, signs +-3, d base +-2, d up +-1).  The staged path above is seven
+// launches of 12-28 us each on the training step's critical chain - per-element passes that spend their time on index
+// arithmetic (64-bit divisions) and tap weights, not on their 6 MB of data.  Here a thread owns ONE COLUMN (pixel column x
+// channel) of the band: everything that depends on the column - neighbour offsets under REFLECT padding, the multiplicities
+// of the adjoint taps, the bilinear weights - is computed once, the row loop slides a three-row window down the column
+// (three LDS reads per element and stage instead of nine), and what depends on the row is wave-uniform.
+//   adjoint of a REFLECT-padded 3-tap filter along an axis of n points: point p collects from p-1, p, p+1 with the edge
+//   weight times m(p-1 -> p), where the neighbour at index 0 / n-1 counts twice for p = 1 / n-2 and the neighbours -1 / n
+//   do not exist (blur3_kernel's transpose branch, written as multiplicities).
+// Between the pyramid and its adjoint only the SIGNS of the four differences survive: one byte per element (2 bits each),
+// and sum_j G(s_j)^T h_j = sum_k sign(d_k) (G(s_k+1) - G(s_k))^T collapses, per tap type (centre / edge / corner), into a
+// 256-entry table indexed by that byte.  Same operators as the staged path; the fp32 summation order differs.
+struct DogArgs {
+  const float* y; const float* t; float* loss; float* dy;
+  int B, H, W, C, RB, nbands;
+  float weight;
+  int offB, offE, offS, offL;    // LDS byte offsets: buffer B, the low-resolution difference rows, the sign bytes, the tables
+};
+__global__ void __launch_bounds__(1024) dog_fused_kernel(const DogArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  float* bufA = reinterpret_cast<float*>(dsm);            // up, later d base
+  float* bufB = reinterpret_cast<float*>(dsm + g.offB);   // base, later d up
+  float* sE = reinterpret_cast<float*>(dsm + g.offE);
+  unsigned char* sS = dsm + g.offS;
+  float* sLut = reinterpret_cast<float*>(dsm + g.offL);   // [3 tap types][256 sign bytes]
+  const int tid = threadIdx.x, NT = 1024;
+  const int b = blockIdx.x / g.nbands, band = blockIdx.x - b * g.nbands;
+  const int H = g.H, W = g.W, C = g.C, H2 = 2 * H, W2 = 2 * W, RW = W2 * C, rw = W * C;
+  const int r0 = band * g.RB, r1 = min(H, r0 + g.RB);
+  const int Pd0 = max(0, 2 * r0 - 1), Pd1 = min(H2, 2 * r1 + 1);
+  const int Pb0 = max(0, Pd0 - 1), Pb1 = min(H2, Pd1 + 1);
+  const int Ps0 = max(0, Pb0 - 1), Ps1 = min(H2, Pb1 + 1);
+  const int Pa0 = max(0, Ps0 - 1), Pa1 = min(H2, Ps1 + 1);
+  const int Pu0 = max(0, Pa0 - 1), Pu1 = min(H2, Pa1 + 1);
+  int e0, e1;
+  { int lo, hi; float tt; axis2x(Pu0, H, lo, hi, tt); e0 = lo; axis2x(Pu1 - 1, H, lo, hi, tt); e1 = hi + 1; }
+  float ga[5], gc[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) gauss3(DOG_S[j], ga[j], gc[j]);
+  float ba, bc;
+  gauss3(1.2489996f, ba, bc);
+  const float inv_n = 1.f / (float)((size_t)g.B * H2 * W2 * C);
+
+  // ---- e = y - t on the low-resolution rows the band's resize reads; the sign-byte tables -----------------------------------
+  for (int i = tid; i < (e1 - e0) * rw; i += NT) {
+    const size_t k = (size_t)(b * H + e0) * rw + i;
+    sE[i] = g.y[k] - g.t[k];
+  }
+  if (tid < 256) {
+    float u[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float sg = (float)((tid >> (2 * k)) & 3) - 1.f;        // sign(d_k): field value 0 / 1 / 2
+      u[0] += sg * (gc[k + 1] * gc[k + 1] - gc[k] * gc[k]);         // centre tap
+      u[1] += sg * (ga[k + 1] * gc[k + 1] - ga[k] * gc[k]);         // edge
+      u[2] += sg * (ga[k + 1] * ga[k + 1] - ga[k] * ga[k]);         // corner
+    }
+    sLut[tid] = u[0]; sLut[256 + tid] = u[1]; sLut[512 + tid] = u[2];
+  }
+  // ---- the thread's column -------------------------------------------------------------------------------------------------
+  const bool act = tid < RW;
+  const int j = act ? tid : 0, X = j / C, c = j - X * C;
+  const int fxm = refl(X - 1, W2) * C + c, fxp = refl(X + 1, W2) * C + c;             // forward neighbours (REFLECT)
+  const int txm = max(X - 1, 0) * C + c, txp = min(X + 1, W2 - 1) * C + c;            // adjoint neighbours, multiplicities
+  const float mxm = X == 0 ? 0.f : (X == 1 ? 2.f : 1.f), mxp = X == W2 - 1 ? 0.f : (X == W2 - 2 ? 2.f : 1.f);
+  int exl, exh; float etx;
+  { int xlo, xhi; axis2x(X, W, xlo, xhi, etx); exl = xlo * C + c; exh = xhi * C + c; }
+  __syncthreads();
+
+  // ---- up = resize2x(e) ----------------------------------------------------------------------------------------------------------
+  if (act) {
+    for (int p = Pu0; p < Pu1; ++p) {
+      int ylo, yhi; float ty;
+      axis2x(p, H, ylo, yhi, ty);
+      const float* el = sE + (ylo - e0) * rw;
+      const float* eh = sE + (yhi - e0) * rw;
+      const float tl = el[exl], tr = el[exh], bl = eh[exl], br = eh[exh];
+      const float top = tl + (tr - tl) * etx, bot = bl + (br - bl) * etx;
+      bufA[(p - Pu0) * RW + j] = top + (bot - top) * ty;
+    }
+  }
+  __syncthreads();
+  // ---- base = G(1.2489996) up, REFLECT: per source row the pair (centre-row sum, edge-row sum) --------------------------------------
+  if (act) {
+    // blur = rows weighted (ba, bc, ba) of the horizontally blurred rows hb(r) = bc v0 + ba (vm + vp); r: reflected image row
+    auto hb = [&](int r) { const float* q = bufA + (r - Pu0) * RW; return bc * q[j] + ba * (q[fxm] + q[fxp]); };
+    float hp = hb(refl(Pa0 - 1, H2)), hm = hb(Pa0);
+    for (int p = Pa0; p < Pa1; ++p) {
+      const float hn = hb(refl(p + 1, H2));
+      bufB[(p - Pa0) * RW + j] = bc * hm + ba * (hp + hn);
+      hp = hm; hm = hn;
+    }
+  }
+  __syncthreads();
+  // ---- pyramid differences: loss and sign bytes --------------------------------------------------------------------------------------
+  float lacc = 0.f;
+  if (act) {
+    // per source row: its own value and the sum of its two horizontal neighbours
+    auto rowv = [&](int r, float& v0, float& vs) { const float* q = bufB + (r - Pa0) * RW; v0 = q[j]; vs = q[fxm] + q[fxp]; };
+    float t0, ts, m0, ms;
+    rowv(refl(Ps0 - 1, H2), t0, ts);
+    rowv(Ps0, m0, ms);
+    for (int p = Ps0; p < Ps1; ++p) {
+      float n0, ns;
+      rowv(refl(p + 1, H2), n0, ns);
+      const float centre = m0, edge = ms + t0 + n0, corner = ts + ns;
+      float bl[5];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) bl[k] = gc[k] * gc[k] * centre + ga[k] * gc[k] * edge + ga[k] * ga[k] * corner;
+      const bool own = p >= 2 * r0 && p < 2 * r1;
+      unsigned code = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float d = bl[k + 1] - bl[k];
+        if (own) lacc += fabsf(d);
+        code |= (d > 0.f ? 2u : (d < 0.f ? 0u : 1u)) << (2 * k);
+      }
+      sS[(p - Ps0) * RW + j] = (unsigned char)code;
+      t0 = m0; ts = ms; m0 = n0; ms = ns;
+    }
+  }
+  __syncthreads();
+  // ---- d base = sum_k sign(d_k) (G(s_k+1) - G(s_k))^T / n * weight -------------------------------------------------------------------
+  const float gpos = g.weight * inv_n;
+  if (act) {
+    // per source row r: what it contributes as the centre row (A) and as an edge row (Bv) of the adjoint stencil
+    auto rowv = [&](int r, float& A, float& Bv) {
+      const unsigned char* q = sS + (r - Ps0) * RW;
+      const unsigned c0 = q[j], cm = q[txm], cp = q[txp];
+      A = sLut[c0] + mxm * sLut[256 + cm] + mxp * sLut[256 + cp];
+      Bv = sLut[256 + c0] + mxm * sLut[512 + cm] + mxp * sLut[512 + cp];
+    };
+    float Bp = 0.f, Am, Bm, dA;
+    if (Pb0 > 0) rowv(Pb0 - 1, dA, Bp);
+    rowv(Pb0, Am, Bm);
+    for (int p = Pb0; p < Pb1; ++p) {
+      float An = 0.f, Bn = 0.f;
+      if (p + 1 < H2) rowv(p + 1, An, Bn);
+      const float mym = p == 0 ? 0.f : (p == 1 ? 2.f : 1.f), myp = p == H2 - 1 ? 0.f : (p == H2 - 2 ? 2.f : 1.f);
+      bufA[(p - Pb0) * RW + j] = gpos * (Am + mym * Bp + myp * Bn);
+      Bp = Bm; Am = An; Bm = Bn;
+    }
+  }
+  __syncthreads();
+  // ---- d up = G(1.2489996)^T d base ----------------------------------------------------------------------------------------------------
+  if (act) {
+    auto rowv = [&](int r) { const float* q = bufA + (r - Pb0) * RW; return bc * q[j] + ba * (mxm * q[txm] + mxp * q[txp]); };
+    float Rp = 0.f, Rm;
+    if (Pd0 > 0) Rp = rowv(Pd0 - 1);
+    Rm = rowv(Pd0);
+    for (int p = Pd0; p < Pd1; ++p) {
+      float Rn = 0.f;
+      if (p + 1 < H2) Rn = rowv(p + 1);
+      const float mym = p == 0 ? 0.f : (p == 1 ? 2.f : 1.f), myp = p == H2 - 1 ? 0.f : (p == H2 - 2 ? 2.f : 1.f);
+      bufB[(p - Pd0) * RW + j] = bc * Rm + ba * (mym * Rp + myp * Rn);
+      Rp = Rm; Rm = Rn;
+    }
+  }
+  __syncthreads();
+  // ---- d y += R^T d up  (up2x_bwd_kernel<1>, accumulate) --------------------------------------------------------------------------
+  for (int i = tid; i < (r1 - r0) * rw; i += NT) {
+    const int row = i / rw, jj = i - row * rw, ix = jj / C, cc = jj - ix * C, iy = r0 + row;
+    float wy[4], wx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int oy = 2 * iy - 1 + k, ox = 2 * ix - 1 + k;
+      wy[k] = 0.f; wx[k] = 0.f;
+      if (oy >= 0 && oy < H2) {
+        int lo, hi; float tt; axis2x(oy, H, lo, hi, tt);
+        wy[k] = (lo == iy ? 1.f - tt : 0.f) + (hi == iy ? tt : 0.f);
+      }
+      if (ox >= 0 && ox < W2) {
+        int lo, hi; float tt; axis2x(ox, W, lo, hi, tt);
+        wx[k] = (lo == ix ? 1.f - tt : 0.f) + (hi == ix ? tt : 0.f);
+      }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 4; ++kx) {
+        const float w = wy[ky] * wx[kx];
+        if (w != 0.f) s += w * bufB[(2 * iy - 1 + ky - Pd0) * RW + (2 * ix - 1 + kx) * C + cc];
+      }
+    float* o = g.dy + (size_t)(b * H + iy) * rw + jj;
+    o[0] = o[0] + s;
+  }
+  // ---- loss ----------------------------------------------------------------------------------------------------------------------
+  __shared__ float sblk[16];
+  lacc = wave_sum(lacc);
+  if ((tid & 63) == 0) sblk[tid >> 6] = lacc;
+  __syncthreads();
+  if (tid == 0 && g.loss) {
+    float t2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t2 += sblk[k];
+    atomicAdd(g.loss, t2 * inv_n);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // scalar losses with gradients
 // ------------------------------------------------------------------------------------------------------------
@@ -1271,6 +1474,36 @@ int hdrsky_dog_mid_bwd(const float* h, int B, int H, int W, int C, float* dbase,
   hipLaunchKernelGGL(dog_mid_bwd_kernel, dim3(grid_for((size_t)B * H * W * C)), dim3(256), 0, S_(stream), h, B, H, W, C, dbase);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
+}
+
+int hdrsky_dog_loss(const float* y, const float* t, int B, int H, int W, int C, float weight, float* loss, float* dy, void* stream) {
+  if (!y || !t || !dy || B <= 0 || H < 4 || W < 4 || C <= 0) return HDRSKY_EINVAL;
+  // a band of RB low-resolution rows needs (2 RB + 10) + (2 RB + 8) high-resolution rows of fp32, RB + 7 low-resolution ones
+  // and 2 RB + 6 rows of sign bytes in LDS
+  const int RW = 2 * W * C, rw = W * C;
+  if (RW > 1024) return HDRSKY_EUNSUPPORTED;               // a thread per (pixel column, channel) of a band
+  for (int RB = 4; RB >= 1; RB >>= 1) {
+    DogArgs g{};
+    g.offB = (2 * RB + 10) * RW * 4;
+    g.offE = g.offB + (2 * RB + 8) * RW * 4;
+    g.offL = g.offE + (RB + 7) * rw * 4;
+    g.offS = g.offL + 3 * 256 * 4;
+    const int lds = roundup(g.offS + (2 * RB + 6) * RW, 16);
+    if (lds > 160 * 1024 - 256) continue;                 // (+ the kernel's static words)
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(dog_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) !=
+          hipSuccess)
+        return HDRSKY_ELAUNCH;
+      attr_set = true;
+    }
+    g.y = y; g.t = t; g.loss = loss; g.dy = dy; g.B = B; g.H = H; g.W = W; g.C = C; g.RB = RB; g.nbands = cdiv(H, RB);
+    g.weight = weight;
+    hipLaunchKernelGGL(dog_fused_kernel, dim3(B * g.nbands), dim3(1024), lds, S_(stream), g);
+    HDRSKY_CHECK_LAUNCH();
+    return HDRSKY_OK;
+  }
+  return HDRSKY_EUNSUPPORTED;     // rows too long for a band in LDS: the staged path (up2x_fwd, blur3, dog_mid, ...)
 }
 
 int hdrsky_l1(const float* a, const float* b, size_t n, float wl, float wg, float* loss, float* da, int accumulate,

@@ -865,6 +865,13 @@ def dog_loss(y_lin, hdr_t, weight, loss_slot, dy_out):
     """loss_slot += weight * DoG-L1(y_lin, hdr_t) (tf_utils.py:61-73, train.py:316-322); dy_out += its gradient wrt y_lin."""
     lib = L.load()
     B, H, W, C = y_lin.shape
+    _f32(y_lin); _f32(hdr_t, B, H, W, C); _f32(dy_out, B, H, W, C)
+    if os.environ.get("HDRSKY_DOG_FUSED", "1") != "0":     # (the variable: an A/B hook)
+        rc = lib.hdrsky_dog_loss(_p(y_lin), _p(hdr_t), B, H, W, C, weight, _p(loss_slot), _p(dy_out), _stream())
+        if rc != L.HDRSKY_EUNSUPPORTED:
+            L.check(rc, "dog_loss")
+            return
+    # rows too long for the one-launch kernel's LDS bands (e.g. 128x512 maps): the staged path
     up = up2x(y_lin, hdr_t)
     base = blur3(up, DOG_SIGMA_BASE)
     h = torch.empty((5,) + tuple(base.shape), dtype=torch.float32, device=base.device)

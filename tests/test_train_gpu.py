@@ -38,6 +38,31 @@ def test_resize_adjoint_blur_adjoint_dog(dev):
     assert_close(dyo, ga, 0.5, "dog grad (max)")
 
 
+@pytest.mark.parametrize("shape", [(2, 8, 16, 3), (3, 32, 128, 3), (2, 5, 7, 3), (1, 4, 4, 1), (2, 9, 33, 2)])
+def test_dog_loss_one_launch_equals_the_staged_path(dev, shape, monkeypatch):
+    """hdrsky_dog_loss (the chain through LDS bands, one launch) against the seven staged launches it replaces (which
+    test_custom_ops_match_autograd pins to the oracle): the same operators - on the training size, on sizes whose bands are
+    clipped at both borders, one channel, and accumulating into a non-zero gradient."""
+    K = pkg("kernels")
+    rng = np.random.default_rng(5)
+    a = torch.from_numpy(rng.uniform(0, 3, shape).astype(np.float32)).to(dev)
+    b = torch.from_numpy(rng.uniform(0, 3, shape).astype(np.float32)).to(dev)
+    g0 = torch.from_numpy(rng.standard_normal(shape).astype(np.float32)).to(dev)
+    out = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("HDRSKY_DOG_FUSED", fused)
+        slot, dy = torch.zeros(1, device=dev), g0.clone()
+        K.dog_loss(a, b, 1000.0, slot, dy)
+        out[fused] = (float(slot), dy)
+    assert abs(out["1"][0] - out["0"][0]) <= 1e-5 * abs(out["0"][0])
+    ga, gb = out["1"][1] - g0, out["0"][1] - g0
+    assert float(gb.abs().max()) > 0
+    # the same operators in another fp32 summation order: round-off everywhere, and a sign(d) that flips where |d| ~ 0
+    # moves the few entries under that pixel's stencil by a visible amount
+    assert rel_rms(ga, gb) < 2e-2
+    assert_close(ga, gb, 0.5, "dog gradient, one launch vs staged (max)")
+
+
 def test_losses_softmax_bn_pool(dev):
     K = pkg("kernels")
     rng = np.random.default_rng(1)
