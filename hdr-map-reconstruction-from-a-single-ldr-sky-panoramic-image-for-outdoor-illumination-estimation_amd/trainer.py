@@ -465,9 +465,11 @@ class Trainer:
         sc2 = 1.0 if "s3" in t else 1.0 / ((h // 2) * (wd // 2))
         return K.grad_cam_maps([(t["A1"], sP1, 1.0 / (h * wd)), (t["A2"], sP2, sc2), (t["A3"], w3, s3)])
 
-    def _down_stack(self, net, params, x, training):
+    def _down_stack(self, net, params, x, training, update_moving=True):
         """downsampling x4 (discriminator.py:20-27 == sunrad_net.py:21-28).  Returns records for the backward pass:
-        training=True -> BN batch statistics (+ moving update), else the moving statistics as a constant affine."""
+        training=True -> BN batch statistics (+ moving update; update_moving=False leaves the moving statistics alone and
+        keeps the layer's statistics partials in the record - `_moving_update` applies them later, in program order),
+        else the moving statistics as a constant affine."""
         c, cp = self.conv, self.compute
         B = x.shape[0]
         R = {"in": x}
@@ -482,15 +484,26 @@ class Trainer:
                 if self.sync is not None:      # batch statistics over the batch of every replica
                     st = self.sync.gather_stats(st)
                 mean, rstd, sc, sh = K.bn_train_finalize(st, params[n + "gamma"], params[n + "beta"], st.part.shape[0], raw.shape[-1],
-                                                         params[n + "moving_mean"], params[n + "moving_variance"])
+                                                         params[n + "moving_mean"] if update_moving else None,
+                                                         params[n + "moving_variance"] if update_moving else None)
             else:
                 sc, sh = K.bn_eval_affine(params[n + "gamma"], params[n + "beta"], params[n + "moving_mean"],
                                           params[n + "moving_variance"])
                 mean = rstd = None
             R[d] = dict(x=cur, xf=xf, raw=raw, mean=mean, rstd=rstd, scale=sc, shift=sh)
+            if training and not update_moving:
+                R[d]["stats"] = st
             cur, xf = raw, InXf(mode=L.IN_AFFINE, slope=0.3, scale=sc, shift=sh)
         R["xf_out"] = xf
         return R
+
+    def _moving_update(self, net, params, R):
+        """The moving-statistics update of a `_down_stack(..., update_moving=False)` pass (the same launch on the same
+        partials: identical batch moments)."""
+        for d in ("d2", "d3", "d4"):
+            n, st = net + d + ".norm.", R[d]["stats"]
+            K.bn_train_finalize(st, params[n + "gamma"], params[n + "beta"], st.part.shape[0], R[d]["raw"].shape[-1],
+                                params[n + "moving_mean"], params[n + "moving_variance"])
 
     def _down_stack_bwd(self, net, params, grads, R, dact4, training, want_input_grad, do_wgrad=True):
         """Backward of _down_stack from the gradient wrt the ACTIVATED d4 output."""
@@ -722,10 +735,24 @@ class Trainer:
                 T["cams"] = self._gradcam(t, T["gt"])
             T["rad"] = self._sunrad_forward(T["ldr"], T["cams"], t, T)
 
+        # the discriminator's pass over the REAL pairs needs nothing the generator produces: it runs beside the forward
+        # pass, in the window stream 2 otherwise idles in (between the VGG target features and the perceptual term, ~0.45 ms)
+        # instead of inside the backward pass where all three streams are busy.  Its BatchNorm moving-statistics update waits
+        # for its place in the reference's program order (after the adversarial term's inference-mode call, in front of the
+        # generated pairs: train.py:302,360-361).  Measured: no gain - the forward pass it runs beside slows down by what the
+        # backward pass wins (2.77 ms either way) - so the default stays ONE batch of 2B in disc_step; HDRSKY_DISC_SPLIT=1
+        # selects the split (A/B hook, covered by tests/test_train_gpu.py)
+        split_disc = os.environ.get("HDRSKY_DISC_SPLIT", "0") == "1"
+
+        def zero_grads():
+            # (the two Dense kernels + biases, 201 of the 222 MB, are overwritten by their weight-gradient launches)
+            K.zero_(self.ds.grad); K.zero_(self.losses); K.zero_(self.gs.grad[:self.fc_grad_range()[0]])
+
+        if split_disc:            # disc_real accumulates into the zeroed buffers: they are cleared first
+            seg("zero", 0)(zero_grads)
+
         @seg("fwd_enc", 0)
         def _():
-            # (the two Dense kernels + biases, 201 of the 222 MB, are overwritten by their weight-gradient launches)
-            K.zero_(self.gs.grad[:self.fc_grad_range()[0]]); K.zero_(self.ds.grad); K.zero_(self.losses)
             ldr = T["ldr"]
             T["c1"], T["s1"] = c["gen.conv1_d"].fwd(ldr, compute=cp, want_stats=True)        # generator.py:92-108
             T["xf2"] = self._inxf(T["s1"], "gen.norm1_d", 0.1)
@@ -772,9 +799,30 @@ class Trainer:
             if early_head:
                 decode_head("u")
 
+        if not split_disc:
+            # nothing in the forward pass touches the gradient / loss buffers: they are cleared behind the encoder-decoder
+            # chain, while stream 0 waits for the sun branch, instead of in front of it (~35 us of the step's critical path)
+            seg("zero", 0)(zero_grads)
+
         @seg("vgg_target", 2)
         def _():
             T["vgg_tgt"] = self._vgg_target(T["hdr_t"])
+
+        if split_disc:
+            @seg("disc_real", 2, ["zero"])
+            def _():       # discriminator_in_step's real half (train.py:351-364): forward, loss, backward, weight gradients
+                cvo = c["dis.out"]
+                Rr = T["disc_real"] = self._down_stack("dis.", self.ds.w, K.concat2(T["ldr"], T["hdr_t"]), training=True,
+                                                       update_moving=False)
+                lg, _ = cvo.fwd(Rr["d4"]["raw"], Rr["xf_out"], cp)
+                dl = torch.empty_like(lg)
+                K.mse(lg, 1.0, 1.0, 0.5, self.losses[6:7], out=dl)
+                self._wg("dis.out", Rr["d4"]["raw"], Rr["xf_out"], dl)
+                da4 = cvo.dgrad(Rr["d4"]["raw"], dl, cp)
+                self._down_stack_bwd("dis.", self.ds.w, self.ds.g, Rr, da4, training=True, want_input_grad=False)
+                # its weight gradients are launched by disc_step: with them this segment outlasts the window (0.49 ms) and
+                # delays the perceptual term's second half, which the backward pass waits for
+                T["disc_real_wg"] = self._take_wgrads()
 
         @seg("fwd_blend", 0, ["fwd_sun"])
         def _():
@@ -838,9 +886,22 @@ class Trainer:
             T["dP3"] = K.fc_finalize(K.fc_dgrad(df1, self.fc1, cp)).reshape(B, h // 8, wd // 8, 128)
 
         # ------------------------------------------------------------------ discriminator step (train.py:351-380)
-        @seg("disc_step", 1, ["loss_adv"])
+        @seg("disc_step", 1, ["loss_adv", "disc_real"] if split_disc else ["loss_adv"])
         def _():       # real and generated pass as one batch of 2B (after the inference-mode call of loss_adv)
             cvo = c["dis.out"]
+            if split_disc:     # the generated half; the real half's moving-statistics update first (program order)
+                self._moving_update("dis.", self.ds.w, T["disc_real"])
+                if T["disc_real_wg"]:      # (a launch of its own: both halves accumulate into the same gradients)
+                    K.conv2d_wgrad_multi(T["disc_real_wg"])
+                Rf = self._down_stack("dis.", self.ds.w, K.concat2(T["ldr"], T["y_lin"]), training=True)
+                lg, _ = cvo.fwd(Rf["d4"]["raw"], Rf["xf_out"], cp)
+                dl = torch.empty_like(lg)
+                K.mse(lg, 0.0, 1.0, 0.5, self.losses[5:6], out=dl)      # generated (train.py:365)
+                self._wg("dis.out", Rf["d4"]["raw"], Rf["xf_out"], dl)
+                da4 = cvo.dgrad(Rf["d4"]["raw"], dl, cp)
+                self._down_stack_bwd("dis.", self.ds.w, self.ds.g, Rf, da4, training=True, want_input_grad=False)
+                self._flush_wgrads()
+                return
             x2 = torch.empty((2 * B,) + tuple(T["ldr"].shape[1:3]) + (6,), dtype=torch.float32, device=self.device)
             K.concat2(T["ldr"], T["hdr_t"], out=x2[:B]); K.concat2(T["ldr"], T["y_lin"], out=x2[B:])
             Rd = self._down_stack_pair("dis.", self.ds.w, x2)
@@ -1164,7 +1225,7 @@ class Trainer:
         saved = (getattr(self, "_T", None), getattr(self, "_segs", None), getattr(self, "_events", None))
         try:
             self._bind(ldr, hdr_t, sunpose_gt, cmf, cams)
-            self._execute(["fwd_sun", "fwd_enc", "vgg_target", "fwd_blend", "loss_main", "loss_vgg", "loss_vgg_b", "loss_adv"])
+            self._execute(["zero", "fwd_sun", "fwd_enc", "vgg_target", "fwd_blend", "loss_main", "loss_vgg", "loss_vgg_b", "loss_adv"])
             T, cvo = self._T, self.conv["dis.out"]
             for other, target, slot in ((hdr_t, 1.0, 6), (T["y_lin"], 0.0, 5)):        # train.py:351-369, training=False
                 R = self._down_stack("dis.", self.ds.w, K.concat2(ldr, other), training=False)

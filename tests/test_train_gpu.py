@@ -696,3 +696,34 @@ def test_train_step_at_a_size_outside_the_mfma_dense_tile(dev):
     for _ in range(2):
         tr.step(ldr.to(dev), hdr.to(dev), gt.to(dev), update=True)
     assert torch.isfinite(tr.gs.flat).all() and torch.isfinite(tr.ds.flat).all() and not torch.equal(w0, tr.gs.flat)
+
+
+def test_split_discriminator_passes_equal_the_paired_batch(dev, monkeypatch):
+    """HDRSKY_DISC_SPLIT=1: the discriminator's pass over the real pairs as a segment of its own beside the forward pass
+    (moving-statistics update deferred to its place in the program order), the generated pairs in disc_step - against the
+    default (both halves as one batch of 2B): same losses, same discriminator gradients (two weight-gradient launches add
+    in another order), same weights and BatchNorm moving statistics after two captured steps."""
+    params, synth, trainer, K = pkg("params"), pkg("synth"), pkg("trainer"), pkg("kernels")
+    mk = lambda: trainer.Trainer(params.init_params(params.generator_spec(), 0), params.init_params(params.sunpose_spec(), 1),
+                                 params.init_params(params.discriminator_spec(), 2), params.init_params(params.vgg_spec(), 3),
+                                 device=dev, precise=False, compute=K.BF16)
+    batch = synth.make_batch(4, seed=77)
+    ldr, hdr, gt = (torch.from_numpy(batch[k]).to(dev) for k in ("ldr", "hdr_t", "sunpose_gt"))
+    res = {}
+    for split in ("0", "1"):
+        monkeypatch.setenv("HDRSKY_DISC_SPLIT", split)
+        t = mk()
+        t.step(ldr, hdr, gt, update=False)
+        torch.cuda.synchronize()
+        names = [n for n, *_ in t._segs]
+        assert ("disc_real" in names) == (split == "1")
+        g, losses = t.ds.grad.clone(), t.losses.clone()
+        t.capture(ldr, hdr, gt)
+        for _ in range(2):
+            t.replay(update=True)
+        torch.cuda.synchronize()
+        res[split] = (g, losses, t.ds.flat.clone(), t.gs.flat.clone())
+    (g0, l0, d0, w0), (g1, l1, d1, w1) = res["0"], res["1"]
+    assert float((l0 - l1).abs().max()) <= 1e-5 * float(l0.abs().max()), (l0.tolist(), l1.tolist())
+    assert rel_max(g1, g0) < 2e-4
+    assert rel_max(d1, d0) < 1e-3 and rel_max(w1, w0) < 1e-3      # weights + moving statistics after two updates
