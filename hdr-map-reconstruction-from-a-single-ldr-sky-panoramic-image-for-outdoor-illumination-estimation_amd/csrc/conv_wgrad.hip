@@ -1654,7 +1654,10 @@ static int wg3_prepare(Wg3Args& a, const hdrsky_wgrad_job& j, int wg_target) {
   a.off_ss = 2 * a.stage_bytes;
   if (a.off_ss < 512 * 8 * 4) a.off_ss = 512 * 8 * 4;   // the bias reduction's scratch overlays the stages
   int chunks = wg_target / a.nblocks;
-  const int mint = 512 / a.BM;                            // at least 512 pixels per workgroup
+  static const int minpx = getenv("HDRSKY_WGRAD3_MINPX") ? atoi(getenv("HDRSKY_WGRAD3_MINPX")) : 256;   // A/B hook
+  // at least this many pixels per workgroup (512: the 4x4 stride-2 first layers ran on 64 workgroups - 26.7 -> 21.9 us at 256,
+  // the 512->1 head 18.6 -> 14.0; 128 is no better)
+  const int mint = minpx / a.BM > 0 ? minpx / a.BM : 1;
   if (chunks > a.ntiles / mint) chunks = a.ntiles / mint;
   if (chunks < 1) chunks = 1;
   a.tiles_per_wg = cdiv(a.ntiles, chunks);

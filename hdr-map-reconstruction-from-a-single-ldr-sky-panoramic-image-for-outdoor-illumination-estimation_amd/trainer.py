@@ -1046,12 +1046,11 @@ class Trainer:
             T["dx_enc"] = dx
             T["wq_res"] = self._take_wgrads()
 
-        # (stream 1, behind wg_dec: on stream 2 these launches queued behind bwd_sunpose / bwd_sunrad / wg_sunrad and the
-        # step ended 80 us later - per-segment timeline of the captured step, profiles/segment_timeline.py.  Other orders of
-        # the tail that were timed - the sun-radiance backward in front of the sun-pose backward with its weight gradients on
-        # stream 1, the Dense update at the end of stream 2, wg_res behind bwd_enc on stream 0, the discriminator step split
-        # into an early real half and a generated half - all lengthened the step: HDRSKY_WG_RES_STREAM is the A/B hook.)
-        @seg("wg_res", int(os.environ.get("HDRSKY_WG_RES_STREAM", "1")), ["bwd_res"])
+        # (stream 2, behind wg_sunrad.  While the weight gradients were slow this segment sat on stream 1 behind wg_dec: stream 2
+        # was the last to finish.  With the round-3 kernels stream 2 is done ~0.4 ms before the others and stream 1's tail - wg_dec,
+        # this, the Dense update - is what the optimizer segment waits for: here the step is 0.5 % shorter (2.755 against 2.770 ms,
+        # two runs each; the Dense update on stream 2 as well: 2.83).  HDRSKY_WG_RES_STREAM / HDRSKY_APPLY_FC_STREAM: A/B hooks.)
+        @seg("wg_res", int(os.environ.get("HDRSKY_WG_RES_STREAM", "2")), ["bwd_res"])
         def _():
             K.conv2d_wgrad_multi(T["wq_res"])
 

@@ -16,10 +16,14 @@ python3 $R/profiles/segment_timeline.py 2>&1 | grep -v amdgpu.ids > $O/segment_t
 python3 $R/profiles/microbench_wgrad2.py 2>&1 | grep -v amdgpu.ids > $O/microbench_wgrad2.txt
 python3 $R/profiles/microbench_wgrad2.py --group 2>&1 | grep -v amdgpu.ids >> $O/microbench_wgrad2.txt
 python3 $R/profiles/stamp_wgrad2.py 2>&1 | grep -v amdgpu.ids > $O/stamp_wgrad2.txt
+python3 $R/profiles/stamp_wgrad3.py 2>&1 | grep -v amdgpu.ids > $O/stamp_wgrad3.txt
+python3 $R/profiles/microbench_dog.py 2>&1 | grep -v amdgpu.ids > $O/microbench_dog.txt
+HDRSKY_DISC_SPLIT=1 python3 $R/profiles/segment_timeline.py 2>&1 | grep -v amdgpu.ids > $O/segment_timeline_disc_split.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_roof -o roof -- python3 $R/bench.py --roofline-only > $O/roofline_only.json 2> $O/prof_roof.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_train -o train -- python3 $R/bench.py --workload train --no-cpu-baseline --no-roofline-top --no-parity --steps 50 > $O/prof_train.json 2> $O/prof_train.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_fwd -o fwd -- python3 $R/bench.py --workload fwd --no-cpu-baseline --no-parity --steps 50 > $O/prof_fwd.json 2> $O/prof_fwd.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_hires_train -o hires_train -- python3 $R/bench.py --workload hires-train --steps 10 > $O/prof_hires_train.json 2> $O/prof_hires_train.log
+python3 $R/profiles/step_timeline.py $O/prof_train > $O/step_timeline.txt 2>&1
 # keep what travels back small: statistics only, no traces
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*.db" -delete
 ls $O
