@@ -465,7 +465,7 @@ class Trainer:
         sc2 = 1.0 if "s3" in t else 1.0 / ((h // 2) * (wd // 2))
         return K.grad_cam_maps([(t["A1"], sP1, 1.0 / (h * wd)), (t["A2"], sP2, sc2), (t["A3"], w3, s3)])
 
-    def _down_stack(self, net, params, x, training, update_moving=True):
+    def _down_stack(self, net, params, x, training, update_moving=True, eval_affine=None):
         """downsampling x4 (discriminator.py:20-27 == sunrad_net.py:21-28).  Returns records for the backward pass:
         training=True -> BN batch statistics (+ moving update; update_moving=False leaves the moving statistics alone and
         keeps the layer's statistics partials in the record - `_moving_update` applies them later, in program order),
@@ -487,8 +487,9 @@ class Trainer:
                                                          params[n + "moving_mean"] if update_moving else None,
                                                          params[n + "moving_variance"] if update_moving else None)
             else:
-                sc, sh = K.bn_eval_affine(params[n + "gamma"], params[n + "beta"], params[n + "moving_mean"],
-                                          params[n + "moving_variance"])
+                # (eval_affine: the inference-mode affines of the three layers, computed ahead of time by the caller)
+                sc, sh = eval_affine[d] if eval_affine is not None else K.bn_eval_affine(
+                    params[n + "gamma"], params[n + "beta"], params[n + "moving_mean"], params[n + "moving_variance"])
                 mean = rstd = None
             R[d] = dict(x=cur, xf=xf, raw=raw, mean=mean, rstd=rstd, scale=sc, shift=sh)
             if training and not update_moving:
@@ -747,6 +748,13 @@ class Trainer:
         def zero_grads():
             # (the two Dense kernels + biases, 201 of the 222 MB, are overwritten by their weight-gradient launches)
             K.zero_(self.ds.grad); K.zero_(self.losses); K.zero_(self.gs.grad[:self.fc_grad_range()[0]])
+            # the discriminator's inference-mode BatchNorm affines for the adversarial term (moving statistics as they stand
+            # at the start of the step: disc_step updates them later): three tiny launches that need nothing of this step, off
+            # the dependent chain
+            dw_ = self.ds.w
+            T["dis_eval_affine"] = {d: K.bn_eval_affine(dw_["dis.%s.norm.gamma" % d], dw_["dis.%s.norm.beta" % d],
+                                                        dw_["dis.%s.norm.moving_mean" % d], dw_["dis.%s.norm.moving_variance" % d])
+                                    for d in ("d2", "d3", "d4")}
 
         if split_disc:            # disc_real accumulates into the zeroed buffers: they are cleared first
             seg("zero", 0)(zero_grads)
@@ -836,8 +844,9 @@ class Trainer:
                      dyg=torch.empty_like(y_gamma))
 
         # ------------------------------------------------------------------ losses (train.py:301-331)
-        @seg("loss_main", 0)
-        def _():
+        # (L1 / DoG / KL are issued at the head of the adversarial term's segment: nothing waits for them alone, and every
+        # segment boundary on the dependent chain is a graph launch of its own, ~15 us of idle stream)
+        def loss_main():
             dyl = T["dyl"] = torch.empty_like(T["y_lin"])
             K.l1(T["y_lin"], T["hdr_t"], 1.0, 10.0, self.losses[3:4], da=dyl)                       # 10 * L1
             K.dog_loss(T["y_lin"], T["hdr_t"], 1000.0, self.losses[2:3], dyl)                       # 1000 * DoG
@@ -860,8 +869,10 @@ class Trainer:
 
         @seg("loss_adv", 0)
         def _():       # adversarial term: discriminator with inference-mode BN (train.py:302)
+            loss_main()
             cvo = c["dis.out"]
-            Rg = self._down_stack("dis.", self.ds.w, K.concat2(T["ldr"], T["y_lin"]), training=False)
+            Rg = self._down_stack("dis.", self.ds.w, K.concat2(T["ldr"], T["y_lin"]), training=False,
+                                  eval_affine=T["dis_eval_affine"])
             logits, _ = cvo.fwd(Rg["d4"]["raw"], Rg["xf_out"], cp)
             dlog = K.mse(logits, 1.0, 1.0, 1.0, self.losses[4:5])
             dact4 = cvo.dgrad(Rg["d4"]["raw"], dlog, cp)
@@ -879,8 +890,15 @@ class Trainer:
                 y, residual = T["dec_" + sfx][6], T["dec_" + sfx][7]
                 tails[sfx] = K.decoder_tail_bwd(y, residual, dy, want_dres=(sfx == "u"))
             T["dpre"] = K.sun_rad_bwd(t["cmf"], t["gmax"], T["gamma"], T["beta"], tails["u"][1], T["dcmf"], sync=self.sync)
-            if self.ext_sun:      # cmf is an input: its gradient (KL + sun-radiance path) has no consumer
-                return
+
+        # The sun-pose net's soft-max and Dense layers backwards (cmf is an input of a sunpose='external' step: no consumer).
+        # Nothing on the decoder / res-block / encoder chain reads their results - the sun-pose conv layers (stream 2), the Dense
+        # weight gradients and the Dense update (stream 1) do: in front of bwd_sunpose on stream 2 they are ~75 us (five launches,
+        # two of them streaming the 67 MB Dense image) that the dependent chain on stream 0 no longer waits for.
+        # HDRSKY_BWD_DENSE_STREAM=0: on stream 0 behind bwd_head, the old order (A/B hook)
+        @seg("bwd_dense", int(os.environ.get("HDRSKY_BWD_DENSE_STREAM", "2")), ["bwd_head"])
+        def _():
+            t = T["t"]
             dz = T["dz"] = K.softmax_bwd(t["cmf"], T["dcmf"], t["z"])       # KL + the sun-radiance path meet in dcmf
             df1 = T["df1"] = K.fc_finalize(K.fc_dgrad(dz, self.fc2, cp), None, relu=False, mask_src=t["f1"])
             T["dP3"] = K.fc_finalize(K.fc_dgrad(df1, self.fc1, cp)).reshape(B, h // 8, wd // 8, 128)
@@ -915,7 +933,7 @@ class Trainer:
             self._flush_wgrads()
 
         # ------------------------------------------------------------------ sun-pose conv layers (sunpose_net.py:54-62)
-        @seg("bwd_sunpose", 2, ["bwd_head"])
+        @seg("bwd_sunpose", 2, ["bwd_dense"])
         def _():
             t, dP = T["t"], T["dP3"]
             if self.da_sun:
@@ -1046,11 +1064,14 @@ class Trainer:
             T["dx_enc"] = dx
             T["wq_res"] = self._take_wgrads()
 
-        # (stream 2, behind wg_sunrad.  While the weight gradients were slow this segment sat on stream 1 behind wg_dec: stream 2
-        # was the last to finish.  With the round-3 kernels stream 2 is done ~0.4 ms before the others and stream 1's tail - wg_dec,
-        # this, the Dense update - is what the optimizer segment waits for: here the step is 0.5 % shorter (2.755 against 2.770 ms,
-        # two runs each; the Dense update on stream 2 as well: 2.83).  HDRSKY_WG_RES_STREAM / HDRSKY_APPLY_FC_STREAM: A/B hooks.)
-        @seg("wg_res", int(os.environ.get("HDRSKY_WG_RES_STREAM", "2")), ["bwd_res"])
+        # (stream 1, behind wg_dec.  Re-timed whenever the balance of the tail changed: stream 2 was better (-0.5 %) while the
+        # sun-pose Dense backward sat on the main chain; with that in front of bwd_sunpose on stream 2 (bwd_dense) stream 2 is the
+        # last side stream to finish again and this segment on stream 1 makes the step 1.3 % shorter (2.736 against 2.772 ms, two
+        # runs each).  Other orders of the tail that were timed - the sun-radiance backward in front of the sun-pose backward with
+        # its weight gradients on stream 1, the Dense update at the end of stream 2, wg_res behind bwd_enc on stream 0, the
+        # discriminator step split into an early real half and a generated half - all lengthened the step or changed nothing.
+        # HDRSKY_WG_RES_STREAM / HDRSKY_APPLY_FC_STREAM / HDRSKY_BWD_DENSE_STREAM: A/B hooks.)
+        @seg("wg_res", int(os.environ.get("HDRSKY_WG_RES_STREAM", "1")), ["bwd_res"])
         def _():
             K.conv2d_wgrad_multi(T["wq_res"])
 
@@ -1068,7 +1089,7 @@ class Trainer:
             self._flush_wgrads()
 
         # Materialised Dense weight gradients (skipped on an updating step of a fused_dense trainer, see _skip)
-        @seg("wg_dense", 1, ["bwd_head"])
+        @seg("wg_dense", 1, ["bwd_dense"])
         def _():
             if self.dense_wgrad_external:
                 return
@@ -1077,11 +1098,11 @@ class Trainer:
             fn(T["t"]["flat"], T["df1"], g["sun.fc1.kernel"], g["sun.fc1.bias"])
 
         # The two Dense layers hold 50.3 M of the 58.3 M parameters and nothing reads their weights or gradients after
-        # bwd_head: their RMSprop update and bf16 re-packing run here, beside the rest of the backward pass, instead of
+        # bwd_dense: their RMSprop update and bf16 re-packing run here, beside the rest of the backward pass, instead of
         # at the end of the step.  (Data-parallel: after the all-reduce of that slice / the all-gather of the operands.)
         # (stream 1, beside the backward chains: at the END of stream 0 or 2, where nothing compute-bound is left to overlap
         # its HBM stream with, the step is 1.3-1.7 % longer - HDRSKY_APPLY_FC_STREAM is the A/B hook)
-        @seg("apply_fc", int(os.environ.get("HDRSKY_APPLY_FC_STREAM", "1")), ["bwd_head", "wg_dense"])
+        @seg("apply_fc", int(os.environ.get("HDRSKY_APPLY_FC_STREAM", "1")), ["bwd_dense", "wg_dense"])
         def _():
             fc0, fc1 = self.fc_grad_range()
             if self.fused_dense:
@@ -1116,8 +1137,20 @@ class Trainer:
             K.rmsprop(self.ds.flat[:self.ds.ntrain], self.ds.grad, self.ds.ms, self.lr, gscale=gscale)
             self.repack(fc=False)
 
+        # HDRSKY_PLAN_MOVE="name=stream@after,...": scheduling experiments - segment `name` goes to `stream`, enqueued right
+        # behind segment `after` (dependencies are unchanged: only where it waits changes)
+        for ent in filter(None, os.environ.get("HDRSKY_PLAN_MOVE", "").split(",")):
+            name, rest = ent.split("=")
+            si, after = rest.split("@")
+            idx = [k for k, sg in enumerate(segs) if sg[0] == name]
+            if not idx or after not in [sg[0] for sg in segs]:
+                continue
+            sg = segs.pop(idx[0])
+            at = [k for k, q in enumerate(segs) if q[0] == after][0]
+            segs.insert(at + 1, (sg[0], int(si), sg[2], sg[3]))
+
         if self.ext_sun:          # no sun-pose net: its backward, Dense weight gradients and Dense optimizer segments go
-            gone = ("bwd_sunpose", "wg_dense", "apply_fc")
+            gone = ("bwd_dense", "bwd_sunpose", "wg_dense", "apply_fc")
             segs[:] = [(n, si, tuple(d for d in deps if d not in gone), fn) for n, si, deps, fn in segs if n not in gone]
         return segs
 
@@ -1130,7 +1163,7 @@ class Trainer:
     @property
     def FC_GRADS_READY(self):
         """Segment after which the Dense slice of the gradients (fused_dense: the operands of its contraction) exists."""
-        return "bwd_head" if self.fused_dense or self.dense_wgrad_external else "wg_dense"
+        return "bwd_dense" if self.fused_dense or self.dense_wgrad_external else "wg_dense"
 
     def _skip(self, update):
         """Segments an `update` / gradient-only step leaves out."""
@@ -1224,7 +1257,7 @@ class Trainer:
         saved = (getattr(self, "_T", None), getattr(self, "_segs", None), getattr(self, "_events", None))
         try:
             self._bind(ldr, hdr_t, sunpose_gt, cmf, cams)
-            self._execute(["zero", "fwd_sun", "fwd_enc", "vgg_target", "fwd_blend", "loss_main", "loss_vgg", "loss_vgg_b", "loss_adv"])
+            self._execute(["zero", "fwd_sun", "fwd_enc", "vgg_target", "fwd_blend", "loss_vgg", "loss_vgg_b", "loss_adv"])
             T, cvo = self._T, self.conv["dis.out"]
             for other, target, slot in ((hdr_t, 1.0, 6), (T["y_lin"], 0.0, 5)):        # train.py:351-369, training=False
                 R = self._down_stack("dis.", self.ds.w, K.concat2(ldr, other), training=False)
