@@ -194,6 +194,14 @@ class Trainer:
         for name, _, _ in P.VGG_CHANNELS:
             self.vgg_pk[name] = PackedConv(self.vgg[name + ".w"], pr)
             self.vgg_pkT[name] = PackedConv(self.vgg[name + ".w"], pr, transpose_flip=True)
+        # The preprocessing x*255 - mean (vgg16.py:133-141) rides in conv1_1's operand staging as a per-channel affine (SAME padding
+        # pads the PREPROCESSED image with zeros: so does the staging), its derivative 255 in conv1_1's data-gradient filter:
+        # two launches less per VGG pass on the perceptual term's critical path.  HDRSKY_VGG_FOLD=0: separate launches (A/B hook)
+        self._vgg_fold = os.environ.get("HDRSKY_VGG_FOLD", "1") != "0"
+        dev_ = self.vgg["conv1_1.w"].device
+        self._vgg_xf = InXf(mode=L.IN_AFFINE, slope=1.0, scale=torch.full((3,), 255.0, dtype=torch.float32, device=dev_),
+                            shift=torch.tensor([-103.939, -116.779, -123.68], dtype=torch.float32, device=dev_))
+        self._vgg_pkT255 = PackedConv(self.vgg["conv1_1.w"] * 255.0, pr, transpose_flip=True)
         self._make_packer()
 
     def _make_packer(self):
@@ -602,7 +610,7 @@ class Trainer:
     def _vgg_forward(self, x_gamma, keep):
         """pool1..3 of a gamma-domain BGR batch; `keep` collects what the backward pass re-reads."""
         cp = self.compute
-        x = K.vgg_pre(x_gamma)
+        x = x_gamma if self._vgg_fold else K.vgg_pre(x_gamma)
         pools = []
         # HDRSKY_BF16: the chain's activations live in bf16 (ReLU only, so they are final: the next conv would round them to
         # bf16 anyway - its result is bit-identical - and the fp32 input / output bursts of these launches halve); the
@@ -613,7 +621,8 @@ class Trainer:
                 if keep is not None:
                     keep[name + ".in"] = x
                 K.label("vgg." + name)
-                x, _ = K.conv2d(x, self.vgg_pk[name], self.vgg[name + ".b"], out_slope=0.0, compute=cp, out_bf16=b16)
+                x, _ = K.conv2d(x, self.vgg_pk[name], self.vgg[name + ".b"], out_slope=0.0, compute=cp, out_bf16=b16,
+                                xf=self._vgg_xf if (self._vgg_fold and name == "conv1_1") else None)
                 if keep is not None:
                     keep[name] = x
             if b16:
@@ -634,14 +643,19 @@ class Trainer:
         cp, B = self.compute, y_gamma.shape[0]
         acts = {}
         pools = self._vgg_forward(y_gamma, acts)
-        dps = []
-        for p, q in zip(pools, target_pools):   # 0.01 * sum_i mean|pool_i(pred) - pool_i(target)|, gradient wrt the prediction
-            dp = torch.empty_like(p)
-            K.l1(p, q, share, 0.01 * share, self.losses[1:2], da=dp)
-            dps.append(dp)
+        # 0.01 * sum_i mean|pool_i(pred) - pool_i(target)|, gradient wrt the prediction.  The L1 term of a block's pooled output is
+        # issued when the backward pass reaches that block and adds its gradient INTO the gradient arriving from the block above
+        # (fp32 there) - no separate gradient tensor + sum launch per block
         g = None
         for bi, blk in reversed(list(enumerate(self.VGG_BLOCKS))):
-            dp = dps[bi] if g is None else K.axpby(dps[bi], 1.0, g, 1.0)
+            if g is None or not self._vgg_fold:
+                dp = torch.empty_like(pools[bi])
+                K.l1(pools[bi], target_pools[bi], share, 0.01 * share, self.losses[1:2], da=dp)
+                if g is not None:
+                    dp = K.axpby(dp, 1.0, g, 1.0)
+            else:
+                K.l1(pools[bi], target_pools[bi], share, 0.01 * share, self.losses[1:2], da=g, accumulate=True)
+                dp = g
             b16 = acts[blk[-1]].dtype == torch.bfloat16     # bf16 chain: gradients between the data-gradient convs are final
             g = K.maxpool_relu_bwd(acts[blk[-1]], dp, out_bf16=b16)   # wrt the pre-ReLU output of the block's last conv
             for k in range(len(blk) - 1, -1, -1):
@@ -653,6 +667,9 @@ class Trainer:
                     g, _ = K.conv2d_dgrad(g, self.vgg_pkT[name], d, compute=cp, mask_bf16=acts[blk[k - 1]], mask_slope=0.0,
                                           out_bf16=True)
                     continue
+                if self._vgg_fold and name == "conv1_1":   # x 255 in the filter, straight into the caller's gradient slice
+                    g, _ = K.conv2d_dgrad(g, self._vgg_pkT255, d, compute=cp, out=out)
+                    return g
                 g, _ = K.conv2d_dgrad(g, self.vgg_pkT[name], d, compute=cp)   # wrt this conv's (post-ReLU) input
                 if k > 0:
                     g = K.affine_act_bwd(acts[blk[k - 1]], g, None, None, 0.0)
