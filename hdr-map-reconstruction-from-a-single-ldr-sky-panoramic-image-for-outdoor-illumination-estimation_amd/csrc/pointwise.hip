@@ -206,6 +206,9 @@ __global__ void __launch_bounds__(256) norm_act_bwd_kernel(const float* __restri
     }
   }
   const float* xb = x + (size_t)b * H * W * C + c;
+  // dy: fp32, or bf16 (bit 1 of the flag word) when it is the output of a data-gradient conv that nothing else reads
+  const bool dy16 = (dx_bf16 & 2) != 0;
+  dx_bf16 &= 1;
   // dx: fp32, or bf16 when its only readers are a data-gradient conv and a weight gradient (both round it to bf16 anyway)
   float* dxb = reinterpret_cast<float*>(dxv) + (size_t)b * H * W * C + c;
   unsigned short* dxh = reinterpret_cast<unsigned short*>(dxv) + (size_t)b * H * W * C + c;
@@ -220,6 +223,15 @@ __global__ void __launch_bounds__(256) norm_act_bwd_kernel(const float* __restri
   const int per = (nunits + S - 1) / S;
   const int u0 = sl_id * per, u1 = min(nunits, u0 + per);
   const float* dyb = dy + (size_t)b * nunits * C + c;
+  const unsigned short* dyh = reinterpret_cast<const unsigned short*>(dy) + (size_t)b * nunits * C + c;
+  auto get_dy = [&](size_t off) {
+    if (dy16) {
+      const uint2 u = *reinterpret_cast<const uint2*>(dyh + off);
+      return make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                         __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u));
+    }
+    return *reinterpret_cast<const float4*>(dyb + off);
+  };
 
   float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -246,7 +258,7 @@ __global__ void __launch_bounds__(256) norm_act_bwd_kernel(const float* __restri
 #pragma unroll 4
       for (int p = u0 + slot; p < u1; p += 64) {
         const float4 xv = *reinterpret_cast<const float4*>(xb + (size_t)p * C);
-        const float4 up = *reinterpret_cast<const float4*>(dyb + (size_t)p * C);
+        const float4 up = get_dy((size_t)p * C);
         const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
         const float us[4] = {up.x, up.y, up.z, up.w};
         float xh[4], g[4];
@@ -272,7 +284,7 @@ __global__ void __launch_bounds__(256) norm_act_bwd_kernel(const float* __restri
 #pragma unroll 2
       for (int pw = u0 + slot; pw < u1; pw += 64) {
         const int ph = pw / Wp, px = pw % Wp;
-        const float4 up = *reinterpret_cast<const float4*>(dyb + (size_t)pw * C);
+        const float4 up = get_dy((size_t)pw * C);
         const float us[4] = {up.x, up.y, up.z, up.w};
         float4 xv[4];
         float act[4][4], xh[4][4];

@@ -438,7 +438,8 @@ def norm_act_bwd(x, stats: Stats, gamma, beta, slope, dy, pooled, eps=IN_EPS, wa
     _f32(x)
     B, H, W, C = x.shape
     _f32(stats.part, B, stats.nparts, 2, C)
-    _f32(dy, B, H // 2 if pooled else H, W // 2 if pooled else W, C)
+    # dy: fp32, or bf16 (the output of a data-gradient conv that nothing else reads: out_bf16 of conv2d_dgrad)
+    (_bf16 if dy.dtype == torch.bfloat16 else _f32)(dy, B, H // 2 if pooled else H, W // 2 if pooled else W, C)
     # out_bf16: dx only feeds a data-gradient conv / a weight gradient, which round it to bf16 anyway (HDRSKY_BF16 mode)
     dx = torch.empty(x.shape, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
     if sums is not None:
@@ -449,7 +450,7 @@ def norm_act_bwd(x, stats: Stats, gamma, beta, slope, dy, pooled, eps=IN_EPS, wa
     S = L.load().hdrsky_norm_act_bwd_nslices(B, H, W, C, int(pooled))
     ws = torch.empty((B, S, 2, C), dtype=torch.float32, device=x.device) if S > 1 else None
     L.check(L.load().hdrsky_norm_act_bwd(_p(x), _p(stats.part), stats.nparts, _p(_f32(gamma, C)), _p(_f32(beta, C)),
-                                         eps, slope, _p(dy), int(pooled), _p(dx), int(out_bf16), _p(sums), _p(dgamma),
+                                         eps, slope, _p(dy), int(pooled), _p(dx), int(out_bf16) | (2 if dy.dtype == torch.bfloat16 else 0), _p(sums), _p(dgamma),
                                          _p(dbeta), _p(ws), B, H, W, C, _stream()),
             "norm_act_bwd")
     return (dx, sums) if want_sums else dx

@@ -85,11 +85,12 @@ class _Conv:
         return K.wgrad_job(x, dy, self.kh, self.kw, gw, gb, stride=self.stride, same=self.same, upsample=self.upsample,
                            xf=xf, compute=compute)
 
-    def dgrad(self, x, dy, compute, residual=None, want_stats=False, out=None):
-        """Gradient wrt the (transformed, pre-resize) conv operand."""
+    def dgrad(self, x, dy, compute, residual=None, want_stats=False, out=None, out_bf16=False):
+        """Gradient wrt the (transformed, pre-resize) conv operand.  out_bf16: stored as bf16 (a gradient whose only reader is
+        the InstanceNorm backward, kernels.norm_act_bwd)."""
         K.label(self.wkey + " (data gradient)")
         d, st = K.conv2d_dgrad(dy, self.pkT, self.desc(x), residual=None if self.upsample == 2 else residual,
-                               compute=compute, want_stats=want_stats)
+                               compute=compute, want_stats=want_stats, out_bf16=out_bf16 and self.upsample != 2)
         if self.upsample == 2:
             d = K.up2x_bwd(d, 1.0, out=out)
         return (d, st) if want_stats else d
@@ -604,6 +605,12 @@ class Trainer:
         """Final activations of ReLU / LeakyReLU-only stretches are stored as bf16 (HDRSKY_BF16 mode; HDRSKY_VGG_BF16=0: A/B hook)."""
         return self.compute == BF16 and not self.precise and os.environ.get("HDRSKY_VGG_BF16", "1") != "0"
 
+    def _nab_bf16(self):
+        """Gradients that go from a data-gradient conv straight into an InstanceNorm backward (and nowhere else) travel as
+        bf16 in the single-product mode: the norm backward's output is stored as bf16 anyway, and its two passes over this
+        tensor are half as long (HDRSKY_NAB_DY_BF16=0: A/B hook)."""
+        return self._act_bf16() and os.environ.get("HDRSKY_NAB_DY_BF16", "1") != "0"
+
     def _deconv_mat(self):
         return not self.precise and K.deconv_materialised(self.compute)
 
@@ -963,11 +970,11 @@ class Trainer:
                     continue
                 dr2 = self._in_bwd(t["r%db" % l], t["st%db" % l], n + ".norm2", 0.0, dP, pooled=True)
                 self._wg(n + ".conv2", t["r%da" % l], t["xf%d" % l], dr2)
-                da = c[n + ".conv2"].dgrad(t["r%da" % l], dr2, cp)
+                da = c[n + ".conv2"].dgrad(t["r%da" % l], dr2, cp, out_bf16=self._nab_bf16())
                 dr1 = self._in_bwd(t["r%da" % l], t["st%da" % l], n + ".norm1", 0.0, da)
                 self._wg(n + ".conv1", t["in%d" % l], None, dr1)
                 if l > 1:
-                    dP = c[n + ".conv1"].dgrad(t["in%d" % l], dr1, cp)
+                    dP = c[n + ".conv1"].dgrad(t["in%d" % l], dr1, cp, out_bf16=self._nab_bf16())
             self._norm_grads("bwd_sunpose", B)
             self._flush_wgrads()
 
@@ -992,7 +999,7 @@ class Trainer:
                 d3, s3, xf2, d2, s2, xf1, y, residual, u3, u2 = T["dec_" + sfx]
                 dc = T["tails"][sfx][0]
                 self._wg("gen.conv1_" + sfx, d2, xf1, dc)
-                da2 = c["gen.conv1_" + sfx].dgrad(d2, dc, cp)
+                da2 = c["gen.conv1_" + sfx].dgrad(d2, dc, cp, out_bf16=self._nab_bf16())
                 dd2 = self._in_bwd(d2, s2, "gen.norm2_" + sfx, 0.1, da2)
                 if u2 is not None:       # weight gradients on the materialised (bf16, already resized) operands
                     self._wg_plain("gen.conv2_" + sfx, u2, dd2)
@@ -1096,10 +1103,10 @@ class Trainer:
         def _():       # encoder head (generator.py:92-108)
             dc3 = self._in_bwd(T["c3"], T["s3"], "gen.norm3_d", 0.1, T["dx_enc"])
             self._wg("gen.conv3_d", T["c2"], T["xf3"], dc3)
-            da2 = c["gen.conv3_d"].dgrad(T["c2"], dc3, cp)
+            da2 = c["gen.conv3_d"].dgrad(T["c2"], dc3, cp, out_bf16=self._nab_bf16())
             dc2 = self._in_bwd(T["c2"], T["s2"], "gen.norm2_d", 0.1, da2)
             self._wg("gen.conv2_d", T["c1"], T["xf2"], dc2)
-            da1 = c["gen.conv2_d"].dgrad(T["c1"], dc2, cp)
+            da1 = c["gen.conv2_d"].dgrad(T["c1"], dc2, cp, out_bf16=self._nab_bf16())
             dc1 = self._in_bwd(T["c1"], T["s1"], "gen.norm1_d", 0.1, da1)
             self._wg("gen.conv1_d", T["ldr"], None, dc1)
             self._norm_grads("bwd_enc", B)

@@ -40,7 +40,7 @@ def test_norm_apply(dev, shape, pool):
     assert_close(y, ref, 1e-4, "norm_apply")
 
 
-@pytest.mark.parametrize("shape", [(2, 16, 64, 64), (2, 8, 32, 128)])
+@pytest.mark.parametrize("shape", [(2, 16, 64, 64), (2, 8, 32, 128), (3, 32, 128, 32)])
 @pytest.mark.parametrize("pooled", [False, True])
 def test_norm_act_bwd(dev, shape, pooled):
     K = pkg("kernels")
@@ -58,6 +58,13 @@ def test_norm_act_bwd(dev, shape, pooled):
     (gx,) = torch.autograd.grad(y, xt, torch.from_numpy(dy))
     got = K.norm_act_bwd(xr, st, d(gam), d(bet), 0.0, d(dy), pooled)
     assert_close(got, gx, 2e-4, "norm_act_bwd")
+    # the incoming gradient handed over as a bf16 tensor (a data-gradient conv's bf16 output): the same bits as the fp32
+    # tensor holding those values, on one-launch and two-launch (reduce + apply) sizes, fp32 and bf16 output
+    dyb = d(dy).to(torch.bfloat16)
+    for out_bf16 in (False, True):
+        a = K.norm_act_bwd(xr, st, d(gam), d(bet), 0.0, dyb, pooled, out_bf16=out_bf16)
+        b = K.norm_act_bwd(xr, st, d(gam), d(bet), 0.0, dyb.float(), pooled, out_bf16=out_bf16)
+        assert a.dtype == b.dtype and torch.equal(a, b)
 
 
 def test_norm_act_bwd_pool_routing_tight_off_the_tie_channels(dev):
