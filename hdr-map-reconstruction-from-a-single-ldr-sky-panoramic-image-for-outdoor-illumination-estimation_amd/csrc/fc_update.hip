@@ -59,7 +59,13 @@ __global__ void __launch_bounds__(256) fc_operands_kernel(OperandJob jx, Operand
   j.dst[((size_t)(c >> 5) * (Mpad >> 3) + mg) * 32 + (c & 31)] = hi;
   if (j.colsum && mg == 0) {
     float s = 0.f;
-    for (int m = 0; m < M; ++m) s += j.src[(size_t)m * j.ld + c];
+    for (int m0 = 0; m0 < M; m0 += 8) {       // row order kept; eight rows' loads in flight (one per trip: M dependent round trips)
+      float r8[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) r8[k] = j.src[(size_t)min(m0 + k, M - 1) * j.ld + c];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) if (m0 + k < M) s += r8[k];
+    }
     j.colsum[c] = j.accumulate ? j.colsum[c] + s : s;
   }
 }

@@ -887,6 +887,38 @@ __global__ void __launch_bounds__(256) softmax_bwd_kernel(const float* __restric
     dz[row + n] = z[row + n] > 0.f ? cmf[row + n] * (dcmf[row + n] - dot) : 0.f;
 }
 
+// the same with the row in registers: 1024 threads x RV 16-byte groups (N <= 4096 RV), both passes from one set of loads - a
+// 4096-bin row on 256 threads was two passes of 16 dependent trips on 32 blocks: 14 us for 1.5 MB
+template <int RV>
+__global__ void __launch_bounds__(1024) softmax_bwd_vec_kernel(const float4* __restrict__ cmf, const float4* __restrict__ dcmf,
+                                                               const float4* __restrict__ z, int n4, float4* __restrict__ dz) {
+  __shared__ float sred[16];
+  const size_t row = (size_t)blockIdx.x * n4;
+  float4 c[RV], d[RV], zz[RV];
+  float s = 0.f;
+#pragma unroll
+  for (int r = 0; r < RV; ++r) {
+    const int q = threadIdx.x + r * 1024;
+    if (q < n4) {
+      c[r] = cmf[row + q]; d[r] = dcmf[row + q]; zz[r] = z[row + q];
+      s += (d[r].x * c[r].x + d[r].y * c[r].y) + (d[r].z * c[r].z + d[r].w * c[r].w);
+    }
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = s;
+  __syncthreads();
+  float dot = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) dot += sred[w];
+#pragma unroll
+  for (int r = 0; r < RV; ++r) {
+    const int q = threadIdx.x + r * 1024;
+    if (q < n4)
+      dz[row + q] = make_float4(zz[r].x > 0.f ? c[r].x * (d[r].x - dot) : 0.f, zz[r].y > 0.f ? c[r].y * (d[r].y - dot) : 0.f,
+                                zz[r].z > 0.f ? c[r].z * (d[r].z - dot) : 0.f, zz[r].w > 0.f ? c[r].w * (d[r].w - dot) : 0.f);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // blend / decoder tail / sun radiance backward
 // ------------------------------------------------------------------------------------------------------------
@@ -918,7 +950,7 @@ __global__ void decoder_tail_bwd_kernel(const float* __restrict__ y, const float
 
 // Backward of hdrsky_sun_rad.  One block per sample: d rad_gamma3 [B,P,3] ->
 //   dpre[b][0..1] = d(pre-sigmoid gamma, beta),  dx[b][p] = dL/d(cmf/gmax),  dotx[b] = sum_p dx*cmf  (for the max term)
-__global__ void __launch_bounds__(256) sun_rad_bwd_kernel(const float* __restrict__ cmf, const unsigned int* gmax_bits,
+__global__ void __launch_bounds__(1024) sun_rad_bwd_kernel(const float* __restrict__ cmf, const unsigned int* gmax_bits,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* __restrict__ drg3, int P, float* __restrict__ dx,
                                                           float* __restrict__ dpre, float* __restrict__ dotx, int n,
@@ -926,15 +958,17 @@ __global__ void __launch_bounds__(256) sun_rad_bwd_kernel(const float* __restric
   // S == 1: block = sample (the 32x128 maps).  S > 1: block = (sample, pixel slice) - a 128x512 map is 65 536 pixels and one
   // block per sample was 8 blocks on 256 CUs (293 us per call) -, partial sums to part[b][s][3], summed in slice order by
   // sun_rad_bwd_fin_kernel
-  __shared__ float sred[3][4];
+  // (256 or 1024 threads: a 4096-pixel slice on 256 threads was 16 dependent trips per thread on 32 blocks, 20 us)
+  __shared__ float sred[3][16];
   const int b = blockIdx.x / S, sl = blockIdx.x % S;
   const int per = (P + S - 1) / S;
   const int p0 = sl * per, p1 = min(P, p0 + per);
+  const int NTH = blockDim.x, nw = NTH >> 6;
   const float gmax = __uint_as_float(*gmax_bits);
   const float g = gamma[b], bt = beta[b];
   const float D = bt * 1.7724539f + 1e-5f, be = bt + 1e-5f;
   float sg = 0.f, sb = 0.f, sd = 0.f;
-  for (int p = p0 + threadIdx.x; p < p1; p += 256) {
+  for (int p = p0 + threadIdx.x; p < p1; p += NTH) {
     const size_t i = (size_t)b * P + p;
     const float x = cmf[i] / gmax;
     const float d1 = 1.f - x;
@@ -960,9 +994,8 @@ __global__ void __launch_bounds__(256) sun_rad_bwd_kernel(const float* __restric
   if ((threadIdx.x & 63) == 0) { sred[0][threadIdx.x >> 6] = sg; sred[1][threadIdx.x >> 6] = sb; sred[2][threadIdx.x >> 6] = sd; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const float tg = (sred[0][0] + sred[0][1]) + (sred[0][2] + sred[0][3]);
-    const float tb = (sred[1][0] + sred[1][1]) + (sred[1][2] + sred[1][3]);
-    const float td = (sred[2][0] + sred[2][1]) + (sred[2][2] + sred[2][3]);
+    float tg = 0.f, tb = 0.f, td = 0.f;
+    for (int w = 0; w < nw; ++w) { tg += sred[0][w]; tb += sred[1][w]; td += sred[2][w]; }
     if (S == 1) {
       dpre[b * 2 + 0] = tg * g * (1.f - g);
       dpre[b * 2 + 1] = tb * bt * (1.f - bt);
@@ -1022,11 +1055,20 @@ __global__ void dense_heads_bwd_kernel(const float* __restrict__ x, const float*
     const int c = i % C;
     const float wg = kg[i], wb = kb[i];
     float ag = 0.f, ab = 0.f;
-    for (int b = 0; b < B; ++b) {
-      const float v = x[(size_t)b * F + i];
-      const float f = leaky(scale ? v * scale[c] + shift[c] : v, slope);
-      ag += dpre[b * 2] * f; ab += dpre[b * 2 + 1] * f;
-      dact[(size_t)b * F + i] = dpre[b * 2] * wg + dpre[b * 2 + 1] * wb;
+    const float sc = scale ? scale[c] : 1.f, sh = scale ? shift[c] : 0.f;
+    for (int b0 = 0; b0 < B; b0 += 8) {       // eight samples' loads in flight (one per trip was a chain of B round trips: 33 us)
+      float v8[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v8[k] = x[(size_t)min(b0 + k, B - 1) * F + i];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int b = b0 + k;
+        if (b < B) {
+          const float f = leaky(scale ? v8[k] * sc + sh : v8[k], slope);
+          ag += dpre[b * 2] * f; ab += dpre[b * 2 + 1] * f;
+          dact[(size_t)b * F + i] = dpre[b * 2] * wg + dpre[b * 2 + 1] * wb;
+        }
+      }
     }
     dkg[i] += ag; dkb[i] += ab;
     if (i == 0) {
@@ -1562,6 +1604,16 @@ int hdrsky_kl(const float* gt, const float* cmf, int B, int N, float* loss, floa
 
 int hdrsky_softmax_bwd(const float* cmf, const float* dcmf, const float* z, int M, int N, float* dz, void* stream) {
   if (!cmf || !dcmf || !z || !dz) return HDRSKY_EINVAL;
+  if ((N & 3) == 0 && N <= 16384 && ((((uintptr_t)cmf | (uintptr_t)dcmf | (uintptr_t)z | (uintptr_t)dz) & 15) == 0)) {
+    if (N <= 4096)
+      hipLaunchKernelGGL((softmax_bwd_vec_kernel<1>), dim3(M), dim3(1024), 0, S_(stream), (const float4*)cmf, (const float4*)dcmf,
+                         (const float4*)z, N / 4, (float4*)dz);
+    else
+      hipLaunchKernelGGL((softmax_bwd_vec_kernel<4>), dim3(M), dim3(1024), 0, S_(stream), (const float4*)cmf, (const float4*)dcmf,
+                         (const float4*)z, N / 4, (float4*)dz);
+    HDRSKY_CHECK_LAUNCH();
+    return HDRSKY_OK;
+  }
   hipLaunchKernelGGL(softmax_bwd_kernel, dim3(M), dim3(256), 0, S_(stream), cmf, dcmf, z, N, dz);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
@@ -1598,8 +1650,8 @@ int hdrsky_sun_rad_bwd_reduce(const float* cmf, const void* gmax_bits, const flo
   hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, S_(stream), (unsigned*)claimed, (size_t)1);   // (see hdrsky_zero)
   const int S = hdrsky_sun_rad_bwd_slices(P);
   float* part = dotx + B + 4;                       // behind the record (dotx[B], tie count): 3 * B * S floats
-  hipLaunchKernelGGL(sun_rad_bwd_kernel, dim3(B * S), dim3(256), 0, S_(stream), cmf, (const unsigned int*)gmax_bits, gamma, beta,
-                     drg3, P, dx, dpre, dotx, B * P, claimed, S, part);
+  hipLaunchKernelGGL(sun_rad_bwd_kernel, dim3(B * S), dim3(P / S >= 2048 ? 1024 : 256), 0, S_(stream), cmf,
+                     (const unsigned int*)gmax_bits, gamma, beta, drg3, P, dx, dpre, dotx, B * P, claimed, S, part);
   if (S > 1) hipLaunchKernelGGL(sun_rad_bwd_fin_kernel, dim3(B), dim3(64), 0, S_(stream), part, S, gamma, beta, dpre, dotx);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
