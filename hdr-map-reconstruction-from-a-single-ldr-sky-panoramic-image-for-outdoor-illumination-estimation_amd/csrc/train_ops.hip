@@ -615,6 +615,7 @@ __global__ void dog_mid_bwd_kernel(const float* __restrict__ h, int B, int H, in
 struct DogArgs {
   const float* y; const float* t; float* loss; float* dy;
   int B, H, W, C, RB, nbands;
+  int SW, nstrips;               // low-resolution columns per workgroup, strips per row band (1: full width)
   float weight;
   int offB, offE, offS, offL;    // LDS byte offsets: buffer B, the low-resolution difference rows, the sign bytes, the tables
 };
@@ -626,9 +627,18 @@ __global__ void __launch_bounds__(1024) dog_fused_kernel(const DogArgs g) {
   unsigned char* sS = dsm + g.offS;
   float* sLut = reinterpret_cast<float*>(dsm + g.offL);   // [3 tap types][256 sign bytes]
   const int tid = threadIdx.x, NT = 1024;
-  const int b = blockIdx.x / g.nbands, band = blockIdx.x - b * g.nbands;
-  const int H = g.H, W = g.W, C = g.C, H2 = 2 * H, W2 = 2 * W, RW = W2 * C, rw = W * C;
+  const int strip = blockIdx.x % g.nstrips, bb_ = blockIdx.x / g.nstrips;
+  const int b = bb_ / g.nbands, band = bb_ - b * g.nbands;
+  const int H = g.H, W = g.W, C = g.C, H2 = 2 * H, W2 = 2 * W;
   const int r0 = band * g.RB, r1 = min(H, r0 + g.RB);
+  // column strip: the workgroup's own low-resolution columns [c0, c1) and the high-resolution columns [xs0, xs1) it carries
+  // through LDS (+-5: the same halo as along the rows - every stage needs one column more than the next); el0 / ew: the
+  // low-resolution columns the resize of those reads.  One strip (the 32x128 maps): the whole row, no halo
+  const int c0 = strip * g.SW, c1 = min(W, c0 + g.SW);
+  const int xs0 = max(0, 2 * c0 - 5), xs1 = min(W2, 2 * c1 + 5), SWh = xs1 - xs0;
+  int el0, el1;
+  { int lo, hi; float tt; axis2x(xs0, W, lo, hi, tt); el0 = lo; axis2x(xs1 - 1, W, lo, hi, tt); el1 = hi + 1; }
+  const int RW = SWh * C, rw = (el1 - el0) * C;
   const int Pd0 = max(0, 2 * r0 - 1), Pd1 = min(H2, 2 * r1 + 1);
   const int Pb0 = max(0, Pd0 - 1), Pb1 = min(H2, Pd1 + 1);
   const int Ps0 = max(0, Pb0 - 1), Ps1 = min(H2, Pb1 + 1);
@@ -645,7 +655,8 @@ __global__ void __launch_bounds__(1024) dog_fused_kernel(const DogArgs g) {
 
   // ---- e = y - t on the low-resolution rows the band's resize reads; the sign-byte tables -----------------------------------
   for (int i = tid; i < (e1 - e0) * rw; i += NT) {
-    const size_t k = (size_t)(b * H + e0) * rw + i;
+    const int er = i / rw, ej = i - er * rw;
+    const size_t k = ((size_t)(b * H + e0 + er) * W + el0) * C + ej;
     sE[i] = g.y[k] - g.t[k];
   }
   if (tid < 256) {
@@ -660,13 +671,18 @@ __global__ void __launch_bounds__(1024) dog_fused_kernel(const DogArgs g) {
     sLut[tid] = u[0]; sLut[256 + tid] = u[1]; sLut[512 + tid] = u[2];
   }
   // ---- the thread's column -------------------------------------------------------------------------------------------------
+  // (X: the column in the IMAGE - reflections, multiplicities and bilinear weights follow the image's borders; the offsets are
+  // local to the strip and clamped into it: at a strip edge that is not an image border the clamped reads feed only halo
+  // columns, whose values no own column depends on)
   const bool act = tid < RW;
-  const int j = act ? tid : 0, X = j / C, c = j - X * C;
-  const int fxm = refl(X - 1, W2) * C + c, fxp = refl(X + 1, W2) * C + c;             // forward neighbours (REFLECT)
-  const int txm = max(X - 1, 0) * C + c, txp = min(X + 1, W2 - 1) * C + c;            // adjoint neighbours, multiplicities
+  const int j = act ? tid : 0, Xl = j / C, c = j - Xl * C, X = xs0 + Xl;
+  auto loc = [&](int xg) { return min(max(xg - xs0, 0), SWh - 1) * C + c; };
+  const int fxm = loc(refl(X - 1, W2)), fxp = loc(refl(X + 1, W2));                   // forward neighbours (REFLECT)
+  const int txm = loc(max(X - 1, 0)), txp = loc(min(X + 1, W2 - 1));                  // adjoint neighbours, multiplicities
   const float mxm = X == 0 ? 0.f : (X == 1 ? 2.f : 1.f), mxp = X == W2 - 1 ? 0.f : (X == W2 - 2 ? 2.f : 1.f);
   int exl, exh; float etx;
-  { int xlo, xhi; axis2x(X, W, xlo, xhi, etx); exl = xlo * C + c; exh = xhi * C + c; }
+  { int xlo, xhi; axis2x(X, W, xlo, xhi, etx); exl = (xlo - el0) * C + c; exh = (xhi - el0) * C + c; }
+  const bool own_col = X >= 2 * c0 && X < 2 * c1;
   __syncthreads();
 
   // ---- up = resize2x(e) ----------------------------------------------------------------------------------------------------------
@@ -709,7 +725,7 @@ __global__ void __launch_bounds__(1024) dog_fused_kernel(const DogArgs g) {
       float bl[5];
 #pragma unroll
       for (int k = 0; k < 5; ++k) bl[k] = gc[k] * gc[k] * centre + ga[k] * gc[k] * edge + ga[k] * ga[k] * corner;
-      const bool own = p >= 2 * r0 && p < 2 * r1;
+      const bool own = own_col && p >= 2 * r0 && p < 2 * r1;
       unsigned code = 0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -760,8 +776,9 @@ __global__ void __launch_bounds__(1024) dog_fused_kernel(const DogArgs g) {
   }
   __syncthreads();
   // ---- d y += R^T d up  (up2x_bwd_kernel<1>, accumulate) --------------------------------------------------------------------------
-  for (int i = tid; i < (r1 - r0) * rw; i += NT) {
-    const int row = i / rw, jj = i - row * rw, ix = jj / C, cc = jj - ix * C, iy = r0 + row;
+  const int ow = (c1 - c0) * C;                            // the strip's own low-resolution columns
+  for (int i = tid; i < (r1 - r0) * ow; i += NT) {
+    const int row = i / ow, jj = i - row * ow, ix = c0 + jj / C, cc = jj % C, iy = r0 + row;
     float wy[4], wx[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -782,9 +799,9 @@ __global__ void __launch_bounds__(1024) dog_fused_kernel(const DogArgs g) {
 #pragma unroll
       for (int kx = 0; kx < 4; ++kx) {
         const float w = wy[ky] * wx[kx];
-        if (w != 0.f) s += w * bufB[(2 * iy - 1 + ky - Pd0) * RW + (2 * ix - 1 + kx) * C + cc];
+        if (w != 0.f) s += w * bufB[(2 * iy - 1 + ky - Pd0) * RW + (2 * ix - 1 + kx - xs0) * C + cc];
       }
-    float* o = g.dy + (size_t)(b * H + iy) * rw + jj;
+    float* o = g.dy + ((size_t)(b * H + iy) * W + ix) * C + cc;
     o[0] = o[0] + s;
   }
   // ---- loss ----------------------------------------------------------------------------------------------------------------------
@@ -1545,10 +1562,19 @@ int hdrsky_dog_loss(const float* y, const float* t, int B, int H, int W, int C, 
   if (!y || !t || !dy || B <= 0 || H < 4 || W < 4 || C <= 0) return HDRSKY_EINVAL;
   // a band of RB low-resolution rows needs (2 RB + 10) + (2 RB + 8) high-resolution rows of fp32, RB + 7 low-resolution ones
   // and 2 RB + 6 rows of sign bytes in LDS
-  const int RW = 2 * W * C, rw = W * C;
-  if (RW > 1024) return HDRSKY_EUNSUPPORTED;               // a thread per (pixel column, channel) of a band
+  // column strips: a thread per (high-resolution column, channel) of the strip incl. its +-5 halo, at most 1024 of them
+  if (C > 64) return HDRSKY_EUNSUPPORTED;
+  int nstrips = 1, SW = W;
+  if (2 * W * C > 1024) {
+    const int swmax = (1024 / C - 10) / 2;                  // own low-resolution columns that fit beside the halo
+    if (swmax < 8) return HDRSKY_EUNSUPPORTED;
+    nstrips = cdiv(W, swmax);
+    SW = cdiv(W, nstrips);
+  }
+  const int RW = (nstrips == 1 ? 2 * W : 2 * SW + 10) * C, rw = (nstrips == 1 ? W : SW + 7) * C;
   for (int RB = 4; RB >= 1; RB >>= 1) {
     DogArgs g{};
+    g.SW = SW; g.nstrips = nstrips;
     g.offB = (2 * RB + 10) * RW * 4;
     g.offE = g.offB + (2 * RB + 8) * RW * 4;
     g.offL = g.offE + (RB + 7) * rw * 4;
@@ -1564,11 +1590,11 @@ int hdrsky_dog_loss(const float* y, const float* t, int B, int H, int W, int C, 
     }
     g.y = y; g.t = t; g.loss = loss; g.dy = dy; g.B = B; g.H = H; g.W = W; g.C = C; g.RB = RB; g.nbands = cdiv(H, RB);
     g.weight = weight;
-    hipLaunchKernelGGL(dog_fused_kernel, dim3(B * g.nbands), dim3(1024), lds, S_(stream), g);
+    hipLaunchKernelGGL(dog_fused_kernel, dim3(B * g.nbands * g.nstrips), dim3(1024), lds, S_(stream), g);
     HDRSKY_CHECK_LAUNCH();
     return HDRSKY_OK;
   }
-  return HDRSKY_EUNSUPPORTED;     // rows too long for a band in LDS: the staged path (up2x_fwd, blur3, dog_mid, ...)
+  return HDRSKY_EUNSUPPORTED;     // (more than 64 channels: the staged path - up2x_fwd, blur3, dog_mid, ...)
 }
 
 int hdrsky_l1(const float* a, const float* b, size_t n, float wl, float wg, float* loss, float* da, int accumulate,

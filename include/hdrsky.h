@@ -330,8 +330,8 @@ int hdrsky_dog_mid(const float* base, int B, int H, int W, int C, float weight, 
 /* dbase = sum_j G(s_j)^T h_j. */
 int hdrsky_dog_mid_bwd(const float* h, int B, int H, int W, int C, float* dbase, void* stream);
 /* The whole DoG term of train.py:316-322 (tf_utils.py:61-73) in one launch: *loss += sum_i mean|DoG_i(y) - DoG_i(t)|,
- * dy += weight * its gradient wrt y ([B,H,W,C] fp32; the five calls above chained through LDS, same arithmetic).
- * HDRSKY_EUNSUPPORTED when a band of rows does not fit in LDS (2 W C > ~4500): use the staged calls. */
+ * dy += weight * its gradient wrt y ([B,H,W,C] fp32; the five calls above chained through LDS bands - rows longer than
+ * 1 024 floats at 2x resolution in column strips -, same operators).  HDRSKY_EUNSUPPORTED for more than 64 channels. */
 int hdrsky_dog_loss(const float* y, const float* t, int B, int H, int W, int C, float weight, float* loss, float* dy, void* stream);
 /* loss += wl*mean|a-b| (b nullable); da (+)= wg*sign(a-b)/n  (train.py:311-313,325). */
 int hdrsky_l1(const float* a, const float* b, size_t n, float wl, float wg, float* loss, float* da, int accumulate, void* stream);

@@ -3,7 +3,7 @@ sys.path.insert(0, "/root/repo")
 PKG = "hdr-map-reconstruction-from-a-single-ldr-sky-panoramic-image-for-outdoor-illumination-estimation_amd"
 K = importlib.import_module(PKG + ".kernels")
 dev = torch.device("cuda:0")
-for shape in [(2, 8, 16, 3), (3, 32, 128, 3), (2, 5, 7, 3), (1, 4, 4, 1), (2, 9, 33, 2), (32, 32, 128, 3)]:
+for shape in [(2, 8, 16, 3), (3, 32, 128, 3), (2, 5, 7, 3), (1, 4, 4, 1), (2, 9, 33, 2), (32, 32, 128, 3), (8, 128, 512, 3)]:
     rng = np.random.default_rng(5)
     a = torch.from_numpy(rng.uniform(0, 3, shape).astype(np.float32)).to(dev)
     b = torch.from_numpy(rng.uniform(0, 3, shape).astype(np.float32)).to(dev)

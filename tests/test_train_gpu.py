@@ -38,11 +38,13 @@ def test_resize_adjoint_blur_adjoint_dog(dev):
     assert_close(dyo, ga, 0.5, "dog grad (max)")
 
 
-@pytest.mark.parametrize("shape", [(2, 8, 16, 3), (3, 32, 128, 3), (2, 5, 7, 3), (1, 4, 4, 1), (2, 9, 33, 2)])
+@pytest.mark.parametrize("shape", [(2, 8, 16, 3), (3, 32, 128, 3), (2, 5, 7, 3), (1, 4, 4, 1), (2, 9, 33, 2), (2, 8, 200, 3),
+                                   (1, 11, 347, 3), (1, 128, 512, 3), (1, 6, 300, 5)])
 def test_dog_loss_one_launch_equals_the_staged_path(dev, shape, monkeypatch):
     """hdrsky_dog_loss (the chain through LDS bands, one launch) against the seven staged launches it replaces (which
     test_custom_ops_match_autograd pins to the oracle): the same operators - on the training size, on sizes whose bands are
-    clipped at both borders, one channel, and accumulating into a non-zero gradient."""
+    clipped at both borders, one channel, rows that are split into column strips (more than 1 024 floats at 2x resolution:
+    two strips, ragged strips, the 128x512 maps), and accumulating into a non-zero gradient."""
     K = pkg("kernels")
     rng = np.random.default_rng(5)
     a = torch.from_numpy(rng.uniform(0, 3, shape).astype(np.float32)).to(dev)
