@@ -411,6 +411,11 @@ __global__ void __launch_bounds__(256) up2x_xf_bf16_kernel(const float* __restri
 template <int V>
 __global__ void __launch_bounds__(256) up2x_bwd_kernel(const float* __restrict__ dy, int B, int H, int W, int C, float scale,
                                                        int accumulate, float* __restrict__ dx) {
+  // bit 1 of `accumulate`: dy is GIVEN as bf16 (the data-gradient conv of a resize-deconvolution writes the gradient at the
+  // doubled resolution - 67 MB in fp32 for the 64-channel layer of a batch of 32 - for this launch alone to read)
+  const bool dy16 = (accumulate & 2) != 0;
+  accumulate &= 1;
+  const unsigned short* dyh = reinterpret_cast<const unsigned short*>(dy);
   const int CV = C / V;
   const size_t total = (size_t)B * H * W * CV;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -440,12 +445,20 @@ __global__ void __launch_bounds__(256) up2x_bwd_kernel(const float* __restrict__
       for (int kx = 0; kx < 4; ++kx) {
         const float w = wy[ky] * wx[kx];
         if (w != 0.f) {   // zero weight <=> output pixel outside the image: never dereferenced
-          const float* p = dy + ((size_t)(bb * 2 * H + 2 * iy - 1 + ky) * 2 * W + 2 * ix - 1 + kx) * C + c;
+          const size_t off = ((size_t)(bb * 2 * H + 2 * iy - 1 + ky) * 2 * W + 2 * ix - 1 + kx) * C + c;
+          const float* p = dy + off;
           if (V == 4) {
-            const float4 d = *reinterpret_cast<const float4*>(p);
+            float4 d;
+            if (dy16) {
+              const uint2 u = *reinterpret_cast<const uint2*>(dyh + off);
+              d = make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                              __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u));
+            } else {
+              d = *reinterpret_cast<const float4*>(p);
+            }
             s[0] += w * d.x; s[1 % V] += w * d.y; s[2 % V] += w * d.z; s[3 % V] += w * d.w;
           } else {
-            s[0] += w * p[0];
+            s[0] += w * (dy16 ? bf2f(dyh[off]) : p[0]);
           }
         }
       }

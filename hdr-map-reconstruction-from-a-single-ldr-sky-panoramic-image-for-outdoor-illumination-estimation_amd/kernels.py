@@ -843,11 +843,12 @@ def up2x_act_bf16(x, xf: Optional[InXf] = None):
 
 def up2x_bwd(dy, scale=1.0, out=None):
     B, H2, W2, C = dy.shape
-    _f32(dy)
+    (_bf16 if dy.dtype == torch.bfloat16 else _f32)(dy)      # bf16: a data-gradient conv's out_bf16 output
     acc = out is not None
     dx = out if acc else torch.empty((B, H2 // 2, W2 // 2, C), dtype=torch.float32, device=dy.device)
     _f32(dx, B, H2 // 2, W2 // 2, C)
-    L.check(L.load().hdrsky_up2x_bwd(_p(dy), B, H2 // 2, W2 // 2, C, scale, int(acc), _p(dx), _stream()), "up2x_bwd")
+    L.check(L.load().hdrsky_up2x_bwd(_p(dy), B, H2 // 2, W2 // 2, C, scale, int(acc) | (2 if dy.dtype == torch.bfloat16 else 0),
+                                     _p(dx), _stream()), "up2x_bwd")
     return dx
 
 

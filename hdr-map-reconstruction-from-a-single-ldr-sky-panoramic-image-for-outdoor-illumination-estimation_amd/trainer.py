@@ -85,12 +85,15 @@ class _Conv:
         return K.wgrad_job(x, dy, self.kh, self.kw, gw, gb, stride=self.stride, same=self.same, upsample=self.upsample,
                            xf=xf, compute=compute)
 
-    def dgrad(self, x, dy, compute, residual=None, want_stats=False, out=None, out_bf16=False):
+    def dgrad(self, x, dy, compute, residual=None, want_stats=False, out=None, out_bf16=False, up_bf16=False):
         """Gradient wrt the (transformed, pre-resize) conv operand.  out_bf16: stored as bf16 (a gradient whose only reader is
         the InstanceNorm backward, kernels.norm_act_bwd)."""
         K.label(self.wkey + " (data gradient)")
+        # (a resize-deconvolution: the gradient at the doubled resolution is read by the resize adjoint below only - bf16
+        # when the caller says so with up_bf16)
         d, st = K.conv2d_dgrad(dy, self.pkT, self.desc(x), residual=None if self.upsample == 2 else residual,
-                               compute=compute, want_stats=want_stats, out_bf16=out_bf16 and self.upsample != 2)
+                               compute=compute, want_stats=want_stats,
+                               out_bf16=(up_bf16 and not want_stats) if self.upsample == 2 else out_bf16)
         if self.upsample == 2:
             d = K.up2x_bwd(d, 1.0, out=out)
         return (d, st) if want_stats else d
@@ -1005,13 +1008,13 @@ class Trainer:
                     self._wg_plain("gen.conv2_" + sfx, u2, dd2)
                 else:
                     self._wg("gen.conv2_" + sfx, d3, xf2, dd2)
-                da3 = c["gen.conv2_" + sfx].dgrad(d3, dd2, cp)
+                da3 = c["gen.conv2_" + sfx].dgrad(d3, dd2, cp, up_bf16=self._nab_bf16())
                 dd3 = self._in_bwd(d3, s3, "gen.norm3_" + sfx, 0.1, da3)
                 if u3 is not None:
                     self._wg_plain("gen.conv3_" + sfx, u3, dd3)
                 else:
                     self._wg("gen.conv3_" + sfx, T["x"][-1], None, dd3)
-                c["gen.conv3_" + sfx].dgrad(T["x"][-1], dd3, cp, out=dres)
+                c["gen.conv3_" + sfx].dgrad(T["x"][-1], dd3, cp, out=dres, up_bf16=self._nab_bf16())
             self._norm_grads("bwd_dec", B)
             T["wq_dec"] = self._take_wgrads()
 

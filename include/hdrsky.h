@@ -320,7 +320,8 @@ int hdrsky_maxpool_fwd(const float* y, int B, int H, int W, int C, float* p, voi
 int hdrsky_maxpool_relu_bwd(const float* y, const float* dp, int B, int H, int W, int C, float* dy, void* stream);
 /* y = resize2x_bilinear(a - b) (b nullable), half-pixel centres (tf_utils.py:64). */
 int hdrsky_up2x_fwd(const float* a, const float* b, int B, int H, int W, int C, float* y, void* stream);
-/* Exact adjoint of the 2x bilinear resize: dx (+)= scale * R^T dy   (backward of ops.py:122 / tf_utils.py:64). */
+/* Exact adjoint of the 2x bilinear resize: dx (+)= scale * R^T dy   (backward of ops.py:122 / tf_utils.py:64).
+ * accumulate: bit 0 = add to dx, bit 1 = dy is given as bf16 (a data-gradient conv's hdrsky_conv_desc.y_bf16 output). */
 int hdrsky_up2x_bwd(const float* dy, int B, int H, int W, int C, float scale, int accumulate, float* dx, void* stream);
 /* TFA gaussian_filter2d 3x3, REFLECT padding (tf_utils.py:65,69-70); transpose=1 applies the adjoint. */
 int hdrsky_blur3(const float* x, int B, int H, int W, int C, float sigma, int transpose, float* y, void* stream);

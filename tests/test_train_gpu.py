@@ -20,6 +20,13 @@ def test_resize_adjoint_blur_adjoint_dog(dev):
     (gx,) = torch.autograd.grad(up, x, dy)
     assert_close(K.up2x(x.detach().to(dev)), up.detach(), 1e-6, "up2x")
     assert_close(K.up2x_bwd(dy.to(dev)), gx, 1e-5, "up2x adjoint")
+    # the gradient handed over as bf16 (a data-gradient conv's bf16 output): the same bits as the fp32 tensor of those values,
+    # for the 16-byte (C % 4 == 0) and the scalar channel paths, plain and accumulating
+    for shp in ((2, 12, 20, 3), (2, 12, 20, 8)):
+        dyb = torch.from_numpy(rng.standard_normal(shp).astype(np.float32)).to(dev).to(torch.bfloat16)
+        assert torch.equal(K.up2x_bwd(dyb), K.up2x_bwd(dyb.float()))
+        acc = torch.ones((shp[0], shp[1] // 2, shp[2] // 2, shp[3]), device=dev)
+        assert torch.equal(K.up2x_bwd(dyb, 0.5, out=acc.clone()), K.up2x_bwd(dyb.float(), 0.5, out=acc.clone()))
     y = torch.from_numpy(rng.standard_normal((2, 8, 12, 3)).astype(np.float32)).requires_grad_(True)
     bl = T.gaussian_filter2d_3x3(y, 1.5450078)
     dz = torch.from_numpy(rng.standard_normal((2, 8, 12, 3)).astype(np.float32))
