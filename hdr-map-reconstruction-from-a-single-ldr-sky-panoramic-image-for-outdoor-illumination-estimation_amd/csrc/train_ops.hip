@@ -47,11 +47,23 @@ __global__ void __launch_bounds__(64) bn_train_finalize_kernel(const float* __re
   }
 }
 
+// four consecutive elements (element offset e, a multiple of 4) of an incoming gradient stored as fp32 or as bf16 (a
+// data-gradient conv's y_bf16 output whose only reader is the kernel at hand)
+__device__ __forceinline__ float4 ld4grad(const float* dy, int dy16, size_t e) {
+  if (dy16) {
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(dy) + e);
+    return make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                       __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u));
+  }
+  return *reinterpret_cast<const float4*>(dy + e);
+}
+
 // g = dy * act'(pre), pre = xhat*gamma+beta, xhat = (x-mean[c])*rstd[c]; per-block partial (sum g, sum g*xhat)
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            float slope, size_t npix, int C, float* __restrict__ part) {
+                                                            float slope, size_t npix, int C, float* __restrict__ part,
+                                                            int dy16) {
   extern __shared__ float sm[];  // [256][8] partials
   const int c4 = C >> 2;
   const int lanes_c = c4 < 256 ? c4 : 256;            // threads along channels (C/4 <= 256)
@@ -65,7 +77,7 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* __restr
     for (int j = 0; j < 4; ++j) { mu[j] = mean[c + j]; rs[j] = rstd[c + j]; gm[j] = gamma[c + j]; bt[j] = beta[c + j]; }
     for (size_t p = (size_t)blockIdx.x * rows + tr; p < npix; p += (size_t)gridDim.x * rows) {
       const float4 xv = *reinterpret_cast<const float4*>(x + p * C + c);
-      const float4 dv = *reinterpret_cast<const float4*>(dy + p * C + c);
+      const float4 dv = ld4grad(dy, dy16, p * C + c);
       const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -131,10 +143,12 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
                                     const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
                                     const float* __restrict__ m1m2, size_t n4, int C, void* __restrict__ dx, int dx_bf16) {
   const int c4 = C >> 2;
+  const int dy16 = dx_bf16 & 2;      // bit 1: dy given as bf16
+  dx_bf16 &= 1;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % c4) * 4;
     const float4 xv = reinterpret_cast<const float4*>(x)[i];
-    const float4 dv = reinterpret_cast<const float4*>(dy)[i];
+    const float4 dv = ld4grad(dy, dy16, i * 4);
     const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
     float o[4];
 #pragma unroll
@@ -154,11 +168,13 @@ __global__ void affine_act_bwd_kernel(const float* __restrict__ x, const float* 
                                       const float* __restrict__ scale, const float* __restrict__ shift, float slope,
                                       size_t n, int C, void* __restrict__ dxv, int dx_bf16) {
   float* dx = reinterpret_cast<float*>(dxv);
+  const int dy16 = dx_bf16 & 2;      // bit 1: dy given as bf16 (V == 4 only)
+  dx_bf16 &= 1;
   for (size_t i = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) * V; i < n; i += (size_t)gridDim.x * blockDim.x * V) {
     const int c = (int)(i % C);
     float v[V], g[V], o[V];
     if (V == 4) {
-      const float4 a = *reinterpret_cast<const float4*>(x + i), b = *reinterpret_cast<const float4*>(dy + i);
+      const float4 a = *reinterpret_cast<const float4*>(x + i), b = ld4grad(dy, dy16, i);
       v[0] = a.x; v[1 % V] = a.y; v[2 % V] = a.z; v[3 % V] = a.w;
       g[0] = b.x; g[1 % V] = b.y; g[2 % V] = b.z; g[3 % V] = b.w;
     } else {
@@ -301,10 +317,12 @@ __global__ void maxpool_relu_bwd_bf16_kernel(const unsigned short* __restrict__ 
 
 __global__ void act_bwd_bf16_kernel(const unsigned short* __restrict__ y, const float* __restrict__ dy, float slope, size_t n4,
                                     void* __restrict__ dx, int dx_bf16) {
+  const int dy16 = dx_bf16 & 2;      // bit 1: dy given as bf16
+  dx_bf16 &= 1;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     float v[4];
     ld4bf(y, i, v);
-    const float4 g = reinterpret_cast<const float4*>(dy)[i];
+    const float4 g = ld4grad(dy, dy16, i * 4);
     const float o[4] = {g.x * (v[0] > 0.f ? 1.f : slope), g.y * (v[1] > 0.f ? 1.f : slope),
                         g.z * (v[2] > 0.f ? 1.f : slope), g.w * (v[3] > 0.f ? 1.f : slope)};
     st4(dx, dx_bf16, i, o);
@@ -1422,7 +1440,7 @@ int hdrsky_bn_act_bwd_reduce(const float* x, const float* dy, const float* mean,
                              const float* beta, float slope, int npix, int C, float* part, void* stream) {
   if (!x || !dy || !mean || !rstd || !gamma || !beta || !part || (C & 3) || C > 1024) return HDRSKY_EINVAL;
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(128), dim3(256), 256 * 8 * sizeof(float), S_(stream), x, dy, mean, rstd,
-                     gamma, beta, slope, (size_t)npix, C, part);
+                     gamma, beta, slope, (size_t)npix, C, part, 0);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }
@@ -1437,7 +1455,7 @@ int hdrsky_bn_act_bwd_apply(const float* x, const float* dy, const float* mean, 
   hipLaunchKernelGGL(bn_bwd_finalize2_kernel, dim3(C), dim3(64), 0, S_(stream), part_all, nblocks_all, (float)count_all,
                      part_local, nblocks_local, C, m1m2, dgamma, dbeta);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for((size_t)npix * C / 4)), dim3(256), 0, S_(stream), x, dy, mean,
-                     rstd, gamma, beta, slope, m1m2, (size_t)npix * C / 4, C, dx, dx_bf16);
+                     rstd, gamma, beta, slope, m1m2, (size_t)npix * C / 4, C, dx, dx_bf16 & 1);   // (fp32 dy: _reduce has no flag)
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }
@@ -1450,7 +1468,7 @@ int hdrsky_bn_act_bwd(const float* x, const float* dy, const float* mean, const 
   float* part = workspace;
   float* m1m2 = workspace + (size_t)2 * nb * C;
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(256), 256 * 8 * sizeof(float), S_(stream), x, dy, mean, rstd,
-                     gamma, beta, slope, (size_t)npix, C, part);
+                     gamma, beta, slope, (size_t)npix, C, part, dx_bf16 & 2);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, S_(stream), part, nb, C, (float)npix, m1m2,
                      dgamma, dbeta);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for((size_t)npix * C / 4)), dim3(256), 0, S_(stream), x, dy, mean,
@@ -1464,7 +1482,7 @@ int hdrsky_affine_act_bwd(const float* x, const float* dy, const float* scale, c
   if (!x || !dy || !dx) return HDRSKY_EINVAL;
   const bool vec = (C & 3) == 0 && (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) |
                                                     reinterpret_cast<uintptr_t>(dx)) & 15) == 0;
-  if (dx_bf16 && !vec) return HDRSKY_EUNSUPPORTED;
+  if (dx_bf16 && !vec) return HDRSKY_EUNSUPPORTED;      // (either bit: bf16 dx or bf16 dy need the 16-byte path)
   if (vec) hipLaunchKernelGGL(affine_act_bwd_kernel<4>, dim3(grid_for(n / 4)), dim3(256), 0, S_(stream), x, dy, scale, shift, slope, n, C, dx, dx_bf16);
   else hipLaunchKernelGGL(affine_act_bwd_kernel<1>, dim3(grid_for(n)), dim3(256), 0, S_(stream), x, dy, scale, shift, slope, n, C, dx, 0);
   HDRSKY_CHECK_LAUNCH();

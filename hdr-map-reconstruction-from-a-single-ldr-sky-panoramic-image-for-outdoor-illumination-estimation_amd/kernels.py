@@ -734,7 +734,11 @@ def bn_act_bwd(x, dy, mean, rstd, gamma, beta, slope, dgamma=None, dbeta=None, o
     """Gradient through LeakyReLU(BatchNorm(x)) in training mode.  sync (parallel.BatchSync): the batch statistics ran over
     every replica's batch - the two means of the formula then run over the all-gathered partial blocks, d gamma / d beta
     over this replica's (the gradient exchange sums them)."""
-    _f32(x); _f32(dy, *x.shape)
+    _f32(x)
+    dy16 = dy.dtype == torch.bfloat16       # a data-gradient conv's bf16 output (single-replica path only)
+    if dy16 and sync is not None:
+        raise ValueError("bn_act_bwd: a bf16 incoming gradient is not supported with batch statistics over replicas")
+    (_bf16 if dy16 else _f32)(dy, *x.shape)
     C = x.shape[-1]
     npix = x.numel() // C
     lib = L.load()
@@ -746,7 +750,8 @@ def bn_act_bwd(x, dy, mean, rstd, gamma, beta, slope, dgamma=None, dbeta=None, o
         dx = _f32(out, *x.shape) if out is not None else torch.empty_like(x)
     args = (_p(x), _p(dy), _p(_f32(mean, C)), _p(_f32(rstd, C)), _p(_f32(gamma, C)), _p(_f32(beta, C)), slope, npix, C)
     if sync is None:
-        L.check(lib.hdrsky_bn_act_bwd(*args, _p(ws), _p(dgamma), _p(dbeta), _p(dx), int(out_bf16), _stream()), "bn_act_bwd")
+        L.check(lib.hdrsky_bn_act_bwd(*args, _p(ws), _p(dgamma), _p(dbeta), _p(dx), int(out_bf16) | (2 if dy16 else 0), _stream()),
+                "bn_act_bwd")
         return dx
     part = ws[:2 * nb * C].view(nb, 2, C)
     L.check(lib.hdrsky_bn_act_bwd_reduce(*args, _p(part), _stream()), "bn_act_bwd_reduce")
@@ -759,18 +764,20 @@ def bn_act_bwd(x, dy, mean, rstd, gamma, beta, slope, dgamma=None, dbeta=None, o
 
 def affine_act_bwd(x, dy, scale, shift, slope, out_bf16=False):
     odt = torch.bfloat16 if out_bf16 else torch.float32
+    dy16 = dy.dtype == torch.bfloat16       # a data-gradient conv's bf16 output
     if x.dtype == torch.bfloat16:      # plain activation backward on an ACTIVATED bf16 tensor
         if scale is not None or shift is not None:
             raise ValueError("a bf16 operand is a final activation: no affine")
-        _bf16(x); _f32(dy, *x.shape)
+        _bf16(x); (_bf16 if dy16 else _f32)(dy, *x.shape)
         dx = torch.empty(dy.shape, dtype=odt, device=dy.device)
-        L.check(L.load().hdrsky_act_bwd_bf16(_p(x), _p(dy), slope, x.numel(), _p(dx), int(out_bf16), _stream()), "act_bwd_bf16")
+        L.check(L.load().hdrsky_act_bwd_bf16(_p(x), _p(dy), slope, x.numel(), _p(dx), int(out_bf16) | (2 if dy16 else 0), _stream()),
+                "act_bwd_bf16")
         return dx
-    _f32(x); _f32(dy, *x.shape)
+    _f32(x); (_bf16 if dy16 else _f32)(dy, *x.shape)
     C = x.shape[-1]
     dx = torch.empty(x.shape, dtype=odt, device=x.device)
-    L.check(L.load().hdrsky_affine_act_bwd(_p(x), _p(dy), _p(scale), _p(shift), slope, x.numel(), C, _p(dx), int(out_bf16),
-                                           _stream()), "affine_act_bwd")
+    L.check(L.load().hdrsky_affine_act_bwd(_p(x), _p(dy), _p(scale), _p(shift), slope, x.numel(), C, _p(dx),
+                                           int(out_bf16) | (2 if dy16 else 0), _stream()), "affine_act_bwd")
     return dx
 
 

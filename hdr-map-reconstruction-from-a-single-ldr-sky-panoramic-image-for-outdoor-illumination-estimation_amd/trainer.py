@@ -534,7 +534,8 @@ class Trainer:
                 draw = K.affine_act_bwd(r["raw"], dy, r["scale"], r["shift"], 0.3, out_bf16=b16)
             if do_wgrad:
                 self._wg(net + d, r["x"], r["xf"], draw)
-            dy = c[net + d].dgrad(r["x"], draw, cp)   # gradient wrt the activated input of this layer
+            # gradient wrt the activated input of this layer: read by the next BatchNorm / activation backward only - bf16
+            dy = c[net + d].dgrad(r["x"], draw, cp, out_bf16=self._nab_bf16() and self.sync is None)
         d1pre = K.affine_act_bwd(R["d1"], dy, None, None, 0.3, out_bf16=self._act_bf16())
         if do_wgrad:
             self._wg(net + "d1", R["in"], None, d1pre)
@@ -584,7 +585,7 @@ class Trainer:
                 K.bn_act_bwd(r["raw"][sl], dy[sl], mean, rstd, params[n + "gamma"], params[n + "beta"], 0.3,
                              grads[n + "gamma"], grads[n + "beta"], out=draw[sl], out_bf16=b16, sync=self.sync)
             self._wg(net + d, r["x"], r["xf"], draw)
-            dy = c[net + d].dgrad(r["x"], draw, cp)
+            dy = c[net + d].dgrad(r["x"], draw, cp, out_bf16=self._nab_bf16() and self.sync is None)
         d1pre = K.affine_act_bwd(R["d1"], dy, None, None, 0.3, out_bf16=self._act_bf16())
         self._wg(net + "d1", R["in"], None, d1pre)
 

@@ -169,7 +169,7 @@ int hdrsky_bn_eval_affine(const float* gamma, const float* beta, const float* mo
 int hdrsky_norm_act_bwd(const float* x, const float* part, int nparts, const float* gamma, const float* beta,
                         float eps, float slope, const float* dy, int pooled, void* dx, int dx_bf16, float* sums,
                         float* dgamma, float* dbeta, float* ws, int B, int H, int W, int C, void* stream);
-/* (hdrsky_norm_act_bwd only: bit 1 of dx_bf16 = dy is GIVEN as bf16 - the output of a data-gradient conv with
+/* (hdrsky_norm_act_bwd, hdrsky_bn_act_bwd, hdrsky_affine_act_bwd, hdrsky_act_bwd_bf16: bit 1 of dx_bf16 = dy is GIVEN as bf16 - the output of a data-gradient conv with
  * hdrsky_conv_desc.y_bf16 that nothing else reads: half the bytes of the two passes over it.)
  * (dx_bf16 here and in hdrsky_bn_act_bwd / hdrsky_affine_act_bwd / hdrsky_act_bwd_bf16: dx is stored as bf16 - for a gradient
  * whose only readers are a data-gradient conv (hdrsky_conv_desc.x_bf16) and a weight gradient (hdrsky_wgrad_job.dy_bf16),
