@@ -113,3 +113,48 @@ def test_integration_md_binding_stub_matches_the_built_library(monkeypatch):
         g.guard[i] = 0xA5A5A5A5
     assert ns["lib"].hdrsky_conv_desc_init(ctypes.cast(ctypes.pointer(g), ctypes.POINTER(stub)), 2, 32, 128, 3, 32, 7, 7, 1, 1, 1) == 0
     assert all(v == 0xA5A5A5A5 for v in g.guard) and (g.d.Ho, g.d.Wo, g.d.pad_t) == (32, 128, 3)
+
+
+def _plan_bytes(L, lib, jobs):
+    """hdrsky_conv2d_wgrad_ws_bytes for a list of (B, H, W, Cin, Cout, k, stride, same, x_bf16, dy_bf16) - host-only planning:
+    the pointers are never dereferenced (placeholders), nothing is launched."""
+    arr = (L.WgradJob * len(jobs))()
+    for j, (B, H, W, Cin, Cout, k, s, same, xb, yb) in zip(arr, jobs):
+        assert lib.hdrsky_conv_desc_init(j.desc, B, H, W, Cin, Cout, k, k, s, int(same), 1) == 0
+        j.desc.compute = L.HDRSKY_BF16
+        j.x, j.dy, j.dw, j.db = 0x1000, 0x2000, 0x3000, 0x4000
+        j.x_bf16, j.dy_bf16 = int(xb), int(yb)
+    return int(lib.hdrsky_conv2d_wgrad_ws_bytes(arr, len(jobs)))
+
+
+def test_weight_gradient_workspace_planning_is_host_only_and_matches_the_decompositions():
+    """The deterministic weight-gradient path is planned on the host (hdrsky_conv2d_wgrad_ws_bytes: no launch, no GPU): the
+    scratch of the three kernels' partial slabs for the layer classes of the training step (batch 32).
+    conv_wgrad3_kernel (narrow side): 256 workgroups x [taps][CP or 64][wide block] slabs + bias partials;
+    conv_wgrad2_kernel: a layer that is not split over pixels needs no slab at all; unsupported geometry: 0."""
+    L = pkg("_lib")
+    lib = L.load()
+    f4 = 4
+    # 7x7 3->32 stem @32x128: 1024 tiles of 128 pixels / 4 per workgroup = 256 chunks x (49 taps x 4 x 32) + 256 x 32 bias words
+    stem = (32, 32, 128, 3, 32, 7, 1, True, 0, 1)
+    assert _plan_bytes(L, lib, [stem]) == (256 * 49 * 4 * 32 + 256 * 32) * f4
+    # 7x7 32->3 tail: the same decomposition with the roles swapped: slabs [49][32][4], bias partials 4 per chunk
+    tail = (32, 32, 128, 32, 3, 7, 1, True, 1, 0)
+    assert _plan_bytes(L, lib, [tail]) == (256 * 49 * 32 * 4 + 256 * 4) * f4
+    # both in one call: one launch, the slabs side by side
+    assert _plan_bytes(L, lib, [stem, tail]) == _plan_bytes(L, lib, [stem]) + _plan_bytes(L, lib, [tail])
+    # 4x4 stride-2 6->64 first layer @32x128 (64-pixel tiles, >= 256 pixels per workgroup: 128 chunks), 8 padded channels
+    d1 = (32, 32, 128, 6, 64, 4, 2, True, 0, 1)
+    assert _plan_bytes(L, lib, [d1]) == (128 * 16 * 8 * 64 + 128 * 64) * f4
+    # a wide layer with two final bf16 operands (LDS-DMA kernel) in a call of its own is split over pixels ...
+    res = (32, 8, 32, 128, 128, 3, 1, True, 1, 1)
+    one = _plan_bytes(L, lib, [res])
+    assert one > 9 * 128 * 128 * f4 and one % f4 == 0
+    # ... and shares the 256-workgroup budget by work in a call of twelve: fewer chunks per layer, less scratch per layer
+    assert _plan_bytes(L, lib, [res] * 12) < 12 * one
+    # a geometry no kernel takes (dilated conv): the planner says so with 0
+    arr = (L.WgradJob * 1)()
+    assert lib.hdrsky_conv_desc_init(arr[0].desc, 2, 8, 32, 32, 32, 3, 3, 1, 1, 1) == 0
+    arr[0].desc.dilate = 2
+    arr[0].x, arr[0].dy, arr[0].dw = 0x1000, 0x2000, 0x3000
+    assert int(lib.hdrsky_conv2d_wgrad_ws_bytes(arr, 1)) == 0
