@@ -48,7 +48,20 @@ struct ConvKArgs {
   unsigned long long* stamps;  // debug: per-workgroup phase time stamps (null in production)
   int x_bf16, y_bf16;          // activation storage (hdrsky_conv_desc)
   int res_mode; float mask_slope;
+  // stride-2 data gradient by output phases (phase != 0): workgroup = a tile of ONE of the four (oy & 1, ox & 1) phases of
+  // the output; KH / KW are then the per-phase tap counts ceil(K / 2), KHf / KWf the full (flipped) filter, pad_t / pad_l
+  // the full conv's K - 1 - pad, H / W (= Hc / Wc) the un-stuffed gradient
+  int phase, KHf, KWf;
 };
+
+// Packed-filter k-step of phase tap `tapp` (ky', kx' of the per-phase KH x KW grid), channel block cb: the full filter's
+// tap (ay + 2 ky', ax + 2 kx'); taps beyond an odd filter's edge read the packed image's all-zero k-step.
+__device__ __forceinline__ int phase_kp(const ConvKArgs& a, int tapp, int cbk, int cin32, int ph) {
+  const int ay = (a.pad_t - (ph >> 1)) & 1, ax = (a.pad_l - ph) & 1;
+  const int kyp = (tapp * a.kw_magic) >> 16;
+  const int ky = ay + 2 * kyp, kx = ax + 2 * (tapp - kyp * a.KW);
+  return (ky < a.KHf && kx < a.KWf) ? (ky * a.KWf + kx) * cin32 + cbk : a.kzero;
+}
 
 // load 8 consecutive channels and apply the producer's affine + leaky activation
 __device__ __forceinline__ void load8_xf(const float* __restrict__ p, const float* sc, const float* sh, bool xf,
@@ -133,6 +146,7 @@ __device__ __forceinline__ void compute_chunk(const ConvKArgs& a, const unsigned
     const int ks_ = min((chunk_) * KC + j * RPP + bsub, a.ksg - 1);                                       \
     int kp_;                                                                                              \
     if (NARROW) kp_ = ks_;                                                                                \
+    else if (PH) kp_ = phase_kp(a, ks_ >> a.log2cbg, (g << a.log2cbg) + (ks_ & ((1 << a.log2cbg) - 1)), cin32, ph); \
     else kp_ = (ks_ >> a.log2cbg) * cin32 + (g << a.log2cbg) + (ks_ & ((1 << a.log2cbg) - 1));           \
     const size_t src_ = (size_t)(kp_ * 4) * a.Npad + boff;                                                \
     glds16(a.whi + src_, sb_lds + (((buf_) * BPLANES + 0) * BITEMS + wave_base + j * NT) * 16);           \
@@ -140,7 +154,9 @@ __device__ __forceinline__ void compute_chunk(const ConvKArgs& a, const unsigned
   }
 // 8-wave variants are compiled for 4 waves per SIMD (<= 128 VGPRs; they need 77-106 and no scratch): two workgroups
 // then fit a CU, which is what lets kernels of the other streams of the training step overlap with this one.
-template <int WM, int WN, int MI, int NI, int TW, bool NARROW, bool PRECISE, bool DB>
+// PH: the stride-2 data gradient by output phases (ConvKArgs::phase; its own instantiations: the extra scalars of the
+// phase arithmetic pushed the 8-wave direct-B variants, which sit at their 128-VGPR budget, into scratch)
+template <int WM, int WN, int MI, int NI, int TW, bool NARROW, bool PRECISE, bool DB, bool PH>
 __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB ? 4 : 2) : 1) conv_igemm_kernel(const ConvKArgs a) {
   constexpr int NW = WM * WN;                // waves per workgroup (4 or 8)
   constexpr int NT = NW * 64;
@@ -183,10 +199,20 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB
   }
   const int nb = bid % a.nblocks; bid /= a.nblocks;
   const int tx = bid % a.tiles_x; bid /= a.tiles_x;
-  const int ty = bid % a.tiles_y;
-  const int b = bid / a.tiles_y;
-  const int oy0 = ty * TH, ox0 = tx * TW, n0 = nb * BN;
-  const int iy0 = oy0 * a.stride - a.pad_t, ix0 = ox0 * a.stride - a.pad_l;
+  const int ty = bid % a.tiles_y; bid /= a.tiles_y;
+  // Output phases of a stride-2 data gradient (a.phase): dx[2m + p] = sum_t dy[m + off_p + t] * w'[a_p + 2t] with
+  // a_p = (pad' - p) & 1, off_p = (p + a_p - pad') / 2 (pad' = K - 1 - pad of the forward conv, w' the flipped filter) -
+  // a stride-1 conv of the UN-stuffed gradient with every other tap, i.e. a quarter of the zero-stuffed form's products
+  // (the same non-zero products in the same order: bit-identical).  The four phases of a sample are neighbours in the
+  // workgroup order (they read the same gradient tile).
+  int b = bid, ph = 0, pad_t = a.pad_t, pad_l = a.pad_l;     // ph = 2 * (oy & 1) + (ox & 1) of this workgroup's phase
+  if (PH) {
+    b = bid >> 2; ph = bid & 3;
+    const int py = ph >> 1, px = ph & 1;
+    pad_t = -((py + ((a.pad_t - py) & 1) - a.pad_t) >> 1); pad_l = -((px + ((a.pad_l - px) & 1) - a.pad_l) >> 1);   // (even numerators: exact)
+  }
+  const int oy0 = ty * TH, ox0 = tx * TW, n0 = nb * BN;    // (phase mode: coordinates on the phase's own grid)
+  const int iy0 = oy0 * a.stride - pad_t, ix0 = ox0 * a.stride - pad_l;
 
   HDRSKY_STAMP(0)
   // ---- prologue: tap offset table + input transform tables (identity when in_mode == NONE) ----
@@ -203,7 +229,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB
       const int tap = ka >> a.log2cbg, cb = ka & cbm;
       const int ky = (tap * a.kw_magic) >> 16;
       const int aoff = (ky * a.WT + (tap - ky * a.KW) + cb * 4 * a.NPIXP) * 16;
-      const int kp = (kb >> a.log2cbg) * cin32t + (kb & cbm);
+      const int kp = PH ? phase_kp(a, kb >> a.log2cbg, kb & cbm, cin32t, ph) : (kb >> a.log2cbg) * cin32t + (kb & cbm);
       sKtab[i] = int2{aoff, kp * 4 * a.Npad};
     }
   }
@@ -404,6 +430,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB
       uint4 bqh[DPF][NI], bql[DPF][NI];
       auto kp_of = [&](int ks) {
         const int kc = min(ks, a.ksg - 1);
+        if (!NARROW && PH) return phase_kp(a, kc >> a.log2cbg, (g << a.log2cbg) + (kc & ((1 << a.log2cbg) - 1)), cin32, ph);
         return NARROW ? kc : (kc >> a.log2cbg) * cin32 + (g << a.log2cbg) + (kc & ((1 << a.log2cbg) - 1));
       };
 #pragma unroll
@@ -577,7 +604,8 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB
   for (int it = 0; it * PPI < BM; ++it) {
     const int m = it * PPI + tid / C4;           // tile-local pixel (fragment-major order)
     const int f = m >> 4;
-    const int oy = oy0 + f / FPR, ox = ox0 + (f % FPR) * 16 + (m & 15);
+    int oy = oy0 + f / FPR, ox = ox0 + (f % FPR) * 16 + (m & 15);
+    if (PH) { oy = 2 * oy + (ph >> 1); ox = 2 * ox + (ph & 1); }
     if (m < BM && oy < a.Ho && ox < a.Wo) {
       const float4 t = *reinterpret_cast<const float4*>(sOut + m * BNP + c4 * 4);
       float v[4] = {t.x + bias4[0], t.y + bias4[1], t.z + bias4[2], t.w + bias4[3]};
@@ -746,11 +774,13 @@ int ilog2(int v) {
 
 struct TileCfg { int wm, wn, mi, ni, tw, db; };
 
-template <int WM, int WN, int MI, int NI, int TW, bool NARROW, bool PRECISE, bool DB>
+constexpr int HDRSKY_EPHASE_FALLBACK = -1000;   // internal: launch_conv declines the phase form of a stride-2 data gradient
+
+template <int WM, int WN, int MI, int NI, int TW, bool NARROW, bool PRECISE, bool DB, bool PH>
 int launch_conv(ConvKArgs& a, hipStream_t stream) {
   constexpr int BM = WM * MI * 16, BN = WN * NI * 16, TH = BM / TW;
-  a.tiles_x = cdiv(a.Wo, TW);
-  a.tiles_y = cdiv(a.Ho, TH);
+  a.tiles_x = cdiv(PH ? cdiv(a.Wo, 2) : a.Wo, TW);    // phase mode: tiles of one phase's grid, four phases per sample
+  a.tiles_y = cdiv(PH ? cdiv(a.Ho, 2) : a.Ho, TH);
   a.nblocks = cdiv(a.Cout, BN);
   a.HT = (TH - 1) * a.stride + a.KH;
   a.WT = (TW - 1) * a.stride + a.KW;
@@ -776,6 +806,9 @@ int launch_conv(ConvKArgs& a, hipStream_t stream) {
     if ((1 << a.log2nq) != cgs / 8) return HDRSKY_EUNSUPPORTED;
     a.ksg = a.ntaps * (cgs / 32);
   }
+  // an odd filter's phases pad their tap grid with the packed image's single all-zero k-step, which the direct-B table
+  // addresses relative to a channel group's base: with several groups the zero-stuffed form runs instead
+  if (PH && ((a.KHf | a.KWf) & 1) && a.ngroups > 1) return HDRSKY_EPHASE_FALLBACK;
   const int a_plane = (NARROW ? 1 : a.cgs / 8) * a.NPIXP * 16;
   a.off_alo = a_plane;
   a.off_b = a_plane * bplanes;
@@ -794,7 +827,7 @@ int launch_conv(ConvKArgs& a, hipStream_t stream) {
   a.off_out = 0;
   if (DB && roundup(lds, 16) + out_bytes <= 80 * 1024) { a.off_out = roundup(lds, 16); lds = a.off_out + out_bytes; }   // (two workgroups per CU must still fit)
   if (lds > 160 * 1024) return HDRSKY_EUNSUPPORTED;
-  auto kern = conv_igemm_kernel<WM, WN, MI, NI, TW, NARROW, PRECISE, DB>;
+  auto kern = conv_igemm_kernel<WM, WN, MI, NI, TW, NARROW, PRECISE, DB, PH>;
   static int max_lds_set = 0;
   if (lds > max_lds_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -802,20 +835,20 @@ int launch_conv(ConvKArgs& a, hipStream_t stream) {
       return HDRSKY_ELAUNCH;
     max_lds_set = 160 * 1024;
   }
-  const int grid = a.B * a.tiles_y * a.tiles_x * a.nblocks;
+  const int grid = a.B * (PH ? 4 : 1) * a.tiles_y * a.tiles_x * a.nblocks;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, stream, a);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }
 
-template <bool NARROW, bool PRECISE>
+template <bool NARROW, bool PRECISE, bool PH = false>
 int dispatch_tile(ConvKArgs& a, const TileCfg& t, hipStream_t s) {
 #define HDRSKY_CASE(WM_, WN_, MI_, NI_, TW_)                                              \
   if (!t.db && t.wm == WM_ && t.wn == WN_ && t.mi == MI_ && t.ni == NI_ && t.tw == TW_) \
-    return launch_conv<WM_, WN_, MI_, NI_, TW_, NARROW, PRECISE, false>(a, s);
+    return launch_conv<WM_, WN_, MI_, NI_, TW_, NARROW, PRECISE, false, PH>(a, s);
 #define HDRSKY_CASE_DB(WM_, WN_, MI_, NI_, TW_)                                           \
   if (t.db && t.wm == WM_ && t.wn == WN_ && t.mi == MI_ && t.ni == NI_ && t.tw == TW_)  \
-    return launch_conv<WM_, WN_, MI_, NI_, TW_, NARROW, PRECISE, true>(a, s);
+    return launch_conv<WM_, WN_, MI_, NI_, TW_, NARROW, PRECISE, true, PH>(a, s);
   // LDS-ring variant
   HDRSKY_CASE(2, 2, 4, 2, 32) HDRSKY_CASE(2, 2, 2, 2, 32) HDRSKY_CASE(2, 2, 2, 2, 16)
   HDRSKY_CASE(4, 1, 4, 2, 32) HDRSKY_CASE(4, 1, 2, 2, 32) HDRSKY_CASE(2, 2, 2, 1, 32) HDRSKY_CASE(2, 2, 2, 1, 16)
@@ -956,6 +989,20 @@ __global__ void __launch_bounds__(256) conv_dot1_kernel(const ConvKArgs a) {
     a.y[((size_t)b * a.Ho + oy) * a.Wo + ox] = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]) + (a.bias != nullptr ? a.bias[0] : 0.f);
 }
 
+// Stride-2 data gradients (descriptor from hdrsky_conv_desc_init_dgrad: dilate == 2) run by output phases on the un-stuffed
+// gradient (conv_igemm_kernel, a.phase) unless per-tile statistics are asked for (their tile count follows the stuffed
+// form); HDRSKY_NO_PHASE=1 keeps the zero-stuffed operand (A/B and bit-identity tests).
+static bool phase_applies(const hdrsky_conv_desc* d) {
+  return d->dilate == 2 && d->Cin > 8 && d->upsample == 1 && d->stride == 1 && !d->want_stats && d->compute != HDRSKY_BF16X3 &&
+         !getenv("HDRSKY_NO_PHASE");   // (the two-plane mode keeps the zero-stuffed form: no phase instantiations of it)
+}
+// the problem one phase-form launch tiles: four phase grids of ceil(Ho/2) x ceil(Wo/2) pixels per sample
+static hdrsky_conv_desc phase_view(const hdrsky_conv_desc* d) {
+  hdrsky_conv_desc v = *d;
+  v.B = 4 * d->B; v.Ho = cdiv(d->Ho, 2); v.Wo = cdiv(d->Wo, 2);
+  return v;
+}
+
 static bool dot1_applies(const hdrsky_conv_desc* d, const float* residual) {
   return d->Cout == 1 && d->Cin >= 32 && (d->Cin % 32) == 0 && d->upsample == 1 && d->dilate == 1 && !d->want_stats && !residual &&
          !d->x_bf16 && !d->y_bf16 && d->out_slope == 1.f && !d->final_relu && d->res_mode == 0 &&
@@ -1040,9 +1087,12 @@ int hdrsky_conv_pack_weights_multi(const void* jobs, int njobs, int total_blocks
 int hdrsky_conv_kernel_name(const hdrsky_conv_desc* d, char* buf, int n) {
   if (!d || !buf || n <= 0) return HDRSKY_EINVAL;
   if (dot1_applies(d, nullptr)) { snprintf(buf, (size_t)n, "conv_dot1_kernel"); return HDRSKY_OK; }
-  const TileCfg t = choose_tile(d);
-  snprintf(buf, (size_t)n, "conv_igemm_kernel<%d, %d, %d, %d, %d, %s, %s, %s>", t.wm, t.wn, t.mi, t.ni, t.tw,
-           d->Cin <= 8 ? "true" : "false", d->compute == HDRSKY_BF16X3 ? "true" : "false", t.db ? "true" : "false");
+  hdrsky_conv_desc pv = *d;
+  if (phase_applies(d)) pv = phase_view(d);   // (an odd filter over several channel groups falls back at launch: not seen here)
+  const TileCfg t = choose_tile(&pv);
+  snprintf(buf, (size_t)n, "conv_igemm_kernel<%d, %d, %d, %d, %d, %s, %s, %s, %s>", t.wm, t.wn, t.mi, t.ni, t.tw,
+           d->Cin <= 8 ? "true" : "false", d->compute == HDRSKY_BF16X3 ? "true" : "false", t.db ? "true" : "false",
+           phase_applies(d) ? "true" : "false");
   return HDRSKY_OK;
 }
 
@@ -1092,6 +1142,15 @@ int hdrsky_conv2d_fwd(const hdrsky_conv_desc* d, const float* x, const void* w_h
     hipLaunchKernelGGL(conv_dot1_kernel, dim3(a.B * a.Ho * a.Wo), dim3(256), 0, s, a);
     HDRSKY_CHECK_LAUNCH();
     return HDRSKY_OK;
+  }
+  if (phase_applies(d)) {
+    ConvKArgs p = a;
+    p.phase = 1; p.KHf = d->KH; p.KWf = d->KW; p.KH = (d->KH + 1) / 2; p.KW = (d->KW + 1) / 2;
+    p.dilate = 1; p.Hc = d->H; p.Wc = d->W;            // the operand is the gradient itself
+    const hdrsky_conv_desc pv = phase_view(d);
+    const TileCfg tp = choose_tile(&pv);
+    const int rc = dispatch_tile<false, false, true>(p, tp, s);
+    if (rc != HDRSKY_EPHASE_FALLBACK) return rc;
   }
   const TileCfg t = choose_tile(d);
   if (narrow) return precise ? dispatch_tile<true, true>(a, t, s) : dispatch_tile<true, false>(a, t, s);
