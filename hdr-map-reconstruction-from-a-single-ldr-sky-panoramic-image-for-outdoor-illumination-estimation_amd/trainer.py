@@ -1128,9 +1128,11 @@ class Trainer:
         # The two Dense layers hold 50.3 M of the 58.3 M parameters and nothing reads their weights or gradients after
         # bwd_dense: their RMSprop update and bf16 re-packing run here, beside the rest of the backward pass, instead of
         # at the end of the step.  (Data-parallel: after the all-reduce of that slice / the all-gather of the operands.)
-        # (stream 1, beside the backward chains: at the END of stream 0 or 2, where nothing compute-bound is left to overlap
-        # its HBM stream with, the step is 1.3-1.7 % longer - HDRSKY_APPLY_FC_STREAM is the A/B hook)
-        @seg("apply_fc", int(os.environ.get("HDRSKY_APPLY_FC_STREAM", "1")), ["bwd_dense", "wg_dense"])
+        # (Round 2 kept it on stream 1 beside the backward chains.  Since the weight-gradient segments moved there it sat at
+        # the END of stream 1, with the conv-side update waiting behind it: now it closes stream 2 - idle from wg_sunrad on -
+        # and `apply` no longer waits for it (disjoint parameters): the two updates overlap, step -1 %
+        # (profiles/r03_plan_ab2.txt; HDRSKY_APPLY_FC_STREAM / HDRSKY_APPLY_AFTER_FC are the A/B hooks))
+        @seg("apply_fc", int(os.environ.get("HDRSKY_APPLY_FC_STREAM", "2")), ["bwd_dense", "wg_dense"])
         def _():
             fc0, fc1 = self.fc_grad_range()
             if self.fused_dense:
@@ -1158,7 +1160,8 @@ class Trainer:
         segs.append(("grads_ready", 0, ("disc_step", "wg_dec", "bwd_sunpose", "wg_res", "wg_sunrad"), None))
 
         # ------------------------------------------------------------------ optimizers (train.py:403,406)
-        @seg("apply", 0, ["apply_fc"])
+        # (starts behind grads_ready, beside the Dense update; HDRSKY_APPLY_AFTER_FC=1: the round-2 order, A/B hook)
+        @seg("apply", 0, ["apply_fc"] if os.environ.get("HDRSKY_APPLY_AFTER_FC", "0") == "1" else [])
         def _():
             gscale, fc0 = self._gscale, self.fc_grad_range()[0]
             K.rmsprop(self.gs.flat[:fc0], self.gs.grad[:fc0], self.gs.ms[:fc0], self.lr, gscale=gscale)
