@@ -1103,6 +1103,12 @@ class Trainer:
         def _():
             K.conv2d_wgrad_multi(T["wq_res"])
 
+        # The encoder head closes the backward pass on stream 0.  The gradients of its two stride-2 layers are complete two
+        # data gradients before the chain ends: their weight gradients (act_bf16 + conv_wgrad2 + reduce, ~100 us) run as
+        # segment wg_enc on stream 1 - idle by then - beside the rest of the chain instead of behind it; only the stem's
+        # (conv_wgrad3) stays at the end.  HDRSKY_WG_ENC_SPLIT=0: one segment, A/B hook.
+        split_enc = os.environ.get("HDRSKY_WG_ENC_SPLIT", "1") != "0"
+
         @seg("bwd_enc", 0)
         def _():       # encoder head (generator.py:92-108)
             dc3 = self._in_bwd(T["c3"], T["s3"], "gen.norm3_d", 0.1, T["dx_enc"])
@@ -1110,7 +1116,18 @@ class Trainer:
             da2 = c["gen.conv3_d"].dgrad(T["c2"], dc3, cp, out_bf16=self._nab_bf16())
             dc2 = self._in_bwd(T["c2"], T["s2"], "gen.norm2_d", 0.1, da2)
             self._wg("gen.conv2_d", T["c1"], T["xf2"], dc2)
-            da1 = c["gen.conv2_d"].dgrad(T["c1"], dc2, cp, out_bf16=self._nab_bf16())
+            T["dc2_enc"] = dc2
+            if split_enc:
+                T["wq_enc"] = self._take_wgrads()
+
+        if split_enc:
+            @seg("wg_enc", 1, ["bwd_enc"])
+            def _():
+                K.conv2d_wgrad_multi(T["wq_enc"])
+
+        @seg("bwd_enc2", 0)
+        def _():
+            da1 = c["gen.conv2_d"].dgrad(T["c1"], T["dc2_enc"], cp, out_bf16=self._nab_bf16())
             dc1 = self._in_bwd(T["c1"], T["s1"], "gen.norm1_d", 0.1, da1)
             self._wg("gen.conv1_d", T["ldr"], None, dc1)
             self._norm_grads("bwd_enc", B)
@@ -1157,7 +1174,7 @@ class Trainer:
                 K.rmsprop(self.gs.flat[o:o + n], self.gs.grad[o:o + n], self.gs.ms[o:o + n], self.lr, gscale=self._gscale)
 
         # every gradient is complete here: a data-parallel driver hooks its all-reduce onto this (empty) segment
-        segs.append(("grads_ready", 0, ("disc_step", "wg_dec", "bwd_sunpose", "wg_res", "wg_sunrad"), None))
+        segs.append(("grads_ready", 0, ("disc_step", "wg_dec", "bwd_sunpose", "wg_res", "wg_sunrad") + (("wg_enc",) if split_enc else ()), None))
 
         # ------------------------------------------------------------------ optimizers (train.py:403,406)
         # (starts behind grads_ready, beside the Dense update; HDRSKY_APPLY_AFTER_FC=1: the round-2 order, A/B hook)
