@@ -892,7 +892,10 @@ TileCfg choose_tile(const hdrsky_conv_desc* d) {
     else if (d->Cout > 16) t = TileCfg{2, 2, 2, 1, 16, 0};
     else t = TileCfg{4, 1, 1, 1, 16, 0};
   } else if (d->Cout >= 64) {
-    if (d->Cout >= 256 && M <= 16384) t = TileCfg{1, 8, 4, 1, 32, 1};   // 64 px x 128 ch
+    // 64 px x 128 ch.  (At up to 4096 pixels - the VGG16 conv3_x layers of a half batch of 16 - that is 128 workgroups and
+    // 64 px x 64 ch is faster ALONE (256->256 at 8x32: 16.8 -> 12.5 us, profiles/r03_microbench_tiles_b16.txt), but inside
+    // the three-stream step the wider block wins: 2.608 against 2.624 ms, r03_tile_w256_ab.txt - not taken.)
+    if (d->Cout >= 256 && M <= 16384) t = TileCfg{1, 8, 4, 1, 32, 1};
     else if (M <= 16384) t = TileCfg{2, 4, 2, 1, 32, 1};               // 64 px x 64 ch, 8 waves
     else t = TileCfg{2, 4, 4, 1, 32, 1};                               // 128 px x 64 ch, 8 waves
   } else if (d->Cout > 16) {
@@ -906,9 +909,11 @@ TileCfg choose_tile(const hdrsky_conv_desc* d) {
         if (sscanf(e, "%d,%d,%d,%d,%d,%d", &o.wm, &o.wn, &o.mi, &o.ni, &o.tw, &o.db) >= 5) t = o;
       }
   } else {
-    // Cout <= 16 (the 3-channel output convs): the 32-wide column block (zero-padded weights) measured
-    // faster than the 16-wide one
-    if (M >= 65536) t = d->compute == HDRSKY_BF16X3 ? TileCfg{4, 2, 4, 1, 32, 1} : TileCfg{8, 1, 4, 2, 32, 0};
+    // Cout <= 16 (the 3-channel output convs).  Round 1 measured the 32-wide column block of the LDS-ring variant
+    // (512 px x 32 ch, zero-padded weights) faster than its 16-wide one; the direct-B loop on 256 px x 16 ch beats both:
+    // 7x7 32->3 at 32x128, batch 32: 21.6 -> 14.1 us, 3x3 64->3: 15.2 -> 10.7 us (profiles/r03_microbench_narrow_out.txt);
+    // inside the step -0.5 %, forward pass -0.8 % (512 px x 16 ch: step -0.9 % but forward +1.7 %, r03_tile_c16_ab.txt)
+    if (M >= 65536) t = d->compute == HDRSKY_BF16X3 ? TileCfg{4, 2, 4, 1, 32, 1} : TileCfg{4, 1, 4, 1, 32, 1};
     else t = TileCfg{4, 1, 2, 1, 32, 0};
     if (M >= 65536 && d->compute != HDRSKY_BF16X3)
       if (const char* e = getenv("HDRSKY_TILE_C16")) {

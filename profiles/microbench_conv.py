@@ -24,6 +24,7 @@ LAYERS = [
     ("dec1 7x7 32->3 @32x128", 32, 128, 32, 3, 7, 1, 2),
     ("d3 4x4s2 128->256 @8x32", 8, 32, 128, 256, 4, 2, 8),
     ("d4 4x4 256->512 @4x16", 4, 16, 256, 512, 4, 1, 8),
+    ("vgg1_1 dgrad 64->3 @32x128", 32, 128, 64, 3, 3, 1, 2),
 ]
 
 def main():
