@@ -1,7 +1,9 @@
-# A/B of conv tile choices inside the step (conv_igemm.hip choose_tile hooks), same box, three rounds
-run() { env $1 python bench.py --workload all --no-cpu-baseline --no-roofline-top --no-parity --steps 100 --warmup 10 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-50s' % '$1', d['ms_per_step'], d['fwd']['ms_per_step'])"; }
-for rep in 1 2 3; do
+# A/B: workgroup target of the InstanceNorm backward's spatial split (pointwise.hip hdrsky_norm_act_bwd_nslices, HDRSKY_NAB_TARGET)
+run() { env $1 python bench.py --workload train --no-cpu-baseline --no-roofline-top --no-parity --steps 100 --warmup 10 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-40s' % '$1', d['ms_per_step'])"; }
+for rep in 1 2; do
 run "HDRSKY_X=default"
-run "HDRSKY_TILE_W256=1,8,4,1,32,1"
-run "HDRSKY_TILE_W256=1,8,2,1,16,1"
+run "HDRSKY_NAB_TARGET=256"
+run "HDRSKY_NAB_TARGET=128"
+run "HDRSKY_NAB_TARGET=64"
+run "HDRSKY_NAB_TARGET=1024"
 done
