@@ -1230,12 +1230,16 @@ class Trainer:
         st = self._streams
         for s in st:
             s.wait_stream(caller)
+        on_stream = {name: si for name, si, _, _ in self._segs}
         for name, si, deps, fn in self._segs:
             if names is not None and name not in names:
                 continue
             s = st[si]
             for d_ in deps:
-                if d_ in self._events:
+                # (a dependency on the same stream is its order: no event.  Found while capturing the whole step as ONE
+                # hipGraph: there a wait for an event recorded on the waiting stream itself crashes hipStreamEndCapture on
+                # ROCm 7.2; that experiment - DESIGN 5, third part - replayed at the SUM of the kernel times and was dropped)
+                if d_ in self._events and on_stream.get(d_) != si:
                     s.wait_event(self._events[d_])
             with torch.cuda.stream(s):
                 if pre_hooks and name in pre_hooks:
