@@ -82,7 +82,7 @@ def _graph_time(torch, launch, iters, warm=10):
     stream = torch.cuda.current_stream()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+    with _no_gc(), torch.cuda.graph(g, capture_error_mode="thread_local"):
         for _ in range(iters):
             launch()
     g.replay()
@@ -315,6 +315,11 @@ def cpu_baseline(torch, workload, nets_np, batch_np, budget_s=24.0, iters=20, wa
                                                                                    time.perf_counter() - t_start)}
 
 
+def _no_gc():
+    """kernels.no_gc: no cyclic-garbage finaliser (an old hipGraphExec) in the middle of a hipGraph capture."""
+    return importlib.import_module(PKG + ".kernels").no_gc()
+
+
 def timed(torch, dist, one_step, steps, warmup, dp, dev):
     """W untimed steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks (seconds)."""
     for _ in range(warmup):
@@ -351,7 +356,7 @@ def capture_forward(torch, fn, dp, no_graph):
         return fn, out
     g = torch.cuda.CUDAGraph()
     # thread_local: RCCL's watchdog thread may query events while this thread captures
-    with torch.cuda.graph(g, capture_error_mode="thread_local" if dp else "global"):
+    with _no_gc(), torch.cuda.graph(g, capture_error_mode="thread_local" if dp else "global"):
         out = fn()
     return g.replay, out
 

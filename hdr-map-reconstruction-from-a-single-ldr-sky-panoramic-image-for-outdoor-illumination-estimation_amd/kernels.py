@@ -4,6 +4,7 @@ PyTorch is plumbing here: device allocations (``torch.empty``), the current HIP 
 ``data_ptr()``; every FLOP happens inside libhdrsky.so.  All functions validate shapes / dtypes /
 contiguity on the host before a kernel is enqueued (a mis-shaped operand must never reach the GPU).
 """
+import contextlib
 import ctypes
 import os
 from dataclasses import dataclass
@@ -38,6 +39,24 @@ def label(name):
 def _trace(kind, kernel, shape, flop, relaunch):
     if TRACE is not None:
         TRACE.append(dict(kind=kind, label=_LABEL[0], kernel=kernel, shape=shape, flop=float(flop), relaunch=relaunch))
+
+
+@contextlib.contextmanager
+def no_gc():
+    """For hipGraph captures: collects garbage NOW and keeps the cyclic collector off inside the block.  torch.cuda.graph no
+    longer collects on entry (torch >= 2.9: only with torch.compiler.config.force_cudagraph_gc), so an unreachable object that
+    owns a hipGraphExec or an event - a Trainer of an earlier test, kept alive by its closures' reference cycle - could be
+    finalised by a collection that happens to start in the middle of a capture: hipGraphExecDestroy on a capturing thread
+    aborts the process (seen once in the GPU suite, in the capture of test_split_discriminator_passes_equal_the_paired_batch)."""
+    import gc
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 
 def conv_kernel_name(d):

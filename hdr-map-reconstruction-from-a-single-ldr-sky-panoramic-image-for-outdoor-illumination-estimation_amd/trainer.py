@@ -1364,13 +1364,14 @@ class Trainer:
         self.repack()
         torch.cuda.synchronize()
         self._graphs = {}
-        for name, si, deps, fn in self._segs:
-            if fn is None:
-                continue
-            gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr, stream=self._streams[si], capture_error_mode="thread_local"):
-                fn()
-            self._graphs[name] = gr
+        with K.no_gc():      # (no finaliser of an old graph / event in the middle of a capture)
+            for name, si, deps, fn in self._segs:
+                if fn is None:
+                    continue
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr, stream=self._streams[si], capture_error_mode="thread_local"):
+                    fn()
+                self._graphs[name] = gr
         torch.cuda.synchronize()
         self._captured = (self._T, self._segs)    # an eager step() / test_step() in between re-binds both (see replay)
         return self._outputs()

@@ -348,7 +348,7 @@ def test_zero_fill_kernel_sizes_and_alignments_also_under_graph_replay(dev):
     assert int(b8[1:1030].max()) == 0 and int(b8[0]) == 9 and int(b8[1030]) == 9
     x = torch.ones(4096, device=dev)
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with pkg("kernels").no_gc(), torch.cuda.graph(g):
         K.zero_(x)
         x.add_(1.0)
     for it in range(4):
