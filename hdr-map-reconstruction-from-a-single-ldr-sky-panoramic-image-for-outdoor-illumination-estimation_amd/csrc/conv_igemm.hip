@@ -898,11 +898,25 @@ TileCfg choose_tile(const hdrsky_conv_desc* d) {
     if (d->Cout >= 256 && M <= 16384) t = TileCfg{1, 8, 4, 1, 32, 1};
     else if (M <= 16384) t = TileCfg{2, 4, 2, 1, 32, 1};               // 64 px x 64 ch, 8 waves
     else t = TileCfg{2, 4, 4, 1, 32, 1};                               // 128 px x 64 ch, 8 waves
+    // (128 px x 128 ch - each operand fragment feeds two MFMAs - is faster on >= 32768 pixels x >= 128 channels: 128x512, batch 8:
+    // 256->256 at 32x128 74.4 -> 53.8 us, the 128x512 training step 5.84 -> 5.72 ms, profiles/r03_tile_wide_ab.txt.  NOT taken:
+    // beside that tile the distortion-aware data-gradient launches stop being reproducible (~0.05 % of their outputs change from
+    // run to run, profiles/dbg_da_contention.py; alone, beside the 128 px x 64 ch tile or beside a streaming kernel they are
+    // bit-stable) - an open defect of da_conv.hip that this tile only exposes, DESIGN 5 third part.  HDRSKY_TILE_WIDE selects it.)
+    if (d->Cout >= 128 && M >= 32768)
+      if (const char* e = getenv("HDRSKY_TILE_WIDE")) {
+        TileCfg o; o.db = 0;
+        if (sscanf(e, "%d,%d,%d,%d,%d,%d", &o.wm, &o.wn, &o.mi, &o.ni, &o.tw, &o.db) >= 5) t = o;
+      }
   } else if (d->Cout > 16) {
     // 256 px x 32 ch; in BF16X3 the double-buffered hi+lo weight ring of the LDS variant does not fit beside the
     // 7x7 halo planes, so that mode streams the weights per wave as well
     if (M >= 65536) t = (narrow || d->compute == HDRSKY_BF16X3) ? TileCfg{4, 2, 4, 1, 32, 1} : TileCfg{8, 1, 4, 2, 32, 0};
     else t = TileCfg{2, 2, 4, 1, 32, 1};                               // 128 px x 32 ch
+    // from 262144 pixels (the 128x512 workload) the direct-B 256 px x 32 ch tile is ahead of the ring variant as well:
+    // 7x7 32->32 at 128x512, batch 8: 88 -> 72 us; with the 16-channel class below: 128x512 training step 5.72 -> 5.66 ms,
+    // forward + losses 2.99 -> 2.93 ms (profiles/r03_tile_hires_ab.txt)
+    if (M >= 262144) t = TileCfg{4, 2, 4, 1, 32, 1};
     if (M >= 65536 && !narrow && d->compute != HDRSKY_BF16X3)
       if (const char* e = getenv("HDRSKY_TILE_C32")) {                 // A/B hook for this class inside the step
         TileCfg o; o.db = 0;
@@ -914,6 +928,7 @@ TileCfg choose_tile(const hdrsky_conv_desc* d) {
     // 7x7 32->3 at 32x128, batch 32: 21.6 -> 14.1 us, 3x3 64->3: 15.2 -> 10.7 us (profiles/r03_microbench_narrow_out.txt);
     // inside the step -0.5 %, forward pass -0.8 % (512 px x 16 ch: step -0.9 % but forward +1.7 %, r03_tile_c16_ab.txt)
     if (M >= 65536) t = d->compute == HDRSKY_BF16X3 ? TileCfg{4, 2, 4, 1, 32, 1} : TileCfg{4, 1, 4, 1, 32, 1};
+    if (M >= 262144 && d->compute != HDRSKY_BF16X3) t = TileCfg{8, 1, 4, 1, 32, 1};   // 128x512: 512 px x 16 ch (7x7 32->3: 51 -> 39 us)
     else t = TileCfg{4, 1, 2, 1, 32, 0};
     if (M >= 65536 && d->compute != HDRSKY_BF16X3)
       if (const char* e = getenv("HDRSKY_TILE_C16")) {

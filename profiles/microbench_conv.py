@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--only", default="")
     ap.add_argument("--tiles", default="", help="semicolon-separated HDRSKY_TILE values to compare with the table")
+    ap.add_argument("--scale", type=int, default=1, help="multiply the map sizes (4: the 128x512 workload, use --batch 8)")
     ap.add_argument("--bf16", action="store_true", help="bf16 activations in and out + ReLU epilogue (the VGG16 chain of the step)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -42,6 +43,7 @@ def main():
     for (name, H, W, Cin, Cout, k, stride, cnt) in LAYERS:
         if args.only and args.only not in name:
             continue
+        H, W = H * args.scale, W * args.scale
         x = torch.randn(B, H, W, Cin, device=dev)
         kw = {}
         if args.bf16 and Cin >= 32:
