@@ -1,0 +1,29 @@
+"""Debug: WHERE do the outputs of hdrsky_da_conv2d_dgrad differ beside the 128 px x 128 ch conv tile (pixel tile, channel)?"""
+import importlib, os, sys, torch, collections
+sys.path.insert(0, os.getcwd())
+os.environ["HDRSKY_TILE_WIDE"] = "2,4,4,2,32,1"
+PKG = "hdr-map-reconstruction-from-a-single-ldr-sky-panoramic-image-for-outdoor-illumination-estimation_amd"
+K = importlib.import_module(PKG + ".kernels")
+dev = torch.device("cuda:0"); torch.manual_seed(0)
+side = torch.cuda.Stream()
+xn = torch.randn(16, 64, 256, 64, device=dev); pwn = K.PackedConv(torch.randn(4, 4, 64, 128, device=dev) * 0.03, False); bn = torch.zeros(128, device=dev)
+B, H, W = 8, 128, 512
+table = K.da_transpose_table(H, W, 3, 1, True, dev); dd2 = torch.randn(B, H, W, 32, device=dev)
+pwT = K.PackedConv(torch.randn(3, 3, 64, 32, device=dev) / 24, False, transpose_flip=True)
+ref = K.da_conv2d_dgrad(dd2, pwT, table, 3, K.BF16).clone(); torch.cuda.synchronize()
+for run in range(3):
+    with torch.cuda.stream(side):
+        for _ in range(6): K.conv2d(xn, pwn, bn, stride=2)
+    y = K.da_conv2d_dgrad(dd2, pwT, table, 3, K.BF16); torch.cuda.synchronize()
+    bad = (y != ref).nonzero()
+    print("run %d: %d wrong elements, NaN %d" % (run, bad.shape[0], int(torch.isnan(y).sum())))
+    if bad.shape[0] == 0: continue
+    b, h, w, c = bad[:, 0], bad[:, 1], bad[:, 2], bad[:, 3]
+    tile = (h * W + w) // 64
+    key = collections.Counter(zip(b.tolist(), tile.tolist()))
+    print("   distinct (sample, 64-pixel tile): %d; elements per tile min/max %d/%d" % (len(key), min(key.values()), max(key.values())))
+    print("   channels hit:", sorted(set(c.tolist()))[:70])
+    print("   pixel-in-tile hit:", sorted(set(((h * W + w) % 64).tolist())))
+    print("   samples hit:", sorted(set(b.tolist())), " first tiles:", sorted(key)[:6])
+    d = (y - ref)[b, h, w, c]
+    print("   |diff| min/median/max: %.3e %.3e %.3e; ref at those: median |%.3f|; got==0: %d" % (float(d.abs().min()), float(d.abs().median()), float(d.abs().max()), float(ref[b, h, w, c].abs().median()), int((y[b, h, w, c] == 0).sum())))
