@@ -316,3 +316,30 @@ def test_source_row_table_covers_every_sample(h, w, k):
     # the sample table's weights: the four bilinear weights of a sample sum to 1 wherever all four corners are inside
     inside = (idx >= 0).all(-1)
     assert np.abs(wt[inside].sum(-1) - 1.0).max() < 1e-4
+
+
+@pytest.mark.gpu
+def test_da_dgrad_is_reproducible_beside_conv_launches(dev):
+    """hdrsky_da_conv2d_dgrad at the 128x512 decoder shape stays bit-identical from run to run while another stream runs the
+    convolutions the training step puts beside it (the shipped tile table).  Guards a defect found in round 3: beside a
+    128 px x 128 ch conv tile (not in the table; HDRSKY_TILE_WIDE) ~0.05 % of this launch's outputs change from run to run
+    (profiles/dbg_da_contention.py)."""
+    K = pkg("kernels")
+    torch.manual_seed(0)
+    side = torch.cuda.Stream()
+    xn = torch.randn(16, 64, 256, 64, device=dev)
+    pwn = K.PackedConv(torch.randn(4, 4, 64, 128, device=dev) * 0.03, False)
+    bn = torch.zeros(128, device=dev)
+    B, H, W = 8, 128, 512
+    table = K.da_transpose_table(H, W, 3, 1, True, dev)
+    dd2 = torch.randn(B, H, W, 32, device=dev)
+    pwT = K.PackedConv(torch.randn(3, 3, 64, 32, device=dev) / 24, False, transpose_flip=True)
+    ref = K.da_conv2d_dgrad(dd2, pwT, table, 3, K.BF16).clone()
+    torch.cuda.synchronize()
+    for _ in range(6):
+        with torch.cuda.stream(side):
+            for _ in range(6):
+                K.conv2d(xn, pwn, bn, stride=2, want_stats=True)
+        y = K.da_conv2d_dgrad(dd2, pwT, table, 3, K.BF16)
+        torch.cuda.synchronize()
+        assert torch.equal(y, ref), "data gradient changed beside conv launches: %d elements" % int((y != ref).sum())
