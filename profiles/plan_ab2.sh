@@ -1,10 +1,6 @@
-# A/B at 128x512: tiles of the <= 16- and 32-output-channel classes (hooks HDRSKY_TILE_C16 / HDRSKY_TILE_C32), same box
-run() { env $1 python bench.py --workload $2 --no-cpu-baseline --no-roofline-top --no-parity --steps $3 --warmup 5 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-12s %-60s' % ('$2', '$1'), d['ms_per_step'])"; }
-for rep in 1 2; do
-for wl in hires-train hires; do
-run "HDRSKY_X=default" $wl 20
-run "HDRSKY_TILE_C16=8,1,4,1,32,1" $wl 20
-run "HDRSKY_TILE_C32=4,2,4,1,32,1" $wl 20
-run "HDRSKY_TILE_C16=8,1,4,1,32,1 HDRSKY_TILE_C32=4,2,4,1,32,1" $wl 20
-done
+# A/B helper of the session (last use: driver-line workload, narrow-output tile old vs new, same box)
+run() { env $1 python bench.py --workload all --no-cpu-baseline --no-parity --no-roofline-top --steps 100 --warmup 10 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-40s' % '$1', d.get('ms_per_step'), d.get('fwd',{}).get('ms_per_step'))"; }
+for rep in 1 2 3; do
+run "HDRSKY_X=default"
+run "HDRSKY_TILE_C16=8,1,4,2,32,0"
 done
