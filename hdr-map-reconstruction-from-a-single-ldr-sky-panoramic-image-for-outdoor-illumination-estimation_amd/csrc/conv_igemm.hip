@@ -923,12 +923,12 @@ TileCfg choose_tile(const hdrsky_conv_desc* d) {
         if (sscanf(e, "%d,%d,%d,%d,%d,%d", &o.wm, &o.wn, &o.mi, &o.ni, &o.tw, &o.db) >= 5) t = o;
       }
   } else {
-    // Cout <= 16 (the 3-channel output convs).  Round 1 measured the 32-wide column block of the LDS-ring variant
-    // (512 px x 32 ch, zero-padded weights) faster than its 16-wide one; the direct-B loop on 256 px x 16 ch beats both:
-    // 7x7 32->3 at 32x128, batch 32: 21.6 -> 14.1 us, 3x3 64->3: 15.2 -> 10.7 us (profiles/r03_microbench_narrow_out.txt);
-    // inside the step -0.5 %, forward pass -0.8 % (512 px x 16 ch: step -0.9 % but forward +1.7 %, r03_tile_c16_ab.txt)
-    if (M >= 65536) t = d->compute == HDRSKY_BF16X3 ? TileCfg{4, 2, 4, 1, 32, 1} : TileCfg{4, 1, 4, 1, 32, 1};
-    if (M >= 262144 && d->compute != HDRSKY_BF16X3) t = TileCfg{8, 1, 4, 1, 32, 1};   // 128x512: 512 px x 16 ch (7x7 32->3: 51 -> 39 us)
+    // Cout <= 16 (the 3-channel output convs).  Round 1 measured the 32-wide column block of the LDS-ring variant (512 px x 32 ch,
+    // zero-padded weights) faster than its 16-wide one; the direct-B loop on 256 px x 16 ch beats both: 7x7 32->3 at 32x128,
+    // batch 32: 21.6 -> 14.1 us, 3x3 64->3: 15.2 -> 10.7 (profiles/r03_microbench_narrow_out.txt); inside the step -0.5 %, forward
+    // pass -0.8 % (r03_tile_c16_ab.txt).  From 262144 pixels (128x512): 512 px x 16 ch (7x7 32->3: 51 -> 39 us).
+    if (M >= 262144 && d->compute != HDRSKY_BF16X3) t = TileCfg{8, 1, 4, 1, 32, 1};
+    else if (M >= 65536) t = d->compute == HDRSKY_BF16X3 ? TileCfg{4, 2, 4, 1, 32, 1} : TileCfg{4, 1, 4, 1, 32, 1};
     else t = TileCfg{4, 1, 2, 1, 32, 0};
     if (M >= 65536 && d->compute != HDRSKY_BF16X3)
       if (const char* e = getenv("HDRSKY_TILE_C16")) {
