@@ -898,16 +898,18 @@ TileCfg choose_tile(const hdrsky_conv_desc* d) {
     if (d->Cout >= 256 && M <= 16384) t = TileCfg{1, 8, 4, 1, 32, 1};
     else if (M <= 16384) t = TileCfg{2, 4, 2, 1, 32, 1};               // 64 px x 64 ch, 8 waves
     else t = TileCfg{2, 4, 4, 1, 32, 1};                               // 128 px x 64 ch, 8 waves
-    // (128 px x 128 ch - each operand fragment feeds two MFMAs - is faster on >= 32768 pixels x >= 128 channels: 128x512, batch 8:
-    // 256->256 at 32x128 74.4 -> 53.8 us, the 128x512 training step 5.84 -> 5.72 ms, profiles/r03_tile_wide_ab.txt.  NOT taken:
-    // beside that tile the distortion-aware data-gradient launches stop being reproducible (~0.05 % of their outputs change from
-    // run to run, profiles/dbg_da_contention.py; alone, beside the 128 px x 64 ch tile or beside a streaming kernel they are
-    // bit-stable) - an open defect of da_conv.hip that this tile only exposes, DESIGN 5 third part.  HDRSKY_TILE_WIDE selects it.)
-    if (d->Cout >= 128 && M >= 32768)
-      if (const char* e = getenv("HDRSKY_TILE_WIDE")) {
+    // 128 px x 128 ch - each operand fragment feeds two MFMAs - on >= 32768 pixels x >= 128 channels: 128x512, batch 8: 256->256 at
+    // 32x128 74.4 -> 53.8 us, 4x4 256->512 52.3 -> 40.1, the 128x512 training step 5.84 -> 5.72 ms (profiles/r03_tile_wide_ab.txt).
+    // (Round 3 kept it out of the table because the distortion-aware data gradient stopped being reproducible beside it; the
+    // cause was not this tile but a packed-f32 instruction form in THAT kernel that misbehaves beside any MFMA-dense wave -
+    // csrc/Makefile, DESIGN.md section 5.1 - and is gone from the library.)
+    if (d->Cout >= 128 && M >= 32768) {
+      t = TileCfg{2, 4, 4, 2, 32, 1};
+      if (const char* e = getenv("HDRSKY_TILE_WIDE")) {                // A/B hook for this class
         TileCfg o; o.db = 0;
         if (sscanf(e, "%d,%d,%d,%d,%d,%d", &o.wm, &o.wn, &o.mi, &o.ni, &o.tw, &o.db) >= 5) t = o;
       }
+    }
   } else if (d->Cout > 16) {
     // 256 px x 32 ch; in BF16X3 the double-buffered hi+lo weight ring of the LDS variant does not fit beside the
     // 7x7 halo planes, so that mode streams the weights per wave as well

@@ -1,0 +1,143 @@
+// Characterisation of what the a15 forensics found (profiles/experiments/da_dbg/run_da_dbg5.py): on
+// gfx950 a VOP3P packed-f32 instruction whose LOW result reads the HIGH dword of a 64-bit source (op_sel bit set) can
+// return a wrong low half while another wave on the same SIMD issues MFMAs back to back.  Which forms, which wrong value,
+// same SIMD or same CU?  Victim waves evaluate ONE instruction form on fixed operands (src0 = (3, 5), src1 = (7, 11),
+// src2 = (13, 17)) in a loop and compare both result halves with the exact expectation after every evaluation.
+//   hipcc --offload-arch=gfx950 -O2 pk_opsel.hip -o pk_opsel && ./pk_opsel [iters] [workgroups]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+struct Out { unsigned lo_mask[2], hi_mask[2]; float lo_bad, hi_bad; unsigned nlo, nhi; };
+
+// one evaluation + check; wrong lanes OR-ed into s[26:27] (low half) / s[28:29] (high half), a wrong value kept in v34 / v35,
+// evaluations with any wrong lane counted in s30 / s31
+#define EVAL(INSTR)                                                                                   \
+  INSTR "\n"                                                                                          \
+  "v_cmp_neq_f32 vcc, v10, v18\n s_or_b64 s[26:27], s[26:27], vcc\n v_cndmask_b32 v34, v34, v10, vcc\n"  \
+  "s_cmp_lg_u64 vcc, 0\n s_addc_u32 s30, s30, 0\n"                                                    \
+  "v_cmp_neq_f32 vcc, v11, v19\n s_or_b64 s[28:29], s[28:29], vcc\n v_cndmask_b32 v35, v35, v11, vcc\n"  \
+  "s_cmp_lg_u64 vcc, 0\n s_addc_u32 s31, s31, 0\n"
+#define R4(x) x x x x
+#define R16(x) R4(R4(x))
+
+#define VICTIM(NAME, INSTR)                                                                                          \
+  __device__ __forceinline__ void NAME(int iters, float elo, float ehi, Out& o) {                                    \
+    unsigned llo, lhi, hlo, hhi, nlo, nhi; float blo, bhi;                                                           \
+    asm volatile(                                                                                                    \
+        "s_mov_b64 s[26:27], 0\n s_mov_b64 s[28:29], 0\n s_mov_b32 s30, 0\n s_mov_b32 s31, 0\n s_mov_b32 s20, %8\n"  \
+        "v_mov_b32 v14, 3.0\n v_mov_b32 v15, 5.0\n v_mov_b32 v16, 7.0\n v_mov_b32 v17, 11.0\n v_mov_b32 v20, 13.0\n v_mov_b32 v21, 17.0\n" \
+        "v_mov_b32 v18, %9\n v_mov_b32 v19, %10\n v_mov_b32 v34, 0\n v_mov_b32 v35, 0\n s_nop 4\n"                   \
+        "1:\n" R16(EVAL(INSTR))                                                                                      \
+        "s_sub_u32 s20, s20, 1\n s_cmp_lg_u32 s20, 0\n s_cbranch_scc1 1b\n"                                          \
+        "v_mov_b32 %0, s26\n v_mov_b32 %1, s27\n v_mov_b32 %2, s28\n v_mov_b32 %3, s29\n v_mov_b32 %4, s30\n v_mov_b32 %5, s31\n" \
+        "v_mov_b32 %6, v34\n v_mov_b32 %7, v35\n"                                                                    \
+        : "=v"(llo), "=v"(lhi), "=v"(hlo), "=v"(hhi), "=v"(nlo), "=v"(nhi), "=v"(blo), "=v"(bhi)                     \
+        : "s"(iters), "v"(elo), "v"(ehi)                                                                             \
+        : "v10", "v11", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v34", "v35", "s20", "s26", "s27", "s28", \
+          "s29", "s30", "s31", "vcc", "scc", "memory");                                                              \
+    o.lo_mask[0] = llo; o.lo_mask[1] = lhi; o.hi_mask[0] = hlo; o.hi_mask[1] = hhi; o.nlo = nlo; o.nhi = nhi;          \
+    o.lo_bad = blo; o.hi_bad = bhi;                                                                                  \
+  }
+
+VICTIM(t_mul_plain, "v_pk_mul_f32 v[10:11], v[14:15], v[16:17]")
+VICTIM(t_mul_lo_from_hi_s1, "v_pk_mul_f32 v[10:11], v[14:15], v[16:17] op_sel:[0,1]")
+VICTIM(t_mul_lo_from_hi_s0, "v_pk_mul_f32 v[10:11], v[14:15], v[16:17] op_sel:[1,0]")
+VICTIM(t_mul_hi_from_lo_s1, "v_pk_mul_f32 v[10:11], v[14:15], v[16:17] op_sel_hi:[1,0]")
+VICTIM(t_mul_hi_from_lo_s0, "v_pk_mul_f32 v[10:11], v[14:15], v[16:17] op_sel_hi:[0,1]")
+VICTIM(t_fma_lo_from_hi_s1, "v_pk_fma_f32 v[10:11], v[14:15], v[16:17], v[20:21] op_sel:[0,1,0]")
+VICTIM(t_fma_hi_from_lo_s1, "v_pk_fma_f32 v[10:11], v[14:15], v[16:17], v[20:21] op_sel_hi:[1,0,1]")
+VICTIM(t_fma_lo_from_hi_s2, "v_pk_fma_f32 v[10:11], v[14:15], v[16:17], v[20:21] op_sel:[0,0,1]")
+VICTIM(t_add_lo_from_hi_s1, "v_pk_add_f32 v[10:11], v[14:15], v[16:17] op_sel:[0,1]")
+VICTIM(t_mov_lo_from_hi, "v_pk_mov_b32 v[10:11], v[14:15], v[16:17] op_sel:[1,0]")
+VICTIM(t_mov_plain, "v_pk_mov_b32 v[10:11], v[14:15], v[16:17]")
+VICTIM(t_scalar_mul, "v_mul_f32 v10, v14, v17\n v_mul_f32 v11, v15, v17")
+
+__device__ __forceinline__ void aggressor_mfma(int iters) {
+  asm volatile(
+      "v_mov_b32 v20, 0x3f803f80\n v_mov_b32 v21, 0x3f803f80\n v_mov_b32 v22, 0x3f803f80\n v_mov_b32 v23, 0x3f803f80\n"
+      "v_mov_b32 v24, 0\n v_mov_b32 v25, 0\n v_mov_b32 v26, 0\n v_mov_b32 v27, 0\n v_mov_b32 v28, 0\n v_mov_b32 v29, 0\n v_mov_b32 v30, 0\n v_mov_b32 v31, 0\n"
+      "v_mov_b32 v32, 0\n v_mov_b32 v33, 0\n v_mov_b32 v34, 0\n v_mov_b32 v35, 0\n v_mov_b32 v36, 0\n v_mov_b32 v37, 0\n v_mov_b32 v38, 0\n v_mov_b32 v39, 0\n"
+      "s_mov_b32 s21, %0\n s_nop 4\n"
+      "2:\n"
+      "v_mfma_f32_16x16x32_bf16 v[24:27], v[20:23], v[20:23], v[24:27]\n v_mfma_f32_16x16x32_bf16 v[28:31], v[20:23], v[20:23], v[28:31]\n"
+      "v_mfma_f32_16x16x32_bf16 v[32:35], v[20:23], v[20:23], v[32:35]\n v_mfma_f32_16x16x32_bf16 v[36:39], v[20:23], v[20:23], v[36:39]\n"
+      "v_mfma_f32_16x16x32_bf16 v[24:27], v[20:23], v[20:23], v[24:27]\n v_mfma_f32_16x16x32_bf16 v[28:31], v[20:23], v[20:23], v[28:31]\n"
+      "v_mfma_f32_16x16x32_bf16 v[32:35], v[20:23], v[20:23], v[32:35]\n v_mfma_f32_16x16x32_bf16 v[36:39], v[20:23], v[20:23], v[36:39]\n"
+      "s_sub_u32 s21, s21, 1\n s_cmp_lg_u32 s21, 0\n s_cbranch_scc1 2b\n s_nop 7\n s_nop 7\n s_nop 7\n"
+      :
+      : "s"(iters)
+      : "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36",
+        "v37", "v38", "v39", "s21", "scc", "memory");
+}
+
+// waves 0-3: victims (one per SIMD); waves 4-7: wave (4 + s) shares the SIMD of victim s.  aggr_mask bit s: wave 4 + s
+// runs the MFMA loop (else it exits at once) - so a victim can be tested with the aggressor on ITS SIMD or on another one.
+template <int T>
+__global__ void __launch_bounds__(512) k(Out* out, int iters, int aggr_iters, unsigned aggr_mask, float elo, float ehi) {
+  const int wave = threadIdx.x >> 6;
+  if (wave < 4) {
+    Out o;
+    if (T == 0) t_mul_plain(iters, elo, ehi, o);
+    else if (T == 1) t_mul_lo_from_hi_s1(iters, elo, ehi, o);
+    else if (T == 2) t_mul_lo_from_hi_s0(iters, elo, ehi, o);
+    else if (T == 3) t_mul_hi_from_lo_s1(iters, elo, ehi, o);
+    else if (T == 4) t_mul_hi_from_lo_s0(iters, elo, ehi, o);
+    else if (T == 5) t_fma_lo_from_hi_s1(iters, elo, ehi, o);
+    else if (T == 6) t_fma_hi_from_lo_s1(iters, elo, ehi, o);
+    else if (T == 7) t_fma_lo_from_hi_s2(iters, elo, ehi, o);
+    else if (T == 8) t_add_lo_from_hi_s1(iters, elo, ehi, o);
+    else if (T == 9) t_mov_lo_from_hi(iters, elo, ehi, o);
+    else if (T == 10) t_mov_plain(iters, elo, ehi, o);
+    else t_scalar_mul(iters, elo, ehi, o);
+    if ((threadIdx.x & 63) == 0) out[blockIdx.x * 4 + wave] = o;
+  } else if ((aggr_mask >> (wave - 4)) & 1u) {
+    aggressor_mfma(aggr_iters);
+  }
+}
+
+template <int T>
+static void run(const char* name, float elo, float ehi, unsigned aggr_mask, int iters, int nblocks, Out* d_out, std::vector<Out>& h) {
+  CHECK(hipMemset(d_out, 0, (size_t)nblocks * 4 * sizeof(Out)));
+  hipLaunchKernelGGL(k<T>, dim3(nblocks), dim3(512), 0, 0, d_out, iters, iters * 3, aggr_mask, elo, ehi);
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipMemcpy(h.data(), d_out, (size_t)nblocks * 4 * sizeof(Out), hipMemcpyDeviceToHost));
+  unsigned long long ml = 0, mh = 0; unsigned long long nl[4] = {0, 0, 0, 0}, nh[4] = {0, 0, 0, 0}; float bl = 0, bh = 0;
+  for (int b = 0; b < nblocks; ++b)
+    for (int w = 0; w < 4; ++w) {
+      const Out& o = h[b * 4 + w];
+      ml |= o.lo_mask[0] | ((unsigned long long)o.lo_mask[1] << 32); mh |= o.hi_mask[0] | ((unsigned long long)o.hi_mask[1] << 32);
+      nl[w] += o.nlo; nh[w] += o.nhi;
+      if (o.nlo) bl = o.lo_bad; if (o.nhi) bh = o.hi_bad;
+    }
+  const double evals = (double)nblocks * iters * 16;
+  printf("%-44s aggr SIMDs %x | wrong LOW: evals per victim wave [%llu %llu %llu %llu] of %.0f, lanes %016llx, e.g. %g (want %g) | wrong HIGH: [%llu %llu %llu %llu], lanes %016llx, e.g. %g (want %g)\n",
+         name, aggr_mask, nl[0], nl[1], nl[2], nl[3], evals, ml, bl, elo, nh[0], nh[1], nh[2], nh[3], mh, bh, ehi);
+  fflush(stdout);
+}
+
+int main(int argc, char** argv) {
+  const int iters = argc > 1 ? atoi(argv[1]) : 20000;
+  const int nblocks = argc > 2 ? atoi(argv[2]) : 512;
+  Out* d_out; CHECK(hipMalloc(&d_out, (size_t)nblocks * 4 * sizeof(Out)));
+  std::vector<Out> h((size_t)nblocks * 4);
+  const unsigned masks[3] = {0x0, 0xf, 0x1};      // no aggressor; one on every SIMD; one on SIMD(wave 4) only
+  for (unsigned m : masks) {
+    run<11>("v_mul_f32 x2 (control)", 33, 55, m, iters, nblocks, d_out, h);
+    run<0>("v_pk_mul_f32 (no modifier)", 21, 55, m, iters, nblocks, d_out, h);
+    run<1>("v_pk_mul_f32 op_sel:[0,1]  lo<-src1.hi", 33, 55, m, iters, nblocks, d_out, h);
+    run<2>("v_pk_mul_f32 op_sel:[1,0]  lo<-src0.hi", 35, 55, m, iters, nblocks, d_out, h);
+    run<3>("v_pk_mul_f32 op_sel_hi:[1,0]  hi<-src1.lo", 21, 35, m, iters, nblocks, d_out, h);
+    run<4>("v_pk_mul_f32 op_sel_hi:[0,1]  hi<-src0.lo", 21, 33, m, iters, nblocks, d_out, h);
+    run<5>("v_pk_fma_f32 op_sel:[0,1,0]  lo<-src1.hi", 46, 72, m, iters, nblocks, d_out, h);
+    run<6>("v_pk_fma_f32 op_sel_hi:[1,0,1]  hi<-src1.lo", 34, 52, m, iters, nblocks, d_out, h);
+    run<7>("v_pk_fma_f32 op_sel:[0,0,1]  lo<-src2.hi", 38, 72, m, iters, nblocks, d_out, h);
+    run<8>("v_pk_add_f32 op_sel:[0,1]  lo<-src1.hi", 14, 16, m, iters, nblocks, d_out, h);
+    run<9>("v_pk_mov_b32 op_sel:[1,0]  lo<-src0.hi", 5, 7, m, iters, nblocks, d_out, h);
+    run<10>("v_pk_mov_b32 (no modifier)", 3, 11, m, iters, nblocks, d_out, h);
+  }
+  return 0;
+}

@@ -1,13 +1,15 @@
-"""Parity at BASELINE.json's full size (batch 32, 32x128) through size-independent properties - the CPU oracle takes
-minutes at this size, so the checks here are relations the arithmetic must satisfy by itself: batch independence of the
-per-sample parts of the graph, linearity and adjointness of the convolution kernels, the tone-map round trip, the
-equality of replayed and eagerly issued steps, and the sum rule that makes data parallelism exact."""
+"""Parity at BASELINE.json's full size (batch 32, 32x128).  Two kinds of checks: (1) the training step against the CPU oracle
+directly (`oracle/step.train_step_grads`: ~0.5 s per forward + a few seconds of autograd at this size on 16 threads) in
+both contraction modes, and the 128x512 step at B = 2; (2) size-independent relations the arithmetic must satisfy by
+itself: batch independence of the per-sample parts of the graph, linearity and adjointness of the convolution kernels, the
+tone-map round trip, the equality of replayed and eagerly issued steps, and the sum rule that makes data parallelism
+exact."""
 import numpy as np
 import pytest
 import torch
 
 from conftest import pkg
-from util import assert_close
+from util import assert_close, rel_max, rel_rms
 
 pytestmark = pytest.mark.gpu
 B, H, W = 32, 32, 128
@@ -194,3 +196,146 @@ def test_bench_mode_psnr_at_trained_like_weights(dev):
     # (the subset runs through the GPU graph as a batch of its own: generator.py:160's tf.reduce_max couples the images of a
     # batch, so rows of a 32-image run are NOT comparable with a subset run through the oracle - 47 dB apart when first tried)
     assert p["within_0p05_db"], p
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The full training step (train.py:382-415) at the HEADLINE size against the oracle: the per-tensor
+# comparisons tests/test_train_gpu.py makes at B = 2, at B = 32.
+# ---------------------------------------------------------------------------------------------------------------------
+def _step_vs_oracle(dev, mode, Bsz):
+    from oracle import step as ostep
+    params, synth, trainer, K = pkg("params"), pkg("synth"), pkg("trainer"), pkg("kernels")
+    torch.set_num_threads(max(torch.get_num_threads(), 8))
+    gen = params.init_params(params.generator_spec(), 0); sun = params.init_params(params.sunpose_spec(), 1)
+    dis = params.init_params(params.discriminator_spec(), 2); vgg = params.init_params(params.vgg_spec(), 3)
+    batch = synth.make_batch(Bsz, seed=1234)
+    tr = trainer.Trainer(gen, sun, dis, vgg, device=dev, precise=(mode == "BF16X3"), compute=getattr(K, mode))
+    tt = lambda dd: {k: torch.from_numpy(v) for k, v in dd.items()}
+    ldr, hdr, gt = (torch.from_numpy(batch[k]) for k in ("ldr", "hdr_t", "sunpose_gt"))
+    losses, gg, gs, gd, sg, sd, outs = ostep.train_step_grads(tt(gen), tt(sun), tt(dis), tt(vgg), ldr, hdr, gt)
+    out = tr.step(ldr.to(dev), hdr.to(dev), gt.to(dev), update=False)
+    return tr, tr.loss_dict(), losses, gg, gs, sg, out, outs, dis, (ldr, hdr)
+
+
+LOSS_NAMES = (("kl", "kl"), ("perceptual", "perceptual"), ("dog", "dog"), ("l1", "l1"), ("adv", "adv"),
+              ("disc_generated", "generated"), ("disc_real", "real"), ("total_gen_loss", "total_gen_loss"),
+              ("total_disc_loss", "total_disc_loss"))
+
+
+def _grad_errors(tr, gg, gs):
+    """(rel max err, rel rms err, elements, name) of every generator-step gradient tensor that is not an exactly-zero bias."""
+    rows = []
+    for prefix, ref in (("gen.", gg), ("sun.", gs)):
+        for k, v in ref.items():
+            g = tr.gs.g[prefix + k]
+            is_bias = k.endswith(".b") or k.endswith("bias_deconv2d")
+            if is_bias and not k.startswith("conv1_f") and not k.startswith("conv1_u"):
+                wk = k[:-2] + ".w" if k.endswith(".b") else k.replace("bias_deconv2d", "kernel_deconv2d")
+                scale = float(ref[wk].abs().max()) * float(np.prod(ref[wk].shape[:3]))
+                assert float(g.abs().max()) <= 1e-4 * scale, (prefix + k, float(g.abs().max()), scale)
+                continue
+            rows.append((rel_max(g, v), rel_rms(g, v), int(v.numel()), prefix + k))
+    return rows
+
+
+def _cosine(tr, gg, gs):
+    dot = na = nb = 0.0
+    for prefix, ref in (("gen.", gg), ("sun.", gs)):
+        for k, v in ref.items():
+            g = tr.gs.g[prefix + k].cpu().double()
+            dot += float((g * v.double()).sum()); na += float((g * g).sum()); nb += float((v.double() ** 2).sum())
+    return dot / (na * nb) ** 0.5, (na / nb) ** 0.5
+
+
+def test_train_step_b32_fp32_class_against_the_oracle(dev):
+    """BF16X3 (the fp32-class mode), B = 32, 32x128: every loss term to 2e-3, the prediction to 1e-3 of its maximum, every
+    generator / sun-pose gradient tensor to 5e-2 of its maximum (median tensor 3e-3: what is left are the discrete effects
+    test_train_gpu.py lists - sign() of the L1 / DoG terms, ReLU / max-pool masks, Grad-CAM arg-max ties), BatchNorm moving
+    statistics to 1e-4, and the discriminator step at OUR prediction (the generated pass is chaotic in its input)."""
+    from oracle import step as ostep
+    tr, got, losses, gg, gs, sg, out, outs, dis, (ldr, hdr) = _step_vs_oracle(dev, "BF16X3", B)
+    for k, rk in LOSS_NAMES:
+        assert abs(got[k] - losses[rk]) <= 2e-3 * abs(losses[rk]) + 1e-6, (k, got[k], losses[rk])
+    # (1e-3 at B = 2; the maximum over 16x the pixels sits higher - measured 1.1e-3, on the alpha ramp of saturated pixels
+    # (width 0.12 on the decompressed value, train.py:258-261) - while the rms error stays two orders below)
+    print("B = 32 BF16X3 y_final_gamma: rel max %.3e, rel rms %.3e" % (rel_max(out["y_final_gamma"], outs["y_final_gamma"]),
+                                                                  rel_rms(out["y_final_gamma"], outs["y_final_gamma"])))
+    assert_close(out["y_final_gamma"], outs["y_final_gamma"], 2.5e-3, "y_final_gamma, B = 32 (training mode)")
+    assert rel_rms(out["y_final_gamma"], outs["y_final_gamma"]) < 1e-4
+    rows = sorted(_grad_errors(tr, gg, gs), reverse=True)
+    print("B = 32 BF16X3 worst gradient tensors (rel max, rel rms, elements, name):", rows[:8])
+    assert rows[0][0] < 5e-2, rows[:5]
+    assert np.median([e for e, _, _, _ in rows]) < 3e-3
+    cos, ratio = _cosine(tr, gg, gs)
+    assert cos > 0.9999 and abs(ratio - 1.0) < 2e-3, (cos, ratio)
+    for k, v in sg.items():
+        assert_close(tr.gs.w["gen." + k], v, 1e-4, "gen " + k)
+    dr = {k: torch.from_numpy(v).clone().requires_grad_("moving" not in k) for k, v in dis.items()}
+    stats = {}
+    dl = ostep.discriminator_losses(dr, ldr, hdr, out["y_final_lin"].cpu(), training=True, new_stats=stats)
+    names = [k for k in dr if "moving" not in k]
+    for k, v in zip(names, torch.autograd.grad(dl["total_disc_loss"], [dr[k] for k in names])):
+        assert_close(tr.ds.g["dis." + k], v, 1e-3, "dis grad " + k)
+    for k, v in stats.items():
+        assert_close(tr.ds.w["dis." + k], v, 1e-4, "dis " + k)
+
+
+def test_train_step_b32_bench_mode_against_the_oracle(dev):
+    """The mode bench.py times (one bf16 MFMA product, fp32 accumulation), B = 32, 32x128, against the fp32 oracle.
+    Loss terms that do not pass through the discriminator: 2e-2 (measured: KL 5e-5, perceptual 1e-4, DoG 6e-3, L1 6e-3,
+    real-pair term 6e-4).  The three terms that evaluate the randomly initialised discriminator AT THE PREDICTION (adv,
+    disc_generated and the totals that contain them) are chaotic in that input - a 1e-4 perturbation of y inside the oracle
+    moves its own discriminator gradients by 2-8 %, tests/test_train_gpu.py - so they are checked twice: against the oracle's
+    step at 6e-2 (measured 3.3 % / 4.0 %), and against the oracle's discriminator evaluated at OUR prediction at 2e-2, which
+    is the bf16 error of the discriminator itself.  Prediction PSNR > 40 dB, whole-gradient cosine > 0.98, norm ratio within
+    5 %; the TEN LARGEST gradient tensors (99.6 % of the 55.6 M trainable scalars) each within a relative rms error of 0.25
+    (bf16 operand rounding, 2^-9 per product term, through ~30 layers of backward pass and the discrete masks)."""
+    from oracle import networks as N
+    from oracle import step as ostep
+    tr, got, losses, gg, gs, sg, out, outs, dis, (ldr, hdr) = _step_vs_oracle(dev, "BF16", B)
+    print("B = 32 bf16 losses (got, oracle):", {k: (round(got[k], 5), round(float(losses[rk]), 5)) for k, rk in LOSS_NAMES})
+    through_d = ("adv", "disc_generated", "total_gen_loss", "total_disc_loss")
+    for k, rk in LOSS_NAMES:
+        tol = 6e-2 if k in through_d else 2e-2
+        assert abs(got[k] - losses[rk]) <= tol * abs(losses[rk]) + 1e-6, (k, got[k], losses[rk])
+    # the discriminator terms on identical inputs: the oracle's discriminator at the prediction this step produced
+    y = out["y_final_lin"].cpu()
+    dd = {k: torch.from_numpy(v) for k, v in dis.items()}
+    adv_o = float(((N.discriminator(dd, ldr, y, training=False) - 1.0) ** 2).mean())
+    dl = ostep.discriminator_losses(dd, ldr, hdr, y, training=True, new_stats={})
+    print("   at OUR prediction: adv %.5f (oracle %.5f), disc_generated %.5f (oracle %.5f)" % (got["adv"], adv_o, got["disc_generated"],
+                                                                                           float(dl["generated"])))
+    assert abs(got["adv"] - adv_o) <= 2e-2 * abs(adv_o), (got["adv"], adv_o)
+    assert abs(got["disc_generated"] - float(dl["generated"])) <= 2e-2 * abs(float(dl["generated"])), (got["disc_generated"], float(dl["generated"]))
+    a, b = out["y_final_gamma"].cpu().double(), outs["y_final_gamma"].double()
+    psnr = float(10 * torch.log10(b.abs().max() ** 2 / ((a - b) ** 2).mean()))
+    cos, ratio = _cosine(tr, gg, gs)
+    rows = _grad_errors(tr, gg, gs)
+    big = sorted(rows, key=lambda r: -r[2])[:10]
+    print("B = 32 bf16: psnr %.1f dB, gradient cosine %.5f, norm ratio %.4f" % (psnr, cos, ratio))
+    print("ten largest tensors (rel max, rel rms, elements, name):", big)
+    assert psnr > 40.0 and cos > 0.98 and abs(ratio - 1.0) < 5e-2, (psnr, cos, ratio)
+    assert max(r[1] for r in big) < 0.25, big
+
+
+def test_hires_train_step_b2_against_the_oracle(dev):
+    """128x512 (configs[4]'s size; sun-pose outputs external), B = 2, BF16X3: the per-tensor checks of
+    tests/test_hires_gpu.py's B = 1 case with a batch (BatchNorm statistics over two samples, reduce_max over the batch)."""
+    from oracle import step as ostep
+    import test_hires_gpu as TH
+    torch.set_num_threads(max(torch.get_num_threads(), 8))
+    tr, (gen, _, dis, vgg) = TH._hires_trainer(dev, "BF16X3", False)
+    ldr, hdr = TH._inputs(2, seed=45)
+    cmf, gt, cams = TH._sun_inputs(2, seed=23)
+    ext = [torch.from_numpy(cmf)] + [torch.from_numpy(c) for c in cams]
+    losses, gg, gs, gd, sg, sd, outs = ostep.train_step_grads(TH._tt(gen), None, TH._tt(dis), TH._tt(vgg), torch.from_numpy(ldr),
+                                                              torch.from_numpy(hdr), torch.from_numpy(gt), sunpose_external=ext)
+    d = lambda x: torch.from_numpy(x).to(dev)
+    out = tr.step(d(ldr), d(hdr), d(gt), update=False, cmf=d(cmf), cams=[d(c) for c in cams])
+    got = tr.loss_dict()
+    for k, rk in LOSS_NAMES[:8]:
+        assert abs(got[k] - losses[rk]) <= 2e-3 * abs(losses[rk]) + 1e-6, (k, got[k], losses[rk])
+    assert_close(out["y_final_gamma"], outs["y_final_gamma"], 1e-3, "y_final_gamma 128x512, B = 2")
+    rows = sorted(_grad_errors(tr, gg, {}), reverse=True)
+    print("128x512 B = 2 worst gradient tensors:", rows[:6])
+    assert rows[0][0] < 5e-2 and np.median([e for e, _, _, _ in rows]) < 3e-3, rows[:5]

@@ -334,6 +334,44 @@ def test_fc_wgrad_bf16_and_fused_update(dev):
     assert torch.equal(fresh.nat_hi.view(torch.int16), pfb.nat_hi.view(torch.int16))
 
 
+@pytest.mark.parametrize("M,Kd,N", [(256, 512, 1024), (256, 8192, 256), (255, 160, 512), (64, 256, 256)])
+def test_fused_dense_update_at_the_gathered_row_count(dev, M, Kd, N):
+    """hdrsky_rmsprop_fc_fused with M = 256 operand rows - what the `gather_dense` exchange hands it at 8 replicas x batch 32
+    (parallel.py) - against the Keras-2 RMSprop formula in float64 on the bf16-rounded operands
+    (train.py:201-202; sunpose_net.py:48-51): g = gscale * bf16(x)^T bf16(dy) with fp32 accumulation, ms <- 0.9 ms + 0.1 g^2,
+    w <- w - lr g / (sqrt(ms) + 1e-7); row-strided operand views (columns of one gathered buffer), a reduction length of fc1's
+    size, a ragged row count; the bf16 images written by the update equal a fresh pack of the new weights; the bias gradient
+    is the fp32 column sum of dy."""
+    K = pkg("kernels")
+    rng = np.random.default_rng(11)
+    wide = torch.from_numpy(rng.standard_normal((M, Kd + N + 16)).astype(np.float32)).to(dev)
+    x, dy = wide[:, 8:8 + Kd], wide[:, 8 + Kd:8 + Kd + N]
+    dy.mul_(0.05)
+    w0 = torch.from_numpy(rng.standard_normal((Kd, N)).astype(np.float32)).to(dev)
+    ms0 = torch.from_numpy(rng.uniform(0, 1e-2, (Kd, N)).astype(np.float32)).to(dev)
+    lr, gscale = 1e-3, 1.0 / 8
+    w, ms, pf = w0.clone(), ms0.clone(), K.PackedFC(w0, precise=False)
+    db = torch.empty(N, device=dev)
+    K.rmsprop_fc_fused(w, ms, x, dy, pf, lr, db=db, gscale=gscale)
+    bf = lambda t: t.to(torch.bfloat16).to(torch.float64)
+    g = gscale * (bf(x).T @ bf(dy))
+    ms_ref = 0.9 * ms0.double() + 0.1 * g * g
+    w_ref = w0.double() - lr * g / (ms_ref.sqrt() + 1e-7)
+    # fp32 accumulation over M <= 256 rows in MFMA order: 1e-6-class on g; the update divides by sqrt(ms) ~ 0.03-0.1
+    assert_close(ms, ms_ref, 2e-6, "fused RMSprop M=%d: slots" % M)
+    assert float((w.double() - w_ref).abs().max()) <= 2e-6 * float(w_ref.abs().max()) + 1e-7, "fused RMSprop M=%d: weights" % M
+    assert_close(db, dy.double().sum(0), 2e-6, "fused RMSprop M=%d: bias gradient" % M)
+    fresh = K.PackedFC(w, precise=False)
+    assert torch.equal(fresh.pk_hi.view(torch.int16), pf.pk_hi.view(torch.int16))
+    assert torch.equal(fresh.nat_hi.view(torch.int16), pf.nat_hi.view(torch.int16))
+    # and against the materialised path (hdrsky_fc_wgrad_bf16 + hdrsky_rmsprop_fc) on the same operands
+    g2 = torch.empty_like(w0); gb = torch.empty(N, device=dev)
+    K.fc_wgrad_bf16(x, dy, g2, gb)
+    wa, msa, pfa = w0.clone(), ms0.clone(), K.PackedFC(w0, precise=False)
+    K.rmsprop_fc(wa, g2, msa, pfa, lr, gscale=gscale)
+    assert_close(w, wa, 1e-6, "fused vs materialised: weights"); assert_close(ms, msa, 2e-6, "fused vs materialised: slots")
+
+
 def test_fused_dense_step_equals_materialised_step(dev):
     """Trainer(fused_dense=True) (the HDRSKY_BF16 default): two updating steps leave the same weights and RMSprop slots
     as the trainer that writes the Dense gradients out and reads them back; the Dense kernel gradient buffers of the
