@@ -56,6 +56,8 @@ SIGNATURES = {
     "hdrsky_version": (ctypes.c_char_p, []),
     "hdrsky_abi_version": (c_int, []),
     "hdrsky_sizeof": (c_size_t, [ctypes.c_char_p]),
+    "hdrsky_hooks_reload": (c_int, []),
+    "hdrsky_experiments_enabled": (c_int, []),
     "hdrsky_conv_desc_init": (c_int, [ctypes.POINTER(ConvDesc)] + [c_int] * 10),
     "hdrsky_conv_desc_init_dgrad": (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvDesc)]),
     "hdrsky_conv_packed_elems": (c_size_t, [c_int] * 4),

@@ -17,7 +17,10 @@
 
 #include <type_traits>
 
+#include <atomic>
+
 #include "common.h"
+#include "hooks.h"
 
 namespace {
 
@@ -828,7 +831,7 @@ int launch_conv(ConvKArgs& a, hipStream_t stream) {
   if (DB && roundup(lds, 16) + out_bytes <= 80 * 1024) { a.off_out = roundup(lds, 16); lds = a.off_out + out_bytes; }   // (two workgroups per CU must still fit)
   if (lds > 160 * 1024) return HDRSKY_EUNSUPPORTED;
   auto kern = conv_igemm_kernel<WM, WN, MI, NI, TW, NARROW, PRECISE, DB, PH>;
-  static int max_lds_set = 0;
+  static std::atomic<int> max_lds_set{0};
   if (lds > max_lds_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
@@ -868,10 +871,14 @@ int dispatch_tile(ConvKArgs& a, const TileCfg& t, hipStream_t s) {
 // Tile heuristic: widest N block the layer fills, then the largest pixel tile that still
 // yields >= ~1 workgroup per CU (256 CUs), preferring more workgroups for small problems.
 TileCfg choose_tile(const hdrsky_conv_desc* d) {
-  if (const char* e = getenv("HDRSKY_TILE")) {  // tuning hook: "wm,wn,mi,ni,tw"
-    TileCfg o;
-    o.db = 0;
-    if (sscanf(e, "%d,%d,%d,%d,%d,%d", &o.wm, &o.wn, &o.mi, &o.ni, &o.tw, &o.db) >= 5) return o;
+  const HdrskyHooks& hk = hdrsky_hooks();
+  auto hooked = [](const HdrskyTileHook& h, TileCfg& t) {   // a tuning hook (HDRSKY_EXPERIMENTS=1) replaces the table's entry
+    if (h.set) t = TileCfg{h.v[0], h.v[1], h.v[2], h.v[3], h.v[4], h.v[5]};
+    return h.set != 0;
+  };
+  {
+    TileCfg o{};
+    if (hooked(hk.tile, o)) return o;          // HDRSKY_TILE: every layer on one tile
   }
   // Measured on MI355X (profiles/microbench_conv.py, B=32, 32x128 network): these layers are bound by
   // per-CU operand traffic and instruction issue, not MFMA, so the table prefers 8-wave workgroups
@@ -883,10 +890,7 @@ TileCfg choose_tile(const hdrsky_conv_desc* d) {
   if (tw == 16) {
     if (d->Cout >= 128) {
       t = TileCfg{1, 8, 2, 1, 16, 1};                                  // 32 px x 128 ch, 8 waves (the 4x16-pixel layers)
-      if (const char* e = getenv("HDRSKY_TILE_T16")) {                 // A/B hook for this class inside the step
-        TileCfg o; o.db = 0;
-        if (sscanf(e, "%d,%d,%d,%d,%d,%d", &o.wm, &o.wn, &o.mi, &o.ni, &o.tw, &o.db) >= 5) t = o;
-      }
+      hooked(hk.tile_t16, t);                                          // A/B hook for this class inside the step
     }
     else if (d->Cout >= 64) t = (d->Ho >= 4) ? TileCfg{1, 4, 4, 1, 16, 1} : TileCfg{1, 4, 2, 1, 16, 1};
     else if (d->Cout > 16) t = TileCfg{2, 2, 2, 1, 16, 0};
@@ -905,10 +909,7 @@ TileCfg choose_tile(const hdrsky_conv_desc* d) {
     // csrc/Makefile, DESIGN.md section 5.1 - and is gone from the library.)
     if (d->Cout >= 128 && M >= 32768) {
       t = TileCfg{2, 4, 4, 2, 32, 1};
-      if (const char* e = getenv("HDRSKY_TILE_WIDE")) {                // A/B hook for this class
-        TileCfg o; o.db = 0;
-        if (sscanf(e, "%d,%d,%d,%d,%d,%d", &o.wm, &o.wn, &o.mi, &o.ni, &o.tw, &o.db) >= 5) t = o;
-      }
+      hooked(hk.tile_wide, t);                                         // A/B hook for this class
     }
   } else if (d->Cout > 16) {
     // 256 px x 32 ch; in BF16X3 the double-buffered hi+lo weight ring of the LDS variant does not fit beside the
@@ -919,11 +920,7 @@ TileCfg choose_tile(const hdrsky_conv_desc* d) {
     // 7x7 32->32 at 128x512, batch 8: 88 -> 72 us; with the 16-channel class below: 128x512 training step 5.72 -> 5.66 ms,
     // forward + losses 2.99 -> 2.93 ms (profiles/r03_tile_hires_ab.txt)
     if (M >= 262144) t = TileCfg{4, 2, 4, 1, 32, 1};
-    if (M >= 65536 && !narrow && d->compute != HDRSKY_BF16X3)
-      if (const char* e = getenv("HDRSKY_TILE_C32")) {                 // A/B hook for this class inside the step
-        TileCfg o; o.db = 0;
-        if (sscanf(e, "%d,%d,%d,%d,%d,%d", &o.wm, &o.wn, &o.mi, &o.ni, &o.tw, &o.db) >= 5) t = o;
-      }
+    if (M >= 65536 && !narrow && d->compute != HDRSKY_BF16X3) hooked(hk.tile_c32, t);   // A/B hook for this class
   } else {
     // Cout <= 16 (the 3-channel output convs).  Round 1 measured the 32-wide column block of the LDS-ring variant (512 px x 32 ch,
     // zero-padded weights) faster than its 16-wide one; the direct-B loop on 256 px x 16 ch beats both: 7x7 32->3 at 32x128,
@@ -932,11 +929,7 @@ TileCfg choose_tile(const hdrsky_conv_desc* d) {
     if (M >= 262144 && d->compute != HDRSKY_BF16X3) t = TileCfg{8, 1, 4, 1, 32, 1};
     else if (M >= 65536) t = d->compute == HDRSKY_BF16X3 ? TileCfg{4, 2, 4, 1, 32, 1} : TileCfg{4, 1, 4, 1, 32, 1};
     else t = TileCfg{4, 1, 2, 1, 32, 0};
-    if (M >= 65536 && d->compute != HDRSKY_BF16X3)
-      if (const char* e = getenv("HDRSKY_TILE_C16")) {
-        TileCfg o; o.db = 0;
-        if (sscanf(e, "%d,%d,%d,%d,%d,%d", &o.wm, &o.wn, &o.mi, &o.ni, &o.tw, &o.db) >= 5) t = o;
-      }
+    if (M >= 65536 && d->compute != HDRSKY_BF16X3) hooked(hk.tile_c16, t);
   }
   return t;
 }
@@ -999,7 +992,11 @@ __global__ void __launch_bounds__(256) conv_dot1_kernel(const ConvKArgs a) {
       for (int j = 0; j < 8; ++j) {
         float w = __builtin_bit_cast(float, (j & 1) ? (hw[j >> 1] & 0xffff0000u) : (hw[j >> 1] << 16));
         if (a.wlo != nullptr) w += __builtin_bit_cast(float, (j & 1) ? (lw[j >> 1] & 0xffff0000u) : (lw[j >> 1] << 16));
-        const float t = affine ? leaky(in[j] * sc8[j] + sh8[j], a.in_slope) : leaky(in[j], a.in_slope);
+        float t = affine ? leaky(in[j] * sc8[j] + sh8[j], a.in_slope) : leaky(in[j], a.in_slope);
+        // the arithmetic contract of hdrsky_conv2d_fwd: in the single-product mode the staged activation is a bf16 value (what
+        // the MFMA path and this layer's data / weight gradients multiply); the two-plane mode multiplies the fp32 activation
+        // by hi + lo - the MFMA path's hi*hi + lo*hi + hi*lo plus the lo*lo term it drops (2^-16 relative)
+        if (a.wlo == nullptr) t = bf2f(f2bf(t));
         acc += t * w;
       }
     }
@@ -1016,7 +1013,7 @@ __global__ void __launch_bounds__(256) conv_dot1_kernel(const ConvKArgs a) {
 // form); HDRSKY_NO_PHASE=1 keeps the zero-stuffed operand (A/B and bit-identity tests).
 static bool phase_applies(const hdrsky_conv_desc* d) {
   return d->dilate == 2 && d->Cin > 8 && d->upsample == 1 && d->stride == 1 && !d->want_stats && d->compute != HDRSKY_BF16X3 &&
-         !getenv("HDRSKY_NO_PHASE");   // (the two-plane mode keeps the zero-stuffed form: no phase instantiations of it)
+         !hdrsky_hooks().no_phase;     // (the two-plane mode keeps the zero-stuffed form: no phase instantiations of it)
 }
 // the problem one phase-form launch tiles: four phase grids of ceil(Ho/2) x ceil(Wo/2) pixels per sample
 static hdrsky_conv_desc phase_view(const hdrsky_conv_desc* d) {
@@ -1028,7 +1025,7 @@ static hdrsky_conv_desc phase_view(const hdrsky_conv_desc* d) {
 static bool dot1_applies(const hdrsky_conv_desc* d, const float* residual) {
   return d->Cout == 1 && d->Cin >= 32 && (d->Cin % 32) == 0 && d->upsample == 1 && d->dilate == 1 && !d->want_stats && !residual &&
          !d->x_bf16 && !d->y_bf16 && d->out_slope == 1.f && !d->final_relu && d->res_mode == 0 &&
-         d->in_mode != HDRSKY_IN_PARTIALS && !getenv("HDRSKY_NO_DOT1");
+         d->in_mode != HDRSKY_IN_PARTIALS && !hdrsky_hooks().no_dot1;
 }
 
 }  // namespace
@@ -1172,7 +1169,9 @@ int hdrsky_conv2d_fwd(const hdrsky_conv_desc* d, const float* x, const void* w_h
     const hdrsky_conv_desc pv = phase_view(d);
     const TileCfg tp = choose_tile(&pv);
     const int rc = dispatch_tile<false, false, true>(p, tp, s);
-    if (rc != HDRSKY_EPHASE_FALLBACK) return rc;
+    // the phase form declined (odd filter over several channel groups) or has no instantiation / LDS plan for the tile of
+    // its phase grid: the zero-stuffed form below computes the same gradient
+    if (rc != HDRSKY_EPHASE_FALLBACK && rc != HDRSKY_EUNSUPPORTED) return rc;
   }
   const TileCfg t = choose_tile(d);
   if (narrow) return precise ? dispatch_tile<true, true>(a, t, s) : dispatch_tile<true, false>(a, t, s);

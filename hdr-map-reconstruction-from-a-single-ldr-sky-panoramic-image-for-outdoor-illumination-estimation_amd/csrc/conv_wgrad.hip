@@ -14,7 +14,10 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include <atomic>
+
 #include "common.h"
+#include "hooks.h"
 
 namespace {
 
@@ -1309,7 +1312,7 @@ struct WgradVariant {
   }
   static int launch(MultiArgs& m, int lds, hipStream_t stream) {
     auto kern = conv_wgrad_kernel<TPW, CBF, OBF, TW, NARROW, PRECISE, UP, NW, CS, OS, XR, BM>;
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};
     if (!attr_set) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024) != hipSuccess)
@@ -1426,7 +1429,7 @@ static bool same_geo(const Geo& p, const Geo& q) {
 // ---- v2 host side -------------------------------------------------------------------------------------------------------
 static bool v2_eligible(const hdrsky_wgrad_job& j) {
   const hdrsky_conv_desc* d = &j.desc;
-  static const int s2min = getenv("HDRSKY_WGRAD2_S2MIN") ? atoi(getenv("HDRSKY_WGRAD2_S2MIN")) : 32;   // A/B hook
+  const int s2min = hdrsky_hooks().wgrad2_s2min;   // (tuning hook; 32)
   return j.x_bf16 && j.dy_bf16 && j.da_ksize == 0 && d->compute == HDRSKY_BF16 && d->upsample == 1 && d->dilate == 1 &&
          // (stride 2: a tile's input patch is ~4x its output and every pixel of it is copied - such layers run on 64-pixel
          // tiles (wg2_prepare); measured, batch 32: 1.25-1.8x the register-staged kernel, 1.9-2.5x at 128x512)
@@ -1479,7 +1482,7 @@ static int wg2_prepare(Wg2Args& a, const hdrsky_wgrad_job& j, int wg_target) {
   const int base = a.cblocks * a.oblocks * a.ntg;
   int chunks = (wg_target + base / 2) / base;
   const long dw_bytes = (long)a.ntaps * a.Cin * a.Cout * 4;
-  static const int mint = getenv("HDRSKY_WGRAD2_MINT") ? atoi(getenv("HDRSKY_WGRAD2_MINT")) : 2;   // A/B hook
+  const int mint = hdrsky_hooks().wgrad2_mint;   // (tuning hook; 2)
   if (chunks > a.ntiles / mint) chunks = a.ntiles / mint;
   if ((long)chunks * dw_bytes > (34L << 20)) chunks = (int)((34L << 20) / dw_bytes);
   if (chunks < 1) chunks = 1;
@@ -1491,7 +1494,7 @@ static int wg2_prepare(Wg2Args& a, const hdrsky_wgrad_job& j, int wg_target) {
 
 static int wg2_launch(Multi2Args& m, int lds, hipStream_t stream) {
   auto kern = conv_wgrad2_kernel<WG2_UPW>;
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return HDRSKY_ELAUNCH;
@@ -1509,7 +1512,7 @@ extern "C" void hdrsky_debug_wgrad2_stamps(void* buf) { g_wg2_stamps = (unsigned
 // in done[].  Jobs the kernel cannot take (LDS budget, geometry) stay unmarked: the caller's v1 path handles them.
 static int wgrad2_groups(const hdrsky_wgrad_job* jobs, int njobs, bool* done, float* ws, size_t ws_floats, size_t* ws_used,
                          bool plan_only, void* stream) {
-  const int wg_hook = getenv("HDRSKY_WGRAD2_WGS") ? atoi(getenv("HDRSKY_WGRAD2_WGS")) : 0;
+  const int wg_hook = hdrsky_hooks().wgrad2_wgs;   // (tuning hook; 0 = by work share)
   const int wg_total = wg_hook > 0 ? wg_hook : 256;
   int members[256], nm = 0;
   double work[256];
@@ -1654,7 +1657,7 @@ static int wg3_prepare(Wg3Args& a, const hdrsky_wgrad_job& j, int wg_target) {
   a.off_ss = 2 * a.stage_bytes;
   if (a.off_ss < 512 * 8 * 4) a.off_ss = 512 * 8 * 4;   // the bias reduction's scratch overlays the stages
   int chunks = wg_target / a.nblocks;
-  static const int minpx = getenv("HDRSKY_WGRAD3_MINPX") ? atoi(getenv("HDRSKY_WGRAD3_MINPX")) : 256;   // A/B hook
+  const int minpx = hdrsky_hooks().wgrad3_minpx;   // (tuning hook; 256)
   // at least this many pixels per workgroup (512: the 4x4 stride-2 first layers ran on 64 workgroups - 26.7 -> 21.9 us at 256,
   // the 512->1 head 18.6 -> 14.0; 128 is no better)
   const int mint = minpx / a.BM > 0 ? minpx / a.BM : 1;
@@ -1674,7 +1677,7 @@ static int wg3_prepare(Wg3Args& a, const hdrsky_wgrad_job& j, int wg_target) {
 template <int D, int WI, int NI, int CPR>
 static int wg3_launch_as(Multi3Args& m, int lds, hipStream_t stream) {
   auto kern = conv_wgrad3_kernel<D, WI, NI, CPR, WG3_UPW>;
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)
       return HDRSKY_ELAUNCH;
@@ -1693,7 +1696,7 @@ static int wg3_launch(int variant, Multi3Args& m, int lds, hipStream_t stream) {
 // Launches (or, plan_only, sizes) the narrow-layer kernel + the shared reduce for the jobs it takes; marks them in done[].
 static int wgrad3_groups(const hdrsky_wgrad_job* jobs, int njobs, bool* done, float* ws, size_t ws_floats, size_t* ws_used,
                          bool plan_only, void* stream) {
-  const int wg_each = getenv("HDRSKY_WGRAD3_WGS") ? atoi(getenv("HDRSKY_WGRAD3_WGS")) : 256;   // tuning hook: workgroups per layer
+  const int wg_each = hdrsky_hooks().wgrad3_wgs;   // (tuning hook: workgroups per layer; 256)
   int all[256], na = 0, cls[256];
   bool deep8 = false;
   for (int k = 0; k < njobs; ++k) {
@@ -1772,20 +1775,21 @@ static int wgrad_multi_impl(const hdrsky_wgrad_job* jobs, int njobs, float* ws, 
   // (profiles/ab_bench.sh, HDRSKY_WGRAD=alone,0,group): a launch there does not have the chip to itself, and every pixel
   // chunk costs a partial slab that the reduce launch reads back - alone 256 (the best value for a launch timed on its own,
   // profiles/microbench_wgrad.py) -> 128 shortened the step by 3 %; 96 / 64 and group 160 / 224 / 256 were worse.
-  int wg_hook = 0, force_small = 0, wg_hook_group = 0;
-  if (const char* e = getenv("HDRSKY_WGRAD")) sscanf(e, "%d,%d,%d", &wg_hook, &force_small, &wg_hook_group);   // tuning hook
+  const HdrskyHooks& hk = hdrsky_hooks();
+  const int wg_hook = hk.wgrad_set ? hk.wgrad[0] : 0, force_small = hk.wgrad_set ? hk.wgrad[1] : 0,
+            wg_hook_group = hk.wgrad_set ? hk.wgrad[2] : 0;                                   // (tuning hook HDRSKY_WGRAD)
   // wide stride-1 layers use 64x64-channel blocks when at least three of them share a launch
   Geo geo[256];
   bool done[256];
   for (int i = 0; i < njobs; ++i) done[i] = false;
   // layers with two final bf16 operands: the LDS-DMA ring kernel (deterministic mode only; HDRSKY_WGRAD2=0: A/B hook)
-  const bool v2_on = !(getenv("HDRSKY_WGRAD2") && atoi(getenv("HDRSKY_WGRAD2")) == 0);
+  const bool v2_on = hk.wgrad2 != 0;
   if (v2_on && (ws != nullptr || plan_only)) {
     const int rc2 = wgrad2_groups(jobs, njobs, done, ws, ws_floats, &ws_used, plan_only, stream);
     if (rc2 != HDRSKY_OK) return rc2;
   }
   // layers with a narrow side (<= 8 input or <= 4 output channels): their own kernel (HDRSKY_WGRAD3=0: A/B hook)
-  const bool v3_on = !(getenv("HDRSKY_WGRAD3") && atoi(getenv("HDRSKY_WGRAD3")) == 0);
+  const bool v3_on = hk.wgrad3 != 0;
   if (v3_on && (ws != nullptr || plan_only)) {
     const int rc3 = wgrad3_groups(jobs, njobs, done, ws, ws_floats, &ws_used, plan_only, stream);
     if (rc3 != HDRSKY_OK) return rc3;

@@ -9,7 +9,10 @@
 #include <cmath>
 #include <cstdlib>
 
+#include <atomic>
+
 #include "common.h"
+#include "hooks.h"
 
 namespace {
 
@@ -549,15 +552,15 @@ static int da_region_plan(DaArgs& a, int C, int nwv, int km, const int* spans, i
   // first row of every group, [5][tiles_x].  Larger groups re-read fewer source rows (a 7x7 tile of 64 pixels stages 13
   // rows of 128 pixels: 26 x its own size; 8 tiles sharing 16 rows: 4 x) - taken while the launch keeps >= 256 workgroups.
   if (!spans || !a.row_lo || (C % 32) != 0) return 0;
-  int hook_level = -1;
-  if (const char* e = getenv("HDRSKY_DA_REGION")) { if (atoi(e) == 0) return 0; }   // tuning / test hooks
-  if (const char* e = getenv("HDRSKY_DA_GROUP")) hook_level = atoi(e);
+  const HdrskyHooks& hk = hdrsky_hooks();
+  if (hk.da_region == 0) return 0;                          // switch: never the region kernels
+  const int hook_level = hk.da_group;                       // tuning hook: tiles per region (-1: one)
   const int nq = C / 8, nt = nwv * 64;
   if ((nq & (nq - 1)) || (a.W & (a.W - 1))) return 0;           // the item / pixel indexing wants powers of two
   a.w_sh = __builtin_ctz(a.W);
   // 32-pixel tiles when 64-pixel tiles would leave half the CUs without a workgroup (the 8x32 / 4x16 maps at batch 32)
   a.tm = (B * a.tiles_x * a.nblocks <= 128 && hook_level <= 0) ? 32 : 64;
-  if (const char* e = getenv("HDRSKY_DA_TM")) { const int t = atoi(e); if (t == 32 || t == 64) a.tm = t; }
+  if (hk.da_tm == 32 || hk.da_tm == 64) a.tm = hk.da_tm;
   if (a.stats) a.tm = 64;       // the InstanceNorm partials are per 64-pixel tile (one writer per slot)
   if (a.tm == 32) a.tiles_x = cdiv(a.H * a.W, 32);
   a.rt_cap = km == 4 ? (64 / a.W + 2) * a.k2 : 0;              // (row, tap) entries of a tile: 16 + 4 bytes each, + k2 ints
@@ -592,12 +595,12 @@ static int da_region_plan(DaArgs& a, int C, int nwv, int km, const int* spans, i
 }
 
 // HDRSKY_DA_REGION=2: fail instead of falling back to the global-memory gather (tests: proves which kernel ran)
-static bool da_region_forced() { const char* e = getenv("HDRSKY_DA_REGION"); return e && atoi(e) == 2; }
+static bool da_region_forced() { return hdrsky_hooks().da_region == 2; }
 
 template <int NWV, int KM, int CBMAX, int TM>
 static int da_region_launch_(const DaArgs& a, int grid, int lds, void* stream) {
   auto k = da_region_kernel<NWV, KM, CBMAX, TM>;
-  static bool set = false;
+  static std::atomic<bool> set{false};
   if (!set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return HDRSKY_ELAUNCH;
@@ -682,7 +685,7 @@ static bool da_taps_per_round(int C, int nwv, int k2, int imax_max, int* tpr) {
   int t = cap / nq;
   if (t < 1) t = 1;
   if (t > k2) t = k2;
-  if (const char* e = getenv("HDRSKY_DA_TPR")) { const int lim = atoi(e); if (lim >= 1 && t > lim) t = lim; }
+  { const int lim = hdrsky_hooks().da_tpr; if (lim >= 1 && t > lim) t = lim; }
   *tpr = t;
   return t * nq <= 2 * nwv;
 }
@@ -1034,8 +1037,7 @@ static int da_wgrad_plan(DaWgArgs& a, const int* spans) {
   if ((F % a.FB) != 0 || (a.FB & (a.FB - 1))) return 0;
   a.nfblk = F / a.FB;
   a.nq_sh = ilog2(nq); a.nqy_sh = ilog2(a.FB / 8); a.cif_sh = ilog2(C / 16); a.cof_sh = ilog2(a.FB / 16);
-  int hook_level = -1;
-  if (const char* e = getenv("HDRSKY_DA_WG_GROUP")) hook_level = atoi(e);
+  const int hook_level = hdrsky_hooks().da_wg_group;     // tuning hook: tiles per region of the kernel-gradient launch (-1: the largest that fits)
   const int* row_lo_base = a.row_lo;
   for (int level = 4; level >= 0; --level) {      // the largest group that fits: fewest partial slabs
     const int G = 1 << level, groups = cdiv(a.tiles_x, G), src_rows = spans[level];
@@ -1163,14 +1165,14 @@ int hdrsky_da_conv2d_fwd(const float* x, const void* w_hi, const void* w_lo, con
   if (lds > 152 * 1024) return HDRSKY_EUNSUPPORTED;          // + 5 KB of static LDS (the tile's offset table)
   a.tab_off = lds;
   a.use_tab = (lds + 64 * a.k2 * 32 <= 152 * 1024) ? 1 : 0;      // sample table: 32 B per (pixel, tap); 7x7 in BF16X3 does not fit
-  if (const char* e = getenv("HDRSKY_DA_TAB")) { if (atoi(e) == 0) a.use_tab = 0; }   // tuning / test hook
+  if (hdrsky_hooks().da_tab == 0) a.use_tab = 0;               // switch (tests: the table-free path)
   if ((64 / W + 2) * a.k2 > 5 * 128) return HDRSKY_EUNSUPPORTED;   // rows a 64-pixel tile spans x taps: the staged offset table
   const int lds_launch = lds + (a.use_tab ? 64 * a.k2 * 32 : 0);
   const int grid = B * a.tiles_x * a.nblocks;
 #define HDRSKY_DA_LAUNCH_(PREC_, NWV_, IMAX_)                                                                      \
   {                                                                                                               \
     auto k = da_conv_kernel<PREC_, NWV_, IMAX_, 4>;                                                                \
-    static bool set = false;                                                                                      \
+    static std::atomic<bool> set{false};                                                                                      \
     if (!set) {                                                                                                   \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,       \
                               152 * 1024) != hipSuccess) return HDRSKY_ELAUNCH;                                   \
@@ -1256,7 +1258,7 @@ int hdrsky_da_conv2d_dgrad(const float* dy, const void* wT_hi, const void* wT_lo
 #define HDRSKY_DAG_LAUNCH(PREC_, NWV_)                                                                             \
   {                                                                                                               \
     auto k = da_conv_kernel<PREC_, NWV_, 2, 8>;                                                                    \
-    static bool set = false;                                                                                      \
+    static std::atomic<bool> set{false};                                                                                      \
     if (!set) {                                                                                                   \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,       \
                               152 * 1024) != hipSuccess) return HDRSKY_ELAUNCH;                                   \
@@ -1318,7 +1320,7 @@ int hdrsky_da_conv2d_wgrad(const float* x, const void* dy, int dy_bf16, const fl
 #define HDRSKY_DAWG(NFR_)                                                                                          \
   {                                                                                                               \
     auto k = da_wgrad_region_kernel<NFR_>;                                                                        \
-    static bool set = false;                                                                                      \
+    static std::atomic<bool> set{false};                                                                                      \
     if (!set) {                                                                                                   \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,       \
                               156 * 1024) != hipSuccess) return HDRSKY_ELAUNCH;                                   \

@@ -11,6 +11,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "hooks.h"
 
 namespace {
 
@@ -167,7 +168,7 @@ int hdrsky_fc_nsplit(int R) {
   // flight per CU) stream the weights faster on their own (3.0 -> 4.1 TB/s), but every consumer of the partial sums
   // (fc_finalize, softmax_head, the next layer's staging) reads twice as many: inside the forward pass 4 is 12 us faster
   // and the training step does not care (profiles/ab_bench.sh; HDRSKY_FC_NSPLIT overrides for A/B runs).
-  static const int pref = getenv("HDRSKY_FC_NSPLIT") ? atoi(getenv("HDRSKY_FC_NSPLIT")) : 4;
+  const int pref = hdrsky_hooks().fc_nsplit;   // (tuning hook; 4)
   int ns = pref > 0 ? pref : 4;
   while (ns > 1 && (R % (ns * RCH)) != 0) ns >>= 1;
   return ns;

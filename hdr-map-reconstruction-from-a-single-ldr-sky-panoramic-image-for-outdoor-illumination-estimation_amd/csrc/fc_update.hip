@@ -25,6 +25,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "hooks.h"
 
 namespace {
 
@@ -175,11 +176,7 @@ inline int mpad(int M) { return roundup(M, MC); }
 // blocks per wave: 2 (82 VGPRs, 5 waves per SIMD, half the A-operand loads; measured 2 % faster at M = 32 and 13 % at
 // M = 256 on the 8192x4096 kernel) unless HDRSKY_FC_UPDATE_NB=1 (58 VGPRs, 8 waves)
 inline int blocks_per_wave() {
-  static const int nb = [] {
-    const char* e = getenv("HDRSKY_FC_UPDATE_NB");
-    return (e && atoi(e) == 1) ? 1 : 2;
-  }();
-  return nb;
+  return hdrsky_hooks().fc_update_nb == 1 ? 1 : 2;   // (tuning hook HDRSKY_FC_UPDATE_NB)
 }
 
 template <bool FUSED>

@@ -1,0 +1,39 @@
+// Every HDRSKY_* environment variable the library looks at, read ONCE into one structure (at the first launch, or again by
+// hdrsky_hooks_reload() - the tests flip switches inside one process): no getenv() on a launch path.
+//
+// Two classes.  SWITCHES select between shipped code paths and are always honoured (the test-suite uses them to prove which
+// kernel ran and to compare paths bit for bit).  TUNING HOOKS belong to the A/B experiments under profiles/ (tile shapes,
+// workgroup budgets, split factors); they are honoured only when HDRSKY_EXPERIMENTS=1 is set and read as their defaults
+// otherwise, so a stray variable in a deployment's environment cannot change what the product runs.
+#pragma once
+
+struct HdrskyTileHook { int set; int v[6]; };   // "wm,wn,mi,ni,tw[,db]"
+
+struct HdrskyHooks {
+  // ---- switches ---------------------------------------------------------------------------------------------------
+  int da_region;       // HDRSKY_DA_REGION   1: LDS-region kernels of the distortion-aware conv where they fit (default);
+                       //                    0: never; 2: fail with HDRSKY_EUNSUPPORTED instead of falling back
+  int da_tm;           // HDRSKY_DA_TM       pixels per tile of the region kernel: 0 = chosen per launch (default), 32, 64
+  int da_tpr;          // HDRSKY_DA_TPR      upper limit of filter taps per barrier round (0 = none)
+  int da_tab;          // HDRSKY_DA_TAB      0: no per-workgroup sample table in da_conv_kernel (default 1)
+  int no_phase;        // HDRSKY_NO_PHASE    stride-2 data gradients on the zero-stuffed operand instead of by output phases
+  int no_dot1;         // HDRSKY_NO_DOT1     the one-output-channel conv through the MFMA tile instead of conv_dot1_kernel
+  int wgrad2;          // HDRSKY_WGRAD2      0: weight gradients never on conv_wgrad2_kernel (default 1)
+  int wgrad3;          // HDRSKY_WGRAD3      0: ... never on conv_wgrad3_kernel (default 1)
+  // ---- tuning hooks (HDRSKY_EXPERIMENTS=1) --------------------------------------------------------------------------
+  int experiments;
+  HdrskyTileHook tile, tile_t16, tile_wide, tile_c32, tile_c16;   // HDRSKY_TILE, _T16, _WIDE, _C32, _C16
+  int wgrad2_s2min;    // HDRSKY_WGRAD2_S2MIN   (32)
+  int wgrad2_mint;     // HDRSKY_WGRAD2_MINT    (2)
+  int wgrad2_wgs;      // HDRSKY_WGRAD2_WGS     (0 = by work share)
+  int wgrad3_minpx;    // HDRSKY_WGRAD3_MINPX   (256)
+  int wgrad3_wgs;      // HDRSKY_WGRAD3_WGS     (256)
+  int wgrad_set, wgrad[3];   // HDRSKY_WGRAD "workgroups,force_small,workgroups_grouped"
+  int da_group;        // HDRSKY_DA_GROUP       (-1)
+  int da_wg_group;     // HDRSKY_DA_WG_GROUP    (-1)
+  int fc_nsplit;       // HDRSKY_FC_NSPLIT      (4)
+  int fc_update_nb;    // HDRSKY_FC_UPDATE_NB   (0 = by the row count)
+  int nab_target;      // HDRSKY_NAB_TARGET     (512)
+};
+
+const HdrskyHooks& hdrsky_hooks();

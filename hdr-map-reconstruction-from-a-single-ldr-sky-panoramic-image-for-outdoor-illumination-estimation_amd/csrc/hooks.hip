@@ -1,0 +1,82 @@
+// The library's environment switches, read once (hooks.h).  Host code only.
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+
+#include "common.h"
+#include "hooks.h"
+
+namespace {
+
+HdrskyHooks g_hooks;
+std::once_flag g_once;
+std::mutex g_mutex;
+
+int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+HdrskyTileHook env_tile(const char* name) {
+  HdrskyTileHook t{};
+  if (const char* e = getenv(name)) {
+    t.v[5] = 0;
+    t.set = sscanf(e, "%d,%d,%d,%d,%d,%d", &t.v[0], &t.v[1], &t.v[2], &t.v[3], &t.v[4], &t.v[5]) >= 5;
+  }
+  return t;
+}
+
+void read_hooks() {
+  HdrskyHooks h{};
+  h.da_region = env_int("HDRSKY_DA_REGION", 1);
+  h.da_tm = env_int("HDRSKY_DA_TM", 0);
+  h.da_tpr = env_int("HDRSKY_DA_TPR", 0);
+  h.da_tab = env_int("HDRSKY_DA_TAB", 1);
+  h.no_phase = getenv("HDRSKY_NO_PHASE") != nullptr;
+  h.no_dot1 = getenv("HDRSKY_NO_DOT1") != nullptr;
+  h.wgrad2 = env_int("HDRSKY_WGRAD2", 1) != 0;
+  h.wgrad3 = env_int("HDRSKY_WGRAD3", 1) != 0;
+  h.experiments = env_int("HDRSKY_EXPERIMENTS", 0) == 1;
+  // tuning hooks: their defaults unless the gate is open
+  h.wgrad2_s2min = 32; h.wgrad2_mint = 2; h.wgrad2_wgs = 0; h.wgrad3_minpx = 256; h.wgrad3_wgs = 256;
+  h.da_group = -1; h.da_wg_group = -1; h.fc_nsplit = 4; h.fc_update_nb = 0; h.nab_target = 512;
+  if (h.experiments) {
+    h.tile = env_tile("HDRSKY_TILE"); h.tile_t16 = env_tile("HDRSKY_TILE_T16"); h.tile_wide = env_tile("HDRSKY_TILE_WIDE");
+    h.tile_c32 = env_tile("HDRSKY_TILE_C32"); h.tile_c16 = env_tile("HDRSKY_TILE_C16");
+    h.wgrad2_s2min = env_int("HDRSKY_WGRAD2_S2MIN", h.wgrad2_s2min);
+    h.wgrad2_mint = env_int("HDRSKY_WGRAD2_MINT", h.wgrad2_mint);
+    h.wgrad2_wgs = env_int("HDRSKY_WGRAD2_WGS", h.wgrad2_wgs);
+    h.wgrad3_minpx = env_int("HDRSKY_WGRAD3_MINPX", h.wgrad3_minpx);
+    h.wgrad3_wgs = env_int("HDRSKY_WGRAD3_WGS", h.wgrad3_wgs);
+    if (const char* e = getenv("HDRSKY_WGRAD")) h.wgrad_set = sscanf(e, "%d,%d,%d", &h.wgrad[0], &h.wgrad[1], &h.wgrad[2]) >= 1;
+    h.da_group = env_int("HDRSKY_DA_GROUP", h.da_group);
+    h.da_wg_group = env_int("HDRSKY_DA_WG_GROUP", h.da_wg_group);
+    h.fc_nsplit = env_int("HDRSKY_FC_NSPLIT", h.fc_nsplit);
+    h.fc_update_nb = env_int("HDRSKY_FC_UPDATE_NB", h.fc_update_nb);
+    h.nab_target = env_int("HDRSKY_NAB_TARGET", h.nab_target);
+  }
+  std::lock_guard<std::mutex> lock(g_mutex);
+  g_hooks = h;
+}
+
+}  // namespace
+
+const HdrskyHooks& hdrsky_hooks() {
+  std::call_once(g_once, read_hooks);
+  return g_hooks;
+}
+
+extern "C" {
+
+// [host] Reads the HDRSKY_* variables again (the test-suite changes them inside one process).  Not to be called while
+// another thread is inside a launch function of the library.
+int hdrsky_hooks_reload(void) {
+  std::call_once(g_once, [] {});
+  read_hooks();
+  return HDRSKY_OK;
+}
+
+// [host] 1 when HDRSKY_EXPERIMENTS=1 opened the tuning hooks at the last (re)load
+int hdrsky_experiments_enabled(void) { return hdrsky_hooks().experiments; }
+
+}  // extern "C"

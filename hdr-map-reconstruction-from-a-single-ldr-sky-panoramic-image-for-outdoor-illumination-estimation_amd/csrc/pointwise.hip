@@ -5,6 +5,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "hooks.h"
 
 namespace {
 
@@ -908,7 +909,7 @@ int hdrsky_bn_eval_affine(const float* gamma, const float* beta, const float* mo
 int hdrsky_norm_act_bwd_nslices(int B, int H, int W, int C, int pooled) {
   const int units = pooled ? (H / 2) * (W / 2) : H * W;
   const int groups = B * (C / 16);
-  static const int target = getenv("HDRSKY_NAB_TARGET") ? atoi(getenv("HDRSKY_NAB_TARGET")) : 512;   // tuning hook
+  const int target = hdrsky_hooks().nab_target;   // (tuning hook; 512)
   int S = groups > 0 ? (target + groups - 1) / groups : 1;
   const int smax = units / 256 > 0 ? units / 256 : 1;   // below ~256 pixels per slice the second launch costs more
   if (S > smax) S = smax;

@@ -27,6 +27,8 @@
 // while the first is being multiplied (counted vmcnt, raw s_barrier).
 #include <cstdio>
 
+#include <atomic>
+
 #include "common.h"
 
 namespace {
@@ -380,7 +382,7 @@ __global__ void __launch_bounds__(256) to_bf16_kernel(const float* __restrict__ 
 template <int NCB>
 int launch_resconv(const RcArgs& a, hipStream_t stream) {
   auto kern = resconv_kernel<NCB>;
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RcGeo<NCB>::LDS) != hipSuccess)
       return HDRSKY_ELAUNCH;

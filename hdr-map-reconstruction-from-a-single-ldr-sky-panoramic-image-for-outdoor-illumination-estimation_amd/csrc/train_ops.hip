@@ -3,6 +3,8 @@
 // the losses with their gradients (KL, L1 means, LSGAN, DoG), blend / decoder-tail / sun-radiance backward and
 // the fused multi-tensor RMSprop.  fp32 throughout; scalar loss values are accumulated with atomics (they are
 // logging only - no gradient depends on them); every gradient is deterministic.
+#include <atomic>
+
 #include "common.h"
 
 namespace {
@@ -1612,7 +1614,7 @@ int hdrsky_dog_loss(const float* y, const float* t, int B, int H, int W, int C, 
     g.offS = g.offL + 3 * 256 * 4;
     const int lds = roundup(g.offS + (2 * RB + 6) * RW, 16);
     if (lds > 160 * 1024 - 256) continue;                 // (+ the kernel's static words)
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};
     if (!attr_set) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(dog_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) !=
           hipSuccess)

@@ -18,6 +18,7 @@ import os
 import torch
 
 from . import _lib as L
+from . import hooks as HOOKS
 from . import kernels as K
 from .kernels import BF16, BF16X3, InXf, PackedConv, PackedFC
 
@@ -134,7 +135,7 @@ def sun3_supported(x, compute):
     # step 3.64 vs 3.61 ms with / without - the two launches are each faster than the generic conv + norm pair alone
     # (6-7 us vs 15 + 8 us), but a sample-resident workgroup owns its CU (100 KB of LDS, 512 threads), so the kernels of
     # the other streams cannot run beside it and the step loses the overlap it gains in kernel time.
-    if os.environ.get("HDRSKY_SUN3", "0") != "1":
+    if not HOOKS.H.sun3:
         return False
     return compute == BF16 and K.resconv_supported(x.shape[1], x.shape[2], 64, 128) and K.resconv_supported(x.shape[1], x.shape[2], 128, 128)
 

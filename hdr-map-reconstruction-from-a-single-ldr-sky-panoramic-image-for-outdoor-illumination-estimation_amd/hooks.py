@@ -1,0 +1,49 @@
+"""Every HDRSKY_* environment variable the Python host code looks at, read ONCE (at import, or again by `reload()` - the
+test-suite changes them inside one process); the C library keeps its own copy (csrc/hooks.h, `hdrsky_hooks_reload`).
+
+SWITCHES select between shipped code paths / deployment options and are always honoured.  TUNING HOOKS belong to the A/B
+experiments of profiles/ (stream placement of plan segments, storage-format toggles that were measured and decided); they
+are honoured only under HDRSKY_EXPERIMENTS=1 and read as their defaults otherwise.  INTEGRATION.md section 5 lists both."""
+import os
+
+
+class _Hooks:
+    def reload(self):
+        env = os.environ.get
+        self.experiments = env("HDRSKY_EXPERIMENTS", "0") == "1"
+        exp = (lambda name, dflt: env(name, dflt)) if self.experiments else (lambda name, dflt: dflt)
+        # ---- switches ----------------------------------------------------------------------------------------------
+        self.wgrad2 = env("HDRSKY_WGRAD2", "1") != "0"                  # conv_wgrad2_kernel for bf16-operand layers
+        self.wgrad_atomic = env("HDRSKY_WGRAD_ATOMIC", "0") == "1"      # fp32-atomics weight gradients (not deterministic)
+        self.da_wgrad_region = env("HDRSKY_DA_WGRAD_REGION", "1") != "0"   # LDS-region kernel gradient of the DA conv
+        self.dog_fused = env("HDRSKY_DOG_FUSED", "1") != "0"            # the DoG loss term as one launch
+        self.dist_backend = env("HDRSKY_DIST_BACKEND") or None          # "gloo" for the one-card rehearsals
+        self.dp_mode = env("HDRSKY_DP_MODE") or None                    # parallel.MODES
+        # ---- tuning hooks (HDRSKY_EXPERIMENTS=1) ---------------------------------------------------------------------
+        self.da_wgrad_region_maxc = int(exp("HDRSKY_DA_WGRAD_REGION_MAXC", "64"))
+        self.inxf_affine_min = int(exp("HDRSKY_INXF_AFFINE_MIN", "64"))
+        self.deconv_mat = exp("HDRSKY_DECONV_MAT", "1") != "0"
+        self.sun3 = exp("HDRSKY_SUN3", "0") == "1"
+        self.vgg_fold = exp("HDRSKY_VGG_FOLD", "1") != "0"
+        self.vgg_bf16 = exp("HDRSKY_VGG_BF16", "1") != "0"
+        self.nab_dy_bf16 = exp("HDRSKY_NAB_DY_BF16", "1") != "0"
+        self.disc_split = exp("HDRSKY_DISC_SPLIT", "0") == "1"
+        self.dec_head_early = exp("HDRSKY_DEC_HEAD_EARLY", "1") != "0"
+        self.bwd_dense_stream = int(exp("HDRSKY_BWD_DENSE_STREAM", "2"))
+        self.wg_res_stream = int(exp("HDRSKY_WG_RES_STREAM", "1"))
+        self.wg_enc_split = exp("HDRSKY_WG_ENC_SPLIT", "1") != "0"
+        self.apply_fc_stream = int(exp("HDRSKY_APPLY_FC_STREAM", "2"))
+        self.apply_after_fc = exp("HDRSKY_APPLY_AFTER_FC", "0") == "1"
+        self.plan_move = exp("HDRSKY_PLAN_MOVE", "")
+        return self
+
+
+H = _Hooks().reload()
+
+
+def reload():
+    """Re-read the environment here AND in the C library (tests; never while launches are in flight on another thread)."""
+    H.reload()
+    from . import _lib
+    if _lib._lib is not None:
+        _lib._lib.hdrsky_hooks_reload()

@@ -13,6 +13,7 @@ from typing import Optional
 import torch
 
 from . import _lib as L
+from . import hooks as HOOKS
 
 BF16, BF16X3 = L.HDRSKY_BF16, L.HDRSKY_BF16X3
 IN_EPS = 1e-3  # tfa InstanceNormalization / Keras BatchNormalization default epsilon
@@ -290,7 +291,7 @@ def _da_wgrad_region(job):
     LDS; BF16 mode, offsets from da_offsets_device).  False: not applicable here - the job stays in the generic launch."""
     d, x, dy, _, dw, db, (offs, ksize, C) = job
     rows = getattr(offs, "da_rows", None)
-    if rows is None or d.compute != BF16 or C > int(os.environ.get("HDRSKY_DA_WGRAD_REGION_MAXC", "64")):
+    if rows is None or d.compute != BF16 or C > HOOKS.H.da_wgrad_region_maxc:
         return False      # (wide layers: measured inside the training step, the grouped generic launch is no slower)
     B, H, W, _ = x.shape
     F = dy.shape[-1]
@@ -330,7 +331,7 @@ def wgrad_job(x, dy, KH, KW, dw, db=None, stride=1, same=True, upsample=1, xf: O
 def wgrad2_on():
     """The LDS-DMA weight-gradient kernel (csrc/conv_wgrad.hip, conv_wgrad2_kernel) takes layers whose operands are both final
     bf16 tensors; HDRSKY_WGRAD2=0 keeps everything on the register-staged kernel (A/B hook)."""
-    return os.environ.get("HDRSKY_WGRAD2", "1") != "0"
+    return HOOKS.H.wgrad2
 
 
 def _materialise_bf16_operand(job):
@@ -359,11 +360,11 @@ def conv2d_wgrad_multi(jobs, deterministic=True):
     """Weight gradients of several independent conv layers in as few launches as the library can manage.
     deterministic (default): the split-K partials go through a scratch buffer and are added in a fixed order - the
     gradients are bit-reproducible; False: fp32 atomics straight into dw (no scratch, arrival-order summation)."""
-    if deterministic and os.environ.get("HDRSKY_DA_WGRAD_REGION", "1") != "0":
+    if deterministic and HOOKS.H.da_wgrad_region:
         jobs = [job for job in jobs if not (len(job) > 6 and _da_wgrad_region(job))]
     if not jobs:
         return
-    if deterministic and wgrad2_on() and os.environ.get("HDRSKY_WGRAD_ATOMIC", "0") != "1":
+    if deterministic and wgrad2_on() and not HOOKS.H.wgrad_atomic:
         jobs = [_materialise_bf16_operand(job) for job in jobs]
     arr = (L.WgradJob * len(jobs))()
     for i, job in enumerate(jobs):
@@ -377,7 +378,7 @@ def conv2d_wgrad_multi(jobs, deterministic=True):
         j.in_scale, j.in_shift, j.in_part, j.in_gamma, j.in_beta = [_p(t) for t in tabs]
         j.x_bf16, j.dy_bf16 = int(x.dtype == torch.bfloat16), int(dy.dtype == torch.bfloat16)
     lib = L.load()
-    if not deterministic or os.environ.get("HDRSKY_WGRAD_ATOMIC", "0") == "1":     # (the variable: an A/B hook)
+    if not deterministic or HOOKS.H.wgrad_atomic:     # (HDRSKY_WGRAD_ATOMIC: an A/B switch)
         L.check(lib.hdrsky_conv2d_wgrad_multi(arr, len(jobs), _stream()), "conv2d_wgrad_multi")
         return
     nbytes = int(lib.hdrsky_conv2d_wgrad_ws_bytes(arr, len(jobs)))
@@ -412,16 +413,15 @@ def norm_apply(x, stats: Stats, gamma, beta, slope=1.0, residual=None, pool=Fals
     return (y, yp) if pool else y
 
 
-INXF_AFFINE_MIN = int(os.environ.get("HDRSKY_INXF_AFFINE_MIN", "64"))
 
 
 def in_xf(stats: Stats, gamma, beta, slope, eps=IN_EPS):
     """The fused operand transform leaky(InstanceNorm(x)) for the conv / weight-gradient that consumes the raw tensor x:
     the tile partials themselves (every workgroup of the consumer derives the tables in its prologue) while a sample has
-    few tiles, tables computed once by hdrsky_in_affine (same formula, equal to an ulp or two) from INXF_AFFINE_MIN tiles per
+    few tiles, tables computed once by hdrsky_in_affine (same formula, equal to an ulp or two) from 64 tiles (tuning hook HDRSKY_INXF_AFFINE_MIN) per
     sample on."""
     B, nparts, _, C = stats.part.shape
-    if nparts < INXF_AFFINE_MIN:
+    if nparts < HOOKS.H.inxf_affine_min:
         return InXf(mode=L.IN_PARTIALS, slope=slope, stats=stats, gamma=gamma, beta=beta, eps=eps)
     scale = torch.empty((B, C), dtype=torch.float32, device=gamma.device)
     shift = torch.empty_like(scale)
@@ -843,7 +843,7 @@ def deconv_materialised(compute):
     """Whether the training step runs its resize-deconvolutions as (operand written once as bf16) + plain conv + plain
     weight gradient - single-product mode; HDRSKY_DECONV_MAT=0 keeps the resize fused into the staging of both (A/B hook:
     step -0.4 %, all of it from the weight gradients; the forward pass alone gains nothing, engine.decode stays fused)."""
-    return compute == BF16 and os.environ.get("HDRSKY_DECONV_MAT", "1") != "0"
+    return compute == BF16 and HOOKS.H.deconv_mat
 
 
 def up2x_act_bf16(x, xf: Optional[InXf] = None):
@@ -894,7 +894,7 @@ def dog_loss(y_lin, hdr_t, weight, loss_slot, dy_out):
     lib = L.load()
     B, H, W, C = y_lin.shape
     _f32(y_lin); _f32(hdr_t, B, H, W, C); _f32(dy_out, B, H, W, C)
-    if os.environ.get("HDRSKY_DOG_FUSED", "1") != "0":     # (the variable: an A/B hook)
+    if HOOKS.H.dog_fused:     # (HDRSKY_DOG_FUSED=0: the seven staged launches)
         rc = lib.hdrsky_dog_loss(_p(y_lin), _p(hdr_t), B, H, W, C, weight, _p(loss_slot), _p(dy_out), _stream())
         if rc != L.HDRSKY_EUNSUPPORTED:
             L.check(rc, "dog_loss")

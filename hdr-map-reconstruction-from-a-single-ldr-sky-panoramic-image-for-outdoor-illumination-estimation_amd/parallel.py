@@ -13,6 +13,8 @@ import os
 import torch
 import torch.distributed as dist
 
+from . import hooks as HOOKS
+
 
 def init_from_env(backend=None, device=None):
     """RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the environment (torchrun contract).  Returns (rank, world, local)."""
@@ -23,7 +25,7 @@ def init_from_env(backend=None, device=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         # HDRSKY_DIST_BACKEND=gloo: rehearsal of the multi-process path with several ranks on ONE card (RCCL refuses that)
-        backend = backend or os.environ.get("HDRSKY_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        backend = backend or HOOKS.H.dist_backend or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if backend == "nccl" and device is not None:
             kw["device_id"] = device
@@ -129,7 +131,7 @@ class GradientExchange:
         (BatchSync) - N replicas of batch B then take the reference's batch N*B step, to fp32 round-off.  Such a step couples
         the replicas inside the forward and backward passes, so it is issued eagerly (step / reduce_all /
         apply_gradients), not captured."""
-        mode = mode or os.environ.get("HDRSKY_DP_MODE") or DEFAULT_MODE
+        mode = mode or HOOKS.H.dp_mode or DEFAULT_MODE
         if mode not in MODES:
             raise ValueError("unknown data-parallel mode %r (one of %s)" % (mode, ", ".join(MODES)))
         self.tr, self.mode = trainer, mode

@@ -18,6 +18,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
+from . import hooks as HOOKS
 from . import engine as E
 from . import kernels as K
 from . import params as P
@@ -201,7 +202,7 @@ class Trainer:
         # The preprocessing x*255 - mean (vgg16.py:133-141) rides in conv1_1's operand staging as a per-channel affine (SAME padding
         # pads the PREPROCESSED image with zeros: so does the staging), its derivative 255 in conv1_1's data-gradient filter:
         # two launches less per VGG pass on the perceptual term's critical path.  HDRSKY_VGG_FOLD=0: separate launches (A/B hook)
-        self._vgg_fold = os.environ.get("HDRSKY_VGG_FOLD", "1") != "0"
+        self._vgg_fold = HOOKS.H.vgg_fold
         dev_ = self.vgg["conv1_1.w"].device
         self._vgg_xf = InXf(mode=L.IN_AFFINE, slope=1.0, scale=torch.full((3,), 255.0, dtype=torch.float32, device=dev_),
                             shift=torch.tensor([-103.939, -116.779, -123.68], dtype=torch.float32, device=dev_))
@@ -251,7 +252,7 @@ class Trainer:
     def _sun3_ok(self):
         # (mirrors the forward's condition: a distortion-aware sun-pose net never takes the sample-resident launches)
         return self.compute == BF16 and not self.precise and not self.da_sun and \
-            K.resconv_supported(self.h // 4, self.w // 4, 64, 128) and os.environ.get("HDRSKY_SUN3", "0") == "1"
+            K.resconv_supported(self.h // 4, self.w // 4, 64, 128) and HOOKS.H.sun3
 
     def _norm_state(self, B):
         st = getattr(self, "_nstate", None)
@@ -607,13 +608,13 @@ class Trainer:
 
     def _act_bf16(self):
         """Final activations of ReLU / LeakyReLU-only stretches are stored as bf16 (HDRSKY_BF16 mode; HDRSKY_VGG_BF16=0: A/B hook)."""
-        return self.compute == BF16 and not self.precise and os.environ.get("HDRSKY_VGG_BF16", "1") != "0"
+        return self.compute == BF16 and not self.precise and HOOKS.H.vgg_bf16
 
     def _nab_bf16(self):
         """Gradients that go from a data-gradient conv straight into an InstanceNorm backward (and nowhere else) travel as
         bf16 in the single-product mode: the norm backward's output is stored as bf16 anyway, and its two passes over this
         tensor are half as long (HDRSKY_NAB_DY_BF16=0: A/B hook)."""
-        return self._act_bf16() and os.environ.get("HDRSKY_NAB_DY_BF16", "1") != "0"
+        return self._act_bf16() and HOOKS.H.nab_dy_bf16
 
     def _deconv_mat(self):
         return not self.precise and K.deconv_materialised(self.compute)
@@ -738,7 +739,7 @@ class Trainer:
                 xf1 = self._inxf(s2, "gen.norm2_" + sfx, 0.1)
                 T["dech_" + sfx] = (d3, s3, xf2, d2, s2, xf1, None, None)
 
-        early_head = os.environ.get("HDRSKY_DEC_HEAD_EARLY", "1") != "0"     # A/B hook
+        early_head = HOOKS.H.dec_head_early     # (tuning hook)
 
         def decode_tail(sfx, residual):
             hd = T["dech_" + sfx]
@@ -771,7 +772,7 @@ class Trainer:
         # generated pairs: train.py:302,360-361).  Measured: no gain - the forward pass it runs beside slows down by what the
         # backward pass wins (2.77 ms either way) - so the default stays ONE batch of 2B in disc_step; HDRSKY_DISC_SPLIT=1
         # selects the split (A/B hook, covered by tests/test_train_gpu.py)
-        split_disc = os.environ.get("HDRSKY_DISC_SPLIT", "0") == "1"
+        split_disc = HOOKS.H.disc_split
 
         def zero_grads():
             # (the two Dense kernels + biases, 201 of the 222 MB, are overwritten by their weight-gradient launches)
@@ -924,7 +925,7 @@ class Trainer:
         # weight gradients and the Dense update (stream 1) do: in front of bwd_sunpose on stream 2 they are ~75 us (five launches,
         # two of them streaming the 67 MB Dense image) that the dependent chain on stream 0 no longer waits for.
         # HDRSKY_BWD_DENSE_STREAM=0: on stream 0 behind bwd_head, the old order (A/B hook)
-        @seg("bwd_dense", int(os.environ.get("HDRSKY_BWD_DENSE_STREAM", "2")), ["bwd_head"])
+        @seg("bwd_dense", HOOKS.H.bwd_dense_stream, ["bwd_head"])
         def _():
             t = T["t"]
             dz = T["dz"] = K.softmax_bwd(t["cmf"], T["dcmf"], t["z"])       # KL + the sun-radiance path meet in dcmf
@@ -1099,7 +1100,7 @@ class Trainer:
         # its weight gradients on stream 1, the Dense update at the end of stream 2, wg_res behind bwd_enc on stream 0, the
         # discriminator step split into an early real half and a generated half - all lengthened the step or changed nothing.
         # HDRSKY_WG_RES_STREAM / HDRSKY_APPLY_FC_STREAM / HDRSKY_BWD_DENSE_STREAM: A/B hooks.)
-        @seg("wg_res", int(os.environ.get("HDRSKY_WG_RES_STREAM", "1")), ["bwd_res"])
+        @seg("wg_res", HOOKS.H.wg_res_stream, ["bwd_res"])
         def _():
             K.conv2d_wgrad_multi(T["wq_res"])
 
@@ -1107,7 +1108,7 @@ class Trainer:
         # data gradients before the chain ends: their weight gradients (act_bf16 + conv_wgrad2 + reduce, ~100 us) run as
         # segment wg_enc on stream 1 - idle by then - beside the rest of the chain instead of behind it; only the stem's
         # (conv_wgrad3) stays at the end.  HDRSKY_WG_ENC_SPLIT=0: one segment, A/B hook.
-        split_enc = os.environ.get("HDRSKY_WG_ENC_SPLIT", "1") != "0"
+        split_enc = HOOKS.H.wg_enc_split
 
         @seg("bwd_enc", 0)
         def _():       # encoder head (generator.py:92-108)
@@ -1149,7 +1150,7 @@ class Trainer:
         # the END of stream 1, with the conv-side update waiting behind it: now it closes stream 2 - idle from wg_sunrad on -
         # and `apply` no longer waits for it (disjoint parameters): the two updates overlap, step -1 %
         # (profiles/r03_plan_ab2.txt; HDRSKY_APPLY_FC_STREAM / HDRSKY_APPLY_AFTER_FC are the A/B hooks))
-        @seg("apply_fc", int(os.environ.get("HDRSKY_APPLY_FC_STREAM", "2")), ["bwd_dense", "wg_dense"])
+        @seg("apply_fc", HOOKS.H.apply_fc_stream, ["bwd_dense", "wg_dense"])
         def _():
             fc0, fc1 = self.fc_grad_range()
             if self.fused_dense:
@@ -1178,7 +1179,7 @@ class Trainer:
 
         # ------------------------------------------------------------------ optimizers (train.py:403,406)
         # (starts behind grads_ready, beside the Dense update; HDRSKY_APPLY_AFTER_FC=1: the round-2 order, A/B hook)
-        @seg("apply", 0, ["apply_fc"] if os.environ.get("HDRSKY_APPLY_AFTER_FC", "0") == "1" else [])
+        @seg("apply", 0, ["apply_fc"] if HOOKS.H.apply_after_fc else [])
         def _():
             gscale, fc0 = self._gscale, self.fc_grad_range()[0]
             K.rmsprop(self.gs.flat[:fc0], self.gs.grad[:fc0], self.gs.ms[:fc0], self.lr, gscale=gscale)
@@ -1187,7 +1188,7 @@ class Trainer:
 
         # HDRSKY_PLAN_MOVE="name=stream@after,...": scheduling experiments - segment `name` goes to `stream`, enqueued right
         # behind segment `after` (dependencies are unchanged: only where it waits changes)
-        for ent in filter(None, os.environ.get("HDRSKY_PLAN_MOVE", "").split(",")):
+        for ent in filter(None, HOOKS.H.plan_move.split(",")):
             name, rest = ent.split("=")
             si, after = rest.split("@")
             idx = [k for k, sg in enumerate(segs) if sg[0] == name]

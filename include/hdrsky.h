@@ -56,6 +56,15 @@ const char* hdrsky_version(void);
 int hdrsky_abi_version(void);
 size_t hdrsky_sizeof(const char* struct_name);
 
+/* Environment switches.  The library reads its HDRSKY_* variables ONCE, at the first call that needs one, into one
+ * structure (csrc/hooks.h lists them): switches between shipped code paths (HDRSKY_DA_REGION, HDRSKY_NO_PHASE, ...) are
+ * always honoured, the tuning hooks of the A/B experiments (tile shapes, workgroup budgets) only under HDRSKY_EXPERIMENTS=1.
+ * hdrsky_hooks_reload [host] reads the environment again (a test-suite that changes variables inside one process); not to
+ * be called while another thread is inside a launch function.  hdrsky_experiments_enabled: 1 when the gate was open at
+ * the last (re)load.  (The reference reads no environment: its switches are argparse flags, train.py:23-31.) */
+int hdrsky_hooks_reload(void);
+int hdrsky_experiments_enabled(void);
+
 /* ------------------------------------------------------------------------------------------
  * Convolution family.  Replaces:
  *   ops.conv2d.call            ops.py:41-42     tf.nn.conv2d(x, w, [1,s,s,1], 'SAME') + bias_add

@@ -1,4 +1,5 @@
 #!/bin/bash
+export HDRSKY_EXPERIMENTS=1   # the tuning hooks this script sets are behind the gate since round 4 (csrc/hooks.h, hooks.py)
 # A/B of bench.py variants back to back on ONE box (different boxes differ by +-2 %): usage  bash profiles/ab_bench.sh
 cd $GRAFT_REPO_ROOT
 run() { echo "== $1"; shift; env "$@" python bench.py --no-cpu-baseline --workload train --steps 100 2>/dev/null | python -c "

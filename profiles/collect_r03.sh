@@ -1,4 +1,5 @@
 #!/bin/bash
+export HDRSKY_EXPERIMENTS=1   # the tuning hooks this script sets are behind the gate since round 4 (csrc/hooks.h, hooks.py)
 # Round-3 evidence behind DESIGN.md section 5: bench lines + rocprofv3 kernel stats of the same commands.
 # usage (GPU box, repo root): bash profiles/collect_r03.sh     (outputs: gpurun_out/r03/, copied to profiles/r03_* by hand)
 cd /tmp && export TMPDIR=/tmp

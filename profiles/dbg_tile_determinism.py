@@ -1,5 +1,17 @@
 """Debug: is a conv launch on a given tile bit-reproducible run to run (outputs and statistics partials)?"""
 import importlib, os, sys, torch
+
+def _hook(name, value):
+    """Set / clear a HDRSKY_* variable and make the package + library read it (they read the environment once:
+    hooks.py, csrc/hooks.h; tuning hooks need the HDRSKY_EXPERIMENTS=1 gate)."""
+    import importlib, os, sys
+    os.environ["HDRSKY_EXPERIMENTS"] = "1"
+    if value is None: os.environ.pop(name, None)
+    else: os.environ[name] = str(value)
+    mods = [m for n, m in sys.modules.items() if n.endswith("_amd.hooks")]
+    if mods: mods[0].reload()
+
+
 sys.path.insert(0, os.getcwd())
 PKG = "hdr-map-reconstruction-from-a-single-ldr-sky-panoramic-image-for-outdoor-illumination-estimation_amd"
 K = importlib.import_module(PKG + ".kernels"); L = importlib.import_module(PKG + "._lib")
@@ -10,7 +22,7 @@ CASES = [("vgg2_1", 4, 64, 256, 64, 128, 3, 1, True, False, False), ("vgg2_2", 4
          ("dis.d2 s2", 16, 64, 256, 64, 128, 4, 2, False, True, True), ("res 128", 8, 32, 128, 128, 128, 3, 1, False, True, True),
          ("d4 256->512", 16, 16, 64, 256, 512, 4, 1, False, True, True)]
 for tile in ("2,4,4,2,32,1", "2,4,4,1,32,1"):
-    os.environ["HDRSKY_TILE_WIDE"] = tile
+    _hook("HDRSKY_TILE_WIDE", tile)
     for name, B, H, W, Cin, Cout, k, st, b16, ws, aff in CASES:
         x = torch.randn(B, H, W, Cin, device=dev)
         if b16: x = x.to(torch.bfloat16)

@@ -3,6 +3,18 @@
 at batch 32: hipGraph of N launches, HIP events.  usage: python profiles/microbench_conv.py [--only vgg] [--tile "..."]"""
 import argparse, importlib, os, sys
 import torch
+
+def _hook(name, value):
+    """Set / clear a HDRSKY_* variable and make the package + library read it (they read the environment once:
+    hooks.py, csrc/hooks.h; tuning hooks need the HDRSKY_EXPERIMENTS=1 gate)."""
+    import importlib, os, sys
+    os.environ["HDRSKY_EXPERIMENTS"] = "1"
+    if value is None: os.environ.pop(name, None)
+    else: os.environ[name] = str(value)
+    mods = [m for n, m in sys.modules.items() if n.endswith("_amd.hooks")]
+    if mods: mods[0].reload()
+
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 PKG = "hdr-map-reconstruction-from-a-single-ldr-sky-panoramic-image-for-outdoor-illumination-estimation_amd"
@@ -52,8 +64,8 @@ def main():
         pw = K.PackedConv(w, False); bias = torch.zeros(Cout, device=dev)
         res = []
         for ci, t in enumerate(cfgs):
-            if t: os.environ["HDRSKY_TILE"] = t
-            else: os.environ.pop("HDRSKY_TILE", None)
+            if t: _hook("HDRSKY_TILE", t)
+            else: _hook("HDRSKY_TILE", None)
             try:
                 y = K.conv2d(x, pw, bias, stride=stride, **kw)[0]
             except Exception as e:

@@ -2,6 +2,18 @@
 the zero-stuffed operand (HDRSKY_NO_PHASE=1), the step's shapes, 20 launches per hipGraph replay.
 [--tiles "wm,wn,mi,ni,tw,db;..."]: additionally time the phase form on these tiles (HDRSKY_TILE)."""
 import importlib, os, sys, torch
+
+def _hook(name, value):
+    """Set / clear a HDRSKY_* variable and make the package + library read it (they read the environment once:
+    hooks.py, csrc/hooks.h; tuning hooks need the HDRSKY_EXPERIMENTS=1 gate)."""
+    import importlib, os, sys
+    os.environ["HDRSKY_EXPERIMENTS"] = "1"
+    if value is None: os.environ.pop(name, None)
+    else: os.environ[name] = str(value)
+    mods = [m for n, m in sys.modules.items() if n.endswith("_amd.hooks")]
+    if mods: mods[0].reload()
+
+
 sys.path.insert(0, os.getcwd())
 PKG = "hdr-map-reconstruction-from-a-single-ldr-sky-panoramic-image-for-outdoor-illumination-estimation_amd"
 K = importlib.import_module(PKG + ".kernels"); L = importlib.import_module(PKG + "._lib")
@@ -39,16 +51,16 @@ for name, B, H, W, Cin, Cout, k, b16 in CASES:
     flop = 2.0 * B * fd.Ho * fd.Wo * k * k * Cin * Cout
     row = []
     for env in ("1", ""):
-        if env: os.environ["HDRSKY_NO_PHASE"] = "1"
-        else: os.environ.pop("HDRSKY_NO_PHASE", None)
+        if env: _hook("HDRSKY_NO_PHASE", "1")
+        else: _hook("HDRSKY_NO_PHASE", None)
         us = timed(f)
         row.append("%s %6.2f us %6.1f TFLOP/s %s" % ("stuffed" if env else "phases ", us, flop / us * 1e-6,
                                                      K.conv_kernel_name(K.conv_dgrad_desc(fd)).replace("conv_igemm_kernel", "")))
     for t in tiles:
-        os.environ["HDRSKY_TILE"] = t
+        _hook("HDRSKY_TILE", t)
         try:
             row.append("phases on %s: %6.2f us" % (t, timed(f)))
         except Exception as e:
             row.append("phases on %s: %s" % (t, type(e).__name__))
-        os.environ.pop("HDRSKY_TILE", None)
+        _hook("HDRSKY_TILE", None)
     print("%-26s B=%2d | %s" % (name, B, " | ".join(row)), flush=True)

@@ -3,6 +3,18 @@
 usage: python profiles/microbench_wgrad.py [--batch 32] [--cfg "4,4,32,128;2,2,32,256"]   (HDRSKY_WGRAD hook values)"""
 import argparse, importlib, os, sys
 import torch
+
+def _hook(name, value):
+    """Set / clear a HDRSKY_* variable and make the package + library read it (they read the environment once:
+    hooks.py, csrc/hooks.h; tuning hooks need the HDRSKY_EXPERIMENTS=1 gate)."""
+    import importlib, os, sys
+    os.environ["HDRSKY_EXPERIMENTS"] = "1"
+    if value is None: os.environ.pop(name, None)
+    else: os.environ[name] = str(value)
+    mods = [m for n, m in sys.modules.items() if n.endswith("_amd.hooks")]
+    if mods: mods[0].reload()
+
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 PKG = "hdr-map-reconstruction-from-a-single-ldr-sky-panoramic-image-for-outdoor-illumination-estimation_amd"
@@ -47,8 +59,8 @@ def main():
         flop = 2.0 * B * d.Ho * d.Wo * k * k * Cin * Cout
         res = []
         for ci, t in enumerate(cfgs):
-            if t: os.environ["HDRSKY_WGRAD"] = t
-            else: os.environ.pop("HDRSKY_WGRAD", None)
+            if t: _hook("HDRSKY_WGRAD", t)
+            else: _hook("HDRSKY_WGRAD", None)
             try:
                 dw, db = K.conv2d_wgrad(x, dy, k, k, stride, True, up)
                 if args.group:

@@ -1,3 +1,4 @@
+export HDRSKY_EXPERIMENTS=1   # the tuning hooks this script sets are behind the gate since round 4 (csrc/hooks.h, hooks.py)
 run() { HDRSKY_PLAN_MOVE="$1" python bench.py --workload train --no-cpu-baseline --no-roofline-top --no-parity --steps 50 --warmup 10 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-60s' % '$1', d['ms_per_step'])"; }
 for rep in 1 2; do
 run ""

@@ -10,6 +10,18 @@ import sys
 import numpy as np
 import torch
 
+def _hook(name, value):
+    """Set / clear a HDRSKY_* variable and make the package + library read it (they read the environment once:
+    hooks.py, csrc/hooks.h; tuning hooks need the HDRSKY_EXPERIMENTS=1 gate)."""
+    import importlib, os, sys
+    os.environ["HDRSKY_EXPERIMENTS"] = "1"
+    if value is None: os.environ.pop(name, None)
+    else: os.environ[name] = str(value)
+    mods = [m for n, m in sys.modules.items() if n.endswith("_amd.hooks")]
+    if mods: mods[0].reload()
+
+
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "profiles"))
@@ -40,9 +52,9 @@ def main():
         bias = torch.zeros(Cout, device=dev)
         for t in tiles:
             if t:
-                os.environ["HDRSKY_TILE"] = t
+                _hook("HDRSKY_TILE", t)
             else:
-                os.environ.pop("HDRSKY_TILE", None)
+                _hook("HDRSKY_TILE", None)
             buf = torch.zeros(65536 * 8, dtype=torch.int64, device=dev)
             for _ in range(20):
                 K.conv2d(x, pw, bias, stride=stride, upsample=up, **kw)

@@ -34,3 +34,21 @@ def _collect_between_tests():
     yield
     import gc
     gc.collect()
+
+
+@pytest.fixture
+def monkeypatch(monkeypatch):
+    """The stock fixture, plus: the package and the C library read their HDRSKY_* variables once (hooks.py, csrc/hooks.h),
+    so every setenv / delenv of a test is followed by a reload - and one more when the test's changes are undone.  Tuning
+    hooks additionally need HDRSKY_EXPERIMENTS=1, which a test sets like any other variable."""
+    def reload():
+        pkg("hooks").reload()
+    set0, del0 = monkeypatch.setenv, monkeypatch.delenv
+    def setenv(name, value, prepend=None):
+        set0(name, value, prepend); reload()
+    def delenv(name, raising=True):
+        del0(name, raising); reload()
+    monkeypatch.setenv, monkeypatch.delenv = setenv, delenv
+    yield monkeypatch
+    monkeypatch.undo()
+    reload()

@@ -87,19 +87,18 @@ def test_conv_fused_in_stats_residual(dev):
     xf = K.InXf(mode=L.IN_PARTIALS, slope=0.1, stats=st, gamma=d(gam), beta=d(bet))
     y, _ = K.conv2d(r1, p2, d(b2), xf=xf, out_slope=0.1, residual=d(res), final_relu=True, compute=K.BF16X3)
     assert_close(y, ref, 3e-4, "fused consumer")
-    # the tables computed once per tensor (hdrsky_in_affine, what kernels.in_xf switches to from INXF_AFFINE_MIN tiles per
+    # the tables computed once per tensor (hdrsky_in_affine, what kernels.in_xf switches to from hooks.H.inxf_affine_min = 64 tiles per
     # sample on) are what every workgroup derives from the partials, to the last ulp or two (same formula; the compiler
     # contracts the multiply-adds of each kernel its own way): forward and weight gradient agree to fp32 round-off
-    import importlib
-    Kmod = importlib.import_module(K.__name__)
-    saved = Kmod.INXF_AFFINE_MIN
+    H = pkg("hooks").H
+    saved = H.inxf_affine_min
     try:
-        Kmod.INXF_AFFINE_MIN = 1
+        H.inxf_affine_min = 1
         xa = K.in_xf(st, d(gam), d(bet), 0.1)
-        Kmod.INXF_AFFINE_MIN = 1 << 30
+        H.inxf_affine_min = 1 << 30
         xp = K.in_xf(st, d(gam), d(bet), 0.1)
     finally:
-        Kmod.INXF_AFFINE_MIN = saved
+        H.inxf_affine_min = saved
     assert xa.mode == L.IN_AFFINE and xp.mode == L.IN_PARTIALS
     for cp in (K.BF16X3, K.BF16):
         ya, _ = K.conv2d(r1, p2, d(b2), xf=xa, out_slope=0.1, residual=d(res), final_relu=True, compute=cp)
@@ -137,6 +136,7 @@ def test_every_tile_instantiation(dev, tile, monkeypatch):
     """Each (WM,WN,MI,NI,TW[,direct-B]) instantiation (4- and 8-wave workgroups) on a wide, a narrow and a
     strided layer, with statistics output, in both compute modes."""
     K = pkg("kernels")
+    monkeypatch.setenv("HDRSKY_EXPERIMENTS", "1")         # HDRSKY_TILE is a tuning hook: behind the gate
     monkeypatch.setenv("HDRSKY_TILE", tile)
     rng = np.random.default_rng(zlib.crc32(tile.encode()))
     B = 2

@@ -142,7 +142,7 @@ def test_da_layer_backward(dev):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("k,shape", [(5, (2, 8, 32, 64, 64)), (7, (1, 16, 64, 32, 32)), (3, (2, 16, 16, 32, 32))])
-def test_da_conv_other_kernel_sizes_and_sample_table(dev, k, shape):
+def test_da_conv_other_kernel_sizes_and_sample_table(dev, k, shape, monkeypatch):
     """5x5 / 7x7 distortion-aware kernels (25 / 49 taps in the per-workgroup sample table) and a 16-pixel-wide map (a
     64-pixel tile spans 4 rows) against the oracle; the table path and the per-item coordinate path agree bit for bit."""
     import os
@@ -159,19 +159,16 @@ def test_da_conv_other_kernel_sizes_and_sample_table(dev, k, shape):
     y = K.da_conv2d(d(x), pw, d(bias), d(offs), K.BF16X3)
     assert_close(y, ref, 3e-4, "da conv %dx%d" % (k, k))
     y16 = K.da_conv2d(d(x), pw, d(bias), d(offs), K.BF16)
-    try:
-        os.environ["HDRSKY_DA_TAB"] = "0"
-        y_n = K.da_conv2d(d(x), pw, d(bias), d(offs), K.BF16X3)
-        y16_n = K.da_conv2d(d(x), pw, d(bias), d(offs), K.BF16)
-    finally:
-        os.environ.pop("HDRSKY_DA_TAB", None)
+    monkeypatch.setenv("HDRSKY_DA_TAB", "0")
+    y_n = K.da_conv2d(d(x), pw, d(bias), d(offs), K.BF16X3)
+    y16_n = K.da_conv2d(d(x), pw, d(bias), d(offs), K.BF16)
+    monkeypatch.delenv("HDRSKY_DA_TAB")
     assert torch.equal(y, y_n) and torch.equal(y16, y16_n)
-    try:      # several taps per barrier round (layers with few input channels) vs one: the same MFMA sequence
-        os.environ["HDRSKY_DA_TPR"] = "1"
-        y_1 = K.da_conv2d(d(x), pw, d(bias), d(offs), K.BF16X3)
-        y16_1 = K.da_conv2d(d(x), pw, d(bias), d(offs), K.BF16)
-    finally:
-        os.environ.pop("HDRSKY_DA_TPR", None)
+    # several taps per barrier round (layers with few input channels) vs one: the same MFMA sequence
+    monkeypatch.setenv("HDRSKY_DA_TPR", "1")
+    y_1 = K.da_conv2d(d(x), pw, d(bias), d(offs), K.BF16X3)
+    y16_1 = K.da_conv2d(d(x), pw, d(bias), d(offs), K.BF16)
+    monkeypatch.delenv("HDRSKY_DA_TPR")
     assert torch.equal(y, y_1) and torch.equal(y16, y16_1)
 
 
@@ -256,6 +253,7 @@ def test_da_region_kernel_gradient(dev, k, shape, monkeypatch):
         _, rdk, rdb = da_ops.da_conv2d_grads(x, kern, da_ops.distortion(H, W, k), dy, k=k)
     offs_r = K.da_offsets_device(H, W, k, 1, True, dev)
     xd, dyd = d(x), d(dy)
+    monkeypatch.setenv("HDRSKY_EXPERIMENTS", "1")                 # the two variables below are tuning hooks: behind the gate
     monkeypatch.setenv("HDRSKY_DA_WGRAD_REGION_MAXC", "256")      # (by default only layers of <= 64 channels take this path)
 
     def run(**env):

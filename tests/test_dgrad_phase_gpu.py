@@ -35,6 +35,7 @@ def _no_phase(flag):
         os.environ["HDRSKY_NO_PHASE"] = "1"
     else:
         os.environ.pop("HDRSKY_NO_PHASE", None)
+    pkg("hooks").reload()          # the switches are read once (hooks.py, csrc/hooks.h)
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])

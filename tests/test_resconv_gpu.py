@@ -162,6 +162,7 @@ def test_sunlayer3_on_the_sample_resident_launches(dev, monkeypatch):
     tr0 = trainer.Trainer(gen, sun, dis, vgg, device=dev, precise=False, compute=K.BF16)
     tr0.step(ldr, hdr, gt, update=False)
     g0 = {k: tr0.gs.g[k].clone() for k in tr0.gs.g if k.startswith("sun.")}
+    monkeypatch.setenv("HDRSKY_EXPERIMENTS", "1")
     monkeypatch.setenv("HDRSKY_SUN3", "1")
     out = engine.generator_forward(nets, ldr, compute=K.BF16)
     for k, tol in (("sunpose_cmf", 2e-3), ("sun_cam3", 2e-2), ("sun_cam2", 5e-2), ("y_final_gamma", 5e-3)):

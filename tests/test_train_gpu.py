@@ -757,6 +757,7 @@ def test_split_discriminator_passes_equal_the_paired_batch(dev, monkeypatch):
     batch = synth.make_batch(4, seed=77)
     ldr, hdr, gt = (torch.from_numpy(batch[k]).to(dev) for k in ("ldr", "hdr_t", "sunpose_gt"))
     res = {}
+    monkeypatch.setenv("HDRSKY_EXPERIMENTS", "1")
     for split in ("0", "1"):
         monkeypatch.setenv("HDRSKY_DISC_SPLIT", split)
         t = mk()
