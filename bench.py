@@ -108,11 +108,13 @@ def dominant_kernel_roofline(torch, K, pw, batch, h, w, iters=200):
     # HBM-side bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE): a RECORDED value
     # (traffic_source names the file and the commit it was measured at), null when no record exists for this batch
     traffic, source = None, None
-    pmc = os.path.join(ROOT, "profiles", "r02_pmc_resconv.json")
-    if batch == 32 and os.path.exists(pmc):
-        with open(pmc) as f:
-            rec = json.load(f)
-        traffic, source = rec.get("hbm_bytes_per_launch"), "profiles/r02_pmc_resconv.json @ %s" % rec.get("commit", "?")
+    for name in ("r04_pmc_resconv.json", "r02_pmc_resconv.json"):      # the newest record of this (unchanged since round 2) kernel
+        pmc = os.path.join(ROOT, "profiles", name)
+        if batch == 32 and os.path.exists(pmc):
+            with open(pmc) as f:
+                rec = json.load(f)
+            traffic, source = rec.get("hbm_bytes_per_launch"), "profiles/%s @ %s" % (name, rec.get("commit", "?"))
+            break
     return {"bound": "mfma", "kernel": "resconv_kernel<4> (res-block 3x3 128->128 + InstanceNorm + leaky, B=%d)" % batch,
             "role": "the res-block launch: 36 of the step's launches, ~6 % of its kernel time - see roofline_top for the "
                     "launches that cost the most",
@@ -160,8 +162,42 @@ def roofline_top(torch, K, tr, ldr, hdr, gt, top=5, iters=30):
     return {"bound": "mfma", "note": "each row timed alone (back-to-back launches of one hipGraph); step_us = launches_per_step x "
                                      "avg_launch_us; share = of the traced matrix-core launches' summed time",
             "traced_launches": len(trace), "traced_gflop_per_step": round(flops / 1e9, 1), "traced_us_per_step": round(total, 1),
-            "traced_frac_of_peak": round(flops / (total * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4), "top": rows[:top],
+            "traced_frac_of_peak": round(flops / (total * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4), "top": rows[:top], "_all_rows": rows,
             "by_kind_us": {k: round(sum(r["step_us"] for r in rows if r["kind"] == k), 1) for k in sorted({r["kind"] for r in rows})}}
+
+
+def in_step_family(roof_top_rows, csv_name="r04_train_b32_kernel_stats.csv"):
+    """The dominant kernel FAMILY inside the three-stream step: conv_igemm_kernel (every forward conv and every conv data
+    gradient that is not a sample-resident res-block launch).  FLOP per step = the traced launches of that family (the plan,
+    live); time per step = sum over the family's instantiations of calls x average duration in the committed rocprofv3
+    kernel statistics of the same command (profiles/<csv>, collected by profiles/collect_r04.sh), divided by the steps of
+    that profile (= the calls of dog_fused_kernel, one per step).  In-step durations are longer than the alone-on-the-chip
+    ones of roofline_top: three streams share the chip."""
+    path = os.path.join(ROOT, "profiles", csv_name)
+    if not os.path.exists(path):
+        return None
+    import csv
+    with open(path) as f:
+        rows = list(csv.DictReader(f))
+    steps = sum(int(r["Calls"]) for r in rows if "dog_fused_kernel" in r["Name"])
+    if steps <= 0:
+        return None
+    out = {}
+    fam_flop = {"conv_igemm_kernel": sum(r["flop_per_launch"] * r["launches_per_step"] for r in roof_top_rows if "conv_igemm_kernel" in r["kernel"]),
+                "weight gradients (conv_wgrad*_kernel + wgrad_reduce_kernel)": sum(r["flop_per_launch"] * r["launches_per_step"] for r in roof_top_rows if r["kind"] == "wgrad"),
+                "resconv_kernel": sum(r["flop_per_launch"] * r["launches_per_step"] for r in roof_top_rows if r["kind"] == "resconv")}
+    match = {"conv_igemm_kernel": ("conv_igemm_kernel",), "weight gradients (conv_wgrad*_kernel + wgrad_reduce_kernel)": ("conv_wgrad", "wgrad_reduce_kernel"),
+             "resconv_kernel": ("resconv_kernel",)}
+    total_ns = sum(float(r["TotalDurationNs"]) for r in rows)
+    for fam, keys in match.items():
+        ns = sum(float(r["TotalDurationNs"]) for r in rows if any(k in r["Name"] for k in keys))
+        calls = sum(int(r["Calls"]) for r in rows if any(k in r["Name"] for k in keys))
+        us = ns / steps / 1e3
+        out[fam] = {"gflop_per_step": round(fam_flop[fam] / 1e9, 1), "launches_per_step": round(calls / steps, 1), "us_per_step": round(us, 1),
+                    "share_of_kernel_time": round(ns / total_ns, 4), "achieved": round(fam_flop[fam] / (us * 1e-6) / 1e12, 1) if us else None,
+                    "frac": round(fam_flop[fam] / (us * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4) if us else None}
+    return {"source": "profiles/%s (%d steps profiled; kernel time per step %.0f us over three streams)" % (csv_name, steps, total_ns / steps / 1e3),
+            "unit": "TFLOP/s", "peak": MFMA_PEAK_TFLOPS, "families": out}
 
 
 def hbm_rooflines(torch, K, batch=32, iters=20):
@@ -654,6 +690,9 @@ def main():
             res["roofline"] = dominant_kernel_roofline(torch, K, roof_pw, batch, 32, 128)
             if roof_top is not None:
                 res["roofline_top"] = roof_top
+                ins = in_step_family(roof_top.pop("_all_rows"))
+                if ins is not None:
+                    res["roofline"]["in_step"] = ins
             res["roofline_hbm"] = hbm_rooflines(torch, K, batch)
             if do_train and not args.no_graph:
                 res["fp32_class"] = fp32_class_step(torch, dist, trainer, K, (gen, sun, dis, vgg), (ldr, hdr, gt), batch, dev, args.da)

@@ -70,6 +70,7 @@ SIGNATURES = {
     "hdrsky_conv2d_wgrad_multi": (c_int, [ctypes.POINTER(WgradJob), c_int, P]),
     "hdrsky_conv2d_wgrad_ws_bytes": (c_size_t, [ctypes.POINTER(WgradJob), c_int]),
     "hdrsky_conv2d_wgrad_multi_det": (c_int, [ctypes.POINTER(WgradJob), c_int, P, c_size_t, P]),
+    "hdrsky_conv2d_wgrad_kernel_names": (c_int, [ctypes.POINTER(WgradJob), c_int, ctypes.c_char_p, c_int]),
     "hdrsky_norm_apply": (c_int, [P, P, c_int, P, P, c_float, c_float, P, P, P, c_int, c_int, c_int, c_int, P]),
     "hdrsky_in_affine": (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_float, P, P, P]),
     "hdrsky_in_finalize": (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_float, P, P, P, P, P]),

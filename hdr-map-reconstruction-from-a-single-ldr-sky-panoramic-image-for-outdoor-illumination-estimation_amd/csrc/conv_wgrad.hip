@@ -15,6 +15,8 @@
 #include <cstdlib>
 
 #include <atomic>
+#include <cstdarg>
+#include <string>
 
 #include "common.h"
 #include "hooks.h"
@@ -1265,6 +1267,17 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const MultiArgs m, in
 // ---- host side -------------------------------------------------------------------------------------------------
 struct Geo { int tpw, cbf, obf, tw, nw, cs, os, xr, bm; bool narrow, precise; int up; };
 
+// hdrsky_conv2d_wgrad_kernel_names: while a planning pass runs with this pointer set, every launch it WOULD make appends
+// its kernel's name as rocprofv3 prints it (bench.py labels its roofline rows with them)
+static thread_local std::string* g_wg_names = nullptr;
+static void note_kernel(const char* fmt, ...) {
+  if (!g_wg_names) return;
+  char buf[192];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  if (!g_wg_names->empty()) *g_wg_names += " + ";
+  *g_wg_names += buf;
+}
+
 template <int TPW, int CBF, int OBF, int TW, bool NARROW, bool PRECISE, int UP, int NW, int CS, int OS, int XR, int BM>
 struct WgradVariant {
   static constexpr int NT = NW * 64, CB = CBF * 16, OB = OBF * 16, TH = BM / TW, NTG = NW / (CS * OS);
@@ -1309,6 +1322,10 @@ struct WgradVariant {
     const int lds = a.off_da + (UP == 2 ? a.H * 2 * 4 : 0);
     if (lds > 160 * 1024) return HDRSKY_EUNSUPPORTED;
     return lds;
+  }
+  static void note() {
+    note_kernel("conv_wgrad_kernel<%d, %d, %d, %d, %s, %s, %d, %d, %d, %d, %d, %d>", TPW, CBF, OBF, TW, NARROW ? "true" : "false",
+                PRECISE ? "true" : "false", UP, NW, CS, OS, XR, BM);
   }
   static int launch(MultiArgs& m, int lds, hipStream_t stream) {
     auto kern = conv_wgrad_kernel<TPW, CBF, OBF, TW, NARROW, PRECISE, UP, NW, CS, OS, XR, BM>;
@@ -1565,7 +1582,10 @@ static int wgrad2_groups(const hdrsky_wgrad_job* jobs, int njobs, bool* done, fl
     }
     m2.first[cnt] = blocks;
     mr.rfirst[cnt] = rblocks;
-    if (!plan_only) {
+    if (plan_only) {
+      note_kernel("conv_wgrad2_kernel<%d>", WG2_UPW);
+      if (rblocks > 0) note_kernel("wgrad_reduce_kernel");
+    } else {
       if (*ws_used > ws_floats) return HDRSKY_EINVAL;
       const int r = wg2_launch(m2, lds, (hipStream_t)stream);
       if (r != HDRSKY_OK) return r;
@@ -1748,7 +1768,10 @@ static int wgrad3_groups(const hdrsky_wgrad_job* jobs, int njobs, bool* done, fl
     }
     m3.first[cnt] = blocks;
     mr.rfirst[cnt] = rblocks;
-    if (!plan_only) {
+    if (plan_only) {
+      note_kernel(variant == 0 ? "conv_wgrad3_kernel<4, 1, 1, 4, %d>" : variant == 1 ? "conv_wgrad3_kernel<4, 1, 1, 8, %d>" : "conv_wgrad3_kernel<2, 2, 2, 8, %d>", WG3_UPW);
+      note_kernel("wgrad_reduce_kernel");
+    } else {
       if (*ws_used > ws_floats) return HDRSKY_EINVAL;
       const int r = wg3_launch(variant, m3, lds, (hipStream_t)stream);
       if (r != HDRSKY_OK) return r;
@@ -1848,7 +1871,7 @@ static int wgrad_multi_impl(const hdrsky_wgrad_job* jobs, int njobs, float* ws, 
         }
         m.first[cnt] = blocks;
         m.rfirst[cnt] = rblocks;
-        if (plan_only) return (int)HDRSKY_OK;
+        if (plan_only) { V::note(); if (ws != nullptr || plan_only) note_kernel("wgrad_reduce_kernel"); return (int)HDRSKY_OK; }
         if (ws != nullptr && ws_used > ws_floats) return (int)HDRSKY_EINVAL;
         int r = V::launch(m, lds, (hipStream_t)stream);
         if (r != HDRSKY_OK || ws == nullptr) return r;
@@ -1871,6 +1894,18 @@ extern "C" size_t hdrsky_conv2d_wgrad_ws_bytes(const hdrsky_wgrad_job* jobs, int
   size_t need = 0;
   if (wgrad_multi_impl(jobs, njobs, nullptr, 0, true, &need, nullptr) != HDRSKY_OK) return 0;
   return (need > 0 ? need : 4) * sizeof(float);         // (0 = error: a call whose layers need no scratch still gets a token buffer)
+}
+
+// [host] the kernels one hdrsky_conv2d_wgrad_multi_det call on these jobs launches, " + "-separated, as rocprofv3 names them
+extern "C" int hdrsky_conv2d_wgrad_kernel_names(const hdrsky_wgrad_job* jobs, int njobs, char* buf, int n) {
+  if (!jobs || !buf || n <= 0) return HDRSKY_EINVAL;
+  std::string names;
+  g_wg_names = &names;
+  size_t need = 0;
+  const int rc = wgrad_multi_impl(jobs, njobs, nullptr, 0, true, &need, nullptr);
+  g_wg_names = nullptr;
+  snprintf(buf, (size_t)n, "%s", names.c_str());
+  return rc;
 }
 
 extern "C" int hdrsky_conv2d_wgrad_multi_det(const hdrsky_wgrad_job* jobs, int njobs, void* ws, size_t ws_bytes, void* stream) {

@@ -37,9 +37,10 @@ def label(name):
     _LABEL[0] = name
 
 
-def _trace(kind, kernel, shape, flop, relaunch):
+def _trace(kind, kernel, shape, flop, relaunch, default_label=None):
     if TRACE is not None:
-        TRACE.append(dict(kind=kind, label=_LABEL[0], kernel=kernel, shape=shape, flop=float(flop), relaunch=relaunch))
+        TRACE.append(dict(kind=kind, label=_LABEL[0] or default_label, kernel=kernel, shape=shape, flop=float(flop), relaunch=relaunch))
+        _LABEL[0] = None          # a label names ONE traced launch (a stale one mislabelled the res-chain rows in round 3)
 
 
 @contextlib.contextmanager
@@ -219,9 +220,11 @@ def conv2d(x, pw: PackedConv, bias=None, stride=1, same=True, upsample=1, xf: Op
     if TRACE is not None:
         keep = (x, pw, bias, in_scale, in_shift, in_part, in_gamma, in_beta, residual, y, stats)
         stuffed = 4 if d.dilate == 2 else 1
-        _trace("dgrad" if pw.flip else "conv", conv_kernel_name(d),
-               "%dx%d %d->%d @%dx%d B=%d%s%s" % (d.KH, d.KW, C, pw.Cout, d.Ho, d.Wo, B, " s2" if d.stride == 2 else "",
-                                                 " up2" if d.upsample == 2 else (" zero-stuffed" if stuffed == 4 else "")),
+        kname = conv_kernel_name(d)
+        # a stride-2 data gradient: by output phases (the PH instantiations, last template argument) or on the zero-stuffed operand
+        form = " up2" if d.upsample == 2 else ((" s2 dgrad by phases" if kname.endswith("true>") else " s2 dgrad zero-stuffed") if stuffed == 4 else "")
+        _trace("dgrad" if pw.flip else "conv", kname,
+               "%dx%d %d->%d @%dx%d B=%d%s%s" % (d.KH, d.KW, C, pw.Cout, d.Ho, d.Wo, B, " s2" if d.stride == 2 else "", form),
                2.0 * B * d.Ho * d.Wo * d.KH * d.KW * C * pw.Cout / stuffed,
                lambda a_=args, k_=keep: L.check(lib.hdrsky_conv2d_fwd(*a_, _stream()), "conv2d_fwd"))
     return y, stats
@@ -390,7 +393,9 @@ def conv2d_wgrad_multi(jobs, deterministic=True):
         flop = sum(2.0 * j[0].B * j[0].Ho * j[0].Wo * j[0].KH * j[0].KW * j[0].Cin * j[0].Cout for j in jobs)
         d0 = jobs[0][0]
         _LABEL[0] = ", ".join(WG_NAMES.get(j[4].data_ptr(), "?") for j in jobs)
-        _trace("wgrad", "conv_wgrad_kernel + wgrad_reduce_kernel (%d layers in one call)" % len(jobs),
+        nbuf = ctypes.create_string_buffer(1024)
+        lib.hdrsky_conv2d_wgrad_kernel_names(arr, len(jobs), nbuf, 1024)
+        _trace("wgrad", "%s (%d layers in one call)" % (nbuf.value.decode() or "conv_wgrad_kernel + wgrad_reduce_kernel", len(jobs)),
                "%d x e.g. %dx%d %d->%d @%dx%d B=%d" % (len(jobs), d0.KH, d0.KW, d0.Cin, d0.Cout, d0.Ho, d0.Wo, d0.B), flop,
                lambda a_=arr, n_=len(jobs), w_=ws, k_=jobs: L.check(
                    lib.hdrsky_conv2d_wgrad_multi_det(a_, n_, _p(w_), w_.numel(), _stream()), "conv2d_wgrad_multi_det"))
@@ -1173,7 +1178,8 @@ def resconv_fwd(x, pw: PackedConv, bias, gamma, beta, slope, residual=None, want
     if TRACE is not None:
         _trace("resconv", "resconv_kernel<%d>" % (Cin // 32), "3x3 %d->%d @%dx%d B=%d + InstanceNorm fwd" % (Cin, Cout, H, W, B),
                2.0 * B * H * W * 9 * Cin * Cout,
-               lambda a_=a, k_=(x, pw, bias, gamma, beta, residual, out): L.check(L.load().hdrsky_resconv(a_, _stream()), "resconv"))
+               lambda a_=a, k_=(x, pw, bias, gamma, beta, residual, out): L.check(L.load().hdrsky_resconv(a_, _stream()), "resconv"),
+               default_label="gen.res.* (sample-resident half block)")
     return out
 
 
@@ -1217,7 +1223,8 @@ def resconv_bwd(dy, pwT, skip=None, norm=None, want_f32=False, want_bf16=True, s
     if TRACE is not None and dy is not None:
         _trace("resconv", "resconv_kernel<%d>" % (Cin // 32), "3x3 %d->%d @%dx%d B=%d data gradient + InstanceNorm bwd" % (Cin, Cout, H, W, B),
                2.0 * B * H * W * 9 * Cin * Cout,
-               lambda a_=a, k_=(dy, pwT, skip, norm, out): L.check(L.load().hdrsky_resconv(a_, _stream()), "resconv"))
+               lambda a_=a, k_=(dy, pwT, skip, norm, out): L.check(L.load().hdrsky_resconv(a_, _stream()), "resconv"),
+               default_label="gen.res.* (data gradient + InstanceNorm backward)")
     return out
 
 

@@ -293,6 +293,9 @@ int hdrsky_conv2d_wgrad_multi(const hdrsky_wgrad_job* jobs, int njobs, void* str
  * and a second launch per group adds the partials to dw / db in a fixed order.  [host] for the size query. */
 size_t hdrsky_conv2d_wgrad_ws_bytes(const hdrsky_wgrad_job* jobs, int njobs);
 int hdrsky_conv2d_wgrad_multi_det(const hdrsky_wgrad_job* jobs, int njobs, void* ws, size_t ws_bytes, void* stream);
+/* [host] The kernels one hdrsky_conv2d_wgrad_multi_det call on these jobs launches, " + "-separated, named as rocprofv3
+ * prints them (e.g. "conv_wgrad2_kernel<5> + wgrad_reduce_kernel"): bench.py labels its roofline rows with it. */
+int hdrsky_conv2d_wgrad_kernel_names(const hdrsky_wgrad_job* jobs, int njobs, char* buf, int n);
 
 /* Keras BatchNormalization(training=True) statistics from the producing conv's partials [nparts_total][2][C]
  * (discriminator.py:25, sunrad_net.py:26): mean/rstd/scale/shift tables + moving-stat update (momentum 0.99,

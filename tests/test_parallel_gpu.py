@@ -312,3 +312,68 @@ def test_sync_batch_stats_two_replicas_equal_one_step_on_the_global_batch(dev, t
     for k, rk in (("kl", "kl"), ("perceptual", "perceptual"), ("dog", "dog"), ("l1", "l1"), ("adv", "adv"),
                   ("disc_generated", "generated"), ("disc_real", "real")):
         assert abs(got[k] - losses[rk]) <= 2e-3 * abs(losses[rk]) + 1e-6, (k, got[k], losses[rk])
+
+
+def _world1_rccl_worker(rank, port, out_dir):
+    """One rank, process group on RCCL (world size 1): the captured B = 32 step replayed quietly, then ten times with the
+    gradient exchange's hooks enqueuing their collectives on the communication stream AND a second process-independent
+    neighbour - MFMA- and LDS-heavy 512-thread conv workgroups looping on a fourth stream."""
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    os.environ.pop("NCCL_DEBUG", None)
+    P, synth, trainer, K, par = _mods()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    B = 32
+    nets = [P.init_params(P.generator_spec(), 0), P.init_params(P.sunpose_spec(), 1), P.init_params(P.discriminator_spec(), 2),
+            P.init_params(P.vgg_spec(), 3)]
+    res = {}
+    for mode in ("allreduce", "gather_dense"):
+        tr = trainer.Trainer(*nets, device=dev, precise=False, compute=K.BF16, world_size=1)
+        ex = par.GradientExchange(tr, device=dev, mode=mode)
+        assert ex.active and ex.hooks and ex.pre_hooks
+        b = synth.make_batch(B, seed=5)
+        data = [torch.from_numpy(b[k]).to(dev) for k in ("ldr", "hdr_t", "sunpose_gt")]
+        tr.capture(*data)
+        w0g, w0d, m0g, m0d = tr.gs.flat.clone(), tr.ds.flat.clone(), tr.gs.ms.clone(), tr.ds.ms.clone()
+        def restore():
+            tr.gs.flat.copy_(w0g); tr.ds.flat.copy_(w0d); tr.gs.ms.copy_(m0g); tr.ds.ms.copy_(m0d); tr.repack()
+        # quiet reference: one updating replay with the exchange's collectives but nothing else on the chip
+        restore(); tr.replay(hooks=ex.hooks, pre_hooks=ex.pre_hooks); torch.cuda.synchronize()
+        ref = (tr.gs.flat.clone(), tr.ds.flat.clone(), tr.gs.ms.clone(), tr.losses.clone())
+        side = torch.cuda.Stream(device=dev)
+        g = torch.Generator(device=dev); g.manual_seed(1)
+        xn = torch.randn(16, 64, 256, 64, device=dev, generator=g)
+        pwn = K.PackedConv(torch.randn(4, 4, 64, 128, device=dev, generator=g) * 0.03, False)
+        bn = torch.zeros(128, device=dev)
+        ok = True
+        for it in range(10):
+            restore(); torch.cuda.synchronize()
+            with torch.cuda.stream(side):
+                for _ in range(12): K.conv2d(xn, pwn, bn, stride=2)          # 128 px x 128 ch tiles: MFMA + LDS heavy, 512 threads
+            tr.replay(hooks=ex.hooks, pre_hooks=ex.pre_hooks)
+            torch.cuda.synchronize()
+            got = (tr.gs.flat, tr.ds.flat, tr.gs.ms, tr.losses)
+            same = [bool(torch.equal(a, c)) for a, c in zip(got, ref)]
+            ok = ok and all(same)
+            if not all(same):
+                res.setdefault("first_bad", (mode, it, same, [int((a != c).sum()) for a, c in zip(got, ref)]))
+        res[mode] = dict(ok=ok, describe=ex.describe())
+        del tr, ex
+    torch.save(res, os.path.join(out_dir, "w1.pt"))
+    torch.distributed.destroy_process_group()
+
+
+def test_captured_step_is_bit_reproducible_beside_rccl_and_a_heavy_neighbour(dev, tmp_path):
+    """The only multi-GPU evidence a one-GPU box can give: the captured B = 32 step, replayed ten times with
+    a world-1 RCCL process group whose all-reduce / all-gather kernels are REALLY enqueued on the communication stream by the
+    exchange's segment hooks, and with 128 px x 128 ch conv tiles looping on a fourth stream, leaves bit-identical weights,
+    RMSprop slots and loss terms to the quiet replay (same collectives, nothing else on the chip) - in both exchange modes.  (Round 3 had shown that a kernel's result
+    CAN depend on its neighbour: a packed-f32 instruction form beside MFMA-dense waves, csrc/Makefile.)"""
+    port = _free_port()
+    mp.spawn(_world1_rccl_worker, args=(port, str(tmp_path)), nprocs=1, join=True)
+    res = torch.load(os.path.join(str(tmp_path), "w1.pt"))
+    print(res)
+    assert "first_bad" not in res, res["first_bad"]
+    assert res["allreduce"]["ok"] and res["gather_dense"]["ok"]
