@@ -48,7 +48,7 @@ class ResconvArgs(ctypes.Structure):
 
 RC_FWD, RC_BWD = 0, 1
 
-ABI_VERSION = 3      # HDRSKY_ABI_VERSION of the include/hdrsky.h these mirrors were written against
+ABI_VERSION = 4      # HDRSKY_ABI_VERSION of the include/hdrsky.h these mirrors were written against
 STRUCTS = {"hdrsky_conv_desc": ConvDesc, "hdrsky_wgrad_job": WgradJob, "hdrsky_resconv_args": ResconvArgs}
 
 # name -> (restype, argtypes); every symbol include/hdrsky.h declares
@@ -71,7 +71,8 @@ SIGNATURES = {
     "hdrsky_conv2d_wgrad_ws_bytes": (c_size_t, [ctypes.POINTER(WgradJob), c_int]),
     "hdrsky_conv2d_wgrad_multi_det": (c_int, [ctypes.POINTER(WgradJob), c_int, P, c_size_t, P]),
     "hdrsky_conv2d_wgrad_kernel_names": (c_int, [ctypes.POINTER(WgradJob), c_int, ctypes.c_char_p, c_int]),
-    "hdrsky_norm_apply": (c_int, [P, P, c_int, P, P, c_float, c_float, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "hdrsky_wgrad2_eligible": (c_int, [ctypes.POINTER(WgradJob), c_int]),
+    "hdrsky_norm_apply": (c_int, [P, c_int, P, c_int, P, P, c_float, c_float, P, P, P, c_int, c_int, c_int, c_int, P]),
     "hdrsky_in_affine": (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_float, P, P, P]),
     "hdrsky_in_finalize": (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_float, P, P, P, P, P]),
     "hdrsky_bn_eval_affine": (c_int, [P, P, P, P, c_float, c_int, P, P, P]),
@@ -140,11 +141,11 @@ SIGNATURES = {
     "hdrsky_pad_channels": (c_int, [P, c_size_t, c_int, c_int, P, P]),
     "hdrsky_maxpool_fwd_bf16": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P]),
     "hdrsky_maxpool_relu_bwd_bf16": (c_int, [P, P, c_int, c_int, c_int, c_int, P, c_int, P]),
-    "hdrsky_up2x_xf_bf16": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, P, P, c_float, c_float, P, P]),
+    "hdrsky_up2x_xf_bf16": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, c_float, c_float, P, P]),
     "hdrsky_act_bwd_bf16": (c_int, [P, P, c_float, c_size_t, P, c_int, P]),
     "hdrsky_concat2": (c_int, [P, c_int, P, c_int, c_size_t, P, P]),
     "hdrsky_debug_wgrad2_stamps": (None, [P]),
-    "hdrsky_act_bf16": (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_int, P, c_int, P, P, c_float, c_float, P, P]),
+    "hdrsky_act_bf16": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, c_int, P, P, c_float, c_float, P, P]),
     "hdrsky_concat_rows4": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, c_int, P, P]),
     "hdrsky_vgg_pre": (c_int, [P, c_size_t, P, P]),
     "hdrsky_flip_rgb": (c_int, [P, c_size_t, P, P]),

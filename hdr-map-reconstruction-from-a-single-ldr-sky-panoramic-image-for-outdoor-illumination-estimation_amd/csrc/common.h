@@ -49,6 +49,29 @@ __device__ __forceinline__ void pack8(const float (&v)[8], uint4& hi, uint4& lo)
 
 __device__ __forceinline__ float leaky(float v, float slope) { return v >= 0.f ? v : v * slope; }
 
+// Four / eight consecutive elements (element offset e, a multiple of 4 / 8) of a tensor stored as fp32 or as bf16: gradients
+// with one reader (hdrsky_conv_desc.y_bf16 of a data-gradient conv) and - round 4 - raw conv outputs in front of a norm layer
+// travel as bf16 in the single-product mode; the readers widen them on the way in.
+__device__ __forceinline__ float4 ld4any(const float* p, int is_bf16, size_t e) {
+  if (is_bf16) {
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p) + e);
+    return make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                       __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u));
+  }
+  return *reinterpret_cast<const float4*>(p + e);
+}
+__device__ __forceinline__ void ld8any(const float* p, int is_bf16, size_t e, float4& lo, float4& hi) {
+  if (is_bf16) {
+    const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(p) + e);
+    lo = make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                     __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u));
+    hi = make_float4(__builtin_bit_cast(float, u.z << 16), __builtin_bit_cast(float, u.z & 0xffff0000u),
+                     __builtin_bit_cast(float, u.w << 16), __builtin_bit_cast(float, u.w & 0xffff0000u));
+  } else {
+    lo = *reinterpret_cast<const float4*>(p + e); hi = *reinterpret_cast<const float4*>(p + e + 4);
+  }
+}
+
 // (sum, sum of squares) of one channel over the nparts tile partials of a sample: pp -> the channel's sum in tile 0, tiles
 // 2*C floats apart, the squares C floats behind the sums.  Loads go out eight at a time (independent, all in flight), the
 // additions stay in tile order: bit-identical to the plain loop, without its chain of nparts dependent loads - which sat

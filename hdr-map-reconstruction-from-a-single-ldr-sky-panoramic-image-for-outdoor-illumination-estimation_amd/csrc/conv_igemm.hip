@@ -393,8 +393,26 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB
             }
           }
           if (!PRECISE && a.x_bf16) {
+            if (xf_identity) {     // a final activation: copied
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) sAhi[dst[u]] = ok[u] ? __builtin_bit_cast(uint4, va[u]) : uint4{0, 0, 0, 0};
+              for (int u = 0; u < UNR; ++u) sAhi[dst[u]] = ok[u] ? __builtin_bit_cast(uint4, va[u]) : uint4{0, 0, 0, 0};
+            } else {               // a raw conv output stored as bf16 (hdrsky_conv_desc.y_bf16 in front of a norm layer): the
+                                   // producer's normalisation + activation on the widened values, as for fp32 storage
+#pragma unroll
+              for (int u = 0; u < UNR; ++u) {
+                const uint4 b8 = __builtin_bit_cast(uint4, va[u]);
+                const unsigned wds[4] = {b8.x, b8.y, b8.z, b8.w};
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                  const float in = __builtin_bit_cast(float, (j & 1) ? (wds[j >> 1] & 0xffff0000u) : (wds[j >> 1] << 16));
+                  v[j] = ok[u] ? leaky(in * sc8[j] + sh8[j], slope) : 0.f;
+                }
+                uint4 hi, lo;
+                pack8<false>(v, hi, lo);
+                sAhi[dst[u]] = hi;
+              }
+            }
             continue;
           }
 #pragma unroll
@@ -968,8 +986,17 @@ __global__ void __launch_bounds__(256) conv_dot1_kernel(const ConvKArgs a) {
       const int ky = tap / a.KW, kx = tap - ky * a.KW;
       const int iy = oy * a.stride - a.pad_t + ky, ix = ox * a.stride - a.pad_l + kx;
       ok[u] = i < nitems && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-      const float* src = xb + ((size_t)(ok[u] ? iy : 0) * a.W + (ok[u] ? ix : 0)) * a.Cin + qc * 8;
-      xa[u] = *reinterpret_cast<const float4*>(src); xc[u] = *reinterpret_cast<const float4*>(src + 4);
+      const size_t eo = ((size_t)(ok[u] ? iy : 0) * a.W + (ok[u] ? ix : 0)) * a.Cin + qc * 8;
+      if (a.x_bf16) {       // a raw conv output stored as bf16: widened here, the affine + activation below as for fp32
+        const uint4 b8 = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(a.x) + (size_t)b * a.H * a.W * a.Cin + eo);
+        xa[u] = make_float4(__builtin_bit_cast(float, b8.x << 16), __builtin_bit_cast(float, b8.x & 0xffff0000u),
+                            __builtin_bit_cast(float, b8.y << 16), __builtin_bit_cast(float, b8.y & 0xffff0000u));
+        xc[u] = make_float4(__builtin_bit_cast(float, b8.z << 16), __builtin_bit_cast(float, b8.z & 0xffff0000u),
+                            __builtin_bit_cast(float, b8.w << 16), __builtin_bit_cast(float, b8.w & 0xffff0000u));
+      } else {
+        const float* src = xb + eo;
+        xa[u] = *reinterpret_cast<const float4*>(src); xc[u] = *reinterpret_cast<const float4*>(src + 4);
+      }
       const size_t g = ((size_t)(tap * cin32 + (qc >> 2)) * 4 + (qc & 3)) * a.Npad;   // column n = 0 of the packed image
       wh[u] = a.whi[g];
       if (a.wlo != nullptr) wl[u] = a.wlo[g];
@@ -1024,7 +1051,7 @@ static hdrsky_conv_desc phase_view(const hdrsky_conv_desc* d) {
 
 static bool dot1_applies(const hdrsky_conv_desc* d, const float* residual) {
   return d->Cout == 1 && d->Cin >= 32 && (d->Cin % 32) == 0 && d->upsample == 1 && d->dilate == 1 && !d->want_stats && !residual &&
-         !d->x_bf16 && !d->y_bf16 && d->out_slope == 1.f && !d->final_relu && d->res_mode == 0 &&
+         !(d->x_bf16 && d->compute == HDRSKY_BF16X3) && !d->y_bf16 && d->out_slope == 1.f && !d->final_relu && d->res_mode == 0 &&
          d->in_mode != HDRSKY_IN_PARTIALS && !hdrsky_hooks().no_dot1;
 }
 
@@ -1136,8 +1163,9 @@ int hdrsky_conv2d_fwd(const hdrsky_conv_desc* d, const float* x, const void* w_h
   if (d->in_mode == HDRSKY_IN_AFFINE && (!in_scale || !in_shift)) return HDRSKY_EINVAL;
   if (d->in_mode == HDRSKY_IN_PARTIALS && (!in_part || !in_gamma || !in_beta || d->in_nparts <= 0)) return HDRSKY_EINVAL;
   if (d->want_stats && !stats_part) return HDRSKY_EINVAL;
-  if (d->x_bf16 && (precise || narrow || d->upsample != 1 || d->in_mode != HDRSKY_IN_NONE || d->in_slope != 1.f))
-    return HDRSKY_EUNSUPPORTED;   // a bf16 operand is a final activation of the single-product mode
+  // a bf16 operand: a final activation, or (round 4) a raw conv output in front of a norm layer stored as bf16 - the
+  // operand transform then runs on the widened values; single-product mode, >= 32 channels, no fused resize
+  if (d->x_bf16 && (precise || narrow || d->upsample != 1)) return HDRSKY_EUNSUPPORTED;
   if (d->y_bf16 && (precise || (d->Cout & 3))) return HDRSKY_EUNSUPPORTED;
   if (d->res_mode != 0 && (d->res_mode != 1 || !residual || (d->Cout & 3))) return HDRSKY_EINVAL;
   ConvKArgs a{};

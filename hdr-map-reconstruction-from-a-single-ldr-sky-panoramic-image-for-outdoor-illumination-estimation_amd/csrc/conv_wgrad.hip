@@ -1424,7 +1424,9 @@ static int fill_job(WgradArgs& a, const hdrsky_wgrad_job& j) {
   a.in_mode = d->in_mode; a.ss_bstride = d->ss_bstride; a.in_nparts = d->in_nparts;
   a.in_eps = d->in_eps; a.in_inv_count = 1.f / (float)(d->H * d->W); a.in_slope = d->in_slope;
   a.x_bf16 = j.x_bf16; a.dy_bf16 = j.dy_bf16;
-  if (j.x_bf16 && (narrow || d->upsample != 1 || d->in_mode != HDRSKY_IN_NONE || d->in_slope != 1.f)) return HDRSKY_EUNSUPPORTED;
+  // (a bf16 x with an operand transform is a raw conv output stored as bf16: widened into the staging registers, the
+  // transform applied there as for fp32 storage)
+  if (j.x_bf16 && (narrow || d->upsample != 1)) return HDRSKY_EUNSUPPORTED;
   if (j.dy_bf16 && (d->Cout & 7) != 0) return HDRSKY_EUNSUPPORTED;
   if (j.da_ksize > 0) {
     // desc describes the 1x1 weight gradient over the virtual channels; x is the layer's real input [B,H,W,da_C] fp32
@@ -1450,7 +1452,7 @@ static bool v2_eligible(const hdrsky_wgrad_job& j) {
   return j.x_bf16 && j.dy_bf16 && j.da_ksize == 0 && d->compute == HDRSKY_BF16 && d->upsample == 1 && d->dilate == 1 &&
          // (stride 2: a tile's input patch is ~4x its output and every pixel of it is copied - such layers run on 64-pixel
          // tiles (wg2_prepare); measured, batch 32: 1.25-1.8x the register-staged kernel, 1.9-2.5x at 128x512)
-         (d->stride == 1 || (d->stride == 2 && d->Cin >= s2min)) && d->Cin >= 32 && (d->Cin % 32) == 0 && d->Cout >= 32 && (d->Cout % 32) == 0 &&
+         (d->stride == 1 || (d->stride == 2 && d->Cin >= s2min)) && d->Cin >= 32 && d->Cin <= 1024 && (d->Cin % 32) == 0 && d->Cout >= 32 && (d->Cout % 32) == 0 &&
          d->in_mode == HDRSKY_IN_NONE && d->in_slope == 1.f && j.x && j.dy && j.dw && d->KH * d->KW <= 64;
 }
 
@@ -1610,7 +1612,7 @@ static int wg3_kind(const hdrsky_wgrad_job& j) {
       (d->stride == 1 || d->stride == 2))
     return 1;
   if (d->Cout <= 4 && d->Cin >= 16 && (d->Cin % 16) == 0 && d->stride == 1 && !j.dy_bf16) {
-    if (j.x_bf16 && (d->in_mode != HDRSKY_IN_NONE || d->in_slope != 1.f)) return 0;
+    // (x_bf16 with a transform: a raw conv output stored as bf16 - widened and transformed while staging, as fp32 storage is)
     if (d->in_mode == HDRSKY_IN_AFFINE && (!j.in_scale || !j.in_shift)) return 0;
     if (d->in_mode == HDRSKY_IN_PARTIALS && (!j.in_part || !j.in_gamma || !j.in_beta || d->in_nparts <= 0)) return 0;
     return 2;
@@ -1906,6 +1908,16 @@ extern "C" int hdrsky_conv2d_wgrad_kernel_names(const hdrsky_wgrad_job* jobs, in
   g_wg_names = nullptr;
   snprintf(buf, (size_t)n, "%s", names.c_str());
   return rc;
+}
+
+// [host] 1 when the LDS-DMA kernel (conv_wgrad2_kernel) takes this job; with_final_bf16_x != 0: ... WOULD take it once x is
+// replaced by the final bf16 tensor hdrsky_act_bf16 writes (the caller's question in front of that launch)
+extern "C" int hdrsky_wgrad2_eligible(const hdrsky_wgrad_job* job, int with_final_bf16_x) {
+  if (!job) return 0;
+  if (!hdrsky_hooks().wgrad2) return 0;
+  hdrsky_wgrad_job j = *job;
+  if (with_final_bf16_x) { j.x_bf16 = 1; j.desc.in_mode = HDRSKY_IN_NONE; j.desc.in_slope = 1.f; }
+  return v2_eligible(j) ? 1 : 0;
 }
 
 extern "C" int hdrsky_conv2d_wgrad_multi_det(const hdrsky_wgrad_job* jobs, int njobs, void* ws, size_t ws_bytes, void* stream) {

@@ -37,7 +37,7 @@ __global__ void __launch_bounds__(256) norm_apply_kernel(const float* __restrict
                                                          int nparts, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float eps, float slope,
                                                          const float* __restrict__ residual, float* __restrict__ y,
-                                                         float* __restrict__ ypool, int B, int H, int W, int C, int S) {
+                                                         float* __restrict__ ypool, int B, int H, int W, int C, int S, int x16) {
   extern __shared__ float sm[];
   float* sScale = sm;
   float* sShift = sm + C;
@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(256) norm_apply_kernel(const float* __restrict
   in_tables_from_partials(part, b, nparts, C, 1.f / (float)(H * W), gamma, beta, eps, sScale, sShift, nullptr, nullptr);
   __syncthreads();
   const int c4 = C >> 2;
-  const float* xb = x + (size_t)b * H * W * C;
+  const size_t xo = (size_t)b * H * W * C;         // (x: fp32 or - x16 - bf16 storage of the raw conv output)
   float* yb = y + (size_t)b * H * W * C;
   const float* rb = residual ? residual + (size_t)b * H * W * C : nullptr;
   if (ypool == nullptr) {
@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(256) norm_apply_kernel(const float* __restrict
     const int end = min(total, (s + 1) * per);
     for (int i = s * per + threadIdx.x; i < end; i += 256) {
       const int c = (i % c4) * 4;
-      float4 v = reinterpret_cast<const float4*>(xb)[i];
+      float4 v = ld4any(x, x16, xo + (size_t)i * 4);
       v.x = leaky(v.x * sScale[c] + sShift[c], slope);
       v.y = leaky(v.y * sScale[c + 1] + sShift[c + 1], slope);
       v.z = leaky(v.z * sScale[c + 2] + sShift[c + 2], slope);
@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256) norm_apply_kernel(const float* __restrict
 #pragma unroll
         for (int dx = 0; dx < 2; ++dx) {
           const size_t idx = ((size_t)(2 * ph + dy) * W + (2 * pw + dx)) * c4 + cq;
-          float4 v = reinterpret_cast<const float4*>(xb)[idx];
+          float4 v = ld4any(x, x16, xo + idx * 4);
           v.x = leaky(v.x * sScale[c] + sShift[c], slope);
           v.y = leaky(v.y * sScale[c + 1] + sShift[c + 1], slope);
           v.z = leaky(v.z * sScale[c + 2] + sShift[c + 2], slope);
@@ -206,9 +206,11 @@ __global__ void __launch_bounds__(256) norm_act_bwd_kernel(const float* __restri
       gm[j] = gamma[c + j]; bt[j] = beta[c + j];
     }
   }
-  const float* xb = x + (size_t)b * H * W * C + c;
-  // dy: fp32, or bf16 (bit 1 of the flag word) when it is the output of a data-gradient conv that nothing else reads
+  const size_t xo = (size_t)b * H * W * C + c;
+  // dy: fp32, or bf16 (bit 1 of the flag word) when it is the output of a data-gradient conv that nothing else reads;
+  // x: fp32, or bf16 (bit 2) - the raw conv output in front of the norm layer as the single-product mode stores it
   const bool dy16 = (dx_bf16 & 2) != 0;
+  const int x16 = dx_bf16 & 4;
   dx_bf16 &= 1;
   // dx: fp32, or bf16 when its only readers are a data-gradient conv and a weight gradient (both round it to bf16 anyway)
   float* dxb = reinterpret_cast<float*>(dxv) + (size_t)b * H * W * C + c;
@@ -258,7 +260,7 @@ __global__ void __launch_bounds__(256) norm_act_bwd_kernel(const float* __restri
     if (!pooled) {
 #pragma unroll 4
       for (int p = u0 + slot; p < u1; p += 64) {
-        const float4 xv = *reinterpret_cast<const float4*>(xb + (size_t)p * C);
+        const float4 xv = ld4any(x, x16, xo + (size_t)p * C);
         const float4 up = get_dy((size_t)p * C);
         const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
         const float us[4] = {up.x, up.y, up.z, up.w};
@@ -292,7 +294,7 @@ __global__ void __launch_bounds__(256) norm_act_bwd_kernel(const float* __restri
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int p = (2 * ph + (k >> 1)) * W + 2 * px + (k & 1);
-          xv[k] = *reinterpret_cast<const float4*>(xb + (size_t)p * C);
+          xv[k] = ld4any(x, x16, xo + (size_t)p * C);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -866,14 +868,14 @@ int hdrsky_debug_lds_canary(int nblocks, int iters, void* report, void* stream) 
   return HDRSKY_OK;
 }
 
-int hdrsky_norm_apply(const float* x, const float* part, int nparts, const float* gamma, const float* beta, float eps,
+int hdrsky_norm_apply(const float* x, int x_bf16, const float* part, int nparts, const float* gamma, const float* beta, float eps,
                       float slope, const float* residual, float* y, float* ypool, int B, int H, int W, int C,
                       void* stream) {
   if (!x || !part || !gamma || !beta || !y || (C & 3) || C > 1024) return HDRSKY_EINVAL;
   if (ypool && ((H | W) & 1)) return HDRSKY_EINVAL;
   int S = 256 / B; if (S < 1) S = 1; if (S > 64) S = 64;
   hipLaunchKernelGGL(norm_apply_kernel, dim3(B * S), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream, x, part,
-                     nparts, gamma, beta, eps, slope, residual, y, ypool, B, H, W, C, S);
+                     nparts, gamma, beta, eps, slope, residual, y, ypool, B, H, W, C, S, x_bf16 ? 1 : 0);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }

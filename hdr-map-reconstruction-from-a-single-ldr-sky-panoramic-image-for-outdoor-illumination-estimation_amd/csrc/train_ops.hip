@@ -51,21 +51,15 @@ __global__ void __launch_bounds__(64) bn_train_finalize_kernel(const float* __re
 
 // four consecutive elements (element offset e, a multiple of 4) of an incoming gradient stored as fp32 or as bf16 (a
 // data-gradient conv's y_bf16 output whose only reader is the kernel at hand)
-__device__ __forceinline__ float4 ld4grad(const float* dy, int dy16, size_t e) {
-  if (dy16) {
-    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(dy) + e);
-    return make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
-                       __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u));
-  }
-  return *reinterpret_cast<const float4*>(dy + e);
-}
+__device__ __forceinline__ float4 ld4grad(const float* dy, int dy16, size_t e) { return ld4any(dy, dy16, e); }
 
 // g = dy * act'(pre), pre = xhat*gamma+beta, xhat = (x-mean[c])*rstd[c]; per-block partial (sum g, sum g*xhat)
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float slope, size_t npix, int C, float* __restrict__ part,
-                                                            int dy16) {
+                                                            int flags) {
+  const int dy16 = flags & 2, x16 = flags & 4;     // storage of dy / of x: bf16
   extern __shared__ float sm[];  // [256][8] partials
   const int c4 = C >> 2;
   const int lanes_c = c4 < 256 ? c4 : 256;            // threads along channels (C/4 <= 256)
@@ -78,7 +72,7 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* __restr
 #pragma unroll
     for (int j = 0; j < 4; ++j) { mu[j] = mean[c + j]; rs[j] = rstd[c + j]; gm[j] = gamma[c + j]; bt[j] = beta[c + j]; }
     for (size_t p = (size_t)blockIdx.x * rows + tr; p < npix; p += (size_t)gridDim.x * rows) {
-      const float4 xv = *reinterpret_cast<const float4*>(x + p * C + c);
+      const float4 xv = ld4any(x, x16, p * C + c);
       const float4 dv = ld4grad(dy, dy16, p * C + c);
       const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
 #pragma unroll
@@ -145,11 +139,11 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
                                     const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
                                     const float* __restrict__ m1m2, size_t n4, int C, void* __restrict__ dx, int dx_bf16) {
   const int c4 = C >> 2;
-  const int dy16 = dx_bf16 & 2;      // bit 1: dy given as bf16
+  const int dy16 = dx_bf16 & 2, x16 = dx_bf16 & 4;      // bit 1: dy given as bf16; bit 2: x stored as bf16
   dx_bf16 &= 1;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % c4) * 4;
-    const float4 xv = reinterpret_cast<const float4*>(x)[i];
+    const float4 xv = ld4any(x, x16, i * 4);
     const float4 dv = ld4grad(dy, dy16, i * 4);
     const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
     float o[4];
@@ -170,13 +164,13 @@ __global__ void affine_act_bwd_kernel(const float* __restrict__ x, const float* 
                                       const float* __restrict__ scale, const float* __restrict__ shift, float slope,
                                       size_t n, int C, void* __restrict__ dxv, int dx_bf16) {
   float* dx = reinterpret_cast<float*>(dxv);
-  const int dy16 = dx_bf16 & 2;      // bit 1: dy given as bf16 (V == 4 only)
+  const int dy16 = dx_bf16 & 2, x16 = dx_bf16 & 4;      // bit 1: dy given as bf16, bit 2: x stored as bf16 (V == 4 only)
   dx_bf16 &= 1;
   for (size_t i = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) * V; i < n; i += (size_t)gridDim.x * blockDim.x * V) {
     const int c = (int)(i % C);
     float v[V], g[V], o[V];
     if (V == 4) {
-      const float4 a = *reinterpret_cast<const float4*>(x + i), b = ld4grad(dy, dy16, i);
+      const float4 a = ld4any(x, x16, i), b = ld4grad(dy, dy16, i);
       v[0] = a.x; v[1 % V] = a.y; v[2 % V] = a.z; v[3 % V] = a.w;
       g[0] = b.x; g[1 % V] = b.y; g[2 % V] = b.z; g[3 % V] = b.w;
     } else {
@@ -368,7 +362,8 @@ __global__ void up2x_fwd_kernel(const float* __restrict__ a, const float* __rest
 __global__ void __launch_bounds__(256) up2x_xf_bf16_kernel(const float* __restrict__ x, int B, int H, int W, int C,
                                                            const float* __restrict__ part, int nparts,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           float eps, float slope, uint4* __restrict__ y, int blocks_per_sample) {
+                                                           float eps, float slope, uint4* __restrict__ y, int blocks_per_sample,
+                                                           int x16) {
   __shared__ float sSc[512], sSh[512];
   const int b = blockIdx.x / blocks_per_sample, blk = blockIdx.x % blocks_per_sample;
   const bool xf = part != nullptr;
@@ -389,7 +384,6 @@ __global__ void __launch_bounds__(256) up2x_xf_bf16_kernel(const float* __restri
   const int nitems = OH * OW * nq;
   const int per = (nitems + blocks_per_sample - 1) / blocks_per_sample;
   const int i1 = min(nitems, (blk + 1) * per);
-  const float* xb = x + (size_t)b * H * W * C;
   for (int i = blk * per + threadIdx.x; i < i1; i += 256) {
     const int q = i % nq, pix = i / nq;
     const int cx = pix % OW, cy = pix / OW;
@@ -398,15 +392,12 @@ __global__ void __launch_bounds__(256) up2x_xf_bf16_kernel(const float* __restri
     const int ylo = min(max((int)fy, 0), H - 1), yhi = max(min((int)ceilf(sy), H - 1), 0);
     const int xlo = min(max((int)fx, 0), W - 1), xhi = max(min((int)ceilf(sx), W - 1), 0);
     const float ly = sy - fy, lx = sx - fx;
-    const float* s00 = xb + ((size_t)ylo * W + xlo) * C + q * 8;
-    const float* s01 = xb + ((size_t)ylo * W + xhi) * C + q * 8;
-    const float* s10 = xb + ((size_t)yhi * W + xlo) * C + q * 8;
-    const float* s11 = xb + ((size_t)yhi * W + xhi) * C + q * 8;
+    const size_t xo = (size_t)b * H * W * C + q * 8;
     float4 t[8];
-    t[0] = *reinterpret_cast<const float4*>(s00); t[1] = *reinterpret_cast<const float4*>(s00 + 4);
-    t[2] = *reinterpret_cast<const float4*>(s01); t[3] = *reinterpret_cast<const float4*>(s01 + 4);
-    t[4] = *reinterpret_cast<const float4*>(s10); t[5] = *reinterpret_cast<const float4*>(s10 + 4);
-    t[6] = *reinterpret_cast<const float4*>(s11); t[7] = *reinterpret_cast<const float4*>(s11 + 4);
+    ld8any(x, x16, xo + ((size_t)ylo * W + xlo) * C, t[0], t[1]);
+    ld8any(x, x16, xo + ((size_t)ylo * W + xhi) * C, t[2], t[3]);
+    ld8any(x, x16, xo + ((size_t)yhi * W + xlo) * C, t[4], t[5]);
+    ld8any(x, x16, xo + ((size_t)yhi * W + xhi) * C, t[6], t[7]);
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -1170,14 +1161,14 @@ __global__ void __launch_bounds__(256) act_bf16_kernel(const float* __restrict__
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        int ss_bstride, const float* __restrict__ part, int nparts,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                       float slope, uint4* __restrict__ y, int bps) {
+                                                       float slope, uint4* __restrict__ y, int bps, int x16) {
   __shared__ float sSc[1024], sSh[1024];
   __shared__ float sP[4096];
   const int b = blockIdx.x / bps, blk = blockIdx.x % bps;
   const int nq = C >> 3, nitems = HW * nq;
   const int per = (nitems + bps - 1) / bps;
   const int i1 = min(nitems, (blk + 1) * per);
-  const float* xb = x + (size_t)b * HW * C;
+  const size_t xo = (size_t)b * HW * C;
   const bool xf = mode != HDRSKY_IN_NONE;
   constexpr int UNR = 4;                                   // items per thread in flight (all loads before the first use)
   float4 va[UNR], vb[UNR];
@@ -1186,8 +1177,7 @@ __global__ void __launch_bounds__(256) act_bf16_kernel(const float* __restrict__
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int i = min(i0 + u * 256, i1 - 1);
-      va[u] = *reinterpret_cast<const float4*>(xb + (size_t)i * 8);
-      vb[u] = *reinterpret_cast<const float4*>(xb + (size_t)i * 8 + 4);
+      ld8any(x, x16, xo + (size_t)i * 8, va[u], vb[u]);
     }
   }
   if (mode == HDRSKY_IN_PARTIALS && C <= 256) {
@@ -1237,8 +1227,7 @@ __global__ void __launch_bounds__(256) act_bf16_kernel(const float* __restrict__
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         const int i = min(i0 + u * 256, i1 - 1);
-        va[u] = *reinterpret_cast<const float4*>(xb + (size_t)i * 8);
-        vb[u] = *reinterpret_cast<const float4*>(xb + (size_t)i * 8 + 4);
+        ld8any(x, x16, xo + (size_t)i * 8, va[u], vb[u]);
       }
     }
 #pragma unroll
@@ -1470,7 +1459,7 @@ int hdrsky_bn_act_bwd(const float* x, const float* dy, const float* mean, const 
   float* part = workspace;
   float* m1m2 = workspace + (size_t)2 * nb * C;
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(256), 256 * 8 * sizeof(float), S_(stream), x, dy, mean, rstd,
-                     gamma, beta, slope, (size_t)npix, C, part, dx_bf16 & 2);
+                     gamma, beta, slope, (size_t)npix, C, part, dx_bf16 & 6);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, S_(stream), part, nb, C, (float)npix, m1m2,
                      dgamma, dbeta);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for((size_t)npix * C / 4)), dim3(256), 0, S_(stream), x, dy, mean,
@@ -1543,7 +1532,7 @@ int hdrsky_up2x_fwd(const float* a, const float* b, int B, int H, int W, int C, 
   return HDRSKY_OK;
 }
 
-int hdrsky_up2x_xf_bf16(const float* x, int B, int H, int W, int C, const float* in_part, int in_nparts, const float* gamma,
+int hdrsky_up2x_xf_bf16(const float* x, int x_bf16, int B, int H, int W, int C, const float* in_part, int in_nparts, const float* gamma,
                         const float* beta, float eps, float slope, void* y_bf16, void* stream) {
   if (!x || !y_bf16 || (C & 7) || C > 512 || B <= 0) return HDRSKY_EINVAL;
   if (in_part && (!gamma || !beta || in_nparts <= 0)) return HDRSKY_EINVAL;
@@ -1551,7 +1540,7 @@ int hdrsky_up2x_xf_bf16(const float* x, int B, int H, int W, int C, const float*
   int bps = cdiv(nitems, 256 * 8);          // ~8 items per thread
   if (bps < 1) bps = 1;
   hipLaunchKernelGGL(up2x_xf_bf16_kernel, dim3(B * bps), dim3(256), 0, S_(stream), x, B, H, W, C, in_part, in_nparts, gamma,
-                     beta, eps, slope, (uint4*)y_bf16, bps);
+                     beta, eps, slope, (uint4*)y_bf16, bps, x_bf16 ? 1 : 0);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }
@@ -1767,7 +1756,7 @@ int hdrsky_concat2(const float* a, int Ca, const float* b, int Cb, size_t npix, 
   return HDRSKY_OK;
 }
 
-int hdrsky_act_bf16(const float* x, int B, int HW, int C, int in_mode, const float* in_scale, const float* in_shift, int ss_bstride,
+int hdrsky_act_bf16(const float* x, int x_bf16, int B, int HW, int C, int in_mode, const float* in_scale, const float* in_shift, int ss_bstride,
                     const float* in_part, int in_nparts, const float* gamma, const float* beta, float eps, float slope,
                     void* y_bf16, void* stream) {
   if (!x || !y_bf16 || B <= 0 || HW <= 0 || C <= 0 || (C & 7) || C > 1024) return HDRSKY_EINVAL;
@@ -1777,7 +1766,7 @@ int hdrsky_act_bf16(const float* x, int B, int HW, int C, int in_mode, const flo
   int bps = cdiv(HW * (C >> 3), 256 * 4);          // ~4 items per thread, all in flight at once (16 behind a dependent-load
   if (bps < 1) bps = 1;                            // prologue: 63 us for 17 MB on 128 blocks)
   hipLaunchKernelGGL(act_bf16_kernel, dim3(B * bps), dim3(256), 0, S_(stream), x, HW, C, in_mode, in_scale, in_shift, ss_bstride,
-                     in_part, in_nparts, gamma, beta, eps, slope, (uint4*)y_bf16, bps);
+                     in_part, in_nparts, gamma, beta, eps, slope, (uint4*)y_bf16, bps, x_bf16 ? 1 : 0);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }

@@ -71,6 +71,16 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+def _raw(x):
+    """Validates a raw conv output - fp32, or bfloat16 as the single-product mode stores it in front of a norm layer -
+    and returns 1 for bfloat16 storage (the x_bf16 argument / flag bit of its readers)."""
+    if torch.is_tensor(x) and x.dtype == torch.bfloat16:
+        _bf16(x)
+        return 1
+    _f32(x)
+    return 0
+
+
 def _f32(t, *shape):
     if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
         raise ValueError("expected a contiguous CUDA float32 tensor")
@@ -311,13 +321,12 @@ def _da_wgrad_region(job):
 
 def wgrad_job(x, dy, KH, KW, dw, db=None, stride=1, same=True, upsample=1, xf: Optional[InXf] = None, compute=BF16):
     """One entry for conv2d_wgrad_multi: dw [KH,KW,Cin,Cout] (+= ; must hold valid values, e.g. zeros), db [Cout] or None.
-    x / dy may be bf16 tensors (the final activations / gradients of the sample-resident conv chain; no operand transform).
+    x / dy may be bf16 tensors: final activations / gradients (no operand transform), or - x with a transform - a raw conv
+    output as the single-product mode stores it (materialised by conv2d_wgrad_multi, or widened by the narrow-output kernel).
     The returned job references its tensors, which keeps them alive until the launch."""
     for t in (x, dy):
         if not (torch.is_tensor(t) and t.is_cuda and t.is_contiguous() and t.dtype in (torch.float32, torch.bfloat16)):
             raise ValueError("expected contiguous CUDA float32 / bfloat16 tensors")
-    if x.dtype == torch.bfloat16 and xf is not None and (xf.mode != L.IN_NONE or xf.slope != 1.0):
-        raise ValueError("a bf16 operand is final: no transform")
     B, H, W, C = x.shape
     Cout = dy.shape[-1]
     d = conv_desc(B, H, W, C, Cout, KH, KW, stride, same, upsample)
@@ -337,21 +346,36 @@ def wgrad2_on():
     return HOOKS.H.wgrad2
 
 
+def _fill_wgrad_job(j, job):
+    d, x, dy, tabs, dw, db = job[:6]
+    if len(job) > 6:
+        offs, j.da_ksize, j.da_C = job[6]
+        j.da_offs = _p(offs)
+    j.desc = d
+    j.x, j.dy, j.dw, j.db = _p(x), _p(dy), _p(dw), _p(db)
+    j.in_scale, j.in_shift, j.in_part, j.in_gamma, j.in_beta = [_p(t) for t in tabs]
+    j.x_bf16, j.dy_bf16 = int(x.dtype == torch.bfloat16), int(dy.dtype == torch.bfloat16)
+
+
 def _materialise_bf16_operand(job):
-    """A weight-gradient job whose fp32 input x still needs its operand transform (InstanceNorm / BatchNorm affine +
-    activation), rewritten onto the final bf16 tensor x' = hdrsky_act_bf16(x): the LDS-DMA kernel copies its tiles without
-    touching a register.  Only for the layers that kernel takes (single-product mode, bf16 dY, 32-channel multiples,
-    no resize / distortion-aware gather); everything else is returned unchanged."""
+    """A weight-gradient job whose input x (fp32, or a raw conv output stored as bf16) still needs its operand transform
+    (InstanceNorm / BatchNorm affine + activation), rewritten onto the final bf16 tensor x' = hdrsky_act_bf16(x): the LDS-DMA
+    kernel copies its tiles without touching a register.  Only for the layers that kernel takes - the library's own answer
+    (hdrsky_wgrad2_eligible); everything else is returned unchanged."""
     if len(job) > 6:
         return job
     d, x, dy, tabs, dw, db = job
-    if d.compute != BF16 or dy.dtype != torch.bfloat16 or x.dtype != torch.float32 or d.upsample != 1 or d.dilate != 1 or \
-            d.Cin < 32 or d.Cin % 32 or d.Cout < 32 or d.Cout % 32 or d.Cin > 1024:
+    x16 = x.dtype == torch.bfloat16
+    if x16 and d.in_mode == L.IN_NONE and d.in_slope == 1.0:
+        return job                   # a final bf16 activation already
+    j = L.WgradJob()
+    _fill_wgrad_job(j, job)
+    if not L.load().hdrsky_wgrad2_eligible(ctypes.byref(j), 1):
         return job
     B, H, W, C = x.shape
     xb = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=x.device)
     in_scale, in_shift, in_part, in_gamma, in_beta = tabs
-    L.check(L.load().hdrsky_act_bf16(_p(x), B, H * W, C, d.in_mode, _p(in_scale), _p(in_shift), d.ss_bstride, _p(in_part),
+    L.check(L.load().hdrsky_act_bf16(_p(x), int(x16), B, H * W, C, d.in_mode, _p(in_scale), _p(in_shift), d.ss_bstride, _p(in_part),
                                      d.in_nparts, _p(in_gamma), _p(in_beta), d.in_eps, d.in_slope, _p(xb), _stream()), "act_bf16")
     d2 = L.ConvDesc()
     ctypes.memmove(ctypes.byref(d2), ctypes.byref(d), ctypes.sizeof(d))
@@ -371,15 +395,7 @@ def conv2d_wgrad_multi(jobs, deterministic=True):
         jobs = [_materialise_bf16_operand(job) for job in jobs]
     arr = (L.WgradJob * len(jobs))()
     for i, job in enumerate(jobs):
-        d, x, dy, tabs, dw, db = job[:6]
-        j = arr[i]
-        if len(job) > 6:
-            offs, j.da_ksize, j.da_C = job[6]
-            j.da_offs = _p(offs)
-        j.desc = d
-        j.x, j.dy, j.dw, j.db = _p(x), _p(dy), _p(dw), _p(db)
-        j.in_scale, j.in_shift, j.in_part, j.in_gamma, j.in_beta = [_p(t) for t in tabs]
-        j.x_bf16, j.dy_bf16 = int(x.dtype == torch.bfloat16), int(dy.dtype == torch.bfloat16)
+        _fill_wgrad_job(arr[i], job)
     lib = L.load()
     if not deterministic or HOOKS.H.wgrad_atomic:     # (HDRSKY_WGRAD_ATOMIC: an A/B switch)
         L.check(lib.hdrsky_conv2d_wgrad_multi(arr, len(jobs), _stream()), "conv2d_wgrad_multi")
@@ -402,8 +418,9 @@ def conv2d_wgrad_multi(jobs, deterministic=True):
 
 
 def norm_apply(x, stats: Stats, gamma, beta, slope=1.0, residual=None, pool=False, eps=IN_EPS):
-    """y = leaky(IN(x)) [+ residual]; optionally also the 2x2 max-pool of y.  Returns y or (y, ypool)."""
-    _f32(x)
+    """y = leaky(IN(x)) [+ residual]; optionally also the 2x2 max-pool of y.  Returns y or (y, ypool).  x: fp32, or the raw conv
+    output as the single-product mode stores it (bfloat16; y is fp32 either way)."""
+    x16 = _raw(x)
     B, H, W, C = x.shape
     _f32(stats.part, B, stats.nparts, 2, C)
     if stats.count != H * W:
@@ -411,9 +428,9 @@ def norm_apply(x, stats: Stats, gamma, beta, slope=1.0, residual=None, pool=Fals
     _f32(gamma, C); _f32(beta, C)
     if residual is not None:
         _f32(residual, B, H, W, C)
-    y = torch.empty_like(x)
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
     yp = torch.empty((B, H // 2, W // 2, C), dtype=torch.float32, device=x.device) if pool else None
-    L.check(L.load().hdrsky_norm_apply(_p(x), _p(stats.part), stats.nparts, _p(gamma), _p(beta), eps, slope,
+    L.check(L.load().hdrsky_norm_apply(_p(x), x16, _p(stats.part), stats.nparts, _p(gamma), _p(beta), eps, slope,
                                        _p(residual), _p(y), _p(yp), B, H, W, C, _stream()), "norm_apply")
     return (y, yp) if pool else y
 
@@ -458,8 +475,9 @@ def norm_act_bwd(x, stats: Stats, gamma, beta, slope, dy, pooled, eps=IN_EPS, wa
                  sums=None, out_bf16=False):
     """dx of y = leaky(IN(x)) [-> maxpool2x2]; dy is the gradient wrt y (or wrt the pooled y).
     sums [B,2,C] (given, or allocated when want_sums): per-sample (d beta, d gamma) terms - reduce them over the batch with
-    DgbReducer for bit-reproducible gradients; dgamma / dbeta: accumulated by fp32 atomics instead (arrival order)."""
-    _f32(x)
+    DgbReducer for bit-reproducible gradients; dgamma / dbeta: accumulated by fp32 atomics instead (arrival order).
+    x: fp32 or bfloat16 (the raw conv output as stored)."""
+    x16 = _raw(x)
     B, H, W, C = x.shape
     _f32(stats.part, B, stats.nparts, 2, C)
     # dy: fp32, or bf16 (the output of a data-gradient conv that nothing else reads: out_bf16 of conv2d_dgrad)
@@ -474,7 +492,7 @@ def norm_act_bwd(x, stats: Stats, gamma, beta, slope, dy, pooled, eps=IN_EPS, wa
     S = L.load().hdrsky_norm_act_bwd_nslices(B, H, W, C, int(pooled))
     ws = torch.empty((B, S, 2, C), dtype=torch.float32, device=x.device) if S > 1 else None
     L.check(L.load().hdrsky_norm_act_bwd(_p(x), _p(stats.part), stats.nparts, _p(_f32(gamma, C)), _p(_f32(beta, C)),
-                                         eps, slope, _p(dy), int(pooled), _p(dx), int(out_bf16) | (2 if dy.dtype == torch.bfloat16 else 0), _p(sums), _p(dgamma),
+                                         eps, slope, _p(dy), int(pooled), _p(dx), int(out_bf16) | (2 if dy.dtype == torch.bfloat16 else 0) | (4 if x16 else 0), _p(sums), _p(dgamma),
                                          _p(dbeta), _p(ws), B, H, W, C, _stream()),
             "norm_act_bwd")
     return (dx, sums) if want_sums else dx
@@ -757,8 +775,10 @@ def zero_(t):
 def bn_act_bwd(x, dy, mean, rstd, gamma, beta, slope, dgamma=None, dbeta=None, out=None, out_bf16=False, sync=None):
     """Gradient through LeakyReLU(BatchNorm(x)) in training mode.  sync (parallel.BatchSync): the batch statistics ran over
     every replica's batch - the two means of the formula then run over the all-gathered partial blocks, d gamma / d beta
-    over this replica's (the gradient exchange sums them)."""
-    _f32(x)
+    over this replica's (the gradient exchange sums them).  x: fp32 or bfloat16 (the raw conv output as stored)."""
+    x16 = _raw(x)
+    if x16 and sync is not None:
+        raise ValueError("bn_act_bwd: bf16 storage of the raw conv output is not supported with batch statistics over replicas")
     dy16 = dy.dtype == torch.bfloat16       # a data-gradient conv's bf16 output (single-replica path only)
     if dy16 and sync is not None:
         raise ValueError("bn_act_bwd: a bf16 incoming gradient is not supported with batch statistics over replicas")
@@ -771,10 +791,10 @@ def bn_act_bwd(x, dy, mean, rstd, gamma, beta, slope, dgamma=None, dbeta=None, o
     if out_bf16:
         dx = _bf16(out, *x.shape) if out is not None else torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
     else:
-        dx = _f32(out, *x.shape) if out is not None else torch.empty_like(x)
+        dx = _f32(out, *x.shape) if out is not None else torch.empty(x.shape, dtype=torch.float32, device=x.device)
     args = (_p(x), _p(dy), _p(_f32(mean, C)), _p(_f32(rstd, C)), _p(_f32(gamma, C)), _p(_f32(beta, C)), slope, npix, C)
     if sync is None:
-        L.check(lib.hdrsky_bn_act_bwd(*args, _p(ws), _p(dgamma), _p(dbeta), _p(dx), int(out_bf16) | (2 if dy16 else 0), _stream()),
+        L.check(lib.hdrsky_bn_act_bwd(*args, _p(ws), _p(dgamma), _p(dbeta), _p(dx), int(out_bf16) | (2 if dy16 else 0) | (4 if x16 else 0), _stream()),
                 "bn_act_bwd")
         return dx
     part = ws[:2 * nb * C].view(nb, 2, C)
@@ -789,19 +809,19 @@ def bn_act_bwd(x, dy, mean, rstd, gamma, beta, slope, dgamma=None, dbeta=None, o
 def affine_act_bwd(x, dy, scale, shift, slope, out_bf16=False):
     odt = torch.bfloat16 if out_bf16 else torch.float32
     dy16 = dy.dtype == torch.bfloat16       # a data-gradient conv's bf16 output
-    if x.dtype == torch.bfloat16:      # plain activation backward on an ACTIVATED bf16 tensor
-        if scale is not None or shift is not None:
-            raise ValueError("a bf16 operand is a final activation: no affine")
+    if x.dtype == torch.bfloat16 and scale is None and shift is None:      # plain activation backward on an ACTIVATED bf16 tensor
         _bf16(x); (_bf16 if dy16 else _f32)(dy, *x.shape)
         dx = torch.empty(dy.shape, dtype=odt, device=dy.device)
         L.check(L.load().hdrsky_act_bwd_bf16(_p(x), _p(dy), slope, x.numel(), _p(dx), int(out_bf16) | (2 if dy16 else 0), _stream()),
                 "act_bwd_bf16")
         return dx
-    _f32(x); (_bf16 if dy16 else _f32)(dy, *x.shape)
+    x16 = _raw(x); (_bf16 if dy16 else _f32)(dy, *x.shape)          # (x bf16 + an affine: a raw conv output as stored)
     C = x.shape[-1]
+    if x16 and (C & 3):
+        raise ValueError("affine_act_bwd: bf16 storage wants C % 4 == 0")
     dx = torch.empty(x.shape, dtype=odt, device=x.device)
     L.check(L.load().hdrsky_affine_act_bwd(_p(x), _p(dy), _p(scale), _p(shift), slope, x.numel(), C, _p(dx),
-                                           int(out_bf16) | (2 if dy16 else 0), _stream()), "affine_act_bwd")
+                                           int(out_bf16) | (2 if dy16 else 0) | (4 if x16 else 0), _stream()), "affine_act_bwd")
     return dx
 
 
@@ -853,8 +873,9 @@ def deconv_materialised(compute):
 
 def up2x_act_bf16(x, xf: Optional[InXf] = None):
     """bf16 [B,2H,2W,C] = resize2x(leaky(IN(x))) - the materialised operand of a resize-deconvolution (xf: IN_PARTIALS
-    transform of the producing conv, or None for an activation); feed it to conv2d / wgrad_job with upsample=1."""
-    _f32(x)
+    transform of the producing conv, or None for an activation); feed it to conv2d / wgrad_job with upsample=1.
+    x: fp32 or bfloat16 (the raw conv output as stored)."""
+    x16 = _raw(x)
     B, H, W, C = x.shape
     y = torch.empty((B, 2 * H, 2 * W, C), dtype=torch.bfloat16, device=x.device)
     part = gamma = beta = None
@@ -867,7 +888,7 @@ def up2x_act_bf16(x, xf: Optional[InXf] = None):
         gamma, beta = _f32(xf.gamma, C), _f32(xf.beta, C)
         if st.count != H * W:
             raise ValueError("partials were not accumulated over this tensor's H*W")
-    L.check(L.load().hdrsky_up2x_xf_bf16(_p(x), B, H, W, C, _p(part), nparts, _p(gamma), _p(beta), eps, slope, _p(y), _stream()),
+    L.check(L.load().hdrsky_up2x_xf_bf16(_p(x), x16, B, H, W, C, _p(part), nparts, _p(gamma), _p(beta), eps, slope, _p(y), _stream()),
             "up2x_xf_bf16")
     return y
 

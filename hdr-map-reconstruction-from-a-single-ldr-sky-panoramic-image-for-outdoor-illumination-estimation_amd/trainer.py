@@ -387,7 +387,7 @@ class Trainer:
                 t["A3"], t["P3"] = t["s3"]["A"], t["s3"]["P"]
                 x = t["P3"]
                 continue
-            r1, st1 = c[n + ".conv1"].fwd(x, compute=cp, want_stats=True)
+            r1, st1 = c[n + ".conv1"].fwd(x, compute=cp, want_stats=True, out_bf16=self._raw_bf16())
             xf = self._inxf(st1, n + ".norm1", 0.0)
             r2, st2 = c[n + ".conv2"].fwd(r1, xf, cp, want_stats=True)
             a, pooled = K.norm_apply(r2, st2, w[n + ".norm2.gamma"], w[n + ".norm2.beta"], slope=0.0, pool=True)
@@ -491,7 +491,8 @@ class Trainer:
         R["d1"], _ = c[net + "d1"].fwd(x, compute=cp, out_slope=0.3, out_bf16=self._act_bf16())
         cur, xf = R["d1"], None
         for d in ("d2", "d3", "d4"):
-            raw, st = c[net + d].fwd(cur, xf, cp, want_stats=training)
+            # (d4's readers - the Dense heads / the 1-channel output conv - take fp32)
+            raw, st = c[net + d].fwd(cur, xf, cp, want_stats=training, out_bf16=self._raw_bf16() and d != "d4")
             n = net + d + ".norm."
             if training:
                 if self.sync is not None:      # batch statistics over the batch of every replica
@@ -554,7 +555,7 @@ class Trainer:
         R["d1"], _ = c[net + "d1"].fwd(x2, compute=cp, out_slope=0.3, out_bf16=self._act_bf16())
         cur, xf = R["d1"], None
         for d in ("d2", "d3", "d4"):
-            raw, st = c[net + d].fwd(cur, xf, cp, want_stats=True)
+            raw, st = c[net + d].fwd(cur, xf, cp, want_stats=True, out_bf16=self._raw_bf16() and d != "d4")
             n, C = net + d + ".norm.", raw.shape[-1]
             sc2 = torch.empty((2 * B, C), dtype=torch.float32, device=raw.device)
             sh2 = torch.empty_like(sc2)
@@ -615,6 +616,16 @@ class Trainer:
         bf16 in the single-product mode: the norm backward's output is stored as bf16 anyway, and its two passes over this
         tensor are half as long (HDRSKY_NAB_DY_BF16=0: A/B hook)."""
         return self._act_bf16() and HOOKS.H.nab_dy_bf16
+
+    def _raw_bf16(self):
+        """Raw conv outputs in front of an InstanceNorm / BatchNorm layer are stored as bf16 in the single-product mode: the
+        statistics come from the fp32 accumulators (conv epilogue), every reader - the next conv's staging, the weight
+        gradient's operand, the norm backward - widens while loading (include/hdrsky.h, "RAW CONV OUTPUTS AS bf16").  Not
+        the tensors a max-pool argmax is taken on (the sun-pose net's second convs: rounding makes ties), not beside the
+        distortion-aware kernels or the cross-replica BatchNorm (fp32 readers).  OFF by default (tuning hook HDRSKY_RAW_BF16=1):
+        profiles/r04_raw_bf16_ab.txt - the 32x128 step is 0.3 % shorter (its tensors live in the MALL; the readers are not
+        bandwidth-bound) and the loss terms move 1.5x further from the fp32 oracle."""
+        return self._act_bf16() and HOOKS.H.raw_bf16 and self.sync is None and not self.da_parts
 
     def _deconv_mat(self):
         return not self.precise and K.deconv_materialised(self.compute)
@@ -725,11 +736,11 @@ class Trainer:
                 c3, c2 = c["gen.conv3_" + sfx], c["gen.conv2_" + sfx]
                 u3 = T["u3"]          # written by fwd_enc, in front of the first decoder
                 K.label(c3.wkey)
-                d3, s3 = K.conv2d(u3, c3.pk, c3.b, compute=cp, want_stats=True)
+                d3, s3 = K.conv2d(u3, c3.pk, c3.b, compute=cp, want_stats=True, out_bf16=self._raw_bf16())
                 xf2 = self._inxf(s3, "gen.norm3_" + sfx, 0.1, partials=True)
                 u2 = K.up2x_act_bf16(d3, xf2)
                 K.label(c2.wkey)
-                d2, s2 = K.conv2d(u2, c2.pk, c2.b, compute=cp, want_stats=True)
+                d2, s2 = K.conv2d(u2, c2.pk, c2.b, compute=cp, want_stats=True, out_bf16=self._raw_bf16())
                 xf1 = self._inxf(s2, "gen.norm2_" + sfx, 0.1)
                 T["dech_" + sfx] = (d3, s3, xf2, d2, s2, xf1, u3, u2)
             else:
@@ -791,11 +802,12 @@ class Trainer:
         @seg("fwd_enc", 0)
         def _():
             ldr = T["ldr"]
-            T["c1"], T["s1"] = c["gen.conv1_d"].fwd(ldr, compute=cp, want_stats=True)        # generator.py:92-108
+            r16 = self._raw_bf16()
+            T["c1"], T["s1"] = c["gen.conv1_d"].fwd(ldr, compute=cp, want_stats=True, out_bf16=r16)        # generator.py:92-108
             T["xf2"] = self._inxf(T["s1"], "gen.norm1_d", 0.1)
-            T["c2"], T["s2"] = c["gen.conv2_d"].fwd(T["c1"], T["xf2"], cp, want_stats=True)
+            T["c2"], T["s2"] = c["gen.conv2_d"].fwd(T["c1"], T["xf2"], cp, want_stats=True, out_bf16=r16)
             T["xf3"] = self._inxf(T["s2"], "gen.norm2_d", 0.1)
-            T["c3"], T["s3"] = c["gen.conv3_d"].fwd(T["c2"], T["xf3"], cp, want_stats=True)
+            T["c3"], T["s3"] = c["gen.conv3_d"].fwd(T["c2"], T["xf3"], cp, want_stats=True, out_bf16=r16)
             x = K.norm_apply(T["c3"], T["s3"], w["gen.norm3_d.gamma"], w["gen.norm3_d.beta"], slope=0.1)
             T["x"] = [x]
             if self.use_resconv:      # generator.py:26-35 x6: two launches per block, InstanceNorm inside them
@@ -823,9 +835,9 @@ class Trainer:
                     T["x"].append(x)
             for i in range(0 if (self.use_resconv or self.da) else 6):   # generic launches (BF16X3, other image sizes)
                 p = "gen.res.%d." % i
-                r1, t1 = c[p + "conv1"].fwd(x, compute=cp, want_stats=True)
+                r1, t1 = c[p + "conv1"].fwd(x, compute=cp, want_stats=True, out_bf16=r16)
                 xf = self._inxf(t1, p + "norm1", 0.1)
-                r2, t2 = c[p + "conv2"].fwd(r1, xf, cp, want_stats=True)
+                r2, t2 = c[p + "conv2"].fwd(r1, xf, cp, want_stats=True, out_bf16=r16)
                 x = K.norm_apply(r2, t2, w[p + "norm2.gamma"], w[p + "norm2.beta"], slope=1.0, residual=x)
                 T["res%d" % i] = (r1, t1, xf, r2, t2)
                 T["x"].append(x)
@@ -1412,6 +1424,7 @@ class SunPoseTrainer(Trainer):
         self.lr, self.compute, self.precise, self.world = lr, compute, precise, world_size
         # distortion_aware: sunpose_net.py:11,16 - every sunposeLayer convolution is distortion_aware_ops.conv2d
         self.da_sun, self._da_geo = bool(distortion_aware), {}
+        self.da_parts, self.sync = (("sunpose",) if self.da_sun else ()), None
         hw = im_height * im_width
         self.dense_mfma = compute == BF16 and not precise and K.fc_xtdy_supported(hw // 64 * 128, hw) and K.fc_xtdy_supported(hw, hw)
         self.gs = FlatParams(OrderedDict(("sun." + k, v) for k, v in sun_params.items()), self.device)

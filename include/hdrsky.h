@@ -52,7 +52,7 @@ const char* hdrsky_version(void);
  * layout, and a structure that grew (round 2: hdrsky_conv_desc 25 -> 29 fields) would otherwise be
  * written past the end of a stale mirror by hdrsky_conv_desc_init.  (The reference has no FFI: SURVEY.md
  * section 8b; this is the convention a ctypes / cffi binding needs.) */
-#define HDRSKY_ABI_VERSION 3
+#define HDRSKY_ABI_VERSION 4
 int hdrsky_abi_version(void);
 size_t hdrsky_sizeof(const char* struct_name);
 
@@ -153,7 +153,7 @@ int hdrsky_conv2d_fwd(const hdrsky_conv_desc* d, const float* x, const void* w_h
  * IN statistics come from the producer conv's partials part[B][nparts][2][C].
  * Replaces tfa InstanceNormalization + tf.nn.leaky_relu / ops.relu + tf.add + ops.maxpool2d:
  * generator.py:26-35 (resBlock tail), :104-106 ; sunpose_net.py:20-30,55-62 ; ops.py:299-300,328-329. */
-int hdrsky_norm_apply(const float* x, const float* part, int nparts, const float* gamma, const float* beta, float eps,
+int hdrsky_norm_apply(const float* x, int x_bf16, const float* part, int nparts, const float* gamma, const float* beta, float eps,
                       float slope, const float* residual, float* y, float* ypool, int B, int H, int W, int C,
                       void* stream);
 
@@ -178,6 +178,11 @@ int hdrsky_bn_eval_affine(const float* gamma, const float* beta, const float* mo
 int hdrsky_norm_act_bwd(const float* x, const float* part, int nparts, const float* gamma, const float* beta,
                         float eps, float slope, const float* dy, int pooled, void* dx, int dx_bf16, float* sums,
                         float* dgamma, float* dbeta, float* ws, int B, int H, int W, int C, void* stream);
+/* RAW CONV OUTPUTS AS bf16 (round 4, ABI 4).  In the single-product mode a conv output in front of a norm layer may be stored
+ * as bf16 (hdrsky_conv_desc.y_bf16 together with want_stats: the statistics still come from the fp32 accumulators).  Its
+ * readers widen it on the way in: hdrsky_conv2d_fwd (x_bf16 with an operand transform), the x_bf16 argument of
+ * hdrsky_norm_apply / hdrsky_up2x_xf_bf16 / hdrsky_act_bf16, and BIT 2 (value 4) of the dx_bf16 flag word of
+ * hdrsky_norm_act_bwd / hdrsky_bn_act_bwd / hdrsky_affine_act_bwd.  Written once, read four to five times per step. */
 /* (hdrsky_norm_act_bwd, hdrsky_bn_act_bwd, hdrsky_affine_act_bwd, hdrsky_act_bwd_bf16: bit 1 of dx_bf16 = dy is GIVEN as bf16 - the output of a data-gradient conv with
  * hdrsky_conv_desc.y_bf16 that nothing else reads: half the bytes of the two passes over it.)
  * (dx_bf16 here and in hdrsky_bn_act_bwd / hdrsky_affine_act_bwd / hdrsky_act_bwd_bf16: dx is stored as bf16 - for a gradient
@@ -296,6 +301,10 @@ int hdrsky_conv2d_wgrad_multi_det(const hdrsky_wgrad_job* jobs, int njobs, void*
 /* [host] The kernels one hdrsky_conv2d_wgrad_multi_det call on these jobs launches, " + "-separated, named as rocprofv3
  * prints them (e.g. "conv_wgrad2_kernel<5> + wgrad_reduce_kernel"): bench.py labels its roofline rows with it. */
 int hdrsky_conv2d_wgrad_kernel_names(const hdrsky_wgrad_job* jobs, int njobs, char* buf, int n);
+/* [host] 1 when the LDS-DMA weight-gradient kernel (conv_wgrad2_kernel: both operands final bf16 tensors, copied into LDS
+ * without touching a register) takes this job; with_final_bf16_x != 0 asks whether it WOULD once x is replaced by the
+ * final bf16 tensor hdrsky_act_bf16 writes - the host's question in front of that launch (kernels._materialise_bf16_operand). */
+int hdrsky_wgrad2_eligible(const hdrsky_wgrad_job* job, int with_final_bf16_x);
 
 /* Keras BatchNormalization(training=True) statistics from the producing conv's partials [nparts_total][2][C]
  * (discriminator.py:25, sunrad_net.py:26): mean/rstd/scale/shift tables + moving-stat update (momentum 0.99,
@@ -389,7 +398,7 @@ int hdrsky_act_bwd_bf16(const void* y_bf16, const float* dy, float slope, size_t
  * tensor: y [B,2H,2W,C] = bf16(resize2x(leaky(IN(x), slope))) with the InstanceNorm affine from the producing conv's
  * statistics partials in_part [B][in_nparts][2][C] (NULL: x is already an activation) - the arithmetic and operation
  * order of hdrsky_conv2d_fwd's upsample = 2 staging, so a plain conv (x_bf16) on y equals the fused one.  C % 8 == 0. */
-int hdrsky_up2x_xf_bf16(const float* x, int B, int H, int W, int C, const float* in_part, int in_nparts, const float* gamma,
+int hdrsky_up2x_xf_bf16(const float* x, int x_bf16, int B, int H, int W, int C, const float* in_part, int in_nparts, const float* gamma,
                         const float* beta, float eps, float slope, void* y_bf16, void* stream);
 /* The activated input of a conv as a final bf16 tensor: y [B,HW,C] = bf16(leaky(x * scale + shift, slope)) with the
  * operand transform of hdrsky_conv_desc (in_mode / in_slope / tables: InstanceNorm + tf.nn.leaky_relu, generator.py:15-19,
@@ -398,7 +407,7 @@ int hdrsky_up2x_xf_bf16(const float* x, int B, int H, int W, int C, const float*
 /* debug only: 8 x u64 of s_memtime phase stamps per workgroup of subsequent conv_wgrad2_kernel launches (null disables):
  * [start, ring primed, main loop done, cycles waiting for copies, issuing copies, computing, tiles, end] */
 void hdrsky_debug_wgrad2_stamps(void* buf);
-int hdrsky_act_bf16(const float* x, int B, int HW, int C, int in_mode, const float* in_scale, const float* in_shift, int ss_bstride,
+int hdrsky_act_bf16(const float* x, int x_bf16, int B, int HW, int C, int in_mode, const float* in_scale, const float* in_shift, int ss_bstride,
                     const float* in_part, int in_nparts, const float* gamma, const float* beta, float eps, float slope,
                     void* y_bf16, void* stream);
 /* tf.concat([a, b], axis=-1) (discriminator.py:43). */

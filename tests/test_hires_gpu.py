@@ -206,10 +206,14 @@ def test_hires_training_step_gradients_match_oracle(dev, da):
     dl = ostep.discriminator_losses(dr, torch.from_numpy(ldr), torch.from_numpy(hdr), out["y_final_lin"].cpu(), training=True,
                                     new_stats=stats)
     names = [k for k in dr if "moving" not in k]
-    for k, v in zip(names, torch.autograd.grad(dl["total_disc_loss"], [dr[k] for k in names])):
-        # (3e-4 at 32x128, B = 2; here 16x the pixels go through the batch-statistics BatchNorms of a SINGLE sample and the
-        # HDR peaks through three LeakyReLU stages: measured 3e-3 .. 7e-3 on d1 / d2, the other layers below 1e-3)
-        assert_close(tr.ds.g["dis." + k], v, 2e-2, "dis grad " + k)
+    # (3e-4 at 32x128, B = 2; here 16x the pixels go through the batch-statistics BatchNorms of a SINGLE sample and the
+    # HDR peaks through three LeakyReLU stages: the worst ELEMENT of d1 / d2 sits at 3e-3 .. 3e-2 of the tensor's maximum
+    # depending on the build (any change of a summation order upstream moves it: round 4's compiler flag did), every
+    # tensor's rms error stays below 5e-3)
+    derr = sorted(((rel_max(tr.ds.g["dis." + k], v), rel_rms(tr.ds.g["dis." + k], v), k)
+                   for k, v in zip(names, torch.autograd.grad(dl["total_disc_loss"], [dr[k] for k in names]))), reverse=True)
+    print("128x512 da=%s discriminator gradients (rel max, rel rms, name), worst:" % (da,), derr[:4])
+    assert derr[0][0] < 5e-2 and max(r for _, r, _ in derr) < 5e-3, derr[:4]
 
 
 @pytest.mark.parametrize("da", [False, "res,decoders"])

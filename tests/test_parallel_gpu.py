@@ -355,7 +355,10 @@ def _world1_rccl_worker(rank, port, out_dir):
             tr.replay(hooks=ex.hooks, pre_hooks=ex.pre_hooks)
             torch.cuda.synchronize()
             got = (tr.gs.flat, tr.ds.flat, tr.gs.ms, tr.losses)
-            same = [bool(torch.equal(a, c)) for a, c in zip(got, ref)]
+            same = [bool(torch.equal(a, c)) for a, c in zip(got[:3], ref[:3])]
+            # the loss SCALARS are logging values summed by one fp32 atomic per block (csrc/train_ops.hip header): arrival
+            # order, so equal to rounding only - no gradient reads them
+            same.append(bool(torch.allclose(got[3], ref[3], rtol=1e-5, atol=1e-7)))
             ok = ok and all(same)
             if not all(same):
                 res.setdefault("first_bad", (mode, it, same, [int((a != c).sum()) for a, c in zip(got, ref)]))
@@ -368,8 +371,9 @@ def _world1_rccl_worker(rank, port, out_dir):
 def test_captured_step_is_bit_reproducible_beside_rccl_and_a_heavy_neighbour(dev, tmp_path):
     """The only multi-GPU evidence a one-GPU box can give: the captured B = 32 step, replayed ten times with
     a world-1 RCCL process group whose all-reduce / all-gather kernels are REALLY enqueued on the communication stream by the
-    exchange's segment hooks, and with 128 px x 128 ch conv tiles looping on a fourth stream, leaves bit-identical weights,
-    RMSprop slots and loss terms to the quiet replay (same collectives, nothing else on the chip) - in both exchange modes.  (Round 3 had shown that a kernel's result
+    exchange's segment hooks, and with 128 px x 128 ch conv tiles looping on a fourth stream, leaves bit-identical weights
+    and RMSprop slots (and loss scalars equal to the rounding of their atomic sums) to the quiet replay (same collectives,
+    nothing else on the chip) - in both exchange modes.  (Round 3 had shown that a kernel's result
     CAN depend on its neighbour: a packed-f32 instruction form beside MFMA-dense waves, csrc/Makefile.)"""
     port = _free_port()
     mp.spawn(_world1_rccl_worker, args=(port, str(tmp_path)), nprocs=1, join=True)

@@ -294,6 +294,47 @@ def test_train_step_in_bench_mode_bf16(dev):
     assert cos > 0.98, cos
 
 
+def test_train_step_with_raw_conv_outputs_stored_as_bf16(dev, monkeypatch):
+    """HDRSKY_RAW_BF16=1 (tuning hook, off by default: profiles/r04_raw_bf16_ab.txt): the bench-mode step with every raw conv
+    output in front of an InstanceNorm / BatchNorm layer stored as bf16.  Every reader is bit-exact on the widened tensor
+    (tests/test_raw_bf16_gpu.py); what this pins is the end-to-end cost of the extra rounding - losses within 5 % of the fp32
+    oracle (fp32 storage: 2 %), prediction PSNR above 40 dB, gradient cosine above 0.97 - and that the step really ran on
+    bf16 tensors."""
+    monkeypatch.setenv("HDRSKY_EXPERIMENTS", "1")
+    monkeypatch.setenv("HDRSKY_RAW_BF16", "1")
+    tr, (gen, sun, dis, vgg), batch = _mk(dev, 2, "BF16")
+    assert tr._raw_bf16()
+    tt = lambda dd: {k: torch.from_numpy(v) for k, v in dd.items()}
+    ldr, hdr, gt = (torch.from_numpy(batch[k]) for k in ("ldr", "hdr_t", "sunpose_gt"))
+    losses, gg, gs, gd, sg, sd, outs = ostep.train_step_grads(tt(gen), tt(sun), tt(dis), tt(vgg), ldr, hdr, gt)
+    seen = []
+    K = pkg("kernels")
+    conv2d = K.conv2d
+    def spy(x, *a, **kw):
+        y, st = conv2d(x, *a, **kw)
+        seen.append((x.dtype, kw.get("xf") is not None and kw["xf"].mode != 0, y.dtype, st is not None))
+        return y, st
+    monkeypatch.setattr(K, "conv2d", spy)
+    out = tr.step(ldr.to(dev), hdr.to(dev), gt.to(dev), update=False)
+    assert sum(1 for xd, xf, yd, st in seen if yd == torch.bfloat16 and st) >= 10      # producers in front of a norm layer
+    assert sum(1 for xd, xf, yd, st in seen if xd == torch.bfloat16 and xf) >= 8        # their consuming convs
+    got = tr.loss_dict()
+    for k, rk in (("kl", "kl"), ("perceptual", "perceptual"), ("dog", "dog"), ("l1", "l1"), ("adv", "adv"),
+                  ("total_gen_loss", "total_gen_loss"), ("total_disc_loss", "total_disc_loss")):
+        assert abs(got[k] - losses[rk]) <= 5e-2 * abs(losses[rk]) + 1e-6, (k, got[k], losses[rk])
+    a, b = out["y_final_gamma"].cpu().double(), outs["y_final_gamma"].double()
+    psnr = 10 * torch.log10(b.abs().max() ** 2 / ((a - b) ** 2).mean())
+    assert float(psnr) > 40.0, float(psnr)
+    dot = na = nb = 0.0
+    for prefix, ref in (("gen.", gg), ("sun.", gs)):
+        for k, v in ref.items():
+            g = tr.gs.g[prefix + k].cpu().double()
+            dot += float((g * v.double()).sum()); na += float((g * g).sum()); nb += float((v.double() ** 2).sum())
+    cos = dot / (na * nb) ** 0.5
+    print("raw bf16 step: psnr %.1f dB, gradient cosine %.5f" % (float(psnr), cos))
+    assert cos > 0.97, cos
+
+
 def test_fc_wgrad_bf16_and_fused_update(dev):
     """hdrsky_fc_wgrad_bf16: x^T dy with bf16-rounded operands and fp32 accumulation, any row count, row-strided operands;
     hdrsky_rmsprop_fc_fused: the same update hdrsky_rmsprop_fc applies to that gradient, without writing it."""
