@@ -8,6 +8,7 @@
 // columns x one reduction slice (split-R for occupancy: 64 column blocks x 4 slices = 256
 // workgroups at N = 4096); weights go HBM -> VGPR directly (streamed once, not shared between
 // waves), activations are staged as bf16 through a double-buffered LDS image shared by the 4 waves.
+#include <atomic>
 #include <cstdlib>
 
 #include "common.h"
@@ -17,34 +18,43 @@ namespace {
 
 constexpr int RCH = 256;  // reduction elements per chunk (8 k-steps of 32)
 
-template <int MF, bool PRECISE>
-__global__ void __launch_bounds__(256) fc_mfma_kernel(const float* __restrict__ x, const uint4* __restrict__ whi,
-                                                      const uint4* __restrict__ wlo, float* __restrict__ out, int M,
-                                                      int R, int O, int nsplit, long stride_col, long stride_kg) {
-  constexpr int MP = MF * 16;
-  __shared__ uint4 sX[2][PRECISE ? 2 : 1][32 * MP];  // [buf][hi/lo][kgroup(32)][m]
+// RG: reduction groups per workgroup.  A workgroup is RG x 4 waves: wave (rg, cw) owns 16 of the 64 output columns and the
+// chunks ch = rg, rg + RG, ... of the workgroup's reduction slice; at the end the groups' accumulators are added through
+// LDS in group order (fixed: bit-reproducible).  What bounds the kernel is the weight bytes in flight per CU (each wave
+// keeps one 8 KB chunk in its registers and the next one in flight): at RG = 1 - one workgroup of four waves per CU - the
+// stream ran at 2.8 TB/s; more reduction SLICES (hdrsky_fc_nsplit) raise it too, but every consumer of the partial sums then
+// reads more slices.  RG = 4 (16 waves, 4 per SIMD, <= 128 VGPRs) has the bytes in flight of 16 slices and the partial sums of 4.
+template <int MF, bool PRECISE, int RG>
+__global__ void __launch_bounds__(256 * RG) fc_mfma_kernel(const float* __restrict__ x, const uint4* __restrict__ whi,
+                                                           const uint4* __restrict__ wlo, float* __restrict__ out, int M,
+                                                           int R, int O, int nsplit, long stride_col, long stride_kg) {
+  constexpr int MP = MF * 16, PL = PRECISE ? 2 : 1;
+  extern __shared__ __attribute__((aligned(16))) unsigned char fc_smem[];
+  uint4* sXall = reinterpret_cast<uint4*>(fc_smem);       // [RG][buf 2][hi/lo][kgroup(32)][m]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rg = wave >> 2, cw = wave & 3, gtid = tid & 255;
   const int kq = lane >> 4, lr = lane & 15;
   const int ob = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
   const int rslice = R / nsplit;
   const int r0 = sp * rslice;
   const int nchunks = (rslice + RCH - 1) / RCH;   // the last chunk may be partial (rslice % 8 == 0): zero-filled
-  const int col = ob * 64 + wave * 16 + lr;
+  const int col = ob * 64 + cw * 16 + lr;
   const bool col_ok = col < O;
   const long wbase = (long)(col_ok ? col : 0) * stride_col;
+  uint4* sX = sXall + (size_t)rg * 2 * PL * 32 * MP;
 
   f32x4_t acc[MF];
 #pragma unroll
   for (int i = 0; i < MF; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   auto stage_x = [&](int chunk, int buf) {
-    // items: MP rows x 32 k-groups of 8
-    for (int i = tid; i < MP * 32; i += 256) {
+    // items: MP rows x 32 k-groups of 8, by the 256 threads of this reduction group
+    for (int i = gtid; i < MP * 32; i += 256) {
       const int m = i >> 5, kg = i & 31;
       float v[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = 0.f;
-      if (m < M && chunk * RCH + kg * 8 < rslice) {
+      if (m < M && chunk < nchunks && chunk * RCH + kg * 8 < rslice) {
         const float* p = x + (size_t)m * R + r0 + chunk * RCH + kg * 8;
         const float4 a = *reinterpret_cast<const float4*>(p);
         const float4 b = *reinterpret_cast<const float4*>(p + 4);
@@ -52,8 +62,8 @@ __global__ void __launch_bounds__(256) fc_mfma_kernel(const float* __restrict__ 
       }
       uint4 hi, lo;
       pack8<PRECISE>(v, hi, lo);
-      sX[buf][0][kg * MP + m] = hi;
-      if (PRECISE) sX[buf][PRECISE ? 1 : 0][kg * MP + m] = lo;
+      sX[(buf * PL + 0) * 32 * MP + kg * MP + m] = hi;
+      if (PRECISE) sX[(buf * PL + PL - 1) * 32 * MP + kg * MP + m] = lo;
     }
   };
 
@@ -67,43 +77,68 @@ __global__ void __launch_bounds__(256) fc_mfma_kernel(const float* __restrict__ 
         bh[s] = whi[idx];
         if (PRECISE) bl[s] = wlo[idx];
       }
-    } else {                                // partial last chunk (reduction lengths that are not multiples of 256)
-      const int left = (rslice - chunk * RCH) >> 3;
+    } else {                                // partial last chunk (reduction lengths that are not multiples of 256), or none
+      const int left = chunk < nchunks ? (rslice - chunk * RCH) >> 3 : 0;
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
         const bool ok = s * 4 + kq < left;
-        const long idx = wbase + (kg0 + (ok ? s * 4 + kq : 0)) * stride_kg;
-        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-        bh[s] = ok ? whi[idx] : z;
-        if (PRECISE) bl[s] = ok ? wlo[idx] : z;
+        const long idx = wbase + (ok ? kg0 + s * 4 + kq : 0) * stride_kg;
+        // (loaded unconditionally from a clamped index, then masked: `ok ? whi[idx] : zero` compiled to a load through a
+        // selected POINTER, with the zero constant parked in scratch memory)
+        const uint4 th = whi[idx];
+        bh[s] = make_uint4(ok ? th.x : 0u, ok ? th.y : 0u, ok ? th.z : 0u, ok ? th.w : 0u);
+        if (PRECISE) {
+          const uint4 tl = wlo[idx];
+          bl[s] = make_uint4(ok ? tl.x : 0u, ok ? tl.y : 0u, ok ? tl.z : 0u, ok ? tl.w : 0u);
+        }
       }
     }
   };
 
-  stage_x(0, 0);
-  load_w(0);
+  // every group walks the same number of trips (barriers are workgroup-wide); a trip past the group's last chunk multiplies zeros
+  const int ntrips = (nchunks + RG - 1) / RG;
+  stage_x(rg, 0);
+  load_w(rg);
   __syncthreads();
-  for (int ch = 0; ch < nchunks; ++ch) {
-    const int buf = ch & 1;
+  for (int it = 0; it < ntrips; ++it) {
+    const int buf = it & 1, nxt = (it + 1) * RG + rg;
     uint4 ch_bh[8], ch_bl[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) { ch_bh[s] = bh[s]; if (PRECISE) ch_bl[s] = bl[s]; }
-    if (ch + 1 < nchunks) load_w(ch + 1);
+    if (it + 1 < ntrips) load_w(nxt);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) {
-        const uint4 ah = sX[buf][0][(s * 4 + kq) * MP + mf * 16 + lr];
+        const uint4 ah = sX[(buf * PL + 0) * 32 * MP + (s * 4 + kq) * MP + mf * 16 + lr];
         if (PRECISE) {
-          const uint4 al = sX[buf][PRECISE ? 1 : 0][(s * 4 + kq) * MP + mf * 16 + lr];
+          const uint4 al = sX[(buf * PL + PL - 1) * 32 * MP + (s * 4 + kq) * MP + mf * 16 + lr];
           acc[mf] = mfma16(al, ch_bh[s], acc[mf]);
           acc[mf] = mfma16(ah, ch_bl[s], acc[mf]);
         }
         acc[mf] = mfma16(ah, ch_bh[s], acc[mf]);
       }
     }
-    if (ch + 1 < nchunks) stage_x(ch + 1, buf ^ 1);
+    if (it + 1 < ntrips) stage_x(nxt, buf ^ 1);
     __syncthreads();
+  }
+  if (RG > 1) {
+    // the groups' partial sums, added in group order by group 0 (the operand buffers are free: everyone is past the last barrier)
+    f32x4_t* sAcc = reinterpret_cast<f32x4_t*>(fc_smem);          // [RG - 1][MF][256]
+    if (rg > 0) {
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) sAcc[((rg - 1) * MF + mf) * 256 + gtid] = acc[mf];
+    }
+    __syncthreads();
+    if (rg > 0) return;
+#pragma unroll
+    for (int g = 1; g < RG; ++g)
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        const f32x4_t t = sAcc[((g - 1) * MF + mf) * 256 + gtid];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[mf][j] += t[j];
+      }
   }
   if (col_ok) {
 #pragma unroll
@@ -135,18 +170,44 @@ __global__ void fc_pack_kernel(const float* __restrict__ w, int K, int N, unsign
   }
 }
 
+template <int MF, bool PRECISE, int RG>
+int launch_fc_v(const float* x, const void* whi, const void* wlo, float* out, int M, int R, int O, int nsplit,
+                long stride_col, long stride_kg, hipStream_t s) {
+  const int grid = cdiv(O, 64) * nsplit;
+  constexpr int lds = RG * 2 * (PRECISE ? 2 : 1) * 32 * (MF * 16) * 16;
+  auto kern = fc_mfma_kernel<MF, PRECISE, RG>;
+  if (lds > 64 * 1024) {
+    static std::atomic<bool> attr_set{false};
+    if (!attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        return HDRSKY_ELAUNCH;
+      attr_set = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * RG), lds, s, x, (const uint4*)whi, (const uint4*)wlo, out, M, R, O, nsplit,
+                     stride_col, stride_kg);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
 template <bool PRECISE>
 int launch_fc(const float* x, const void* whi, const void* wlo, float* out, int M, int R, int O, int nsplit,
               long stride_col, long stride_kg, hipStream_t s) {
-  const int grid = cdiv(O, 64) * nsplit;
-  if (M <= 16)
-    hipLaunchKernelGGL((fc_mfma_kernel<1, PRECISE>), dim3(grid), dim3(256), 0, s, x, (const uint4*)whi,
-                       (const uint4*)wlo, out, M, R, O, nsplit, stride_col, stride_kg);
-  else
-    hipLaunchKernelGGL((fc_mfma_kernel<2, PRECISE>), dim3(grid), dim3(256), 0, s, x, (const uint4*)whi,
-                       (const uint4*)wlo, out, M, R, O, nsplit, stride_col, stride_kg);
-  HDRSKY_CHECK_LAUNCH();
-  return HDRSKY_OK;
+  // reduction groups per workgroup (tuning hook HDRSKY_FC_RG; the split-product mode holds twice the registers and LDS: 1)
+  // Measured (profiles/r04_fc_rg_ab.txt, fc1 8192 -> 4096, 32 rows): forward 24.3 -> 16.7 us at 4 groups (2.8 -> 4.0 TB/s of
+  // weight stream); the data gradient (natural image: 16-byte pieces of 4096 different rows per load) gains little beyond 2
+  // (18.4 -> 17.1 us).  Forward pass 0.508 -> 0.504 ms; the training step does not notice.
+  const int hook = hdrsky_hooks().fc_rg;
+  const int rg = PRECISE ? 1 : (stride_col == 1 ? hook : (hook < 2 ? hook : 2));
+  const int chunks = (R / nsplit + RCH - 1) / RCH;
+  if (M <= 16) {
+    if (rg >= 4 && chunks >= 4) return launch_fc_v<1, PRECISE, PRECISE ? 1 : 4>(x, whi, wlo, out, M, R, O, nsplit, stride_col, stride_kg, s);
+    if (rg >= 2 && chunks >= 2) return launch_fc_v<1, PRECISE, PRECISE ? 1 : 2>(x, whi, wlo, out, M, R, O, nsplit, stride_col, stride_kg, s);
+    return launch_fc_v<1, PRECISE, 1>(x, whi, wlo, out, M, R, O, nsplit, stride_col, stride_kg, s);
+  }
+  if (rg >= 4 && chunks >= 4) return launch_fc_v<2, PRECISE, PRECISE ? 1 : 4>(x, whi, wlo, out, M, R, O, nsplit, stride_col, stride_kg, s);
+  if (rg >= 2 && chunks >= 2) return launch_fc_v<2, PRECISE, PRECISE ? 1 : 2>(x, whi, wlo, out, M, R, O, nsplit, stride_col, stride_kg, s);
+  return launch_fc_v<2, PRECISE, 1>(x, whi, wlo, out, M, R, O, nsplit, stride_col, stride_kg, s);
 }
 
 }  // namespace
