@@ -820,7 +820,9 @@ int launch_conv(ConvKArgs& a, hipStream_t stream) {
     a.cgs = 8; a.ngroups = 1; a.log2nq = 0; a.log2cbg = 0;
     a.ksg = cdiv(a.ntaps, 4);
   } else {
-    int cgs = a.Cin;
+    // channel groups are powers of two (index arithmetic by shifts) that divide Cin: all of Cin when it is one, else its
+    // largest power-of-two divisor (1152 = 9 x 128: the 1x1 conv over the k*k*C gathered channels of a distortion-aware layer)
+    int cgs = (a.Cin & (a.Cin - 1)) ? (a.Cin & -a.Cin) : a.Cin;
     while (cgs > 32 && (cgs / 8) * a.NPIXP * 16 * bplanes > budget) cgs >>= 1;
     if ((cgs / 8) * a.NPIXP * 16 * bplanes > budget || (a.Cin % cgs) != 0) return HDRSKY_EUNSUPPORTED;
     a.cgs = cgs; a.ngroups = a.Cin / cgs; a.log2nq = ilog2(cgs / 8); a.log2cbg = ilog2(cgs / 32);

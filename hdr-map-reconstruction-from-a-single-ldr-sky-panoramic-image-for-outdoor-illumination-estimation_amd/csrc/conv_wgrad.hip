@@ -1452,7 +1452,7 @@ static bool v2_eligible(const hdrsky_wgrad_job& j) {
   return j.x_bf16 && j.dy_bf16 && j.da_ksize == 0 && d->compute == HDRSKY_BF16 && d->upsample == 1 && d->dilate == 1 &&
          // (stride 2: a tile's input patch is ~4x its output and every pixel of it is copied - such layers run on 64-pixel
          // tiles (wg2_prepare); measured, batch 32: 1.25-1.8x the register-staged kernel, 1.9-2.5x at 128x512)
-         (d->stride == 1 || (d->stride == 2 && d->Cin >= s2min)) && d->Cin >= 32 && d->Cin <= 1024 && (d->Cin % 32) == 0 && d->Cout >= 32 && (d->Cout % 32) == 0 &&
+         (d->stride == 1 || (d->stride == 2 && d->Cin >= s2min)) && d->Cin >= 32 && d->Cin <= 4096 && (d->Cin % 32) == 0 && d->Cout >= 32 && (d->Cout % 32) == 0 &&
          d->in_mode == HDRSKY_IN_NONE && d->in_slope == 1.f && j.x && j.dy && j.dw && d->KH * d->KW <= 64;
 }
 

@@ -676,6 +676,85 @@ __global__ void __launch_bounds__(256) da_gather_scatter_kernel(const DaGsArgs a
   }
 }
 
+// ---- the gathered operand as a bf16 tensor ----------------------------------------------------------------------------
+// G[b][p][t*C + c] = sum_m w(p,t,m) * src[b][idx(p,t,m)][c], rounded to bf16: exactly what the fused kernels above feed the
+// matrix cores, written once.  With it the layer IS the reference's own formulation (distortion_aware_ops.py:107-121: gather,
+// then matmul with the [k*k*C, F] kernel): a 1x1 convolution over k*k*C channels for the generic conv / weight-gradient
+// kernels, whose packed filter image is the k x k filter's own (same k-step order).  Two position sources:
+//   offs != NULL: the forward's four corners (da_tap, the reference's float32 arithmetic);
+//   gidx / gw [H*W][k*k][km]: a sample table - the TRANSPOSED table of hdrsky_da_conv2d_dgrad (km = 8) makes this the
+//   operand of the data gradient, in the tap order of the transpose_flip filter image.
+// src: fp32 or bf16.  Thread = (sample, pixel, tap, 8 channels): 16-byte loads per corner, one 16-byte store; consecutive
+// threads write consecutive bytes.  Measured against the fused region kernels on the 128x512 step: profiles/r04_da_mat_ab.txt.
+struct DaG16Args {
+  const float* src; int src_bf16;
+  unsigned short* dst;
+  const float* offs;
+  const int* gidx; const float* gw; int km;
+  int B, H, W, C, ksize, k2, pad, in_h, in_w;
+  int nq, lognq, pixb;   // 8-channel groups per pixel (lognq >= 0: a power of two); pixels per workgroup
+};
+
+// Workgroup = (sample, DA_G16_PIXB consecutive pixels): the sample positions of its (pixel, tap) pairs are worked out ONCE
+// (one thread each: da_tap, or a table row) into LDS; the items (pixel, tap, 8 channels) - contiguous 16-byte pieces of G in
+// exactly this order - are then shared out over the threads: per item one LDS entry, up to km 16/32-byte source loads, one
+// 16-byte store.  No per-item index division (the first version spent most of its time in 64-bit divisions: 105 us for the
+// 75 MB of a 128-channel layer at 32x128, batch 8).
+constexpr int DA_G16_KM = 8;
+__global__ void __launch_bounds__(256) da_gather_bf16_kernel(const DaG16Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char g16_smem[];
+  int* sIdx = reinterpret_cast<int*>(g16_smem);                     // [pixb * k2][km]
+  const int km = a.offs != nullptr ? 4 : a.km;
+  const int npt = a.pixb * a.k2;
+  float* sW = reinterpret_cast<float*>(g16_smem) + npt * km;
+  const int HW = a.H * a.W;
+  const int pix0 = blockIdx.x * a.pixb, b = blockIdx.y;
+  const int npix = min(a.pixb, HW - pix0);
+  for (int e = threadIdx.x; e < npix * a.k2; e += 256) {
+    const int pl = e / a.k2, t = e - pl * a.k2, pix = pix0 + pl;
+    if (a.offs != nullptr) {
+      const int oy = pix / a.W, ox = pix - oy * a.W;
+      const float off_y = a.offs[(oy * a.k2 + t) * 2], off_x = a.offs[(oy * a.k2 + t) * 2 + 1];
+      const Tap4 s = da_tap((float)(oy + t / a.ksize), (float)(ox + t % a.ksize), off_y, off_x, a.in_h, a.in_w);
+      const int ys[4] = {s.y0, s.y0, s.y1, s.y1}, xs[4] = {s.x0, s.x1, s.x0, s.x1};
+      const float ws[4] = {s.w0, s.w1, s.w2, s.w3};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int yy = ys[k] - a.pad, xx = xs[k] - a.pad;      // un-padded coordinates; the border is zero
+        sIdx[e * 4 + k] = (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) ? yy * a.W + xx : -1;
+        sW[e * 4 + k] = ws[k];
+      }
+    } else {
+      const int* gi = a.gidx + ((size_t)pix * a.k2 + t) * km;
+      const float* gwt = a.gw + ((size_t)pix * a.k2 + t) * km;
+      for (int m = 0; m < km; ++m) { sIdx[e * km + m] = gi[m]; sW[e * km + m] = gwt[m]; }
+    }
+  }
+  __syncthreads();
+  const size_t sbase = (size_t)b * HW * a.C;
+  uint4* dst = reinterpret_cast<uint4*>(a.dst) + ((size_t)b * HW + pix0) * a.k2 * a.nq;
+  const int nitems = npix * a.k2 * a.nq;
+  for (int it = threadIdx.x; it < nitems; it += 256) {
+    const int e = a.lognq >= 0 ? it >> a.lognq : it / a.nq, q = it - e * a.nq;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    for (int m = 0; m < km; ++m) {
+      const int sp = sIdx[e * km + m];
+      if (sp >= 0) {
+        const float w = sW[e * km + m];
+        float4 lo, hi;
+        ld8any(a.src, a.src_bf16, sbase + (size_t)sp * a.C + q * 8, lo, hi);
+        v[0] += w * lo.x; v[1] += w * lo.y; v[2] += w * lo.z; v[3] += w * lo.w;
+        v[4] += w * hi.x; v[5] += w * hi.y; v[6] += w * hi.z; v[7] += w * hi.w;
+      }
+    }
+    uint4 h8, l8;
+    pack8<false>(v, h8, l8);
+    dst[it] = h8;
+  }
+}
+
 // Taps per barrier round for a layer with C input channels on nwv waves when a thread may hold up to imax_max (pixel,
 // 8-channel) items per round; returns whether two items per thread suffice (the smaller register variant of the forward).
 // HDRSKY_DA_TPR caps it (1 = one tap per round, the layout before): tuning / test hook.
@@ -1276,6 +1355,33 @@ int hdrsky_da_conv2d_dgrad(const float* dy, const void* wT_hi, const void* wT_lo
 // G[B,H,W,k*k*C] = bilinear gather of x[B,H,W,C] (the operand of the layer's matmul, distortion_aware_ops.py:62-113)
 int hdrsky_da_gather(const float* x, const float* offs, int B, int H, int W, int C, int ksize, float* G, void* stream) {
   return da_gs_launch(false, x, offs, B, H, W, C, ksize, G, stream);
+}
+
+// G (bf16) [B,H,W,k*k*C]: the operand the matrix cores see, from the forward's corners (offs) or from a sample table
+int hdrsky_da_gather_bf16(const void* x, int x_bf16, const float* offs, const int* gidx, const float* gw, int km, int B, int H,
+                          int W, int C, int ksize, void* G, void* stream) {
+  if (!x || !G || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7) || (ksize & 1) == 0 || ksize > 7) return HDRSKY_EINVAL;
+  if (!offs && (!gidx || !gw || km <= 0)) return HDRSKY_EINVAL;
+  if ((size_t)H * W * ksize * ksize * (size_t)(km > 0 ? km : 1) >= ((size_t)1 << 31)) return HDRSKY_EUNSUPPORTED;
+  DaG16Args a{};
+  a.src = (const float*)x; a.src_bf16 = x_bf16; a.dst = (unsigned short*)G; a.offs = offs; a.gidx = gidx; a.gw = gw; a.km = km;
+  a.B = B; a.H = H; a.W = W; a.C = C; a.ksize = ksize; a.k2 = ksize * ksize;
+  a.pad = ksize > 1 ? (ksize - 1) / 2 : 0;
+  a.in_h = H + (ksize > 1 ? ksize - 1 : 0); a.in_w = W + (ksize > 1 ? ksize - 1 : 0);
+  if (!offs && km > DA_G16_KM) return HDRSKY_EUNSUPPORTED;
+  a.nq = C >> 3;
+  a.lognq = -1;
+  for (int l = 0; l < 12; ++l) if ((1 << l) == a.nq) a.lognq = l;
+  // pixels per workgroup: ~2304 items (9 per thread), at most what 32 KB of position entries hold, and a y grid dimension per sample
+  int pixb = 2304 / (a.k2 * a.nq);
+  pixb = pixb < 1 ? 1 : (pixb > 64 ? 64 : pixb);
+  const int kme = offs ? 4 : km;
+  while (pixb > 1 && pixb * a.k2 * kme * 8 > 32 * 1024) pixb >>= 1;
+  a.pixb = pixb;
+  if (B > 65535) return HDRSKY_EUNSUPPORTED;
+  hipLaunchKernelGGL(da_gather_bf16_kernel, dim3(cdiv(H * W, pixb), B), dim3(256), pixb * a.k2 * kme * 8, (hipStream_t)stream, a);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
 }
 
 // dx[B,H,W,C] += transpose of the gather applied to dG[B,H,W,k*k*C] (fp32 atomics: zero dx first)

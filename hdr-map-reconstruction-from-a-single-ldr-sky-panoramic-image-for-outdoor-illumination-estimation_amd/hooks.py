@@ -17,6 +17,7 @@ class _Hooks:
         self.wgrad_atomic = env("HDRSKY_WGRAD_ATOMIC", "0") == "1"      # fp32-atomics weight gradients (not deterministic)
         self.da_wgrad_region = env("HDRSKY_DA_WGRAD_REGION", "1") != "0"   # LDS-region kernel gradient of the DA conv
         self.dog_fused = env("HDRSKY_DOG_FUSED", "1") != "0"            # the DoG loss term as one launch
+        self.da_mat = env("HDRSKY_DA_MAT", "1") != "0"                  # distortion-aware layers: gathered operand written once (bf16) + 1x1 conv
         self.dist_backend = env("HDRSKY_DIST_BACKEND") or None          # "gloo" for the one-card rehearsals
         self.dp_mode = env("HDRSKY_DP_MODE") or None                    # parallel.MODES
         # ---- tuning hooks (HDRSKY_EXPERIMENTS=1) ---------------------------------------------------------------------

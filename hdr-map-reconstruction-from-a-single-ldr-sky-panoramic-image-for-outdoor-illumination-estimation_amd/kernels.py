@@ -131,6 +131,14 @@ class PackedConv:
         L.check(lib.hdrsky_conv_pack_weights(_p(w), self.KH, self.KW, self.Cin, self.Cout, int(self.flip),
                                              _p(self.hi), _p(self.lo), _stream()), "conv_pack_weights")
 
+    def as_1x1(self):
+        """The same image read as the filter of a 1x1 convolution over KH*KW*Cin channels (its k-steps are in exactly that
+        order: tap-major, 32-channel blocks) - the matmul of a distortion-aware layer on its gathered operand."""
+        v = object.__new__(PackedConv)
+        v.KH = v.KW = 1
+        v.Cin, v.Cout, v.flip, v.hi, v.lo = self.KH * self.KW * self.Cin, self.Cout, self.flip, self.hi, self.lo
+        return v
+
 
 class MultiPacker:
     """One-launch re-pack of a list of (fp32 HWIO weight view, PackedConv) pairs (hdrsky_conv_pack_weights_multi)."""
@@ -284,12 +292,19 @@ def conv2d_wgrad(x, dy, KH, KW, stride=1, same=True, upsample=1, xf: Optional[In
 def da_wgrad_job(x, dy, ksize, offs, dw, db=None, compute=BF16):
     """conv2d_wgrad_multi entry for a distortion-aware layer (distortion_aware_ops.conv2d, kernel [k*k*C, F]): dw [k*k*C, F]
     += G^T dY with the gathered operand G recomputed inside the launch (never in memory).  x [B,H,W,C] fp32, C % 32 == 0."""
-    _f32(x); _f32(dy); _f32(offs)
     B, H, W, C = x.shape
     F = dy.shape[-1]
     k2 = ksize * ksize
     if tuple(dy.shape) != (B, H, W, F) or C % 32 or tuple(offs.shape) != (H, k2, 2):
         raise ValueError("da_wgrad_job: x %s, dy %s, offs %s" % (tuple(x.shape), tuple(dy.shape), tuple(offs.shape)))
+    if da_mat_ok(compute, ksize, C, H * W, "wgrad"):   # dW = G^T dY: a plain 1x1 weight gradient on the gathered operand (the forward's, or written here)
+        kept = getattr(x, "_da_G", None)
+        G = kept[2] if kept is not None and kept[:2] == (offs.data_ptr(), ksize) else da_gather_bf16(x, offs, ksize=ksize)
+        if dy.dtype != torch.bfloat16:      # (a gradient the fused data-gradient kernel reads as fp32: the LDS-DMA kernel wants bf16)
+            dy = to_bf16(_f32(dy))
+        _f32(dw, k2 * C, F)
+        return wgrad_job(G, dy, 1, 1, dw.view(1, 1, k2 * C, F), db, compute=compute)
+    _f32(x); _f32(dy); _f32(offs)
     d = conv_desc(B, H, W, k2 * C, F, 1, 1, 1, True, 1)
     d.compute = compute
     tabs = _xf_args(d, None, B, H, W, k2 * C)
@@ -1360,13 +1375,67 @@ def _da_rows(t):
     return (r[0].data_ptr(), r[1].ctypes.data) if r is not None else (None, None)
 
 
-def da_conv2d(x, pw: PackedConv, bias, offs, compute=BF16, want_stats=False):
+def da_materialised(compute):
+    """Single-product mode: a distortion-aware layer runs as the reference writes it (distortion_aware_ops.py:107-121) - the
+    gathered operand G [B,H,W,k*k*C] is written once as bf16 (hdrsky_da_gather_bf16) and the generic 1x1 conv / weight-gradient
+    kernels run on it - instead of the kernels that gather while staging (csrc/da_conv.hip), which stay for the split-product
+    mode.  The fused kernels re-gather per output-channel block and sit at 1-2 % of the matrix-core peak on the 128x512 maps
+    (profiles/r04_da_mat_ab.txt).  HDRSKY_DA_MAT=0: the fused kernels (switch)."""
+    return compute == BF16 and HOOKS.H.da_mat
+
+
+DA_MAT_MIN_PIXELS = {"fwd": 1024, "dgrad": 4096, "wgrad": 1024}
+
+
+def da_mat_ok(compute, ksize, C, pixels=None, what="wgrad"):
+    """... for one launch of a layer whose matmul runs over k*k*C channels on maps of `pixels` = H*W.  Channels: where the generic
+    conv can take them in a few groups (its groups are power-of-two divisors of the channel count: 9 x 32, 9 x 64, 9 x 128 - not
+    the 49 x 32 of a 7 x 7 layer).  Size, by launch (profiles/r04_da_mat_ab.txt, microbench_da_mat.py; us, written / fused):
+      kernel gradient: from 1024 pixels per sample (128x512 maps, batch 8: 230 against 1022; on 8x32 maps 39 + 17 for the gather
+        against 66 alone, but the twelve res-block layers of the 32x128 step share ONE fused launch: 3.41 against 3.47 ms);
+      data gradient: from 4096 pixels per sample (32x128 maps: 64 / 79; 8x32: 48 / 20 - the fused kernel's workgroup stages a
+        sample's few source rows once);
+      forward: from 1024 pixels and only where the kernel gradient will read the operand again (a training step: da_conv2d(...,
+        train=True)); alone the fused forward is ahead or level everywhere (8x32: 22 / 44, 32x128: 63 / 67, 64x256: 205 / 264)."""
+    kc = ksize * ksize * C
+    g = kc & -kc
+    return da_materialised(compute) and g >= 32 and kc // g <= 16 and (pixels is None or pixels >= DA_MAT_MIN_PIXELS[what])
+
+
+def da_gather_bf16(x, offs=None, table=None, ksize=3):
+    """G (bfloat16) [B,H,W,k*k*C]: the gathered operand from the forward's corners (offs) or from a sample table (gidx, gw)
+    [H*W, k*k, km] - da_transpose_table's makes G the operand of the data gradient (x = dY).  x: fp32 or bfloat16."""
+    B, H, W, C = x.shape
+    x16 = _raw(x)
+    k2 = ksize * ksize
+    G = torch.empty((B, H, W, k2 * C), dtype=torch.bfloat16, device=x.device)
+    if offs is not None:
+        _f32(offs, H, k2, 2)
+        gidx = gw = None; km = 0
+    else:
+        gidx, gw = table
+        km = gidx.shape[-1]
+        if tuple(gidx.shape) != (H * W, k2, km) or gidx.dtype != torch.int32 or tuple(gw.shape) != tuple(gidx.shape):
+            raise ValueError("da_gather_bf16: table does not match the map")
+        _f32(gw)
+    L.check(L.load().hdrsky_da_gather_bf16(_p(x), x16, _p(offs), _p(gidx), _p(gw), km, B, H, W, C, ksize, _p(G), _stream()),
+            "da_gather_bf16")
+    return G
+
+
+def da_conv2d(x, pw: PackedConv, bias, offs, compute=BF16, want_stats=False, train=False):
     """distortion_aware_ops.conv2d.call: offs = device tensor [H, k*k, 2] from da_offsets(H, W, k, ...).
-    want_stats: also return the InstanceNorm partials of y (Stats, as conv2d does) -> (y, Stats)."""
-    _f32(x)
+    want_stats: also return the InstanceNorm partials of y (Stats, as conv2d does) -> (y, Stats).
+    train: the layer's kernel gradient will follow (it reads the gathered operand again: da_mat_ok)."""
     B, H, W, C = x.shape
     if C != pw.Cin or pw.KH != pw.KW:
         raise ValueError("filter / input mismatch")
+    if train and da_mat_ok(compute, pw.KH, C, H * W, "fwd"):
+        G = da_gather_bf16(x, offs, ksize=pw.KH)
+        x._da_G = (offs.data_ptr(), pw.KH, G)      # the weight gradient of the layer reads it again (da_wgrad_job)
+        y, st = conv2d(G, pw.as_1x1(), bias, compute=compute, want_stats=want_stats)
+        return (y, st) if want_stats else y
+    _f32(x)
     _f32(offs, H, pw.KH * pw.KW, 2)
     if bias is not None:
         _f32(bias, pw.Cout)
@@ -1434,13 +1503,15 @@ def da_transpose_table(h, w, ksize=3, dilation_rate=1, skydome=True, device="cud
 def da_conv2d_dgrad(dy, pwT: PackedConv, table, ksize, compute=BF16):
     """dx of y = da_conv2d(x; kernel): deterministic, no k*k-fold tensor.  pwT = PackedConv(kernel.view(k,k,C,F),
     transpose_flip=True); table = da_transpose_table(H, W, k, ...)."""
-    _f32(dy)
     B, H, W, F = dy.shape
     gidx, gw = table
     if pwT.Cin != F or not pwT.flip or (pwT.KH, pwT.KW) != (ksize, ksize):
         raise ValueError("da_conv2d_dgrad: needs the transpose_flip image of the k x k filter")
     if tuple(gidx.shape) != (H * W, ksize * ksize, DA_KMAX) or gidx.dtype != torch.int32:
         raise ValueError("da_conv2d_dgrad: table does not match the map")
+    if da_mat_ok(compute, ksize, F, H * W, "dgrad"):      # the same sums as a gather of dY on the transposed table + the 1x1 conv on it
+        return conv2d(da_gather_bf16(dy, table=table, ksize=ksize), pwT.as_1x1(), None, compute=compute)[0]
+    _f32(dy)
     if compute == BF16X3 and pwT.lo is None:
         raise ValueError("BF16X3 needs the lo weight plane")
     dx = torch.empty((B, H, W, pwT.Cout), dtype=torch.float32, device=dy.device)

@@ -296,6 +296,12 @@ class Trainer:
         return K.norm_act_bwd(x, stats, w[name + ".gamma"], w[name + ".beta"], slope, dy, pooled,
                               sums=self._norm_state(x.shape[0])[0][name], out_bf16=self._act_bf16() and not f32)
 
+    def _da_f32(self, cv, raw):
+        """Whether the gradient wrt the raw output `raw` of the distortion-aware layer `cv` must stay fp32: the fused data-gradient
+        kernel takes fp32 sources; where the data gradient runs on a written gathered operand (kernels.da_mat_ok) it reads
+        bf16, like the kernel gradient."""
+        return not K.da_mat_ok(self.compute, cv.kh, cv.cout, raw.shape[1] * raw.shape[2], "dgrad")
+
     def _norm_grads(self, seg, B):
         """Adds the per-sample (d gamma, d beta) terms of segment `seg`'s norm layers to the gradient vectors."""
         self._norm_state(B)[1][seg].run()
@@ -372,9 +378,9 @@ class Trainer:
                 cv1, cv2 = c[n + ".conv1"], c[n + ".conv2"]
                 offs = self._da(x.shape[1], x.shape[2], cv1.kh)[0]
                 xin, pk1 = (K.pad_channels(x, 32), self._pk1pad) if l == 1 else (x, cv1.pk)
-                r1, st1 = K.da_conv2d(xin, pk1, cv1.b, offs, cp, want_stats=True)
+                r1, st1 = K.da_conv2d(xin, pk1, cv1.b, offs, cp, want_stats=True, train=True)
                 a1 = K.norm_apply(r1, st1, w[n + ".norm1.gamma"], w[n + ".norm1.beta"], slope=0.0)
-                r2, st2 = K.da_conv2d(a1, cv2.pk, cv2.b, offs, cp, want_stats=True)
+                r2, st2 = K.da_conv2d(a1, cv2.pk, cv2.b, offs, cp, want_stats=True, train=True)
                 a, pooled = K.norm_apply(r2, st2, w[n + ".norm2.gamma"], w[n + ".norm2.beta"], slope=0.0, pool=True)
                 t["in%d" % l], t["r%da" % l], t["st%da" % l], t["a%da" % l] = xin, r1, st1, a1
                 t["r%db" % l], t["st%db" % l], t["A%d" % l], t["P%d" % l] = r2, st2, a, pooled
@@ -423,10 +429,10 @@ class Trainer:
             n = "sun.sunlayer%d" % l
             k = c[n + ".conv1"].kh
             tab = self._da(self.h >> (l - 1), self.w >> (l - 1), k)[1]
-            dr2 = self._in_bwd(t["r%db" % l], t["st%db" % l], n + ".norm2", 0.0, dP, pooled=True, f32=True)
+            dr2 = self._in_bwd(t["r%db" % l], t["st%db" % l], n + ".norm2", 0.0, dP, pooled=True, f32=self._da_f32(c[n + ".conv2"], t["r%db" % l]))
             self._wg_da(n + ".conv2", t["a%da" % l], dr2)
             da = K.da_conv2d_dgrad(dr2, c[n + ".conv2"].pkT, tab, k, cp)
-            dr1 = self._in_bwd(t["r%da" % l], t["st%da" % l], n + ".norm1", 0.0, da, f32=True)
+            dr1 = self._in_bwd(t["r%da" % l], t["st%da" % l], n + ".norm1", 0.0, da, f32=self._da_f32(c[n + ".conv1"], t["r%da" % l]))
             if l > 1:
                 self._wg_da(n + ".conv1", t["in%d" % l], dr1)
                 dP = K.da_conv2d_dgrad(dr1, c[n + ".conv1"].pkT, tab, k, cp)
@@ -724,9 +730,9 @@ class Trainer:
             if self.da_dec:       # distortion_aware_ops.deconv2d (:272-542): bilinear 2x resize, then the distortion-aware 3x3
                 c3, c2 = c["gen.conv3_" + sfx], c["gen.conv2_" + sfx]
                 u3 = K.up2x(res_out)
-                d3, s3 = K.da_conv2d(u3, c3.pk, c3.b, self._da(u3.shape[1], u3.shape[2])[0], cp, want_stats=True)
+                d3, s3 = K.da_conv2d(u3, c3.pk, c3.b, self._da(u3.shape[1], u3.shape[2])[0], cp, want_stats=True, train=True)
                 u2 = K.up2x(K.norm_apply(d3, s3, w["gen.norm3_%s.gamma" % sfx], w["gen.norm3_%s.beta" % sfx], slope=0.1))
-                d2, s2 = K.da_conv2d(u2, c2.pk, c2.b, self._da(u2.shape[1], u2.shape[2])[0], cp, want_stats=True)
+                d2, s2 = K.da_conv2d(u2, c2.pk, c2.b, self._da(u2.shape[1], u2.shape[2])[0], cp, want_stats=True, train=True)
                 xf1 = self._inxf(s2, "gen.norm2_" + sfx, 0.1)
                 T["dech_" + sfx] = (d3, s3, u3, d2, s2, xf1, u2)
             elif self._deconv_mat():
@@ -826,9 +832,9 @@ class Trainer:
                 for i in range(6):
                     p = "gen.res.%d." % i
                     cv1, cv2 = c[p + "conv1"], c[p + "conv2"]
-                    c1, t1 = K.da_conv2d(x, cv1.pk, cv1.b, offs, cp, want_stats=True)
+                    c1, t1 = K.da_conv2d(x, cv1.pk, cv1.b, offs, cp, want_stats=True, train=True)
                     a1 = K.norm_apply(c1, t1, w[p + "norm1.gamma"], w[p + "norm1.beta"], slope=0.1)
-                    c2, t2 = K.da_conv2d(a1, cv2.pk, cv2.b, offs, cp, want_stats=True)
+                    c2, t2 = K.da_conv2d(a1, cv2.pk, cv2.b, offs, cp, want_stats=True, train=True)
                     xn = K.norm_apply(c2, t2, w[p + "norm2.gamma"], w[p + "norm2.beta"], slope=1.0, residual=x)
                     T["res%d" % i] = (c1, t1, a1, c2, t2)
                     x = xn
@@ -1005,10 +1011,10 @@ class Trainer:
                 dc = T["tails"][sfx][0]
                 self._wg("gen.conv1_" + sfx, d2, xf1, dc)
                 da2 = c["gen.conv1_" + sfx].dgrad(d2, dc, cp)
-                dd2 = self._in_bwd(d2, s2, "gen.norm2_" + sfx, 0.1, da2, f32=True)
+                dd2 = self._in_bwd(d2, s2, "gen.norm2_" + sfx, 0.1, da2, f32=self._da_f32(c["gen.conv2_" + sfx], d2))
                 self._wg_da("gen.conv2_" + sfx, u2, dd2)
                 du2 = K.da_conv2d_dgrad(dd2, c["gen.conv2_" + sfx].pkT, self._da(u2.shape[1], u2.shape[2])[1], 3, cp)
-                dd3 = self._in_bwd(d3, s3, "gen.norm3_" + sfx, 0.1, K.up2x_bwd(du2), f32=True)
+                dd3 = self._in_bwd(d3, s3, "gen.norm3_" + sfx, 0.1, K.up2x_bwd(du2), f32=self._da_f32(c["gen.conv3_" + sfx], d3))
                 self._wg_da("gen.conv3_" + sfx, u3, dd3)
                 du3 = K.da_conv2d_dgrad(dd3, c["gen.conv3_" + sfx].pkT, self._da(u3.shape[1], u3.shape[2])[1], 3, cp)
                 K.up2x_bwd(du3, 1.0, out=dres)
@@ -1083,10 +1089,10 @@ class Trainer:
                 for i in range(5, -1, -1):
                     p = "gen.res.%d." % i
                     c1, t1, a1, c2, t2 = T["res%d" % i]
-                    dr2 = self._in_bwd(c2, t2, p + "norm2", 1.0, dx, f32=True)
+                    dr2 = self._in_bwd(c2, t2, p + "norm2", 1.0, dx, f32=self._da_f32(c[p + "conv2"], c2))
                     self._wg_da(p + "conv2", a1, dr2)
                     da1 = K.da_conv2d_dgrad(dr2, c[p + "conv2"].pkT, self._da_table, 3, cp)
-                    dr1 = self._in_bwd(c1, t1, p + "norm1", 0.1, da1, f32=True)
+                    dr1 = self._in_bwd(c1, t1, p + "norm1", 0.1, da1, f32=self._da_f32(c[p + "conv1"], c1))
                     self._wg_da(p + "conv1", T["x"][i], dr1)
                     dxx = K.da_conv2d_dgrad(dr1, c[p + "conv1"].pkT, self._da_table, 3, cp)
                     dx = K.axpby(dx, 1.0, dxx, 1.0)                                     # + identity branch

@@ -503,6 +503,13 @@ int hdrsky_da_conv2d_fwd(const float* x, const void* w_hi, const void* w_lo, con
  * dG = hdrsky_conv2d_fwd(1x1 with the transposed kernel; dY) and dx = hdrsky_da_scatter(dG) (dx zeroed; fp32 atomics). */
 int hdrsky_da_gather(const float* x, const float* offs, int B, int H, int W, int C, int ksize, float* G, void* stream);
 int hdrsky_da_scatter(const float* dG, const float* offs, int B, int H, int W, int C, int ksize, float* dx, void* stream);
+/* The gathered operand as a bf16 tensor G [B,H,W,k*k*C] - what the fused kernels feed the matrix cores, written once
+ * (single-product mode).  With it the layer is distortion_aware_ops.py:107-121 literally: y = hdrsky_conv2d_fwd(1x1 over
+ * k*k*C channels; G) with the k x k filter's own packed image (same k-step order), dW = hdrsky_conv2d_wgrad(1x1; G, dY), and
+ * the data gradient is the same pair on the transposed table.  Positions: offs (device, hdrsky_da_offsets) = the forward's
+ * four corners; or offs = NULL and gidx / gw [H*W][k*k][km] = a sample table (hdrsky_da_conv2d_dgrad's, km = 8: then x is dY
+ * and G the operand of the 1x1 conv with the transpose_flip image).  x: fp32, or bf16 with x_bf16 != 0.  C % 8 == 0. */
+int hdrsky_da_gather_bf16(const void* x, int x_bf16, const float* offs, const int* gidx, const float* gw, int km, int B, int H, int W, int C, int ksize, void* G, void* stream);
 /* [host] The forward's sample table of an H x W map: per (pixel oy*W+ox, tap) the four bilinear corners as source pixel
  * indices (row-major, -1 = zero padding) and weights, [H*W][k*k][4] each - exactly what hdrsky_da_conv2d_fwd gathers
  * (distortion_aware_ops.py:62-106 in float32).  offs: HOST copy of hdrsky_da_offsets. */

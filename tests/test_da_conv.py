@@ -255,6 +255,7 @@ def test_da_region_kernel_gradient(dev, k, shape, monkeypatch):
     xd, dyd = d(x), d(dy)
     monkeypatch.setenv("HDRSKY_EXPERIMENTS", "1")                 # the two variables below are tuning hooks: behind the gate
     monkeypatch.setenv("HDRSKY_DA_WGRAD_REGION_MAXC", "256")      # (by default only layers of <= 64 channels take this path)
+    monkeypatch.setenv("HDRSKY_DA_MAT", "0")                      # the fused kernels are the subject (not the written operand)
 
     def run(**env):
         for kk, v in env.items():
@@ -369,14 +370,21 @@ def test_da_launches_are_reproducible_beside_their_neighbours(dev, shape, monkey
     name, neighbours = _neighbour_launchers(dev)
     assert "2, 4, 4, 2, 32" in name or name == "", name          # the neighbour of (a) really is the wide tile
     side = torch.cuda.Stream()
-    def launches(region):
-        monkeypatch.setenv("HDRSKY_DA_REGION", "1" if region else "0")
-        fwd = K.da_conv2d(x, pw, bias, offs, K.BF16)
+    # variants: the fused kernels with the LDS-region gather, with the global-memory gather, and (round 4) the layer on its
+    # written gathered operand (hdrsky_da_gather_bf16 + generic 1x1 conv / weight gradient) - whatever kernels.da_mat_ok
+    # would pick for the shape, all three are launched here
+    def launches(variant):
+        monkeypatch.setenv("HDRSKY_DA_MAT", "1" if variant == "written" else "0")
+        monkeypatch.setenv("HDRSKY_DA_REGION", "0" if variant == "global" else "1")
+        if hasattr(x, "_da_G"):
+            del x._da_G
+        fwd = K.da_conv2d(x, pw, bias, offs, K.BF16, train=True)
         dx = K.da_conv2d_dgrad(dy, pwT, table, 3, K.BF16)
         dw = torch.zeros(9 * C, F, device=dev); dbg = torch.zeros(F, device=dev)
         K.da_conv2d_bwd(x, dy, kern.reshape(9 * C, F), offs, 3, K.BF16, want_dx=False, dw=dw, db=dbg)
         return fwd, dx, dw, dbg
-    for region in (True, False):
+    monkeypatch.setattr(K, "DA_MAT_MIN_PIXELS", {"fwd": 0, "dgrad": 0, "wgrad": 0})
+    for region in ("region", "global", "written"):
         torch.cuda.synchronize()
         ref = [t.clone() for t in launches(region)]
         torch.cuda.synchronize()
@@ -388,4 +396,73 @@ def test_da_launches_are_reproducible_beside_their_neighbours(dev, shape, monkey
                 torch.cuda.synchronize()
                 for what, a, b in zip(("forward", "data gradient", "kernel gradient", "bias gradient"), got, ref):
                     assert torch.equal(a, b), "%s (%s kernel) changed beside the %s, launch %d: %d elements, max |diff| %.3e" % (
-                        what, "region" if region else "global-memory", label, it, int((a != b).sum()), float((a - b).abs().max()))
+                        what, region, label, it, int((a != b).sum()), float((a - b).abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 32, 128, 128, 128), (3, 16, 64, 64, 32), (2, 32, 128, 32, 64), (1, 64, 256, 64, 32)])
+def test_da_layer_on_the_written_gathered_operand(dev, shape, monkeypatch):
+    """Single-product mode from 1024 pixels per sample on (kernels.da_mat_ok): the layer as distortion_aware_ops.py:107-121 writes
+    it - hdrsky_da_gather_bf16 + the generic 1x1 conv / weight gradient on k*k*C channels, the data gradient the same pair on the
+    transposed table.  (a) the bf16 operand is the fp32 gather (hdrsky_da_gather, da_tap arithmetic) rounded once, bit for bit,
+    from fp32 and - for a bf16 source - from the widened values; a sample table with the forward's corners gives the same bits;
+    (b) forward, data gradient and kernel gradient agree with the fused kernels (HDRSKY_DA_MAT=0) to 5e-3 of the tensor's scale
+    - those blend corners that were rounded to bf16 when their rows were staged in LDS and round the blend again, the written
+    operand is rounded once - and with the numpy oracle to the bf16 tolerance; the forward written only for a training step
+    (train=True), the data gradient from 4096 pixels per sample, the kernel gradient always (kernels.da_mat_ok)."""
+    K = pkg("kernels")
+    B, H, W, C, F = shape
+    assert K.da_mat_ok(K.BF16, 3, C, H * W, "fwd") and K.da_mat_ok(K.BF16, 3, C, 1024, "wgrad") and not K.da_mat_ok(K.BF16, 3, C, 256, "wgrad") and not K.da_mat_ok(K.BF16X3, 3, C, H * W)
+    assert K.da_mat_ok(K.BF16, 3, F, H * W, "dgrad") == (H * W >= 4096) and not K.da_mat_ok(K.BF16, 7, 32, H * W)
+    rng = np.random.default_rng(B + H + C + F)
+    x = rng.standard_normal((B, H, W, C)).astype(np.float32)
+    kern = (rng.standard_normal((9 * C, F)) / np.sqrt(9 * C)).astype(np.float32)
+    bias = rng.standard_normal(F).astype(np.float32)
+    dy = rng.standard_normal((B, H, W, F)).astype(np.float32)
+    d = lambda a: torch.from_numpy(a).to(dev)
+    xd, kd, bd, dyd = d(x), d(kern), d(bias), d(dy)
+    offs = K.da_offsets_device(H, W, 3, device=dev)
+    # (a)
+    G32 = K.da_gather(xd, offs, 3)
+    G16 = K.da_gather_bf16(xd, offs, ksize=3)
+    assert G16.dtype == torch.bfloat16 and torch.equal(G16, G32.to(torch.bfloat16))
+    xb = xd.to(torch.bfloat16)
+    assert torch.equal(K.da_gather_bf16(xb, offs, ksize=3), K.da_gather(xb.float(), offs, 3).to(torch.bfloat16))
+    _, idx, wt = K._da_host_table(H, W, 3, 1, True)
+    tab4 = (torch.from_numpy(idx).to(dev), torch.from_numpy(wt).to(dev))
+    assert torch.equal(K.da_gather_bf16(xd, table=tab4, ksize=3), G16)
+    # (b)
+    pw = K.PackedConv(kd.view(3, 3, C, F), precise=False)
+    pwT = K.PackedConv(kd.view(3, 3, C, F), precise=False, transpose_flip=True)
+    table = K.da_transpose_table(H, W, 3, device=dev)
+
+    def run():
+        y, st = K.da_conv2d(xd, pw, bd, offs, K.BF16, want_stats=True, train=True)
+        dx = K.da_conv2d_dgrad(dyd, pwT, table, 3, K.BF16)
+        dw, db = torch.zeros(9 * C, F, device=dev), torch.zeros(F, device=dev)
+        K.conv2d_wgrad_multi([K.da_wgrad_job(xd, dyd, 3, offs, dw, db, K.BF16)])
+        return y, st.part.sum(1), dx, dw, db
+    got = run()
+    assert getattr(xd, "_da_G", None) is not None
+    monkeypatch.setenv("HDRSKY_DA_MAT", "0")
+    del xd._da_G
+    fused = run()
+    assert getattr(xd, "_da_G", None) is None
+    for name, a, b_ in zip(("y", "statistics", "dx", "dkernel", "dbias"), got, fused):
+        err = float((a.double() - b_.double()).abs().max() / b_.double().abs().max())
+        assert err < 5e-3, (name, err)
+    ref = da_ops.da_conv2d(x, kern, bias, da_ops.distortion(H, W))
+    rdx, rdk, rdb = da_ops.da_conv2d_grads(x, kern, da_ops.distortion(H, W), dy)
+    assert_close_bf16(got[0], ref, "written-operand forward"); assert_close_bf16(got[2], rdx, "written-operand dx")
+    assert_close_bf16(got[3], rdk, "written-operand dkernel"); assert_close(got[4], rdb, 5e-3, "written-operand dbias")      # (column sums of the bf16-rounded gradient, as for every plain layer of this mode)
+    # bf16 gradients in (what the training step hands over when both readers run on written operands): same results as from
+    # the widened values
+    dyb = dyd.to(torch.bfloat16)
+    monkeypatch.setenv("HDRSKY_DA_MAT", "1")
+    if H * W >= 4096:
+        dxb = K.da_conv2d_dgrad(dyb, pwT, table, 3, K.BF16)
+        assert torch.equal(dxb, K.da_conv2d_dgrad(dyb.float(), pwT, table, 3, K.BF16))
+    # inference (no train flag): the fused forward
+    assert not hasattr(xd, "_da_G")
+    K.da_conv2d(xd, pw, bd, offs, K.BF16)
+    assert getattr(xd, "_da_G", None) is None
