@@ -1431,7 +1431,8 @@ def da_conv2d(x, pw: PackedConv, bias, offs, compute=BF16, want_stats=False, tra
     if C != pw.Cin or pw.KH != pw.KW:
         raise ValueError("filter / input mismatch")
     if train and da_mat_ok(compute, pw.KH, C, H * W, "fwd"):
-        G = da_gather_bf16(x, offs, ksize=pw.KH)
+        kept = getattr(x, "_da_G", None)            # (two layers on one input - the decoders' first deconvolutions - share it)
+        G = kept[2] if kept is not None and kept[:2] == (offs.data_ptr(), pw.KH) else da_gather_bf16(x, offs, ksize=pw.KH)
         x._da_G = (offs.data_ptr(), pw.KH, G)      # the weight gradient of the layer reads it again (da_wgrad_job)
         y, st = conv2d(G, pw.as_1x1(), bias, compute=compute, want_stats=want_stats)
         return (y, st) if want_stats else y

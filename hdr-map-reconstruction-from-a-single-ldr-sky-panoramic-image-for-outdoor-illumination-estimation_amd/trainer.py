@@ -729,9 +729,21 @@ class Trainer:
             res_out = T["x"][-1]
             if self.da_dec:       # distortion_aware_ops.deconv2d (:272-542): bilinear 2x resize, then the distortion-aware 3x3
                 c3, c2 = c["gen.conv3_" + sfx], c["gen.conv2_" + sfx]
-                u3 = K.up2x(res_out)
+                # where a layer runs on its written gathered operand (kernels.da_mat_ok) the resized map feeds nothing but that
+                # gather: written as bf16 by the resize launch (with the InstanceNorm + LeakyReLU in front of it folded in),
+                # and the two decoders share the resized encoder output and its gathered operand
+                px3 = 4 * res_out.shape[1] * res_out.shape[2]
+                if K.da_mat_ok(cp, 3, c3.cin, px3, "fwd"):
+                    if sfx == "f":      # (the first decoder of every pass writes it: T outlives a pass)
+                        T["u3_da"] = K.up2x_act_bf16(res_out)
+                    u3 = T["u3_da"]
+                else:
+                    u3 = K.up2x(res_out)
                 d3, s3 = K.da_conv2d(u3, c3.pk, c3.b, self._da(u3.shape[1], u3.shape[2])[0], cp, want_stats=True, train=True)
-                u2 = K.up2x(K.norm_apply(d3, s3, w["gen.norm3_%s.gamma" % sfx], w["gen.norm3_%s.beta" % sfx], slope=0.1))
+                if K.da_mat_ok(cp, 3, c2.cin, 4 * px3, "fwd"):
+                    u2 = K.up2x_act_bf16(d3, self._inxf(s3, "gen.norm3_" + sfx, 0.1, partials=True))
+                else:
+                    u2 = K.up2x(K.norm_apply(d3, s3, w["gen.norm3_%s.gamma" % sfx], w["gen.norm3_%s.beta" % sfx], slope=0.1))
                 d2, s2 = K.da_conv2d(u2, c2.pk, c2.b, self._da(u2.shape[1], u2.shape[2])[0], cp, want_stats=True, train=True)
                 xf1 = self._inxf(s2, "gen.norm2_" + sfx, 0.1)
                 T["dech_" + sfx] = (d3, s3, u3, d2, s2, xf1, u2)
