@@ -244,7 +244,7 @@ def parity_object(torch, mods, dev, nets_np, batch, oracle_outputs=None):
     captured training step on seeded synthetic batches (<pkg>/train.py::fit_synthetic, what `python -m <pkg>.train` runs) in the
     fp32-class BF16X3 mode - the stand-in for a model the REFERENCE trained: weights fitted by the bf16 step are adapted to
     bf16 arithmetic and score 0.03-0.06 dB better in the mode that trained them (HDRSKY_PARITY_FIT=bf16 reproduces that:
-    profiles/parity_fit_mode.py) - then the inference graph on a held-out seeded batch in the bench mode (HDRSKY_BF16)
+    profiles/parity_fit_mode.py, profiles/LABNOTES.md r3 section 0) - then the inference graph on a held-out seeded batch in the bench mode (HDRSKY_BF16)
     and in BF16X3:
       psnr_*_vs_target_db          PSNR of y_final_gamma against hdr_logCompression(hdr_t), whole batch
       psnr_bf16_vs_x3_db, q_max_db the two modes against each other; q_max = that - 19.4 dB is the output quality up to

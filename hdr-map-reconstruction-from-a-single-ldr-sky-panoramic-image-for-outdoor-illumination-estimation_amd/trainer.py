@@ -799,7 +799,7 @@ class Trainer:
         # instead of inside the backward pass where all three streams are busy.  Its BatchNorm moving-statistics update waits
         # for its place in the reference's program order (after the adversarial term's inference-mode call, in front of the
         # generated pairs: train.py:302,360-361).  Measured: no gain - the forward pass it runs beside slows down by what the
-        # backward pass wins (2.77 ms either way) - so the default stays ONE batch of 2B in disc_step; HDRSKY_DISC_SPLIT=1
+        # backward pass wins (2.77 ms either way, profiles/LABNOTES.md r3 5.0) - so the default stays ONE batch of 2B in disc_step; HDRSKY_DISC_SPLIT=1
         # selects the split (A/B hook, covered by tests/test_train_gpu.py)
         split_disc = HOOKS.H.disc_split
 
@@ -1269,7 +1269,7 @@ class Trainer:
             for d_ in deps:
                 # (a dependency on the same stream is its order: no event.  Found while capturing the whole step as ONE
                 # hipGraph: there a wait for an event recorded on the waiting stream itself crashes hipStreamEndCapture on
-                # ROCm 7.2; that experiment - DESIGN 5, third part - replayed at the SUM of the kernel times and was dropped)
+                # ROCm 7.2; that experiment - profiles/LABNOTES.md r3 section 5, third part - replayed at the SUM of the kernel times and was dropped)
                 if d_ in self._events and on_stream.get(d_) != si:
                     s.wait_event(self._events[d_])
             with torch.cuda.stream(s):
