@@ -107,6 +107,9 @@ SIGNATURES = {
     "hdrsky_da_gather": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
     "hdrsky_da_scatter": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
     "hdrsky_da_gather_bf16": (c_int, [P, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "hdrsky_gemm1x1_supported": (c_int, [c_int, c_int, c_int]),
+    "hdrsky_gemm1x1_stats_nparts": (c_int, [c_int]),
+    "hdrsky_gemm1x1_bf16": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, c_int, P, P]),
     "hdrsky_da_sample_table": (c_int, [P, c_int, c_int, c_int, P, P]),
     "hdrsky_da_conv2d_wgrad_ws_bytes": (c_size_t, [P, P, c_int, c_int, c_int, c_int, c_int, c_int]),
     "hdrsky_da_conv2d_wgrad": (c_int, [P, P, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, c_size_t, P]),

@@ -1384,19 +1384,18 @@ def da_materialised(compute):
     return compute == BF16 and HOOKS.H.da_mat
 
 
-DA_MAT_MIN_PIXELS = {"fwd": 1024, "dgrad": 4096, "wgrad": 1024}
+DA_MAT_MIN_PIXELS = {"fwd": 1024, "dgrad": 1024, "wgrad": 1024}
 
 
 def da_mat_ok(compute, ksize, C, pixels=None, what="wgrad"):
     """... for one launch of a layer whose matmul runs over k*k*C channels on maps of `pixels` = H*W.  Channels: where the generic
-    conv can take them in a few groups (its groups are power-of-two divisors of the channel count: 9 x 32, 9 x 64, 9 x 128 - not
-    the 49 x 32 of a 7 x 7 layer).  Size, by launch (profiles/r04_da_mat_ab.txt, microbench_da_mat.py; us, written / fused):
-      kernel gradient: from 1024 pixels per sample (128x512 maps, batch 8: 230 against 1022; on 8x32 maps 39 + 17 for the gather
-        against 66 alone, but the twelve res-block layers of the 32x128 step share ONE fused launch: 3.41 against 3.47 ms);
-      data gradient: from 4096 pixels per sample (32x128 maps: 64 / 79; 8x32: 48 / 20 - the fused kernel's workgroup stages a
-        sample's few source rows once);
-      forward: from 1024 pixels and only where the kernel gradient will read the operand again (a training step: da_conv2d(...,
-        train=True)); alone the fused forward is ahead or level everywhere (8x32: 22 / 44, 32x128: 63 / 67, 64x256: 205 / 264)."""
+    conv could take them in a few groups (power-of-two divisors of the channel count: 9 x 32, 9 x 64, 9 x 128 - not the 49 x 32 of
+    a 7 x 7 layer; hdrsky_gemm1x1_bf16 takes every multiple of 64).  Size: from 1024 pixels per sample, for all three launches
+    (profiles/r04_da_mat_ab.txt, microbench_da_mat.py; us alone, written incl. its gather / fused): 128->128 on 32x128 maps at batch 8:
+    forward 44 / 63, data gradient 56 / 79, kernel gradient 89 / 212; 64->32 on 128x512: 300 / 499, 402 / 432, 230 / 1024;
+    64->64 on 16x64 at batch 32: 27 / 32, 31 / 40, 37 / 58.  On the 8x32 maps of the 32x128 network the fused kernels - a workgroup
+    stages a sample's few source rows once - are level or ahead (25 / 22, 30 / 20; the kernel gradients of its twelve res-block layers
+    share ONE fused launch), so they stay there."""
     kc = ksize * ksize * C
     g = kc & -kc
     return da_materialised(compute) and g >= 32 and kc // g <= 16 and (pixels is None or pixels >= DA_MAT_MIN_PIXELS[what])
@@ -1423,18 +1422,46 @@ def da_gather_bf16(x, offs=None, table=None, ksize=3):
     return G
 
 
+def gemm1x1(G, pw1: PackedConv, bias=None, want_stats=False, out_bf16=False):
+    """y [B,H,W,N] = G [B,H,W,K] (bfloat16, final) x the 1x1 view of a packed filter (PackedConv.as_1x1()) + bias, single-product
+    mode: hdrsky_gemm1x1_bf16 where it takes the shape (whole 128-pixel tiles per sample, K % 64 == 0, N % 32 == 0), the generic
+    conv as a 1x1 layer otherwise.  Returns (y, Stats | None)."""
+    _bf16(G)
+    B, H, W, Kc = G.shape
+    N = pw1.Cout
+    lib = L.load()
+    if (pw1.KH, pw1.KW, pw1.Cin) != (1, 1, Kc):
+        raise ValueError("gemm1x1: filter view does not match the operand")
+    if not lib.hdrsky_gemm1x1_supported(H * W, Kc, N):
+        return conv2d(G, pw1, bias, compute=BF16, want_stats=want_stats, out_bf16=out_bf16)
+    if bias is not None:
+        _f32(bias, N)
+    y = torch.empty((B, H, W, N), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=G.device)
+    st = None
+    if want_stats:
+        nparts = lib.hdrsky_gemm1x1_stats_nparts(H * W)
+        st = Stats(torch.empty((B, nparts, 2, N), dtype=torch.float32, device=G.device), nparts, H * W)
+    L.check(lib.hdrsky_gemm1x1_bf16(_p(G), _p(pw1.hi), _p(bias), B, H * W, Kc, N, _p(y), int(out_bf16), _p(st.part) if st else None,
+                                    _stream()), "gemm1x1_bf16")
+    if TRACE is not None:
+        _trace("conv", "gemm1x1_kernel", "1x1 %d->%d @%dx%d B=%d (written gathered operand)" % (Kc, N, H, W, B), 2.0 * B * H * W * Kc * N,
+               lambda: lib.hdrsky_gemm1x1_bf16(_p(G), _p(pw1.hi), _p(bias), B, H * W, Kc, N, _p(y), int(out_bf16), _p(st.part) if st else None, _stream()))
+    return y, st
+
+
 def da_conv2d(x, pw: PackedConv, bias, offs, compute=BF16, want_stats=False, train=False):
     """distortion_aware_ops.conv2d.call: offs = device tensor [H, k*k, 2] from da_offsets(H, W, k, ...).
     want_stats: also return the InstanceNorm partials of y (Stats, as conv2d does) -> (y, Stats).
-    train: the layer's kernel gradient will follow (it reads the gathered operand again: da_mat_ok)."""
+    train: the layer's kernel gradient will follow (it reads the gathered operand again; kept for callers - the written
+    operand is the faster forward from 1024 pixels per sample with or without it: da_mat_ok)."""
     B, H, W, C = x.shape
     if C != pw.Cin or pw.KH != pw.KW:
         raise ValueError("filter / input mismatch")
-    if train and da_mat_ok(compute, pw.KH, C, H * W, "fwd"):
+    if da_mat_ok(compute, pw.KH, C, H * W, "fwd"):
         kept = getattr(x, "_da_G", None)            # (two layers on one input - the decoders' first deconvolutions - share it)
         G = kept[2] if kept is not None and kept[:2] == (offs.data_ptr(), pw.KH) else da_gather_bf16(x, offs, ksize=pw.KH)
         x._da_G = (offs.data_ptr(), pw.KH, G)      # the weight gradient of the layer reads it again (da_wgrad_job)
-        y, st = conv2d(G, pw.as_1x1(), bias, compute=compute, want_stats=want_stats)
+        y, st = gemm1x1(G, pw.as_1x1(), bias, want_stats=want_stats)
         return (y, st) if want_stats else y
     _f32(x)
     _f32(offs, H, pw.KH * pw.KW, 2)
@@ -1511,7 +1538,7 @@ def da_conv2d_dgrad(dy, pwT: PackedConv, table, ksize, compute=BF16):
     if tuple(gidx.shape) != (H * W, ksize * ksize, DA_KMAX) or gidx.dtype != torch.int32:
         raise ValueError("da_conv2d_dgrad: table does not match the map")
     if da_mat_ok(compute, ksize, F, H * W, "dgrad"):      # the same sums as a gather of dY on the transposed table + the 1x1 conv on it
-        return conv2d(da_gather_bf16(dy, table=table, ksize=ksize), pwT.as_1x1(), None, compute=compute)[0]
+        return gemm1x1(da_gather_bf16(dy, table=table, ksize=ksize), pwT.as_1x1())[0]
     _f32(dy)
     if compute == BF16X3 and pwT.lo is None:
         raise ValueError("BF16X3 needs the lo weight plane")

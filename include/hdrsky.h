@@ -510,6 +510,16 @@ int hdrsky_da_scatter(const float* dG, const float* offs, int B, int H, int W, i
  * four corners; or offs = NULL and gidx / gw [H*W][k*k][km] = a sample table (hdrsky_da_conv2d_dgrad's, km = 8: then x is dY
  * and G the operand of the 1x1 conv with the transpose_flip image).  x: fp32, or bf16 with x_bf16 != 0.  C % 8 == 0. */
 int hdrsky_da_gather_bf16(const void* x, int x_bf16, const float* offs, const int* gidx, const float* gw, int km, int B, int H, int W, int C, int ksize, void* G, void* stream);
+/* The matmul on that operand (distortion_aware_ops.py:117-121: tf.matmul(gathered, kernel) + bias), a 1x1 convolution over
+ * K = k*k*C channels of a FINAL bf16 NHWC tensor: y [B*HW][N] = A [B*HW][K] (bf16) x W + bias, W = the hi plane of the
+ * hdrsky_conv_pack_weights image of the k x k filter (or of its transpose_flip image: data gradient on the transposed table).
+ * Both operands travel global -> LDS by LDS-DMA through a four-stage ring (csrc/gemm_1x1.hip); hdrsky_conv2d_fwd takes the
+ * same call as a 1x1 conv, in power-of-two channel groups, 2-3x slower.  stats_part (optional): InstanceNorm partials
+ * [B][hdrsky_gemm1x1_stats_nparts(HW)][2][N] of the fp32 results, for hdrsky_norm_apply / hdrsky_in_affine.
+ * hdrsky_gemm1x1_supported: HW % 128 == 0 (whole 128-pixel tiles per sample), K % 64 == 0, N % 32 == 0. */
+int hdrsky_gemm1x1_supported(int HW, int K, int N); /* [host] */
+int hdrsky_gemm1x1_stats_nparts(int HW); /* [host] */
+int hdrsky_gemm1x1_bf16(const void* A, const void* w_hi, const float* bias, int B, int HW, int K, int N, void* y, int y_bf16, float* stats_part, void* stream);
 /* [host] The forward's sample table of an H x W map: per (pixel oy*W+ox, tap) the four bilinear corners as source pixel
  * indices (row-major, -1 = zero padding) and weights, [H*W][k*k][4] each - exactly what hdrsky_da_conv2d_fwd gathers
  * (distortion_aware_ops.py:62-106 in float32).  offs: HOST copy of hdrsky_da_offsets. */

@@ -11,7 +11,7 @@ PKG = "hdr-map-reconstruction-from-a-single-ldr-sky-panoramic-image-for-outdoor-
 K = importlib.import_module(PKG + ".kernels")
 HK = importlib.import_module(PKG + ".hooks")
 dev = torch.device("cuda:0")
-K.DA_MAT_MIN_PIXELS = 0          # the table decides: both paths everywhere
+K.DA_MAT_MIN_PIXELS = {"fwd": 0, "dgrad": 0, "wgrad": 0}          # the table decides: both paths everywhere
 
 SHAPES = [  # name, B, H, W, C, F
     ("res 32x128 net", 32, 8, 32, 128, 128),
@@ -54,7 +54,10 @@ for name, B, H, W, C, F in SHAPES:
         dy = torch.randn(B, H, W, F, device=dev)
         if mat == "1":
             dy = dy.to(torch.bfloat16)
-        t_f = gtime(lambda: K.da_conv2d(x, pw, bias, offs, K.BF16, want_stats=True))
+        def fwd():      # (a fresh input every pass: the operand kept on the tensor object would otherwise be re-used)
+            x.__dict__.pop("_da_G", None)
+            return K.da_conv2d(x, pw, bias, offs, K.BF16, want_stats=True, train=True)
+        t_f = gtime(fwd)
         t_d = gtime(lambda: K.da_conv2d_dgrad(dy, pwT, table, 3, K.BF16))
         t_w = gtime(lambda: K.conv2d_wgrad_multi([K.da_wgrad_job(x, dy, 3, offs, dw, db, K.BF16)]))       # (operand kept by the forward when written)
         t_g = gtime(lambda: K.da_gather_bf16(x, offs, ksize=3)) if mat == "1" else 0.0

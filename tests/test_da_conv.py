@@ -408,12 +408,12 @@ def test_da_layer_on_the_written_gathered_operand(dev, shape, monkeypatch):
     from fp32 and - for a bf16 source - from the widened values; a sample table with the forward's corners gives the same bits;
     (b) forward, data gradient and kernel gradient agree with the fused kernels (HDRSKY_DA_MAT=0) to 5e-3 of the tensor's scale
     - those blend corners that were rounded to bf16 when their rows were staged in LDS and round the blend again, the written
-    operand is rounded once - and with the numpy oracle to the bf16 tolerance; the forward written only for a training step
-    (train=True), the data gradient from 4096 pixels per sample, the kernel gradient always (kernels.da_mat_ok)."""
+    operand is rounded once - and with the numpy oracle to the bf16 tolerance; all three launches from 1024 pixels per sample
+    (kernels.da_mat_ok); the matmul on hdrsky_gemm1x1_bf16 where it takes the shape."""
     K = pkg("kernels")
     B, H, W, C, F = shape
     assert K.da_mat_ok(K.BF16, 3, C, H * W, "fwd") and K.da_mat_ok(K.BF16, 3, C, 1024, "wgrad") and not K.da_mat_ok(K.BF16, 3, C, 256, "wgrad") and not K.da_mat_ok(K.BF16X3, 3, C, H * W)
-    assert K.da_mat_ok(K.BF16, 3, F, H * W, "dgrad") == (H * W >= 4096) and not K.da_mat_ok(K.BF16, 7, 32, H * W)
+    assert K.da_mat_ok(K.BF16, 3, F, H * W, "dgrad") and not K.da_mat_ok(K.BF16, 3, F, 256, "dgrad") and not K.da_mat_ok(K.BF16, 7, 32, H * W)
     rng = np.random.default_rng(B + H + C + F)
     x = rng.standard_normal((B, H, W, C)).astype(np.float32)
     kern = (rng.standard_normal((9 * C, F)) / np.sqrt(9 * C)).astype(np.float32)
@@ -459,10 +459,42 @@ def test_da_layer_on_the_written_gathered_operand(dev, shape, monkeypatch):
     # the widened values
     dyb = dyd.to(torch.bfloat16)
     monkeypatch.setenv("HDRSKY_DA_MAT", "1")
-    if H * W >= 4096:
-        dxb = K.da_conv2d_dgrad(dyb, pwT, table, 3, K.BF16)
-        assert torch.equal(dxb, K.da_conv2d_dgrad(dyb.float(), pwT, table, 3, K.BF16))
-    # inference (no train flag): the fused forward
-    assert not hasattr(xd, "_da_G")
-    K.da_conv2d(xd, pw, bd, offs, K.BF16)
-    assert getattr(xd, "_da_G", None) is None
+    dxb = K.da_conv2d_dgrad(dyb, pwT, table, 3, K.BF16)
+    assert torch.equal(dxb, K.da_conv2d_dgrad(dyb.float(), pwT, table, 3, K.BF16))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,K,N", [(2, 32, 128, 1152, 128), (3, 16, 64, 576, 64), (1, 32, 128, 576, 32), (2, 8, 16, 64, 32),
+                                       (1, 64, 256, 1152, 64), (2, 16, 64, 1152, 256), (5, 8, 16, 192, 96)])
+def test_gemm1x1_on_a_bf16_operand(dev, B, H, W, K, N):
+    """hdrsky_gemm1x1_bf16 (LDS-DMA ring; the matmul of a distortion-aware layer on its written operand) against the fp64 product
+    of the same bf16-rounded operands (fp32 accumulation: 2e-6 of the scale), its InstanceNorm partials against the sums of its own
+    fp32 output, the bf16 output = the fp32 one rounded, bit-identical repeats - and against the generic conv run as a 1x1 layer."""
+    K_, L = pkg("kernels"), pkg("_lib")
+    g = torch.Generator(device=dev); g.manual_seed(B * 7 + K + N)
+    G = torch.randn(B, H, W, K, device=dev, generator=g).to(torch.bfloat16)
+    w = torch.randn(1, 1, K, N, device=dev, generator=g) / K ** 0.5
+    bias = torch.randn(N, device=dev, generator=g)
+    pw = K_.PackedConv(w, precise=False)
+    assert L.load().hdrsky_gemm1x1_supported(H * W, K, N)
+    y, st = K_.gemm1x1(G, pw, bias, want_stats=True)
+    ref = G.double().reshape(-1, K) @ w.to(torch.bfloat16).double().reshape(K, N) + bias.double()
+    err = float((y.double().reshape(-1, N) - ref).abs().max() / ref.abs().max())
+    assert err < 2e-6, err
+    part = st.part.sum(1).double()                                       # [B, 2, N]
+    yy = y.double().reshape(B, H * W, N)
+    assert st.count == H * W and st.part.shape == (B, H * W // 128, 2, N)
+    assert float((part[:, 0] - yy.sum(1)).abs().max()) <= 1e-5 * float(yy.abs().sum(1).max())
+    assert float((part[:, 1] - (yy * yy).sum(1)).abs().max()) <= 1e-5 * float((yy * yy).sum(1).max())
+    y16, _ = K_.gemm1x1(G, pw, bias, out_bf16=True)
+    assert torch.equal(y16, y.to(torch.bfloat16))
+    y2, st2 = K_.gemm1x1(G, pw, bias, want_stats=True)
+    assert torch.equal(y, y2) and torch.equal(st.part, st2.part)
+    yc, _ = K_.conv2d(G, pw, bias, compute=K_.BF16)
+    assert float((yc - y).abs().max() / y.abs().max()) < 2e-6
+    # shapes it does not take go to the generic conv (same wrapper)
+    if N == 32:
+        Gs = G[:, :, :, :K].reshape(B, H, W, K)[:, :3].contiguous()      # 3 rows: HW % 128 != 0 for these widths
+        if (3 * W) % 128:
+            ys, _ = K_.gemm1x1(Gs, pw, bias)
+            assert float((ys - y[:, :3]).abs().max() / y.abs().max()) < 2e-6
