@@ -44,6 +44,7 @@ struct WgradArgs {
   int RX, RY;                    // LDS row strides (bytes) of the X / dY tiles
   int off_xlo, off_y, off_ylo, off_ss, off_red, off_da;
   int nchunks;                   // pixel split of this job
+  int rS;                        // reduce launch in per-job mode (S argument 0): chunk slices per block for this job (4 or 16)
   int x_bf16, dy_bf16;           // operands stored as bf16 (the sample-resident conv chain) instead of fp32
   float* ws;                     // deterministic mode: this job's workspace (per (chunk, block) slabs [taps][CB][OB], then
   float* ws_db;                  //   per (chunk, co block) bias slabs [OB]); null = fp32 atomics straight into dw / db
@@ -1188,6 +1189,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const MultiArgs m, in
   while (job + 1 < m.njobs && (int)blockIdx.x >= m.rfirst[job + 1]) ++job;
   const WgradArgs& a = m.job[job];
   if (CB == 0) { CB = a.RX; OB = a.RY; }               // launch of conv_wgrad2_kernel: the block shape is a job field
+  if (S == 0) S = a.rS;                                 // ... and so is the slice count (jobs of several compute launches share this one)
   const int nblk = a.cblocks * a.oblocks, ob4 = OB >> 2;
   const size_t slab = (size_t)a.ntaps * CB * OB;                 // floats of one (chunk, block) partial
   const size_t nvec = (size_t)nblk * a.ntaps * CB * ob4;         // float4 of one chunk
@@ -1445,6 +1447,38 @@ static bool same_geo(const Geo& p, const Geo& q) {
 }
 
 
+// The fixed-order reduce of the LDS-DMA and the narrow-layer kernels' partial slabs: ONE launch per call of
+// hdrsky_conv2d_wgrad_multi_det for the jobs of all their compute launches (each used to be followed by its own: four launches
+// for a call with both kinds of layer, the two reduces ~10 us each of mostly launch latency), block shape and slice count per job.
+struct PendingReduce {
+  MultiArgs mr{};
+  int rblocks = 0;
+  bool plan_only = false;
+  void* stream = nullptr;
+  int flush() {
+    if (mr.njobs > 0 && rblocks > 0) {
+      mr.rfirst[mr.njobs] = rblocks;
+      if (plan_only) note_kernel("wgrad_reduce_kernel");
+      else {
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(256), 0, (hipStream_t)stream, mr, 0, 0, 0);
+        HDRSKY_CHECK_LAUNCH();
+      }
+    }
+    mr = MultiArgs{}; rblocks = 0;
+    return HDRSKY_OK;
+  }
+  // appends one job's reduce (nblocks4 = float4 elements of one chunk's slab set); flushes first when the argument block is full
+  int add(const WgradArgs& ar, size_t nvec, int S) {
+    if (mr.njobs == WG_MAXJ) { const int rc = flush(); if (rc != HDRSKY_OK) return rc; }
+    WgradArgs& d = mr.job[mr.njobs];
+    d = ar; d.rS = S;
+    mr.rfirst[mr.njobs] = rblocks;
+    rblocks += (int)((nvec + 256 / S - 1) / (256 / S));
+    ++mr.njobs;
+    return HDRSKY_OK;
+  }
+};
+
 // ---- v2 host side -------------------------------------------------------------------------------------------------------
 static bool v2_eligible(const hdrsky_wgrad_job& j) {
   const hdrsky_conv_desc* d = &j.desc;
@@ -1530,7 +1564,7 @@ extern "C" void hdrsky_debug_wgrad2_stamps(void* buf) { g_wg2_stamps = (unsigned
 // Launches (or, plan_only, sizes) the v2 kernel + the shared reduce for the eligible jobs among jobs[0..njobs); marks them
 // in done[].  Jobs the kernel cannot take (LDS budget, geometry) stay unmarked: the caller's v1 path handles them.
 static int wgrad2_groups(const hdrsky_wgrad_job* jobs, int njobs, bool* done, float* ws, size_t ws_floats, size_t* ws_used,
-                         bool plan_only, void* stream) {
+                         bool plan_only, void* stream, PendingReduce& red) {
   const int wg_hook = hdrsky_hooks().wgrad2_wgs;   // (tuning hook; 0 = by work share)
   const int wg_total = wg_hook > 0 ? wg_hook : 256;
   int members[256], nm = 0;
@@ -1548,10 +1582,10 @@ static int wgrad2_groups(const hdrsky_wgrad_job* jobs, int njobs, bool* done, fl
     double wpart = 0.0;
     for (int q = 0; q < cnt; ++q) wpart += work[base + q];
     Multi2Args m2{};
-    MultiArgs mr{};
-    m2.njobs = mr.njobs = cnt;
+    m2.njobs = cnt;
     m2.stamps = g_wg2_stamps;
-    int lds = 0, blocks = 0, rblocks = 0, maxchunks = 1;
+    int lds = 0, blocks = 0, maxchunks = 1;
+    WgradArgs rjobs[WG2_MAXJ]; size_t rvec[WG2_MAXJ];
     for (int q = 0; q < cnt; ++q) {
       Wg2Args tmp;
       if (wg2_prepare(tmp, jobs[members[base + q]], (int)(wg_total * work[base + q] / wpart + 0.5)) >= 0 && tmp.nchunks > maxchunks)
@@ -1574,28 +1608,22 @@ static int wgrad2_groups(const hdrsky_wgrad_job* jobs, int njobs, bool* done, fl
       a.ws = ws + *ws_used;
       a.ws_db = (j.db != nullptr && !a.direct) ? ws + *ws_used + nslab : nullptr;
       *ws_used += nslab + (j.db != nullptr ? nbias : 0);
-      WgradArgs& ar = mr.job[q];     // what wgrad_reduce_kernel reads
+      WgradArgs& ar = rjobs[q];      // what wgrad_reduce_kernel reads
       ar = WgradArgs{};
       ar.dw = j.dw; ar.db = j.db; ar.ws = a.ws; ar.ws_db = a.ws_db; ar.Cin = a.Cin; ar.Cout = a.Cout;
       ar.nchunks = a.nchunks; ar.cblocks = a.cblocks; ar.oblocks = a.oblocks; ar.ntaps = a.ntaps;
       ar.RX = CB; ar.RY = OB;        // per-job block shape of the reduce launch (CB = OB = 0 arguments)
-      mr.rfirst[q] = rblocks;
-      if (!a.direct) rblocks += (int)(((size_t)a.cblocks * a.oblocks * a.ntaps * CB * (OB / 4) + 256 / S - 1) / (256 / S));
+      rvec[q] = a.direct ? 0 : (size_t)a.cblocks * a.oblocks * a.ntaps * CB * (OB / 4);
     }
     m2.first[cnt] = blocks;
-    mr.rfirst[cnt] = rblocks;
-    if (plan_only) {
-      note_kernel("conv_wgrad2_kernel<%d>", WG2_UPW);
-      if (rblocks > 0) note_kernel("wgrad_reduce_kernel");
-    } else {
+    if (plan_only) note_kernel("conv_wgrad2_kernel<%d>", WG2_UPW);
+    else {
       if (*ws_used > ws_floats) return HDRSKY_EINVAL;
       const int r = wg2_launch(m2, lds, (hipStream_t)stream);
       if (r != HDRSKY_OK) return r;
-      if (rblocks > 0) {
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(256), 0, (hipStream_t)stream, mr, 0, 0, S);
-        HDRSKY_CHECK_LAUNCH();
-      }
     }
+    for (int q = 0; q < cnt; ++q)
+      if (rvec[q] > 0) { const int rc = red.add(rjobs[q], rvec[q], S); if (rc != HDRSKY_OK) return rc; }
     for (int q = 0; q < cnt; ++q) done[members[base + q]] = true;
   }
   return HDRSKY_OK;
@@ -1717,7 +1745,7 @@ static int wg3_launch(int variant, Multi3Args& m, int lds, hipStream_t stream) {
 
 // Launches (or, plan_only, sizes) the narrow-layer kernel + the shared reduce for the jobs it takes; marks them in done[].
 static int wgrad3_groups(const hdrsky_wgrad_job* jobs, int njobs, bool* done, float* ws, size_t ws_floats, size_t* ws_used,
-                         bool plan_only, void* stream) {
+                         bool plan_only, void* stream, PendingReduce& red) {
   const int wg_each = hdrsky_hooks().wgrad3_wgs;   // (tuning hook: workgroups per layer; 256)
   int all[256], na = 0, cls[256];
   bool deep8 = false;
@@ -1736,10 +1764,10 @@ static int wgrad3_groups(const hdrsky_wgrad_job* jobs, int njobs, bool* done, fl
   for (int base = 0; base < nm; base += WG3_MAXJ) {
     const int cnt = nm - base < WG3_MAXJ ? nm - base : WG3_MAXJ;
     Multi3Args m3{};
-    MultiArgs mr{};
-    m3.njobs = mr.njobs = cnt;
+    m3.njobs = cnt;
     m3.stamps = g_wg2_stamps;
-    int lds = 0, blocks = 0, rblocks = 0, maxchunks = 1;
+    int lds = 0, blocks = 0, maxchunks = 1;
+    WgradArgs rjobs[WG3_MAXJ]; size_t rvec[WG3_MAXJ];
     for (int q = 0; q < cnt; ++q) {
       Wg3Args tmp;
       if (wg3_prepare(tmp, jobs[members[base + q]], wg_each) >= 0 && tmp.nchunks > maxchunks) maxchunks = tmp.nchunks;
@@ -1760,26 +1788,22 @@ static int wgrad3_groups(const hdrsky_wgrad_job* jobs, int njobs, bool* done, fl
       a.ws = ws + *ws_used;
       a.ws_db = j.db != nullptr ? ws + *ws_used + nslab : nullptr;
       *ws_used += nslab + (j.db != nullptr ? nbias : 0);
-      WgradArgs& ar = mr.job[q];     // what wgrad_reduce_kernel reads
+      WgradArgs& ar = rjobs[q];      // what wgrad_reduce_kernel reads
       ar = WgradArgs{};
       ar.dw = j.dw; ar.db = j.db; ar.ws = a.ws; ar.ws_db = a.ws_db; ar.Cin = j.desc.Cin; ar.Cout = j.desc.Cout;
       ar.nchunks = a.nchunks; ar.cblocks = cblocks; ar.oblocks = oblocks; ar.ntaps = ntaps;
       ar.RX = a.slabCB; ar.RY = a.slabOB;
-      mr.rfirst[q] = rblocks;
-      rblocks += (int)(((size_t)a.nblocks * ntaps * a.slabCB * (a.slabOB / 4) + 256 / S - 1) / (256 / S));
+      rvec[q] = (size_t)a.nblocks * ntaps * a.slabCB * (a.slabOB / 4);
     }
     m3.first[cnt] = blocks;
-    mr.rfirst[cnt] = rblocks;
-    if (plan_only) {
+    if (plan_only)
       note_kernel(variant == 0 ? "conv_wgrad3_kernel<4, 1, 1, 4, %d>" : variant == 1 ? "conv_wgrad3_kernel<4, 1, 1, 8, %d>" : "conv_wgrad3_kernel<2, 2, 2, 8, %d>", WG3_UPW);
-      note_kernel("wgrad_reduce_kernel");
-    } else {
+    else {
       if (*ws_used > ws_floats) return HDRSKY_EINVAL;
       const int r = wg3_launch(variant, m3, lds, (hipStream_t)stream);
       if (r != HDRSKY_OK) return r;
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(256), 0, (hipStream_t)stream, mr, 0, 0, S);
-      HDRSKY_CHECK_LAUNCH();
     }
+    for (int q = 0; q < cnt; ++q) { const int rc = red.add(rjobs[q], rvec[q], S); if (rc != HDRSKY_OK) return rc; }
     for (int q = 0; q < cnt; ++q) done[members[base + q]] = true;
   }
   }
@@ -1807,18 +1831,21 @@ static int wgrad_multi_impl(const hdrsky_wgrad_job* jobs, int njobs, float* ws, 
   Geo geo[256];
   bool done[256];
   for (int i = 0; i < njobs; ++i) done[i] = false;
+  PendingReduce red;
+  red.plan_only = plan_only; red.stream = stream;
   // layers with two final bf16 operands: the LDS-DMA ring kernel (deterministic mode only; HDRSKY_WGRAD2=0: A/B hook)
   const bool v2_on = hk.wgrad2 != 0;
   if (v2_on && (ws != nullptr || plan_only)) {
-    const int rc2 = wgrad2_groups(jobs, njobs, done, ws, ws_floats, &ws_used, plan_only, stream);
+    const int rc2 = wgrad2_groups(jobs, njobs, done, ws, ws_floats, &ws_used, plan_only, stream, red);
     if (rc2 != HDRSKY_OK) return rc2;
   }
   // layers with a narrow side (<= 8 input or <= 4 output channels): their own kernel (HDRSKY_WGRAD3=0: A/B hook)
   const bool v3_on = hk.wgrad3 != 0;
   if (v3_on && (ws != nullptr || plan_only)) {
-    const int rc3 = wgrad3_groups(jobs, njobs, done, ws, ws_floats, &ws_used, plan_only, stream);
+    const int rc3 = wgrad3_groups(jobs, njobs, done, ws, ws_floats, &ws_used, plan_only, stream, red);
     if (rc3 != HDRSKY_OK) return rc3;
   }
+  { const int rcr = red.flush(); if (rcr != HDRSKY_OK) return rcr; }       // one reduce launch for both kinds of layer
   int nwide = 0;
   for (int i = 0; i < njobs; ++i) nwide += (!done[i] && can_go_big(jobs[i])) ? 1 : 0;
   const bool use_big = nwide >= 3 && !force_small;
