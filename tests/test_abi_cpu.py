@@ -192,3 +192,33 @@ def test_no_packed_f32_with_src1_op_sel(tmp_path):
     assert mfma > 1000, "the disassembly does not look like the library's device code"
     assert not bad, "%d packed-f32 instructions with op_sel[src1] = 1, e.g. %s" % (len(bad), bad[:3])
     assert total < 64, "%d packed-f32 instructions: is -fno-slp-vectorize still in csrc/Makefile?" % total
+
+
+def test_tuning_hooks_are_ignored_without_the_experiments_gate(monkeypatch):
+    """csrc/hooks.h / <pkg>/hooks.py: switches are always honoured, tuning hooks only under HDRSKY_EXPERIMENTS=1 - a stray
+    HDRSKY_TILE in a deployment's environment must not change which kernel the product launches.  Checked on the host side of
+    the library (hdrsky_conv_kernel_name needs no GPU) and on the Python side."""
+    L, HK = pkg("_lib"), pkg("hooks")
+    lib = L.load()
+    d = L.ConvDesc()
+    assert lib.hdrsky_conv_desc_init(d, 32, 16, 64, 64, 64, 3, 3, 1, 1, 1) == 0
+    d.compute = L.BF16 if hasattr(L, "BF16") else 0
+
+    def name():
+        buf = ctypes.create_string_buffer(256)
+        assert lib.hdrsky_conv_kernel_name(d, buf, 256) == 0
+        return buf.value.decode()
+    import ctypes
+    base = name()
+    monkeypatch.setenv("HDRSKY_TILE", "2,2,2,2,32,0")
+    monkeypatch.setenv("HDRSKY_RAW_BF16", "1")
+    assert name() == base and not lib.hdrsky_experiments_enabled() and not HK.H.raw_bf16 and not HK.H.experiments
+    monkeypatch.setenv("HDRSKY_EXPERIMENTS", "1")
+    assert lib.hdrsky_experiments_enabled() and HK.H.raw_bf16 and "<2, 2, 2, 2, 32" in name() and name() != base
+    monkeypatch.delenv("HDRSKY_EXPERIMENTS")
+    assert name() == base and not HK.H.raw_bf16
+    # a switch is honoured without the gate
+    monkeypatch.setenv("HDRSKY_DA_MAT", "0")
+    assert not HK.H.da_mat
+    monkeypatch.delenv("HDRSKY_DA_MAT")
+    assert HK.H.da_mat
