@@ -124,6 +124,23 @@ def dominant_kernel_roofline(torch, K, pw, batch, h, w, iters=200):
             "algorithmic_bytes": batch * 256 * 128 * 2 * 3 + 9 * 128 * 128 * 2}
 
 
+def gemm1x1_roofline(torch, K, batch=8, h=32, w=128, C=128, F=128, iters=100):
+    """The matmul of a distortion-aware 3x3 layer on its written gathered operand (hdrsky_gemm1x1_bf16: G [B,h,w,9C] bf16 x the
+    layer's packed filter) on the res-block shape of the 128x512 network, timed live like the roofline object of the driver
+    line.  Algorithmic FLOPs = 2 * B*h*w * 9C * F; algorithmic bytes = G once (bf16) + the filter + the fp32 output."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    G = torch.randn(batch, h, w, 9 * C, device=dev).to(torch.bfloat16)
+    pw = K.PackedConv(torch.randn(3, 3, C, F, device=dev) / (9 * C) ** 0.5, False).as_1x1()
+    bias = torch.zeros(F, device=dev)
+    us = _graph_time(torch, lambda: K.gemm1x1(G, pw, bias, want_stats=True), iters)
+    flop = 2.0 * batch * h * w * 9 * C * F
+    achieved = flop / (us * 1e-6) / 1e12
+    return {"bound": "mfma", "kernel": "gemm1x1_kernel<4> (distortion-aware 3x3 %d->%d layer on its written gathered operand, %dx%d maps, B=%d)" % (C, F, h, w, batch),
+            "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 5),
+            "traffic": None, "avg_launch_us": round(us, 3), "flop_per_launch": flop,
+            "algorithmic_bytes": batch * h * w * (9 * C * 2 + F * 4) + 9 * C * F * 2}
+
+
 def roofline_top(torch, K, tr, ldr, hdr, gt, top=5, iters=30):
     """The matrix-core launches of ONE training step ranked by the kernel time they cost: an eager step is traced
     (kernels.TRACE: every conv / data-gradient / weight-gradient / sample-resident launch with its layer label, kernel
@@ -682,7 +699,8 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         if hires_train:
-            pass
+            if args.da:       # the best-utilised launch of a distortion-aware 128x512 step (the driver line's roofline object is resconv's)
+                res["roofline"] = gemm1x1_roofline(torch, K)
         elif hires:
             res["roofline_hbm"] = [fc_row]
             res["sunpose_fc"] = fc_row
