@@ -66,6 +66,8 @@ SIGNATURES = {
     "hdrsky_conv_stats_nparts": (c_int, [ctypes.POINTER(ConvDesc)]),
     "hdrsky_conv_kernel_name": (c_int, [ctypes.POINTER(ConvDesc), ctypes.c_char_p, c_int]),
     "hdrsky_conv2d_fwd": (c_int, [ctypes.POINTER(ConvDesc)] + [P] * 13),
+    "hdrsky_conv2d_emit_supported": (c_int, [ctypes.POINTER(ConvDesc)]),
+    "hdrsky_conv2d_fwd_emit": (c_int, [ctypes.POINTER(ConvDesc)] + [P] * 14),
     "hdrsky_conv2d_wgrad": (c_int, [ctypes.POINTER(ConvDesc)] + [P] * 10),
     "hdrsky_conv2d_wgrad_multi": (c_int, [ctypes.POINTER(WgradJob), c_int, P]),
     "hdrsky_conv2d_wgrad_ws_bytes": (c_size_t, [ctypes.POINTER(WgradJob), c_int]),

@@ -51,6 +51,11 @@ struct ConvKArgs {
   unsigned long long* stamps;  // debug: per-workgroup phase time stamps (null in production)
   int x_bf16, y_bf16;          // activation storage (hdrsky_conv_desc)
   int res_mode; float mask_slope;
+  // xb_out (optional, single-product mode, plain staging): the TRANSFORMED operand act(norm(x)) as a bf16 NHWC tensor of x's shape -
+  // exactly the values staged for the matrix cores, written by the workgroups of output-channel block 0, every input pixel by
+  // the tile that owns it.  It is the operand of the layer's weight gradient (conv_wgrad2_kernel), which needed a launch of its
+  // own (hdrsky_act_bf16) to produce it.
+  unsigned short* xb_out;
   // stride-2 data gradient by output phases (phase != 0): workgroup = a tile of ONE of the four (oy & 1, ox & 1) phases of
   // the output; KH / KW are then the per-phase tap counts ceil(K / 2), KHf / KWf the full (flipped) filter, pad_t / pad_l
   // the full conv's K - 1 - pad, H / W (= Hc / Wc) the un-stuffed gradient
@@ -159,7 +164,10 @@ __device__ __forceinline__ void compute_chunk(const ConvKArgs& a, const unsigned
 // then fit a CU, which is what lets kernels of the other streams of the training step overlap with this one.
 // PH: the stride-2 data gradient by output phases (ConvKArgs::phase; its own instantiations: the extra scalars of the
 // phase arithmetic pushed the 8-wave direct-B variants, which sit at their 128-VGPR budget, into scratch)
-template <int WM, int WN, int MI, int NI, int TW, bool NARROW, bool PRECISE, bool DB, bool PH>
+// EMIT: the instantiations that also write the transformed operand (ConvKArgs::xb_out) - their own, because the extra address
+// registers of the staging pushed the 8-wave variants at their 128-VGPR budget into a spill around the k loop (+3.5 % on the
+// training step when every launch paid for it; as instantiations only the nine launches per step that emit do)
+template <int WM, int WN, int MI, int NI, int TW, bool NARROW, bool PRECISE, bool DB, bool PH, bool EMIT = false>
 __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB ? 4 : 2) : 1) conv_igemm_kernel(const ConvKArgs a) {
   constexpr int NW = WM * WN;                // waves per workgroup (4 or 8)
   constexpr int NT = NW * 64;
@@ -366,10 +374,15 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB
         constexpr int UNR = 4;
         const int dummy = a.NPIXP - 1;  // pad slot of plane 0: never read
         const int dsh = a.dilate == 2 ? 1 : 0;
+        // xb_out: this tile owns the input pixels under its own output block (TH x TW outputs x stride: a partition of the image)
+        const bool emit_xb = EMIT && !PRECISE && nb == 0;
+        const int own_y0 = oy0 * a.stride, own_y1 = (oy0 + TH) * a.stride, own_x0 = ox0 * a.stride, own_x1 = (ox0 + TW) * a.stride;
+        unsigned short* xbo = a.xb_out + (size_t)b * a.H * a.W * a.Cin + g * a.cgs;
         for (int i0 = tid; i0 < nitems; i0 += NT * UNR) {
           float4 va[UNR], vb[UNR];
           bool ok[UNR];
           int dst[UNR];
+          int emit[UNR];      // xb_out: element offset (inside the sample's channel group) of an item this tile owns, else -1
 #pragma unroll
           for (int u = 0; u < UNR; ++u) {
             const int i = i0 + u * NT;
@@ -384,6 +397,10 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB
             ok[u] = v;
             dst[u] = (i < nitems) ? q * a.NPIXP + p : dummy;
             const size_t eo = ((size_t)(v ? cy : 0) * a.W + (v ? cx : 0)) * a.Cin + q * 8;
+            if (EMIT && !PRECISE) {
+              const bool own = emit_xb && v && i < nitems && cy >= own_y0 && cy < own_y1 && cx >= own_x0 && cx < own_x1;
+              emit[u] = own ? (int)eo : -1;
+            }
             if (!PRECISE && a.x_bf16) {   // workgroup-uniform: a final bf16 activation is copied, not converted
               va[u] = __builtin_bit_cast(float4, *reinterpret_cast<const uint4*>(
                                                      reinterpret_cast<const unsigned short*>(a.x) + (size_t)b * a.H * a.W * a.Cin + g * a.cgs + eo));
@@ -411,6 +428,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB
                 uint4 hi, lo;
                 pack8<false>(v, hi, lo);
                 sAhi[dst[u]] = hi;
+                if (EMIT && emit_xb && emit[u] >= 0) *reinterpret_cast<uint4*>(xbo + emit[u]) = hi;
               }
             }
             continue;
@@ -433,6 +451,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB
             pack8<PRECISE>(v, hi, lo);
             sAhi[dst[u]] = hi;
             if (PRECISE) sAlo[dst[u]] = lo;
+            if (EMIT && !PRECISE && emit_xb && emit[u] >= 0) *reinterpret_cast<uint4*>(xbo + emit[u]) = hi;
           }
         }
       }
@@ -797,7 +816,7 @@ struct TileCfg { int wm, wn, mi, ni, tw, db; };
 
 constexpr int HDRSKY_EPHASE_FALLBACK = -1000;   // internal: launch_conv declines the phase form of a stride-2 data gradient
 
-template <int WM, int WN, int MI, int NI, int TW, bool NARROW, bool PRECISE, bool DB, bool PH>
+template <int WM, int WN, int MI, int NI, int TW, bool NARROW, bool PRECISE, bool DB, bool PH, bool EMIT = false>
 int launch_conv(ConvKArgs& a, hipStream_t stream) {
   constexpr int BM = WM * MI * 16, BN = WN * NI * 16, TH = BM / TW;
   a.tiles_x = cdiv(PH ? cdiv(a.Wo, 2) : a.Wo, TW);    // phase mode: tiles of one phase's grid, four phases per sample
@@ -850,7 +869,7 @@ int launch_conv(ConvKArgs& a, hipStream_t stream) {
   a.off_out = 0;
   if (DB && roundup(lds, 16) + out_bytes <= 80 * 1024) { a.off_out = roundup(lds, 16); lds = a.off_out + out_bytes; }   // (two workgroups per CU must still fit)
   if (lds > 160 * 1024) return HDRSKY_EUNSUPPORTED;
-  auto kern = conv_igemm_kernel<WM, WN, MI, NI, TW, NARROW, PRECISE, DB, PH>;
+  auto kern = conv_igemm_kernel<WM, WN, MI, NI, TW, NARROW, PRECISE, DB, PH, EMIT>;
   static std::atomic<int> max_lds_set{0};
   if (lds > max_lds_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -864,14 +883,14 @@ int launch_conv(ConvKArgs& a, hipStream_t stream) {
   return HDRSKY_OK;
 }
 
-template <bool NARROW, bool PRECISE, bool PH = false>
+template <bool NARROW, bool PRECISE, bool PH = false, bool EMIT = false>
 int dispatch_tile(ConvKArgs& a, const TileCfg& t, hipStream_t s) {
 #define HDRSKY_CASE(WM_, WN_, MI_, NI_, TW_)                                              \
   if (!t.db && t.wm == WM_ && t.wn == WN_ && t.mi == MI_ && t.ni == NI_ && t.tw == TW_) \
-    return launch_conv<WM_, WN_, MI_, NI_, TW_, NARROW, PRECISE, false, PH>(a, s);
+    return launch_conv<WM_, WN_, MI_, NI_, TW_, NARROW, PRECISE, false, PH, EMIT>(a, s);
 #define HDRSKY_CASE_DB(WM_, WN_, MI_, NI_, TW_)                                           \
   if (t.db && t.wm == WM_ && t.wn == WN_ && t.mi == MI_ && t.ni == NI_ && t.tw == TW_)  \
-    return launch_conv<WM_, WN_, MI_, NI_, TW_, NARROW, PRECISE, true, PH>(a, s);
+    return launch_conv<WM_, WN_, MI_, NI_, TW_, NARROW, PRECISE, true, PH, EMIT>(a, s);
   // LDS-ring variant
   HDRSKY_CASE(2, 2, 4, 2, 32) HDRSKY_CASE(2, 2, 2, 2, 32) HDRSKY_CASE(2, 2, 2, 2, 16)
   HDRSKY_CASE(4, 1, 4, 2, 32) HDRSKY_CASE(4, 1, 2, 2, 32) HDRSKY_CASE(2, 2, 2, 1, 32) HDRSKY_CASE(2, 2, 2, 1, 16)
@@ -1138,7 +1157,7 @@ int hdrsky_conv_kernel_name(const hdrsky_conv_desc* d, char* buf, int n) {
   hdrsky_conv_desc pv = *d;
   if (phase_applies(d)) pv = phase_view(d);   // (an odd filter over several channel groups falls back at launch: not seen here)
   const TileCfg t = choose_tile(&pv);
-  snprintf(buf, (size_t)n, "conv_igemm_kernel<%d, %d, %d, %d, %d, %s, %s, %s, %s>", t.wm, t.wn, t.mi, t.ni, t.tw,
+  snprintf(buf, (size_t)n, "conv_igemm_kernel<%d, %d, %d, %d, %d, %s, %s, %s, %s, false>", t.wm, t.wn, t.mi, t.ni, t.tw,
            d->Cin <= 8 ? "true" : "false", d->compute == HDRSKY_BF16X3 ? "true" : "false", t.db ? "true" : "false",
            phase_applies(d) ? "true" : "false");
   return HDRSKY_OK;
@@ -1151,10 +1170,42 @@ int hdrsky_conv_stats_nparts(const hdrsky_conv_desc* d) {
   return cdiv(d->Ho, bm / t.tw) * cdiv(d->Wo, t.tw);
 }
 
+// [host] 1 when hdrsky_conv2d_fwd_emit can write the transformed operand of this layer: single-product mode, >= 32 input channels,
+// stride 1 or 2 without resize / dilation, an operand transform to apply (else x itself is the operand)
+int hdrsky_conv2d_emit_supported(const hdrsky_conv_desc* d) {
+  if (!d || d->compute != HDRSKY_BF16 || d->Cin <= 8 || (d->Cin % 32) != 0) return 0;
+  if (d->upsample != 1 || d->dilate != 1 || (d->stride != 1 && d->stride != 2) || d->Cout == 1) return 0;
+  if (d->in_mode == HDRSKY_IN_NONE && d->in_slope == 1.f) return 0;
+  return 1;
+}
+
+static int conv2d_fwd_impl(const hdrsky_conv_desc* d, const float* x, const void* w_hi, const void* w_lo,
+                           const float* bias, const float* in_scale, const float* in_shift, const float* in_part,
+                           const float* in_gamma, const float* in_beta, const float* residual, float* y,
+                           float* stats_part, void* xb_out, void* stream);
+
 int hdrsky_conv2d_fwd(const hdrsky_conv_desc* d, const float* x, const void* w_hi, const void* w_lo,
                       const float* bias, const float* in_scale, const float* in_shift, const float* in_part,
                       const float* in_gamma, const float* in_beta, const float* residual, float* y,
                       float* stats_part, void* stream) {
+  return conv2d_fwd_impl(d, x, w_hi, w_lo, bias, in_scale, in_shift, in_part, in_gamma, in_beta, residual, y, stats_part, nullptr, stream);
+}
+
+// hdrsky_conv2d_fwd that ALSO writes xb_out [B,H,W,Cin] bf16 = act(norm(x)), the operand as the matrix cores saw it - what the
+// layer's weight gradient (hdrsky_wgrad_job with a final bf16 x) reads, without the hdrsky_act_bf16 launch that used to make it
+int hdrsky_conv2d_fwd_emit(const hdrsky_conv_desc* d, const float* x, const void* w_hi, const void* w_lo,
+                           const float* bias, const float* in_scale, const float* in_shift, const float* in_part,
+                           const float* in_gamma, const float* in_beta, const float* residual, float* y,
+                           float* stats_part, void* xb_out, void* stream) {
+  if (!xb_out) return HDRSKY_EINVAL;
+  if (!hdrsky_conv2d_emit_supported(d)) return HDRSKY_EUNSUPPORTED;
+  return conv2d_fwd_impl(d, x, w_hi, w_lo, bias, in_scale, in_shift, in_part, in_gamma, in_beta, residual, y, stats_part, xb_out, stream);
+}
+
+static int conv2d_fwd_impl(const hdrsky_conv_desc* d, const float* x, const void* w_hi, const void* w_lo,
+                           const float* bias, const float* in_scale, const float* in_shift, const float* in_part,
+                           const float* in_gamma, const float* in_beta, const float* residual, float* y,
+                           float* stats_part, void* xb_out, void* stream) {
   if (!d || !x || !w_hi || !y) return HDRSKY_EINVAL;
   const bool narrow = d->Cin <= 8;
   if (!narrow && (d->Cin % 32) != 0) return HDRSKY_EUNSUPPORTED;
@@ -1184,6 +1235,7 @@ int hdrsky_conv2d_fwd(const hdrsky_conv_desc* d, const float* x, const void* w_h
   a.out_slope = d->out_slope; a.final_relu = d->final_relu; a.want_stats = d->want_stats;
   a.stamps = g_stamps;
   a.x_bf16 = d->x_bf16; a.y_bf16 = d->y_bf16; a.res_mode = d->res_mode; a.mask_slope = d->mask_slope;
+  a.xb_out = (unsigned short*)xb_out;
   hipStream_t s = (hipStream_t)stream;
   if (dot1_applies(d, residual)) {       // one output channel: a dot product per pixel, not a 16-column MFMA tile
     a.ntaps = d->KH * d->KW;
@@ -1205,6 +1257,7 @@ int hdrsky_conv2d_fwd(const hdrsky_conv_desc* d, const float* x, const void* w_h
   }
   const TileCfg t = choose_tile(d);
   if (narrow) return precise ? dispatch_tile<true, true>(a, t, s) : dispatch_tile<true, false>(a, t, s);
+  if (a.xb_out != nullptr) return dispatch_tile<false, false, false, true>(a, t, s);      // (hdrsky_conv2d_emit_supported: never narrow / precise)
   return precise ? dispatch_tile<false, true>(a, t, s) : dispatch_tile<false, false>(a, t, s);
 }
 

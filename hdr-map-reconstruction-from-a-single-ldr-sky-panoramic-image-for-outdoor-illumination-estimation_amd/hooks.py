@@ -31,6 +31,8 @@ class _Hooks:
         # raw conv outputs in front of a norm layer as bf16 (ABI 4): measured on the 32x128 step, -0.3 % step time (everything
         # sits in the 256 MB MALL: storage width is not what bounds these launches) for 1.5x the loss-term error - off
         self.raw_bf16 = exp("HDRSKY_RAW_BF16", "0") == "1"
+        # the forward conv writes its transformed operand as bf16 for the layer's weight gradient (no hdrsky_act_bf16 launch)
+        self.emit_xb = exp("HDRSKY_EMIT_XB", "1") != "0"
         self.disc_split = exp("HDRSKY_DISC_SPLIT", "0") == "1"
         self.dec_head_early = exp("HDRSKY_DEC_HEAD_EARLY", "1") != "0"
         self.bwd_dense_stream = int(exp("HDRSKY_BWD_DENSE_STREAM", "2"))

@@ -175,7 +175,7 @@ def _bf16(t, *shape):
 
 def conv2d(x, pw: PackedConv, bias=None, stride=1, same=True, upsample=1, xf: Optional[InXf] = None,
            out_slope=1.0, residual=None, final_relu=False, want_stats=False, compute=BF16, desc=None, out=None,
-           out_bf16=False, mask_bf16=None, mask_slope=0.0):
+           out_bf16=False, mask_bf16=None, mask_slope=0.0, emit_xb=False):
     """y = final_relu(act(conv(xf(x)) + bias) + residual); returns (y, Stats|None).
     HDRSKY_BF16 mode: x may be a bfloat16 tensor (a final activation: no xf), out_bf16 stores y as bfloat16; mask_bf16
     (instead of residual): a bfloat16 ACTIVATED tensor of y's shape - y is multiplied by (it > 0 ? 1 : mask_slope), the
@@ -194,6 +194,7 @@ def conv2d(x, pw: PackedConv, bias=None, stride=1, same=True, upsample=1, xf: Op
     d.compute = compute
     if compute == BF16X3 and pw.lo is None:
         raise ValueError("BF16X3 needs the lo weight plane (PackedConv(precise=True))")
+    xf_given = xf
     xf = xf or InXf()
     d.in_mode, d.in_slope = xf.mode, float(xf.slope)
     in_scale = in_shift = in_part = in_gamma = in_beta = None
@@ -234,13 +235,21 @@ def conv2d(x, pw: PackedConv, bias=None, stride=1, same=True, upsample=1, xf: Op
         stats = Stats(torch.empty((B, nparts, 2, pw.Cout), dtype=torch.float32, device=x.device), nparts, d.Ho * d.Wo)
     args = (d, _p(x), _p(pw.hi), _p(pw.lo), _p(bias), _p(in_scale), _p(in_shift), _p(in_part), _p(in_gamma), _p(in_beta),
             _p(residual), _p(y), _p(stats.part) if stats else None)
-    L.check(lib.hdrsky_conv2d_fwd(*args, _stream()), "conv2d_fwd")
+    # emit_xb: the transformed operand act(norm(x)) written as a bf16 tensor by this launch - the x of the layer's weight gradient
+    # (kept on the tensor object together with the transform it belongs to: wgrad_job finds it there)
+    xb = None
+    if emit_xb and xf_given is not None and lib.hdrsky_conv2d_emit_supported(d):
+        xb = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=x.device)
+        L.check(lib.hdrsky_conv2d_fwd_emit(*args, _p(xb), _stream()), "conv2d_fwd_emit")
+        x._xb = (xf_given, xb)
+    else:
+        L.check(lib.hdrsky_conv2d_fwd(*args, _stream()), "conv2d_fwd")
     if TRACE is not None:
         keep = (x, pw, bias, in_scale, in_shift, in_part, in_gamma, in_beta, residual, y, stats)
         stuffed = 4 if d.dilate == 2 else 1
         kname = conv_kernel_name(d)
         # a stride-2 data gradient: by output phases (the PH instantiations, last template argument) or on the zero-stuffed operand
-        form = " up2" if d.upsample == 2 else ((" s2 dgrad by phases" if kname.endswith("true>") else " s2 dgrad zero-stuffed") if stuffed == 4 else "")
+        form = " up2" if d.upsample == 2 else ((" s2 dgrad by phases" if kname.endswith("true, false>") else " s2 dgrad zero-stuffed") if stuffed == 4 else "")
         _trace("dgrad" if pw.flip else "conv", kname,
                "%dx%d %d->%d @%dx%d B=%d%s%s" % (d.KH, d.KW, C, pw.Cout, d.Ho, d.Wo, B, " s2" if d.stride == 2 else "", form),
                2.0 * B * d.Ho * d.Wo * d.KH * d.KW * C * pw.Cout / stuffed,
@@ -339,6 +348,9 @@ def wgrad_job(x, dy, KH, KW, dw, db=None, stride=1, same=True, upsample=1, xf: O
     x / dy may be bf16 tensors: final activations / gradients (no operand transform), or - x with a transform - a raw conv
     output as the single-product mode stores it (materialised by conv2d_wgrad_multi, or widened by the narrow-output kernel).
     The returned job references its tensors, which keeps them alive until the launch."""
+    kept = getattr(x, "_xb", None)
+    if kept is not None and xf is not None and kept[0] is xf and upsample == 1 and compute == BF16 and dy.dtype == torch.bfloat16:
+        x, xf = kept[1], None        # the forward launch wrote act(norm(x)) as bf16 (conv2d(emit_xb=True)): the final operand
     for t in (x, dy):
         if not (torch.is_tensor(t) and t.is_cuda and t.is_contiguous() and t.dtype in (torch.float32, torch.bfloat16)):
             raise ValueError("expected contiguous CUDA float32 / bfloat16 tensors")

@@ -67,6 +67,9 @@ class _Conv:
         self.need_dgrad, self.precise = need_dgrad, precise
         self.pk = PackedConv(w, precise)
         self.pkT = PackedConv(w, precise, transpose_flip=True) if need_dgrad else None
+        # (the layers conv_wgrad2_kernel takes: csrc/conv_wgrad.hip v2_eligible)
+        self.emit_xb = (not precise) and upsample == 1 and self.cin >= 32 and self.cin % 32 == 0 and self.cout >= 32 and \
+            self.cout % 32 == 0 and stride in (1, 2) and self.kh * self.kw <= 64
 
     def repack(self):
         self.pk.repack(self.w)
@@ -79,6 +82,10 @@ class _Conv:
 
     def fwd(self, x, xf=None, compute=BF16, **kw):
         K.label(self.wkey)
+        # a training-mode forward (statistics wanted) in front of a weight gradient on the LDS-DMA kernel: the launch also writes
+        # its transformed operand as bf16 (kernels.conv2d(emit_xb=True)) - no hdrsky_act_bf16 launch in the backward pass
+        if xf is not None and kw.get("want_stats") and self.emit_xb and compute == BF16 and HOOKS.H.emit_xb:
+            kw.setdefault("emit_xb", True)
         return K.conv2d(x, self.pk, self.b, stride=self.stride, same=self.same, upsample=self.upsample, xf=xf,
                         compute=compute, **kw)
 

@@ -143,6 +143,13 @@ int hdrsky_conv2d_fwd(const hdrsky_conv_desc* d, const float* x, const void* w_h
                       const float* bias, const float* in_scale, const float* in_shift,
                       const float* in_part, const float* in_gamma, const float* in_beta,
                       const float* residual, float* y, float* stats_part, void* stream);
+/* The same launch, ALSO writing xb_out [B,H,W,Cin] bf16 = act(norm(x)): the transformed operand exactly as the matrix cores saw
+ * it (every input pixel written once, by the tile that owns it).  It is the x of the layer's weight gradient (a hdrsky_wgrad_job
+ * with x_bf16 and no transform: the LDS-DMA kernel), which otherwise needs hdrsky_act_bf16 to produce it from the raw tensor.
+ * hdrsky_conv2d_emit_supported: single-product mode, Cin a multiple of 32, stride 1 or 2, no resize / dilation, Cout > 1, and an
+ * operand transform to apply. */
+int hdrsky_conv2d_emit_supported(const hdrsky_conv_desc* d); /* [host] */
+int hdrsky_conv2d_fwd_emit(const hdrsky_conv_desc* d, const float* x, const void* w_hi, const void* w_lo, const float* bias, const float* in_scale, const float* in_shift, const float* in_part, const float* in_gamma, const float* in_beta, const float* residual, float* y, float* stats_part, void* xb_out, void* stream);
 
 
 /* ------------------------------------------------------------------------------------------
