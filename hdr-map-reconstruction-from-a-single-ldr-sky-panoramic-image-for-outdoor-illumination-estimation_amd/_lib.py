@@ -147,6 +147,7 @@ SIGNATURES = {
     "hdrsky_pad_channels": (c_int, [P, c_size_t, c_int, c_int, P, P]),
     "hdrsky_maxpool_fwd_bf16": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P]),
     "hdrsky_maxpool_relu_bwd_bf16": (c_int, [P, P, c_int, c_int, c_int, c_int, P, c_int, P]),
+    "hdrsky_maxpool_relu_l1_bwd_bf16": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P, P, c_int, P]),
     "hdrsky_up2x_xf_bf16": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, c_float, c_float, P, P]),
     "hdrsky_act_bwd_bf16": (c_int, [P, P, c_float, c_size_t, P, c_int, P]),
     "hdrsky_concat2": (c_int, [P, c_int, P, c_int, c_size_t, P, P]),

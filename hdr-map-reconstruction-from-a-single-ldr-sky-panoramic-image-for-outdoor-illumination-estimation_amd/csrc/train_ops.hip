@@ -271,17 +271,36 @@ __global__ void maxpool_fwd_bf16_kernel(const unsigned short* __restrict__ y, in
   }
 }
 
-template <bool OB>
-__global__ void maxpool_relu_bwd_bf16_kernel(const unsigned short* __restrict__ y, const float* __restrict__ dp, int B, int H,
-                                             int W, int C, void* __restrict__ dyv) {
+// L1: dp is not read as given - it is (dp or 0) + the gradient of the L1 term wl * mean|pool - target| of this block's pooled
+// features, whose value is accumulated into *loss (the perceptual term of train.py:308-313: three hdrsky_l1 launches per VGG16
+// backward pass folded into the pool backward that consumed their output; same values: (+-wg/n) + dp)
+template <bool OB, bool L1>
+__global__ void __launch_bounds__(256) maxpool_relu_bwd_bf16_kernel(const unsigned short* __restrict__ y, const float* __restrict__ dp, int B,
+                                                                    int H, int W, int C, void* __restrict__ dyv,
+                                                                    const float* __restrict__ pool, const float* __restrict__ target,
+                                                                    float gp, float lscale, float* loss) {
   const int c4 = C >> 2, Hp = H >> 1, Wp = W >> 1;
   const size_t total = (size_t)B * Hp * Wp * c4;
+  float acc = 0.f;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int cq = (int)(i % c4);
     const size_t pix = i / c4;
     const int pw = (int)(pix % Wp), ph = (int)((pix / Wp) % Hp), b = (int)(pix / ((size_t)Wp * Hp));
-    const float4 up = reinterpret_cast<const float4*>(dp)[i];
-    const float us[4] = {up.x, up.y, up.z, up.w};
+    float us[4];
+    if (L1) {
+      const float4 pa = reinterpret_cast<const float4*>(pool)[i], pb = reinterpret_cast<const float4*>(target)[i];
+      const float d[4] = {pa.x - pb.x, pa.y - pb.y, pa.z - pb.z, pa.w - pb.w};
+      acc += (fabsf(d[0]) + fabsf(d[1])) + (fabsf(d[2]) + fabsf(d[3]));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) us[j] = d[j] > 0.f ? gp : (d[j] < 0.f ? -gp : 0.f);
+      if (dp != nullptr) {
+        const float4 q = reinterpret_cast<const float4*>(dp)[i];
+        us[0] += q.x; us[1] += q.y; us[2] += q.z; us[3] += q.w;
+      }
+    } else {
+      const float4 up = reinterpret_cast<const float4*>(dp)[i];
+      us[0] = up.x; us[1] = up.y; us[2] = up.z; us[3] = up.w;
+    }
     float v[4][4];
     size_t idx[4];
 #pragma unroll
@@ -309,6 +328,7 @@ __global__ void maxpool_relu_bwd_bf16_kernel(const unsigned short* __restrict__ 
         reinterpret_cast<float4*>(dyv)[idx[k]] = make_float4(o[k][0], o[k][1], o[k][2], o[k][3]);
     }
   }
+  if (L1) block_atomic_add(acc, lscale, loss);
 }
 
 __global__ void act_bwd_bf16_kernel(const unsigned short* __restrict__ y, const float* __restrict__ dy, float slope, size_t n4,
@@ -1507,11 +1527,27 @@ int hdrsky_maxpool_relu_bwd_bf16(const void* y, const float* dp, int B, int H, i
                                  void* stream) {
   if (!y || !dp || !dy || (C & 3) || ((H | W) & 1)) return HDRSKY_EINVAL;
   if (dy_bf16)
-    hipLaunchKernelGGL(maxpool_relu_bwd_bf16_kernel<true>, dim3(grid_for((size_t)B * H * W * C / 16)), dim3(256), 0, S_(stream),
-                       (const unsigned short*)y, dp, B, H, W, C, dy);
+    hipLaunchKernelGGL((maxpool_relu_bwd_bf16_kernel<true, false>), dim3(grid_for((size_t)B * H * W * C / 16)), dim3(256), 0, S_(stream),
+                       (const unsigned short*)y, dp, B, H, W, C, dy, nullptr, nullptr, 0.f, 0.f, nullptr);
   else
-    hipLaunchKernelGGL(maxpool_relu_bwd_bf16_kernel<false>, dim3(grid_for((size_t)B * H * W * C / 16)), dim3(256), 0, S_(stream),
-                       (const unsigned short*)y, dp, B, H, W, C, dy);
+    hipLaunchKernelGGL((maxpool_relu_bwd_bf16_kernel<false, false>), dim3(grid_for((size_t)B * H * W * C / 16)), dim3(256), 0, S_(stream),
+                       (const unsigned short*)y, dp, B, H, W, C, dy, nullptr, nullptr, 0.f, 0.f, nullptr);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+// the same with the L1 term of the block's pooled features folded in: dp' = (dp or 0) + wg * sign(pool - target) / n,
+// *loss += wl * mean|pool - target|  (n = elements of pool)
+int hdrsky_maxpool_relu_l1_bwd_bf16(const void* y, const float* pool, const float* target, const float* dp, int B, int H, int W, int C,
+                                    float wl, float wg, float* loss, void* dy, int dy_bf16, void* stream) {
+  if (!y || !pool || !target || !dy || (C & 3) || ((H | W) & 1)) return HDRSKY_EINVAL;
+  const float inv_n = 1.f / ((float)B * (H / 2) * (W / 2) * C);
+  if (dy_bf16)
+    hipLaunchKernelGGL((maxpool_relu_bwd_bf16_kernel<true, true>), dim3(grid_for((size_t)B * H * W * C / 16)), dim3(256), 0, S_(stream),
+                       (const unsigned short*)y, dp, B, H, W, C, dy, pool, target, wg * inv_n, wl * inv_n, loss);
+  else
+    hipLaunchKernelGGL((maxpool_relu_bwd_bf16_kernel<false, true>), dim3(grid_for((size_t)B * H * W * C / 16)), dim3(256), 0, S_(stream),
+                       (const unsigned short*)y, dp, B, H, W, C, dy, pool, target, wg * inv_n, wl * inv_n, loss);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }

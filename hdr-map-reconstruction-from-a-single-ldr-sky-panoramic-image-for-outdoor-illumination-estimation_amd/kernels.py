@@ -881,6 +881,19 @@ def maxpool_relu_bwd(y, dp, out_bf16=False):
     return dy
 
 
+def maxpool_relu_l1_bwd(y, pool, target, dp, wl, wg, loss_slot, out_bf16=True):
+    """maxpool_relu_bwd(y, dp') with dp' = (dp or 0) + the gradient of wl * mean|pool - target| (weight wg), the term's value added
+    to loss_slot: the L1 launch of a VGG16 block's pooled features folded into its pool backward.  y: bfloat16 activation."""
+    B, H, W, C = y.shape
+    _bf16(y); _f32(pool, B, H // 2, W // 2, C); _f32(target, B, H // 2, W // 2, C)
+    if dp is not None:
+        _f32(dp, B, H // 2, W // 2, C)
+    dy = torch.empty((B, H, W, C), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=y.device)
+    L.check(L.load().hdrsky_maxpool_relu_l1_bwd_bf16(_p(y), _p(pool), _p(target), _p(dp), B, H, W, C, wl, wg, _p(loss_slot), _p(dy),
+                                                     int(out_bf16), _stream()), "maxpool_relu_l1_bwd_bf16")
+    return dy
+
+
 def up2x(a, b=None):
     B, H, W, C = a.shape
     _f32(a)

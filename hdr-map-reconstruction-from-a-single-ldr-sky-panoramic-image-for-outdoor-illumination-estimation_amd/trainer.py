@@ -684,7 +684,11 @@ class Trainer:
         # (fp32 there) - no separate gradient tensor + sum launch per block
         g = None
         for bi, blk in reversed(list(enumerate(self.VGG_BLOCKS))):
-            if g is None or not self._vgg_fold:
+            if self._vgg_fold and acts[blk[-1]].dtype == torch.bfloat16:
+                # bf16 chain: the block's L1 term inside its pool backward (one launch instead of hdrsky_l1 + the pool backward)
+                g = K.maxpool_relu_l1_bwd(acts[blk[-1]], pools[bi], target_pools[bi], g, share, 0.01 * share, self.losses[1:2])
+                dp = None
+            elif g is None or not self._vgg_fold:
                 dp = torch.empty_like(pools[bi])
                 K.l1(pools[bi], target_pools[bi], share, 0.01 * share, self.losses[1:2], da=dp)
                 if g is not None:
@@ -693,7 +697,8 @@ class Trainer:
                 K.l1(pools[bi], target_pools[bi], share, 0.01 * share, self.losses[1:2], da=g, accumulate=True)
                 dp = g
             b16 = acts[blk[-1]].dtype == torch.bfloat16     # bf16 chain: gradients between the data-gradient convs are final
-            g = K.maxpool_relu_bwd(acts[blk[-1]], dp, out_bf16=b16)   # wrt the pre-ReLU output of the block's last conv
+            if dp is not None:
+                g = K.maxpool_relu_bwd(acts[blk[-1]], dp, out_bf16=b16)   # wrt the pre-ReLU output of the block's last conv
             for k in range(len(blk) - 1, -1, -1):
                 name = blk[k]
                 xin = acts[name + ".in"]

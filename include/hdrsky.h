@@ -400,6 +400,10 @@ int hdrsky_pad_channels(const float* x, size_t npix, int C, int Cpad, float* out
 int hdrsky_maxpool_fwd_bf16(const void* y_bf16, int B, int H, int W, int C, float* p_f32, void* p_bf16, void* stream);
 int hdrsky_maxpool_relu_bwd_bf16(const void* y_bf16, const float* dp, int B, int H, int W, int C, void* dy, int dy_bf16,
                                  void* stream);   /* dy_bf16: dy is stored as bf16 (the operand of the next data-gradient conv) */
+/* ... with the L1 term of the block's pooled features folded in (the perceptual term, train.py:308-313: pool = pool_i(vgg(pred)),
+ * target = pool_i(vgg(hdr_t)), both fp32 [B,H/2,W/2,C]): dp' = (dp or 0, NULL allowed) + wg * sign(pool - target) / n is what gets
+ * routed, *loss += wl * mean|pool - target| - the hdrsky_l1 launch in front of every pool backward of the VGG16 pass. */
+int hdrsky_maxpool_relu_l1_bwd_bf16(const void* y_bf16, const float* pool, const float* target, const float* dp, int B, int H, int W, int C, float wl, float wg, float* loss, void* dy, int dy_bf16, void* stream);
 int hdrsky_act_bwd_bf16(const void* y_bf16, const float* dy, float slope, size_t n, void* dx, int dx_bf16, void* stream);
 /* The operand of a resize-deconvolution (ops.py:44-126 method 'resize': tf.image.resize 2x, then the conv) as a bf16
  * tensor: y [B,2H,2W,C] = bf16(resize2x(leaky(IN(x), slope))) with the InstanceNorm affine from the producing conv's
