@@ -140,6 +140,7 @@ SIGNATURES = {
     "hdrsky_kl": (c_int, [P, P, c_int, c_int, P, P, P]),
     "hdrsky_softmax_bwd": (c_int, [P, P, P, c_int, c_int, P, P]),
     "hdrsky_blend_bwd": (c_int, [P, P, P, P, c_size_t, P, P, P]),
+    "hdrsky_head_bwd": (c_int, [P] * 9 + [c_size_t, P, P, P, P]),
     "hdrsky_decoder_tail_bwd": (c_int, [P, P, P, c_size_t, P, P, P]),
     "hdrsky_sun_rad_bwd": (c_int, [P, P, P, P, P, c_int, c_int, P, P, P, P]),
     "hdrsky_dense_heads_bwd": (c_int, [P, P, P, c_float, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P]),

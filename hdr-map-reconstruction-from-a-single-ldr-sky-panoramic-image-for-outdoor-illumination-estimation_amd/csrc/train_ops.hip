@@ -997,6 +997,32 @@ __global__ void blend_bwd_kernel(const float* __restrict__ y_gamma, const float*
   }
 }
 
+// The first stretch of the generator's backward pass in one launch (train.py:258-261,293-299 backwards; three channels per pixel):
+//   t = dyg + (dyl + din[pixel][3 + c]) * d tone-map;  dsky = (1 - alpha) t, dsun = alpha t       (blend_bwd_kernel; din = the
+//   adversarial term's gradient wrt the discriminator's 6-channel input, whose channels 3..5 are the prediction: slice + sum)
+//   both decoder tails y = relu(res + lrelu(c, 0.1)) backwards                                      (decoder_tail_bwd_kernel x2)
+// - five launches (slice_channels, axpby, blend_bwd, decoder_tail_bwd x2) on the dependent chain of the step, same arithmetic.
+__global__ void __launch_bounds__(256) head_bwd_kernel(const float* __restrict__ y_gamma, const float* __restrict__ alpha,
+                                                       const float* __restrict__ dyg, const float* __restrict__ dyl,
+                                                       const float* __restrict__ din6, const float* __restrict__ y_f,
+                                                       const float* __restrict__ res_f, const float* __restrict__ y_u,
+                                                       const float* __restrict__ res_u, size_t n, float* __restrict__ dc_f,
+                                                       float* __restrict__ dc_u, float* __restrict__ dres_u) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float t = dyg ? dyg[i] : 0.f;
+    float l = dyl ? dyl[i] : 0.f;
+    if (din6) { const size_t px = i / 3; l = l + din6[px * 6 + 3 + (i - px * 3)]; }
+    if (dyl || din6) t += l * expf(y_gamma[i] * LN11) * (LN11 / 10.f);
+    const float a = alpha[i];
+    const float dsky = (1.f - a) * t, dsun = a * t;
+    const float yf = y_f[i], yu = y_u[i];
+    const float gf = yf > 0.f ? dsky : 0.f, gu = yu > 0.f ? dsun : 0.f;
+    dc_f[i] = gf * ((yf - res_f[i]) > 0.f ? 1.f : 0.1f);
+    dc_u[i] = gu * ((yu - res_u[i]) > 0.f ? 1.f : 0.1f);
+    dres_u[i] = gu;
+  }
+}
+
 // y = relu(res + lrelu(c, 0.1)):  g = dy*[y>0];  dres = g;  dc = g * (y - res > 0 ? 1 : 0.1)   (generator.py:119-124)
 __global__ void decoder_tail_bwd_kernel(const float* __restrict__ y, const float* __restrict__ res,
                                         const float* __restrict__ dy, size_t n, float* __restrict__ dc,
@@ -1707,6 +1733,16 @@ int hdrsky_blend_bwd(const float* y_gamma, const float* alpha, const float* dyg,
                      float* dsun, void* stream) {
   if (!y_gamma || !alpha || !dsky || !dsun) return HDRSKY_EINVAL;
   hipLaunchKernelGGL(blend_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, S_(stream), y_gamma, alpha, dyg, dyl, n, dsky, dsun);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_head_bwd(const float* y_gamma, const float* alpha, const float* dyg, const float* dyl, const float* din6, const float* y_f,
+                    const float* res_f, const float* y_u, const float* res_u, size_t n, float* dc_f, float* dc_u, float* dres_u,
+                    void* stream) {
+  if (!y_gamma || !alpha || !y_f || !res_f || !y_u || !res_u || !dc_f || !dc_u || !dres_u || (n % 3) != 0) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(head_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, S_(stream), y_gamma, alpha, dyg, dyl, din6, y_f, res_f, y_u,
+                     res_u, n, dc_f, dc_u, dres_u);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }

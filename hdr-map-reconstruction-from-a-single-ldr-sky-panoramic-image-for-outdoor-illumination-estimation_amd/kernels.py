@@ -1013,6 +1013,20 @@ def blend_bwd(y_gamma, alpha, dyg, dyl):
     return ds, du
 
 
+def head_bwd(y_gamma, alpha, dyg, dyl, din6, y_f, res_f, y_u, res_u):
+    """blend_bwd + both decoder_tail_bwd in one launch; din6 [B,H,W,6] (or None): the adversarial term's gradient wrt the
+    discriminator input, whose channels 3..5 are added to dyl.  Returns (dc_f, dc_u, dres_u)."""
+    shp = y_gamma.shape
+    for t in (alpha, y_f, res_f, y_u, res_u):
+        _f32(t, *shp)
+    if din6 is not None:
+        _f32(din6, *(tuple(shp[:-1]) + (6,)))
+    dc_f, dc_u, dres_u = torch.empty_like(y_gamma), torch.empty_like(y_gamma), torch.empty_like(y_gamma)
+    L.check(L.load().hdrsky_head_bwd(_p(_f32(y_gamma)), _p(alpha), _p(dyg), _p(dyl), _p(din6), _p(y_f), _p(res_f), _p(y_u), _p(res_u),
+                                     y_gamma.numel(), _p(dc_f), _p(dc_u), _p(dres_u), _stream()), "head_bwd")
+    return dc_f, dc_u, dres_u
+
+
 def decoder_tail_bwd(y, res, dy, want_dres):
     dc = torch.empty_like(y)
     dres = torch.empty_like(y) if want_dres else None

@@ -948,18 +948,15 @@ class Trainer:
             dlog = K.mse(logits, 1.0, 1.0, 1.0, self.losses[4:5])
             dact4 = cvo.dgrad(Rg["d4"]["raw"], dlog, cp)
             din = self._down_stack_bwd("dis.", self.ds.w, None, Rg, dact4, training=False, want_input_grad=True, do_wgrad=False)
-            T["d_adv"] = K.slice_channels(din, 3, 3, 1.0)
+            T["din_adv"] = din        # (channels 3..5 = d / d prediction: picked up by the head's backward launch)
 
         # ------------------------------------------------------------------ backward, first stretch
         @seg("bwd_head", 0, ["loss_vgg", "loss_vgg_b"])
         def _():       # blend -> decoder tails -> sun radiance head -> dcmf complete -> sun-pose Dense layers
             t, dyl = T["t"], T["dyl"]
-            K.axpby(dyl, 1.0, T["d_adv"], 1.0, out=dyl)
-            dsky, dsun = K.blend_bwd(T["y_gamma"], T["alpha"], T["dyg"], dyl)
-            tails = T["tails"] = {}
-            for sfx, dy in (("f", dsky), ("u", dsun)):
-                y, residual = T["dec_" + sfx][6], T["dec_" + sfx][7]
-                tails[sfx] = K.decoder_tail_bwd(y, residual, dy, want_dres=(sfx == "u"))
+            (yf, rf), (yu, ru) = (T["dec_f"][6], T["dec_f"][7]), (T["dec_u"][6], T["dec_u"][7])
+            dc_f, dc_u, dres_u = K.head_bwd(T["y_gamma"], T["alpha"], T["dyg"], dyl, T["din_adv"], yf, rf, yu, ru)
+            tails = T["tails"] = {"f": (dc_f, None), "u": (dc_u, dres_u)}
             T["dpre"] = K.sun_rad_bwd(t["cmf"], t["gmax"], T["gamma"], T["beta"], tails["u"][1], T["dcmf"], sync=self.sync)
 
         # The sun-pose net's soft-max and Dense layers backwards (cmf is an input of a sunpose='external' step: no consumer).

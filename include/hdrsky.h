@@ -372,6 +372,10 @@ int hdrsky_kl(const float* gt, const float* cmf, int B, int N, float* loss, floa
 int hdrsky_softmax_bwd(const float* cmf, const float* dcmf, const float* z, int M, int N, float* dz, void* stream);
 /* Backward of hdrsky_blend (alpha is a constant, train.py:257): dyg / dyl nullable. */
 int hdrsky_blend_bwd(const float* y_gamma, const float* alpha, const float* dyg, const float* dyl, size_t n, float* dsky, float* dsun, void* stream);
+/* hdrsky_blend_bwd + both hdrsky_decoder_tail_bwd in one launch, with the adversarial term's gradient (channels 3..5 of the
+ * discriminator's 6-channel input gradient din6 [pixels][6], NULL allowed) added to dyl on the way: the first stretch of the
+ * generator's backward pass (three-channel tensors of n elements; dres_u = the gradient wrt the sun decoder's residual input). */
+int hdrsky_head_bwd(const float* y_gamma, const float* alpha, const float* dyg, const float* dyl, const float* din6, const float* y_f, const float* res_f, const float* y_u, const float* res_u, size_t n, float* dc_f, float* dc_u, float* dres_u, void* stream);
 /* Backward of y = relu(res + lrelu(c,0.1)) (generator.py:119-124,151-155): dc and (nullable) dres. */
 int hdrsky_decoder_tail_bwd(const float* y, const float* res, const float* dy, size_t n, float* dc, float* dres, void* stream);
 /* Backward of hdrsky_sun_rad: dpre[B][2] (pre-sigmoid gamma/beta), dcmf += (incl. the batch reduce_max term,
