@@ -44,7 +44,8 @@ __device__ __forceinline__ f32x16_t mfma32(const uint4& a, const uint4& b, f32x1
 // src [M][ld] fp32 -> bf16 fragment image dst[C/32][Mpad/8][32 columns] of 16-byte groups (8 consecutive rows of one
 // column; rows >= M zero): a wave's MFMA operand load is then two contiguous 512-byte runs.  blockIdx.z picks the matrix
 // (0: x, 1: dy); thread = (column, group of 8 rows); colsum (dy only): fp32 sums over the M rows, in row order
-struct OperandJob { const float* src; int ld, C; uint4* dst; float* colsum; int accumulate; };
+struct OperandJob { const float* src; int ld, C; uint4* dst; float* colsum; int accumulate;
+                    float* bw; float* bms; float lr, rho, eps, gscale; };   // bw != null: RMSprop of the bias vector with the column sums, here
 __global__ void __launch_bounds__(256) fc_operands_kernel(OperandJob jx, OperandJob jd, int M, int Mpad) {
   const OperandJob j = blockIdx.z ? jd : jx;
   const int c = blockIdx.x * 256 + threadIdx.x, mg = blockIdx.y;
@@ -68,6 +69,12 @@ __global__ void __launch_bounds__(256) fc_operands_kernel(OperandJob jx, Operand
       for (int k = 0; k < 8; ++k) if (m0 + k < M) s += r8[k];
     }
     j.colsum[c] = j.accumulate ? j.colsum[c] + s : s;
+    if (j.bw != nullptr) {      // the Dense bias: its gradient is this column sum - updated here instead of by a launch of its own
+      const float g = s * j.gscale;
+      const float m_ = j.rho * j.bms[c] + (1.f - j.rho) * g * g;
+      j.bms[c] = m_;
+      j.bw[c] -= j.lr * g / (sqrtf(m_) + j.eps);
+    }
   }
 }
 
@@ -192,11 +199,12 @@ inline void launch_xtdy(hipStream_t st, const uint4* xT, const uint4* dT, int Mp
 
 // launch 1 of both entry points; returns the transposed operand images inside ws
 inline int operands(const float* x, int ldx, const float* dy, int ldy, int M, int K, int N, float* db, int accumulate,
-                    void* ws, hipStream_t st, const uint4** xT, const uint4** dT) {
+                    void* ws, hipStream_t st, const uint4** xT, const uint4** dT, float* bw = nullptr, float* bms = nullptr,
+                    float lr = 0.f, float rho = 0.f, float eps = 0.f, float gscale = 1.f) {
   const int Mp = mpad(M);
   uint4* px = (uint4*)ws;
   uint4* pd = px + (size_t)K * (Mp >> 3);
-  OperandJob jx{x, ldx, K, px, nullptr, 0}, jd{dy, ldy, N, pd, db, accumulate};
+  OperandJob jx{x, ldx, K, px, nullptr, 0, nullptr, nullptr, 0.f, 0.f, 0.f, 1.f}, jd{dy, ldy, N, pd, db, accumulate, bw, bms, lr, rho, eps, gscale};
   hipLaunchKernelGGL(fc_operands_kernel, dim3(cdiv(K > N ? K : N, 256), Mp >> 3, 2), dim3(256), 0, st, jx, jd, M, Mp);
   HDRSKY_CHECK_LAUNCH();
   *xT = px; *dT = pd;
@@ -223,12 +231,26 @@ int hdrsky_fc_wgrad_bf16(const float* x, int ldx, const float* dy, int ldy, int 
   return HDRSKY_OK;
 }
 
+int hdrsky_rmsprop_fc_fused_bias(float* w, float* ms, const float* x, int ldx, const float* dy, int ldy, int M, int K, int N,
+                                 float lr, float rho, float eps, float gscale, void* packed_hi, void* natural_hi, float* db,
+                                 float* bias, float* bias_ms, void* ws, void* stream);
+
 int hdrsky_rmsprop_fc_fused(float* w, float* ms, const float* x, int ldx, const float* dy, int ldy, int M, int K, int N,
                             float lr, float rho, float eps, float gscale, void* packed_hi, void* natural_hi, float* db,
                             void* ws, void* stream) {
+  return hdrsky_rmsprop_fc_fused_bias(w, ms, x, ldx, dy, ldy, M, K, N, lr, rho, eps, gscale, packed_hi, natural_hi, db, nullptr, nullptr,
+                                      ws, stream);
+}
+
+// ... with the layer's bias vector updated too (bias [N], bias_ms [N]; db [N] must be given: the column sums of dy are its gradient),
+// by the operand launch that forms those sums - not by an hdrsky_rmsprop launch behind the update
+int hdrsky_rmsprop_fc_fused_bias(float* w, float* ms, const float* x, int ldx, const float* dy, int ldy, int M, int K, int N,
+                                 float lr, float rho, float eps, float gscale, void* packed_hi, void* natural_hi, float* db,
+                                 float* bias, float* bias_ms, void* ws, void* stream) {
   if (!w || !ms || !x || !dy || !packed_hi || !ws || !shapes_ok(x, ldx, dy, ldy, M, K, N)) return HDRSKY_EINVAL;
+  if ((bias != nullptr) != (bias_ms != nullptr) || (bias && !db)) return HDRSKY_EINVAL;
   const uint4 *xT, *dT;
-  const int rc = operands(x, ldx, dy, ldy, M, K, N, db, 0, ws, (hipStream_t)stream, &xT, &dT);
+  const int rc = operands(x, ldx, dy, ldy, M, K, N, db, 0, ws, (hipStream_t)stream, &xT, &dT, bias, bias_ms, lr, rho, eps, gscale);
   if (rc != HDRSKY_OK) return rc;
   launch_xtdy<true>((hipStream_t)stream, xT, dT, mpad(M), K, N, w, ms, lr, rho, eps, gscale, packed_hi, natural_hi, 0);
   HDRSKY_CHECK_LAUNCH();

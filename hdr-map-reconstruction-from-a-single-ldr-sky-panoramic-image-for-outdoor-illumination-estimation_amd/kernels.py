@@ -1169,15 +1169,22 @@ def fc_wgrad_bf16(x, dy, dw, db, accumulate=False):
             "fc_wgrad_bf16")
 
 
-def rmsprop_fc_fused(w, ms, x, dy, pf, lr, db=None, rho=0.9, eps=1e-7, gscale=1.0):
+def rmsprop_fc_fused(w, ms, x, dy, pf, lr, db=None, rho=0.9, eps=1e-7, gscale=1.0, bias=None, bias_ms=None):
     """RMSprop of a Dense kernel with its gradient gscale * x^T dy recomputed inside the update (never materialised);
-    refreshes the bf16 images of `pf`; db (optional) receives the bias gradient."""
+    refreshes the bf16 images of `pf`; db (optional) receives the bias gradient; bias / bias_ms [N] (with db): the bias vector
+    gets its RMSprop step inside the same call."""
     (M, Kd), N = x.shape, dy.shape[1]
     _f32(w, Kd, N); _f32(ms, Kd, N)
     if pf.pk_lo is not None or (pf.K, pf.N) != (Kd, N) or dy.shape[0] != M:
         raise ValueError("rmsprop_fc_fused: BF16 images of the same kernel and matching operand rows only")
     px, ldx = _rows2d(x, "rmsprop_fc_fused x"); pd, ldy = _rows2d(dy, "rmsprop_fc_fused dy")
     ws = _xtdy_ws(M, Kd, N, x.device)
+    if bias is not None:
+        _f32(bias, N); _f32(bias_ms, N); _f32(db, N)
+        L.check(L.load().hdrsky_rmsprop_fc_fused_bias(_p(w), _p(ms), px, ldx, pd, ldy, M, Kd, N, lr, rho, eps, gscale, _p(pf.pk_hi),
+                                                      _p(pf.nat_hi), _p(db), _p(bias), _p(bias_ms), _p(ws), _stream()),
+                "rmsprop_fc_fused_bias")
+        return
     L.check(L.load().hdrsky_rmsprop_fc_fused(_p(w), _p(ms), px, ldx, pd, ldy, M, Kd, N, lr, rho, eps, gscale, _p(pf.pk_hi),
                                              _p(pf.nat_hi), _p(db), _p(ws), _stream()), "rmsprop_fc_fused")
 

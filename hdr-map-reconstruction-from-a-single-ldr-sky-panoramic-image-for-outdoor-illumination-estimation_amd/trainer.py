@@ -1196,10 +1196,10 @@ class Trainer:
                 flat, df1, f1, dz = self.dense_operands or (T["t"]["flat"], T["df1"], T["t"]["f1"], T["dz"])
                 for name, pf, x_, dy_ in (("sun.fc2", self.fc2, f1, dz), ("sun.fc1", self.fc1, flat, df1)):
                     o, n, shape = self.gs.offsets[name + ".kernel"]
+                    ob, nb_, _ = self.gs.offsets[name + ".bias"]      # (the bias vector's step rides in the operand launch)
                     K.rmsprop_fc_fused(w[name + ".kernel"], self.gs.ms[o:o + n].view(shape), x_, dy_, pf, self.lr,
-                                       db=g[name + ".bias"], gscale=self._gscale)
-                    o, n, _ = self.gs.offsets[name + ".bias"]
-                    K.rmsprop(self.gs.flat[o:o + n], self.gs.grad[o:o + n], self.gs.ms[o:o + n], self.lr, gscale=self._gscale)
+                                       db=g[name + ".bias"], gscale=self._gscale,
+                                       bias=self.gs.flat[ob:ob + nb_], bias_ms=self.gs.ms[ob:ob + nb_])
                 return
             if self.precise:      # BF16X3 keeps residual planes: plain update, then re-pack
                 K.rmsprop(self.gs.flat[fc0:fc1], self.gs.grad[fc0:fc1], self.gs.ms[fc0:fc1], self.lr, gscale=self._gscale)

@@ -461,6 +461,9 @@ size_t hdrsky_fc_xtdy_ws_bytes(int M, int K, int N);
 int hdrsky_rmsprop_fc_fused(float* w, float* ms, const float* x, int ldx, const float* dy, int ldy, int M, int K, int N,
                             float lr, float rho, float eps, float gscale, void* packed_hi, void* natural_hi, float* db,
                             void* ws, void* stream);
+/* ... that also applies the RMSprop step to the layer's bias vector (bias, bias_ms [N]; db [N] - the column sums of dy - must be
+ * given), inside the launch that forms those sums. */
+int hdrsky_rmsprop_fc_fused_bias(float* w, float* ms, const float* x, int ldx, const float* dy, int ldy, int M, int K, int N, float lr, float rho, float eps, float gscale, void* packed_hi, void* natural_hi, float* db, float* bias, float* bias_ms, void* ws, void* stream);
 /* tf.keras.optimizers.Adam (train_sun.py:191 / tf_utils.py:324; defaults beta 0.9 / 0.999, eps 1e-7) over a flat buffer:
  * m, v are the slots; lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t) is computed by the caller for step t; g is scaled by gscale. */
 int hdrsky_adam(float* w, const float* g, float* m, float* v, size_t n, float lr_t, float beta1, float beta2, float eps,
