@@ -419,12 +419,12 @@ int hdrsky_up2x_xf_bf16(const float* x, int x_bf16, int B, int H, int W, int C, 
  * operand transform of hdrsky_conv_desc (in_mode / in_slope / tables: InstanceNorm + tf.nn.leaky_relu, generator.py:15-19,
  * 61-85, sunpose_net.py:12-18; BatchNormalization + LeakyReLU, discriminator.py:16-17) - the arithmetic of the conv /
  * weight-gradient staging.  Operand of the LDS-DMA weight-gradient path (hdrsky_wgrad_job.x_bf16).  C % 8 == 0, C <= 1024. */
-/* debug only: 8 x u64 of s_memtime phase stamps per workgroup of subsequent conv_wgrad2_kernel launches (null disables):
- * [start, ring primed, main loop done, cycles waiting for copies, issuing copies, computing, tiles, end] */
-void hdrsky_debug_wgrad2_stamps(void* buf);
 int hdrsky_act_bf16(const float* x, int x_bf16, int B, int HW, int C, int in_mode, const float* in_scale, const float* in_shift, int ss_bstride,
                     const float* in_part, int in_nparts, const float* gamma, const float* beta, float eps, float slope,
                     void* y_bf16, void* stream);
+/* debug only: 8 x u64 of s_memtime phase stamps per workgroup of subsequent conv_wgrad2_kernel launches (null disables):
+ * [start, ring primed, main loop done, cycles waiting for copies, issuing copies, computing, tiles, end] */
+void hdrsky_debug_wgrad2_stamps(void* buf);
 /* tf.concat([a, b], axis=-1) (discriminator.py:43). */
 int hdrsky_concat2(const float* a, int Ca, const float* b, int Cb, size_t npix, float* out, void* stream);
 /* Row-wise concatenation of four [M, w_i] fp32 matrices into out [M, w0+w1+w2+w3] (w_i % 4 == 0, 16-byte aligned
