@@ -1176,6 +1176,7 @@ int hdrsky_conv2d_emit_supported(const hdrsky_conv_desc* d) {
   if (!d || d->compute != HDRSKY_BF16 || d->Cin <= 8 || (d->Cin % 32) != 0) return 0;
   if (d->upsample != 1 || d->dilate != 1 || (d->stride != 1 && d->stride != 2) || d->Cout == 1) return 0;
   if (d->in_mode == HDRSKY_IN_NONE && d->in_slope == 1.f) return 0;
+  if (d->Ho * d->stride < d->H || d->Wo * d->stride < d->W) return 0;     // (VALID geometry: the output blocks' input pixels do not cover the image)
   return 1;
 }
 

@@ -165,3 +165,54 @@ def test_one_channel_output_conv_reads_bf16(dev):
     y16, _ = K.conv2d(x16, pw, b, same=False, xf=xf, compute=K.BF16)
     y32, _ = K.conv2d(x32, pw, b, same=False, xf=xf, compute=K.BF16)
     assert torch.equal(y16, y32)
+
+
+@pytest.mark.parametrize("shape,k,stride,cout", [((3, 16, 64, 64), 3, 2, 128), ((2, 32, 128, 32), 3, 2, 64), ((2, 8, 32, 128), 4, 2, 256),
+                                                 ((2, 32, 128, 32), 7, 1, 32), ((2, 9, 21, 64), 3, 1, 64), ((3, 9, 37, 32), 3, 2, 64),
+                                                 ((2, 4, 16, 256), 4, 1, 512)])
+@pytest.mark.parametrize("mode", ["partials", "affine"])
+def test_forward_conv_writes_the_operand_of_its_weight_gradient(dev, shape, k, stride, cout, mode):
+    """hdrsky_conv2d_fwd_emit (conv_igemm_kernel<..., EMIT>): the launch's result and statistics are those of hdrsky_conv2d_fwd, and
+    the bf16 tensor it writes beside them - act(norm(x)), every input pixel by the tile that owns it - equals hdrsky_act_bf16's
+    bit for bit (incl. stride 2, odd sizes, several channel groups); the weight gradient taken on it is the one taken through the
+    materialising launch."""
+    K, L = pkg("kernels"), pkg("_lib")
+    B, H, W, C = shape
+    g = _g(dev, 21)
+    x = (torch.randn(*shape, device=dev, generator=g) * 1.5 + 0.3).contiguous()
+    w = torch.randn(k, k, C, cout, device=dev, generator=g) / (k * C ** 0.5)
+    b = torch.randn(cout, device=dev, generator=g)
+    gamma, beta = torch.rand(C, device=dev, generator=g) + 0.5, torch.randn(C, device=dev, generator=g) * 0.2
+    if mode == "partials":
+        xf = K.InXf(mode=L.IN_PARTIALS, slope=0.1, stats=_stats_of(K, x), gamma=gamma, beta=beta, eps=K.IN_EPS)
+    else:
+        xf = K.InXf(mode=L.IN_AFFINE, slope=0.3, scale=torch.rand(B, C, device=dev, generator=g) + 0.5,
+                    shift=torch.randn(B, C, device=dev, generator=g) * 0.3)
+    pw = K.PackedConv(w, precise=False)
+    y0, s0 = K.conv2d(x, pw, b, stride=stride, xf=xf, compute=K.BF16, want_stats=True)
+    assert not hasattr(x, "_xb")
+    y1, s1 = K.conv2d(x, pw, b, stride=stride, xf=xf, compute=K.BF16, want_stats=True, emit_xb=True)
+    assert torch.equal(y0, y1) and torch.equal(s0.part, s1.part)
+    kept = getattr(x, "_xb", None)
+    assert kept is not None and kept[0] is xf and kept[1].dtype == torch.bfloat16 and kept[1].shape == x.shape
+    # the materialising launch on the same tensor and transform
+    d = K.conv_desc(B, H, W, C, cout, k, k, stride, True, 1)
+    d.compute = K.BF16
+    tabs = K._xf_args(d, xf, B, H, W, C)
+    ref = torch.empty_like(kept[1])
+    L.check(L.load().hdrsky_act_bf16(K._p(x), 0, B, H * W, C, d.in_mode, K._p(tabs[0]), K._p(tabs[1]), d.ss_bstride, K._p(tabs[2]),
+                                     d.in_nparts, K._p(tabs[3]), K._p(tabs[4]), d.in_eps, d.in_slope, K._p(ref), K._stream()), "act_bf16")
+    assert torch.equal(kept[1], ref), int((kept[1] != ref).sum())
+    # and the weight gradient: through the kept operand (wgrad_job finds it) == through the materialising path
+    dy = (torch.randn(*y0.shape, device=dev, generator=g) * 0.1).to(torch.bfloat16)
+    outs = []
+    for use_kept in (True, False):
+        if not use_kept:
+            del x._xb
+        dw, db = torch.zeros(k, k, C, cout, device=dev), torch.zeros(cout, device=dev)
+        K.conv2d_wgrad_multi([K.wgrad_job(x, dy, k, k, dw, db, stride=stride, xf=xf, compute=K.BF16)])
+        outs.append((dw, db))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # a VALID-geometry layer is not taken (its output blocks do not cover the image)
+    dv = K.conv_desc(B, H, W, C, cout, k, k, 1, False, 1); dv.compute = K.BF16; dv.in_mode, dv.in_slope = d.in_mode, d.in_slope
+    assert not L.load().hdrsky_conv2d_emit_supported(dv) and L.load().hdrsky_conv2d_emit_supported(d)
