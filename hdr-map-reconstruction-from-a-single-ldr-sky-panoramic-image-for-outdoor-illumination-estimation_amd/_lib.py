@@ -160,6 +160,7 @@ SIGNATURES = {
     "hdrsky_axpby": (c_int, [P, c_float, P, c_float, c_size_t, P, P]),
     "hdrsky_fc_wgrad": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, P]),
     "hdrsky_rmsprop": (c_int, [P, P, P, c_size_t, c_float, c_float, c_float, c_float, P]),
+    "hdrsky_rmsprop2": (c_int, [P, P, P, c_size_t, P, P, P, c_size_t, c_float, c_float, c_float, c_float, P]),
     "hdrsky_rmsprop_fc": (c_int, [P, P, P, c_int, c_int, c_float, c_float, c_float, c_float, P, P, P]),
     "hdrsky_fc_wgrad_bf16": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P]),
     "hdrsky_fc_xtdy_ws_bytes": (c_size_t, [c_int, c_int, c_int]),

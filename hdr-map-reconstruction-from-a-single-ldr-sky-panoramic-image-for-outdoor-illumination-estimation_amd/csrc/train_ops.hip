@@ -1405,6 +1405,31 @@ __global__ void __launch_bounds__(256) rmsprop_kernel(float* __restrict__ w, con
   }
 }
 
+// the same over TWO flat buffers in one launch (the generator / sun-pose conv parameters and the discriminator's: two launches at
+// the very end of the step, where nothing else is left to overlap their latency): blocks [0, nb1) walk buffer 1, the rest buffer 2
+__global__ void __launch_bounds__(256) rmsprop2_kernel(float* __restrict__ w1, const float* __restrict__ g1, float* __restrict__ ms1,
+                                                       size_t n41, int nb1, float* __restrict__ w2, const float* __restrict__ g2,
+                                                       float* __restrict__ ms2, size_t n42, float lr, float rho, float eps, float gscale) {
+  const bool second = (int)blockIdx.x >= nb1;
+  float* w = second ? w2 : w1; const float* g = second ? g2 : g1; float* ms = second ? ms2 : ms1;
+  const size_t n4 = second ? n42 : n41;
+  const size_t nblk = second ? gridDim.x - nb1 : nb1, blk = second ? blockIdx.x - nb1 : blockIdx.x;
+  for (size_t i = blk * (size_t)blockDim.x + threadIdx.x; i < n4; i += nblk * blockDim.x) {
+    float4 wv = reinterpret_cast<float4*>(w)[i];
+    const float4 gv = reinterpret_cast<const float4*>(g)[i];
+    float4 mv = reinterpret_cast<float4*>(ms)[i];
+    const float gs[4] = {gv.x * gscale, gv.y * gscale, gv.z * gscale, gv.w * gscale};
+    float ws[4] = {wv.x, wv.y, wv.z, wv.w}, m[4] = {mv.x, mv.y, mv.z, mv.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      m[j] = rho * m[j] + (1.f - rho) * gs[j] * gs[j];
+      ws[j] -= lr * gs[j] / (sqrtf(m[j]) + eps);
+    }
+    reinterpret_cast<float4*>(w)[i] = make_float4(ws[0], ws[1], ws[2], ws[3]);
+    reinterpret_cast<float4*>(ms)[i] = make_float4(m[0], m[1], m[2], m[3]);
+  }
+}
+
 // RMSprop of a Dense kernel [K][N] fused with the refresh of its two bf16 MFMA images (packed [K/8][N][8] for the
 // forward, natural [K][N] for the data gradient): the weights are read and written once instead of three times.
 // Thread = (8 consecutive k, one n): every access is coalesced across n and the packed row is one 16-byte store.
@@ -1922,6 +1947,16 @@ int hdrsky_rmsprop(float* w, const float* g, float* ms, size_t n, float lr, floa
                    void* stream) {
   if (!w || !g || !ms || (n & 3)) return HDRSKY_EINVAL;
   hipLaunchKernelGGL(rmsprop_kernel, dim3(grid_for(n / 4, 1024)), dim3(256), 0, S_(stream), w, g, ms, n / 4, lr, rho, eps, gscale);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+int hdrsky_rmsprop2(float* w1, const float* g1, float* ms1, size_t n1, float* w2, const float* g2, float* ms2, size_t n2, float lr,
+                    float rho, float eps, float gscale, void* stream) {
+  if (!w1 || !g1 || !ms1 || !w2 || !g2 || !ms2 || (n1 & 3) || (n2 & 3) || n1 == 0 || n2 == 0) return HDRSKY_EINVAL;
+  const int nb1 = grid_for(n1 / 4, 1024), nb2 = grid_for(n2 / 4, 1024);
+  hipLaunchKernelGGL(rmsprop2_kernel, dim3(nb1 + nb2), dim3(256), 0, S_(stream), w1, g1, ms1, n1 / 4, nb1, w2, g2, ms2, n2 / 4, lr, rho,
+                     eps, gscale);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }

@@ -1195,6 +1195,13 @@ def rmsprop(w, g, ms, lr, rho=0.9, eps=1e-7, gscale=1.0):
     L.check(L.load().hdrsky_rmsprop(_p(w), _p(g), _p(ms), n, lr, rho, eps, gscale, _stream()), "rmsprop")
 
 
+def rmsprop2(w1, g1, ms1, w2, g2, ms2, lr, rho=0.9, eps=1e-7, gscale=1.0):
+    """rmsprop over two flat buffers (two optimizers with the same hyper-parameters) in one launch."""
+    n1, n2 = w1.numel(), w2.numel()
+    _f32(w1); _f32(g1, n1); _f32(ms1, n1); _f32(w2); _f32(g2, n2); _f32(ms2, n2)
+    L.check(L.load().hdrsky_rmsprop2(_p(w1), _p(g1), _p(ms1), n1, _p(w2), _p(g2), _p(ms2), n2, lr, rho, eps, gscale, _stream()), "rmsprop2")
+
+
 def rmsprop_fc(w, g, ms, pf, lr, rho=0.9, eps=1e-7, gscale=1.0):
     """RMSprop step of a Dense kernel w [K,N] (views of the flat buffers) fused with the refresh of its PackedFC images."""
     Kd, N = w.shape

@@ -1221,8 +1221,12 @@ class Trainer:
         @seg("apply", 0, ["apply_fc"] if HOOKS.H.apply_after_fc else [])
         def _():
             gscale, fc0 = self._gscale, self.fc_grad_range()[0]
-            K.rmsprop(self.gs.flat[:fc0], self.gs.grad[:fc0], self.gs.ms[:fc0], self.lr, gscale=gscale)
-            K.rmsprop(self.ds.flat[:self.ds.ntrain], self.ds.grad, self.ds.ms, self.lr, gscale=gscale)
+            if fc0 % 4 == 0 and self.ds.ntrain % 4 == 0:      # both optimizers' conv-side parameters: one launch
+                K.rmsprop2(self.gs.flat[:fc0], self.gs.grad[:fc0], self.gs.ms[:fc0],
+                           self.ds.flat[:self.ds.ntrain], self.ds.grad, self.ds.ms, self.lr, gscale=gscale)
+            else:
+                K.rmsprop(self.gs.flat[:fc0], self.gs.grad[:fc0], self.gs.ms[:fc0], self.lr, gscale=gscale)
+                K.rmsprop(self.ds.flat[:self.ds.ntrain], self.ds.grad, self.ds.ms, self.lr, gscale=gscale)
             self.repack(fc=False)
 
         # HDRSKY_PLAN_MOVE="name=stream@after,...": scheduling experiments - segment `name` goes to `stream`, enqueued right

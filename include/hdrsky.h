@@ -443,6 +443,8 @@ int hdrsky_axpby(const float* a, float sa, const float* b, float sb, size_t n, f
 int hdrsky_fc_wgrad(const float* x, const float* dy, int M, int K, int N, int accumulate, float* dw, float* db, void* stream);
 /* Keras-2 OptimizerV2 RMSprop step over one flat buffer (train.py:201-202,403,406): g is first multiplied by gscale. */
 int hdrsky_rmsprop(float* w, const float* g, float* ms, size_t n, float lr, float rho, float eps, float gscale, void* stream);
+/* the same step over two flat buffers (two optimizers' parameters) in one launch */
+int hdrsky_rmsprop2(float* w1, const float* g1, float* ms1, size_t n1, float* w2, const float* g2, float* ms2, size_t n2, float lr, float rho, float eps, float gscale, void* stream);
 /* The same update for a Dense kernel w[K][N], fused with the refresh of its bf16 images (hdrsky_fc_pack_weights layouts:
  * packed_hi [K/8][N][8], natural_hi [K][N] or NULL) - HDRSKY_BF16 mode only (no residual planes). */
 int hdrsky_rmsprop_fc(float* w, const float* g, float* ms, int K, int N, float lr, float rho, float eps, float gscale,
