@@ -1502,16 +1502,19 @@ def gemm1x1(G, pw1: PackedConv, bias=None, want_stats=False, out_bf16=False):
     return y, st
 
 
-def da_conv2d(x, pw: PackedConv, bias, offs, compute=BF16, want_stats=False, train=False):
+def da_conv2d(x, pw: PackedConv, bias, offs, compute=BF16, want_stats=False, train=False, reuse_operand=False):
     """distortion_aware_ops.conv2d.call: offs = device tensor [H, k*k, 2] from da_offsets(H, W, k, ...).
     want_stats: also return the InstanceNorm partials of y (Stats, as conv2d does) -> (y, Stats).
     train: the layer's kernel gradient will follow (it reads the gathered operand again; kept for callers - the written
-    operand is the faster forward from 1024 pixels per sample with or without it: da_mat_ok)."""
+    operand is the faster forward from 1024 pixels per sample with or without it: da_mat_ok).  The operand is kept on the
+    tensor object x for that kernel gradient (da_wgrad_job), which therefore must be queued before x is rewritten."""
     B, H, W, C = x.shape
     if C != pw.Cin or pw.KH != pw.KW:
         raise ValueError("filter / input mismatch")
     if da_mat_ok(compute, pw.KH, C, H * W, "fwd"):
-        kept = getattr(x, "_da_G", None)            # (two layers on one input - the decoders' first deconvolutions - share it)
+        # reuse_operand: a second layer on the SAME, unchanged input (the decoders' first deconvolutions) takes the operand the first
+        # one wrote - the caller's promise: nothing here can tell whether x was rewritten in between
+        kept = getattr(x, "_da_G", None) if reuse_operand else None
         G = kept[2] if kept is not None and kept[:2] == (offs.data_ptr(), pw.KH) else da_gather_bf16(x, offs, ksize=pw.KH)
         x._da_G = (offs.data_ptr(), pw.KH, G)      # the weight gradient of the layer reads it again (da_wgrad_job)
         y, st = gemm1x1(G, pw.as_1x1(), bias, want_stats=want_stats)

@@ -751,7 +751,8 @@ class Trainer:
                     u3 = T["u3_da"]
                 else:
                     u3 = K.up2x(res_out)
-                d3, s3 = K.da_conv2d(u3, c3.pk, c3.b, self._da(u3.shape[1], u3.shape[2])[0], cp, want_stats=True, train=True)
+                d3, s3 = K.da_conv2d(u3, c3.pk, c3.b, self._da(u3.shape[1], u3.shape[2])[0], cp, want_stats=True, train=True,
+                                     reuse_operand=(sfx == "u"))
                 if K.da_mat_ok(cp, 3, c2.cin, 4 * px3, "fwd"):
                     u2 = K.up2x_act_bf16(d3, self._inxf(s3, "gen.norm3_" + sfx, 0.1, partials=True))
                 else:
