@@ -135,9 +135,15 @@ def gemm1x1_roofline(torch, K, batch=8, h=32, w=128, C=128, F=128, iters=100):
     us = _graph_time(torch, lambda: K.gemm1x1(G, pw, bias, want_stats=True), iters)
     flop = 2.0 * batch * h * w * 9 * C * F
     achieved = flop / (us * 1e-6) / 1e12
+    traffic, source = None, None          # HBM-side bytes per launch: a RECORDED PMC measurement of this shape (profiles/pmc_gemm1x1.py)
+    pmc = os.path.join(ROOT, "profiles", "r04_pmc_gemm1x1.json")
+    if (batch, h, w, C, F) == (8, 32, 128, 128, 128) and os.path.exists(pmc):
+        with open(pmc) as f:
+            rec = json.load(f)
+        traffic, source = rec.get("hbm_bytes_per_launch"), "profiles/r04_pmc_gemm1x1.json @ %s" % rec.get("commit", "?")
     return {"bound": "mfma", "kernel": "gemm1x1_kernel<4> (distortion-aware 3x3 %d->%d layer on its written gathered operand, %dx%d maps, B=%d)" % (C, F, h, w, batch),
             "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 5),
-            "traffic": None, "avg_launch_us": round(us, 3), "flop_per_launch": flop,
+            "traffic": traffic, "traffic_source": source, "avg_launch_us": round(us, 3), "flop_per_launch": flop,
             "algorithmic_bytes": batch * h * w * (9 * C * 2 + F * 4) + 9 * C * F * 2}
 
 
