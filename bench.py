@@ -144,6 +144,8 @@ def gemm1x1_roofline(torch, K, batch=8, h=32, w=128, C=128, F=128, iters=100):
     return {"bound": "mfma", "kernel": "gemm1x1_kernel<4> (distortion-aware 3x3 %d->%d layer on its written gathered operand, %dx%d maps, B=%d)" % (C, F, h, w, batch),
             "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 5),
             "traffic": traffic, "traffic_source": source, "avg_launch_us": round(us, 3), "flop_per_launch": flop,
+            # the operand G is read once from HBM: against that stream the launch is much closer to its roof than against the matrix cores
+            "hbm_achieved_gbs": round((batch * h * w * (9 * C * 2 + F * 4) + 9 * C * F * 2) / (us * 1e-6) / 1e9, 1), "hbm_peak_gbs": HBM_PEAK_GBS,
             "algorithmic_bytes": batch * h * w * (9 * C * 2 + F * 4) + 9 * C * F * 2}
 
 
