@@ -68,10 +68,17 @@ def parse():
                          "default of a bare --da), sunpose (sunpose_net.py:11,16), decoders (distortion_aware_ops.deconv2d in "
                          "both decoders), or all")
     ap.add_argument("--dp-mode", default=None, help="gradient exchange of the N > 1 training step (parallel.py: MODES)")
+    ap.add_argument("--steps-only", action="store_true",
+                    help="only the timed loop of the chosen workload: no roofline / roofline_top / roofline_hbm / fp32_class / parity / "
+                         "cpu_baseline legs (the command behind profiles/r05_train_b32_kernel_stats.csv: a profile of it holds "
+                         "bench-mode steps and nothing else)")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run only the timed loop of the roofline kernel and print its object (the command behind "
                          "profiles/r02_roofline_kernel_stats.csv)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.steps_only:
+        args.no_cpu_baseline = args.no_parity = args.no_roofline_top = True
+    return args
 
 
 def _graph_time(torch, launch, iters, warm=10):
@@ -191,20 +198,46 @@ def roofline_top(torch, K, tr, ldr, hdr, gt, top=5, iters=30):
             "by_kind_us": {k: round(sum(r["step_us"] for r in rows if r["kind"] == k), 1) for k in sorted({r["kind"] for r in rows})}}
 
 
-def in_step_family(roof_top_rows, csv_name="r04_train_b32_kernel_stats.csv"):
-    """The dominant kernel FAMILY inside the three-stream step: conv_igemm_kernel (every forward conv and every conv data
-    gradient that is not a sample-resident res-block launch).  FLOP per step = the traced launches of that family (the plan,
-    live); time per step = sum over the family's instantiations of calls x average duration in the committed rocprofv3
-    kernel statistics of the same command (profiles/<csv>, collected by profiles/collect_r04.sh), divided by the steps of
-    that profile (= the calls of dog_fused_kernel, one per step).  In-step durations are longer than the alone-on-the-chip
-    ones of roofline_top: three streams share the chip."""
+def _precise_instantiation(name):
+    """True for the fp32-class (BF16X3, PRECISE = true) instantiations of the matrix-core kernels and for the kernels only
+    the fp32-class step launches - a profile that holds them was not a profile of bench-mode steps alone."""
+    import re
+    m = re.search(r"conv_igemm_kernel<([^>]*)>", name)
+    if m:
+        a = [t.strip() for t in m.group(1).split(",")]
+        return len(a) > 6 and a[6] == "true"
+    m = re.search(r"fc_mfma_kernel<([^>]*)>", name)
+    if m:
+        a = [t.strip() for t in m.group(1).split(",")]
+        return len(a) > 1 and a[1] == "true"
+    m = re.search(r"da_conv_kernel<([^>]*)>", name)
+    if m:
+        return m.group(1).split(",")[0].strip() == "true"
+    return "conv_wgrad_kernel<" in name      # the register-staged weight gradient: BF16X3 / resize-fused layers only
+
+
+def in_step_family(roof_top_rows, batch, da, csv_name="r05_train_b32_kernel_stats.csv"):
+    """The dominant kernel FAMILIES inside the three-stream step, from a RECORDED profile: FLOP per step = the traced launches
+    of the family (the plan, live); time per step = calls x average duration of the family's instantiations in the committed
+    rocprofv3 kernel statistics profiles/<csv> of `bench.py --workload train --steps-only` (nothing but bench-mode steps in
+    the process), divided by the steps of that profile (= calls of rmsprop2_kernel, one per bench-mode step).  The sidecar
+    profiles/<csv>.json records the command, batch and commit of that profile; the object is only emitted for a run of the
+    same batch / distortion-aware setting, refused if the statistics hold a fp32-class (PRECISE) instantiation, and is marked
+    recorded=true: in-step durations are longer than the alone-on-the-chip ones of roofline_top (three streams share the chip)."""
     path = os.path.join(ROOT, "profiles", csv_name)
-    if not os.path.exists(path):
+    side = path + ".json"
+    if not (os.path.exists(path) and os.path.exists(side)):
+        return None
+    with open(side) as f:
+        rec = json.load(f)
+    if rec.get("batch") != batch or sorted(rec.get("distortion_aware", [])) != sorted(da):
         return None
     import csv
     with open(path) as f:
         rows = list(csv.DictReader(f))
-    steps = sum(int(r["Calls"]) for r in rows if "dog_fused_kernel" in r["Name"])
+    if any(_precise_instantiation(r["Name"]) for r in rows):
+        return None
+    steps = sum(int(r["Calls"]) for r in rows if "rmsprop2_kernel" in r["Name"])
     if steps <= 0:
         return None
     out = {}
@@ -214,6 +247,7 @@ def in_step_family(roof_top_rows, csv_name="r04_train_b32_kernel_stats.csv"):
     match = {"conv_igemm_kernel": ("conv_igemm_kernel",), "weight gradients (conv_wgrad*_kernel + wgrad_reduce_kernel)": ("conv_wgrad", "wgrad_reduce_kernel"),
              "resconv_kernel": ("resconv_kernel",)}
     total_ns = sum(float(r["TotalDurationNs"]) for r in rows)
+    total_calls = sum(int(r["Calls"]) for r in rows)
     for fam, keys in match.items():
         ns = sum(float(r["TotalDurationNs"]) for r in rows if any(k in r["Name"] for k in keys))
         calls = sum(int(r["Calls"]) for r in rows if any(k in r["Name"] for k in keys))
@@ -221,8 +255,9 @@ def in_step_family(roof_top_rows, csv_name="r04_train_b32_kernel_stats.csv"):
         out[fam] = {"gflop_per_step": round(fam_flop[fam] / 1e9, 1), "launches_per_step": round(calls / steps, 1), "us_per_step": round(us, 1),
                     "share_of_kernel_time": round(ns / total_ns, 4), "achieved": round(fam_flop[fam] / (us * 1e-6) / 1e12, 1) if us else None,
                     "frac": round(fam_flop[fam] / (us * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4) if us else None}
-    return {"source": "profiles/%s (%d steps profiled; kernel time per step %.0f us over three streams)" % (csv_name, steps, total_ns / steps / 1e3),
-            "unit": "TFLOP/s", "peak": MFMA_PEAK_TFLOPS, "families": out}
+    return {"recorded": True, "source": "profiles/%s" % csv_name, "command": rec.get("command"), "commit": rec.get("commit"),
+            "steps_bf16": steps, "launches_per_step": round(total_calls / steps, 1),
+            "kernel_us_per_step": round(total_ns / steps / 1e3, 1), "unit": "TFLOP/s", "peak": MFMA_PEAK_TFLOPS, "families": out}
 
 
 def hbm_rooflines(torch, K, batch=32, iters=20):
@@ -681,7 +716,13 @@ def main():
         if do_fwd:
             nets = engine.Nets(gen, sun, device=dev, precise=False)
             roof_pw = roof_pw if roof_pw is not None else nets.pk["gen.res.0.conv1"]
-            one_step, out = capture_forward(torch, lambda: engine.generator_forward(nets, ldr, compute=K.BF16, distortion_aware=args.da), dp, args.no_graph)
+            if args.no_graph:
+                one_step, out = capture_forward(torch, lambda: engine.generator_forward(nets, ldr, compute=K.BF16, distortion_aware=args.da), dp, True)
+            else:
+                # one hipGraph per branch on its own stream (engine.ForwardGraphs): a single graph with the fork / join inside runs
+                # the two branches almost one after the other on this runtime (profiles/r04_fwd_timeline.txt)
+                fg = engine.ForwardGraphs(nets, ldr, compute=K.BF16, distortion_aware=args.da)
+                one_step, out = fg.replay, fg.out
             dtf = timed(torch, dist, one_step, args.steps, args.warmup, dp, dev)
             assert torch.isfinite(out["y_final_lin"]).all()
             imgs = batch * world * args.steps
@@ -712,11 +753,13 @@ def main():
         elif hires:
             res["roofline_hbm"] = [fc_row]
             res["sunpose_fc"] = fc_row
+        elif args.steps_only:
+            pass
         else:
             res["roofline"] = dominant_kernel_roofline(torch, K, roof_pw, batch, 32, 128)
             if roof_top is not None:
                 res["roofline_top"] = roof_top
-                ins = in_step_family(roof_top.pop("_all_rows"))
+                ins = in_step_family(roof_top.pop("_all_rows"), batch, sorted(engine.da_parts(args.da)))
                 if ins is not None:
                     res["roofline"]["in_step"] = ins
             res["roofline_hbm"] = hbm_rooflines(torch, K, batch)

@@ -372,28 +372,92 @@ def sun_rad_estimation(nets, ldr, cams, t, compute, training=False):
     return rad_lin, rad_gamma, gamma, beta
 
 
+def _forward_sun(nets, ldr, pick_src, compute, da):
+    """The sun branch of the generator graph: sun-pose net -> Grad-CAM sweep -> sun-radiance head."""
+    t = sunpose_forward(nets, ldr, compute, da, pick="self" if pick_src is None else pick_src)
+    cams = gradcam_sweep(nets, t, t["cmf"] if pick_src is None else pick_src, compute)
+    rad_lin, rad_gamma, gamma, beta = sun_rad_estimation(nets, ldr, cams, t, compute)
+    return dict(t=t, cams=cams, rad_lin=rad_lin, rad_gamma=rad_gamma, gamma=gamma, beta=beta)
+
+
+def _forward_main(nets, ldr, compute, da):
+    """The encoder branch: encoder, sky decoder, and the sun decoder up to its last layer (which needs the sun branch)."""
+    res_out = encode(nets, ldr, compute, distortion_aware="res" in da)
+    sky_gamma = decode(nets, res_out, "f", ldr, compute, da)
+    sun_head = decode_head(nets, res_out, "u", compute, da)      # (only its last layer needs the sun branch's radiance map)
+    return dict(res_out=res_out, sky_gamma=sky_gamma, sun_head=sun_head)
+
+
+def _forward_tail(nets, ldr, S, M, compute):
+    """Joins the two branches: the sun decoder's last layer on the radiance map, alpha mask, blending, tone mapping."""
+    B, H, W, _ = ldr.shape
+    t, cams = S["t"], S["cams"]
+    sun_gamma = decode_tail(nets, M["sun_head"], "u", S["rad_gamma"], compute)
+    y_gamma, y_lin, alpha, sky_lin, sun_lin = K.blend(M["sky_gamma"], sun_gamma, THRESHOLD)
+    return dict(y_final_lin=y_lin, y_final_gamma=y_gamma, sky_pred_lin=sky_lin, sun_pred_lin=sun_lin, gamma=S["gamma"],
+                beta=S["beta"], alpha_c3=alpha, sunpose_cmf=t["cmf"], sunpose_pred=t["cmf"].reshape(B, H, W, 1),
+                sun_cam1=cams[0], sun_cam2=cams[1], sun_cam3=cams[2], sun_rad_lin=S["rad_lin"], res_out=M["res_out"],
+                actv_maps=(t["A1"], t["A2"], t["A3"]))
+
+
 def generator_forward(nets, ldr, pick_src=None, compute=BF16, distortion_aware=False):
     """inference.py:81-115 (pick_src=None: y_c = max cmf) / train.py:239-299 in test mode
     (pick_src = sunpose_gt).  ldr [B,H,W,3] BGR in [0,1].  Returns the reference's outputs as a dict.
     distortion_aware: see da_parts."""
     da = da_parts(distortion_aware)
-    B, H, W, _ = ldr.shape
     # two independent branches (generator encoder + sky decoder | sun-pose net + Grad-CAM + sun radiance) run on
-    # two HIP streams; under hipGraph capture this becomes a fork/join in the graph.
+    # two HIP streams; under hipGraph capture this becomes a fork/join in the graph (ForwardGraphs: one graph per branch).
     main = torch.cuda.current_stream()
     side = nets.side_stream
     side.wait_stream(main)
     with torch.cuda.stream(side):
-        t = sunpose_forward(nets, ldr, compute, da, pick="self" if pick_src is None else pick_src)
-        cams = gradcam_sweep(nets, t, t["cmf"] if pick_src is None else pick_src, compute)
-        rad_lin, rad_gamma, gamma, beta = sun_rad_estimation(nets, ldr, cams, t, compute)
-    res_out = encode(nets, ldr, compute, distortion_aware="res" in da)
-    sky_gamma = decode(nets, res_out, "f", ldr, compute, da)
-    sun_head = decode_head(nets, res_out, "u", compute, da)      # (only its last layer needs the sun branch's radiance map)
+        S = _forward_sun(nets, ldr, pick_src, compute, da)
+    M = _forward_main(nets, ldr, compute, da)
     main.wait_stream(side)
-    sun_gamma = decode_tail(nets, sun_head, "u", rad_gamma, compute)
-    y_gamma, y_lin, alpha, sky_lin, sun_lin = K.blend(sky_gamma, sun_gamma, THRESHOLD)
-    return dict(y_final_lin=y_lin, y_final_gamma=y_gamma, sky_pred_lin=sky_lin, sun_pred_lin=sun_lin, gamma=gamma,
-                beta=beta, alpha_c3=alpha, sunpose_cmf=t["cmf"], sunpose_pred=t["cmf"].reshape(B, H, W, 1),
-                sun_cam1=cams[0], sun_cam2=cams[1], sun_cam3=cams[2], sun_rad_lin=rad_lin, res_out=res_out,
-                actv_maps=(t["A1"], t["A2"], t["A3"]))
+    return _forward_tail(nets, ldr, S, M, compute)
+
+
+class ForwardGraphs:
+    """generator_forward on a static input as THREE hipGraphs: the sun branch on the side stream, the encoder branch and the
+    joining tail on the main stream, ordered by one event - the pattern of trainer.Trainer's segments.  One hipGraph with a
+    fork / join inside executes its two branches almost one after the other on this runtime (profiles/r04_fwd_timeline.txt:
+    the encoder branch starts 316 us into the pass although it depends on the input alone; the whole-step experiment of
+    profiles/LABNOTES.md r3 section 5 saw the same); two single-stream graphs on two streams do run side by side.
+    replay() enqueues one pass behind the caller's current stream; `out` is generator_forward's dict (static tensors)."""
+
+    def __init__(self, nets, ldr, pick_src=None, compute=BF16, distortion_aware=False, warmup=2):
+        da = da_parts(distortion_aware)
+        self.nets, self.ldr = nets, ldr
+        self.main, self.side = torch.cuda.Stream(device=nets.device), nets.side_stream
+        self.joined = torch.cuda.Event()
+        cur = torch.cuda.current_stream()
+        for _ in range(warmup):       # lazy kernel attributes, allocator
+            self.main.wait_stream(cur)
+            with torch.cuda.stream(self.main):
+                generator_forward(nets, ldr, pick_src, compute, distortion_aware)
+            cur.wait_stream(self.main)
+        torch.cuda.synchronize()
+        self.g_sun, self.g_main, self.g_tail = (torch.cuda.CUDAGraph() for _ in range(3))
+        with K.no_gc():
+            with torch.cuda.graph(self.g_sun, stream=self.side, capture_error_mode="thread_local"):
+                S = _forward_sun(nets, ldr, pick_src, compute, da)
+            with torch.cuda.graph(self.g_main, stream=self.main, capture_error_mode="thread_local"):
+                M = _forward_main(nets, ldr, compute, da)
+            with torch.cuda.graph(self.g_tail, stream=self.main, capture_error_mode="thread_local"):
+                self.out = _forward_tail(nets, ldr, S, M, compute)
+        self._keep = (S, M)
+        torch.cuda.synchronize()
+
+    def replay(self):
+        cur = torch.cuda.current_stream()
+        self.side.wait_stream(cur)
+        self.main.wait_stream(cur)
+        with torch.cuda.stream(self.side):
+            self.g_sun.replay()
+            self.joined.record(self.side)
+        with torch.cuda.stream(self.main):
+            self.g_main.replay()
+            self.main.wait_event(self.joined)
+            self.g_tail.replay()
+        cur.wait_stream(self.main)
+        return self.out

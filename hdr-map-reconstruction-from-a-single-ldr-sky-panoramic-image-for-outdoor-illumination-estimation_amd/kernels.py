@@ -110,6 +110,24 @@ class InXf:
     eps: float = IN_EPS
 
 
+class Operand:
+    """Explicit handle of a bf16 operand that a FORWARD launch wrote for the weight gradient of its layer - the caller owns it and
+    hands the same object to the forward call and to the weight-gradient job (rounds 3-4 parked these tensors as attributes on
+    the input tensor object, keyed by nothing that says whether the input was rewritten in between).
+      conv2d(..., emit_xb=op)     -> op.tensor = act(norm(x)) as bf16 (hdrsky_conv2d_fwd_emit), op.key = the transform object
+      da_conv2d(..., operand=op)  -> op.tensor = the gathered operand G [B,H,W,k*k*C], op.key = (offsets, k, input pointer, shape)
+      wgrad_job / da_wgrad_job(..., operand=op) use op.tensor when op.key matches their arguments and fall back to x otherwise.
+    The operand is what the forward pass multiplied: a gradient through it is the gradient of THAT forward, whatever happened
+    to x since.  A forward call without a handle keeps nothing (an inference pass does not hold 4.5x its input)."""
+    __slots__ = ("tensor", "key")
+
+    def __init__(self):
+        self.tensor, self.key = None, None
+
+    def clear(self):
+        self.tensor, self.key = None, None
+
+
 class PackedConv:
     """MFMA B-operand image of a [KH,KW,Cin,Cout] filter (bf16 hi plane + optional lo residual plane).
     transpose_flip=True packs the data-gradient filter w'[ky,kx,co,ci] = w[KH-1-ky,KW-1-kx,ci,co]."""
@@ -175,7 +193,7 @@ def _bf16(t, *shape):
 
 def conv2d(x, pw: PackedConv, bias=None, stride=1, same=True, upsample=1, xf: Optional[InXf] = None,
            out_slope=1.0, residual=None, final_relu=False, want_stats=False, compute=BF16, desc=None, out=None,
-           out_bf16=False, mask_bf16=None, mask_slope=0.0, emit_xb=False):
+           out_bf16=False, mask_bf16=None, mask_slope=0.0, emit_xb: Optional["Operand"] = None):
     """y = final_relu(act(conv(xf(x)) + bias) + residual); returns (y, Stats|None).
     HDRSKY_BF16 mode: x may be a bfloat16 tensor (a final activation: no xf), out_bf16 stores y as bfloat16; mask_bf16
     (instead of residual): a bfloat16 ACTIVATED tensor of y's shape - y is multiplied by (it > 0 ? 1 : mask_slope), the
@@ -235,13 +253,14 @@ def conv2d(x, pw: PackedConv, bias=None, stride=1, same=True, upsample=1, xf: Op
         stats = Stats(torch.empty((B, nparts, 2, pw.Cout), dtype=torch.float32, device=x.device), nparts, d.Ho * d.Wo)
     args = (d, _p(x), _p(pw.hi), _p(pw.lo), _p(bias), _p(in_scale), _p(in_shift), _p(in_part), _p(in_gamma), _p(in_beta),
             _p(residual), _p(y), _p(stats.part) if stats else None)
-    # emit_xb: the transformed operand act(norm(x)) written as a bf16 tensor by this launch - the x of the layer's weight gradient
-    # (kept on the tensor object together with the transform it belongs to: wgrad_job finds it there)
-    xb = None
-    if emit_xb and xf_given is not None and lib.hdrsky_conv2d_emit_supported(d):
+    # emit_xb (an Operand handle): the transformed operand act(norm(x)) written as a bf16 tensor by this launch - the x of the
+    # layer's weight gradient, handed over through the handle together with the transform it belongs to (wgrad_job(operand=))
+    if emit_xb is not None:
+        emit_xb.clear()
+    if emit_xb is not None and xf_given is not None and lib.hdrsky_conv2d_emit_supported(d):
         xb = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=x.device)
         L.check(lib.hdrsky_conv2d_fwd_emit(*args, _p(xb), _stream()), "conv2d_fwd_emit")
-        x._xb = (xf_given, xb)
+        emit_xb.tensor, emit_xb.key = xb, xf_given
     else:
         L.check(lib.hdrsky_conv2d_fwd(*args, _stream()), "conv2d_fwd")
     if TRACE is not None:
@@ -298,17 +317,24 @@ def conv2d_wgrad(x, dy, KH, KW, stride=1, same=True, upsample=1, xf: Optional[In
     return dw, db
 
 
-def da_wgrad_job(x, dy, ksize, offs, dw, db=None, compute=BF16):
+def _da_key(x, offs, ksize):
+    return (offs.data_ptr(), int(ksize), x.data_ptr(), tuple(x.shape), x.dtype)
+
+
+def da_wgrad_job(x, dy, ksize, offs, dw, db=None, compute=BF16, operand: Optional["Operand"] = None):
     """conv2d_wgrad_multi entry for a distortion-aware layer (distortion_aware_ops.conv2d, kernel [k*k*C, F]): dw [k*k*C, F]
-    += G^T dY with the gathered operand G recomputed inside the launch (never in memory).  x [B,H,W,C] fp32, C % 32 == 0."""
+    += G^T dY with the gathered operand G recomputed inside the launch (never in memory), or - single-product mode from 1024
+    pixels per sample (da_mat_ok) - a plain 1x1 weight gradient on the written operand: the one the forward left in `operand`
+    (da_conv2d(operand=)), else gathered here from x.  x [B,H,W,C] fp32, C % 32 == 0."""
     B, H, W, C = x.shape
     F = dy.shape[-1]
     k2 = ksize * ksize
     if tuple(dy.shape) != (B, H, W, F) or C % 32 or tuple(offs.shape) != (H, k2, 2):
         raise ValueError("da_wgrad_job: x %s, dy %s, offs %s" % (tuple(x.shape), tuple(dy.shape), tuple(offs.shape)))
     if da_mat_ok(compute, ksize, C, H * W, "wgrad"):   # dW = G^T dY: a plain 1x1 weight gradient on the gathered operand (the forward's, or written here)
-        kept = getattr(x, "_da_G", None)
-        G = kept[2] if kept is not None and kept[:2] == (offs.data_ptr(), ksize) else da_gather_bf16(x, offs, ksize=ksize)
+        # the operand the layer's forward wrote (operand: the caller's handle), else gathered here from x as it stands
+        G = operand.tensor if operand is not None and operand.tensor is not None and operand.key == _da_key(x, offs, ksize) \
+            else da_gather_bf16(x, offs, ksize=ksize)
         if dy.dtype != torch.bfloat16:      # (a gradient the fused data-gradient kernel reads as fp32: the LDS-DMA kernel wants bf16)
             dy = to_bf16(_f32(dy))
         _f32(dw, k2 * C, F)
@@ -343,14 +369,16 @@ def _da_wgrad_region(job):
     return True
 
 
-def wgrad_job(x, dy, KH, KW, dw, db=None, stride=1, same=True, upsample=1, xf: Optional[InXf] = None, compute=BF16):
+def wgrad_job(x, dy, KH, KW, dw, db=None, stride=1, same=True, upsample=1, xf: Optional[InXf] = None, compute=BF16,
+              operand: Optional["Operand"] = None):
     """One entry for conv2d_wgrad_multi: dw [KH,KW,Cin,Cout] (+= ; must hold valid values, e.g. zeros), db [Cout] or None.
     x / dy may be bf16 tensors: final activations / gradients (no operand transform), or - x with a transform - a raw conv
     output as the single-product mode stores it (materialised by conv2d_wgrad_multi, or widened by the narrow-output kernel).
+    operand: the handle the layer's forward call filled (conv2d(emit_xb=op)) - used when it belongs to this transform.
     The returned job references its tensors, which keeps them alive until the launch."""
-    kept = getattr(x, "_xb", None)
-    if kept is not None and xf is not None and kept[0] is xf and upsample == 1 and compute == BF16 and dy.dtype == torch.bfloat16:
-        x, xf = kept[1], None        # the forward launch wrote act(norm(x)) as bf16 (conv2d(emit_xb=True)): the final operand
+    if operand is not None and operand.tensor is not None and xf is not None and operand.key is xf and upsample == 1 and \
+            compute == BF16 and dy.dtype == torch.bfloat16 and tuple(operand.tensor.shape) == tuple(x.shape):
+        x, xf = operand.tensor, None        # the forward launch wrote act(norm(x)) as bf16 (conv2d(emit_xb=op)): the final operand
     for t in (x, dy):
         if not (torch.is_tensor(t) and t.is_cuda and t.is_contiguous() and t.dtype in (torch.float32, torch.bfloat16)):
             raise ValueError("expected contiguous CUDA float32 / bfloat16 tensors")
@@ -397,9 +425,11 @@ def _materialise_bf16_operand(job):
         return job                   # a final bf16 activation already
     j = L.WgradJob()
     _fill_wgrad_job(j, job)
-    if not L.load().hdrsky_wgrad2_eligible(ctypes.byref(j), 1):
-        return job
     B, H, W, C = x.shape
+    # (hdrsky_act_bf16 takes up to 1024 channels; the LDS-DMA kernel's own limit is wider since the 1x1 gradient on a gathered
+    # operand - a transform-carrying operand beyond that stays on the register-staged kernel: ADVICE r4)
+    if C > 1024 or not L.load().hdrsky_wgrad2_eligible(ctypes.byref(j), 1):
+        return job
     xb = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=x.device)
     in_scale, in_shift, in_part, in_gamma, in_beta = tabs
     L.check(L.load().hdrsky_act_bf16(_p(x), int(x16), B, H * W, C, d.in_mode, _p(in_scale), _p(in_shift), d.ss_bstride, _p(in_part),
@@ -1502,21 +1532,26 @@ def gemm1x1(G, pw1: PackedConv, bias=None, want_stats=False, out_bf16=False):
     return y, st
 
 
-def da_conv2d(x, pw: PackedConv, bias, offs, compute=BF16, want_stats=False, train=False, reuse_operand=False):
+def da_conv2d(x, pw: PackedConv, bias, offs, compute=BF16, want_stats=False, train=False, reuse_operand=False,
+              operand: Optional["Operand"] = None):
     """distortion_aware_ops.conv2d.call: offs = device tensor [H, k*k, 2] from da_offsets(H, W, k, ...).
     want_stats: also return the InstanceNorm partials of y (Stats, as conv2d does) -> (y, Stats).
-    train: the layer's kernel gradient will follow (it reads the gathered operand again; kept for callers - the written
-    operand is the faster forward from 1024 pixels per sample with or without it: da_mat_ok).  The operand is kept on the
-    tensor object x for that kernel gradient (da_wgrad_job), which therefore must be queued before x is rewritten."""
+    train: the layer's kernel gradient will follow (kept for callers - the written operand is the faster forward from 1024
+    pixels per sample with or without it: da_mat_ok).  operand (an Operand handle, training): where the layer runs on its
+    written gathered operand, the handle receives it and da_wgrad_job(operand=) reads it again; without a handle nothing is
+    kept.  reuse_operand: a second layer on the SAME, unchanged input (the decoders' first deconvolutions) takes the operand
+    the handle already holds for this (offsets, k, input) - the caller's promise that x was not rewritten in between."""
     B, H, W, C = x.shape
     if C != pw.Cin or pw.KH != pw.KW:
         raise ValueError("filter / input mismatch")
     if da_mat_ok(compute, pw.KH, C, H * W, "fwd"):
-        # reuse_operand: a second layer on the SAME, unchanged input (the decoders' first deconvolutions) takes the operand the first
-        # one wrote - the caller's promise: nothing here can tell whether x was rewritten in between
-        kept = getattr(x, "_da_G", None) if reuse_operand else None
-        G = kept[2] if kept is not None and kept[:2] == (offs.data_ptr(), pw.KH) else da_gather_bf16(x, offs, ksize=pw.KH)
-        x._da_G = (offs.data_ptr(), pw.KH, G)      # the weight gradient of the layer reads it again (da_wgrad_job)
+        key = _da_key(x, offs, pw.KH)
+        if reuse_operand and operand is not None and operand.tensor is not None and operand.key == key:
+            G = operand.tensor
+        else:
+            G = da_gather_bf16(x, offs, ksize=pw.KH)
+        if operand is not None:
+            operand.tensor, operand.key = G, key      # the weight gradient of the layer reads it again (da_wgrad_job(operand=))
         y, st = gemm1x1(G, pw.as_1x1(), bias, want_stats=want_stats)
         return (y, st) if want_stats else y
     _f32(x)

@@ -70,6 +70,9 @@ class _Conv:
         # (the layers conv_wgrad2_kernel takes: csrc/conv_wgrad.hip v2_eligible)
         self.emit_xb = (not precise) and upsample == 1 and self.cin >= 32 and self.cin % 32 == 0 and self.cout >= 32 and \
             self.cout % 32 == 0 and stride in (1, 2) and self.kh * self.kw <= 64
+        # the layer's handle for operands its forward launch writes for its weight gradient (kernels.Operand): the bf16
+        # act(norm(x)) of conv2d(emit_xb=), the gathered operand of a distortion-aware layer
+        self.op = K.Operand()
 
     def repack(self):
         self.pk.repack(self.w)
@@ -85,13 +88,13 @@ class _Conv:
         # a training-mode forward (statistics wanted) in front of a weight gradient on the LDS-DMA kernel: the launch also writes
         # its transformed operand as bf16 (kernels.conv2d(emit_xb=True)) - no hdrsky_act_bf16 launch in the backward pass
         if xf is not None and kw.get("want_stats") and self.emit_xb and compute == BF16 and HOOKS.H.emit_xb:
-            kw.setdefault("emit_xb", True)
+            kw.setdefault("emit_xb", self.op)
         return K.conv2d(x, self.pk, self.b, stride=self.stride, same=self.same, upsample=self.upsample, xf=xf,
                         compute=compute, **kw)
 
     def wgrad_job(self, x, xf, dy, gw, gb, compute):
         return K.wgrad_job(x, dy, self.kh, self.kw, gw, gb, stride=self.stride, same=self.same, upsample=self.upsample,
-                           xf=xf, compute=compute)
+                           xf=xf, compute=compute, operand=self.op)
 
     def dgrad(self, x, dy, compute, residual=None, want_stats=False, out=None, out_bf16=False, up_bf16=False):
         """Gradient wrt the (transformed, pre-resize) conv operand.  out_bf16: stored as bf16 (a gradient whose only reader is
@@ -368,7 +371,7 @@ class Trainer:
         q = self._wjobs.setdefault(torch.cuda.current_stream().cuda_stream, [])
         offs = self._da(x.shape[1], x.shape[2], cv.kh)[0]
         q.append(K.da_wgrad_job(x, dy, cv.kh, offs, dw if dw is not None else g[cv.wkey].view(cv.kh * cv.kw * cv.cin, cv.cout),
-                                g[cv.bkey], self.compute))
+                                g[cv.bkey], self.compute, operand=cv.op))
 
     def _flush_wgrads(self):
         """Launches the weight gradients queued on the current stream."""
@@ -385,9 +388,9 @@ class Trainer:
                 cv1, cv2 = c[n + ".conv1"], c[n + ".conv2"]
                 offs = self._da(x.shape[1], x.shape[2], cv1.kh)[0]
                 xin, pk1 = (K.pad_channels(x, 32), self._pk1pad) if l == 1 else (x, cv1.pk)
-                r1, st1 = K.da_conv2d(xin, pk1, cv1.b, offs, cp, want_stats=True, train=True)
+                r1, st1 = K.da_conv2d(xin, pk1, cv1.b, offs, cp, want_stats=True, train=True, operand=cv1.op)
                 a1 = K.norm_apply(r1, st1, w[n + ".norm1.gamma"], w[n + ".norm1.beta"], slope=0.0)
-                r2, st2 = K.da_conv2d(a1, cv2.pk, cv2.b, offs, cp, want_stats=True, train=True)
+                r2, st2 = K.da_conv2d(a1, cv2.pk, cv2.b, offs, cp, want_stats=True, train=True, operand=cv2.op)
                 a, pooled = K.norm_apply(r2, st2, w[n + ".norm2.gamma"], w[n + ".norm2.beta"], slope=0.0, pool=True)
                 t["in%d" % l], t["r%da" % l], t["st%da" % l], t["a%da" % l] = xin, r1, st1, a1
                 t["r%db" % l], t["st%db" % l], t["A%d" % l], t["P%d" % l] = r2, st2, a, pooled
@@ -751,13 +754,17 @@ class Trainer:
                     u3 = T["u3_da"]
                 else:
                     u3 = K.up2x(res_out)
+                # (the two decoders' first layers read the same resized map: the sun decoder's takes - and hands its kernel
+                # gradient - the gathered operand the sky decoder's wrote, through one shared handle)
+                if sfx == "u":
+                    c3.op = c["gen.conv3_f"].op
                 d3, s3 = K.da_conv2d(u3, c3.pk, c3.b, self._da(u3.shape[1], u3.shape[2])[0], cp, want_stats=True, train=True,
-                                     reuse_operand=(sfx == "u"))
+                                     reuse_operand=(sfx == "u"), operand=c3.op)
                 if K.da_mat_ok(cp, 3, c2.cin, 4 * px3, "fwd"):
                     u2 = K.up2x_act_bf16(d3, self._inxf(s3, "gen.norm3_" + sfx, 0.1, partials=True))
                 else:
                     u2 = K.up2x(K.norm_apply(d3, s3, w["gen.norm3_%s.gamma" % sfx], w["gen.norm3_%s.beta" % sfx], slope=0.1))
-                d2, s2 = K.da_conv2d(u2, c2.pk, c2.b, self._da(u2.shape[1], u2.shape[2])[0], cp, want_stats=True, train=True)
+                d2, s2 = K.da_conv2d(u2, c2.pk, c2.b, self._da(u2.shape[1], u2.shape[2])[0], cp, want_stats=True, train=True, operand=c2.op)
                 xf1 = self._inxf(s2, "gen.norm2_" + sfx, 0.1)
                 T["dech_" + sfx] = (d3, s3, u3, d2, s2, xf1, u2)
             elif self._deconv_mat():
@@ -857,9 +864,9 @@ class Trainer:
                 for i in range(6):
                     p = "gen.res.%d." % i
                     cv1, cv2 = c[p + "conv1"], c[p + "conv2"]
-                    c1, t1 = K.da_conv2d(x, cv1.pk, cv1.b, offs, cp, want_stats=True, train=True)
+                    c1, t1 = K.da_conv2d(x, cv1.pk, cv1.b, offs, cp, want_stats=True, train=True, operand=cv1.op)
                     a1 = K.norm_apply(c1, t1, w[p + "norm1.gamma"], w[p + "norm1.beta"], slope=0.1)
-                    c2, t2 = K.da_conv2d(a1, cv2.pk, cv2.b, offs, cp, want_stats=True, train=True)
+                    c2, t2 = K.da_conv2d(a1, cv2.pk, cv2.b, offs, cp, want_stats=True, train=True, operand=cv2.op)
                     xn = K.norm_apply(c2, t2, w[p + "norm2.gamma"], w[p + "norm2.beta"], slope=1.0, residual=x)
                     T["res%d" % i] = (c1, t1, a1, c2, t2)
                     x = xn

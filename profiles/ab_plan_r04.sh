@@ -1,4 +1,7 @@
 #!/bin/bash
+# NOTE (round 5): HDRSKY_FC_UPDATE_WGS named a persistent-workgroup throttle of fc_xtdy_kernel that was removed before round 4's
+# final commit (csrc/hooks.h does not read it): the rows of profiles/r04_plan_ab.txt that carry it repeat their neighbours
+# without it and are NOT reproducible with the committed code.  The HDRSKY_PLAN_MOVE rows are.
 # Round 4: the Dense update (apply_fc: ~320 us, HBM-bound, the tail of the step on stream 2) on a stream of its own right
 # behind bwd_dense, as every tile's workgroup or throttled to a fraction of the chip (HDRSKY_FC_UPDATE_WGS persistent
 # workgroups), so that it hides beside the backward pass.   usage (GPU box): bash profiles/ab_plan_r04.sh

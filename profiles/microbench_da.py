@@ -6,6 +6,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import hdrsky_amd as hs
 K = importlib.import_module(hs.__name__ + ".kernels")
+HK = importlib.import_module(hs.__name__ + ".hooks")      # HDRSKY_* variables are read once: reload() after every change
 dev = torch.device("cuda:0")
 
 
@@ -23,12 +24,12 @@ def timeit(fn, iters=30):
 def both(fn):
     out = []
     for mode in ("0", "2"):
-        os.environ["HDRSKY_DA_REGION"] = mode
+        os.environ["HDRSKY_DA_REGION"] = mode; HK.reload()
         try:
             out.append(timeit(fn))
         except Exception:
             out.append(float("nan"))
-    os.environ.pop("HDRSKY_DA_REGION")
+    os.environ.pop("HDRSKY_DA_REGION"); HK.reload()
     return out
 
 

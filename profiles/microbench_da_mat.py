@@ -49,17 +49,15 @@ for name, B, H, W, C, F in SHAPES:
     row = []
     for mat in ("1", "0"):
         os.environ["HDRSKY_DA_MAT"] = mat; HK.reload()
-        if hasattr(x, "_da_G"):
-            del x._da_G
+        op = K.Operand()
         dy = torch.randn(B, H, W, F, device=dev)
         if mat == "1":
             dy = dy.to(torch.bfloat16)
-        def fwd():      # (a fresh input every pass: the operand kept on the tensor object would otherwise be re-used)
-            x.__dict__.pop("_da_G", None)
-            return K.da_conv2d(x, pw, bias, offs, K.BF16, want_stats=True, train=True)
+        def fwd():      # (the operand goes to the caller's handle, which the kernel gradient below reads)
+            return K.da_conv2d(x, pw, bias, offs, K.BF16, want_stats=True, train=True, operand=op)
         t_f = gtime(fwd)
         t_d = gtime(lambda: K.da_conv2d_dgrad(dy, pwT, table, 3, K.BF16))
-        t_w = gtime(lambda: K.conv2d_wgrad_multi([K.da_wgrad_job(x, dy, 3, offs, dw, db, K.BF16)]))       # (operand kept by the forward when written)
+        t_w = gtime(lambda: K.conv2d_wgrad_multi([K.da_wgrad_job(x, dy, 3, offs, dw, db, K.BF16, operand=op)]))       # (operand kept by the forward when written)
         t_g = gtime(lambda: K.da_gather_bf16(x, offs, ksize=3)) if mat == "1" else 0.0
         row.append("%s: fwd %7.1f  dgrad %7.1f  wgrad %7.1f%s" % ("written" if mat == "1" else "fused  ", t_f, t_d, t_w,
                                                                  "  (gather alone %6.1f)" % t_g if mat == "1" else ""))

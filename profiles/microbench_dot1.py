@@ -1,7 +1,8 @@
 import importlib, os, sys, torch
 sys.path.insert(0, os.getcwd())
 PKG = "hdr-map-reconstruction-from-a-single-ldr-sky-panoramic-image-for-outdoor-illumination-estimation_amd"
-K = importlib.import_module(PKG + ".kernels"); L = importlib.import_module(PKG + "._lib")
+os.environ["HDRSKY_EXPERIMENTS"] = "1"      # HDRSKY_NO_DOT1 is a tuning hook of the C library
+K = importlib.import_module(PKG + ".kernels"); L = importlib.import_module(PKG + "._lib"); HK = importlib.import_module(PKG + ".hooks")
 dev = torch.device("cuda:0")
 for B in (32, 64):
     x = torch.randn(B, 4, 16, 512, device=dev)
@@ -11,6 +12,7 @@ for B in (32, 64):
     for env in ("", "1"):
         if env: os.environ["HDRSKY_NO_DOT1"] = "1"
         else: os.environ.pop("HDRSKY_NO_DOT1", None)
+        HK.reload()      # the variables are read once (csrc/hooks.h): re-read after every change
         f = lambda: K.conv2d(x, pw, bias, same=False, xf=xf)
         for _ in range(3): f()
         g = torch.cuda.CUDAGraph()

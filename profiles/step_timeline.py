@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
-"""Kernel-by-kernel timeline of ONE training step from a rocprofv3 --kernel-trace CSV of `bench.py --workload train`:
-step_timeline.py DIR [queue rank]  - the step is the last complete run between two launches of the marker kernel
-(rmsprop_kernel, the generator's update at the end of `apply`); kernels are listed per HIP stream (queue) with their start
-offset, duration and the gap to the previous kernel of the same queue."""
+"""Kernel-by-kernel timeline of ONE bench-mode training step from a rocprofv3 --kernel-trace CSV of
+`bench.py --workload train --steps-only`: step_timeline.py DIR [queue rank]  - the step is the last complete run between two
+launches of the marker kernel (rmsprop2_kernel: both optimizers' conv-side update, ONE launch per bench-mode step at the end
+of `apply`; round 4's marker `rmsprop_kernel` is launched by the fp32-class step only, which is how r04_step_timeline.txt came
+to describe a BF16X3 step).  The chosen window must not hold a fp32-class (PRECISE = true) instantiation: asserted.
+Kernels are listed per HIP stream (queue) with their start offset, duration and the gap to the previous kernel of the queue."""
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
@@ -10,14 +12,32 @@ for r in rows:
     r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
 rows.sort(key=lambda r: r["s"])
 short = lambda n: n.replace("(anonymous namespace)::", "").replace("void ", "")[:78]
-marks = [i for i, r in enumerate(rows) if "rmsprop_kernel" in r["Kernel_Name"]]
-# marker launches come in bursts (several per apply); a step boundary = a gap of > 1 ms between marker launches
-bounds = [marks[0]] + [marks[k] for k in range(1, len(marks)) if rows[marks[k]]["s"] - rows[marks[k - 1]]["s"] > 1_000_000]
-lo, hi = bounds[-3], bounds[-2]
-# the step runs from just after the last marker burst of step n-1 to the last marker of step n
-last_of = lambda b: max(i for i in marks if rows[i]["s"] - rows[b]["s"] < 500_000 and i >= b)
-a, b = last_of(lo) + 1, last_of(hi) + 1
+import re
+def precise(name):
+    m = re.search(r"conv_igemm_kernel<([^>]*)>", name)
+    if m:
+        a = [t.strip() for t in m.group(1).split(",")]
+        return len(a) > 6 and a[6] == "true"
+    m = re.search(r"fc_mfma_kernel<([^>]*)>", name)
+    if m:
+        return [t.strip() for t in m.group(1).split(",")][1] == "true"
+    return "conv_wgrad_kernel<" in name or "rmsprop_kernel(" in name
+marks = [i for i, r in enumerate(rows) if "rmsprop2_kernel" in r["Kernel_Name"]]
+assert len(marks) >= 4, "no rmsprop2_kernel launches: not a trace of bench-mode steps"
+# one marker per step.  A step ends with a join of its three streams, so its successor's first kernel is the first one
+# behind the marker that starts after EVERYTHING before it has ended (the Dense update on another stream may still run
+# when rmsprop2 starts, the filter re-pack follows it)
+def step_start(m):
+    end = max(r["e"] for r in rows[max(0, m - 40):m + 1])
+    for i in range(m + 1, min(len(rows), m + 40)):
+        if rows[i]["s"] >= end:
+            return i
+        end = max(end, rows[i]["e"])
+    raise SystemExit("no stream join found behind marker %d" % m)
+a, b = step_start(marks[-3]), step_start(marks[-2])
 step = rows[a:b]
+bad = [r["Kernel_Name"] for r in step if precise(r["Kernel_Name"])]
+assert not bad, "fp32-class instantiation inside the chosen step: %s" % bad[0]
 t0 = step[0]["s"]
 qs = collections.OrderedDict()
 for r in step:

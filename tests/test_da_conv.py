@@ -376,9 +376,7 @@ def test_da_launches_are_reproducible_beside_their_neighbours(dev, shape, monkey
     def launches(variant):
         monkeypatch.setenv("HDRSKY_DA_MAT", "1" if variant == "written" else "0")
         monkeypatch.setenv("HDRSKY_DA_REGION", "0" if variant == "global" else "1")
-        if hasattr(x, "_da_G"):
-            del x._da_G
-        fwd = K.da_conv2d(x, pw, bias, offs, K.BF16, train=True)
+        fwd = K.da_conv2d(x, pw, bias, offs, K.BF16, train=True)      # (no handle: the kernel gradient gathers again)
         dx = K.da_conv2d_dgrad(dy, pwT, table, 3, K.BF16)
         dw = torch.zeros(9 * C, F, device=dev); dbg = torch.zeros(F, device=dev)
         K.da_conv2d_bwd(x, dy, kern.reshape(9 * C, F), offs, 3, K.BF16, want_dx=False, dw=dw, db=dbg)
@@ -436,18 +434,27 @@ def test_da_layer_on_the_written_gathered_operand(dev, shape, monkeypatch):
     pwT = K.PackedConv(kd.view(3, 3, C, F), precise=False, transpose_flip=True)
     table = K.da_transpose_table(H, W, 3, device=dev)
 
-    def run():
-        y, st = K.da_conv2d(xd, pw, bd, offs, K.BF16, want_stats=True, train=True)
+    op = K.Operand()
+
+    def run(handle=op):
+        y, st = K.da_conv2d(xd, pw, bd, offs, K.BF16, want_stats=True, train=True, operand=handle)
         dx = K.da_conv2d_dgrad(dyd, pwT, table, 3, K.BF16)
         dw, db = torch.zeros(9 * C, F, device=dev), torch.zeros(F, device=dev)
-        K.conv2d_wgrad_multi([K.da_wgrad_job(xd, dyd, 3, offs, dw, db, K.BF16)])
+        K.conv2d_wgrad_multi([K.da_wgrad_job(xd, dyd, 3, offs, dw, db, K.BF16, operand=handle)])
         return y, st.part.sum(1), dx, dw, db
     got = run()
-    assert getattr(xd, "_da_G", None) is not None
+    # the forward handed its gathered operand to the caller's handle (nothing is parked on the input tensor any more) ...
+    assert op.tensor is not None and torch.equal(op.tensor, G16) and not hasattr(xd, "_da_G")
+    # ... and a kernel gradient without the handle, or with a handle that belongs to another input, gathers again: same bits
+    nohandle = run(None)
+    stale = K.Operand(); stale.tensor, stale.key = torch.zeros_like(G16), K._da_key(xd.clone(), offs, 3)
+    dws, dbs = torch.zeros(9 * C, F, device=dev), torch.zeros(F, device=dev)
+    K.conv2d_wgrad_multi([K.da_wgrad_job(xd, dyd, 3, offs, dws, dbs, K.BF16, operand=stale)])
+    assert torch.equal(nohandle[3], got[3]) and torch.equal(dws, got[3]), "kernel gradient from a re-gathered operand"
     monkeypatch.setenv("HDRSKY_DA_MAT", "0")
-    del xd._da_G
+    op.clear()
     fused = run()
-    assert getattr(xd, "_da_G", None) is None
+    assert op.tensor is None
     for name, a, b_ in zip(("y", "statistics", "dx", "dkernel", "dbias"), got, fused):
         err = float((a.double() - b_.double()).abs().max() / b_.double().abs().max())
         assert err < 5e-3, (name, err)

@@ -97,3 +97,24 @@ def test_captured_forward_replays_match_eager(dev, da):
         for k, v in ref.items():
             assert torch.equal(out[k], v), (it, k)
         del spare
+
+
+@pytest.mark.parametrize("da", [False, "all"])
+def test_forward_graphs_on_two_streams_match_eager(dev, da):
+    """engine.ForwardGraphs (what bench.py's `fwd` times since round 5: one hipGraph per branch on its own stream, the tail
+    behind an event) replayed several times, with the input rewritten in between, against the eager pass: bit for bit."""
+    K = pkg("kernels")
+    engine, nets, gen, sun, batch = _setup(dev, 8)
+    ldr = torch.from_numpy(batch["ldr"]).to(dev)
+    other = torch.from_numpy(pkg("synth").make_batch(8, seed=77)["ldr"]).to(dev)
+    fn = lambda x: {k: v.clone() for k, v in engine.generator_forward(nets, x, compute=K.BF16, distortion_aware=da).items() if torch.is_tensor(v)}
+    ref_a, ref_b = fn(ldr.clone()), fn(other)
+    torch.cuda.synchronize()
+    x = ldr.clone()
+    fg = engine.ForwardGraphs(nets, x, compute=K.BF16, distortion_aware=da)
+    for it in range(4):
+        x.copy_(ldr if it % 2 == 0 else other)
+        out = fg.replay()
+        torch.cuda.synchronize()
+        for k, v in (ref_a if it % 2 == 0 else ref_b).items():
+            assert torch.equal(out[k], v), (it, k)

@@ -213,7 +213,17 @@ def test_hires_training_step_gradients_match_oracle(dev, da):
     derr = sorted(((rel_max(tr.ds.g["dis." + k], v), rel_rms(tr.ds.g["dis." + k], v), k)
                    for k, v in zip(names, torch.autograd.grad(dl["total_disc_loss"], [dr[k] for k in names]))), reverse=True)
     print("128x512 da=%s discriminator gradients (rel max, rel rms, name), worst:" % (da,), derr[:4])
-    assert derr[0][0] < 5e-2 and max(r for _, r, _ in derr) < 5e-3, derr[:4]
+    # What the two bounds protect.  rms < 5e-3 per tensor is the assertion that says "the gradient is right" (measured 2e-4 ..
+    # 2e-3 on every build).  The worst-ELEMENT bound is 5e-2 here and 2e-2 in the B = 2 twin
+    # (test_fullsize_gpu.py::test_hires_train_step_b2_against_the_oracle) because of what a SINGLE-sample BatchNorm does: with
+    # B = 1 the batch statistics of d2 / d3 / d4 run over one image, the backward's two means (mean dy, mean dy * xhat) are sums
+    # over that one image's pixels, and a channel whose single-image variance is small multiplies the fp32-class rounding of
+    # its inputs by rstd - the element that carries the maximum error is always in such a channel of d1 / d2's kernel gradient
+    # (round 3 build: 1.2e-2; round 4 build with -fno-slp-vectorize, which changed the summation order inside bn_bwd_reduce: d2
+    # kernel 2.999e-2, gpurun_out/r04d/pytest.txt; other tensors 3e-3 .. 9e-3).  With two samples the statistics average over
+    # both and the same element class stays below 2e-2.  The measured values of THIS build are in the assertion message.
+    assert derr[0][0] < 5e-2 and max(r for _, r, _ in derr) < 5e-3, \
+        "discriminator gradients, 128x512 B = 1 (worst element, rms, tensor): %s" % (derr[:4],)
 
 
 @pytest.mark.parametrize("da", [False, "res,decoders"])

@@ -190,11 +190,12 @@ def test_forward_conv_writes_the_operand_of_its_weight_gradient(dev, shape, k, s
                     shift=torch.randn(B, C, device=dev, generator=g) * 0.3)
     pw = K.PackedConv(w, precise=False)
     y0, s0 = K.conv2d(x, pw, b, stride=stride, xf=xf, compute=K.BF16, want_stats=True)
-    assert not hasattr(x, "_xb")
-    y1, s1 = K.conv2d(x, pw, b, stride=stride, xf=xf, compute=K.BF16, want_stats=True, emit_xb=True)
+    op = K.Operand()
+    y1, s1 = K.conv2d(x, pw, b, stride=stride, xf=xf, compute=K.BF16, want_stats=True, emit_xb=op)
     assert torch.equal(y0, y1) and torch.equal(s0.part, s1.part)
-    kept = getattr(x, "_xb", None)
-    assert kept is not None and kept[0] is xf and kept[1].dtype == torch.bfloat16 and kept[1].shape == x.shape
+    assert not hasattr(x, "_xb")          # the operand travels in the caller's handle, not on the tensor object
+    kept = (op.key, op.tensor)
+    assert kept[1] is not None and kept[0] is xf and kept[1].dtype == torch.bfloat16 and kept[1].shape == x.shape
     # the materialising launch on the same tensor and transform
     d = K.conv_desc(B, H, W, C, cout, k, k, stride, True, 1)
     d.compute = K.BF16
@@ -207,10 +208,8 @@ def test_forward_conv_writes_the_operand_of_its_weight_gradient(dev, shape, k, s
     dy = (torch.randn(*y0.shape, device=dev, generator=g) * 0.1).to(torch.bfloat16)
     outs = []
     for use_kept in (True, False):
-        if not use_kept:
-            del x._xb
         dw, db = torch.zeros(k, k, C, cout, device=dev), torch.zeros(cout, device=dev)
-        K.conv2d_wgrad_multi([K.wgrad_job(x, dy, k, k, dw, db, stride=stride, xf=xf, compute=K.BF16)])
+        K.conv2d_wgrad_multi([K.wgrad_job(x, dy, k, k, dw, db, stride=stride, xf=xf, compute=K.BF16, operand=op if use_kept else None)])
         outs.append((dw, db))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     # a VALID-geometry layer is not taken (its output blocks do not cover the image)
