@@ -80,6 +80,7 @@ SIGNATURES = {
     "hdrsky_bn_eval_affine": (c_int, [P, P, P, P, c_float, c_int, P, P, P]),
     "hdrsky_norm_act_bwd": (c_int, [P, P, c_int, P, P, c_float, c_float, P, c_int, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "hdrsky_norm_act_bwd_nslices": (c_int, [c_int] * 5),
+    "hdrsky_norm_act_bwd_one_launch": (c_int, [c_int] * 4),
     "hdrsky_fc_pack_weights": (c_int, [P, c_int, c_int, P, P, P, P, P]),
     "hdrsky_fc_nsplit": (c_int, [c_int]),
     "hdrsky_fc_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),

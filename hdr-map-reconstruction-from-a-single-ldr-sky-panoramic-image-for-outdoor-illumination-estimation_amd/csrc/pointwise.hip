@@ -365,6 +365,180 @@ __global__ void __launch_bounds__(256) norm_act_bwd_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same backward in ONE launch and ONE read of (x, dy) for maps whose (sample, 16-channel group) slab fits the registers
+// of a workgroup (round 5; the sliced form above reads x and dy twice and is two launches from 512 pixels per slice on: 20 of
+// the training step's 29 norm_act_bwd launches).  Block = (sample, 16-channel group), NT threads; a thread holds NV units
+// (pixels, or 2x2 windows of the pooled form) of one float4 channel column as xhat in registers with the upstream gradient
+// beside it, the two sums are reduced over the block in a fixed order (xor shuffles inside a wave, waves in index order),
+// and the formula is applied to the registers.  Same arithmetic per element as norm_act_bwd_kernel; the sums are added in
+// another (still fixed) order, so results differ from the sliced form by fp32 rounding of those two sums only.
+// ---------------------------------------------------------------------------------------------
+template <int NT, int NV, int CG, bool POOLED, bool DY16>
+__global__ void __launch_bounds__(NT) norm_act_bwd1_kernel(const float* __restrict__ x, const float* __restrict__ part, int nparts,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                           float slope, const float* __restrict__ dy, void* __restrict__ dxv,
+                                                           int flags, float* __restrict__ sums, float* dgamma, float* dbeta, int H,
+                                                           int W, int C) {
+  constexpr int NW = NT / 64, NC = CG / 4, NS = NT / NC;      // waves; float4 columns per pixel; pixel (window) slots per pass
+  static_assert(NT >= 16 * CG && (CG == 8 || CG == 16), "statistics prologue: 16 partial slices x CG channels");
+  __shared__ float sPart[16][CG][2];
+  __shared__ float sMR[CG][2];
+  __shared__ float sRed[NW][2][CG];
+  __shared__ float sM[2][CG];
+  const int groups = C / CG;
+  const int b = blockIdx.x / groups, cg = blockIdx.x % groups;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cl = (tid % NC) * 4, slot = tid / NC;
+  const int c = cg * CG + cl;
+  const bool dx_bf16 = (flags & 1) != 0;
+  const int x16 = flags & 4;
+  // statistics of the CG channels from the forward conv's tile partials (as in norm_act_bwd_kernel)
+  if (tid < 16 * CG) {
+    const int ch = tid % CG, sl = tid / CG;
+    float s = 0.f, ss = 0.f;
+    const float* pp = part + (size_t)b * nparts * 2 * C + cg * CG + ch;
+    for (int p = sl; p < nparts; p += 16) { s += pp[(2 * p) * C]; ss += pp[(2 * p + 1) * C]; }
+    sPart[sl][ch][0] = s; sPart[sl][ch][1] = ss;
+  }
+  __syncthreads();
+  if (tid < CG) {
+    float ts = 0.f, tss = 0.f;
+    for (int k = 0; k < 16; ++k) { ts += sPart[k][tid][0]; tss += sPart[k][tid][1]; }
+    const float inv_count = 1.f / (float)(H * W);
+    const float m = ts * inv_count;
+    const float var = fmaxf(tss * inv_count - m * m, 0.f);
+    sMR[tid][0] = m; sMR[tid][1] = 1.f / sqrtf(var + eps);
+  }
+  __syncthreads();
+  float mean[4], rstd[4], gm[4], bt[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { mean[j] = sMR[cl + j][0]; rstd[j] = sMR[cl + j][1]; gm[j] = gamma[c + j]; bt[j] = beta[c + j]; }
+  const int Wp = W >> 1;
+  const int nunits = POOLED ? (H >> 1) * Wp : H * W;
+  // workgroup-uniform bases + 32-bit element offsets (a sample's slab is < 2^31 elements): one address register per load
+  const float* xs32 = x + (size_t)b * H * W * C;
+  const unsigned short* xs16 = reinterpret_cast<const unsigned short*>(x) + (size_t)b * H * W * C;
+  const float* dyb = dy + (size_t)b * nunits * C;
+  const unsigned short* dyh = reinterpret_cast<const unsigned short*>(dy) + (size_t)b * nunits * C;
+  constexpr int PX = POOLED ? 4 : 1;             // pixels per unit
+  auto pix_off = [&](int u, int q) -> unsigned {
+    if (!POOLED) return (unsigned)u * (unsigned)C + (unsigned)c;
+    const int ph = u / Wp, px = u - ph * Wp;
+    return (unsigned)((2 * ph + (q >> 1)) * W + 2 * px + (q & 1)) * (unsigned)C + (unsigned)c;
+  };
+  float xh[NV][PX][4];
+  uint2 u16[DY16 ? NV : 1];
+  float4 u32[DY16 ? 1 : NV];
+  // ---- one read of x and dy: every load of the thread issued before the first use --------------------------------
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const unsigned uo = (unsigned)(slot + k * NS) * (unsigned)C + (unsigned)c;
+    if (DY16) u16[k] = *reinterpret_cast<const uint2*>(dyh + uo);
+    else u32[k] = *reinterpret_cast<const float4*>(dyb + uo);
+#pragma unroll
+    for (int q = 0; q < PX; ++q) {
+      const unsigned o = pix_off(slot + k * NS, q);
+      float4 v;
+      if (x16) {
+        const uint2 t = *reinterpret_cast<const uint2*>(xs16 + o);
+        v = make_float4(__builtin_bit_cast(float, t.x << 16), __builtin_bit_cast(float, t.x & 0xffff0000u),
+                        __builtin_bit_cast(float, t.y << 16), __builtin_bit_cast(float, t.y & 0xffff0000u));
+      } else {
+        v = *reinterpret_cast<const float4*>(xs32 + o);
+      }
+      xh[k][q][0] = v.x; xh[k][q][1] = v.y; xh[k][q][2] = v.z; xh[k][q][3] = v.w;
+    }
+  }
+  auto up_of = [&](int k, float (&us)[4]) {
+    if (DY16) {
+      us[0] = __builtin_bit_cast(float, u16[k].x << 16); us[1] = __builtin_bit_cast(float, u16[k].x & 0xffff0000u);
+      us[2] = __builtin_bit_cast(float, u16[k].y << 16); us[3] = __builtin_bit_cast(float, u16[k].y & 0xffff0000u);
+    } else {
+      us[0] = u32[k].x; us[1] = u32[k].y; us[2] = u32[k].z; us[3] = u32[k].w;
+    }
+  };
+  // g of unit k, pixel q, channel j (pool routing to the first maximum in scan order, activation mask)
+  auto grads = [&](int k, float (&g)[PX][4]) {
+    float us[4];
+    up_of(k, us);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (POOLED) {
+        int am = 0;
+        float best = leaky(xh[k][0][j] * gm[j] + bt[j], slope);
+#pragma unroll
+        for (int q = 1; q < PX; ++q) {
+          const float a = leaky(xh[k][q][j] * gm[j] + bt[j], slope);
+          if (a > best) { best = a; am = q; }
+        }
+#pragma unroll
+        for (int q = 0; q < PX; ++q) g[q][j] = (q == am) ? us[j] * ((xh[k][q][j] * gm[j] + bt[j]) > 0.f ? 1.f : slope) : 0.f;
+      } else {
+        g[0][j] = us[j] * ((xh[k][0][j] * gm[j] + bt[j]) > 0.f ? 1.f : slope);
+      }
+    }
+  };
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+#pragma unroll
+    for (int q = 0; q < PX; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xh[k][q][j] = (xh[k][q][j] - mean[j]) * rstd[j];
+    float g[PX][4];
+    grads(k, g);
+#pragma unroll
+    for (int q = 0; q < PX; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s1[j] += g[q][j]; s2[j] += g[q][j] * xh[k][q][j]; }
+  }
+  // ---- block sums, fixed order: lanes of equal channel column inside the wave, then the waves in index order ----------
+#pragma unroll
+  for (int o = NC; o < 64; o <<= 1)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s1[j] += __shfl_xor(s1[j], o); s2[j] += __shfl_xor(s2[j], o); }
+  if (lane < NC) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sRed[wave][0][cl + j] = s1[j]; sRed[wave][1][cl + j] = s2[j]; }
+  }
+  __syncthreads();
+  if (tid < 2 * CG) {
+    const int which = tid / CG, ch = tid % CG;
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t += sRed[w][which][ch];
+    sM[which][ch] = t;
+    if (sums) sums[((size_t)b * 2 + which) * C + cg * CG + ch] = t;
+    if (which == 0 && dbeta) atomicAdd(dbeta + cg * CG + ch, t);
+    if (which == 1 && dgamma) atomicAdd(dgamma + cg * CG + ch, t);
+  }
+  __syncthreads();
+  const float inv_count = 1.f / (float)(H * W);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { s1[j] = sM[0][cl + j] * inv_count; s2[j] = sM[1][cl + j] * inv_count; }
+  // ---- apply from the registers ----------------------------------------------------------------------------------
+  float* dxb = reinterpret_cast<float*>(dxv) + (size_t)b * H * W * C;
+  unsigned short* dxh = reinterpret_cast<unsigned short*>(dxv) + (size_t)b * H * W * C;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    float g[PX][4];
+    grads(k, g);
+#pragma unroll
+    for (int q = 0; q < PX; ++q) {
+      const unsigned po = pix_off(slot + k * NS, q);
+      float o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = gm[j] * rstd[j] * (g[q][j] - s1[j] - xh[k][q][j] * s2[j]);
+      if (dx_bf16)
+        *reinterpret_cast<uint2*>(dxh + po) =
+            uint2{(unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16), (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16)};
+      else
+        *reinterpret_cast<float4*>(dxb + po) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // soft-max head of the sun-pose net (sunpose_net.py:64-70): z = relu(sum_s part[s] + bias),
 // cmf = softmax(z); also the running global max of cmf (generator.py:160 reduce_max over the
 // whole batch tensor) via an order-independent integer atomicMax on the (positive) float bits.
@@ -919,6 +1093,16 @@ int hdrsky_norm_act_bwd_nslices(int B, int H, int W, int C, int pooled) {
   return S < 1 ? 1 : S;
 }
 
+// Shapes the one-launch form takes (pixels - or 2x2 windows of the pooled form - per sample: the maps of the 32x128 network
+// and the 32x128 map of the 128x512 one).  HDRSKY_NAB_ONE=0: the sliced form (switch).
+int hdrsky_norm_act_bwd_one_launch(int H, int W, int pooled, int dy_bf16) {
+  (void)dy_bf16;
+  if (!hdrsky_hooks().nab_one) return 0;
+  const int units = pooled ? (H / 2) * (W / 2) : H * W;
+  if (pooled) return units == 1024 || units == 256;
+  return units == 4096 || units == 1024 || units == 256;
+}
+
 int hdrsky_norm_act_bwd(const float* x, const float* part, int nparts, const float* gamma, const float* beta,
                         float eps, float slope, const float* dy, int pooled, void* dx, int dx_bf16, float* sums,
                         float* dgamma, float* dbeta, float* ws, int B, int H, int W, int C, void* stream) {
@@ -926,6 +1110,32 @@ int hdrsky_norm_act_bwd(const float* x, const float* part, int nparts, const flo
   if (pooled && ((H | W) & 1)) return HDRSKY_EINVAL;
   const int S = hdrsky_norm_act_bwd_nslices(B, H, W, C, pooled);
   const int groups = B * (C / 16);
+  // the register-resident single launch (norm_act_bwd1_kernel) where a (sample, channel group) slab is NT x NV units
+  if (hdrsky_norm_act_bwd_one_launch(H, W, pooled, (dx_bf16 & 2) != 0)) {
+    const int units = pooled ? (H / 2) * (W / 2) : H * W;
+    const bool dy16 = (dx_bf16 & 2) != 0;
+#define HDRSKY_NAB1(NT_, NV_, CG_, P_)                                                                                              \
+    do {                                                                                                                             \
+      if ((C % CG_) != 0) return HDRSKY_EINVAL;                                                                                      \
+      if (dy16)                                                                                                                      \
+        hipLaunchKernelGGL((norm_act_bwd1_kernel<NT_, NV_, CG_, P_, true>), dim3(B * (C / CG_)), dim3(NT_), 0, (hipStream_t)stream, x, \
+                           part, nparts, gamma, beta, eps, slope, dy, dx, dx_bf16, sums, dgamma, dbeta, H, W, C);                      \
+      else                                                                                                                           \
+        hipLaunchKernelGGL((norm_act_bwd1_kernel<NT_, NV_, CG_, P_, false>), dim3(B * (C / CG_)), dim3(NT_), 0, (hipStream_t)stream, x, \
+                           part, nparts, gamma, beta, eps, slope, dy, dx, dx_bf16, sums, dgamma, dbeta, H, W, C);                      \
+    } while (0)
+    // units per sample -> (threads, units per thread, channels per workgroup): 64 (32 for the pooled form) values of xhat per
+    // thread at most - the 4096-pixel maps and the pooled forms on 8-channel groups
+    if (!pooled && units == 4096) HDRSKY_NAB1(1024, 8, 8, false);
+    else if (!pooled && units == 1024) HDRSKY_NAB1(1024, 4, 16, false);
+    else if (!pooled && units == 256) HDRSKY_NAB1(256, 4, 16, false);
+    else if (pooled && units == 1024) HDRSKY_NAB1(1024, 2, 8, true);
+    else if (pooled && units == 256) HDRSKY_NAB1(512, 2, 16, true);
+    else return HDRSKY_EINVAL;
+#undef HDRSKY_NAB1
+    HDRSKY_CHECK_LAUNCH();
+    return HDRSKY_OK;
+  }
   if (S == 1) {
     hipLaunchKernelGGL(norm_act_bwd_kernel<2>, dim3(groups), dim3(256), 0, (hipStream_t)stream, x, part, nparts, gamma,
                        beta, eps, slope, dy, pooled, dx, dx_bf16, sums, dgamma, dbeta, ws, 1, B, H, W, C);

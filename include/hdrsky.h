@@ -197,6 +197,10 @@ int hdrsky_norm_act_bwd(const float* x, const float* part, int nparts, const flo
  * which round it to bf16 while staging anyway: bit-neutral, half the bytes.) */
 /* Spatial slices S the call above splits each sample into; when S > 1 it needs the workspace ws [B][S][2][C]. [host] */
 int hdrsky_norm_act_bwd_nslices(int B, int H, int W, int C, int pooled);
+/* 1 when hdrsky_norm_act_bwd runs the call as ONE launch that reads x and dy once - the (sample, 8- or 16-channel group) slab held
+ * in the registers of one workgroup: 256 / 1024 / 4096 pixels (256 / 1024 windows of the pooled form) per sample; the workspace
+ * is then not touched.  HDRSKY_NAB_ONE=0 switches it off. [host] */
+int hdrsky_norm_act_bwd_one_launch(int H, int W, int pooled, int dy_bf16);
 
 /* ------------------------------------------------------------------------------------------
  * Sun-pose dense head (sunpose_net.py:48-52,64-70) and its Grad-CAM backward (grad_cam.py:29-44)

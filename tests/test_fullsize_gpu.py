@@ -294,8 +294,8 @@ def test_train_step_b32_bench_mode_against_the_oracle(dev):
     moves its own discriminator gradients by 2-8 %, tests/test_train_gpu.py - so they are checked twice: against the oracle's
     step at 6e-2 (measured 3.3 % / 4.0 %), and against the oracle's discriminator evaluated at OUR prediction at 2e-2, which
     is the bf16 error of the discriminator itself.  Prediction PSNR > 40 dB, whole-gradient cosine > 0.98, norm ratio within
-    5 %; the TEN LARGEST gradient tensors (99.6 % of the 55.6 M trainable scalars) each within a relative rms error of 0.25
-    (bf16 operand rounding, 2^-9 per product term, through ~30 layers of backward pass and the discrete masks)."""
+    5 %; the TEN LARGEST gradient tensors (99.6 % of the 55.6 M trainable scalars) each within TWICE the relative rms error this
+    build measures for it (0.04 ... 0.11: the table below)."""
     from oracle import networks as N
     from oracle import step as ostep
     tr, got, losses, gg, gs, sg, out, outs, dis, (ldr, hdr) = _step_vs_oracle(dev, "BF16", B)
@@ -321,7 +321,17 @@ def test_train_step_b32_bench_mode_against_the_oracle(dev):
     print("B = 32 bf16: psnr %.1f dB, gradient cosine %.5f, norm ratio %.4f" % (psnr, cos, ratio))
     print("ten largest tensors (rel max, rel rms, elements, name):", big)
     assert psnr > 40.0 and cos > 0.98 and abs(ratio - 1.0) < 5e-2, (psnr, cos, ratio)
-    assert max(r[1] for r in big) < 0.25, big
+    # per-tensor relative rms error of the ten largest tensors, asserted at 2x what this build measures (VERDICT r4 item 3;
+    # round-5 build, gpurun_out/r05a/pytest_s.txt: psnr 48.3 dB, cosine 0.99645, norm ratio 0.9586).  The error is bf16 operand
+    # rounding (2^-9 per product term) through ~30 layers of backward pass and the discrete masks: largest where the gradient is
+    # the small difference of many terms (the res blocks' kernels, the first Dense layer), smallest for the last Dense layer.
+    measured = {"sun.fc1.kernel": 0.110, "sun.fc2.kernel": 0.0431, "gen.sun.d4.conv.kernel": 0.0556, "gen.sun.d3.conv.kernel": 0.0680,
+                "gen.res.0.conv1.w": 0.1132, "gen.res.0.conv2.w": 0.0973, "gen.res.1.conv1.w": 0.1138, "gen.res.1.conv2.w": 0.0847,
+                "gen.res.2.conv1.w": 0.0988, "gen.res.2.conv2.w": 0.0819}
+    assert {r[3] for r in big} <= set(measured) | {"gen.res.%d.conv%d.w" % (i, j) for i in range(6) for j in (1, 2)}, big
+    for _, rms, _, name in big:
+        assert rms < 2.0 * measured.get(name, 0.114), "%s: relative rms error %.4f against the fp32 oracle, measured %.4f in round 5" % (
+            name, rms, measured.get(name, 0.114))
 
 
 def test_hires_train_step_b2_against_the_oracle(dev):

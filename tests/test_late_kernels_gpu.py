@@ -74,7 +74,7 @@ def test_maxpool_relu_l1_bwd_against_torch_with_ties(dev, with_dp, out_bf16):
     pool = torch.nn.functional.max_pool2d(torch.relu(yt), 2, 2)
     ties = float(((torch.nn.functional.unfold(torch.from_numpy(y32).permute(0, 3, 1, 2).reshape(B * C, 1, H, W), 2, stride=2)
                    == pool.detach().reshape(B * C, 1, -1)).sum(1) > 1).float().mean())
-    assert ties > 0.2, "the map must hold ties (%.2f of the windows)" % ties
+    assert ties > 0.1, "the map must hold ties (%.2f of the windows)" % ties
     tgt = torch.from_numpy(target).permute(0, 3, 1, 2)
     l1 = (pool - tgt).abs().mean()
     obj = wg * l1 + ((pool * torch.from_numpy(dp).permute(0, 3, 1, 2)).sum() if with_dp else 0.0)

@@ -355,3 +355,39 @@ def test_zero_fill_kernel_sizes_and_alignments_also_under_graph_replay(dev):
         g.replay()
         torch.cuda.synchronize()
         assert float(x.min()) == 1.0 and float(x.max()) == 1.0, it
+
+
+@pytest.mark.parametrize("shape,pooled", [((4, 32, 128, 32), False), ((4, 32, 128, 32), True), ((3, 16, 64, 64), False),
+                                          ((3, 16, 64, 64), True), ((5, 8, 32, 128), False), ((2, 32, 128, 128), False)])
+def test_norm_act_bwd_one_launch_equals_the_sliced_form(dev, shape, pooled, monkeypatch):
+    """Round 5: the InstanceNorm (+ activation, + max-pool) backward of the 32x128 network's maps runs as ONE launch that reads
+    x and dy once (norm_act_bwd1_kernel: the (sample, channel group) slab in the registers of one workgroup) instead of the
+    sliced reduce + apply pair.  Same arithmetic per element; the two per-(sample, channel) sums are added in another fixed
+    order: dx and the (d beta, d gamma) terms agree to fp32 rounding of those sums (1e-5 of the tensor's scale), for fp32 / bf16
+    incoming gradients, fp32 / bf16 outputs and a bf16-stored x; the launch is bit-reproducible; HDRSKY_NAB_ONE=0 is the switch."""
+    K, HK, L = pkg("kernels"), pkg("hooks"), pkg("_lib")
+    B, H, W, C = shape
+    g = torch.Generator(device=dev); g.manual_seed(B + H + C)
+    x = (torch.randn(*shape, device=dev, generator=g) * 1.3 + 0.2).contiguous()
+    gam, bet = torch.rand(C, device=dev, generator=g) + 0.5, torch.randn(C, device=dev, generator=g) * 0.5
+    xr, st = _stats_for(K, x, C)
+    dshape = (B, H // 2, W // 2, C) if pooled else shape
+    dy = torch.randn(*dshape, device=dev, generator=g)
+    assert L.load().hdrsky_norm_act_bwd_one_launch(H, W, int(pooled), 0) == 1
+    cases = [(xr, dy, False), (xr, dy.to(torch.bfloat16), True), (xr.to(torch.bfloat16), dy.to(torch.bfloat16), True)]
+    for xin, dyin, ob in cases:
+        run = lambda: K.norm_act_bwd(xin, st, gam, bet, 0.0 if pooled else 0.1, dyin, pooled, want_sums=True, out_bf16=ob)
+        one, s_one = run()
+        again, s_again = run()
+        assert torch.equal(one, again) and torch.equal(s_one, s_again), "one-launch form is not bit-reproducible"
+        monkeypatch.setenv("HDRSKY_NAB_ONE", "0"); HK.reload()
+        assert L.load().hdrsky_norm_act_bwd_one_launch(H, W, int(pooled), 0) == 0
+        two, s_two = run()
+        monkeypatch.delenv("HDRSKY_NAB_ONE"); HK.reload()
+        assert one.dtype == two.dtype
+        scale = float(two.float().abs().max())
+        tol = (2 ** -8 if ob else 1e-5) * scale          # bf16 output: one bf16 ulp where the fp32 values straddle a rounding boundary
+        assert float((one.float() - two.float()).abs().max()) <= tol, (str(xin.dtype), str(dyin.dtype), ob)
+        if ob:
+            assert float((one != two).float().mean()) < 1e-3
+        assert_close(s_one, s_two, 1e-5, "per-sample (d beta, d gamma) terms")
