@@ -716,13 +716,13 @@ def main():
         if do_fwd:
             nets = engine.Nets(gen, sun, device=dev, precise=False)
             roof_pw = roof_pw if roof_pw is not None else nets.pk["gen.res.0.conv1"]
-            if args.no_graph:
-                one_step, out = capture_forward(torch, lambda: engine.generator_forward(nets, ldr, compute=K.BF16, distortion_aware=args.da), dp, True)
-            else:
-                # one hipGraph per branch on its own stream (engine.ForwardGraphs): a single graph with the fork / join inside runs
-                # the two branches almost one after the other on this runtime (profiles/r04_fwd_timeline.txt)
-                fg = engine.ForwardGraphs(nets, ldr, compute=K.BF16, distortion_aware=args.da)
-                one_step, out = fg.replay, fg.out
+            # ONE hipGraph with the fork / join of the two branches inside.  Round 5 measured the alternative - one graph per branch
+            # on its own stream (engine.ForwardGraphs, profiles/fwd_branches.py -> profiles/r05_fwd_branches.txt): 0.571 ms against
+            # 0.509 ms.  The runtime does start the encoder branch of the single graph late (profiles/r04_fwd_timeline.txt), but
+            # that is no loss: side by side the two branches slow each other down by more than they overlap (sun branch 373 us
+            # alone, 499 us beside the encoder branch; encoder branch 237 -> 388 us) - the launches share the chip, they do not
+            # wait for it.
+            one_step, out = capture_forward(torch, lambda: engine.generator_forward(nets, ldr, compute=K.BF16, distortion_aware=args.da), dp, args.no_graph)
             dtf = timed(torch, dist, one_step, args.steps, args.warmup, dp, dev)
             assert torch.isfinite(out["y_final_lin"]).all()
             imgs = batch * world * args.steps
