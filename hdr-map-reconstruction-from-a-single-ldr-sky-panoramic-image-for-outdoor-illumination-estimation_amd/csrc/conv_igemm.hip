@@ -909,7 +909,44 @@ int dispatch_tile(ConvKArgs& a, const TileCfg& t, hipStream_t s) {
 
 // Tile heuristic: widest N block the layer fills, then the largest pixel tile that still
 // yields >= ~1 workgroup per CU (256 CUs), preferring more workgroups for small problems.
-TileCfg choose_tile(const hdrsky_conv_desc* d) {
+TileCfg choose_tile_r4(const hdrsky_conv_desc* d);
+
+// Round 5: the table re-measured in a second regime - the chip full of waves of the launch's own kind (three streams replaying
+// graphs of the launch: profiles/tile_sweep.py -> profiles/r05_tile_sweep.txt) - beside the launch's latency alone on the chip,
+// which rounds 1-3 tuned (choose_tile_r4 below).  Saturated, the kernel is bound by its LDS fragment reads (one 1 KB A fragment
+// per MFMA with NI = 1: twice the MFMA time), the staging burst and the epilogue burst.  A first version that took the best
+// SATURATED tile of every class (-12 % summed over the step's launches in that regime) made the step 0.8 % SLOWER
+// (profiles/r05_tile_table_ab.txt): the step's dependent chains pay the latency of a launch, and a fatter tile holds its compute
+// unit longer against the launches of the other two streams.  What is kept are the entries that win saturated by >= 10 % WITHOUT
+// losing alone.  `ph`: the launch is a stride-2 data gradient by output phases.
+// HDRSKY_TILE_TABLE=4: round 4's table (switch: A/B and bit-identity tests - a tile changes the statistics partials' order).
+TileCfg choose_tile(const hdrsky_conv_desc* d, bool ph = false) {
+  const HdrskyHooks& hk = hdrsky_hooks();
+  TileCfg t = choose_tile_r4(d);
+  if (hk.tile_table == 4 || hk.tile.set || d->compute == HDRSKY_BF16X3) return t;
+  const long M = (long)d->B * d->Ho * d->Wo;
+  if (M >= 262144 || d->Wo < 32) return t;        // (the 128x512 network and the 4x16 maps: round 4's entries)
+  const bool narrow = d->Cin <= 8;
+  if (d->Cout >= 64) {
+    if (narrow) return t;
+    if (d->Cout >= 128 && d->Cout < 256 && M == 16384) t = TileCfg{1, 8, 4, 1, 32, 1};   // 64->128 / 128->128 at 16x64, batch 16, and their transposes: 64 px x 128 ch (alone -4..-8 %, saturated -26..-30 %)
+    else if (d->Cout < 128 && M > 16384) {
+      if (ph) t = TileCfg{2, 2, 4, 2, 32, 1};                                            // stride-2 data gradients by phases -> 64 channels (alone +-0, saturated -22..-29 %)
+      else if (d->Cin <= 32 && M >= 65536) t = TileCfg{8, 1, 4, 2, 32, 0};               // 3x3 32->64 at full resolution (decoder data gradient: alone -10 %, saturated -21 %)
+      else if (d->Cin <= 32 && M <= 32768) t = TileCfg{1, 4, 4, 1, 32, 1};               // 3x3 32->64 at 16x64 (alone -3 %, saturated -12 %)
+    }
+  } else if (d->Cout > 16) {
+    if (M >= 65536 && !hk.tile_c32.set) {
+      if (narrow && d->want_stats) t = TileCfg{8, 1, 4, 2, 32, 0};                       // 7x7 3->32 forward: the ring on 512 px (alone +-0, saturated -31 %)
+      else if (!narrow && !ph && d->KH == 3) t = TileCfg{4, 2, 4, 1, 32, 1};             // 3x3 64->32 at full resolution: direct-B 256 px x 32 ch (alone +1 %, saturated -12 %)
+    }
+  } else {
+    if (M >= 65536 && !ph && d->KH >= 7 && !hk.tile_c16.set) t = TileCfg{8, 1, 4, 1, 32, 1};   // 7x7 32->3: 512 px x 16 ch (alone -8 %, saturated -33 %)
+  }
+  return t;
+}
+
+TileCfg choose_tile_r4(const hdrsky_conv_desc* d) {
   const HdrskyHooks& hk = hdrsky_hooks();
   auto hooked = [](const HdrskyTileHook& h, TileCfg& t) {   // a tuning hook (HDRSKY_EXPERIMENTS=1) replaces the table's entry
     if (h.set) t = TileCfg{h.v[0], h.v[1], h.v[2], h.v[3], h.v[4], h.v[5]};
@@ -1156,7 +1193,7 @@ int hdrsky_conv_kernel_name(const hdrsky_conv_desc* d, char* buf, int n) {
   if (dot1_applies(d, nullptr)) { snprintf(buf, (size_t)n, "conv_dot1_kernel"); return HDRSKY_OK; }
   hdrsky_conv_desc pv = *d;
   if (phase_applies(d)) pv = phase_view(d);   // (an odd filter over several channel groups falls back at launch: not seen here)
-  const TileCfg t = choose_tile(&pv);
+  const TileCfg t = choose_tile(&pv, phase_applies(d));
   snprintf(buf, (size_t)n, "conv_igemm_kernel<%d, %d, %d, %d, %d, %s, %s, %s, %s, false>", t.wm, t.wn, t.mi, t.ni, t.tw,
            d->Cin <= 8 ? "true" : "false", d->compute == HDRSKY_BF16X3 ? "true" : "false", t.db ? "true" : "false",
            phase_applies(d) ? "true" : "false");
@@ -1250,7 +1287,7 @@ static int conv2d_fwd_impl(const hdrsky_conv_desc* d, const float* x, const void
     p.phase = 1; p.KHf = d->KH; p.KWf = d->KW; p.KH = (d->KH + 1) / 2; p.KW = (d->KW + 1) / 2;
     p.dilate = 1; p.Hc = d->H; p.Wc = d->W;            // the operand is the gradient itself
     const hdrsky_conv_desc pv = phase_view(d);
-    const TileCfg tp = choose_tile(&pv);
+    const TileCfg tp = choose_tile(&pv, true);
     const int rc = dispatch_tile<false, false, true>(p, tp, s);
     // the phase form declined (odd filter over several channel groups) or has no instantiation / LDS plan for the tile of
     // its phase grid: the zero-stuffed form below computes the same gradient

@@ -20,6 +20,7 @@ struct HdrskyHooks {
   int no_dot1;         // HDRSKY_NO_DOT1     the one-output-channel conv through the MFMA tile instead of conv_dot1_kernel
   int wgrad2;          // HDRSKY_WGRAD2      0: weight gradients never on conv_wgrad2_kernel (default 1)
   int wgrad3;          // HDRSKY_WGRAD3      0: ... never on conv_wgrad3_kernel (default 1)
+  int tile_table;      // HDRSKY_TILE_TABLE  4: the tile table of rounds 1-4 (tuned on launch latency alone); default 5: re-measured saturated
   int nab_one;         // HDRSKY_NAB_ONE     0: InstanceNorm backward never on the one-launch register-resident kernel (default 1)
   // ---- tuning hooks (HDRSKY_EXPERIMENTS=1) --------------------------------------------------------------------------
   int experiments;

@@ -37,6 +37,7 @@ void read_hooks() {
   h.wgrad2 = env_int("HDRSKY_WGRAD2", 1) != 0;
   h.wgrad3 = env_int("HDRSKY_WGRAD3", 1) != 0;
   h.nab_one = env_int("HDRSKY_NAB_ONE", 1) != 0;
+  h.tile_table = env_int("HDRSKY_TILE_TABLE", 5);
   h.experiments = env_int("HDRSKY_EXPERIMENTS", 0) == 1;
   // tuning hooks: their defaults unless the gate is open
   h.wgrad2_s2min = 32; h.wgrad2_mint = 2; h.wgrad2_wgs = 0; h.wgrad3_minpx = 256; h.wgrad3_wgs = 256;

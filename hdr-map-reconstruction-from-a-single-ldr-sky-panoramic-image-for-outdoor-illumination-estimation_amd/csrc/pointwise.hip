@@ -1126,7 +1126,7 @@ int hdrsky_norm_act_bwd(const float* x, const float* part, int nparts, const flo
     } while (0)
     // units per sample -> (threads, units per thread, channels per workgroup): 64 (32 for the pooled form) values of xhat per
     // thread at most - the 4096-pixel maps and the pooled forms on 8-channel groups
-    if (!pooled && units == 4096) HDRSKY_NAB1(1024, 8, 8, false);
+    if (!pooled && units == 4096) { if (dy16) HDRSKY_NAB1(1024, 16, 16, false); else HDRSKY_NAB1(1024, 8, 8, false); }
     else if (!pooled && units == 1024) HDRSKY_NAB1(1024, 4, 16, false);
     else if (!pooled && units == 256) HDRSKY_NAB1(256, 4, 16, false);
     else if (pooled && units == 1024) HDRSKY_NAB1(1024, 2, 8, true);

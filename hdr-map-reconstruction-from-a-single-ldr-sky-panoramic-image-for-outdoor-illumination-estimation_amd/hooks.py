@@ -34,6 +34,8 @@ class _Hooks:
         # the forward conv writes its transformed operand as bf16 for the layer's weight gradient (no hdrsky_act_bf16 launch)
         self.emit_xb = exp("HDRSKY_EMIT_XB", "1") != "0"
         self.disc_split = exp("HDRSKY_DISC_SPLIT", "0") == "1"
+        # the perceptual term's prediction pass as two half batches on two streams (1), or as one pass on stream 1 (0)
+        self.vgg_split = exp("HDRSKY_VGG_SPLIT", "1") != "0"
         self.dec_head_early = exp("HDRSKY_DEC_HEAD_EARLY", "1") != "0"
         self.bwd_dense_stream = int(exp("HDRSKY_BWD_DENSE_STREAM", "2"))
         self.wg_res_stream = int(exp("HDRSKY_WG_RES_STREAM", "1"))

@@ -933,7 +933,7 @@ class Trainer:
 
         # 0.01 * perceptual: the longest pole between the forward pass and the backward pass, and the main chain idles
         # meanwhile - the batch is split in two halves that run on two streams (the L1 terms are batch means)
-        half = B // 2
+        half = B // 2 if HOOKS.H.vgg_split else 0      # (HDRSKY_VGG_SPLIT=0: one pass over the whole batch on stream 1, A/B hook)
 
         @seg("loss_vgg", 1, ["fwd_blend", "vgg_target"])
         def _():
@@ -959,7 +959,7 @@ class Trainer:
             T["din_adv"] = din        # (channels 3..5 = d / d prediction: picked up by the head's backward launch)
 
         # ------------------------------------------------------------------ backward, first stretch
-        @seg("bwd_head", 0, ["loss_vgg", "loss_vgg_b"])
+        @seg("bwd_head", 0, ["loss_vgg", "loss_vgg_b"] if half > 0 else ["loss_vgg"])
         def _():       # blend -> decoder tails -> sun radiance head -> dcmf complete -> sun-pose Dense layers
             t, dyl = T["t"], T["dyl"]
             (yf, rf), (yu, ru) = (T["dec_f"][6], T["dec_f"][7]), (T["dec_u"][6], T["dec_u"][7])
