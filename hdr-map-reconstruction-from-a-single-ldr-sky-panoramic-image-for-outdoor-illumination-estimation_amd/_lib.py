@@ -68,6 +68,10 @@ SIGNATURES = {
     "hdrsky_conv2d_fwd": (c_int, [ctypes.POINTER(ConvDesc)] + [P] * 13),
     "hdrsky_conv2d_emit_supported": (c_int, [ctypes.POINTER(ConvDesc)]),
     "hdrsky_conv2d_fwd_emit": (c_int, [ctypes.POINTER(ConvDesc)] + [P] * 14),
+    "hdrsky_conv2d_fwd_pair": (c_int, [ctypes.POINTER(ConvDesc), P, c_int] + [P] * 18),
+    "hdrsky_in_affine_pair": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, P, c_float, P, P, P]),
+    "hdrsky_norm_act_bwd_pair": (c_int, [P, P, c_int, P, P, P, P, c_float, c_float, P, c_int, P, c_int, P, P, c_int, c_int, c_int, c_int, P]),
+    "hdrsky_up2x_xf_bf16_pair": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, c_float, c_float, P, P]),
     "hdrsky_conv2d_wgrad": (c_int, [ctypes.POINTER(ConvDesc)] + [P] * 10),
     "hdrsky_conv2d_wgrad_multi": (c_int, [ctypes.POINTER(WgradJob), c_int, P]),
     "hdrsky_conv2d_wgrad_ws_bytes": (c_size_t, [ctypes.POINTER(WgradJob), c_int]),

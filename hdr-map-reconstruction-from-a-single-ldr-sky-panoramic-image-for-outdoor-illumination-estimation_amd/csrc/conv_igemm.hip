@@ -60,6 +60,11 @@ struct ConvKArgs {
   // the output; KH / KW are then the per-phase tap counts ceil(K / 2), KHf / KWf the full (flipped) filter, pad_t / pad_l
   // the full conv's K - 1 - pad, H / W (= Hc / Wc) the un-stuffed gradient
   int phase, KHf, KWf;
+  // PAIRED launch (hdrsky_conv2d_fwd_pair): two layers of identical geometry in one grid - samples [0, gsplit) use the first
+  // parameter set (whi, wlo, bias, in_gamma, in_beta, residual), samples [gsplit, B) the second (the *2 pointers).  x_shared:
+  // both halves read the same gsplit input samples (two layers on one input).  gsplit == 0: an ordinary launch.
+  const uint4* whi2; const uint4* wlo2; const float* bias2; const float* in_gamma2; const float* in_beta2; const float* residual2;
+  int gsplit, x_shared;
 };
 
 // Packed-filter k-step of phase tap `tapp` (ky', kx' of the per-phase KH x KW grid), channel block cb: the full filter's
@@ -157,8 +162,8 @@ __device__ __forceinline__ void compute_chunk(const ConvKArgs& a, const unsigned
     else if (PH) kp_ = phase_kp(a, ks_ >> a.log2cbg, (g << a.log2cbg) + (ks_ & ((1 << a.log2cbg) - 1)), cin32, ph); \
     else kp_ = (ks_ >> a.log2cbg) * cin32 + (g << a.log2cbg) + (ks_ & ((1 << a.log2cbg) - 1));           \
     const size_t src_ = (size_t)(kp_ * 4) * a.Npad + boff;                                                \
-    glds16(a.whi + src_, sb_lds + (((buf_) * BPLANES + 0) * BITEMS + wave_base + j * NT) * 16);           \
-    if (PRECISE) glds16(a.wlo + src_, sb_lds + (((buf_) * BPLANES + 1) * BITEMS + wave_base + j * NT) * 16); \
+    glds16(whi + src_, sb_lds + (((buf_) * BPLANES + 0) * BITEMS + wave_base + j * NT) * 16);           \
+    if (PRECISE) glds16(wlo + src_, sb_lds + (((buf_) * BPLANES + 1) * BITEMS + wave_base + j * NT) * 16); \
   }
 // 8-wave variants are compiled for 4 waves per SIMD (<= 128 VGPRs; they need 77-106 and no scratch): two workgroups
 // then fit a CU, which is what lets kernels of the other streams of the training step overlap with this one.
@@ -167,7 +172,10 @@ __device__ __forceinline__ void compute_chunk(const ConvKArgs& a, const unsigned
 // EMIT: the instantiations that also write the transformed operand (ConvKArgs::xb_out) - their own, because the extra address
 // registers of the staging pushed the 8-wave variants at their 128-VGPR budget into a spill around the k loop (+3.5 % on the
 // training step when every launch paid for it; as instantiations only the nine launches per step that emit do)
-template <int WM, int WN, int MI, int NI, int TW, bool NARROW, bool PRECISE, bool DB, bool PH, bool EMIT = false>
+// PAIR: the instantiations of the paired launches (ConvKArgs::gsplit) - their own for the reason EMIT's are: the second parameter
+// set's scalars pushed the 8-wave direct-B variants at their 128-VGPR budget into a spill around the k loop when every launch
+// carried them (four plain instantiations went from 0 to 36 B of scratch); only the tiles the paired layers take are instantiated
+template <int WM, int WN, int MI, int NI, int TW, bool NARROW, bool PRECISE, bool DB, bool PH, bool EMIT = false, bool PAIR = false>
 __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB ? 4 : 2) : 1) conv_igemm_kernel(const ConvKArgs a) {
   constexpr int NW = WM * WN;                // waves per workgroup (4 or 8)
   constexpr int NT = NW * 64;
@@ -222,6 +230,16 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB
     const int py = ph >> 1, px = ph & 1;
     pad_t = -((py + ((a.pad_t - py) & 1) - a.pad_t) >> 1); pad_l = -((px + ((a.pad_l - px) & 1) - a.pad_l) >> 1);   // (even numerators: exact)
   }
+  // paired launch: the second half of the batch runs on the second layer's parameters (workgroup-uniform scalar selects)
+  const bool g1 = PAIR && b >= a.gsplit;
+  const uint4* const whi = g1 ? a.whi2 : a.whi;
+  const uint4* const wlo = g1 ? a.wlo2 : a.wlo;
+  const float* const bias = g1 ? a.bias2 : a.bias;
+  const float* const in_gamma = g1 ? a.in_gamma2 : a.in_gamma;
+  const float* const in_beta = g1 ? a.in_beta2 : a.in_beta;
+  const float* const residual = g1 ? a.residual2 : a.residual;
+  const int bx = (g1 && a.x_shared) ? b - a.gsplit : b;      // sample of the INPUT tensor (and of its transform tables)
+  const int br = g1 ? b - a.gsplit : b;                      // sample inside the group's own residual tensor
   const int oy0 = ty * TH, ox0 = tx * TW, n0 = nb * BN;    // (phase mode: coordinates on the phase's own grid)
   const int iy0 = oy0 * a.stride - pad_t, ix0 = ox0 * a.stride - pad_l;
 
@@ -246,18 +264,18 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB
   }
   if (a.in_mode == HDRSKY_IN_AFFINE) {
     for (int c = tid; c < a.Cin; c += NT) {
-      sScale[c] = a.in_scale[b * a.ss_bstride + c];
-      sShift[c] = a.in_shift[b * a.ss_bstride + c];
+      sScale[c] = a.in_scale[bx * a.ss_bstride + c];
+      sShift[c] = a.in_shift[bx * a.ss_bstride + c];
     }
   } else if (a.in_mode == HDRSKY_IN_PARTIALS) {
     for (int c = tid; c < a.Cin; c += NT) {
       float s, ss;
-      in_partial_sums(a.in_part + (size_t)b * a.in_nparts * 2 * a.Cin + c, a.in_nparts, a.Cin, s, ss);
+      in_partial_sums(a.in_part + (size_t)bx * a.in_nparts * 2 * a.Cin + c, a.in_nparts, a.Cin, s, ss);
       const float mean = s * a.in_inv_count;
       const float var = fmaxf(ss * a.in_inv_count - mean * mean, 0.f);
-      const float inv = a.in_gamma[c] / sqrtf(var + a.in_eps);
+      const float inv = in_gamma[c] / sqrtf(var + a.in_eps);
       sScale[c] = inv;
-      sShift[c] = a.in_beta[c] - mean * inv;
+      sShift[c] = in_beta[c] - mean * inv;
     }
   } else {
     for (int c = tid; c < a.Cin; c += NT) { sScale[c] = 1.f; sShift[c] = 0.f; }
@@ -307,7 +325,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB
         const int hx = p - hy * a.WT;
         const int cy = iy0 + hy, cx = ix0 + hx;
         const bool ok = cy >= 0 && cy < a.Hc && cx >= 0 && cx < a.Wc;
-        const float* src = a.x + ((size_t)(b * a.H + (ok ? cy : 0)) * a.W + (ok ? cx : 0)) * a.Cin;
+        const float* src = a.x + ((size_t)(bx * a.H + (ok ? cy : 0)) * a.W + (ok ? cx : 0)) * a.Cin;
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -323,7 +341,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB
     } else {
       const int nq = 1 << a.log2nq;
       const int nitems = a.NPIX << a.log2nq;
-      const float* xb = a.x + (size_t)b * a.H * a.W * a.Cin + g * a.cgs;
+      const float* xb = a.x + (size_t)bx * a.H * a.W * a.Cin + g * a.cgs;
       // NT % nq == 0, so a thread always stages the same 8-channel chunk: its affine lives in registers
       const int qt = tid & (nq - 1);
       float sc8[8], sh8[8];
@@ -403,7 +421,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB
             }
             if (!PRECISE && a.x_bf16) {   // workgroup-uniform: a final bf16 activation is copied, not converted
               va[u] = __builtin_bit_cast(float4, *reinterpret_cast<const uint4*>(
-                                                     reinterpret_cast<const unsigned short*>(a.x) + (size_t)b * a.H * a.W * a.Cin + g * a.cgs + eo));
+                                                     reinterpret_cast<const unsigned short*>(a.x) + (size_t)bx * a.H * a.W * a.Cin + g * a.cgs + eo));
             } else {
               va[u] = *reinterpret_cast<const float4*>(xb + eo);
               vb[u] = *reinterpret_cast<const float4*>(xb + eo + 4);
@@ -464,8 +482,8 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB
       // registers; a fragment's register is refilled right after the MFMAs that consumed it issue.
       __syncthreads();  // operand planes staged
       constexpr int DPF = (NI == 1) ? 8 : 4;
-      const uint4* wlh = a.whi + (size_t)kq * a.Npad + n0 + (wn * NI) * 16 + lr;
-      const uint4* wll = PRECISE ? a.wlo + (size_t)kq * a.Npad + n0 + (wn * NI) * 16 + lr : nullptr;
+      const uint4* wlh = whi + (size_t)kq * a.Npad + n0 + (wn * NI) * 16 + lr;
+      const uint4* wll = PRECISE ? wlo + (size_t)kq * a.Npad + n0 + (wn * NI) * 16 + lr : nullptr;
       const unsigned kstride = 4u * (unsigned)a.Npad;   // uint4 elements per k-step; 32-bit offsets: the packed filter is < 2^32 elements
       uint4 bqh[DPF][NI], bql[DPF][NI];
       auto kp_of = [&](int ks) {
@@ -638,7 +656,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB
   const int n = n0 + c4 * 4;
   float bias4[4], cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int e = 0; e < 4; ++e) bias4[e] = (a.bias != nullptr && n + e < a.Cout) ? a.bias[n + e] : 0.f;
+  for (int e = 0; e < 4; ++e) bias4[e] = (bias != nullptr && n + e < a.Cout) ? bias[n + e] : 0.f;
   const bool vec = ((a.Cout & 3) == 0) && (n + 3 < a.Cout);
 #pragma unroll
   for (int it = 0; it * PPI < BM; ++it) {
@@ -650,21 +668,22 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB
       const float4 t = *reinterpret_cast<const float4*>(sOut + m * BNP + c4 * 4);
       float v[4] = {t.x + bias4[0], t.y + bias4[1], t.z + bias4[2], t.w + bias4[3]};
       const size_t idx = ((size_t)(b * a.Ho + oy) * a.Wo + ox) * a.Cout + n;
+      const size_t ridx = ((size_t)(br * a.Ho + oy) * a.Wo + ox) * a.Cout + n;      // inside the group's residual / mask tensor
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         if (n + e < a.Cout) { cs[e] += v[e]; cq[e] += v[e] * v[e]; }
         v[e] = leaky(v[e], a.out_slope);
       }
       if (vec) {
-        if (a.residual != nullptr) {
+        if (residual != nullptr) {
           if (a.res_mode == 1) {   // bf16 activated tensor: gradient mask of the activation behind this data gradient
-            const uint2 mk = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(a.residual) + idx);
+            const uint2 mk = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(residual) + ridx);
             const float m4[4] = {__builtin_bit_cast(float, mk.x << 16), __builtin_bit_cast(float, mk.x & 0xffff0000u),
                                  __builtin_bit_cast(float, mk.y << 16), __builtin_bit_cast(float, mk.y & 0xffff0000u)};
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] *= (m4[e] > 0.f ? 1.f : a.mask_slope);
           } else {
-            const float4 r = *reinterpret_cast<const float4*>(a.residual + idx);
+            const float4 r = *reinterpret_cast<const float4*>(residual + ridx);
             v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
           }
         }
@@ -682,7 +701,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB
         for (int e = 0; e < 4; ++e)
           if (n + e < a.Cout) {
             float o = v[e];
-            if (a.residual != nullptr) o += a.residual[idx + e];
+            if (residual != nullptr) o += residual[ridx + e];
             if (a.final_relu) o = fmaxf(o, 0.f);
             a.y[idx + e] = o;
           }
@@ -816,7 +835,7 @@ struct TileCfg { int wm, wn, mi, ni, tw, db; };
 
 constexpr int HDRSKY_EPHASE_FALLBACK = -1000;   // internal: launch_conv declines the phase form of a stride-2 data gradient
 
-template <int WM, int WN, int MI, int NI, int TW, bool NARROW, bool PRECISE, bool DB, bool PH, bool EMIT = false>
+template <int WM, int WN, int MI, int NI, int TW, bool NARROW, bool PRECISE, bool DB, bool PH, bool EMIT = false, bool PAIR = false>
 int launch_conv(ConvKArgs& a, hipStream_t stream) {
   constexpr int BM = WM * MI * 16, BN = WN * NI * 16, TH = BM / TW;
   a.tiles_x = cdiv(PH ? cdiv(a.Wo, 2) : a.Wo, TW);    // phase mode: tiles of one phase's grid, four phases per sample
@@ -869,7 +888,7 @@ int launch_conv(ConvKArgs& a, hipStream_t stream) {
   a.off_out = 0;
   if (DB && roundup(lds, 16) + out_bytes <= 80 * 1024) { a.off_out = roundup(lds, 16); lds = a.off_out + out_bytes; }   // (two workgroups per CU must still fit)
   if (lds > 160 * 1024) return HDRSKY_EUNSUPPORTED;
-  auto kern = conv_igemm_kernel<WM, WN, MI, NI, TW, NARROW, PRECISE, DB, PH, EMIT>;
+  auto kern = conv_igemm_kernel<WM, WN, MI, NI, TW, NARROW, PRECISE, DB, PH, EMIT, PAIR>;
   static std::atomic<int> max_lds_set{0};
   if (lds > max_lds_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -904,6 +923,20 @@ int dispatch_tile(ConvKArgs& a, const TileCfg& t, hipStream_t s) {
   HDRSKY_CASE_DB(1, 8, 2, 1, 16)
 #undef HDRSKY_CASE_DB
 #undef HDRSKY_CASE
+  return HDRSKY_EUNSUPPORTED;
+}
+
+// The paired launches' instantiations (single-product mode, no phases, no emit): the tiles the decoder layers and their data
+// gradients take at batch 32 and at the 128x512 network's batch 8; another tile -> HDRSKY_EUNSUPPORTED (the caller issues the
+// two launches)
+template <bool NARROW>
+int dispatch_tile_pair(ConvKArgs& a, const TileCfg& t, hipStream_t s) {
+#define HDRSKY_PCASE(WM_, WN_, MI_, NI_, TW_, DB_)                                                         \
+  if ((t.db != 0) == DB_ && t.wm == WM_ && t.wn == WN_ && t.mi == MI_ && t.ni == NI_ && t.tw == TW_)    \
+    return launch_conv<WM_, WN_, MI_, NI_, TW_, NARROW, false, DB_, false, false, true>(a, s);
+  HDRSKY_PCASE(2, 4, 4, 1, 32, true) HDRSKY_PCASE(4, 2, 4, 1, 32, true) HDRSKY_PCASE(8, 1, 4, 1, 32, true) HDRSKY_PCASE(4, 1, 4, 1, 32, true)
+  HDRSKY_PCASE(2, 4, 4, 2, 32, true) HDRSKY_PCASE(2, 2, 4, 1, 32, true) HDRSKY_PCASE(8, 1, 4, 2, 32, false) HDRSKY_PCASE(2, 4, 2, 1, 32, true)
+#undef HDRSKY_PCASE
   return HDRSKY_EUNSUPPORTED;
 }
 
@@ -1217,10 +1250,12 @@ int hdrsky_conv2d_emit_supported(const hdrsky_conv_desc* d) {
   return 1;
 }
 
+struct ConvPair { const void* w_hi2; const void* w_lo2; const float* bias2; const float* in_gamma2; const float* in_beta2;
+                  const float* residual2; int x_shared; };
 static int conv2d_fwd_impl(const hdrsky_conv_desc* d, const float* x, const void* w_hi, const void* w_lo,
                            const float* bias, const float* in_scale, const float* in_shift, const float* in_part,
                            const float* in_gamma, const float* in_beta, const float* residual, float* y,
-                           float* stats_part, void* xb_out, void* stream);
+                           float* stats_part, void* xb_out, void* stream, const ConvPair* pair = nullptr);
 
 int hdrsky_conv2d_fwd(const hdrsky_conv_desc* d, const float* x, const void* w_hi, const void* w_lo,
                       const float* bias, const float* in_scale, const float* in_shift, const float* in_part,
@@ -1240,10 +1275,30 @@ int hdrsky_conv2d_fwd_emit(const hdrsky_conv_desc* d, const float* x, const void
   return conv2d_fwd_impl(d, x, w_hi, w_lo, bias, in_scale, in_shift, in_part, in_gamma, in_beta, residual, y, stats_part, xb_out, stream);
 }
 
+// Two layers of identical geometry as ONE launch (round 5: the sky / sun decoder pairs of generator.py:110-156 and their data
+// gradients - identical shapes issued twice per step): d->B = 2 x the layers' batch; samples [0, B/2) run on (w_hi, w_lo, bias,
+// in_gamma, in_beta, residual), samples [B/2, B) on the *2 set; x_shared != 0: x holds B/2 samples that BOTH layers read (no
+// operand transform then); in_scale / in_shift / in_part are tables of the whole batch as for any launch.  The tile is the one a
+// launch of B/2 samples takes and a sample's arithmetic does not depend on its neighbours: y, the statistics partials and
+// everything downstream are bit-identical to the two separate launches (tests/test_pair_gpu.py).
+int hdrsky_conv2d_fwd_pair(const hdrsky_conv_desc* d, const float* x, int x_shared, const void* w_hi, const void* w_lo, const float* bias,
+                           const void* w_hi2, const void* w_lo2, const float* bias2, const float* in_scale, const float* in_shift,
+                           const float* in_part, const float* in_gamma, const float* in_beta, const float* in_gamma2,
+                           const float* in_beta2, const float* residual, const float* residual2, float* y, float* stats_part,
+                           void* stream) {
+  if (!d || (d->B & 1) || !w_hi2) return HDRSKY_EINVAL;
+  if ((bias != nullptr) != (bias2 != nullptr) || (residual != nullptr) != (residual2 != nullptr)) return HDRSKY_EINVAL;
+  if (d->compute == HDRSKY_BF16X3 && !w_lo2) return HDRSKY_EINVAL;
+  if (d->in_mode == HDRSKY_IN_PARTIALS && (!in_gamma2 || !in_beta2)) return HDRSKY_EINVAL;
+  if (x_shared && (d->in_mode != HDRSKY_IN_NONE)) return HDRSKY_EUNSUPPORTED;
+  const ConvPair pr{w_hi2, w_lo2, bias2, in_gamma2, in_beta2, residual2, x_shared};
+  return conv2d_fwd_impl(d, x, w_hi, w_lo, bias, in_scale, in_shift, in_part, in_gamma, in_beta, residual, y, stats_part, nullptr, stream, &pr);
+}
+
 static int conv2d_fwd_impl(const hdrsky_conv_desc* d, const float* x, const void* w_hi, const void* w_lo,
                            const float* bias, const float* in_scale, const float* in_shift, const float* in_part,
                            const float* in_gamma, const float* in_beta, const float* residual, float* y,
-                           float* stats_part, void* xb_out, void* stream) {
+                           float* stats_part, void* xb_out, void* stream, const ConvPair* pair) {
   if (!d || !x || !w_hi || !y) return HDRSKY_EINVAL;
   const bool narrow = d->Cin <= 8;
   if (!narrow && (d->Cin % 32) != 0) return HDRSKY_EUNSUPPORTED;
@@ -1275,6 +1330,16 @@ static int conv2d_fwd_impl(const hdrsky_conv_desc* d, const float* x, const void
   a.x_bf16 = d->x_bf16; a.y_bf16 = d->y_bf16; a.res_mode = d->res_mode; a.mask_slope = d->mask_slope;
   a.xb_out = (unsigned short*)xb_out;
   hipStream_t s = (hipStream_t)stream;
+  hdrsky_conv_desc dt = *d;              // what the tile is chosen on: a paired launch takes the tile of ONE of its layers
+  if (pair) {
+    a.whi2 = (const uint4*)pair->w_hi2; a.wlo2 = (const uint4*)pair->w_lo2; a.bias2 = pair->bias2;
+    a.in_gamma2 = pair->in_gamma2; a.in_beta2 = pair->in_beta2; a.residual2 = pair->residual2;
+    a.gsplit = d->B / 2; a.x_shared = pair->x_shared;
+    dt.B = d->B / 2;
+    if (dot1_applies(d, residual) || xb_out || precise || phase_applies(d)) return HDRSKY_EUNSUPPORTED;
+    const TileCfg tp = choose_tile(&dt);
+    return narrow ? dispatch_tile_pair<true>(a, tp, s) : dispatch_tile_pair<false>(a, tp, s);
+  }
   if (dot1_applies(d, residual)) {       // one output channel: a dot product per pixel, not a 16-column MFMA tile
     a.ntaps = d->KH * d->KW;
     if (!precise) a.wlo = nullptr;
@@ -1286,14 +1351,14 @@ static int conv2d_fwd_impl(const hdrsky_conv_desc* d, const float* x, const void
     ConvKArgs p = a;
     p.phase = 1; p.KHf = d->KH; p.KWf = d->KW; p.KH = (d->KH + 1) / 2; p.KW = (d->KW + 1) / 2;
     p.dilate = 1; p.Hc = d->H; p.Wc = d->W;            // the operand is the gradient itself
-    const hdrsky_conv_desc pv = phase_view(d);
+    const hdrsky_conv_desc pv = phase_view(&dt);
     const TileCfg tp = choose_tile(&pv, true);
     const int rc = dispatch_tile<false, false, true>(p, tp, s);
     // the phase form declined (odd filter over several channel groups) or has no instantiation / LDS plan for the tile of
     // its phase grid: the zero-stuffed form below computes the same gradient
     if (rc != HDRSKY_EPHASE_FALLBACK && rc != HDRSKY_EUNSUPPORTED) return rc;
   }
-  const TileCfg t = choose_tile(d);
+  const TileCfg t = choose_tile(&dt);
   if (narrow) return precise ? dispatch_tile<true, true>(a, t, s) : dispatch_tile<true, false>(a, t, s);
   if (a.xb_out != nullptr) return dispatch_tile<false, false, false, true>(a, t, s);      // (hdrsky_conv2d_emit_supported: never narrow / precise)
   return precise ? dispatch_tile<false, true>(a, t, s) : dispatch_tile<false, false>(a, t, s);

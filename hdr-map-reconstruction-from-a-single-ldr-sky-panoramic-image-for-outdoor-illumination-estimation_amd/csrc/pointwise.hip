@@ -103,7 +103,9 @@ __global__ void __launch_bounds__(256) norm_apply_kernel(const float* __restrict
 // 128x512 map has 512 tile partials per sample and a 64-channel layer on it 4096 workgroups (1 GB of L2 reads for tables)
 __global__ void __launch_bounds__(256) in_affine_kernel(const float* __restrict__ part, int nparts, int B, int C, float inv_count,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        float eps, float* __restrict__ scale, float* __restrict__ shift) {
+                                                        float eps, float* __restrict__ scale, float* __restrict__ shift,
+                                                        const float* __restrict__ gamma2 = nullptr, const float* __restrict__ beta2 = nullptr,
+                                                        int gsplit = 0) {
   // block = (sample, 32 channels) x 8 slices of the tile range: slice q adds the tiles [q * per, (q + 1) * per) in order
   // (loads eight at a time), then the slices are added in slice order - a fixed order
   __shared__ float sS[8][32], sQ[8][32];
@@ -119,9 +121,10 @@ __global__ void __launch_bounds__(256) in_affine_kernel(const float* __restrict_
   for (int k = 1; k < 8; ++k) { s += sS[k][threadIdx.x]; ss += sQ[k][threadIdx.x]; }
   const float mean = s * inv_count;
   const float var = fmaxf(ss * inv_count - mean * mean, 0.f);
-  const float inv = gamma[c] / sqrtf(var + eps);
+  const bool g1 = gsplit > 0 && b >= gsplit;      // paired tensors: the second half of the batch is another layer's (its own gamma / beta)
+  const float inv = (g1 ? gamma2 : gamma)[c] / sqrtf(var + eps);
   scale[(size_t)b * C + c] = inv;
-  shift[(size_t)b * C + c] = beta[c] - mean * inv;
+  shift[(size_t)b * C + c] = (g1 ? beta2 : beta)[c] - mean * inv;
 }
 
 __global__ void in_finalize_kernel(const float* __restrict__ part, int nparts, int B, int C, float inv_count,
@@ -169,7 +172,8 @@ __global__ void __launch_bounds__(256) norm_act_bwd_kernel(const float* __restri
                                                            const float* __restrict__ dy, int pooled,
                                                            void* __restrict__ dxv, int dx_bf16, float* __restrict__ sums,
                                                            float* dgamma, float* dbeta, float* __restrict__ ws, int S,
-                                                           int B, int H, int W, int C) {
+                                                           int B, int H, int W, int C, const float* __restrict__ gamma2 = nullptr,
+                                                           const float* __restrict__ beta2 = nullptr, int gsplit = 0) {
   __shared__ float sRed[64][2][16];
   __shared__ float sM[2][16];
   const int groups = C >> 4;
@@ -203,7 +207,8 @@ __global__ void __launch_bounds__(256) norm_act_bwd_kernel(const float* __restri
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       mean[j] = sMR[cl + j][0]; rstd[j] = sMR[cl + j][1];
-      gm[j] = gamma[c + j]; bt[j] = beta[c + j];
+      const bool g1 = gsplit > 0 && b >= gsplit;      // paired tensors (hdrsky_norm_act_bwd_pair): the second half's own gamma / beta
+      gm[j] = (g1 ? gamma2 : gamma)[c + j]; bt[j] = (g1 ? beta2 : beta)[c + j];
     }
   }
   const size_t xo = (size_t)b * H * W * C + c;
@@ -378,7 +383,8 @@ __global__ void __launch_bounds__(NT) norm_act_bwd1_kernel(const float* __restri
                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                            float slope, const float* __restrict__ dy, void* __restrict__ dxv,
                                                            int flags, float* __restrict__ sums, float* dgamma, float* dbeta, int H,
-                                                           int W, int C) {
+                                                           int W, int C, const float* __restrict__ gamma2 = nullptr,
+                                                           const float* __restrict__ beta2 = nullptr, int gsplit = 0) {
   constexpr int NW = NT / 64, NC = CG / 4, NS = NT / NC;      // waves; float4 columns per pixel; pixel (window) slots per pass
   static_assert(NT >= 16 * CG && (CG == 8 || CG == 16), "statistics prologue: 16 partial slices x CG channels");
   __shared__ float sPart[16][CG][2];
@@ -411,8 +417,9 @@ __global__ void __launch_bounds__(NT) norm_act_bwd1_kernel(const float* __restri
   }
   __syncthreads();
   float mean[4], rstd[4], gm[4], bt[4];
+  const bool g1 = gsplit > 0 && b >= gsplit;      // paired tensors (hdrsky_norm_act_bwd_pair): the second half's own gamma / beta
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { mean[j] = sMR[cl + j][0]; rstd[j] = sMR[cl + j][1]; gm[j] = gamma[c + j]; bt[j] = beta[c + j]; }
+  for (int j = 0; j < 4; ++j) { mean[j] = sMR[cl + j][0]; rstd[j] = sMR[cl + j][1]; gm[j] = (g1 ? gamma2 : gamma)[c + j]; bt[j] = (g1 ? beta2 : beta)[c + j]; }
   const int Wp = W >> 1;
   const int nunits = POOLED ? (H >> 1) * Wp : H * W;
   // workgroup-uniform bases + 32-bit element offsets (a sample's slab is < 2^31 elements): one address register per load
@@ -1072,6 +1079,17 @@ int hdrsky_in_affine(const float* part, int nparts, int B, int C, int count, con
   return HDRSKY_OK;
 }
 
+// hdrsky_in_affine for a PAIRED tensor: samples [0, B/2) are one layer's output (gamma, beta), samples [B/2, B) another's
+// (gamma2, beta2) - the same values as two calls on the halves
+int hdrsky_in_affine_pair(const float* part, int nparts, int B, int C, int count, const float* gamma, const float* beta,
+                          const float* gamma2, const float* beta2, float eps, float* scale, float* shift, void* stream) {
+  if (!part || !gamma || !beta || !gamma2 || !beta2 || !scale || !shift || nparts <= 0 || count <= 0 || (B & 1)) return HDRSKY_EINVAL;
+  hipLaunchKernelGGL(in_affine_kernel, dim3(B * cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, part, nparts, B, C,
+                     1.f / (float)count, gamma, beta, eps, scale, shift, gamma2, beta2, B / 2);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
 int hdrsky_bn_eval_affine(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var,
                           float eps, int C, float* scale, float* shift, void* stream) {
   if (!gamma || !beta || !moving_mean || !moving_var || !scale || !shift) return HDRSKY_EINVAL;
@@ -1103,9 +1121,10 @@ int hdrsky_norm_act_bwd_one_launch(int H, int W, int pooled, int dy_bf16) {
   return units == 4096 || units == 1024 || units == 256;
 }
 
-int hdrsky_norm_act_bwd(const float* x, const float* part, int nparts, const float* gamma, const float* beta,
-                        float eps, float slope, const float* dy, int pooled, void* dx, int dx_bf16, float* sums,
-                        float* dgamma, float* dbeta, float* ws, int B, int H, int W, int C, void* stream) {
+static int norm_act_bwd_impl(const float* x, const float* part, int nparts, const float* gamma, const float* beta,
+                             float eps, float slope, const float* dy, int pooled, void* dx, int dx_bf16, float* sums,
+                             float* dgamma, float* dbeta, float* ws, int B, int H, int W, int C, void* stream,
+                             const float* gamma2, const float* beta2, int gsplit) {
   if (!x || !part || !gamma || !beta || !dy || !dx || (C & 15)) return HDRSKY_EINVAL;
   if (pooled && ((H | W) & 1)) return HDRSKY_EINVAL;
   const int S = hdrsky_norm_act_bwd_nslices(B, H, W, C, pooled);
@@ -1119,10 +1138,10 @@ int hdrsky_norm_act_bwd(const float* x, const float* part, int nparts, const flo
       if ((C % CG_) != 0) return HDRSKY_EINVAL;                                                                                      \
       if (dy16)                                                                                                                      \
         hipLaunchKernelGGL((norm_act_bwd1_kernel<NT_, NV_, CG_, P_, true>), dim3(B * (C / CG_)), dim3(NT_), 0, (hipStream_t)stream, x, \
-                           part, nparts, gamma, beta, eps, slope, dy, dx, dx_bf16, sums, dgamma, dbeta, H, W, C);                      \
+                           part, nparts, gamma, beta, eps, slope, dy, dx, dx_bf16, sums, dgamma, dbeta, H, W, C, gamma2, beta2, gsplit); \
       else                                                                                                                           \
         hipLaunchKernelGGL((norm_act_bwd1_kernel<NT_, NV_, CG_, P_, false>), dim3(B * (C / CG_)), dim3(NT_), 0, (hipStream_t)stream, x, \
-                           part, nparts, gamma, beta, eps, slope, dy, dx, dx_bf16, sums, dgamma, dbeta, H, W, C);                      \
+                           part, nparts, gamma, beta, eps, slope, dy, dx, dx_bf16, sums, dgamma, dbeta, H, W, C, gamma2, beta2, gsplit); \
     } while (0)
     // units per sample -> (threads, units per thread, channels per workgroup): 64 (32 for the pooled form) values of xhat per
     // thread at most - the 4096-pixel maps and the pooled forms on 8-channel groups
@@ -1138,18 +1157,36 @@ int hdrsky_norm_act_bwd(const float* x, const float* part, int nparts, const flo
   }
   if (S == 1) {
     hipLaunchKernelGGL(norm_act_bwd_kernel<2>, dim3(groups), dim3(256), 0, (hipStream_t)stream, x, part, nparts, gamma,
-                       beta, eps, slope, dy, pooled, dx, dx_bf16, sums, dgamma, dbeta, ws, 1, B, H, W, C);
+                       beta, eps, slope, dy, pooled, dx, dx_bf16, sums, dgamma, dbeta, ws, 1, B, H, W, C, gamma2, beta2, gsplit);
     HDRSKY_CHECK_LAUNCH();
     return HDRSKY_OK;
   }
   if (!ws) return HDRSKY_EINVAL;
   hipLaunchKernelGGL(norm_act_bwd_kernel<0>, dim3(groups * S), dim3(256), 0, (hipStream_t)stream, x, part, nparts, gamma,
-                     beta, eps, slope, dy, pooled, dx, dx_bf16, sums, dgamma, dbeta, ws, S, B, H, W, C);
+                     beta, eps, slope, dy, pooled, dx, dx_bf16, sums, dgamma, dbeta, ws, S, B, H, W, C, gamma2, beta2, gsplit);
   HDRSKY_CHECK_LAUNCH();
   hipLaunchKernelGGL(norm_act_bwd_kernel<1>, dim3(groups * S), dim3(256), 0, (hipStream_t)stream, x, part, nparts, gamma,
-                     beta, eps, slope, dy, pooled, dx, dx_bf16, sums, dgamma, dbeta, ws, S, B, H, W, C);
+                     beta, eps, slope, dy, pooled, dx, dx_bf16, sums, dgamma, dbeta, ws, S, B, H, W, C, gamma2, beta2, gsplit);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
+}
+
+int hdrsky_norm_act_bwd(const float* x, const float* part, int nparts, const float* gamma, const float* beta,
+                        float eps, float slope, const float* dy, int pooled, void* dx, int dx_bf16, float* sums,
+                        float* dgamma, float* dbeta, float* ws, int B, int H, int W, int C, void* stream) {
+  return norm_act_bwd_impl(x, part, nparts, gamma, beta, eps, slope, dy, pooled, dx, dx_bf16, sums, dgamma, dbeta, ws, B, H, W, C, stream,
+                           nullptr, nullptr, 0);
+}
+
+// hdrsky_norm_act_bwd on a PAIRED tensor: samples [0, B/2) belong to the layer with (gamma, beta), samples [B/2, B) to the one with
+// (gamma2, beta2) - one launch, the values of two calls on the halves (the statistics, sums and the formula are per sample; the
+// workspace ws is that of a B-sample call).  No atomics form: the per-sample terms go to `sums`.
+int hdrsky_norm_act_bwd_pair(const float* x, const float* part, int nparts, const float* gamma, const float* beta, const float* gamma2,
+                             const float* beta2, float eps, float slope, const float* dy, int pooled, void* dx, int dx_bf16,
+                             float* sums, float* ws, int B, int H, int W, int C, void* stream) {
+  if (!gamma2 || !beta2 || (B & 1)) return HDRSKY_EINVAL;
+  return norm_act_bwd_impl(x, part, nparts, gamma, beta, eps, slope, dy, pooled, dx, dx_bf16, sums, nullptr, nullptr, ws, B, H, W, C, stream,
+                           gamma2, beta2, B / 2);
 }
 
 int hdrsky_global_max(const float* x, size_t n, void* gmax_bits, void* stream) {

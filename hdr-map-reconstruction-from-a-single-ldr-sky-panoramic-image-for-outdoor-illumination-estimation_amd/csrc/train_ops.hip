@@ -383,10 +383,12 @@ __global__ void __launch_bounds__(256) up2x_xf_bf16_kernel(const float* __restri
                                                            const float* __restrict__ part, int nparts,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float eps, float slope, uint4* __restrict__ y, int blocks_per_sample,
-                                                           int x16) {
+                                                           int x16, const float* __restrict__ gamma2 = nullptr,
+                                                           const float* __restrict__ beta2 = nullptr, int gsplit = 0) {
   __shared__ float sSc[512], sSh[512];
   const int b = blockIdx.x / blocks_per_sample, blk = blockIdx.x % blocks_per_sample;
   const bool xf = part != nullptr;
+  if (gsplit > 0 && b >= gsplit) { gamma = gamma2; beta = beta2; }      // paired tensors: the second half is another layer's output
   if (xf) {
     const float inv_count = 1.f / (float)(H * W);
     for (int c = threadIdx.x; c < C; c += 256) {
@@ -445,6 +447,9 @@ __global__ void __launch_bounds__(256) up2x_bwd_kernel(const float* __restrict__
   // bit 1 of `accumulate`: dy is GIVEN as bf16 (the data-gradient conv of a resize-deconvolution writes the gradient at the
   // doubled resolution - 67 MB in fp32 for the 64-channel layer of a batch of 32 - for this launch alone to read)
   const bool dy16 = (accumulate & 2) != 0;
+  // bit 2: PAIRED gradient - dy holds 2 B samples and dx[b] = adjoint(dy[b]) + adjoint(dy[b + B]): the two decoders' gradients
+  // with respect to the encoder output they share, in the order of two accumulating calls (first half, then second half)
+  const bool pair = (accumulate & 4) != 0;
   accumulate &= 1;
   const unsigned short* dyh = reinterpret_cast<const unsigned short*>(dy);
   const int CV = C / V;
@@ -467,16 +472,20 @@ __global__ void __launch_bounds__(256) up2x_bwd_kernel(const float* __restrict__
         wx[k] = (lo == ix ? 1.f - t : 0.f) + (hi == ix ? t : 0.f);
       }
     }
-    float s[V];
+    float s[V], s2[V];
 #pragma unroll
-    for (int v = 0; v < V; ++v) s[v] = 0.f;
+    for (int v = 0; v < V; ++v) { s[v] = 0.f; s2[v] = 0.f; }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+    if (half == 1 && !pair) break;
+    const int bs = bb + half * B;       // sample of dy
 #pragma unroll
     for (int ky = 0; ky < 4; ++ky)
 #pragma unroll
       for (int kx = 0; kx < 4; ++kx) {
         const float w = wy[ky] * wx[kx];
         if (w != 0.f) {   // zero weight <=> output pixel outside the image: never dereferenced
-          const size_t off = ((size_t)(bb * 2 * H + 2 * iy - 1 + ky) * 2 * W + 2 * ix - 1 + kx) * C + c;
+          const size_t off = ((size_t)(bs * 2 * H + 2 * iy - 1 + ky) * 2 * W + 2 * ix - 1 + kx) * C + c;
           const float* p = dy + off;
           if (V == 4) {
             float4 d;
@@ -487,19 +496,25 @@ __global__ void __launch_bounds__(256) up2x_bwd_kernel(const float* __restrict__
             } else {
               d = *reinterpret_cast<const float4*>(p);
             }
-            s[0] += w * d.x; s[1 % V] += w * d.y; s[2 % V] += w * d.z; s[3 % V] += w * d.w;
+            if (half == 0) { s[0] += w * d.x; s[1 % V] += w * d.y; s[2 % V] += w * d.z; s[3 % V] += w * d.w; }
+            else { s2[0] += w * d.x; s2[1 % V] += w * d.y; s2[2 % V] += w * d.z; s2[3 % V] += w * d.w; }
           } else {
-            s[0] += w * (dy16 ? bf2f(dyh[off]) : p[0]);
+            if (half == 0) s[0] += w * (dy16 ? bf2f(dyh[off]) : p[0]);
+            else s2[0] += w * (dy16 ? bf2f(dyh[off]) : p[0]);
           }
         }
       }
+    }
     float* o = dx + pix * C + c;
     if (V == 4) {
       float4 r = make_float4(s[0] * scale, s[1 % V] * scale, s[2 % V] * scale, s[3 % V] * scale);
-      if (accumulate) { const float4 q = *reinterpret_cast<const float4*>(o); r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w; }
+      if (accumulate) { const float4 q = *reinterpret_cast<const float4*>(o); r.x = q.x + r.x; r.y = q.y + r.y; r.z = q.z + r.z; r.w = q.w + r.w; }
+      if (pair) { r.x += s2[0] * scale; r.y += s2[1 % V] * scale; r.z += s2[2 % V] * scale; r.w += s2[3 % V] * scale; }
       *reinterpret_cast<float4*>(o) = r;
     } else {
-      o[0] = accumulate ? o[0] + s[0] * scale : s[0] * scale;
+      float r = accumulate ? o[0] + s[0] * scale : s[0] * scale;
+      if (pair) r += s2[0] * scale;
+      o[0] = r;
     }
   }
 }
@@ -1628,6 +1643,19 @@ int hdrsky_up2x_xf_bf16(const float* x, int x_bf16, int B, int H, int W, int C, 
   if (bps < 1) bps = 1;
   hipLaunchKernelGGL(up2x_xf_bf16_kernel, dim3(B * bps), dim3(256), 0, S_(stream), x, B, H, W, C, in_part, in_nparts, gamma,
                      beta, eps, slope, (uint4*)y_bf16, bps, x_bf16 ? 1 : 0);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
+// hdrsky_up2x_xf_bf16 on a PAIRED tensor (samples [0, B/2): gamma / beta, samples [B/2, B): gamma2 / beta2)
+int hdrsky_up2x_xf_bf16_pair(const float* x, int x_bf16, int B, int H, int W, int C, const float* in_part, int in_nparts, const float* gamma,
+                             const float* beta, const float* gamma2, const float* beta2, float eps, float slope, void* y_bf16, void* stream) {
+  if (!x || !y_bf16 || (C & 7) || C > 512 || B <= 0 || (B & 1) || !in_part || !gamma || !beta || !gamma2 || !beta2 || in_nparts <= 0) return HDRSKY_EINVAL;
+  const int nitems = 4 * H * W * (C / 8);
+  int bps = cdiv(nitems, 256 * 8);
+  if (bps < 1) bps = 1;
+  hipLaunchKernelGGL(up2x_xf_bf16_kernel, dim3(B * bps), dim3(256), 0, S_(stream), x, B, H, W, C, in_part, in_nparts, gamma,
+                     beta, eps, slope, (uint4*)y_bf16, bps, x_bf16 ? 1 : 0, gamma2, beta2, B / 2);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }

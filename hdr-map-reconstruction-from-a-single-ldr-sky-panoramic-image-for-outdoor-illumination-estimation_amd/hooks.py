@@ -36,6 +36,8 @@ class _Hooks:
         self.disc_split = exp("HDRSKY_DISC_SPLIT", "0") == "1"
         # the perceptual term's prediction pass as two half batches on two streams (1), or as one pass on stream 1 (0)
         self.vgg_split = exp("HDRSKY_VGG_SPLIT", "1") != "0"
+        # the sky / sun decoders' layers of equal shape as paired launches on a batch of 2 B (forward heads and the whole backward chain)
+        self.dec_pair = exp("HDRSKY_DEC_PAIR", "1") != "0"
         self.dec_head_early = exp("HDRSKY_DEC_HEAD_EARLY", "1") != "0"
         self.bwd_dense_stream = int(exp("HDRSKY_BWD_DENSE_STREAM", "2"))
         self.wg_res_stream = int(exp("HDRSKY_WG_RES_STREAM", "1"))

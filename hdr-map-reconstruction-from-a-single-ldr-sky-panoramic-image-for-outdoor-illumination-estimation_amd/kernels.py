@@ -108,6 +108,17 @@ class InXf:
     gamma: Optional[torch.Tensor] = None
     beta: Optional[torch.Tensor] = None
     eps: float = IN_EPS
+    gamma2: Optional[torch.Tensor] = None  # PARTIALS of a PAIRED tensor (two layers' outputs as one batch): the second half's layer
+    beta2: Optional[torch.Tensor] = None
+
+
+@dataclass
+class ConvPair:
+    """Second parameter set of a PAIRED conv launch (hdrsky_conv2d_fwd_pair): samples [B/2, B) of the launch run on this filter /
+    bias / residual (and on InXf.gamma2 / beta2 of a PARTIALS transform); samples [0, B/2) on conv2d's own arguments."""
+    pw: "PackedConv"
+    bias: Optional[torch.Tensor] = None
+    residual: Optional[torch.Tensor] = None
 
 
 class Operand:
@@ -193,12 +204,16 @@ def _bf16(t, *shape):
 
 def conv2d(x, pw: PackedConv, bias=None, stride=1, same=True, upsample=1, xf: Optional[InXf] = None,
            out_slope=1.0, residual=None, final_relu=False, want_stats=False, compute=BF16, desc=None, out=None,
-           out_bf16=False, mask_bf16=None, mask_slope=0.0, emit_xb: Optional["Operand"] = None):
+           out_bf16=False, mask_bf16=None, mask_slope=0.0, emit_xb: Optional["Operand"] = None, pair: Optional["ConvPair"] = None,
+           x_shared=False):
     """y = final_relu(act(conv(xf(x)) + bias) + residual); returns (y, Stats|None).
     HDRSKY_BF16 mode: x may be a bfloat16 tensor (a final activation: no xf), out_bf16 stores y as bfloat16; mask_bf16
     (instead of residual): a bfloat16 ACTIVATED tensor of y's shape - y is multiplied by (it > 0 ? 1 : mask_slope), the
     activation backward fused into a data-gradient conv."""
     lib = L.load()
+    if pair is not None:
+        return _conv2d_pair(x, pw, bias, stride, same, upsample, xf, out_slope, residual, final_relu, want_stats, compute, desc, out,
+                            out_bf16, mask_bf16, mask_slope, pair, x_shared)
     if torch.is_tensor(x) and x.dtype == torch.bfloat16:
         _bf16(x)
     else:
@@ -273,6 +288,99 @@ def conv2d(x, pw: PackedConv, bias=None, stride=1, same=True, upsample=1, xf: Op
                "%dx%d %d->%d @%dx%d B=%d%s%s" % (d.KH, d.KW, C, pw.Cout, d.Ho, d.Wo, B, " s2" if d.stride == 2 else "", form),
                2.0 * B * d.Ho * d.Wo * d.KH * d.KW * C * pw.Cout / stuffed,
                lambda a_=args, k_=keep: L.check(lib.hdrsky_conv2d_fwd(*a_, _stream()), "conv2d_fwd"))
+    return y, stats
+
+
+def _half_xf(xf, lo, hi, second):
+    """The operand transform of one half of a paired tensor (the fallback of _conv2d_pair: two separate launches)."""
+    if xf is None or xf.mode == L.IN_NONE:
+        return xf
+    if xf.mode == L.IN_AFFINE:
+        if xf.scale.dim() == 1:
+            return xf
+        return InXf(mode=L.IN_AFFINE, slope=xf.slope, scale=xf.scale[lo:hi], shift=xf.shift[lo:hi])
+    st = xf.stats
+    return InXf(mode=L.IN_PARTIALS, slope=xf.slope, stats=Stats(st.part[lo:hi], st.nparts, st.count), eps=xf.eps,
+                gamma=xf.gamma2 if second else xf.gamma, beta=xf.beta2 if second else xf.beta)
+
+
+def _conv2d_pair(x, pw, bias, stride, same, upsample, xf, out_slope, residual, final_relu, want_stats, compute, desc, out, out_bf16,
+                 mask_bf16, mask_slope, pair, x_shared):
+    """conv2d(..., pair=ConvPair): two layers of identical geometry as ONE launch (hdrsky_conv2d_fwd_pair) on a batch of 2 Bh samples -
+    the first Bh on (pw, bias, residual, xf.gamma / beta), the last Bh on the pair's.  x: [2 Bh, ...], or [Bh, ...] with x_shared (both
+    layers read the same input).  Returns (y [2 Bh, ...], Stats of 2 Bh samples): bit-identical to the two separate launches, which
+    is also what runs where the library has no paired instantiation for the layer's tile."""
+    lib = L.load()
+    (_bf16 if x.dtype == torch.bfloat16 else _f32)(x)
+    Bx, H, W, C = x.shape
+    Bt = 2 * Bx if x_shared else Bx
+    pw2 = pair.pw
+    if Bt % 2 or C != pw.Cin or (pw2.KH, pw2.KW, pw2.Cin, pw2.Cout, pw2.flip) != (pw.KH, pw.KW, pw.Cin, pw.Cout, pw.flip):
+        raise ValueError("conv2d pair: two filters of one geometry on an even batch")
+    Bh = Bt // 2
+    if desc is not None:
+        d = L.ConvDesc(); ctypes.memmove(ctypes.byref(d), ctypes.byref(desc), ctypes.sizeof(d))
+        if d.B != Bt:
+            raise ValueError("conv2d pair: the descriptor must describe the whole batch")
+    else:
+        d = conv_desc(Bt, H, W, C, pw.Cout, pw.KH, pw.KW, stride, same, upsample)
+    d.compute = compute
+    xfo = xf or InXf()
+    if x_shared and xfo.mode != L.IN_NONE:
+        raise ValueError("conv2d pair: a shared input takes no operand transform")
+    dh = L.ConvDesc(); ctypes.memmove(ctypes.byref(dh), ctypes.byref(d), ctypes.sizeof(d)); dh.B = Bh     # one layer's launch
+    tabs = _xf_args(d, xf, Bt, H, W, C)
+    dh.in_mode, dh.in_slope, dh.ss_bstride, dh.in_nparts, dh.in_eps = d.in_mode, d.in_slope, d.ss_bstride, d.in_nparts, d.in_eps
+    g2 = b2 = None
+    if xfo.mode == L.IN_PARTIALS:
+        g2, b2 = _f32(xfo.gamma2, C), _f32(xfo.beta2, C)
+    for dd in (d, dh):
+        dd.out_slope, dd.final_relu, dd.want_stats = float(out_slope), int(bool(final_relu)), int(bool(want_stats))
+        dd.x_bf16, dd.y_bf16 = int(x.dtype == torch.bfloat16), int(bool(out_bf16))
+    if (bias is None) != (pair.bias is None):
+        raise ValueError("conv2d pair: both layers with or without a bias")
+    if bias is not None:
+        _f32(bias, pw.Cout); _f32(pair.bias, pw.Cout)
+    ydt = torch.bfloat16 if out_bf16 else torch.float32
+    y = out if out is not None else torch.empty((Bt, d.Ho, d.Wo, pw.Cout), dtype=ydt, device=x.device)
+    (_bf16 if out_bf16 else _f32)(y, Bt, d.Ho, d.Wo, pw.Cout)
+    res1, res2 = residual, pair.residual
+    if mask_bf16 is not None:
+        raise ValueError("conv2d pair: no activation-mask form")
+    if (res1 is None) != (res2 is None):
+        raise ValueError("conv2d pair: both layers with or without a residual")
+    if res1 is not None:
+        _f32(res1, Bh, d.Ho, d.Wo, pw.Cout); _f32(res2, Bh, d.Ho, d.Wo, pw.Cout)
+    stats = None
+    if want_stats:
+        nparts = lib.hdrsky_conv_stats_nparts(dh)
+        stats = Stats(torch.empty((Bt, nparts, 2, pw.Cout), dtype=torch.float32, device=x.device), nparts, d.Ho * d.Wo)
+    in_scale, in_shift, in_part, in_gamma, in_beta = tabs
+    rc = lib.hdrsky_conv2d_fwd_pair(d, _p(x), int(bool(x_shared)), _p(pw.hi), _p(pw.lo), _p(bias), _p(pw2.hi), _p(pw2.lo), _p(pair.bias),
+                                    _p(in_scale), _p(in_shift), _p(in_part), _p(in_gamma), _p(in_beta), _p(g2), _p(b2), _p(res1), _p(res2),
+                                    _p(y), _p(stats.part) if stats else None, _stream())
+    if rc == L.HDRSKY_EUNSUPPORTED:      # no paired instantiation for this tile / mode: the two launches
+        for hf, (pwh, bh, rh) in enumerate(((pw, bias, res1), (pw2, pair.bias, res2))):
+            lo, hi = hf * Bh, (hf + 1) * Bh
+            dsc = None
+            if desc is not None:
+                dsc = L.ConvDesc(); ctypes.memmove(ctypes.byref(dsc), ctypes.byref(desc), ctypes.sizeof(dsc)); dsc.B = Bh
+            yh, sth = conv2d(x if x_shared else x[lo:hi], pwh, bh, stride=stride, same=same, upsample=upsample, xf=_half_xf(xf, lo, hi, hf == 1),
+                             out_slope=out_slope, residual=rh, final_relu=final_relu, want_stats=want_stats, compute=compute, desc=dsc,
+                             out=y[lo:hi], out_bf16=out_bf16)
+            if stats is not None:
+                stats.part[lo:hi].copy_(sth.part)
+        return y, stats
+    L.check(rc, "conv2d_fwd_pair")
+    if TRACE is not None:
+        args = (d, _p(x), int(bool(x_shared)), _p(pw.hi), _p(pw.lo), _p(bias), _p(pw2.hi), _p(pw2.lo), _p(pair.bias), _p(in_scale), _p(in_shift),
+                _p(in_part), _p(in_gamma), _p(in_beta), _p(g2), _p(b2), _p(res1), _p(res2), _p(y), _p(stats.part) if stats else None)
+        keep = (x, pw, pw2, bias, pair.bias, in_scale, in_shift, in_part, in_gamma, in_beta, g2, b2, res1, res2, y, stats)
+        stuffed = 4 if d.dilate == 2 else 1
+        _trace("dgrad" if pw.flip else "conv", conv_kernel_name(dh).replace("false>", "false, true>") + " (paired)",
+               "2 x %dx%d %d->%d @%dx%d B=%d%s" % (d.KH, d.KW, C, pw.Cout, d.Ho, d.Wo, Bh, " s2" if d.stride == 2 else ""),
+               2.0 * Bt * d.Ho * d.Wo * d.KH * d.KW * C * pw.Cout / stuffed,
+               lambda a_=args, k_=keep: L.check(lib.hdrsky_conv2d_fwd_pair(*a_, _stream()), "conv2d_fwd_pair"))
     return y, stats
 
 
@@ -494,16 +602,21 @@ def norm_apply(x, stats: Stats, gamma, beta, slope=1.0, residual=None, pool=Fals
 
 
 
-def in_xf(stats: Stats, gamma, beta, slope, eps=IN_EPS):
+def in_xf(stats: Stats, gamma, beta, slope, eps=IN_EPS, pair=None):
     """The fused operand transform leaky(InstanceNorm(x)) for the conv / weight-gradient that consumes the raw tensor x:
     the tile partials themselves (every workgroup of the consumer derives the tables in its prologue) while a sample has
     few tiles, tables computed once by hdrsky_in_affine (same formula, equal to an ulp or two) from 64 tiles (tuning hook HDRSKY_INXF_AFFINE_MIN) per
     sample on."""
     B, nparts, _, C = stats.part.shape
+    g2, b2 = pair if pair is not None else (None, None)      # a PAIRED tensor: the second half of the batch is another layer's output
     if nparts < HOOKS.H.inxf_affine_min:
-        return InXf(mode=L.IN_PARTIALS, slope=slope, stats=stats, gamma=gamma, beta=beta, eps=eps)
+        return InXf(mode=L.IN_PARTIALS, slope=slope, stats=stats, gamma=gamma, beta=beta, eps=eps, gamma2=g2, beta2=b2)
     scale = torch.empty((B, C), dtype=torch.float32, device=gamma.device)
     shift = torch.empty_like(scale)
+    if pair is not None:
+        L.check(L.load().hdrsky_in_affine_pair(_p(stats.part), nparts, B, C, stats.count, _p(_f32(gamma, C)), _p(_f32(beta, C)), _p(_f32(g2, C)),
+                                               _p(_f32(b2, C)), eps, _p(scale), _p(shift), _stream()), "in_affine_pair")
+        return InXf(mode=L.IN_AFFINE, slope=slope, scale=scale, shift=shift)
     L.check(L.load().hdrsky_in_affine(_p(stats.part), nparts, B, C, stats.count, _p(_f32(gamma, C)), _p(_f32(beta, C)), eps,
                                       _p(scale), _p(shift), _stream()), "in_affine")
     return InXf(mode=L.IN_AFFINE, slope=slope, scale=scale, shift=shift)
@@ -529,7 +642,7 @@ def bn_eval_affine(gamma, beta, mm, mv, eps=IN_EPS):
 
 
 def norm_act_bwd(x, stats: Stats, gamma, beta, slope, dy, pooled, eps=IN_EPS, want_sums=False, dgamma=None, dbeta=None,
-                 sums=None, out_bf16=False):
+                 sums=None, out_bf16=False, pair=None):
     """dx of y = leaky(IN(x)) [-> maxpool2x2]; dy is the gradient wrt y (or wrt the pooled y).
     sums [B,2,C] (given, or allocated when want_sums): per-sample (d beta, d gamma) terms - reduce them over the batch with
     DgbReducer for bit-reproducible gradients; dgamma / dbeta: accumulated by fp32 atomics instead (arrival order).
@@ -548,6 +661,14 @@ def norm_act_bwd(x, stats: Stats, gamma, beta, slope, dy, pooled, eps=IN_EPS, wa
         sums = torch.empty((B, 2, C), dtype=torch.float32, device=x.device)
     S = L.load().hdrsky_norm_act_bwd_nslices(B, H, W, C, int(pooled))
     ws = torch.empty((B, S, 2, C), dtype=torch.float32, device=x.device) if S > 1 else None
+    if pair is not None:      # a PAIRED tensor: (gamma, beta) for the first half of the batch, pair = (gamma2, beta2) for the second
+        if dgamma is not None or dbeta is not None:
+            raise ValueError("norm_act_bwd pair: per-sample sums only")
+        L.check(L.load().hdrsky_norm_act_bwd_pair(_p(x), _p(stats.part), stats.nparts, _p(_f32(gamma, C)), _p(_f32(beta, C)), _p(_f32(pair[0], C)),
+                                                  _p(_f32(pair[1], C)), eps, slope, _p(dy), int(pooled), _p(dx),
+                                                  int(out_bf16) | (2 if dy.dtype == torch.bfloat16 else 0) | (4 if x16 else 0), _p(sums), _p(ws),
+                                                  B, H, W, C, _stream()), "norm_act_bwd_pair")
+        return (dx, sums) if want_sums else dx
     L.check(L.load().hdrsky_norm_act_bwd(_p(x), _p(stats.part), stats.nparts, _p(_f32(gamma, C)), _p(_f32(beta, C)),
                                          eps, slope, _p(dy), int(pooled), _p(dx), int(out_bf16) | (2 if dy.dtype == torch.bfloat16 else 0) | (4 if x16 else 0), _p(sums), _p(dgamma),
                                          _p(dbeta), _p(ws), B, H, W, C, _stream()),
@@ -958,19 +1079,30 @@ def up2x_act_bf16(x, xf: Optional[InXf] = None):
         gamma, beta = _f32(xf.gamma, C), _f32(xf.beta, C)
         if st.count != H * W:
             raise ValueError("partials were not accumulated over this tensor's H*W")
+    if xf is not None and xf.gamma2 is not None:      # a PAIRED tensor
+        L.check(L.load().hdrsky_up2x_xf_bf16_pair(_p(x), x16, B, H, W, C, _p(part), nparts, _p(gamma), _p(beta), _p(_f32(xf.gamma2, C)),
+                                                  _p(_f32(xf.beta2, C)), eps, slope, _p(y), _stream()), "up2x_xf_bf16_pair")
+        return y
     L.check(L.load().hdrsky_up2x_xf_bf16(_p(x), x16, B, H, W, C, _p(part), nparts, _p(gamma), _p(beta), eps, slope, _p(y), _stream()),
             "up2x_xf_bf16")
     return y
 
 
-def up2x_bwd(dy, scale=1.0, out=None):
+def up2x_bwd(dy, scale=1.0, out=None, pair_sum=False):
+    """Adjoint of the bilinear 2x resize; out: ACCUMULATED into.  pair_sum: dy holds 2 B samples (a paired gradient) and
+    dx[b] = adjoint(dy[b]) + adjoint(dy[b + B]) - two layers' gradients with respect to an input they share, in the order of two
+    accumulating calls."""
     B, H2, W2, C = dy.shape
     (_bf16 if dy.dtype == torch.bfloat16 else _f32)(dy)      # bf16: a data-gradient conv's out_bf16 output
+    if pair_sum:
+        if B % 2:
+            raise ValueError("up2x_bwd pair_sum: an even batch")
+        B //= 2
     acc = out is not None
     dx = out if acc else torch.empty((B, H2 // 2, W2 // 2, C), dtype=torch.float32, device=dy.device)
     _f32(dx, B, H2 // 2, W2 // 2, C)
-    L.check(L.load().hdrsky_up2x_bwd(_p(dy), B, H2 // 2, W2 // 2, C, scale, int(acc) | (2 if dy.dtype == torch.bfloat16 else 0),
-                                     _p(dx), _stream()), "up2x_bwd")
+    L.check(L.load().hdrsky_up2x_bwd(_p(dy), B, H2 // 2, W2 // 2, C, scale,
+                                     int(acc) | (2 if dy.dtype == torch.bfloat16 else 0) | (4 if pair_sum else 0), _p(dx), _stream()), "up2x_bwd")
     return dx
 
 
@@ -1043,7 +1175,7 @@ def blend_bwd(y_gamma, alpha, dyg, dyl):
     return ds, du
 
 
-def head_bwd(y_gamma, alpha, dyg, dyl, din6, y_f, res_f, y_u, res_u):
+def head_bwd(y_gamma, alpha, dyg, dyl, din6, y_f, res_f, y_u, res_u, out=None):
     """blend_bwd + both decoder_tail_bwd in one launch; din6 [B,H,W,6] (or None): the adversarial term's gradient wrt the
     discriminator input, whose channels 3..5 are added to dyl.  Returns (dc_f, dc_u, dres_u)."""
     shp = y_gamma.shape
@@ -1051,7 +1183,10 @@ def head_bwd(y_gamma, alpha, dyg, dyl, din6, y_f, res_f, y_u, res_u):
         _f32(t, *shp)
     if din6 is not None:
         _f32(din6, *(tuple(shp[:-1]) + (6,)))
-    dc_f, dc_u, dres_u = torch.empty_like(y_gamma), torch.empty_like(y_gamma), torch.empty_like(y_gamma)
+    if out is not None:      # (dc_f, dc_u, dres_u) given - e.g. the two halves of one paired tensor
+        dc_f, dc_u, dres_u = (_f32(t, *shp) for t in out)
+    else:
+        dc_f, dc_u, dres_u = torch.empty_like(y_gamma), torch.empty_like(y_gamma), torch.empty_like(y_gamma)
     L.check(L.load().hdrsky_head_bwd(_p(_f32(y_gamma)), _p(alpha), _p(dyg), _p(dyl), _p(din6), _p(y_f), _p(res_f), _p(y_u), _p(res_u),
                                      y_gamma.numel(), _p(dc_f), _p(dc_u), _p(dres_u), _stream()), "head_bwd")
     return dc_f, dc_u, dres_u

@@ -270,12 +270,17 @@ class Trainer:
             st = self._nstate = {}
         if B not in st:
             w, g, sums, red = self.gs.w, self.gs.g, {}, {}
+            pairs = {}      # the two decoders' norm layers of one depth share a table of 2 B samples (paired launches)
+            for k in (2, 3):
+                tp = torch.zeros((2 * B, 2, w["gen.norm%d_f.gamma" % k].numel()), dtype=torch.float32, device=self.device)
+                pairs["gen.norm%d_f" % k], pairs["gen.norm%d_u" % k] = tp[:B], tp[B:]
+                sums["gen.norm%d_f+u" % k] = tp
             for seg, names in self.NORM_GROUPS.items():
                 entries = []
                 for n in names:
                     if n + ".gamma" not in w:
                         continue
-                    t = torch.zeros((B, 2, w[n + ".gamma"].numel()), dtype=torch.float32, device=self.device)
+                    t = pairs[n] if n in pairs else torch.zeros((B, 2, w[n + ".gamma"].numel()), dtype=torch.float32, device=self.device)
                     sums[n] = t
                     if n in self.RESCONV_NORMS and self._sun3_ok():
                         entries.append((t, g[n + ".gamma"], g[n + ".beta"]))  # hdrsky_resconv's table: (d gamma, d beta)
@@ -789,6 +794,32 @@ class Trainer:
                 T["dech_" + sfx] = (d3, s3, xf2, d2, s2, xf1, None, None)
 
         early_head = HOOKS.H.dec_head_early     # (tuning hook)
+        # Round 5: the two decoders run the same layer shapes on the same encoder output with their own weights
+        # (generator.py:110-156).  Their two resize-deconvolutions and - backwards - the whole chain from the 7x7 tails' data
+        # gradients to the gradient with respect to the encoder output are issued as PAIRED launches on a batch of 2 B (first
+        # half: sky decoder, second half: sun decoder; kernels.ConvPair, include/hdrsky.h "PAIRED LAUNCHES"): 3 instead of 6
+        # launches forward, 9 instead of 18 backward, every value bit-identical to the unpaired launches
+        # (tests/test_pair_gpu.py).  HDRSKY_DEC_PAIR=0: the unpaired plan (A/B hook).
+        dec_pair = self._deconv_mat() and not self.da_dec and HOOKS.H.dec_pair
+
+        def decode_heads_pair():
+            c3f, c3u, c2f, c2u = (c["gen.conv%d_%s" % (k, sfx)] for k in (3, 2) for sfx in ("f", "u"))
+            u3 = T["u3"]
+            K.label("gen.conv3_f + gen.conv3_u")
+            d3, s3 = K.conv2d(u3, c3f.pk, c3f.b, compute=cp, want_stats=True, out_bf16=self._raw_bf16(), pair=K.ConvPair(c3u.pk, c3u.b),
+                              x_shared=True)
+            xf2 = InXf(mode=L.IN_PARTIALS, slope=0.1, stats=s3, gamma=w["gen.norm3_f.gamma"], beta=w["gen.norm3_f.beta"],
+                       gamma2=w["gen.norm3_u.gamma"], beta2=w["gen.norm3_u.beta"])
+            u2 = K.up2x_act_bf16(d3, xf2)
+            K.label("gen.conv2_f + gen.conv2_u")
+            d2, s2 = K.conv2d(u2, c2f.pk, c2f.b, compute=cp, want_stats=True, out_bf16=self._raw_bf16(), pair=K.ConvPair(c2u.pk, c2u.b))
+            xf1 = K.in_xf(s2, w["gen.norm2_f.gamma"], w["gen.norm2_f.beta"], 0.1, pair=(w["gen.norm2_u.gamma"], w["gen.norm2_u.beta"]))
+            T["dec_pair"] = dict(d3=d3, s3=s3, u2=u2, d2=d2, s2=s2, u3=u3)
+            for i, sfx in enumerate(("f", "u")):      # each decoder's own record: views of the paired tensors
+                lo, hi = i * B, (i + 1) * B
+                half = lambda st: K.Stats(st.part[lo:hi], st.nparts, st.count)
+                T["dech_" + sfx] = (d3[lo:hi], half(s3), K._half_xf(xf2, lo, hi, i == 1), d2[lo:hi], half(s2), K._half_xf(xf1, lo, hi, i == 1),
+                                    u3, u2[lo:hi])
 
         def decode_tail(sfx, residual):
             hd = T["dech_" + sfx]
@@ -881,9 +912,12 @@ class Trainer:
                 T["x"].append(x)
             if self._deconv_mat() and not self.da_dec:
                 T["u3"] = K.up2x_act_bf16(T["x"][-1])      # the resized encoder output, shared by both decoders
-            decode_head("f")
+            if dec_pair:
+                decode_heads_pair()
+            else:
+                decode_head("f")
             T["sky_gamma"] = decode_tail("f", ldr)
-            if early_head:
+            if early_head and not dec_pair:
                 decode_head("u")
 
         if not split_disc:
@@ -914,7 +948,7 @@ class Trainer:
         @seg("fwd_blend", 0, ["fwd_sun"])
         def _():
             rad_lin, rad_gamma, gamma, beta = T["rad"]
-            if not early_head:
+            if not early_head and not dec_pair:
                 decode_head("u")
             sun_gamma = decode_tail("u", rad_gamma)
             y_gamma, y_lin, alpha, sky_lin, sun_lin = K.blend(T["sky_gamma"], sun_gamma, E.THRESHOLD)
@@ -963,7 +997,11 @@ class Trainer:
         def _():       # blend -> decoder tails -> sun radiance head -> dcmf complete -> sun-pose Dense layers
             t, dyl = T["t"], T["dyl"]
             (yf, rf), (yu, ru) = (T["dec_f"][6], T["dec_f"][7]), (T["dec_u"][6], T["dec_u"][7])
-            dc_f, dc_u, dres_u = K.head_bwd(T["y_gamma"], T["alpha"], T["dyg"], dyl, T["din_adv"], yf, rf, yu, ru)
+            out = None
+            if dec_pair:      # the two tails' gradients as the halves of one paired tensor (the paired data gradient reads it)
+                T["dc_pair"] = torch.empty((2 * B,) + tuple(yf.shape[1:]), dtype=torch.float32, device=self.device)
+                out = (T["dc_pair"][:B], T["dc_pair"][B:], torch.empty_like(yu))
+            dc_f, dc_u, dres_u = K.head_bwd(T["y_gamma"], T["alpha"], T["dyg"], dyl, T["din_adv"], yf, rf, yu, ru, out=out)
             tails = T["tails"] = {"f": (dc_f, None), "u": (dc_u, dres_u)}
             T["dpre"] = K.sun_rad_bwd(t["cmf"], t["gmax"], T["gamma"], T["beta"], tails["u"][1], T["dcmf"], sync=self.sync)
 
@@ -1047,7 +1085,32 @@ class Trainer:
                 self._wg_da("gen.conv3_" + sfx, u3, dd3)
                 du3 = K.da_conv2d_dgrad(dd3, c["gen.conv3_" + sfx].pkT, self._da(u3.shape[1], u3.shape[2])[1], 3, cp)
                 K.up2x_bwd(du3, 1.0, out=dres)
-            for sfx in () if self.da_dec else ("f", "u"):
+            if dec_pair:
+                PR, nab, sums = T["dec_pair"], self._nab_bf16(), self._norm_state(B)[0]
+                c1f, c1u, c2f, c2u, c3f, c3u = (c["gen.conv%d_%s" % (k, sfx)] for k in (1, 2, 3) for sfx in ("f", "u"))
+                d2, s2, d3, s3, u2, u3 = PR["d2"], PR["s2"], PR["d3"], PR["s3"], PR["u2"], PR["u3"]
+                for i, sfx in enumerate(("f", "u")):
+                    self._wg("gen.conv1_" + sfx, T["dec_" + sfx][3], T["dec_" + sfx][5], T["tails"][sfx][0])
+                K.label("gen.conv1_f + gen.conv1_u (data gradients)")
+                da2, _ = K.conv2d_dgrad(T["dc_pair"], c1f.pkT, K.conv_desc(2 * B, d2.shape[1], d2.shape[2], d2.shape[3], c1f.cout, c1f.kh, c1f.kw,
+                                                                       1, True, 1), compute=cp, out_bf16=nab, pair=K.ConvPair(c1u.pkT))
+                dd2 = K.norm_act_bwd(d2, s2, w["gen.norm2_f.gamma"], w["gen.norm2_f.beta"], 0.1, da2, False, sums=sums["gen.norm2_f+u"],
+                                     out_bf16=self._act_bf16(), pair=(w["gen.norm2_u.gamma"], w["gen.norm2_u.beta"]))
+                for i, sfx in enumerate(("f", "u")):
+                    self._wg_plain("gen.conv2_" + sfx, u2[i * B:(i + 1) * B], dd2[i * B:(i + 1) * B])
+                K.label("gen.conv2_f + gen.conv2_u (data gradients)")
+                g2, _ = K.conv2d_dgrad(dd2, c2f.pkT, K.conv_desc(2 * B, u2.shape[1], u2.shape[2], u2.shape[3], c2f.cout, c2f.kh, c2f.kw, 1, True, 1),
+                                       compute=cp, out_bf16=nab, pair=K.ConvPair(c2u.pkT))
+                da3 = K.up2x_bwd(g2, 1.0)
+                dd3 = K.norm_act_bwd(d3, s3, w["gen.norm3_f.gamma"], w["gen.norm3_f.beta"], 0.1, da3, False, sums=sums["gen.norm3_f+u"],
+                                     out_bf16=self._act_bf16(), pair=(w["gen.norm3_u.gamma"], w["gen.norm3_u.beta"]))
+                for i, sfx in enumerate(("f", "u")):
+                    self._wg_plain("gen.conv3_" + sfx, u3, dd3[i * B:(i + 1) * B])
+                K.label("gen.conv3_f + gen.conv3_u (data gradients)")
+                g3, _ = K.conv2d_dgrad(dd3, c3f.pkT, K.conv_desc(2 * B, u3.shape[1], u3.shape[2], u3.shape[3], c3f.cout, c3f.kh, c3f.kw, 1, True, 1),
+                                       compute=cp, out_bf16=nab, pair=K.ConvPair(c3u.pkT))
+                K.up2x_bwd(g3, 1.0, out=dres, pair_sum=True)      # both decoders' gradients w.r.t. the encoder output they share
+            for sfx in () if (self.da_dec or dec_pair) else ("f", "u"):
                 d3, s3, xf2, d2, s2, xf1, y, residual, u3, u2 = T["dec_" + sfx]
                 dc = T["tails"][sfx][0]
                 self._wg("gen.conv1_" + sfx, d2, xf1, dc)

@@ -151,6 +151,30 @@ int hdrsky_conv2d_fwd(const hdrsky_conv_desc* d, const float* x, const void* w_h
 int hdrsky_conv2d_emit_supported(const hdrsky_conv_desc* d); /* [host] */
 int hdrsky_conv2d_fwd_emit(const hdrsky_conv_desc* d, const float* x, const void* w_hi, const void* w_lo, const float* bias, const float* in_scale, const float* in_shift, const float* in_part, const float* in_gamma, const float* in_beta, const float* residual, float* y, float* stats_part, void* xb_out, void* stream);
 
+/* PAIRED LAUNCHES (round 5).  Two layers of identical geometry whose launches the step used to issue one after the other - the sky and
+ * sun decoders of generator.py:110-156, forward and backward - run as ONE launch on a tensor of 2 x the batch: samples [0, B/2) belong to
+ * the first layer (its filter, bias, gamma, beta, residual), samples [B/2, B) to the second (the *2 arguments).  Every sample's
+ * arithmetic is that of the unpaired launch on its own layer (the conv takes the tile a B/2-sample launch takes), so outputs,
+ * statistics partials and everything derived from them are bit-identical to the two separate launches.
+ * hdrsky_conv2d_fwd_pair: d->B = 2 x the layers' batch; x_shared != 0: x holds B/2 samples that both layers read (no operand
+ * transform then); in_scale / in_shift / in_part are the whole batch's tables as for any launch; no emit / one-channel form. */
+int hdrsky_conv2d_fwd_pair(const hdrsky_conv_desc* d, const float* x, int x_shared, const void* w_hi, const void* w_lo, const float* bias,
+                           const void* w_hi2, const void* w_lo2, const float* bias2, const float* in_scale, const float* in_shift,
+                           const float* in_part, const float* in_gamma, const float* in_beta, const float* in_gamma2,
+                           const float* in_beta2, const float* residual, const float* residual2, float* y, float* stats_part,
+                           void* stream);
+/* hdrsky_in_affine / hdrsky_norm_act_bwd (no atomics form) / hdrsky_up2x_xf_bf16 on a paired tensor: gamma / beta for the first
+ * half of the batch, gamma2 / beta2 for the second.  hdrsky_up2x_bwd: bit 2 (value 4) of `accumulate` = dy holds 2 B samples and
+ * dx[b] = adjoint(dy[b]) + adjoint(dy[b + B]) (two layers' gradients with respect to an input they share). */
+int hdrsky_in_affine_pair(const float* part, int nparts, int B, int C, int count, const float* gamma, const float* beta,
+                          const float* gamma2, const float* beta2, float eps, float* scale, float* shift, void* stream);
+int hdrsky_norm_act_bwd_pair(const float* x, const float* part, int nparts, const float* gamma, const float* beta, const float* gamma2,
+                             const float* beta2, float eps, float slope, const float* dy, int pooled, void* dx, int dx_bf16,
+                             float* sums, float* ws, int B, int H, int W, int C, void* stream);
+int hdrsky_up2x_xf_bf16_pair(const float* x, int x_bf16, int B, int H, int W, int C, const float* in_part, int in_nparts, const float* gamma,
+                             const float* beta, const float* gamma2, const float* beta2, float eps, float slope, void* y_bf16, void* stream);
+
+
 
 /* ------------------------------------------------------------------------------------------
  * Normalisation / activation / pooling around the convolutions
