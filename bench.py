@@ -68,6 +68,9 @@ def parse():
                          "default of a bare --da), sunpose (sunpose_net.py:11,16), decoders (distortion_aware_ops.deconv2d in "
                          "both decoders), or all")
     ap.add_argument("--dp-mode", default=None, help="gradient exchange of the N > 1 training step (parallel.py: MODES)")
+    ap.add_argument("--defer-dense", action="store_true",
+                    help="train workload: the Dense kernels' update opens the NEXT replay (Trainer(defer_dense=True), flushed inside the timed "
+                         "region) instead of closing its own step - measured level with the default (profiles/r05_defer_dense_ab.txt)")
     ap.add_argument("--steps-only", action="store_true",
                     help="only the timed loop of the chosen workload: no roofline / roofline_top / roofline_hbm / fp32_class / parity / "
                          "cpu_baseline legs (the command behind profiles/r05_train_b32_kernel_stats.csv: a profile of it holds "
@@ -433,10 +436,15 @@ def _no_gc():
     return importlib.import_module(PKG + ".kernels").no_gc()
 
 
-def timed(torch, dist, one_step, steps, warmup, dp, dev):
-    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks (seconds)."""
+def timed(torch, dist, one_step, steps, warmup, dp, dev, finish=None):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks (seconds).
+    finish (the trainer's flush): work a step may leave pending for the next one - the deferred Dense update of
+    Trainer(defer_dense=True), which opens the NEXT replay - is completed INSIDE the timed region, after the K-th step and after
+    the warm-up: the region holds exactly K whole steps' work."""
     for _ in range(warmup):
         one_step()
+    if finish is not None:
+        finish()
     torch.cuda.synchronize()
     if dp:
         dist.barrier()
@@ -444,6 +452,8 @@ def timed(torch, dist, one_step, steps, warmup, dp, dev):
     t0 = time.perf_counter()
     for _ in range(steps):
         one_step()
+    if finish is not None:
+        finish()
     torch.cuda.synchronize()
     if dp:
         dist.barrier()
@@ -676,8 +686,12 @@ def main():
         do_train, do_fwd = args.workload in ("all", "train"), args.workload in ("all", "fwd")
         roof_pw, roof_top = None, None
         if do_train:
+            # --defer-dense: the Dense kernels' RMSprop launch (1 GB of HBM traffic that nothing in the step waits for) opens the NEXT
+            # replay, in the window one stream idles in beside the forward pass, instead of closing the step (trainer.Trainer);
+            # tr.flush() inside the timed region applies the last one: K timed steps hold K whole updates.  Measured level with the
+            # default plan (2.566 vs 2.566 ms): the forward pass it runs beside slows down by what the tail of the step wins.
             tr = trainer.Trainer(gen, sun, dis, vgg, device=dev, precise=False, compute=K.BF16, world_size=world,
-                                 distortion_aware=args.da)
+                                 distortion_aware=args.da, defer_dense=args.defer_dense)
             # One step = the Trainer's segment plan (forward, losses, both backward passes, RMSprop x2 + weight
             # re-packing), every segment captured into its own hipGraph and replayed on its stream.  N > 1: each replica
             # runs the reference's batch-32 step on its shard; gradients are summed over replicas (RCCL; every loss is a
@@ -694,7 +708,7 @@ def main():
             else:
                 out = tr.capture(ldr, hdr, gt)
                 one_step = lambda: tr.replay(hooks=hooks, pre_hooks=pre_hooks)
-            dt = timed(torch, dist, one_step, args.steps, args.warmup, dp, dev)
+            dt = timed(torch, dist, one_step, args.steps, args.warmup, dp, dev, finish=tr.flush)
             assert torch.isfinite(out["y_final_lin"]).all()
             if rank == 0 and not args.no_roofline_top:
                 roof_top = roofline_top(torch, K, tr, ldr, hdr, gt, top=args.roofline_rows or 10 ** 6)
@@ -709,7 +723,8 @@ def main():
                            "per_gpu_batch": batch, "global_batch": batch * world,
                            "parallelism": ("dp%d over %s, %d ranks (%s: %s)" % (world, comm_backend, comm_ranks, ex.mode, ex.describe()))
                                           if world > 1 else "single",
-                           "hipgraph": not args.no_graph, "distortion_aware": sorted(engine.da_parts(args.da))},
+                           "hipgraph": not args.no_graph, "distortion_aware": sorted(engine.da_parts(args.da)),
+                           "dense_update": "deferred into the next replay's forward pass (flushed inside the timed region)" if tr._defer else "inside its step"},
                 "algorithmic_tflops": round(imgs / dt * TRAIN_MFLOP_PER_IMG * 1e6 / 1e12, 2)})
             del tr, ex, one_step, out
             torch.cuda.empty_cache()

@@ -173,6 +173,8 @@ SIGNATURES = {
                                         P, P, P, P, P]),
     "hdrsky_rmsprop_fc_fused_bias": (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float,
                                              P, P, P, P, P, P, P]),
+    "hdrsky_rmsprop_fc_fused_prepare": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, P, P, P, P, P]),
+    "hdrsky_rmsprop_fc_fused_apply": (c_int, [P, P, c_int, c_int, c_int, c_float, c_float, c_float, c_float, P, P, P, P]),
     "hdrsky_adam": (c_int, [P, P, P, P, c_size_t, c_float, c_float, c_float, c_float, c_float, P]),
     "hdrsky_resconv_supported": (c_int, [c_int] * 6),
     "hdrsky_resconv": (c_int, [ctypes.POINTER(ResconvArgs), P]),

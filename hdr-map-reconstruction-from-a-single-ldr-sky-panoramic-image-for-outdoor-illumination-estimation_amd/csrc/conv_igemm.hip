@@ -921,6 +921,9 @@ int dispatch_tile(ConvKArgs& a, const TileCfg& t, hipStream_t s) {
   HDRSKY_CASE_DB(4, 2, 4, 1, 32) HDRSKY_CASE_DB(2, 4, 2, 1, 32) HDRSKY_CASE_DB(4, 1, 4, 1, 32) HDRSKY_CASE_DB(8, 1, 4, 1, 32)
   HDRSKY_CASE_DB(1, 4, 4, 1, 16) HDRSKY_CASE_DB(1, 4, 2, 1, 16) HDRSKY_CASE_DB(2, 2, 4, 2, 32) HDRSKY_CASE_DB(2, 4, 4, 2, 32)
   HDRSKY_CASE_DB(1, 8, 2, 1, 16)
+  // round 5: 64 px x 64 ch per WAVE (MI = NI = 4: an A fragment read from LDS feeds four MFMAs - at NI = 1 the kernel is bound by its
+  // LDS fragment reads, 1 KB per MFMA against 0.5 KB per MFMA-time of LDS bandwidth), four waves with the full register budget
+  HDRSKY_CASE_DB(4, 1, 4, 4, 32) HDRSKY_CASE_DB(2, 2, 4, 4, 32) HDRSKY_CASE_DB(4, 1, 2, 4, 32) HDRSKY_CASE_DB(1, 4, 4, 4, 32)
 #undef HDRSKY_CASE_DB
 #undef HDRSKY_CASE
   return HDRSKY_EUNSUPPORTED;
@@ -958,6 +961,8 @@ TileCfg choose_tile(const hdrsky_conv_desc* d, bool ph = false) {
   TileCfg t = choose_tile_r4(d);
   if (hk.tile_table == 4 || hk.tile.set || d->compute == HDRSKY_BF16X3) return t;
   const long M = (long)d->B * d->Ho * d->Wo;
+  if (hk.tile_c64.set && d->Cout >= 64 && d->Cout < 128 && d->Cin >= 64 && M >= 65536 && !ph)      // A/B hook: the 64->64 class at full resolution
+    return TileCfg{hk.tile_c64.v[0], hk.tile_c64.v[1], hk.tile_c64.v[2], hk.tile_c64.v[3], hk.tile_c64.v[4], hk.tile_c64.v[5]};
   if (M >= 262144 || d->Wo < 32) return t;        // (the 128x512 network and the 4x16 maps: round 4's entries)
   const bool narrow = d->Cin <= 8;
   if (d->Cout >= 64) {

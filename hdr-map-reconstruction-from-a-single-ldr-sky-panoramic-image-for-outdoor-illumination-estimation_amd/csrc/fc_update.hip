@@ -257,4 +257,30 @@ int hdrsky_rmsprop_fc_fused_bias(float* w, float* ms, const float* x, int ldx, c
   return HDRSKY_OK;
 }
 
+// The fused update in two calls (round 5: the update itself deferred into the next step's forward pass, where one stream idles,
+// instead of closing the step - trainer.Trainer(defer_dense=True)):
+//   _prepare: launch 1 - x and dy to their transposed bf16 images inside ws, the bias gradient db (and, given bias / bias_ms, the
+//             bias vector's RMSprop step).  After it the update depends on nothing but ws: x and dy may be rewritten.
+//   _apply:   launch 2 - contracts the images of ws and updates w, ms and the two bf16 MFMA images.  The same launches with the same
+//             arguments as hdrsky_rmsprop_fc_fused_bias issues back to back: bit-identical results.
+int hdrsky_rmsprop_fc_fused_prepare(const float* x, int ldx, const float* dy, int ldy, int M, int K, int N, float lr, float rho, float eps,
+                                    float gscale, float* db, float* bias, float* bias_ms, void* ws, void* stream) {
+  if (!x || !dy || !ws || !shapes_ok(x, ldx, dy, ldy, M, K, N)) return HDRSKY_EINVAL;
+  if ((bias != nullptr) != (bias_ms != nullptr) || (bias && !db)) return HDRSKY_EINVAL;
+  const uint4 *xT, *dT;
+  return operands(x, ldx, dy, ldy, M, K, N, db, 0, ws, (hipStream_t)stream, &xT, &dT, bias, bias_ms, lr, rho, eps, gscale);
+}
+
+int hdrsky_rmsprop_fc_fused_apply(float* w, float* ms, int M, int K, int N, float lr, float rho, float eps, float gscale, void* packed_hi,
+                                  void* natural_hi, const void* ws, void* stream) {
+  if (!w || !ms || !packed_hi || !ws || M <= 0 || K <= 0 || N <= 0 || (size_t)K * N >= ((size_t)1 << 30) || (K % WK) != 0 || (N % 256) != 0)
+    return HDRSKY_EINVAL;
+  const int Mp = mpad(M);
+  const uint4* xT = (const uint4*)ws;
+  const uint4* dT = xT + (size_t)K * (Mp >> 3);
+  launch_xtdy<true>((hipStream_t)stream, xT, dT, Mp, K, N, w, ms, lr, rho, eps, gscale, packed_hi, natural_hi, 0);
+  HDRSKY_CHECK_LAUNCH();
+  return HDRSKY_OK;
+}
+
 }  // extern "C"

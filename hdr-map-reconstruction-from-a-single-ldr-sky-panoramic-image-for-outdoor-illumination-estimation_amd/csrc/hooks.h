@@ -24,7 +24,7 @@ struct HdrskyHooks {
   int nab_one;         // HDRSKY_NAB_ONE     0: InstanceNorm backward never on the one-launch register-resident kernel (default 1)
   // ---- tuning hooks (HDRSKY_EXPERIMENTS=1) --------------------------------------------------------------------------
   int experiments;
-  HdrskyTileHook tile, tile_t16, tile_wide, tile_c32, tile_c16;   // HDRSKY_TILE, _T16, _WIDE, _C32, _C16
+  HdrskyTileHook tile, tile_t16, tile_wide, tile_c32, tile_c16, tile_c64;   // HDRSKY_TILE, _T16, _WIDE, _C32, _C16, _C64 (64->64 from 65536 pixels)
   int wgrad2_s2min;    // HDRSKY_WGRAD2_S2MIN   (32)
   int wgrad2_mint;     // HDRSKY_WGRAD2_MINT    (2)
   int wgrad2_wgs;      // HDRSKY_WGRAD2_WGS     (0 = by work share)

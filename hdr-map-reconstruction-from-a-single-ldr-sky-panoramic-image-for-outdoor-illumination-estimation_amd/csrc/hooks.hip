@@ -44,7 +44,7 @@ void read_hooks() {
   h.da_group = -1; h.da_wg_group = -1; h.fc_nsplit = 4; h.fc_update_nb = 0; h.fc_rg = 4; h.nab_target = 512;
   if (h.experiments) {
     h.tile = env_tile("HDRSKY_TILE"); h.tile_t16 = env_tile("HDRSKY_TILE_T16"); h.tile_wide = env_tile("HDRSKY_TILE_WIDE");
-    h.tile_c32 = env_tile("HDRSKY_TILE_C32"); h.tile_c16 = env_tile("HDRSKY_TILE_C16");
+    h.tile_c32 = env_tile("HDRSKY_TILE_C32"); h.tile_c16 = env_tile("HDRSKY_TILE_C16"); h.tile_c64 = env_tile("HDRSKY_TILE_C64");
     h.wgrad2_s2min = env_int("HDRSKY_WGRAD2_S2MIN", h.wgrad2_s2min);
     h.wgrad2_mint = env_int("HDRSKY_WGRAD2_MINT", h.wgrad2_mint);
     h.wgrad2_wgs = env_int("HDRSKY_WGRAD2_WGS", h.wgrad2_wgs);

@@ -1354,6 +1354,37 @@ def rmsprop_fc_fused(w, ms, x, dy, pf, lr, db=None, rho=0.9, eps=1e-7, gscale=1.
                                              _p(pf.nat_hi), _p(db), _p(ws), _stream()), "rmsprop_fc_fused")
 
 
+def rmsprop_fc_fused_prepare(x, dy, Kd, N, lr, ws, db, rho=0.9, eps=1e-7, gscale=1.0, bias=None, bias_ms=None):
+    """First half of rmsprop_fc_fused (hdrsky_rmsprop_fc_fused_prepare): the operands' bf16 images into the caller's workspace ws
+    (fc_xtdy_ws), the bias gradient db and - given bias / bias_ms - the bias vector's step.  rmsprop_fc_fused_apply(…, ws) is the update."""
+    M = x.shape[0]
+    if tuple(x.shape) != (M, Kd) or tuple(dy.shape) != (M, N):
+        raise ValueError("rmsprop_fc_fused_prepare: operand shapes")
+    px, ldx = _rows2d(x, "rmsprop_fc_fused x"); pd, ldy = _rows2d(dy, "rmsprop_fc_fused dy")
+    if ws.numel() < L.load().hdrsky_fc_xtdy_ws_bytes(M, Kd, N):
+        raise ValueError("rmsprop_fc_fused_prepare: workspace too small")
+    _f32(db, N)
+    if bias is not None:
+        _f32(bias, N); _f32(bias_ms, N)
+    L.check(L.load().hdrsky_rmsprop_fc_fused_prepare(px, ldx, pd, ldy, M, Kd, N, lr, rho, eps, gscale, _p(db), _p(bias), _p(bias_ms), _p(ws),
+                                                     _stream()), "rmsprop_fc_fused_prepare")
+
+
+def rmsprop_fc_fused_apply(w, ms, M, pf, lr, ws, rho=0.9, eps=1e-7, gscale=1.0):
+    """Second half: w, ms and the bf16 images of `pf` from the operand images in ws (M = the row count _prepare was given)."""
+    Kd, N = w.shape
+    _f32(w, Kd, N); _f32(ms, Kd, N)
+    if pf.pk_lo is not None or (pf.K, pf.N) != (Kd, N):
+        raise ValueError("rmsprop_fc_fused_apply: BF16 images of the same kernel only")
+    L.check(L.load().hdrsky_rmsprop_fc_fused_apply(_p(w), _p(ms), M, Kd, N, lr, rho, eps, gscale, _p(pf.pk_hi), _p(pf.nat_hi), _p(ws), _stream()),
+            "rmsprop_fc_fused_apply")
+
+
+def fc_xtdy_ws(M, Kd, N, device):
+    """Workspace of the fused Dense update for M operand rows (persistent when the update is deferred)."""
+    return _xtdy_ws(M, Kd, N, device)
+
+
 def rmsprop(w, g, ms, lr, rho=0.9, eps=1e-7, gscale=1.0):
     n = w.numel()
     _f32(w); _f32(g, n); _f32(ms, n)

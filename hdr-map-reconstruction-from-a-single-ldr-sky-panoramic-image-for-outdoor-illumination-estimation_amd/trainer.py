@@ -113,7 +113,7 @@ class _Conv:
 class Trainer:
     def __init__(self, gen_params, sun_params, dis_params, vgg_params, device="cuda", lr=1e-4, im_height=32,
                  im_width=128, precise=False, compute=BF16, world_size=1, resconv=True, distortion_aware=False,
-                 fused_dense=True, sunpose="net"):
+                 fused_dense=True, sunpose="net", defer_dense=False):
         """sunpose="external": the step takes the sun-pose net's outputs - cmf [B,H*W] and the three Grad-CAM maps - as
         INPUTS (step(..., cmf=, cams=)) instead of owning the net: SURVEY.md section 8d's substitution for the 128x512
         configuration, whose faithful sun-pose net has 12.9 G parameters (sun_params may be None).  Everything else of
@@ -150,6 +150,15 @@ class Trainer:
         self.dense_mfma = compute == BF16 and not precise and not self.ext_sun and \
             K.fc_xtdy_supported(hw // 64 * 128, hw) and K.fc_xtdy_supported(hw, hw)
         self.fused_dense = bool(fused_dense) and self.dense_mfma
+        # defer_dense (captured steps of a fused_dense trainer): the Dense kernels' update - 1 GB of HBM traffic, 0.3 ms, nothing
+        # in the step waits for it - does not close the step on stream 2 any more.  The step ends with its first launch only (the
+        # operands' bf16 images into a persistent workspace + the bias vectors' step: `apply_fc`), the update itself
+        # (`apply_fc_run`) opens the NEXT replay on stream 2, which idles there for ~0.4 ms beside the forward pass; the sun-pose
+        # net's Dense layers (`fwd_sun_fc`) wait for it.  Same launches, same arguments, same results; what changes is when the
+        # Dense weights are current: after replay() only once flush() - or the next replay - has run (step(), test_step(),
+        # capture() and loss_dict() flush themselves).  Off by default; bench.py and train.py's loop switch it on.
+        self.defer_dense = bool(defer_dense) and self.fused_dense
+        self._fc_pending, self._fc_ws = False, {}
         self.dense_operands = None          # (flat, df1, f1, dz) of the GLOBAL batch, set by parallel.GradientExchange
         self.on_bind = None                 # callable(B) run when a step is bound to a batch (static exchange buffers)
         self.sync = None                    # parallel.BatchSync: batch statistics / the batch maximum over every replica's batch
@@ -384,7 +393,7 @@ class Trainer:
         if q:
             K.conv2d_wgrad_multi(q)
 
-    def _sunpose_forward(self, ldr, pick=None):
+    def _sunpose_forward(self, ldr, pick=None, convs_only=False):
         w, c, cp = self.gs.w, self.conv, self.compute
         t, x = {"da": self.da_sun}, ldr
         for l in (1, 2, 3):
@@ -417,7 +426,12 @@ class Trainer:
             x = pooled
         B = ldr.shape[0]
         t["flat"] = x.reshape(B, -1)
-        t["gmax"] = torch.empty(1, dtype=torch.int32, device=ldr.device)      # cleared by the finalize launch below
+        return t if convs_only else self._sunpose_dense(t, pick)
+
+    def _sunpose_dense(self, t, pick=None):
+        """The Dense layers + soft-max head of sunposeEstimation (sunpose_net.py:64-72) on the record of the conv layers."""
+        w, cp = self.gs.w, self.compute
+        t["gmax"] = torch.empty(1, dtype=torch.int32, device=t["flat"].device)      # cleared by the finalize launch below
         t["f1"] = K.fc_finalize(K.fc_fwd(t["flat"], self.fc1, cp), w["sun.fc1.bias"], relu=True, zero_word=t["gmax"])
         if pick is None:
             t["z"], t["cmf"] = K.softmax_head(K.fc_fwd(t["f1"], self.fc2, cp), w["sun.fc2.bias"], t["gmax"])
@@ -835,15 +849,41 @@ class Trainer:
 
         # ------------------------------------------------------------------ forward (train.py:239-299)
         # (the longest independent chain is enqueued first; segment order = host launch order)
-        @seg("fwd_sun", 1)
-        def _():       # sun-pose net, Grad-CAM (constants for the gradient: train.py:257-271), sun radiance head
-            if self.ext_sun:      # the net's outputs are inputs of the step; tf.reduce_max(sunpose_pred) from its own launch
-                t = T["t"] = {"cmf": T["cmf_in"], "gmax": K.global_max(T["cmf_in"])}
-                T["cams"] = T["cams_in"]
-            else:
-                t = T["t"] = self._sunpose_forward(T["ldr"], pick=T["gt"])
+        defer = self._defer
+        sun_done = "fwd_sun_fc" if defer else "fwd_sun"      # the segment that completes the sun branch
+        if defer:
+            # the PREVIOUS step's Dense update (see __init__: defer_dense), in the window stream 2 idles in beside the forward pass
+            M = (self.dense_operands[0] if self.dense_operands else T["ldr"]).shape[0]
+            for name, pf in (("sun.fc2", self.fc2), ("sun.fc1", self.fc1)):
+                if name not in self._fc_ws or self._fc_ws[name][0] != M:
+                    self._fc_ws[name] = (M, K.fc_xtdy_ws(M, pf.K, pf.N, self.device))
+
+            @seg("apply_fc_run", 2)
+            def _():
+                for name, pf in (("sun.fc2", self.fc2), ("sun.fc1", self.fc1)):
+                    o, n, shape = self.gs.offsets[name + ".kernel"]
+                    K.rmsprop_fc_fused_apply(w[name + ".kernel"], self.gs.ms[o:o + n].view(shape), self._fc_ws[name][0], pf, self.lr,
+                                             self._fc_ws[name][1], gscale=self._gscale)
+
+            @seg("fwd_sun", 1)
+            def _():       # the sun-pose net's conv layers: nothing here reads the Dense kernels
+                T["t"] = self._sunpose_forward(T["ldr"], pick=T["gt"], convs_only=True)
+
+            @seg("fwd_sun_fc", 1, ["apply_fc_run"])
+            def _():       # Dense layers + soft-max head on the updated kernels, Grad-CAM, sun radiance head
+                t = self._sunpose_dense(T["t"], T["gt"])
                 T["cams"] = self._gradcam(t, T["gt"])
-            T["rad"] = self._sunrad_forward(T["ldr"], T["cams"], t, T)
+                T["rad"] = self._sunrad_forward(T["ldr"], T["cams"], t, T)
+        else:
+            @seg("fwd_sun", 1)
+            def _():       # sun-pose net, Grad-CAM (constants for the gradient: train.py:257-271), sun radiance head
+                if self.ext_sun:      # the net's outputs are inputs of the step; tf.reduce_max(sunpose_pred) from its own launch
+                    t = T["t"] = {"cmf": T["cmf_in"], "gmax": K.global_max(T["cmf_in"])}
+                    T["cams"] = T["cams_in"]
+                else:
+                    t = T["t"] = self._sunpose_forward(T["ldr"], pick=T["gt"])
+                    T["cams"] = self._gradcam(t, T["gt"])
+                T["rad"] = self._sunrad_forward(T["ldr"], T["cams"], t, T)
 
         # the discriminator's pass over the REAL pairs needs nothing the generator produces: it runs beside the forward
         # pass, in the window stream 2 otherwise idles in (between the VGG target features and the perceptual term, ~0.45 ms)
@@ -945,7 +985,7 @@ class Trainer:
                 # delays the perceptual term's second half, which the backward pass waits for
                 T["disc_real_wg"] = self._take_wgrads()
 
-        @seg("fwd_blend", 0, ["fwd_sun"])
+        @seg("fwd_blend", 0, [sun_done])
         def _():
             rad_lin, rad_gamma, gamma, beta = T["rad"]
             if not early_head and not dec_pair:
@@ -1263,6 +1303,13 @@ class Trainer:
         @seg("apply_fc", HOOKS.H.apply_fc_stream, ["bwd_dense", "wg_dense"])
         def _():
             fc0, fc1 = self.fc_grad_range()
+            if defer:      # the operands' images + the bias vectors' step; the kernels' update opens the next replay (apply_fc_run)
+                flat, df1, f1, dz = self.dense_operands or (T["t"]["flat"], T["df1"], T["t"]["f1"], T["dz"])
+                for name, pf, x_, dy_ in (("sun.fc2", self.fc2, f1, dz), ("sun.fc1", self.fc1, flat, df1)):
+                    ob, nb_, _ = self.gs.offsets[name + ".bias"]
+                    K.rmsprop_fc_fused_prepare(x_, dy_, pf.K, pf.N, self.lr, self._fc_ws[name][1], g[name + ".bias"], gscale=self._gscale,
+                                               bias=self.gs.flat[ob:ob + nb_], bias_ms=self.gs.ms[ob:ob + nb_])
+                return
             if self.fused_dense:
                 flat, df1, f1, dz = self.dense_operands or (T["t"]["flat"], T["df1"], T["t"]["f1"], T["dz"])
                 for name, pf, x_, dy_ in (("sun.fc2", self.fc2, f1, dz), ("sun.fc1", self.fc1, flat, df1)):
@@ -1329,10 +1376,25 @@ class Trainer:
         return "bwd_dense" if self.fused_dense or self.dense_wgrad_external else "wg_dense"
 
     def _skip(self, update):
-        """Segments an `update` / gradient-only step leaves out."""
+        """Segments an `update` / gradient-only step leaves out (apply_fc_run: only while a deferred Dense update is pending)."""
+        late = () if self._fc_pending else ("apply_fc_run",)
         if not update:
-            return self.APPLY
-        return ("wg_dense",) if self.fused_dense else ()
+            return tuple(self.APPLY) + late
+        return (("wg_dense",) if self.fused_dense else ()) + late
+
+    @property
+    def _defer(self):
+        """The Dense update of a captured step is deferred into the next replay (see __init__: defer_dense)."""
+        return bool(getattr(self, "defer_dense", False)) and self.fused_dense and not self.ext_sun
+
+    def flush(self):
+        """Applies a deferred Dense update now (defer_dense): after it the trainer's weights are those the reference holds after
+        optimizer.apply_gradients.  A no-op otherwise."""
+        if not self._fc_pending:
+            return
+        captured = self._graphs is not None and getattr(self, "_captured", None) is not None and self._T is self._captured[0]
+        self._execute(["apply_fc_run"], graphs=self._graphs if captured else None)
+        self._fc_pending = False
 
     def _take_wgrads(self):
         return self._wjobs.pop(torch.cuda.current_stream().cuda_stream, [])
@@ -1410,9 +1472,13 @@ class Trainer:
         """ldr / hdr_t [B,H,W,3] BGR (train.py:386-387 rgb2bgr already applied), sunpose_gt [B,H*W]; cmf / cams: the
         sun-pose net's outputs for a sunpose='external' trainer.
         Returns the dict generator_in_step returns (train.py:349) - losses are in self.losses (device)."""
+        self.flush()                      # (a pending deferred update belongs to the previous binding's workspace)
         self._bind(ldr, hdr_t, sunpose_gt, cmf, cams)
         skip = self._skip(update)
         self._execute([n for n, *_ in self._segs if n not in skip])
+        if update and self._defer:      # an eager step is never left half applied
+            self._fc_pending = True
+            self.flush()
         return self._outputs()
 
     def test_step(self, ldr, hdr_t, sunpose_gt, cmf=None, cams=None):
@@ -1420,11 +1486,12 @@ class Trainer:
         every BatchNorm in inference mode, all loss terms (generator_in_step / discriminator_in_step with
         training=False) and no update.  Returns the output dict of `step`; the loss terms are in self.losses /
         loss_dict().  Issued eagerly (not part of the captured step); gradients buffers are left zeroed / partial."""
+        self.flush()
         self._bn_training = False
         saved = (getattr(self, "_T", None), getattr(self, "_segs", None), getattr(self, "_events", None))
         try:
             self._bind(ldr, hdr_t, sunpose_gt, cmf, cams)
-            self._execute(["zero", "fwd_sun", "fwd_enc", "vgg_target", "fwd_blend", "loss_vgg", "loss_vgg_b", "loss_adv"])
+            self._execute(["zero", "fwd_sun", "fwd_sun_fc", "fwd_enc", "vgg_target", "fwd_blend", "loss_vgg", "loss_vgg_b", "loss_adv"])
             T, cvo = self._T, self.conv["dis.out"]
             for other, target, slot in ((hdr_t, 1.0, 6), (T["y_lin"], 0.0, 5)):        # train.py:351-369, training=False
                 R = self._down_stack("dis.", self.ds.w, K.concat2(ldr, other), training=False)
@@ -1450,6 +1517,9 @@ class Trainer:
         if gscale is not None:
             self._gscale = float(gscale)
         self._execute(self.APPLY)
+        if self._defer:
+            self._fc_pending = True
+            self.flush()
 
     def fc_grad_range(self):
         """[start, end) of the two Dense layers' gradients inside gs.grad - contiguous, the last trainables of the
@@ -1466,16 +1536,20 @@ class Trainer:
         if self.sync is not None:
             raise RuntimeError("Trainer.capture: a step with batch statistics over several replicas (parallel.BatchSync) holds "
                                "collectives inside its segments - issue it eagerly (step / reduce_all / apply_gradients)")
+        self.flush()
         self._bind(ldr, hdr_t, sunpose_gt, cmf, cams)
         # the warm-up steps (lazy kernel attributes, allocator) must not train: weights, RMSprop slots and BatchNorm
         # moving statistics are put back afterwards (and replicas of a data-parallel job stay identical)
         state = [(t, t.clone()) for t in (self.gs.flat, self.gs.ms, self.ds.flat, self.ds.ms)]
         for _ in range(warmup):
-            self._execute()
+            self._execute([n for n, *_ in self._segs if n != "apply_fc_run"])
+            if self._defer:      # (the deferred half, so that its launches are warm too)
+                self._execute(["apply_fc_run"])
         torch.cuda.synchronize()
         for t, saved in state:
             t.copy_(saved)
         del state
+        self._fc_pending = False
         self.repack()
         torch.cuda.synchronize()
         self._graphs = {}
@@ -1501,6 +1575,8 @@ class Trainer:
             self._events = {}
         skip = self._skip(update)
         self._execute([n for n, *_ in self._segs if n not in skip], graphs=self._graphs, hooks=hooks, pre_hooks=pre_hooks)
+        if self._defer:      # apply_fc_run (if it was pending) has run; an updating step leaves a new one
+            self._fc_pending = bool(update)
 
     def loss_dict(self):
         """Host copy of the loss terms with the reference's names (train.py:480-489) - synchronises."""
@@ -1527,6 +1603,7 @@ class SunPoseTrainer(Trainer):
         # distortion_aware: sunpose_net.py:11,16 - every sunposeLayer convolution is distortion_aware_ops.conv2d
         self.da_sun, self._da_geo = bool(distortion_aware), {}
         self.da_parts, self.sync = (("sunpose",) if self.da_sun else ()), None
+        self.defer_dense, self._fc_pending, self.fused_dense, self.ext_sun = False, False, False, False
         hw = im_height * im_width
         self.dense_mfma = compute == BF16 and not precise and K.fc_xtdy_supported(hw // 64 * 128, hw) and K.fc_xtdy_supported(hw, hw)
         self.gs = FlatParams(OrderedDict(("sun." + k, v) for k, v in sun_params.items()), self.device)

@@ -494,6 +494,15 @@ int hdrsky_rmsprop_fc_fused(float* w, float* ms, const float* x, int ldx, const 
 /* ... that also applies the RMSprop step to the layer's bias vector (bias, bias_ms [N]; db [N] - the column sums of dy - must be
  * given), inside the launch that forms those sums. */
 int hdrsky_rmsprop_fc_fused_bias(float* w, float* ms, const float* x, int ldx, const float* dy, int ldy, int M, int K, int N, float lr, float rho, float eps, float gscale, void* packed_hi, void* natural_hi, float* db, float* bias, float* bias_ms, void* ws, void* stream);
+/* hdrsky_rmsprop_fc_fused_bias as two calls with the same launches, so that the update can be issued later than its operands exist
+ * (the next step's forward pass has an idle stream; the end of the step has none): _prepare writes the operands' transposed bf16
+ * images into ws (hdrsky_fc_xtdy_ws_bytes), db and - given bias / bias_ms - the bias vector's step; _apply contracts ws and updates
+ * w, ms and the two bf16 images.  Between the two calls ws must stay untouched; x and dy may be rewritten. */
+int hdrsky_rmsprop_fc_fused_prepare(const float* x, int ldx, const float* dy, int ldy, int M, int K, int N, float lr, float rho, float eps,
+                                    float gscale, float* db, float* bias, float* bias_ms, void* ws, void* stream);
+int hdrsky_rmsprop_fc_fused_apply(float* w, float* ms, int M, int K, int N, float lr, float rho, float eps, float gscale, void* packed_hi,
+                                  void* natural_hi, const void* ws, void* stream);
+
 /* tf.keras.optimizers.Adam (train_sun.py:191 / tf_utils.py:324; defaults beta 0.9 / 0.999, eps 1e-7) over a flat buffer:
  * m, v are the slots; lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t) is computed by the caller for step t; g is scaled by gscale. */
 int hdrsky_adam(float* w, const float* g, float* m, float* v, size_t n, float lr_t, float beta1, float beta2, float eps,

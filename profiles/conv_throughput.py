@@ -35,7 +35,7 @@ def run(graphs, reps=4):
 SHAPES = [("vgg 64->64 @32x128 B16", 16, 32, 128, 64, 64, 3, True), ("vgg 128->128 @16x64 B16", 16, 16, 64, 128, 128, 3, True),
           ("vgg 256->256 @8x32 B16", 16, 8, 32, 256, 256, 3, True), ("dec 64->32 @32x128 B32 (f32 out+stats)", 32, 32, 128, 64, 32, 3, False),
           ("dec 128->64 @16x64 B32", 32, 16, 64, 128, 64, 3, False), ("sun 32->32 7x7 @32x128 B32", 32, 32, 128, 32, 32, 7, False)]
-TILES = [None, "2,4,4,1,32,1", "2,2,4,2,32,1", "2,4,4,2,32,1", "1,4,4,1,32,1", "2,4,2,1,32,1", "2,2,4,2,32,0", "4,1,4,2,32,0", "8,1,4,2,32,0", "4,2,4,1,32,1", "1,8,4,1,32,1"]
+TILES = [None, "2,4,4,1,32,1", "2,2,4,2,32,1", "2,4,4,2,32,1", "1,4,4,1,32,1", "4,2,4,1,32,1", "1,8,4,1,32,1", "4,1,4,4,32,1", "2,2,4,4,32,1", "4,1,2,4,32,1", "1,4,4,4,32,1"]
 for name, B, H, W, C, F, k, bf in SHAPES:
     x = torch.randn(B, H, W, C, device=dev)
     if bf:
