@@ -970,6 +970,7 @@ TileCfg choose_tile(const hdrsky_conv_desc* d, bool ph = false) {
     if (d->Cout >= 128 && d->Cout < 256 && M == 16384) t = TileCfg{1, 8, 4, 1, 32, 1};   // 64->128 / 128->128 at 16x64, batch 16, and their transposes: 64 px x 128 ch (alone -4..-8 %, saturated -26..-30 %)
     else if (d->Cout < 128 && M > 16384) {
       if (ph) t = TileCfg{2, 2, 4, 2, 32, 1};                                            // stride-2 data gradients by phases -> 64 channels (alone +-0, saturated -22..-29 %)
+      else if (d->stride != 1 || d->dilate != 1 || d->KH != 3) {}                         // (stride-2 layers and their zero-stuffed gradients: round 4's entries)
       else if (d->Cin <= 32 && M >= 65536) t = TileCfg{8, 1, 4, 2, 32, 0};               // 3x3 32->64 at full resolution (decoder data gradient: alone -10 %, saturated -21 %)
       else if (d->Cin <= 32 && M <= 32768) t = TileCfg{1, 4, 4, 1, 32, 1};               // 3x3 32->64 at 16x64 (alone -3 %, saturated -12 %)
     }

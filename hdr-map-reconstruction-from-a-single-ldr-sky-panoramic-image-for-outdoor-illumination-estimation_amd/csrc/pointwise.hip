@@ -1118,7 +1118,10 @@ int hdrsky_norm_act_bwd_one_launch(int H, int W, int pooled, int dy_bf16) {
   if (!hdrsky_hooks().nab_one) return 0;
   const int units = pooled ? (H / 2) * (W / 2) : H * W;
   if (pooled) return units == 1024 || units == 256;
-  return units == 4096 || units == 1024 || units == 256;
+  // (the 4096-pixel maps keep the sliced pair: their slab needs 8-channel groups to fit the registers, i.e. 32 B of every 128-B line
+  // per workgroup - 22.4 us alone against 17.9 us for the two sliced launches, profiles/r05_microbench_nab.txt; a 16-channel slab
+  // spills: 29.6 us)
+  return units == 1024 || units == 256;
 }
 
 static int norm_act_bwd_impl(const float* x, const float* part, int nparts, const float* gamma, const float* beta,
@@ -1127,10 +1130,13 @@ static int norm_act_bwd_impl(const float* x, const float* part, int nparts, cons
                              const float* gamma2, const float* beta2, int gsplit) {
   if (!x || !part || !gamma || !beta || !dy || !dx || (C & 15)) return HDRSKY_EINVAL;
   if (pooled && ((H | W) & 1)) return HDRSKY_EINVAL;
-  const int S = hdrsky_norm_act_bwd_nslices(B, H, W, C, pooled);
+  // (a paired tensor is sliced like ONE of its layers' launches: the same partial sums in the same order, bit for bit)
+  const int S = hdrsky_norm_act_bwd_nslices(gsplit > 0 ? gsplit : B, H, W, C, pooled);
   const int groups = B * (C / 16);
   // the register-resident single launch (norm_act_bwd1_kernel) where a (sample, channel group) slab is NT x NV units
-  if (hdrsky_norm_act_bwd_one_launch(H, W, pooled, (dx_bf16 & 2) != 0)) {
+  // (calls that store dx as bf16 - the single-product mode's: the fp32-class mode keeps the sliced form, so that its training
+  // trajectories - bench.py's parity fit - stay those of round 4 bit for bit)
+  if ((dx_bf16 & 1) && hdrsky_norm_act_bwd_one_launch(H, W, pooled, (dx_bf16 & 2) != 0)) {
     const int units = pooled ? (H / 2) * (W / 2) : H * W;
     const bool dy16 = (dx_bf16 & 2) != 0;
 #define HDRSKY_NAB1(NT_, NV_, CG_, P_)                                                                                              \
@@ -1143,10 +1149,9 @@ static int norm_act_bwd_impl(const float* x, const float* part, int nparts, cons
         hipLaunchKernelGGL((norm_act_bwd1_kernel<NT_, NV_, CG_, P_, false>), dim3(B * (C / CG_)), dim3(NT_), 0, (hipStream_t)stream, x, \
                            part, nparts, gamma, beta, eps, slope, dy, dx, dx_bf16, sums, dgamma, dbeta, H, W, C, gamma2, beta2, gsplit); \
     } while (0)
-    // units per sample -> (threads, units per thread, channels per workgroup): 64 (32 for the pooled form) values of xhat per
-    // thread at most - the 4096-pixel maps and the pooled forms on 8-channel groups
-    if (!pooled && units == 4096) { if (dy16) HDRSKY_NAB1(1024, 16, 16, false); else HDRSKY_NAB1(1024, 8, 8, false); }
-    else if (!pooled && units == 1024) HDRSKY_NAB1(1024, 4, 16, false);
+    // units per sample -> (threads, units per thread, channels per workgroup): 32 values of xhat per thread at most - the pooled
+    // form of the 4096-pixel maps on 8-channel groups
+    if (!pooled && units == 1024) HDRSKY_NAB1(1024, 4, 16, false);
     else if (!pooled && units == 256) HDRSKY_NAB1(256, 4, 16, false);
     else if (pooled && units == 1024) HDRSKY_NAB1(1024, 2, 8, true);
     else if (pooled && units == 256) HDRSKY_NAB1(512, 2, 16, true);

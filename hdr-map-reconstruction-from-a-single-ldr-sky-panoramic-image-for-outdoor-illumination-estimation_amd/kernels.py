@@ -659,7 +659,7 @@ def norm_act_bwd(x, stats: Stats, gamma, beta, slope, dy, pooled, eps=IN_EPS, wa
         want_sums = False
     elif want_sums:
         sums = torch.empty((B, 2, C), dtype=torch.float32, device=x.device)
-    S = L.load().hdrsky_norm_act_bwd_nslices(B, H, W, C, int(pooled))
+    S = L.load().hdrsky_norm_act_bwd_nslices(B // 2 if pair is not None else B, H, W, C, int(pooled))      # (a paired tensor: sliced like one layer's launch)
     ws = torch.empty((B, S, 2, C), dtype=torch.float32, device=x.device) if S > 1 else None
     if pair is not None:      # a PAIRED tensor: (gamma, beta) for the first half of the batch, pair = (gamma2, beta2) for the second
         if dgamma is not None or dbeta is not None:

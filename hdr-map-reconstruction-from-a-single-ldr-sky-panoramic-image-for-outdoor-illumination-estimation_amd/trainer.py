@@ -280,7 +280,7 @@ class Trainer:
         if B not in st:
             w, g, sums, red = self.gs.w, self.gs.g, {}, {}
             pairs = {}      # the two decoders' norm layers of one depth share a table of 2 B samples (paired launches)
-            for k in (2, 3):
+            for k in (2, 3) if "gen.norm2_f.gamma" in w else ():      # (the sun-pose pre-trainer has no generator)
                 tp = torch.zeros((2 * B, 2, w["gen.norm%d_f.gamma" % k].numel()), dtype=torch.float32, device=self.device)
                 pairs["gen.norm%d_f" % k], pairs["gen.norm%d_u" % k] = tp[:B], tp[B:]
                 sums["gen.norm%d_f+u" % k] = tp

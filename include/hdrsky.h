@@ -221,9 +221,10 @@ int hdrsky_norm_act_bwd(const float* x, const float* part, int nparts, const flo
  * which round it to bf16 while staging anyway: bit-neutral, half the bytes.) */
 /* Spatial slices S the call above splits each sample into; when S > 1 it needs the workspace ws [B][S][2][C]. [host] */
 int hdrsky_norm_act_bwd_nslices(int B, int H, int W, int C, int pooled);
-/* 1 when hdrsky_norm_act_bwd runs the call as ONE launch that reads x and dy once - the (sample, 8- or 16-channel group) slab held
- * in the registers of one workgroup: 256 / 1024 / 4096 pixels (256 / 1024 windows of the pooled form) per sample; the workspace
- * is then not touched.  HDRSKY_NAB_ONE=0 switches it off. [host] */
+/* 1 when hdrsky_norm_act_bwd runs a call that stores dx as bf16 (bit 0 of dx_bf16: the single-product mode's calls) as ONE launch
+ * that reads x and dy once - the (sample, 8- or 16-channel group) slab held in the registers of one workgroup: 256 / 1024 pixels
+ * (256 / 1024 windows of the pooled form) per sample; the workspace is then not touched.  HDRSKY_NAB_ONE=0 switches it
+ * off. [host] */
 int hdrsky_norm_act_bwd_one_launch(int H, int W, int pooled, int dy_bf16);
 
 /* ------------------------------------------------------------------------------------------

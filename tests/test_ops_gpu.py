@@ -65,6 +65,9 @@ def test_norm_act_bwd(dev, shape, pooled):
         a = K.norm_act_bwd(xr, st, d(gam), d(bet), 0.0, dyb, pooled, out_bf16=out_bf16)
         b = K.norm_act_bwd(xr, st, d(gam), d(bet), 0.0, dyb.float(), pooled, out_bf16=out_bf16)
         assert a.dtype == b.dtype and torch.equal(a, b)
+        if out_bf16:      # (the calls that store dx as bf16 run the one-launch register-resident form on these shapes: against the oracle
+                          # at the precision of a bf16 gradient in, a bf16 gradient out)
+            assert_close(a.float(), gx, 1.2e-2, "norm_act_bwd, bf16 gradient in / out")
 
 
 def test_norm_act_bwd_pool_routing_tight_off_the_tie_channels(dev):
@@ -357,8 +360,8 @@ def test_zero_fill_kernel_sizes_and_alignments_also_under_graph_replay(dev):
         assert float(x.min()) == 1.0 and float(x.max()) == 1.0, it
 
 
-@pytest.mark.parametrize("shape,pooled", [((4, 32, 128, 32), False), ((4, 32, 128, 32), True), ((3, 16, 64, 64), False),
-                                          ((3, 16, 64, 64), True), ((5, 8, 32, 128), False), ((2, 32, 128, 128), False)])
+@pytest.mark.parametrize("shape,pooled", [((4, 32, 128, 32), True), ((3, 16, 64, 64), False), ((3, 16, 64, 64), True), ((5, 8, 32, 128), False),
+                                          ((2, 16, 64, 128), False)])
 def test_norm_act_bwd_one_launch_equals_the_sliced_form(dev, shape, pooled, monkeypatch):
     """Round 5: the InstanceNorm (+ activation, + max-pool) backward of the 32x128 network's maps runs as ONE launch that reads
     x and dy once (norm_act_bwd1_kernel: the (sample, channel group) slab in the registers of one workgroup) instead of the
@@ -374,7 +377,8 @@ def test_norm_act_bwd_one_launch_equals_the_sliced_form(dev, shape, pooled, monk
     dshape = (B, H // 2, W // 2, C) if pooled else shape
     dy = torch.randn(*dshape, device=dev, generator=g)
     assert L.load().hdrsky_norm_act_bwd_one_launch(H, W, int(pooled), 0) == 1
-    cases = [(xr, dy, False), (xr, dy.to(torch.bfloat16), True), (xr.to(torch.bfloat16), dy.to(torch.bfloat16), True)]
+    # (the one-launch form takes the calls that store dx as bf16 - the single-product mode's; fp32 outputs stay on the sliced form)
+    cases = [(xr, dy, True), (xr, dy.to(torch.bfloat16), True), (xr.to(torch.bfloat16), dy.to(torch.bfloat16), True)]
     for xin, dyin, ob in cases:
         run = lambda: K.norm_act_bwd(xin, st, gam, bet, 0.0 if pooled else 0.1, dyin, pooled, want_sums=True, out_bf16=ob)
         one, s_one = run()
