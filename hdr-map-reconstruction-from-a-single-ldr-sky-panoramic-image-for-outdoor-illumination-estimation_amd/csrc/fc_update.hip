@@ -82,7 +82,9 @@ __device__ __forceinline__ unsigned swap_pairs(unsigned v) {   // lane 2j <-> la
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);
 }
 
-template <bool FUSED, int NB>
+// NT (bit mask): non-temporal cache policy (aux = 2) on 1: the stores of the two bf16 images, 2: the stores of w / ms, 4: the loads
+// of w / ms - bytes that are read or written exactly once per step and only evict what other launches would still find in L2 / MALL
+template <bool FUSED, int NB, int NT = 0>
 __global__ void __launch_bounds__(256, NB == 1 ? 8 : 5) fc_xtdy_kernel(const uint4* __restrict__ xT, const uint4* __restrict__ dT,
                                                          int Mpad, int K, int N, float* __restrict__ w,
                                                          float* __restrict__ ms, float lr, float rho, float eps,
@@ -90,6 +92,7 @@ __global__ void __launch_bounds__(256, NB == 1 ? 8 : 5) fc_xtdy_kernel(const uin
                                                          unsigned* __restrict__ nat_hi, int accumulate) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
+  constexpr int AUX_IMG = (NT & 1) ? 2 : 0, AUX_ST = (NT & 2) ? 2 : 0, AUX_LD = (NT & 4) ? 2 : 0;
   constexpr int WN = 32 * NB;
   const int kb = blockIdx.y * WK, nw = (blockIdx.x * 4 + wave) * WN;
   const int mq = Mpad >> 3;           // 16-byte groups per operand row
@@ -125,8 +128,8 @@ __global__ void __launch_bounds__(256, NB == 1 ? 8 : 5) fc_xtdy_kernel(const uin
       float wv[16], mv[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        wv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, vo, ROWB(i), 0));
-        mv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, vo, ROWB(i), 0));
+        wv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, vo, ROWB(i), AUX_LD));
+        mv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, vo, ROWB(i), AUX_LD));
       }
       unsigned hb[16];
 #pragma unroll
@@ -136,8 +139,8 @@ __global__ void __launch_bounds__(256, NB == 1 ? 8 : 5) fc_xtdy_kernel(const uin
           const float gg = acc[b][i] * gscale;
           const float m_ = rho * mv[i] + (1.f - rho) * gg * gg;
           const float nv = wv[i] - lr * gg / (sqrtf(m_) + eps);
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m_), rm, vo, ROWB(i), 0);
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, nv), rw, vo, ROWB(i), 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m_), rm, vo, ROWB(i), AUX_ST);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, nv), rw, vo, ROWB(i), AUX_ST);
           hb[i] = f2bf(nv);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -148,7 +151,7 @@ __global__ void __launch_bounds__(256, NB == 1 ? 8 : 5) fc_xtdy_kernel(const uin
       for (int q = 0; q < 4; ++q) {
         typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
         const u32x2_t v = {hb[4 * q] | (hb[4 * q + 1] << 16), hb[4 * q + 2] | (hb[4 * q + 3] << 16)};
-        __builtin_amdgcn_raw_buffer_store_b64(v, rp, vp, (unsigned)((kb >> 3) + q) * (unsigned)N * 16u, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(v, rp, vp, (unsigned)((kb >> 3) + q) * (unsigned)N * 16u, AUX_IMG);
       }
       // natural image [K][N] bf16: neighbouring lanes trade one value so that every lane stores a 32-bit pair
       // (even lane: row i, columns n, n+1; odd lane: row i+1, columns n-1, n); a NULL image has zero records (dropped)
@@ -158,7 +161,7 @@ __global__ void __launch_bounds__(256, NB == 1 ? 8 : 5) fc_xtdy_kernel(const uin
       for (int i = 0; i < 16; i += 2) {
         const unsigned got = swap_pairs(odd ? hb[i] : hb[i + 1]);
         const unsigned word = odd ? (got | (hb[i + 1] << 16)) : (hb[i] | (got << 16));
-        __builtin_amdgcn_raw_buffer_store_b32(word, rn, vn, ROWB(i) >> 1, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(word, rn, vn, ROWB(i) >> 1, AUX_IMG);
       }
     } else {
 #pragma unroll
@@ -189,7 +192,14 @@ inline int blocks_per_wave() {
 template <bool FUSED>
 inline void launch_xtdy(hipStream_t st, const uint4* xT, const uint4* dT, int Mp, int K, int N, float* w, float* ms, float lr,
                         float rho, float eps, float gscale, void* pk, void* nat, int accumulate) {
-  if (blocks_per_wave() == 2)
+  const int nt = FUSED ? hdrsky_hooks().fc_nt : 0;
+  if (blocks_per_wave() == 2 && nt != 0) {
+#define HDRSKY_XTDY_NT(NT_)                                                                                                    \
+    case NT_: hipLaunchKernelGGL((fc_xtdy_kernel<FUSED, 2, NT_>), dim3(N / 256, K / WK), dim3(256), 0, st, xT, dT, Mp, K, N, w, ms, lr, \
+                                 rho, eps, gscale, (uint2*)pk, (unsigned*)nat, accumulate); break;
+    switch (nt) { HDRSKY_XTDY_NT(1) HDRSKY_XTDY_NT(2) HDRSKY_XTDY_NT(3) HDRSKY_XTDY_NT(4) HDRSKY_XTDY_NT(5) HDRSKY_XTDY_NT(6) HDRSKY_XTDY_NT(7) default: break; }
+#undef HDRSKY_XTDY_NT
+  } else if (blocks_per_wave() == 2)
     hipLaunchKernelGGL((fc_xtdy_kernel<FUSED, 2>), dim3(N / 256, K / WK), dim3(256), 0, st, xT, dT, Mp, K, N, w, ms, lr, rho,
                        eps, gscale, (uint2*)pk, (unsigned*)nat, accumulate);
   else

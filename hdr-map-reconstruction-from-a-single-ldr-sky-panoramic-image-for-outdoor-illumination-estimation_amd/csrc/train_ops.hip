@@ -1465,10 +1465,12 @@ __global__ void __launch_bounds__(256) rmsprop_fc_kernel(float* __restrict__ w, 
       const float wv = w[idx] - lr * gg / (sqrtf(m) + eps);
       ms[idx] = m; w[idx] = wv;
       h[j] = f2bf(wv);
-      if (nat_hi) nat_hi[idx] = h[j];
-    }
-    pk_hi[i] = uint4{h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16), h[4] | ((unsigned)h[5] << 16),
-                     h[6] | ((unsigned)h[7] << 16)};
+      if (nat_hi) __builtin_nontemporal_store(h[j], nat_hi + idx);      // (the images are written once and read by the NEXT step: round 5,
+    }                                                                    //  non-temporal stores: profiles/r05_fc_nt.txt)
+    const uint4 pk = uint4{h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16), h[4] | ((unsigned)h[5] << 16),
+                           h[6] | ((unsigned)h[7] << 16)};
+    __builtin_nontemporal_store(pk.x, &pk_hi[i].x); __builtin_nontemporal_store(pk.y, &pk_hi[i].y);
+    __builtin_nontemporal_store(pk.z, &pk_hi[i].z); __builtin_nontemporal_store(pk.w, &pk_hi[i].w);
   }
 }
 
