@@ -41,7 +41,9 @@ class _Hooks:
         self.dec_head_early = exp("HDRSKY_DEC_HEAD_EARLY", "1") != "0"
         self.bwd_dense_stream = int(exp("HDRSKY_BWD_DENSE_STREAM", "2"))
         self.wg_res_stream = int(exp("HDRSKY_WG_RES_STREAM", "1"))
-        self.wg_enc_split = exp("HDRSKY_WG_ENC_SPLIT", "1") != "0"
+        # (round 5: with the decoders paired the main chain ends ~300 us before the side streams - the encoder head's weight
+        # gradients close it again instead of queueing behind wg_res on stream 1: -0.5 %, profiles/r05_plan_ab_final.txt)
+        self.wg_enc_split = exp("HDRSKY_WG_ENC_SPLIT", "0") != "0"
         self.apply_fc_stream = int(exp("HDRSKY_APPLY_FC_STREAM", "2"))
         self.apply_after_fc = exp("HDRSKY_APPLY_AFTER_FC", "0") == "1"
         self.plan_move = exp("HDRSKY_PLAN_MOVE", "")

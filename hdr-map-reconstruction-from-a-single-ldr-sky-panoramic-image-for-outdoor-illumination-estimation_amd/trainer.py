@@ -1257,7 +1257,8 @@ class Trainer:
         # The encoder head closes the backward pass on stream 0.  The gradients of its two stride-2 layers are complete two
         # data gradients before the chain ends: their weight gradients (act_bf16 + conv_wgrad2 + reduce, ~100 us) run as
         # segment wg_enc on stream 1 - idle by then - beside the rest of the chain instead of behind it; only the stem's
-        # (conv_wgrad3) stays at the end.  HDRSKY_WG_ENC_SPLIT=0: one segment, A/B hook.
+        # (conv_wgrad3) stays at the end.  Rounds 3-4: HDRSKY_WG_ENC_SPLIT=1.  Round 5 (paired decoders: stream 0 is the FIRST to
+        # finish its backward chain, stream 1 the last): one segment at the end of stream 0 again, the default; =1: A/B hook.
         split_enc = HOOKS.H.wg_enc_split
 
         @seg("bwd_enc", 0)
