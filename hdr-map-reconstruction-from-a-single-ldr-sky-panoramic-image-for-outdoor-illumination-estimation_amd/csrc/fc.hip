@@ -27,8 +27,16 @@ constexpr int RCH = 256;  // reduction elements per chunk (8 k-steps of 32)
 template <int MF, bool PRECISE, int RG>
 __global__ void __launch_bounds__(256 * RG) fc_mfma_kernel(const float* __restrict__ x, const uint4* __restrict__ whi,
                                                            const uint4* __restrict__ wlo, float* __restrict__ out, int M,
-                                                           int R, int O, int nsplit, long stride_col, long stride_kg) {
+                                                           int R, int O, int nsplit, long stride_col, long stride_kg, int nt) {
   constexpr int MP = MF * 16, PL = PRECISE ? 2 : 1;
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+  // nt: the weight stream - every byte read once per launch by one workgroup - with the non-temporal policy: 100 MB per forward
+  // (200 MB with the Grad-CAM sweep's data gradients) that otherwise evict the activations of the other branch from L2 / MALL.
+  // Round 5 (profiles/r05_nt_more.txt): generator forward 0.510 -> 0.474 ms, training step -0.2 %.  HDRSKY_FC_W_NT=0: tuning hook.
+  auto ldw = [&](const uint4* p) -> uint4 {
+    if (nt) { const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p)); return make_uint4(v.x, v.y, v.z, v.w); }
+    return *p;
+  };
   extern __shared__ __attribute__((aligned(16))) unsigned char fc_smem[];
   uint4* sXall = reinterpret_cast<uint4*>(fc_smem);       // [RG][buf 2][hi/lo][kgroup(32)][m]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -74,8 +82,8 @@ __global__ void __launch_bounds__(256 * RG) fc_mfma_kernel(const float* __restri
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
         const long idx = wbase + (kg0 + s * 4 + kq) * stride_kg;
-        bh[s] = whi[idx];
-        if (PRECISE) bl[s] = wlo[idx];
+        bh[s] = ldw(whi + idx);
+        if (PRECISE) bl[s] = ldw(wlo + idx);
       }
     } else {                                // partial last chunk (reduction lengths that are not multiples of 256), or none
       const int left = chunk < nchunks ? (rslice - chunk * RCH) >> 3 : 0;
@@ -185,7 +193,7 @@ int launch_fc_v(const float* x, const void* whi, const void* wlo, float* out, in
     }
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * RG), lds, s, x, (const uint4*)whi, (const uint4*)wlo, out, M, R, O, nsplit,
-                     stride_col, stride_kg);
+                     stride_col, stride_kg, hdrsky_hooks().fc_w_nt);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }

@@ -6,6 +6,7 @@
 #include <atomic>
 
 #include "common.h"
+#include "hooks.h"
 
 namespace {
 
@@ -1424,7 +1425,9 @@ __global__ void __launch_bounds__(256) rmsprop_kernel(float* __restrict__ w, con
 // the very end of the step, where nothing else is left to overlap their latency): blocks [0, nb1) walk buffer 1, the rest buffer 2
 __global__ void __launch_bounds__(256) rmsprop2_kernel(float* __restrict__ w1, const float* __restrict__ g1, float* __restrict__ ms1,
                                                        size_t n41, int nb1, float* __restrict__ w2, const float* __restrict__ g2,
-                                                       float* __restrict__ ms2, size_t n42, float lr, float rho, float eps, float gscale) {
+                                                       float* __restrict__ ms2, size_t n42, float lr, float rho, float eps, float gscale,
+                                                       int nt) {
+  typedef __attribute__((ext_vector_type(4))) float f32v4_t;
   const bool second = (int)blockIdx.x >= nb1;
   float* w = second ? w2 : w1; const float* g = second ? g2 : g1; float* ms = second ? ms2 : ms1;
   const size_t n4 = second ? n42 : n41;
@@ -1440,8 +1443,13 @@ __global__ void __launch_bounds__(256) rmsprop2_kernel(float* __restrict__ w1, c
       m[j] = rho * m[j] + (1.f - rho) * gs[j] * gs[j];
       ws[j] -= lr * gs[j] / (sqrtf(m[j]) + eps);
     }
-    reinterpret_cast<float4*>(w)[i] = make_float4(ws[0], ws[1], ws[2], ws[3]);
-    reinterpret_cast<float4*>(ms)[i] = make_float4(m[0], m[1], m[2], m[3]);
+    if (nt) {      // (tuning hook HDRSKY_OPT_NT: the updated weights / slots are next read one step later)
+      __builtin_nontemporal_store(f32v4_t{ws[0], ws[1], ws[2], ws[3]}, reinterpret_cast<f32v4_t*>(w) + i);
+      __builtin_nontemporal_store(f32v4_t{m[0], m[1], m[2], m[3]}, reinterpret_cast<f32v4_t*>(ms) + i);
+    } else {
+      reinterpret_cast<float4*>(w)[i] = make_float4(ws[0], ws[1], ws[2], ws[3]);
+      reinterpret_cast<float4*>(ms)[i] = make_float4(m[0], m[1], m[2], m[3]);
+    }
   }
 }
 
@@ -1986,7 +1994,7 @@ int hdrsky_rmsprop2(float* w1, const float* g1, float* ms1, size_t n1, float* w2
   if (!w1 || !g1 || !ms1 || !w2 || !g2 || !ms2 || (n1 & 3) || (n2 & 3) || n1 == 0 || n2 == 0) return HDRSKY_EINVAL;
   const int nb1 = grid_for(n1 / 4, 1024), nb2 = grid_for(n2 / 4, 1024);
   hipLaunchKernelGGL(rmsprop2_kernel, dim3(nb1 + nb2), dim3(256), 0, S_(stream), w1, g1, ms1, n1 / 4, nb1, w2, g2, ms2, n2 / 4, lr, rho,
-                     eps, gscale);
+                     eps, gscale, hdrsky_hooks().opt_nt);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }
