@@ -163,12 +163,14 @@ def sun3_backward(rec, dP, pkT1, pkT2, g1, b1, g2, b2, dgb1=None, dgb2=None):
     return dc2, dc1, dx
 
 
-def sunpose_forward(nets, ldr, compute, distortion_aware=False, pick=None):
+def sunpose_forward(nets, ldr, compute, distortion_aware=False, pick=None, convs_only=False, t=None):
     """sunpose_net.model.sunposeEstimation (sunpose_net.py:54-72) -> dict with cmf, z, A1..3 (+ what the
     Grad-CAM sweep re-reads: raw conv outputs and their IN partials).  distortion_aware ("sunpose" in da_parts): the
     convolutions are distortion_aware_ops.conv2d (sunpose_net.py:11,16)."""
     s, pk = nets.sun, nets.pk
     da = "sunpose" in da_parts(distortion_aware)
+    if t is not None:      # (second half: the Dense layers + soft-max head on the record `t` of a convs_only call)
+        return _sunpose_dense(nets, t, compute, pick)
     t = {"da": da}
     x = ldr
     for l in (1, 2, 3):
@@ -201,9 +203,15 @@ def sunpose_forward(nets, ldr, compute, distortion_aware=False, pick=None):
         t["r%da" % l], t["st%da" % l], t["r%db" % l], t["st%db" % l], t["A%d" % l], t["P%d" % l] = r1, st1, r2, st2, a, pooled
         x = pooled
     B = ldr.shape[0]
-    flat = x.reshape(B, -1)
-    t["flat"] = flat
-    t["gmax"] = torch.empty(1, dtype=torch.int32, device=ldr.device)      # cleared by the finalize launch below
+    t["flat"] = x.reshape(B, -1)
+    return t if convs_only else _sunpose_dense(nets, t, compute, pick)
+
+
+def _sunpose_dense(nets, t, compute, pick):
+    """Dense layers + soft-max head of sunposeEstimation (sunpose_net.py:64-72) on the conv layers' record."""
+    s, pk = nets.sun, nets.pk
+    flat = t["flat"]
+    t["gmax"] = torch.empty(1, dtype=torch.int32, device=flat.device)      # cleared by the finalize launch below
     t["f1"] = K.fc_finalize(K.fc_fwd(flat, pk["sun.fc1"], compute), s["fc1.bias"], relu=True, zero_word=t["gmax"])
     part2 = K.fc_fwd(t["f1"], pk["sun.fc2"], compute)
     if pick is None:
@@ -411,7 +419,21 @@ def generator_forward(nets, ldr, pick_src=None, compute=BF16, distortion_aware=F
     side = nets.side_stream
     side.wait_stream(main)
     with torch.cuda.stream(side):
-        S = _forward_sun(nets, ldr, pick_src, compute, da)
+        if HOOKS.H.fwd_stagger:
+            # the encoder branch forks off BEHIND the sun-pose net's conv layers (an edge of the captured graph): it then runs beside
+            # the sun branch's Dense layers (an HBM weight stream) and the small launches of the Grad-CAM sweep instead of beside its
+            # full-resolution convolutions - the two branches' matrix-core launches no longer share the chip
+            t = sunpose_forward(nets, ldr, compute, da, convs_only=True)
+            forked = torch.cuda.Event(); forked.record(side)
+            t = sunpose_forward(nets, ldr, compute, da, pick="self" if pick_src is None else pick_src, t=t)
+            cams = gradcam_sweep(nets, t, t["cmf"] if pick_src is None else pick_src, compute)
+            rad_lin, rad_gamma, gamma, beta = sun_rad_estimation(nets, ldr, cams, t, compute)
+            S = dict(t=t, cams=cams, rad_lin=rad_lin, rad_gamma=rad_gamma, gamma=gamma, beta=beta)
+        else:
+            forked = None
+            S = _forward_sun(nets, ldr, pick_src, compute, da)
+    if forked is not None:
+        main.wait_event(forked)
     M = _forward_main(nets, ldr, compute, da)
     main.wait_stream(side)
     return _forward_tail(nets, ldr, S, M, compute)

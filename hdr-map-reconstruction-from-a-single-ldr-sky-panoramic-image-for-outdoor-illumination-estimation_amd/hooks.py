@@ -34,6 +34,8 @@ class _Hooks:
         # the forward conv writes its transformed operand as bf16 for the layer's weight gradient (no hdrsky_act_bf16 launch)
         self.emit_xb = exp("HDRSKY_EMIT_XB", "1") != "0"
         self.disc_split = exp("HDRSKY_DISC_SPLIT", "0") == "1"
+        # generator_forward: the encoder branch forks off behind the sun-pose net's conv layers instead of at the input
+        self.fwd_stagger = exp("HDRSKY_FWD_STAGGER", "0") == "1"
         # the perceptual term's prediction pass as two half batches on two streams (1), or as one pass on stream 1 (0)
         self.vgg_split = exp("HDRSKY_VGG_SPLIT", "1") != "0"
         # the sky / sun decoders' layers of equal shape as paired launches on a batch of 2 B (forward heads and the whole backward chain)
