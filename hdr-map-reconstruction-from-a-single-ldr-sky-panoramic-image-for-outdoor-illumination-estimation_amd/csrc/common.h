@@ -163,6 +163,15 @@ __host__ __device__ __forceinline__ Tap4 da_tap(float base_y, float base_x, floa
 // LDS-DMA of 16 bytes per lane: LDS destination = lds_dst (wave-uniform byte address) + lane * 16.  Inline asm so that
 // the compiler's vmcnt bookkeeping does not see it (it would drain every DMA before the first ds_read): completion is
 // waited for by the explicit counted s_waitcnt below.  M0 is saved / restored inside the statement.
+// ... with the non-temporal policy (bytes one workgroup reads once and nobody re-reads soon)
+__device__ __forceinline__ void glds16_nt(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"

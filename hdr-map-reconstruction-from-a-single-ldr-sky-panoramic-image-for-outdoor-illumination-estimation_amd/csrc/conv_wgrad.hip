@@ -539,6 +539,7 @@ struct Wg2Args {
 constexpr int WG2_MAXJ = 12;
 struct Multi2Args {
   int njobs;
+  int nt;                        // tuning hook HDRSKY_WGRAD2_NT: 1 = the x operand's copies non-temporal, 2 = dy's, 3 = both
   unsigned long long* stamps;    // debug: per-workgroup s_memtime phase stamps (hdrsky_debug_wgrad2_stamps), null in production
   int first[WG2_MAXJ + 1];
   Wg2Args job[WG2_MAXJ];
@@ -629,6 +630,7 @@ __global__ void __launch_bounds__(768) conv_wgrad2_kernel(const Multi2Args m) {
     }
     int ib = tile0 / tps;                               // cursor of the next tile to copy, advanced incrementally
     int ity = (tile0 - ib * tps) / a.tiles_x, itx = (tile0 - ib * tps) - ity * a.tiles_x;
+    const bool nt_x = (m.nt & 1) != 0, nt_y = (m.nt & 2) != 0;
     auto issue = [&](int st) {
       const int oy0 = ity * a.TH, ox0 = itx * TW;
       const int iy0 = oy0 * a.stride - a.pad_t + ky0, ix0 = ox0 * a.stride - a.pad_l;
@@ -642,7 +644,7 @@ __global__ void __launch_bounds__(768) conv_wgrad2_kernel(const Multi2Args m) {
           const int cy = iy0 + (int)(sl & 1023u), cx = ix0 + (int)((sl >> 10) & 1023u);
           const bool ok = (int)sl < 0 && (unsigned)cy < (unsigned)a.H && (unsigned)cx < (unsigned)a.W;
           const void* src = ok ? (const void*)(xb + (size_t)(cy * a.W + cx) * a.Cin + ((sl >> 20) & 15u) * 8) : (const void*)(g_zero_page + lane * 4);
-          glds16(src, sbase + (unsigned)k * (NWL * 1024u));
+          if (nt_x) glds16_nt(src, sbase + (unsigned)k * (NWL * 1024u)); else glds16(src, sbase + (unsigned)k * (NWL * 1024u));
         }
       }
 #pragma unroll
@@ -652,7 +654,7 @@ __global__ void __launch_bounds__(768) conv_wgrad2_kernel(const Multi2Args m) {
           const int oy = oy0 + (int)(sl & 1023u), ox = ox0 + (int)((sl >> 10) & 1023u);
           const bool ok = (int)sl < 0 && oy < a.Ho && ox < a.Wo;
           const void* src = ok ? (const void*)(yb + (size_t)(oy * a.Wo + ox) * a.Cout + ((sl >> 20) & 15u) * 8) : (const void*)(g_zero_page + lane * 4);
-          glds16(src, sbase + (unsigned)a.xbytes + (unsigned)k * (NWL * 1024u));
+          if (nt_y) glds16_nt(src, sbase + (unsigned)a.xbytes + (unsigned)k * (NWL * 1024u)); else glds16(src, sbase + (unsigned)a.xbytes + (unsigned)k * (NWL * 1024u));
         }
       }
       if (++itx == a.tiles_x) { itx = 0; if (++ity == a.tiles_y) { ity = 0; ++ib; } }
@@ -1582,6 +1584,7 @@ static int wgrad2_groups(const hdrsky_wgrad_job* jobs, int njobs, bool* done, fl
     double wpart = 0.0;
     for (int q = 0; q < cnt; ++q) wpart += work[base + q];
     Multi2Args m2{};
+    m2.nt = hdrsky_hooks().wgrad2_nt;
     m2.njobs = cnt;
     m2.stamps = g_wg2_stamps;
     int lds = 0, blocks = 0, maxchunks = 1;

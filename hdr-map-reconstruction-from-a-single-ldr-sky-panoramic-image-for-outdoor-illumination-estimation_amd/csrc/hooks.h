@@ -37,6 +37,8 @@ struct HdrskyHooks {
   int fc_update_nb;    // HDRSKY_FC_UPDATE_NB   (0 = by the row count)
   int fc_rg;           // HDRSKY_FC_RG          (reduction groups per workgroup of fc_mfma_kernel: 1, 2 or 4)
   int nab_target;      // HDRSKY_NAB_TARGET     (512)
+  int wgrad2_nt;       // HDRSKY_WGRAD2_NT      (0) non-temporal operand copies of conv_wgrad2_kernel: 1 x, 2 dy
+  int nab_nt;          // HDRSKY_NAB_NT         (0) non-temporal loads of x in the one-launch InstanceNorm backward
   int fc_w_nt;         // HDRSKY_FC_W_NT        (1) non-temporal loads of the Dense layers' weight stream (fc_mfma_kernel)
   int opt_nt;          // HDRSKY_OPT_NT         (0) non-temporal stores of w / ms in rmsprop2_kernel
   int fc_nt;           // HDRSKY_FC_NT          (1) non-temporal policy of the fused Dense update: 1 image stores, 2 w / ms stores, 4 w / ms loads

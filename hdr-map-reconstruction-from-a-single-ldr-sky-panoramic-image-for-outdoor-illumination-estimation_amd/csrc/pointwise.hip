@@ -450,6 +450,10 @@ __global__ void __launch_bounds__(NT) norm_act_bwd1_kernel(const float* __restri
         const uint2 t = *reinterpret_cast<const uint2*>(xs16 + o);
         v = make_float4(__builtin_bit_cast(float, t.x << 16), __builtin_bit_cast(float, t.x & 0xffff0000u),
                         __builtin_bit_cast(float, t.y << 16), __builtin_bit_cast(float, t.y & 0xffff0000u));
+      } else if (flags & 8) {      // (tuning hook HDRSKY_NAB_NT: x - a raw conv output of the forward pass, read here for the last time)
+        typedef __attribute__((ext_vector_type(4))) float f32v4_t;
+        const f32v4_t t = __builtin_nontemporal_load(reinterpret_cast<const f32v4_t*>(xs32 + o));
+        v = make_float4(t.x, t.y, t.z, t.w);
       } else {
         v = *reinterpret_cast<const float4*>(xs32 + o);
       }
@@ -1139,6 +1143,7 @@ static int norm_act_bwd_impl(const float* x, const float* part, int nparts, cons
   if ((dx_bf16 & 1) && hdrsky_norm_act_bwd_one_launch(H, W, pooled, (dx_bf16 & 2) != 0)) {
     const int units = pooled ? (H / 2) * (W / 2) : H * W;
     const bool dy16 = (dx_bf16 & 2) != 0;
+    if (hdrsky_hooks().nab_nt) dx_bf16 |= 8;
 #define HDRSKY_NAB1(NT_, NV_, CG_, P_)                                                                                              \
     do {                                                                                                                             \
       if ((C % CG_) != 0) return HDRSKY_EINVAL;                                                                                      \
