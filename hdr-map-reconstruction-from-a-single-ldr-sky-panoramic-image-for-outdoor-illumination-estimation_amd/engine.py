@@ -447,10 +447,12 @@ class ForwardGraphs:
     profiles/LABNOTES.md r3 section 5 saw the same); two single-stream graphs on two streams do run side by side.
     replay() enqueues one pass behind the caller's current stream; `out` is generator_forward's dict (static tensors)."""
 
-    def __init__(self, nets, ldr, pick_src=None, compute=BF16, distortion_aware=False, warmup=2):
+    def __init__(self, nets, ldr, pick_src=None, compute=BF16, distortion_aware=False, warmup=2, main_stream=None, side_stream=None):
         da = da_parts(distortion_aware)
         self.nets, self.ldr = nets, ldr
-        self.main, self.side = torch.cuda.Stream(device=nets.device), nets.side_stream
+        # (main_stream / side_stream: the caller's streams - e.g. streams with a compute-unit mask, kernels.masked_stream)
+        self.main = main_stream if main_stream is not None else torch.cuda.Stream(device=nets.device)
+        self.side = side_stream if side_stream is not None else nets.side_stream
         self.joined = torch.cuda.Event()
         cur = torch.cuda.current_stream()
         for _ in range(warmup):       # lazy kernel attributes, allocator

@@ -61,6 +61,34 @@ def no_gc():
             gc.enable()
 
 
+_HIP = [None]
+
+
+def masked_stream(cu_lo, cu_hi, ncu=256):
+    """A HIP stream whose kernels run on compute units [cu_lo, cu_hi) only (hipExtStreamCreateWithCUMask on the HIP runtime torch
+    loaded), wrapped as a torch stream.  Experiments of profiles/cu_mask_*.py: reserving compute units for the dependent chain of
+    small launches that the step / the forward pass waits for."""
+    if _HIP[0] is None:
+        path = None
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64" in line:
+                    path = line.split()[-1]
+                    break
+        if path is None:
+            raise RuntimeError("masked_stream: the HIP runtime is not loaded yet (touch the GPU first)")
+        _HIP[0] = ctypes.CDLL(path)
+    words = (ncu + 31) // 32
+    mask = (ctypes.c_uint32 * words)()
+    for cu in range(cu_lo, cu_hi):
+        mask[cu // 32] |= 1 << (cu % 32)
+    st = ctypes.c_void_p()
+    rc = _HIP[0].hipExtStreamCreateWithCUMask(ctypes.byref(st), words, mask)
+    if rc != 0:
+        raise RuntimeError("hipExtStreamCreateWithCUMask failed: %d" % rc)
+    return torch.cuda.ExternalStream(st.value)
+
+
 def conv_kernel_name(d):
     buf = ctypes.create_string_buffer(160)
     L.check(L.load().hdrsky_conv_kernel_name(d, buf, 160), "conv_kernel_name")
