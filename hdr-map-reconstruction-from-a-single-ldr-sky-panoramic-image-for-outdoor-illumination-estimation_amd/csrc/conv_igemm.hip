@@ -939,6 +939,7 @@ int dispatch_tile_pair(ConvKArgs& a, const TileCfg& t, hipStream_t s) {
     return launch_conv<WM_, WN_, MI_, NI_, TW_, NARROW, false, DB_, false, false, true>(a, s);
   HDRSKY_PCASE(2, 4, 4, 1, 32, true) HDRSKY_PCASE(4, 2, 4, 1, 32, true) HDRSKY_PCASE(8, 1, 4, 1, 32, true) HDRSKY_PCASE(4, 1, 4, 1, 32, true)
   HDRSKY_PCASE(2, 4, 4, 2, 32, true) HDRSKY_PCASE(2, 2, 4, 1, 32, true) HDRSKY_PCASE(8, 1, 4, 2, 32, false) HDRSKY_PCASE(2, 4, 2, 1, 32, true)
+  HDRSKY_PCASE(2, 2, 4, 2, 32, true) HDRSKY_PCASE(4, 1, 4, 4, 32, true)      // (the 128x512 network's decoder entries)
 #undef HDRSKY_PCASE
   return HDRSKY_EUNSUPPORTED;
 }
@@ -963,8 +964,20 @@ TileCfg choose_tile(const hdrsky_conv_desc* d, bool ph = false) {
   const long M = (long)d->B * d->Ho * d->Wo;
   if (hk.tile_c64.set && d->Cout >= 64 && d->Cout < 128 && d->Cin >= 64 && M >= 65536 && !ph)      // A/B hook: the 64->64 class at full resolution
     return TileCfg{hk.tile_c64.v[0], hk.tile_c64.v[1], hk.tile_c64.v[2], hk.tile_c64.v[3], hk.tile_c64.v[4], hk.tile_c64.v[5]};
-  if (M >= 262144 || d->Wo < 32) return t;        // (the 128x512 network and the 4x16 maps: round 4's entries)
   const bool narrow = d->Cin <= 8;
+  if (d->Wo < 32) return t;                        // (the 4x16 maps: round 4's entries)
+  // The 128x512 network (profiles/r05_tile_sweep_hires.txt, batch 8).  Its launches are 2-8x the size of the 32x128 network's, a
+  // launch alone covers the chip several times over, and the entries below win in BOTH regimes.
+  if (d->Cout >= 256 && M * d->Cout >= 256L * 128 * 128 && M <= 16384)
+    return TileCfg{2, 4, 4, 2, 32, 1};             // 128 px x 128 ch as soon as that is >= 256 workgroups (round 4: from 32768 px): 256->256 at 32x128 x4 alone -22 %, saturated -21 %; 4x4 256->512 at 16x64 x8 -24 % / -26 %
+  if (M >= 131072 && d->Cout >= 64 && d->Cout < 128 && !ph) {
+    if (narrow) { if (d->KH == 3 && M >= 262144) return TileCfg{2, 2, 4, 2, 32, 0}; }                     // VGG16 conv1_1 (3->64): the ring on 128 px x 64 ch (alone -3..-12 %, saturated -13..-17 %)
+    else if (M >= 262144) return TileCfg{4, 1, 4, 4, 32, 1};                                             // 64->64 / 32->64 at 128x512: one wave holds all 64 channels of its 64 px - an A fragment feeds four MFMAs (alone -13..-16 %, saturated -18..-24 %; the 64->64 data gradient +-0)
+    else if (d->Cin >= 128 && d->KH == 3 && d->stride == 1) return TileCfg{2, 2, 4, 2, 32, 1};           // 3x3 128->64 at 64x256 (decoder): alone -2 %, saturated -14 %
+  }
+  if (M >= 262144 && narrow && d->Cout > 16 && d->Cout < 64 && d->KH >= 7)
+    return TileCfg{8, 1, 4, 2, 32, 0};             // 7x7 3->32 at 128x512, forward and the 32->3 layers' data gradient: the ring on 512 px (alone -7..-12 %, saturated -17..-22 %)
+  if (M >= 262144) return t;                       // (the rest of the 128x512 network: round 4's entries)
   if (d->Cout >= 64) {
     if (narrow) return t;
     if (d->Cout >= 128 && d->Cout < 256 && M == 16384) t = TileCfg{1, 8, 4, 1, 32, 1};   // 64->128 / 128->128 at 16x64, batch 16, and their transposes: 64 px x 128 ch (alone -4..-8 %, saturated -26..-30 %)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-5 evidence on the current code.  usage (GPU box, repo root): bash profiles/collect_r05.sh TAG STAGE...
-#   stages: tests | bench | timelines | prof_train | prof_fwd | pmc_step | hires | pk
+#   stages: tests | bench | timelines | prof_train | prof_fwd | prof_hires | pmc_step | hires | pk
 # outputs: gpurun_out/TAG/ (copied to profiles/r05_* by hand).  Every profile is taken from `bench.py --steps-only`, i.e. a
 # process that runs bench-mode steps and nothing else (round 4's statistics mixed 15 fp32-class steps and the roofline
 # microbenchmarks into the same CSV); step_timeline.py asserts that its window holds no fp32-class instantiation.
@@ -41,6 +41,9 @@ hires)
   python3 $R/bench.py --workload hires-train --steps 20 > $O/bench_hires_train.json 2> $O/bench_hires_train.err
   python3 $R/bench.py --workload hires-train --da res,decoders --steps 20 > $O/bench_hires_train_da.json 2> $O/bench_hires_train_da.err
   python3 $R/bench.py --workload train --da --steps 20 --no-cpu-baseline --no-roofline-top --no-parity > $O/bench_train_da.json 2> $O/bench_da.err ;;
+prof_hires)
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_hires -o hires -- python3 $R/bench.py --workload hires-train --steps 30 --warmup 3 --no-cpu-baseline --no-parity --no-roofline-top > $O/prof_hires.json 2> $O/prof_hires.log
+  cp $(find $O/prof_hires -name "*kernel_stats.csv" | head -1) $O/hires_train_b8_kernel_stats.csv; head -12 $O/hires_train_b8_kernel_stats.csv | cut -c1-200 ;;
 pk)
   (cd $R/profiles/experiments/pk_hazard && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 pk_opsel.hip -o /tmp/pk_opsel && timeout -k 10 240 /tmp/pk_opsel > $O/pk_opsel_erratum.txt 2>&1; tail -3 $O/pk_opsel_erratum.txt) ;;
 esac
