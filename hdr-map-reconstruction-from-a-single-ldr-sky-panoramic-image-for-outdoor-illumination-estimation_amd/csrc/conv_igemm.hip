@@ -883,10 +883,11 @@ int launch_conv(ConvKArgs& a, hipStream_t stream) {
   if (out_bytes > a.off_stat) { a.off_stat = roundup(out_bytes, 16); lds = a.off_stat + NW * BN * 2 * 4; }
   a.off_ktab = roundup(lds, 16);
   if (DB && !NARROW) lds = a.off_ktab + (a.ksg + 8) * 8;   // k-step table of the direct-B loop
-  // direct-B variant: give the epilogue tile its own LDS when it fits, so that a wave that has finished its main
-  // loop can write its accumulators without waiting for the slowest wave to stop reading the operand planes
+  // direct-B variant: the epilogue tile may get LDS of its own, so that a wave that has finished its main loop can write its
+  // accumulators without waiting for the slowest wave to stop reading the operand planes (rounds 3-4, threshold 80 KB; since
+  // round 5 the threshold is 0 = always aliased: hooks.h, HDRSKY_CONV_EPI_LDS)
   a.off_out = 0;
-  if (DB && roundup(lds, 16) + out_bytes <= 80 * 1024) { a.off_out = roundup(lds, 16); lds = a.off_out + out_bytes; }   // (two workgroups per CU must still fit)
+  if (DB && roundup(lds, 16) + out_bytes <= hdrsky_hooks().conv_epi_lds * 1024) { a.off_out = roundup(lds, 16); lds = a.off_out + out_bytes; }   // (two workgroups per CU must still fit)
   if (lds > 160 * 1024) return HDRSKY_EUNSUPPORTED;
   auto kern = conv_igemm_kernel<WM, WN, MI, NI, TW, NARROW, PRECISE, DB, PH, EMIT, PAIR>;
   static std::atomic<int> max_lds_set{0};
@@ -910,6 +911,9 @@ int dispatch_tile(ConvKArgs& a, const TileCfg& t, hipStream_t s) {
 #define HDRSKY_CASE_DB(WM_, WN_, MI_, NI_, TW_)                                           \
   if (t.db && t.wm == WM_ && t.wn == WN_ && t.mi == MI_ && t.ni == NI_ && t.tw == TW_)  \
     return launch_conv<WM_, WN_, MI_, NI_, TW_, NARROW, PRECISE, true, PH, EMIT>(a, s);
+#ifdef HDRSKY_ONE_TILE      // (diagnostic builds: one instantiation per mode, seconds instead of minutes per compile)
+  HDRSKY_CASE_DB(2, 4, 4, 1, 32)
+#else
   // LDS-ring variant
   HDRSKY_CASE(2, 2, 4, 2, 32) HDRSKY_CASE(2, 2, 2, 2, 32) HDRSKY_CASE(2, 2, 2, 2, 16)
   HDRSKY_CASE(4, 1, 4, 2, 32) HDRSKY_CASE(4, 1, 2, 2, 32) HDRSKY_CASE(2, 2, 2, 1, 32) HDRSKY_CASE(2, 2, 2, 1, 16)
@@ -924,6 +928,7 @@ int dispatch_tile(ConvKArgs& a, const TileCfg& t, hipStream_t s) {
   // round 5: 64 px x 64 ch per WAVE (MI = NI = 4: an A fragment read from LDS feeds four MFMAs - at NI = 1 the kernel is bound by its
   // LDS fragment reads, 1 KB per MFMA against 0.5 KB per MFMA-time of LDS bandwidth), four waves with the full register budget
   HDRSKY_CASE_DB(4, 1, 4, 4, 32) HDRSKY_CASE_DB(2, 2, 4, 4, 32) HDRSKY_CASE_DB(4, 1, 2, 4, 32) HDRSKY_CASE_DB(1, 4, 4, 4, 32)
+#endif
 #undef HDRSKY_CASE_DB
 #undef HDRSKY_CASE
   return HDRSKY_EUNSUPPORTED;
@@ -937,9 +942,11 @@ int dispatch_tile_pair(ConvKArgs& a, const TileCfg& t, hipStream_t s) {
 #define HDRSKY_PCASE(WM_, WN_, MI_, NI_, TW_, DB_)                                                         \
   if ((t.db != 0) == DB_ && t.wm == WM_ && t.wn == WN_ && t.mi == MI_ && t.ni == NI_ && t.tw == TW_)    \
     return launch_conv<WM_, WN_, MI_, NI_, TW_, NARROW, false, DB_, false, false, true>(a, s);
+#ifndef HDRSKY_ONE_TILE
   HDRSKY_PCASE(2, 4, 4, 1, 32, true) HDRSKY_PCASE(4, 2, 4, 1, 32, true) HDRSKY_PCASE(8, 1, 4, 1, 32, true) HDRSKY_PCASE(4, 1, 4, 1, 32, true)
   HDRSKY_PCASE(2, 4, 4, 2, 32, true) HDRSKY_PCASE(2, 2, 4, 1, 32, true) HDRSKY_PCASE(8, 1, 4, 2, 32, false) HDRSKY_PCASE(2, 4, 2, 1, 32, true)
   HDRSKY_PCASE(2, 2, 4, 2, 32, true) HDRSKY_PCASE(4, 1, 4, 4, 32, true)      // (the 128x512 network's decoder entries)
+#endif
 #undef HDRSKY_PCASE
   return HDRSKY_EUNSUPPORTED;
 }

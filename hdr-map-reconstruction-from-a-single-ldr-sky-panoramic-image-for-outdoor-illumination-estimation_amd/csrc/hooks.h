@@ -39,6 +39,10 @@ struct HdrskyHooks {
   int nab_target;      // HDRSKY_NAB_TARGET     (512)
   int wgrad2_nt;       // HDRSKY_WGRAD2_NT      (0) non-temporal operand copies of conv_wgrad2_kernel: 1 x, 2 dy
   int nab_nt;          // HDRSKY_NAB_NT         (0) non-temporal loads of x in the one-launch InstanceNorm backward
+  int conv_epi_lds;    // HDRSKY_CONV_EPI_LDS   (0) conv_igemm, direct-B: the epilogue tile gets LDS of its own while operand planes + tile stay within this many KB
+                       //                       (rounds 3-4: 80, a finished wave writes its accumulators without waiting for the slowest; inside the step the
+                       //                       smaller footprint - four workgroups of a 64-channel layer per compute unit instead of two - is worth more:
+                       //                       step -0.8 %, forward -2.5 %, profiles/r05_conv_epi_lds_ab.txt)
   int fc_w_nt;         // HDRSKY_FC_W_NT        (1) non-temporal loads of the Dense layers' weight stream (fc_mfma_kernel)
   int opt_nt;          // HDRSKY_OPT_NT         (0) non-temporal stores of w / ms in rmsprop2_kernel
   int fc_nt;           // HDRSKY_FC_NT          (1) non-temporal policy of the fused Dense update: 1 image stores, 2 w / ms stores, 4 w / ms loads

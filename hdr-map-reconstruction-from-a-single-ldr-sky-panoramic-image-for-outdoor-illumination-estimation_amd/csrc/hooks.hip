@@ -41,7 +41,7 @@ void read_hooks() {
   h.experiments = env_int("HDRSKY_EXPERIMENTS", 0) == 1;
   // tuning hooks: their defaults unless the gate is open
   h.wgrad2_s2min = 32; h.wgrad2_mint = 2; h.wgrad2_wgs = 0; h.wgrad3_minpx = 256; h.wgrad3_wgs = 256;
-  h.da_group = -1; h.da_wg_group = -1; h.fc_nsplit = 4; h.fc_update_nb = 0; h.fc_rg = 4; h.nab_target = 512; h.fc_nt = 1; h.fc_w_nt = 1; h.opt_nt = 0; h.wgrad2_nt = 0; h.nab_nt = 0;
+  h.da_group = -1; h.da_wg_group = -1; h.fc_nsplit = 4; h.fc_update_nb = 0; h.fc_rg = 4; h.nab_target = 512; h.fc_nt = 1; h.fc_w_nt = 1; h.opt_nt = 0; h.wgrad2_nt = 0; h.nab_nt = 0; h.conv_epi_lds = 0;
   if (h.experiments) {
     h.tile = env_tile("HDRSKY_TILE"); h.tile_t16 = env_tile("HDRSKY_TILE_T16"); h.tile_wide = env_tile("HDRSKY_TILE_WIDE");
     h.tile_c32 = env_tile("HDRSKY_TILE_C32"); h.tile_c16 = env_tile("HDRSKY_TILE_C16"); h.tile_c64 = env_tile("HDRSKY_TILE_C64");
@@ -62,6 +62,7 @@ void read_hooks() {
     h.opt_nt = env_int("HDRSKY_OPT_NT", h.opt_nt) != 0;
     h.wgrad2_nt = env_int("HDRSKY_WGRAD2_NT", h.wgrad2_nt) & 3;
     h.nab_nt = env_int("HDRSKY_NAB_NT", h.nab_nt) != 0;
+    h.conv_epi_lds = env_int("HDRSKY_CONV_EPI_LDS", h.conv_epi_lds);
   }
   std::lock_guard<std::mutex> lock(g_mutex);
   g_hooks = h;
