@@ -176,7 +176,10 @@ __device__ __forceinline__ void compute_chunk(const ConvKArgs& a, const unsigned
 // set's scalars pushed the 8-wave direct-B variants at their 128-VGPR budget into a spill around the k loop when every launch
 // carried them (four plain instantiations went from 0 to 36 B of scratch); only the tiles the paired layers take are instantiated
 template <int WM, int WN, int MI, int NI, int TW, bool NARROW, bool PRECISE, bool DB, bool PH, bool EMIT = false, bool PAIR = false>
-__global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB ? 4 : 2) : 1) conv_igemm_kernel(const ConvKArgs a) {
+#ifndef HDRSKY_DB_MINW
+#define HDRSKY_DB_MINW 4      // waves per SIMD the 8-wave direct-B instantiations are compiled for (register budget 512 / that)
+#endif
+__global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB ? HDRSKY_DB_MINW : 2) : 1) conv_igemm_kernel(const ConvKArgs a) {
   constexpr int NW = WM * WN;                // waves per workgroup (4 or 8)
   constexpr int NT = NW * 64;
   constexpr int BM = WM * MI * 16;

@@ -36,6 +36,8 @@ class _Hooks:
         self.disc_split = exp("HDRSKY_DISC_SPLIT", "0") == "1"
         # generator_forward: the encoder branch forks off behind the sun-pose net's conv layers instead of at the input
         self.fwd_stagger = exp("HDRSKY_FWD_STAGGER", "0") == "1"
+        # HDRSKY_STREAM_PRIO="p0,p1,p2": priorities of the training step's three streams (torch: -1 = high, 0 = default)
+        self.stream_prio = [int(v) for v in exp("HDRSKY_STREAM_PRIO", "0,0,0").split(",")]
         # the perceptual term's prediction pass as two half batches on two streams (1), or as one pass on stream 1 (0)
         self.vgg_split = exp("HDRSKY_VGG_SPLIT", "1") != "0"
         # the sky / sun decoders' layers of equal shape as paired launches on a batch of 2 B (forward heads and the whole backward chain)

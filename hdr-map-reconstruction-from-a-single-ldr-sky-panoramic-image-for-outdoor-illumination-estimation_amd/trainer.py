@@ -172,7 +172,7 @@ class Trainer:
         # once those are done, the work that only has to finish by the end of the step (discriminator step, Dense-layer
         # optimizer | sun-pose backward, weight gradients).  More streams than that end up sharing one of the runtime's
         # four hardware queues with each other or with RCCL's stream (measured: 4.6 instead of 4.1 ms per step).
-        self._streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
+        self._streams = [torch.cuda.Stream(device=self.device, priority=HOOKS.H.stream_prio[i]) for i in range(3)]
         self._graphs, self._gscale = None, 1.0 / world_size
         self._bn_training = True            # False only inside test_step (sun-radiance head BatchNorm in inference mode)
         self.losses = torch.zeros(len(LOSS_SLOTS), dtype=torch.float32, device=self.device)
