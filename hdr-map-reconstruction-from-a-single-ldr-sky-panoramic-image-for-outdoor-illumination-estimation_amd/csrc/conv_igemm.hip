@@ -176,6 +176,9 @@ __device__ __forceinline__ void compute_chunk(const ConvKArgs& a, const unsigned
 // set's scalars pushed the 8-wave direct-B variants at their 128-VGPR budget into a spill around the k loop when every launch
 // carried them (four plain instantiations went from 0 to 36 B of scratch); only the tiles the paired layers take are instantiated
 template <int WM, int WN, int MI, int NI, int TW, bool NARROW, bool PRECISE, bool DB, bool PH, bool EMIT = false, bool PAIR = false>
+#ifndef HDRSKY_EPI_DIRECT
+#define HDRSKY_EPI_DIRECT 1    // 0: every variant through the LDS tile (A/B builds)
+#endif
 #ifndef HDRSKY_DB_MINW
 #define HDRSKY_DB_MINW 4      // waves per SIMD the 8-wave direct-B instantiations are compiled for (register budget 512 / that)
 #endif
@@ -192,6 +195,13 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB
   constexpr int BPLANES = PRECISE ? 2 : 1;
   constexpr int BNP = BN + 4;                // padded row of the epilogue tile
   static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+  // Epilogue straight from the accumulators (single-product direct-B variants): the MFMAs run with the operands swapped -
+  // D[cout][pixel] instead of D[pixel][cout] - so that a lane holds FOUR CONSECUTIVE CHANNELS of one pixel: bias, statistics,
+  // activation, residual / mask and the 16-byte (fp32) or 8-byte (bf16) store happen on the registers, with no LDS tile, no
+  // barrier in front of it and no wait for the slowest wave of the workgroup.  Every output value is the same sum in the same
+  // order (bit-identical y); the statistics partials add their pixels in another order than the LDS-tile epilogue.  The
+  // fp32-class mode keeps the LDS tile (its statistics, and with them the long fits of the parity tests, stay bit-stable).
+  constexpr bool DIRECT = DB && !PRECISE && (HDRSKY_EPI_DIRECT != 0);
   static_assert(BITEMS % NT == 0 && BPT >= 1, "B chunk must tile the block");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -539,7 +549,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB
                     acc[mi][ni] = mfma16(al[j & 1][mi], bqh[j][ni], acc[mi][ni]);
                     acc[mi][ni] = mfma16(ah[j & 1][mi], bql[j][ni], acc[mi][ni]);
                   }
-                  acc[mi][ni] = mfma16(ah[j & 1][mi], bqh[j][ni], acc[mi][ni]);
+                  acc[mi][ni] = DIRECT ? mfma16(bqh[j][ni], ah[j & 1][mi], acc[mi][ni]) : mfma16(ah[j & 1][mi], bqh[j][ni], acc[mi][ni]);
                 }
 #pragma unroll
               for (int ni = 0; ni < NI; ++ni) {   // refill with step ks+DPF (clamped in the table: surplus loads are unused)
@@ -597,7 +607,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB
                     acc[mi][ni] = mfma16(al[j & 1][mi], bqh[j][ni], acc[mi][ni]);
                     acc[mi][ni] = mfma16(ah[j & 1][mi], bql[j][ni], acc[mi][ni]);
                   }
-                  acc[mi][ni] = mfma16(ah[j & 1][mi], bqh[j][ni], acc[mi][ni]);
+                  acc[mi][ni] = DIRECT ? mfma16(bqh[j][ni], ah[j & 1][mi], acc[mi][ni]) : mfma16(ah[j & 1][mi], bqh[j][ni], acc[mi][ni]);
                 }
               const unsigned o = (unsigned)kp_of(ks + DPF) * kstride;  // clamped at the end: surplus loads are unused
   #pragma unroll
@@ -611,7 +621,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB
       }
       // all waves done with the operand planes before the next group restages them / the epilogue tile overwrites
       // them; not needed after the last group when the epilogue tile has its own LDS (off_out != 0)
-      if (g + 1 < a.ngroups || a.off_out == 0) __syncthreads();
+      if (g + 1 < a.ngroups || (!DIRECT && a.off_out == 0)) __syncthreads();
     } else {
       // ---- B ring: LDS double buffer; chunk ch+1 is copied by LDS-DMA into the other buffer (free since the barrier
       // that ended iteration ch-1) while the MFMAs of chunk ch run: no registers, no ds_write, nothing in scratch.
@@ -642,6 +652,106 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB
   }
 
   HDRSKY_STAMP(3)
+  if constexpr (DIRECT) {
+    // ---- epilogue from the registers: lane (kq, lr) holds channels n0 + (wn NI + ni) 16 + 4 kq .. + 3 of the pixels lr of its MI fragments
+    float cs[NI][4], cq[NI][4];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { cs[ni][e] = 0.f; cq[ni][e] = 0.f; }
+    const bool vec4 = (a.Cout & 3) == 0;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int n = n0 + (wn * NI + ni) * 16 + kq * 4;
+      float bias4[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bias4[e] = (bias != nullptr && n + e < a.Cout) ? bias[n + e] : 0.f;
+      const bool vec = vec4 && (n + 3 < a.Cout);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int f = wm * MI + mi;
+        int oy = oy0 + f / FPR, ox = ox0 + (f % FPR) * 16 + lr;
+        if (PH) { oy = 2 * oy + (ph >> 1); ox = 2 * ox + (ph & 1); }
+        if (oy < a.Ho && ox < a.Wo && n < a.Cout) {
+          float v[4] = {acc[mi][ni][0] + bias4[0], acc[mi][ni][1] + bias4[1], acc[mi][ni][2] + bias4[2], acc[mi][ni][3] + bias4[3]};
+          const size_t idx = ((size_t)(b * a.Ho + oy) * a.Wo + ox) * a.Cout + n;
+          const size_t ridx = ((size_t)(br * a.Ho + oy) * a.Wo + ox) * a.Cout + n;      // inside the group's residual / mask tensor
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (n + e < a.Cout) { cs[ni][e] += v[e]; cq[ni][e] += v[e] * v[e]; }
+            v[e] = leaky(v[e], a.out_slope);
+          }
+          if (vec) {
+            if (residual != nullptr) {
+              if (a.res_mode == 1) {   // bf16 activated tensor: gradient mask of the activation behind this data gradient
+                const uint2 mk = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(residual) + ridx);
+                const float m4[4] = {__builtin_bit_cast(float, mk.x << 16), __builtin_bit_cast(float, mk.x & 0xffff0000u),
+                                     __builtin_bit_cast(float, mk.y << 16), __builtin_bit_cast(float, mk.y & 0xffff0000u)};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= (m4[e] > 0.f ? 1.f : a.mask_slope);
+              } else {
+                const float4 r = *reinterpret_cast<const float4*>(residual + ridx);
+                v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+              }
+            }
+            if (a.final_relu) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if (a.y_bf16)
+              *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.y) + idx) =
+                  uint2{(unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16)};
+            else
+              *reinterpret_cast<float4*>(a.y + idx) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (n + e < a.Cout) {
+                float o = v[e];
+                if (residual != nullptr) o += residual[ridx + e];
+                if (a.final_relu) o = fmaxf(o, 0.f);
+                a.y[idx + e] = o;
+              }
+          }
+        }
+      }
+    }
+    if (a.want_stats) {
+      // sum over the 16 pixels (lanes lr) of a k-quarter row, then over the waves that share the column block
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) { cs[ni][e] += __shfl_xor(cs[ni][e], o); cq[ni][e] += __shfl_xor(cq[ni][e], o); }
+        }
+      if (lr == 0) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int col = (wn * NI + ni) * 16 + kq * 4 + e;
+            sStat[(wm * BN + col) * 2 + 0] = cs[ni][e];
+            sStat[(wm * BN + col) * 2 + 1] = cq[ni][e];
+          }
+      }
+      __syncthreads();
+      if (tid < BN && n0 + tid < a.Cout) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) {
+          s += sStat[(w * BN + tid) * 2 + 0];
+          q += sStat[(w * BN + tid) * 2 + 1];
+        }
+        const int nparts = a.tiles_x * a.tiles_y;
+        float* dst = a.stats + ((size_t)(b * nparts + ty * a.tiles_x + tx) * 2) * a.Cout + n0 + tid;
+        dst[0] = s;
+        dst[a.Cout] = q;
+      }
+    }
+    HDRSKY_STAMP(5)
+    return;
+  }
   // ---- epilogue: accumulators -> LDS tile [BM][BN] -> coalesced 16-byte rows ------------------------
   // (the last __syncthreads of the ring guarantees every wave is done reading the operand planes)
   float* sOut = reinterpret_cast<float*>(smem + a.off_out);
@@ -882,7 +992,8 @@ int launch_conv(ConvKArgs& a, hipStream_t stream) {
   int lds = a.off_stat + NW * BN * 2 * 4;
   // the epilogue re-uses the operand planes (from offset 0) as a [BM][BN+4] fp32 tile; it must not reach
   // the stat scratch
-  const int out_bytes = BM * (BN + 4) * 4;
+  constexpr bool DIRECT = DB && !PRECISE && (HDRSKY_EPI_DIRECT != 0);     // epilogue from the registers: no LDS tile
+  const int out_bytes = DIRECT ? 0 : BM * (BN + 4) * 4;
   if (out_bytes > a.off_stat) { a.off_stat = roundup(out_bytes, 16); lds = a.off_stat + NW * BN * 2 * 4; }
   a.off_ktab = roundup(lds, 16);
   if (DB && !NARROW) lds = a.off_ktab + (a.ksg + 8) * 8;   // k-step table of the direct-B loop
