@@ -175,7 +175,10 @@ __device__ __forceinline__ void compute_chunk(const ConvKArgs& a, const unsigned
 // PAIR: the instantiations of the paired launches (ConvKArgs::gsplit) - their own for the reason EMIT's are: the second parameter
 // set's scalars pushed the 8-wave direct-B variants at their 128-VGPR budget into a spill around the k loop when every launch
 // carried them (four plain instantiations went from 0 to 36 B of scratch); only the tiles the paired layers take are instantiated
-template <int WM, int WN, int MI, int NI, int TW, bool NARROW, bool PRECISE, bool DB, bool PH, bool EMIT = false, bool PAIR = false>
+template <int WM, int WN, int MI, int NI, int TW, bool NARROW, bool PRECISE, bool DB, bool PH, bool EMIT = false, bool PAIR = false, bool UP = false>
+#ifndef HDRSKY_EARLY_B
+#define HDRSKY_EARLY_B 1       // 0: the filter window is filled behind the staging barrier (A/B builds)
+#endif
 #ifndef HDRSKY_EPI_DIRECT
 #define HDRSKY_EPI_DIRECT 1    // 0: every variant through the LDS tile (A/B builds)
 #endif
@@ -258,7 +261,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB
 
   HDRSKY_STAMP(0)
   // ---- prologue: tap offset table + input transform tables (identity when in_mode == NONE) ----
-  for (int t = tid; t < a.ntaps; t += NT) sTap[t] = (t / a.KW) * a.WT + (t % a.KW);
+  if (!DB) { for (int t = tid; t < a.ntaps; t += NT) sTap[t] = (t / a.KW) * a.WT + (t % a.KW); }   // (the direct-B loop reads sKtab instead)
   if (DB && !NARROW) {
     // k-step table of the direct-B main loop (channel group 0; a group only shifts the filter base): entry ks holds the
     // LDS byte offset of the A fragments of step ks+1 and the packed-filter element offset of step ks+DPF, both clamped
@@ -290,10 +293,13 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB
       sScale[c] = inv;
       sShift[c] = in_beta[c] - mean * inv;
     }
-  } else {
+  } else if (a.in_slope != 1.f || NARROW || UP) {
     for (int c = tid; c < a.Cin; c += NT) { sScale[c] = 1.f; sShift[c] = 0.f; }
   }
-  __syncthreads();
+  // an identity input on the plain staging path (a final activation: the VGG16 chain, the data gradients) reads neither table
+  // before the barrier that ends the staging: no barrier here
+  const bool tables_read = !(a.in_mode == HDRSKY_IN_NONE && a.in_slope == 1.f && !NARROW && !UP && DB);
+  if (tables_read) __syncthreads();
   HDRSKY_STAMP(1)
 
   // ---- per-lane fragment bases ---------------------------------------------------------------
@@ -325,8 +331,35 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB
   const float slope = a.in_slope;
   const bool xf_identity = a.in_mode == HDRSKY_IN_NONE && slope == 1.f;   // staging then skips the affine + activation
 
+  // direct-B loop: the register window of filter fragments (DPF k-steps x NI).  In the single-product mode its first fill is
+  // issued BEFORE the group's operand staging: the L2 round trip of the filter rows runs under the staging instead of behind
+  // the barrier that ends it (32 registers live across the staging; the fp32-class mode's 64 would not fit beside it).
+  constexpr int DPF = (NI == 1) ? 8 : 4;
+  constexpr bool EARLY_B = DB && !PRECISE && !UP && !EMIT && (MI * NI < 8 || NW == 4) && (HDRSKY_EARLY_B != 0);     // (EMIT's owner bookkeeping and the 32 accumulator registers of the 8-wave 128 px x 128 ch tile spill beside the window)
+  uint4 bqh[DB ? DPF : 1][NI], bql[DB ? DPF : 1][NI];
+  const unsigned kstride = 4u * (unsigned)a.Npad;   // uint4 elements per k-step; 32-bit offsets: the packed filter is < 2^32 elements
+  const uint4* const wlh = whi + (size_t)kq * a.Npad + n0 + (wn * NI) * 16 + lr;
+  const uint4* const wll = PRECISE ? wlo + (size_t)kq * a.Npad + n0 + (wn * NI) * 16 + lr : nullptr;
+  auto kp_of = [&](int g, int ks) __attribute__((always_inline)) {
+    const int kc = min(ks, a.ksg - 1);
+    if (!NARROW && PH) return phase_kp(a, kc >> a.log2cbg, (g << a.log2cbg) + (kc & ((1 << a.log2cbg) - 1)), cin32, ph);
+    return NARROW ? kc : (kc >> a.log2cbg) * cin32 + (g << a.log2cbg) + (kc & ((1 << a.log2cbg) - 1));
+  };
+  auto fill_b = [&](int g) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < DPF; ++j) {
+      const unsigned o = (unsigned)kp_of(g, j) * kstride;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        bqh[j][ni] = wlh[o + ni * 16];
+        if (PRECISE) bql[j][ni] = wll[o + ni * 16];
+      }
+    }
+  };
+
   for (int g = 0; g < a.ngroups; ++g) {
     if (g > 0 && !DB) __syncthreads();  // everyone finished reading the previous group's planes
+    if constexpr (EARLY_B) fill_b(g);
 
     // LDS-ring variant: first B chunk goes in flight (LDS-DMA into ring buffer 0) before the (long) A staging
     if (!DB) { HDRSKY_DMA_B(0, 0) }
@@ -360,7 +393,8 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB
       float sc8[8], sh8[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) { sc8[j] = sScale[g * a.cgs + qt * 8 + j]; sh8[j] = sShift[g * a.cgs + qt * 8 + j]; }
-      if (a.upsample == 2) {
+      if constexpr (UP) {     // the resize-fused staging: instantiations of their own (its 32 source registers per item beside the
+                              // filter window and the plain path's batch would not fit the 128-register budget: dispatch_tile_up)
         for (int i = tid; i < nitems; i += NT) {
           const int p = i >> a.log2nq, q = i & (nq - 1);
           const int hy = (int)(((unsigned)p * (unsigned)a.wt_magic) >> 24);
@@ -494,25 +528,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB
       // (16-byte rows of the packed image, L2/L1-resident) into a rotating window of DPF k-steps of
       // registers; a fragment's register is refilled right after the MFMAs that consumed it issue.
       __syncthreads();  // operand planes staged
-      constexpr int DPF = (NI == 1) ? 8 : 4;
-      const uint4* wlh = whi + (size_t)kq * a.Npad + n0 + (wn * NI) * 16 + lr;
-      const uint4* wll = PRECISE ? wlo + (size_t)kq * a.Npad + n0 + (wn * NI) * 16 + lr : nullptr;
-      const unsigned kstride = 4u * (unsigned)a.Npad;   // uint4 elements per k-step; 32-bit offsets: the packed filter is < 2^32 elements
-      uint4 bqh[DPF][NI], bql[DPF][NI];
-      auto kp_of = [&](int ks) {
-        const int kc = min(ks, a.ksg - 1);
-        if (!NARROW && PH) return phase_kp(a, kc >> a.log2cbg, (g << a.log2cbg) + (kc & ((1 << a.log2cbg) - 1)), cin32, ph);
-        return NARROW ? kc : (kc >> a.log2cbg) * cin32 + (g << a.log2cbg) + (kc & ((1 << a.log2cbg) - 1));
-      };
-#pragma unroll
-      for (int j = 0; j < DPF; ++j) {
-        const unsigned o = (unsigned)kp_of(j) * kstride;
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          bqh[j][ni] = wlh[o + ni * 16];
-          if (PRECISE) bql[j][ni] = wll[o + ni * 16];
-        }
-      }
+      if constexpr (!EARLY_B) fill_b(g);
       if constexpr (!NARROW) {
         // Table-driven form (see the prologue): per group of DPF k-steps one LDS read fetches the A offsets of the next
         // steps and the filter refill offsets, v_readlane turns them into scalars - no tap / channel-block arithmetic,
@@ -609,7 +625,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 && !PRECISE) ? (DB
                   }
                   acc[mi][ni] = DIRECT ? mfma16(bqh[j][ni], ah[j & 1][mi], acc[mi][ni]) : mfma16(ah[j & 1][mi], bqh[j][ni], acc[mi][ni]);
                 }
-              const unsigned o = (unsigned)kp_of(ks + DPF) * kstride;  // clamped at the end: surplus loads are unused
+              const unsigned o = (unsigned)kp_of(g, ks + DPF) * kstride;  // clamped at the end: surplus loads are unused
   #pragma unroll
               for (int ni = 0; ni < NI; ++ni) {
                 bqh[j][ni] = wlh[o + ni * 16];
@@ -948,7 +964,7 @@ struct TileCfg { int wm, wn, mi, ni, tw, db; };
 
 constexpr int HDRSKY_EPHASE_FALLBACK = -1000;   // internal: launch_conv declines the phase form of a stride-2 data gradient
 
-template <int WM, int WN, int MI, int NI, int TW, bool NARROW, bool PRECISE, bool DB, bool PH, bool EMIT = false, bool PAIR = false>
+template <int WM, int WN, int MI, int NI, int TW, bool NARROW, bool PRECISE, bool DB, bool PH, bool EMIT = false, bool PAIR = false, bool UP = false>
 int launch_conv(ConvKArgs& a, hipStream_t stream) {
   constexpr int BM = WM * MI * 16, BN = WN * NI * 16, TH = BM / TW;
   a.tiles_x = cdiv(PH ? cdiv(a.Wo, 2) : a.Wo, TW);    // phase mode: tiles of one phase's grid, four phases per sample
@@ -1003,7 +1019,8 @@ int launch_conv(ConvKArgs& a, hipStream_t stream) {
   a.off_out = 0;
   if (DB && roundup(lds, 16) + out_bytes <= hdrsky_hooks().conv_epi_lds * 1024) { a.off_out = roundup(lds, 16); lds = a.off_out + out_bytes; }   // (two workgroups per CU must still fit)
   if (lds > 160 * 1024) return HDRSKY_EUNSUPPORTED;
-  auto kern = conv_igemm_kernel<WM, WN, MI, NI, TW, NARROW, PRECISE, DB, PH, EMIT, PAIR>;
+  if ((a.upsample == 2) != UP) return HDRSKY_EUNSUPPORTED;     // (UP: the instantiations with the resize-fused staging, dispatch_tile_up)
+  auto kern = conv_igemm_kernel<WM, WN, MI, NI, TW, NARROW, PRECISE, DB, PH, EMIT, PAIR, UP>;
   static std::atomic<int> max_lds_set{0};
   if (lds > max_lds_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1045,6 +1062,27 @@ int dispatch_tile(ConvKArgs& a, const TileCfg& t, hipStream_t s) {
 #endif
 #undef HDRSKY_CASE_DB
 #undef HDRSKY_CASE
+  return HDRSKY_EUNSUPPORTED;
+}
+
+// The resize-fused staging's instantiations (hdrsky_conv_desc.upsample == 2: engine.decode's four deconvolutions and the
+// eager / fp32-class steps): the tiles the table gives those layers at 32x128 and 128x512; another tile falls back to the
+// class's round-1 entry.
+template <bool PRECISE>
+int dispatch_tile_up(ConvKArgs& a, TileCfg t, hipStream_t s) {
+  for (int attempt = 0; attempt < 2; ++attempt) {
+#define HDRSKY_UCASE(WM_, WN_, MI_, NI_, TW_, DB_)                                                         \
+    if ((t.db != 0) == DB_ && t.wm == WM_ && t.wn == WN_ && t.mi == MI_ && t.ni == NI_ && t.tw == TW_)    \
+      return launch_conv<WM_, WN_, MI_, NI_, TW_, false, PRECISE, DB_, false, false, false, true>(a, s);
+    HDRSKY_UCASE(2, 4, 4, 1, 32, true) HDRSKY_UCASE(4, 2, 4, 1, 32, true)
+#ifndef HDRSKY_ONE_TILE
+    HDRSKY_UCASE(2, 2, 4, 2, 32, true) HDRSKY_UCASE(2, 4, 4, 2, 32, true)
+    HDRSKY_UCASE(1, 4, 4, 1, 32, true) HDRSKY_UCASE(2, 2, 4, 1, 32, true) HDRSKY_UCASE(1, 8, 4, 1, 32, true) HDRSKY_UCASE(2, 4, 2, 1, 32, true)
+    HDRSKY_UCASE(8, 1, 4, 2, 32, false) HDRSKY_UCASE(2, 2, 2, 2, 32, false) HDRSKY_UCASE(2, 2, 4, 2, 32, false) HDRSKY_UCASE(4, 1, 4, 2, 32, false)
+#endif
+#undef HDRSKY_UCASE
+    t = a.Cout >= 64 ? TileCfg{2, 4, 4, 1, 32, 1} : TileCfg{4, 2, 4, 1, 32, 1};
+  }
   return HDRSKY_EUNSUPPORTED;
 }
 
@@ -1476,7 +1514,7 @@ static int conv2d_fwd_impl(const hdrsky_conv_desc* d, const float* x, const void
     a.in_gamma2 = pair->in_gamma2; a.in_beta2 = pair->in_beta2; a.residual2 = pair->residual2;
     a.gsplit = d->B / 2; a.x_shared = pair->x_shared;
     dt.B = d->B / 2;
-    if (dot1_applies(d, residual) || xb_out || precise || phase_applies(d)) return HDRSKY_EUNSUPPORTED;
+    if (dot1_applies(d, residual) || xb_out || precise || phase_applies(d) || d->upsample == 2) return HDRSKY_EUNSUPPORTED;
     const TileCfg tp = choose_tile(&dt);
     return narrow ? dispatch_tile_pair<true>(a, tp, s) : dispatch_tile_pair<false>(a, tp, s);
   }
@@ -1499,6 +1537,10 @@ static int conv2d_fwd_impl(const hdrsky_conv_desc* d, const float* x, const void
     if (rc != HDRSKY_EPHASE_FALLBACK && rc != HDRSKY_EUNSUPPORTED) return rc;
   }
   const TileCfg t = choose_tile(&dt);
+  if (d->upsample == 2) {
+    if (narrow || a.xb_out != nullptr) return HDRSKY_EUNSUPPORTED;
+    return precise ? dispatch_tile_up<true>(a, t, s) : dispatch_tile_up<false>(a, t, s);
+  }
   if (narrow) return precise ? dispatch_tile<true, true>(a, t, s) : dispatch_tile<true, false>(a, t, s);
   if (a.xb_out != nullptr) return dispatch_tile<false, false, false, true>(a, t, s);      // (hdrsky_conv2d_emit_supported: never narrow / precise)
   return precise ? dispatch_tile<false, true>(a, t, s) : dispatch_tile<false, false>(a, t, s);
