@@ -1121,6 +1121,12 @@ TileCfg choose_tile(const hdrsky_conv_desc* d, bool ph = false) {
   TileCfg t = choose_tile_r4(d);
   if (hk.tile_table == 4 || hk.tile.set || d->compute == HDRSKY_BF16X3) return t;
   const long M = (long)d->B * d->Ho * d->Wo;
+  for (int i = 0; i < hk.ntile_rules; ++i) {       // HDRSKY_TILE_RULES (A/B runs)
+    const HdrskyTileRule& r = hk.tile_rules[i];
+    if (d->Cout >= r.lo[0] && d->Cout <= r.hi[0] && M >= r.lo[1] && M <= r.hi[1] && d->Cin >= r.lo[2] && d->Cin <= r.hi[2] &&
+        (r.kh < 0 || r.kh == d->KH) && (r.ph < 0 || r.ph == (int)ph))
+      return TileCfg{r.v[0], r.v[1], r.v[2], r.v[3], r.v[4], r.v[5]};
+  }
   if (hk.tile_c64.set && d->Cout >= 64 && d->Cout < 128 && d->Cin >= 64 && M >= 65536 && !ph)      // A/B hook: the 64->64 class at full resolution
     return TileCfg{hk.tile_c64.v[0], hk.tile_c64.v[1], hk.tile_c64.v[2], hk.tile_c64.v[3], hk.tile_c64.v[4], hk.tile_c64.v[5]};
   const bool narrow = d->Cin <= 8;

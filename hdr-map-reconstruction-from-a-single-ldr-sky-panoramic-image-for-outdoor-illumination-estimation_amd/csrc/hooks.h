@@ -8,6 +8,9 @@
 #pragma once
 
 struct HdrskyTileHook { int set; int v[6]; };   // "wm,wn,mi,ni,tw[,db]"
+// HDRSKY_TILE_RULES="cout_lo,cout_hi,m_lo,m_hi,cin_lo,cin_hi,kh,ph=wm,wn,mi,ni,tw,db;...": table entries injected for an A/B run
+// (kh / ph: -1 = any).  The first matching rule wins, ahead of the table (single-product mode only).
+struct HdrskyTileRule { long lo[3], hi[3]; int kh, ph; int v[6]; };
 
 struct HdrskyHooks {
   // ---- switches ---------------------------------------------------------------------------------------------------
@@ -24,6 +27,7 @@ struct HdrskyHooks {
   int nab_one;         // HDRSKY_NAB_ONE     0: InstanceNorm backward never on the one-launch register-resident kernel (default 1)
   // ---- tuning hooks (HDRSKY_EXPERIMENTS=1) --------------------------------------------------------------------------
   int experiments;
+  int ntile_rules; HdrskyTileRule tile_rules[16];
   HdrskyTileHook tile, tile_t16, tile_wide, tile_c32, tile_c16, tile_c64;   // HDRSKY_TILE, _T16, _WIDE, _C32, _C16, _C64 (64->64 from 65536 pixels)
   int wgrad2_s2min;    // HDRSKY_WGRAD2_S2MIN   (32)
   int wgrad2_mint;     // HDRSKY_WGRAD2_MINT    (2)

@@ -44,6 +44,22 @@ void read_hooks() {
   h.da_group = -1; h.da_wg_group = -1; h.fc_nsplit = 4; h.fc_update_nb = 0; h.fc_rg = 4; h.nab_target = 512; h.fc_nt = 1; h.fc_w_nt = 1; h.opt_nt = 0; h.wgrad2_nt = 0; h.nab_nt = 0; h.conv_epi_lds = 0;
   if (h.experiments) {
     h.tile = env_tile("HDRSKY_TILE"); h.tile_t16 = env_tile("HDRSKY_TILE_T16"); h.tile_wide = env_tile("HDRSKY_TILE_WIDE");
+    if (const char* tr = getenv("HDRSKY_TILE_RULES")) {
+      const char* p = tr;
+      while (*p && h.ntile_rules < 16) {
+        HdrskyTileRule r{};
+        long q[8]; int v[6];
+        if (sscanf(p, "%ld,%ld,%ld,%ld,%ld,%ld,%ld,%ld=%d,%d,%d,%d,%d,%d", &q[0], &q[1], &q[2], &q[3], &q[4], &q[5], &q[6], &q[7],
+                   &v[0], &v[1], &v[2], &v[3], &v[4], &v[5]) == 14) {
+          for (int i = 0; i < 3; ++i) { r.lo[i] = q[2 * i]; r.hi[i] = q[2 * i + 1]; }
+          r.kh = (int)q[6]; r.ph = (int)q[7];
+          for (int i = 0; i < 6; ++i) r.v[i] = v[i];
+          h.tile_rules[h.ntile_rules++] = r;
+        }
+        while (*p && *p != ';') ++p;
+        if (*p == ';') ++p;
+      }
+    }
     h.tile_c32 = env_tile("HDRSKY_TILE_C32"); h.tile_c16 = env_tile("HDRSKY_TILE_C16"); h.tile_c64 = env_tile("HDRSKY_TILE_C64");
     h.wgrad2_s2min = env_int("HDRSKY_WGRAD2_S2MIN", h.wgrad2_s2min);
     h.wgrad2_mint = env_int("HDRSKY_WGRAD2_MINT", h.wgrad2_mint);
