@@ -25,7 +25,11 @@ def timeit(fn):
     return e0.elapsed_time(e1) * 1e3 / iters
 
 
-for (H, W, C, pooled) in [(32, 128, 32, 0), (16, 64, 64, 0), (8, 32, 128, 0), (32, 128, 32, 1), (16, 64, 64, 1), (8, 32, 128, 1)]:
+SHAPES = [(32, 128, 32, 0), (16, 64, 64, 0), (8, 32, 128, 0), (32, 128, 32, 1), (16, 64, 64, 1), (8, 32, 128, 1)]
+if "--hires" in sys.argv:      # the 128x512 network at batch 8
+    B = 8
+    SHAPES = [(128, 512, 32, 0), (64, 256, 64, 0), (32, 128, 128, 0), (128, 512, 32, 1), (64, 256, 64, 1)]
+for (H, W, C, pooled) in SHAPES:
     x = torch.randn(B, H, W, C, device=dev)
     nparts = 8
     part = torch.rand(B, nparts, 2, C, device=dev) * (H * W / nparts); part[:, :, 1] += H * W / nparts
@@ -41,4 +45,5 @@ for (H, W, C, pooled) in [(32, 128, 32, 0), (16, 64, 64, 0), (8, 32, 128, 0), (3
             us[one] = timeit(lambda: K.norm_act_bwd(x, st, g, bt, 0.1, dyi, bool(pooled), out_bf16=ob))
         os.environ.pop("HDRSKY_NAB_ONE"); HK.reload()
         row.append("%s: one launch %6.2f us | sliced %6.2f us" % ("bf16 dy/dx" if dy16 else "fp32 dy/dx", us["1"], us["0"]))
-    print("[%d,%d,%d,%d] pooled=%d  %s" % (B, H, W, C, pooled, "   ".join(row)), flush=True)
+    mb = B * H * W * C * (4 + 2 + 2 / (4 if pooled else 1)) / 1e6      # x fp32 once + dx bf16 + dy bf16: the one-read floor
+    print("[%d,%d,%d,%d] pooled=%d  %s   (floor %.1f MB = %.1f us at 8 TB/s)" % (B, H, W, C, pooled, "   ".join(row), mb, mb / 8.0), flush=True)
