@@ -1568,7 +1568,11 @@ extern "C" void hdrsky_debug_wgrad2_stamps(void* buf) { g_wg2_stamps = (unsigned
 static int wgrad2_groups(const hdrsky_wgrad_job* jobs, int njobs, bool* done, float* ws, size_t ws_floats, size_t* ws_used,
                          bool plan_only, void* stream, PendingReduce& red) {
   const int wg_hook = hdrsky_hooks().wgrad2_wgs;   // (tuning hook; 0 = by work share)
-  const int wg_total = wg_hook > 0 ? wg_hook : 256;
+  // 192 workgroups of 768 threads, not one per compute unit: inside the three-stream step the quarter of the chip the launch leaves
+  // free is worth more to the other streams than the shorter launch is to this one, and fewer pixel chunks mean smaller partial
+  // slabs for the reduce (round 5: 32x128 step -1.2 ... -1.7 %, 128x512 step -0.4 ... -1.3 % against 256; 128 and 320+ are worse:
+  // profiles/r05_wgrad_wgs_ab*.txt)
+  const int wg_total = wg_hook > 0 ? wg_hook : 192;
   int members[256], nm = 0;
   double work[256];
   for (int k = 0; k < njobs; ++k) {

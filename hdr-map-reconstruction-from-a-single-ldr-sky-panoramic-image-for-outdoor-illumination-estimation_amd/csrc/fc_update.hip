@@ -183,28 +183,29 @@ inline bool shapes_ok(const float* x, int ldx, const float* dy, int ldy, int M, 
 
 inline int mpad(int M) { return roundup(M, MC); }
 
-// blocks per wave: 2 (82 VGPRs, 5 waves per SIMD, half the A-operand loads; measured 2 % faster at M = 32 and 13 % at
-// M = 256 on the 8192x4096 kernel) unless HDRSKY_FC_UPDATE_NB=1 (58 VGPRs, 8 waves)
+// 32x32 MFMA blocks per wave.  Two (82 VGPRs, 5 waves per SIMD, half the A-operand loads) measured 2 % faster at M = 32 and 13 %
+// at M = 256 on the 8192x4096 kernel ALONE and was the default of rounds 3-4.  Inside the three-stream step ONE block per wave (58
+// VGPRs, 8 waves per SIMD, twice the workgroups of half the footprint) is worth 1.1 % of the step (2.426 -> 2.398 ms,
+// profiles/r05_fc_update_nb_ab.txt) and with the non-temporal image stores it is no slower alone either (114 us, 0.73 of the HBM
+// peak): the default since round 5.  HDRSKY_FC_UPDATE_NB=2: tuning hook.
 inline int blocks_per_wave() {
-  return hdrsky_hooks().fc_update_nb == 1 ? 1 : 2;   // (tuning hook HDRSKY_FC_UPDATE_NB)
+  return hdrsky_hooks().fc_update_nb == 2 ? 2 : 1;
 }
 
 template <bool FUSED>
 inline void launch_xtdy(hipStream_t st, const uint4* xT, const uint4* dT, int Mp, int K, int N, float* w, float* ms, float lr,
                         float rho, float eps, float gscale, void* pk, void* nat, int accumulate) {
   const int nt = FUSED ? hdrsky_hooks().fc_nt : 0;
-  if (blocks_per_wave() == 2 && nt != 0) {
-#define HDRSKY_XTDY_NT(NT_)                                                                                                    \
-    case NT_: hipLaunchKernelGGL((fc_xtdy_kernel<FUSED, 2, NT_>), dim3(N / 256, K / WK), dim3(256), 0, st, xT, dT, Mp, K, N, w, ms, lr, \
-                                 rho, eps, gscale, (uint2*)pk, (unsigned*)nat, accumulate); break;
-    switch (nt) { HDRSKY_XTDY_NT(1) HDRSKY_XTDY_NT(2) HDRSKY_XTDY_NT(3) HDRSKY_XTDY_NT(4) HDRSKY_XTDY_NT(5) HDRSKY_XTDY_NT(6) HDRSKY_XTDY_NT(7) default: break; }
+#define HDRSKY_XTDY_NT(NB_, NT_)                                                                                                      \
+    case NT_: hipLaunchKernelGGL((fc_xtdy_kernel<FUSED, NB_, NT_>), dim3(N / (128 * NB_), K / WK), dim3(256), 0, st, xT, dT, Mp, K, N, w, \
+                                 ms, lr, rho, eps, gscale, (uint2*)pk, (unsigned*)nat, accumulate); break;
+  if (blocks_per_wave() == 2) {
+    switch (nt) { HDRSKY_XTDY_NT(2, 1) HDRSKY_XTDY_NT(2, 2) HDRSKY_XTDY_NT(2, 3) HDRSKY_XTDY_NT(2, 4) HDRSKY_XTDY_NT(2, 5) HDRSKY_XTDY_NT(2, 6) HDRSKY_XTDY_NT(2, 7)
+                  default: HDRSKY_XTDY_NT(2, 0) }
+  } else {
+    switch (nt) { HDRSKY_XTDY_NT(1, 1) default: HDRSKY_XTDY_NT(1, 0) }
+  }
 #undef HDRSKY_XTDY_NT
-  } else if (blocks_per_wave() == 2)
-    hipLaunchKernelGGL((fc_xtdy_kernel<FUSED, 2>), dim3(N / 256, K / WK), dim3(256), 0, st, xT, dT, Mp, K, N, w, ms, lr, rho,
-                       eps, gscale, (uint2*)pk, (unsigned*)nat, accumulate);
-  else
-    hipLaunchKernelGGL((fc_xtdy_kernel<FUSED, 1>), dim3(N / 128, K / WK), dim3(256), 0, st, xT, dT, Mp, K, N, w, ms, lr, rho,
-                       eps, gscale, (uint2*)pk, (unsigned*)nat, accumulate);
 }
 
 // launch 1 of both entry points; returns the transposed operand images inside ws

@@ -31,7 +31,7 @@ struct HdrskyHooks {
   HdrskyTileHook tile, tile_t16, tile_wide, tile_c32, tile_c16, tile_c64;   // HDRSKY_TILE, _T16, _WIDE, _C32, _C16, _C64 (64->64 from 65536 pixels)
   int wgrad2_s2min;    // HDRSKY_WGRAD2_S2MIN   (32)
   int wgrad2_mint;     // HDRSKY_WGRAD2_MINT    (2)
-  int wgrad2_wgs;      // HDRSKY_WGRAD2_WGS     (0 = by work share)
+  int wgrad2_wgs;      // HDRSKY_WGRAD2_WGS     (0 = 192 workgroups shared out by work)
   int wgrad3_minpx;    // HDRSKY_WGRAD3_MINPX   (256)
   int wgrad3_wgs;      // HDRSKY_WGRAD3_WGS     (256)
   int wgrad_set, wgrad[3];   // HDRSKY_WGRAD "workgroups,force_small,workgroups_grouped"
