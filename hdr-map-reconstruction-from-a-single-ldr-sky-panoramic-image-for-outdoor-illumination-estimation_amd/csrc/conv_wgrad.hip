@@ -566,7 +566,10 @@ __device__ __forceinline__ void wait_vmcnt(int n) {   // n: wave-uniform; larger
 // issue, then wait, then multiply: per tile 1.4 k cycles of issue + 1.3 k of waiting in front of 3.4 k of MFMA phase
 // (profiles/stamp_wgrad2.py).  Everybody meets at one barrier per tile.
 template <int UPW>
-__global__ void __launch_bounds__(768) conv_wgrad2_kernel(const Multi2Args m) {
+#ifndef HDRSKY_WG2_MINW
+#define HDRSKY_WG2_MINW 3      // waves per SIMD conv_wgrad2_kernel is compiled for (12-wave workgroups: 3 = the whole register file for one workgroup)
+#endif
+__global__ void __launch_bounds__(768, HDRSKY_WG2_MINW) conv_wgrad2_kernel(const Multi2Args m) {
   constexpr int NWC = 8, NWL = 4, NTC = NWC * 64;
   constexpr int OBFM = 4;                               // co fragments the accumulator array holds (obf <= 4)
   constexpr int MAXPX = 16, MAXPY = 6;                  // DMA pieces per loader wave and tile the slot registers hold
