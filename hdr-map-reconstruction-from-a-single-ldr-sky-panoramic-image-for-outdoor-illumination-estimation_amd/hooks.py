@@ -50,6 +50,8 @@ class _Hooks:
         self.wg_enc_split = exp("HDRSKY_WG_ENC_SPLIT", "0") != "0"
         self.apply_fc_stream = int(exp("HDRSKY_APPLY_FC_STREAM", "2"))
         self.apply_after_fc = exp("HDRSKY_APPLY_AFTER_FC", "0") == "1"
+        # HDRSKY_APPLY_FC_CUS="lo,hi[,step]": the Dense update on a fourth stream confined to these compute units (experiment)
+        self.apply_fc_cus = [int(v) for v in exp("HDRSKY_APPLY_FC_CUS", "").split(",") if v]
         self.plan_move = exp("HDRSKY_PLAN_MOVE", "")
         return self
 

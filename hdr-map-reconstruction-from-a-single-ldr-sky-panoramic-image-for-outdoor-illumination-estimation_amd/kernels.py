@@ -64,7 +64,7 @@ def no_gc():
 _HIP = [None]
 
 
-def masked_stream(cu_lo, cu_hi, ncu=256):
+def masked_stream(cu_lo, cu_hi, ncu=256, step=1):
     """A HIP stream whose kernels run on compute units [cu_lo, cu_hi) only (hipExtStreamCreateWithCUMask on the HIP runtime torch
     loaded), wrapped as a torch stream.  Experiments of profiles/cu_mask_*.py: reserving compute units for the dependent chain of
     small launches that the step / the forward pass waits for."""
@@ -80,7 +80,7 @@ def masked_stream(cu_lo, cu_hi, ncu=256):
         _HIP[0] = ctypes.CDLL(path)
     words = (ncu + 31) // 32
     mask = (ctypes.c_uint32 * words)()
-    for cu in range(cu_lo, cu_hi):
+    for cu in range(cu_lo, cu_hi, step):      # (step > 1: every step-th unit of the range - a mask spread over the dies)
         mask[cu // 32] |= 1 << (cu % 32)
     st = ctypes.c_void_p()
     rc = _HIP[0].hipExtStreamCreateWithCUMask(ctypes.byref(st), words, mask)

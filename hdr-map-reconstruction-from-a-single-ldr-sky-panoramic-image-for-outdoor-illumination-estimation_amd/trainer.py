@@ -173,6 +173,9 @@ class Trainer:
         # optimizer | sun-pose backward, weight gradients).  More streams than that end up sharing one of the runtime's
         # four hardware queues with each other or with RCCL's stream (measured: 4.6 instead of 4.1 ms per step).
         self._streams = [torch.cuda.Stream(device=self.device, priority=HOOKS.H.stream_prio[i]) for i in range(3)]
+        if HOOKS.H.apply_fc_cus:      # (experiment: an HBM-bound segment beside the backward pass on a slice of the chip)
+            c = HOOKS.H.apply_fc_cus
+            self._streams.append(torch.cuda.Stream(device=self.device) if c[0] < 0 else K.masked_stream(c[0], c[1], step=c[2] if len(c) > 2 else 1))     # (-1: a plain fourth stream)
         self._graphs, self._gscale = None, 1.0 / world_size
         self._bn_training = True            # False only inside test_step (sun-radiance head BatchNorm in inference mode)
         self.losses = torch.zeros(len(LOSS_SLOTS), dtype=torch.float32, device=self.device)
@@ -1301,7 +1304,7 @@ class Trainer:
         # the END of stream 1, with the conv-side update waiting behind it: now it closes stream 2 - idle from wg_sunrad on -
         # and `apply` no longer waits for it (disjoint parameters): the two updates overlap, step -1 %
         # (profiles/r03_plan_ab2.txt; HDRSKY_APPLY_FC_STREAM / HDRSKY_APPLY_AFTER_FC are the A/B hooks))
-        @seg("apply_fc", HOOKS.H.apply_fc_stream, ["bwd_dense", "wg_dense"])
+        @seg("apply_fc", 3 if HOOKS.H.apply_fc_cus else HOOKS.H.apply_fc_stream, ["bwd_dense", "wg_dense"])
         def _():
             fc0, fc1 = self.fc_grad_range()
             if defer:      # the operands' images + the bias vectors' step; the kernels' update opens the next replay (apply_fc_run)
