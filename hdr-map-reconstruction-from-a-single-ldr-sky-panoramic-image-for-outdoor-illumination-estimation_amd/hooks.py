@@ -53,6 +53,8 @@ class _Hooks:
         # HDRSKY_APPLY_FC_CUS="lo,hi[,step]": the Dense update on a fourth stream confined to these compute units (experiment)
         self.apply_fc_cus = [int(v) for v in exp("HDRSKY_APPLY_FC_CUS", "").split(",") if v]
         self.plan_move = exp("HDRSKY_PLAN_MOVE", "")
+        self.vgg_target_late = exp("HDRSKY_VGG_TARGET_LATE", "1") != "0"      # the target pass of the perceptual term behind fwd_enc (round 5)
+        self.plan_deps = exp("HDRSKY_PLAN_DEPS", "")      # "segment:dependency,...": extra dependencies (scheduling experiments)
         return self
 
 

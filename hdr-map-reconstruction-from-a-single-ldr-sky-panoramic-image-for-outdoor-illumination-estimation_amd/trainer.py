@@ -968,7 +968,12 @@ class Trainer:
             # chain, while stream 0 waits for the sun branch, instead of in front of it (~35 us of the step's critical path)
             seg("zero", 0)(zero_grads)
 
-        @seg("vgg_target", 2)
+        # The perceptual term's target pass has no input from the forward pass and used to open stream 2 beside it ("for free").
+        # It is not free: its seven launches are the LARGEST of the forward phase (batch 32, 64-256 channels) and they take the chip
+        # from the two dependent chains of small launches the step is waiting for (fwd_sun 335 us alone, 585 us beside them).
+        # Behind the encoder-decoder chain - stream 2 idles until the perceptual term anyway - the step is 1.5 % shorter
+        # (2.390 -> 2.355 ms, profiles/r05_plan_deps_ab.txt; behind the sun branch instead: +3 %, the term then waits for it).
+        @seg("vgg_target", 2, ["fwd_enc"] if HOOKS.H.vgg_target_late else [])
         def _():
             T["vgg_tgt"] = self._vgg_target(T["hdr_t"])
 
@@ -1362,6 +1367,14 @@ class Trainer:
             sg = segs.pop(idx[0])
             at = [k for k, q in enumerate(segs) if q[0] == after][0]
             segs.insert(at + 1, (sg[0], int(si), sg[2], sg[3]))
+
+        # HDRSKY_PLAN_DEPS="name:dep,...": scheduling experiments - segment `name` additionally waits for segment `dep`
+        for ent in filter(None, HOOKS.H.plan_deps.split(",")):
+            name, dep = ent.split(":")
+            order = [sg[0] for sg in segs]
+            if name in order and dep in order and order.index(dep) < order.index(name):
+                k = order.index(name)
+                segs[k] = (segs[k][0], segs[k][1], tuple(segs[k][2]) + (dep,), segs[k][3])
 
         if self.ext_sun:          # no sun-pose net: its backward, Dense weight gradients and Dense optimizer segments go
             gone = ("bwd_dense", "bwd_sunpose", "wg_dense", "apply_fc")
