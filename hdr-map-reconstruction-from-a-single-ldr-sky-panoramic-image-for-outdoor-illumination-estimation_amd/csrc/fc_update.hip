@@ -94,8 +94,11 @@ __global__ void __launch_bounds__(256, NB == 1 ? 8 : 5) fc_xtdy_kernel(const uin
   const int r = lane & 31, h = lane >> 5;
   constexpr int AUX_IMG = (NT & 1) ? 2 : 0, AUX_ST = (NT & 2) ? 2 : 0, AUX_LD = (NT & 4) ? 2 : 0;
   constexpr int WN = 32 * NB;
-  const int kb = blockIdx.y * WK, nw = (blockIdx.x * 4 + wave) * WN;
+  const int nw = (blockIdx.x * 4 + wave) * WN;
   const int mq = Mpad >> 3;           // 16-byte groups per operand row
+  // gridDim.y < K / WK: a workgroup walks its k tiles (a launch capped to few workgroups that trickles along beside other
+  // streams' work instead of taking the chip: hdrsky_hooks().fc_update_rows)
+  for (int kb = blockIdx.y * WK; kb < K; kb += gridDim.y * WK) {
 
   f32x16_t acc[NB];
 #pragma unroll
@@ -174,6 +177,7 @@ __global__ void __launch_bounds__(256, NB == 1 ? 8 : 5) fc_xtdy_kernel(const uin
 #undef ROWB
     __builtin_amdgcn_sched_barrier(0);   // one 32x32 block at a time: keeps the loads of the next out of this one's registers
   }
+  }   // k tiles of this workgroup
 }
 
 inline bool shapes_ok(const float* x, int ldx, const float* dy, int ldy, int M, int K, int N) {
@@ -196,8 +200,10 @@ template <bool FUSED>
 inline void launch_xtdy(hipStream_t st, const uint4* xT, const uint4* dT, int Mp, int K, int N, float* w, float* ms, float lr,
                         float rho, float eps, float gscale, void* pk, void* nat, int accumulate) {
   const int nt = FUSED ? hdrsky_hooks().fc_nt : 0;
+  const int cap = FUSED ? hdrsky_hooks().fc_update_rows : 0;      // (tuning hook HDRSKY_FC_UPDATE_ROWS: grid rows of the fused update; 0 = one per k tile)
+  const int rows = (cap > 0 && cap < K / WK) ? cap : K / WK;
 #define HDRSKY_XTDY_NT(NB_, NT_)                                                                                                      \
-    case NT_: hipLaunchKernelGGL((fc_xtdy_kernel<FUSED, NB_, NT_>), dim3(N / (128 * NB_), K / WK), dim3(256), 0, st, xT, dT, Mp, K, N, w, \
+    case NT_: hipLaunchKernelGGL((fc_xtdy_kernel<FUSED, NB_, NT_>), dim3(N / (128 * NB_), rows), dim3(256), 0, st, xT, dT, Mp, K, N, w, \
                                  ms, lr, rho, eps, gscale, (uint2*)pk, (unsigned*)nat, accumulate); break;
   if (blocks_per_wave() == 2) {
     switch (nt) { HDRSKY_XTDY_NT(2, 1) HDRSKY_XTDY_NT(2, 2) HDRSKY_XTDY_NT(2, 3) HDRSKY_XTDY_NT(2, 4) HDRSKY_XTDY_NT(2, 5) HDRSKY_XTDY_NT(2, 6) HDRSKY_XTDY_NT(2, 7)

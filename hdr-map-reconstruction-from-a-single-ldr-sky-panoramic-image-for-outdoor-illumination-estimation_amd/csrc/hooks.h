@@ -39,6 +39,7 @@ struct HdrskyHooks {
   int da_wg_group;     // HDRSKY_DA_WG_GROUP    (-1)
   int fc_nsplit;       // HDRSKY_FC_NSPLIT      (4)
   int fc_update_nb;    // HDRSKY_FC_UPDATE_NB   (0: one 32x32 MFMA block per wave of the fused Dense update; 2: two, the default of rounds 3-4)
+  int fc_update_rows;  // HDRSKY_FC_UPDATE_ROWS (0) grid rows of the fused Dense update (0 = one workgroup row per 32-k tile; fewer: the workgroups walk their tiles)
   int fc_rg;           // HDRSKY_FC_RG          (reduction groups per workgroup of fc_mfma_kernel: 1, 2 or 4)
   int nab_target;      // HDRSKY_NAB_TARGET     (512)
   int wgrad2_nt;       // HDRSKY_WGRAD2_NT      (0) non-temporal operand copies of conv_wgrad2_kernel: 1 x, 2 dy

@@ -71,6 +71,7 @@ void read_hooks() {
     h.da_wg_group = env_int("HDRSKY_DA_WG_GROUP", h.da_wg_group);
     h.fc_nsplit = env_int("HDRSKY_FC_NSPLIT", h.fc_nsplit);
     h.fc_update_nb = env_int("HDRSKY_FC_UPDATE_NB", h.fc_update_nb);
+    h.fc_update_rows = env_int("HDRSKY_FC_UPDATE_ROWS", 0);
     h.fc_rg = env_int("HDRSKY_FC_RG", h.fc_rg);
     h.nab_target = env_int("HDRSKY_NAB_TARGET", h.nab_target);
     h.fc_nt = env_int("HDRSKY_FC_NT", h.fc_nt) & 7;
