@@ -1372,9 +1372,11 @@ class Trainer:
         for ent in filter(None, HOOKS.H.plan_deps.split(",")):
             name, dep = ent.split(":")
             order = [sg[0] for sg in segs]
-            if name in order and dep in order and order.index(dep) < order.index(name):
-                k = order.index(name)
-                segs[k] = (segs[k][0], segs[k][1], tuple(segs[k][2]) + (dep,), segs[k][3])
+            if name not in order or dep not in order or order.index(dep) >= order.index(name):
+                # (a dependency must be ENQUEUED before its waiter: the wait is on an event the earlier segment records)
+                raise ValueError("HDRSKY_PLAN_DEPS: %r is not a segment pair in enqueue order (%s)" % (ent, ", ".join(order)))
+            k = order.index(name)
+            segs[k] = (segs[k][0], segs[k][1], tuple(segs[k][2]) + (dep,), segs[k][3])
 
         if self.ext_sun:          # no sun-pose net: its backward, Dense weight gradients and Dense optimizer segments go
             gone = ("bwd_dense", "bwd_sunpose", "wg_dense", "apply_fc")
