@@ -853,7 +853,8 @@ class Trainer:
         # ------------------------------------------------------------------ forward (train.py:239-299)
         # (the longest independent chain is enqueued first; segment order = host launch order)
         defer = self._defer
-        sun_done = "fwd_sun_fc" if defer else "fwd_sun"      # the segment that completes the sun branch
+        sun_split = HOOKS.H.fwd_sun_split and not defer and not self.ext_sun      # (experiment: the sun branch as two segments)
+        sun_done = "fwd_sun_fc" if (defer or sun_split) else "fwd_sun"      # the segment that completes the sun branch
         if defer:
             # the PREVIOUS step's Dense update (see __init__: defer_dense), in the window stream 2 idles in beside the forward pass
             M = (self.dense_operands[0] if self.dense_operands else T["ldr"]).shape[0]
@@ -874,6 +875,16 @@ class Trainer:
 
             @seg("fwd_sun_fc", 1, ["apply_fc_run"])
             def _():       # Dense layers + soft-max head on the updated kernels, Grad-CAM, sun radiance head
+                t = self._sunpose_dense(T["t"], T["gt"])
+                T["cams"] = self._gradcam(t, T["gt"])
+                T["rad"] = self._sunrad_forward(T["ldr"], T["cams"], t, T)
+        elif sun_split:
+            @seg("fwd_sun", 1)
+            def _():
+                T["t"] = self._sunpose_forward(T["ldr"], pick=T["gt"], convs_only=True)
+
+            @seg("fwd_sun_fc", 1)
+            def _():
                 t = self._sunpose_dense(T["t"], T["gt"])
                 T["cams"] = self._gradcam(t, T["gt"])
                 T["rad"] = self._sunrad_forward(T["ldr"], T["cams"], t, T)
