@@ -36,7 +36,7 @@ void read_hooks() {
   h.no_dot1 = getenv("HDRSKY_NO_DOT1") != nullptr;
   h.wgrad2 = env_int("HDRSKY_WGRAD2", 1) != 0;
   h.wgrad3 = env_int("HDRSKY_WGRAD3", 1) != 0;
-  h.nab_one = env_int("HDRSKY_NAB_ONE", 1) != 0;
+  h.nab_one = env_int("HDRSKY_NAB_ONE", 1);
   h.tile_table = env_int("HDRSKY_TILE_TABLE", 5);
   h.experiments = env_int("HDRSKY_EXPERIMENTS", 0) == 1;
   // tuning hooks: their defaults unless the gate is open

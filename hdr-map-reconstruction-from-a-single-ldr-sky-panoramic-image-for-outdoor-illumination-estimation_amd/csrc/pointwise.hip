@@ -1119,7 +1119,8 @@ int hdrsky_norm_act_bwd_nslices(int B, int H, int W, int C, int pooled) {
 // and the 32x128 map of the 128x512 one).  HDRSKY_NAB_ONE=0: the sliced form (switch).
 int hdrsky_norm_act_bwd_one_launch(int H, int W, int pooled, int dy_bf16) {
   (void)dy_bf16;
-  if (!hdrsky_hooks().nab_one) return 0;
+  const int mode = hdrsky_hooks().nab_one;       // 1: every supported shape; 2 / 3 (A/B): the non-pooled / the pooled forms only
+  if (!mode || (mode == 2 && pooled) || (mode == 3 && !pooled)) return 0;
   const int units = pooled ? (H / 2) * (W / 2) : H * W;
   if (pooled) return units == 1024 || units == 256;
   // (the 4096-pixel maps keep the sliced pair: their slab needs 8-channel groups to fit the registers, i.e. 32 B of every 128-B line
