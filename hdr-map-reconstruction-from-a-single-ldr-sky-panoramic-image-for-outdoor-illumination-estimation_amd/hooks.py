@@ -55,6 +55,7 @@ class _Hooks:
         self.plan_move = exp("HDRSKY_PLAN_MOVE", "")
         self.vgg_target_late = exp("HDRSKY_VGG_TARGET_LATE", "1") != "0"      # the target pass of the perceptual term behind fwd_enc (round 5)
         self.fwd_sun_split = exp("HDRSKY_FWD_SUN_SPLIT", "0") == "1"      # the sun branch as conv + rest segments (scheduling experiments)
+        self.plan_merge = exp("HDRSKY_PLAN_MERGE", "auto")  # "a+b+c,d+e": consecutive segments of one stream as ONE segment (one hipGraph); "auto": the trainer's defaults; "": none
         self.plan_deps = exp("HDRSKY_PLAN_DEPS", "")      # "segment:dependency,...": extra dependencies (scheduling experiments)
         return self
 

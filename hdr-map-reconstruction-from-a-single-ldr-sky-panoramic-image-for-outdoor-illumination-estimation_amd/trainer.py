@@ -1392,7 +1392,48 @@ class Trainer:
         if self.ext_sun:          # no sun-pose net: its backward, Dense weight gradients and Dense optimizer segments go
             gone = ("bwd_dense", "bwd_sunpose", "wg_dense", "apply_fc")
             segs[:] = [(n, si, tuple(d for d in deps if d not in gone), fn) for n, si, deps, fn in segs if n not in gone]
+
+        # Default merges (round 5): the sun-side backward chain of stream 2 (the step's critical chain) as ONE graph - single GPU only:
+        # a data-parallel exchange starts the Dense slice's collective behind bwd_dense - and three pairs whose outside waiters are
+        # not due before the pair has finished anyway.  Step -1.0 ... -1.3 % (profiles/r05_plan_merge_ab.txt).
+        if HOOKS.H.plan_merge == "auto":
+            auto = (["bwd_dense+bwd_sunpose+bwd_sunrad+wg_sunrad"] if self.world == 1 else []) + \
+                   ["bwd_sunrad+wg_sunrad", "wg_dec+wg_res", "bwd_dec+bwd_res", "bwd_enc+bwd_enc2"]
+            self._merge_plan(segs, ",".join(auto), strict=False)
+        else:
+            self._merge_plan(segs, HOOKS.H.plan_merge)
         return segs
+
+    @staticmethod
+    def _merge_plan(segs, spec, strict=True):
+        """HDRSKY_PLAN_MERGE / the default merges: the segments a+b+c of ONE stream become one segment - one hipGraph replay instead
+        of three (a graph launch costs the stream ~13-19 us of idle time: profiles/r05_segment_timeline.txt).  The merged segment
+        keeps the first name, waits for every member's outside dependencies and sits where the LAST member sat in the enqueue
+        order (all those dependencies are enqueued by then); segments that waited for a member wait for the merged one.  Refused:
+        members on different streams, another segment of that stream between them, a segment between them that waits for one."""
+        for grp in filter(None, spec.split(",")):
+            names = grp.split("+")
+            order = [sg[0] for sg in segs]
+            if any(n not in order for n in names):
+                continue                          # (a plan without these segments: the sun-pose trainer, the external sun-pose net)
+            idx = [order.index(n) for n in names]
+            si = segs[idx[0]][1]
+            between = [sg for k, sg in enumerate(segs) if idx[0] < k < idx[-1] and k not in idx]
+            if idx != sorted(idx) or any(segs[k][1] != si for k in idx) or any(sg[1] == si for sg in between) or \
+               any(set(sg[2]) & set(names) for sg in between):
+                if not strict:
+                    continue                      # (a default merge that another hook's plan does not allow)
+                raise ValueError("HDRSKY_PLAN_MERGE: %r cannot be merged in this plan" % grp)
+            fns = [segs[k][3] for k in idx]
+            deps = tuple(d for k in idx for d in segs[k][2] if d not in names)
+            merged = (names[0], si, tuple(dict.fromkeys(deps)), (lambda fns=fns: [f() for f in fns if f is not None] and None))
+            last = idx[-1]
+            segs[last] = merged
+            for k in reversed(idx[:-1]):
+                del segs[k]
+            for k, sg in enumerate(segs):         # waiters of a member wait for the merged segment
+                if set(sg[2]) & set(names[1:]):
+                    segs[k] = (sg[0], sg[1], tuple(dict.fromkeys(names[0] if d in names[1:] else d for d in sg[2])), sg[3])
 
     GRADS_READY = "grads_ready"                                  # hook point of a data-parallel driver
     DISC_GRADS_READY = "disc_step"                               # the discriminator's gradients are complete behind it

@@ -1,5 +1,6 @@
 """Round 5, late additions - claims under test:
-(1) the plan variants only move WHEN a segment runs: the step with the perceptual term's target pass behind fwd_enc (default) equals
+(1) the plan variants only move WHEN a segment runs: the default step (target pass behind fwd_enc, the default segment merges) equals the
+    unmerged plan (HDRSKY_PLAN_MERGE=), other merges,
     the round-4 plan (HDRSKY_VGG_TARGET_LATE=0) and a plan with extra dependencies (HDRSKY_PLAN_DEPS) bit for bit - gradients and
     updated weights; the loss values, sums by fp32 atomics, to rounding - over captured replays;
 (2) the fused Dense update on a capped grid whose workgroups walk their k tiles (HDRSKY_FC_UPDATE_ROWS) writes the same w / ms / bf16
@@ -29,7 +30,7 @@ def _reload():
 def _run_plan(dev, monkeypatch, env):
     synth, trainer, K = pkg("synth"), pkg("trainer"), pkg("kernels")
     monkeypatch.setenv("HDRSKY_EXPERIMENTS", "1")
-    for k in ("HDRSKY_VGG_TARGET_LATE", "HDRSKY_PLAN_DEPS"):
+    for k in ("HDRSKY_VGG_TARGET_LATE", "HDRSKY_PLAN_DEPS", "HDRSKY_PLAN_MERGE"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -52,23 +53,32 @@ def _run_plan(dev, monkeypatch, env):
 
 def test_plan_variants_are_bit_identical(dev, monkeypatch):
     base_order, base = _run_plan(dev, monkeypatch, {})
+    names = [n for n, _ in base_order]
     assert "fwd_enc" in dict(base_order)["vgg_target"], "default plan: the target pass waits for fwd_enc"
-    for env in ({"HDRSKY_VGG_TARGET_LATE": "0"}, {"HDRSKY_PLAN_DEPS": "bwd_sunrad:disc_step,loss_vgg_b:loss_vgg"}):
+    # default merges: the sun-side backward chain, the decoder / res-block pairs and the encoder pair are one segment each
+    assert "bwd_sunpose" not in names and "wg_sunrad" not in names and "bwd_res" not in names and "wg_res" not in names and "bwd_enc2" not in names
+    assert set(dict(base_order)["wg_dec"]) >= {"bwd_dec"} and "bwd_res" not in dict(base_order)["wg_dec"]      # (waits for the merged pair)
+    variants = (({"HDRSKY_VGG_TARGET_LATE": "0"}, lambda o: "fwd_enc" not in dict(o)["vgg_target"]),
+                ({"HDRSKY_PLAN_MERGE": ""}, lambda o: {"bwd_sunpose", "wg_sunrad", "bwd_res", "wg_res", "bwd_enc2"} <= {n for n, _ in o}),
+                ({"HDRSKY_PLAN_MERGE": "", "HDRSKY_PLAN_DEPS": "bwd_sunrad:disc_step,loss_vgg_b:loss_vgg"},
+                 lambda o: "disc_step" in dict(o)["bwd_sunrad"] and "loss_vgg" in dict(o)["loss_vgg_b"]),
+                ({"HDRSKY_PLAN_DEPS": "bwd_sunrad:disc_step"}, lambda o: "disc_step" in dict(o)["bwd_dense"]),     # (the merged chain inherits it)
+                ({"HDRSKY_PLAN_MERGE": "grads_ready+apply,fwd_enc+zero"}, lambda o: "apply" not in {n for n, _ in o} and "bwd_sunpose" in {n for n, _ in o}))
+    for env, check in variants:
         order, got = _run_plan(dev, monkeypatch, env)
-        if "HDRSKY_VGG_TARGET_LATE" in env:
-            assert "fwd_enc" not in dict(order)["vgg_target"]
-        else:
-            assert "disc_step" in dict(order)["bwd_sunrad"] and "loss_vgg" in dict(order)["loss_vgg_b"]
+        assert check(order), (env, order)
         for it, (a, b) in enumerate(zip(base, got)):
             for name in a[0]:      # (the loss VALUES are sums by fp32 atomics: equal to rounding, in any plan; the gradients are bit-reproducible)
                 assert abs(a[0][name] - b[0][name]) <= 2e-6 * abs(a[0][name]) + 1e-9, (env, it, name, a[0][name], b[0][name])
             for k in range(1, 5):
                 assert torch.equal(a[k], b[k]), (env, it, k)
-    monkeypatch.delenv("HDRSKY_VGG_TARGET_LATE", raising=False)
-    monkeypatch.setenv("HDRSKY_PLAN_DEPS", "disc_step:apply"); _reload()      # a dependency on a LATER segment: refused, not ignored
-    with pytest.raises(ValueError):
-        _run_plan(dev, monkeypatch, {"HDRSKY_PLAN_DEPS": "disc_step:apply"})
-    monkeypatch.delenv("HDRSKY_PLAN_DEPS", raising=False)
+    for k in ("HDRSKY_VGG_TARGET_LATE", "HDRSKY_PLAN_MERGE"):
+        monkeypatch.delenv(k, raising=False)
+    for bad in ({"HDRSKY_PLAN_DEPS": "disc_step:apply"}, {"HDRSKY_PLAN_MERGE": "bwd_dec+wg_dec"}, {"HDRSKY_PLAN_MERGE": "loss_adv+bwd_dec"}):
+        with pytest.raises(ValueError):      # a dependency on a LATER segment / members on two streams / a segment of the stream in between
+            _run_plan(dev, monkeypatch, bad)
+    for k in ("HDRSKY_PLAN_DEPS", "HDRSKY_PLAN_MERGE"):
+        monkeypatch.delenv(k, raising=False)
     _reload()
 
 
