@@ -1394,11 +1394,14 @@ class Trainer:
             segs[:] = [(n, si, tuple(d for d in deps if d not in gone), fn) for n, si, deps, fn in segs if n not in gone]
 
         # Default merges (round 5): the sun-side backward chain of stream 2 (the step's critical chain) as ONE graph - single GPU only:
-        # a data-parallel exchange starts the Dense slice's collective behind bwd_dense - and three pairs whose outside waiters are
-        # not due before the pair has finished anyway.  Step -1.0 ... -1.3 % (profiles/r05_plan_merge_ab.txt).
+        # a data-parallel exchange starts the Dense slice's collective behind bwd_dense - and the two encoder segments that close
+        # the main chain; nothing outside waits for a member of either before its last one.  Step -1.0 % (profiles/
+        # r05_plan_merge_ab.txt).  NOT merged: bwd_dec + bwd_res and wg_dec + wg_res - another -0.3 % on the plain 32x128 plan,
+        # where the decoders' weight gradients wait for the discriminator step anyway, but +2.5 ... +4.5 % with distortion-aware
+        # layers, whose weight gradients are due as soon as bwd_dec is done (profiles/r05_plan_merge_da_ab.txt).
         if HOOKS.H.plan_merge == "auto":
             auto = (["bwd_dense+bwd_sunpose+bwd_sunrad+wg_sunrad"] if self.world == 1 else []) + \
-                   ["bwd_sunrad+wg_sunrad", "wg_dec+wg_res", "bwd_dec+bwd_res", "bwd_enc+bwd_enc2"]
+                   ["bwd_sunrad+wg_sunrad", "bwd_enc+bwd_enc2"]
             self._merge_plan(segs, ",".join(auto), strict=False)
         else:
             self._merge_plan(segs, HOOKS.H.plan_merge)

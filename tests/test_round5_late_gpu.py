@@ -56,10 +56,11 @@ def test_plan_variants_are_bit_identical(dev, monkeypatch):
     names = [n for n, _ in base_order]
     assert "fwd_enc" in dict(base_order)["vgg_target"], "default plan: the target pass waits for fwd_enc"
     # default merges: the sun-side backward chain, the decoder / res-block pairs and the encoder pair are one segment each
-    assert "bwd_sunpose" not in names and "wg_sunrad" not in names and "bwd_res" not in names and "wg_res" not in names and "bwd_enc2" not in names
-    assert set(dict(base_order)["wg_dec"]) >= {"bwd_dec"} and "bwd_res" not in dict(base_order)["wg_dec"]      # (waits for the merged pair)
+    assert "bwd_sunpose" not in names and "wg_sunrad" not in names and "bwd_enc2" not in names and "bwd_res" in names and "wg_res" in names
     variants = (({"HDRSKY_VGG_TARGET_LATE": "0"}, lambda o: "fwd_enc" not in dict(o)["vgg_target"]),
-                ({"HDRSKY_PLAN_MERGE": ""}, lambda o: {"bwd_sunpose", "wg_sunrad", "bwd_res", "wg_res", "bwd_enc2"} <= {n for n, _ in o}),
+                ({"HDRSKY_PLAN_MERGE": ""}, lambda o: {"bwd_sunpose", "wg_sunrad", "bwd_enc2"} <= {n for n, _ in o}),
+                ({"HDRSKY_PLAN_MERGE": "bwd_dense+bwd_sunpose+bwd_sunrad+wg_sunrad,wg_dec+wg_res,bwd_dec+bwd_res"},
+                 lambda o: "bwd_res" not in {n for n, _ in o} and "bwd_res" not in dict(o)["wg_dec"] and "bwd_dec" in dict(o)["wg_dec"]),
                 ({"HDRSKY_PLAN_MERGE": "", "HDRSKY_PLAN_DEPS": "bwd_sunrad:disc_step,loss_vgg_b:loss_vgg"},
                  lambda o: "disc_step" in dict(o)["bwd_sunrad"] and "loss_vgg" in dict(o)["loss_vgg_b"]),
                 ({"HDRSKY_PLAN_DEPS": "bwd_sunrad:disc_step"}, lambda o: "disc_step" in dict(o)["bwd_dense"]),     # (the merged chain inherits it)
