@@ -89,6 +89,8 @@ SIGNATURES = {
     "hdrsky_fc_nsplit": (c_int, [c_int]),
     "hdrsky_fc_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
     "hdrsky_fc_dgrad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "hdrsky_fc_fwd_fin": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P, P, P, P]),
+    "hdrsky_fc_dgrad_fin": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P, P, P, P]),
     "hdrsky_fc_finalize": (c_int, [P, c_int, c_int, c_int, P, c_int, P, P, P, P]),
     "hdrsky_global_max": (c_int, [P, c_size_t, P, P]),
     "hdrsky_softmax_head": (c_int, [P, c_int, c_int, c_int, P, P, P, P, P]),

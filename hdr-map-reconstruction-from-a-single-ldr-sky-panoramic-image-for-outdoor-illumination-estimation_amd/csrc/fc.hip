@@ -18,6 +18,21 @@ namespace {
 
 constexpr int RCH = 256;  // reduction elements per chunk (8 k-steps of 32)
 
+// Finalisation inside the launch (hdrsky_fc_fwd_fin / hdrsky_fc_dgrad_fin): y[m][o] = act(bias[o] + sum_s part[s][m][o]), optional
+// mask - what hdrsky_fc_finalize computes from the partial sums with a launch of its own (three of them sit on the dependent
+// chain of the sun branch).  The workgroup that finishes LAST among the nsplit slices of a column block (a ticket per block)
+// adds the slices in slice order - the same sum in the same order, whichever workgroup that is.  Visibility between workgroups
+// on different dies (MI355X_MICROARCH.md, valid forms): the slices are stored write-through (`sc1`), drained (vmcnt(0)) ahead of
+// the workgroup barrier and the ticket atomic; the last workgroup reads them with `sc1` loads - no fence, no L2 write-back.  The ticket resets itself for the next launch.
+struct FcFin {
+  float* y;                 // nullptr: partial sums only
+  const float* bias;
+  const float* mask_src;
+  unsigned* tickets;        // [column blocks], zero before the first launch
+  unsigned* zero_word;      // cleared by the launch (softmax_head's max accumulator further down the chain), or nullptr
+  int relu;
+};
+
 // RG: reduction groups per workgroup.  A workgroup is RG x 4 waves: wave (rg, cw) owns 16 of the 64 output columns and the
 // chunks ch = rg, rg + RG, ... of the workgroup's reduction slice; at the end the groups' accumulators are added through
 // LDS in group order (fixed: bit-reproducible).  What bounds the kernel is the weight bytes in flight per CU (each wave
@@ -27,7 +42,7 @@ constexpr int RCH = 256;  // reduction elements per chunk (8 k-steps of 32)
 template <int MF, bool PRECISE, int RG>
 __global__ void __launch_bounds__(256 * RG) fc_mfma_kernel(const float* __restrict__ x, const uint4* __restrict__ whi,
                                                            const uint4* __restrict__ wlo, float* __restrict__ out, int M,
-                                                           int R, int O, int nsplit, long stride_col, long stride_kg, int nt) {
+                                                           int R, int O, int nsplit, long stride_col, long stride_kg, int nt, FcFin fin) {
   constexpr int MP = MF * 16, PL = PRECISE ? 2 : 1;
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
   // nt: the weight stream - every byte read once per launch by one workgroup - with the non-temporal policy: 100 MB per forward
@@ -138,25 +153,57 @@ __global__ void __launch_bounds__(256 * RG) fc_mfma_kernel(const float* __restri
       for (int mf = 0; mf < MF; ++mf) sAcc[((rg - 1) * MF + mf) * 256 + gtid] = acc[mf];
     }
     __syncthreads();
-    if (rg > 0) return;
+    if (rg > 0 && fin.y == nullptr) return;
+    if (rg == 0) {
 #pragma unroll
-    for (int g = 1; g < RG; ++g)
+      for (int g = 1; g < RG; ++g)
 #pragma unroll
-      for (int mf = 0; mf < MF; ++mf) {
-        const f32x4_t t = sAcc[((g - 1) * MF + mf) * 256 + gtid];
+        for (int mf = 0; mf < MF; ++mf) {
+          const f32x4_t t = sAcc[((g - 1) * MF + mf) * 256 + gtid];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[mf][j] += t[j];
-      }
+          for (int j = 0; j < 4; ++j) acc[mf][j] += t[j];
+        }
+    }
   }
-  if (col_ok) {
+  if (col_ok && rg == 0) {
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int m = mf * 16 + kq * 4 + j;
-        if (m < M) out[((size_t)sp * M + m) * O + col] = acc[mf][j];
+        if (m < M) {
+          float* dst = out + ((size_t)sp * M + m) * O + col;
+          // (finalising launch: a write-through store - agent-scope relaxed atomic, `sc1` - so that the last workgroup's `sc1` loads
+          // find the slice without an L2 write-back / invalidate: an agent-scope FENCE here flushes the whole L2 of the die and
+          // cost the step 38 %, profiles/r05_fc_fin_ab.txt)
+          if (fin.y != nullptr) __hip_atomic_store(dst, acc[mf][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else *dst = acc[mf][j];
+        }
       }
   }
+  if (fin.y == nullptr) return;            // (kernel argument: uniform)
+  // ---- finalisation by the last workgroup of this column block ---------------------------------------------------------
+  __shared__ unsigned s_last;
+  if (blockIdx.x == 0 && tid == 0 && fin.zero_word) *fin.zero_word = 0u;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's write-through stores have landed ...
+  __syncthreads();                                      // ... and every wave's of the workgroup, before its ticket
+  if (tid == 0) {
+    const unsigned t = __hip_atomic_fetch_add(fin.tickets + ob, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (t == (unsigned)(nsplit - 1)) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  for (int i = tid; i < M * 64; i += 256 * RG) {
+    const int m = i >> 6, c = ob * 64 + (i & 63);
+    if (c >= O) continue;
+    float v = fin.bias ? fin.bias[c] : 0.f;
+    for (int s2 = 0; s2 < nsplit; ++s2)
+      v += __hip_atomic_load(out + ((size_t)s2 * M + m) * O + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (fin.relu) v = fmaxf(v, 0.f);
+    if (fin.mask_src) v = fin.mask_src[(size_t)m * O + c] > 0.f ? v : 0.f;
+    fin.y[(size_t)m * O + c] = v;
+  }
+  if (tid == 0) __hip_atomic_store(fin.tickets + ob, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // fp32 [K][N] -> packed [K/8][N][8] bf16 (hi/lo) and natural [K][N] bf16 (hi/lo)
@@ -180,7 +227,7 @@ __global__ void fc_pack_kernel(const float* __restrict__ w, int K, int N, unsign
 
 template <int MF, bool PRECISE, int RG>
 int launch_fc_v(const float* x, const void* whi, const void* wlo, float* out, int M, int R, int O, int nsplit,
-                long stride_col, long stride_kg, hipStream_t s) {
+                long stride_col, long stride_kg, hipStream_t s, const FcFin& fin) {
   const int grid = cdiv(O, 64) * nsplit;
   constexpr int lds = RG * 2 * (PRECISE ? 2 : 1) * 32 * (MF * 16) * 16;
   auto kern = fc_mfma_kernel<MF, PRECISE, RG>;
@@ -193,14 +240,14 @@ int launch_fc_v(const float* x, const void* whi, const void* wlo, float* out, in
     }
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * RG), lds, s, x, (const uint4*)whi, (const uint4*)wlo, out, M, R, O, nsplit,
-                     stride_col, stride_kg, hdrsky_hooks().fc_w_nt);
+                     stride_col, stride_kg, hdrsky_hooks().fc_w_nt, fin);
   HDRSKY_CHECK_LAUNCH();
   return HDRSKY_OK;
 }
 
 template <bool PRECISE>
 int launch_fc(const float* x, const void* whi, const void* wlo, float* out, int M, int R, int O, int nsplit,
-              long stride_col, long stride_kg, hipStream_t s) {
+              long stride_col, long stride_kg, hipStream_t s, const FcFin& fin = FcFin{}) {
   // reduction groups per workgroup (tuning hook HDRSKY_FC_RG; the split-product mode holds twice the registers and LDS: 1)
   // Measured (profiles/r04_fc_rg_ab.txt, fc1 8192 -> 4096, 32 rows): forward 24.3 -> 16.7 us at 4 groups (2.8 -> 4.0 TB/s of
   // weight stream); the data gradient (natural image: 16-byte pieces of 4096 different rows per load) gains little beyond 2
@@ -209,13 +256,13 @@ int launch_fc(const float* x, const void* whi, const void* wlo, float* out, int 
   const int rg = PRECISE ? 1 : (stride_col == 1 ? hook : (hook < 2 ? hook : 2));
   const int chunks = (R / nsplit + RCH - 1) / RCH;
   if (M <= 16) {
-    if (rg >= 4 && chunks >= 4) return launch_fc_v<1, PRECISE, PRECISE ? 1 : 4>(x, whi, wlo, out, M, R, O, nsplit, stride_col, stride_kg, s);
-    if (rg >= 2 && chunks >= 2) return launch_fc_v<1, PRECISE, PRECISE ? 1 : 2>(x, whi, wlo, out, M, R, O, nsplit, stride_col, stride_kg, s);
-    return launch_fc_v<1, PRECISE, 1>(x, whi, wlo, out, M, R, O, nsplit, stride_col, stride_kg, s);
+    if (rg >= 4 && chunks >= 4) return launch_fc_v<1, PRECISE, PRECISE ? 1 : 4>(x, whi, wlo, out, M, R, O, nsplit, stride_col, stride_kg, s, fin);
+    if (rg >= 2 && chunks >= 2) return launch_fc_v<1, PRECISE, PRECISE ? 1 : 2>(x, whi, wlo, out, M, R, O, nsplit, stride_col, stride_kg, s, fin);
+    return launch_fc_v<1, PRECISE, 1>(x, whi, wlo, out, M, R, O, nsplit, stride_col, stride_kg, s, fin);
   }
-  if (rg >= 4 && chunks >= 4) return launch_fc_v<2, PRECISE, PRECISE ? 1 : 4>(x, whi, wlo, out, M, R, O, nsplit, stride_col, stride_kg, s);
-  if (rg >= 2 && chunks >= 2) return launch_fc_v<2, PRECISE, PRECISE ? 1 : 2>(x, whi, wlo, out, M, R, O, nsplit, stride_col, stride_kg, s);
-  return launch_fc_v<2, PRECISE, 1>(x, whi, wlo, out, M, R, O, nsplit, stride_col, stride_kg, s);
+  if (rg >= 4 && chunks >= 4) return launch_fc_v<2, PRECISE, PRECISE ? 1 : 4>(x, whi, wlo, out, M, R, O, nsplit, stride_col, stride_kg, s, fin);
+  if (rg >= 2 && chunks >= 2) return launch_fc_v<2, PRECISE, PRECISE ? 1 : 2>(x, whi, wlo, out, M, R, O, nsplit, stride_col, stride_kg, s, fin);
+  return launch_fc_v<2, PRECISE, 1>(x, whi, wlo, out, M, R, O, nsplit, stride_col, stride_kg, s, fin);
 }
 
 }  // namespace
@@ -265,6 +312,36 @@ int hdrsky_fc_dgrad(const float* dy, const void* natural_hi, const void* natural
     return launch_fc<true>(dy, natural_hi, natural_lo, dx_part, M, N, K, nsplit, N / 8, 1, (hipStream_t)stream);
   }
   return launch_fc<false>(dy, natural_hi, nullptr, dx_part, M, N, K, nsplit, N / 8, 1, (hipStream_t)stream);
+}
+
+// hdrsky_fc_fwd + hdrsky_fc_finalize in ONE launch: y[M][N] = act(bias + x @ W) (optional mask; zero_word cleared).  part_ws: the
+// [nsplit][M][N] partial sums (workspace, also valid afterwards); tickets: cdiv(N, 64) zero-initialised words owned by this
+// call site (they reset themselves; two launches that share them must not overlap).  Results bit-identical to the two launches.
+int hdrsky_fc_fwd_fin(const float* x, const void* packed_hi, const void* packed_lo, int M, int K, int N, int nsplit, int compute,
+                      float* part_ws, void* tickets, const float* bias, int relu, const float* mask_src, float* y, void* zero_word,
+                      void* stream) {
+  if (!x || !packed_hi || !part_ws || !tickets || !y || M <= 0 || M > 32 || nsplit <= 0 || (K % (nsplit * 8)) != 0 || (N & 7))
+    return HDRSKY_EINVAL;
+  const FcFin fin{y, bias, mask_src, (unsigned*)tickets, (unsigned*)zero_word, relu};
+  if (compute == HDRSKY_BF16X3) {
+    if (!packed_lo) return HDRSKY_EINVAL;
+    return launch_fc<true>(x, packed_hi, packed_lo, part_ws, M, K, N, nsplit, 1, N, (hipStream_t)stream, fin);
+  }
+  return launch_fc<false>(x, packed_hi, nullptr, part_ws, M, K, N, nsplit, 1, N, (hipStream_t)stream, fin);
+}
+
+// the same for the data gradient: dx[M][K] = mask(dy @ W^T) (tickets: cdiv(K, 64) words)
+int hdrsky_fc_dgrad_fin(const float* dy, const void* natural_hi, const void* natural_lo, int M, int K, int N, int nsplit, int compute,
+                        float* part_ws, void* tickets, const float* bias, int relu, const float* mask_src, float* dx, void* zero_word,
+                        void* stream) {
+  if (!dy || !natural_hi || !part_ws || !tickets || !dx || M <= 0 || M > 32 || nsplit <= 0 || (N % (nsplit * 8)) != 0 || (K & 7))
+    return HDRSKY_EINVAL;
+  const FcFin fin{dx, bias, mask_src, (unsigned*)tickets, (unsigned*)zero_word, relu};
+  if (compute == HDRSKY_BF16X3) {
+    if (!natural_lo) return HDRSKY_EINVAL;
+    return launch_fc<true>(dy, natural_hi, natural_lo, part_ws, M, N, K, nsplit, N / 8, 1, (hipStream_t)stream, fin);
+  }
+  return launch_fc<false>(dy, natural_hi, nullptr, part_ws, M, N, K, nsplit, N / 8, 1, (hipStream_t)stream, fin);
 }
 
 }  // extern "C"

@@ -212,7 +212,7 @@ def _sunpose_dense(nets, t, compute, pick):
     s, pk = nets.sun, nets.pk
     flat = t["flat"]
     t["gmax"] = torch.empty(1, dtype=torch.int32, device=flat.device)      # cleared by the finalize launch below
-    t["f1"] = K.fc_finalize(K.fc_fwd(flat, pk["sun.fc1"], compute), s["fc1.bias"], relu=True, zero_word=t["gmax"])
+    t["f1"] = K.fc_fwd_fin(flat, pk["sun.fc1"], compute, s["fc1.bias"], relu=True, zero_word=t["gmax"])
     part2 = K.fc_fwd(t["f1"], pk["sun.fc2"], compute)
     if pick is None:
         t["z"], t["cmf"] = K.softmax_head(part2, s["fc2.bias"], t["gmax"])
@@ -229,8 +229,8 @@ def gradcam_sweep(nets, t, pick_src, compute):
     B = t["cmf"].shape[0]
     h, w = nets.h, nets.w
     dz = t["dz_pick"] if "dz_pick" in t else K.softmax_pick_bwd(t["cmf"], t["z"], pick_src)[0]
-    df1 = K.fc_finalize(K.fc_dgrad(dz, pk["sun.fc2"], compute), None, relu=False, mask_src=t["f1"])
-    dflat = K.fc_finalize(K.fc_dgrad(df1, pk["sun.fc1"], compute))
+    df1 = K.fc_dgrad_fin(dz, pk["sun.fc2"], compute, mask_src=t["f1"])
+    dflat = K.fc_dgrad_fin(df1, pk["sun.fc1"], compute)
     dP3 = dflat.reshape(B, h // 8, w // 8, 128)
     small = (h // 8) * (w // 8) <= 256        # cam3's GAP weights: summed inside its own launch when the map is small
     w3 = dP3 if small else K.spatial_sum(dP3, 1.0 / ((h // 4) * (w // 4)))

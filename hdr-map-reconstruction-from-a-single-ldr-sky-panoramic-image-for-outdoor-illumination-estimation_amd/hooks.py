@@ -56,6 +56,10 @@ class _Hooks:
         self.vgg_target_late = exp("HDRSKY_VGG_TARGET_LATE", "1") != "0"      # the target pass of the perceptual term behind fwd_enc (round 5)
         self.fwd_sun_split = exp("HDRSKY_FWD_SUN_SPLIT", "0") == "1"      # the sun branch as conv + rest segments (scheduling experiments)
         self.plan_merge = exp("HDRSKY_PLAN_MERGE", "auto")  # "a+b+c,d+e": consecutive segments of one stream as ONE segment (one hipGraph); "auto": the trainer's defaults; "": none
+        # HDRSKY_FC_FIN=1: Dense layers' bias / activation / mask inside the product's launch (hdrsky_fc_fwd_fin / _dgrad_fin, last-workgroup
+        # ticket).  Off: bit-identical but no faster than the hdrsky_fc_finalize launch it saves (step level, forward pass +2 %: the slices
+        # must be stored write-through; with agent-scope fences instead, which flush the die's L2, the step was 38 % slower)
+        self.fc_fin = exp("HDRSKY_FC_FIN", "0") == "1"
         self.plan_deps = exp("HDRSKY_PLAN_DEPS", "")      # "segment:dependency,...": extra dependencies (scheduling experiments)
         return self
 

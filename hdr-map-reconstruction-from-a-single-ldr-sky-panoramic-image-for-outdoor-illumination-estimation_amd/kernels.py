@@ -753,6 +753,47 @@ def fc_dgrad(dy, pf: PackedFC, compute=BF16):
     return out
 
 
+def _fc_fin(x, pf, compute, dgrad, bias, relu, mask_src, zero_word):
+    """fc_fwd / fc_dgrad + fc_finalize: ONE launch (hdrsky_fc_fwd_fin / hdrsky_fc_dgrad_fin - the last workgroup of a column block
+    adds the reduction slices in slice order: bit-identical) where the rows fit a launch and HDRSKY_FC_FIN is not 0, else the two."""
+    M = x.shape[0]
+    if M > FC_MAX_ROWS or not HOOKS.H.fc_fin:
+        return fc_finalize((fc_dgrad if dgrad else fc_fwd)(x, pf, compute), bias, relu, mask_src, zero_word)
+    R, O = (pf.N, pf.K) if dgrad else (pf.K, pf.N)
+    _f32(x, M, R)
+    lib = L.load()
+    ns = lib.hdrsky_fc_nsplit(R)
+    part = torch.empty((ns, M, O), dtype=torch.float32, device=x.device)
+    y = torch.empty((M, O), dtype=torch.float32, device=x.device)
+    if bias is not None:
+        _f32(bias, O)
+    if mask_src is not None:
+        _f32(mask_src, M, O)
+    # the tickets of this call site: one set per (layer, direction, stream) - launches on one stream are ordered, and a captured
+    # graph replays the launch with the same words
+    cnt = pf.__dict__.setdefault("_tickets", {})
+    key = (bool(dgrad), torch.cuda.current_stream().cuda_stream)
+    if key not in cnt:
+        cnt[key] = torch.zeros(((O + 63) // 64,), dtype=torch.int32, device=x.device)
+    if dgrad:
+        L.check(lib.hdrsky_fc_dgrad_fin(_p(x), _p(pf.nat_hi), _p(pf.nat_lo), M, pf.K, pf.N, ns, compute, _p(part), _p(cnt[key]), _p(bias),
+                                        int(relu), _p(mask_src), _p(y), _p(zero_word), _stream()), "fc_dgrad_fin")
+    else:
+        L.check(lib.hdrsky_fc_fwd_fin(_p(x), _p(pf.pk_hi), _p(pf.pk_lo), M, pf.K, pf.N, ns, compute, _p(part), _p(cnt[key]), _p(bias),
+                                      int(relu), _p(mask_src), _p(y), _p(zero_word), _stream()), "fc_fwd_fin")
+    return y
+
+
+def fc_fwd_fin(x, pf: PackedFC, compute=BF16, bias=None, relu=False, mask_src=None, zero_word=None):
+    """act(bias + x @ W) [M, N] (Keras Dense, sunpose_net.py:48-51): fc_finalize(fc_fwd(...)) in one launch."""
+    return _fc_fin(x, pf, compute, False, bias, relu, mask_src, zero_word)
+
+
+def fc_dgrad_fin(dy, pf: PackedFC, compute=BF16, mask_src=None):
+    """mask(dy @ W^T) [M, K] (tf.gradients through Dense, grad_cam.py:31): fc_finalize(fc_dgrad(...)) in one launch."""
+    return _fc_fin(dy, pf, compute, True, None, False, mask_src, None)
+
+
 def fc_finalize(part, bias=None, relu=False, mask_src=None, zero_word=None):
     """zero_word: an int32[1] tensor this launch clears (softmax_head's max accumulator further down the chain)."""
     ns, M, N = part.shape

@@ -435,7 +435,7 @@ class Trainer:
         """The Dense layers + soft-max head of sunposeEstimation (sunpose_net.py:64-72) on the record of the conv layers."""
         w, cp = self.gs.w, self.compute
         t["gmax"] = torch.empty(1, dtype=torch.int32, device=t["flat"].device)      # cleared by the finalize launch below
-        t["f1"] = K.fc_finalize(K.fc_fwd(t["flat"], self.fc1, cp), w["sun.fc1.bias"], relu=True, zero_word=t["gmax"])
+        t["f1"] = K.fc_fwd_fin(t["flat"], self.fc1, cp, w["sun.fc1.bias"], relu=True, zero_word=t["gmax"])
         if pick is None:
             t["z"], t["cmf"] = K.softmax_head(K.fc_fwd(t["f1"], self.fc2, cp), w["sun.fc2.bias"], t["gmax"])
         else:     # Grad-CAM seed of the class pick[m].argmax() from the same launch (train.py:265-267)
@@ -482,8 +482,8 @@ class Trainer:
         w, c, cp = self.gs.w, self.conv, self.compute
         B, h, wd = t["cmf"].shape[0], self.h, self.w
         dz = t["dz_pick"] if "dz_pick" in t else K.softmax_pick_bwd(t["cmf"], t["z"], pick_src)[0]
-        df1 = K.fc_finalize(K.fc_dgrad(dz, self.fc2, cp), None, relu=False, mask_src=t["f1"])
-        dP3 = K.fc_finalize(K.fc_dgrad(df1, self.fc1, cp)).reshape(B, h // 8, wd // 8, 128)
+        df1 = K.fc_dgrad_fin(dz, self.fc2, cp, mask_src=t["f1"])
+        dP3 = K.fc_dgrad_fin(df1, self.fc1, cp).reshape(B, h // 8, wd // 8, 128)
         small = (h // 8) * (wd // 8) <= 256       # cam3's GAP weights: summed inside its own launch when the map is small
         w3 = dP3 if small else K.spatial_sum(dP3, 1.0 / ((h // 4) * (wd // 4)))
         s3 = 1.0 / ((h // 4) * (wd // 4)) if small else 1.0
@@ -1073,8 +1073,8 @@ class Trainer:
         def _():
             t = T["t"]
             dz = T["dz"] = K.softmax_bwd(t["cmf"], T["dcmf"], t["z"])       # KL + the sun-radiance path meet in dcmf
-            df1 = T["df1"] = K.fc_finalize(K.fc_dgrad(dz, self.fc2, cp), None, relu=False, mask_src=t["f1"])
-            T["dP3"] = K.fc_finalize(K.fc_dgrad(df1, self.fc1, cp)).reshape(B, h // 8, wd // 8, 128)
+            df1 = T["df1"] = K.fc_dgrad_fin(dz, self.fc2, cp, mask_src=t["f1"])
+            T["dP3"] = K.fc_dgrad_fin(df1, self.fc1, cp).reshape(B, h // 8, wd // 8, 128)
 
         # ------------------------------------------------------------------ discriminator step (train.py:351-380)
         @seg("disc_step", 1, ["loss_adv", "disc_real"] if split_disc else ["loss_adv"])
@@ -1710,9 +1710,9 @@ class SunPoseTrainer(Trainer):
         dz = K.softmax_bwd(t["cmf"], dcmf, t["z"])
         fc_wgrad = K.fc_wgrad_bf16 if self.dense_mfma else K.fc_wgrad
         fc_wgrad(t["f1"], dz, g["sun.fc2.kernel"], g["sun.fc2.bias"])
-        df1 = K.fc_finalize(K.fc_dgrad(dz, self.fc2, cp), None, relu=False, mask_src=t["f1"])
+        df1 = K.fc_dgrad_fin(dz, self.fc2, cp, mask_src=t["f1"])
         fc_wgrad(t["flat"], df1, g["sun.fc1.kernel"], g["sun.fc1.bias"])
-        dP = K.fc_finalize(K.fc_dgrad(df1, self.fc1, cp)).reshape(B, self.h // 8, self.w // 8, 128)
+        dP = K.fc_dgrad_fin(df1, self.fc1, cp).reshape(B, self.h // 8, self.w // 8, 128)
         for l in (3, 2, 1) if not self.da_sun else ():
             n = "sun.sunlayer%d" % l
             if l == 3 and "s3" in t:

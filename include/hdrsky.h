@@ -237,6 +237,12 @@ int hdrsky_fc_fwd(const float* x, const void* packed_hi, const void* packed_lo, 
                   int compute, float* out_part, void* stream);
 int hdrsky_fc_dgrad(const float* dy, const void* natural_hi, const void* natural_lo, int M, int K, int N, int nsplit,
                     int compute, float* dx_part, void* stream);
+/* hdrsky_fc_fwd / hdrsky_fc_dgrad + hdrsky_fc_finalize in ONE launch (round 5): the workgroup that finishes last among the nsplit
+ * reduction slices of a 64-column block adds the slices in slice order - bit-identical to the two launches.  part_ws [nsplit][M][N or K]:
+ * the partial sums (workspace); tickets: ceil(columns / 64) zero-initialised 32-bit words owned by the call site (self-resetting;
+ * launches that share them must not overlap); bias / mask_src / zero_word as hdrsky_fc_finalize (sunpose_net.py:48-51, grad_cam.py:31). */
+int hdrsky_fc_fwd_fin(const float* x, const void* packed_hi, const void* packed_lo, int M, int K, int N, int nsplit, int compute, float* part_ws, void* tickets, const float* bias, int relu, const float* mask_src, float* y, void* zero_word, void* stream);
+int hdrsky_fc_dgrad_fin(const float* dy, const void* natural_hi, const void* natural_lo, int M, int K, int N, int nsplit, int compute, float* part_ws, void* tickets, const float* bias, int relu, const float* mask_src, float* dx, void* zero_word, void* stream);
 /* y = [relu](sum_s part[s] + bias) [* (mask_src > 0)]; zero_word (nullable): a 4-byte word this launch clears - the max
  * accumulator of a hdrsky_softmax_head later on the same stream, saving a memset launch in the chain. */
 int hdrsky_fc_finalize(const float* part, int nsplit, int M, int N, const float* bias, int relu, const float* mask_src,

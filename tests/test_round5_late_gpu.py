@@ -166,3 +166,51 @@ def test_tile_rules_select_by_layer_and_do_not_change_y(dev, monkeypatch):
         name1 = K.conv_kernel_name(d)
         assert (name1 != name0) == hit and (("<2, 4, 2, 1, 32" in name1) == hit), (rule, name0, name1)
     monkeypatch.delenv("HDRSKY_TILE_RULES", raising=False); _reload()
+
+
+def test_dense_finalisation_inside_the_launch_is_bit_identical(dev, monkeypatch):
+    monkeypatch.setenv("HDRSKY_EXPERIMENTS", "1"); monkeypatch.setenv("HDRSKY_FC_FIN", "1"); _reload()      # (off by default: not faster)
+    """hdrsky_fc_fwd_fin / hdrsky_fc_dgrad_fin (the last workgroup of a column block adds the reduction slices) against
+    hdrsky_fc_fwd / _dgrad + hdrsky_fc_finalize: bit for bit, over many back-to-back launches on changing inputs (a stale read of
+    another workgroup's slice would show as a mismatch), eager and from a replayed graph, both compute modes, ragged row counts."""
+    K = pkg("kernels")
+    g = torch.Generator(device=dev); g.manual_seed(21)
+    Kd, N = 2048, 1024
+    w = torch.randn(Kd, N, device=dev, generator=g) * 0.03
+    bias = torch.randn(N, device=dev, generator=g)
+    for precise, compute in ((False, K.BF16), (True, K.BF16X3)):
+        pf = K.PackedFC(w, precise=precise)
+        for M in (1, 7, 32):
+            for it in range(40):
+                x = torch.randn(M, Kd, device=dev, generator=g)
+                dy = torch.randn(M, N, device=dev, generator=g)
+                mask = torch.randn(M, Kd, device=dev, generator=g)
+                zw = torch.ones(1, dtype=torch.int32, device=dev)
+                a = K.fc_fwd_fin(x, pf, compute, bias, relu=True, zero_word=zw)
+                b = K.fc_finalize(K.fc_fwd(x, pf, compute), bias, relu=True)
+                assert torch.equal(a, b) and int(zw.item()) == 0, (precise, M, it)
+                a = K.fc_dgrad_fin(dy, pf, compute, mask_src=mask)
+                b = K.fc_finalize(K.fc_dgrad(dy, pf, compute), None, relu=False, mask_src=mask)
+                assert torch.equal(a, b), (precise, M, it, "dgrad")
+    # replayed graph: the tickets reset themselves
+    pf = K.PackedFC(w, precise=False)
+    x = torch.randn(32, Kd, device=dev, generator=g)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        y0 = K.fc_fwd_fin(x, pf, K.BF16, bias, relu=True)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=s):
+            y = K.fc_fwd_fin(x, pf, K.BF16, bias, relu=True)
+            d = K.fc_dgrad_fin(y, pf, K.BF16)
+        for it in range(30):
+            x.copy_(torch.randn(32, Kd, device=dev, generator=g))
+            gr.replay()
+            s.synchronize()
+            ref = K.fc_finalize(K.fc_fwd(x, pf, K.BF16), bias, relu=True)
+            assert torch.equal(y, ref), it
+            assert torch.equal(d, K.fc_finalize(K.fc_dgrad(ref, pf, K.BF16))), it
+    # HDRSKY_FC_FIN=0: the two launches
+    monkeypatch.setenv("HDRSKY_FC_FIN", "0"); _reload()
+    assert not pkg("hooks").H.fc_fin
+    assert torch.equal(K.fc_fwd_fin(x, pf, K.BF16, bias, relu=True), K.fc_finalize(K.fc_fwd(x, pf, K.BF16), bias, relu=True))
+    monkeypatch.delenv("HDRSKY_FC_FIN", raising=False); _reload()
